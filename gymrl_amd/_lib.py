@@ -1,0 +1,70 @@
+"""Loader for libgymrl_hip.so (the C-ABI of include/gymrl.h).
+
+The library is built in-tree by gymrl_amd/csrc/Makefile (hipcc --offload-arch=gfx950)
+and lives next to this file so that it travels with the repo snapshot.  Loading
+never silently degrades: a missing library raises at first use.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgymrl_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_lib = None
+
+# every symbol include/gymrl.h declares (tests/test_abi.py checks the export table)
+SYMBOLS = [
+    "gymrl_abi_version", "gymrl_device_ok",
+    "gymrl_env_obs_dim", "gymrl_env_act_dim", "gymrl_env_is_discrete", "gymrl_env_max_steps",
+    "gymrl_env_state_bytes", "gymrl_env_reset", "gymrl_env_step",
+    "gymrl_categorical_sample",
+    "gymrl_gae_workspace_bytes", "gymrl_gae", "gymrl_gae_dw", "gymrl_gae_decoupled",
+    "gymrl_reduce_workspace_bytes", "gymrl_moments", "gymrl_normalize",
+    "gymrl_ppo_loss_fwd_bwd", "gymrl_ppo_full_loss_fwd_bwd",
+    "gymrl_sqnorm", "gymrl_adam_step", "gymrl_soft_update",
+]
+
+
+def build(force=False):
+    """Compile the HIP library in-tree (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "clean"])
+    subprocess.check_call(["make", "-C", CSRC, "-s", "-j8"])
+    return LIB_PATH
+
+
+class PPOCfg(C.Structure):
+    _fields_ = [("clip_eps", C.c_float), ("dual_clip", C.c_float), ("value_coef", C.c_float),
+                ("entropy_coef", C.c_float)]
+
+
+class PPOFullCfg(C.Structure):
+    _fields_ = [("clip_eps_min", C.c_float), ("clip_eps_max", C.c_float), ("dual_clip", C.c_float),
+                ("erc_beta_low", C.c_float), ("erc_beta_high", C.c_float), ("entropy_coef", C.c_float)]
+
+
+def lib():
+    """The loaded C-ABI library.  Raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (or __graft_entry__.build()). "
+                "gymrl_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.gymrl_env_state_bytes.restype = C.c_size_t
+        L.gymrl_gae_workspace_bytes.restype = C.c_size_t
+        L.gymrl_reduce_workspace_bytes.restype = C.c_size_t
+        for name in SYMBOLS:
+            if name.endswith("_bytes"):
+                continue
+            getattr(L, name).restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc}" + (" (EINVAL)" if rc == -22 else ""))

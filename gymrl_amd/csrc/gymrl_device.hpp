@@ -1,0 +1,179 @@
+// gymrl_device.hpp — device-side helpers shared by the gfx950 kernels.
+//
+//  * bit-reproducible f32 exp/log/sincos/tanh built only from IEEE +,*,fma,
+//    rint, frexp, ldexp (no ocml transcendentals), so a kernel result can be
+//    bit-compared with the CPU oracle's independent restatement;
+//  * Philox4x32-10 counter-based RNG (integer only => exact on every machine);
+//  * wave64 / workgroup reductions.
+//
+// All translation units are compiled with -ffp-contract=off: every fused
+// multiply-add in this tree is an explicit fmaf()/fma().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GYMRL_WAVE 64
+
+#define GYMRL_CHECK_LAUNCH()                                   \
+  do {                                                         \
+    hipError_t e__ = hipGetLastError();                        \
+    if (e__ != hipSuccess) return -1000 - (int)e__;            \
+  } while (0)
+
+namespace gymrl {
+
+// ---------------------------------------------------------------- Philox ---
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32(uint64_t key, uint32_t c0, uint32_t c1,
+                                            uint32_t c2, uint32_t c3) {
+  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return u32x4{c0, c1, c2, c3};
+}
+
+// [0,1) with 24 random bits
+__device__ __forceinline__ float u01f(uint32_t x) { return (float)(x >> 8) * 0x1p-24f; }
+// (0,1] with 24 random bits (safe for log)
+__device__ __forceinline__ float u01f_open0(uint32_t x) { return (float)((x >> 8) + 1u) * 0x1p-24f; }
+// [0,1) with 53 random bits
+__device__ __forceinline__ double u01d(uint32_t a, uint32_t b) {
+  return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * 0x1p-53;
+}
+
+// RNG domain tags (c3 of the counter)
+enum : uint32_t {
+  RNG_ENV_RESET = 0x10000000u,
+  RNG_ENV_STEP  = 0x20000000u,
+  RNG_POLICY    = 0x30000000u,
+  RNG_REPLAY    = 0x40000000u,
+  RNG_NOISE     = 0x50000000u,
+};
+
+// ------------------------------------------------- reproducible f32 math ---
+// exp: Cody-Waite reduction by ln2 (hi/lo), degree-6 polynomial (Cephes expf
+// coefficients), result flushed to 0 below -87.33 and to +inf above 88.72.
+__device__ __forceinline__ float det_expf(float x) {
+  if (!(x > -87.33654f)) return (x != x) ? x : 0.0f;
+  if (x > 88.72283f) return __builtin_inff();
+  float n = __builtin_rintf(x * 1.44269504088896341f);
+  float r = fmaf(n, -0.693359375f, x);
+  r = fmaf(n, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = fmaf(p, r, 1.3981999507e-3f);
+  p = fmaf(p, r, 8.3334519073e-3f);
+  p = fmaf(p, r, 4.1665795894e-2f);
+  p = fmaf(p, r, 1.6666665459e-1f);
+  p = fmaf(p, r, 5.0000001201e-1f);
+  float y = fmaf(p, r * r, r) + 1.0f;
+  return __builtin_ldexpf(y, (int)n);
+}
+
+// log for finite x > 0 (normal or denormal); Cephes logf polynomial.
+__device__ __forceinline__ float det_logf(float x) {
+  int e;
+  float m = __builtin_frexpf(x, &e);
+  if (m < 0.707106781186547524f) { e -= 1; m = m + m - 1.0f; } else { m = m - 1.0f; }
+  float z = m * m;
+  float p = 7.0376836292e-2f;
+  p = fmaf(p, m, -1.1514610310e-1f);
+  p = fmaf(p, m, 1.1676998740e-1f);
+  p = fmaf(p, m, -1.2420140846e-1f);
+  p = fmaf(p, m, 1.4249322787e-1f);
+  p = fmaf(p, m, -1.6668057665e-1f);
+  p = fmaf(p, m, 2.0000714765e-1f);
+  p = fmaf(p, m, -2.4999993993e-1f);
+  p = fmaf(p, m, 3.3333331174e-1f);
+  float y = p * m * z;
+  float fe = (float)e;
+  y = fmaf(fe, -2.12194440e-4f, y);
+  y = fmaf(-0.5f, z, y);
+  float r = m + y;
+  return fmaf(fe, 0.693359375f, r);
+}
+
+// sin & cos for |x| < ~8000: quadrant reduction with a 3-term Cody-Waite pi/2,
+// Cephes sinf/cosf minimax polynomials on [-pi/4, pi/4].
+__device__ __forceinline__ void det_sincosf(float x, float* s, float* c) {
+  float q = __builtin_rintf(x * 0.636619772367581343f);  // 2/pi
+  int qi = (int)q;
+  float r = fmaf(q, -1.5703125f, x);
+  r = fmaf(q, -4.837512969970703125e-4f, r);
+  r = fmaf(q, -7.54978995489188e-8f, r);
+  float z = r * r;
+  float ps = -1.9515295891e-4f;
+  ps = fmaf(ps, z, 8.3321608736e-3f);
+  ps = fmaf(ps, z, -1.6666654611e-1f);
+  float sn = fmaf(ps * z, r, r);
+  float pc = 2.443315711809948e-5f;
+  pc = fmaf(pc, z, -1.388731625493765e-3f);
+  pc = fmaf(pc, z, 4.166664568298827e-2f);
+  float cs = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+  float ss = (qi & 1) ? cs : sn;
+  float cc = (qi & 1) ? sn : cs;
+  if (qi & 2) ss = -ss;
+  if ((qi + 1) & 2) cc = -cc;
+  *s = ss; *c = cc;
+}
+
+// tanh via det_expf; odd polynomial below 0.625 (Cephes tanhf).
+__device__ __forceinline__ float det_tanhf(float x) {
+  float a = __builtin_fabsf(x);
+  if (a >= 0.625f) {
+    float r;
+    if (a > 9.0f) r = 1.0f;
+    else { float e = det_expf(a + a); r = 1.0f - 2.0f / (e + 1.0f); }
+    return x < 0.0f ? -r : r;
+  }
+  float z = x * x;
+  float p = -5.70498872745e-3f;
+  p = fmaf(p, z, 2.06390887954e-2f);
+  p = fmaf(p, z, -5.37397155531e-2f);
+  p = fmaf(p, z, 1.33314422036e-1f);
+  p = fmaf(p, z, -3.33332819422e-1f);
+  return fmaf(p * z, x, x);
+}
+
+// ------------------------------------------------------------ reductions ---
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sumf(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Block-wide sum of K doubles per thread -> K atomics per block (lane 0 of
+// wave 0).  BLOCK is the workgroup size (multiple of 64, <= 1024).
+template <int K, int BLOCK>
+__device__ __forceinline__ void block_atomic_add(double (&v)[K], double* out) {
+  __shared__ double sm[K][BLOCK / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double s = wave_sum(v[k]);
+    if (lane == 0) sm[k][wid] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) s += sm[threadIdx.x][w];
+    atomicAdd(out + threadIdx.x, s);
+  }
+}
+
+}  // namespace gymrl

@@ -1,0 +1,325 @@
+// ppo.hip — categorical policy head + fused PPO loss forward/backward (gfx950).
+//
+//   P2  gymrl_categorical_sample       ppo_lunarlander.py:92-104
+//   L1  gymrl_ppo_loss_fwd_bwd         ppo_lunarlander.py:110-117, 278-300, 309-322
+//   L3  gymrl_ppo_full_loss_fwd_bwd    ppo_full_lunarlander.py:575-652
+//
+// One lane = one sample; the A (<= 8) logits of a sample live in registers, the
+// row is fetched as one 16-B load when A == 4 (1 KiB per wave-instruction).
+// Everything here is HBM-bound: 56 algorithmic bytes per sample for L1
+// (logits 16 + v 4 + act 4 + logp_old 4 + adv 4 + ret 4 read, dlogits 16 + dv 4
+// written); metrics go wave-shuffle -> LDS -> one f64 atomic per block and term.
+// exp/log are the bit-reproducible det_* forms so that the CPU oracle can
+// reproduce integer action draws exactly.
+#include "gymrl_device.hpp"
+#include "../../include/gymrl.h"
+
+using namespace gymrl;
+
+namespace {
+
+constexpr int kBlock = 256;
+
+template <int A>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, size_t row, float (&z)[A]) {
+  if constexpr (A == 4) {
+    const float4 v = reinterpret_cast<const float4*>(p)[row];
+    z[0] = v.x; z[1] = v.y; z[2] = v.z; z[3] = v.w;
+  } else if constexpr (A == 2) {
+    const float2 v = reinterpret_cast<const float2*>(p)[row];
+    z[0] = v.x; z[1] = v.y;
+  } else {
+#pragma unroll
+    for (int k = 0; k < A; ++k) z[k] = p[row * A + k];
+  }
+}
+template <int A>
+__device__ __forceinline__ void store_row(float* __restrict__ p, size_t row, const float (&z)[A]) {
+  if constexpr (A == 4) {
+    reinterpret_cast<float4*>(p)[row] = make_float4(z[0], z[1], z[2], z[3]);
+  } else if constexpr (A == 2) {
+    reinterpret_cast<float2*>(p)[row] = make_float2(z[0], z[1]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < A; ++k) p[row * A + k] = z[k];
+  }
+}
+
+// log-softmax pieces shared by all kernels: ln_k = z_k - lse, p_k = e_k / s.
+template <int A>
+__device__ __forceinline__ void log_softmax(const float (&z)[A], float (&ln)[A], float (&p)[A],
+                                            float& H) {
+  float m = z[0];
+#pragma unroll
+  for (int k = 1; k < A; ++k) m = fmaxf(m, z[k]);
+  float e[A];
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < A; ++k) { e[k] = det_expf(z[k] - m); s += e[k]; }
+  const float lse = m + det_logf(s);
+  H = 0.0f;
+#pragma unroll
+  for (int k = 0; k < A; ++k) {
+    ln[k] = z[k] - lse;
+    p[k] = e[k] / s;
+    H -= p[k] * ln[k];
+  }
+}
+
+// ------------------------------------------------------------- P2 sample ----
+template <int A>
+__global__ __launch_bounds__(kBlock) void categorical_sample_kernel(
+    const float* __restrict__ logits, const float* __restrict__ value_in,
+    const float* __restrict__ noise_exp, uint64_t seed, uint64_t counter, int64_t env_id0, int n,
+    int deterministic, int32_t* __restrict__ act_out, float* __restrict__ logp_out,
+    float* __restrict__ ent_out, float* __restrict__ value_out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  float z[A], ln[A], p[A], H;
+  load_row<A>(logits, i, z);
+  log_softmax<A>(z, ln, p, H);
+  int a = 0;
+  if (deterministic) {
+    float best = z[0];
+#pragma unroll
+    for (int k = 1; k < A; ++k) if (z[k] > best) { best = z[k]; a = k; }
+  } else {
+    float q[A];
+    if (noise_exp) {
+      load_row<A>(noise_exp, i, q);
+    } else {
+      const uint64_t env = (uint64_t)(env_id0 + i);
+#pragma unroll
+      for (int blk = 0; blk < (A + 3) / 4; ++blk) {
+        const u32x4 r = philox4x32(seed, (uint32_t)env, (uint32_t)(env >> 32), (uint32_t)counter,
+                                   RNG_POLICY | ((uint32_t)((counter >> 32) & 0x3FFFFFu) << 2) | (uint32_t)blk);
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (blk * 4 + k < A) q[blk * 4 + k] = -det_logf(u01f_open0(w[k]));
+      }
+    }
+    float best = p[0] / q[0];
+#pragma unroll
+    for (int k = 1; k < A; ++k) {
+      const float c = p[k] / q[k];
+      if (c > best) { best = c; a = k; }
+    }
+  }
+  float lp = ln[0];
+#pragma unroll
+  for (int k = 1; k < A; ++k) if (a == k) lp = ln[k];
+  act_out[i] = a;
+  logp_out[i] = lp;
+  if (ent_out) ent_out[i] = H;
+  if (value_out && value_in) value_out[i] = value_in[i];
+}
+
+// ---------------------------------------------------------------- L1 loss ---
+template <int A>
+__global__ __launch_bounds__(kBlock) void ppo_loss_kernel(
+    const float* __restrict__ logits, const float* __restrict__ value,
+    const int32_t* __restrict__ idx, const int32_t* __restrict__ act,
+    const float* __restrict__ logp_old, const float* __restrict__ adv,
+    const float* __restrict__ ret, const double* __restrict__ adv_moments, int B,
+    gymrl_ppo_cfg cfg, float* __restrict__ dlogits_out, float* __restrict__ dvalue_out,
+    double* __restrict__ metrics_sum) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  double met[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  if (b < B) {
+    float z[A], ln[A], p[A], H;
+    load_row<A>(logits, b, z);
+    const float v = value[b];
+    const int i = idx ? idx[b] : b;
+    const int a = act[i];
+    const float lpo = logp_old[i];
+    float ad = adv[i];
+    const float rt = ret[i];
+    if (adv_moments) {
+      const double cnt = adv_moments[0];
+      const double mean = adv_moments[1] / cnt;
+      double var = adv_moments[2] / cnt - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      ad = (float)(((double)ad - mean) / (sqrt(var) + 1e-8));
+    }
+    log_softmax<A>(z, ln, p, H);
+    float lp = ln[0];
+#pragma unroll
+    for (int k = 1; k < A; ++k) if (a == k) lp = ln[k];
+
+    const float invB = 1.0f / (float)B;
+    const float lo = 1.0f - cfg.clip_eps, hi = 1.0f + cfg.clip_eps;
+    const float ratio = det_expf(lp - lpo);
+    const float s1 = ratio * ad;
+    const float rc = fminf(fmaxf(ratio, lo), hi);
+    const float s2 = rc * ad;
+    const float inr = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;   // clamp passes grad on [lo, hi]
+    const float w1 = s1 < s2 ? 1.0f : (s1 == s2 ? 0.5f : 0.0f);     // torch.min tie: 1/2, 1/2
+    const float ms = fminf(s1, s2);
+    float dms_dr = w1 * ad + (1.0f - w1) * ad * inr;
+    float obj = ms;
+    if (ad < 0.0f) {
+      const float dc = cfg.dual_clip * ad;
+      obj = fmaxf(ms, dc);
+      const float wm = ms > dc ? 1.0f : (ms == dc ? 0.5f : 0.0f);   // torch.max tie
+      dms_dr *= wm;
+    }
+    // dL/dlp = -(1/B) * dobj/dr * r
+    const float g_lp = -invB * dms_dr * ratio;
+    const float g_H = -cfg.entropy_coef * invB;
+    float dz[A];
+#pragma unroll
+    for (int k = 0; k < A; ++k) {
+      const float onehot = (a == k) ? 1.0f : 0.0f;
+      dz[k] = g_lp * (onehot - p[k]) + g_H * (-p[k] * (ln[k] + H));
+    }
+    store_row<A>(dlogits_out, b, dz);
+    const float dvr = v - rt;
+    dvalue_out[b] = cfg.value_coef * 2.0f * dvr * invB;
+
+    met[0] = -(double)obj;
+    met[1] = (double)(cfg.value_coef * (dvr * dvr));
+    met[2] = (double)H;
+    met[3] = (ratio < lo || ratio > hi) ? 1.0 : 0.0;
+    met[4] = (double)(lpo - lp);
+  }
+  if (metrics_sum) block_atomic_add<5, kBlock>(met, metrics_sum);
+}
+
+// ---------------------------------------------------------------- L3 loss ---
+template <int A>
+__global__ __launch_bounds__(kBlock) void ppo_full_loss_kernel(
+    const float* __restrict__ logits, const float* __restrict__ value,
+    const int32_t* __restrict__ idx, const int32_t* __restrict__ act,
+    const float* __restrict__ logp_old, const float* __restrict__ ent_old,
+    const float* __restrict__ adv, const float* __restrict__ ret, int B, gymrl_ppo_full_cfg cfg,
+    float* __restrict__ dlogits_out, float* __restrict__ dvalue_out,
+    double* __restrict__ metrics_sum) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  double met[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (b < B) {
+    float z[A], ln[A], p[A], H;
+    load_row<A>(logits, b, z);
+    const float v = value[b];
+    const int i = idx ? idx[b] : b;
+    const int a = act[i];
+    const float lpo = logp_old[i];
+    const float eo = ent_old[i];
+    const float ad = adv[i];
+    const float rt = ret[i];
+    log_softmax<A>(z, ln, p, H);
+    float lp = ln[0];
+#pragma unroll
+    for (int k = 1; k < A; ++k) if (a == k) lp = ln[k];
+
+    const float invB = 1.0f / (float)B;
+    // entropy-ratio mask (no gradient) — :586-590
+    const float er = H / (eo + 1e-8f);
+    const float corr = (er > (1.0f - cfg.erc_beta_low) && er < (1.0f + cfg.erc_beta_high)) ? 1.0f : 0.0f;
+    const float ratio = det_expf(lp - lpo);
+    const float lo = 1.0f - cfg.clip_eps_min, hi = 1.0f + cfg.clip_eps_max;
+    const float r1 = fminf(fmaxf(ratio, 0.0f), cfg.dual_clip);
+    const float r2 = fminf(fmaxf(ratio, lo), hi);
+    const float s1 = r1 * ad, s2 = r2 * ad;
+    const float in1 = (ratio >= 0.0f && ratio <= cfg.dual_clip) ? 1.0f : 0.0f;
+    const float in2 = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
+    const float w1 = s1 < s2 ? 1.0f : (s1 == s2 ? 0.5f : 0.0f);
+    const float ms = fminf(s1, s2);
+    const float dms_dr = w1 * ad * in1 + (1.0f - w1) * ad * in2;
+    const float g_lp = -invB * corr * dms_dr * ratio;
+    const float g_H = -cfg.entropy_coef * invB * corr;
+    float dz[A];
+#pragma unroll
+    for (int k = 0; k < A; ++k) {
+      const float onehot = (a == k) ? 1.0f : 0.0f;
+      dz[k] = g_lp * (onehot - p[k]) + g_H * (-p[k] * (ln[k] + H));
+    }
+    store_row<A>(dlogits_out, b, dz);
+    const float dvr = v - rt;
+    dvalue_out[b] = corr * dvr * invB;
+
+    met[0] = (double)(-ms * corr);
+    met[1] = (double)(0.5f * corr * (dvr * dvr));
+    met[2] = (double)(H * corr);
+    met[3] = (ratio < lo || ratio > hi) ? (double)corr : 0.0;
+    met[4] = (double)(lpo - lp);
+    met[5] = 1.0 - (double)corr;
+    met[6] = (double)lp;
+    met[7] = (double)ad;
+    met[8] = (double)lp * (double)ad;
+  }
+  if (metrics_sum) block_atomic_add<9, kBlock>(met, metrics_sum);
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+#define DISPATCH_A(A_, CALL)              \
+  switch (A_) {                           \
+    case 2: { constexpr int A = 2; CALL; } break; \
+    case 3: { constexpr int A = 3; CALL; } break; \
+    case 4: { constexpr int A = 4; CALL; } break; \
+    case 5: { constexpr int A = 5; CALL; } break; \
+    case 6: { constexpr int A = 6; CALL; } break; \
+    case 7: { constexpr int A = 7; CALL; } break; \
+    case 8: { constexpr int A = 8; CALL; } break; \
+    default: return -22;                  \
+  }
+
+extern "C" {
+
+int gymrl_categorical_sample(const float* logits, const float* value_in, const float* noise_exp,
+                             uint64_t seed, uint64_t counter, int64_t env_id0, int n,
+                             int n_actions, int deterministic, int32_t* act_out, float* logp_out,
+                             float* ent_out, float* value_out, void* stream_) {
+  if (!logits || !act_out || !logp_out || n < 0) return -22;
+  if (n == 0) return 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  DISPATCH_A(n_actions,
+             hipLaunchKernelGGL(categorical_sample_kernel<A>, dim3(cdiv(n, kBlock)), dim3(kBlock),
+                                0, stream, logits, value_in, noise_exp, seed, counter, env_id0, n,
+                                deterministic, act_out, logp_out, ent_out, value_out));
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_ppo_loss_fwd_bwd(const float* logits, const float* value, const int32_t* idx,
+                           const int32_t* act, const float* logp_old, const float* adv,
+                           const float* ret, const double* adv_moments, int B, int n_actions,
+                           const gymrl_ppo_cfg* cfg_host, float* dlogits_out, float* dvalue_out,
+                           double* metrics_sum, void* stream_) {
+  if (!logits || !value || !act || !logp_old || !adv || !ret || !cfg_host || !dlogits_out ||
+      !dvalue_out || B < 0)
+    return -22;
+  if (B == 0) return 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  const gymrl_ppo_cfg cfg = *cfg_host;
+  DISPATCH_A(n_actions,
+             hipLaunchKernelGGL(ppo_loss_kernel<A>, dim3(cdiv(B, kBlock)), dim3(kBlock), 0, stream,
+                                logits, value, idx, act, logp_old, adv, ret, adv_moments, B, cfg,
+                                dlogits_out, dvalue_out, metrics_sum));
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const int32_t* idx,
+                                const int32_t* act, const float* logp_old, const float* ent_old,
+                                const float* adv, const float* ret, int B, int n_actions,
+                                const gymrl_ppo_full_cfg* cfg_host, float* dlogits_out,
+                                float* dvalue_out, double* metrics_sum, void* stream_) {
+  if (!logits || !value || !act || !logp_old || !ent_old || !adv || !ret || !cfg_host ||
+      !dlogits_out || !dvalue_out || B < 0)
+    return -22;
+  if (B == 0) return 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  const gymrl_ppo_full_cfg cfg = *cfg_host;
+  DISPATCH_A(n_actions,
+             hipLaunchKernelGGL(ppo_full_loss_kernel<A>, dim3(cdiv(B, kBlock)), dim3(kBlock), 0,
+                                stream, logits, value, idx, act, logp_old, ent_old, adv, ret, B, cfg,
+                                dlogits_out, dvalue_out, metrics_sum));
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,228 @@
+/*
+ * gymrl.h — C-ABI of libgymrl_hip.so: the MI355X (gfx950) vectorised-rollout +
+ * PPO/DQN/SAC learner hot path that sits behind the Config / Trainer surface of
+ * Starlight0798/gymRL's algorithms/<algo>_<env>.py scripts.
+ *
+ * The reference has no FFI of its own (pure Python); every entry point below
+ * cites the reference function (file:line under the gymRL tree) whose arithmetic
+ * it replaces.  INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes; no torch / C++ types.
+ *   - every data pointer is a DEVICE pointer (HBM) unless the name ends in _host.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *   - return 0 on success, -EINVAL (-22) on a bad argument, -(hipError_t) - 1000
+ *     when a launch fails.  Nothing allocates, nothing synchronises, nothing
+ *     copies to the host: the caller owns every buffer.  Safe to capture in a
+ *     hipGraph.
+ *   - layouts are time-major SoA slabs: x[T][N] (t outer, env inner) so that a
+ *     wavefront's 64 lanes (= 64 env instances) touch 64 consecutive words.
+ */
+#ifndef GYMRL_H
+#define GYMRL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GYMRL_ABI_VERSION 1
+
+/* ---------------------------------------------------------------- misc --- */
+int gymrl_abi_version(void);
+/* 1 when a gfx950 device is visible to the HIP runtime, else 0. */
+int gymrl_device_ok(void);
+
+/* ------------------------------------------------------------- env kinds -- */
+enum {
+  GYMRL_ENV_CARTPOLE    = 0, /* CartPole-v1   obs 4, 2 discrete actions   */
+  GYMRL_ENV_PENDULUM    = 1, /* Pendulum-v1   obs 3, 1 continuous in [-2,2] */
+  GYMRL_ENV_LUNARLANDER = 2  /* LunarLander-v3 obs 8, 4 discrete actions  */
+};
+
+/*
+ * Batched env stepper.  Replaces gym.make / env.reset / env.step as used by
+ * ppo_lunarlander.py:160,200,211,222  dqn_cartpole.py:94,176,181
+ * rainbow_dqn_cartpole.py:270,369,373  sac_pendulum.py:154,275,281
+ * utils/runner.py:53,111,123.
+ * One env instance per lane; state is a caller-owned SoA byte buffer of
+ * gymrl_env_state_bytes(kind, n_envs) bytes (256-B aligned base required).
+ */
+int    gymrl_env_obs_dim(int kind);
+int    gymrl_env_act_dim(int kind);     /* #discrete actions, or continuous dim */
+int    gymrl_env_is_discrete(int kind);
+int    gymrl_env_max_steps(int kind);   /* TimeLimit: 500 / 200 / 1000 */
+size_t gymrl_env_state_bytes(int kind, int n_envs);
+
+/* (Re)initialise every env: episode counter := 0, draws from the counter-based
+ * Philox stream keyed by (seed, env_id0 + lane, episode).  obs_out [N, obs_dim]. */
+int gymrl_env_reset(int kind, void* state, int n_envs, uint64_t seed,
+                    int64_t env_id0, float* obs_out, void* stream);
+
+/* One vector step with auto-reset.
+ *   action        i32[N] (discrete) or f32[N, act_dim] (continuous)
+ *   obs_out       f32[N, obs]  observation the policy sees next (post-reset
+ *                 where done — ppo_lunarlander.py:220-223)
+ *   term_obs_out  f32[N, obs] or NULL: pre-reset observation (what off-policy
+ *                 buffers store as next_state — dqn_cartpole.py:183)
+ *   rew_out       f32[N]
+ *   terminated_out / truncated_out  u8[N]  (rainbow_dqn_cartpole.py:376 needs both)
+ *   done_out      u8[N] or NULL  = terminated | truncated (ppo_lunarlander.py:212)
+ *   ep_ret_out    f32[N] or NULL: finished episode's return where done, else unchanged
+ *   ep_len_out    i32[N] or NULL: finished episode's length where done
+ *   ep_stats      f64[3] or NULL: += (#finished episodes, sum of returns, sum of lengths)
+ */
+int gymrl_env_step(int kind, void* state, int n_envs, uint64_t seed, int64_t env_id0,
+                   const void* action, float* obs_out, float* term_obs_out,
+                   float* rew_out, uint8_t* terminated_out, uint8_t* truncated_out,
+                   uint8_t* done_out, float* ep_ret_out, int32_t* ep_len_out,
+                   double* ep_stats, void* stream);
+
+/* -------------------------------------------------- categorical policy ---- */
+/*
+ * Categorical(logits).sample()/log_prob/entropy — ppo_lunarlander.py:92-104.
+ * sample == argmax_k(softmax(z)_k / q_k), q ~ Exp(1)  (torch.multinomial's CPU
+ * path).  noise_exp f32[N,A] supplies q explicitly (parity
+ * mode); when NULL q is drawn in-kernel from Philox(seed, counter, env).
+ * deterministic != 0 -> action = argmax(z) (ppo_lunarlander.py:98-99).
+ * value_in f32[N] (may be NULL) is copied to value_out so the rollout slab row
+ * is written by one kernel.  A <= 8.
+ */
+int gymrl_categorical_sample(const float* logits, const float* value_in,
+                             const float* noise_exp, uint64_t seed, uint64_t counter,
+                             int64_t env_id0, int n, int n_actions, int deterministic,
+                             int32_t* act_out, float* logp_out, float* ent_out,
+                             float* value_out, void* stream);
+
+/* ------------------------------------------------------------------ GAE --- */
+/*
+ * G1: PPOTrainer.compute_gae — ppo_lunarlander.py:179-196.
+ *   delta_t = r_t + g*V_{t+1}*(1-d_t) - V_t ; A_t = delta_t + g*l*(1-d_t)*A_{t+1}
+ *   V_T = next_val ; ret = A + V.   float64 recursion, float32 storage.
+ * rew,val f32[T][N]; done u8[T][N]; next_val f32[N]; adv_out, ret_out f32[T][N].
+ * moments_out f64[3] or NULL: = (count, sum A, sum A^2) over the float64
+ * advantages (feeds the whole-rollout normalisation of ppo_lunarlander.py:236);
+ * reduced in a fixed order (no float atomics) so training is reproducible.
+ * variant 0 = one lane walks one env sequentially (reference operation order);
+ * variant 1 = time-blocked affine scan (roofline variant; needs N % 4 == 0 and
+ *             16-B aligned rows, else it falls back to variant 0).
+ * workspace: gymrl_gae_workspace_bytes(T, N) bytes, 256-B aligned; required for
+ * variant 1 or when moments_out != NULL.
+ */
+size_t gymrl_gae_workspace_bytes(int T, int N);
+int gymrl_gae(const float* rew, const float* val, const uint8_t* done,
+              const float* next_val, int T, int N, double gamma, double lam,
+              float* adv_out, float* ret_out, double* moments_out,
+              int variant, void* workspace, void* stream);
+
+/* G2: ReplayBuffer_on_policy.compute_advantage — utils/buffer.py:21-35
+ * (== ppo_rnn_lunarlander.py:187-204): stored next values, separate dw
+ * (terminated) and done masks, float32 recursion.  All arrays [T][N]. */
+int gymrl_gae_dw(const float* rew, const float* val, const float* next_val,
+                 const uint8_t* done, const uint8_t* dw, int T, int N,
+                 double gamma, double lam, float* adv_out, float* vtarget_out,
+                 double* moments_out, void* workspace, void* stream);
+
+/* G3: ppo_full compute_advantages — ppo_full_lunarlander.py:507-535: two scans
+ * sharing delta (lam_actor, lam_critic); ret = adv_critic + V; adv_actor raw. */
+int gymrl_gae_decoupled(const float* rew, const float* val, const uint8_t* done,
+                        const float* next_val, int T, int N, double gamma,
+                        double lam_actor, double lam_critic,
+                        float* adv_actor_out, float* ret_out, void* stream);
+
+/* Whole-rollout advantage normalisation — ppo_lunarlander.py:236 (ddof 0) and
+ * utils/buffer.py:33 (ddof 1).  moments f64[3] = (count, sum, sumsq) on device.
+ * x <- (x - mean) / (std + eps), f64 arithmetic, f32 storage. */
+size_t gymrl_reduce_workspace_bytes(void);
+int gymrl_moments(const float* x, int64_t n, double* moments_out, void* workspace,
+                  void* stream);
+int gymrl_normalize(float* x, int64_t n, const double* moments, int ddof,
+                    double eps, void* stream);
+
+/* ------------------------------------------------------------- PPO loss --- */
+typedef struct {
+  float clip_eps;     /* ppo_lunarlander.py:41  (0.2)  */
+  float dual_clip;    /* :42 (3.0)                     */
+  float value_coef;   /* :44 (0.5)                     */
+  float entropy_coef; /* :43 (0.01)                    */
+} gymrl_ppo_cfg;
+
+/*
+ * L1+L2: evaluate_actions + clipped/dual-clip surrogate + value + entropy loss,
+ * forward AND backward w.r.t. logits/value, plus the five metrics —
+ * ppo_lunarlander.py:110-117, 278-300, 309-322.
+ *   logits f32[B,A], value f32[B]: network outputs for minibatch rows 0..B-1
+ *   idx    i32[B] or NULL: row b reads act/logp_old/adv/ret at idx[b] of the
+ *          rollout slab (fused minibatch gather, ppo_lunarlander.py:268-272)
+ *   act i32[*], logp_old f32[*], adv f32[*], ret f32[*]
+ *   adv_moments f64[3] or NULL: when given, adv is normalised on the fly with
+ *          (mean, population std + 1e-8) — ppo_lunarlander.py:236
+ *   dlogits_out f32[B,A], dvalue_out f32[B]: d(loss)/d(logits|value), loss =
+ *          mean over the B rows (torch autograd tie rules)
+ *   metrics_sum f64[5] or NULL: += (sum -obj, vf*sum (v-ret)^2, sum H, #clipped,
+ *          sum (logp_old - logp)).  The caller keeps one zeroed row per minibatch
+ *          and divides by B on the host after the whole update (one D2H copy
+ *          instead of ppo_lunarlander.py:309-322's five .item() per minibatch).
+ */
+int gymrl_ppo_loss_fwd_bwd(const float* logits, const float* value, const int32_t* idx,
+                           const int32_t* act, const float* logp_old, const float* adv,
+                           const float* ret, const double* adv_moments, int B, int A,
+                           const gymrl_ppo_cfg* cfg_host, float* dlogits_out,
+                           float* dvalue_out, double* metrics_sum, void* stream);
+
+typedef struct {
+  float clip_eps_min;  /* ppo_full_lunarlander.py:34 (0.2)  */
+  float clip_eps_max;  /* :35 (0.28)                        */
+  float dual_clip;     /* :36 (3.0) ratio clamp upper bound */
+  float erc_beta_low;  /* :39 (0.06)                        */
+  float erc_beta_high; /* :40 (0.06)                        */
+  float entropy_coef;  /* current (annealed) value, :662-666 */
+} gymrl_ppo_full_cfg;
+
+/* L3: ppo_full update_model minibatch loss — ppo_full_lunarlander.py:575-652.
+ * ent_old f32[*] = behaviour-policy entropy stored at collection (:488).
+ * clip_cov_ratio must be 0 (the reference default, :44) — the cov-clip branch
+ * :611-616 is then dead and is not implemented.
+ * metrics_sum f64[9]: += (sum policy term, sum 0.5*corr*(v-ret)^2, sum H*corr,
+ * sum clipped*corr, sum (logp_old-logp), #erc-masked, sum logp, sum adv,
+ * sum logp*adv) — the last three give covs.mean() (:594-596) per minibatch. */
+int gymrl_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const int32_t* idx,
+                                const int32_t* act, const float* logp_old,
+                                const float* ent_old, const float* adv, const float* ret,
+                                int B, int A, const gymrl_ppo_full_cfg* cfg_host,
+                                float* dlogits_out, float* dvalue_out,
+                                double* metrics_sum, void* stream);
+
+/* ------------------------------------------------------------ optimiser --- */
+/*
+ * O1 / D4 / R4: clip_grad_norm_ + Adam on ONE flat fp32 parameter buffer —
+ * ppo_lunarlander.py:169,302-307; dqn_cartpole.py:163-166 (clamp_abs = 1);
+ * rainbow_dqn_cartpole.py:343-345; sac_pendulum.py:244-255.
+ *   gymrl_sqnorm:    sqnorm_out f64[1] (device) = sum (g*grad_scale)^2, fixed-order
+ *                    reduction; workspace >= gymrl_reduce_workspace_bytes()
+ *   gymrl_adam_step: scale = max_grad_norm>0 ? min(1, max_norm/(sqrt(sqnorm)+1e-6)) : 1
+ *                    g' = clamp_abs>0 ? clamp(g*grad_scale, +-clamp_abs) : g*grad_scale*scale
+ *                    m,v,p updated as torch.optim.Adam (no amsgrad, no decay);
+ *                    g is zeroed (zero_grad fused) when zero_grad != 0.
+ *   lr_dev f32[1] or NULL (then lr_host is used): device-resident lr lets LR
+ *   annealing change the rate without re-capturing a graph.
+ *   grad_scale multiplies g first (1/world_size after an all-reduce SUM).
+ */
+int gymrl_sqnorm(const float* g, int64_t n, float grad_scale, double* sqnorm_out,
+                 void* workspace, void* stream);
+int gymrl_adam_step(float* p, float* g, float* m, float* v, int64_t n,
+                    double lr_host, const float* lr_dev, double beta1, double beta2,
+                    double eps, int64_t step, float grad_scale, float max_grad_norm,
+                    const double* sqnorm, float clamp_abs, int zero_grad, void* stream);
+
+/* R4 / A4: theta' <- tau*theta + (1-tau)*theta' on flat buffers —
+ * rainbow_dqn_cartpole.py:347-352, sac_pendulum.py:194-199. */
+int gymrl_soft_update(float* target, const float* source, int64_t n, double tau,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GYMRL_H */

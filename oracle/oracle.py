@@ -1,0 +1,250 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/libgymrl_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package gymrl_amd/ must never import it.
+Every function takes and returns numpy arrays; see gymrl_oracle.c for the
+reference file:line each one restates.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libgymrl_oracle.so")
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_expf.restype = C.c_float
+        _lib.orc_expf.argtypes = [C.c_float]
+        _lib.orc_logf.restype = C.c_float
+        _lib.orc_logf.argtypes = [C.c_float]
+        _lib.orc_tanhf.restype = C.c_float
+        _lib.orc_tanhf.argtypes = [C.c_float]
+        _lib.orc_env_create.restype = C.c_void_p
+        _lib.orc_env_create.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int64]
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+# ------------------------------------------------------------------ math ----
+def expf(x):
+    L = lib()
+    return np.array([L.orc_expf(float(v)) for v in np.asarray(x, np.float32).ravel()], np.float32).reshape(np.shape(x))
+
+
+def logf(x):
+    L = lib()
+    return np.array([L.orc_logf(float(v)) for v in np.asarray(x, np.float32).ravel()], np.float32).reshape(np.shape(x))
+
+
+def tanhf(x):
+    L = lib()
+    return np.array([L.orc_tanhf(float(v)) for v in np.asarray(x, np.float32).ravel()], np.float32).reshape(np.shape(x))
+
+
+def sincosf(x):
+    L = lib()
+    xs = np.asarray(x, np.float32).ravel()
+    s = np.empty_like(xs)
+    c = np.empty_like(xs)
+    ss, cc = C.c_float(), C.c_float()
+    for i, v in enumerate(xs):
+        L.orc_sincosf(C.c_float(float(v)), C.byref(ss), C.byref(cc))
+        s[i], c[i] = ss.value, cc.value
+    return s.reshape(np.shape(x)), c.reshape(np.shape(x))
+
+
+def philox(key, c0, c1, c2, c3):
+    out = (C.c_uint32 * 4)()
+    lib().orc_philox(C.c_uint64(key), C.c_uint32(c0), C.c_uint32(c1), C.c_uint32(c2), C.c_uint32(c3), out)
+    return list(out)
+
+
+# ------------------------------------------------------------------- GAE ----
+def gae(rew, val, done, next_val, gamma, lam, want_moments=False):
+    rew, val, done, next_val = _f32(rew), _f32(val), _u8(done), _f32(next_val)
+    T, N = rew.shape
+    adv, ret = np.empty((T, N), np.float32), np.empty((T, N), np.float32)
+    mom = np.zeros(3, np.float64)
+    lib().orc_gae(_p(rew), _p(val), _p(done), _p(next_val), C.c_int(T), C.c_int(N), C.c_double(gamma),
+                  C.c_double(lam), _p(adv), _p(ret), _p(mom))
+    return (adv, ret, mom) if want_moments else (adv, ret)
+
+
+def gae_dw(rew, val, next_val, done, dw, gamma, lam):
+    rew, val, next_val, done, dw = _f32(rew), _f32(val), _f32(next_val), _u8(done), _u8(dw)
+    T, N = rew.shape
+    adv, vt = np.empty((T, N), np.float32), np.empty((T, N), np.float32)
+    mom = np.zeros(3, np.float64)
+    lib().orc_gae_dw(_p(rew), _p(val), _p(next_val), _p(done), _p(dw), C.c_int(T), C.c_int(N),
+                     C.c_double(gamma), C.c_double(lam), _p(adv), _p(vt), _p(mom))
+    return adv, vt, mom
+
+
+def gae_decoupled(rew, val, done, next_val, gamma, lam_actor, lam_critic):
+    rew, val, done, next_val = _f32(rew), _f32(val), _u8(done), _f32(next_val)
+    T, N = rew.shape
+    adv, ret = np.empty((T, N), np.float32), np.empty((T, N), np.float32)
+    lib().orc_gae_decoupled(_p(rew), _p(val), _p(done), _p(next_val), C.c_int(T), C.c_int(N),
+                            C.c_double(gamma), C.c_double(lam_actor), C.c_double(lam_critic), _p(adv), _p(ret))
+    return adv, ret
+
+
+def moments(x):
+    x = _f32(x).ravel()
+    mom = np.zeros(3, np.float64)
+    lib().orc_moments(_p(x), C.c_int64(x.size), _p(mom))
+    return mom
+
+
+def normalize(x, mom, ddof=0, eps=1e-8):
+    x = _f32(x).copy()
+    mom = np.ascontiguousarray(mom, np.float64)
+    lib().orc_normalize(_p(x), C.c_int64(x.size), _p(mom), C.c_int(ddof), C.c_double(eps))
+    return x
+
+
+# ------------------------------------------------------------ categorical ---
+def categorical_sample(logits, value=None, noise_exp=None, seed=0, counter=0, env_id0=0, deterministic=False):
+    logits = _f32(logits)
+    n, A = logits.shape
+    act = np.empty(n, np.int32)
+    logp, ent = np.empty(n, np.float32), np.empty(n, np.float32)
+    vin = None if value is None else _f32(value)
+    vout = None if value is None else np.empty(n, np.float32)
+    q = None if noise_exp is None else _f32(noise_exp)
+    lib().orc_categorical_sample(_p(logits), _p(vin), _p(q), C.c_uint64(seed), C.c_uint64(counter),
+                                 C.c_int64(env_id0), C.c_int(n), C.c_int(A), C.c_int(int(deterministic)),
+                                 _p(act), _p(logp), _p(ent), _p(vout))
+    return act, logp, ent, vout
+
+
+# --------------------------------------------------------------- PPO loss ---
+class PPOCfg(C.Structure):
+    _fields_ = [("clip_eps", C.c_float), ("dual_clip", C.c_float), ("value_coef", C.c_float),
+                ("entropy_coef", C.c_float)]
+
+
+class PPOFullCfg(C.Structure):
+    _fields_ = [("clip_eps_min", C.c_float), ("clip_eps_max", C.c_float), ("dual_clip", C.c_float),
+                ("erc_beta_low", C.c_float), ("erc_beta_high", C.c_float), ("entropy_coef", C.c_float)]
+
+
+def ppo_loss_fwd_bwd(logits, value, act, logp_old, adv, ret, cfg, idx=None, adv_moments=None):
+    logits, value = _f32(logits), _f32(value)
+    B, A = logits.shape
+    act, logp_old, adv, ret = _i32(act), _f32(logp_old), _f32(adv), _f32(ret)
+    idx_ = None if idx is None else _i32(idx)
+    mom = None if adv_moments is None else np.ascontiguousarray(adv_moments, np.float64)
+    dl, dv = np.empty((B, A), np.float32), np.empty(B, np.float32)
+    met = np.zeros(5, np.float64)
+    c = PPOCfg(*cfg)
+    lib().orc_ppo_loss_fwd_bwd(_p(logits), _p(value), _p(idx_), _p(act), _p(logp_old), _p(adv), _p(ret),
+                               _p(mom), C.c_int(B), C.c_int(A), C.byref(c), _p(dl), _p(dv), _p(met))
+    return dl, dv, met
+
+
+def ppo_full_loss_fwd_bwd(logits, value, act, logp_old, ent_old, adv, ret, cfg, idx=None):
+    logits, value = _f32(logits), _f32(value)
+    B, A = logits.shape
+    act, logp_old, ent_old, adv, ret = _i32(act), _f32(logp_old), _f32(ent_old), _f32(adv), _f32(ret)
+    idx_ = None if idx is None else _i32(idx)
+    dl, dv = np.empty((B, A), np.float32), np.empty(B, np.float32)
+    met = np.zeros(9, np.float64)
+    c = PPOFullCfg(*cfg)
+    lib().orc_ppo_full_loss_fwd_bwd(_p(logits), _p(value), _p(idx_), _p(act), _p(logp_old), _p(ent_old),
+                                    _p(adv), _p(ret), C.c_int(B), C.c_int(A), C.byref(c), _p(dl), _p(dv), _p(met))
+    return dl, dv, met
+
+
+# -------------------------------------------------------------- optimiser ---
+def sqnorm(g, grad_scale=1.0):
+    g = _f32(g).ravel()
+    out = np.zeros(1, np.float64)
+    lib().orc_sqnorm(_p(g), C.c_int64(g.size), C.c_float(grad_scale), _p(out))
+    return out
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, max_grad_norm=0.0, clamp_abs=0.0,
+              zero_grad=False):
+    """In place on copies; returns (p, g, m, v)."""
+    p, g, m, v = [_f32(a).ravel().copy() for a in (p, g, m, v)]
+    sq = sqnorm(g, grad_scale) if max_grad_norm > 0 else None
+    lib().orc_adam_step(_p(p), _p(g), _p(m), _p(v), C.c_int64(p.size), C.c_double(lr), C.c_double(beta1),
+                        C.c_double(beta2), C.c_double(eps), C.c_int64(step), C.c_float(grad_scale),
+                        C.c_float(max_grad_norm), _p(sq), C.c_float(clamp_abs), C.c_int(int(zero_grad)))
+    return p, g, m, v
+
+
+def soft_update(target, source, tau):
+    t = _f32(target).ravel().copy()
+    s = _f32(source).ravel()
+    lib().orc_soft_update(_p(t), _p(s), C.c_int64(t.size), C.c_double(tau))
+    return t
+
+
+# -------------------------------------------------------------------- env ---
+CARTPOLE, PENDULUM, LUNARLANDER = 0, 1, 2
+_OBS = {0: 4, 1: 3, 2: 8}
+
+
+class Env:
+    """Vector of oracle envs with the same auto-reset contract as gymrl_env_step."""
+
+    def __init__(self, kind, n, seed=0, env_id0=0):
+        self.kind, self.n, self.D = kind, n, _OBS[kind]
+        self._h = C.c_void_p(lib().orc_env_create(kind, n, C.c_uint64(seed), C.c_int64(env_id0)))
+
+    def __del__(self):
+        try:
+            lib().orc_env_destroy(self._h)
+        except Exception:
+            pass
+
+    def reset(self):
+        obs = np.zeros((self.n, self.D), np.float32)
+        lib().orc_env_reset(self._h, _p(obs))
+        return obs
+
+    def step(self, action):
+        action = _i32(action) if self.kind != PENDULUM else _f32(action)
+        n, D = self.n, self.D
+        obs, tobs = np.zeros((n, D), np.float32), np.zeros((n, D), np.float32)
+        rew = np.zeros(n, np.float32)
+        term, trunc, done = np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        ep_ret, ep_len = np.zeros(n, np.float32), np.zeros(n, np.int32)
+        stats = np.zeros(3, np.float64)
+        lib().orc_env_step(self._h, _p(action), _p(obs), _p(tobs), _p(rew), _p(term), _p(trunc), _p(done),
+                           _p(ep_ret), _p(ep_len), _p(stats))
+        return dict(obs=obs, term_obs=tobs, rew=rew, terminated=term, truncated=trunc, done=done,
+                    ep_ret=ep_ret, ep_len=ep_len, ep_stats=stats)

@@ -1,0 +1,40 @@
+"""pytest config: `gpu` marker + repo root on sys.path.
+
+`-m "not gpu"` runs here (no GPU): oracle vs golden vectors, host logic, C-ABI
+symbol checks, gloo world_size-2 tests.  `-m gpu` runs on an MI355X: the HIP
+kernels, through the C-ABI, against the oracle and the golden fixtures.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as orc
+    orc.build()
+    return orc
+
+
+def rel_close(a, b, tol=1e-5):
+    """|a-b| <= tol*max(1,|b|) — the tolerance form SURVEY.md section 8d prescribes."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    return float(err.max()) if err.size else 0.0

@@ -1,0 +1,375 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE's own Python learner code.
+
+Runs only in the build container (needs /root/reference).  It imports the
+reference scripts behind a stub `gymnasium` (the scripts touch gym only through
+gym.make), drives their functions on seeded inputs, and stores inputs + expected
+outputs as small .npz fixtures next to this file.  No reference source is copied:
+the fixtures are data.  The fixtures pin oracle/gymrl_oracle.c
+(tests/test_oracle_golden.py), which in turn checks the HIP kernels on the GPU.
+
+    python tests/golden/make_golden.py            # regenerate everything
+"""
+import importlib.util
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------- stub gym ----
+class _Space:
+    def __init__(self, shape=None, n=None, high=None):
+        self.shape, self.n = shape, n
+        self.high = None if high is None else np.array(high, np.float32)
+
+    def sample(self):
+        return random.randrange(self.n)
+
+
+class _FakeEnv:
+    """Shape-only env: the golden generators never step it."""
+
+    def __init__(self, name):
+        if name.startswith("LunarLander"):
+            self.observation_space, self.action_space, steps = _Space((8,)), _Space(n=4), 1000
+        elif name.startswith("CartPole"):
+            self.observation_space, self.action_space, steps = _Space((4,)), _Space(n=2), 500
+        else:
+            self.observation_space, self.action_space, steps = _Space((3,)), _Space((1,), high=[2.0]), 200
+        self.spec = types.SimpleNamespace(max_episode_steps=steps)
+
+    def reset(self, seed=None):
+        return np.zeros(self.observation_space.shape, np.float32), {}
+
+    def close(self):
+        pass
+
+
+def _install_stub_gym():
+    g = types.ModuleType("gymnasium")
+    g.make = lambda name, **kw: _FakeEnv(name)
+    sys.modules["gymnasium"] = g
+
+
+def load_ref(relpath, modname):
+    _install_stub_gym()
+    spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def seed_all(s):
+    random.seed(s)
+    np.random.seed(s)
+    torch.manual_seed(s)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path}  ({os.path.getsize(path)} B)")
+
+
+# ------------------------------------------------------------------- G1 ------
+def gen_gae():
+    """PPOTrainer.compute_gae (ppo_lunarlander.py:179-196) on single-env rollouts."""
+    ppo = load_ref("algorithms/ppo_lunarlander.py", "ref_ppo")
+    rng = np.random.default_rng(1)
+    cases = {}
+    k = 0
+    for T in (1, 7, 64, 2048):
+        for pattern in ("none", "all", "last", "random"):
+            rew = rng.normal(size=T) * np.where(rng.random(T) < 0.01, 100.0, 1.0)
+            val = rng.normal(size=T).astype(np.float32)
+            if pattern == "none":
+                done = np.zeros(T, bool)
+            elif pattern == "all":
+                done = np.ones(T, bool)
+            elif pattern == "last":
+                done = np.zeros(T, bool)
+                done[-1] = True
+            else:
+                done = rng.random(T) < 0.05
+            next_value = float(np.float32(rng.normal()))
+            tr = ppo.PPOTrainer.__new__(ppo.PPOTrainer)
+            tr.cfg = ppo.Config()
+            tr.buffer = ppo.RolloutBuffer()
+            # rewards in the reference are python floats that came from float32 env values
+            rew32 = rew.astype(np.float32)
+            tr.buffer.rewards = [float(x) for x in rew32]
+            tr.buffer.values = [float(x) for x in val]
+            tr.buffer.dones = [bool(x) for x in done]
+            adv, ret = tr.compute_gae(next_value)
+            assert adv.dtype == np.float64
+            norm = (adv - adv.mean()) / (adv.std() + 1e-8)      # :236
+            cases[f"c{k}_rew"] = rew32
+            cases[f"c{k}_val"] = val
+            cases[f"c{k}_done"] = done.astype(np.uint8)
+            cases[f"c{k}_next"] = np.float32(next_value)
+            cases[f"c{k}_adv"] = adv
+            cases[f"c{k}_ret"] = ret
+            cases[f"c{k}_norm"] = norm
+            k += 1
+    cases["n_cases"] = np.int64(k)
+    cases["gamma"] = np.float64(ppo.Config().gamma)
+    cases["lam"] = np.float64(ppo.Config().gae_lambda)
+    save("gae_g1", **cases)
+
+
+def gen_gae_g2():
+    """ReplayBuffer_on_policy.compute_advantage (utils/buffer.py:21-35)."""
+    sys.path.insert(0, REF)
+    from utils.buffer import ReplayBuffer_on_policy
+    rng = np.random.default_rng(2)
+    cfg = types.SimpleNamespace(gamma=0.99, lamda=0.95, device="cpu")
+    cases = {}
+    k = 0
+    for T in (2, 9, 200):
+        for _ in range(2):
+            rew = rng.normal(size=(T, 1)).astype(np.float32)
+            val = rng.normal(size=(T, 1)).astype(np.float32)
+            nval = rng.normal(size=(T, 1)).astype(np.float32)
+            done = (rng.random((T, 1)) < 0.1)
+            dw = done & (rng.random((T, 1)) < 0.5)
+            buf = ReplayBuffer_on_policy(cfg)
+            adv, vt = buf.compute_advantage(torch.tensor(rew), torch.tensor(done.astype(np.float32)),
+                                            torch.tensor(dw.astype(np.float32)), torch.tensor(val),
+                                            torch.tensor(nval))
+            for nm, a in (("rew", rew), ("val", val), ("nval", nval), ("done", done.astype(np.uint8)),
+                          ("dw", dw.astype(np.uint8)), ("advn", adv.numpy()), ("vt", vt.numpy())):
+                cases[f"c{k}_{nm}"] = a
+            k += 1
+    cases["n_cases"] = np.int64(k)
+    cases["gamma"] = np.float64(cfg.gamma)
+    cases["lam"] = np.float64(cfg.lamda)
+    save("gae_g2", **cases)
+
+
+def gen_gae_g3():
+    """ppo_full compute_advantages (ppo_full_lunarlander.py:507-535), lam_actor != lam_critic."""
+    pf = load_ref("algorithms/ppo_full_lunarlander.py", "ref_ppo_full")
+    rng = np.random.default_rng(3)
+    cases = {}
+    k = 0
+    for T in (5, 333):
+        rew = rng.normal(size=T).astype(np.float32)
+        val = rng.normal(size=T).astype(np.float32)
+        done = rng.random(T) < 0.03
+        nv = float(np.float32(rng.normal()))
+        tr = pf.PPOTrainer.__new__(pf.PPOTrainer)
+        tr.cfg = pf.Config()
+        tr.cfg.lam_actor, tr.cfg.lam_critic = 0.9, 0.97
+        tr.buffer = pf.RolloutBuffer()
+        tr.buffer.rewards = [float(x) for x in rew]
+        tr.buffer.values = [float(x) for x in val]
+        tr.buffer.dones = [bool(x) for x in done]
+        tr.buffer.next_value = nv
+        adv, ret = tr.compute_advantages()
+        for nm, a in (("rew", rew), ("val", val), ("done", done.astype(np.uint8)), ("next", np.float32(nv)),
+                      ("adv", np.asarray(adv, np.float64)), ("ret", np.asarray(ret, np.float64))):
+            cases[f"c{k}_{nm}"] = a
+        k += 1
+    cases["n_cases"] = np.int64(k)
+    cases["gamma"] = np.float64(tr.cfg.gamma)
+    cases["lam_actor"], cases["lam_critic"] = np.float64(0.9), np.float64(0.97)
+    save("gae_g3", **cases)
+
+
+# ------------------------------------------------------------------- P2 ------
+def gen_categorical():
+    """ActorCritic.get_action's Categorical (ppo_lunarlander.py:92-104): action under
+    a torch seed + the Exp(1) draw torch.multinomial consumed under the same seed."""
+    rng = np.random.default_rng(4)
+    from torch.distributions import Categorical
+    n, A = 512, 4
+    logits = (rng.normal(size=(n, A)) * rng.choice([0.1, 1.0, 5.0], size=(n, 1))).astype(np.float32)
+    lt = torch.tensor(logits)
+    torch.manual_seed(1234)
+    dist = Categorical(logits=lt)
+    action = dist.sample()
+    logp = dist.log_prob(action)
+    ent = dist.entropy()
+    torch.manual_seed(1234)
+    q = torch.empty_like(dist.probs).exponential_(1.0)
+    assert torch.equal((dist.probs / q).argmax(-1), action), "multinomial != argmax(p/q)"
+    save("categorical", logits=logits, noise_exp=q.numpy(), action=action.numpy().astype(np.int32),
+         logp=logp.numpy(), entropy=ent.numpy(), argmax=lt.argmax(-1).numpy().astype(np.int32))
+
+
+# ------------------------------------------------------------- L1 / O1 -------
+def gen_ppo_loss():
+    """One reference minibatch: loss terms, metrics, dlogits/dvalue (autograd hooks),
+    parameter grads, clipped-norm Adam step (ppo_lunarlander.py:274-322)."""
+    ppo = load_ref("algorithms/ppo_lunarlander.py", "ref_ppo")
+    cfg = ppo.Config()
+    out = {}
+    for case, B in enumerate((64, 257)):
+        seed_all(10 + case)
+        model = ppo.ActorCritic(8, 4, 32)  # small hidden: fixture stays a few hundred KB
+        opt = torch.optim.Adam(model.parameters(), lr=cfg.lr, eps=1e-5)
+        states = torch.randn(B, 8)
+        with torch.no_grad():
+            lg, _ = model(states)
+            # behaviour policy = perturbed current policy so ~10% of ratios clip
+            old_logits = lg + 0.6 * torch.randn_like(lg)
+            d_old = torch.distributions.Categorical(logits=old_logits)
+            actions = d_old.sample()
+            old_lp = d_old.log_prob(actions)
+        adv = torch.randn(B) * 2.0
+        ret = torch.randn(B) * 3.0
+        params0 = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy().copy()
+
+        logits, values = model(states)
+        logits.retain_grad()
+        values.retain_grad()
+        dist = torch.distributions.Categorical(logits=logits)
+        new_lp = dist.log_prob(actions)
+        entropy = dist.entropy()
+        v = values.squeeze(-1)
+        ratio = torch.exp(new_lp - old_lp)
+        surr1 = ratio * adv
+        surr2 = torch.clamp(ratio, 1 - cfg.clip_eps, 1 + cfg.clip_eps) * adv
+        min_surr = torch.min(surr1, surr2)
+        policy_loss = -torch.mean(torch.where(adv < 0, torch.max(min_surr, cfg.dual_clip * adv), min_surr))
+        value_loss = cfg.value_coef * torch.mean((v - ret).pow(2))
+        entropy_loss = -cfg.entropy_coef * entropy.mean()
+        loss = policy_loss + value_loss + entropy_loss
+        opt.zero_grad()
+        loss.backward()
+        grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).numpy().copy()
+        total_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.max_grad_norm)
+        opt.step()
+        params1 = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy().copy()
+        st = [opt.state[p] for p in model.parameters()]
+        m1 = torch.cat([s["exp_avg"].reshape(-1) for s in st]).numpy().copy()
+        v1 = torch.cat([s["exp_avg_sq"].reshape(-1) for s in st]).numpy().copy()
+        clip_frac = ((ratio < 1 - cfg.clip_eps) | (ratio > 1 + cfg.clip_eps)).float().mean().item()
+        kl = (old_lp - new_lp).mean().item()
+        pre = f"c{case}_"
+        out.update({
+            pre + "logits": logits.detach().numpy(), pre + "values": v.detach().numpy(),
+            pre + "actions": actions.numpy().astype(np.int32), pre + "old_lp": old_lp.numpy(),
+            pre + "adv": adv.numpy(), pre + "ret": ret.numpy(),
+            pre + "dlogits": logits.grad.numpy(), pre + "dvalues": values.grad.squeeze(-1).numpy(),
+            pre + "metrics": np.array([policy_loss.item(), value_loss.item(), entropy.mean().item(),
+                                       clip_frac, kl], np.float64),
+            pre + "params0": params0, pre + "grads": grads, pre + "total_norm": np.float64(total_norm.item()),
+            pre + "params1": params1, pre + "m1": m1, pre + "v1": v1,
+        })
+    out["n_cases"] = np.int64(2)
+    out["cfg"] = np.array([cfg.clip_eps, cfg.dual_clip, cfg.value_coef, cfg.entropy_coef], np.float64)
+    out["adam"] = np.array([cfg.lr, 0.9, 0.999, 1e-5, cfg.max_grad_norm], np.float64)
+    save("ppo_loss", **out)
+
+
+def gen_adam_multi():
+    """torch.optim.Adam over several steps with and without clipping / grad clamp
+    (ppo_lunarlander.py:302-307, dqn_cartpole.py:163-166)."""
+    seed_all(20)
+    n = 1003
+    out = {}
+    for case, (lr, eps, max_norm, clamp) in enumerate([(3e-4, 1e-5, 0.5, 0.0), (1e-3, 1e-8, 0.0, 1.0),
+                                                       (1e-3, 1e-8, 10.0, 0.0)]):
+        p = torch.nn.Parameter(torch.randn(n))
+        opt = torch.optim.Adam([p], lr=lr, eps=eps)
+        p0 = p.detach().numpy().copy()
+        gs = []
+        for step in range(5):
+            g = torch.randn(n) * (3.0 if step % 2 == 0 else 0.01)
+            gs.append(g.numpy().copy())
+            p.grad = g.clone()
+            if clamp > 0:
+                p.grad.data.clamp_(-clamp, clamp)
+            if max_norm > 0:
+                torch.nn.utils.clip_grad_norm_([p], max_norm)
+            opt.step()
+        out[f"c{case}_p0"] = p0
+        out[f"c{case}_grads"] = np.stack(gs)
+        out[f"c{case}_p5"] = p.detach().numpy().copy()
+        out[f"c{case}_m5"] = opt.state[p]["exp_avg"].numpy().copy()
+        out[f"c{case}_v5"] = opt.state[p]["exp_avg_sq"].numpy().copy()
+        out[f"c{case}_hp"] = np.array([lr, 0.9, 0.999, eps, max_norm, clamp], np.float64)
+    out["n_cases"] = np.int64(3)
+    save("adam", **out)
+
+
+# ------------------------------------------------------------------- L3 ------
+def gen_ppo_full_loss():
+    """ppo_full update_model minibatch loss (ppo_full_lunarlander.py:575-652) on given
+    logits/values (the mHC network itself runs through PyTorch and is not restated)."""
+    pf = load_ref("algorithms/ppo_full_lunarlander.py", "ref_ppo_full")
+    cfg = pf.Config()
+    from torch.distributions import Categorical
+    out = {}
+    for case, B in enumerate((128, 1024)):
+        seed_all(30 + case)
+        logits = (torch.randn(B, 4) * 1.5).requires_grad_(True)
+        values = torch.randn(B, 1, requires_grad=True)
+        with torch.no_grad():
+            old_logits = logits + 0.4 * torch.randn(B, 4)
+            d_old = Categorical(logits=old_logits)
+            a_batch = d_old.sample()
+            old_lp = d_old.log_prob(a_batch)
+            old_ent = d_old.entropy()
+        adv_batch = torch.randn(B) * 2
+        ret_batch = torch.randn(B) * 3
+        ent_coef = 0.0077
+        dist = Categorical(logits=logits)
+        new_lp = dist.log_prob(a_batch)
+        new_ent = dist.entropy()
+        entropy_ratio = new_ent / (old_ent + 1e-8)
+        erc_mask = ((entropy_ratio > (1 - cfg.erc_beta_low)) & (entropy_ratio < (1 + cfg.erc_beta_high))).float()
+        ratio = (new_lp - old_lp).exp()
+        covs = (new_lp - new_lp.mean()) * (adv_batch - adv_batch.mean())
+        corr = torch.ones_like(adv_batch) * erc_mask
+        clip_ratio = ratio.clamp(0.0, cfg.dual_clip)
+        surr1 = clip_ratio * adv_batch
+        surr2 = torch.clamp(ratio, 1 - cfg.clip_eps_min, 1 + cfg.clip_eps_max) * adv_batch
+        clip_frac = torch.mean(((ratio < (1 - cfg.clip_eps_min)) | (ratio > (1 + cfg.clip_eps_max))).float() * corr)
+        policy_loss = torch.mean(-torch.min(surr1, surr2) * corr)
+        value_loss = torch.mean(0.5 * corr * (values.squeeze() - ret_batch).pow(2))
+        entropy = (dist.entropy() * corr).mean()
+        entropy_loss = torch.mean(-ent_coef * entropy)
+        loss = policy_loss + value_loss + entropy_loss
+        loss.backward()
+        pre = f"c{case}_"
+        out.update({
+            pre + "logits": logits.detach().numpy(), pre + "values": values.detach().squeeze(-1).numpy(),
+            pre + "actions": a_batch.numpy().astype(np.int32), pre + "old_lp": old_lp.numpy(),
+            pre + "old_ent": old_ent.numpy(), pre + "adv": adv_batch.numpy(), pre + "ret": ret_batch.numpy(),
+            pre + "dlogits": logits.grad.numpy(), pre + "dvalues": values.grad.squeeze(-1).numpy(),
+            pre + "metrics": np.array([policy_loss.item(), value_loss.item(), entropy.item(), clip_frac.item(),
+                                       (old_lp - new_lp).mean().item(), 1.0 - erc_mask.mean().item(),
+                                       covs.mean().item()], np.float64),
+        })
+    out["n_cases"] = np.int64(2)
+    out["cfg"] = np.array([cfg.clip_eps_min, cfg.clip_eps_max, cfg.dual_clip, cfg.erc_beta_low,
+                           cfg.erc_beta_high, 0.0077], np.float64)
+    save("ppo_full_loss", **out)
+
+
+def gen_soft_update():
+    """SACTrainer.soft_update arithmetic (sac_pendulum.py:194-199) on flat tensors."""
+    seed_all(40)
+    tgt, src = torch.randn(777), torch.randn(777)
+    tau = 0.005
+    new = tau * src + (1.0 - tau) * tgt
+    save("soft_update", target=tgt.numpy(), source=src.numpy(), tau=np.float64(tau), out=new.numpy())
+
+
+GENERATORS = [gen_gae, gen_gae_g2, gen_gae_g3, gen_categorical, gen_ppo_loss, gen_adam_multi,
+              gen_ppo_full_loss, gen_soft_update]
+
+if __name__ == "__main__":
+    names = sys.argv[1:]
+    for g in GENERATORS:
+        if not names or g.__name__ in names:
+            g()

@@ -1,0 +1,63 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports
+every symbol include/gymrl.h declares; no compute is launched (no GPU here)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "gymrl.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(gymrl_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gymrl_amd import _lib
+    L = _lib.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/gymrl.h but not exported"
+    assert sorted(_lib.SYMBOLS) == declared, "gymrl_amd/_lib.py SYMBOLS out of sync with include/gymrl.h"
+    assert L.gymrl_abi_version() == 1
+
+
+def test_size_queries_need_no_gpu():
+    from gymrl_amd import _lib
+    L = _lib.lib()
+    assert L.gymrl_env_obs_dim(0) == 4 and L.gymrl_env_obs_dim(1) == 3 and L.gymrl_env_obs_dim(2) == 8
+    assert L.gymrl_env_act_dim(0) == 2 and L.gymrl_env_act_dim(2) == 4
+    assert L.gymrl_env_max_steps(0) == 500 and L.gymrl_env_max_steps(1) == 200 and L.gymrl_env_max_steps(2) == 1000
+    assert L.gymrl_env_state_bytes(0, 4096) > 0
+    assert L.gymrl_gae_workspace_bytes(2048, 4096) > 0
+    assert L.gymrl_env_obs_dim(99) == -22          # EINVAL, like the header says
+
+
+def test_bad_arguments_return_einval_without_gpu():
+    from gymrl_amd import _lib
+    L = _lib.lib()
+    null = ctypes.c_void_p(None)
+    assert L.gymrl_gae(null, null, null, null, 4, 4, ctypes.c_double(0.99), ctypes.c_double(0.95), null, null,
+                       null, 0, null, null) == -22
+    assert L.gymrl_soft_update(null, null, ctypes.c_int64(8), ctypes.c_double(0.005), null) == -22
+
+
+def test_ops_refuse_cpu_tensors():
+    import pytest
+    import torch
+    from gymrl_amd import ops
+    x = torch.zeros(4, 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gae(x, x, x.to(torch.uint8), x[0], 0.99, 0.95, variant=0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "gymrl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                for needle in ("import oracle", "from oracle", "libgymrl_oracle", "oracle/", "orc_"):
+                    assert needle not in src, f"{f} uses the oracle ({needle})"

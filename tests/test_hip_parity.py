@@ -1,0 +1,270 @@
+"""GPU parity tests proper: HIP kernels (through the C-ABI) vs the CPU oracle on
+the same seeded inputs, and vs the golden fixtures captured from the reference."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_close
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    from gymrl_amd import ops
+    assert ops.device_ok(), "libgymrl_hip.so did not find a gfx950 device"
+    return torch.device("cuda:0")
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _gae_inputs(T, N, seed, p_done=1 / 300):
+    rng = np.random.default_rng(seed)
+    rew = (rng.normal(size=(T, N)) * np.where(rng.random((T, N)) < 0.01, 100.0, 1.0)).astype(np.float32)
+    val = rng.normal(size=(T, N)).astype(np.float32)
+    done = (rng.random((T, N)) < p_done).astype(np.uint8)
+    nv = rng.normal(size=N).astype(np.float32)
+    return rew, val, done, nv
+
+
+@pytest.mark.parametrize("T,N", [(1, 64), (7, 4), (64, 256), (33, 100), (300, 1028), (128, 4096)])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_gae_vs_oracle(dev, oracle, T, N, variant):
+    from gymrl_amd import ops
+    rew, val, done, nv = _gae_inputs(T, N, seed=T * 1000 + N, p_done=0.03)
+    a_ref, r_ref, m_ref = oracle.gae(rew, val, done, nv, 0.99, 0.95, want_moments=True)
+    mom = torch.zeros(3, dtype=torch.float64, device=dev)
+    adv, ret = ops.gae(t(rew, dev), t(val, dev), t(done, dev), t(nv, dev), 0.99, 0.95, moments_out=mom,
+                       variant=variant)
+    adv, ret, mom = adv.cpu().numpy(), ret.cpu().numpy(), mom.cpu().numpy()
+    if variant == 0 or N % 4 != 0:
+        assert np.array_equal(adv, a_ref) and np.array_equal(ret, r_ref)   # same f64 op order: bit-exact
+    assert rel_close(adv, a_ref) <= TOL and rel_close(ret, r_ref) <= TOL
+    assert mom[0] == T * N and rel_close(mom[1:], m_ref[1:], 1e-9) <= 1e-9
+
+
+def test_gae_golden(dev):
+    from gymrl_amd import ops
+    g = load_golden("gae_g1")
+    for k in range(int(g["n_cases"])):
+        rew, val, done = g[f"c{k}_rew"][:, None], g[f"c{k}_val"][:, None], g[f"c{k}_done"][:, None]
+        nv = np.array([g[f"c{k}_next"]], np.float32)
+        for variant in (0, 1):
+            adv, ret = ops.gae(t(rew, dev), t(val, dev), t(done, dev), t(nv, dev), float(g["gamma"]),
+                               float(g["lam"]), variant=variant)
+            assert rel_close(adv.cpu().numpy()[:, 0], g[f"c{k}_adv"]) <= TOL
+            assert rel_close(ret.cpu().numpy()[:, 0], g[f"c{k}_ret"]) <= TOL
+
+
+def test_gae_full_size_properties(dev):
+    """BASELINE config 2 size (T=2048, N=4096): blocked == sequential kernel, and the
+    linearity property GAE(r1+r2, v1+v2) == GAE(r1,v1) + GAE(r2,v2) for shared dones."""
+    from gymrl_amd import ops
+    T, N = 2048, 4096
+    gen = torch.Generator(device=dev).manual_seed(1)
+    r1 = torch.randn(T, N, device=dev, generator=gen)
+    v1 = torch.randn(T, N, device=dev, generator=gen)
+    r2 = torch.randn(T, N, device=dev, generator=gen)
+    v2 = torch.randn(T, N, device=dev, generator=gen)
+    done = (torch.rand(T, N, device=dev, generator=gen) < 1 / 300).to(torch.uint8)
+    n1 = torch.randn(N, device=dev, generator=gen)
+    n2 = torch.randn(N, device=dev, generator=gen)
+    a0, q0 = ops.gae(r1, v1, done, n1, 0.99, 0.95, variant=0)
+    a1, q1 = ops.gae(r1, v1, done, n1, 0.99, 0.95, variant=1)
+    assert (a0 - a1).abs().max().item() <= 1e-5 * max(1.0, a0.abs().max().item())
+    assert (q0 - q1).abs().max().item() <= 1e-5 * max(1.0, q0.abs().max().item())
+    a2, _ = ops.gae(r2, v2, done, n2, 0.99, 0.95, variant=1)
+    a12, _ = ops.gae(r1 + r2, v1 + v2, done, n1 + n2, 0.99, 0.95, variant=1)
+    assert (a12 - (a1 + a2)).abs().max().item() <= 2e-5 * max(1.0, a12.abs().max().item())
+
+
+def test_gae_g2_g3(dev, oracle):
+    from gymrl_amd import ops
+    rng = np.random.default_rng(5)
+    T, N = 200, 130
+    rew, val, nval = (rng.normal(size=(T, N)).astype(np.float32) for _ in range(3))
+    done = (rng.random((T, N)) < 0.05).astype(np.uint8)
+    dw = (done & (rng.random((T, N)) < 0.5)).astype(np.uint8)
+    a_ref, v_ref, m_ref = oracle.gae_dw(rew, val, nval, done, dw, 0.99, 0.95)
+    mom = torch.zeros(3, dtype=torch.float64, device=dev)
+    adv, vt = ops.gae_dw(t(rew, dev), t(val, dev), t(nval, dev), t(done, dev), t(dw, dev), 0.99, 0.95, moments_out=mom)
+    assert np.array_equal(adv.cpu().numpy(), a_ref) and np.array_equal(vt.cpu().numpy(), v_ref)
+    assert rel_close(mom.cpu().numpy(), m_ref, 1e-9) <= 1e-9
+    nv = rng.normal(size=N).astype(np.float32)
+    a_ref, r_ref = oracle.gae_decoupled(rew, val, done, nv, 0.995, 0.9, 0.97)
+    adv, ret = ops.gae_decoupled(t(rew, dev), t(val, dev), t(done, dev), t(nv, dev), 0.995, 0.9, 0.97)
+    assert np.array_equal(adv.cpu().numpy(), a_ref) and np.array_equal(ret.cpu().numpy(), r_ref)
+    g = load_golden("gae_g3")
+    for k in range(int(g["n_cases"])):
+        adv, ret = ops.gae_decoupled(t(g[f"c{k}_rew"][:, None], dev), t(g[f"c{k}_val"][:, None], dev),
+                                     t(g[f"c{k}_done"][:, None], dev), t(np.array([g[f"c{k}_next"]], np.float32), dev),
+                                     float(g["gamma"]), float(g["lam_actor"]), float(g["lam_critic"]))
+        assert rel_close(adv.cpu().numpy()[:, 0], g[f"c{k}_adv"]) <= TOL
+        assert rel_close(ret.cpu().numpy()[:, 0], g[f"c{k}_ret"]) <= TOL
+
+
+def test_moments_normalize(dev, oracle):
+    from gymrl_amd import ops
+    rng = np.random.default_rng(6)
+    for n in (1, 3, 1000, 100003):
+        x = (rng.normal(size=n) * 3 + 0.5).astype(np.float32)
+        m_ref = oracle.moments(x)
+        xd = t(x, dev)
+        mom = ops.moments(xd)
+        assert rel_close(mom.cpu().numpy(), m_ref, 1e-12) <= 1e-12
+        if n > 2:
+            for ddof in (0, 1):
+                y = ops.normalize_(xd.clone(), mom, ddof=ddof).cpu().numpy()
+                assert rel_close(y, oracle.normalize(x, m_ref, ddof=ddof)) <= 1e-6
+
+
+@pytest.mark.parametrize("A", [2, 3, 4, 6, 8])
+def test_categorical_vs_oracle(dev, oracle, A):
+    from gymrl_amd import ops
+    rng = np.random.default_rng(7 + A)
+    n = 5000
+    logits = (rng.normal(size=(n, A)) * rng.choice([0.1, 1.0, 8.0], size=(n, 1))).astype(np.float32)
+    value = rng.normal(size=n).astype(np.float32)
+    q = rng.exponential(size=(n, A)).astype(np.float32)
+    # explicit noise, in-kernel Philox noise, deterministic
+    for kw in (dict(noise_exp=q), dict(seed=99, counter=12345678901, env_id0=4096), dict(deterministic=True)):
+        a_ref, lp_ref, e_ref, v_ref = oracle.categorical_sample(logits, value=value, **kw)
+        kw_t = {k: (t(v, dev) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+        a, lp, e, v = ops.categorical_sample(t(logits, dev), value=t(value, dev), **kw_t)
+        assert np.array_equal(a.cpu().numpy(), a_ref)            # integer action draws: bit-exact
+        assert np.array_equal(lp.cpu().numpy(), lp_ref) and np.array_equal(e.cpu().numpy(), e_ref)
+        assert np.array_equal(v.cpu().numpy(), v_ref)
+
+
+def test_categorical_golden_and_distribution(dev):
+    from gymrl_amd import ops
+    g = load_golden("categorical")
+    a, lp, e, _ = ops.categorical_sample(t(g["logits"], dev), noise_exp=t(g["noise_exp"], dev))
+    assert np.array_equal(a.cpu().numpy(), g["action"])
+    assert rel_close(lp.cpu().numpy(), g["logp"]) <= TOL and rel_close(e.cpu().numpy(), g["entropy"]) <= TOL
+    # in-kernel Philox draws follow softmax(logits): chi-square-ish check on 1M draws
+    z = torch.tensor([[0.0, 1.0, -1.0, 0.5]], device=dev).repeat(1 << 20, 1).contiguous()
+    a, _, _, _ = ops.categorical_sample(z, seed=3, counter=7)
+    freq = torch.bincount(a.long(), minlength=4).double() / a.numel()
+    p = torch.softmax(z[0].double(), 0)
+    assert (freq - p).abs().max().item() < 2e-3
+
+
+def test_ppo_loss_vs_oracle_and_golden(dev, oracle):
+    from gymrl_amd import ops
+    rng = np.random.default_rng(8)
+    cfg = (0.2, 3.0, 0.5, 0.01)
+    for B, A, S in ((64, 4, 64), (1000, 4, 5000), (16384, 4, 16384), (777, 2, 900), (300, 6, 300)):
+        logits = rng.normal(size=(B, A)).astype(np.float32)
+        value = rng.normal(size=B).astype(np.float32)
+        act = rng.integers(0, A, size=S).astype(np.int32)
+        lp_old = (np.log(1.0 / A) + 0.3 * rng.normal(size=S)).astype(np.float32)
+        adv = rng.normal(size=S).astype(np.float32) * 2
+        ret = rng.normal(size=S).astype(np.float32) * 3
+        idx = rng.permutation(S)[:B].astype(np.int32) if S != B else None
+        mom = oracle.moments(adv) if S != B else None
+        dl_ref, dv_ref, met_ref = oracle.ppo_loss_fwd_bwd(logits, value, act, lp_old, adv, ret, cfg, idx=idx,
+                                                          adv_moments=mom)
+        met = torch.zeros(5, dtype=torch.float64, device=dev)
+        dl, dv = ops.ppo_loss_fwd_bwd(t(logits, dev), t(value, dev), t(act, dev), t(lp_old, dev), t(adv, dev),
+                                      t(ret, dev), cfg, idx=None if idx is None else t(idx, dev),
+                                      adv_moments=None if mom is None else t(mom, dev), metrics_sum=met)
+        assert np.array_equal(dl.cpu().numpy(), dl_ref) and np.array_equal(dv.cpu().numpy(), dv_ref)
+        assert rel_close(met.cpu().numpy(), met_ref, 1e-9) <= 1e-9
+    g = load_golden("ppo_loss")
+    gcfg = tuple(float(x) for x in g["cfg"])
+    for k in range(int(g["n_cases"])):
+        B = g[f"c{k}_logits"].shape[0]
+        met = torch.zeros(5, dtype=torch.float64, device=dev)
+        dl, dv = ops.ppo_loss_fwd_bwd(t(g[f"c{k}_logits"], dev), t(g[f"c{k}_values"], dev), t(g[f"c{k}_actions"], dev),
+                                      t(g[f"c{k}_old_lp"], dev), t(g[f"c{k}_adv"], dev), t(g[f"c{k}_ret"], dev),
+                                      gcfg, metrics_sum=met)
+        assert np.max(np.abs(dl.cpu().numpy() - g[f"c{k}_dlogits"])) <= TOL * np.abs(g[f"c{k}_dlogits"]).max()
+        assert np.max(np.abs(dv.cpu().numpy() - g[f"c{k}_dvalues"])) <= TOL * np.abs(g[f"c{k}_dvalues"]).max()
+        assert rel_close(met.cpu().numpy() / B, g[f"c{k}_metrics"]) <= TOL
+
+
+def test_ppo_full_loss_vs_oracle_and_golden(dev, oracle):
+    from gymrl_amd import ops
+    g = load_golden("ppo_full_loss")
+    cfg = tuple(float(x) for x in g["cfg"])
+    for k in range(int(g["n_cases"])):
+        args = [g[f"c{k}_{n}"] for n in ("logits", "values", "actions", "old_lp", "old_ent", "adv", "ret")]
+        B = args[0].shape[0]
+        dl_ref, dv_ref, met_ref = oracle.ppo_full_loss_fwd_bwd(*args, cfg)
+        met = torch.zeros(9, dtype=torch.float64, device=dev)
+        dl, dv = ops.ppo_full_loss_fwd_bwd(*[t(a, dev) for a in args], cfg, metrics_sum=met)
+        assert np.array_equal(dl.cpu().numpy(), dl_ref) and np.array_equal(dv.cpu().numpy(), dv_ref)
+        assert rel_close(met.cpu().numpy(), met_ref, 1e-9) <= 1e-9
+        assert np.max(np.abs(dl.cpu().numpy() - g[f"c{k}_dlogits"])) <= TOL * np.abs(g[f"c{k}_dlogits"]).max()
+
+
+def test_adam_and_soft_update(dev, oracle):
+    from gymrl_amd import ops
+    a = load_golden("adam")
+    ws = ops.reduce_workspace(dev)
+    sq = torch.zeros(1, dtype=torch.float64, device=dev)
+    for k in range(int(a["n_cases"])):
+        lr, b1, b2, eps, max_norm, clamp = (float(x) for x in a[f"c{k}_hp"])
+        p = t(a[f"c{k}_p0"].copy(), dev)
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        po, mo, vo = a[f"c{k}_p0"].copy(), np.zeros_like(a[f"c{k}_p0"]), np.zeros_like(a[f"c{k}_p0"])
+        for step, gr in enumerate(a[f"c{k}_grads"], 1):
+            g = t(gr.copy(), dev)
+            if max_norm > 0:
+                ops.sqnorm(g, sq, ws)
+            ops.adam_step(p, g, m, v, lr, b1, b2, eps, step, max_grad_norm=max_norm, sqnorm_buf=sq, clamp_abs=clamp)
+            assert g.abs().max().item() == 0.0          # fused zero_grad
+            po, _, mo, vo = oracle.adam_step(po, gr, mo, vo, lr, b1, b2, eps, step, max_grad_norm=max_norm, clamp_abs=clamp)
+        assert np.max(np.abs(p.cpu().numpy() - po)) <= 1e-6                    # vs oracle (norm reduce order differs)
+        assert np.max(np.abs(p.cpu().numpy() - a[f"c{k}_p5"])) <= 2e-6         # vs torch.optim.Adam golden
+        assert rel_close(m.cpu().numpy(), a[f"c{k}_m5"]) <= TOL and rel_close(v.cpu().numpy(), a[f"c{k}_v5"]) <= TOL
+    g = load_golden("soft_update")
+    tgt = t(g["target"].copy(), dev)
+    ops.soft_update(tgt, t(g["source"], dev), float(g["tau"]))
+    assert np.array_equal(tgt.cpu().numpy(), oracle.soft_update(g["target"], g["source"], float(g["tau"])))
+    assert np.max(np.abs(tgt.cpu().numpy() - g["out"])) <= 1e-7
+
+
+@pytest.mark.parametrize("kind,steps", [(0, 700), (1, 450)])
+def test_classic_env_vs_oracle(dev, oracle, kind, steps):
+    """CartPole / Pendulum trajectories with auto-reset: same Philox stream, float64
+    state; observations may differ in the last ulp where libm and ocml sin/cos differ."""
+    from gymrl_amd import ops
+    n, seed, id0 = 200, 11, 1000
+    D, A, discrete, _ = ops.env_dims(kind)
+    env = oracle.Env(kind, n, seed=seed, env_id0=id0)
+    o_ref = env.reset()
+    state = ops.env_state(kind, n, dev)
+    obs = torch.empty(n, D, device=dev)
+    tobs = torch.empty(n, D, device=dev)
+    rew = torch.empty(n, device=dev)
+    term, trunc, done = (torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(3))
+    ep_ret = torch.zeros(n, device=dev)
+    ep_len = torch.zeros(n, dtype=torch.int32, device=dev)
+    stats = torch.zeros(3, dtype=torch.float64, device=dev)
+    ops.env_reset(kind, state, n, seed, id0, obs)
+    assert np.allclose(obs.cpu().numpy(), o_ref, atol=1e-6)
+    rng = np.random.default_rng(12)
+    tot = np.zeros(3)
+    for s in range(steps):
+        act = rng.integers(0, A, size=n).astype(np.int32) if discrete else (rng.normal(size=(n, 1)) * 1.5).astype(np.float32)
+        r = env.step(act)
+        ops.env_step(kind, state, n, seed, id0, t(act, dev), obs, rew, term, trunc, term_obs_out=tobs, done_out=done,
+                     ep_ret_out=ep_ret, ep_len_out=ep_len, ep_stats=stats)
+        assert np.array_equal(term.cpu().numpy(), r["terminated"]) and np.array_equal(trunc.cpu().numpy(), r["truncated"]), s
+        assert np.array_equal(done.cpu().numpy(), r["done"])
+        assert np.allclose(obs.cpu().numpy(), r["obs"], atol=2e-6), s
+        assert np.allclose(tobs.cpu().numpy(), r["term_obs"], atol=2e-6), s
+        assert np.allclose(rew.cpu().numpy(), r["rew"], rtol=1e-6, atol=1e-6), s
+        d = r["done"].astype(bool)
+        if d.any():
+            assert np.allclose(ep_ret.cpu().numpy()[d], r["ep_ret"][d], rtol=1e-6)
+            assert np.array_equal(ep_len.cpu().numpy()[d], r["ep_len"][d])
+        tot += r["ep_stats"]
+    assert tot[0] > 0 and np.allclose(stats.cpu().numpy(), tot, rtol=1e-9)
