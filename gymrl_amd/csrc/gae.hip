@@ -27,6 +27,7 @@ namespace {
 constexpr int kSeqBlock = 64;   // lane-per-env kernels: one wave per workgroup
 constexpr int kSeqBatch = 16;   // rows prefetched per batch in the sequential walk
 constexpr int kBlkTC    = 16;   // time-chunk length of the blocked variant
+constexpr int kBlkV     = 2;    // adjacent envs per lane (8-B row loads, 512 B per wave-row)
 constexpr int kBlkBlock = 256;
 constexpr int kRedBlock = 256;
 
@@ -78,94 +79,137 @@ __global__ __launch_bounds__(kSeqBlock) void gae_seq_kernel(
 }
 
 // ------------------------------------------------------------- G1 blocked ---
-// Thread = 4 adjacent envs (float4 / uchar4 rows: 1 KiB per wave-row) x one
-// chunk of TC time steps.  grid.x covers N/4 env-quads, grid.y covers chunks.
-struct Chunk4 {
-  float4 r[kBlkTC];
-  float4 v[kBlkTC];
-  uchar4 d[kBlkTC];
-  float4 vend;  // V at (chunk end + 1), or next_val
+// Thread = V adjacent envs (one 4V-byte vector load per row) x one chunk of TC
+// time steps.  grid.x covers N/V env groups, grid.y covers chunks.
+template <int V> struct VecF;
+template <> struct VecF<2> { using f = float2; using u = uchar2; };
+template <> struct VecF<4> { using f = float4; using u = uchar4; };
+
+template <int TC, int V>
+struct Chunk {
+  float r[TC][V];
+  float v[TC][V];
+  uint8_t d[TC][V];
+  float vend[V];  // V at (chunk end + 1), or next_val
 };
 
-__device__ __forceinline__ void load_chunk(Chunk4& c, const float* __restrict__ rew,
+template <int V>
+__device__ __forceinline__ void ldv(const float* __restrict__ p, float (&out)[V]) {
+  const typename VecF<V>::f t = *reinterpret_cast<const typename VecF<V>::f*>(p);
+  out[0] = t.x; out[1] = t.y;
+  if constexpr (V == 4) { out[2] = t.z; out[3] = t.w; }
+}
+template <int V>
+__device__ __forceinline__ void ldv(const uint8_t* __restrict__ p, uint8_t (&out)[V]) {
+  const typename VecF<V>::u t = *reinterpret_cast<const typename VecF<V>::u*>(p);
+  out[0] = t.x; out[1] = t.y;
+  if constexpr (V == 4) { out[2] = t.z; out[3] = t.w; }
+}
+
+template <int TC, int V>
+__device__ __forceinline__ void load_chunk(Chunk<TC, V>& c, const float* __restrict__ rew,
                                            const float* __restrict__ val,
                                            const uint8_t* __restrict__ done,
                                            const float* __restrict__ next_val, int T, int N,
                                            int q, int t0) {
-  const int tend = min(t0 + kBlkTC, T);
+  const int tend = min(t0 + TC, T);
 #pragma unroll
-  for (int j = 0; j < kBlkTC; ++j) {
+  for (int j = 0; j < TC; ++j) {
     const int t = t0 + j;
     if (t < tend) {
-      const size_t o = (size_t)t * N + 4 * (size_t)q;
-      c.r[j] = *reinterpret_cast<const float4*>(rew + o);
-      c.v[j] = *reinterpret_cast<const float4*>(val + o);
-      c.d[j] = *reinterpret_cast<const uchar4*>(done + o);
+      const size_t o = (size_t)t * N + V * (size_t)q;
+      ldv<V>(rew + o, c.r[j]);
+      ldv<V>(val + o, c.v[j]);
+      ldv<V>(done + o, c.d[j]);
     }
   }
-  c.vend = (tend == T) ? *reinterpret_cast<const float4*>(next_val + 4 * (size_t)q)
-                       : *reinterpret_cast<const float4*>(val + (size_t)tend * N + 4 * (size_t)q);
+  if (tend == T) ldv<V>(next_val + V * (size_t)q, c.vend);
+  else ldv<V>(val + (size_t)tend * N + V * (size_t)q, c.vend);
 }
 
-#define F4(v, k) ((k) == 0 ? (v).x : (k) == 1 ? (v).y : (k) == 2 ? (v).z : (v).w)
-
 // pass 1: (A, b) of every chunk.  agg layout: [chunk][N] double2.
+template <int TC, int V>
 __global__ __launch_bounds__(kBlkBlock) void gae_blk_aggregate_kernel(
     const float* __restrict__ rew, const float* __restrict__ val,
     const uint8_t* __restrict__ done, const float* __restrict__ next_val, int T, int N,
     double gamma, double gl, double2* __restrict__ agg) {
   const int q = blockIdx.x * kBlkBlock + threadIdx.x;
   const int c = blockIdx.y;
-  if (4 * q >= N) return;
-  const int t0 = c * kBlkTC;
-  Chunk4 ch;
-  load_chunk(ch, rew, val, done, next_val, T, N, q, t0);
-  const int len = min(kBlkTC, T - t0);
+  if (V * q >= N) return;
+  const int t0 = c * TC;
+  Chunk<TC, V> ch;
+  load_chunk<TC, V>(ch, rew, val, done, next_val, T, N, q, t0);
+  const int len = min(TC, T - t0);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < V; ++k) {
     double A = 1.0, b = 0.0;
-    double vnext = (double)F4(ch.vend, k);
+    double vnext = (double)ch.vend[k];
 #pragma unroll
-    for (int j = kBlkTC - 1; j >= 0; --j) {
+    for (int j = TC - 1; j >= 0; --j) {
       if (j < len) {
-        const double nd = 1.0 - (double)(F4(ch.d[j], k) != 0);
-        const double vv = (double)F4(ch.v[j], k);
-        const double delta = ((double)F4(ch.r[j], k) + (gamma * vnext) * nd) - vv;
+        const double nd = 1.0 - (double)(ch.d[j][k] != 0);
+        const double vv = (double)ch.v[j][k];
+        const double delta = ((double)ch.r[j][k] + (gamma * vnext) * nd) - vv;
         const double a = gl * nd;
         b = delta + a * b;
         A = a * A;
         vnext = vv;
       }
     }
-    agg[(size_t)c * N + 4 * (size_t)q + k] = make_double2(A, b);
+    agg[(size_t)c * N + V * (size_t)q + k] = make_double2(A, b);
   }
 }
 
 // pass 2: carry[c][n] = advantage entering chunk c from the future (t = chunk end).
-__global__ __launch_bounds__(kSeqBlock) void gae_blk_carry_kernel(
+// Latency-bound if walked serially (C dependent HBM round trips), so a workgroup
+// takes 64 envs (lanes) x kCarrySeg chunk-segments (waves): every thread loads its
+// segment's <= kCarryL aggregates at once, composes them, the segment maps are
+// exchanged through LDS, and each thread replays its own segment from its carry-in.
+constexpr int kCarrySeg = 16;
+constexpr int kCarryL   = 8;    // chunks per segment per round (registers: 8 double2)
+
+__global__ __launch_bounds__(kSeqBlock * kCarrySeg) void gae_blk_carry_kernel(
     const double2* __restrict__ agg, int C, int N, double* __restrict__ carry) {
-  const int n = blockIdx.x * kSeqBlock + threadIdx.x;
-  if (n >= N) return;
-  double x = 0.0;
-  for (int c1 = C; c1 > 0; c1 -= 8) {
-    double2 ab[8];
+  __shared__ double2 seg_map[kCarrySeg][kSeqBlock];
+  const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int n = blockIdx.x * kSeqBlock + lane;
+  const bool valid = n < N;
+  // rounds of kCarrySeg*kCarryL chunks, walked from the last chunk down; `top` = value
+  // entering the highest chunk of the round.
+  double top = 0.0;
+  for (int c_hi = C; c_hi > 0; c_hi -= kCarrySeg * kCarryL) {
+    // this thread's chunks: c_hi-1 - seg'*kCarryL - j with seg' = kCarrySeg-1-seg so that
+    // seg kCarrySeg-1 holds the highest chunks (matches the compose order below).
+    const int c_top = c_hi - 1 - (kCarrySeg - 1 - seg) * kCarryL;
+    double2 ab[kCarryL];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = c1 - 1 - j;
-      if (c >= 0) ab[j] = agg[(size_t)c * N + n];
+    for (int j = 0; j < kCarryL; ++j) {
+      const int c = c_top - j;
+      ab[j] = (valid && c >= 0) ? agg[(size_t)c * N + n] : make_double2(1.0, 0.0);
     }
+    double A = 1.0, b = 0.0;   // segment map x -> b + A*x, composed from the top chunk down
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = c1 - 1 - j;
-      if (c >= 0) {
-        carry[(size_t)c * N + n] = x;
-        x = ab[j].y + ab[j].x * x;
-      }
+    for (int j = 0; j < kCarryL; ++j) { b = ab[j].y + ab[j].x * b; A = ab[j].x * A; }
+    seg_map[seg][lane] = make_double2(A, b);
+    __syncthreads();
+    double x = top;
+    for (int s2 = kCarrySeg - 1; s2 > seg; --s2) { const double2 m = seg_map[s2][lane]; x = m.y + m.x * x; }
+    // value leaving the whole round (needed by the next, lower round)
+    double nxt = top;
+    for (int s2 = kCarrySeg - 1; s2 >= 0; --s2) { const double2 m = seg_map[s2][lane]; nxt = m.y + m.x * nxt; }
+#pragma unroll
+    for (int j = 0; j < kCarryL; ++j) {
+      const int c = c_top - j;
+      if (valid && c >= 0) carry[(size_t)c * N + n] = x;
+      x = ab[j].y + ab[j].x * x;
     }
+    top = nxt;
+    __syncthreads();
   }
 }
 
 // pass 3: replay each chunk from its carry-in; write adv/ret; moment partials.
+template <int TC, int V>
 __global__ __launch_bounds__(kBlkBlock) void gae_blk_apply_kernel(
     const float* __restrict__ rew, const float* __restrict__ val,
     const uint8_t* __restrict__ done, const float* __restrict__ next_val, int T, int N,
@@ -174,35 +218,40 @@ __global__ __launch_bounds__(kBlkBlock) void gae_blk_apply_kernel(
   const int q = blockIdx.x * kBlkBlock + threadIdx.x;
   const int c = blockIdx.y;
   double s1 = 0.0, s2 = 0.0;
-  if (4 * q < N) {
-    const int t0 = c * kBlkTC;
-    Chunk4 ch;
-    load_chunk(ch, rew, val, done, next_val, T, N, q, t0);
-    const int len = min(kBlkTC, T - t0);
-    double x[4], vnext[4];
+  if (V * q < N) {
+    const int t0 = c * TC;
+    Chunk<TC, V> ch;
+    load_chunk<TC, V>(ch, rew, val, done, next_val, T, N, q, t0);
+    const int len = min(TC, T - t0);
+    double x[V], vnext[V];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      x[k] = carry[(size_t)c * N + 4 * (size_t)q + k];
-      vnext[k] = (double)F4(ch.vend, k);
+    for (int k = 0; k < V; ++k) {
+      x[k] = carry[(size_t)c * N + V * (size_t)q + k];
+      vnext[k] = (double)ch.vend[k];
     }
 #pragma unroll
-    for (int j = kBlkTC - 1; j >= 0; --j) {
+    for (int j = TC - 1; j >= 0; --j) {
       if (j < len) {
-        float a4[4], r4[4];
+        float a4[V], r4[V];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const double nd = 1.0 - (double)(F4(ch.d[j], k) != 0);
-          const double vv = (double)F4(ch.v[j], k);
-          const double delta = ((double)F4(ch.r[j], k) + (gamma * vnext[k]) * nd) - vv;
+        for (int k = 0; k < V; ++k) {
+          const double nd = 1.0 - (double)(ch.d[j][k] != 0);
+          const double vv = (double)ch.v[j][k];
+          const double delta = ((double)ch.r[j][k] + (gamma * vnext[k]) * nd) - vv;
           x[k] = delta + (gl * nd) * x[k];
           a4[k] = (float)x[k];
           r4[k] = (float)(x[k] + vv);
           s1 += x[k]; s2 += x[k] * x[k];
           vnext[k] = vv;
         }
-        const size_t o = (size_t)(t0 + j) * N + 4 * (size_t)q;
-        *reinterpret_cast<float4*>(adv_out + o) = make_float4(a4[0], a4[1], a4[2], a4[3]);
-        *reinterpret_cast<float4*>(ret_out + o) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+        const size_t o = (size_t)(t0 + j) * N + V * (size_t)q;
+        if constexpr (V == 4) {
+          *reinterpret_cast<float4*>(adv_out + o) = make_float4(a4[0], a4[1], a4[2], a4[3]);
+          *reinterpret_cast<float4*>(ret_out + o) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+        } else {
+          *reinterpret_cast<float2*>(adv_out + o) = make_float2(a4[0], a4[1]);
+          *reinterpret_cast<float2*>(ret_out + o) = make_float2(r4[0], r4[1]);
+        }
       }
     }
   }
@@ -371,7 +420,7 @@ size_t gymrl_gae_workspace_bytes(int T, int N) {
   const size_t C = (size_t)cdiv(T, kBlkTC);
   const size_t agg = C * (size_t)N * sizeof(double2);
   const size_t carry = C * (size_t)N * sizeof(double);
-  const size_t parts = sizeof(double) * 2 * ((size_t)cdiv(cdiv(N, 4), kBlkBlock) * C + (size_t)cdiv(N, kSeqBlock) + 16);
+  const size_t parts = sizeof(double) * 2 * ((size_t)cdiv(cdiv(N, kBlkV), kBlkBlock) * C + (size_t)cdiv(N, kSeqBlock) + 16);
   return agg + carry + parts + 1024;
 }
 
@@ -395,12 +444,12 @@ int gymrl_gae(const float* rew, const float* val, const uint8_t* done, const flo
     double2* agg = (double2*)ws;
     double* carry = (double*)(ws + (size_t)C * N * sizeof(double2));
     double* parts = carry + (size_t)C * N;
-    dim3 grid(cdiv(N / 4, kBlkBlock), C);
-    hipLaunchKernelGGL(gae_blk_aggregate_kernel, grid, dim3(kBlkBlock), 0, stream, rew, val, done,
+    dim3 grid(cdiv(N / kBlkV, kBlkBlock), C);
+    hipLaunchKernelGGL((gae_blk_aggregate_kernel<kBlkTC, kBlkV>), grid, dim3(kBlkBlock), 0, stream, rew, val, done,
                        next_val, T, N, gamma, gl, agg);
-    hipLaunchKernelGGL(gae_blk_carry_kernel, dim3(cdiv(N, kSeqBlock)), dim3(kSeqBlock), 0, stream,
-                       agg, C, N, carry);
-    hipLaunchKernelGGL(gae_blk_apply_kernel, grid, dim3(kBlkBlock), 0, stream, rew, val, done,
+    hipLaunchKernelGGL(gae_blk_carry_kernel, dim3(cdiv(N, kSeqBlock)), dim3(kSeqBlock * kCarrySeg), 0,
+                       stream, agg, C, N, carry);
+    hipLaunchKernelGGL((gae_blk_apply_kernel<kBlkTC, kBlkV>), grid, dim3(kBlkBlock), 0, stream, rew, val, done,
                        next_val, T, N, gamma, gl, carry, adv_out, ret_out,
                        moments_out ? parts : nullptr);
     if (moments_out)

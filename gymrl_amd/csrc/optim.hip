@@ -149,7 +149,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 extern "C" {
 
-size_t gymrl_reduce_workspace_bytes(void) { return sizeof(double) * 2 * 4096; }
+size_t gymrl_reduce_workspace_bytes(void) { return sizeof(double) * 16384; }
 
 int gymrl_sqnorm(const float* g, int64_t n, float grad_scale, double* sqnorm_out, void* workspace,
                  void* stream_) {

@@ -66,6 +66,25 @@ __device__ __forceinline__ void log_softmax(const float (&z)[A], float (&ln)[A],
   }
 }
 
+// K per-thread doubles -> one row of K doubles per block in partials[block][K].
+template <int K, int BLOCK>
+__device__ __forceinline__ void block_partials(double (&v)[K], double* __restrict__ partials) {
+  __shared__ double sm[K][BLOCK / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double s = wave_sum(v[k]);
+    if (lane == 0) sm[k][wid] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) s += sm[threadIdx.x][w];
+    partials[(size_t)blockIdx.x * K + threadIdx.x] = s;
+  }
+}
+
 // ------------------------------------------------------------- P2 sample ----
 template <int A>
 __global__ __launch_bounds__(kBlock) void categorical_sample_kernel(
@@ -123,10 +142,20 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_kernel(
     const float* __restrict__ logp_old, const float* __restrict__ adv,
     const float* __restrict__ ret, const double* __restrict__ adv_moments, int B,
     gymrl_ppo_cfg cfg, float* __restrict__ dlogits_out, float* __restrict__ dvalue_out,
-    double* __restrict__ metrics_sum) {
-  const int b = blockIdx.x * kBlock + threadIdx.x;
+    double* __restrict__ partials) {
   double met[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  if (b < B) {
+  // whole-rollout advantage normalisation constants (ppo_lunarlander.py:236): one f64
+  // sqrt/divide per workgroup instead of per sample.
+  __shared__ double s_norm[2];
+  if (adv_moments && threadIdx.x == 0) {
+    const double cnt = adv_moments[0];
+    const double mean = adv_moments[1] / cnt;
+    double var = adv_moments[2] / cnt - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    s_norm[0] = mean; s_norm[1] = sqrt(var) + 1e-8;
+  }
+  __syncthreads();
+  for (int b = blockIdx.x * kBlock + threadIdx.x; b < B; b += gridDim.x * kBlock) {
     float z[A], ln[A], p[A], H;
     load_row<A>(logits, b, z);
     const float v = value[b];
@@ -135,13 +164,7 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_kernel(
     const float lpo = logp_old[i];
     float ad = adv[i];
     const float rt = ret[i];
-    if (adv_moments) {
-      const double cnt = adv_moments[0];
-      const double mean = adv_moments[1] / cnt;
-      double var = adv_moments[2] / cnt - mean * mean;
-      var = var > 0.0 ? var : 0.0;
-      ad = (float)(((double)ad - mean) / (sqrt(var) + 1e-8));
-    }
+    if (adv_moments) ad = (float)(((double)ad - s_norm[0]) / s_norm[1]);
     log_softmax<A>(z, ln, p, H);
     float lp = ln[0];
 #pragma unroll
@@ -177,13 +200,13 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_kernel(
     const float dvr = v - rt;
     dvalue_out[b] = cfg.value_coef * 2.0f * dvr * invB;
 
-    met[0] = -(double)obj;
-    met[1] = (double)(cfg.value_coef * (dvr * dvr));
-    met[2] = (double)H;
-    met[3] = (ratio < lo || ratio > hi) ? 1.0 : 0.0;
-    met[4] = (double)(lpo - lp);
+    met[0] += -(double)obj;
+    met[1] += (double)(cfg.value_coef * (dvr * dvr));
+    met[2] += (double)H;
+    met[3] += (ratio < lo || ratio > hi) ? 1.0 : 0.0;
+    met[4] += (double)(lpo - lp);
   }
-  if (metrics_sum) block_atomic_add<5, kBlock>(met, metrics_sum);
+  if (partials) block_partials<5, kBlock>(met, partials);
 }
 
 // ---------------------------------------------------------------- L3 loss ---
@@ -194,10 +217,9 @@ __global__ __launch_bounds__(kBlock) void ppo_full_loss_kernel(
     const float* __restrict__ logp_old, const float* __restrict__ ent_old,
     const float* __restrict__ adv, const float* __restrict__ ret, int B, gymrl_ppo_full_cfg cfg,
     float* __restrict__ dlogits_out, float* __restrict__ dvalue_out,
-    double* __restrict__ metrics_sum) {
-  const int b = blockIdx.x * kBlock + threadIdx.x;
+    double* __restrict__ partials) {
   double met[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (b < B) {
+  for (int b = blockIdx.x * kBlock + threadIdx.x; b < B; b += gridDim.x * kBlock) {
     float z[A], ln[A], p[A], H;
     load_row<A>(logits, b, z);
     const float v = value[b];
@@ -238,18 +260,49 @@ __global__ __launch_bounds__(kBlock) void ppo_full_loss_kernel(
     const float dvr = v - rt;
     dvalue_out[b] = corr * dvr * invB;
 
-    met[0] = (double)(-ms * corr);
-    met[1] = (double)(0.5f * corr * (dvr * dvr));
-    met[2] = (double)(H * corr);
-    met[3] = (ratio < lo || ratio > hi) ? (double)corr : 0.0;
-    met[4] = (double)(lpo - lp);
-    met[5] = 1.0 - (double)corr;
-    met[6] = (double)lp;
-    met[7] = (double)ad;
-    met[8] = (double)lp * (double)ad;
+    met[0] += (double)(-ms * corr);
+    met[1] += (double)(0.5f * corr * (dvr * dvr));
+    met[2] += (double)(H * corr);
+    met[3] += (ratio < lo || ratio > hi) ? (double)corr : 0.0;
+    met[4] += (double)(lpo - lp);
+    met[5] += 1.0 - (double)corr;
+    met[6] += (double)lp;
+    met[7] += (double)ad;
+    met[8] += (double)lp * (double)ad;
   }
-  if (metrics_sum) block_atomic_add<9, kBlock>(met, metrics_sum);
+  if (partials) block_partials<9, kBlock>(met, partials);
 }
+
+// metrics_sum[k] += sum over blocks of partials[block][k], fixed order (no atomics:
+// 32k same-address f64 atomics cost ~400 us at B = 8.4M, more than the kernel itself).
+template <int K>
+__global__ __launch_bounds__(kBlock) void metrics_finalize_kernel(const double* __restrict__ partials,
+                                                                  int nblocks,
+                                                                  double* __restrict__ metrics_sum) {
+  __shared__ double sm[K][kBlock / 64];
+  double v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += kBlock) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += partials[(size_t)i * K + k];
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double s = wave_sum(v[k]);
+    if (lane == 0) sm[k][wid] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) s += sm[threadIdx.x][w];
+    metrics_sum[threadIdx.x] += s;
+  }
+}
+
+constexpr int kMaxLossBlocks = 1024;
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -288,17 +341,22 @@ int gymrl_ppo_loss_fwd_bwd(const float* logits, const float* value, const int32_
                            const int32_t* act, const float* logp_old, const float* adv,
                            const float* ret, const double* adv_moments, int B, int n_actions,
                            const gymrl_ppo_cfg* cfg_host, float* dlogits_out, float* dvalue_out,
-                           double* metrics_sum, void* stream_) {
+                           double* metrics_sum, void* workspace, void* stream_) {
   if (!logits || !value || !act || !logp_old || !adv || !ret || !cfg_host || !dlogits_out ||
-      !dvalue_out || B < 0)
+      !dvalue_out || B < 0 || (metrics_sum && !workspace))
     return -22;
   if (B == 0) return 0;
   hipStream_t stream = (hipStream_t)stream_;
   const gymrl_ppo_cfg cfg = *cfg_host;
+  const int nb = cdiv(B, kBlock) < kMaxLossBlocks ? cdiv(B, kBlock) : kMaxLossBlocks;
+  double* parts = metrics_sum ? (double*)workspace : nullptr;
   DISPATCH_A(n_actions,
-             hipLaunchKernelGGL(ppo_loss_kernel<A>, dim3(cdiv(B, kBlock)), dim3(kBlock), 0, stream,
+             hipLaunchKernelGGL(ppo_loss_kernel<A>, dim3(nb), dim3(kBlock), 0, stream,
                                 logits, value, idx, act, logp_old, adv, ret, adv_moments, B, cfg,
-                                dlogits_out, dvalue_out, metrics_sum));
+                                dlogits_out, dvalue_out, parts));
+  if (metrics_sum)
+    hipLaunchKernelGGL(metrics_finalize_kernel<5>, dim3(1), dim3(kBlock), 0, stream, parts, nb,
+                       metrics_sum);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
@@ -307,17 +365,23 @@ int gymrl_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const i
                                 const int32_t* act, const float* logp_old, const float* ent_old,
                                 const float* adv, const float* ret, int B, int n_actions,
                                 const gymrl_ppo_full_cfg* cfg_host, float* dlogits_out,
-                                float* dvalue_out, double* metrics_sum, void* stream_) {
+                                float* dvalue_out, double* metrics_sum, void* workspace,
+                                void* stream_) {
   if (!logits || !value || !act || !logp_old || !ent_old || !adv || !ret || !cfg_host ||
-      !dlogits_out || !dvalue_out || B < 0)
+      !dlogits_out || !dvalue_out || B < 0 || (metrics_sum && !workspace))
     return -22;
   if (B == 0) return 0;
   hipStream_t stream = (hipStream_t)stream_;
   const gymrl_ppo_full_cfg cfg = *cfg_host;
+  const int nb = cdiv(B, kBlock) < kMaxLossBlocks ? cdiv(B, kBlock) : kMaxLossBlocks;
+  double* parts = metrics_sum ? (double*)workspace : nullptr;
   DISPATCH_A(n_actions,
-             hipLaunchKernelGGL(ppo_full_loss_kernel<A>, dim3(cdiv(B, kBlock)), dim3(kBlock), 0,
+             hipLaunchKernelGGL(ppo_full_loss_kernel<A>, dim3(nb), dim3(kBlock), 0,
                                 stream, logits, value, idx, act, logp_old, ent_old, adv, ret, B, cfg,
-                                dlogits_out, dvalue_out, metrics_sum));
+                                dlogits_out, dvalue_out, parts));
+  if (metrics_sum)
+    hipLaunchKernelGGL(metrics_finalize_kernel<9>, dim3(1), dim3(kBlock), 0, stream, parts, nb,
+                       metrics_sum);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

@@ -1,0 +1,63 @@
+"""Device-resident batched environments (CartPole-v1 / Pendulum-v1 / LunarLander-v3).
+
+Stands where `gym.make(name)` stands in the reference trainers
+(ppo_lunarlander.py:160, dqn_cartpole.py:94, rainbow_dqn_cartpole.py:270,
+sac_pendulum.py:154, utils/runner.py:53).  N env instances live in one SoA state
+buffer in HBM and are stepped by one HIP kernel launch (one env per lane) with
+auto-reset; observations, rewards and flags never leave the device.
+"""
+import types
+
+import torch
+
+from . import ops
+
+
+class _Space:
+    def __init__(self, shape=None, n=None, high=None):
+        self.shape, self.n, self.high = shape, n, high
+
+
+class VecEnv:
+    """N lane-parallel env instances.  Mirrors the parts of the gymnasium surface the
+    reference touches: observation_space.shape, action_space.n|shape|high,
+    spec.max_episode_steps, reset(seed), step(action)."""
+
+    def __init__(self, env_name, num_envs, device="cuda:0", seed=0, env_id0=0):
+        if env_name not in ops.ENV_KINDS:
+            raise ValueError(f"unsupported env {env_name!r}; have {sorted(ops.ENV_KINDS)}")
+        self.name, self.kind, self.n = env_name, ops.ENV_KINDS[env_name], int(num_envs)
+        self.device = torch.device(device)
+        self.seed, self.env_id0 = int(seed), int(env_id0)
+        self.obs_dim, self.act_dim, self.discrete, self.max_steps = ops.env_dims(self.kind)
+        self.observation_space = _Space(shape=(self.obs_dim,))
+        self.action_space = (_Space(n=self.act_dim) if self.discrete
+                             else _Space(shape=(self.act_dim,), high=[2.0] * self.act_dim))
+        self.spec = types.SimpleNamespace(max_episode_steps=self.max_steps, id=env_name)
+        self.state = ops.env_state(self.kind, self.n, self.device)
+        d, n = self.device, self.n
+        self.terminated = torch.zeros(n, dtype=torch.uint8, device=d)
+        self.truncated = torch.zeros(n, dtype=torch.uint8, device=d)
+        self.ep_stats = torch.zeros(3, dtype=torch.float64, device=d)  # (#episodes, sum return, sum len)
+
+    def reset(self, obs_out=None, seed=None):
+        if seed is not None:
+            self.seed = int(seed)
+        obs_out = torch.empty(self.n, self.obs_dim, device=self.device) if obs_out is None else obs_out
+        ops.env_reset(self.kind, self.state, self.n, self.seed, self.env_id0, obs_out)
+        return obs_out
+
+    def step(self, action, obs_out, rew_out, done_out=None, term_obs_out=None, ep_ret_out=None,
+             ep_len_out=None, terminated_out=None, truncated_out=None):
+        ops.env_step(self.kind, self.state, self.n, self.seed, self.env_id0, action, obs_out, rew_out,
+                     self.terminated if terminated_out is None else terminated_out,
+                     self.truncated if truncated_out is None else truncated_out,
+                     term_obs_out=term_obs_out, done_out=done_out, ep_ret_out=ep_ret_out,
+                     ep_len_out=ep_len_out, ep_stats=self.ep_stats)
+
+    def close(self):
+        pass
+
+
+def make(env_name, num_envs=1, **kw):
+    return VecEnv(env_name, num_envs, **kw)

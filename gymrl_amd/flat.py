@@ -1,0 +1,66 @@
+"""Flat parameter / gradient buffers + the fused Adam front-end.
+
+The reference keeps an nn.Module and a torch.optim.Adam per network
+(ppo_lunarlander.py:165-169).  Here every network keeps its nn.Module interface
+(so the GEMMs run through PyTorch-ROCm autograd), but all parameters are views
+into ONE flat fp32 buffer and all gradients views into another, so that
+clip_grad_norm_ + Adam (+ zero_grad) is two kernel launches on contiguous memory
+and a multi-GPU gradient all-reduce is one collective on one buffer.
+"""
+import torch
+
+from . import ops
+
+_ALIGN = 64  # floats (256 B): keeps every parameter view aligned for hipBLASLt and float4 kernels
+
+
+def flatten_module(module, device):
+    """Move `module` to `device` with all parameters aliased into one flat buffer.
+    Returns (flat_params, flat_grads)."""
+    params = [p for p in module.parameters()]
+    offs, total = [], 0
+    for p in params:
+        offs.append(total)
+        total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+    flat = torch.zeros(total, dtype=torch.float32, device=device)
+    grad = torch.zeros(total, dtype=torch.float32, device=device)
+    module.to(device)
+    for p, o in zip(params, offs):
+        n = p.numel()
+        flat[o:o + n].copy_(p.data.reshape(-1))
+        p.data = flat[o:o + n].view(p.shape)
+        p.grad = grad[o:o + n].view(p.shape)
+    module._flat_params, module._flat_grads = flat, grad
+    return flat, grad
+
+
+class FusedAdam:
+    """torch.optim.Adam(lr, betas, eps) + clip_grad_norm_ + zero_grad over one flat
+    buffer, through gymrl_sqnorm / gymrl_adam_step.  Keeps the `param_groups[i]["lr"]`
+    interface the reference's LR annealing writes to (ppo_lunarlander.py:337-341)."""
+
+    def __init__(self, flat_params, flat_grads, lr, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=0.0,
+                 clamp_abs=0.0):
+        self.p, self.g = flat_params, flat_grads
+        self.m = torch.zeros_like(flat_params)
+        self.v = torch.zeros_like(flat_params)
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps)]
+        self.max_grad_norm, self.clamp_abs = float(max_grad_norm), float(clamp_abs)
+        self.step_count = 0
+        self._sq = torch.zeros(1, dtype=torch.float64, device=flat_params.device)
+        self._ws = ops.reduce_workspace(flat_params.device)
+
+    def zero_grad(self):
+        """No-op: gymrl_adam_step zeroes the gradient buffer it just consumed."""
+
+    def step(self, grad_scale=1.0):
+        g = self.param_groups[0]
+        self.step_count += 1
+        if self.max_grad_norm > 0:
+            ops.sqnorm(self.g, self._sq, self._ws, grad_scale)
+        ops.adam_step(self.p, self.g, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                      self.step_count, grad_scale=grad_scale, max_grad_norm=self.max_grad_norm,
+                      sqnorm_buf=self._sq, clamp_abs=self.clamp_abs, zero_grad=True)
+
+    def state_dict(self):
+        return dict(m=self.m, v=self.v, step=self.step_count, param_groups=self.param_groups)

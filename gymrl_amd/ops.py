@@ -121,36 +121,52 @@ def categorical_sample(logits, value=None, noise_exp=None, seed=0, counter=0, en
 
 
 # --------------------------------------------------------------- PPO loss ---
+_ws_cache = {}
+
+
+def _reduce_ws(device):
+    key = (device.type, device.index)
+    if key not in _ws_cache:
+        _ws_cache[key] = reduce_workspace(device)
+    return _ws_cache[key]
+
+
 def ppo_loss_fwd_bwd(logits, value, act, logp_old, adv, ret, cfg, idx=None, adv_moments=None, dlogits_out=None,
-                     dvalue_out=None, metrics_sum=None):
+                     dvalue_out=None, metrics_sum=None, workspace=None):
     """L1+L2 (ppo_lunarlander.py:278-322).  cfg = (clip_eps, dual_clip, value_coef, entropy_coef)."""
     B, A = logits.shape
     dlogits_out = torch.empty_like(logits) if dlogits_out is None else dlogits_out
     dvalue_out = torch.empty(B, dtype=torch.float32, device=logits.device) if dvalue_out is None else dvalue_out
     c = PPOCfg(*cfg)
+    if metrics_sum is not None and workspace is None:
+        workspace = _reduce_ws(logits.device)
     check(lib().gymrl_ppo_loss_fwd_bwd(_ptr(logits, torch.float32), _ptr(value, torch.float32),
                                        _ptr(idx, torch.int32, True), _ptr(act, torch.int32),
                                        _ptr(logp_old, torch.float32), _ptr(adv, torch.float32),
                                        _ptr(ret, torch.float32), _ptr(adv_moments, torch.float64, True),
                                        C.c_int(B), C.c_int(A), C.byref(c), _ptr(dlogits_out), _ptr(dvalue_out),
-                                       _ptr(metrics_sum, torch.float64, True), _stream()),
+                                       _ptr(metrics_sum, torch.float64, True), _ptr(workspace, None, True),
+                                       _stream()),
           "gymrl_ppo_loss_fwd_bwd")
     return dlogits_out, dvalue_out
 
 
 def ppo_full_loss_fwd_bwd(logits, value, act, logp_old, ent_old, adv, ret, cfg, idx=None, dlogits_out=None,
-                          dvalue_out=None, metrics_sum=None):
+                          dvalue_out=None, metrics_sum=None, workspace=None):
     """L3 (ppo_full_lunarlander.py:575-652)."""
     B, A = logits.shape
     dlogits_out = torch.empty_like(logits) if dlogits_out is None else dlogits_out
     dvalue_out = torch.empty(B, dtype=torch.float32, device=logits.device) if dvalue_out is None else dvalue_out
     c = PPOFullCfg(*cfg)
+    if metrics_sum is not None and workspace is None:
+        workspace = _reduce_ws(logits.device)
     check(lib().gymrl_ppo_full_loss_fwd_bwd(_ptr(logits, torch.float32), _ptr(value, torch.float32),
                                             _ptr(idx, torch.int32, True), _ptr(act, torch.int32),
                                             _ptr(logp_old, torch.float32), _ptr(ent_old, torch.float32),
                                             _ptr(adv, torch.float32), _ptr(ret, torch.float32), C.c_int(B),
                                             C.c_int(A), C.byref(c), _ptr(dlogits_out), _ptr(dvalue_out),
-                                            _ptr(metrics_sum, torch.float64, True), _stream()),
+                                            _ptr(metrics_sum, torch.float64, True),
+                                            _ptr(workspace, None, True), _stream()),
           "gymrl_ppo_full_loss_fwd_bwd")
     return dlogits_out, dvalue_out
 

@@ -1,0 +1,316 @@
+"""PPO (clip + dual-clip + GAE) — MI355X engine behind the reference's
+algorithms/ppo_lunarlander.py surface: Config :29-52, ActorCritic :63-117,
+RolloutBuffer :120-154, PPOTrainer :157-426 (compute_gae :179-196,
+collect_rollout :198-231, update :233-330, train :332-366, eval :368-399).
+
+Same class / method / attribute names and return types; what changed underneath:
+  * `num_envs` env instances step in lock-step on the GPU (one per lane) instead of
+    one gymnasium env; the rollout is a time-major SoA slab [T][N] in HBM;
+  * categorical sampling, GAE (+ advantage moments), the clipped-surrogate loss
+    forward/backward (+ metrics) and clip-norm + Adam are HIP kernels behind the
+    C-ABI (include/gymrl.h); only the 256-wide MLP GEMMs go through PyTorch-ROCm;
+  * host syncs: one per rollout (episode returns) and one per update (metrics),
+    instead of 3 per env step and 5 per minibatch;
+  * with torch.distributed initialised every rank owns `num_envs` envs and the
+    flat gradient is all-reduced (RCCL over xGMI) once per optimiser step.
+"""
+from collections import deque
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import dist as gdist
+from . import ops
+from .envs import VecEnv
+from .flat import FusedAdam, flatten_module
+
+
+class Config:
+    def __init__(self):
+        self.env_name = "LunarLander-v3"
+        self.seed = None
+
+        self.max_train_steps = 1_000_000
+        self.update_freq = 2048          # steps PER ENV per rollout (T); the reference has one env
+        self.num_epochs = 10
+        self.batch_size = 64             # minibatch size when num_minibatches is None
+        self.num_minibatches = None      # if set: minibatch = T*N / num_minibatches (reference ratio: 32)
+
+        self.gamma = 0.99
+        self.gae_lambda = 0.95
+        self.clip_eps = 0.2
+        self.dual_clip = 3.0
+        self.entropy_coef = 0.01
+        self.value_coef = 0.5
+        self.max_grad_norm = 0.5
+
+        self.lr = 3e-4
+        self.anneal_lr = True
+
+        self.hidden_dim = 256
+
+        self.device = "cuda"             # MI355X only: there is no CPU path in this package
+        # --- additions of the vectorised engine (defaults reproduce the reference loop) ---
+        self.num_envs = 1
+        self.reset_each_rollout = True   # ppo_lunarlander.py:200 resets the env at every rollout start
+        self.gae_variant = 1             # 1 = time-blocked scan, 0 = sequential reference order
+        self.solved_reward = 200.0
+
+
+def layer_init(layer, std=np.sqrt(2)):
+    """ppo_lunarlander.py:55-60."""
+    if isinstance(layer, nn.Linear):
+        nn.init.orthogonal_(layer.weight, gain=std)
+        if layer.bias is not None:
+            nn.init.constant_(layer.bias, 0)
+    return layer
+
+
+class ActorCritic(nn.Module):
+    """Same architecture and init as ppo_lunarlander.py:63-90 (200,965 params at 8/4/256)."""
+
+    def __init__(self, state_dim, action_dim, hidden_dim=256):
+        super().__init__()
+        self.shared = nn.Sequential(
+            layer_init(nn.Linear(state_dim, hidden_dim)), nn.Tanh(),
+            layer_init(nn.Linear(hidden_dim, hidden_dim)), nn.Tanh(),
+        )
+        self.actor = nn.Sequential(
+            layer_init(nn.Linear(hidden_dim, hidden_dim)), nn.Tanh(),
+            layer_init(nn.Linear(hidden_dim, action_dim), std=0.01),
+        )
+        self.critic = nn.Sequential(
+            layer_init(nn.Linear(hidden_dim, hidden_dim)), nn.Tanh(),
+            layer_init(nn.Linear(hidden_dim, 1), std=1.0),
+        )
+
+    def forward(self, x):
+        features = self.shared(x)
+        return self.actor(features), self.critic(features)
+
+    @torch.no_grad()
+    def get_action(self, state, deterministic=False, seed=0, counter=0, env_id0=0, noise_exp=None):
+        """Batched counterpart of :92-104: state [N, obs] -> (action i32[N], logp[N], value[N])."""
+        logits, value = self.forward(state)
+        act, logp, _, val = ops.categorical_sample(logits, value=value.squeeze(-1).contiguous(),
+                                                   noise_exp=noise_exp, seed=seed, counter=counter,
+                                                   env_id0=env_id0, deterministic=deterministic)
+        return act, logp, val
+
+    @torch.no_grad()
+    def get_value(self, state):
+        return self.forward(state)[1].squeeze(-1)
+
+
+class RolloutBuffer:
+    """Time-major SoA slab [T][N] in HBM replacing the six python lists of :120-154."""
+
+    def __init__(self, T, N, obs_dim, device):
+        self.T, self.N = T, N
+        self.states = torch.zeros(T + 1, N, obs_dim, device=device)      # row T = bootstrap observation
+        self.actions = torch.zeros(T, N, dtype=torch.int32, device=device)
+        self.log_probs = torch.zeros(T, N, device=device)
+        self.values = torch.zeros(T, N, device=device)
+        self.rewards = torch.zeros(T, N, device=device)
+        self.dones = torch.zeros(T, N, dtype=torch.uint8, device=device)
+        self.ep_returns = torch.zeros(T, N, device=device)                # valid where dones == 1
+        self.advantages = torch.zeros(T, N, device=device)
+        self.returns = torch.zeros(T, N, device=device)
+        self.pos = 0
+
+    def clear(self):
+        self.pos = 0
+
+    def __len__(self):
+        return self.pos * self.N
+
+
+class PPOTrainer:
+    def __init__(self, config):
+        self.cfg = config
+        if not torch.cuda.is_available() or not ops.device_ok():
+            raise RuntimeError("gymrl_amd.PPOTrainer needs an MI355X (gfx950) and libgymrl_hip.so; no CPU fallback")
+        self.rank, self.world_size = gdist.rank(), gdist.world_size()
+        self.device = torch.device(config.device if ":" in str(config.device) else f"cuda:{torch.cuda.current_device()}")
+        self.base_seed = 0 if config.seed is None else int(config.seed)
+        N = int(config.num_envs)
+        self.env = VecEnv(config.env_name, N, device=self.device, seed=self.base_seed, env_id0=self.rank * N)
+
+        state_dim = self.env.observation_space.shape[0]
+        action_dim = self.env.action_space.n
+        self.action_dim = action_dim
+
+        # identical initial parameters on every rank: CPU init under a fixed torch seed
+        gen_state = torch.random.get_rng_state()
+        torch.manual_seed(self.base_seed)
+        self.model = ActorCritic(state_dim, action_dim, config.hidden_dim)
+        torch.random.set_rng_state(gen_state)
+        self.flat_params, self.flat_grads = flatten_module(self.model, self.device)
+        gdist.broadcast(self.flat_params)
+        self.optimizer = FusedAdam(self.flat_params, self.flat_grads, lr=config.lr, eps=1e-5,
+                                   max_grad_norm=config.max_grad_norm)
+
+        T = int(config.update_freq)
+        self.buffer = RolloutBuffer(T, N, state_dim, self.device)
+        self.step_count = 0
+        self.rollout_count = 0
+        self.episode_rewards = deque(maxlen=100)
+        self._gae_ws = ops.gae_workspace(T, N, self.device)
+        self._moments = torch.zeros(3, dtype=torch.float64, device=self.device)
+        self._next_value = torch.zeros(N, device=self.device)
+        self._perm_gen = torch.Generator(device=self.device)
+        self._perm_gen.manual_seed(self.base_seed * 7919 + 13 + self.rank)
+        self._loss_cfg = (config.clip_eps, config.dual_clip, config.value_coef, config.entropy_coef)
+        if self.rank == 0:
+            print(f"Device: {self.device} x{self.world_size} | envs/GPU: {N} | rollout T: {T}")
+            print(f"State dim: {state_dim}, Action dim: {action_dim}")
+            print(f"Model parameters: {sum(p.numel() for p in self.model.parameters()):,}")
+
+    # ------------------------------------------------------------------ GAE --
+    def compute_gae(self, next_value=None):
+        """:179-196 over every env of the slab; returns (advantages, returns) [T, N]
+        (un-normalised; the whole-rollout moments are left in self._moments)."""
+        b = self.buffer
+        nv = self._next_value if next_value is None else next_value
+        ops.gae(b.rewards, b.values, b.dones, nv, self.cfg.gamma, self.cfg.gae_lambda, b.advantages,
+                b.returns, self._moments, self.cfg.gae_variant, self._gae_ws)
+        return b.advantages, b.returns
+
+    # -------------------------------------------------------------- rollout --
+    @torch.no_grad()
+    def collect_rollout(self):
+        """:198-231 for N envs at once.  Returns next_value f32[N] (bootstrap)."""
+        cfg, b, env = self.cfg, self.buffer, self.env
+        b.clear()
+        if cfg.reset_each_rollout or self.rollout_count == 0:
+            # :200 env.reset(seed=cfg.seed): a fixed cfg.seed replays the same stream every
+            # rollout (reference behaviour); seed=None draws a fresh stream per rollout.
+            seed = self.base_seed if cfg.seed is not None else self.base_seed + 0x9E3779B1 * (self.rollout_count + 1)
+            env.reset(b.states[0], seed=seed & 0x7FFFFFFFFFFFFFFF)
+        else:
+            b.states[0].copy_(b.states[b.T])
+        counter0 = self.rollout_count * b.T
+        for t in range(b.T):
+            logits, value = self.model(b.states[t])
+            ops.categorical_sample(logits, value=value.view(-1), seed=env.seed, counter=counter0 + t,
+                                   env_id0=env.env_id0, act_out=b.actions[t], logp_out=b.log_probs[t],
+                                   ent_out=None, value_out=b.values[t])
+            env.step(b.actions[t], b.states[t + 1], b.rewards[t], done_out=b.dones[t],
+                     ep_ret_out=b.ep_returns[t])
+        b.pos = b.T
+        self.step_count += b.T * b.N
+        self.rollout_count += 1
+        self._next_value.copy_(self.model.get_value(b.states[b.T]))
+        # :220-221 episode_rewards.append on done — one compaction + one D2H per rollout
+        finished = b.ep_returns[b.dones.bool()]
+        for r in finished[-self.episode_rewards.maxlen:].tolist():
+            self.episode_rewards.append(r)
+        return self._next_value
+
+    # --------------------------------------------------------------- update --
+    def _minibatch_size(self):
+        total = len(self.buffer)
+        if self.cfg.num_minibatches:
+            return max(1, total // int(self.cfg.num_minibatches))
+        return int(self.cfg.batch_size)
+
+    def update(self, next_value=None, indices=None):
+        """:233-330.  `indices` (optional i32/i64 [num_epochs, T*N]) replays an explicit
+        shuffle order (parity mode); by default a device randperm per epoch (:262)."""
+        cfg, b = self.cfg, self.buffer
+        self.compute_gae(next_value)
+        if self.world_size > 1:
+            gdist.all_reduce_sum(self._moments)          # :236 mean/std over the WHOLE rollout (all ranks)
+        total = len(b)
+        mb = self._minibatch_size()
+        n_mb = (total + mb - 1) // mb
+        states = b.states[:b.T].reshape(total, -1)
+        actions, old_lp = b.actions.view(-1), b.log_probs.view(-1)
+        adv, ret = b.advantages.view(-1), b.returns.view(-1)
+        metrics = torch.zeros(cfg.num_epochs * n_mb, 5, dtype=torch.float64, device=self.device)
+        sizes = []
+        row = 0
+        for epoch in range(cfg.num_epochs):
+            if indices is not None:
+                perm = torch.as_tensor(indices[epoch], device=self.device).to(torch.int32)
+            else:
+                perm = torch.randperm(total, device=self.device, generator=self._perm_gen).to(torch.int32)
+            for start in range(0, total, mb):
+                mb_idx = perm[start:start + mb]
+                B = mb_idx.numel()
+                logits, values = self.model(states.index_select(0, mb_idx))
+                values = values.view(-1)
+                dlogits = torch.empty_like(logits)
+                dvalues = torch.empty_like(values)
+                ops.ppo_loss_fwd_bwd(logits, values, actions, old_lp, adv, ret, self._loss_cfg, idx=mb_idx,
+                                     adv_moments=self._moments, dlogits_out=dlogits, dvalue_out=dvalues,
+                                     metrics_sum=metrics[row])
+                torch.autograd.backward([logits, values], [dlogits, dvalues])
+                if self.world_size > 1:
+                    gdist.all_reduce_sum(self.flat_grads)
+                self.optimizer.step(grad_scale=1.0 / self.world_size)
+                sizes.append(B)
+                row += 1
+        m = metrics.cpu().numpy() / np.asarray(sizes, np.float64)[:, None]   # the one host sync of the update
+        m = m.mean(axis=0)
+        return {"policy_loss": m[0], "value_loss": m[1], "entropy": m[2], "clip_frac": m[3], "approx_kl": m[4]}
+
+    # ---------------------------------------------------------------- train --
+    def train(self):
+        if self.rank == 0:
+            print("Starting training...")
+        update_count = 0
+        while self.step_count * self.world_size < self.cfg.max_train_steps:
+            if self.cfg.anneal_lr:
+                frac = 1.0 - self.step_count * self.world_size / self.cfg.max_train_steps
+                lr = self.cfg.lr * frac
+                for param_group in self.optimizer.param_groups:
+                    param_group["lr"] = lr
+            next_value = self.collect_rollout()
+            metrics = self.update(next_value)
+            update_count += 1
+            if len(self.episode_rewards) > 0 and self.rank == 0:
+                avg_reward = np.mean(self.episode_rewards)
+                print(f"Step: {self.step_count * self.world_size:,} | Updates: {update_count} | "
+                      f"Avg Reward: {avg_reward:.1f} | Policy Loss: {metrics['policy_loss']:.4f} | "
+                      f"Value Loss: {metrics['value_loss']:.4f} | Entropy: {metrics['entropy']:.4f} | "
+                      f"KL: {metrics['approx_kl']:.4f} | Clip: {metrics['clip_frac']:.2%}")
+            if len(self.episode_rewards) >= 100 and np.mean(self.episode_rewards) >= self.cfg.solved_reward:
+                if self.rank == 0:
+                    print(f"\nEnvironment solved at step {self.step_count * self.world_size:,}!")
+                break
+        if self.rank == 0:
+            print("Training completed!")
+        self.env.close()
+
+    @torch.no_grad()
+    def eval(self, num_episodes=10):
+        """:368-399: deterministic (argmax) episodes — run as `num_episodes` parallel envs,
+        each contributing its first finished episode."""
+        env = VecEnv(self.cfg.env_name, num_episodes, device=self.device, seed=self.base_seed + 1_000_003,
+                     env_id0=1 << 40)
+        obs = env.reset()
+        nxt = torch.empty_like(obs)
+        rew = torch.empty(num_episodes, device=self.device)
+        done = torch.zeros(num_episodes, dtype=torch.uint8, device=self.device)
+        ep_ret = torch.zeros(num_episodes, device=self.device)
+        result = torch.full((num_episodes,), float("nan"), device=self.device)
+        self.model.eval()
+        for _ in range(env.max_steps + 1):
+            act, _, _ = self.model.get_action(obs, deterministic=True)
+            env.step(act, nxt, rew, done_out=done, ep_ret_out=ep_ret)
+            first = done.bool() & torch.isnan(result)
+            result = torch.where(first, ep_ret, result)
+            obs, nxt = nxt, obs
+            if not torch.isnan(result).any():
+                break
+        self.model.train()
+        rewards = result.tolist()
+        if self.rank == 0:
+            print(f"Evaluation Results: Mean = {np.mean(rewards):.1f} +/- {np.std(rewards):.1f}")
+        return rewards
+
+    def test(self):
+        """:401-426 without the render window (the batched env has no renderer)."""
+        return self.eval(num_episodes=5)

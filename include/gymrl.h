@@ -165,12 +165,15 @@ typedef struct {
  *          sum (logp_old - logp)).  The caller keeps one zeroed row per minibatch
  *          and divides by B on the host after the whole update (one D2H copy
  *          instead of ppo_lunarlander.py:309-322's five .item() per minibatch).
+ *          Reduced block partials -> fixed-order sum through `workspace`
+ *          (>= gymrl_reduce_workspace_bytes(), required when metrics_sum != NULL).
  */
 int gymrl_ppo_loss_fwd_bwd(const float* logits, const float* value, const int32_t* idx,
                            const int32_t* act, const float* logp_old, const float* adv,
                            const float* ret, const double* adv_moments, int B, int A,
                            const gymrl_ppo_cfg* cfg_host, float* dlogits_out,
-                           float* dvalue_out, double* metrics_sum, void* stream);
+                           float* dvalue_out, double* metrics_sum, void* workspace,
+                           void* stream);
 
 typedef struct {
   float clip_eps_min;  /* ppo_full_lunarlander.py:34 (0.2)  */
@@ -193,7 +196,7 @@ int gymrl_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const i
                                 const float* ent_old, const float* adv, const float* ret,
                                 int B, int A, const gymrl_ppo_full_cfg* cfg_host,
                                 float* dlogits_out, float* dvalue_out,
-                                double* metrics_sum, void* stream);
+                                double* metrics_sum, void* workspace, void* stream);
 
 /* ------------------------------------------------------------ optimiser --- */
 /*
