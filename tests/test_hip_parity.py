@@ -268,3 +268,61 @@ def test_classic_env_vs_oracle(dev, oracle, kind, steps):
             assert np.array_equal(ep_len.cpu().numpy()[d], r["ep_len"][d])
         tot += r["ep_stats"]
     assert tot[0] > 0 and np.allclose(stats.cpu().numpy(), tot, rtol=1e-9)
+
+
+def _lander_heuristic(s):
+    """gymnasium's documented heuristic controller (discrete form) — lands most episodes,
+    so trajectories exercise leg contacts, friction, the block solver and the sleep rule."""
+    angle_targ = np.clip(s[:, 0] * 0.5 + s[:, 2] * 1.0, -0.4, 0.4)
+    hover_targ = 0.55 * np.abs(s[:, 0])
+    angle_todo = (angle_targ - s[:, 4]) * 0.5 - s[:, 5] * 1.0
+    hover_todo = (hover_targ - s[:, 1]) * 0.5 - s[:, 3] * 0.5
+    legs = (s[:, 6] > 0) | (s[:, 7] > 0)
+    angle_todo = np.where(legs, 0, angle_todo)
+    hover_todo = np.where(legs, -s[:, 3] * 0.5, hover_todo)
+    main = (hover_todo > np.abs(angle_todo)) & (hover_todo > 0.05)
+    a = np.zeros(len(s), np.int32)
+    a = np.where(main, 2, a)
+    a = np.where(~main & (angle_todo < -0.05), 3, a)
+    a = np.where(~main & (angle_todo > 0.05), 1, a)
+    return a.astype(np.int32)
+
+
+def test_lunarlander_vs_oracle_bit_exact(dev, oracle):
+    """LunarLander-v3: the HIP solver and the CPU restatement agree on every bit of every
+    observation, reward and flag over auto-resetting trajectories (random + heuristic policy)."""
+    from gymrl_amd import ops
+    kind, n, seed, id0 = 2, 192, 21, 5000
+    env = oracle.Env(kind, n, seed=seed, env_id0=id0)
+    o_ref = env.reset()
+    state = ops.env_state(kind, n, dev)
+    obs, tobs = torch.empty(n, 8, device=dev), torch.empty(n, 8, device=dev)
+    rew = torch.empty(n, device=dev)
+    term, trunc, done = (torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(3))
+    ep_ret = torch.zeros(n, device=dev)
+    ep_len = torch.zeros(n, dtype=torch.int32, device=dev)
+    stats = torch.zeros(3, dtype=torch.float64, device=dev)
+    ops.env_reset(kind, state, n, seed, id0, obs)
+    assert np.array_equal(obs.cpu().numpy(), o_ref)
+    rng = np.random.default_rng(22)
+    o = o_ref
+    landed = crashed = 0
+    for s in range(450):
+        act = _lander_heuristic(o)
+        rnd = rng.integers(0, 4, size=n).astype(np.int32)
+        act = np.where(np.arange(n) < n // 3, rnd, act).astype(np.int32)      # a third of the envs act randomly
+        r = env.step(act)
+        ops.env_step(kind, state, n, seed, id0, t(act, dev), obs, rew, term, trunc, term_obs_out=tobs, done_out=done,
+                     ep_ret_out=ep_ret, ep_len_out=ep_len, ep_stats=stats)
+        assert np.array_equal(obs.cpu().numpy(), r["obs"]), s
+        assert np.array_equal(tobs.cpu().numpy(), r["term_obs"]), s
+        assert np.array_equal(rew.cpu().numpy(), r["rew"]), s
+        assert np.array_equal(term.cpu().numpy(), r["terminated"]) and np.array_equal(trunc.cpu().numpy(), r["truncated"])
+        d = r["done"].astype(bool)
+        landed += int((r["rew"][d] == 100).sum())
+        crashed += int((r["rew"][d] == -100).sum())
+        if d.any():
+            assert np.array_equal(ep_len.cpu().numpy()[d], r["ep_len"][d])
+            assert np.allclose(ep_ret.cpu().numpy()[d], r["ep_ret"][d], rtol=1e-6)
+        o = r["obs"]
+    assert landed > 20 and crashed > 20          # both terminal kinds were exercised
