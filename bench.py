@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of PPO LunarLander-v3 at 4096 envs/GPU
+(BASELINE.json configs[1]) + fraction of the HBM roofline on the GAE+loss pass,
+with the reference-structured CPU loop timed beside it (cpu_baseline).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full PPO iteration on every rank: a rollout of T vector steps over
+N lane-parallel envs (policy forward, categorical sample, LunarLander physics, slab
+writes), GAE + advantage moments, and num_epochs x num_minibatches optimiser steps
+(minibatch gather, MLP forward/backward, fused clipped-surrogate loss, gradient
+all-reduce when N_gpus > 1, clip-norm + Adam).  Nothing is skipped in the timed
+region.  value = (T * N * world_size * K) / max-over-ranks wall time.  Weak scaling:
+every rank owns its own 4096 envs (global env ids r*N .. (r+1)*N-1).
+Data: synthetic — the build's own LunarLander-v3 solver on fixed-seed Philox episodes,
+randomly initialised ActorCritic(8, 4, 256).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12   # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--envs", type=int, default=4096, help="env instances per GPU")
+    ap.add_argument("--rollout", type=int, default=2048, help="T: vector steps per rollout (reference update_freq)")
+    ap.add_argument("--epochs", type=int, default=10)
+    ap.add_argument("--minibatches", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    a = ap.parse_args()
+
+    from gymrl_amd import dist as gdist
+    rank, world, local_rank = gdist.init_from_env()
+    if world != a.gpus and rank == 0:
+        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    from gymrl_amd.ppo_lunarlander import Config, KernelTimers, PPOTrainer
+    cfg = Config()
+    cfg.env_name = "LunarLander-v3"
+    cfg.seed = 0                       # fixed-seed episodes
+    cfg.num_envs = a.envs
+    cfg.update_freq = a.rollout
+    cfg.num_epochs = a.epochs
+    cfg.num_minibatches = a.minibatches
+    cfg.max_train_steps = 10**12       # keep the LR anneal well-defined for any K
+    cfg.device = str(dev)
+    if rank != 0:
+        sys.stdout = open(os.devnull, "w")
+    trainer = PPOTrainer(cfg)
+    T, N = cfg.update_freq, cfg.num_envs
+
+    def step():
+        if cfg.anneal_lr:
+            lr = cfg.lr * (1.0 - trainer.step_count * world / cfg.max_train_steps)
+            for g in trainer.optimizer.param_groups:
+                g["lr"] = lr
+        nv = trainer.collect_rollout()
+        return trainer.update(nv)
+
+    for _ in range(a.warmup):
+        step()
+    timers = KernelTimers()
+    trainer._timers = timers
+    gdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    metrics = None
+    for _ in range(a.steps):
+        metrics = step()
+    gdist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    gdist.all_reduce_max(dt_t)
+    dt = float(dt_t.item())
+    trainer._timers = None
+
+    if rank != 0:
+        return
+    sys.stdout = sys.__stdout__
+    ks = timers.summary()
+    transitions = T * N
+    # algorithmic bytes: GAE 17 B/elt, loss fwd+bwd 56 B/sample,
+    # gather 64 B line in + 48 B out + 4 B index, Adam 36 B/param incl. norm pre-pass + zero_grad
+    bytes_per_unit = {"gae": 17.0, "ppo_loss_fwd_bwd": 56.0, "gather_minibatch": 116.0, "adam_step": 36.0}
+    kernels = {}
+    for k, v in ks.items():
+        ent = dict(launches=v["launches"], avg_us=round(v["avg_us"], 2))
+        if k in bytes_per_unit:
+            gbps = bytes_per_unit[k] * v["units"] / v["total_s"] / 1e9
+            ent.update(bytes_per_unit=bytes_per_unit[k], achieved_GBps=round(gbps, 1), frac=round(gbps * 1e9 / HBM_PEAK, 4))
+        kernels[k] = ent
+    # the pass BASELINE.json's metric names: GAE (moments fused) + one clipped-surrogate
+    # loss pass over the rollout = 17 + 56 = 73 algorithmic bytes per transition
+    gae_s = ks["gae"]["total_s"] / ks["gae"]["launches"]
+    loss_s_per_pass = ks["ppo_loss_fwd_bwd"]["total_s"] / (a.steps * cfg.num_epochs)
+    pass_bytes = 73.0 * transitions
+    achieved = pass_bytes / (gae_s + loss_s_per_pass)
+    roofline = dict(bound="hbm", achieved=round(achieved / 1e9, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK, 4), traffic=None,
+                    kernel="gae(G1: aggregate+carry+apply+moments) + ppo_loss_fwd_bwd, one pass over the rollout",
+                    bytes_per_launch=pass_bytes, launch_s=gae_s + loss_s_per_pass, kernels=kernels)
+
+    out = {
+        "metric": "env-steps/sec at N envs/GPU (PPO LunarLander), 1/2/4/8 GPUs + %HBM roofline",
+        "value": transitions * world * a.steps / dt,
+        "unit": "env-steps/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "PPO LunarLander-v3, 4096 vectorised envs per MI355X (BASELINE.json configs[1])",
+                   "envs_per_gpu": N, "rollout_len": T, "transitions_per_step_per_gpu": transitions,
+                   "num_epochs": cfg.num_epochs, "num_minibatches": cfg.num_minibatches,
+                   "minibatch": transitions // cfg.num_minibatches, "model": "ActorCritic 8-256-256-{256-4,256-1} tanh, 200,965 params",
+                   "parallelism": f"dp{world} (env shards + flat-gradient all-reduce)" if world > 1 else "single GPU"},
+        "roofline": roofline,
+        "train_metrics": {k: float(v) for k, v in (metrics or {}).items()},
+        "avg_episode_return": (sum(trainer.episode_rewards) / len(trainer.episode_rewards)) if trainer.episode_rewards else None,
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        from oracle.ref_ppo_cpu import time_cpu_baseline
+        out["cpu_baseline"] = time_cpu_baseline(a.cpu_budget)
+        out["cpu_baseline"]["host_cores"] = os.cpu_count()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -23,6 +23,7 @@ SYMBOLS = [
     "gymrl_gae_workspace_bytes", "gymrl_gae", "gymrl_gae_dw", "gymrl_gae_decoupled",
     "gymrl_reduce_workspace_bytes", "gymrl_moments", "gymrl_normalize",
     "gymrl_ppo_loss_fwd_bwd", "gymrl_ppo_full_loss_fwd_bwd",
+    "gymrl_pack_rollout", "gymrl_gather_minibatch",
     "gymrl_sqnorm", "gymrl_adam_step", "gymrl_soft_update",
 ]
 

@@ -304,6 +304,53 @@ __global__ __launch_bounds__(kBlock) void metrics_finalize_kernel(const double* 
 
 constexpr int kMaxLossBlocks = 1024;
 
+// ------------------------------------------------------- minibatch staging ---
+// P6/P7 (ppo_lunarlander.py:238-272).  A uniformly random minibatch touches one
+// random row per sample; gathering five SoA arrays costs five 64-B lines per sample
+// for 48 useful bytes.  So the rollout is packed ONCE into 64-B records
+//   [ obs(<=12 f32) | act bits | logp_old | adv | ret ]
+// (one cache line per transition, streaming pass), and each minibatch is ONE random
+// line per sample gathered into contiguous SoA rows that the GEMMs and the loss
+// kernel then stream.
+constexpr int kRecF = 16;   // floats per packed record (64 B)
+
+__global__ __launch_bounds__(kBlock) void pack_rollout_kernel(
+    const float* __restrict__ obs, const int32_t* __restrict__ act, const float* __restrict__ logp,
+    const float* __restrict__ adv, const float* __restrict__ ret, int64_t M, int D,
+    float* __restrict__ packed) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < M; i += stride) {
+    float r[kRecF];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) r[k] = k < D ? obs[i * D + k] : 0.0f;
+    r[12] = __int_as_float(act[i]); r[13] = logp[i]; r[14] = adv[i]; r[15] = ret[i];
+    float4* dst = reinterpret_cast<float4*>(packed + i * kRecF);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gather_minibatch_kernel(
+    const float* __restrict__ packed, const int32_t* __restrict__ idx, int B, int D,
+    float* __restrict__ obs_out, int32_t* __restrict__ act_out, float* __restrict__ logp_out,
+    float* __restrict__ adv_out, float* __restrict__ ret_out) {
+  for (int b = blockIdx.x * kBlock + threadIdx.x; b < B; b += gridDim.x * kBlock) {
+    const float4* src = reinterpret_cast<const float4*>(packed + (size_t)idx[b] * kRecF);
+    const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+    const float r[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+    if (D == 8) {
+      reinterpret_cast<float4*>(obs_out)[2 * (size_t)b] = q0;
+      reinterpret_cast<float4*>(obs_out)[2 * (size_t)b + 1] = q1;
+    } else if (D == 4) {
+      reinterpret_cast<float4*>(obs_out)[b] = q0;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) if (k < D) obs_out[(size_t)b * D + k] = r[k];
+    }
+    act_out[b] = __float_as_int(q3.x); logp_out[b] = q3.y; adv_out[b] = q3.z; ret_out[b] = q3.w;
+  }
+}
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace
@@ -382,6 +429,34 @@ int gymrl_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const i
   if (metrics_sum)
     hipLaunchKernelGGL(metrics_finalize_kernel<9>, dim3(1), dim3(kBlock), 0, stream, parts, nb,
                        metrics_sum);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_pack_rollout(const float* obs, const int32_t* act, const float* logp, const float* adv,
+                       const float* ret, int64_t M, int obs_dim, float* packed, void* stream_) {
+  if (!obs || !act || !logp || !adv || !ret || !packed || M < 0 || obs_dim < 1 || obs_dim > 12) return -22;
+  if ((reinterpret_cast<uintptr_t>(packed) & 15) != 0) return -22;
+  if (M == 0) return 0;
+  int64_t nb = (M + kBlock - 1) / kBlock;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(pack_rollout_kernel, dim3((int)nb), dim3(kBlock), 0, (hipStream_t)stream_, obs, act,
+                     logp, adv, ret, M, obs_dim, packed);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_gather_minibatch(const float* packed, const int32_t* idx, int B, int obs_dim, float* obs_out,
+                           int32_t* act_out, float* logp_out, float* adv_out, float* ret_out,
+                           void* stream_) {
+  if (!packed || !idx || !obs_out || !act_out || !logp_out || !adv_out || !ret_out || B < 0 ||
+      obs_dim < 1 || obs_dim > 12)
+    return -22;
+  if ((reinterpret_cast<uintptr_t>(packed) & 15) != 0 || (reinterpret_cast<uintptr_t>(obs_out) & 15) != 0) return -22;
+  if (B == 0) return 0;
+  const int nb = cdiv(B, kBlock) < 4096 ? cdiv(B, kBlock) : 4096;
+  hipLaunchKernelGGL(gather_minibatch_kernel, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream_, packed, idx,
+                     B, obs_dim, obs_out, act_out, logp_out, adv_out, ret_out);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

@@ -171,6 +171,30 @@ def ppo_full_loss_fwd_bwd(logits, value, act, logp_old, ent_old, adv, ret, cfg, 
     return dlogits_out, dvalue_out
 
 
+def pack_rollout(obs, act, logp, adv, ret, packed=None):
+    """P6: one 64-B record per transition (ppo_lunarlander.py:238-250).  obs [M, D]."""
+    M, D = obs.shape
+    packed = torch.empty(M, 16, dtype=torch.float32, device=obs.device) if packed is None else packed
+    check(lib().gymrl_pack_rollout(_ptr(obs, torch.float32), _ptr(act, torch.int32), _ptr(logp, torch.float32),
+                                   _ptr(adv, torch.float32), _ptr(ret, torch.float32), C.c_int64(M), C.c_int(D),
+                                   _ptr(packed, torch.float32), _stream()), "gymrl_pack_rollout")
+    return packed
+
+
+def gather_minibatch(packed, idx, obs_dim, out=None):
+    """P7: rows idx[0..B) of the packed rollout -> contiguous (obs, act, logp_old, adv, ret)."""
+    B, dev = idx.numel(), packed.device
+    if out is None:
+        out = (torch.empty(B, obs_dim, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
+               torch.empty(B, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev))
+    obs, act, logp, adv, ret = out
+    check(lib().gymrl_gather_minibatch(_ptr(packed, torch.float32), _ptr(idx, torch.int32), C.c_int(B),
+                                       C.c_int(obs_dim), _ptr(obs, torch.float32), _ptr(act, torch.int32),
+                                       _ptr(logp, torch.float32), _ptr(adv, torch.float32),
+                                       _ptr(ret, torch.float32), _stream()), "gymrl_gather_minibatch")
+    return out
+
+
 # -------------------------------------------------------------- optimiser ---
 def sqnorm(g, out, workspace, grad_scale=1.0):
     check(lib().gymrl_sqnorm(_ptr(g, torch.float32), C.c_int64(g.numel()), C.c_float(grad_scale),

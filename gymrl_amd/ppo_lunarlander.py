@@ -126,6 +126,38 @@ class RolloutBuffer:
         return self.pos * self.N
 
 
+class KernelTimers:
+    """HIP-event timers on torch's current stream (the stream the C-ABI launches on):
+    per label, summed device time and work units — bench.py turns them into achieved
+    GB/s against the HBM roofline."""
+
+    def __init__(self):
+        self.pairs = {}
+        self._open = {}
+
+    def start(self, label):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self._open[label] = e
+
+    def stop(self, label, units):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.pairs.setdefault(label, []).append((self._open.pop(label), e, units))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for label, prs in self.pairs.items():
+            ms = [s.elapsed_time(e) for s, e, _ in prs]
+            out[label] = dict(launches=len(prs), total_s=sum(ms) * 1e-3, units=sum(u for _, _, u in prs),
+                              avg_us=1e3 * sum(ms) / len(ms))
+        return out
+
+    def reset(self):
+        self.pairs.clear()
+
+
 class PPOTrainer:
     def __init__(self, config):
         self.cfg = config
@@ -162,6 +194,12 @@ class PPOTrainer:
         self._perm_gen = torch.Generator(device=self.device)
         self._perm_gen.manual_seed(self.base_seed * 7919 + 13 + self.rank)
         self._loss_cfg = (config.clip_eps, config.dual_clip, config.value_coef, config.entropy_coef)
+        self._packed = None      # [T*N, 16] packed rollout records (allocated on first update)
+        mb = self._minibatch_size_for(T * N)
+        self._stage = (torch.empty(mb, state_dim, device=self.device), torch.empty(mb, dtype=torch.int32, device=self.device),
+                       torch.empty(mb, device=self.device), torch.empty(mb, device=self.device),
+                       torch.empty(mb, device=self.device))
+        self._timers = None      # set to a KernelTimers() to time kernels with HIP events (bench.py)
         if self.rank == 0:
             print(f"Device: {self.device} x{self.world_size} | envs/GPU: {N} | rollout T: {T}")
             print(f"State dim: {state_dim}, Action dim: {action_dim}")
@@ -173,8 +211,12 @@ class PPOTrainer:
         (un-normalised; the whole-rollout moments are left in self._moments)."""
         b = self.buffer
         nv = self._next_value if next_value is None else next_value
+        if self._timers is not None:
+            self._timers.start("gae")
         ops.gae(b.rewards, b.values, b.dones, nv, self.cfg.gamma, self.cfg.gae_lambda, b.advantages,
                 b.returns, self._moments, self.cfg.gae_variant, self._gae_ws)
+        if self._timers is not None:
+            self._timers.stop("gae", b.T * b.N)
         return b.advantages, b.returns
 
     # -------------------------------------------------------------- rollout --
@@ -191,13 +233,18 @@ class PPOTrainer:
         else:
             b.states[0].copy_(b.states[b.T])
         counter0 = self.rollout_count * b.T
+        tm = self._timers
         for t in range(b.T):
             logits, value = self.model(b.states[t])
+            if tm is not None and t % 64 == 0:
+                tm.start("env_step+sample")
             ops.categorical_sample(logits, value=value.view(-1), seed=env.seed, counter=counter0 + t,
                                    env_id0=env.env_id0, act_out=b.actions[t], logp_out=b.log_probs[t],
                                    ent_out=None, value_out=b.values[t])
             env.step(b.actions[t], b.states[t + 1], b.rewards[t], done_out=b.dones[t],
                      ep_ret_out=b.ep_returns[t])
+            if tm is not None and t % 64 == 0:
+                tm.stop("env_step+sample", b.N)
         b.pos = b.T
         self.step_count += b.T * b.N
         self.rollout_count += 1
@@ -209,11 +256,13 @@ class PPOTrainer:
         return self._next_value
 
     # --------------------------------------------------------------- update --
-    def _minibatch_size(self):
-        total = len(self.buffer)
+    def _minibatch_size_for(self, total):
         if self.cfg.num_minibatches:
             return max(1, total // int(self.cfg.num_minibatches))
-        return int(self.cfg.batch_size)
+        return min(int(self.cfg.batch_size), total)
+
+    def _minibatch_size(self):
+        return self._minibatch_size_for(len(self.buffer))
 
     def update(self, next_value=None, indices=None):
         """:233-330.  `indices` (optional i32/i64 [num_epochs, T*N]) replays an explicit
@@ -225,9 +274,12 @@ class PPOTrainer:
         total = len(b)
         mb = self._minibatch_size()
         n_mb = (total + mb - 1) // mb
-        states = b.states[:b.T].reshape(total, -1)
-        actions, old_lp = b.actions.view(-1), b.log_probs.view(-1)
-        adv, ret = b.advantages.view(-1), b.returns.view(-1)
+        obs_dim = b.states.shape[-1]
+        tm = self._timers
+        # P6: one 64-B record per transition so that a shuffled minibatch is one random line per sample
+        self._packed = ops.pack_rollout(b.states[:b.T].reshape(total, obs_dim), b.actions.view(-1),
+                                        b.log_probs.view(-1), b.advantages.view(-1), b.returns.view(-1),
+                                        self._packed)
         metrics = torch.zeros(cfg.num_epochs * n_mb, 5, dtype=torch.float64, device=self.device)
         sizes = []
         row = 0
@@ -239,17 +291,31 @@ class PPOTrainer:
             for start in range(0, total, mb):
                 mb_idx = perm[start:start + mb]
                 B = mb_idx.numel()
-                logits, values = self.model(states.index_select(0, mb_idx))
+                stage = self._stage if B == mb else None
+                if tm is not None:
+                    tm.start("gather_minibatch")
+                mb_obs, mb_act, mb_lp, mb_adv, mb_ret = ops.gather_minibatch(self._packed, mb_idx, obs_dim, stage)
+                if tm is not None:
+                    tm.stop("gather_minibatch", B)
+                logits, values = self.model(mb_obs)
                 values = values.view(-1)
                 dlogits = torch.empty_like(logits)
                 dvalues = torch.empty_like(values)
-                ops.ppo_loss_fwd_bwd(logits, values, actions, old_lp, adv, ret, self._loss_cfg, idx=mb_idx,
+                if tm is not None:
+                    tm.start("ppo_loss_fwd_bwd")
+                ops.ppo_loss_fwd_bwd(logits, values, mb_act, mb_lp, mb_adv, mb_ret, self._loss_cfg,
                                      adv_moments=self._moments, dlogits_out=dlogits, dvalue_out=dvalues,
                                      metrics_sum=metrics[row])
+                if tm is not None:
+                    tm.stop("ppo_loss_fwd_bwd", B)
                 torch.autograd.backward([logits, values], [dlogits, dvalues])
                 if self.world_size > 1:
                     gdist.all_reduce_sum(self.flat_grads)
+                if tm is not None:
+                    tm.start("adam_step")
                 self.optimizer.step(grad_scale=1.0 / self.world_size)
+                if tm is not None:
+                    tm.stop("adam_step", self.flat_params.numel())
                 sizes.append(B)
                 row += 1
         m = metrics.cpu().numpy() / np.asarray(sizes, np.float64)[:, None]   # the one host sync of the update

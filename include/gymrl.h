@@ -198,6 +198,21 @@ int gymrl_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const i
                                 float* dlogits_out, float* dvalue_out,
                                 double* metrics_sum, void* workspace, void* stream);
 
+/*
+ * P6/P7: minibatch staging — ppo_lunarlander.py:238-272 (lists -> tensors, shuffled
+ * index slices).  gymrl_pack_rollout writes one 64-B record per transition
+ *   packed[i] = { obs[i][0..D) (zero padded to 12) | act bits | logp_old | adv | ret }
+ * once per rollout; gymrl_gather_minibatch then fetches ONE random cache line per
+ * sample (idx i32[B] = a slice of the epoch's permutation) into contiguous rows
+ * obs_out f32[B,D], act_out i32[B], logp_out/adv_out/ret_out f32[B].  D <= 12.
+ */
+int gymrl_pack_rollout(const float* obs, const int32_t* act, const float* logp,
+                       const float* adv, const float* ret, int64_t M, int obs_dim,
+                       float* packed, void* stream);
+int gymrl_gather_minibatch(const float* packed, const int32_t* idx, int B, int obs_dim,
+                           float* obs_out, int32_t* act_out, float* logp_out,
+                           float* adv_out, float* ret_out, void* stream);
+
 /* ------------------------------------------------------------ optimiser --- */
 /*
  * O1 / D4 / R4: clip_grad_norm_ + Adam on ONE flat fp32 parameter buffer —

@@ -187,6 +187,24 @@ def ppo_full_loss_fwd_bwd(logits, value, act, logp_old, ent_old, adv, ret, cfg, 
     return dl, dv, met
 
 
+def pack_rollout(obs, act, logp, adv, ret):
+    """ppo_lunarlander.py:238-250 staging as one 64-B record per transition (numpy restatement)."""
+    obs = _f32(obs)
+    M, D = obs.shape
+    rec = np.zeros((M, 16), np.float32)
+    rec[:, :D] = obs
+    rec[:, 12] = _i32(act).view(np.float32)
+    rec[:, 13], rec[:, 14], rec[:, 15] = _f32(logp), _f32(adv), _f32(ret)
+    return rec
+
+
+def gather_minibatch(packed, idx, obs_dim):
+    """ppo_lunarlander.py:264-272: rows of the shuffled index slice."""
+    r = packed[np.asarray(idx, np.int64)]
+    return (np.ascontiguousarray(r[:, :obs_dim]), np.ascontiguousarray(r[:, 12]).view(np.int32), r[:, 13].copy(),
+            r[:, 14].copy(), r[:, 15].copy())
+
+
 # -------------------------------------------------------------- optimiser ---
 def sqnorm(g, grad_scale=1.0):
     g = _f32(g).ravel()

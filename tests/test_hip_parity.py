@@ -326,3 +326,20 @@ def test_lunarlander_vs_oracle_bit_exact(dev, oracle):
             assert np.allclose(ep_ret.cpu().numpy()[d], r["ep_ret"][d], rtol=1e-6)
         o = r["obs"]
     assert landed > 20 and crashed > 20          # both terminal kinds were exercised
+
+
+@pytest.mark.parametrize("D", [3, 4, 8])
+def test_pack_and_gather_minibatch(dev, oracle, D):
+    from gymrl_amd import ops
+    rng = np.random.default_rng(30 + D)
+    M, B = 10007, 3001
+    obs = rng.normal(size=(M, D)).astype(np.float32)
+    act = rng.integers(0, 4, size=M).astype(np.int32)
+    logp, adv, ret = (rng.normal(size=M).astype(np.float32) for _ in range(3))
+    idx = rng.permutation(M)[:B].astype(np.int32)
+    rec_ref = oracle.pack_rollout(obs, act, logp, adv, ret)
+    rec = ops.pack_rollout(t(obs, dev), t(act, dev), t(logp, dev), t(adv, dev), t(ret, dev))
+    assert np.array_equal(rec.cpu().numpy().view(np.uint32), rec_ref.view(np.uint32))     # byte moves: bit-exact
+    got = ops.gather_minibatch(rec, t(idx, dev), D)
+    for g, r in zip(got, oracle.gather_minibatch(rec_ref, idx, D)):
+        assert np.array_equal(g.cpu().numpy(), r)
