@@ -8,6 +8,10 @@ import ctypes as C
 import os
 import subprocess
 
+# PyTorch-ROCm owns device memory and streams; importing it FIRST makes the process use
+# one HIP runtime (torch's bundled libamdhip64) for both torch and this library.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgymrl_hip.so")
 CSRC = os.path.join(_HERE, "csrc")

@@ -194,6 +194,7 @@ class PPOTrainer:
         self._perm_gen = torch.Generator(device=self.device)
         self._perm_gen.manual_seed(self.base_seed * 7919 + 13 + self.rank)
         self._loss_cfg = (config.clip_eps, config.dual_clip, config.value_coef, config.entropy_coef)
+        self._finished = None
         self._packed = None      # [T*N, 16] packed rollout records (allocated on first update)
         mb = self._minibatch_size_for(T * N)
         self._stage = (torch.empty(mb, state_dim, device=self.device), torch.empty(mb, dtype=torch.int32, device=self.device),
@@ -249,11 +250,18 @@ class PPOTrainer:
         self.step_count += b.T * b.N
         self.rollout_count += 1
         self._next_value.copy_(self.model.get_value(b.states[b.T]))
-        # :220-221 episode_rewards.append on done — one compaction + one D2H per rollout
-        finished = b.ep_returns[b.dones.bool()]
-        for r in finished[-self.episode_rewards.maxlen:].tolist():
-            self.episode_rewards.append(r)
+        # :220-221 episode_rewards.append on done: compacted on the device here, read back by
+        # _drain_episode_returns() once the update's kernels are queued (no sync in the rollout)
+        self._finished = True
         return self._next_value
+
+    def _drain_episode_returns(self):
+        if self._finished:
+            b = self.buffer
+            done = b.ep_returns[b.dones.bool()][-self.episode_rewards.maxlen:]   # (t, n) order == time order
+            for r in done.tolist():
+                self.episode_rewards.append(r)
+            self._finished = None
 
     # --------------------------------------------------------------- update --
     def _minibatch_size_for(self, total):
@@ -318,6 +326,7 @@ class PPOTrainer:
                     tm.stop("adam_step", self.flat_params.numel())
                 sizes.append(B)
                 row += 1
+        self._drain_episode_returns()
         m = metrics.cpu().numpy() / np.asarray(sizes, np.float64)[:, None]   # the one host sync of the update
         m = m.mean(axis=0)
         return {"policy_loss": m[0], "value_loss": m[1], "entropy": m[2], "clip_frac": m[3], "approx_kl": m[4]}

@@ -89,6 +89,7 @@ typedef struct {
   uint32_t episode;
 } lander_t;
 
+long long orc_lunar_dbg_pos_iters = 0;   /* debug counter: position sweeps executed */
 static float cross2(float ax, float ay, float bx, float by) { return ax * by - ay * bx; }
 static float dot2(float ax, float ay, float bx, float by) { return ax * bx + ay * by; }
 static float clampf(float x, float lo, float hi) { return fmaxf(lo, fminf(x, hi)); }
@@ -545,6 +546,7 @@ static void world_step(lander_t* W, int action, float disp0, float disp1, float 
 
   int position_solved = 0;
   for (int it = 0; it < POS_ITERS; ++it) {
+    orc_lunar_dbg_pos_iters++;
     float min_sep = 0.0f;
     for (int ob = 0; ob < 3; ++ob) {                      /* b2ContactSolver::SolvePositionConstraints */
       int b = ORDER[ob];
