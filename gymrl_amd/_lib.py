@@ -29,6 +29,11 @@ SYMBOLS = [
     "gymrl_ppo_loss_fwd_bwd", "gymrl_ppo_full_loss_fwd_bwd",
     "gymrl_pack_rollout", "gymrl_gather_minibatch",
     "gymrl_sqnorm", "gymrl_adam_step", "gymrl_soft_update",
+    "gymrl_replay_append", "gymrl_replay_gather", "gymrl_uniform_indices", "gymrl_nstep_push",
+    "gymrl_per_workspace_bytes", "gymrl_per_update", "gymrl_per_max_leaf", "gymrl_per_priorities",
+    "gymrl_per_sample", "gymrl_noisy_noise", "gymrl_epsilon_greedy", "gymrl_dqn_td_loss",
+    "gymrl_sac_sample_fwd", "gymrl_sac_sample_bwd", "gymrl_sac_target", "gymrl_sac_critic_loss",
+    "gymrl_sac_actor_loss", "gymrl_sac_alpha_step", "gymrl_running_norm", "gymrl_reward_scaling",
 ]
 
 
@@ -62,6 +67,7 @@ def lib():
         L.gymrl_env_state_bytes.restype = C.c_size_t
         L.gymrl_gae_workspace_bytes.restype = C.c_size_t
         L.gymrl_reduce_workspace_bytes.restype = C.c_size_t
+        L.gymrl_per_workspace_bytes.restype = C.c_size_t
         for name in SYMBOLS:
             if name.endswith("_bytes"):
                 continue

@@ -1,0 +1,292 @@
+// per.hip — prioritised replay sum-tree on the GPU (float64, reference op order).
+//
+//   S1  SumTree.update / get_index / priority_max   rainbow_dqn_cartpole.py:116-152
+//   S3  PrioritizedNStepBuffer.sample               :220-256
+//   S4  update_priorities                           :258-261
+//   S1'-S4' variant B                               ddqn_per_cartpole.py:67-147
+//
+// The reference's tree is updated incrementally (every ancestor += p - old leaf), one
+// element after another, so its float64 contents depend on the ORDER of additions.  The
+// batched update keeps that order per node: pass 1 resolves duplicate leaves (a later
+// element sees the earlier element's priority as "old") and writes leaves last-writer-
+// wins; pass 2 gives one workgroup to each tree depth, where every node's additions are
+// applied by the first batch element that touches it, walking the batch in order.
+// Nodes are independent of each other, so the result equals the sequential loop bit for
+// bit.  Sampling is a pointer chase (ceil(log2 cap)+1 dependent f64 loads per draw):
+// latency-bound, one lane per draw, upper tree levels stay L2-resident.
+#include "gymrl_device.hpp"
+#include "../../include/gymrl.h"
+
+using namespace gymrl;
+
+namespace {
+
+constexpr int kBlock = 256;
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ int depth_of(int64_t t) { return 63 - __clzll((unsigned long long)(t + 1)); }
+
+// workspace layout: [leaf i64[B]] [change f64[B]] [scratch f64[...]]
+struct Ws {
+  int64_t* leaf; double* change; double* partial;
+  __host__ __device__ Ws(void* p, int B) {
+    char* c = (char*)p;
+    leaf = (int64_t*)c; c += sizeof(int64_t) * (size_t)B;
+    change = (double*)c; c += sizeof(double) * (size_t)B;
+    partial = (double*)c;
+  }
+};
+
+__device__ __forceinline__ double prio_of(const double* prio, const double* ps_dev, double ps, int i) {
+  return prio ? prio[i] : (ps_dev ? ps_dev[0] : ps);
+}
+
+// pass 1 (single workgroup): leaves + per-element change.
+__global__ __launch_bounds__(1024) void per_leaf_kernel(double* __restrict__ tree, int64_t cap,
+                                                        const int32_t* __restrict__ idx,
+                                                        int64_t idx_start, int idx_is_tree,
+                                                        const double* __restrict__ prio,
+                                                        const double* __restrict__ ps_dev, double ps,
+                                                        int B, int64_t* __restrict__ leaf_out,
+                                                        double* __restrict__ change_out) {
+  // phase A: leaf index of every element
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    int64_t leaf;
+    if (idx) leaf = idx_is_tree ? (int64_t)idx[i] : (int64_t)idx[i] + cap - 1;
+    else leaf = (idx_start + i) % cap + cap - 1;
+    leaf_out[i] = leaf;
+  }
+  __syncthreads();
+  // phase B: change_i = p_i - (value of the leaf just before element i is applied)
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    const int64_t leaf = leaf_out[i];
+    double prev = tree[leaf];
+    if (idx) {   // duplicates possible: the latest earlier element on the same leaf
+      for (int j = i - 1; j >= 0; --j)
+        if (leaf_out[j] == leaf) { prev = prio_of(prio, ps_dev, ps, j); break; }
+    }
+    change_out[i] = prio_of(prio, ps_dev, ps, i) - prev;
+  }
+  __syncthreads();
+  // phase C: last writer wins
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    const int64_t leaf = leaf_out[i];
+    bool last = true;
+    if (idx) {
+      for (int j = i + 1; j < B; ++j)
+        if (leaf_out[j] == leaf) { last = false; break; }
+    }
+    if (last) tree[leaf] = prio_of(prio, ps_dev, ps, i);
+  }
+}
+
+// pass 2: blockIdx.x = node depth d (0 = root).  A node's additions happen in batch order.
+__global__ __launch_bounds__(1024) void per_ancestor_kernel(double* __restrict__ tree,
+                                                            const int64_t* __restrict__ leaf,
+                                                            const double* __restrict__ change, int B,
+                                                            int sorted) {
+  const int d = blockIdx.x;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    const int64_t lf = leaf[i];
+    const int L = depth_of(lf);
+    if (L <= d) continue;                                  // this element has no ancestor at depth d
+    const int64_t node = ((lf + 1) >> (L - d)) - 1;
+    // leader = first batch element reaching this node
+    bool leader = true;
+    if (sorted) {
+      if (i > 0) {
+        const int64_t lp = leaf[i - 1];
+        const int Lp = depth_of(lp);
+        leader = !(Lp > d && (((lp + 1) >> (Lp - d)) - 1) == node);
+      }
+    } else {
+      for (int j = 0; j < i; ++j) {
+        const int64_t lj = leaf[j];
+        const int Lj = depth_of(lj);
+        if (Lj > d && (((lj + 1) >> (Lj - d)) - 1) == node) { leader = false; break; }
+      }
+    }
+    if (!leader) continue;
+    double acc = tree[node];
+    for (int j = i; j < B; ++j) {
+      const int64_t lj = leaf[j];
+      const int Lj = depth_of(lj);
+      const bool same = Lj > d && (((lj + 1) >> (Lj - d)) - 1) == node;
+      if (same) acc += change[j];
+      else if (sorted) break;                              // consecutive rows: a node's elements are one run
+    }
+    tree[node] = acc;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void max_leaf_partial_kernel(const double* __restrict__ tree,
+                                                                  int64_t cap,
+                                                                  double* __restrict__ partial) {
+  double m = -1.0e308;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < cap; i += (int64_t)gridDim.x * kBlock)
+    m = fmax(m, tree[cap - 1 + i]);
+  __shared__ double sm[kBlock];
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+__global__ __launch_bounds__(kBlock) void max_final_kernel(const double* __restrict__ partial, int n,
+                                                           double* __restrict__ out) {
+  double m = -1.0e308;
+  for (int i = threadIdx.x; i < n; i += kBlock) m = fmax(m, partial[i]);
+  __shared__ double sm[kBlock];
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sm[0];
+}
+
+__global__ __launch_bounds__(kBlock) void per_priorities_kernel(const float* __restrict__ td, int B,
+                                                                double alpha, double eps, double clip,
+                                                                double* __restrict__ out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  // float32 arithmetic like the reference: np.abs(f32) + python float and ** python float stay
+  // float32 under NumPy >= 2; x**a as exp(a*log x) with the reproducible f32 kernels
+  float e = fabsf(td[i]) + (float)eps;
+  if (clip > 0.0 && e > (float)clip) e = (float)clip;
+  out[i] = (double)det_expf((float)alpha * det_logf(e));
+}
+
+// stratified descent + un-normalised IS weights; per-block max of the weights.
+__global__ __launch_bounds__(kBlock) void per_sample_kernel(
+    const double* __restrict__ tree, int64_t cap, const double* __restrict__ u, uint64_t seed,
+    uint64_t counter, int B, int64_t size, double beta, int variant_b, int32_t* __restrict__ idx_out,
+    double* __restrict__ prio_out, float* __restrict__ w32, double* __restrict__ w64,
+    double* __restrict__ blockmax) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const int64_t tcap = 2 * cap - 1;
+  double w = 0.0;
+  if (i < B) {
+    const double total = tree[0];
+    const double segment = total / (double)B;
+    const double a = segment * (double)i, b = segment * (double)(i + 1);
+    double ui;
+    if (u) ui = u[i];
+    else {
+      const u32x4 r = philox4x32(seed, (uint32_t)i, 1u, (uint32_t)counter,
+                                 RNG_REPLAY | (uint32_t)((counter >> 32) & 0x0FFFFFFFu));
+      ui = u01d(r.x, r.y);
+    }
+    double v = a + (b - a) * ui;                          // np.random.uniform(a, b)
+    int64_t p = 0;
+    while (true) {
+      const int64_t left = 2 * p + 1;
+      if (left >= tcap) break;
+      const double lv = tree[left];
+      if (v <= lv) p = left;
+      else { v -= lv; p = left + 1; }
+    }
+    const double pr = tree[p];
+    idx_out[i] = (int32_t)(variant_b ? p : p - cap + 1);
+    if (prio_out) prio_out[i] = pr;
+    const double prob = pr / total;
+    const double wd = pow((double)size * prob, -beta);
+    if (variant_b) { w64[i] = wd; w = wd; }
+    else { const float wf = (float)wd; w32[i] = wf; w = (double)wf; }   // is_weight is a float32 tensor (:224-226)
+  }
+  __shared__ double sm[kBlock];
+  sm[threadIdx.x] = w;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) blockmax[blockIdx.x] = sm[0];
+}
+
+__global__ __launch_bounds__(kBlock) void per_normalize_kernel(float* __restrict__ w32,
+                                                               const double* __restrict__ w64, int B,
+                                                               const double* __restrict__ blockmax,
+                                                               int nblocks, int variant_b) {
+  double m = 0.0;
+  for (int k = 0; k < nblocks; ++k) m = fmax(m, blockmax[k]);
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  if (variant_b) w32[i] = (float)(w64[i] / m);            // float64 division, then the float32 tensor cast
+  else w32[i] = w32[i] / (float)m;                        // is_weight /= is_weight.max() in float32 (:241)
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t gymrl_per_workspace_bytes(int B) {
+  if (B < 0) return 0;
+  const size_t nb = (size_t)cdiv(B > 0 ? B : 1, kBlock);
+  return (sizeof(int64_t) + sizeof(double)) * (size_t)B + sizeof(double) * ((size_t)B + nb + 4096) + 256;
+}
+
+int gymrl_per_update(double* tree, int64_t cap, const int32_t* idx, int64_t idx_start,
+                     int idx_is_tree, const double* prio, const double* prio_scalar_dev,
+                     double prio_scalar, int B, void* workspace, void* stream_) {
+  if (!tree || !workspace || cap <= 0 || B < 0 || (!idx && (idx_start < 0 || B > cap))) return -22;
+  if (B == 0) return 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  Ws ws(workspace, B);
+  hipLaunchKernelGGL(per_leaf_kernel, dim3(1), dim3(1024), 0, stream, tree, cap, idx, idx_start,
+                     idx_is_tree, prio, prio_scalar_dev, prio_scalar, B, ws.leaf, ws.change);
+  // deepest leaf depth = depth of the last tree slot; ancestors live at depths 0 .. that-1
+  int depth = 0;
+  { int64_t t = 2 * cap - 2; while (t > 0) { t = (t - 1) / 2; ++depth; } }
+  // consecutive rows form one run per node only when all leaves share a depth (cap = 2^k) and
+  // the row range does not wrap; otherwise the general ordered search is used
+  const int sorted = (!idx && (cap & (cap - 1)) == 0 && (idx_start % cap) + B <= cap) ? 1 : 0;
+  if (depth > 0)
+    hipLaunchKernelGGL(per_ancestor_kernel, dim3(depth), dim3(1024), 0, stream, tree, ws.leaf, ws.change,
+                       B, sorted);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_per_max_leaf(const double* tree, int64_t cap, double* out, void* workspace, void* stream_) {
+  if (!tree || !out || !workspace || cap <= 0) return -22;
+  hipStream_t stream = (hipStream_t)stream_;
+  int nb = cdiv(cap, (int64_t)kBlock * 8);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(max_leaf_partial_kernel, dim3(nb), dim3(kBlock), 0, stream, tree, cap, (double*)workspace);
+  hipLaunchKernelGGL(max_final_kernel, dim3(1), dim3(kBlock), 0, stream, (const double*)workspace, nb, out);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_per_priorities(const float* td, int B, double alpha, double eps, double clip, double* prio_out,
+                         void* stream_) {
+  if (!td || !prio_out || B < 0) return -22;
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(per_priorities_kernel, dim3(cdiv(B, kBlock)), dim3(kBlock), 0, (hipStream_t)stream_,
+                     td, B, alpha, eps, clip, prio_out);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_per_sample(const double* tree, int64_t cap, const double* u, uint64_t seed, uint64_t counter,
+                     int B, int64_t size, double beta, int variant_b, int32_t* idx_out, double* prio_out,
+                     float* w_out, void* workspace, void* stream_) {
+  if (!tree || !idx_out || !w_out || !workspace || cap <= 0 || B <= 0 || size <= 0) return -22;
+  hipStream_t stream = (hipStream_t)stream_;
+  Ws ws(workspace, B);
+  const int nb = cdiv(B, kBlock);
+  double* w64 = ws.change;                 // reuse: f64[B]
+  double* bmax = ws.partial;               // f64[nb]
+  hipLaunchKernelGGL(per_sample_kernel, dim3(nb), dim3(kBlock), 0, stream, tree, cap, u, seed, counter, B,
+                     size, beta, variant_b, idx_out, prio_out, w_out, w64, bmax);
+  hipLaunchKernelGGL(per_normalize_kernel, dim3(nb), dim3(kBlock), 0, stream, w_out, w64, B, bmax, nb,
+                     variant_b);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

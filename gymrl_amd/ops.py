@@ -249,3 +249,190 @@ def env_step(kind, state, n, seed, env_id0, action, obs_out, rew_out, terminated
                                _ptr(truncated_out, torch.uint8), _ptr(done_out, torch.uint8, True),
                                _ptr(ep_ret_out, torch.float32, True), _ptr(ep_len_out, torch.int32, True),
                                _ptr(ep_stats, torch.float64, True), _stream()), "gymrl_env_step")
+
+
+# ============================================================== off-policy ===
+def replay_append(ring, cursor, src_state, src_action, src_reward, src_next_state, src_flag):
+    """D2/A3: write n rows at (cursor + i) % cap.  ring = (state, action_words, reward, next_state, flag)."""
+    state, action, reward, next_state, flag = ring
+    cap, D = state.shape
+    AW = action.shape[1]
+    n = src_reward.numel()
+    check(lib().gymrl_replay_append(_ptr(state, torch.float32), _ptr(action), _ptr(reward, torch.float32),
+                                    _ptr(next_state, torch.float32), _ptr(flag, torch.uint8), C.c_int64(cap),
+                                    C.c_int64(cursor), C.c_int(D), C.c_int(AW), C.c_int(n),
+                                    _ptr(src_state, torch.float32), _ptr(src_action), _ptr(src_reward, torch.float32),
+                                    _ptr(src_next_state, torch.float32), _ptr(src_flag, torch.uint8), _stream()),
+          "gymrl_replay_append")
+
+
+def replay_gather(ring, idx, action_dtype=torch.int32):
+    """rows idx -> (state[B,D], action[B,AW], reward[B], next_state[B,D], flag f32[B])."""
+    state, action, reward, next_state, flag = ring
+    cap, D = state.shape
+    AW = action.shape[1]
+    B, dev = idx.numel(), state.device
+    out = (torch.empty(B, D, device=dev), torch.empty(B, AW, dtype=action_dtype, device=dev),
+           torch.empty(B, device=dev), torch.empty(B, D, device=dev), torch.empty(B, device=dev))
+    check(lib().gymrl_replay_gather(_ptr(state, torch.float32), _ptr(action), _ptr(reward, torch.float32),
+                                    _ptr(next_state, torch.float32), _ptr(flag, torch.uint8), _ptr(idx, torch.int32),
+                                    C.c_int(B), C.c_int(D), C.c_int(AW), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
+                                    _ptr(out[3]), _ptr(out[4]), _stream()), "gymrl_replay_gather")
+    return out
+
+
+def uniform_indices(seed, counter, size, B, device):
+    idx = torch.empty(B, dtype=torch.int32, device=device)
+    check(lib().gymrl_uniform_indices(C.c_uint64(seed), C.c_uint64(counter), C.c_int64(size), C.c_int(B),
+                                      _ptr(idx), _stream()), "gymrl_uniform_indices")
+    return idx
+
+
+def nstep_push(win, n_steps, pushes, gamma, obs, action, reward, next_obs, terminal, done, ring, cursor):
+    """S2.  win = (w_state[n,N,D], w_action i32[n,N], w_reward[n,N], w_next[n,N,D], w_terminal u8, w_done u8).
+    Returns True when N rows were emitted into the ring at (cursor + env) % cap."""
+    w_state, w_action, w_reward, w_next, w_term, w_done = win
+    state, act_w, rew, nxt, flag = ring
+    N, D = obs.shape
+    rc = lib().gymrl_nstep_push(_ptr(w_state, torch.float32), _ptr(w_action, torch.int32), _ptr(w_reward, torch.float32),
+                                _ptr(w_next, torch.float32), _ptr(w_term, torch.uint8), _ptr(w_done, torch.uint8),
+                                C.c_int(n_steps), C.c_int64(pushes), C.c_int(N), C.c_int(D), C.c_double(gamma),
+                                _ptr(obs, torch.float32), _ptr(action, torch.int32), _ptr(reward, torch.float32),
+                                _ptr(next_obs, torch.float32), _ptr(terminal, torch.uint8), _ptr(done, torch.uint8),
+                                _ptr(state, torch.float32), _ptr(act_w), _ptr(rew, torch.float32),
+                                _ptr(nxt, torch.float32), _ptr(flag, torch.uint8), C.c_int64(state.shape[0]),
+                                C.c_int64(cursor), _stream())
+    if rc < 0:
+        check(rc, "gymrl_nstep_push")
+    return rc == 1
+
+
+def per_workspace(B, device):
+    return torch.empty(int(lib().gymrl_per_workspace_bytes(C.c_int(B))), dtype=torch.uint8, device=device)
+
+
+def per_update(tree, cap, B, workspace, idx=None, idx_start=0, idx_is_tree=False, prio=None, prio_scalar_dev=None,
+               prio_scalar=0.0):
+    check(lib().gymrl_per_update(_ptr(tree, torch.float64), C.c_int64(cap), _ptr(idx, torch.int32, True),
+                                 C.c_int64(idx_start), C.c_int(int(idx_is_tree)), _ptr(prio, torch.float64, True),
+                                 _ptr(prio_scalar_dev, torch.float64, True), C.c_double(prio_scalar), C.c_int(B),
+                                 _ptr(workspace), _stream()), "gymrl_per_update")
+
+
+def per_max_leaf(tree, cap, out, workspace):
+    check(lib().gymrl_per_max_leaf(_ptr(tree, torch.float64), C.c_int64(cap), _ptr(out, torch.float64),
+                                   _ptr(workspace), _stream()), "gymrl_per_max_leaf")
+    return out
+
+
+def per_priorities(td, alpha, eps, clip=0.0, out=None):
+    out = torch.empty(td.numel(), dtype=torch.float64, device=td.device) if out is None else out
+    check(lib().gymrl_per_priorities(_ptr(td, torch.float32), C.c_int(td.numel()), C.c_double(alpha), C.c_double(eps),
+                                     C.c_double(clip), _ptr(out, torch.float64), _stream()), "gymrl_per_priorities")
+    return out
+
+
+def per_sample(tree, cap, B, size, beta, workspace, u=None, seed=0, counter=0, variant_b=False):
+    dev = tree.device
+    idx = torch.empty(B, dtype=torch.int32, device=dev)
+    prio = torch.empty(B, dtype=torch.float64, device=dev)
+    w = torch.empty(B, dtype=torch.float32, device=dev)
+    check(lib().gymrl_per_sample(_ptr(tree, torch.float64), C.c_int64(cap), _ptr(u, torch.float64, True),
+                                 C.c_uint64(seed), C.c_uint64(counter), C.c_int(B), C.c_int64(size), C.c_double(beta),
+                                 C.c_int(int(variant_b)), _ptr(idx), _ptr(prio), _ptr(w), _ptr(workspace), _stream()),
+          "gymrl_per_sample")
+    return idx, prio, w
+
+
+def noisy_noise(nin, nout, w_eps, b_eps, eps_in=None, eps_out=None, seed=0, counter=0):
+    check(lib().gymrl_noisy_noise(_ptr(eps_in, torch.float32, True), _ptr(eps_out, torch.float32, True),
+                                  C.c_uint64(seed), C.c_uint64(counter), C.c_int(nin), C.c_int(nout),
+                                  _ptr(w_eps, torch.float32), _ptr(b_eps, torch.float32), _stream()), "gymrl_noisy_noise")
+
+
+def epsilon_greedy(q, epsilon, u=None, seed=0, counter=0, env_id0=0, act_out=None):
+    n, A = q.shape
+    act_out = torch.empty(n, dtype=torch.int32, device=q.device) if act_out is None else act_out
+    check(lib().gymrl_epsilon_greedy(_ptr(q, torch.float32), _ptr(u, torch.float32, True), C.c_uint64(seed),
+                                     C.c_uint64(counter), C.c_int64(env_id0), C.c_int(n), C.c_int(A),
+                                     C.c_float(epsilon), _ptr(act_out, torch.int32), _stream()), "gymrl_epsilon_greedy")
+    return act_out
+
+
+def dqn_td_loss(q, q_next_target, act, rew, flag, gamma_n, q_next_online=None, w=None, loss_sum=None):
+    B, A = q.shape
+    td = torch.empty(B, device=q.device)
+    dq = torch.empty_like(q)
+    ws = _reduce_ws(q.device) if loss_sum is not None else None
+    check(lib().gymrl_dqn_td_loss(_ptr(q, torch.float32), _ptr(q_next_online, torch.float32, True),
+                                  _ptr(q_next_target, torch.float32), _ptr(act, torch.int32), _ptr(rew, torch.float32),
+                                  _ptr(flag, torch.float32), _ptr(w, torch.float32, True), C.c_int(B), C.c_int(A),
+                                  C.c_double(gamma_n), _ptr(td), _ptr(dq), _ptr(loss_sum, torch.float64, True),
+                                  _ptr(ws, None, True), _stream()), "gymrl_dqn_td_loss")
+    return td, dq
+
+
+def sac_sample_fwd(mean, log_std, eps, bound):
+    B, A = mean.shape
+    action, logp = torch.empty_like(mean), torch.empty(B, device=mean.device)
+    check(lib().gymrl_sac_sample_fwd(_ptr(mean, torch.float32), _ptr(log_std, torch.float32), _ptr(eps, torch.float32),
+                                     C.c_int(B), C.c_int(A), C.c_float(bound), _ptr(action), _ptr(logp), _stream()),
+          "gymrl_sac_sample_fwd")
+    return action, logp
+
+
+def sac_sample_bwd(mean, log_std, eps, d_action, d_logp, bound):
+    B, A = mean.shape
+    dm, ds = torch.empty_like(mean), torch.empty_like(mean)
+    check(lib().gymrl_sac_sample_bwd(_ptr(mean, torch.float32), _ptr(log_std, torch.float32), _ptr(eps, torch.float32),
+                                     _ptr(d_action, torch.float32, True), _ptr(d_logp, torch.float32, True), C.c_int(B),
+                                     C.c_int(A), C.c_float(bound), _ptr(dm), _ptr(ds), _stream()), "gymrl_sac_sample_bwd")
+    return dm, ds
+
+
+def sac_target(rew, done, q1n, q2n, logp_n, log_alpha, gamma):
+    y = torch.empty_like(rew)
+    check(lib().gymrl_sac_target(_ptr(rew, torch.float32), _ptr(done, torch.float32), _ptr(q1n, torch.float32),
+                                 _ptr(q2n, torch.float32), _ptr(logp_n, torch.float32), _ptr(log_alpha, torch.float64),
+                                 C.c_int(rew.numel()), C.c_double(gamma), _ptr(y), _stream()), "gymrl_sac_target")
+    return y
+
+
+def sac_critic_loss(q1, q2, y, sums):
+    d1, d2 = torch.empty_like(q1), torch.empty_like(q2)
+    check(lib().gymrl_sac_critic_loss(_ptr(q1, torch.float32), _ptr(q2, torch.float32), _ptr(y, torch.float32),
+                                      C.c_int(q1.numel()), _ptr(d1), _ptr(d2), _ptr(sums, torch.float64),
+                                      _ptr(_reduce_ws(q1.device)), _stream()), "gymrl_sac_critic_loss")
+    return d1, d2
+
+
+def sac_actor_loss(logp, q1, q2, log_alpha, target_entropy, sums):
+    dl, d1, d2 = torch.empty_like(logp), torch.empty_like(q1), torch.empty_like(q2)
+    check(lib().gymrl_sac_actor_loss(_ptr(logp, torch.float32), _ptr(q1, torch.float32), _ptr(q2, torch.float32),
+                                     _ptr(log_alpha, torch.float64), C.c_int(logp.numel()), C.c_double(target_entropy),
+                                     _ptr(dl), _ptr(d1), _ptr(d2), _ptr(sums, torch.float64),
+                                     _ptr(_reduce_ws(q1.device)), _stream()), "gymrl_sac_actor_loss")
+    return dl, d1, d2
+
+
+def sac_alpha_step(log_alpha, m, v, sums, B, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, loss_out=None):
+    check(lib().gymrl_sac_alpha_step(_ptr(log_alpha, torch.float64), _ptr(m, torch.float64), _ptr(v, torch.float64),
+                                     _ptr(sums, torch.float64), C.c_int(B), C.c_double(lr), C.c_double(beta1),
+                                     C.c_double(beta2), C.c_double(eps), C.c_int64(step),
+                                     _ptr(loss_out, torch.float64, True), _stream()), "gymrl_sac_alpha_step")
+
+
+def running_norm(x, stats, update=True, out=None):
+    N, D = x.shape
+    out = torch.empty_like(x) if out is None else out
+    check(lib().gymrl_running_norm(_ptr(x, torch.float32), C.c_int(N), C.c_int(D), _ptr(stats, torch.float64),
+                                   C.c_int(int(update)), _ptr(out, torch.float32), _stream()), "gymrl_running_norm")
+    return out
+
+
+def reward_scaling(r, done, gamma, R, stats, out=None):
+    out = torch.empty_like(r) if out is None else out
+    check(lib().gymrl_reward_scaling(_ptr(r, torch.float32), _ptr(done, torch.uint8, True), C.c_int(r.numel()),
+                                     C.c_double(gamma), _ptr(R, torch.float64), _ptr(stats, torch.float64),
+                                     _ptr(out, torch.float32), _stream()), "gymrl_reward_scaling")
+    return out

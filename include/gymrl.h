@@ -240,6 +240,163 @@ int gymrl_adam_step(float* p, float* g, float* m, float* v, int64_t n,
 int gymrl_soft_update(float* target, const float* source, int64_t n, double tau,
                       void* stream);
 
+/* ========================================================= off-policy ===== */
+/*
+ * D2 / A3 / S2: device-resident replay ring, SoA rows [cap]:
+ *   state f32[cap,D], action u32[cap,AW] (raw 4-byte words: i32 discrete action or
+ *   f32 continuous components), reward f32[cap], next_state f32[cap,D], flag u8[cap]
+ *   (done for DQN/SAC — dqn_cartpole.py:183, sac_pendulum.py:283; terminal for
+ *   Rainbow — rainbow_dqn_cartpole.py:376-380).
+ * Replaces ReplayBuffer.push/sample (dqn_cartpole.py:68-88, sac_pendulum.py:128-148)
+ * and utils/buffer.py:105-135.  append writes rows (cursor + i) % cap, i < n.
+ */
+int gymrl_replay_append(float* state, uint32_t* action, float* reward, float* next_state,
+                        uint8_t* flag, int64_t cap, int64_t cursor, int D, int AW, int n,
+                        const float* src_state, const void* src_action, const float* src_reward,
+                        const float* src_next_state, const uint8_t* src_flag, void* stream);
+/* rows idx[b] -> contiguous batch (torch.tensor(np.array(...)) of dqn_cartpole.py:143-155) */
+int gymrl_replay_gather(const float* state, const uint32_t* action, const float* reward,
+                        const float* next_state, const uint8_t* flag, const int32_t* idx, int B,
+                        int D, int AW, float* state_out, void* action_out, float* reward_out,
+                        float* next_state_out, float* flag_out, void* stream);
+/* idx[b] = floor(U[0,1) * size), Philox(seed, counter, b) — the vectorised stand-in for
+ * random.sample (dqn_cartpole.py:76; with replacement). */
+int gymrl_uniform_indices(uint64_t seed, uint64_t counter, int64_t size, int B,
+                          int32_t* idx_out, void* stream);
+
+/*
+ * S2: PrioritizedNStepBuffer.store_transition + _get_n_step_transition —
+ * rainbow_dqn_cartpole.py:179-218 — for N envs at once.  Each env keeps its own
+ * n-deep window (never cleared at episode end, :163) in caller-owned SoA arrays
+ *   w_state f32[n,N,D], w_action i32[n,N], w_reward f32[n,N], w_next f32[n,N,D],
+ *   w_terminal u8[n,N], w_done u8[n,N];
+ * `pushes` = number of calls so far (slot = pushes % n).  When pushes + 1 >= n every env
+ * emits one n-step row into the replay ring at (cursor + env) % cap:
+ *   R = sum via R = r_i + gamma*(1-d_i)*R (float64, newest to oldest, :212-214),
+ *   (next_state, terminal) from the newest entry unless some d_i, then from the
+ *   EARLIEST done (:215-216).  Returns 1 if rows were emitted, 0 if still filling, <0 error.
+ */
+int gymrl_nstep_push(float* w_state, int32_t* w_action, float* w_reward, float* w_next,
+                     uint8_t* w_terminal, uint8_t* w_done, int n_steps, int64_t pushes,
+                     int N, int D, double gamma,
+                     const float* obs, const int32_t* action, const float* reward,
+                     const float* next_obs, const uint8_t* terminal, const uint8_t* done,
+                     float* r_state, uint32_t* r_action, float* r_reward, float* r_next,
+                     uint8_t* r_flag, int64_t cap, int64_t cursor, void* stream);
+
+/*
+ * S1 / S1': SumTree — rainbow_dqn_cartpole.py:116-152 (variant A) and
+ * ddqn_per_cartpole.py:67-104 (variant B).  tree f64[2*cap-1], leaf i at i+cap-1;
+ * cap need not be a power of two (the array rule is followed literally).
+ *   gymrl_per_update: the reference's `for idx, p in zip(...): tree.update(idx, p)`
+ *     (:258-261 / :146-147): leaf := p, every ancestor += (p - old leaf), applied in
+ *     batch order — duplicates resolve last-writer-wins and every node receives its
+ *     additions in the reference's order, so the float64 array matches bit for bit.
+ *     idx NULL -> consecutive rows (idx_start + b) % cap (the store path :201-205).
+ *     idx_is_tree != 0 -> idx are tree indices (variant B, :75-80).
+ *     prio f64[B], or prio NULL and prio_scalar for all (store: 1.0 or priority_max).
+ *     workspace >= gymrl_per_workspace_bytes(B).
+ *   gymrl_per_max_leaf: priority_max (:151-152) = max over all leaves -> out f64[1].
+ *   gymrl_per_priorities: p = min(|td| + eps, clip)^alpha in float64 (:259 eps 0.01,
+ *     clip inf; ddqn_per_cartpole.py:142-145 eps 1e-4, clip 1.0).
+ *   gymrl_per_sample: stratified draw (:228-239): segment = total/B,
+ *     v = seg*b + seg*u[b] (u f64[B] in [0,1), or NULL -> Philox(seed, counter, b)),
+ *     get_index descent (:130-144); idx_out data (A) or tree (B) indices, prio_out f64,
+ *     w_out f32[B] = (size * p/total)^(-beta) / max — float32 normalisation for
+ *     variant A (:226,:239,:241), float64 for variant B (ddqn_per_cartpole.py:135-138).
+ */
+size_t gymrl_per_workspace_bytes(int B);
+int gymrl_per_update(double* tree, int64_t cap, const int32_t* idx, int64_t idx_start,
+                     int idx_is_tree, const double* prio, const double* prio_scalar_dev,
+                     double prio_scalar, int B, void* workspace, void* stream);
+int gymrl_per_max_leaf(const double* tree, int64_t cap, double* out, void* workspace,
+                       void* stream);
+int gymrl_per_priorities(const float* td, int B, double alpha, double eps, double clip,
+                         double* prio_out, void* stream);
+int gymrl_per_sample(const double* tree, int64_t cap, const double* u, uint64_t seed,
+                     uint64_t counter, int B, int64_t size, double beta, int variant_b,
+                     int32_t* idx_out, double* prio_out, float* w_out, void* workspace,
+                     void* stream);
+
+/* R1: NoisyLinear.scale_noise + reset_noise — rainbow_dqn_cartpole.py:77-87.
+ * f(x) = sign(x)*sqrt(|x|); w_eps[out,in] = outer(f(eps_out), f(eps_in)); b_eps = f(eps_out).
+ * eps_in/eps_out raw N(0,1) f32 (parity mode) or NULL -> Box-Muller on Philox(seed, counter). */
+int gymrl_noisy_noise(const float* eps_in_raw, const float* eps_out_raw, uint64_t seed,
+                      uint64_t counter, int in_features, int out_features, float* w_eps_out,
+                      float* b_eps_out, void* stream);
+
+/* D3: epsilon-greedy action selection for N envs — dqn_cartpole.py:117-133.
+ * u f32[N,2] uniforms (or NULL -> Philox): u[.,0] < eps -> action = floor(u[.,1]*A) else argmax q. */
+int gymrl_epsilon_greedy(const float* q, const float* u, uint64_t seed, uint64_t counter,
+                         int64_t env_id0, int n, int A, float epsilon, int32_t* act_out,
+                         void* stream);
+
+/*
+ * D4 / R4: TD target + loss forward/backward on the Q heads —
+ * dqn_cartpole.py:157-161 (q_next_online NULL: max_a' Q_tgt), rainbow_dqn_cartpole.py:319-338
+ * and ddqn_per_cartpole.py:224-233 (double DQN: a* = argmax q_next_online, weights w).
+ *   y = r + gamma_n * q_tgt(s', a*) * (1 - flag);  td = q(s,a) - y
+ *   loss = mean(td^2 * w) (w NULL -> 1, i.e. F.mse_loss);  dq[b,a] = 2*td*w/B
+ * td_out f32[B] (feeds update_priorities), dq_out f32[B,A], loss_sum f64[1] += sum td^2*w.
+ */
+int gymrl_dqn_td_loss(const float* q, const float* q_next_online, const float* q_next_target,
+                      const int32_t* act, const float* rew, const float* flag, const float* w,
+                      int B, int A, double gamma_n, float* td_out, float* dq_out,
+                      double* loss_sum, void* workspace, void* stream);
+
+/*
+ * A1: Actor.sample — sac_pendulum.py:76-87 — forward and backward.
+ *   x = mean + exp(log_std)*eps; a = tanh(x)*bound;
+ *   logp = sum_j [ Normal(mean,std).log_prob(x) - log(bound*(1 - tanh(x)^2) + 1e-6) ]
+ * fwd: mean, log_std, eps f32[B,A] -> action f32[B,A], logp f32[B].
+ * bwd: d_action f32[B,A] (may be NULL), d_logp f32[B] -> d_mean, d_log_std f32[B,A].
+ */
+int gymrl_sac_sample_fwd(const float* mean, const float* log_std, const float* eps, int B, int A,
+                         float bound, float* action_out, float* logp_out, void* stream);
+int gymrl_sac_sample_bwd(const float* mean, const float* log_std, const float* eps,
+                         const float* d_action, const float* d_logp, int B, int A, float bound,
+                         float* d_mean_out, float* d_log_std_out, void* stream);
+
+/*
+ * A4: SACTrainer.update pieces — sac_pendulum.py:233-263.
+ *   target:  y = r + gamma*(1-done)*(min(q1n,q2n) - alpha*logp_n)            (:233-237)
+ *   critic:  loss = mse(q1,y) + mse(q2,y); dq1 = 2(q1-y)/B, dq2 = 2(q2-y)/B   (:239-242)
+ *   actor:   loss = mean(alpha*logp - min(q1,q2)); dlogp = alpha/B,
+ *            dq_k = -(1/B) on the smaller critic (tie 1/2,1/2)                (:248-251)
+ *   alpha:   loss = -mean(log_alpha*(logp + target_entropy)); one Adam step on the
+ *            float64 scalar log_alpha (state m, v f64[1])                     (:257-263)
+ * log_alpha f64[1] lives on the device; alpha = (float)exp(log_alpha) inside the kernels.
+ * sums f64[4] += (critic loss sum, actor loss sum, sum(logp + target_entropy), 0).
+ */
+int gymrl_sac_target(const float* rew, const float* done, const float* q1n, const float* q2n,
+                     const float* logp_n, const double* log_alpha, int B, double gamma,
+                     float* y_out, void* stream);
+int gymrl_sac_critic_loss(const float* q1, const float* q2, const float* y, int B,
+                          float* dq1_out, float* dq2_out, double* sums, void* workspace,
+                          void* stream);
+int gymrl_sac_actor_loss(const float* logp, const float* q1, const float* q2,
+                         const double* log_alpha, int B, double target_entropy,
+                         float* dlogp_out, float* dq1_out, float* dq2_out, double* sums,
+                         void* workspace, void* stream);
+int gymrl_sac_alpha_step(double* log_alpha, double* m, double* v, const double* sums, int B,
+                         double lr, double beta1, double beta2, double eps, int64_t step,
+                         double* alpha_loss_out, void* stream);
+
+/*
+ * N1-N3: utils/normalization.py — RunningMeanStd.update :12-22 (Welford, population
+ * std, n == 1 sets std = x), Normalization.__call__ :29-35, RewardScaling :38-52.
+ * stats f64[2 + 3*D] = (n, unused, mean[D] (float32 values), S[D], std[D]).
+ * x f32[N,D] is consumed in env order 0..N-1 exactly like N successive reference calls
+ * (the reference has ONE stream; this is its sequential-equivalent batch semantics).
+ *   running_norm:   update (if update != 0) then y = (x - mean)/(std + 1e-8)
+ *   reward_scaling: R[env] = gamma*R[env] + r[env]; update(R); y = r/(std + 1e-8);
+ *                   R[env] := 0 where done (RewardScaling.reset at episode start)
+ */
+int gymrl_running_norm(const float* x, int N, int D, double* stats, int update, float* y_out,
+                       void* stream);
+int gymrl_reward_scaling(const float* r, const uint8_t* done, int N, double gamma, double* R,
+                         double* stats, float* y_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

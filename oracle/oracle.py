@@ -266,3 +266,204 @@ class Env:
                            _p(ep_ret), _p(ep_len), _p(stats))
         return dict(obs=obs, term_obs=tobs, rew=rew, terminated=term, truncated=trunc, done=done,
                     ep_ret=ep_ret, ep_len=ep_len, ep_stats=stats)
+
+
+# =============================================================== off-policy ===
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class SumTree:
+    """rainbow_dqn_cartpole.py:116-152 on a float64 numpy array (C loops)."""
+
+    def __init__(self, capacity):
+        self.capacity = int(capacity)
+        self.tree = np.zeros(2 * self.capacity - 1, np.float64)
+
+    def update(self, data_index, priority):
+        lib().orc_tree_update(_p(self.tree), C.c_int64(self.capacity), C.c_int64(int(data_index)), C.c_double(priority))
+
+    def update_many(self, idx=None, prio=None, idx_start=0, idx_is_tree=False, prio_scalar=0.0, B=None):
+        idx_ = None if idx is None else _i32(idx)
+        pr = None if prio is None else _f64(prio)
+        B = (idx_.size if idx_ is not None else (pr.size if pr is not None else B))
+        lib().orc_tree_update_many(_p(self.tree), C.c_int64(self.capacity), _p(idx_), C.c_int64(idx_start),
+                                   C.c_int(int(idx_is_tree)), _p(pr), C.c_double(prio_scalar), C.c_int(B))
+
+    def max_leaf(self):
+        lib().orc_tree_max_leaf.restype = C.c_double
+        return lib().orc_tree_max_leaf(_p(self.tree), C.c_int64(self.capacity))
+
+    def sample(self, B, size, beta, u=None, seed=0, counter=0, variant_b=False):
+        u_ = None if u is None else _f64(u)
+        idx, prio, w = np.empty(B, np.int32), np.empty(B, np.float64), np.empty(B, np.float32)
+        lib().orc_per_sample(_p(self.tree), C.c_int64(self.capacity), _p(u_), C.c_uint64(seed), C.c_uint64(counter),
+                             C.c_int(B), C.c_int64(size), C.c_double(beta), C.c_int(int(variant_b)), _p(idx),
+                             _p(prio), _p(w))
+        return idx, prio, w
+
+
+def per_priorities(td, alpha, eps, clip=0.0):
+    td = _f32(td)
+    out = np.empty(td.size, np.float64)
+    lib().orc_per_priorities(_p(td), C.c_int(td.size), C.c_double(alpha), C.c_double(eps), C.c_double(clip), _p(out))
+    return out
+
+
+def uniform_indices(seed, counter, size, B):
+    idx = np.empty(B, np.int32)
+    lib().orc_uniform_indices(C.c_uint64(seed), C.c_uint64(counter), C.c_int64(size), C.c_int(B), _p(idx))
+    return idx
+
+
+class ReplayRing:
+    """numpy restatement of the SoA ring (dqn_cartpole.py:68-88 / sac_pendulum.py:128-148)."""
+
+    def __init__(self, cap, D, AW=1):
+        self.cap, self.D, self.AW = cap, D, AW
+        self.state, self.next_state = np.zeros((cap, D), np.float32), np.zeros((cap, D), np.float32)
+        self.action = np.zeros((cap, AW), np.uint32)
+        self.reward, self.flag = np.zeros(cap, np.float32), np.zeros(cap, np.uint8)
+        self.cursor, self.size = 0, 0
+
+    def append(self, s, a, r, s2, f):
+        n = len(r)
+        rows = (self.cursor + np.arange(n)) % self.cap
+        self.state[rows], self.next_state[rows] = s, s2
+        self.action[rows] = np.ascontiguousarray(a).view(np.uint32).reshape(n, self.AW)
+        self.reward[rows], self.flag[rows] = r, f
+        self.cursor = (self.cursor + n) % self.cap
+        self.size = min(self.size + n, self.cap)
+
+    def gather(self, idx):
+        idx = np.asarray(idx, np.int64)
+        return (self.state[idx], self.action[idx], self.reward[idx], self.next_state[idx],
+                self.flag[idx].astype(np.float32))
+
+
+class NStepWindows:
+    """rainbow_dqn_cartpole.py:179-218 for N env windows feeding a ReplayRing."""
+
+    def __init__(self, n_steps, N, D, gamma):
+        self.n, self.N, self.D, self.gamma, self.pushes = n_steps, N, D, gamma, 0
+        self.w_state, self.w_next = np.zeros((n_steps, N, D), np.float32), np.zeros((n_steps, N, D), np.float32)
+        self.w_action, self.w_reward = np.zeros((n_steps, N), np.int32), np.zeros((n_steps, N), np.float32)
+        self.w_terminal, self.w_done = np.zeros((n_steps, N), np.uint8), np.zeros((n_steps, N), np.uint8)
+
+    def push(self, ring, obs, action, reward, next_obs, terminal, done):
+        obs, next_obs, reward = _f32(obs), _f32(next_obs), _f32(reward)
+        action, terminal, done = _i32(action), _u8(terminal), _u8(done)
+        emit = lib().orc_nstep_push(_p(self.w_state), _p(self.w_action), _p(self.w_reward), _p(self.w_next),
+                                    _p(self.w_terminal), _p(self.w_done), C.c_int(self.n), C.c_int64(self.pushes),
+                                    C.c_int(self.N), C.c_int(self.D), C.c_double(self.gamma), _p(obs), _p(action),
+                                    _p(reward), _p(next_obs), _p(terminal), _p(done), _p(ring.state),
+                                    _p(ring.action), _p(ring.reward), _p(ring.next_state), _p(ring.flag),
+                                    C.c_int64(ring.cap), C.c_int64(ring.cursor))
+        self.pushes += 1
+        if emit:
+            ring.cursor = (ring.cursor + self.N) % ring.cap
+            ring.size = min(ring.size + self.N, ring.cap)
+        return bool(emit)
+
+
+def noisy_noise(nin, nout, eps_in=None, eps_out=None, seed=0, counter=0):
+    ei = None if eps_in is None else _f32(eps_in)
+    eo = None if eps_out is None else _f32(eps_out)
+    w, b = np.empty((nout, nin), np.float32), np.empty(nout, np.float32)
+    lib().orc_noisy_noise(_p(ei), _p(eo), C.c_uint64(seed), C.c_uint64(counter), C.c_int(nin), C.c_int(nout), _p(w), _p(b))
+    return w, b
+
+
+def epsilon_greedy(q, epsilon, u=None, seed=0, counter=0, env_id0=0):
+    q = _f32(q)
+    n, A = q.shape
+    u_ = None if u is None else _f32(u)
+    act = np.empty(n, np.int32)
+    lib().orc_epsilon_greedy(_p(q), _p(u_), C.c_uint64(seed), C.c_uint64(counter), C.c_int64(env_id0), C.c_int(n),
+                             C.c_int(A), C.c_float(epsilon), _p(act))
+    return act
+
+
+def dqn_td_loss(q, q_next_target, act, rew, flag, gamma_n, q_next_online=None, w=None):
+    q, qt = _f32(q), _f32(q_next_target)
+    B, A = q.shape
+    qo = None if q_next_online is None else _f32(q_next_online)
+    w_ = None if w is None else _f32(w)
+    td, dq, loss = np.empty(B, np.float32), np.empty((B, A), np.float32), np.zeros(1, np.float64)
+    lib().orc_dqn_td_loss(_p(q), _p(qo), _p(qt), _p(_i32(act)), _p(_f32(rew)), _p(_f32(flag)), _p(w_), C.c_int(B),
+                          C.c_int(A), C.c_double(gamma_n), _p(td), _p(dq), _p(loss))
+    return td, dq, loss
+
+
+def sac_sample_fwd(mean, log_std, eps, bound):
+    mean, log_std, eps = _f32(mean), _f32(log_std), _f32(eps)
+    B, A = mean.shape
+    act, logp = np.empty((B, A), np.float32), np.empty(B, np.float32)
+    lib().orc_sac_sample_fwd(_p(mean), _p(log_std), _p(eps), C.c_int(B), C.c_int(A), C.c_float(bound), _p(act), _p(logp))
+    return act, logp
+
+
+def sac_sample_bwd(mean, log_std, eps, d_action, d_logp, bound):
+    mean, log_std, eps = _f32(mean), _f32(log_std), _f32(eps)
+    B, A = mean.shape
+    da = None if d_action is None else _f32(d_action)
+    dl = None if d_logp is None else _f32(d_logp)
+    dm, ds = np.empty((B, A), np.float32), np.empty((B, A), np.float32)
+    lib().orc_sac_sample_bwd(_p(mean), _p(log_std), _p(eps), _p(da), _p(dl), C.c_int(B), C.c_int(A), C.c_float(bound),
+                             _p(dm), _p(ds))
+    return dm, ds
+
+
+def sac_target(rew, done, q1n, q2n, logp_n, log_alpha, gamma):
+    B = len(rew)
+    y = np.empty(B, np.float32)
+    la = np.array([log_alpha], np.float64)
+    lib().orc_sac_target(_p(_f32(rew)), _p(_f32(done)), _p(_f32(q1n)), _p(_f32(q2n)), _p(_f32(logp_n)), _p(la),
+                         C.c_int(B), C.c_double(gamma), _p(y))
+    return y
+
+
+def sac_critic_loss(q1, q2, y):
+    B = len(y)
+    d1, d2, sums = np.empty(B, np.float32), np.empty(B, np.float32), np.zeros(4, np.float64)
+    lib().orc_sac_critic_loss(_p(_f32(q1)), _p(_f32(q2)), _p(_f32(y)), C.c_int(B), _p(d1), _p(d2), _p(sums))
+    return d1, d2, sums
+
+
+def sac_actor_loss(logp, q1, q2, log_alpha, target_entropy):
+    B = len(logp)
+    dl, d1, d2, sums = (np.empty(B, np.float32) for _ in range(3)), None, None, None
+    dl, d1, d2 = np.empty(B, np.float32), np.empty(B, np.float32), np.empty(B, np.float32)
+    sums = np.zeros(4, np.float64)
+    la = np.array([log_alpha], np.float64)
+    lib().orc_sac_actor_loss(_p(_f32(logp)), _p(_f32(q1)), _p(_f32(q2)), _p(la), C.c_int(B), C.c_double(target_entropy),
+                             _p(dl), _p(d1), _p(d2), _p(sums))
+    return dl, d1, d2, sums
+
+
+def sac_alpha_step(log_alpha, m, v, sums, B, lr, beta1=0.9, beta2=0.999, eps=1e-8, step=1):
+    la, m_, v_ = np.array([log_alpha], np.float64), np.array([m], np.float64), np.array([v], np.float64)
+    loss = np.zeros(1, np.float64)
+    lib().orc_sac_alpha_step(_p(la), _p(m_), _p(v_), _p(_f64(sums)), C.c_int(B), C.c_double(lr), C.c_double(beta1),
+                             C.c_double(beta2), C.c_double(eps), C.c_int64(step), _p(loss))
+    return la[0], m_[0], v_[0], loss[0]
+
+
+def running_norm_stats(D):
+    return np.zeros(2 + 3 * D, np.float64)
+
+
+def running_norm(x, stats, update=True):
+    x = _f32(x)
+    N, D = x.shape
+    y = np.empty((N, D), np.float32)
+    lib().orc_running_norm(_p(x), C.c_int(N), C.c_int(D), _p(stats), C.c_int(int(update)), _p(y))
+    return y
+
+
+def reward_scaling(r, done, gamma, R, stats):
+    r = _f32(r)
+    y = np.empty(r.size, np.float32)
+    d = None if done is None else _u8(done)
+    lib().orc_reward_scaling(_p(r), _p(d), C.c_int(r.size), C.c_double(gamma), _p(R), _p(stats), _p(y))
+    return y

@@ -365,8 +365,245 @@ def gen_soft_update():
     save("soft_update", target=tgt.numpy(), source=src.numpy(), tau=np.float64(tau), out=new.numpy())
 
 
+# ============================================================== off-policy ====
+def gen_sumtree():
+    """SumTree (rainbow_dqn_cartpole.py:116-152): scripted update/get_index/priority_max traces,
+    capacity 20 (the reference default's shape: not a power of two) and 16."""
+    rb = load_ref("algorithms/rainbow_dqn_cartpole.py", "ref_rainbow")
+    rng = np.random.default_rng(50)
+    out = {}
+    for case, cap in enumerate((20, 16, 5)):
+        tree = rb.SumTree(cap)
+        ops_idx, ops_p, snaps = [], [], []
+        for rnd in range(6):
+            B = int(rng.integers(1, 2 * cap))
+            idx = rng.integers(0, cap, size=B)
+            pr = rng.random(B) * 3 + 0.01
+            for i, p in zip(idx, pr):
+                tree.update(int(i), float(p))
+            ops_idx.append(np.pad(idx, (0, 2 * cap - B), constant_values=-1))
+            ops_p.append(np.pad(pr, (0, 2 * cap - B)))
+            snaps.append(tree.tree.copy())
+        vs = rng.random(64) * tree.priority_sum
+        gi = np.array([tree.get_index(float(v)) for v in vs])
+        out[f"c{case}_cap"] = np.int64(cap)
+        out[f"c{case}_ops_idx"] = np.stack(ops_idx).astype(np.int32)
+        out[f"c{case}_ops_p"] = np.stack(ops_p)
+        out[f"c{case}_snaps"] = np.stack(snaps)
+        out[f"c{case}_v"] = vs
+        out[f"c{case}_get_idx"] = gi[:, 0].astype(np.int64)
+        out[f"c{case}_get_prio"] = gi[:, 1]
+        out[f"c{case}_max"] = np.float64(tree.priority_max)
+    out["n_cases"] = np.int64(3)
+    save("sumtree", **out)
+
+
+def gen_per_nstep():
+    """PrioritizedNStepBuffer (rainbow_dqn_cartpole.py:155-264): store_transition stream with
+    dones at every window position, then sample (with the uniforms numpy consumed) and
+    update_priorities; full buffer + tree snapshots."""
+    rb = load_ref("algorithms/rainbow_dqn_cartpole.py", "ref_rainbow")
+    cfg = rb.Config()
+    cfg.memory_capacity, cfg.batch_size, cfg.device = 48, 16, "cpu"
+    buf = rb.PrioritizedNStepBuffer(cfg, 4)
+    rng = np.random.default_rng(51)
+    T = 70
+    obs = rng.normal(size=(T + 1, 4)).astype(np.float32)
+    act = rng.integers(0, 2, size=T)
+    rew = rng.normal(size=T).astype(np.float32)
+    done = rng.random(T) < 0.2
+    term = done & (rng.random(T) < 0.7)
+    for t in range(T):
+        buf.store_transition(obs[t], int(act[t]), float(rew[t]), obs[t + 1], bool(term[t]), bool(done[t]))
+    tree_after_store = buf.sum_tree.tree.copy()
+    state_arr = {k: v.copy() for k, v in buf.buffer.items()}
+    np.random.seed(777)
+    batch, index, w = buf.sample(300, 1000)
+    np.random.seed(777)
+    u = np.random.random_sample(cfg.batch_size)
+    td = rng.normal(size=cfg.batch_size).astype(np.float32)   # td_error.detach().cpu().numpy() is float32 (:340)
+    td[3] = td[7]                      # exercise equal priorities
+    index2 = index.copy()
+    index2[5] = index2[2]              # and a duplicate leaf inside one batch
+    buf.update_priorities(index2, td)
+    save("per_nstep", obs=obs, act=act.astype(np.int32), rew=rew, done=done.astype(np.uint8),
+         term=term.astype(np.uint8), cap=np.int64(cfg.memory_capacity), n_steps=np.int64(cfg.n_steps),
+         gamma=np.float64(cfg.gamma), alpha=np.float64(cfg.alpha), beta=np.float64(buf.beta),
+         size=np.int64(buf.current_size), count=np.int64(buf.count),
+         buf_state=state_arr["state"], buf_action=state_arr["action"], buf_reward=state_arr["reward"],
+         buf_next=state_arr["next_state"], buf_terminal=state_arr["terminal"], tree_after_store=tree_after_store,
+         u=u, index=index.astype(np.int64), is_weight=w.numpy(), batch_reward=batch["reward"].numpy(),
+         batch_state=batch["state"].numpy(), td=td, index2=index2.astype(np.int64),
+         tree_after_update=buf.sum_tree.tree.copy())
+
+
+def gen_per_variant_b():
+    """ddqn_per_cartpole.py:67-147 (PER variant B): push/sample/update_priorities trace."""
+    pb = load_ref("algorithms/ddqn_per_cartpole.py", "ref_ddqn_per")
+    cfg = pb.Config()
+    cfg.memory_capacity, cfg.batch_size = 32, 8
+    beta0 = cfg.beta
+    buf = pb.PrioritizedReplayBuffer(cfg)
+    rng = np.random.default_rng(52)
+    for t in range(45):
+        buf.push((np.float32(t), 0, 0.0, np.float32(t + 1), False))
+    tree_after_push = buf.tree.tree.copy()
+    random.seed(99)
+    _, indices, w = buf.sample(cfg.batch_size)
+    random.seed(99)
+    u = np.array([random.random() for _ in range(cfg.batch_size)])
+    errs = (np.abs(rng.normal(size=cfg.batch_size)) * 2).astype(np.float32)   # td_errors.abs()...numpy() is float32
+    buf.update_priorities(indices, errs)
+    save("per_variant_b", cap=np.int64(32), n_push=np.int64(45), tree_after_push=tree_after_push, u=u,
+         indices=indices.astype(np.int64), is_weight=np.asarray(w, np.float64), errs=errs,
+         tree_after_update=buf.tree.tree.copy(), beta=np.float64(cfg.beta), beta0=np.float64(beta0),
+         size=np.int64(buf.tree.size), alpha=np.float64(cfg.alpha), eps=np.float64(cfg.eps),
+         error_max=np.float64(cfg.error_max))
+
+
+def gen_noisy():
+    """NoisyLinear.reset_noise (rainbow_dqn_cartpole.py:77-87): raw randn draws -> epsilons."""
+    rb = load_ref("algorithms/rainbow_dqn_cartpole.py", "ref_rainbow")
+    out = {}
+    for case, (nin, nout) in enumerate(((256, 2), (256, 1), (7, 5))):
+        layer = rb.NoisyLinear(nin, nout)
+        torch.manual_seed(60 + case)
+        layer.reset_noise()
+        torch.manual_seed(60 + case)
+        raw_in = torch.randn(nin)
+        raw_out = torch.randn(nout)
+        out[f"c{case}_raw_in"], out[f"c{case}_raw_out"] = raw_in.numpy(), raw_out.numpy()
+        out[f"c{case}_w_eps"], out[f"c{case}_b_eps"] = layer.weight_epsilon.numpy().copy(), layer.bias_epsilon.numpy().copy()
+    out["n_cases"] = np.int64(3)
+    save("noisy", **out)
+
+
+def gen_dqn_update():
+    """One DQNTrainer.update() (dqn_cartpole.py:135-168) and one RainbowDQNTrainer.update()
+    (rainbow_dqn_cartpole.py:311-361) on a memory whose whole content is the batch."""
+    dq = load_ref("algorithms/dqn_cartpole.py", "ref_dqn")
+    cfg = dq.Config()
+    cfg.device, cfg.batch_size, cfg.hidden_dim = "cpu", 32, 32
+    seed_all(70)
+    tr = dq.DQNTrainer(cfg)
+    rng = np.random.default_rng(70)
+    trans = []
+    for i in range(cfg.batch_size):
+        trans.append((rng.normal(size=4).astype(np.float32), int(rng.integers(0, 2)), float(rng.normal()),
+                      rng.normal(size=4).astype(np.float32), bool(rng.random() < 0.2)))
+        tr.memory.push(*trans[-1])
+    with torch.no_grad():   # de-correlate target from policy
+        for p in tr.target_net.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    sd_policy = {k: v.numpy().copy() for k, v in tr.policy_net.state_dict().items()}
+    sd_target = {k: v.numpy().copy() for k, v in tr.target_net.state_dict().items()}
+    random.seed(5)
+    loss = tr.update()
+    random.seed(5)
+    order = random.sample(range(cfg.batch_size), cfg.batch_size)     # same draw as random.sample(deque, B)
+    out = dict(order=np.array(order, np.int32), loss=np.float64(loss),
+               states=np.stack([t[0] for t in trans]), actions=np.array([t[1] for t in trans], np.int32),
+               rewards=np.array([t[2] for t in trans], np.float32), next_states=np.stack([t[3] for t in trans]),
+               dones=np.array([t[4] for t in trans], np.uint8), gamma=np.float64(cfg.gamma), lr=np.float64(cfg.lr))
+    for k, v in sd_policy.items():
+        out["p0_" + k] = v
+    for k, v in sd_target.items():
+        out["t0_" + k] = v
+    for k, v in tr.policy_net.state_dict().items():
+        out["p1_" + k] = v.numpy().copy()
+    save("dqn_update", **out)
+
+
+def gen_sac():
+    """Actor.sample forward/backward (sac_pendulum.py:76-87) + one SACTrainer.update() (:213-267)."""
+    sac = load_ref("algorithms/sac_pendulum.py", "ref_sac")
+    cfg = sac.Config()
+    cfg.device, cfg.batch_size, cfg.hidden_dim = "cpu", 24, 32
+    seed_all(80)
+    tr = sac.SACTrainer(cfg)
+    states = torch.randn(64, 3)
+    mean, log_std = tr.actor.forward(states)
+    mean = (mean * 3).detach().requires_grad_(True)          # spread over tanh's range
+    log_std = (log_std.detach() - 1.0 + torch.randn(64, 1)).clamp(cfg.log_std_min, cfg.log_std_max).requires_grad_(True)
+    torch.manual_seed(81)
+    eps = torch.randn(64, 1)
+    std = log_std.exp()
+    torch.manual_seed(81)
+    normal = torch.distributions.Normal(mean, std)
+    x_t = normal.rsample()
+    action = torch.tanh(x_t) * tr.action_bound
+    log_prob = normal.log_prob(x_t)
+    log_prob = log_prob - torch.log(tr.action_bound * (1 - torch.tanh(x_t).pow(2)) + 1e-6)
+    log_prob = log_prob.sum(dim=1, keepdim=True)
+    assert torch.allclose(x_t, mean + std * eps)
+    ga, gl = torch.randn(64, 1), torch.randn(64, 1)
+    ((action * ga).sum() + (log_prob * gl).sum()).backward()
+    out = dict(mean=mean.detach().numpy(), log_std=log_std.detach().numpy(), eps=eps.numpy(),
+               action=action.detach().numpy(), logp=log_prob.detach().numpy()[:, 0], g_action=ga.numpy(),
+               g_logp=gl.numpy()[:, 0], d_mean=mean.grad.numpy(), d_log_std=log_std.grad.numpy(),
+               bound=np.float64(tr.action_bound))
+    # ---- one full update() on a memory that is exactly one batch ----
+    rng = np.random.default_rng(82)
+    trans = []
+    for i in range(cfg.batch_size):
+        trans.append((rng.normal(size=3).astype(np.float32), rng.uniform(-2, 2, size=1).astype(np.float32),
+                      float(rng.normal()), rng.normal(size=3).astype(np.float32), bool(rng.random() < 0.15)))
+        tr.memory.push(*trans[-1])
+    with torch.no_grad():
+        for p in tr.critic_target.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    for name, net in (("actor", tr.actor), ("critic", tr.critic), ("critic_target", tr.critic_target)):
+        for k, v in net.state_dict().items():
+            out[f"u0_{name}_{k}"] = v.numpy().copy()
+    random.seed(9)
+    torch.manual_seed(83)
+    al, cl, aal = tr.update()
+    random.seed(9)
+    order = random.sample(range(cfg.batch_size), cfg.batch_size)
+    torch.manual_seed(83)
+    eps_next = torch.randn(cfg.batch_size, 1)        # actor.sample(next_states)
+    eps_cur = torch.randn(cfg.batch_size, 1)         # actor.sample(states)
+    for name, net in (("actor", tr.actor), ("critic", tr.critic), ("critic_target", tr.critic_target)):
+        for k, v in net.state_dict().items():
+            out[f"u1_{name}_{k}"] = v.numpy().copy()
+    out.update(u_order=np.array(order, np.int32), u_losses=np.array([al, cl, aal], np.float64),
+               u_states=np.stack([t[0] for t in trans]), u_actions=np.stack([t[1] for t in trans]),
+               u_rewards=np.array([t[2] for t in trans], np.float32), u_next_states=np.stack([t[3] for t in trans]),
+               u_dones=np.array([t[4] for t in trans], np.uint8), u_eps_next=eps_next.numpy(), u_eps_cur=eps_cur.numpy(),
+               u_log_alpha0=np.float64(np.log(cfg.init_alpha)), u_log_alpha1=np.float64(tr.log_alpha.item()),
+               u_gamma=np.float64(cfg.gamma), u_tau=np.float64(cfg.tau), u_lr=np.float64(cfg.lr_actor),
+               u_target_entropy=np.float64(tr.target_entropy))
+    save("sac", **out)
+
+
+def gen_normalization():
+    """utils/normalization.py: RunningMeanStd / Normalization / RewardScaling traces (incl. the
+    n == 1 special case and a negative first reward)."""
+    sys.path.insert(0, REF)
+    from utils.normalization import Normalization, RewardScaling
+    rng = np.random.default_rng(90)
+    x = (rng.normal(size=(40, 8)) * np.array([1, 2, 0.5, 3, 1, 1, 0.1, 10]) + 0.3).astype(np.float32)
+    norm = Normalization(shape=8)
+    ys = np.stack([np.asarray(norm(x[i]), np.float64) for i in range(40)])
+    y_eval = np.asarray(norm(x[3], update=False), np.float64)
+    rs = RewardScaling(shape=1, gamma=0.99)
+    r = rng.normal(size=60).astype(np.float32)
+    r[0] = -3.0
+    done = rng.random(60) < 0.1
+    outs = []
+    for i in range(60):
+        outs.append(float(rs(float(r[i]))[0]))
+        if done[i]:
+            rs.reset()
+    save("normalization", x=x, y=ys, y_eval=y_eval, mean=np.asarray(norm.running_ms.mean, np.float64),
+         S=np.asarray(norm.running_ms.S, np.float64), std=np.asarray(norm.running_ms.std, np.float64),
+         n=np.int64(norm.running_ms.n), r=r, done=done.astype(np.uint8), r_scaled=np.array(outs, np.float64),
+         gamma=np.float64(0.99))
+
+
 GENERATORS = [gen_gae, gen_gae_g2, gen_gae_g3, gen_categorical, gen_ppo_loss, gen_adam_multi,
-              gen_ppo_full_loss, gen_soft_update]
+              gen_ppo_full_loss, gen_soft_update, gen_sumtree, gen_per_nstep, gen_per_variant_b, gen_noisy,
+              gen_dqn_update, gen_sac, gen_normalization]
 
 if __name__ == "__main__":
     names = sys.argv[1:]
