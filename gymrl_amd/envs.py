@@ -61,3 +61,33 @@ class VecEnv:
 
 def make(env_name, num_envs=1, **kw):
     return VecEnv(env_name, num_envs, **kw)
+
+
+class EpisodeTracker:
+    """Finished-episode returns without a host sync per step: (ep_ret, done) rows are kept
+    on the device and drained every `flush_every` vector steps into a python deque, in
+    time order (the reference appends episode_reward at every done)."""
+
+    def __init__(self, num_envs, device, flush_every=16):
+        self.K = flush_every
+        self.ret = torch.zeros(flush_every, num_envs, device=device)
+        self.done = torch.zeros(flush_every, num_envs, dtype=torch.uint8, device=device)
+        self.k = 0
+        self.episodes = 0
+
+    def slot(self):
+        """-> (ep_ret_out[N], done_out[N]) views for the current vector step."""
+        return self.ret[self.k], self.done[self.k]
+
+    def advance(self, sink):
+        self.k += 1
+        if self.k == self.K:
+            self.flush(sink)
+
+    def flush(self, sink):
+        if self.k:
+            fin = self.ret[:self.k][self.done[:self.k].bool()].tolist()
+            for r in fin:
+                sink.append(r)
+            self.episodes += len(fin)
+            self.k = 0

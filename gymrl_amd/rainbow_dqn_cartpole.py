@@ -1,0 +1,300 @@
+"""Rainbow DQN (Double + Dueling + NoisyNet + PER sum-tree + n-step + soft target) — MI355X
+engine behind the reference's algorithms/rainbow_dqn_cartpole.py surface: Config :32-48,
+NoisyLinear :51-97, DuelingNoisyNetwork :100-113, SumTree :116-152,
+PrioritizedNStepBuffer :155-264, RainbowDQNTrainer :267-446 (select_action :293-309,
+update :311-361, train :363-405).
+
+Underneath: per-env n-step windows + ring append, the float64 sum-tree (ordered batched
+update, stratified sampling, priority_max), NoisyNet noise generation, the double-DQN TD
+loss forward/backward, clip-norm + Adam and the soft target update are HIP kernels behind
+the C-ABI; the four Linear layers run through PyTorch-ROCm autograd.
+"""
+import copy
+import math
+from collections import deque
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .envs import EpisodeTracker, VecEnv
+from .flat import FusedAdam, flatten_module
+
+
+class Config:
+    def __init__(self):
+        self.env_name = "CartPole-v1"
+        self.seed = None
+        self.max_episodes = 500
+        self.max_steps = 500
+        self.batch_size = 256
+        self.gamma = 0.9
+        self.tau = 0.005
+        self.lr = 1e-3
+        self.memory_capacity = 20000
+        self.hidden_dim = 256
+        self.n_steps = 5
+        self.alpha = 0.6
+        self.beta_init = 0.4
+        self.grad_clip = 10.0
+        self.device = "cuda"
+        # --- vectorised-engine additions ---
+        self.num_envs = 1
+        self.updates_per_step = 1
+
+
+class NoisyLinear(nn.Module):
+    """rainbow_dqn_cartpole.py:51-97; the factorised noise is produced by gymrl_noisy_noise
+    (in-kernel Box-Muller on Philox, or explicit raw N(0,1) draws in parity mode)."""
+
+    _counter = 0
+
+    def __init__(self, in_features, out_features, sigma_init=0.5, seed=0):
+        super().__init__()
+        self.in_features, self.out_features, self.sigma_init, self.seed = in_features, out_features, sigma_init, seed
+        self.weight_mu = nn.Parameter(torch.empty(out_features, in_features))
+        self.weight_sigma = nn.Parameter(torch.empty(out_features, in_features))
+        self.register_buffer("weight_epsilon", torch.zeros(out_features, in_features))
+        self.bias_mu = nn.Parameter(torch.empty(out_features))
+        self.bias_sigma = nn.Parameter(torch.empty(out_features))
+        self.register_buffer("bias_epsilon", torch.zeros(out_features))
+        self.raw_noise = None            # parity mode: iterator of (eps_in_raw, eps_out_raw) device tensors
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        mu_range = 1 / math.sqrt(self.in_features)
+        self.weight_mu.data.uniform_(-mu_range, mu_range)
+        self.bias_mu.data.uniform_(-mu_range, mu_range)
+        self.weight_sigma.data.fill_(self.sigma_init / math.sqrt(self.in_features))
+        self.bias_sigma.data.fill_(self.sigma_init / math.sqrt(self.out_features))
+
+    def reset_noise(self):
+        if not self.weight_epsilon.is_cuda:
+            return                        # CPU construction time: the buffers are filled on first GPU forward
+        if self.raw_noise is not None:
+            ei, eo = next(self.raw_noise)
+            ops.noisy_noise(self.in_features, self.out_features, self.weight_epsilon, self.bias_epsilon, ei, eo)
+        else:
+            NoisyLinear._counter += 1
+            ops.noisy_noise(self.in_features, self.out_features, self.weight_epsilon, self.bias_epsilon,
+                            seed=self.seed, counter=NoisyLinear._counter)
+
+    def forward(self, x):
+        if self.training:
+            self.reset_noise()            # new noise on every training-mode forward (:90-91)
+            weight = self.weight_mu + self.weight_sigma.mul(self.weight_epsilon)
+            bias = self.bias_mu + self.bias_sigma.mul(self.bias_epsilon)
+        else:
+            weight, bias = self.weight_mu, self.bias_mu
+        return F.linear(x, weight, bias)
+
+
+class DuelingNoisyNetwork(nn.Module):
+    def __init__(self, state_dim, action_dim, hidden_dim=256, seed=0):
+        super().__init__()
+        self.fc1 = nn.Linear(state_dim, hidden_dim)
+        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
+        self.advantage = NoisyLinear(hidden_dim, action_dim, seed=seed)
+        self.value = NoisyLinear(hidden_dim, 1, seed=seed + 1)
+
+    def forward(self, x):
+        x = F.relu(self.fc2(F.relu(self.fc1(x))))
+        advantage, value = self.advantage(x), self.value(x)
+        return value + (advantage - advantage.mean(dim=-1, keepdim=True))
+
+
+class SumTree:
+    """rainbow_dqn_cartpole.py:116-152 on a device float64 array."""
+
+    def __init__(self, capacity, device):
+        self.capacity, self.tree_capacity = int(capacity), 2 * int(capacity) - 1
+        self.tree = torch.zeros(self.tree_capacity, dtype=torch.float64, device=device)
+        self._ws = ops.per_workspace(max(8192, capacity), device)
+        self._max = torch.zeros(1, dtype=torch.float64, device=device)
+
+    def update(self, data_index, priority):
+        idx = torch.as_tensor([int(data_index)], dtype=torch.int32, device=self.tree.device)
+        pr = torch.as_tensor([float(priority)], dtype=torch.float64, device=self.tree.device)
+        ops.per_update(self.tree, self.capacity, 1, self._ws, idx=idx, prio=pr)
+
+    def update_batch(self, idx, prio):
+        ops.per_update(self.tree, self.capacity, idx.numel(), self._ws, idx=idx, prio=prio)
+
+    def update_range(self, start, n, priority=None, priority_dev=None):
+        ops.per_update(self.tree, self.capacity, n, self._ws, idx_start=start, prio_scalar=priority or 0.0,
+                       prio_scalar_dev=priority_dev)
+
+    @property
+    def priority_sum(self):
+        return self.tree[0]
+
+    @property
+    def priority_max(self):
+        return ops.per_max_leaf(self.tree, self.capacity, self._max, self._ws)
+
+
+class PrioritizedNStepBuffer:
+    """rainbow_dqn_cartpole.py:155-264 for N env streams (one n-step window per env)."""
+
+    def __init__(self, config, state_dim, num_envs=1, device=None, seed=0):
+        self.device = torch.device(device or config.device)
+        self.capacity, self.batch_size = int(config.memory_capacity), int(config.batch_size)
+        self.n_steps, self.gamma, self.alpha = int(config.n_steps), float(config.gamma), float(config.alpha)
+        self.beta = self.beta_init = float(config.beta_init)
+        self.N, d = int(num_envs), self.device
+        if self.capacity < self.N:
+            raise ValueError("memory_capacity must be >= num_envs")
+        self.sum_tree = SumTree(self.capacity, d)
+        n, N, D = self.n_steps, self.N, state_dim
+        self.win = (torch.zeros(n, N, D, device=d), torch.zeros(n, N, dtype=torch.int32, device=d),
+                    torch.zeros(n, N, device=d), torch.zeros(n, N, D, device=d),
+                    torch.zeros(n, N, dtype=torch.uint8, device=d), torch.zeros(n, N, dtype=torch.uint8, device=d))
+        self.ring = (torch.zeros(self.capacity, D, device=d), torch.zeros(self.capacity, 1, dtype=torch.int32, device=d),
+                     torch.zeros(self.capacity, device=d), torch.zeros(self.capacity, D, device=d),
+                     torch.zeros(self.capacity, dtype=torch.uint8, device=d))
+        self.current_size, self.count, self.pushes = 0, 0, 0
+        self.seed, self.draws = seed, 0
+
+    def store_transition(self, state, action, reward, next_state, terminal, done):
+        """:179-205 for N rows [N, ...]; new rows get priority 1.0 (empty buffer) or priority_max."""
+        emitted = ops.nstep_push(self.win, self.n_steps, self.pushes, self.gamma, state, action, reward, next_state,
+                                 terminal, done, self.ring, self.count)
+        self.pushes += 1
+        if emitted:
+            if self.current_size == 0:
+                self.sum_tree.update_range(self.count, self.N, priority=1.0)
+            else:
+                self.sum_tree.update_range(self.count, self.N, priority_dev=self.sum_tree.priority_max)
+            self.count = (self.count + self.N) % self.capacity
+            self.current_size = min(self.current_size + self.N, self.capacity)
+
+    def sample(self, total_steps, max_train_steps, u=None):
+        """:220-256 -> (batch dict, batch_index i32[B], is_weight f32[B])."""
+        self.beta = self.beta_init + (1 - self.beta_init) * (total_steps / max_train_steps)
+        self.draws += 1
+        idx, _, w = ops.per_sample(self.sum_tree.tree, self.capacity, self.batch_size, self.current_size, self.beta,
+                                   self.sum_tree._ws, u=u, seed=self.seed, counter=self.draws)
+        s, a, r, s2, f = ops.replay_gather(self.ring, idx)
+        return {"state": s, "action": a.long(), "reward": r, "next_state": s2, "terminal": f}, idx, w
+
+    def update_priorities(self, batch_index, td_errors):
+        """:258-261: p = (|td| + 0.01)^alpha, applied in batch order."""
+        pr = ops.per_priorities(td_errors, self.alpha, 0.01)
+        self.sum_tree.update_batch(batch_index, pr)
+
+    def __len__(self):
+        return self.current_size
+
+
+class RainbowDQNTrainer:
+    def __init__(self, config):
+        self.cfg = config
+        if not torch.cuda.is_available() or not ops.device_ok():
+            raise RuntimeError("gymrl_amd.RainbowDQNTrainer needs an MI355X and libgymrl_hip.so; no CPU fallback")
+        self.device = torch.device(config.device if ":" in str(config.device) else f"cuda:{torch.cuda.current_device()}")
+        self.base_seed = 0 if config.seed is None else int(config.seed)
+        self.env = VecEnv(config.env_name, config.num_envs, device=self.device, seed=self.base_seed)
+        self.state_dim, self.action_dim = self.env.observation_space.shape[0], self.env.action_space.n
+        self.max_steps_per_episode = self.env.spec.max_episode_steps
+        self.max_train_steps = self.max_steps_per_episode * config.max_episodes
+        g = torch.random.get_rng_state()
+        torch.manual_seed(self.base_seed)
+        self.policy_net = DuelingNoisyNetwork(self.state_dim, self.action_dim, config.hidden_dim, seed=self.base_seed)
+        torch.random.set_rng_state(g)
+        self.target_net = copy.deepcopy(self.policy_net)
+        self.flat_params, self.flat_grads = flatten_module(self.policy_net, self.device)
+        self.target_flat, _ = flatten_module(self.target_net, self.device)
+        self.target_net.eval()
+        self.optimizer = FusedAdam(self.flat_params, self.flat_grads, lr=config.lr, eps=1e-8,
+                                   max_grad_norm=config.grad_clip)
+        self.memory = PrioritizedNStepBuffer(config, self.state_dim, config.num_envs, self.device, seed=self.base_seed)
+        self.total_steps = 0
+        self.episode_rewards = deque(maxlen=100)
+        self._loss = torch.zeros(1, dtype=torch.float64, device=self.device)
+
+    @torch.no_grad()
+    def select_action(self, state, deterministic=False):
+        """:293-309 for a batch [N, D]: greedy on the noisy Q (no epsilon)."""
+        if not deterministic:
+            self.total_steps += state.shape[0]
+        if deterministic:
+            self.policy_net.eval()
+        q = self.policy_net(state)
+        if deterministic:
+            self.policy_net.train()
+        return q.argmax(dim=-1).to(torch.int32)
+
+    def update(self, u=None):
+        """:311-361.  Returns the loss as a python float."""
+        cfg = self.cfg
+        if len(self.memory) < cfg.batch_size:
+            return 0.0
+        batch, batch_index, is_weight = self.memory.sample(self.total_steps, self.max_train_steps, u=u)
+        with torch.no_grad():
+            q_next_online = self.policy_net(batch["next_state"])          # fresh noise (:320)
+            q_next_target = self.target_net(batch["next_state"])          # eval mode: mu weights only
+        q = self.policy_net(batch["state"])                               # fresh noise again (:334)
+        self._loss.zero_()
+        td, dq = ops.dqn_td_loss(q, q_next_target, batch["action"].view(-1).to(torch.int32), batch["reward"],
+                                 batch["terminal"], cfg.gamma ** cfg.n_steps, q_next_online=q_next_online,
+                                 w=is_weight, loss_sum=self._loss)
+        self.memory.update_priorities(batch_index, td)                    # before backward (:340)
+        q.backward(dq)
+        self.optimizer.step()                                             # clip_grad_norm_(10) + Adam
+        ops.soft_update(self.target_flat, self.flat_params, cfg.tau)      # :347-352 (parameters only)
+        lr_now = 0.9 * cfg.lr * (1 - self.total_steps / self.max_train_steps) + 0.1 * cfg.lr
+        for param_group in self.optimizer.param_groups:
+            param_group["lr"] = lr_now
+        return float(self._loss.item()) / cfg.batch_size
+
+    def train(self, max_vector_steps=None):
+        """:363-405 with N lock-stepped envs."""
+        cfg, env = self.cfg, self.env
+        N, D = env.n, env.obs_dim
+        obs, nxt, tobs = (torch.empty(N, D, device=self.device) for _ in range(3))
+        rew = torch.empty(N, device=self.device)
+        term = torch.zeros(N, dtype=torch.uint8, device=self.device)
+        trunc = torch.zeros(N, dtype=torch.uint8, device=self.device)
+        tracker = EpisodeTracker(N, self.device, flush_every=1 if N == 1 else 16)
+        env.reset(obs)
+        step = 0
+        limit = max_vector_steps or (cfg.max_episodes * cfg.max_steps // N + 1)
+        while tracker.episodes < cfg.max_episodes and step < limit:
+            action = self.select_action(obs)
+            ep_ret, done = tracker.slot()
+            env.step(action, nxt, rew, done_out=done, term_obs_out=tobs, ep_ret_out=ep_ret, terminated_out=term,
+                     truncated_out=trunc)
+            # terminal = done and not the time-limit step (:376): exactly gymnasium's `terminated`
+            self.memory.store_transition(obs, action, rew, tobs, term, done)
+            for _ in range(cfg.updates_per_step):
+                self.update()
+            obs, nxt = nxt, obs
+            step += 1
+            tracker.advance(self.episode_rewards)
+            if len(self.episode_rewards) >= 100 and np.mean(self.episode_rewards) >= 495.0:
+                break
+        tracker.flush(self.episode_rewards)
+        self.env.close()
+
+    @torch.no_grad()
+    def eval(self, num_episodes=10):
+        env = VecEnv(self.cfg.env_name, num_episodes, device=self.device, seed=self.base_seed + 999, env_id0=1 << 40)
+        obs = env.reset()
+        nxt = torch.empty_like(obs)
+        rew = torch.empty(num_episodes, device=self.device)
+        done = torch.zeros(num_episodes, dtype=torch.uint8, device=self.device)
+        ep_ret = torch.zeros(num_episodes, device=self.device)
+        result = torch.full((num_episodes,), float("nan"), device=self.device)
+        for _ in range(env.max_steps + 1):
+            act = self.select_action(obs, deterministic=True)
+            env.step(act, nxt, rew, done_out=done, ep_ret_out=ep_ret)
+            result = torch.where(done.bool() & torch.isnan(result), ep_ret, result)
+            obs, nxt = nxt, obs
+            if not torch.isnan(result).any():
+                break
+        return result.tolist()
+
+    def test(self):
+        return self.eval(num_episodes=5)

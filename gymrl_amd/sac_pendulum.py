@@ -1,0 +1,248 @@
+"""SAC (twin-Q, tanh-Gaussian reparameterised actor, automatic temperature) — MI355X engine
+behind the reference's algorithms/sac_pendulum.py surface: Config :29-46, Actor :49-98,
+Critic :101-125, ReplayBuffer :128-148, SACTrainer :151-351 (soft_update :194-199,
+select_action :202-211, update :213-267, train :269-310).
+
+Underneath: Pendulum instances step on the GPU; replay ring, the reparameterised sample
++ log-prob (forward AND backward), the soft-Bellman target, the critic / actor losses'
+forward+backward, the float64 log_alpha Adam step, the three fused Adam steps and the
+Polyak update are HIP kernels behind the C-ABI; Linear layers run through PyTorch-ROCm.
+"""
+import copy
+from collections import deque
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .dqn_cartpole import ReplayBuffer as _Ring
+from .envs import EpisodeTracker, VecEnv
+from .flat import FusedAdam, flatten_module
+
+
+class Config:
+    def __init__(self):
+        self.env_name = "Pendulum-v1"
+        self.seed = None
+        self.max_episodes = 500
+        self.max_steps = 200
+        self.batch_size = 128
+        self.gamma = 0.99
+        self.lr_actor = 3e-4
+        self.lr_critic = 3e-4
+        self.lr_alpha = 3e-4
+        self.tau = 0.005
+        self.init_alpha = 0.2
+        self.memory_capacity = 100000
+        self.hidden_dim = 256
+        self.log_std_min = -20
+        self.log_std_max = 2
+        self.device = "cuda"
+        # --- vectorised-engine additions ---
+        self.num_envs = 1
+        self.updates_per_step = 1
+
+
+class _SacSample(torch.autograd.Function):
+    """Actor.sample's tail (:78-87) as one HIP kernel each way."""
+
+    @staticmethod
+    def forward(ctx, mean, log_std, eps, bound):
+        mean, log_std = mean.contiguous(), log_std.contiguous()
+        action, logp = ops.sac_sample_fwd(mean, log_std, eps, bound)
+        ctx.save_for_backward(mean, log_std, eps)
+        ctx.bound = bound
+        return action, logp.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, d_action, d_logp):
+        mean, log_std, eps = ctx.saved_tensors
+        da = None if d_action is None else d_action.contiguous()
+        dl = None if d_logp is None else d_logp.reshape(-1).contiguous()
+        dm, ds = ops.sac_sample_bwd(mean, log_std, eps, da, dl, ctx.bound)
+        return dm, ds, None, None
+
+
+class Actor(nn.Module):
+    def __init__(self, state_dim, action_dim, hidden_dim, action_bound, log_std_min, log_std_max):
+        super().__init__()
+        self.action_bound, self.log_std_min, self.log_std_max = action_bound, log_std_min, log_std_max
+        self.fc1 = nn.Linear(state_dim, hidden_dim)
+        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
+        self.mean = nn.Linear(hidden_dim, action_dim)
+        self.log_std = nn.Linear(hidden_dim, action_dim)
+
+    def forward(self, x):
+        x = F.relu(self.fc2(F.relu(self.fc1(x))))
+        return self.mean(x), self.log_std(x).clamp(self.log_std_min, self.log_std_max)
+
+    def sample(self, state, eps=None):
+        """:76-87 -> (action [B, A], log_prob [B, 1]).  eps: explicit N(0,1) draws (parity mode)."""
+        mean, log_std = self.forward(state)
+        if eps is None:
+            eps = torch.randn_like(mean)
+        return _SacSample.apply(mean, log_std, eps, float(self.action_bound))
+
+    @torch.no_grad()
+    def get_action(self, state, deterministic=False, eps=None):
+        mean, log_std = self.forward(state)
+        if deterministic:
+            return torch.tanh(mean) * self.action_bound
+        if eps is None:
+            eps = torch.randn_like(mean)
+        return ops.sac_sample_fwd(mean.contiguous(), log_std.contiguous(), eps, float(self.action_bound))[0]
+
+
+class Critic(nn.Module):
+    """Both Q networks in one module (:101-125)."""
+
+    def __init__(self, state_dim, action_dim, hidden_dim):
+        super().__init__()
+        self.fc1 = nn.Linear(state_dim + action_dim, hidden_dim)
+        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
+        self.fc3 = nn.Linear(hidden_dim, 1)
+        self.fc4 = nn.Linear(state_dim + action_dim, hidden_dim)
+        self.fc5 = nn.Linear(hidden_dim, hidden_dim)
+        self.fc6 = nn.Linear(hidden_dim, 1)
+
+    def forward(self, state, action):
+        x = torch.cat([state, action], dim=1)
+        q1 = self.fc3(F.relu(self.fc2(F.relu(self.fc1(x)))))
+        q2 = self.fc6(F.relu(self.fc5(F.relu(self.fc4(x)))))
+        return q1, q2
+
+
+class ReplayBuffer(_Ring):
+    """Device ring with float32 action words (:128-148)."""
+
+    def __init__(self, capacity, state_dim, action_dim, device, seed=0):
+        super().__init__(capacity, state_dim, device, action_words=action_dim, action_dtype=torch.float32, seed=seed)
+
+    def push(self, state, action, reward, next_state, done):
+        super().push(state, action.contiguous().view(torch.int32), reward, next_state, done)
+
+
+class SACTrainer:
+    def __init__(self, config):
+        self.cfg = config
+        if not torch.cuda.is_available() or not ops.device_ok():
+            raise RuntimeError("gymrl_amd.SACTrainer needs an MI355X and libgymrl_hip.so; no CPU fallback")
+        self.device = torch.device(config.device if ":" in str(config.device) else f"cuda:{torch.cuda.current_device()}")
+        self.base_seed = 0 if config.seed is None else int(config.seed)
+        self.env = VecEnv(config.env_name, config.num_envs, device=self.device, seed=self.base_seed)
+        state_dim, action_dim = self.env.observation_space.shape[0], self.env.action_space.shape[0]
+        self.action_bound = float(self.env.action_space.high[0])
+        g = torch.random.get_rng_state()
+        torch.manual_seed(self.base_seed)
+        self.actor = Actor(state_dim, action_dim, config.hidden_dim, self.action_bound, config.log_std_min,
+                           config.log_std_max)
+        self.critic = Critic(state_dim, action_dim, config.hidden_dim)
+        torch.random.set_rng_state(g)
+        self.critic_target = copy.deepcopy(self.critic)
+        self.actor_flat, self.actor_grads = flatten_module(self.actor, self.device)
+        self.critic_flat, self.critic_grads = flatten_module(self.critic, self.device)
+        self.critic_target_flat, _ = flatten_module(self.critic_target, self.device)
+        self.actor_optimizer = FusedAdam(self.actor_flat, self.actor_grads, lr=config.lr_actor)
+        self.critic_optimizer = FusedAdam(self.critic_flat, self.critic_grads, lr=config.lr_critic)
+        self.target_entropy = -action_dim
+        d64 = dict(dtype=torch.float64, device=self.device)
+        self.log_alpha = torch.tensor([np.log(config.init_alpha)], **d64)      # float64 like the reference (:177-179)
+        self._alpha_m, self._alpha_v = torch.zeros(1, **d64), torch.zeros(1, **d64)
+        self._alpha_steps = 0
+        self._sums = torch.zeros(4, **d64)
+        self._alpha_loss = torch.zeros(1, **d64)
+        self.memory = ReplayBuffer(config.memory_capacity, state_dim, action_dim, self.device, seed=self.base_seed)
+        self.episode_rewards = deque(maxlen=100)
+
+    @property
+    def alpha(self):
+        return self.log_alpha.exp()
+
+    def soft_update(self, target_flat=None, source_flat=None):
+        """:194-199 on the flat parameter buffers."""
+        ops.soft_update(self.critic_target_flat if target_flat is None else target_flat,
+                        self.critic_flat if source_flat is None else source_flat, self.cfg.tau)
+
+    @torch.no_grad()
+    def select_action(self, state, deterministic=False, eps=None):
+        """:202-211 for a batch [N, D] -> f32[N, A] (stays on the device)."""
+        return self.actor.get_action(state, deterministic, eps)
+
+    def update(self, indices=None, eps_next=None, eps_cur=None):
+        """:213-267 -> (actor_loss, critic_loss, alpha_loss) python floats."""
+        cfg = self.cfg
+        if len(self.memory) < cfg.batch_size:
+            return 0.0, 0.0, 0.0
+        states, actions, rewards, next_states, dones = self.memory.sample(cfg.batch_size, indices)
+        B = states.shape[0]
+        self._sums.zero_()
+        with torch.no_grad():                                                  # :233-237
+            next_actions, next_logp = self.actor.sample(next_states, eps_next)
+            tq1, tq2 = self.critic_target(next_states, next_actions)
+            y = ops.sac_target(rewards, dones, tq1.view(-1), tq2.view(-1), next_logp.view(-1).contiguous(),
+                               self.log_alpha, cfg.gamma)
+        q1, q2 = self.critic(states, actions)                                  # :239-246
+        dq1, dq2 = ops.sac_critic_loss(q1.view(-1), q2.view(-1), y, self._sums)
+        self.critic_grads.zero_()                                              # critic_optimizer.zero_grad()
+        torch.autograd.backward([q1, q2], [dq1.view_as(q1), dq2.view_as(q2)])
+        self.critic_optimizer.step()
+
+        new_actions, logp = self.actor.sample(states, eps_cur)                 # :248-255
+        q1, q2 = self.critic(states, new_actions)
+        dlogp, dq1, dq2 = ops.sac_actor_loss(logp.view(-1).contiguous(), q1.view(-1), q2.view(-1), self.log_alpha,
+                                             self.target_entropy, self._sums)
+        torch.autograd.backward([q1, q2, logp], [dq1.view_as(q1), dq2.view_as(q2), dlogp.view_as(logp)])
+        self.actor_optimizer.step()
+
+        self._alpha_steps += 1                                                 # :257-263
+        ops.sac_alpha_step(self.log_alpha, self._alpha_m, self._alpha_v, self._sums, B, cfg.lr_alpha,
+                           self._alpha_steps, loss_out=self._alpha_loss)
+        self.soft_update()                                                     # :265
+        s = self._sums.tolist()
+        return s[1] / B, s[0] / B, float(self._alpha_loss.item())
+
+    def train(self, max_vector_steps=None):
+        """:269-310 with N lock-stepped envs."""
+        cfg, env = self.cfg, self.env
+        N, D = env.n, env.obs_dim
+        obs, nxt, tobs = (torch.empty(N, D, device=self.device) for _ in range(3))
+        rew = torch.empty(N, device=self.device)
+        tracker = EpisodeTracker(N, self.device, flush_every=1 if N == 1 else 16)
+        env.reset(obs)
+        step = 0
+        limit = max_vector_steps or (cfg.max_episodes * cfg.max_steps // N + 1)
+        while tracker.episodes < cfg.max_episodes and step < limit:
+            action = self.select_action(obs)
+            ep_ret, done = tracker.slot()
+            env.step(action, nxt, rew, done_out=done, term_obs_out=tobs, ep_ret_out=ep_ret)
+            self.memory.push(obs, action, rew, tobs, done)                     # done = terminated or truncated (:283)
+            for _ in range(cfg.updates_per_step):
+                self.update()
+            obs, nxt = nxt, obs
+            step += 1
+            tracker.advance(self.episode_rewards)
+        tracker.flush(self.episode_rewards)
+        self.env.close()
+
+    @torch.no_grad()
+    def eval(self, num_episodes=10):
+        env = VecEnv(self.cfg.env_name, num_episodes, device=self.device, seed=self.base_seed + 999, env_id0=1 << 40)
+        obs = env.reset()
+        nxt = torch.empty_like(obs)
+        rew = torch.empty(num_episodes, device=self.device)
+        done = torch.zeros(num_episodes, dtype=torch.uint8, device=self.device)
+        ep_ret = torch.zeros(num_episodes, device=self.device)
+        result = torch.full((num_episodes,), float("nan"), device=self.device)
+        for _ in range(env.max_steps + 1):
+            act = self.select_action(obs, deterministic=True)
+            env.step(act.contiguous(), nxt, rew, done_out=done, ep_ret_out=ep_ret)
+            result = torch.where(done.bool() & torch.isnan(result), ep_ret, result)
+            obs, nxt = nxt, obs
+            if not torch.isnan(result).any():
+                break
+        return result.tolist()
+
+    def test(self):
+        return self.eval(num_episodes=5)
