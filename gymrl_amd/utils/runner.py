@@ -1,0 +1,156 @@
+"""utils/runner.py:16-226 for lane-parallel envs: BasicConfig, make_env, train, evaluate, test,
+BenchMark.  The agent duck-type is the reference's (:81-206): `agent.memory` (its class decides
+on/off-policy), `agent.choose_action(state)` -> (a, logp, v) on-policy or a off-policy,
+`agent.evaluate(state)`, `agent.update()` -> dict, optional `agent.state_norm` /
+`agent.reward_scaler`, `agent.save_model()` / `agent.load_model()`, `agent.learn_step`.
+States, actions and rewards are [N, ...] device tensors (one vector step per loop turn).
+"""
+import time
+
+import numpy as np
+import torch
+
+from ..envs import EpisodeTracker, VecEnv
+from .buffer import ReplayBuffer_on_policy
+from .normalization import Normalization, RewardScaling
+
+
+class BasicConfig:
+    def __init__(self):
+        self.render_mode = 'rgb_array'
+        self.train_eps = 500
+        self.test_eps = 3
+        self.eval_eps = 10
+        self.eval_freq = 10
+        self.max_steps = 1000
+        self.lr_start = 1e-3
+        self.lr_end = 1e-5
+        self.batch_size = 1024
+        self.mini_batch = 16
+        self.epochs = 3
+        self.clip = 0.2
+        self.dual_clip = 3.0
+        self.gamma = 0.99
+        self.lamda = 0.95
+        self.val_coef = 0.5
+        self.ent_coef = 1e-2
+        self.grad_clip = 0.5
+        self.load_model = False
+        self.save_freq = 50
+        self.use_state_norm = True
+        self.use_reward_scale = True
+        self.device = "cuda"
+        self.num_envs = 64
+
+    def show(self):
+        print('-' * 30 + '参数列表' + '-' * 30)
+        for k, v in vars(self).items():
+            print(k, '=', v)
+        print('-' * 60)
+
+
+def make_env(cfg):
+    """:52-78: builds the (vectorised) env and fills cfg.n_states / n_actions / action_bound / max_steps."""
+    env = VecEnv(cfg.env_name, cfg.num_envs, device=cfg.device, seed=getattr(cfg, "seed", 0) or 0)
+    cfg.state_shape = env.observation_space.shape
+    cfg.n_states = env.obs_dim
+    if env.discrete:
+        cfg.n_actions, cfg.action_bound = env.act_dim, None
+    else:
+        cfg.n_actions, cfg.action_bound = env.act_dim, float(env.action_space.high[0])
+    cfg.max_steps = env.max_steps
+    return env
+
+
+def train(env, agent, cfg, max_vector_steps=None):
+    """:81-166.  Returns the list of finished-episode returns."""
+    if cfg.load_model:
+        agent.load_model()
+    if cfg.use_state_norm and not hasattr(agent, 'state_norm'):
+        agent.state_norm = Normalization(shape=cfg.n_states, device=cfg.device)
+    if cfg.use_reward_scale and not hasattr(agent, 'reward_scaler'):
+        agent.reward_scaler = RewardScaling(shape=1, gamma=cfg.gamma, num_envs=env.n, device=cfg.device)
+    on_policy = isinstance(agent.memory, ReplayBuffer_on_policy)
+    N, D, dev = env.n, env.obs_dim, env.device
+    obs, nxt, tobs = (torch.empty(N, D, device=dev) for _ in range(3))
+    rew = torch.empty(N, device=dev)
+    term = torch.zeros(N, dtype=torch.uint8, device=dev)
+    trunc = torch.zeros(N, dtype=torch.uint8, device=dev)
+    returns = []
+    tracker = EpisodeTracker(N, dev)
+    env.reset(obs, seed=int(np.random.randint(1, 2 ** 31 - 1)))
+    state = agent.state_norm(obs) if cfg.use_state_norm else obs
+    if on_policy:
+        action, log_prob, value = agent.choose_action(state)
+    step, limit = 0, max_vector_steps or (cfg.train_eps * cfg.max_steps // N + 1)
+    metrics = {}
+    while tracker.episodes < cfg.train_eps and step < limit:
+        if not on_policy:
+            action = agent.choose_action(state)
+        ep_ret, done = tracker.slot()
+        env.step(action, nxt, rew, done_out=done, term_obs_out=tobs, ep_ret_out=ep_ret, terminated_out=term,
+                 truncated_out=trunc)
+        r = agent.reward_scaler(rew, done) if cfg.use_reward_scale else rew
+        next_state = agent.state_norm(nxt) if cfg.use_state_norm else nxt.clone()
+        if on_policy:
+            next_action, next_log_prob, next_value = agent.choose_action(next_state)   # chosen before storing (:129)
+            agent.memory.store((state, action, r.clone(), done.clone(), term.clone(), log_prob, value, next_value))
+            action, log_prob, value = next_action, next_log_prob, next_value
+        else:
+            agent.memory.store((state, action, r.clone(), next_state, done.clone()))
+        state = next_state
+        obs, nxt = nxt, obs
+        step += 1
+        if agent.memory.size() >= cfg.batch_size:                                      # :142-144
+            metrics = agent.update()
+        tracker.advance(returns)
+    tracker.flush(returns)
+    return returns, metrics
+
+
+@torch.no_grad()
+def evaluate(env_name, agent, cfg, episodes=None):
+    """:169-184: deterministic episodes on a fresh env vector; mean return."""
+    n = episodes or cfg.eval_eps
+    env = VecEnv(env_name, n, device=cfg.device, seed=12345, env_id0=1 << 40)
+    obs = env.reset()
+    nxt, rew = torch.empty_like(obs), torch.empty(n, device=env.device)
+    done = torch.zeros(n, dtype=torch.uint8, device=env.device)
+    ep_ret = torch.zeros(n, device=env.device)
+    result = torch.full((n,), float("nan"), device=env.device)
+    for _ in range(env.max_steps + 1):
+        state = agent.state_norm(obs, update=False) if getattr(cfg, "use_state_norm", False) else obs
+        env.step(agent.evaluate(state), nxt, rew, done_out=done, ep_ret_out=ep_ret)
+        result = torch.where(done.bool() & torch.isnan(result), ep_ret, result)
+        obs, nxt = nxt, obs
+        if not torch.isnan(result).any():
+            break
+    return float(result.mean().item())
+
+
+def test(env_name, agent, cfg):
+    """:187-206 (no renderer on the batched env)."""
+    agent.load_model()
+    return [evaluate(env_name, agent, cfg, episodes=1) for _ in range(cfg.test_eps)]
+
+
+class BenchMark:
+    """:209-226."""
+
+    @staticmethod
+    def train(algo, config, max_vector_steps=None):
+        cfg = config()
+        env = make_env(cfg)                      # must precede agent construction: it fills the dims
+        agent = algo(cfg)
+        t0 = time.time()
+        out = train(env, agent, cfg, max_vector_steps)
+        print(f"train: {time.time() - t0:.1f}s")
+        return agent, out
+
+    @staticmethod
+    def test(algo, config):
+        cfg = config()
+        cfg.render_mode = 'human'
+        make_env(cfg)
+        agent = algo(cfg)
+        return test(cfg.env_name, agent, cfg)

@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _load(module, g, prefix):
-    sd = {k[len(prefix):]: torch.from_numpy(np.array(g[k])) for k in g.files if k.startswith(prefix)}
+    sd = {k[len(prefix):]: torch.from_numpy(np.array(g[k])) for k in g.files
+          if k.startswith(prefix) and not k[len(prefix):].startswith("target_")}
     module.load_state_dict(sd)
 
 
