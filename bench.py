@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=10)
     ap.add_argument("--minibatches", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--cpu-budget", type=float, default=24.0)
     a = ap.parse_args()
 
     from gymrl_amd import dist as gdist
@@ -138,7 +138,6 @@ def main():
     if world == 1 and not a.no_cpu_baseline:
         from oracle.ref_ppo_cpu import time_cpu_baseline
         out["cpu_baseline"] = time_cpu_baseline(a.cpu_budget)
-        out["cpu_baseline"]["host_cores"] = os.cpu_count()
     print(json.dumps(out))
 
 
