@@ -1,0 +1,339 @@
+"""PPO-full (mHC backbone, decoupled-lambda GAE, clip-higher, ratio-clamp dual clip, entropy-
+ratio mask, LR + entropy annealing) — MI355X engine behind the reference's
+algorithms/ppo_full_lunarlander.py surface: Config :19-52, ActorCritic :364-412,
+RolloutBuffer :416-436, PPOTrainer :440-747 (collect_experience :462-505,
+compute_advantages :507-535, update_model :537-679).
+
+The mHC network (manifold hyper-connections with a 10-iteration Sinkhorn-Knopp on the
+exp of a rate x rate mixing matrix) is dense PyTorch-ROCm autograd work — SURVEY.md section 8a
+F1 keeps it off the hand-kernel list.  It is written here from the architecture's definition
+with the reference's parameter names, so reference state_dicts load unchanged
+(tests/test_trainers_gpu.py checks forward/backward equivalence on a golden).  Rollout,
+categorical sampling (+ behaviour entropy), G3 GAE, the L3 loss forward/backward + metrics,
+clip-norm + Adam and the gradient all-reduce are the HIP / RCCL path.
+"""
+import math
+from collections import deque
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import dist as gdist
+from . import ops
+from .envs import VecEnv
+from .flat import FusedAdam, flatten_module
+
+
+class Config:
+    def __init__(self):
+        self.env_name = "LunarLander-v3"
+        self.seed = None
+        self.use_mhc = True
+        self.mhc_dim = 128
+        self.mhc_rate = 2
+        self.mhc_layers = 2
+        self.mhc_sk_it = 10
+        self.max_train_steps = 5e6
+        self.update_freq = 4096            # steps PER ENV per rollout
+        self.num_epochs = 4
+        self.batch_size = 1024
+        self.num_minibatches = None        # if set: minibatch = T*N / num_minibatches
+        self.gamma = 0.995
+        self.lam_actor = 0.95
+        self.lam_critic = 0.95
+        self.clip_eps_min = 0.2
+        self.clip_eps_max = 0.28
+        self.clip_cov_ratio = 0.0
+        self.clip_cov_min = 1.0
+        self.clip_cov_max = 5.0
+        self.dual_clip = 3.0
+        self.entropy_coef = 0.01
+        self.erc_beta_low = 0.06
+        self.erc_beta_high = 0.06
+        self.lr = 3e-4
+        self.max_grad_norm = 0.5
+        self.anneal = True
+        self.device = "cuda"
+        self.num_envs = 1
+
+
+def _ortho(layer, std):
+    nn.init.orthogonal_(layer.weight, gain=std)
+    if layer.bias is not None:
+        nn.init.constant_(layer.bias, 0)
+    return layer
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim, eps=1e-6):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+    def forward(self, x):
+        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.eps) * self.weight
+
+
+class ManifoldHyperConnectionFuse(nn.Module):
+    """One hyper-connection: per-sample gates (H_pre, H_post) and a doubly-stochastic branch
+    mixing matrix H_res from an RMS-fused linear read-out of the branch stack (:106-194)."""
+
+    def __init__(self, dim, rate, max_sk_it):
+        super().__init__()
+        self.n, self.dim, self.nc, self.max_sk_it = rate, dim, rate * dim, max_sk_it
+        n = rate
+        self.norm = RMSNorm(dim * rate)
+        self.w = nn.Parameter(torch.zeros(self.nc, n * n + 2 * n))
+        self.alpha = nn.Parameter(torch.ones(3) * 0.01)
+        beta = torch.zeros(n * n + 2 * n)
+        beta[:2 * n] = 0.01
+        mix = torch.full((n, n), -2.0)
+        mix.fill_diagonal_(2.0)                      # start close to the identity: branches stay independent
+        beta[2 * n:] = mix.flatten()
+        self.beta = nn.Parameter(beta)
+
+    def gates(self, h):
+        """h [B, n, D] -> (pre [B, n], post [B, n], mix [B, n, n])."""
+        B, n = h.shape[0], self.n
+        flat = h.reshape(B, self.nc)
+        H = (self.norm.weight * flat) @ self.w
+        r_inv = 1.0 / (flat.norm(dim=-1, keepdim=True) / math.sqrt(self.nc) + 1e-6)
+        pre = torch.sigmoid(r_inv * H[:, :n] * self.alpha[0] + self.beta[:n])
+        post = 2 * torch.sigmoid(r_inv * H[:, n:2 * n] * self.alpha[1] + self.beta[n:2 * n])
+        A = (r_inv * H[:, 2 * n:] * self.alpha[2] + self.beta[2 * n:]).reshape(B, n, n).exp()
+        with torch.no_grad():                        # Sinkhorn-Knopp scalings, treated as constants
+            u = torch.ones(B, n, device=h.device)
+            v = torch.ones(B, n, device=h.device)
+            for _ in range(self.max_sk_it):
+                u = 1.0 / ((A * v.unsqueeze(1)).sum(-1) + 1e-8)
+                v = 1.0 / ((A * u.unsqueeze(2)).sum(1) + 1e-8)
+        return pre, post, u.unsqueeze(2) * A * v.unsqueeze(1)
+
+
+class MHCBlock(nn.Module):
+    def __init__(self, dim, rate, max_sk_it):
+        super().__init__()
+        self.linear1 = nn.Linear(dim, dim)
+        self.mhc1 = ManifoldHyperConnectionFuse(dim, rate, max_sk_it)
+        self.linear2 = nn.Linear(dim, dim)
+        self.mhc2 = ManifoldHyperConnectionFuse(dim, rate, max_sk_it)
+        self.act = nn.SiLU()
+
+    @staticmethod
+    def _sub(h, fuse, linear, act):
+        pre, post, mix = fuse.gates(h)
+        read = torch.bmm(pre.unsqueeze(1), h)                    # weighted sum of branches  [B, 1, D]
+        out = act(linear(read))
+        return torch.bmm(post.unsqueeze(2), out) + torch.bmm(mix, h)   # broadcast back + inter-branch mixing
+
+    def forward(self, h):
+        h = self._sub(h, self.mhc1, self.linear1, self.act)
+        return self._sub(h, self.mhc2, self.linear2, self.act)
+
+
+class MHCBackbone(nn.Module):
+    def __init__(self, input_dim, output_dim, rate, num_layers, max_sk_it):
+        super().__init__()
+        self.rate = rate
+        self.input_proj = nn.Linear(input_dim, output_dim)
+        self.layers = nn.ModuleList([MHCBlock(output_dim, rate, max_sk_it) for _ in range(num_layers)])
+        self.final_norm = RMSNorm(output_dim)
+
+    def forward(self, x):
+        h = self.input_proj(x).unsqueeze(1).repeat(1, self.rate, 1)     # [B, n, D]
+        for layer in self.layers:
+            h = layer(h)
+        return self.final_norm(h.sum(dim=1))
+
+
+class MLP(nn.Module):
+    """Linear -> SiLU -> RMSNorm -> ... -> Linear (last gain = last_std), keys `mlp.<i>` (:287-318)."""
+
+    def __init__(self, dims, last_std=None):
+        super().__init__()
+        layers = []
+        for i in range(len(dims) - 1):
+            last = i == len(dims) - 2
+            layers.append(_ortho(nn.Linear(dims[i], dims[i + 1]), last_std if (last and last_std) else np.sqrt(2)))
+            if not last:
+                layers += [nn.SiLU(), RMSNorm(dims[i + 1])]
+        self.mlp = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.mlp(x)
+
+
+class ActorCritic(nn.Module):
+    def __init__(self, state_dim, action_dim, config=None):
+        super().__init__()
+        cfg = config or Config()
+        if not getattr(cfg, "use_mhc", True):
+            raise NotImplementedError("the PSCN backbone (use_mhc=False) is outside the hot-path scope")
+        self.shared = MHCBackbone(state_dim, cfg.mhc_dim, cfg.mhc_rate, cfg.mhc_layers, cfg.mhc_sk_it)
+        self.actor = MLP([cfg.mhc_dim, 256, action_dim], last_std=0.001)
+        self.critic = MLP([cfg.mhc_dim, 256, 1], last_std=1.0)
+
+    def forward(self, x):
+        x = self.shared(x)
+        return self.actor(x), self.critic(x)
+
+    @torch.no_grad()
+    def get_action(self, x, deterministic=False, seed=0, counter=0, env_id0=0):
+        """:395-407 batched -> (action i32[N], logp[N], value[N], entropy[N])."""
+        logits, value = self.forward(x)
+        act, logp, ent, val = ops.categorical_sample(logits, value=value.view(-1), seed=seed, counter=counter,
+                                                     env_id0=env_id0, deterministic=deterministic)
+        return act, logp, val, ent
+
+    @torch.no_grad()
+    def get_value(self, x):
+        return self.forward(x)[1].view(-1)
+
+
+class RolloutBuffer:
+    """[T][N] slabs incl. the behaviour-policy entropies (:416-436)."""
+
+    def __init__(self, T, N, obs_dim, device):
+        z = lambda *s, **k: torch.zeros(*s, device=device, **k)   # noqa: E731
+        self.T, self.N = T, N
+        self.states = z(T + 1, N, obs_dim)
+        self.actions = z(T, N, dtype=torch.int32)
+        self.log_probs, self.values, self.rewards, self.old_entropies = z(T, N), z(T, N), z(T, N), z(T, N)
+        self.dones = z(T, N, dtype=torch.uint8)
+        self.ep_returns = z(T, N)
+        self.next_value = z(N)
+
+    def clear(self):
+        pass
+
+
+class PPOTrainer:
+    def __init__(self, config):
+        self.cfg = config
+        if config.clip_cov_ratio != 0:
+            raise NotImplementedError("clip_cov_ratio > 0 (the covariance-clip branch, :611-616) is not built")
+        if not torch.cuda.is_available() or not ops.device_ok():
+            raise RuntimeError("gymrl_amd PPO-full needs an MI355X and libgymrl_hip.so; no CPU fallback")
+        self.rank, self.world_size = gdist.rank(), gdist.world_size()
+        self.device = torch.device(config.device if ":" in str(config.device) else f"cuda:{torch.cuda.current_device()}")
+        self.base_seed = 0 if config.seed is None else int(config.seed)
+        N = int(config.num_envs)
+        self.env = VecEnv(config.env_name, N, device=self.device, seed=self.base_seed, env_id0=self.rank * N)
+        state_dim, action_dim = self.env.observation_space.shape[0], self.env.action_space.n
+        g = torch.random.get_rng_state()
+        torch.manual_seed(self.base_seed)
+        self.model = ActorCritic(state_dim, action_dim, config=config)
+        torch.random.set_rng_state(g)
+        self.flat_params, self.flat_grads = flatten_module(self.model, self.device)
+        gdist.broadcast(self.flat_params)
+        self.optimizer = FusedAdam(self.flat_params, self.flat_grads, lr=config.lr, eps=1e-5,
+                                   max_grad_norm=config.max_grad_norm)
+        self.step_count = 0
+        self.rollout_count = 0
+        self.episode_rewards = deque(maxlen=10)
+        self.lr, self.ent_coef = config.lr, config.entropy_coef
+        self.buffer = RolloutBuffer(int(config.update_freq), N, state_dim, self.device)
+        self._perm_gen = torch.Generator(device=self.device)
+        self._perm_gen.manual_seed(self.base_seed * 7919 + 17 + self.rank)
+
+    @torch.no_grad()
+    def collect_experience(self):
+        """:462-505 for N envs."""
+        b, env, cfg = self.buffer, self.env, self.cfg
+        seed = (self.base_seed if cfg.seed is not None else self.base_seed + 0x9E3779B1 * (self.rollout_count + 1))
+        env.reset(b.states[0], seed=seed & 0x7FFFFFFFFFFFFFFF)
+        c0 = self.rollout_count * b.T
+        for t in range(b.T):
+            logits, value = self.model(b.states[t])
+            ops.categorical_sample(logits, value=value.view(-1), seed=env.seed, counter=c0 + t, env_id0=env.env_id0,
+                                   act_out=b.actions[t], logp_out=b.log_probs[t], ent_out=b.old_entropies[t],
+                                   value_out=b.values[t])
+            env.step(b.actions[t], b.states[t + 1], b.rewards[t], done_out=b.dones[t], ep_ret_out=b.ep_returns[t])
+        self.step_count += b.T * b.N
+        self.rollout_count += 1
+        b.next_value.copy_(self.model.get_value(b.states[b.T]))
+
+    def compute_advantages(self):
+        """:507-535 -> (adv_actor [T,N] un-normalised, returns [T,N])."""
+        b, cfg = self.buffer, self.cfg
+        return ops.gae_decoupled(b.rewards, b.values, b.dones, b.next_value, cfg.gamma, cfg.lam_actor, cfg.lam_critic)
+
+    def update_model(self, advantages, returns):
+        """:537-679.  Returns the metric means the reference prints."""
+        cfg, b = self.cfg, self.buffer
+        total = b.T * b.N
+        mb = max(1, total // int(cfg.num_minibatches)) if cfg.num_minibatches else min(int(cfg.batch_size), total)
+        n_mb = (total + mb - 1) // mb
+        states = b.states[:b.T].reshape(total, -1)
+        act, lp, ent_old = b.actions.view(-1), b.log_probs.view(-1), b.old_entropies.view(-1)
+        adv, ret = advantages.reshape(-1), returns.reshape(-1)
+        metrics = torch.zeros(cfg.num_epochs * n_mb, 9, dtype=torch.float64, device=self.device)
+        sizes, row = [], 0
+        for _ in range(cfg.num_epochs):
+            perm = torch.randperm(total, device=self.device, generator=self._perm_gen).to(torch.int32)   # shuffle=True
+            for start in range(0, total, mb):
+                idx = perm[start:start + mb]
+                B = idx.numel()
+                logits, values = self.model(states.index_select(0, idx))
+                values = values.view(-1)
+                lcfg = (cfg.clip_eps_min, cfg.clip_eps_max, cfg.dual_clip, cfg.erc_beta_low, cfg.erc_beta_high,
+                        self.ent_coef)
+                dlogits, dvalues = ops.ppo_full_loss_fwd_bwd(logits, values, act, lp, ent_old, adv, ret, lcfg, idx=idx,
+                                                             metrics_sum=metrics[row])
+                torch.autograd.backward([logits, values], [dlogits, dvalues])
+                if self.world_size > 1:
+                    gdist.all_reduce_sum(self.flat_grads)
+                self.optimizer.step(grad_scale=1.0 / self.world_size)
+                sizes.append(B)
+                row += 1
+        if cfg.anneal:                                                     # :660-666 (after the update)
+            frac = 1 - self.step_count * self.world_size / cfg.max_train_steps
+            self.lr = cfg.lr * frac
+            for param_group in self.optimizer.param_groups:
+                param_group["lr"] = self.lr
+            self.ent_coef = cfg.entropy_coef * frac
+        done = b.ep_returns[b.dones.bool()][-self.episode_rewards.maxlen:]
+        for r in done.tolist():
+            self.episode_rewards.append(r)
+        m = metrics.cpu().numpy()
+        Bs = np.asarray(sizes, np.float64)
+        cov = (m[:, 8] - m[:, 6] * m[:, 7] / Bs) / Bs                      # covs.mean() per minibatch (:594-596)
+        return {"policy_loss": float((m[:, 0] / Bs).mean()), "value_loss": float((m[:, 1] / Bs).mean()),
+                "entropy": float((m[:, 2] / Bs).mean()), "clip_frac": float((m[:, 3] / Bs).mean()),
+                "approx_kl": float((m[:, 4] / Bs).mean()), "erc_clip_frac": float((m[:, 5] / Bs).mean()),
+                "cov": float(cov.mean())}
+
+    def train(self):
+        update_count = 0
+        while self.step_count * self.world_size < self.cfg.max_train_steps:
+            self.collect_experience()
+            advantages, returns = self.compute_advantages()
+            metrics = self.update_model(advantages, returns)
+            update_count += 1
+            if self.episode_rewards and self.rank == 0:
+                print(f"Step: {self.step_count * self.world_size:,} | Updates: {update_count} | "
+                      f"Avg Reward: {np.mean(self.episode_rewards):.1f} | KL: {metrics['approx_kl']:.4f}")
+        self.env.close()
+
+    @torch.no_grad()
+    def eval(self, num_episodes=10):
+        env = VecEnv(self.cfg.env_name, num_episodes, device=self.device, seed=self.base_seed + 1_000_003,
+                     env_id0=1 << 40)
+        obs = env.reset()
+        nxt = torch.empty_like(obs)
+        rew = torch.empty(num_episodes, device=self.device)
+        done = torch.zeros(num_episodes, dtype=torch.uint8, device=self.device)
+        ep_ret = torch.zeros(num_episodes, device=self.device)
+        result = torch.full((num_episodes,), float("nan"), device=self.device)
+        for _ in range(env.max_steps + 1):
+            act = self.model.get_action(obs, deterministic=True)[0]
+            env.step(act, nxt, rew, done_out=done, ep_ret_out=ep_ret)
+            result = torch.where(done.bool() & torch.isnan(result), ep_ret, result)
+            obs, nxt = nxt, obs
+            if not torch.isnan(result).any():
+                break
+        return result.tolist()
+
+    def test(self):
+        return self.eval(num_episodes=5)

@@ -601,7 +601,33 @@ def gen_normalization():
          gamma=np.float64(0.99))
 
 
-GENERATORS = [gen_gae, gen_gae_g2, gen_gae_g3, gen_categorical, gen_ppo_loss, gen_adam_multi,
+def gen_ppo_full_net():
+    """ppo_full ActorCritic (mHC backbone, ppo_full_lunarlander.py:364-412) forward + parameter
+    gradients at mhc_dim=32 (small fixture); the w / alpha / beta parameters are perturbed so the
+    gates and the Sinkhorn mixing are exercised away from their init."""
+    pf = load_ref("algorithms/ppo_full_lunarlander.py", "ref_ppo_full")
+    cfg = pf.Config()
+    cfg.mhc_dim = 32
+    seed_all(95)
+    net = pf.ActorCritic(8, 4, config=cfg)
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if n_.endswith(".w") or n_.endswith(".alpha") or n_.endswith(".beta") or n_.endswith("norm.weight"):
+                p_.add_(0.3 * torch.randn_like(p_))
+    x = torch.randn(16, 8)
+    w1, w2 = torch.randn(16, 4), torch.randn(16, 1)
+    logits, values = net(x)
+    ((logits * w1).sum() + (values * w2).sum()).backward()
+    out = {"x": x.numpy(), "w1": w1.numpy(), "w2": w2.numpy(), "logits": logits.detach().numpy(),
+           "values": values.detach().numpy()}
+    for k, v in net.state_dict().items():
+        out["sd_" + k] = v.numpy().copy()
+    for k, p_ in net.named_parameters():
+        out["grad_" + k] = p_.grad.numpy().copy()
+    save("ppo_full_net", **out)
+
+
+GENERATORS = [gen_ppo_full_net, gen_gae, gen_gae_g2, gen_gae_g3, gen_categorical, gen_ppo_loss, gen_adam_multi,
               gen_ppo_full_loss, gen_soft_update, gen_sumtree, gen_per_nstep, gen_per_variant_b, gen_noisy,
               gen_dqn_update, gen_sac, gen_normalization]
 

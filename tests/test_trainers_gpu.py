@@ -95,3 +95,19 @@ def test_dqn_rainbow_sac_smoke():
     tr.train(max_vector_steps=250)
     a, cr, al = tr.update()
     assert all(np.isfinite(x) for x in (a, cr, al)) and 0.0 < tr.alpha.item() < 1.0
+
+
+def test_ppo_full_iterations():
+    """PPO-full (config 5's algorithm) on the HIP path: mHC network through PyTorch, G3 GAE, L3 loss."""
+    from gymrl_amd.ppo_full_lunarlander import Config, PPOTrainer
+    cfg = Config()
+    cfg.num_envs, cfg.update_freq, cfg.num_epochs, cfg.batch_size, cfg.seed = 256, 64, 2, 4096, 1
+    tr = PPOTrainer(cfg)
+    for _ in range(3):
+        tr.collect_experience()
+        adv, ret = tr.compute_advantages()
+        m = tr.update_model(adv, ret)
+        assert all(np.isfinite(v) for v in m.values()), m
+        assert 0.0 <= m["erc_clip_frac"] <= 1.0 and 0.0 <= m["clip_frac"] <= 1.0
+    assert tr.lr < cfg.lr and tr.ent_coef < cfg.entropy_coef          # annealed after each update (:660-666)
+    assert tr.step_count == 3 * 256 * 64
