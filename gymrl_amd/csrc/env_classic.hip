@@ -265,6 +265,13 @@ int gymrl_env_reset(int kind, void* state, int n, uint64_t seed, int64_t env_id0
   return 0;
 }
 
+int gymrl_env_refill(int kind, void* state, int n, uint64_t seed, int64_t env_id0, void* stream_) {
+  if (!state || n < 0 || !aligned(state, 256)) return -22;
+  if (n == 0) return 0;
+  if (kind == GYMRL_ENV_LUNARLANDER) return lunar_refill(state, n, seed, env_id0, (hipStream_t)stream_);
+  return (kind == GYMRL_ENV_CARTPOLE || kind == GYMRL_ENV_PENDULUM) ? 0 : -22;   // cheap resets: nothing to prepare
+}
+
 int gymrl_env_step(int kind, void* state, int n, uint64_t seed, int64_t env_id0, const void* action,
                    float* obs_out, float* term_obs_out, float* rew_out, uint8_t* terminated_out,
                    uint8_t* truncated_out, uint8_t* done_out, float* ep_ret_out,

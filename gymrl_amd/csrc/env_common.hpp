@@ -78,6 +78,7 @@ __device__ __forceinline__ void accumulate_ep_stats(double* ep_stats, bool done,
 // launchers implemented per env kind
 size_t lunar_state_bytes(int n);
 int lunar_reset(void* state, int n, uint64_t seed, int64_t env_id0, float* obs_out, hipStream_t s);
+int lunar_refill(void* state, int n, uint64_t seed, int64_t env_id0, hipStream_t s);
 int lunar_step(void* state, int n, uint64_t seed, int64_t env_id0, const int32_t* action,
                float* obs_out, float* term_obs_out, float* rew_out, uint8_t* terminated_out,
                uint8_t* truncated_out, uint8_t* done_out, float* ep_ret_out, int32_t* ep_len_out,

@@ -908,14 +908,27 @@ __device__ __forceinline__ void init_episode(World& W, const Lds& lds, uint64_t 
 // Everything a lane needs between steps; [field][N] arrays (coalesced dword accesses).
 constexpr int kWorldWords = 18 + 3 + 10 + 3 * 2 * (2 + 4 + 2 * 5) + 3 + 1 + 11 + 1 + 1;   // f32/u32/i32 words
 
+// A second world per env ("spare") holds the NEXT episode's post-reset state, computed by
+// gymrl_env_refill off the critical path (reset() costs a full solver pass because it ends
+// with step(0)); the step kernel swaps it in when an episode ends and falls back to the
+// inline reset when the spare is not ready.  Bit-identical either way: the spare is a pure
+// function of (seed, env id, episode).
+constexpr uint32_t kNoSpare = 0xFFFFFFFFu;
+
 struct LunarState {
   uint32_t* words;     // [kWorldWords][N]
   EpisodeFields ep;
+  uint32_t* spare_words;    // [kWorldWords][N]
+  float* spare_obs;         // [8][N]
+  uint32_t* spare_episode;  // episode index the spare was built for, or kNoSpare
   size_t bytes;
   __host__ __device__ LunarState(void* buf, int n) {
     Carver c(buf, n);
     words = c.take<uint32_t>(kWorldWords);
     ep.ep_ret = c.take<double>(); ep.ep_len = c.take<int32_t>(); ep.episode = c.take<uint32_t>();
+    spare_words = c.take<uint32_t>(kWorldWords);
+    spare_obs = c.take<float>(8);
+    spare_episode = c.take<uint32_t>();
     bytes = c.off;
   }
 };
@@ -978,9 +991,32 @@ __global__ __launch_bounds__(kEnvBlock) void lunar_reset_kernel(void* buf, int n
     env_step_once(W, lds, 0, seed, (uint64_t)(env_id0 + i), 0u, 0u, fx, fy, o, rew, term);   // reset() ends with step(0)
     world_io(W, lds, st.words, n, i, true);
     st.ep.ep_ret[i] = 0.0; st.ep.ep_len[i] = 0; st.ep.episode[i] = 0u;
+    st.spare_episode[i] = kNoSpare;
   }
   const int nv = min(kEnvBlock, n - blockIdx.x * kEnvBlock);
   store_obs_tile<8>(obs_out + (size_t)blockIdx.x * kEnvBlock * 8, o, tile, threadIdx.x, nv);
+}
+
+// Builds the spare world of episode (current + 1) for every env that lacks one.
+__global__ __launch_bounds__(kEnvBlock) void lunar_refill_kernel(void* buf, int n, uint64_t seed,
+                                                                 int64_t env_id0) {
+  __shared__ uint32_t lds_words[kLdsWords * kEnvBlock];
+  const Lds lds{lds_words + threadIdx.x};
+  LunarState st(buf, n);
+  const int i = blockIdx.x * kEnvBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t want = st.ep.episode[i] + 1u;
+  if (st.spare_episode[i] == want) return;
+  World W;
+  float fx, fy, rew, o[8]; bool term;
+  const uint64_t env = (uint64_t)(env_id0 + i);
+  init_episode(W, lds, seed, env, want, fx, fy);
+  env_step_once(W, lds, 0, seed, env, want, 0u, fx, fy, o, rew, term);
+  world_io(W, lds, st.spare_words, n, i, true);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) st.spare_obs[(size_t)k * n + i] = o[k];
+  __threadfence();                      // world before flag (a concurrent step kernel may poll it)
+  st.spare_episode[i] = want;
 }
 
 __global__ __launch_bounds__(kEnvBlock) void lunar_step_kernel(
@@ -1028,8 +1064,15 @@ __global__ __launch_bounds__(kEnvBlock) void lunar_step_kernel(
         if (ep_ret_out) ep_ret_out[i] = (float)ret;
         if (ep_len_out) ep_len_out[i] = len;
         ep = episode + 1u; step_idx = 0u; act = 0;
-        init_episode(W, lds, seed, env, ep, fx, fy);
         st.ep.ep_ret[i] = 0.0; st.ep.ep_len[i] = 0; st.ep.episode[i] = ep;
+        if (st.spare_episode[i] == ep) {             // next episode already prepared off the critical path
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          world_io(W, lds, st.spare_words, n, i, false);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o_next[k] = st.spare_obs[(size_t)k * n + i];
+          break;
+        }
+        init_episode(W, lds, seed, env, ep, fx, fy);
       } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) o_next[k] = o[k];
@@ -1055,6 +1098,12 @@ size_t lunar_state_bytes(int n) { return LunarState(nullptr, n).bytes; }
 int lunar_reset(void* state, int n, uint64_t seed, int64_t env_id0, float* obs_out, hipStream_t s) {
   hipLaunchKernelGGL(lunar_reset_kernel, dim3(cdiv(n, kEnvBlock)), dim3(kEnvBlock), 0, s, state, n, seed,
                      env_id0, obs_out);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int lunar_refill(void* state, int n, uint64_t seed, int64_t env_id0, hipStream_t s) {
+  hipLaunchKernelGGL(lunar_refill_kernel, dim3(cdiv(n, kEnvBlock)), dim3(kEnvBlock), 0, s, state, n, seed, env_id0);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

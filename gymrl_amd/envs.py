@@ -23,7 +23,7 @@ class VecEnv:
     reference touches: observation_space.shape, action_space.n|shape|high,
     spec.max_episode_steps, reset(seed), step(action)."""
 
-    def __init__(self, env_name, num_envs, device="cuda:0", seed=0, env_id0=0):
+    def __init__(self, env_name, num_envs, device="cuda:0", seed=0, env_id0=0, prefetch_resets=True):
         if env_name not in ops.ENV_KINDS:
             raise ValueError(f"unsupported env {env_name!r}; have {sorted(ops.ENV_KINDS)}")
         self.name, self.kind, self.n = env_name, ops.ENV_KINDS[env_name], int(num_envs)
@@ -39,13 +39,23 @@ class VecEnv:
         self.terminated = torch.zeros(n, dtype=torch.uint8, device=d)
         self.truncated = torch.zeros(n, dtype=torch.uint8, device=d)
         self.ep_stats = torch.zeros(3, dtype=torch.float64, device=d)  # (#episodes, sum return, sum len)
+        # expensive resets (LunarLander) are prepared on a side stream, off the step's critical path
+        self._side = torch.cuda.Stream(device=d) if (self.kind == ops.LUNARLANDER and prefetch_resets) else None
 
     def reset(self, obs_out=None, seed=None):
         if seed is not None:
             self.seed = int(seed)
         obs_out = torch.empty(self.n, self.obs_dim, device=self.device) if obs_out is None else obs_out
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)      # no refill may still be writing spares
         ops.env_reset(self.kind, self.state, self.n, self.seed, self.env_id0, obs_out)
+        self._refill()
         return obs_out
+
+    def _refill(self):
+        if self._side is not None:
+            self._side.wait_stream(torch.cuda.current_stream())      # after the step/reset just queued
+            ops.env_refill(self.kind, self.state, self.n, self.seed, self.env_id0, stream=self._side)
 
     def step(self, action, obs_out, rew_out, done_out=None, term_obs_out=None, ep_ret_out=None,
              ep_len_out=None, terminated_out=None, truncated_out=None):
@@ -54,9 +64,17 @@ class VecEnv:
                      self.truncated if truncated_out is None else truncated_out,
                      term_obs_out=term_obs_out, done_out=done_out, ep_ret_out=ep_ret_out,
                      ep_len_out=ep_len_out, ep_stats=self.ep_stats)
+        self._refill()
 
     def close(self):
-        pass
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def make(env_name, num_envs=1, **kw):

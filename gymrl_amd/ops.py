@@ -241,6 +241,12 @@ def env_reset(kind, state, n, seed, env_id0, obs_out):
                                 _ptr(obs_out, torch.float32), _stream()), "gymrl_env_reset")
 
 
+def env_refill(kind, state, n, seed, env_id0, stream=None):
+    st = _stream() if stream is None else _vp(stream.cuda_stream)
+    check(lib().gymrl_env_refill(C.c_int(kind), _ptr(state), C.c_int(n), C.c_uint64(seed), C.c_int64(env_id0), st),
+          "gymrl_env_refill")
+
+
 def env_step(kind, state, n, seed, env_id0, action, obs_out, rew_out, terminated_out, truncated_out,
              term_obs_out=None, done_out=None, ep_ret_out=None, ep_len_out=None, ep_stats=None):
     check(lib().gymrl_env_step(C.c_int(kind), _ptr(state), C.c_int(n), C.c_uint64(seed), C.c_int64(env_id0),

@@ -80,6 +80,15 @@ int gymrl_env_step(int kind, void* state, int n_envs, uint64_t seed, int64_t env
                    uint8_t* done_out, float* ep_ret_out, int32_t* ep_len_out,
                    double* ep_stats, void* stream);
 
+/* Optional latency hiding for expensive resets (LunarLander's reset() ends with a full
+ * physics step): prepares, for every env that lacks one, the post-reset world of its NEXT
+ * episode in a spare slot of `state`; gymrl_env_step then swaps it in when the episode ends
+ * instead of running the reset inside the step.  Results are bit-identical with or without
+ * it.  Intended for a side stream (it may overlap later gymrl_env_step calls on the same
+ * state); a no-op for CartPole / Pendulum. */
+int gymrl_env_refill(int kind, void* state, int n_envs, uint64_t seed, int64_t env_id0,
+                     void* stream);
+
 /* -------------------------------------------------- categorical policy ---- */
 /*
  * Categorical(logits).sample()/log_prob/entropy — ppo_lunarlander.py:92-104.

@@ -288,10 +288,18 @@ def _lander_heuristic(s):
     return a.astype(np.int32)
 
 
-def test_lunarlander_vs_oracle_bit_exact(dev, oracle):
+@pytest.mark.parametrize("refill", [False, True])
+def test_lunarlander_vs_oracle_bit_exact(dev, oracle, refill):
     """LunarLander-v3: the HIP solver and the CPU restatement agree on every bit of every
-    observation, reward and flag over auto-resetting trajectories (random + heuristic policy)."""
+    observation, reward and flag over auto-resetting trajectories (random + heuristic policy);
+    with refill=True the next-episode worlds come from gymrl_env_refill on a side stream."""
     from gymrl_amd import ops
+    side = torch.cuda.Stream(device=dev) if refill else None
+
+    def maybe_refill():
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            ops.env_refill(kind, state, n, seed, id0, stream=side)
     kind, n, seed, id0 = 2, 192, 21, 5000
     env = oracle.Env(kind, n, seed=seed, env_id0=id0)
     o_ref = env.reset()
@@ -303,6 +311,7 @@ def test_lunarlander_vs_oracle_bit_exact(dev, oracle):
     ep_len = torch.zeros(n, dtype=torch.int32, device=dev)
     stats = torch.zeros(3, dtype=torch.float64, device=dev)
     ops.env_reset(kind, state, n, seed, id0, obs)
+    maybe_refill()
     assert np.array_equal(obs.cpu().numpy(), o_ref)
     rng = np.random.default_rng(22)
     o = o_ref
@@ -314,6 +323,7 @@ def test_lunarlander_vs_oracle_bit_exact(dev, oracle):
         r = env.step(act)
         ops.env_step(kind, state, n, seed, id0, t(act, dev), obs, rew, term, trunc, term_obs_out=tobs, done_out=done,
                      ep_ret_out=ep_ret, ep_len_out=ep_len, ep_stats=stats)
+        maybe_refill()
         assert np.array_equal(obs.cpu().numpy(), r["obs"]), s
         assert np.array_equal(tobs.cpu().numpy(), r["term_obs"]), s
         assert np.array_equal(rew.cpu().numpy(), r["rew"]), s
@@ -326,6 +336,8 @@ def test_lunarlander_vs_oracle_bit_exact(dev, oracle):
             assert np.allclose(ep_ret.cpu().numpy()[d], r["ep_ret"][d], rtol=1e-6)
         o = r["obs"]
     assert landed > 20 and crashed > 20          # both terminal kinds were exercised
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)
 
 
 @pytest.mark.parametrize("D", [3, 4, 8])
