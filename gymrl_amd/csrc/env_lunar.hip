@@ -550,6 +550,30 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int action,
     }
   }
 
+  // The 180 sweeps read the contact data of every active slot each time; LDS round trips
+  // (one wave per SIMD: nothing hides them) dominated the kernel, so the per-slot solver
+  // constants and running impulses are hoisted into VGPRs for the duration of the loop
+  // (6 slots x 21 words; b and s fully unrolled => static register indices).
+  int vcn[3][2];
+  float vcf[3][2][16], vim[3][2][4];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      vcn[b][s] = any_contact ? (int)lds.vu(b, s, VC_COUNT) : 0;
+      if (vcn[b][s] > 0) {
+#pragma unroll
+        for (int f = 0; f < 16; ++f) vcf[b][s][f] = lds.vc(b, s, VC_NX + f);
+        vim[b][s][0] = lds.mf(b, s, MF_P0 + P_NI); vim[b][s][1] = lds.mf(b, s, MF_P0 + P_TI);
+        vim[b][s][2] = lds.mf(b, s, MF_P1 + P_NI); vim[b][s][3] = lds.mf(b, s, MF_P1 + P_TI);
+      } else {
+#pragma unroll
+        for (int f = 0; f < 16; ++f) vcf[b][s][f] = 0.0f;
+        vim[b][s][0] = vim[b][s][1] = vim[b][s][2] = vim[b][s][3] = 0.0f;
+      }
+    }
+  }
+
   // velocity iterations
 #pragma nounroll
   for (int it = 0; it < kVelIters; ++it) {
@@ -616,19 +640,18 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int action,
         const int b = ob == 0 ? 2 : (ob == 1 ? 0 : 1);
         const float mB = kInvM[b], iB = kInvI[b];
         const float fr = b == 0 ? sqrtf(0.1f * 0.1f) : sqrtf(0.2f * 0.1f);
-#pragma nounroll
+#pragma unroll
         for (int s = 0; s < 2; ++s) {
-          const int vcount = (int)lds.vu(b, s, VC_COUNT);
+          const int vcount = vcn[b][s];
           if (vcount > 0) {
-            const float nx = lds.vc(b, s, VC_NX), ny = lds.vc(b, s, VC_NY), tx = ny, ty = -nx;
-            const float rx0 = lds.vc(b, s, VC_RX0), ry0 = lds.vc(b, s, VC_RY0);
-            const float rx1 = lds.vc(b, s, VC_RX1), ry1 = lds.vc(b, s, VC_RY1);
-            float ni0 = lds.mf(b, s, MF_P0 + P_NI), ti0 = lds.mf(b, s, MF_P0 + P_TI);
-            float ni1 = lds.mf(b, s, MF_P1 + P_NI), ti1 = lds.mf(b, s, MF_P1 + P_TI);
+            const float* c = vcf[b][s];                 // indices: VC_* - VC_NX
+            const float nx = c[VC_NX - 1], ny = c[VC_NY - 1], tx = ny, ty = -nx;
+            const float rx0 = c[VC_RX0 - 1], ry0 = c[VC_RY0 - 1], rx1 = c[VC_RX1 - 1], ry1 = c[VC_RY1 - 1];
+            float ni0 = vim[b][s][0], ti0 = vim[b][s][1], ni1 = vim[b][s][2], ti1 = vim[b][s][3];
             {  // friction, point 0
               const float dvx = B[b].vx + (-B[b].w * ry0), dvy = B[b].vy + (B[b].w * rx0);
               const float vt = dot2(dvx, dvy, tx, ty);
-              float lam = lds.vc(b, s, VC_TM0) * (-vt);
+              float lam = c[VC_TM0 - 1] * (-vt);
               const float maxF = fr * ni0;
               const float nw = clampf(ti0 + lam, -maxF, maxF);
               lam = nw - ti0; ti0 = nw;
@@ -639,7 +662,7 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int action,
             if (vcount == 2) {  // friction, point 1
               const float dvx = B[b].vx + (-B[b].w * ry1), dvy = B[b].vy + (B[b].w * rx1);
               const float vt = dot2(dvx, dvy, tx, ty);
-              float lam = lds.vc(b, s, VC_TM1) * (-vt);
+              float lam = c[VC_TM1 - 1] * (-vt);
               const float maxF = fr * ni1;
               const float nw = clampf(ti1 + lam, -maxF, maxF);
               lam = nw - ti1; ti1 = nw;
@@ -650,7 +673,7 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int action,
             if (vcount == 1) {
               const float dvx = B[b].vx + (-B[b].w * ry0), dvy = B[b].vy + (B[b].w * rx0);
               const float vn = dot2(dvx, dvy, nx, ny);
-              float lam = -lds.vc(b, s, VC_NM0) * vn;
+              float lam = -c[VC_NM0 - 1] * vn;
               const float nw = fmaxf(ni0 + lam, 0.0f);
               lam = nw - ni0; ni0 = nw;
               const float Px = lam * nx, Py = lam * ny;
@@ -658,23 +681,23 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int action,
               B[b].w += iB * cross2(rx0, ry0, Px, Py);
             } else {
               // 2-point block solver (b2ContactSolver::SolveVelocityConstraints)
-              const float k11 = lds.vc(b, s, VC_K11), k12 = lds.vc(b, s, VC_K12), k22 = lds.vc(b, s, VC_K22);
+              const float k11 = c[VC_K11 - 1], k12 = c[VC_K12 - 1], k22 = c[VC_K22 - 1];
               const float a1 = ni0, a2 = ni1;
               const float dv1x = B[b].vx + (-B[b].w * ry0), dv1y = B[b].vy + (B[b].w * rx0);
               const float dv2x = B[b].vx + (-B[b].w * ry1), dv2y = B[b].vy + (B[b].w * rx1);
               float vn1 = dot2(dv1x, dv1y, nx, ny), vn2 = dot2(dv2x, dv2y, nx, ny);
               const float b1 = vn1 - (k11 * a1 + k12 * a2);
               const float b2 = vn2 - (k12 * a1 + k22 * a2);
-              float x1 = -(lds.vc(b, s, VC_I11) * b1 + lds.vc(b, s, VC_I12) * b2);
-              float x2 = -(lds.vc(b, s, VC_I12) * b1 + lds.vc(b, s, VC_I22) * b2);
+              float x1 = -(c[VC_I11 - 1] * b1 + c[VC_I12 - 1] * b2);
+              float x2 = -(c[VC_I12 - 1] * b1 + c[VC_I22 - 1] * b2);
               bool ok = (x1 >= 0.0f && x2 >= 0.0f);
               if (!ok) {
-                x1 = -lds.vc(b, s, VC_NM0) * b1; x2 = 0.0f;
+                x1 = -c[VC_NM0 - 1] * b1; x2 = 0.0f;
                 vn2 = k12 * x1 + b2;
                 ok = (x1 >= 0.0f && vn2 >= 0.0f);
               }
               if (!ok) {
-                x1 = 0.0f; x2 = -lds.vc(b, s, VC_NM1) * b2;
+                x1 = 0.0f; x2 = -c[VC_NM1 - 1] * b2;
                 vn1 = k12 * x2 + b1;
                 ok = (x2 >= 0.0f && vn1 >= 0.0f);
               }
@@ -690,9 +713,22 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int action,
                 ni0 = x1; ni1 = x2;
               }
             }
-            lds.mf(b, s, MF_P0 + P_NI) = ni0; lds.mf(b, s, MF_P0 + P_TI) = ti0;
-            if (vcount == 2) { lds.mf(b, s, MF_P1 + P_NI) = ni1; lds.mf(b, s, MF_P1 + P_TI) = ti1; }
+            vim[b][s][0] = ni0; vim[b][s][1] = ti0;
+            if (vcount == 2) { vim[b][s][2] = ni1; vim[b][s][3] = ti1; }
           }
+        }
+      }
+    }
+  }
+  // b2ContactSolver::StoreImpulses
+  if (any_contact) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (vcn[b][s] > 0) {
+          lds.mf(b, s, MF_P0 + P_NI) = vim[b][s][0]; lds.mf(b, s, MF_P0 + P_TI) = vim[b][s][1];
+          if (vcn[b][s] == 2) { lds.mf(b, s, MF_P1 + P_NI) = vim[b][s][2]; lds.mf(b, s, MF_P1 + P_TI) = vim[b][s][3]; }
         }
       }
     }
