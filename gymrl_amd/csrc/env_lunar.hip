@@ -11,12 +11,18 @@
 // solver, 180 velocity / <= 60 position iterations per 1/50 s step, Box2D's
 // sleep rule (the +100 "landed" terminal), gymnasium's reward shaping.
 //
-// Mapping: one env per lane, one wavefront per workgroup (N/64 waves spread over
-// N/64 CUs).  Each lane keeps its whole world in registers — at N = 4096 there is
-// one wave per SIMD at most, so the full 512-VGPR budget is free and LDS is only
-// used to stage the [64][8] observation tile into 1-KiB coalesced stores.
-// Bound: ALU latency (~180 dependent solver sweeps), not HBM: the ~400 B of SoA
-// state per env is read and written once per step with coalesced dword accesses.
+// Mapping: FOUR lanes per env (a DPP quad), 16 envs per wavefront, one wavefront per
+// workgroup (N/16 workgroups: 256 at N = 4096, one per CU).  Every lane of a quad carries
+// the three bodies and both joints in VGPRs and replays the joint solve redundantly; the
+// contact work is split by role: lane 0 owns the hull's terrain contacts, lanes 1/2 the
+// legs' (lane 3 mirrors lane 0 and never stores).  The three bodies' contact solves only
+// touch their own body (the terrain is static), so inside a solver sweep they run side by
+// side in one instruction stream and the quad re-synchronises with nine quad-broadcasts
+// (v_mov_dpp quad_perm) — a sweep is ~700 instructions instead of ~1290 for a lane that
+// walks all three bodies.  Per-lane manifolds and solver scratch live in LDS columns
+// ([word][lane]); the 180 velocity sweeps run out of VGPRs only.
+// Bound: ALU latency (180 dependent sweeps at one wave per SIMD), not HBM: the 576 B of
+// SoA state per env is read and written once per step.
 //
 // Determinism: IEEE f32 +,-,*,/,sqrt and explicit fmaf only (-ffp-contract=off),
 // det_sincosf for rotations, Philox for every random draw — the CPU oracle's
@@ -79,15 +85,27 @@ struct Manifold {
 // free); contacts are rare, so this keeps the always-hot state (bodies, joints) in VGPRs.
 constexpr int kMfWords = 16;   // count, faceB, lnx, lny, lpx, lpy, 2 x {lpx, lpy, key, ni, ti}
 constexpr int kVcWords = 17;   // count, nx, ny, rx0, ry0, rx1, ry1, nm0, nm1, tm0, tm1, K(3), K^-1(3)
-constexpr int kLdsWords = 6 * kMfWords + 6 * kVcWords;
+constexpr int kLdsWords = 2 * kMfWords + 2 * kVcWords;   // per lane: its own body's two slots
+constexpr int kQuad = 4;                                  // lanes per env
+constexpr int kEnvsPerBlock = kEnvBlock / kQuad;          // 16
 
 struct Lds {
   uint32_t* w;   // base + lane
-  __device__ __forceinline__ float& mf(int b, int s, int f) const { return reinterpret_cast<float*>(w)[((b * 2 + s) * kMfWords + f) * kEnvBlock]; }
-  __device__ __forceinline__ uint32_t& mu(int b, int s, int f) const { return w[((b * 2 + s) * kMfWords + f) * kEnvBlock]; }
-  __device__ __forceinline__ float& vc(int b, int s, int f) const { return reinterpret_cast<float*>(w)[(6 * kMfWords + (b * 2 + s) * kVcWords + f) * kEnvBlock]; }
-  __device__ __forceinline__ uint32_t& vu(int b, int s, int f) const { return w[(6 * kMfWords + (b * 2 + s) * kVcWords + f) * kEnvBlock]; }
+  __device__ __forceinline__ float& mf(int s, int f) const { return reinterpret_cast<float*>(w)[(s * kMfWords + f) * kEnvBlock]; }
+  __device__ __forceinline__ uint32_t& mu(int s, int f) const { return w[(s * kMfWords + f) * kEnvBlock]; }
+  __device__ __forceinline__ float& vc(int s, int f) const { return reinterpret_cast<float*>(w)[(2 * kMfWords + s * kVcWords + f) * kEnvBlock]; }
+  __device__ __forceinline__ uint32_t& vu(int s, int f) const { return w[(2 * kMfWords + s * kVcWords + f) * kEnvBlock]; }
 };
+
+// quad broadcast: every lane of a quad reads lane R's value (v_mov_b32 dpp quad_perm:[R,R,R,R])
+template <int R>
+__device__ __forceinline__ float quad_bcast(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), R * 0x55, 0xF, 0xF, false));
+}
+template <int R>
+__device__ __forceinline__ uint32_t quad_bcast_u(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, R * 0x55, 0xF, 0xF, false);
+}
 enum { MF_COUNT = 0, MF_FACEB = 1, MF_LNX = 2, MF_LNY = 3, MF_LPX = 4, MF_LPY = 5, MF_P0 = 6, MF_P1 = 11,
        P_LPX = 0, P_LPY = 1, P_KEY = 2, P_NI = 3, P_TI = 4 };
 enum { VC_COUNT = 0, VC_NX = 1, VC_NY = 2, VC_RX0 = 3, VC_RY0 = 4, VC_RX1 = 5, VC_RY1 = 6, VC_NM0 = 7, VC_NM1 = 8,
@@ -97,7 +115,7 @@ struct World {
   Body b[3];
   float sleep[3];
   Joint j[2];
-  int edge0[3];             // terrain edge index of slot 0 for each body (slot 1 = edge0 + 1)
+  int edge0;                // terrain edge index of slot 0 of THIS lane's body (slot 1 = edge0 + 1)
   uint32_t touching;        // bit (10*body + edge): pair was touching after the last Collide
   float ty[11];             // smoothed terrain heights at x = 0, 2, ..., 20
   uint32_t flags;           // bit0 leg0 ground contact, bit1 leg1, bit2 game_over, bit3 has prev_shaping, bit4 asleep
@@ -274,7 +292,6 @@ __device__ __forceinline__ void collide_edge_polygon(Manifold& mf, const float* 
   }
   mf.count = cnt;
 }
-
 __device__ __forceinline__ void body_xf(const Body& b, float lcy, float& px, float& py, float& qs, float& qc) {
   det_sincosf(b.a, &qs, &qc);
   // p = c - R * localCenter, localCenter = (0, lcy)
@@ -282,11 +299,40 @@ __device__ __forceinline__ void body_xf(const Body& b, float lcy, float& px, flo
   py = b.cy - (qs * 0.0f + qc * lcy);
 }
 
+// role -> owned body: lanes 0/3 the hull, 1 legs[0], 2 legs[1]
+__device__ __forceinline__ float sel3(int mb, float a, float b, float c) { return mb == 0 ? a : (mb == 1 ? b : c); }
+__device__ __forceinline__ Body select_body(const Body (&B)[3], int mb) {
+  Body r;   // field-wise selects: keeps the body array in VGPRs (no address-taken struct copy)
+  r.cx = sel3(mb, B[0].cx, B[1].cx, B[2].cx); r.cy = sel3(mb, B[0].cy, B[1].cy, B[2].cy);
+  r.a = sel3(mb, B[0].a, B[1].a, B[2].a);
+  r.vx = sel3(mb, B[0].vx, B[1].vx, B[2].vx); r.vy = sel3(mb, B[0].vy, B[1].vy, B[2].vy);
+  r.w = sel3(mb, B[0].w, B[1].w, B[2].w);
+  return r;
+}
+
+// Every lane of the quad adopts lane r's copy of body r (velocities or positions).
+__device__ __forceinline__ void quad_share_velocity(Body (&B)[3], const Body& mine) {
+  B[0].vx = quad_bcast<0>(mine.vx); B[0].vy = quad_bcast<0>(mine.vy); B[0].w = quad_bcast<0>(mine.w);
+  B[1].vx = quad_bcast<1>(mine.vx); B[1].vy = quad_bcast<1>(mine.vy); B[1].w = quad_bcast<1>(mine.w);
+  B[2].vx = quad_bcast<2>(mine.vx); B[2].vy = quad_bcast<2>(mine.vy); B[2].w = quad_bcast<2>(mine.w);
+}
+__device__ __forceinline__ void quad_share_position(Body (&B)[3], const Body& mine) {
+  B[0].cx = quad_bcast<0>(mine.cx); B[0].cy = quad_bcast<0>(mine.cy); B[0].a = quad_bcast<0>(mine.a);
+  B[1].cx = quad_bcast<1>(mine.cx); B[1].cy = quad_bcast<1>(mine.cy); B[1].a = quad_bcast<1>(mine.a);
+  B[2].cx = quad_bcast<2>(mine.cx); B[2].cy = quad_bcast<2>(mine.cy); B[2].a = quad_bcast<2>(mine.a);
+}
+
 // ------------------------------------------------------------------ one physics step
 // Applies the engine impulses for `action`, runs Collide + Solve, updates flags.
-__device__ __forceinline__ void world_step(World& W, const Lds& lds, int action, float disp0, float disp1,
-                                           float fx, float fy, float& m_power, float& s_power) {
+// `role` = lane & 3; mb = body this lane owns for contact work.
+__device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, int action, float disp0,
+                                           float disp1, float fx, float fy, float& m_power, float& s_power) {
   Body(&B)[3] = W.b;
+  const int mb = role == 3 ? 0 : role;
+  const bool is_hull = mb == 0;
+  const float mB_ = is_hull ? kInvM[0] : kInvM[1], iB_ = is_hull ? kInvI[0] : kInvI[1];
+  const float lcy_ = is_hull ? kHullLcY : 0.0f;
+  const float fr_ = is_hull ? sqrtf(0.1f * 0.1f) : sqrtf(0.2f * 0.1f);     // b2MixFriction with the terrain
   // ---- engines (gymnasium LunarLander.step) ----
   m_power = 0.0f; s_power = 0.0f;
   {
@@ -317,16 +363,16 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int action,
     }
   }
 
-  // ---- Collide: manifolds from the current transforms, warm-start matching, begin/end ----
-  uint32_t touching_now = 0u;
-  bool any_contact = false;
-#pragma unroll
-  for (int b = 0; b < 3; ++b) {
+  // ---- Collide (own body): manifolds from the current transform, warm-start matching ----
+  uint32_t my_touch = 0u;          // bit e: own body touches terrain edge e
+  bool my_contact = false;
+  {
+    const Body me = select_body(B, mb);
     float px, py, qs, qc;
-    body_xf(B[b], b == 0 ? kHullLcY : 0.0f, px, py, qs, qc);
+    body_xf(me, lcy_, px, py, qs, qc);
     // polygon x-extent -> candidate terrain edges (2 m wide each)
     float minx = 3.4e38f, maxx = -3.4e38f, miny = 3.4e38f;
-    if (b == 0) {
+    if (is_hull) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         const float x = (qc * kHullVx[i] - qs * kHullVy[i]) + px, y = (qs * kHullVx[i] + qc * kHullVy[i]) + py;
@@ -347,16 +393,16 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int action,
     int ocount[2]; uint32_t okey[2][2]; float oni[2][2], oti[2][2];
 #pragma unroll
     for (int os = 0; os < 2; ++os) {
-      ocount[os] = (int)lds.mu(b, os, MF_COUNT);
+      ocount[os] = (int)lds.mu(os, MF_COUNT);
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        okey[os][q] = lds.mu(b, os, MF_P0 + 5 * q + P_KEY);
-        oni[os][q] = lds.mf(b, os, MF_P0 + 5 * q + P_NI);
-        oti[os][q] = lds.mf(b, os, MF_P0 + 5 * q + P_TI);
+        okey[os][q] = lds.mu(os, MF_P0 + 5 * q + P_KEY);
+        oni[os][q] = lds.mf(os, MF_P0 + 5 * q + P_NI);
+        oti[os][q] = lds.mf(os, MF_P0 + 5 * q + P_TI);
       }
     }
-    const int old_e0 = W.edge0[b];
-    W.edge0[b] = e_lo;
+    const int old_e0 = W.edge0;
+    W.edge0 = e_lo;
 #pragma nounroll
     for (int s = 0; s < 2; ++s) {
       Manifold mf;
@@ -369,8 +415,8 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int action,
         for (int k = 0; k < 10; ++k) if (k == e) { y1 = W.ty[k]; y2 = W.ty[k + 1]; }
         const float x1 = 2.0f * (float)e, x2 = 2.0f * (float)(e + 1);
         if (miny - 2.0f * kPolyRadius <= fmaxf(y1, y2)) {
-          const float ccx = b == 0 ? B[0].cx : px, ccy = b == 0 ? B[0].cy : py;  // centroid == centre of mass
-          if (b == 0) collide_edge_polygon<6>(mf, kHullVx, kHullVy, kHullNx, kHullNy, px, py, qs, qc, ccx, ccy, x1, y1, x2, y2);
+          const float ccx = is_hull ? me.cx : px, ccy = is_hull ? me.cy : py;  // centroid == centre of mass
+          if (is_hull) collide_edge_polygon<6>(mf, kHullVx, kHullVy, kHullNx, kHullNy, px, py, qs, qc, ccx, ccy, x1, y1, x2, y2);
           else collide_edge_polygon<4>(mf, kLegVx, kLegVy, kLegNx, kLegNy, px, py, qs, qc, ccx, ccy, x1, y1, x2, y2);
         }
         // warm start: impulses of the same (edge, feature) from the previous step
@@ -391,20 +437,23 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int action,
             }
           }
         }
-        if (mf.count > 0) { touching_now |= 1u << (10 * b + e); any_contact = true; }
+        if (mf.count > 0) { my_touch |= 1u << e; my_contact = true; }
       }
-      lds.mu(b, s, MF_COUNT) = (uint32_t)mf.count; lds.mu(b, s, MF_FACEB) = (uint32_t)mf.faceB;
-      lds.mf(b, s, MF_LNX) = mf.lnx; lds.mf(b, s, MF_LNY) = mf.lny;
-      lds.mf(b, s, MF_LPX) = mf.lpx; lds.mf(b, s, MF_LPY) = mf.lpy;
+      lds.mu(s, MF_COUNT) = (uint32_t)mf.count; lds.mu(s, MF_FACEB) = (uint32_t)mf.faceB;
+      lds.mf(s, MF_LNX) = mf.lnx; lds.mf(s, MF_LNY) = mf.lny;
+      lds.mf(s, MF_LPX) = mf.lpx; lds.mf(s, MF_LPY) = mf.lpy;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        lds.mf(b, s, MF_P0 + 5 * k + P_LPX) = mf.p[k].lpx; lds.mf(b, s, MF_P0 + 5 * k + P_LPY) = mf.p[k].lpy;
-        lds.mu(b, s, MF_P0 + 5 * k + P_KEY) = mf.p[k].key;
-        lds.mf(b, s, MF_P0 + 5 * k + P_NI) = mf.p[k].ni; lds.mf(b, s, MF_P0 + 5 * k + P_TI) = mf.p[k].ti;
+        lds.mf(s, MF_P0 + 5 * k + P_LPX) = mf.p[k].lpx; lds.mf(s, MF_P0 + 5 * k + P_LPY) = mf.p[k].lpy;
+        lds.mu(s, MF_P0 + 5 * k + P_KEY) = mf.p[k].key;
+        lds.mf(s, MF_P0 + 5 * k + P_NI) = mf.p[k].ni; lds.mf(s, MF_P0 + 5 * k + P_TI) = mf.p[k].ti;
       }
     }
   }
-  // contact listener (gymnasium ContactDetector): edge order ascending per body
+  // contact listener (gymnasium ContactDetector) on the quad's combined touching mask
+  const uint32_t touching_now = quad_bcast_u<0>(my_touch) | (quad_bcast_u<1>(my_touch) << 10) |
+                                (quad_bcast_u<2>(my_touch) << 20);
+  const bool any_contact = touching_now != 0u;       // uniform across the quad
   {
     const uint32_t began = touching_now & ~W.touching, ended = W.touching & ~touching_now;
     if (began & 0x3FFu) W.flags |= 4u;                       // hull touched the moon: game over
@@ -430,27 +479,34 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int action,
     B[b].vy += h * (-10.0f + kInvM[b] * Fy);
   }
 
-  // contact velocity constraints + warm start
-  if (any_contact) {
+  // contact velocity constraints + warm start (own body), kept in VGPRs for the sweeps
+  int vcn[2] = {0, 0};
+  float vcf[2][16], vim[2][4];
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int f = 0; f < 16; ++f) vcf[s][f] = 0.0f;
+    vim[s][0] = vim[s][1] = vim[s][2] = vim[s][3] = 0.0f;
+  }
+  if (any_contact) {
+    Body me = select_body(B, mb);
+    if (my_contact) {
       float px, py, qs, qc;
-      body_xf(B[b], b == 0 ? kHullLcY : 0.0f, px, py, qs, qc);
-      const float mB = kInvM[b], iB = kInvI[b];
-#pragma nounroll
+      body_xf(me, lcy_, px, py, qs, qc);
+#pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const int count = (int)lds.mu(b, s, MF_COUNT);
+        const int count = (int)lds.mu(s, MF_COUNT);
         int vcount = count;
         if (count > 0) {
-          const bool faceB = lds.mu(b, s, MF_FACEB) != 0u;
-          const float lnx = lds.mf(b, s, MF_LNX), lny = lds.mf(b, s, MF_LNY);
-          const float lpx = lds.mf(b, s, MF_LPX), lpy = lds.mf(b, s, MF_LPY);
+          const bool faceB = lds.mu(s, MF_FACEB) != 0u;
+          const float lnx = lds.mf(s, MF_LNX), lny = lds.mf(s, MF_LNY);
+          const float lpx = lds.mf(s, MF_LPX), lpy = lds.mf(s, MF_LPY);
           float nx, ny, wpx[2], wpy[2];
           if (!faceB) {
             nx = lnx; ny = lny;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-              const float qx = lds.mf(b, s, MF_P0 + 5 * k + P_LPX), qy = lds.mf(b, s, MF_P0 + 5 * k + P_LPY);
+              const float qx = lds.mf(s, MF_P0 + 5 * k + P_LPX), qy = lds.mf(s, MF_P0 + 5 * k + P_LPY);
               const float clx = (qc * qx - qs * qy) + px, cly = (qs * qx + qc * qy) + py;
               const float d = kPolyRadius - dot2(clx - lpx, cly - lpy, nx, ny);
               const float cAx = clx + d * nx, cAy = cly + d * ny;
@@ -462,7 +518,7 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int action,
             const float ppx = (qc * lpx - qs * lpy) + px, ppy = (qs * lpx + qc * lpy) + py;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-              const float clx = lds.mf(b, s, MF_P0 + 5 * k + P_LPX), cly = lds.mf(b, s, MF_P0 + 5 * k + P_LPY);
+              const float clx = lds.mf(s, MF_P0 + 5 * k + P_LPX), cly = lds.mf(s, MF_P0 + 5 * k + P_LPY);
               const float d = kPolyRadius - dot2(clx - ppx, cly - ppy, nx, ny);
               const float cBx = clx + d * nx, cBy = cly + d * ny;
               const float cAx = clx - kPolyRadius * nx, cAy = cly - kPolyRadius * ny;
@@ -474,45 +530,48 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int action,
           float rx[2], ry[2];
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
-            rx[k] = wpx[k] - B[b].cx; ry[k] = wpy[k] - B[b].cy;
+            rx[k] = wpx[k] - me.cx; ry[k] = wpy[k] - me.cy;
             const float rn = cross2(rx[k], ry[k], nx, ny);
-            const float kn = mB + iB * rn * rn;
-            lds.vc(b, s, VC_NM0 + k) = kn > 0.0f ? 1.0f / kn : 0.0f;
+            const float kn = mB_ + iB_ * rn * rn;
+            vcf[s][VC_NM0 - 1 + k] = kn > 0.0f ? 1.0f / kn : 0.0f;
             const float rt = cross2(rx[k], ry[k], tx, ty);
-            const float kt = mB + iB * rt * rt;
-            lds.vc(b, s, VC_TM0 + k) = kt > 0.0f ? 1.0f / kt : 0.0f;
-            lds.vc(b, s, VC_RX0 + 2 * k) = rx[k]; lds.vc(b, s, VC_RY0 + 2 * k) = ry[k];
+            const float kt = mB_ + iB_ * rt * rt;
+            vcf[s][VC_TM0 - 1 + k] = kt > 0.0f ? 1.0f / kt : 0.0f;
+            vcf[s][VC_RX0 - 1 + 2 * k] = rx[k]; vcf[s][VC_RY0 - 1 + 2 * k] = ry[k];
           }
-          lds.vc(b, s, VC_NX) = nx; lds.vc(b, s, VC_NY) = ny;
+          vcf[s][VC_NX - 1] = nx; vcf[s][VC_NY - 1] = ny;
           if (count == 2) {
             const float rn1 = cross2(rx[0], ry[0], nx, ny), rn2 = cross2(rx[1], ry[1], nx, ny);
-            const float k11 = mB + iB * rn1 * rn1, k22 = mB + iB * rn2 * rn2, k12 = mB + iB * rn1 * rn2;
+            const float k11 = mB_ + iB_ * rn1 * rn1, k22 = mB_ + iB_ * rn2 * rn2, k12 = mB_ + iB_ * rn1 * rn2;
             if (k11 * k11 < 1000.0f * (k11 * k22 - k12 * k12)) {
               float det = k11 * k22 - k12 * k12;
               if (det != 0.0f) det = 1.0f / det;
-              lds.vc(b, s, VC_K11) = k11; lds.vc(b, s, VC_K12) = k12; lds.vc(b, s, VC_K22) = k22;
-              lds.vc(b, s, VC_I11) = det * k22; lds.vc(b, s, VC_I12) = -det * k12; lds.vc(b, s, VC_I22) = det * k11;
+              vcf[s][VC_K11 - 1] = k11; vcf[s][VC_K12 - 1] = k12; vcf[s][VC_K22 - 1] = k22;
+              vcf[s][VC_I11 - 1] = det * k22; vcf[s][VC_I12 - 1] = -det * k12; vcf[s][VC_I22 - 1] = det * k11;
             } else {
               vcount = 1;   // nearly redundant second point: Box2D drops it from the velocity solve
             }
           }
+          vim[s][0] = lds.mf(s, MF_P0 + P_NI); vim[s][1] = lds.mf(s, MF_P0 + P_TI);
+          vim[s][2] = lds.mf(s, MF_P1 + P_NI); vim[s][3] = lds.mf(s, MF_P1 + P_TI);
           // warm start
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
             if (k < vcount) {
-              const float ni = lds.mf(b, s, MF_P0 + 5 * k + P_NI), ti = lds.mf(b, s, MF_P0 + 5 * k + P_TI);
+              const float ni = vim[s][2 * k], ti = vim[s][2 * k + 1];
               const float Px = ni * nx + ti * tx, Py = ni * ny + ti * ty;
-              B[b].w += iB * cross2(rx[k], ry[k], Px, Py);
-              B[b].vx += mB * Px; B[b].vy += mB * Py;
+              me.w += iB_ * cross2(rx[k], ry[k], Px, Py);
+              me.vx += mB_ * Px; me.vy += mB_ * Py;
             }
           }
         }
-        lds.vu(b, s, VC_COUNT) = (uint32_t)vcount;
+        vcn[s] = vcount;
       }
     }
+    quad_share_velocity(B, me);
   }
 
-  // joints: InitVelocityConstraints (island order: joint of legs[1], then legs[0])
+  // joints: InitVelocityConstraints (island order: joint of legs[1], then legs[0]); replicated per lane
   float jrAx[2], jrAy[2], jrBx[2], jrBy[2];
   float K11[2], K12[2], K13[2], K22[2], K23[2], K33[2], mmass[2];
   {
@@ -547,30 +606,6 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int action,
       B[0].w -= iA * (cross2(jrAx[L], jrAy[L], Px, Py) + J.im + J.iz);
       B[bi].vx += mB * Px; B[bi].vy += mB * Py;
       B[bi].w += iB * (cross2(jrBx[L], jrBy[L], Px, Py) + J.im + J.iz);
-    }
-  }
-
-  // The 180 sweeps read the contact data of every active slot each time; LDS round trips
-  // (one wave per SIMD: nothing hides them) dominated the kernel, so the per-slot solver
-  // constants and running impulses are hoisted into VGPRs for the duration of the loop
-  // (6 slots x 21 words; b and s fully unrolled => static register indices).
-  int vcn[3][2];
-  float vcf[3][2][16], vim[3][2][4];
-#pragma unroll
-  for (int b = 0; b < 3; ++b) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      vcn[b][s] = any_contact ? (int)lds.vu(b, s, VC_COUNT) : 0;
-      if (vcn[b][s] > 0) {
-#pragma unroll
-        for (int f = 0; f < 16; ++f) vcf[b][s][f] = lds.vc(b, s, VC_NX + f);
-        vim[b][s][0] = lds.mf(b, s, MF_P0 + P_NI); vim[b][s][1] = lds.mf(b, s, MF_P0 + P_TI);
-        vim[b][s][2] = lds.mf(b, s, MF_P1 + P_NI); vim[b][s][3] = lds.mf(b, s, MF_P1 + P_TI);
-      } else {
-#pragma unroll
-        for (int f = 0; f < 16; ++f) vcf[b][s][f] = 0.0f;
-        vim[b][s][0] = vim[b][s][1] = vim[b][s][2] = vim[b][s][3] = 0.0f;
-      }
     }
   }
 
@@ -633,103 +668,95 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int action,
       B[bi].vx += mB * ipx; B[bi].vy += mB * ipy;
       B[bi].w += iB * (cross2(jrBx[L], jrBy[L], ipx, ipy) + ipz);
     }
-    // contacts (island order: legs[1], hull, legs[0])
+    // contacts: each lane solves its own body's slots, then the quad exchanges velocities
     if (any_contact) {
+      Body me = select_body(B, mb);
 #pragma unroll
-      for (int ob = 0; ob < 3; ++ob) {
-        const int b = ob == 0 ? 2 : (ob == 1 ? 0 : 1);
-        const float mB = kInvM[b], iB = kInvI[b];
-        const float fr = b == 0 ? sqrtf(0.1f * 0.1f) : sqrtf(0.2f * 0.1f);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int vcount = vcn[b][s];
-          if (vcount > 0) {
-            const float* c = vcf[b][s];                 // indices: VC_* - VC_NX
-            const float nx = c[VC_NX - 1], ny = c[VC_NY - 1], tx = ny, ty = -nx;
-            const float rx0 = c[VC_RX0 - 1], ry0 = c[VC_RY0 - 1], rx1 = c[VC_RX1 - 1], ry1 = c[VC_RY1 - 1];
-            float ni0 = vim[b][s][0], ti0 = vim[b][s][1], ni1 = vim[b][s][2], ti1 = vim[b][s][3];
-            {  // friction, point 0
-              const float dvx = B[b].vx + (-B[b].w * ry0), dvy = B[b].vy + (B[b].w * rx0);
-              const float vt = dot2(dvx, dvy, tx, ty);
-              float lam = c[VC_TM0 - 1] * (-vt);
-              const float maxF = fr * ni0;
-              const float nw = clampf(ti0 + lam, -maxF, maxF);
-              lam = nw - ti0; ti0 = nw;
-              const float Px = lam * tx, Py = lam * ty;
-              B[b].vx += mB * Px; B[b].vy += mB * Py;
-              B[b].w += iB * cross2(rx0, ry0, Px, Py);
-            }
-            if (vcount == 2) {  // friction, point 1
-              const float dvx = B[b].vx + (-B[b].w * ry1), dvy = B[b].vy + (B[b].w * rx1);
-              const float vt = dot2(dvx, dvy, tx, ty);
-              float lam = c[VC_TM1 - 1] * (-vt);
-              const float maxF = fr * ni1;
-              const float nw = clampf(ti1 + lam, -maxF, maxF);
-              lam = nw - ti1; ti1 = nw;
-              const float Px = lam * tx, Py = lam * ty;
-              B[b].vx += mB * Px; B[b].vy += mB * Py;
-              B[b].w += iB * cross2(rx1, ry1, Px, Py);
-            }
-            if (vcount == 1) {
-              const float dvx = B[b].vx + (-B[b].w * ry0), dvy = B[b].vy + (B[b].w * rx0);
-              const float vn = dot2(dvx, dvy, nx, ny);
-              float lam = -c[VC_NM0 - 1] * vn;
-              const float nw = fmaxf(ni0 + lam, 0.0f);
-              lam = nw - ni0; ni0 = nw;
-              const float Px = lam * nx, Py = lam * ny;
-              B[b].vx += mB * Px; B[b].vy += mB * Py;
-              B[b].w += iB * cross2(rx0, ry0, Px, Py);
-            } else {
-              // 2-point block solver (b2ContactSolver::SolveVelocityConstraints)
-              const float k11 = c[VC_K11 - 1], k12 = c[VC_K12 - 1], k22 = c[VC_K22 - 1];
-              const float a1 = ni0, a2 = ni1;
-              const float dv1x = B[b].vx + (-B[b].w * ry0), dv1y = B[b].vy + (B[b].w * rx0);
-              const float dv2x = B[b].vx + (-B[b].w * ry1), dv2y = B[b].vy + (B[b].w * rx1);
-              float vn1 = dot2(dv1x, dv1y, nx, ny), vn2 = dot2(dv2x, dv2y, nx, ny);
-              const float b1 = vn1 - (k11 * a1 + k12 * a2);
-              const float b2 = vn2 - (k12 * a1 + k22 * a2);
-              float x1 = -(c[VC_I11 - 1] * b1 + c[VC_I12 - 1] * b2);
-              float x2 = -(c[VC_I12 - 1] * b1 + c[VC_I22 - 1] * b2);
-              bool ok = (x1 >= 0.0f && x2 >= 0.0f);
-              if (!ok) {
-                x1 = -c[VC_NM0 - 1] * b1; x2 = 0.0f;
-                vn2 = k12 * x1 + b2;
-                ok = (x1 >= 0.0f && vn2 >= 0.0f);
-              }
-              if (!ok) {
-                x1 = 0.0f; x2 = -c[VC_NM1 - 1] * b2;
-                vn1 = k12 * x2 + b1;
-                ok = (x2 >= 0.0f && vn1 >= 0.0f);
-              }
-              if (!ok) {
-                x1 = 0.0f; x2 = 0.0f;
-                ok = (b1 >= 0.0f && b2 >= 0.0f);
-              }
-              if (ok) {
-                const float d1 = x1 - a1, d2 = x2 - a2;
-                const float P1x = d1 * nx, P1y = d1 * ny, P2x = d2 * nx, P2y = d2 * ny;
-                B[b].vx += mB * (P1x + P2x); B[b].vy += mB * (P1y + P2y);
-                B[b].w += iB * (cross2(rx0, ry0, P1x, P1y) + cross2(rx1, ry1, P2x, P2y));
-                ni0 = x1; ni1 = x2;
-              }
-            }
-            vim[b][s][0] = ni0; vim[b][s][1] = ti0;
-            if (vcount == 2) { vim[b][s][2] = ni1; vim[b][s][3] = ti1; }
+      for (int s = 0; s < 2; ++s) {
+        const int vcount = vcn[s];
+        if (vcount > 0) {
+          const float nx = vcf[s][VC_NX - 1], ny = vcf[s][VC_NY - 1], tx = ny, ty = -nx;
+          const float rx0 = vcf[s][VC_RX0 - 1], ry0 = vcf[s][VC_RY0 - 1], rx1 = vcf[s][VC_RX1 - 1], ry1 = vcf[s][VC_RY1 - 1];
+          float ni0 = vim[s][0], ti0 = vim[s][1], ni1 = vim[s][2], ti1 = vim[s][3];
+          {  // friction, point 0
+            const float dvx = me.vx + (-me.w * ry0), dvy = me.vy + (me.w * rx0);
+            const float vt = dot2(dvx, dvy, tx, ty);
+            float lam = vcf[s][VC_TM0 - 1] * (-vt);
+            const float maxF = fr_ * ni0;
+            const float nw = clampf(ti0 + lam, -maxF, maxF);
+            lam = nw - ti0; ti0 = nw;
+            const float Px = lam * tx, Py = lam * ty;
+            me.vx += mB_ * Px; me.vy += mB_ * Py;
+            me.w += iB_ * cross2(rx0, ry0, Px, Py);
           }
+          if (vcount == 2) {  // friction, point 1
+            const float dvx = me.vx + (-me.w * ry1), dvy = me.vy + (me.w * rx1);
+            const float vt = dot2(dvx, dvy, tx, ty);
+            float lam = vcf[s][VC_TM1 - 1] * (-vt);
+            const float maxF = fr_ * ni1;
+            const float nw = clampf(ti1 + lam, -maxF, maxF);
+            lam = nw - ti1; ti1 = nw;
+            const float Px = lam * tx, Py = lam * ty;
+            me.vx += mB_ * Px; me.vy += mB_ * Py;
+            me.w += iB_ * cross2(rx1, ry1, Px, Py);
+          }
+          if (vcount == 1) {
+            const float dvx = me.vx + (-me.w * ry0), dvy = me.vy + (me.w * rx0);
+            const float vn = dot2(dvx, dvy, nx, ny);
+            float lam = -vcf[s][VC_NM0 - 1] * vn;
+            const float nw = fmaxf(ni0 + lam, 0.0f);
+            lam = nw - ni0; ni0 = nw;
+            const float Px = lam * nx, Py = lam * ny;
+            me.vx += mB_ * Px; me.vy += mB_ * Py;
+            me.w += iB_ * cross2(rx0, ry0, Px, Py);
+          } else {
+            // 2-point block solver (b2ContactSolver::SolveVelocityConstraints)
+            const float k11 = vcf[s][VC_K11 - 1], k12 = vcf[s][VC_K12 - 1], k22 = vcf[s][VC_K22 - 1];
+            const float a1 = ni0, a2 = ni1;
+            const float dv1x = me.vx + (-me.w * ry0), dv1y = me.vy + (me.w * rx0);
+            const float dv2x = me.vx + (-me.w * ry1), dv2y = me.vy + (me.w * rx1);
+            float vn1 = dot2(dv1x, dv1y, nx, ny), vn2 = dot2(dv2x, dv2y, nx, ny);
+            const float b1 = vn1 - (k11 * a1 + k12 * a2);
+            const float b2 = vn2 - (k12 * a1 + k22 * a2);
+            float x1 = -(vcf[s][VC_I11 - 1] * b1 + vcf[s][VC_I12 - 1] * b2);
+            float x2 = -(vcf[s][VC_I12 - 1] * b1 + vcf[s][VC_I22 - 1] * b2);
+            bool ok = (x1 >= 0.0f && x2 >= 0.0f);
+            if (!ok) {
+              x1 = -vcf[s][VC_NM0 - 1] * b1; x2 = 0.0f;
+              vn2 = k12 * x1 + b2;
+              ok = (x1 >= 0.0f && vn2 >= 0.0f);
+            }
+            if (!ok) {
+              x1 = 0.0f; x2 = -vcf[s][VC_NM1 - 1] * b2;
+              vn1 = k12 * x2 + b1;
+              ok = (x2 >= 0.0f && vn1 >= 0.0f);
+            }
+            if (!ok) {
+              x1 = 0.0f; x2 = 0.0f;
+              ok = (b1 >= 0.0f && b2 >= 0.0f);
+            }
+            if (ok) {
+              const float d1 = x1 - a1, d2 = x2 - a2;
+              const float P1x = d1 * nx, P1y = d1 * ny, P2x = d2 * nx, P2y = d2 * ny;
+              me.vx += mB_ * (P1x + P2x); me.vy += mB_ * (P1y + P2y);
+              me.w += iB_ * (cross2(rx0, ry0, P1x, P1y) + cross2(rx1, ry1, P2x, P2y));
+              ni0 = x1; ni1 = x2;
+            }
+          }
+          vim[s][0] = ni0; vim[s][1] = ti0;
+          if (vcount == 2) { vim[s][2] = ni1; vim[s][3] = ti1; }
         }
       }
+      quad_share_velocity(B, me);
     }
   }
   // b2ContactSolver::StoreImpulses
-  if (any_contact) {
+  if (my_contact) {
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        if (vcn[b][s] > 0) {
-          lds.mf(b, s, MF_P0 + P_NI) = vim[b][s][0]; lds.mf(b, s, MF_P0 + P_TI) = vim[b][s][1];
-          if (vcn[b][s] == 2) { lds.mf(b, s, MF_P1 + P_NI) = vim[b][s][2]; lds.mf(b, s, MF_P1 + P_TI) = vim[b][s][3]; }
-        }
+    for (int s = 0; s < 2; ++s) {
+      if (vcn[s] > 0) {
+        lds.mf(s, MF_P0 + P_NI) = vim[s][0]; lds.mf(s, MF_P0 + P_TI) = vim[s][1];
+        if (vcn[s] == 2) { lds.mf(s, MF_P1 + P_NI) = vim[s][2]; lds.mf(s, MF_P1 + P_TI) = vim[s][3]; }
       }
     }
   }
@@ -756,49 +783,47 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int action,
   for (int it = 0; it < kPosIters; ++it) {
     float min_sep = 0.0f;
     if (any_contact) {
-#pragma unroll
-      for (int ob = 0; ob < 3; ++ob) {
-        const int b = ob == 0 ? 2 : (ob == 1 ? 0 : 1);
-        const float mB = kInvM[b], iB = kInvI[b];
-        const float lcy = b == 0 ? kHullLcY : 0.0f;
+      Body me = select_body(B, mb);
+      float my_min = 0.0f;
 #pragma nounroll
-        for (int s = 0; s < 2; ++s) {
-          const int cnt = (int)lds.mu(b, s, MF_COUNT);   // the position solver keeps every manifold point
-          if (cnt > 0) {
-            const bool faceB = lds.mu(b, s, MF_FACEB) != 0u;
-            const float lnx = lds.mf(b, s, MF_LNX), lny = lds.mf(b, s, MF_LNY);
-            const float lpx = lds.mf(b, s, MF_LPX), lpy = lds.mf(b, s, MF_LPY);
+      for (int s = 0; s < 2; ++s) {
+        const int cnt = my_contact ? (int)lds.mu(s, MF_COUNT) : 0;   // the position solver keeps every manifold point
+        if (cnt > 0) {
+          const bool faceB = lds.mu(s, MF_FACEB) != 0u;
+          const float lnx = lds.mf(s, MF_LNX), lny = lds.mf(s, MF_LNY);
+          const float lpx = lds.mf(s, MF_LPX), lpy = lds.mf(s, MF_LPY);
 #pragma nounroll
-            for (int k = 0; k < cnt; ++k) {
-              const float qx = lds.mf(b, s, MF_P0 + 5 * k + P_LPX), qy = lds.mf(b, s, MF_P0 + 5 * k + P_LPY);
-              float px, py, qs, qc;
-              body_xf(B[b], lcy, px, py, qs, qc);
-              float nx, ny, ptx, pty, sep;
-              if (!faceB) {
-                nx = lnx; ny = lny;
-                const float clx = (qc * qx - qs * qy) + px, cly = (qs * qx + qc * qy) + py;
-                sep = dot2(clx - lpx, cly - lpy, nx, ny) - kPolyRadius - kPolyRadius;
-                ptx = clx; pty = cly;
-              } else {
-                nx = qc * lnx - qs * lny; ny = qs * lnx + qc * lny;
-                const float ppx = (qc * lpx - qs * lpy) + px, ppy = (qs * lpx + qc * lpy) + py;
-                sep = dot2(qx - ppx, qy - ppy, nx, ny) - kPolyRadius - kPolyRadius;
-                ptx = qx; pty = qy;
-                nx = -nx; ny = -ny;
-              }
-              const float rx = ptx - B[b].cx, ry = pty - B[b].cy;
-              min_sep = fminf(min_sep, sep);
-              const float C = clampf(kBaumgarte * (sep + kLinearSlop), -kMaxLinCorr, 0.0f);
-              const float rn = cross2(rx, ry, nx, ny);
-              const float K = mB + iB * rn * rn;
-              const float imp = K > 0.0f ? -C / K : 0.0f;
-              const float Px = imp * nx, Py = imp * ny;
-              B[b].cx += mB * Px; B[b].cy += mB * Py;
-              B[b].a += iB * cross2(rx, ry, Px, Py);
+          for (int k = 0; k < cnt; ++k) {
+            const float qx = lds.mf(s, MF_P0 + 5 * k + P_LPX), qy = lds.mf(s, MF_P0 + 5 * k + P_LPY);
+            float px, py, qs, qc;
+            body_xf(me, lcy_, px, py, qs, qc);
+            float nx, ny, ptx, pty, sep;
+            if (!faceB) {
+              nx = lnx; ny = lny;
+              const float clx = (qc * qx - qs * qy) + px, cly = (qs * qx + qc * qy) + py;
+              sep = dot2(clx - lpx, cly - lpy, nx, ny) - kPolyRadius - kPolyRadius;
+              ptx = clx; pty = cly;
+            } else {
+              nx = qc * lnx - qs * lny; ny = qs * lnx + qc * lny;
+              const float ppx = (qc * lpx - qs * lpy) + px, ppy = (qs * lpx + qc * lpy) + py;
+              sep = dot2(qx - ppx, qy - ppy, nx, ny) - kPolyRadius - kPolyRadius;
+              ptx = qx; pty = qy;
+              nx = -nx; ny = -ny;
             }
+            const float rx = ptx - me.cx, ry = pty - me.cy;
+            my_min = fminf(my_min, sep);
+            const float C = clampf(kBaumgarte * (sep + kLinearSlop), -kMaxLinCorr, 0.0f);
+            const float rn = cross2(rx, ry, nx, ny);
+            const float K = mB_ + iB_ * rn * rn;
+            const float imp = K > 0.0f ? -C / K : 0.0f;
+            const float Px = imp * nx, Py = imp * ny;
+            me.cx += mB_ * Px; me.cy += mB_ * Py;
+            me.a += iB_ * cross2(rx, ry, Px, Py);
           }
         }
       }
+      quad_share_position(B, me);
+      min_sep = fminf(fminf(quad_bcast<0>(my_min), quad_bcast<1>(my_min)), quad_bcast<2>(my_min));
     }
     const bool contacts_ok = min_sep >= -3.0f * kLinearSlop;
     bool joints_ok = true;
@@ -885,14 +910,14 @@ __device__ __forceinline__ float shaping_of(const float (&o)[8]) {
          100.0f * fabsf(o[4]) + 10.0f * o[6] + 10.0f * o[7];
 }
 
-// gymnasium step(): returns reward / terminated, fills o.
-__device__ __forceinline__ void env_step_once(World& W, const Lds& lds, int action, uint64_t seed, uint64_t env,
-                                              uint32_t episode, uint32_t step_idx, float fx, float fy,
-                                              float (&o)[8], float& reward, bool& terminated) {
+// gymnasium step(): returns reward / terminated, fills o (replicated on the quad's lanes).
+__device__ __forceinline__ void env_step_once(World& W, const Lds& lds, int role, int action, uint64_t seed,
+                                              uint64_t env, uint32_t episode, uint32_t step_idx, float fx,
+                                              float fy, float (&o)[8], float& reward, bool& terminated) {
   const u32x4 r = philox4x32(seed, (uint32_t)env, (uint32_t)(env >> 32), episode, RNG_ENV_STEP | step_idx);
   const float d0 = (-1.0f + 2.0f * u01f(r.x)) / kScale, d1 = (-1.0f + 2.0f * u01f(r.y)) / kScale;
   float mp, sp;
-  world_step(W, lds, action, d0, d1, fx, fy, mp, sp);
+  world_step(W, lds, role, action, d0, d1, fx, fy, mp, sp);
   lander_obs(W, o);
   const float shaping = shaping_of(o);
   reward = 0.0f;
@@ -934,15 +959,19 @@ __device__ __forceinline__ void init_episode(World& W, const Lds& lds, uint64_t 
     W.j[L] = Joint{0.0f, 0.0f, 0.0f, 0.0f, 0};
   }
 #pragma unroll
-  for (int b = 0; b < 3; ++b) { W.sleep[b] = 0.0f; W.edge0[b] = 0; }
+  for (int b = 0; b < 3; ++b) W.sleep[b] = 0.0f;
+  W.edge0 = 0;
 #pragma nounroll
-  for (int k = 0; k < 6 * kMfWords; ++k) lds.w[k * kEnvBlock] = 0u;
+  for (int k = 0; k < 2 * kMfWords; ++k) lds.w[k * kEnvBlock] = 0u;
   W.touching = 0u; W.flags = 0u; W.prev_shaping = 0.0f;
 }
 
 // ------------------------------------------------------------------ SoA state in HBM
-// Everything a lane needs between steps; [field][N] arrays (coalesced dword accesses).
-constexpr int kWorldWords = 18 + 3 + 10 + 3 * 2 * (2 + 4 + 2 * 5) + 3 + 1 + 11 + 1 + 1;   // f32/u32/i32 words
+// Everything an env needs between steps; [field][N] dword arrays.  Word order:
+//   bodies 18 | sleep 3 | joints 10 | manifolds 3 bodies x 2 slots x 16 | edge0 3 | touching |
+//   terrain 11 | flags | prev_shaping
+constexpr int kWorldWords = 18 + 3 + 10 + 3 * 2 * kMfWords + 3 + 1 + 11 + 1 + 1;   // 144
+constexpr int kWMf = 31, kWEdge0 = 31 + 96, kWTail = 31 + 96 + 3;
 
 // A second world per env ("spare") holds the NEXT episode's post-reset state, computed by
 // gymrl_env_refill off the critical path (reset() costs a full solver pass because it ends
@@ -970,23 +999,27 @@ struct LunarState {
 };
 
 struct WordIO {
-  uint32_t* base; int n; int i; int k;
+  uint32_t* base; int n; int i; int k; bool wr;   // wr: this lane performs stores
   __device__ __forceinline__ void f(float& x, bool store) {
-    if (store) base[(size_t)k * n + i] = __float_as_uint(x); else x = __uint_as_float(base[(size_t)k * n + i]);
+    if (store) { if (wr) base[(size_t)k * n + i] = __float_as_uint(x); } else x = __uint_as_float(base[(size_t)k * n + i]);
     ++k;
   }
   __device__ __forceinline__ void u(uint32_t& x, bool store) {
-    if (store) base[(size_t)k * n + i] = x; else x = base[(size_t)k * n + i];
+    if (store) { if (wr) base[(size_t)k * n + i] = x; } else x = base[(size_t)k * n + i];
     ++k;
   }
   __device__ __forceinline__ void d(int& x, bool store) {
-    if (store) base[(size_t)k * n + i] = (uint32_t)x; else x = (int)base[(size_t)k * n + i];
+    if (store) { if (wr) base[(size_t)k * n + i] = (uint32_t)x; } else x = (int)base[(size_t)k * n + i];
     ++k;
   }
 };
 
-__device__ __forceinline__ void world_io(World& W, const Lds& lds, uint32_t* base, int n, int i, bool store) {
-  WordIO io{base, n, i, 0};
+// Loads: every lane of the quad reads the replicated words and its own body's manifolds.
+// Stores: lane 0 writes the replicated words, lanes 0..2 their body's manifolds + edge0.
+__device__ __forceinline__ void world_io(World& W, const Lds& lds, int role, uint32_t* base, int n, int i,
+                                         bool store) {
+  const int mb = role == 3 ? 0 : role;
+  WordIO io{base, n, i, 0, role == 0};
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
     io.f(W.b[b].cx, store); io.f(W.b[b].cy, store); io.f(W.b[b].a, store);
@@ -999,11 +1032,15 @@ __device__ __forceinline__ void world_io(World& W, const Lds& lds, uint32_t* bas
     io.f(W.j[L].ix, store); io.f(W.j[L].iy, store); io.f(W.j[L].iz, store); io.f(W.j[L].im, store);
     io.d(W.j[L].state, store);
   }
-  // manifold words stream HBM <-> LDS without touching the register file
+  // own body's manifold words stream HBM <-> LDS without touching the register file
+  {
+    WordIO mo{base, n, i, kWMf + mb * 2 * kMfWords, role < 3};
 #pragma nounroll
-  for (int k = 0; k < 6 * kMfWords; ++k) io.u(lds.w[k * kEnvBlock], store);
-#pragma unroll
-  for (int b = 0; b < 3; ++b) io.d(W.edge0[b], store);
+    for (int k = 0; k < 2 * kMfWords; ++k) mo.u(lds.w[k * kEnvBlock], store);
+    WordIO eo{base, n, i, kWEdge0 + mb, role < 3};
+    eo.d(W.edge0, store);
+  }
+  io.k = kWTail;
   io.u(W.touching, store);
 #pragma unroll
   for (int k = 0; k < 11; ++k) io.f(W.ty[k], store);
@@ -1011,26 +1048,32 @@ __device__ __forceinline__ void world_io(World& W, const Lds& lds, uint32_t* bas
   io.f(W.prev_shaping, store);
 }
 
+// obs [N][8]: lanes 0/1 of each quad write the two 16-B halves of their env's row, so a
+// wave's 32 storing lanes cover 512 contiguous bytes.
+__device__ __forceinline__ void store_obs_quad(float* __restrict__ dst, int env, int role, const float (&o)[8]) {
+  if (role == 0) reinterpret_cast<float4*>(dst)[2 * (size_t)env] = make_float4(o[0], o[1], o[2], o[3]);
+  if (role == 1) reinterpret_cast<float4*>(dst)[2 * (size_t)env + 1] = make_float4(o[4], o[5], o[6], o[7]);
+}
+
 __global__ __launch_bounds__(kEnvBlock) void lunar_reset_kernel(void* buf, int n, uint64_t seed,
                                                                 int64_t env_id0,
                                                                 float* __restrict__ obs_out) {
-  __shared__ __attribute__((aligned(16))) float tile[kEnvBlock * 8];
   __shared__ uint32_t lds_words[kLdsWords * kEnvBlock];
   const Lds lds{lds_words + threadIdx.x};
   LunarState st(buf, n);
-  const int i = blockIdx.x * kEnvBlock + threadIdx.x;
-  float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (i < n) {
-    World W;
-    float fx, fy, rew; bool term;
-    init_episode(W, lds, seed, (uint64_t)(env_id0 + i), 0u, fx, fy);
-    env_step_once(W, lds, 0, seed, (uint64_t)(env_id0 + i), 0u, 0u, fx, fy, o, rew, term);   // reset() ends with step(0)
-    world_io(W, lds, st.words, n, i, true);
+  const int role = threadIdx.x & 3;
+  const int i = blockIdx.x * kEnvsPerBlock + (threadIdx.x >> 2);
+  if (i >= n) return;                       // whole quads leave together
+  World W;
+  float fx, fy, rew, o[8]; bool term;
+  init_episode(W, lds, seed, (uint64_t)(env_id0 + i), 0u, fx, fy);
+  env_step_once(W, lds, role, 0, seed, (uint64_t)(env_id0 + i), 0u, 0u, fx, fy, o, rew, term);   // reset() ends with step(0)
+  world_io(W, lds, role, st.words, n, i, true);
+  if (role == 0) {
     st.ep.ep_ret[i] = 0.0; st.ep.ep_len[i] = 0; st.ep.episode[i] = 0u;
     st.spare_episode[i] = kNoSpare;
   }
-  const int nv = min(kEnvBlock, n - blockIdx.x * kEnvBlock);
-  store_obs_tile<8>(obs_out + (size_t)blockIdx.x * kEnvBlock * 8, o, tile, threadIdx.x, nv);
+  store_obs_quad(obs_out, i, role, o);
 }
 
 // Builds the spare world of episode (current + 1) for every env that lacks one.
@@ -1039,20 +1082,25 @@ __global__ __launch_bounds__(kEnvBlock) void lunar_refill_kernel(void* buf, int 
   __shared__ uint32_t lds_words[kLdsWords * kEnvBlock];
   const Lds lds{lds_words + threadIdx.x};
   LunarState st(buf, n);
-  const int i = blockIdx.x * kEnvBlock + threadIdx.x;
+  const int role = threadIdx.x & 3;
+  const int i = blockIdx.x * kEnvsPerBlock + (threadIdx.x >> 2);
   if (i >= n) return;
   const uint32_t want = st.ep.episode[i] + 1u;
-  if (st.spare_episode[i] == want) return;
+  if (st.spare_episode[i] == want) return;  // uniform across the quad
   World W;
   float fx, fy, rew, o[8]; bool term;
   const uint64_t env = (uint64_t)(env_id0 + i);
   init_episode(W, lds, seed, env, want, fx, fy);
-  env_step_once(W, lds, 0, seed, env, want, 0u, fx, fy, o, rew, term);
-  world_io(W, lds, st.spare_words, n, i, true);
+  env_step_once(W, lds, role, 0, seed, env, want, 0u, fx, fy, o, rew, term);
+  world_io(W, lds, role, st.spare_words, n, i, true);
+  if (role < 2) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) st.spare_obs[(size_t)k * n + i] = o[k];
+    for (int k = 0; k < 4; ++k) st.spare_obs[(size_t)(4 * role + k) * n + i] = o[4 * role + k];
+  }
   __threadfence();                      // world before flag (a concurrent step kernel may poll it)
-  st.spare_episode[i] = want;
+  // the flag must follow every lane's stores: lanes 1,2 wrote manifold words
+  __builtin_amdgcn_wave_barrier();
+  if (role == 0) st.spare_episode[i] = want;
 }
 
 __global__ __launch_bounds__(kEnvBlock) void lunar_step_kernel(
@@ -1061,49 +1109,57 @@ __global__ __launch_bounds__(kEnvBlock) void lunar_step_kernel(
     uint8_t* __restrict__ terminated_out, uint8_t* __restrict__ truncated_out,
     uint8_t* __restrict__ done_out, float* __restrict__ ep_ret_out,
     int32_t* __restrict__ ep_len_out, double* __restrict__ ep_stats) {
-  __shared__ __attribute__((aligned(16))) float tile[kEnvBlock * 8];
   __shared__ uint32_t lds_words[kLdsWords * kEnvBlock];
   const Lds lds{lds_words + threadIdx.x};
   LunarState st(buf, n);
-  const int i = blockIdx.x * kEnvBlock + threadIdx.x;
+  const int role = threadIdx.x & 3;
+  const int i = blockIdx.x * kEnvsPerBlock + (threadIdx.x >> 2);
   const bool valid = i < n;
+  const bool lead = role == 0;
   bool done = false;
   double ret = 0.0; int len = 0;
-  float o_next[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o_term[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (valid) {
     World W;
-    world_io(W, lds, st.words, n, i, false);
+    float o_next[8], o_term[8];
+    world_io(W, lds, role, st.words, n, i, false);
     const uint64_t env = (uint64_t)(env_id0 + i);
     const uint32_t episode = st.ep.episode[i];
     len = st.ep.ep_len[i];
+    const double ret0 = st.ep.ep_ret[i];
     int act = action[i];
     act = act < 0 ? 0 : (act > 3 ? 3 : act);
     uint32_t ep = episode, step_idx = (uint32_t)len;
     float fx = 0.0f, fy = 0.0f;
-    // pass 0 = the requested step; pass 1 (only where the episode ended) = the new episode's
-    // reset(), whose trailing step(0) reuses the single inlined copy of the solver.
+    // pass 0 = the requested step; pass 1 (only where the episode ended and no spare world is
+    // ready) = the new episode's reset(), whose trailing step(0) reuses the one inlined solver.
 #pragma nounroll
     for (int pass = 0; pass < 2; ++pass) {
       float o[8], reward; bool terminated;
-      env_step_once(W, lds, act, seed, env, ep, step_idx, fx, fy, o, reward, terminated);
+      env_step_once(W, lds, role, act, seed, env, ep, step_idx, fx, fy, o, reward, terminated);
       if (pass == 0) {
         len += 1;
         const bool truncated = len >= kMaxSteps;
         done = terminated || truncated;
-        ret = st.ep.ep_ret[i] + (double)reward;
-        rew_out[i] = reward;
-        terminated_out[i] = terminated; truncated_out[i] = truncated;
-        if (done_out) done_out[i] = done;
+        ret = ret0 + (double)reward;
+        if (lead) {
+          rew_out[i] = reward;
+          terminated_out[i] = terminated; truncated_out[i] = truncated;
+          if (done_out) done_out[i] = done;
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) { o_term[k] = o[k]; o_next[k] = o[k]; }
-        if (!done) { st.ep.ep_ret[i] = ret; st.ep.ep_len[i] = len; break; }
-        if (ep_ret_out) ep_ret_out[i] = (float)ret;
-        if (ep_len_out) ep_len_out[i] = len;
+        if (!done) { if (lead) { st.ep.ep_ret[i] = ret; st.ep.ep_len[i] = len; } break; }
         ep = episode + 1u; step_idx = 0u; act = 0;
-        st.ep.ep_ret[i] = 0.0; st.ep.ep_len[i] = 0; st.ep.episode[i] = ep;
-        if (st.spare_episode[i] == ep) {             // next episode already prepared off the critical path
+        // every lane reads the spare flag BEFORE lane 0 rewrites the episode bookkeeping
+        const bool have_spare = st.spare_episode[i] == ep;
+        if (lead) {
+          if (ep_ret_out) ep_ret_out[i] = (float)ret;
+          if (ep_len_out) ep_len_out[i] = len;
+          st.ep.ep_ret[i] = 0.0; st.ep.ep_len[i] = 0; st.ep.episode[i] = ep;
+        }
+        if (have_spare) {                            // next episode already prepared off the critical path
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          world_io(W, lds, st.spare_words, n, i, false);
+          world_io(W, lds, role, st.spare_words, n, i, false);
 #pragma unroll
           for (int k = 0; k < 8; ++k) o_next[k] = st.spare_obs[(size_t)k * n + i];
           break;
@@ -1114,13 +1170,11 @@ __global__ __launch_bounds__(kEnvBlock) void lunar_step_kernel(
         for (int k = 0; k < 8; ++k) o_next[k] = o[k];
       }
     }
-    world_io(W, lds, st.words, n, i, true);
+    world_io(W, lds, role, st.words, n, i, true);
+    store_obs_quad(obs_out, i, role, o_next);
+    if (term_obs_out) store_obs_quad(term_obs_out, i, role, o_term);
   }
-  const int nv = min(kEnvBlock, n - blockIdx.x * kEnvBlock);
-  const size_t base = (size_t)blockIdx.x * kEnvBlock * 8;
-  store_obs_tile<8>(obs_out + base, o_next, tile, threadIdx.x, nv);
-  if (term_obs_out) store_obs_tile<8>(term_obs_out + base, o_term, tile, threadIdx.x, nv);
-  accumulate_ep_stats(ep_stats, done, ret, len);
+  accumulate_ep_stats(ep_stats, done && lead, ret, len);
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -1132,14 +1186,14 @@ namespace gymrl {
 size_t lunar_state_bytes(int n) { return LunarState(nullptr, n).bytes; }
 
 int lunar_reset(void* state, int n, uint64_t seed, int64_t env_id0, float* obs_out, hipStream_t s) {
-  hipLaunchKernelGGL(lunar_reset_kernel, dim3(cdiv(n, kEnvBlock)), dim3(kEnvBlock), 0, s, state, n, seed,
+  hipLaunchKernelGGL(lunar_reset_kernel, dim3(cdiv(n, kEnvsPerBlock)), dim3(kEnvBlock), 0, s, state, n, seed,
                      env_id0, obs_out);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
 
 int lunar_refill(void* state, int n, uint64_t seed, int64_t env_id0, hipStream_t s) {
-  hipLaunchKernelGGL(lunar_refill_kernel, dim3(cdiv(n, kEnvBlock)), dim3(kEnvBlock), 0, s, state, n, seed, env_id0);
+  hipLaunchKernelGGL(lunar_refill_kernel, dim3(cdiv(n, kEnvsPerBlock)), dim3(kEnvBlock), 0, s, state, n, seed, env_id0);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
@@ -1148,7 +1202,7 @@ int lunar_step(void* state, int n, uint64_t seed, int64_t env_id0, const int32_t
                float* obs_out, float* term_obs_out, float* rew_out, uint8_t* terminated_out,
                uint8_t* truncated_out, uint8_t* done_out, float* ep_ret_out, int32_t* ep_len_out,
                double* ep_stats, hipStream_t s) {
-  hipLaunchKernelGGL(lunar_step_kernel, dim3(cdiv(n, kEnvBlock)), dim3(kEnvBlock), 0, s, state, n, seed,
+  hipLaunchKernelGGL(lunar_step_kernel, dim3(cdiv(n, kEnvsPerBlock)), dim3(kEnvBlock), 0, s, state, n, seed,
                      env_id0, action, obs_out, term_obs_out, rew_out, terminated_out, truncated_out,
                      done_out, ep_ret_out, ep_len_out, ep_stats);
   GYMRL_CHECK_LAUNCH();
