@@ -113,8 +113,15 @@ def main():
     loss_s_per_pass = ks["ppo_loss_fwd_bwd"]["total_s"] / (a.steps * cfg.num_epochs)
     pass_bytes = 73.0 * transitions
     achieved = pass_bytes / (gae_s + loss_s_per_pass)
+    # HBM traffic of the same kernels from the PMC passes committed under profiles/ (rocprofv3
+    # cannot run inside the bench): bytes per transition measured at T x N = 2048 x 4096
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if os.path.exists(pmc):
+        pm = json.load(open(pmc))
+        traffic = round((pm["gae"]["hbm_bytes_per_transition"] + pm["ppo_loss"]["hbm_bytes_per_sample"]) * transitions)
     roofline = dict(bound="hbm", achieved=round(achieved / 1e9, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK, 4), traffic=None,
+                    frac=round(achieved / HBM_PEAK, 4), traffic=traffic,
                     kernel="gae(G1: aggregate+carry+apply+moments) + ppo_loss_fwd_bwd, one pass over the rollout",
                     bytes_per_launch=pass_bytes, launch_s=gae_s + loss_s_per_pass, kernels=kernels)
 
