@@ -24,7 +24,7 @@ SYMBOLS = [
     "gymrl_env_obs_dim", "gymrl_env_act_dim", "gymrl_env_is_discrete", "gymrl_env_max_steps",
     "gymrl_env_state_bytes", "gymrl_env_reset", "gymrl_env_step", "gymrl_env_refill",
     "gymrl_categorical_sample",
-    "gymrl_gae_workspace_bytes", "gymrl_gae", "gymrl_gae_dw", "gymrl_gae_decoupled",
+    "gymrl_gae_workspace_bytes", "gymrl_gae", "gymrl_gae_online_flush", "gymrl_gae_chunk", "gymrl_gae_dw", "gymrl_gae_decoupled",
     "gymrl_reduce_workspace_bytes", "gymrl_moments", "gymrl_normalize",
     "gymrl_ppo_loss_fwd_bwd", "gymrl_ppo_full_loss_fwd_bwd",
     "gymrl_pack_rollout", "gymrl_gather_minibatch",
@@ -48,6 +48,12 @@ def build(force=False):
 class PPOCfg(C.Structure):
     _fields_ = [("clip_eps", C.c_float), ("dual_clip", C.c_float), ("value_coef", C.c_float),
                 ("entropy_coef", C.c_float)]
+
+
+class GaeOnline(C.Structure):
+    _fields_ = [("rew_prev", C.c_void_p), ("done_prev", C.c_void_p), ("val_prev", C.c_void_p),
+                ("running", C.c_void_p), ("gae_workspace", C.c_void_p), ("t_prev", C.c_int), ("T", C.c_int),
+                ("gamma", C.c_double), ("lam", C.c_double)]
 
 
 class PPOFullCfg(C.Structure):

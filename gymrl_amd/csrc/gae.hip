@@ -271,6 +271,20 @@ __global__ __launch_bounds__(kBlkBlock) void gae_blk_apply_kernel(
   }
 }
 
+// pass 1 folded into the producer: the rollout composes each step into its chunk's (A, b)
+// as soon as V_{t+1} is known (the categorical-sample kernel of step t+1 calls this body),
+// so the HBM-bound GAE launch no longer re-reads r, v, d (variant 2: carry + apply only).
+// Forward composition F <- F o f_t of x -> delta_t + a_t x:  b += A*delta_t ; A *= a_t.
+__global__ __launch_bounds__(kRedBlock) void gae_online_kernel(
+    const float* __restrict__ rew_prev, const uint8_t* __restrict__ done_prev,
+    const float* __restrict__ val_prev, const float* __restrict__ val_cur, int N, double gamma,
+    double gl, int first, int last, double* __restrict__ running, double2* __restrict__ agg_row) {
+  const int i = blockIdx.x * kRedBlock + threadIdx.x;
+  if (i >= N) return;
+  gymrl::gae_online_compose(rew_prev[i], done_prev[i], val_prev[i], val_cur[i], gamma, gl, first, last,
+                            running, agg_row, N, i);
+}
+
 // Deterministic final reduction of (s1, s2) partials -> moments (count, sum, sumsq).
 __global__ __launch_bounds__(kRedBlock) void moments_finalize_kernel(
     const double* __restrict__ partials, int nparts, double count,
@@ -438,15 +452,16 @@ int gymrl_gae(const float* rew, const float* val, const uint8_t* done, const flo
   const bool vec_ok = (N % 4 == 0) && aligned16(rew) && aligned16(val) && aligned16(adv_out) &&
                       aligned16(ret_out) && aligned16(next_val) &&
                       ((reinterpret_cast<uintptr_t>(done) & 3) == 0);
-  if (variant == 1 && vec_ok && workspace) {
+  if ((variant == 1 || variant == 2) && vec_ok && workspace) {
     const int C = cdiv(T, kBlkTC);
     char* ws = (char*)workspace;
     double2* agg = (double2*)ws;
     double* carry = (double*)(ws + (size_t)C * N * sizeof(double2));
     double* parts = carry + (size_t)C * N;
     dim3 grid(cdiv(N / kBlkV, kBlkBlock), C);
-    hipLaunchKernelGGL((gae_blk_aggregate_kernel<kBlkTC, kBlkV>), grid, dim3(kBlkBlock), 0, stream, rew, val, done,
-                       next_val, T, N, gamma, gl, agg);
+    if (variant == 1)   // variant 2: the chunk maps were composed online during the rollout
+      hipLaunchKernelGGL((gae_blk_aggregate_kernel<kBlkTC, kBlkV>), grid, dim3(kBlkBlock), 0, stream, rew, val, done,
+                         next_val, T, N, gamma, gl, agg);
     hipLaunchKernelGGL(gae_blk_carry_kernel, dim3(cdiv(N, kSeqBlock)), dim3(kSeqBlock * kCarrySeg), 0,
                        stream, agg, C, N, carry);
     hipLaunchKernelGGL((gae_blk_apply_kernel<kBlkTC, kBlkV>), grid, dim3(kBlkBlock), 0, stream, rew, val, done,
@@ -464,6 +479,22 @@ int gymrl_gae(const float* rew, const float* val, const uint8_t* done, const flo
       hipLaunchKernelGGL(moments_finalize_kernel, dim3(1), dim3(kRedBlock), 0, stream, parts, nb,
                          (double)T * (double)N, moments_out);
   }
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_gae_chunk(void) { return kBlkTC; }
+
+int gymrl_gae_online_flush(const gymrl_gae_online* o, const float* val_cur, int N, void* stream_) {
+  if (!o || !val_cur || !o->rew_prev || !o->done_prev || !o->val_prev || !o->running || !o->gae_workspace ||
+      N <= 0 || o->t_prev < 0 || o->t_prev >= o->T)
+    return -22;
+  const int c = o->t_prev / kBlkTC;
+  const int first = (o->t_prev % kBlkTC) == 0, last = (o->t_prev % kBlkTC) == kBlkTC - 1 || o->t_prev == o->T - 1;
+  double2* agg = (double2*)o->gae_workspace + (size_t)c * N;
+  hipLaunchKernelGGL(gae_online_kernel, dim3(cdiv(N, kRedBlock)), dim3(kRedBlock), 0, (hipStream_t)stream_,
+                     o->rew_prev, o->done_prev, o->val_prev, val_cur, N, o->gamma,
+                     (double)(float)(o->gamma * o->lam), first, last, o->running, agg);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

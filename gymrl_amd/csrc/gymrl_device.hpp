@@ -144,6 +144,22 @@ __device__ __forceinline__ float det_tanhf(float x) {
   return fmaf(p * z, x, x);
 }
 
+// --------------------------------------------------- online GAE chunk maps ---
+// One step of the forward composition used by gymrl_gae(variant 2); shared by the
+// categorical-sample kernel (fused) and the flush kernel.  running = f64[2][N].
+__device__ __forceinline__ void gae_online_compose(float r, uint8_t d, float v_prev, float v_cur, double gamma,
+                                                   double gl, int first, int last, double* __restrict__ running,
+                                                   double2* __restrict__ agg_row, int N, int i) {
+  double A = first ? 1.0 : running[i];
+  double b = first ? 0.0 : running[(size_t)N + i];
+  const double nd = 1.0 - (double)(d != 0);
+  const double delta = ((double)r + (gamma * (double)v_cur) * nd) - (double)v_prev;
+  b = b + A * delta;
+  A = A * (gl * nd);
+  if (last) agg_row[i] = make_double2(A, b);
+  else { running[i] = A; running[(size_t)N + i] = b; }
+}
+
 // ------------------------------------------------------------ reductions ---
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -86,14 +86,23 @@ __device__ __forceinline__ void block_partials(double (&v)[K], double* __restric
 }
 
 // ------------------------------------------------------------- P2 sample ----
+struct OnlineGae {   // device-side view of gymrl_gae_online (rew_prev == nullptr: disabled)
+  const float* rew_prev; const uint8_t* done_prev; const float* val_prev;
+  double* running; double2* agg_row; double gamma, gl; int first, last;
+};
+
 template <int A>
 __global__ __launch_bounds__(kBlock) void categorical_sample_kernel(
     const float* __restrict__ logits, const float* __restrict__ value_in,
     const float* __restrict__ noise_exp, uint64_t seed, uint64_t counter, int64_t env_id0, int n,
     int deterministic, int32_t* __restrict__ act_out, float* __restrict__ logp_out,
-    float* __restrict__ ent_out, float* __restrict__ value_out) {
+    float* __restrict__ ent_out, float* __restrict__ value_out, OnlineGae og) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
+  // fused producer side of GAE: value_in is V_t, which completes step t-1's delta
+  if (og.rew_prev)
+    gae_online_compose(og.rew_prev[i], og.done_prev[i], og.val_prev[i], value_in[i], og.gamma, og.gl, og.first,
+                       og.last, og.running, og.agg_row, n, i);
   float z[A], ln[A], p[A], H;
   load_row<A>(logits, i, z);
   log_softmax<A>(z, ln, p, H);
@@ -372,14 +381,28 @@ extern "C" {
 int gymrl_categorical_sample(const float* logits, const float* value_in, const float* noise_exp,
                              uint64_t seed, uint64_t counter, int64_t env_id0, int n,
                              int n_actions, int deterministic, int32_t* act_out, float* logp_out,
-                             float* ent_out, float* value_out, void* stream_) {
+                             float* ent_out, float* value_out, const gymrl_gae_online* online,
+                             void* stream_) {
   if (!logits || !act_out || !logp_out || n < 0) return -22;
   if (n == 0) return 0;
   hipStream_t stream = (hipStream_t)stream_;
+  OnlineGae og{};
+  if (online) {
+    if (!value_in || !online->rew_prev || !online->done_prev || !online->val_prev || !online->running ||
+        !online->gae_workspace || online->t_prev < 0 || online->t_prev >= online->T)
+      return -22;
+    const int tc = gymrl_gae_chunk();
+    og.rew_prev = online->rew_prev; og.done_prev = online->done_prev; og.val_prev = online->val_prev;
+    og.running = online->running;
+    og.agg_row = (double2*)online->gae_workspace + (size_t)(online->t_prev / tc) * n;
+    og.gamma = online->gamma; og.gl = (double)(float)(online->gamma * online->lam);
+    og.first = (online->t_prev % tc) == 0;
+    og.last = (online->t_prev % tc) == tc - 1 || online->t_prev == online->T - 1;
+  }
   DISPATCH_A(n_actions,
              hipLaunchKernelGGL(categorical_sample_kernel<A>, dim3(cdiv(n, kBlock)), dim3(kBlock),
                                 0, stream, logits, value_in, noise_exp, seed, counter, env_id0, n,
-                                deterministic, act_out, logp_out, ent_out, value_out));
+                                deterministic, act_out, logp_out, ent_out, value_out, og));
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

@@ -8,7 +8,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import PPOCfg, PPOFullCfg, check, lib
+from ._lib import GaeOnline, PPOCfg, PPOFullCfg, check, lib
 
 _vp = C.c_void_p
 
@@ -101,8 +101,19 @@ def normalize_(x, mom, ddof=0, eps=1e-8):
 
 
 # ------------------------------------------------------------ categorical ---
+def gae_online(rew_prev, done_prev, val_prev, running, workspace, t_prev, T, gamma, lam):
+    """Descriptor for the producer-side GAE fusion (gymrl_gae_online): rows t-1 of the slab."""
+    return GaeOnline(rew_prev.data_ptr(), done_prev.data_ptr(), val_prev.data_ptr(), running.data_ptr(),
+                     workspace.data_ptr(), int(t_prev), int(T), float(gamma), float(lam))
+
+
+def gae_online_flush(online, val_cur):
+    check(lib().gymrl_gae_online_flush(C.byref(online), _ptr(val_cur, torch.float32), C.c_int(val_cur.numel()),
+                                       _stream()), "gymrl_gae_online_flush")
+
+
 def categorical_sample(logits, value=None, noise_exp=None, seed=0, counter=0, env_id0=0, deterministic=False,
-                       act_out=None, logp_out=None, ent_out=None, value_out=None):
+                       act_out=None, logp_out=None, ent_out=None, value_out=None, online=None):
     """P2 (ppo_lunarlander.py:92-104).  Returns (action i32[N], logp, entropy, value_out)."""
     n, A = logits.shape
     dev = logits.device
@@ -115,7 +126,8 @@ def categorical_sample(logits, value=None, noise_exp=None, seed=0, counter=0, en
                                          _ptr(noise_exp, torch.float32, True), C.c_uint64(seed),
                                          C.c_uint64(counter), C.c_int64(env_id0), C.c_int(n), C.c_int(A),
                                          C.c_int(int(deterministic)), _ptr(act_out, torch.int32), _ptr(logp_out),
-                                         _ptr(ent_out, None, True), _ptr(value_out, None, True), _stream()),
+                                         _ptr(ent_out, None, True), _ptr(value_out, None, True),
+                                         C.byref(online) if online is not None else None, _stream()),
           "gymrl_categorical_sample")
     return act_out, logp_out, ent_out, value_out
 

@@ -197,6 +197,8 @@ class PPOTrainer:
         self._perm_gen.manual_seed(self.base_seed * 7919 + 13 + self.rank)
         self._loss_cfg = (config.clip_eps, config.dual_clip, config.value_coef, config.entropy_coef)
         self._finished = None
+        self._agg_ready = False
+        self._gae_running = torch.zeros(2, N, dtype=torch.float64, device=self.device)
         self._packed = None      # [T*N, 16] packed rollout records (allocated on first update)
         mb = self._minibatch_size_for(T * N)
         self._stage = (torch.empty(mb, state_dim, device=self.device), torch.empty(mb, dtype=torch.int32, device=self.device),
@@ -211,13 +213,17 @@ class PPOTrainer:
     # ------------------------------------------------------------------ GAE --
     def compute_gae(self, next_value=None):
         """:179-196 over every env of the slab; returns (advantages, returns) [T, N]
-        (un-normalised; the whole-rollout moments are left in self._moments)."""
+        (un-normalised; the whole-rollout moments are left in self._moments).  With
+        next_value=None the bootstrap values of the last collect_rollout() are used."""
         b = self.buffer
         nv = self._next_value if next_value is None else next_value
+        # variant 2 = the blocked scan minus its first pass: the rollout composed the chunk maps
+        variant = 2 if (self.cfg.gae_variant == 1 and self._agg_ready and next_value is None) else self.cfg.gae_variant
+        self._agg_ready = False
         if self._timers is not None:
             self._timers.start("gae")
         ops.gae(b.rewards, b.values, b.dones, nv, self.cfg.gamma, self.cfg.gae_lambda, b.advantages,
-                b.returns, self._moments, self.cfg.gae_variant, self._gae_ws)
+                b.returns, self._moments, variant, self._gae_ws)
         if self._timers is not None:
             self._timers.stop("gae", b.T * b.N)
         return b.advantages, b.returns
@@ -237,13 +243,17 @@ class PPOTrainer:
             b.states[0].copy_(b.states[b.T])
         counter0 = self.rollout_count * b.T
         tm = self._timers
+        fuse_gae = cfg.gae_variant == 1 and b.N % 4 == 0
         for t in range(b.T):
             logits, value = self.model(b.states[t])
             if tm is not None and t % 64 == 0:
                 tm.start("env_step+sample")
+            # while sampling step t, fold step t-1 (whose delta needs V_t) into its GAE chunk map
+            online = (ops.gae_online(b.rewards[t - 1], b.dones[t - 1], b.values[t - 1], self._gae_running,
+                                     self._gae_ws, t - 1, b.T, cfg.gamma, cfg.gae_lambda) if fuse_gae and t > 0 else None)
             ops.categorical_sample(logits, value=value.view(-1), seed=env.seed, counter=counter0 + t,
                                    env_id0=env.env_id0, act_out=b.actions[t], logp_out=b.log_probs[t],
-                                   ent_out=None, value_out=b.values[t])
+                                   ent_out=None, value_out=b.values[t], online=online)
             env.step(b.actions[t], b.states[t + 1], b.rewards[t], done_out=b.dones[t],
                      ep_ret_out=b.ep_returns[t])
             if tm is not None and t % 64 == 0:
@@ -252,6 +262,11 @@ class PPOTrainer:
         self.step_count += b.T * b.N
         self.rollout_count += 1
         self._next_value.copy_(self.model.get_value(b.states[b.T]))
+        if fuse_gae:
+            ops.gae_online_flush(ops.gae_online(b.rewards[b.T - 1], b.dones[b.T - 1], b.values[b.T - 1],
+                                                self._gae_running, self._gae_ws, b.T - 1, b.T, cfg.gamma,
+                                                cfg.gae_lambda), self._next_value)
+            self._agg_ready = True
         # :220-221 episode_rewards.append on done: compacted on the device here, read back by
         # _drain_episode_returns() once the update's kernels are queued (no sync in the rollout)
         self._finished = True
@@ -275,10 +290,11 @@ class PPOTrainer:
         return self._minibatch_size_for(len(self.buffer))
 
     def update(self, next_value=None, indices=None):
-        """:233-330.  `indices` (optional i32/i64 [num_epochs, T*N]) replays an explicit
+        """:233-330.  (next_value is accepted for signature compatibility; when it is the tensor
+        collect_rollout() returned, the GAE maps composed during the rollout are reused.)  `indices` (optional i32/i64 [num_epochs, T*N]) replays an explicit
         shuffle order (parity mode); by default a device randperm per epoch (:262)."""
         cfg, b = self.cfg, self.buffer
-        self.compute_gae(next_value)
+        self.compute_gae(None if next_value is self._next_value else next_value)
         if self.world_size > 1:
             gdist.all_reduce_sum(self._moments)          # :236 mean/std over the WHOLE rollout (all ranks)
         total = len(b)

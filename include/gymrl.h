@@ -99,11 +99,29 @@ int gymrl_env_refill(int kind, void* state, int n_envs, uint64_t seed, int64_t e
  * value_in f32[N] (may be NULL) is copied to value_out so the rollout slab row
  * is written by one kernel.  A <= 8.
  */
+/* Optional producer-side fusion of GAE's chunk reduction (see gymrl_gae variant 2): while
+ * sampling step t the kernel also composes step t-1 — whose delta needs V_t = value_in —
+ * into the affine map of its time chunk.  All pointers are rows of the rollout slab. */
+typedef struct {
+  const float* rew_prev;      /* f32[N] rewards of step t-1                         */
+  const uint8_t* done_prev;   /* u8[N]  done flags of step t-1                      */
+  const float* val_prev;      /* f32[N] values of step t-1                          */
+  double* running;            /* f64[2][N] map of the chunk being composed (scratch) */
+  void* gae_workspace;        /* the workspace later handed to gymrl_gae(variant 2)  */
+  int t_prev;                 /* t-1, 0-based                                        */
+  int T;                      /* rollout length                                      */
+  double gamma, lam;
+} gymrl_gae_online;
+
 int gymrl_categorical_sample(const float* logits, const float* value_in,
                              const float* noise_exp, uint64_t seed, uint64_t counter,
                              int64_t env_id0, int n, int n_actions, int deterministic,
                              int32_t* act_out, float* logp_out, float* ent_out,
-                             float* value_out, void* stream);
+                             float* value_out, const gymrl_gae_online* online, void* stream);
+/* Last step of a rollout: composes step T-1 with val_cur = the bootstrap value V_T. */
+int gymrl_gae_online_flush(const gymrl_gae_online* online, const float* val_cur, int N,
+                           void* stream);
+int gymrl_gae_chunk(void);   /* time-chunk length of the blocked GAE (16) */
 
 /* ------------------------------------------------------------------ GAE --- */
 /*
@@ -116,7 +134,10 @@ int gymrl_categorical_sample(const float* logits, const float* value_in,
  * reduced in a fixed order (no float atomics) so training is reproducible.
  * variant 0 = one lane walks one env sequentially (reference operation order);
  * variant 1 = time-blocked affine scan (roofline variant; needs N % 4 == 0 and
- *             16-B aligned rows, else it falls back to variant 0).
+ *             16-B aligned rows, else it falls back to variant 0);
+ * variant 2 = variant 1 without its first pass: the per-chunk maps were composed during
+ *             the rollout (gymrl_gae_online in gymrl_categorical_sample + _flush), so the
+ *             launch reads r, v, d once (17 -> ~19 HBM bytes per transition instead of 29).
  * workspace: gymrl_gae_workspace_bytes(T, N) bytes, 256-B aligned; required for
  * variant 1 or when moments_out != NULL.
  */

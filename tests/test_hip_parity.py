@@ -355,3 +355,25 @@ def test_pack_and_gather_minibatch(dev, oracle, D):
     got = ops.gather_minibatch(rec, t(idx, dev), D)
     for g, r in zip(got, oracle.gather_minibatch(rec_ref, idx, D)):
         assert np.array_equal(g.cpu().numpy(), r)
+
+
+def test_gae_online_variant2(dev, oracle):
+    """GAE with its chunk-reduction pass folded into the rollout: the categorical-sample kernel of
+    step t composes step t-1 into its chunk map; variant 2 then equals the oracle's recursion."""
+    from gymrl_amd import ops
+    for T, N in ((37, 64), (128, 260), (256, 1024)):
+        rew, val, done, nv = _gae_inputs(T, N, seed=T + N, p_done=0.03)
+        rw, vl, dn, nvd = t(rew, dev), t(val, dev), t(done, dev), t(nv, dev)
+        ws = ops.gae_workspace(T, N, dev)
+        running = torch.zeros(2, N, dtype=torch.float64, device=dev)
+        logits = torch.zeros(N, 4, device=dev)
+        for step in range(1, T):       # the rollout: V_t arrives with step t's sample kernel
+            ops.categorical_sample(logits, value=vl[step].contiguous(), seed=1, counter=step,
+                                   online=ops.gae_online(rw[step - 1], dn[step - 1], vl[step - 1], running, ws, step - 1,
+                                                         T, 0.99, 0.95))
+        ops.gae_online_flush(ops.gae_online(rw[T - 1], dn[T - 1], vl[T - 1], running, ws, T - 1, T, 0.99, 0.95), nvd)
+        mom = torch.zeros(3, dtype=torch.float64, device=dev)
+        adv, ret = ops.gae(rw, vl, dn, nvd, 0.99, 0.95, moments_out=mom, variant=2, workspace=ws)
+        a_ref, r_ref, m_ref = oracle.gae(rew, val, done, nv, 0.99, 0.95, want_moments=True)
+        assert rel_close(adv.cpu().numpy(), a_ref) <= TOL and rel_close(ret.cpu().numpy(), r_ref) <= TOL
+        assert rel_close(mom.cpu().numpy()[1:], m_ref[1:], 1e-9) <= 1e-9

@@ -44,7 +44,7 @@ def main():
     ws = ops.gae_workspace(T, N, dev)
     mom = torch.zeros(3, dtype=torch.float64, device=dev)
     out = {}
-    for variant in (0, 1):
+    for variant in (0, 1, 2):      # 2 reuses the chunk maps variant 1 just left in the workspace
         dt = timeit(lambda: ops.gae(rew, val, done, nv, 0.99, 0.95, adv, ret, mom, variant, ws))
         gb = 17.0 * T * N / dt
         out[f"gae_v{variant}"] = dict(us=dt * 1e6, GBps=gb / 1e9, frac=gb / PEAK)
