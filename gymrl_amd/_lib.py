@@ -27,7 +27,7 @@ SYMBOLS = [
     "gymrl_gae_workspace_bytes", "gymrl_gae", "gymrl_gae_online_flush", "gymrl_gae_chunk", "gymrl_gae_dw", "gymrl_gae_decoupled",
     "gymrl_reduce_workspace_bytes", "gymrl_moments", "gymrl_normalize",
     "gymrl_ppo_loss_fwd_bwd", "gymrl_ppo_full_loss_fwd_bwd",
-    "gymrl_pack_rollout", "gymrl_gather_minibatch",
+    "gymrl_pack_rollout", "gymrl_gather_minibatch", "gymrl_loss_blocks", "gymrl_reduce_rows",
     "gymrl_sqnorm", "gymrl_adam_step", "gymrl_soft_update",
     "gymrl_replay_append", "gymrl_replay_gather", "gymrl_uniform_indices", "gymrl_nstep_push",
     "gymrl_per_workspace_bytes", "gymrl_per_update", "gymrl_per_max_leaf", "gymrl_per_priorities",

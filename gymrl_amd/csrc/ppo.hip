@@ -163,16 +163,22 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_kernel(
     var = var > 0.0 ? var : 0.0;
     s_norm[0] = mean; s_norm[1] = sqrt(var) + 1e-8;
   }
-  __syncthreads();
-  for (int b = blockIdx.x * kBlock + threadIdx.x; b < B; b += gridDim.x * kBlock) {
+  // (the barrier publishing s_norm sits AFTER the first sample's loads are issued, so the two
+  //  memory latencies overlap; at one sample per lane this is most of the kernel's critical path)
+  bool synced = false;
+  for (int b = blockIdx.x * kBlock + threadIdx.x; b < B || !synced; b += gridDim.x * kBlock) {
+    const bool live = b < B;
+    const int bb = live ? b : 0;
     float z[A], ln[A], p[A], H;
-    load_row<A>(logits, b, z);
-    const float v = value[b];
-    const int i = idx ? idx[b] : b;
+    load_row<A>(logits, bb, z);
+    const float v = value[bb];
+    const int i = idx ? idx[bb] : bb;
     const int a = act[i];
     const float lpo = logp_old[i];
     float ad = adv[i];
     const float rt = ret[i];
+    if (!synced) { __syncthreads(); synced = true; }
+    if (!live) break;
     if (adv_moments) ad = (float)(((double)ad - s_norm[0]) / s_norm[1]);
     log_softmax<A>(z, ln, p, H);
     float lp = ln[0];
@@ -419,7 +425,7 @@ int gymrl_ppo_loss_fwd_bwd(const float* logits, const float* value, const int32_
   hipStream_t stream = (hipStream_t)stream_;
   const gymrl_ppo_cfg cfg = *cfg_host;
   const int nb = cdiv(B, kBlock) < kMaxLossBlocks ? cdiv(B, kBlock) : kMaxLossBlocks;
-  double* parts = metrics_sum ? (double*)workspace : nullptr;
+  double* parts = (double*)workspace;   // block partials [nb][5]; with metrics_sum == NULL they are the output
   DISPATCH_A(n_actions,
              hipLaunchKernelGGL(ppo_loss_kernel<A>, dim3(nb), dim3(kBlock), 0, stream,
                                 logits, value, idx, act, logp_old, adv, ret, adv_moments, B, cfg,
@@ -444,7 +450,7 @@ int gymrl_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const i
   hipStream_t stream = (hipStream_t)stream_;
   const gymrl_ppo_full_cfg cfg = *cfg_host;
   const int nb = cdiv(B, kBlock) < kMaxLossBlocks ? cdiv(B, kBlock) : kMaxLossBlocks;
-  double* parts = metrics_sum ? (double*)workspace : nullptr;
+  double* parts = (double*)workspace;
   DISPATCH_A(n_actions,
              hipLaunchKernelGGL(ppo_full_loss_kernel<A>, dim3(nb), dim3(kBlock), 0,
                                 stream, logits, value, idx, act, logp_old, ent_old, adv, ret, B, cfg,
@@ -452,6 +458,39 @@ int gymrl_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const i
   if (metrics_sum)
     hipLaunchKernelGGL(metrics_finalize_kernel<9>, dim3(1), dim3(kBlock), 0, stream, parts, nb,
                        metrics_sum);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// out[r][k] = sum_b partials[r][b][k]: one launch reduces the block partials of a whole
+// update's minibatches (instead of one tiny finalize launch per minibatch).
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const double* __restrict__ partials,
+                                                          int blocks_per_row, int K,
+                                                          double* __restrict__ out) {
+  __shared__ double sm[256];
+  const double* src = partials + (size_t)blockIdx.x * blocks_per_row * K;
+  for (int k = 0; k < K; ++k) {
+    double a = 0.0;
+    for (int b = threadIdx.x; b < blocks_per_row; b += 256) a += src[(size_t)b * K + k];
+    sm[threadIdx.x] = a;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+      if (threadIdx.x < s2) sm[threadIdx.x] += sm[threadIdx.x + s2];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(size_t)blockIdx.x * K + k] = sm[0];
+    __syncthreads();
+  }
+}
+
+int gymrl_loss_blocks(int B) { return cdiv(B, kBlock) < kMaxLossBlocks ? cdiv(B, kBlock) : kMaxLossBlocks; }
+
+int gymrl_reduce_rows(const double* partials, int rows, int blocks_per_row, int K, double* out,
+                      void* stream_) {
+  if (!partials || !out || rows < 0 || blocks_per_row <= 0 || K <= 0) return -22;
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream_, partials,
+                     blocks_per_row, K, out);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

@@ -183,6 +183,18 @@ def ppo_full_loss_fwd_bwd(logits, value, act, logp_old, ent_old, adv, ret, cfg, 
     return dlogits_out, dvalue_out
 
 
+def loss_blocks(B):
+    return int(lib().gymrl_loss_blocks(C.c_int(B)))
+
+
+def reduce_rows(partials, rows, blocks_per_row, K):
+    """[rows, blocks_per_row, K] f64 block partials -> [rows, K] sums (one launch)."""
+    out = torch.empty(rows, K, dtype=torch.float64, device=partials.device)
+    check(lib().gymrl_reduce_rows(_ptr(partials, torch.float64), C.c_int(rows), C.c_int(blocks_per_row), C.c_int(K),
+                                  _ptr(out), _stream()), "gymrl_reduce_rows")
+    return out
+
+
 def pack_rollout(obs, act, logp, adv, ret, packed=None):
     """P6: one 64-B record per transition (ppo_lunarlander.py:238-250).  obs [M, D]."""
     M, D = obs.shape

@@ -197,6 +197,7 @@ class PPOTrainer:
         self._perm_gen.manual_seed(self.base_seed * 7919 + 13 + self.rank)
         self._loss_cfg = (config.clip_eps, config.dual_clip, config.value_coef, config.entropy_coef)
         self._finished = None
+        self._metric_parts = None
         self._agg_ready = False
         self._gae_running = torch.zeros(2, N, dtype=torch.float64, device=self.device)
         self._packed = None      # [T*N, 16] packed rollout records (allocated on first update)
@@ -306,7 +307,12 @@ class PPOTrainer:
         self._packed = ops.pack_rollout(b.states[:b.T].reshape(total, obs_dim), b.actions.view(-1),
                                         b.log_probs.view(-1), b.advantages.view(-1), b.returns.view(-1),
                                         self._packed)
-        metrics = torch.zeros(cfg.num_epochs * n_mb, 5, dtype=torch.float64, device=self.device)
+        # block partials of every minibatch's 5 metric sums; reduced by ONE launch after the last step
+        nblk = ops.loss_blocks(mb)
+        if self._metric_parts is None or self._metric_parts.shape[:2] != (cfg.num_epochs * n_mb, nblk):
+            self._metric_parts = torch.zeros(cfg.num_epochs * n_mb, nblk, 5, dtype=torch.float64, device=self.device)
+        else:
+            self._metric_parts.zero_()
         sizes = []
         row = 0
         for epoch in range(cfg.num_epochs):
@@ -331,7 +337,7 @@ class PPOTrainer:
                     tm.start("ppo_loss_fwd_bwd")
                 ops.ppo_loss_fwd_bwd(logits, values, mb_act, mb_lp, mb_adv, mb_ret, self._loss_cfg,
                                      adv_moments=self._moments, dlogits_out=dlogits, dvalue_out=dvalues,
-                                     metrics_sum=metrics[row])
+                                     workspace=self._metric_parts[row])
                 if tm is not None:
                     tm.stop("ppo_loss_fwd_bwd", B)
                 torch.autograd.backward([logits, values], [dlogits, dvalues])
@@ -344,6 +350,7 @@ class PPOTrainer:
                     tm.stop("adam_step", self.flat_params.numel())
                 sizes.append(B)
                 row += 1
+        metrics = ops.reduce_rows(self._metric_parts, row, nblk, 5)
         self._drain_episode_returns()
         m = metrics.cpu().numpy() / np.asarray(sizes, np.float64)[:, None]   # the one host sync of the update
         m = m.mean(axis=0)

