@@ -31,6 +31,56 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12   # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def full_pass(trainer, T, N, dev, iters=5):
+    """SURVEY.md section 8(d)'s definition of the GAE+loss pass: ONE launch of each kernel over the
+    whole rollout (T*N transitions, 73 algorithmic bytes each), on the trainer's own slab, HIP
+    events around each launch, caches flushed in between (a 1-GiB fill) so nothing is served from
+    the 256-MB MALL.  Also measures a device-to-device copy for the 'fraction of measured copy
+    bandwidth' figure."""
+    from gymrl_amd import ops
+    buf = trainer.buffer
+    B = T * N
+    g = torch.Generator(device=dev).manual_seed(2)
+    logits = torch.randn(B, 4, device=dev, generator=g)
+    v = torch.randn(B, device=dev, generator=g)
+    act = buf.actions.view(-1)
+    lpo = buf.log_probs.view(-1)
+    adv, ret = buf.advantages, buf.returns
+    dl, dv = torch.empty_like(logits), torch.empty_like(v)
+    met = torch.zeros(5, dtype=torch.float64, device=dev)
+    mom = torch.zeros(3, dtype=torch.float64, device=dev)
+    nv = trainer._next_value
+    cfg = trainer.cfg
+    lcfg = trainer._loss_cfg
+    flush = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    src = torch.empty(1 << 29, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    variant = trainer._last_gae_variant      # 2: the chunk maps of the last rollout are still in the workspace
+
+    def timed(fn):
+        tot = 0.0
+        for _ in range(iters):
+            flush.fill_(1)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            fn()
+            e.record()
+            torch.cuda.synchronize()
+            tot += s.elapsed_time(e)
+        return tot / iters * 1e-3
+
+    gae_s = timed(lambda: ops.gae(buf.rewards, buf.values, buf.dones, nv, cfg.gamma, cfg.gae_lambda,
+                                  adv, ret, mom, variant, trainer._gae_ws))
+    loss_s = timed(lambda: ops.ppo_loss_fwd_bwd(logits, v, act, lpo, adv.view(-1), ret.view(-1), lcfg, None, mom, dl, dv, met))
+    copy_s = timed(lambda: dst.copy_(src))
+    copy_bw = 2.0 * src.numel() / copy_s
+    bw = 73.0 * B / (gae_s + loss_s)
+    return dict(gae_us=round(gae_s * 1e6, 1), gae_variant=variant, loss_us=round(loss_s * 1e6, 1),
+                achieved_GBps=round(bw / 1e9, 1), frac=round(bw / HBM_PEAK, 4),
+                copy_GBps=round(copy_bw / 1e9, 1), frac_of_copy=round(bw / copy_bw, 4),
+                note="one launch per kernel over T*N transitions, cold caches, HIP events per launch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,16 +116,25 @@ def main():
     trainer = PPOTrainer(cfg)
     T, N = cfg.update_freq, cfg.num_envs
 
+    phase_events = []
+
     def step():
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        phase_events.append(ev)
+        ev[0].record()
         if cfg.anneal_lr:
             lr = cfg.lr * (1.0 - trainer.step_count * world / cfg.max_train_steps)
             for g in trainer.optimizer.param_groups:
                 g["lr"] = lr
         nv = trainer.collect_rollout()
-        return trainer.update(nv)
+        ev[1].record()
+        m = trainer.update(nv)
+        ev[2].record()
+        return m
 
     for _ in range(a.warmup):
         step()
+    phase_events.clear()
     timers = KernelTimers()
     trainer._timers = timers
     gdist.barrier()
@@ -97,6 +156,8 @@ def main():
     sys.stdout = sys.__stdout__
     ks = timers.summary()
     transitions = T * N
+    rollout_s = sum(e[0].elapsed_time(e[1]) for e in phase_events) * 1e-3 / a.steps
+    update_s = sum(e[1].elapsed_time(e[2]) for e in phase_events) * 1e-3 / a.steps
     # algorithmic bytes: GAE 17 B/elt, loss fwd+bwd 56 B/sample,
     # gather 64 B line in + 48 B out + 4 B index, Adam 36 B/param incl. norm pre-pass + zero_grad
     bytes_per_unit = {"gae": 17.0, "ppo_loss_fwd_bwd": 56.0, "gather_minibatch": 116.0, "adam_step": 36.0}
@@ -122,8 +183,10 @@ def main():
         traffic = round((pm["gae"]["hbm_bytes_per_transition"] + pm["ppo_loss"]["hbm_bytes_per_sample"]) * transitions)
     roofline = dict(bound="hbm", achieved=round(achieved / 1e9, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
                     frac=round(achieved / HBM_PEAK, 4), traffic=traffic,
-                    kernel="gae(G1: aggregate+carry+apply+moments) + ppo_loss_fwd_bwd, one pass over the rollout",
-                    bytes_per_launch=pass_bytes, launch_s=gae_s + loss_s_per_pass, kernels=kernels)
+                    kernel="gae(G1: chunk maps fused in the rollout + carry + apply + moments) + ppo_loss_fwd_bwd, "
+                           "one pass over the rollout as the trainer launches it (32 minibatch launches per pass)",
+                    bytes_per_launch=pass_bytes, launch_s=gae_s + loss_s_per_pass, kernels=kernels,
+                    pass_at_rollout_size=full_pass(trainer, T, N, dev))
 
     out = {
         "metric": "env-steps/sec at N envs/GPU (PPO LunarLander), 1/2/4/8 GPUs + %HBM roofline",
@@ -139,6 +202,8 @@ def main():
                    "minibatch": transitions // cfg.num_minibatches, "model": "ActorCritic 8-256-256-{256-4,256-1} tanh, 200,965 params",
                    "parallelism": f"dp{world} (env shards + flat-gradient all-reduce)" if world > 1 else "single GPU"},
         "roofline": roofline,
+        "phases": {"rollout_ms": round(rollout_s * 1e3, 1), "update_ms": round(update_s * 1e3, 1),
+                   "rollout_only_env_steps_per_s": round(transitions / rollout_s)},
         "train_metrics": {k: float(v) for k, v in (metrics or {}).items()},
         "avg_episode_return": (sum(trainer.episode_rewards) / len(trainer.episode_rewards)) if trainer.episode_rewards else None,
     }

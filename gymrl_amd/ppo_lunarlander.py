@@ -199,6 +199,8 @@ class PPOTrainer:
         self._finished = None
         self._metric_parts = None
         self._agg_ready = False
+        self._parity_noise = None      # tests: f32[rollouts, T, N, A] Exp(1) draws (ops.categorical_sample noise_exp)
+        self._parity_indices = []      # tests: per-update [num_epochs, T*N] shuffle orders consumed by update()
         self._gae_running = torch.zeros(2, N, dtype=torch.float64, device=self.device)
         self._packed = None      # [T*N, 16] packed rollout records (allocated on first update)
         mb = self._minibatch_size_for(T * N)
@@ -221,6 +223,7 @@ class PPOTrainer:
         # variant 2 = the blocked scan minus its first pass: the rollout composed the chunk maps
         variant = 2 if (self.cfg.gae_variant == 1 and self._agg_ready and next_value is None) else self.cfg.gae_variant
         self._agg_ready = False
+        self._last_gae_variant = variant
         if self._timers is not None:
             self._timers.start("gae")
         ops.gae(b.rewards, b.values, b.dones, nv, self.cfg.gamma, self.cfg.gae_lambda, b.advantages,
@@ -245,6 +248,8 @@ class PPOTrainer:
         counter0 = self.rollout_count * b.T
         tm = self._timers
         fuse_gae = cfg.gae_variant == 1 and b.N % 4 == 0
+        # parity mode: explicit Exp(1) draws f32[rollouts, T, N, A] replace the Philox stream
+        noise = None if self._parity_noise is None else self._parity_noise[self.rollout_count]
         for t in range(b.T):
             logits, value = self.model(b.states[t])
             if tm is not None and t % 64 == 0:
@@ -252,7 +257,8 @@ class PPOTrainer:
             # while sampling step t, fold step t-1 (whose delta needs V_t) into its GAE chunk map
             online = (ops.gae_online(b.rewards[t - 1], b.dones[t - 1], b.values[t - 1], self._gae_running,
                                      self._gae_ws, t - 1, b.T, cfg.gamma, cfg.gae_lambda) if fuse_gae and t > 0 else None)
-            ops.categorical_sample(logits, value=value.view(-1), seed=env.seed, counter=counter0 + t,
+            ops.categorical_sample(logits, value=value.view(-1), noise_exp=None if noise is None else noise[t],
+                                   seed=env.seed, counter=counter0 + t,
                                    env_id0=env.env_id0, act_out=b.actions[t], logp_out=b.log_probs[t],
                                    ent_out=None, value_out=b.values[t], online=online)
             env.step(b.actions[t], b.states[t + 1], b.rewards[t], done_out=b.dones[t],
@@ -295,6 +301,8 @@ class PPOTrainer:
         collect_rollout() returned, the GAE maps composed during the rollout are reused.)  `indices` (optional i32/i64 [num_epochs, T*N]) replays an explicit
         shuffle order (parity mode); by default a device randperm per epoch (:262)."""
         cfg, b = self.cfg, self.buffer
+        if indices is None and self._parity_indices:
+            indices = self._parity_indices.pop(0)
         self.compute_gae(None if next_value is self._next_value else next_value)
         if self.world_size > 1:
             gdist.all_reduce_sum(self._moments)          # :236 mean/std over the WHOLE rollout (all ranks)

@@ -631,8 +631,89 @@ GENERATORS = [gen_ppo_full_net, gen_gae, gen_gae_g2, gen_gae_g3, gen_categorical
               gen_ppo_full_loss, gen_soft_update, gen_sumtree, gen_per_nstep, gen_per_variant_b, gen_noisy,
               gen_dqn_update, gen_sac, gen_normalization]
 
+
+# --------------------------------------------------------------- H1 trace ----
+def gen_ppo_trace():
+    """Row H1: the reference PPOTrainer.train() run unmodified for two
+    rollout+update iterations on the build-owned scripted env (tests/scripted_env.py), python /
+    numpy / torch seeded 0.  Records every buffer field, the Exp(1) draws Categorical.sample
+    consumed, next_value, un-normalised adv/ret, the minibatch index order np.random.shuffle
+    produced, the metrics dicts, lr, step_count, episode_rewards and the state_dict after
+    each update (ppo_lunarlander.py:198-366)."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from scripted_env import ScriptedEnv
+    ppo = load_ref("algorithms/ppo_lunarlander.py", "ref_ppo_trace")
+    sys.modules["gymnasium"].make = lambda name, **kw: ScriptedEnv(8, 4)
+    cfg = ppo.Config()
+    cfg.update_freq, cfg.batch_size, cfg.num_epochs, cfg.hidden_dim = 96, 40, 2, 32   # 96/40: short last slice
+    cfg.max_train_steps = 2 * cfg.update_freq
+    cfg.lr = 1e-2                      # large enough that ratios clip within two updates
+    cfg.device = "cpu"
+    seed_all(0)
+    tr = ppo.PPOTrainer(cfg)
+    out = {"init_" + k: v.numpy().copy() for k, v in tr.model.state_dict().items()}
+
+    noise, rollouts, perms, lrs = [], [], [], []
+    orig_get_action = tr.model.get_action
+
+    def get_action(x, deterministic=False):
+        st = torch.get_rng_state()
+        res = orig_get_action(x, deterministic)
+        after = torch.get_rng_state()
+        torch.set_rng_state(st)
+        q = torch.empty(1, 4).exponential_(1.0)
+        torch.set_rng_state(after)
+        noise.append(q.numpy()[0].copy())
+        return res
+    tr.model.get_action = get_action
+
+    orig_shuffle = np.random.shuffle
+
+    def shuffle(a):
+        orig_shuffle(a)
+        perms.append(np.array(a, np.int32))
+    np.random.shuffle = shuffle
+
+    orig_update = tr.update
+    upd = []
+
+    def update(next_value):
+        b = tr.buffer
+        adv, ret = tr.compute_gae(next_value)
+        rollouts.append(dict(states=np.array(b.states, np.float32), actions=np.array(b.actions, np.int32),
+                             log_probs=np.array(b.log_probs, np.float32), values=np.array(b.values, np.float32),
+                             rewards=np.array(b.rewards, np.float64), dones=np.array(b.dones, np.uint8),
+                             next_value=np.float64(next_value), adv=np.asarray(adv, np.float64),
+                             ret=np.asarray(ret, np.float64)))
+        lrs.append(tr.optimizer.param_groups[0]["lr"])
+        m = orig_update(next_value)
+        upd.append(dict(metrics=np.array([m["policy_loss"], m["value_loss"], m["entropy"], m["clip_frac"],
+                                          m["approx_kl"]], np.float64),
+                        step_count=np.int64(tr.step_count), episode_rewards=np.array(tr.episode_rewards, np.float64),
+                        **{"sd_" + k: v.numpy().copy() for k, v in tr.model.state_dict().items()}))
+        return m
+    tr.update = update
+    try:
+        tr.train()
+    finally:
+        np.random.shuffle = orig_shuffle
+    assert len(rollouts) == 2 and len(perms) == 2 * cfg.num_epochs
+    T = cfg.update_freq
+    out["noise_exp"] = np.stack(noise).reshape(2, T, 1, 4).astype(np.float32)
+    out["perms"] = np.stack(perms).reshape(2, cfg.num_epochs, T)
+    out["lr"] = np.array(lrs, np.float64)
+    for r in range(2):
+        for k, v in rollouts[r].items():
+            out[f"r{r}_{k}"] = v
+        for k, v in upd[r].items():
+            out[f"r{r}_{k}"] = v
+    out["cfg"] = np.array([cfg.update_freq, cfg.batch_size, cfg.num_epochs, cfg.hidden_dim, cfg.max_train_steps], np.int64)
+    out["lr0"] = np.float64(cfg.lr)
+    save("ppo_trace", **out)
+
+
 if __name__ == "__main__":
     names = sys.argv[1:]
-    for g in GENERATORS:
+    for g in GENERATORS + [gen_ppo_trace]:
         if not names or g.__name__ in names:
             g()

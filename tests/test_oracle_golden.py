@@ -121,3 +121,45 @@ def test_soft_update_matches_torch(oracle):
     g = load_golden("soft_update")
     out = oracle.soft_update(g["target"], g["source"], float(g["tau"]))
     assert np.max(np.abs(out - g["out"])) <= 1e-7
+
+
+def test_ppo_trace_fixture_is_self_consistent(oracle):
+    """Row H1 fixture (reference train() on the scripted env): the scripted env replays the recorded
+    observation / reward / done sequence from the recorded actions; the oracle's categorical rule on the
+    initial network's logits + the recorded Exp(1) draws reproduces rollout 0's actions / log-probs /
+    values; the oracle GAE reproduces the recorded adv/ret."""
+    from scripted_env import ScriptedEnv
+    g = load_golden("ppo_trace")
+    env = ScriptedEnv(8, 4)
+    for r in range(2):
+        p = f"r{r}_"
+        obs, _ = env.reset()
+        ep_ret, finished = 0.0, []
+        for t in range(int(g["cfg"][0])):
+            assert np.array_equal(obs, g[p + "states"][t]), (r, t)
+            obs, rew, te, tr, _ = env.step(int(g[p + "actions"][t]))
+            assert rew == g[p + "rewards"][t] and int(te or tr) == g[p + "dones"][t]
+            ep_ret += rew
+            if te or tr:
+                finished.append(ep_ret)
+                ep_ret = 0.0
+                obs, _ = env.reset()
+        prev = [] if r == 0 else list(g["r0_episode_rewards"])
+        assert np.allclose((prev + finished)[-100:], g[p + "episode_rewards"])
+        adv, ret, _ = oracle.gae(g[p + "rewards"].astype(np.float32)[:, None], g[p + "values"][:, None],
+                                 g[p + "dones"][:, None], np.array([g[p + "next_value"]], np.float32),
+                                 0.99, 0.95, want_moments=True)
+        assert np.array_equal(adv[:, 0], g[p + "adv"].astype(np.float32))
+        assert np.array_equal(ret[:, 0], g[p + "ret"].astype(np.float32))
+    # P2 on rollout 0: numpy forward of the recorded initial ActorCritic (:63-90)
+    def lin(x, name):
+        return x @ g["init_" + name + ".weight"].T.astype(np.float64) + g["init_" + name + ".bias"]
+    x = g["r0_states"].astype(np.float64)
+    h = np.tanh(lin(np.tanh(lin(x, "shared.0")), "shared.2"))
+    logits = lin(np.tanh(lin(h, "actor.0")), "actor.2").astype(np.float32)
+    value = lin(np.tanh(lin(h, "critic.0")), "critic.2")[:, 0]
+    act, logp, _, _ = oracle.categorical_sample(logits, noise_exp=g["noise_exp"][0, :, 0])
+    assert np.array_equal(act, g["r0_actions"])
+    assert rel_close(logp, g["r0_log_probs"]) <= TOL and rel_close(value, g["r0_values"]) <= TOL
+    # O2: lr = lr0 * (1 - step_count / max_train_steps) before each rollout (:337-341)
+    assert np.allclose(g["lr"], [float(g["lr0"]), float(g["lr0"]) * 0.5])
