@@ -34,6 +34,7 @@ SYMBOLS = [
     "gymrl_per_sample", "gymrl_noisy_noise", "gymrl_epsilon_greedy", "gymrl_dqn_td_loss",
     "gymrl_sac_sample_fwd", "gymrl_sac_sample_bwd", "gymrl_sac_target", "gymrl_sac_critic_loss",
     "gymrl_sac_actor_loss", "gymrl_sac_alpha_step", "gymrl_running_norm", "gymrl_reward_scaling",
+    "gymrl_mlp_packed_floats", "gymrl_mlp_pack", "gymrl_mlp_forward",
 ]
 
 
@@ -56,6 +57,19 @@ class GaeOnline(C.Structure):
                 ("gamma", C.c_double), ("lam", C.c_double)]
 
 
+MLP_MAX_STAGES, MLP_MAX_WIDTH, MLP_MAX_INPUT = 8, 256, 64
+ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
+
+
+class MlpStage(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("in_dim", C.c_int),
+                ("out_dim", C.c_int), ("act", C.c_int), ("src", C.c_int), ("dst", C.c_int), ("out_stride", C.c_int)]
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("n_stages", C.c_int), ("stage", MlpStage * MLP_MAX_STAGES)]
+
+
 class PPOFullCfg(C.Structure):
     _fields_ = [("clip_eps_min", C.c_float), ("clip_eps_max", C.c_float), ("dual_clip", C.c_float),
                 ("erc_beta_low", C.c_float), ("erc_beta_high", C.c_float), ("entropy_coef", C.c_float)]
@@ -74,8 +88,9 @@ def lib():
         L.gymrl_gae_workspace_bytes.restype = C.c_size_t
         L.gymrl_reduce_workspace_bytes.restype = C.c_size_t
         L.gymrl_per_workspace_bytes.restype = C.c_size_t
+        L.gymrl_mlp_packed_floats.restype = C.c_size_t
         for name in SYMBOLS:
-            if name.endswith("_bytes"):
+            if name.endswith(("_bytes", "_floats")):
                 continue
             getattr(L, name).restype = C.c_int
         _lib = L

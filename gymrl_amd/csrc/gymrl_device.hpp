@@ -144,6 +144,36 @@ __device__ __forceinline__ float det_tanhf(float x) {
   return fmaf(p * z, x, x);
 }
 
+// Branch-free det_tanhf (bit-identical for every finite x): both ranges are evaluated and
+// selected, so a wave whose lanes straddle |x| = 0.625 does not execute two divergent paths
+// one after the other.  Used where tanh sits in an MFMA epilogue.
+__device__ __forceinline__ float det_tanhf_sel(float x) {
+  const float a = __builtin_fabsf(x);
+  const float t = __builtin_fminf(a, 9.0f);          // keeps exp in range; overridden below when a > 9
+  const float xx = t + t;
+  float n = __builtin_rintf(xx * 1.44269504088896341f);
+  float r = fmaf(n, -0.693359375f, xx);
+  r = fmaf(n, 2.12194440e-4f, r);
+  float pe = 1.9875691500e-4f;
+  pe = fmaf(pe, r, 1.3981999507e-3f);
+  pe = fmaf(pe, r, 8.3334519073e-3f);
+  pe = fmaf(pe, r, 4.1665795894e-2f);
+  pe = fmaf(pe, r, 1.6666665459e-1f);
+  pe = fmaf(pe, r, 5.0000001201e-1f);
+  const float e = __builtin_ldexpf(fmaf(pe, r * r, r) + 1.0f, (int)n);
+  float big = 1.0f - 2.0f / (e + 1.0f);
+  big = a > 9.0f ? 1.0f : big;
+  big = x < 0.0f ? -big : big;
+  const float z = x * x;
+  float p = -5.70498872745e-3f;
+  p = fmaf(p, z, 2.06390887954e-2f);
+  p = fmaf(p, z, -5.37397155531e-2f);
+  p = fmaf(p, z, 1.33314422036e-1f);
+  p = fmaf(p, z, -3.33332819422e-1f);
+  const float small = fmaf(p * z, x, x);
+  return a >= 0.625f ? big : small;
+}
+
 // --------------------------------------------------- online GAE chunk maps ---
 // One step of the forward composition used by gymrl_gae(variant 2); shared by the
 // categorical-sample kernel (fused) and the flush kernel.  running = f64[2][N].

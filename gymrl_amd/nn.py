@@ -40,3 +40,66 @@ class Linear(nn.Linear):
                 and self.weight.requires_grad and self.bias is not None):
             return _SplitKLinear.apply(x, self.weight, self.bias)
         return F.linear(x, self.weight, self.bias)
+
+
+class FusedMLP:
+    """Inference forward of a Linear(+Tanh|ReLU) network as ONE launch (`gymrl_mlp_forward`,
+    csrc/mlp.hip: 16 rows per workgroup, activations in LDS, f32 MFMA).  Built from a list of
+    (linear_module, activation, src, dst) stages.  The kernel reads a packed copy of each weight
+    (the MFMA B-operand image, `gymrl_mlp_pack`): call refresh() after the parameters changed —
+    once per rollout in the PPO trainer — biases are read in place.  Outputs of dst == -1 stages
+    are allocated once per batch size and reused.
+
+        fused = FusedMLP([(net.shared[0], "tanh", -1, 0), (net.shared[2], "tanh", 0, 1),
+                          (net.actor[0], "tanh", 1, 0), (net.actor[2], None, 0, -1),
+                          (net.critic[0], "tanh", 1, 0), (net.critic[2], None, 0, -1)])
+        logits, value = fused(obs)
+    """
+
+    _ACT = {None: 0, "none": 0, "tanh": 1, "relu": 2}
+
+    def __init__(self, stages):
+        self.stages = list(stages)
+        self._cache = {}
+        self._packed = None
+
+    def refresh(self):
+        """Re-pack every layer's weight (one tiny launch per layer)."""
+        from . import ops
+        if self._packed is None:
+            self._packed = [None] * len(self.stages)
+        for i, (m, _, _, _) in enumerate(self.stages):
+            self._packed[i] = ops.mlp_pack(m.weight.detach(), self._packed[i])
+
+    @staticmethod
+    def supported(stages, in_dim):
+        from . import ops
+        if in_dim > ops.MLP_MAX_INPUT or len(stages) > ops.MLP_MAX_STAGES:
+            return False
+        return all(m.in_features <= ops.MLP_MAX_WIDTH and (dst < 0 or m.out_features <= ops.MLP_MAX_WIDTH)
+                   for m, _, _, dst in stages)
+
+    def _build(self, n, device):
+        from . import ops
+        outs, table = [], []
+        for (m, act, src, dst), packed in zip(self.stages, self._packed):
+            out = torch.empty(n, m.out_features, device=device) if dst < 0 else None
+            if out is not None:
+                outs.append(out)
+            table.append(dict(W=packed, shape=(m.out_features, m.in_features),
+                              b=None if m.bias is None else m.bias.detach(),
+                              act=self._ACT[act], src=src, dst=dst, out=out))
+        ptrs = tuple(m.bias.data_ptr() for m, _, _, _ in self.stages if m.bias is not None)
+        return ops.mlp_desc(table), outs, ptrs
+
+    @torch.no_grad()
+    def __call__(self, x, refresh=False):
+        from . import ops
+        if refresh or self._packed is None:
+            self.refresh()
+        key = (x.shape[0], x.device)
+        ent = self._cache.get(key)
+        if ent is None or ent[2] != tuple(m.bias.data_ptr() for m, _, _, _ in self.stages if m.bias is not None):
+            ent = self._cache[key] = self._build(x.shape[0], x.device)
+        ops.mlp_forward(x, ent[0])
+        return ent[1]

@@ -8,7 +8,8 @@ import ctypes as C
 
 import torch
 
-from ._lib import GaeOnline, PPOCfg, PPOFullCfg, check, lib
+from ._lib import (ACT_NONE, ACT_RELU, ACT_TANH, MLP_MAX_INPUT, MLP_MAX_STAGES, MLP_MAX_WIDTH, GaeOnline,
+                   MlpDesc, PPOCfg, PPOFullCfg, check, lib)
 
 _vp = C.c_void_p
 
@@ -466,3 +467,46 @@ def reward_scaling(r, done, gamma, R, stats, out=None):
                                      C.c_double(gamma), _ptr(R, torch.float64), _ptr(stats, torch.float64),
                                      _ptr(out, torch.float32), _stream()), "gymrl_reward_scaling")
     return out
+
+
+# ------------------------------------------------------------ MLP forward ---
+def mlp_pack(W, packed=None):
+    """gymrl_mlp_pack: nn.Linear weight [out, in] -> MFMA B-operand image (f32 1-D).  Reuses `packed`."""
+    out_dim, in_dim = W.shape
+    n = lib().gymrl_mlp_packed_floats(C.c_int(out_dim), C.c_int(in_dim))
+    if packed is None:
+        packed = torch.empty(n, dtype=torch.float32, device=W.device)
+    elif packed.numel() != n:
+        raise ValueError("packed buffer has the wrong size")
+    check(lib().gymrl_mlp_pack(_ptr(W, torch.float32), C.c_int(out_dim), C.c_int(in_dim), _ptr(packed, torch.float32),
+                               _stream()), "gymrl_mlp_pack")
+    return packed
+
+
+def mlp_desc(stages):
+    """Build the stage table of gymrl_mlp_forward.  stages: list of dicts
+    {W (packed by mlp_pack), shape=(out_dim, in_dim), b|None, act, src, dst, out|None}; the tensors must stay
+    alive (and in place) for as long as the descriptor is used."""
+    if not 0 < len(stages) <= MLP_MAX_STAGES:
+        raise ValueError(f"1..{MLP_MAX_STAGES} stages")
+    d = MlpDesc()
+    d.n_stages = len(stages)
+    for i, st in enumerate(stages):
+        W, out = st["W"], st.get("out")
+        e = d.stage[i]
+        e.W, e.b = _ptr(W, torch.float32).value, _ptr(st.get("b"), torch.float32, True).value
+        e.out_dim, e.in_dim = st["shape"]
+        e.act, e.src, e.dst = int(st.get("act", ACT_NONE)), int(st["src"]), int(st["dst"])
+        if e.dst < 0:
+            if out is None or out.dim() != 2 or out.shape[1] != e.out_dim:
+                raise ValueError("dst == -1 needs an `out` tensor [n_rows, out_dim]")
+            e.out, e.out_stride = _ptr(out, torch.float32).value, out.stride(0)
+    return d
+
+
+def mlp_forward(x, desc):
+    """gymrl_mlp_forward: the whole Linear(+Tanh|ReLU) chain on x [n_rows, in_dim] in one launch; outputs
+    go to the `out` tensors named in the descriptor."""
+    n, in_dim = x.shape
+    check(lib().gymrl_mlp_forward(_ptr(x, torch.float32), C.c_int(n), C.c_int(in_dim), C.byref(desc), _stream()),
+          "gymrl_mlp_forward")

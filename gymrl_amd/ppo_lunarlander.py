@@ -24,7 +24,7 @@ from . import dist as gdist
 from . import ops
 from .envs import VecEnv
 from .flat import FusedAdam, flatten_module
-from .nn import Linear
+from .nn import FusedMLP, Linear
 
 
 class Config:
@@ -56,6 +56,7 @@ class Config:
         self.num_envs = 1
         self.reset_each_rollout = True   # ppo_lunarlander.py:200 resets the env at every rollout start
         self.gae_variant = 1             # 1 = time-blocked scan, 0 = sequential reference order
+        self.fused_policy_forward = True  # rollout forward = one gymrl_mlp_forward launch (False: per-layer torch)
         self.solved_reward = 200.0
 
 
@@ -86,10 +87,38 @@ class ActorCritic(nn.Module):
             layer_init(Linear(hidden_dim, hidden_dim)), nn.Tanh(),
             layer_init(Linear(hidden_dim, 1), std=1.0),
         )
+        self._fused = None
 
     def forward(self, x):
         features = self.shared(x)
         return self.actor(features), self.critic(features)
+
+    def _act_net(self):
+        if self._fused is None:
+            stages = [(self.shared[0], "tanh", -1, 0), (self.shared[2], "tanh", 0, 1),
+                      (self.actor[0], "tanh", 1, 0), (self.actor[2], None, 0, -1),
+                      (self.critic[0], "tanh", 1, 0), (self.critic[2], None, 0, -1)]
+            # wider-than-LDS networks keep the per-layer library path
+            ok = FusedMLP.supported(stages, self.shared[0].in_features)
+            self._fused = FusedMLP(stages) if ok else False
+        return self._fused
+
+    def refresh_act(self):
+        """Re-pack the weights act_forward(refresh=False) reads (call after every parameter update)."""
+        if self._act_net():
+            self._fused.refresh()
+
+    @torch.no_grad()
+    def act_forward(self, x, refresh=True):
+        """Inference forward for the rollout (:92-108): the six Linear(+Tanh) layers in one launch
+        (gymrl_mlp_forward).  Returns (logits [N, A], value [N, 1]); the tensors are reused by the
+        next call with the same batch size.  refresh=False skips re-packing the weights (the
+        rollout loop packs once at its start: parameters do not change inside a rollout)."""
+        net = self._act_net()
+        if net is False:
+            return self.forward(x)
+        logits, value = net(x, refresh)
+        return logits, value
 
     @torch.no_grad()
     def get_action(self, state, deterministic=False, seed=0, counter=0, env_id0=0, noise_exp=None):
@@ -250,8 +279,13 @@ class PPOTrainer:
         fuse_gae = cfg.gae_variant == 1 and b.N % 4 == 0
         # parity mode: explicit Exp(1) draws f32[rollouts, T, N, A] replace the Philox stream
         noise = None if self._parity_noise is None else self._parity_noise[self.rollout_count]
+        if cfg.fused_policy_forward:
+            self.model.refresh_act()                     # pack the current weights once per rollout
+            fwd = lambda o: self.model.act_forward(o, refresh=False)   # noqa: E731
+        else:
+            fwd = self.model
         for t in range(b.T):
-            logits, value = self.model(b.states[t])
+            logits, value = fwd(b.states[t])
             if tm is not None and t % 64 == 0:
                 tm.start("env_step+sample")
             # while sampling step t, fold step t-1 (whose delta needs V_t) into its GAE chunk map
@@ -268,7 +302,7 @@ class PPOTrainer:
         b.pos = b.T
         self.step_count += b.T * b.N
         self.rollout_count += 1
-        self._next_value.copy_(self.model.get_value(b.states[b.T]))
+        self._next_value.copy_(fwd(b.states[b.T])[1].view(-1))
         if fuse_gae:
             ops.gae_online_flush(ops.gae_online(b.rewards[b.T - 1], b.dones[b.T - 1], b.values[b.T - 1],
                                                 self._gae_running, self._gae_ws, b.T - 1, b.T, cfg.gamma,

@@ -279,6 +279,50 @@ int gymrl_adam_step(float* p, float* g, float* m, float* v, int64_t n,
 int gymrl_soft_update(float* target, const float* source, int64_t n, double tau,
                       void* stream);
 
+/* ============================================================ MLP forward == */
+/*
+ * P1 / D1 / A1 inference path: ActorCritic.forward ppo_lunarlander.py:86-90 (as called by
+ * get_action :92-104 and get_value :106-108 once per env step), QNetwork.forward
+ * dqn_cartpole.py:62-65 and Actor.forward sac_pendulum.py:66-74 in select_action.  The
+ * reference runs one torch Linear + activation call per layer on a B = 1 batch; here the
+ * whole chain of Linear(+Tanh|ReLU) layers runs in ONE launch on [n_rows, in_dim] rows, 16
+ * rows per workgroup, activations in LDS, f32 MFMA (v_mfma_f32_16x16x4_f32: exact f32).
+ *
+ * A network is a list of <= GYMRL_MLP_MAX_STAGES stages  y = act(x W^T + b):
+ *   W = the PACKED image of the f32[out_dim, in_dim] row-major weight (torch
+ *   nn.Linear.weight) that gymrl_mlp_pack writes — gymrl_mlp_packed_floats(out_dim, in_dim)
+ *   floats, P[tile][kblock][lane][c] = W[16 tile + (lane & 15)][16 kblock + 4 (lane >> 4) + c],
+ *   zero padded to 16-row tiles and to K rounded up to 64; repack after every parameter
+ *   update (one tiny launch per layer).  b f32[out_dim] or NULL (read in place);
+ *   src = -1 reads the network input x, 0..2 reads LDS buffer `src` (written by an earlier
+ *   stage); dst = 0..2 writes LDS buffer `dst` (out_dim <= GYMRL_MLP_MAX_WIDTH), dst = -1
+ *   writes out[row*out_stride + col] in HBM.  in_dim <= GYMRL_MLP_MAX_WIDTH (network input
+ *   <= GYMRL_MLP_MAX_INPUT).  Two heads on one trunk are two stages reading the same src.
+ * Summation order (bit-reproducible on the CPU, see csrc/mlp.hip): per output element
+ *   acc = 0; for kb in 0,16,.. < roundup(in_dim,64): for j in 0..3: for q in 0..3:
+ *     acc = fmaf(x[kb+4q+j], W[n][kb+4q+j], acc)   (k >= in_dim contribute fmaf(0,0,acc));
+ *   y = act(acc + b[n]); tanh = the deterministic
+ *   polynomial/exp kernel of csrc/gymrl_device.hpp.
+ */
+#define GYMRL_MLP_MAX_STAGES 8
+#define GYMRL_MLP_MAX_WIDTH 256
+#define GYMRL_MLP_MAX_INPUT 64
+enum { GYMRL_ACT_NONE = 0, GYMRL_ACT_TANH = 1, GYMRL_ACT_RELU = 2 };
+typedef struct {
+  const float* W;
+  const float* b;
+  float* out;       /* dst == -1 only */
+  int in_dim, out_dim, act, src, dst, out_stride;
+} gymrl_mlp_stage;
+typedef struct {
+  int n_stages;
+  gymrl_mlp_stage stage[GYMRL_MLP_MAX_STAGES];
+} gymrl_mlp_desc;
+size_t gymrl_mlp_packed_floats(int out_dim, int in_dim);
+int gymrl_mlp_pack(const float* W, int out_dim, int in_dim, float* packed, void* stream);
+int gymrl_mlp_forward(const float* x, int n_rows, int in_dim, const gymrl_mlp_desc* desc,
+                      void* stream);
+
 /* ========================================================= off-policy ===== */
 /*
  * D2 / A3 / S2: device-resident replay ring, SoA rows [cap]:

@@ -101,6 +101,34 @@ float orc_tanhf(float x) {
   return fmaf(p * z, x, x);
 }
 
+/* ------------------------------------------------------------------ MLP ---
+ * One stage of gymrl_mlp_forward (include/gymrl.h; the inference forward of
+ * ActorCritic ppo_lunarlander.py:86-90, QNetwork dqn_cartpole.py:62-65, Actor
+ * sac_pendulum.py:66-74): y = act(x W^T + b), W [out][in] row-major, in the kernel's
+ * documented summation order — K padded to a multiple of 64, for each 16-block the
+ * four k = kb+4q+j (q = 0..3) of MFMA j are chained with fmaf, j = 0..3 in turn.
+ * act: 0 none, 1 tanh (orc_tanhf), 2 relu. */
+void orc_linear_act(const float* x, const float* W, const float* b, int n, int in_dim, int out_dim, int act,
+                    float* y) {
+  const int k16 = (in_dim + 63) & ~63;
+  for (int r = 0; r < n; ++r)
+    for (int c = 0; c < out_dim; ++c) {
+      float acc = 0.0f;
+      for (int kb = 0; kb < k16; kb += 16)
+        for (int j = 0; j < 4; ++j)
+          for (int q = 0; q < 4; ++q) {
+            const int k = kb + 4 * q + j;
+            const float a = k < in_dim ? x[(size_t)r * in_dim + k] : 0.0f;
+            const float w = k < in_dim ? W[(size_t)c * in_dim + k] : 0.0f;
+            acc = fmaf(a, w, acc);
+          }
+      float v = acc + (b ? b[c] : 0.0f);
+      if (act == 1) v = orc_tanhf(v);
+      else if (act == 2) v = fmaxf(v, 0.0f);
+      y[(size_t)r * out_dim + c] = v;
+    }
+}
+
 /* ============================================================== Philox ==== */
 /* Philox4x32-10 (Salmon et al. 2011), the build's own counter-based env/policy
  * stream; integer only. */

@@ -72,6 +72,30 @@ def tanhf(x):
     return np.array([L.orc_tanhf(float(v)) for v in np.asarray(x, np.float32).ravel()], np.float32).reshape(np.shape(x))
 
 
+def linear_act(x, W, b, act=0):
+    """One stage of gymrl_mlp_forward: act(x W^T + b) in the kernel's summation order."""
+    x, W = _f32(x), _f32(W)
+    n, in_dim = x.shape
+    out_dim = W.shape[0]
+    b = None if b is None else _f32(b)
+    y = np.empty((n, out_dim), np.float32)
+    lib().orc_linear_act(_p(x), _p(W), _p(b), n, in_dim, out_dim, int(act), _p(y))
+    return y
+
+
+def mlp_forward(x, stages):
+    """stages: list of (W, b, act, src, dst); src -1 = x, dst -1 = network output.  Returns the list of
+    outputs of the dst == -1 stages in order (include/gymrl.h gymrl_mlp_forward)."""
+    bufs, outs = {-1: _f32(x)}, []
+    for W, b, act, src, dst in stages:
+        y = linear_act(bufs[src], W, b, act)
+        if dst < 0:
+            outs.append(y)
+        else:
+            bufs[dst] = y
+    return outs
+
+
 def sincosf(x):
     L = lib()
     xs = np.asarray(x, np.float32).ravel()

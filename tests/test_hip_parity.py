@@ -377,3 +377,81 @@ def test_gae_online_variant2(dev, oracle):
         a_ref, r_ref, m_ref = oracle.gae(rew, val, done, nv, 0.99, 0.95, want_moments=True)
         assert rel_close(adv.cpu().numpy(), a_ref) <= TOL and rel_close(ret.cpu().numpy(), r_ref) <= TOL
         assert rel_close(mom.cpu().numpy()[1:], m_ref[1:], 1e-9) <= 1e-9
+
+
+# ---------------------------------------------------------------- MLP forward ---
+def _mlp_case(rng, in_dim, hidden, heads, act):
+    """stages (W, b, act, src, dst) of a 2-layer trunk + one 2-layer head per entry of `heads`."""
+    def lin(o, i, scale=1.0):
+        return (rng.normal(size=(o, i)) * scale / np.sqrt(i)).astype(np.float32), rng.normal(size=o).astype(np.float32) * 0.1
+    st = [(*lin(hidden, in_dim), act, -1, 0), (*lin(hidden, hidden), act, 0, 1)]
+    for h in heads:
+        st.append((*lin(hidden, hidden), act, 1, 0))
+        st.append((*lin(h, hidden), 0, 0, -1))
+    return st
+
+
+def _pack_ref(W):
+    """include/gymrl.h: P[tile][kblock][lane][c] = W[16 tile + (lane & 15)][16 kblock + 4 (lane >> 4) + c]."""
+    out_dim, in_dim = W.shape
+    nt, nkb = (out_dim + 15) // 16, ((in_dim + 63) // 64) * 4
+    Wp = np.zeros((nt * 16, nkb * 16), np.float32)
+    Wp[:out_dim, :in_dim] = W
+    # [tile, n_in, kblock, q, c] -> [tile, kblock, q, n_in, c]  (lane = 16 q + n_in)
+    return Wp.reshape(nt, 16, nkb, 4, 4).transpose(0, 2, 3, 1, 4).reshape(-1).copy()
+
+
+@pytest.mark.parametrize("in_dim,hidden,heads,act,n", [
+    (8, 64, (4, 1), 1, 37),        # PPO ActorCritic shape, ragged last workgroup
+    (8, 256, (4, 1), 1, 4096),     # BASELINE config 2 shape
+    (4, 256, (2,), 2, 100),        # DQN QNetwork (ReLU)
+    (3, 256, (1, 1), 2, 33),       # SAC actor: obs dim 3 -> scalar weight loads, K padding
+    (8, 40, (20, 3), 1, 16),       # widths that are not multiples of 16 (LDS zero padding)
+    (64, 128, (17,), 1, 1),        # widest input, single row
+])
+def test_mlp_forward_vs_oracle_bit_exact(dev, oracle, in_dim, hidden, heads, act, n):
+    """gymrl_mlp_forward == the oracle's fmaf-chain restatement bit for bit (f32 MFMA is exact f32)."""
+    from gymrl_amd import ops
+    rng = np.random.default_rng(in_dim * 1000 + hidden + n)
+    stages = _mlp_case(rng, in_dim, hidden, heads, act)
+    x = rng.normal(size=(n, in_dim)).astype(np.float32)
+    want = oracle.mlp_forward(x, stages)
+    outs, table = [], []
+    for W, b, a, src, dst in stages:
+        out = torch.full((n, W.shape[0]), float("nan"), device=dev) if dst < 0 else None
+        if out is not None:
+            outs.append(out)
+        packed = ops.mlp_pack(torch.from_numpy(W).to(dev))
+        assert np.array_equal(packed.cpu().numpy(), _pack_ref(W)), "gymrl_mlp_pack layout"
+        table.append(dict(W=packed, shape=W.shape, b=torch.from_numpy(b).to(dev), act=a, src=src, dst=dst, out=out))
+    ops.mlp_forward(torch.from_numpy(x).to(dev), ops.mlp_desc(table))
+    for got, ref in zip(outs, want):
+        assert np.array_equal(got.cpu().numpy(), ref)
+    # and against plain float64 math (the oracle itself is not the only witness)
+    h = x.astype(np.float64)
+    f = (lambda z: z, np.tanh, lambda z: np.maximum(z, 0))[act]
+    W0, b0, W1, b1 = stages[0][0], stages[0][1], stages[1][0], stages[1][1]
+    h2 = f(f(h @ W0.T.astype(np.float64) + b0) @ W1.T.astype(np.float64) + b1)
+    Wh, bh, Wo, bo = stages[2][0], stages[2][1], stages[3][0], stages[3][1]
+    ref0 = f(h2 @ Wh.T.astype(np.float64) + bh) @ Wo.T.astype(np.float64) + bo
+    assert np.max(np.abs(outs[0].cpu().numpy() - ref0)) <= 2e-5 * max(1.0, np.abs(ref0).max())
+
+
+def test_mlp_forward_matches_torch_module(dev):
+    """ActorCritic.act_forward (one launch) vs the per-layer torch forward of the same module."""
+    from gymrl_amd.flat import flatten_module
+    from gymrl_amd.ppo_lunarlander import ActorCritic
+    torch.manual_seed(3)
+    net = ActorCritic(8, 4, 256)
+    flatten_module(net, dev)
+    x = torch.randn(4096, 8, device=dev)
+    logits, value = net.act_forward(x)
+    with torch.no_grad():
+        rl, rv = net(x)
+    assert torch.allclose(logits, rl, atol=2e-6, rtol=1e-5) and torch.allclose(value, rv, atol=2e-5, rtol=1e-5)
+    # biases are read in place, weights through the packed copy: refresh=False keeps the old weights
+    with torch.no_grad():
+        net.actor[2].bias.add_(1.0)
+        net.actor[2].weight.mul_(2.0)
+    assert torch.allclose(net.act_forward(x, refresh=False)[0], rl + 1.0, atol=2e-6, rtol=1e-5)
+    assert torch.allclose(net.act_forward(x)[0], 2.0 * (rl - net.actor[2].bias + 1.0) + net.actor[2].bias, atol=4e-6, rtol=1e-5)

@@ -81,6 +81,18 @@ def main():
             ops.adam_step(p, gr, m, vv, 3e-4, 0.9, 0.999, 1e-5, 1, max_grad_norm=0.5, sqnorm_buf=sq, zero_grad=True)
         dt = timeit(step)
         out[f"adam_{n}"] = dict(us=dt * 1e6, GBps=36.0 * n / dt / 1e9, frac=36.0 * n / dt / PEAK)
+    # rollout policy forward: one gymrl_mlp_forward launch vs the per-layer torch path
+    from gymrl_amd.flat import flatten_module
+    from gymrl_amd.ppo_lunarlander import ActorCritic
+    net = ActorCritic(8, 4, 256)
+    flatten_module(net, dev)
+    obs = torch.randn(N, 8, device=dev, generator=g)
+    flops = 2.0 * N * (8 * 256 + 3 * 256 * 256 + 256 * 5)
+    dt = timeit(lambda: net.act_forward(obs), iters=50)
+    out["mlp_forward_fused"] = dict(us=dt * 1e6, TFLOPs=flops / dt / 1e12, frac_f32_mfma=flops / dt / 157.3e12)
+    with torch.no_grad():
+        dt = timeit(lambda: net(obs), iters=50)
+    out["mlp_forward_torch"] = dict(us=dt * 1e6, TFLOPs=flops / dt / 1e12)
     print(json.dumps(out, indent=1))
 
 
