@@ -35,6 +35,8 @@ SYMBOLS = [
     "gymrl_sac_sample_fwd", "gymrl_sac_sample_bwd", "gymrl_sac_target", "gymrl_sac_critic_loss",
     "gymrl_sac_actor_loss", "gymrl_sac_alpha_step", "gymrl_running_norm", "gymrl_reward_scaling",
     "gymrl_mlp_packed_floats", "gymrl_mlp_pack", "gymrl_mlp_forward",
+    "gymrl_mlp_train_workspace_bytes", "gymrl_linear_tanh_smallk", "gymrl_tanh_inplace", "gymrl_tanh_bwd_colsum",
+    "gymrl_linear_smallk_bwd", "gymrl_heads_bwd",
 ]
 
 
@@ -89,6 +91,7 @@ def lib():
         L.gymrl_reduce_workspace_bytes.restype = C.c_size_t
         L.gymrl_per_workspace_bytes.restype = C.c_size_t
         L.gymrl_mlp_packed_floats.restype = C.c_size_t
+        L.gymrl_mlp_train_workspace_bytes.restype = C.c_size_t
         for name in SYMBOLS:
             if name.endswith(("_bytes", "_floats")):
                 continue

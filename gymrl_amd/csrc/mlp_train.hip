@@ -1,0 +1,410 @@
+// mlp_train.hip — the HBM-bound pieces of the ActorCritic update around the library GEMMs.
+//
+// One PPO minibatch (ppo_lunarlander.py:274-307) pushes B = T*N/32 rows (262,144 at
+// BASELINE config 2) through six 256-wide layers.  The 256x256 contractions are MFMA-bound
+// library GEMMs at ~90 % of the f32 matrix peak; everything else autograd launches around
+// them is one full pass over a [B, 256] activation per op (tanh, tanh', bias-gradient
+// reductions, gradient accumulation of the two heads, K = 8 / N = 4 "GEMMs" that only move
+// memory) — 36 % of the update's GPU time.  These kernels fuse those passes:
+//
+//   linear_tanh_smallk      H1 = tanh(X W1^T + b1), K = obs_dim <= 16: VALU dot products, one
+//                           write of H1 (replaces a K=8 GEMM tile-padded to 32 + a tanh pass)
+//   tanh_inplace            H = tanh(Z) after a library GEMM
+//   heads_bwd               both heads' backward in ONE pass over [Ha | Hc]: dZ = (dOut W) * (1 - H^2)
+//                           written once, plus dW2 / db2 of both heads and the bias gradient
+//                           of the layer below (replaces 4 skinny GEMMs, 2 tanh', 4 reductions
+//                           and the accumulation of the two heads' trunk gradients)
+//   tanh_bwd_colsum         dZ = dH * (1 - H^2) in place + column sums (bias gradient)
+//   linear_smallk_bwd       first layer: dZ1 = dH1 * (1 - H1^2) is never written; dW1, db1
+//                           are accumulated straight from dH1, H1, X
+//
+// Row-major [B, C] activations, C a power of two <= 256; a row is C/4 adjacent lanes x float4
+// so a wavefront touches 64/(C/4) whole rows per load.  Column reductions are deterministic:
+// per-lane serial f32 sums over the rows a lane visits, LDS tree inside the workgroup, one f32
+// partial row per workgroup, fixed-order f64 finalize.
+#include "gymrl_device.hpp"
+#include "../../include/gymrl.h"
+
+namespace {
+
+using namespace gymrl;
+
+constexpr int kTB = 256;        // threads per workgroup (4 waves)
+constexpr int kMaxBlocks = 1024;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// tanh for the training forward: |x| < 0.625 -> the odd polynomial of det_tanhf (full
+// relative accuracy near 0), else 1 - 2/(exp(2x)+1) on the hardware exp2 / rcp units
+// (~2 ulp).  Deterministic on the device, not restated on the CPU: the update's forward is
+// compared with torch at 1e-5, not bit for bit.
+__device__ __forceinline__ float fast_tanhf(float x) {
+  const float a = __builtin_fabsf(x);
+  const float e = __builtin_amdgcn_exp2f(__builtin_fminf(a, 10.0f) * 2.885390081777927f);  // exp(2a)
+  float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+  big = x < 0.0f ? -big : big;
+  const float z = x * x;
+  float p = -5.70498872745e-3f;
+  p = fmaf(p, z, 2.06390887954e-2f);
+  p = fmaf(p, z, -5.37397155531e-2f);
+  p = fmaf(p, z, 1.33314422036e-1f);
+  p = fmaf(p, z, -3.33332819422e-1f);
+  const float small = fmaf(p * z, x, x);
+  return a >= 0.625f ? big : small;
+}
+
+struct RowMap {            // lane -> (row within the wave's group, float4 column)
+  int lpr, rpw, r_in, c4;
+  __device__ RowMap(int C, int lane) : lpr(C >> 2), rpw(64 / (C >> 2)), r_in(lane / (C >> 2)), c4(lane % (C >> 2)) {}
+};
+
+inline int grid_for(int64_t rows, int C) {
+  const int rows_per_block = (kTB / 64) * (64 / (C / 4));
+  int64_t nb = (rows + rows_per_block - 1) / rows_per_block;
+  return (int)(nb < kMaxBlocks ? (nb < 1 ? 1 : nb) : kMaxBlocks);
+}
+
+// Workgroup reduction of NV per-lane column accumulators (each lane owns 4 adjacent columns
+// x NV/4 logical vectors) over the rpw row groups of each wave and the 4 waves; the result
+// row (NV/4 vectors of C columns) goes to partials[blockIdx][v*C + col].
+template <int NV>
+__device__ __forceinline__ void block_colsum(const float (&acc)[NV], int C, const RowMap& m, float* sm,
+                                             float* __restrict__ partials) {
+  static_assert(NV % 4 == 0, "vectors of 4 columns");
+  const int wave = threadIdx.x >> 6;
+  const int groups = (kTB / 64) * m.rpw;           // row groups in the workgroup
+  const int g = wave * m.rpw + m.r_in;
+  const int width = (NV / 4) * C;
+  // sm[g][v*C + 4*c4 + j]
+#pragma unroll
+  for (int v = 0; v < NV / 4; ++v)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sm[(size_t)g * width + v * C + 4 * m.c4 + j] = acc[4 * v + j];
+  __syncthreads();
+  for (int e = threadIdx.x; e < width; e += kTB) {
+    float s = 0.0f;
+    for (int gg = 0; gg < groups; ++gg) s += sm[(size_t)gg * width + e];
+    partials[(size_t)blockIdx.x * width + e] = s;
+  }
+}
+
+// Sum of partials[b][e] over b for one output element per 8 threads: thread (te = tid % 32,
+// tb = tid / 32) accumulates blocks tb, tb+8, .. in f64 (independent, pipelined loads), the 8
+// sub-sums are combined in tb order through LDS.  Returns the sum to the tb == 0 thread.
+constexpr int kFinE = 32, kFinB = kTB / kFinE;
+__device__ __forceinline__ double reduce_partials(const float* __restrict__ partials, int nblocks, int width, int e,
+                                                  bool valid) {
+  __shared__ double fin[kFinB][kFinE];
+  const int te = threadIdx.x % kFinE, tb = threadIdx.x / kFinE;
+  double s = 0.0;
+  if (valid) {
+    int b = tb;
+    for (; b + 3 * kFinB < nblocks; b += 4 * kFinB) {
+      const float p0 = partials[(size_t)b * width + e], p1 = partials[(size_t)(b + kFinB) * width + e];
+      const float p2 = partials[(size_t)(b + 2 * kFinB) * width + e], p3 = partials[(size_t)(b + 3 * kFinB) * width + e];
+      s += (double)p0; s += (double)p1; s += (double)p2; s += (double)p3;
+    }
+    for (; b < nblocks; b += kFinB) s += (double)partials[(size_t)b * width + e];
+  }
+  fin[tb][te] = s;
+  __syncthreads();
+  double t = 0.0;
+  if (tb == 0) {
+#pragma unroll
+    for (int k = 0; k < kFinB; ++k) t += fin[k][te];
+  }
+  return t;
+}
+
+// ------------------------------------------------------------------ F1 -------
+template <int D>
+__global__ __launch_bounds__(kTB) void linear_tanh_smallk_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                 const float* __restrict__ b, int64_t B, int C,
+                                                                 float* __restrict__ out) {
+  const RowMap m(C, threadIdx.x & 63);
+  float w[4][D], bias[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bias[j] = b ? b[4 * m.c4 + j] : 0.0f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) w[j][d] = W[(size_t)(4 * m.c4 + j) * D + d];
+  }
+  const int64_t stride = (int64_t)gridDim.x * (kTB / 64) * m.rpw;
+  for (int64_t r = ((int64_t)blockIdx.x * (kTB / 64) + (threadIdx.x >> 6)) * m.rpw + m.r_in; r < B; r += stride) {
+    float xv[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) xv[d] = x[r * D + d];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) acc = fmaf(xv[d], w[j][d], acc);
+      o[j] = fast_tanhf(acc + bias[j]);
+    }
+    *reinterpret_cast<f32x4*>(out + r * C + 4 * m.c4) = o;
+  }
+}
+
+__global__ __launch_bounds__(kTB) void tanh_inplace_kernel(float* __restrict__ z, int64_t n4) {
+  f32x4* p = reinterpret_cast<f32x4*>(z);
+  for (int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kTB) {
+    f32x4 v = p[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = fast_tanhf(v[j]);
+    p[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------ B2' ------
+__global__ __launch_bounds__(kTB) void tanh_bwd_colsum_kernel(float* __restrict__ dH, const float* __restrict__ H, int64_t B,
+                                                              int C, float* __restrict__ partials) {
+  extern __shared__ float sm[];
+  const RowMap m(C, threadIdx.x & 63);
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  const int64_t stride = (int64_t)gridDim.x * (kTB / 64) * m.rpw;
+  for (int64_t r = ((int64_t)blockIdx.x * (kTB / 64) + (threadIdx.x >> 6)) * m.rpw + m.r_in; r < B; r += stride) {
+    const size_t o = (size_t)r * C + 4 * m.c4;
+    const f32x4 h = *reinterpret_cast<const f32x4*>(H + o);
+    f32x4 g = *reinterpret_cast<const f32x4*>(dH + o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      g[j] = g[j] * (1.0f - h[j] * h[j]);
+      acc[j] += g[j];
+    }
+    *reinterpret_cast<f32x4*>(dH + o) = g;
+  }
+  block_colsum<4>(acc, C, m, sm, partials);
+}
+
+// ------------------------------------------------------------------ B1 -------
+// partial row layout: [db (C) | dW^T laid as d-major: d*C + col] -> (D+1) vectors of C columns
+template <int D>
+__global__ __launch_bounds__(kTB) void linear_smallk_bwd_kernel(const float* __restrict__ dH, const float* __restrict__ H,
+                                                                const float* __restrict__ x, int64_t B, int C,
+                                                                float* __restrict__ partials) {
+  extern __shared__ float sm[];
+  const RowMap m(C, threadIdx.x & 63);
+  float acc[4 * (D + 1)];
+#pragma unroll
+  for (int i = 0; i < 4 * (D + 1); ++i) acc[i] = 0.0f;
+  const int64_t stride = (int64_t)gridDim.x * (kTB / 64) * m.rpw;
+  for (int64_t r = ((int64_t)blockIdx.x * (kTB / 64) + (threadIdx.x >> 6)) * m.rpw + m.r_in; r < B; r += stride) {
+    const size_t o = (size_t)r * C + 4 * m.c4;
+    const f32x4 h = *reinterpret_cast<const f32x4*>(H + o);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dH + o);
+    float xv[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) xv[d] = x[r * D + d];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float dz = g[j] * (1.0f - h[j] * h[j]);
+      acc[j] += dz;
+#pragma unroll
+      for (int d = 0; d < D; ++d) acc[4 * (d + 1) + j] = fmaf(dz, xv[d], acc[4 * (d + 1) + j]);
+    }
+  }
+  block_colsum<4 * (D + 1)>(acc, C, m, sm, partials);
+}
+
+// dW[col][d] = sum over blocks of partials[b][(d+1)*C + col]; db[col] = ... [col]
+__global__ __launch_bounds__(kTB) void smallk_finalize_kernel(const float* __restrict__ partials, int nblocks, int C, int D,
+                                                              float* __restrict__ dW, float* __restrict__ db) {
+  const int e = blockIdx.x * kFinE + threadIdx.x % kFinE;
+  const int width = (D + 1) * C;
+  const double s = reduce_partials(partials, nblocks, width, e, e < width);
+  if (e >= width || threadIdx.x >= kFinE) return;
+  const int v = e / C, col = e - v * C;
+  if (v == 0) db[col] = (float)s;
+  else dW[(size_t)col * D + (v - 1)] = (float)s;
+}
+
+// ------------------------------------------------------------------ B4 -------
+// Hac [B, 2C] = [Ha | Hc] (tanh outputs of the actor / critic hidden layers).
+// dZac [B, 2C] = [ (dlogits Wa2) * (1 - Ha^2) | (dv Wc2) * (1 - Hc^2) ]
+// partial row: [dbac (2C) | dWa2 (A*C) | dWc2 (C) | dba2.. (C: only first A+1 used)]
+template <int A>
+__global__ __launch_bounds__(kTB) void heads_bwd_kernel(const float* __restrict__ Hac, const float* __restrict__ dlogits,
+                                                        const float* __restrict__ dv, int64_t B, int C,
+                                                        const float* __restrict__ Wa2, const float* __restrict__ Wc2,
+                                                        float* __restrict__ dZac, float* __restrict__ partials) {
+  extern __shared__ float sm[];
+  const RowMap m(C, threadIdx.x & 63);
+  float wa[A][4], wc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    wc[j] = Wc2[4 * m.c4 + j];
+#pragma unroll
+    for (int a = 0; a < A; ++a) wa[a][j] = Wa2[(size_t)a * C + 4 * m.c4 + j];
+  }
+  // accumulators: [0..3] dba (Ha cols), [4..7] dbc (Hc cols), [8 + 4a + j] dWa2[a], [8+4A + j] dWc2,
+  // [12+4A + 0..3]: sums of dlogits / dv (A+1 values, lane-redundant; padded to a multiple of 4)
+  constexpr int NACC = 8 + 4 * A + 4 + 4 * ((A + 1 + 3) / 4);
+  float acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+  const int64_t stride = (int64_t)gridDim.x * (kTB / 64) * m.rpw;
+  for (int64_t r = ((int64_t)blockIdx.x * (kTB / 64) + (threadIdx.x >> 6)) * m.rpw + m.r_in; r < B; r += stride) {
+    const size_t o = (size_t)r * 2 * C + 4 * m.c4;
+    const f32x4 ha = *reinterpret_cast<const f32x4*>(Hac + o);
+    const f32x4 hc = *reinterpret_cast<const f32x4*>(Hac + o + C);
+    float dl[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) dl[a] = dlogits[r * A + a];
+    const float dvr = dv[r];
+    f32x4 za, zc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float s = 0.0f;
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        s = fmaf(dl[a], wa[a][j], s);
+        acc[8 + 4 * a + j] = fmaf(dl[a], ha[j], acc[8 + 4 * a + j]);
+      }
+      za[j] = s * (1.0f - ha[j] * ha[j]);
+      zc[j] = (dvr * wc[j]) * (1.0f - hc[j] * hc[j]);
+      acc[j] += za[j];
+      acc[4 + j] += zc[j];
+      acc[8 + 4 * A + j] = fmaf(dvr, hc[j], acc[8 + 4 * A + j]);
+    }
+#pragma unroll
+    for (int a = 0; a < A; ++a) acc[12 + 4 * A + a] += dl[a];
+    acc[12 + 4 * A + A] += dvr;
+    *reinterpret_cast<f32x4*>(dZac + o) = za;
+    *reinterpret_cast<f32x4*>(dZac + o + C) = zc;
+  }
+  // only the c4 == 0 lane of a row group contributes the dlogits / dv sums (they are lane-redundant)
+  if (m.c4 != 0) {
+#pragma unroll
+    for (int i = 12 + 4 * A; i < NACC; ++i) acc[i] = 0.0f;
+  }
+  block_colsum<NACC>(acc, C, m, sm, partials);
+}
+
+// partial row (vectors of C): v0 dba, v1 dbc, v2..v(1+A) dWa2[a], v(2+A) dWc2, v(3+A).. dlogit sums at col 0..3
+template <int A>
+__global__ __launch_bounds__(kTB) void heads_finalize_kernel(const float* __restrict__ partials, int nblocks, int C,
+                                                             float* __restrict__ dbac, float* __restrict__ dWa2,
+                                                             float* __restrict__ dWc2, float* __restrict__ dba2,
+                                                             float* __restrict__ dbc2) {
+  constexpr int NV = (8 + 4 * A + 4 + 4 * ((A + 1 + 3) / 4)) / 4;
+  const int width = NV * C;
+  const int e = blockIdx.x * kFinE + threadIdx.x % kFinE;
+  const int v = e / C, col = e - v * C;
+  const bool want = e < width && !(v >= 3 + A && col >= 4);
+  const double s = reduce_partials(partials, nblocks, width, e, want);
+  if (!want || threadIdx.x >= kFinE) return;
+  const float f = (float)s;
+  if (v == 0) dbac[col] = f;
+  else if (v == 1) dbac[C + col] = f;
+  else if (v < 2 + A) dWa2[(size_t)(v - 2) * C + col] = f;
+  else if (v == 2 + A) dWc2[col] = f;
+  else {
+    const int k = 4 * (v - 3 - A) + col;       // index into (dlogit sums..., dv sum)
+    if (k < A) dba2[k] = f;
+    else if (k == A) dbc2[0] = f;
+  }
+}
+
+inline bool pow2_cols(int C) { return C >= 16 && C <= 256 && (C & (C - 1)) == 0; }
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline size_t sm_bytes(int C, int nv4) { return sizeof(float) * (size_t)(kTB / 64) * (64 / (C / 4)) * nv4 * C; }
+
+}  // namespace
+
+extern "C" {
+
+size_t gymrl_mlp_train_workspace_bytes(int C, int D, int A) {
+  if (C <= 0 || D < 0 || A < 0) return 0;
+  const size_t w1 = (size_t)(D + 1) * C, w2 = (size_t)(3 + A + (A + 1 + 3) / 4) * C;
+  return sizeof(float) * kMaxBlocks * (w1 > w2 ? w1 : w2) + 256;
+}
+
+int gymrl_linear_tanh_smallk(const float* x, const float* W, const float* b, int64_t B, int D, int C, float* out,
+                             void* stream) {
+  if (!x || !W || !out || B < 0 || !pow2_cols(C) || !al16(out)) return -22;
+  if (B == 0) return 0;
+  const dim3 grid(grid_for(B, C) * 1), block(kTB);
+  hipStream_t s = (hipStream_t)stream;
+  switch (D) {
+    case 2: hipLaunchKernelGGL(linear_tanh_smallk_kernel<2>, grid, block, 0, s, x, W, b, B, C, out); break;
+    case 3: hipLaunchKernelGGL(linear_tanh_smallk_kernel<3>, grid, block, 0, s, x, W, b, B, C, out); break;
+    case 4: hipLaunchKernelGGL(linear_tanh_smallk_kernel<4>, grid, block, 0, s, x, W, b, B, C, out); break;
+    case 8: hipLaunchKernelGGL(linear_tanh_smallk_kernel<8>, grid, block, 0, s, x, W, b, B, C, out); break;
+    default: return -22;
+  }
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_tanh_inplace(float* z, int64_t n, void* stream) {
+  if (!z || n < 0 || (n & 3) || !al16(z)) return -22;
+  if (n == 0) return 0;
+  const int64_t n4 = n / 4;
+  int64_t nb = (n4 + kTB - 1) / kTB;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(tanh_inplace_kernel, dim3((unsigned)nb), dim3(kTB), 0, (hipStream_t)stream, z, n4);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_tanh_bwd_colsum(float* dH, const float* H, int64_t B, int C, float* colsum_out, void* workspace,
+                          void* stream) {
+  if (!dH || !H || !colsum_out || !workspace || B < 0 || !pow2_cols(C) || !al16(dH) || !al16(H)) return -22;
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = grid_for(B, C);
+  float* parts = (float*)workspace;
+  hipLaunchKernelGGL(tanh_bwd_colsum_kernel, dim3(nb), dim3(kTB), sm_bytes(C, 1), s, dH, H, B, C, parts);
+  hipLaunchKernelGGL(smallk_finalize_kernel, dim3((C + kFinE - 1) / kFinE), dim3(kTB), 0, s, parts, nb, C, 0, (float*)nullptr,
+                     colsum_out);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_linear_smallk_bwd(const float* dH, const float* H, const float* x, int64_t B, int D, int C, float* dW,
+                            float* db, void* workspace, void* stream) {
+  if (!dH || !H || !x || !dW || !db || !workspace || B < 0 || !pow2_cols(C) || !al16(dH) || !al16(H)) return -22;
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = grid_for(B, C);
+  float* parts = (float*)workspace;
+  const dim3 grid(nb), block(kTB);
+  switch (D) {
+    case 2: hipLaunchKernelGGL(linear_smallk_bwd_kernel<2>, grid, block, sm_bytes(C, 3), s, dH, H, x, B, C, parts); break;
+    case 3: hipLaunchKernelGGL(linear_smallk_bwd_kernel<3>, grid, block, sm_bytes(C, 4), s, dH, H, x, B, C, parts); break;
+    case 4: hipLaunchKernelGGL(linear_smallk_bwd_kernel<4>, grid, block, sm_bytes(C, 5), s, dH, H, x, B, C, parts); break;
+    case 8: hipLaunchKernelGGL(linear_smallk_bwd_kernel<8>, grid, block, sm_bytes(C, 9), s, dH, H, x, B, C, parts); break;
+    default: return -22;
+  }
+  hipLaunchKernelGGL(smallk_finalize_kernel, dim3(((D + 1) * C + kFinE - 1) / kFinE), dim3(kTB), 0, s, parts, nb, C, D, dW, db);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_heads_bwd(const float* Hac, const float* dlogits, const float* dv, int64_t B, int C, int A,
+                    const float* Wa2, const float* Wc2, float* dZac, float* dbac, float* dWa2, float* dba2,
+                    float* dWc2, float* dbc2, void* workspace, void* stream) {
+  if (!Hac || !dlogits || !dv || !Wa2 || !Wc2 || !dZac || !dbac || !dWa2 || !dba2 || !dWc2 || !dbc2 || !workspace ||
+      B < 0 || !pow2_cols(C) || !al16(Hac) || !al16(dZac))
+    return -22;
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = grid_for(B, C);
+  float* parts = (float*)workspace;
+  const dim3 grid(nb), block(kTB);
+  if (A == 4) {
+    constexpr int NV = (8 + 16 + 4 + 8) / 4;
+    hipLaunchKernelGGL(heads_bwd_kernel<4>, grid, block, sm_bytes(C, NV), s, Hac, dlogits, dv, B, C, Wa2, Wc2, dZac, parts);
+    hipLaunchKernelGGL(heads_finalize_kernel<4>, dim3((NV * C + kFinE - 1) / kFinE), block, 0, s, parts, nb, C, dbac, dWa2,
+                       dWc2, dba2, dbc2);
+  } else if (A == 2) {
+    constexpr int NV = (8 + 8 + 4 + 4) / 4;
+    hipLaunchKernelGGL(heads_bwd_kernel<2>, grid, block, sm_bytes(C, NV), s, Hac, dlogits, dv, B, C, Wa2, Wc2, dZac, parts);
+    hipLaunchKernelGGL(heads_finalize_kernel<2>, dim3((NV * C + kFinE - 1) / kFinE), block, 0, s, parts, nb, C, dbac, dWa2,
+                       dWc2, dba2, dbc2);
+  } else {
+    return -22;
+  }
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

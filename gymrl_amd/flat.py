@@ -14,10 +14,15 @@ from . import ops
 _ALIGN = 64  # floats (256 B): keeps every parameter view aligned for hipBLASLt and float4 kernels
 
 
-def flatten_module(module, device):
+def flatten_module(module, device, order=None):
     """Move `module` to `device` with all parameters aliased into one flat buffer.
-    Returns (flat_params, flat_grads)."""
-    params = [p for p in module.parameters()]
+    Returns (flat_params, flat_grads).  `order` (optional list of parameter names) fixes the
+    layout of the named parameters at the front of the buffer, in that order — used to make two
+    layers' weights adjacent so that they can be driven as one GEMM; state_dict keys are untouched."""
+    named = dict(module.named_parameters())
+    params = [named[n] for n in (order or [])]
+    seen = {id(p) for p in params}
+    params += [p for p in module.parameters() if id(p) not in seen]
     offs, total = [], 0
     for p in params:
         offs.append(total)

@@ -510,3 +510,50 @@ def mlp_forward(x, desc):
     n, in_dim = x.shape
     check(lib().gymrl_mlp_forward(_ptr(x, torch.float32), C.c_int(n), C.c_int(in_dim), C.byref(desc), _stream()),
           "gymrl_mlp_forward")
+
+
+# ------------------------------------------------------ MLP update passes ---
+def mlp_train_workspace(C_, D, A, device):
+    n = lib().gymrl_mlp_train_workspace_bytes(C.c_int(C_), C.c_int(D), C.c_int(A))
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+def linear_tanh_smallk(x, W, b, out):
+    """out = tanh(x W^T + b) for a first layer with in_features in {2,3,4,8} (shared.0 + Tanh)."""
+    B, D = x.shape
+    check(lib().gymrl_linear_tanh_smallk(_ptr(x, torch.float32), _ptr(W, torch.float32), _ptr(b, torch.float32, True),
+                                         C.c_int64(B), C.c_int(D), C.c_int(W.shape[0]), _ptr(out, torch.float32),
+                                         _stream()), "gymrl_linear_tanh_smallk")
+    return out
+
+
+def tanh_inplace(z):
+    check(lib().gymrl_tanh_inplace(_ptr(z, torch.float32), C.c_int64(z.numel()), _stream()), "gymrl_tanh_inplace")
+    return z
+
+
+def tanh_bwd_colsum(dH, H, colsum_out, workspace):
+    """dH <- dH * (1 - H^2) in place; colsum_out[c] = sum_r dH[r, c]."""
+    B, Cc = dH.shape
+    check(lib().gymrl_tanh_bwd_colsum(_ptr(dH, torch.float32), _ptr(H, torch.float32), C.c_int64(B), C.c_int(Cc),
+                                      _ptr(colsum_out, torch.float32), _ptr(workspace), _stream()),
+          "gymrl_tanh_bwd_colsum")
+    return dH
+
+
+def linear_smallk_bwd(dH, H, x, dW, db, workspace):
+    """First layer backward without materialising dZ: dW = (dH (1 - H^2))^T x, db = colsum."""
+    B, Cc = dH.shape
+    check(lib().gymrl_linear_smallk_bwd(_ptr(dH, torch.float32), _ptr(H, torch.float32), _ptr(x, torch.float32),
+                                        C.c_int64(B), C.c_int(x.shape[1]), C.c_int(Cc), _ptr(dW, torch.float32),
+                                        _ptr(db, torch.float32), _ptr(workspace), _stream()), "gymrl_linear_smallk_bwd")
+
+
+def heads_bwd(Hac, dlogits, dv, Wa2, Wc2, dZac, dbac, dWa2, dba2, dWc2, dbc2, workspace):
+    """Backward of both heads in one pass over Hac = [Ha | Hc] (include/gymrl.h gymrl_heads_bwd)."""
+    B, C2 = Hac.shape
+    check(lib().gymrl_heads_bwd(_ptr(Hac, torch.float32), _ptr(dlogits, torch.float32), _ptr(dv, torch.float32),
+                                C.c_int64(B), C.c_int(C2 // 2), C.c_int(dlogits.shape[1]), _ptr(Wa2, torch.float32),
+                                _ptr(Wc2, torch.float32), _ptr(dZac, torch.float32), _ptr(dbac, torch.float32),
+                                _ptr(dWa2, torch.float32), _ptr(dba2, torch.float32), _ptr(dWc2, torch.float32),
+                                _ptr(dbc2, torch.float32), _ptr(workspace), _stream()), "gymrl_heads_bwd")

@@ -24,6 +24,7 @@ from . import dist as gdist
 from . import ops
 from .envs import VecEnv
 from .flat import FusedAdam, flatten_module
+from . import ppo_net
 from .nn import FusedMLP, Linear
 
 
@@ -57,6 +58,7 @@ class Config:
         self.reset_each_rollout = True   # ppo_lunarlander.py:200 resets the env at every rollout start
         self.gae_variant = 1             # 1 = time-blocked scan, 0 = sequential reference order
         self.fused_policy_forward = True  # rollout forward = one gymrl_mlp_forward launch (False: per-layer torch)
+        self.fused_update = True          # update forward/backward scheduled by ppo_net (False: torch autograd)
         self.solved_reward = 200.0
 
 
@@ -209,7 +211,8 @@ class PPOTrainer:
         torch.manual_seed(self.base_seed)
         self.model = ActorCritic(state_dim, action_dim, config.hidden_dim)
         torch.random.set_rng_state(gen_state)
-        self.flat_params, self.flat_grads = flatten_module(self.model, self.device)
+        self.flat_params, self.flat_grads = flatten_module(self.model, self.device, order=ppo_net.LAYOUT)
+        self._fused_update = None      # built on first update() when cfg.fused_update and the shape allows it
         gdist.broadcast(self.flat_params)
         self.optimizer = FusedAdam(self.flat_params, self.flat_grads, lr=config.lr, eps=1e-5,
                                    max_grad_norm=config.max_grad_norm)
@@ -357,6 +360,11 @@ class PPOTrainer:
             self._metric_parts.zero_()
         sizes = []
         row = 0
+        fu = None
+        if cfg.fused_update and ppo_net.supported(self.model):
+            if self._fused_update is None or self._fused_update.R < mb:
+                self._fused_update = ppo_net.FusedActorCriticUpdate(self.model, mb)
+            fu = self._fused_update
         for epoch in range(cfg.num_epochs):
             if indices is not None:
                 perm = torch.as_tensor(indices[epoch], device=self.device).to(torch.int32)
@@ -371,8 +379,11 @@ class PPOTrainer:
                 mb_obs, mb_act, mb_lp, mb_adv, mb_ret = ops.gather_minibatch(self._packed, mb_idx, obs_dim, stage)
                 if tm is not None:
                     tm.stop("gather_minibatch", B)
-                logits, values = self.model(mb_obs)
-                values = values.view(-1)
+                if fu is not None:
+                    logits, values = fu.forward(mb_obs)
+                else:
+                    logits, values = self.model(mb_obs)
+                    values = values.view(-1)
                 dlogits = torch.empty_like(logits)
                 dvalues = torch.empty_like(values)
                 if tm is not None:
@@ -382,7 +393,10 @@ class PPOTrainer:
                                      workspace=self._metric_parts[row])
                 if tm is not None:
                     tm.stop("ppo_loss_fwd_bwd", B)
-                torch.autograd.backward([logits, values], [dlogits, dvalues])
+                if fu is not None:
+                    fu.backward(dlogits, dvalues)
+                else:
+                    torch.autograd.backward([logits, values], [dlogits, dvalues])
                 if self.world_size > 1:
                     gdist.all_reduce_sum(self.flat_grads)
                 if tm is not None:

@@ -1,0 +1,125 @@
+"""Hand-scheduled forward/backward of the PPO ActorCritic for the update phase.
+
+`ActorCritic.evaluate_actions` + `loss.backward()` (ppo_lunarlander.py:110-117, :303) on a
+B = 262,144-row minibatch is, under autograd, 10 library GEMMs plus ~30 elementwise /
+reduction launches that each stream a [B, 256] activation through HBM.  Here the same math
+is scheduled by hand:
+
+    forward   H1  = tanh(X W1^T + b1)                 gymrl_linear_tanh_smallk   (K = obs_dim)
+              H2  = tanh(H1 W2^T + b2)                addmm (hipBLASLt) + gymrl_tanh_inplace
+              Hac = tanh(H2 [Wa1;Wc1]^T + [ba1;bc1])  ONE GEMM for actor.0 and critic.0 (N = 512)
+              logits = Ha Wa2^T + ba2,  v = Hc Wc2^T + bc2        two skinny GEMMs on views of Hac
+    backward  dZac, dbac, dWa2, dba2, dWc2, dbc2      gymrl_heads_bwd: one pass over Hac
+              d[Wa1;Wc1] = dZac^T H2                  split-K batched GEMM
+              dH2 = dZac [Wa1;Wc1]                    ONE GEMM (K = 512): no gradient accumulation
+              dZ2 = dH2 (1 - H2^2), db2               gymrl_tanh_bwd_colsum (in place)
+              dW2 = dZ2^T H1, dH1 = dZ2 W2            GEMMs
+              dW1, db1                                gymrl_linear_smallk_bwd (dZ1 never stored)
+
+The parameters stay the module's own nn.Parameters (state_dict-compatible with the reference);
+`flatten_module(order=LAYOUT)` only places actor.0 / critic.0 next to each other in the flat
+buffer so that [Wa1;Wc1] and [ba1;bc1] are plain views.  Gradients are written (not
+accumulated) into the parameters' .grad views of the flat gradient buffer.
+"""
+import torch
+
+from . import ops
+
+# flat-buffer order that makes [actor.0 ; critic.0] contiguous (weights, then biases)
+LAYOUT = ["shared.0.weight", "shared.0.bias", "shared.2.weight", "shared.2.bias",
+          "actor.0.weight", "critic.0.weight", "actor.0.bias", "critic.0.bias",
+          "actor.2.weight", "actor.2.bias", "critic.2.weight", "critic.2.bias"]
+
+
+def supported(model):
+    H = model.shared[0].out_features
+    D = model.shared[0].in_features
+    A = model.actor[2].out_features
+    # multiples of 64 keep flatten_module's 64-float padding from separating actor.0 / critic.0
+    return (H in (64, 128, 256) and D in (2, 3, 4, 8) and A in (2, 4)
+            and model.shared[2].out_features == H and model.actor[0].out_features == H
+            and model.critic[0].out_features == H)
+
+
+class FusedActorCriticUpdate:
+    def __init__(self, model, max_rows):
+        if not supported(model):
+            raise ValueError("unsupported ActorCritic shape for the fused update path")
+        self.m = model
+        W1 = model.shared[0].weight
+        dev = W1.device
+        self.H, self.D, self.A = W1.shape[0], W1.shape[1], model.actor[2].out_features
+        H = self.H
+        wa, wc = model.actor[0].weight, model.critic[0].weight
+        ba, bc = model.actor[0].bias, model.critic[0].bias
+        if wc.data_ptr() != wa.data_ptr() + wa.numel() * 4 or bc.data_ptr() != ba.data_ptr() + ba.numel() * 4:
+            raise ValueError("actor.0 / critic.0 are not adjacent: flatten_module(model, device, order=ppo_net.LAYOUT)")
+        flat, gflat = model._flat_params, model._flat_grads
+
+        def view(p, n, shape, buf):
+            off = (p.data_ptr() - flat.data_ptr()) // 4
+            return buf[off:off + n].view(shape)
+        self.Wac = view(wa, 2 * H * H, (2 * H, H), flat)
+        self.bac = view(ba, 2 * H, (2 * H,), flat)
+        self.dWac = view(wa, 2 * H * H, (2 * H, H), gflat)
+        self.dbac = view(ba, 2 * H, (2 * H,), gflat)
+        self.ws = ops.mlp_train_workspace(H, self.D, self.A, dev)
+        R = int(max_rows)
+        self.R = R
+        self.H1 = torch.empty(R, H, device=dev)
+        self.H2 = torch.empty(R, H, device=dev)
+        self.Hac = torch.empty(R, 2 * H, device=dev)
+        self.dZac = torch.empty(R, 2 * H, device=dev)
+        self.dH2 = torch.empty(R, H, device=dev)
+        self.dH1 = torch.empty(R, H, device=dev)
+        self.logits = torch.empty(R, self.A, device=dev)
+        self.value = torch.empty(R, 1, device=dev)
+        self._x = None
+
+    @torch.no_grad()
+    def forward(self, x):
+        """x [B, obs] -> (logits [B, A], values [B]); keeps the activations backward() needs."""
+        m, B, H = self.m, x.shape[0], self.H
+        if B > self.R:
+            raise ValueError("minibatch larger than the buffers")
+        H1, H2, Hac = self.H1[:B], self.H2[:B], self.Hac[:B]
+        ops.linear_tanh_smallk(x, m.shared[0].weight, m.shared[0].bias, H1)
+        torch.addmm(m.shared[2].bias, H1, m.shared[2].weight.t(), out=H2)
+        ops.tanh_inplace(H2)
+        torch.addmm(self.bac, H2, self.Wac.t(), out=Hac)
+        ops.tanh_inplace(Hac)
+        logits, value = self.logits[:B], self.value[:B]
+        torch.addmm(m.actor[2].bias, Hac[:, :H], m.actor[2].weight.t(), out=logits)
+        torch.addmm(m.critic[2].bias, Hac[:, H:], m.critic[2].weight.t(), out=value)
+        self._x = x
+        return logits, value.view(-1)
+
+    @staticmethod
+    def _dw(dy, x, out):
+        """out = dy^T x with the reduction dimension (rows) split into independent slices."""
+        B, N = dy.shape
+        K = x.shape[1]
+        S = 128
+        while S > 1 and (B % S or B // S < 64):
+            S //= 2
+        if S == 1:
+            return torch.mm(dy.t(), x, out=out)
+        tmp = torch.bmm(dy.view(S, B // S, N).transpose(1, 2), x.view(S, B // S, K))
+        return torch.sum(tmp, 0, out=out)
+
+    @torch.no_grad()
+    def backward(self, dlogits, dvalues):
+        """Writes every parameter gradient (overwrite, not accumulate) from dL/dlogits, dL/dvalues."""
+        m, x, H = self.m, self._x, self.H
+        B = x.shape[0]
+        H1, H2, Hac = self.H1[:B], self.H2[:B], self.Hac[:B]
+        dZac, dH2, dH1 = self.dZac[:B], self.dH2[:B], self.dH1[:B]
+        ops.heads_bwd(Hac, dlogits, dvalues.view(-1), m.actor[2].weight, m.critic[2].weight, dZac, self.dbac,
+                      m.actor[2].weight.grad, m.actor[2].bias.grad, m.critic[2].weight.grad, m.critic[2].bias.grad,
+                      self.ws)
+        self._dw(dZac, H2, self.dWac)
+        torch.mm(dZac, self.Wac, out=dH2)
+        ops.tanh_bwd_colsum(dH2, H2, m.shared[2].bias.grad, self.ws)
+        self._dw(dH2, H1, m.shared[2].weight.grad)
+        torch.mm(dH2, m.shared[2].weight, out=dH1)
+        ops.linear_smallk_bwd(dH1, H1, x, m.shared[0].weight.grad, m.shared[0].bias.grad, self.ws)

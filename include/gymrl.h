@@ -323,6 +323,42 @@ int gymrl_mlp_pack(const float* W, int out_dim, int in_dim, float* packed, void*
 int gymrl_mlp_forward(const float* x, int n_rows, int in_dim, const gymrl_mlp_desc* desc,
                       void* stream);
 
+/* ===================================================== MLP update path ===== */
+/*
+ * The HBM-bound passes of one ActorCritic minibatch update around the library GEMMs —
+ * ppo_lunarlander.py:274-307: evaluate_actions' forward :110-117 (shared/actor/critic
+ * Sequentials :67-84) and loss.backward() :303.  Activations are row-major f32 [B, C],
+ * C a power of two in 16..256.  workspace: gymrl_mlp_train_workspace_bytes(C, D, A) bytes.
+ * Column reductions are deterministic (fixed-order f64 finalize over per-workgroup partials).
+ *
+ *   linear_tanh_smallk : out = tanh(x W^T + b), x [B, D], W [C, D], D in {2,3,4,8}
+ *                        (shared.0: Linear(obs, hidden) + Tanh)
+ *   tanh_inplace       : z <- tanh(z) on n floats (after a library GEMM with bias)
+ *   tanh_bwd_colsum    : dH <- dH * (1 - H^2) in place; colsum_out[c] = sum_r dH[r][c]
+ *                        (Tanh backward + the bias gradient of the Linear below it)
+ *   linear_smallk_bwd  : dZ = dH * (1 - H^2) (never stored); dW [C, D] = dZ^T x; db [C] = colsum dZ
+ *   heads_bwd          : Hac [B, 2C] = [Ha | Hc], the Tanh outputs of actor.0 / critic.0;
+ *                        dlogits [B, A] (A in {2,4}), dv [B] from gymrl_ppo_loss_fwd_bwd;
+ *                        Wa2 [A, C] = actor.2.weight, Wc2 [1, C] = critic.2.weight.  Writes
+ *                        dZac [B, 2C] = [(dlogits Wa2)(1 - Ha^2) | (dv Wc2)(1 - Hc^2)],
+ *                        dbac [2C] = colsum dZac, dWa2 = dlogits^T Ha, dba2 = colsum dlogits,
+ *                        dWc2 = dv^T Hc, dbc2 = sum dv — one pass over Hac instead of four
+ *                        skinny GEMMs, two tanh' passes and four reductions.
+ * tanh here is |x| < 0.625 ? odd polynomial : 1 - 2/(exp(2x)+1) on the hardware exp2/rcp
+ * units (device-deterministic, ~2 ulp; compared with torch at 1e-5, not bit for bit).
+ */
+size_t gymrl_mlp_train_workspace_bytes(int C, int D, int A);
+int gymrl_linear_tanh_smallk(const float* x, const float* W, const float* b, int64_t B, int D, int C,
+                             float* out, void* stream);
+int gymrl_tanh_inplace(float* z, int64_t n, void* stream);
+int gymrl_tanh_bwd_colsum(float* dH, const float* H, int64_t B, int C, float* colsum_out,
+                          void* workspace, void* stream);
+int gymrl_linear_smallk_bwd(const float* dH, const float* H, const float* x, int64_t B, int D, int C,
+                            float* dW, float* db, void* workspace, void* stream);
+int gymrl_heads_bwd(const float* Hac, const float* dlogits, const float* dv, int64_t B, int C, int A,
+                    const float* Wa2, const float* Wc2, float* dZac, float* dbac, float* dWa2,
+                    float* dba2, float* dWc2, float* dbc2, void* workspace, void* stream);
+
 /* ========================================================= off-policy ===== */
 /*
  * D2 / A3 / S2: device-resident replay ring, SoA rows [cap]:
