@@ -160,7 +160,14 @@ def main():
     update_s = sum(e[1].elapsed_time(e[2]) for e in phase_events) * 1e-3 / a.steps
     # algorithmic bytes: GAE 17 B/elt, loss fwd+bwd 56 B/sample,
     # gather 64 B line in + 48 B out + 4 B index, Adam 36 B/param incl. norm pre-pass + zero_grad
-    bytes_per_unit = {"gae": 17.0, "ppo_loss_fwd_bwd": 56.0, "gather_minibatch": 116.0, "adam_step": 36.0}
+    # update-path passes (csrc/mlp_train.hip), per row of a [B, C=256] activation (obs D=8, A=4):
+    #   linear_tanh_smallk read 4D + write 4C; heads_bwd read 8C + 4(A+1), write 8C; tanh_bwd_colsum
+    #   read 8C, write 4C; linear_smallk_bwd read 8C + 4D; tanh_inplace 8 B per element
+    Cw, Dw, Aw = cfg.hidden_dim, 8, 4
+    bytes_per_unit = {"gae": 17.0, "ppo_loss_fwd_bwd": 56.0, "gather_minibatch": 116.0, "adam_step": 36.0,
+                      "linear_tanh_smallk": 4.0 * (Dw + Cw), "tanh_inplace": 8.0,
+                      "heads_bwd": 16.0 * Cw + 4.0 * (Aw + 1), "tanh_bwd_colsum": 12.0 * Cw,
+                      "linear_smallk_bwd": 8.0 * Cw + 4.0 * Dw}
     kernels = {}
     for k, v in ks.items():
         ent = dict(launches=v["launches"], avg_us=round(v["avg_us"], 2))

@@ -365,6 +365,7 @@ class PPOTrainer:
             if self._fused_update is None or self._fused_update.R < mb:
                 self._fused_update = ppo_net.FusedActorCriticUpdate(self.model, mb)
             fu = self._fused_update
+            fu.timers = tm
         for epoch in range(cfg.num_epochs):
             if indices is not None:
                 perm = torch.as_tensor(indices[epoch], device=self.device).to(torch.int32)

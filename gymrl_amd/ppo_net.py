@@ -75,6 +75,16 @@ class FusedActorCriticUpdate:
         self.logits = torch.empty(R, self.A, device=dev)
         self.value = torch.empty(R, 1, device=dev)
         self._x = None
+        self.timers = None      # bench.py: KernelTimers bracketing the hand-written HBM passes
+
+    def _timed(self, name, units, fn, *args):
+        tm = self.timers
+        if tm is None:
+            return fn(*args)
+        tm.start(name)
+        r = fn(*args)
+        tm.stop(name, units)
+        return r
 
     @torch.no_grad()
     def forward(self, x):
@@ -83,11 +93,11 @@ class FusedActorCriticUpdate:
         if B > self.R:
             raise ValueError("minibatch larger than the buffers")
         H1, H2, Hac = self.H1[:B], self.H2[:B], self.Hac[:B]
-        ops.linear_tanh_smallk(x, m.shared[0].weight, m.shared[0].bias, H1)
+        self._timed("linear_tanh_smallk", B, ops.linear_tanh_smallk, x, m.shared[0].weight, m.shared[0].bias, H1)
         torch.addmm(m.shared[2].bias, H1, m.shared[2].weight.t(), out=H2)
-        ops.tanh_inplace(H2)
+        self._timed("tanh_inplace", H2.numel(), ops.tanh_inplace, H2)
         torch.addmm(self.bac, H2, self.Wac.t(), out=Hac)
-        ops.tanh_inplace(Hac)
+        self._timed("tanh_inplace", Hac.numel(), ops.tanh_inplace, Hac)
         logits, value = self.logits[:B], self.value[:B]
         torch.addmm(m.actor[2].bias, Hac[:, :H], m.actor[2].weight.t(), out=logits)
         torch.addmm(m.critic[2].bias, Hac[:, H:], m.critic[2].weight.t(), out=value)
@@ -114,12 +124,13 @@ class FusedActorCriticUpdate:
         B = x.shape[0]
         H1, H2, Hac = self.H1[:B], self.H2[:B], self.Hac[:B]
         dZac, dH2, dH1 = self.dZac[:B], self.dH2[:B], self.dH1[:B]
-        ops.heads_bwd(Hac, dlogits, dvalues.view(-1), m.actor[2].weight, m.critic[2].weight, dZac, self.dbac,
-                      m.actor[2].weight.grad, m.actor[2].bias.grad, m.critic[2].weight.grad, m.critic[2].bias.grad,
-                      self.ws)
+        self._timed("heads_bwd", B, ops.heads_bwd, Hac, dlogits, dvalues.view(-1), m.actor[2].weight,
+                    m.critic[2].weight, dZac, self.dbac, m.actor[2].weight.grad, m.actor[2].bias.grad,
+                    m.critic[2].weight.grad, m.critic[2].bias.grad, self.ws)
         self._dw(dZac, H2, self.dWac)
         torch.mm(dZac, self.Wac, out=dH2)
-        ops.tanh_bwd_colsum(dH2, H2, m.shared[2].bias.grad, self.ws)
+        self._timed("tanh_bwd_colsum", B, ops.tanh_bwd_colsum, dH2, H2, m.shared[2].bias.grad, self.ws)
         self._dw(dH2, H1, m.shared[2].weight.grad)
         torch.mm(dH2, m.shared[2].weight, out=dH1)
-        ops.linear_smallk_bwd(dH1, H1, x, m.shared[0].weight.grad, m.shared[0].bias.grad, self.ws)
+        self._timed("linear_smallk_bwd", B, ops.linear_smallk_bwd, dH1, H1, x, m.shared[0].weight.grad,
+                    m.shared[0].bias.grad, self.ws)

@@ -712,8 +712,56 @@ def gen_ppo_trace():
     save("ppo_trace", **out)
 
 
+def gen_rainbow_update():
+    """R4: one full RainbowDQNTrainer.update() (rainbow_dqn_cartpole.py:311-361) — PER sample with the
+    uniforms numpy consumed, double-DQN target with fresh NoisyNet noise on both policy forwards (raw
+    randn draws recorded), IS-weighted loss, priority update before backward, clip_grad_norm_(10) +
+    Adam, soft target update, lr schedule."""
+    rb = load_ref("algorithms/rainbow_dqn_cartpole.py", "ref_rainbow_upd")
+    cfg = rb.Config()
+    cfg.device, cfg.batch_size, cfg.hidden_dim, cfg.memory_capacity = "cpu", 32, 32, 64
+    seed_all(90)
+    tr = rb.RainbowDQNTrainer(cfg)
+    rng = np.random.default_rng(90)
+    T = 60
+    obs = rng.normal(size=(T + 1, 4)).astype(np.float32)
+    act = rng.integers(0, 2, size=T)
+    rew = rng.normal(size=T).astype(np.float32)
+    done = rng.random(T) < 0.15
+    term = done & (rng.random(T) < 0.7)
+    for t in range(T):
+        tr.memory.store_transition(obs[t], int(act[t]), float(rew[t]), obs[t + 1], bool(term[t]), bool(done[t]))
+    with torch.no_grad():
+        for p in tr.target_net.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    tr.total_steps = 137
+    out = {"p0_" + k: v.numpy().copy() for k, v in tr.policy_net.state_dict().items()}
+    out.update({"t0_" + k: v.numpy().copy() for k, v in tr.target_net.state_dict().items()})
+    raw = []
+
+    def scale_noise(size):
+        x = torch.randn(size)
+        raw.append(x.numpy().copy())
+        return x.sign().mul(x.abs().sqrt())
+    rb.NoisyLinear.scale_noise = staticmethod(scale_noise)
+    np.random.seed(4242)
+    loss = tr.update()
+    np.random.seed(4242)
+    u = np.random.random_sample(cfg.batch_size)
+    assert len(raw) == 8, len(raw)           # 2 training-mode forwards x 2 NoisyLinear x (eps_in, eps_out)
+    for i, r in enumerate(raw):
+        out[f"raw{i}"] = r.astype(np.float32)
+    out.update({"p1_" + k: v.numpy().copy() for k, v in tr.policy_net.state_dict().items()})
+    out.update({"t1_" + k: v.numpy().copy() for k, v in tr.target_net.state_dict().items()})
+    out.update(obs=obs, act=act.astype(np.int32), rew=rew, done=done.astype(np.uint8), term=term.astype(np.uint8),
+               u=u, loss=np.float64(loss), lr_now=np.float64(tr.optimizer.param_groups[0]["lr"]),
+               tree_after=tr.memory.sum_tree.tree.copy(), total_steps=np.int64(137),
+               max_episodes=np.int64(cfg.max_episodes), lr0=np.float64(cfg.lr))
+    save("rainbow_update", **out)
+
+
 if __name__ == "__main__":
     names = sys.argv[1:]
-    for g in GENERATORS + [gen_ppo_trace]:
+    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update]:
         if not names or g.__name__ in names:
             g()

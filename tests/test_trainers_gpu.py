@@ -170,3 +170,35 @@ def test_ppo_train_trace_matches_reference():
         assert np.all(np.abs(np.asarray(got) - want) <= 2e-5 * np.maximum(1.0, np.abs(want))), (got, want)
         err = max(float(np.max(np.abs(v - g[p + "sd_" + k]))) for k, v in s["sd"].items())
         assert err <= 5e-5, err
+
+
+def test_rainbow_update_matches_reference():
+    """R4: one reference RainbowDQNTrainer.update() (tests/golden/rainbow_update.npz) reproduced from the
+    same transition stream, weights, PER uniforms and raw NoisyNet draws: loss, policy parameters after
+    clip+Adam, soft-updated target, float64 sum-tree after the priority update, lr schedule."""
+    from gymrl_amd.rainbow_dqn_cartpole import Config, RainbowDQNTrainer
+    g = load_golden("rainbow_update")
+    cfg = Config()
+    cfg.batch_size, cfg.hidden_dim, cfg.memory_capacity, cfg.num_envs = 32, 32, 64, 1
+    cfg.max_episodes, cfg.lr = int(g["max_episodes"]), float(g["lr0"])
+    tr = RainbowDQNTrainer(cfg)
+    dev = tr.device
+    _load(tr.policy_net, g, "p0_")
+    _load(tr.target_net, g, "t0_")
+    T = len(g["rew"])
+    for s in range(T):
+        tr.memory.store_transition(torch.from_numpy(g["obs"][s][None]).to(dev), torch.from_numpy(g["act"][s:s + 1]).to(dev),
+                                   torch.from_numpy(g["rew"][s:s + 1]).to(dev), torch.from_numpy(g["obs"][s + 1][None]).to(dev),
+                                   torch.from_numpy(g["term"][s:s + 1]).to(dev), torch.from_numpy(g["done"][s:s + 1]).to(dev))
+    tr.total_steps = int(g["total_steps"])
+    raw = [torch.from_numpy(g[f"raw{i}"]).to(dev) for i in range(8)]
+    # forward order: advantage.reset_noise (eps_in, eps_out) then value.reset_noise, twice (:320, :334)
+    tr.policy_net.advantage.raw_noise = iter([(raw[0], raw[1]), (raw[4], raw[5])])
+    tr.policy_net.value.raw_noise = iter([(raw[2], raw[3]), (raw[6], raw[7])])
+    loss = tr.update(u=torch.from_numpy(g["u"]).to(dev))
+    assert abs(loss - float(g["loss"])) <= 1e-5 * max(1.0, abs(float(g["loss"])))
+    assert _maxdiff(tr.policy_net, g, "p1_") <= 5e-6
+    assert _maxdiff(tr.target_net, g, "t1_") <= 5e-6
+    tree = tr.memory.sum_tree.tree.cpu().numpy()
+    assert np.max(np.abs(tree - g["tree_after"]) / np.maximum(1.0, np.abs(g["tree_after"]))) <= 2e-6
+    assert abs(tr.optimizer.param_groups[0]["lr"] - float(g["lr_now"])) <= 1e-12
