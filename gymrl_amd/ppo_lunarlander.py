@@ -413,6 +413,25 @@ class PPOTrainer:
         m = m.mean(axis=0)
         return {"policy_loss": m[0], "value_loss": m[1], "entropy": m[2], "clip_frac": m[3], "approx_kl": m[4]}
 
+    # ----------------------------------------------------------- checkpoint --
+    def save_checkpoint(self, path):
+        """ModelLoader-style dict (utils/model.py:337-349): `model_state_dict`, `optimizer_state_dict`
+        (torch.optim.Adam layout) + the counters a resumed run needs."""
+        from .utils import checkpoint
+        return checkpoint.save_agent(path, {"model": self.model}, {"optimizer": (self.model, self.optimizer)},
+                                     step_count=self.step_count, rollout_count=self.rollout_count,
+                                     episode_rewards=list(self.episode_rewards))
+
+    def load_checkpoint(self, path):
+        from .utils import checkpoint
+        rest = checkpoint.load_agent(path, {"model": self.model}, {"optimizer": (self.model, self.optimizer)})
+        self.step_count = int(rest.get("step_count", 0))
+        self.rollout_count = int(rest.get("rollout_count", 0))
+        self.episode_rewards.clear()
+        self.episode_rewards.extend(rest.get("episode_rewards", []))
+        gdist.broadcast(self.flat_params)
+        return rest
+
     # ---------------------------------------------------------------- train --
     def train(self):
         if self.rank == 0:

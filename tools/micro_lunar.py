@@ -7,7 +7,7 @@ from gymrl_amd.envs import VecEnv
 dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 
-def run(prefetch, steps, warm, policy):
+def run(prefetch, steps, warm, policy, drain=False):
     env = VecEnv("LunarLander-v3", N, device=dev, seed=1, prefetch_resets=prefetch)
     obs = env.reset(); nxt = torch.empty_like(obs)
     rew = torch.empty(N, device=dev); done = torch.zeros(N, dtype=torch.uint8, device=dev)
@@ -19,6 +19,8 @@ def run(prefetch, steps, warm, policy):
     torch.cuda.synchronize()
     evs = []
     for s in range(steps):
+        if drain:
+            torch.cuda.synchronize()        # the previous step's refill has finished: the step kernel runs alone
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); env.step(acts[s % 64], nxt, rew, done_out=done); b.record()
         evs.append((a, b)); obs, nxt = nxt, obs
@@ -33,3 +35,4 @@ print("N", N)
 print("fresh flight (noop, first 40 steps, no contacts/resets):", run(False, 40, 0, "noop"))
 print("steady random, inline resets:", run(False, 200, 300, "random"))
 print("steady random, refill side stream:", run(True, 200, 300, "random"))
+print("steady random, refill side stream, drained before each step:", run(True, 200, 300, "random", drain=True))
