@@ -34,7 +34,7 @@ HBM_PEAK = 8.0e12   # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARC
 def full_pass(trainer, T, N, dev, iters=5):
     """SURVEY.md section 8(d)'s definition of the GAE+loss pass: ONE launch of each kernel over the
     whole rollout (T*N transitions, 73 algorithmic bytes each), on the trainer's own slab, HIP
-    events around each launch, caches flushed in between (a 1-GiB fill) so nothing is served from
+    events around each launch, caches flushed in between (a 1-GiB read) so nothing is served from
     the 256-MB MALL.  Also measures a device-to-device copy for the 'fraction of measured copy
     bandwidth' figure."""
     from gymrl_amd import ops
@@ -60,7 +60,7 @@ def full_pass(trainer, T, N, dev, iters=5):
     def timed(fn):
         tot = 0.0
         for _ in range(iters):
-            flush.fill_(1)
+            flush.sum()                      # a 1-GiB read: L2 / MALL hold clean lines of something else
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             fn()
@@ -175,25 +175,46 @@ def main():
             gbps = bytes_per_unit[k] * v["units"] / v["total_s"] / 1e9
             ent.update(bytes_per_unit=bytes_per_unit[k], achieved_GBps=round(gbps, 1), frac=round(gbps * 1e9 / HBM_PEAK, 4))
         kernels[k] = ent
-    # the pass BASELINE.json's metric names: GAE (moments fused) + one clipped-surrogate
-    # loss pass over the rollout = 17 + 56 = 73 algorithmic bytes per transition
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    pm = json.load(open(pmc)) if os.path.exists(pmc) else None
+    # (1) The dominant hand-written HBM-bound work of the timed region: the five update passes of
+    # csrc/mlp_train.hip, launched once per minibatch around the library GEMMs (14 % of the step).
+    # achieved = their algorithmic bytes per minibatch / the sum of their average launch durations,
+    # HIP events on the launch stream inside the timed region; traffic = PMC bytes of the same launches.
+    upd = ["linear_tanh_smallk", "tanh_inplace", "heads_bwd", "tanh_bwd_colsum", "linear_smallk_bwd"]
+    if all(k in ks for k in upd):
+        n_mb = ks["heads_bwd"]["launches"]
+        upd_bytes = sum(bytes_per_unit[k] * ks[k]["units"] for k in upd) / n_mb
+        upd_s = sum(ks[k]["total_s"] for k in upd) / n_mb
+        upd_traffic = None
+        if pm is not None and all(k in pm for k in upd):
+            upd_traffic = round(sum(pm[k]["hbm_bytes_per_unit"] * ks[k]["units"] for k in upd) / n_mb)
+        head = dict(kernel="update passes of one minibatch (csrc/mlp_train.hip): linear_tanh_smallk + 2 x tanh_inplace + "
+                           "heads_bwd + tanh_bwd_colsum + linear_smallk_bwd",
+                    achieved=round(upd_bytes / upd_s / 1e9, 1), frac=round(upd_bytes / upd_s / HBM_PEAK, 4),
+                    traffic=upd_traffic, bytes_per_launch=upd_bytes, launch_s=upd_s)
+    else:
+        head = None
+    # (2) The pass BASELINE.json's metric names: GAE (moments fused) + one clipped-surrogate loss pass over
+    # the rollout = 17 + 56 = 73 algorithmic bytes per transition.  In the run the loss is 32 minibatch
+    # launches per pass (14.7 MB each: launch-latency bound); SURVEY 8(d) defines the pass at T*N in one launch.
     gae_s = ks["gae"]["total_s"] / ks["gae"]["launches"]
     loss_s_per_pass = ks["ppo_loss_fwd_bwd"]["total_s"] / (a.steps * cfg.num_epochs)
     pass_bytes = 73.0 * transitions
     achieved = pass_bytes / (gae_s + loss_s_per_pass)
-    # HBM traffic of the same kernels from the PMC passes committed under profiles/ (rocprofv3
-    # cannot run inside the bench): bytes per transition measured at T x N = 2048 x 4096
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if os.path.exists(pmc):
-        pm = json.load(open(pmc))
+    if pm is not None:
         traffic = round((pm["gae"]["hbm_bytes_per_transition"] + pm["ppo_loss"]["hbm_bytes_per_sample"]) * transitions)
-    roofline = dict(bound="hbm", achieved=round(achieved / 1e9, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK, 4), traffic=traffic,
-                    kernel="gae(G1: chunk maps fused in the rollout + carry + apply + moments) + ppo_loss_fwd_bwd, "
-                           "one pass over the rollout as the trainer launches it (32 minibatch launches per pass)",
-                    bytes_per_launch=pass_bytes, launch_s=gae_s + loss_s_per_pass, kernels=kernels,
-                    pass_at_rollout_size=full_pass(trainer, T, N, dev))
+    gae_loss = dict(kernel="gae(G1: chunk maps fused in the rollout + carry + apply + moments) + ppo_loss_fwd_bwd",
+                    in_run=dict(achieved=round(achieved / 1e9, 1), frac=round(achieved / HBM_PEAK, 4),
+                                launch_s=gae_s + loss_s_per_pass, note="1 GAE launch + 32 minibatch loss launches per pass"),
+                    at_rollout_size=full_pass(trainer, T, N, dev), traffic=traffic, bytes_per_pass=pass_bytes)
+    if head is None:
+        head = dict(kernel=gae_loss["kernel"], achieved=gae_loss["in_run"]["achieved"], frac=gae_loss["in_run"]["frac"],
+                    traffic=traffic, bytes_per_launch=pass_bytes, launch_s=gae_s + loss_s_per_pass)
+    roofline = dict(bound="hbm", achieved=head["achieved"], peak=HBM_PEAK / 1e9, unit="GB/s", frac=head["frac"],
+                    traffic=head["traffic"], kernel=head["kernel"], bytes_per_launch=head["bytes_per_launch"],
+                    launch_s=head["launch_s"], gae_loss_pass=gae_loss, kernels=kernels)
 
     out = {
         "metric": "env-steps/sec at N envs/GPU (PPO LunarLander), 1/2/4/8 GPUs + %HBM roofline",
