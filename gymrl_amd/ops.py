@@ -501,6 +501,7 @@ def mlp_desc(stages):
             if out is None or out.dim() != 2 or out.shape[1] != e.out_dim:
                 raise ValueError("dst == -1 needs an `out` tensor [n_rows, out_dim]")
             e.out, e.out_stride = _ptr(out, torch.float32).value, out.stride(0)
+    d._keepalive = list(stages)      # the table holds raw pointers: keep the tensors alive with it
     return d
 
 

@@ -233,6 +233,7 @@ class PPOTrainer:
         self._agg_ready = False
         self._parity_noise = None      # tests: f32[rollouts, T, N, A] Exp(1) draws (ops.categorical_sample noise_exp)
         self._parity_indices = []      # tests: per-update [num_epochs, T*N] shuffle orders consumed by update()
+        self._eval_env_factory = None  # tests: num_episodes -> env object for eval() (default: a fresh VecEnv)
         self._gae_running = torch.zeros(2, N, dtype=torch.float64, device=self.device)
         self._packed = None      # [T*N, 16] packed rollout records (allocated on first update)
         mb = self._minibatch_size_for(T * N)
@@ -464,8 +465,11 @@ class PPOTrainer:
     def eval(self, num_episodes=10):
         """:368-399: deterministic (argmax) episodes — run as `num_episodes` parallel envs,
         each contributing its first finished episode."""
-        env = VecEnv(self.cfg.env_name, num_episodes, device=self.device, seed=self.base_seed + 1_000_003,
-                     env_id0=1 << 40)
+        if self._eval_env_factory is not None:
+            env = self._eval_env_factory(num_episodes)
+        else:
+            env = VecEnv(self.cfg.env_name, num_episodes, device=self.device, seed=self.base_seed + 1_000_003,
+                         env_id0=1 << 40)
         obs = env.reset()
         nxt = torch.empty_like(obs)
         rew = torch.empty(num_episodes, device=self.device)

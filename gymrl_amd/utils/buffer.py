@@ -97,3 +97,66 @@ class ReplayBuffer_off_policy:
         self.draws += 1
         s, a, r, s2, d = ops.replay_gather(self._ring, idx, self._adtype)
         return s, a.float(), r, s2, d
+
+
+class ReplayBuffer_on_policy_v2:
+    """utils/buffer.py:53-102: dense episode-major slabs [batch_size, max_steps, ...] + an `active`
+    mask (`dw` defaults to 1), one row per episode, `sample()` trimmed to the longest episode.
+
+    The reference fills one row at a time (`store` ... `next_episode`).  With N env streams every env
+    owns the row of its current episode and `next_episode(mask)` hands the finished envs the next free
+    rows in env order, so N = 1 reproduces the reference exactly.  The slabs live on `cfg.device`
+    (already the `[T][N]`-style device layout `sample()` returns); only tensor indexing is involved,
+    no kernels of their own."""
+
+    def __init__(self, cfg, num_envs=1):
+        self.cfg, self.N = cfg, int(num_envs)
+        self.clear()
+
+    def clear(self):
+        E, L, d = int(self.cfg.batch_size), int(self.cfg.max_steps), torch.device(self.cfg.device)
+        f = dict(dtype=torch.float32, device=d)
+        self.buffer = {
+            's': torch.zeros([E, L] + list(self.cfg.state_shape), **f),
+            'a': torch.zeros(E, L, dtype=torch.int64, device=d),
+            'a_logprob': torch.zeros(E, L, **f), 'r': torch.zeros(E, L, **f), 'd': torch.zeros(E, L, **f),
+            'dw': torch.ones(E, L, **f), 'v': torch.zeros(E, L, **f), 'v_': torch.zeros(E, L, **f),
+            'active': torch.zeros(E, L, dtype=torch.int8, device=d),
+        }
+        self.size = torch.zeros(E, dtype=torch.int64, device=d)
+        self._row = torch.arange(self.N, dtype=torch.int64, device=d)     # row of env i's current episode
+        self._next_free = self.N
+        self.episode_num = 0                                             # finished episodes (= current row for N = 1)
+
+    def store(self, transitions):
+        """(s, a, r, d, dw, a_logprob, v, v_) with a leading env dimension [N] (scalars accepted for N = 1).
+        Envs whose row lies beyond batch_size are dropped (the reference would raise IndexError)."""
+        dev = self.size.device
+        s, a, r, d, dw, a_logprob, v, v_ = (torch.as_tensor(x, device=dev) for x in transitions)
+        row = self._row
+        ok = row < self.size.numel()
+        row = row[ok]
+        pos = self.size[row]
+        b = self.buffer
+        b['s'][row, pos] = s.reshape(self.N, *b['s'].shape[2:]).float()[ok]
+        for key, val in (('a', a), ('a_logprob', a_logprob), ('r', r), ('d', d), ('dw', dw), ('v', v), ('v_', v_)):
+            b[key][row, pos] = val.reshape(self.N).to(b[key].dtype)[ok]
+        b['active'][row, pos] = 1
+        self.size[row] += 1
+
+    def next_episode(self, mask=None):
+        """Reference signature for N = 1; `mask` [N] (bool / u8) selects the envs whose episode ended."""
+        if mask is None:
+            mask = torch.ones(self.N, dtype=torch.bool, device=self.size.device)
+        mask = torch.as_tensor(mask, device=self.size.device).bool().reshape(self.N)
+        k = int(mask.sum())                                   # host read: rows are a python-side resource
+        if k:
+            self._row[mask] = self._next_free + torch.arange(k, dtype=torch.int64, device=self.size.device)
+            self._next_free += k
+            self.episode_num += k
+
+    def sample(self):
+        n = int(self.size.max())
+        b = self.buffer
+        return (b['s'][:, :n], b['a'][:, :n], b['a_logprob'][:, :n], b['r'][:, :n], b['d'][:, :n], b['dw'][:, :n],
+                b['v'][:, :n], b['v_'][:, :n], b['active'][:, :n].float())

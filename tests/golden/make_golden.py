@@ -698,6 +698,10 @@ def gen_ppo_trace():
     finally:
         np.random.shuffle = orig_shuffle
     assert len(rollouts) == 2 and len(perms) == 2 * cfg.num_epochs
+    # P8: eval() continues on the training env (:368-399): deterministic argmax episodes
+    tr.model.get_action = orig_get_action
+    out["eval_episode0"] = np.int64(tr.env.episode + 1)
+    out["eval_returns"] = np.array(tr.eval(num_episodes=3), np.float64)
     T = cfg.update_freq
     out["noise_exp"] = np.stack(noise).reshape(2, T, 1, 4).astype(np.float32)
     out["perms"] = np.stack(perms).reshape(2, cfg.num_epochs, T)
@@ -760,8 +764,34 @@ def gen_rainbow_update():
     save("rainbow_update", **out)
 
 
+def gen_buffer_v2():
+    """U3: ReplayBuffer_on_policy_v2 (utils/buffer.py:53-102): episodes of different lengths stored row by
+    row, sample() trimmed to the longest; all nine returned tensors."""
+    sys.path.insert(0, REF)
+    from utils.buffer import ReplayBuffer_on_policy_v2
+    cfg = types.SimpleNamespace(batch_size=5, max_steps=12, state_shape=(3,), device="cpu")
+    buf = ReplayBuffer_on_policy_v2(cfg)
+    rng = np.random.default_rng(61)
+    lens = [4, 9, 1, 7]                       # the fifth row stays empty (dw == 1 there)
+    stream = []
+    for L in lens:
+        for t in range(L):
+            tr = (rng.normal(size=3).astype(np.float32), int(rng.integers(0, 4)), float(np.float32(rng.normal())),
+                  float(t == L - 1), float((t == L - 1) and L != 9), float(np.float32(rng.normal())),
+                  float(np.float32(rng.normal())), float(np.float32(rng.normal())))
+            buf.store(tr)
+            stream.append(tr)
+        buf.next_episode()
+    out = buf.sample()
+    names = ["s", "a", "a_logprob", "r", "d", "dw", "v", "v_", "active"]
+    res = {"out_" + n: t.numpy() for n, t in zip(names, out)}
+    res.update(lens=np.array(lens), stream_s=np.stack([t[0] for t in stream]),
+               stream_rest=np.array([t[1:] for t in stream], np.float64), episode_num=np.int64(buf.episode_num))
+    save("buffer_v2", **res)
+
+
 if __name__ == "__main__":
     names = sys.argv[1:]
-    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update]:
+    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2]:
         if not names or g.__name__ in names:
             g()

@@ -58,13 +58,15 @@ class ScriptedVecEnv:
     """The same script behind gymrl_amd.envs.VecEnv's device interface (N independent copies;
     copy i starts `i` resets ahead so lanes differ).  Host-computed: a test fixture, not a product path."""
 
-    def __init__(self, num_envs, device, obs_dim=8, n_actions=4):
+    def __init__(self, num_envs, device, obs_dim=8, n_actions=4, episode0=None):
         import torch
         self.torch = torch
         self.n, self.device = num_envs, device
         self.envs = [ScriptedEnv(obs_dim, n_actions) for _ in range(num_envs)]
         for i, e in enumerate(self.envs):
-            e.episode += i * 1000
+            # training: lanes far apart; evaluation (episode0 given): copy i plays episode episode0 + i,
+            # the i-th of the reference's sequential evaluation episodes
+            e.episode += i * 1000 if episode0 is None else episode0 + i
         self.obs_dim, self.act_dim, self.discrete, self.max_steps = obs_dim, n_actions, True, 500
         self.seed, self.env_id0 = 0, 0
         self.ep_ret = [0.0] * num_envs

@@ -170,6 +170,10 @@ def test_ppo_train_trace_matches_reference():
         assert np.all(np.abs(np.asarray(got) - want) <= 2e-5 * np.maximum(1.0, np.abs(want))), (got, want)
         err = max(float(np.max(np.abs(v - g[p + "sd_" + k]))) for k, v in s["sd"].items())
         assert err <= 5e-5, err
+    # P8: deterministic evaluation episodes (:368-399) — copy i plays the reference's i-th eval episode
+    ep0 = int(g["eval_episode0"])
+    tr._eval_env_factory = lambda n: ScriptedVecEnv(n, tr.device, episode0=ep0)
+    assert np.allclose(tr.eval(num_episodes=3), g["eval_returns"], rtol=0, atol=1e-6)
 
 
 def test_rainbow_update_matches_reference():
