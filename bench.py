@@ -152,8 +152,16 @@ def main():
     trainer._timers = None
 
     if rank != 0:
+        gdist.shutdown()               # waits for rank 0's post-processing, then leaves together
         return
     sys.stdout = sys.__stdout__
+    try:
+        report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev)
+    finally:
+        gdist.shutdown()               # always release the other ranks, even if the report fails
+
+
+def report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev):
     ks = timers.summary()
     transitions = T * N
     rollout_s = sum(e[0].elapsed_time(e[1]) for e in phase_events) * 1e-3 / a.steps
@@ -161,11 +169,13 @@ def main():
     # algorithmic bytes: GAE 17 B/elt, loss fwd+bwd 56 B/sample,
     # gather 64 B line in + 48 B out + 4 B index, Adam 36 B/param incl. norm pre-pass + zero_grad
     # update-path passes (csrc/mlp_train.hip), per row of a [B, C=256] activation (obs D=8, A=4):
-    #   linear_tanh_smallk read 4D + write 4C; heads_bwd read 8C + 4(A+1), write 8C; tanh_bwd_colsum
+    #   linear_tanh_smallk read 4D + write 4C; heads_fwd_tanh read 8C, write 8C + 4(A+1); heads_bwd read 8C + 4(A+1),
+    #   write 8C; tanh_bwd_colsum
     #   read 8C, write 4C; linear_smallk_bwd read 8C + 4D; tanh_inplace 8 B per element
     Cw, Dw, Aw = cfg.hidden_dim, 8, 4
     bytes_per_unit = {"gae": 17.0, "ppo_loss_fwd_bwd": 56.0, "gather_minibatch": 116.0, "adam_step": 36.0,
                       "linear_tanh_smallk": 4.0 * (Dw + Cw), "tanh_inplace": 8.0,
+                      "heads_fwd_tanh": 16.0 * Cw + 4.0 * (Aw + 1),
                       "heads_bwd": 16.0 * Cw + 4.0 * (Aw + 1), "tanh_bwd_colsum": 12.0 * Cw,
                       "linear_smallk_bwd": 8.0 * Cw + 4.0 * Dw}
     kernels = {}
@@ -181,7 +191,7 @@ def main():
     # csrc/mlp_train.hip, launched once per minibatch around the library GEMMs (14 % of the step).
     # achieved = their algorithmic bytes per minibatch / the sum of their average launch durations,
     # HIP events on the launch stream inside the timed region; traffic = PMC bytes of the same launches.
-    upd = ["linear_tanh_smallk", "tanh_inplace", "heads_bwd", "tanh_bwd_colsum", "linear_smallk_bwd"]
+    upd = ["linear_tanh_smallk", "tanh_inplace", "heads_fwd_tanh", "heads_bwd", "tanh_bwd_colsum", "linear_smallk_bwd"]
     if all(k in ks for k in upd):
         n_mb = ks["heads_bwd"]["launches"]
         upd_bytes = sum(bytes_per_unit[k] * ks[k]["units"] for k in upd) / n_mb
@@ -189,8 +199,8 @@ def main():
         upd_traffic = None
         if pm is not None and all(k in pm for k in upd):
             upd_traffic = round(sum(pm[k]["hbm_bytes_per_unit"] * ks[k]["units"] for k in upd) / n_mb)
-        head = dict(kernel="update passes of one minibatch (csrc/mlp_train.hip): linear_tanh_smallk + 2 x tanh_inplace + "
-                           "heads_bwd + tanh_bwd_colsum + linear_smallk_bwd",
+        head = dict(kernel="update passes of one minibatch (csrc/mlp_train.hip): linear_tanh_smallk + tanh_inplace + "
+                           "heads_fwd_tanh + heads_bwd + tanh_bwd_colsum + linear_smallk_bwd",
                     achieved=round(upd_bytes / upd_s / 1e9, 1), frac=round(upd_bytes / upd_s / HBM_PEAK, 4),
                     traffic=upd_traffic, bytes_per_launch=upd_bytes, launch_s=upd_s)
     else:
@@ -239,6 +249,7 @@ def main():
         from oracle.ref_ppo_cpu import time_cpu_baseline
         out["cpu_baseline"] = time_cpu_baseline(a.cpu_budget)
     print(json.dumps(out))
+    sys.stdout.flush()
 
 
 if __name__ == "__main__":

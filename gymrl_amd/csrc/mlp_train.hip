@@ -116,6 +116,22 @@ __device__ __forceinline__ double reduce_partials(const float* __restrict__ part
   return t;
 }
 
+// One input row x[0..D): every lane of a row group reads the same D floats (one request per
+// wave); whole float4s when D allows it.
+template <int D>
+__device__ __forceinline__ void load_row(float (&xv)[D], const float* __restrict__ p) {
+  if constexpr (D % 4 == 0) {
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + d);
+      xv[d] = v[0]; xv[d + 1] = v[1]; xv[d + 2] = v[2]; xv[d + 3] = v[3];
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < D; ++d) xv[d] = p[d];
+  }
+}
+
 // ------------------------------------------------------------------ F1 -------
 template <int D>
 __global__ __launch_bounds__(kTB) void linear_tanh_smallk_kernel(const float* __restrict__ x, const float* __restrict__ W,
@@ -132,8 +148,7 @@ __global__ __launch_bounds__(kTB) void linear_tanh_smallk_kernel(const float* __
   const int64_t stride = (int64_t)gridDim.x * (kTB / 64) * m.rpw;
   for (int64_t r = ((int64_t)blockIdx.x * (kTB / 64) + (threadIdx.x >> 6)) * m.rpw + m.r_in; r < B; r += stride) {
     float xv[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) xv[d] = x[r * D + d];
+    load_row<D>(xv, x + r * D);
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -153,6 +168,71 @@ __global__ __launch_bounds__(kTB) void tanh_inplace_kernel(float* __restrict__ z
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = fast_tanhf(v[j]);
     p[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------ F3/F4 ----
+// Zac [B, 2C] (pre-activations of actor.0 | critic.0, bias included) -> Hac = tanh(Zac) in place,
+// logits[r][a] = ba2[a] + sum_j Ha[r][j] Wa2[a][j], value[r] = bc2 + sum_j Hc[r][j] Wc2[j]: the
+// heads are evaluated on the tanh values while they are still in registers, so Hac is not read
+// again by two skinny GEMMs.  The dot products are reduced across the C/4 lanes of a row by an
+// xor butterfly (fixed order).
+template <int A>
+__global__ __launch_bounds__(kTB) void heads_fwd_tanh_kernel(float* __restrict__ Zac, int64_t B, int C,
+                                                             const float* __restrict__ Wa2, const float* __restrict__ ba2,
+                                                             const float* __restrict__ Wc2, const float* __restrict__ bc2,
+                                                             float* __restrict__ logits, float* __restrict__ value) {
+  const RowMap m(C, threadIdx.x & 63);
+  float wa[A][4], wc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    wc[j] = Wc2[4 * m.c4 + j];
+#pragma unroll
+    for (int a = 0; a < A; ++a) wa[a][j] = Wa2[(size_t)a * C + 4 * m.c4 + j];
+  }
+  float bias[A + 1];
+#pragma unroll
+  for (int a = 0; a < A; ++a) bias[a] = ba2 ? ba2[a] : 0.0f;
+  bias[A] = bc2 ? bc2[0] : 0.0f;
+  const int64_t stride = (int64_t)gridDim.x * (kTB / 64) * m.rpw;
+  const int64_t r0 = ((int64_t)blockIdx.x * (kTB / 64) + (threadIdx.x >> 6)) * m.rpw + m.r_in;
+  // every lane of a wave runs the same number of iterations (the butterfly needs all lanes)
+  const int64_t rbase = ((int64_t)blockIdx.x * (kTB / 64) + (threadIdx.x >> 6)) * m.rpw;
+  for (int64_t rb = rbase, r = r0; rb < B; rb += stride, r += stride) {
+    const bool live = r < B;
+    const size_t o = (size_t)(live ? r : 0) * 2 * C + 4 * m.c4;
+    f32x4 ha = {0.0f, 0.0f, 0.0f, 0.0f}, hc = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (live) {
+      ha = *reinterpret_cast<const f32x4*>(Zac + o);
+      hc = *reinterpret_cast<const f32x4*>(Zac + o + C);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ha[j] = fast_tanhf(ha[j]); hc[j] = fast_tanhf(hc[j]); }
+      *reinterpret_cast<f32x4*>(Zac + o) = ha;
+      *reinterpret_cast<f32x4*>(Zac + o + C) = hc;
+    }
+    float p[A + 1];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      float s = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s = fmaf(ha[j], wa[a][j], s);
+      p[a] = s;
+    }
+    {
+      float s = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s = fmaf(hc[j], wc[j], s);
+      p[A] = s;
+    }
+    for (int off = m.lpr >> 1; off > 0; off >>= 1) {
+#pragma unroll
+      for (int a = 0; a <= A; ++a) p[a] += __shfl_xor(p[a], off, 64);
+    }
+    if (live && m.c4 == 0) {
+#pragma unroll
+      for (int a = 0; a < A; ++a) logits[r * A + a] = p[a] + bias[a];
+      value[r] = p[A] + bias[A];
+    }
   }
 }
 
@@ -194,8 +274,7 @@ __global__ __launch_bounds__(kTB) void linear_smallk_bwd_kernel(const float* __r
     const f32x4 h = *reinterpret_cast<const f32x4*>(H + o);
     const f32x4 g = *reinterpret_cast<const f32x4*>(dH + o);
     float xv[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) xv[d] = x[r * D + d];
+    load_row<D>(xv, x + r * D);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float dz = g[j] * (1.0f - h[j] * h[j]);
@@ -322,7 +401,7 @@ size_t gymrl_mlp_train_workspace_bytes(int C, int D, int A) {
 
 int gymrl_linear_tanh_smallk(const float* x, const float* W, const float* b, int64_t B, int D, int C, float* out,
                              void* stream) {
-  if (!x || !W || !out || B < 0 || !pow2_cols(C) || !al16(out)) return -22;
+  if (!x || !W || !out || B < 0 || !pow2_cols(C) || !al16(out) || !al16(x)) return -22;
   if (B == 0) return 0;
   const dim3 grid(grid_for(B, C) * 1), block(kTB);
   hipStream_t s = (hipStream_t)stream;
@@ -363,7 +442,7 @@ int gymrl_tanh_bwd_colsum(float* dH, const float* H, int64_t B, int C, float* co
 
 int gymrl_linear_smallk_bwd(const float* dH, const float* H, const float* x, int64_t B, int D, int C, float* dW,
                             float* db, void* workspace, void* stream) {
-  if (!dH || !H || !x || !dW || !db || !workspace || B < 0 || !pow2_cols(C) || !al16(dH) || !al16(H)) return -22;
+  if (!dH || !H || !x || !dW || !db || !workspace || B < 0 || !pow2_cols(C) || !al16(dH) || !al16(H) || !al16(x)) return -22;
   hipStream_t s = (hipStream_t)stream;
   const int nb = grid_for(B, C);
   float* parts = (float*)workspace;
@@ -376,6 +455,19 @@ int gymrl_linear_smallk_bwd(const float* dH, const float* H, const float* x, int
     default: return -22;
   }
   hipLaunchKernelGGL(smallk_finalize_kernel, dim3(((D + 1) * C + kFinE - 1) / kFinE), dim3(kTB), 0, s, parts, nb, C, D, dW, db);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_heads_fwd_tanh(float* Zac, int64_t B, int C, int A, const float* Wa2, const float* ba2, const float* Wc2,
+                         const float* bc2, float* logits, float* value, void* stream) {
+  if (!Zac || !Wa2 || !Wc2 || !logits || !value || B < 0 || !pow2_cols(C) || !al16(Zac)) return -22;
+  if (B == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(grid_for(B, C)), block(kTB);
+  if (A == 4) hipLaunchKernelGGL(heads_fwd_tanh_kernel<4>, grid, block, 0, s, Zac, B, C, Wa2, ba2, Wc2, bc2, logits, value);
+  else if (A == 2) hipLaunchKernelGGL(heads_fwd_tanh_kernel<2>, grid, block, 0, s, Zac, B, C, Wa2, ba2, Wc2, bc2, logits, value);
+  else return -22;
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

@@ -68,6 +68,15 @@ def barrier():
         td.barrier()
 
 
+def shutdown():
+    """Collective teardown: every rank waits for the slowest one, then the process group is destroyed
+    (ranks that simply exit while another still runs local work make RCCL's watchdog noisy)."""
+    if is_dist():
+        if world_size() > 1:
+            td.barrier()
+        td.destroy_process_group()
+
+
 def shard_env_ids(num_envs_per_rank, rk=None):
     """Global env-id range owned by a rank (the Philox stream is keyed by env id, so
     an N-GPU run steps exactly the env instances a 1-GPU run with N*num_envs would)."""

@@ -550,6 +550,15 @@ def linear_smallk_bwd(dH, H, x, dW, db, workspace):
                                         _ptr(db, torch.float32), _ptr(workspace), _stream()), "gymrl_linear_smallk_bwd")
 
 
+def heads_fwd_tanh(Zac, Wa2, ba2, Wc2, bc2, logits, value):
+    """Zac [B, 2C] -> tanh in place + logits [B, A] + value [B] (include/gymrl.h gymrl_heads_fwd_tanh)."""
+    B, C2 = Zac.shape
+    check(lib().gymrl_heads_fwd_tanh(_ptr(Zac, torch.float32), C.c_int64(B), C.c_int(C2 // 2), C.c_int(Wa2.shape[0]),
+                                     _ptr(Wa2, torch.float32), _ptr(ba2, torch.float32, True), _ptr(Wc2, torch.float32),
+                                     _ptr(bc2, torch.float32, True), _ptr(logits, torch.float32),
+                                     _ptr(value, torch.float32), _stream()), "gymrl_heads_fwd_tanh")
+
+
 def heads_bwd(Hac, dlogits, dv, Wa2, Wc2, dZac, dbac, dWa2, dba2, dWc2, dbc2, workspace):
     """Backward of both heads in one pass over Hac = [Ha | Hc] (include/gymrl.h gymrl_heads_bwd)."""
     B, C2 = Hac.shape

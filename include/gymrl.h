@@ -337,6 +337,10 @@ int gymrl_mlp_forward(const float* x, int n_rows, int in_dim, const gymrl_mlp_de
  *   tanh_bwd_colsum    : dH <- dH * (1 - H^2) in place; colsum_out[c] = sum_r dH[r][c]
  *                        (Tanh backward + the bias gradient of the Linear below it)
  *   linear_smallk_bwd  : dZ = dH * (1 - H^2) (never stored); dW [C, D] = dZ^T x; db [C] = colsum dZ
+ *   heads_fwd_tanh     : Zac [B, 2C] = pre-activations of actor.0 | critic.0 (one N = 2C GEMM, bias
+ *                        included) -> Hac = tanh(Zac) in place AND logits [B, A] = Ha Wa2^T + ba2,
+ *                        value [B] = Hc Wc2^T + bc2 from the tanh values still in registers
+ *                        (actor.0/critic.0's Tanh + actor.2 + critic.2 forward in one pass)
  *   heads_bwd          : Hac [B, 2C] = [Ha | Hc], the Tanh outputs of actor.0 / critic.0;
  *                        dlogits [B, A] (A in {2,4}), dv [B] from gymrl_ppo_loss_fwd_bwd;
  *                        Wa2 [A, C] = actor.2.weight, Wc2 [1, C] = critic.2.weight.  Writes
@@ -355,6 +359,8 @@ int gymrl_tanh_bwd_colsum(float* dH, const float* H, int64_t B, int C, float* co
                           void* workspace, void* stream);
 int gymrl_linear_smallk_bwd(const float* dH, const float* H, const float* x, int64_t B, int D, int C,
                             float* dW, float* db, void* workspace, void* stream);
+int gymrl_heads_fwd_tanh(float* Zac, int64_t B, int C, int A, const float* Wa2, const float* ba2,
+                         const float* Wc2, const float* bc2, float* logits, float* value, void* stream);
 int gymrl_heads_bwd(const float* Hac, const float* dlogits, const float* dv, int64_t B, int C, int A,
                     const float* Wa2, const float* Wc2, float* dZac, float* dbac, float* dWa2,
                     float* dba2, float* dWc2, float* dbc2, void* workspace, void* stream);
