@@ -13,7 +13,7 @@ import subprocess
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgymrl_hip.so")
+LIB_PATH = os.environ.get("GYMRL_HIP_LIB") or os.path.join(_HERE, "libgymrl_hip.so")   # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
 
 _lib = None

@@ -41,6 +41,38 @@ __global__ void probe_valu(long long* out, int iters, float seed) {
   }
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+__global__ void probe_pk(long long* out, int iters, float seed) {
+  v2f x = {seed + threadIdx.x, seed * 0.25f}, y = {seed, seed * 0.5f}, one = {1.0f, 1.0f};
+  long long c0 = clock64(), w0 = wall_clock64();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { x = x * y; x = x + one; }      // v_pk_mul_f32 -> v_pk_add_f32, dependent
+  }
+  long long c1 = clock64(), w1 = wall_clock64();
+  if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; out[2] = (long long)(x[0] + x[1]); }
+}
+__global__ void probe_muladd(long long* out, int iters, float seed) {
+  float x = seed + threadIdx.x, y = seed;
+  long long c0 = clock64(), w0 = wall_clock64();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { x = x * y; x = x + 1.0f; }      // v_mul_f32 -> v_add_f32, dependent (contract off)
+  }
+  long long c1 = clock64(), w1 = wall_clock64();
+  if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; out[2] = (long long)x; }
+}
+__global__ void probe_muladd2(long long* out, int iters, float seed) {
+  float x = seed + threadIdx.x, y = seed, u = seed * 0.5f + threadIdx.x;
+  long long c0 = clock64(), w0 = wall_clock64();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { x = x * y; u = u * y; x = x + 1.0f; u = u + 1.0f; }   // two independent chains
+  }
+  long long c1 = clock64(), w1 = wall_clock64();
+  if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; out[2] = (long long)(x + u); }
+}
+
 int main() {
   long long* d;
   hipMalloc(&d, sizeof(long long) * 3 * 4096);
@@ -67,6 +99,17 @@ int main() {
     double clk = (double)h[0], wall = (double)h[1];
     printf("valu  grid %4d x 1 wave: shader clocks %.0f, wall %.0f -> %.3f GHz, %.2f clk/fma(dependent), %.2f us\n", grid, clk,
            wall, clk / wall * 0.1, clk / (256.0 * 64), wall / 100.0);
+  }
+  {
+    hipLaunchKernelGGL(probe_pk, dim3(1), dim3(64), 0, 0, d, 256, 1.0f); hipDeviceSynchronize();
+    hipMemcpy(h.data(), d, sizeof(long long) * 3, hipMemcpyDeviceToHost);
+    printf("pk_mul->pk_add dependent: %.2f clk per instruction\n", (double)h[0] / (256.0 * 64));
+    hipLaunchKernelGGL(probe_muladd, dim3(1), dim3(64), 0, 0, d, 256, 1.0f); hipDeviceSynchronize();
+    hipMemcpy(h.data(), d, sizeof(long long) * 3, hipMemcpyDeviceToHost);
+    printf("mul->add dependent (scalar): %.2f clk per instruction\n", (double)h[0] / (256.0 * 64));
+    hipLaunchKernelGGL(probe_muladd2, dim3(1), dim3(64), 0, 0, d, 256, 1.0f); hipDeviceSynchronize();
+    hipMemcpy(h.data(), d, sizeof(long long) * 3, hipMemcpyDeviceToHost);
+    printf("two independent mul->add chains: %.2f clk per instruction\n", (double)h[0] / (256.0 * 128));
   }
   return 0;
 }
