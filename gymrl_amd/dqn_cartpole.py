@@ -118,6 +118,8 @@ class DQNTrainer:
         self.episode_rewards = deque(maxlen=100)
         self._loss = torch.zeros(1, dtype=torch.float64, device=self.device)
         self._act_counter = 0
+        self._parity_u = None          # tests: iterator of f32[N, 2] uniforms for select_action (explore?, which action)
+        self._parity_indices = None    # tests: iterator of i32[B] replay indices for update()
 
     def get_epsilon(self):
         """:117-122 — advanced once per (vector) action selection."""
@@ -141,6 +143,8 @@ class DQNTrainer:
         """:135-168.  Returns the loss as a python float (one host sync, like loss.item())."""
         if len(self.memory) < self.cfg.batch_size:
             return 0.0
+        if indices is None and self._parity_indices is not None:
+            indices = next(self._parity_indices)
         states, actions, rewards, next_states, dones = self.memory.sample(self.cfg.batch_size, indices)
         q = self.policy_net(states)
         with torch.no_grad():
@@ -162,7 +166,7 @@ class DQNTrainer:
         step, last_target = 0, 0
         limit = max_vector_steps or (cfg.max_episodes * cfg.max_steps // N + 1)
         while tracker.episodes < cfg.max_episodes and step < limit:
-            action = self.select_action(obs)
+            action = self.select_action(obs, u=None if self._parity_u is None else next(self._parity_u))
             ep_ret, done = tracker.slot()
             env.step(action, nxt, rew, done_out=done, term_obs_out=tobs, ep_ret_out=ep_ret)
             self.memory.push(obs, action, rew, tobs, done)      # next_state = pre-reset observation (:183)

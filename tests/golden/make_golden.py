@@ -790,8 +790,75 @@ def gen_buffer_v2():
     save("buffer_v2", **res)
 
 
+def gen_dqn_trace():
+    """H1 for the off-policy loop (rows D3/D5): the reference DQNTrainer.train() run unmodified on the
+    scripted env — epsilon schedule advanced per non-deterministic action, python-random exploration,
+    push of the pre-reset next_state, update every step once the buffer holds a batch, hard target copy
+    every 4 episodes, episode bookkeeping.  Records every python-random draw the loop consumed."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from scripted_env import ScriptedEnv
+    dq = load_ref("algorithms/dqn_cartpole.py", "ref_dqn_trace")
+    env = ScriptedEnv(4, 2)
+    env.action_space.sample = lambda: random.randrange(2)
+    sys.modules["gymnasium"].make = lambda name, **kw: env
+    cfg = dq.Config()
+    cfg.device, cfg.hidden_dim, cfg.batch_size, cfg.memory_capacity = "cpu", 32, 16, 400
+    cfg.max_episodes, cfg.epsilon_decay, cfg.target_update_freq = 12, 60, 4
+    seed_all(123)
+    tr = dq.DQNTrainer(cfg)
+    with torch.no_grad():                       # wide Q gaps: an argmax cannot flip on 1e-6 differences
+        tr.policy_net.net[4].weight.mul_(60.0)
+    tr.target_net.load_state_dict(tr.policy_net.state_dict())
+    out = {"p0_" + k: v.numpy().copy() for k, v in tr.policy_net.state_dict().items()}
+
+    u0, explore_a, idx_log, actions, losses = [], [], [], [], []
+    orig_random, orig_sample, orig_randrange = random.random, random.sample, random.randrange
+
+    def rec_random():
+        v = orig_random()
+        u0.append(v)
+        explore_a.append(-1)
+        return v
+
+    def rec_randrange(n):
+        v = orig_randrange(n)
+        explore_a[-1] = v
+        return v
+
+    def rec_sample(population, k):
+        idx = orig_sample(range(len(population)), k)
+        idx_log.append(np.array(idx, np.int32))
+        return [population[i] for i in idx]
+    random.random, random.sample, random.randrange = rec_random, rec_sample, rec_randrange
+    orig_update, orig_select = tr.update, tr.select_action
+
+    def update():
+        v = orig_update()
+        losses.append(v)
+        return v
+
+    def select_action(state, deterministic=False):
+        a = orig_select(state, deterministic)
+        actions.append(a)
+        return a
+    tr.update, tr.select_action = update, select_action
+    try:
+        tr.train()
+    finally:
+        random.random, random.sample, random.randrange = orig_random, orig_sample, orig_randrange
+    out.update({"p1_" + k: v.numpy().copy() for k, v in tr.policy_net.state_dict().items()})
+    out.update({"t1_" + k: v.numpy().copy() for k, v in tr.target_net.state_dict().items()})
+    out.update(u0=np.array(u0, np.float64), explore_a=np.array(explore_a, np.int32), actions=np.array(actions, np.int32),
+               indices=np.stack(idx_log), losses=np.array(losses, np.float64),
+               episode_rewards=np.array(tr.episode_rewards, np.float64), sample_count=np.int64(tr.sample_count),
+               epsilon=np.float64(tr.epsilon),
+               cfg=np.array([cfg.hidden_dim, cfg.batch_size, cfg.memory_capacity, cfg.max_episodes, cfg.epsilon_decay,
+                             cfg.target_update_freq], np.int64))
+    save("dqn_trace", **out)
+
+
 if __name__ == "__main__":
     names = sys.argv[1:]
-    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2]:
+    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2, gen_dqn_trace]:
         if not names or g.__name__ in names:
             g()

@@ -206,3 +206,47 @@ def test_rainbow_update_matches_reference():
     tree = tr.memory.sum_tree.tree.cpu().numpy()
     assert np.max(np.abs(tree - g["tree_after"]) / np.maximum(1.0, np.abs(g["tree_after"]))) <= 2e-6
     assert abs(tr.optimizer.param_groups[0]["lr"] - float(g["lr_now"])) <= 1e-12
+
+
+def test_dqn_train_trace_matches_reference():
+    """H1 for the off-policy loop (D3/D5): the reference DQNTrainer.train() on the scripted env
+    (tests/golden/dqn_trace.npz) replayed by gymrl_amd's DQNTrainer.train() with the recorded python-random
+    draws: every action (explore / greedy), the epsilon schedule, update-every-step after warm-up, hard
+    target copy every 4 episodes, episode returns, the per-update losses and the final networks."""
+    from gymrl_amd.dqn_cartpole import Config, DQNTrainer
+    from scripted_env import ScriptedVecEnv
+    g = load_golden("dqn_trace")
+    hidden, batch, cap, episodes, decay, freq = (int(x) for x in g["cfg"])
+    cfg = Config()
+    cfg.hidden_dim, cfg.batch_size, cfg.memory_capacity, cfg.max_episodes = hidden, batch, cap, episodes
+    cfg.epsilon_decay, cfg.target_update_freq, cfg.num_envs = decay, freq, 1
+    tr = DQNTrainer(cfg)
+    dev = tr.device
+    _load(tr.policy_net, g, "p0_")
+    tr.load_target()
+    tr.env = ScriptedVecEnv(1, dev, obs_dim=4, n_actions=2)
+    A = 2
+    u = np.stack([g["u0"], (np.maximum(g["explore_a"], 0) + 0.5) / A], 1).astype(np.float32)
+    tr._parity_u = iter([torch.from_numpy(u[i:i + 1]).to(dev) for i in range(len(u))])
+    tr._parity_indices = iter([torch.from_numpy(ix).to(dev) for ix in g["indices"]])
+    actions, losses = [], []
+    orig_select, orig_update = tr.select_action, tr.update
+
+    def select_action(state, deterministic=False, u=None):
+        a = orig_select(state, deterministic, u)
+        actions.append(int(a[0]))
+        return a
+
+    def update(indices=None):
+        v = orig_update(indices)
+        losses.append(v)
+        return v
+    tr.select_action, tr.update = select_action, update
+    tr.train()
+    assert actions == g["actions"].tolist(), "action sequence (epsilon-greedy draws + greedy argmax)"
+    assert tr.sample_count == int(g["sample_count"]) and abs(tr.epsilon - float(g["epsilon"])) <= 1e-12
+    assert np.allclose(list(tr.episode_rewards), g["episode_rewards"], rtol=0, atol=1e-6)
+    assert len(losses) == len(g["losses"])
+    assert np.all(np.abs(np.asarray(losses) - g["losses"]) <= 2e-4 * np.maximum(1.0, np.abs(g["losses"])))
+    assert _maxdiff(tr.policy_net, g, "p1_") <= 2e-4
+    assert _maxdiff(tr.target_net, g, "t1_") <= 2e-4
