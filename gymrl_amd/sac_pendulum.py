@@ -155,6 +155,8 @@ class SACTrainer:
         self._alpha_loss = torch.zeros(1, **d64)
         self.memory = ReplayBuffer(config.memory_capacity, state_dim, action_dim, self.device, seed=self.base_seed)
         self.episode_rewards = deque(maxlen=100)
+        self._parity_eps = None        # tests: iterator of f32[N, A] N(0,1) draws for select_action
+        self._parity_updates = None    # tests: iterator of (indices i32[B], eps_next [B, A], eps_cur [B, A]) for update()
 
     @property
     def alpha(self):
@@ -175,6 +177,8 @@ class SACTrainer:
         cfg = self.cfg
         if len(self.memory) < cfg.batch_size:
             return 0.0, 0.0, 0.0
+        if indices is None and self._parity_updates is not None:
+            indices, eps_next, eps_cur = next(self._parity_updates)
         states, actions, rewards, next_states, dones = self.memory.sample(cfg.batch_size, indices)
         B = states.shape[0]
         self._sums.zero_()
@@ -214,7 +218,7 @@ class SACTrainer:
         step = 0
         limit = max_vector_steps or (cfg.max_episodes * cfg.max_steps // N + 1)
         while tracker.episodes < cfg.max_episodes and step < limit:
-            action = self.select_action(obs)
+            action = self.select_action(obs, eps=None if self._parity_eps is None else next(self._parity_eps))
             ep_ret, done = tracker.slot()
             env.step(action, nxt, rew, done_out=done, term_obs_out=tobs, ep_ret_out=ep_ret)
             self.memory.push(obs, action, rew, tobs, done)                     # done = terminated or truncated (:283)

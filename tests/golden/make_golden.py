@@ -857,8 +857,75 @@ def gen_dqn_trace():
     save("dqn_trace", **out)
 
 
+def gen_sac_trace():
+    """H1 for SAC (row A5): the reference SACTrainer.train() run unmodified on the continuous scripted env —
+    stochastic action per step, push, update every step once the buffer holds a batch (critic, actor,
+    alpha, soft update), done = terminated or truncated.  Records every N(0,1) draw rsample consumed and
+    every replay index."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from scripted_env import ScriptedEnv
+    sac = load_ref("algorithms/sac_pendulum.py", "ref_sac_trace")
+    sys.modules["gymnasium"].make = lambda name, **kw: ScriptedEnv(3, continuous=True)
+    cfg = sac.Config()
+    cfg.device, cfg.hidden_dim, cfg.batch_size, cfg.memory_capacity, cfg.max_episodes = "cpu", 32, 16, 400, 8
+    seed_all(321)
+    tr = sac.SACTrainer(cfg)
+    out = {}
+    for name, net in (("actor", tr.actor), ("critic", tr.critic)):
+        for k, v in net.state_dict().items():
+            out[f"p0_{name}_{k}"] = v.numpy().copy()
+    act_eps, upd_eps, idx_log, actions, losses = [], [], [], [], []
+
+    def draws(fn, shape_of):
+        def wrapped(state, *a, **kw):
+            before = torch.get_rng_state()
+            res = fn(state, *a, **kw)
+            after = torch.get_rng_state()
+            torch.set_rng_state(before)
+            e = torch.randn(state.shape[0], 1)
+            torch.set_rng_state(after)
+            shape_of.append(e.numpy().copy())
+            return res
+        return wrapped
+    tr.actor.get_action = draws(tr.actor.get_action, act_eps)
+    tr.actor.sample = draws(tr.actor.sample, upd_eps)
+    orig_sample = random.sample
+
+    def rec_sample(population, k):
+        idx = orig_sample(range(len(population)), k)
+        idx_log.append(np.array(idx, np.int32))
+        return [population[i] for i in idx]
+    random.sample = rec_sample
+    orig_update, orig_select = tr.update, tr.select_action
+
+    def update():
+        v = orig_update()
+        losses.append(v)
+        return v
+
+    def select_action(state, deterministic=False):
+        a = orig_select(state, deterministic)
+        actions.append(np.array(a, np.float32))
+        return a
+    tr.update, tr.select_action = update, select_action
+    try:
+        tr.train()
+    finally:
+        random.sample = orig_sample
+    for name, net in (("actor", tr.actor), ("critic", tr.critic), ("critic_target", tr.critic_target)):
+        for k, v in net.state_dict().items():
+            out[f"p1_{name}_{k}"] = v.numpy().copy()
+    n_upd = len(idx_log)
+    assert len(upd_eps) == 2 * n_upd
+    out.update(act_eps=np.stack(act_eps), eps_next=np.stack(upd_eps[0::2]), eps_cur=np.stack(upd_eps[1::2]),
+               indices=np.stack(idx_log), actions=np.stack(actions), losses=np.array(losses, np.float64),
+               episode_rewards=np.array(tr.episode_rewards, np.float64), log_alpha=np.float64(tr.log_alpha.item()),
+               cfg=np.array([cfg.hidden_dim, cfg.batch_size, cfg.memory_capacity, cfg.max_episodes], np.int64))
+    save("sac_trace", **out)
+
+
 if __name__ == "__main__":
     names = sys.argv[1:]
-    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2, gen_dqn_trace]:
+    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2, gen_dqn_trace, gen_sac_trace]:
         if not names or g.__name__ in names:
             g()

@@ -18,7 +18,7 @@ class ScriptedEnv:
     """gymnasium-style single env: reset(seed) -> (obs, info); step(a) -> 5-tuple."""
 
     def __init__(self, obs_dim=8, n_actions=4, continuous=False):
-        self.obs_dim, self.n_actions = obs_dim, n_actions
+        self.obs_dim, self.n_actions, self.continuous = obs_dim, n_actions, continuous
         self.observation_space = types.SimpleNamespace(shape=(obs_dim,))
         if continuous:
             self.action_space = types.SimpleNamespace(shape=(1,), high=np.array([2.0], np.float32))
@@ -41,7 +41,10 @@ class ScriptedEnv:
         return self._obs(), {}
 
     def step(self, action):
-        a = int(action)
+        if self.continuous:      # quantise a bounded real action to 0..8 (boundaries every 0.5)
+            a = int(min(8, max(0, np.floor((float(np.asarray(action).reshape(-1)[0]) + 2.0) * 2.0))))
+        else:
+            a = int(action)
         self.t += 1
         self.last_a = a
         reward = float(((self.episode * 7 + self.t * 3 + a * 11) % 23) - 11) / 4.0
@@ -58,11 +61,11 @@ class ScriptedVecEnv:
     """The same script behind gymrl_amd.envs.VecEnv's device interface (N independent copies;
     copy i starts `i` resets ahead so lanes differ).  Host-computed: a test fixture, not a product path."""
 
-    def __init__(self, num_envs, device, obs_dim=8, n_actions=4, episode0=None):
+    def __init__(self, num_envs, device, obs_dim=8, n_actions=4, episode0=None, continuous=False):
         import torch
         self.torch = torch
         self.n, self.device = num_envs, device
-        self.envs = [ScriptedEnv(obs_dim, n_actions) for _ in range(num_envs)]
+        self.envs = [ScriptedEnv(obs_dim, n_actions, continuous) for _ in range(num_envs)]
         for i, e in enumerate(self.envs):
             # training: lanes far apart; evaluation (episode0 given): copy i plays episode episode0 + i,
             # the i-th of the reference's sequential evaluation episodes

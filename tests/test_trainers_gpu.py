@@ -250,3 +250,47 @@ def test_dqn_train_trace_matches_reference():
     assert np.all(np.abs(np.asarray(losses) - g["losses"]) <= 2e-4 * np.maximum(1.0, np.abs(g["losses"])))
     assert _maxdiff(tr.policy_net, g, "p1_") <= 2e-4
     assert _maxdiff(tr.target_net, g, "t1_") <= 2e-4
+
+
+def test_sac_train_trace_matches_reference():
+    """H1 for SAC (A5): the reference SACTrainer.train() on the continuous scripted env
+    (tests/golden/sac_trace.npz) replayed by gymrl_amd's SACTrainer.train() with the recorded N(0,1) draws
+    and replay indices: actions, losses per update, episode returns, final actor / critics / target, alpha."""
+    from gymrl_amd.sac_pendulum import Config, SACTrainer
+    from scripted_env import ScriptedVecEnv
+    g = load_golden("sac_trace")
+    hidden, batch, cap, episodes = (int(x) for x in g["cfg"])
+    cfg = Config()
+    cfg.hidden_dim, cfg.batch_size, cfg.memory_capacity, cfg.max_episodes, cfg.num_envs = hidden, batch, cap, episodes, 1
+    tr = SACTrainer(cfg)
+    dev = tr.device
+    for name, net in (("actor", tr.actor), ("critic", tr.critic)):
+        pre = f"p0_{name}_"
+        net.load_state_dict({k[len(pre):]: torch.from_numpy(np.array(g[k])) for k in g.files if k.startswith(pre)})
+    tr.critic_target_flat.copy_(tr.critic_flat)                       # deepcopy(critic) (:169)
+    tr.env = ScriptedVecEnv(1, dev, obs_dim=3, continuous=True)
+    td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    tr._parity_eps = iter([td(e) for e in g["act_eps"]])
+    tr._parity_updates = iter([(td(i), td(a), td(b)) for i, a, b in zip(g["indices"], g["eps_next"], g["eps_cur"])])
+    actions, losses = [], []
+    orig_select, orig_update = tr.select_action, tr.update
+
+    def select_action(state, deterministic=False, eps=None):
+        a = orig_select(state, deterministic, eps)
+        actions.append(a[0].cpu().numpy().copy())
+        return a
+
+    def update(*a, **kw):
+        v = orig_update(*a, **kw)
+        losses.append(v)
+        return v
+    tr.select_action, tr.update = select_action, update
+    tr.train()
+    assert len(actions) == len(g["actions"]) and np.allclose(np.stack(actions), g["actions"], rtol=0, atol=5e-4)
+    assert np.allclose(list(tr.episode_rewards), g["episode_rewards"], rtol=0, atol=1e-6)
+    got = np.asarray(losses, np.float64)
+    assert got.shape == g["losses"].shape
+    assert np.all(np.abs(got - g["losses"]) <= 1e-3 * np.maximum(1.0, np.abs(g["losses"])))
+    for name, net in (("actor", tr.actor), ("critic", tr.critic), ("critic_target", tr.critic_target)):
+        assert _maxdiff(net, g, f"p1_{name}_") <= 5e-4, name
+    assert abs(float(tr.log_alpha.item()) - float(g["log_alpha"])) <= 1e-5
