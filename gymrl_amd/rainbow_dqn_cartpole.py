@@ -213,6 +213,7 @@ class RainbowDQNTrainer:
         self.total_steps = 0
         self.episode_rewards = deque(maxlen=100)
         self._loss = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self._parity_u = None          # tests: iterator of f64[B] PER uniforms for update()
 
     @torch.no_grad()
     def select_action(self, state, deterministic=False):
@@ -231,6 +232,8 @@ class RainbowDQNTrainer:
         cfg = self.cfg
         if len(self.memory) < cfg.batch_size:
             return 0.0
+        if u is None and self._parity_u is not None:
+            u = next(self._parity_u)
         batch, batch_index, is_weight = self.memory.sample(self.total_steps, self.max_train_steps, u=u)
         with torch.no_grad():
             q_next_online = self.policy_net(batch["next_state"])          # fresh noise (:320)
@@ -256,7 +259,8 @@ class RainbowDQNTrainer:
         obs, nxt, tobs = (torch.empty(N, D, device=self.device) for _ in range(3))
         rew = torch.empty(N, device=self.device)
         term = torch.zeros(N, dtype=torch.uint8, device=self.device)
-        trunc = torch.zeros(N, dtype=torch.uint8, device=self.device)
+        ep_len = torch.zeros(N, dtype=torch.int32, device=self.device)
+        term_b = torch.zeros(N, dtype=torch.bool, device=self.device)
         tracker = EpisodeTracker(N, self.device, flush_every=1 if N == 1 else 16)
         env.reset(obs)
         step = 0
@@ -264,9 +268,12 @@ class RainbowDQNTrainer:
         while tracker.episodes < cfg.max_episodes and step < limit:
             action = self.select_action(obs)
             ep_ret, done = tracker.slot()
-            env.step(action, nxt, rew, done_out=done, term_obs_out=tobs, ep_ret_out=ep_ret, terminated_out=term,
-                     truncated_out=trunc)
-            # terminal = done and not the time-limit step (:376): exactly gymnasium's `terminated`
+            env.step(action, nxt, rew, done_out=done, term_obs_out=tobs, ep_ret_out=ep_ret, ep_len_out=ep_len)
+            # :376 terminal = done and step != max_steps_per_episode - 1: decided by the step INDEX inside the
+            # episode, not by gymnasium's terminated flag (a pole that falls exactly on the last step of the
+            # time limit is stored as non-terminal, an early truncation as terminal)
+            torch.logical_and(done.bool(), ep_len != self.max_steps_per_episode, out=term_b)
+            term.copy_(term_b)
             self.memory.store_transition(obs, action, rew, tobs, term, done)
             for _ in range(cfg.updates_per_step):
                 self.update()

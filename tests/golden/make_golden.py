@@ -924,8 +924,77 @@ def gen_sac_trace():
     save("sac_trace", **out)
 
 
+def gen_rainbow_trace():
+    """H1 for Rainbow (row R5): the reference RainbowDQNTrainer.train() run unmodified on the scripted env with
+    a 14-step time limit — greedy action on the noisy Q (fresh noise per forward), total_steps, `terminal =
+    done and step != max_steps_per_episode - 1` (:376), n-step PER store, update every step once the buffer
+    holds a batch (ring of 64 wraps twice).  Records every raw NoisyNet draw and every PER uniform."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from scripted_env import ScriptedEnv
+    rb = load_ref("algorithms/rainbow_dqn_cartpole.py", "ref_rainbow_trace")
+    env = ScriptedEnv(4, 2)
+    env.spec.max_episode_steps = 14
+    sys.modules["gymnasium"].make = lambda name, **kw: env
+    cfg = rb.Config()
+    cfg.device, cfg.hidden_dim, cfg.batch_size, cfg.memory_capacity, cfg.max_episodes = "cpu", 32, 16, 64, 10
+    seed_all(777)
+    tr = rb.RainbowDQNTrainer(cfg)
+    out = {"p0_" + k: v.numpy().copy() for k, v in tr.policy_net.state_dict().items()}
+    raw = {"advantage": ([], []), "value": ([], [])}
+    which = {"layer": None, "k": 0}
+    orig_reset = rb.NoisyLinear.reset_noise
+
+    def reset_noise(self):
+        which["layer"] = "advantage" if self is tr.policy_net.advantage else ("value" if self is tr.policy_net.value else None)
+        which["k"] = 0
+        orig_reset(self)
+    rb.NoisyLinear.reset_noise = reset_noise
+
+    def scale_noise(size):
+        x = torch.randn(size)
+        if which["layer"] is not None:
+            raw[which["layer"]][which["k"]].append(x.numpy().copy())
+            which["k"] += 1
+        return x.sign().mul(x.abs().sqrt())
+    rb.NoisyLinear.scale_noise = staticmethod(scale_noise)
+    actions, losses, us, terminals = [], [], [], []
+    orig_update, orig_select, orig_store = tr.update, tr.select_action, tr.memory.store_transition
+
+    def update():
+        st = np.random.get_state()
+        v = orig_update()
+        if len(tr.memory) >= cfg.batch_size:
+            st2 = np.random.get_state()
+            np.random.set_state(st)
+            us.append(np.random.random_sample(cfg.batch_size))
+            np.random.set_state(st2)
+        losses.append(v)
+        return v
+
+    def select_action(state, deterministic=False):
+        a = orig_select(state, deterministic)
+        actions.append(a)
+        return a
+
+    def store_transition(s_, a_, r_, s2_, terminal, done):
+        terminals.append(bool(terminal))
+        return orig_store(s_, a_, r_, s2_, terminal, done)
+    tr.update, tr.select_action, tr.memory.store_transition = update, select_action, store_transition
+    tr.train()
+    out.update({"p1_" + k: v.numpy().copy() for k, v in tr.policy_net.state_dict().items()})
+    out.update({"t1_" + k: v.numpy().copy() for k, v in tr.target_net.state_dict().items()})
+    out.update(adv_in=np.stack(raw["advantage"][0]), adv_out=np.stack(raw["advantage"][1]),
+               val_in=np.stack(raw["value"][0]), val_out=np.stack(raw["value"][1]), u=np.stack(us),
+               actions=np.array(actions, np.int32), losses=np.array(losses, np.float64),
+               terminals=np.array(terminals, np.uint8), episode_rewards=np.array(tr.episode_rewards, np.float64),
+               total_steps=np.int64(tr.total_steps), tree=tr.memory.sum_tree.tree.copy(),
+               lr_now=np.float64(tr.optimizer.param_groups[0]["lr"]),
+               cfg=np.array([cfg.hidden_dim, cfg.batch_size, cfg.memory_capacity, cfg.max_episodes, 14], np.int64))
+    save("rainbow_trace", **out)
+
+
 if __name__ == "__main__":
     names = sys.argv[1:]
-    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2, gen_dqn_trace, gen_sac_trace]:
+    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2, gen_dqn_trace, gen_sac_trace, gen_rainbow_trace]:
         if not names or g.__name__ in names:
             g()

@@ -71,14 +71,17 @@ class ScriptedVecEnv:
             # the i-th of the reference's sequential evaluation episodes
             e.episode += i * 1000 if episode0 is None else episode0 + i
         self.obs_dim, self.act_dim, self.discrete, self.max_steps = obs_dim, n_actions, True, 500
+        self.spec = types.SimpleNamespace(max_episode_steps=500)
         self.seed, self.env_id0 = 0, 0
         self.ep_ret = [0.0] * num_envs
+        self.ep_len = [0] * num_envs
 
     def reset(self, obs_out=None, seed=None):
         if seed is not None:
             self.seed = int(seed)
         obs = np.stack([e.reset(seed=seed)[0] for e in self.envs])
         self.ep_ret = [0.0] * self.n
+        self.ep_len = [0] * self.n
         t = self.torch.from_numpy(obs).to(self.device)
         if obs_out is None:
             return t
@@ -94,21 +97,23 @@ class ScriptedVecEnv:
         term = np.zeros(self.n, np.uint8)
         trunc = np.zeros(self.n, np.uint8)
         epr = np.zeros(self.n, np.float32)
+        epl = np.zeros(self.n, np.int32)
         for i, e in enumerate(self.envs):
             o, r, te, tr, _ = e.step(acts[i])
             self.ep_ret[i] += r
+            self.ep_len[i] += 1
             tobs[i] = o
             rew[i], term[i], trunc[i] = r, te, tr
-            epr[i] = self.ep_ret[i]
+            epr[i], epl[i] = self.ep_ret[i], self.ep_len[i]
             if te or tr:
                 o, _ = e.reset()
-                self.ep_ret[i] = 0.0
+                self.ep_ret[i], self.ep_len[i] = 0.0, 0
             obs[i] = o
         T = self.torch
         obs_out.copy_(T.from_numpy(obs).to(self.device))
         rew_out.copy_(T.from_numpy(rew).to(self.device))
         for dst, src in ((done_out, term | trunc), (ep_ret_out, epr), (term_obs_out, tobs),
-                         (terminated_out, term), (truncated_out, trunc)):
+                         (terminated_out, term), (truncated_out, trunc), (ep_len_out, epl)):
             if dst is not None:
                 dst.copy_(T.from_numpy(src).to(self.device))
 
