@@ -36,7 +36,7 @@ SYMBOLS = [
     "gymrl_sac_actor_loss", "gymrl_sac_alpha_step", "gymrl_running_norm", "gymrl_reward_scaling",
     "gymrl_mlp_packed_floats", "gymrl_mlp_pack", "gymrl_mlp_forward",
     "gymrl_mlp_train_workspace_bytes", "gymrl_linear_tanh_smallk", "gymrl_tanh_inplace", "gymrl_tanh_bwd_colsum",
-    "gymrl_linear_smallk_bwd", "gymrl_heads_fwd_tanh", "gymrl_heads_bwd",
+    "gymrl_linear_smallk_bwd", "gymrl_heads_fwd_tanh", "gymrl_heads_bwd", "gymrl_rollout_lunar",
 ]
 
 
@@ -70,6 +70,15 @@ class MlpStage(C.Structure):
 
 class MlpDesc(C.Structure):
     _fields_ = [("n_stages", C.c_int), ("stage", MlpStage * MLP_MAX_STAGES)]
+
+
+class RolloutLunarArgs(C.Structure):
+    _fields_ = [("env_state", C.c_void_p), ("n_envs", C.c_int), ("seed", C.c_uint64), ("env_id0", C.c_int64),
+                ("counter0", C.c_uint64), ("obs", C.c_void_p), ("act", C.c_void_p), ("logp", C.c_void_p),
+                ("val", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p), ("ep_ret", C.c_void_p),
+                ("next_value", C.c_void_p), ("noise_exp", C.c_void_p), ("gae_running", C.c_void_p),
+                ("gae_workspace", C.c_void_p), ("gamma", C.c_double), ("lam", C.c_double), ("ep_stats", C.c_void_p),
+                ("wg_ticks", C.c_void_p), ("T", C.c_int), ("t0", C.c_int), ("nsteps", C.c_int)]
 
 
 class PPOFullCfg(C.Structure):

@@ -1,0 +1,1140 @@
+// env_lunar_device.hpp — device side of env_lunar.hip (shared with the persistent rollout kernel).
+// env_lunar.hip — LunarLander-v3 (discrete, no wind) batched stepper for gfx950.
+//
+// Replaces env.reset()/env.step() of gym.make("LunarLander-v3") as called from
+// ppo_lunarlander.py:200,211,222 and ppo_full_lunarlander.py:466,474,496.  The
+// arithmetic behind that call is gymnasium's lunar_lander.py on top of Box2D 2.3
+// (both third-party, absent from the reference tree, unpinned: SURVEY.md §8c.2),
+// so this file is a purpose-built rigid-body solver that follows their published
+// structure: 3 dynamic bodies (hull + 2 legs), 2 revolute joints with motor +
+// limits, polygon-vs-terrain-edge manifolds (SAT + clipping, 0.98/0.001
+// hysteresis), sequential impulses with warm starting and the 2-point block
+// solver, 180 velocity / <= 60 position iterations per 1/50 s step, Box2D's
+// sleep rule (the +100 "landed" terminal), gymnasium's reward shaping.
+//
+// Mapping: FOUR lanes per env (a DPP quad), 16 envs per wavefront, one wavefront per
+// workgroup (N/16 workgroups: 256 at N = 4096, one per CU).  Every lane of a quad carries
+// the three bodies and both joints in VGPRs and replays the joint solve redundantly; the
+// contact work is split by role: lane 0 owns the hull's terrain contacts, lanes 1/2 the
+// legs' (lane 3 mirrors lane 0 and never stores).  The three bodies' contact solves only
+// touch their own body (the terrain is static), so inside a solver sweep they run side by
+// side in one instruction stream and the quad re-synchronises with nine quad-broadcasts
+// (v_mov_dpp quad_perm) — a sweep is ~700 instructions instead of ~1290 for a lane that
+// walks all three bodies.  Per-lane manifolds and solver scratch live in LDS columns
+// ([word][lane]); the 180 velocity sweeps run out of VGPRs only.
+// Bound: ALU latency (180 dependent sweeps at one wave per SIMD), not HBM: the 576 B of
+// SoA state per env is read and written once per step.
+//
+// Determinism: IEEE f32 +,-,*,/,sqrt and explicit fmaf only (-ffp-contract=off),
+// det_sincosf for rotations, Philox for every random draw — the CPU oracle's
+// independent restatement reproduces every bit.
+#pragma once
+#include "env_common.hpp"
+
+namespace gymrl {
+namespace lunar {
+
+
+// ------------------------------------------------------------------ constants
+constexpr float kScale = 30.0f;
+constexpr float kW = 600.0f / kScale;            // 20
+constexpr float kH = 400.0f / kScale;            // 13.333
+constexpr float kHelipadY = kH / 4.0f;
+constexpr float kLegDown = 18.0f / kScale;
+constexpr float kLegAway = 20.0f / kScale;
+constexpr float kDt = 1.0f / 50.0f;
+constexpr int kVelIters = 180, kPosIters = 60, kMaxSteps = 1000;
+constexpr float kLinearSlop = 0.005f, kAngularSlop = 2.0f / 180.0f * 3.14159265359f;
+constexpr float kPolyRadius = 2.0f * kLinearSlop;           // b2_polygonRadius
+constexpr float kMaxLinCorr = 0.2f, kMaxAngCorr = 8.0f / 180.0f * 3.14159265359f;
+constexpr float kBaumgarte = 0.2f;
+constexpr float kMaxTranslation = 2.0f, kMaxRotation = 0.5f * 3.14159265359f;
+constexpr float kTimeToSleep = 0.5f, kLinSleepTol = 0.01f, kAngSleepTol = 2.0f / 180.0f * 3.14159265359f;
+constexpr float kMotorTorque = 40.0f;
+
+// body indices: 0 = hull, 1 = legs[0] (i = -1, right), 2 = legs[1] (i = +1, left)
+// mass data from Box2D's polygon ComputeMass (density 5 hull / 1 legs), precomputed in double
+__device__ constexpr float kInvM[3] = {0.20761245674740486f, 14.0625f, 14.0625f};
+__device__ constexpr float kInvI[3] = {1.2757043935679302f, 558.3639705882352f, 558.3639705882352f};
+constexpr float kHullLcY = 0.10130718954248369f;            // hull local centre of mass (x = 0)
+// hull polygon, CCW hull order Box2D's Set() produces, and its outward normals
+__device__ constexpr float kHullVx[6] = {17.f / 30, 17.f / 30, 14.f / 30, -14.f / 30, -17.f / 30, -17.f / 30};
+__device__ constexpr float kHullVy[6] = {-10.f / 30, 0.f, 17.f / 30, 17.f / 30, 0.f, -10.f / 30};
+__device__ constexpr float kHullNx[6] = {1.0f, 0.9847835588179369f, 0.0f, -0.9847835588179369f, -1.0f, 0.0f};
+__device__ constexpr float kHullNy[6] = {0.0f, 0.17378533390904766f, 1.0f, 0.17378533390904766f, 0.0f, -1.0f};
+__device__ constexpr float kLegVx[4] = {-2.f / 30, 2.f / 30, 2.f / 30, -2.f / 30};
+__device__ constexpr float kLegVy[4] = {-8.f / 30, -8.f / 30, 8.f / 30, 8.f / 30};
+__device__ constexpr float kLegNx[4] = {0.0f, 1.0f, 0.0f, -1.0f};
+__device__ constexpr float kLegNy[4] = {-1.0f, 0.0f, 1.0f, 0.0f};
+
+struct Body { float cx, cy, a, vx, vy, w; };   // centre of mass, angle, velocities
+
+struct Joint {              // revolute joint hull(A) -> leg(B)
+  float ix, iy, iz, im;     // accumulated impulse (x, y, limit), motor impulse
+  int state;                // 0 inactive, 1 at lower, 2 at upper
+};
+
+struct ContactPt { float lpx, lpy; uint32_t key; float ni, ti; };   // local point, feature key, impulses
+struct Manifold {
+  int count;                // 0, 1, 2
+  int faceB;                // 0: reference face on the terrain edge (A), 1: on the polygon (B)
+  float lnx, lny, lpx, lpy; // local normal / plane point (A frame == world for the static terrain)
+  ContactPt p[2];
+};
+
+// Manifolds (warm-start impulses included) and the solver's per-contact scratch live in
+// LDS during a step, one dword column per lane ([word][64 lanes]: bank = lane, conflict
+// free); contacts are rare, so this keeps the always-hot state (bodies, joints) in VGPRs.
+constexpr int kMfWords = 16;   // count, faceB, lnx, lny, lpx, lpy, 2 x {lpx, lpy, key, ni, ti}
+constexpr int kVcWords = 17;   // count, nx, ny, rx0, ry0, rx1, ry1, nm0, nm1, tm0, tm1, K(3), K^-1(3)
+constexpr int kLdsWords = 2 * kMfWords + 2 * kVcWords;   // per lane: its own body's two slots
+constexpr int kQuad = 4;                                  // lanes per env
+constexpr int kEnvsPerBlock = kEnvBlock / kQuad;          // 16
+
+struct Lds {
+  uint32_t* w;   // base + lane
+  __device__ __forceinline__ float& mf(int s, int f) const { return reinterpret_cast<float*>(w)[(s * kMfWords + f) * kEnvBlock]; }
+  __device__ __forceinline__ uint32_t& mu(int s, int f) const { return w[(s * kMfWords + f) * kEnvBlock]; }
+  __device__ __forceinline__ float& vc(int s, int f) const { return reinterpret_cast<float*>(w)[(2 * kMfWords + s * kVcWords + f) * kEnvBlock]; }
+  __device__ __forceinline__ uint32_t& vu(int s, int f) const { return w[(2 * kMfWords + s * kVcWords + f) * kEnvBlock]; }
+};
+
+// quad broadcast: every lane of a quad reads lane R's value (v_mov_b32 dpp quad_perm:[R,R,R,R])
+template <int R>
+__device__ __forceinline__ float quad_bcast(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), R * 0x55, 0xF, 0xF, false));
+}
+template <int R>
+__device__ __forceinline__ uint32_t quad_bcast_u(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, R * 0x55, 0xF, 0xF, false);
+}
+enum { MF_COUNT = 0, MF_FACEB = 1, MF_LNX = 2, MF_LNY = 3, MF_LPX = 4, MF_LPY = 5, MF_P0 = 6, MF_P1 = 11,
+       P_LPX = 0, P_LPY = 1, P_KEY = 2, P_NI = 3, P_TI = 4 };
+enum { VC_COUNT = 0, VC_NX = 1, VC_NY = 2, VC_RX0 = 3, VC_RY0 = 4, VC_RX1 = 5, VC_RY1 = 6, VC_NM0 = 7, VC_NM1 = 8,
+       VC_TM0 = 9, VC_TM1 = 10, VC_K11 = 11, VC_K12 = 12, VC_K22 = 13, VC_I11 = 14, VC_I12 = 15, VC_I22 = 16 };
+
+struct World {
+  Body b[3];
+  float sleep[3];
+  Joint j[2];
+  int edge0;                // terrain edge index of slot 0 of THIS lane's body (slot 1 = edge0 + 1)
+  uint32_t touching;        // bit (10*body + edge): pair was touching after the last Collide
+  float ty[11];             // smoothed terrain heights at x = 0, 2, ..., 20
+  uint32_t flags;           // bit0 leg0 ground contact, bit1 leg1, bit2 game_over, bit3 has prev_shaping, bit4 asleep
+  float prev_shaping;
+};
+
+__device__ __forceinline__ float cross2(float ax, float ay, float bx, float by) { return ax * by - ay * bx; }
+__device__ __forceinline__ float dot2(float ax, float ay, float bx, float by) { return ax * bx + ay * by; }
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fmaxf(lo, fminf(x, hi)); }
+
+// joint geometry per leg L (0: i=-1, 1: i=+1)
+__device__ __forceinline__ float leg_sign(int L) { return L == 0 ? -1.0f : 1.0f; }
+__device__ __forceinline__ float joint_lower(int L) { return L == 0 ? 0.4f : -0.9f; }
+__device__ __forceinline__ float joint_upper(int L) { return L == 0 ? 0.9f : -0.4f; }
+
+// ------------------------------------------------------------------ collision
+// b2CollideEdgeAndPolygon for an edge without adjacent vertices, edge body static at
+// the identity transform.  NV/V*/N* describe the polygon in its body frame; (px,py,qs,qc)
+// is the polygon body's transform; (ccx, ccy) its centroid in world coordinates.
+template <int NV>
+__device__ __forceinline__ void collide_edge_polygon(Manifold& mf, const float* __restrict__ VX,
+                                                     const float* __restrict__ VY,
+                                                     const float* __restrict__ NX,
+                                                     const float* __restrict__ NY, float px, float py,
+                                                     float qs, float qc, float ccx, float ccy,
+                                                     float v1x, float v1y, float v2x, float v2y) {
+  mf.count = 0;
+  float wx[NV], wy[NV], wnx[NV], wny[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    wx[i] = (qc * VX[i] - qs * VY[i]) + px;
+    wy[i] = (qs * VX[i] + qc * VY[i]) + py;
+    wnx[i] = qc * NX[i] - qs * NY[i];
+    wny[i] = qs * NX[i] + qc * NY[i];
+  }
+  float ex = v2x - v1x, ey = v2y - v1y;
+  const float el = sqrtf(ex * ex + ey * ey);
+  const float inv = 1.0f / el;
+  ex *= inv; ey *= inv;
+  const float n1x = ey, n1y = -ex;
+  const float offset1 = dot2(n1x, n1y, ccx - v1x, ccy - v1y);
+  const bool front = offset1 >= 0.0f;
+  const float Nx = front ? n1x : -n1x, Ny = front ? n1y : -n1y;
+  const float radius = 2.0f * kPolyRadius;
+
+  // edge axis
+  float esep = 3.4e38f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float s = dot2(Nx, Ny, wx[i] - v1x, wy[i] - v1y);
+    if (s < esep) esep = s;
+  }
+  if (esep > radius) return;
+  // polygon axes
+  float psep = -3.4e38f;
+  int pidx = -1;
+  bool separated = false;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float nx = -wnx[i], ny = -wny[i];
+    const float s1 = dot2(nx, ny, wx[i] - v1x, wy[i] - v1y);
+    const float s2 = dot2(nx, ny, wx[i] - v2x, wy[i] - v2y);
+    const float s = fminf(s1, s2);
+    if (!separated) {
+      if (s > radius) { separated = true; }
+      else if (s > psep) { psep = s; pidx = i; }
+    }
+  }
+  if (separated) return;
+  const bool use_edge = (pidx < 0) || !(psep > 0.98f * esep + 0.001f);
+
+  // incident edge (ie0, ie1) and reference face
+  float i0x, i0y, i1x, i1y;
+  uint32_t id0, id1;
+  float rv1x, rv1y, rv2x, rv2y, rnx, rny;
+  int ri1, ri2;
+  if (use_edge) {
+    int best = 0;
+    float bestv = dot2(Nx, Ny, wnx[0], wny[0]);
+#pragma unroll
+    for (int i = 1; i < NV; ++i) {
+      const float v = dot2(Nx, Ny, wnx[i], wny[i]);
+      if (v < bestv) { bestv = v; best = i; }
+    }
+    const int b2 = best + 1 < NV ? best + 1 : 0;
+    i0x = wx[0]; i0y = wy[0]; i1x = wx[0]; i1y = wy[0];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (i == best) { i0x = wx[i]; i0y = wy[i]; }
+      if (i == b2) { i1x = wx[i]; i1y = wy[i]; }
+    }
+    // id bytes: indexA | indexB<<8 | typeA<<16 | typeB<<24   (type: 0 vertex, 1 face)
+    id0 = 0u | ((uint32_t)best << 8) | (1u << 16) | (0u << 24);
+    id1 = 0u | ((uint32_t)b2 << 8) | (1u << 16) | (0u << 24);
+    if (front) { ri1 = 0; ri2 = 1; rv1x = v1x; rv1y = v1y; rv2x = v2x; rv2y = v2y; rnx = n1x; rny = n1y; }
+    else { ri1 = 1; ri2 = 0; rv1x = v2x; rv1y = v2y; rv2x = v1x; rv2y = v1y; rnx = -n1x; rny = -n1y; }
+  } else {
+    i0x = v1x; i0y = v1y; i1x = v2x; i1y = v2y;
+    id0 = 0u | ((uint32_t)pidx << 8) | (0u << 16) | (1u << 24);
+    id1 = 0u | ((uint32_t)pidx << 8) | (0u << 16) | (1u << 24);
+    ri1 = pidx; ri2 = pidx + 1 < NV ? pidx + 1 : 0;
+    rv1x = wx[0]; rv1y = wy[0]; rv2x = wx[0]; rv2y = wy[0]; rnx = wnx[0]; rny = wny[0];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (i == ri1) { rv1x = wx[i]; rv1y = wy[i]; rnx = wnx[i]; rny = wny[i]; }
+      if (i == ri2) { rv2x = wx[i]; rv2y = wy[i]; }
+    }
+  }
+  const float sn1x = rny, sn1y = -rnx;
+  const float so1 = dot2(sn1x, sn1y, rv1x, rv1y);
+  const float so2 = dot2(-sn1x, -sn1y, rv2x, rv2y);
+
+  // b2ClipSegmentToLine x2
+  float c0x, c0y, c1x, c1y; uint32_t cid0, cid1; int np = 0;
+  {
+    const float d0 = dot2(sn1x, sn1y, i0x, i0y) - so1;
+    const float d1 = dot2(sn1x, sn1y, i1x, i1y) - so1;
+    c0x = c0y = c1x = c1y = 0.0f; cid0 = cid1 = 0u;
+    if (d0 <= 0.0f) { c0x = i0x; c0y = i0y; cid0 = id0; np = 1; }
+    if (d1 <= 0.0f) { if (np == 0) { c0x = i1x; c0y = i1y; cid0 = id1; } else { c1x = i1x; c1y = i1y; cid1 = id1; } ++np; }
+    if (d0 * d1 < 0.0f) {
+      const float t = d0 / (d0 - d1);
+      const float nxp = i0x + t * (i1x - i0x), nyp = i0y + t * (i1y - i0y);
+      const uint32_t nid = (uint32_t)ri1 | (((id0 >> 8) & 0xFFu) << 8) | (0u << 16) | (1u << 24);
+      if (np == 0) { c0x = nxp; c0y = nyp; cid0 = nid; } else { c1x = nxp; c1y = nyp; cid1 = nid; }
+      ++np;
+    }
+  }
+  if (np < 2) return;
+  float e0x, e0y, e1x, e1y; uint32_t eid0, eid1; np = 0;
+  {
+    const float d0 = dot2(-sn1x, -sn1y, c0x, c0y) - so2;
+    const float d1 = dot2(-sn1x, -sn1y, c1x, c1y) - so2;
+    e0x = e0y = e1x = e1y = 0.0f; eid0 = eid1 = 0u;
+    if (d0 <= 0.0f) { e0x = c0x; e0y = c0y; eid0 = cid0; np = 1; }
+    if (d1 <= 0.0f) { if (np == 0) { e0x = c1x; e0y = c1y; eid0 = cid1; } else { e1x = c1x; e1y = c1y; eid1 = cid1; } ++np; }
+    if (d0 * d1 < 0.0f) {
+      const float t = d0 / (d0 - d1);
+      const float nxp = c0x + t * (c1x - c0x), nyp = c0y + t * (c1y - c0y);
+      const uint32_t nid = (uint32_t)ri2 | (((cid0 >> 8) & 0xFFu) << 8) | (0u << 16) | (1u << 24);
+      if (np == 0) { e0x = nxp; e0y = nyp; eid0 = nid; } else { e1x = nxp; e1y = nyp; eid1 = nid; }
+      ++np;
+    }
+  }
+  if (np < 2) return;
+
+  mf.faceB = use_edge ? 0 : 1;
+  if (use_edge) { mf.lnx = rnx; mf.lny = rny; mf.lpx = rv1x; mf.lpy = rv1y; }
+  else {
+    mf.lnx = NX[0]; mf.lny = NY[0]; mf.lpx = VX[0]; mf.lpy = VY[0];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) if (i == ri1) { mf.lnx = NX[i]; mf.lny = NY[i]; mf.lpx = VX[i]; mf.lpy = VY[i]; }
+  }
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float qx = k == 0 ? e0x : e1x, qy = k == 0 ? e0y : e1y;
+    const uint32_t qid = k == 0 ? eid0 : eid1;
+    const float sep = dot2(rnx, rny, qx - rv1x, qy - rv1y);
+    if (sep <= radius) {
+      float lx, ly; uint32_t key;
+      if (use_edge) {   // store in polygon-local coordinates: MulT(xf, q)
+        const float dx = qx - px, dy = qy - py;
+        lx = qc * dx + qs * dy; ly = -qs * dx + qc * dy;
+        key = qid;
+      } else {          // store in edge (world) frame, id with A/B swapped
+        lx = qx; ly = qy;
+        key = ((qid >> 8) & 0xFFu) | ((qid & 0xFFu) << 8) | (((qid >> 24) & 0xFFu) << 16) | (((qid >> 16) & 0xFFu) << 24);
+      }
+      if (cnt == 0) { mf.p[0].lpx = lx; mf.p[0].lpy = ly; mf.p[0].key = key; }
+      else { mf.p[1].lpx = lx; mf.p[1].lpy = ly; mf.p[1].key = key; }
+      ++cnt;
+    }
+  }
+  mf.count = cnt;
+}
+__device__ __forceinline__ void body_xf(const Body& b, float lcy, float& px, float& py, float& qs, float& qc) {
+  det_sincosf(b.a, &qs, &qc);
+  // p = c - R * localCenter, localCenter = (0, lcy)
+  px = b.cx - (qc * 0.0f - qs * lcy);
+  py = b.cy - (qs * 0.0f + qc * lcy);
+}
+
+// role -> owned body: lanes 0/3 the hull, 1 legs[0], 2 legs[1]
+__device__ __forceinline__ float sel3(int mb, float a, float b, float c) { return mb == 0 ? a : (mb == 1 ? b : c); }
+__device__ __forceinline__ Body select_body(const Body (&B)[3], int mb) {
+  Body r;   // field-wise selects: keeps the body array in VGPRs (no address-taken struct copy)
+  r.cx = sel3(mb, B[0].cx, B[1].cx, B[2].cx); r.cy = sel3(mb, B[0].cy, B[1].cy, B[2].cy);
+  r.a = sel3(mb, B[0].a, B[1].a, B[2].a);
+  r.vx = sel3(mb, B[0].vx, B[1].vx, B[2].vx); r.vy = sel3(mb, B[0].vy, B[1].vy, B[2].vy);
+  r.w = sel3(mb, B[0].w, B[1].w, B[2].w);
+  return r;
+}
+
+// Every lane of the quad adopts lane r's copy of body r (velocities or positions).
+__device__ __forceinline__ void quad_share_velocity(Body (&B)[3], const Body& mine) {
+  B[0].vx = quad_bcast<0>(mine.vx); B[0].vy = quad_bcast<0>(mine.vy); B[0].w = quad_bcast<0>(mine.w);
+  B[1].vx = quad_bcast<1>(mine.vx); B[1].vy = quad_bcast<1>(mine.vy); B[1].w = quad_bcast<1>(mine.w);
+  B[2].vx = quad_bcast<2>(mine.vx); B[2].vy = quad_bcast<2>(mine.vy); B[2].w = quad_bcast<2>(mine.w);
+}
+__device__ __forceinline__ void quad_share_position(Body (&B)[3], const Body& mine) {
+  B[0].cx = quad_bcast<0>(mine.cx); B[0].cy = quad_bcast<0>(mine.cy); B[0].a = quad_bcast<0>(mine.a);
+  B[1].cx = quad_bcast<1>(mine.cx); B[1].cy = quad_bcast<1>(mine.cy); B[1].a = quad_bcast<1>(mine.a);
+  B[2].cx = quad_bcast<2>(mine.cx); B[2].cy = quad_bcast<2>(mine.cy); B[2].a = quad_bcast<2>(mine.a);
+}
+
+// ------------------------------------------------------------------ one physics step
+// Applies the engine impulses for `action`, runs Collide + Solve, updates flags.
+// `role` = lane & 3; mb = body this lane owns for contact work.
+__device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, int action, float disp0,
+                                           float disp1, float fx, float fy, float& m_power, float& s_power) {
+  Body(&B)[3] = W.b;
+  const int mb = role == 3 ? 0 : role;
+  const bool is_hull = mb == 0;
+  const float mB_ = is_hull ? kInvM[0] : kInvM[1], iB_ = is_hull ? kInvI[0] : kInvI[1];
+  const float lcy_ = is_hull ? kHullLcY : 0.0f;
+  const float fr_ = is_hull ? sqrtf(0.1f * 0.1f) : sqrtf(0.2f * 0.1f);     // b2MixFriction with the terrain
+  // ---- engines (gymnasium LunarLander.step) ----
+  m_power = 0.0f; s_power = 0.0f;
+  {
+    float sn, cs;
+    det_sincosf(B[0].a, &sn, &cs);
+    const float tipx = sn, tipy = cs, sidex = -cs, sidey = sn;
+    const float posx = B[0].cx - (cs * 0.0f - sn * kHullLcY);
+    const float posy = B[0].cy - (sn * 0.0f + cs * kHullLcY);
+    if (action == 2) {
+      m_power = 1.0f;
+      const float ox = tipx * (4.0f / kScale + 2.0f * disp0) + sidex * disp1;
+      const float oy = -tipy * (4.0f / kScale + 2.0f * disp0) - sidey * disp1;
+      const float ipx = posx + ox, ipy = posy + oy;
+      const float Ix = -ox * 13.0f * m_power, Iy = -oy * 13.0f * m_power;
+      B[0].vx += kInvM[0] * Ix; B[0].vy += kInvM[0] * Iy;
+      B[0].w += kInvI[0] * cross2(ipx - B[0].cx, ipy - B[0].cy, Ix, Iy);
+    }
+    if (action == 1 || action == 3) {
+      const float dir = (float)(action - 2);
+      s_power = 1.0f;
+      const float ox = tipx * disp0 + sidex * (3.0f * disp1 + dir * 12.0f / kScale);
+      const float oy = -tipy * disp0 - sidey * (3.0f * disp1 + dir * 12.0f / kScale);
+      const float ipx = posx + ox - tipx * 17.0f / kScale;
+      const float ipy = posy + oy + tipy * 14.0f / kScale;
+      const float Ix = -ox * 0.6f * s_power, Iy = -oy * 0.6f * s_power;
+      B[0].vx += kInvM[0] * Ix; B[0].vy += kInvM[0] * Iy;
+      B[0].w += kInvI[0] * cross2(ipx - B[0].cx, ipy - B[0].cy, Ix, Iy);
+    }
+  }
+
+  // ---- Collide (own body): manifolds from the current transform, warm-start matching ----
+  uint32_t my_touch = 0u;          // bit e: own body touches terrain edge e
+  bool my_contact = false;
+  {
+    const Body me = select_body(B, mb);
+    float px, py, qs, qc;
+    body_xf(me, lcy_, px, py, qs, qc);
+    // polygon x-extent -> candidate terrain edges (2 m wide each)
+    float minx = 3.4e38f, maxx = -3.4e38f, miny = 3.4e38f;
+    if (is_hull) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const float x = (qc * kHullVx[i] - qs * kHullVy[i]) + px, y = (qs * kHullVx[i] + qc * kHullVy[i]) + py;
+        minx = fminf(minx, x); maxx = fmaxf(maxx, x); miny = fminf(miny, y);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float x = (qc * kLegVx[i] - qs * kLegVy[i]) + px, y = (qs * kLegVx[i] + qc * kLegVy[i]) + py;
+        minx = fminf(minx, x); maxx = fmaxf(maxx, x); miny = fminf(miny, y);
+      }
+    }
+    int e_lo = (int)floorf((minx - 2.0f * kPolyRadius) * 0.5f);
+    int e_hi = (int)floorf((maxx + 2.0f * kPolyRadius) * 0.5f);
+    e_lo = e_lo < 0 ? 0 : e_lo;
+    e_hi = e_hi > 9 ? 9 : e_hi;
+    // previous step's points of this body (for warm starting), before the slots are rewritten
+    int ocount[2]; uint32_t okey[2][2]; float oni[2][2], oti[2][2];
+#pragma unroll
+    for (int os = 0; os < 2; ++os) {
+      ocount[os] = (int)lds.mu(os, MF_COUNT);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        okey[os][q] = lds.mu(os, MF_P0 + 5 * q + P_KEY);
+        oni[os][q] = lds.mf(os, MF_P0 + 5 * q + P_NI);
+        oti[os][q] = lds.mf(os, MF_P0 + 5 * q + P_TI);
+      }
+    }
+    const int old_e0 = W.edge0;
+    W.edge0 = e_lo;
+#pragma nounroll
+    for (int s = 0; s < 2; ++s) {
+      Manifold mf;
+      mf.count = 0; mf.faceB = 0; mf.lnx = mf.lny = mf.lpx = mf.lpy = 0.0f;
+      mf.p[0] = ContactPt{0.0f, 0.0f, 0u, 0.0f, 0.0f}; mf.p[1] = mf.p[0];
+      const int e = e_lo + s;
+      if (e <= e_hi && e >= 0 && e <= 9) {
+        float y1 = W.ty[0], y2 = W.ty[1];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) if (k == e) { y1 = W.ty[k]; y2 = W.ty[k + 1]; }
+        const float x1 = 2.0f * (float)e, x2 = 2.0f * (float)(e + 1);
+        if (miny - 2.0f * kPolyRadius <= fmaxf(y1, y2)) {
+          const float ccx = is_hull ? me.cx : px, ccy = is_hull ? me.cy : py;  // centroid == centre of mass
+          if (is_hull) collide_edge_polygon<6>(mf, kHullVx, kHullVy, kHullNx, kHullNy, px, py, qs, qc, ccx, ccy, x1, y1, x2, y2);
+          else collide_edge_polygon<4>(mf, kLegVx, kLegVy, kLegNx, kLegNy, px, py, qs, qc, ccx, ccy, x1, y1, x2, y2);
+        }
+        // warm start: impulses of the same (edge, feature) from the previous step
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          mf.p[k].ni = 0.0f; mf.p[k].ti = 0.0f;
+          if (k < mf.count) {
+            bool found = false;   // b2Contact::Update: first old point with the same feature id
+#pragma unroll
+            for (int os = 0; os < 2; ++os) {
+              if (old_e0 + os == e) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                  if (!found && q < ocount[os] && okey[os][q] == mf.p[k].key) {
+                    mf.p[k].ni = oni[os][q]; mf.p[k].ti = oti[os][q]; found = true;
+                  }
+              }
+            }
+          }
+        }
+        if (mf.count > 0) { my_touch |= 1u << e; my_contact = true; }
+      }
+      lds.mu(s, MF_COUNT) = (uint32_t)mf.count; lds.mu(s, MF_FACEB) = (uint32_t)mf.faceB;
+      lds.mf(s, MF_LNX) = mf.lnx; lds.mf(s, MF_LNY) = mf.lny;
+      lds.mf(s, MF_LPX) = mf.lpx; lds.mf(s, MF_LPY) = mf.lpy;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        lds.mf(s, MF_P0 + 5 * k + P_LPX) = mf.p[k].lpx; lds.mf(s, MF_P0 + 5 * k + P_LPY) = mf.p[k].lpy;
+        lds.mu(s, MF_P0 + 5 * k + P_KEY) = mf.p[k].key;
+        lds.mf(s, MF_P0 + 5 * k + P_NI) = mf.p[k].ni; lds.mf(s, MF_P0 + 5 * k + P_TI) = mf.p[k].ti;
+      }
+    }
+  }
+  // contact listener (gymnasium ContactDetector) on the quad's combined touching mask
+  const uint32_t touching_now = quad_bcast_u<0>(my_touch) | (quad_bcast_u<1>(my_touch) << 10) |
+                                (quad_bcast_u<2>(my_touch) << 20);
+  const bool any_contact = touching_now != 0u;       // uniform across the quad
+  {
+    const uint32_t began = touching_now & ~W.touching, ended = W.touching & ~touching_now;
+    if (began & 0x3FFu) W.flags |= 4u;                       // hull touched the moon: game over
+#pragma unroll
+    for (int L = 0; L < 2; ++L) {
+#pragma unroll
+      for (int e = 0; e < 10; ++e) {
+        const uint32_t bit = 1u << (10 * (L + 1) + e);
+        if (began & bit) W.flags |= (1u << L);
+        if (ended & bit) W.flags &= ~(1u << L);
+      }
+    }
+    W.touching = touching_now;
+  }
+
+  // ---- Solve (b2Island::Solve) ----
+  const float h = kDt;
+  // integrate velocities: gravity (0,-10) + the pending reset force on the hull
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const float Fx = b == 0 ? fx : 0.0f, Fy = b == 0 ? fy : 0.0f;
+    B[b].vx += h * (0.0f + kInvM[b] * Fx);
+    B[b].vy += h * (-10.0f + kInvM[b] * Fy);
+  }
+
+  // contact velocity constraints + warm start (own body), kept in VGPRs for the sweeps
+  int vcn[2] = {0, 0};
+  float vcf[2][16], vim[2][4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int f = 0; f < 16; ++f) vcf[s][f] = 0.0f;
+    vim[s][0] = vim[s][1] = vim[s][2] = vim[s][3] = 0.0f;
+  }
+  if (any_contact) {
+    Body me = select_body(B, mb);
+    if (my_contact) {
+      float px, py, qs, qc;
+      body_xf(me, lcy_, px, py, qs, qc);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int count = (int)lds.mu(s, MF_COUNT);
+        int vcount = count;
+        if (count > 0) {
+          const bool faceB = lds.mu(s, MF_FACEB) != 0u;
+          const float lnx = lds.mf(s, MF_LNX), lny = lds.mf(s, MF_LNY);
+          const float lpx = lds.mf(s, MF_LPX), lpy = lds.mf(s, MF_LPY);
+          float nx, ny, wpx[2], wpy[2];
+          if (!faceB) {
+            nx = lnx; ny = lny;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const float qx = lds.mf(s, MF_P0 + 5 * k + P_LPX), qy = lds.mf(s, MF_P0 + 5 * k + P_LPY);
+              const float clx = (qc * qx - qs * qy) + px, cly = (qs * qx + qc * qy) + py;
+              const float d = kPolyRadius - dot2(clx - lpx, cly - lpy, nx, ny);
+              const float cAx = clx + d * nx, cAy = cly + d * ny;
+              const float cBx = clx - kPolyRadius * nx, cBy = cly - kPolyRadius * ny;
+              wpx[k] = 0.5f * (cAx + cBx); wpy[k] = 0.5f * (cAy + cBy);
+            }
+          } else {
+            nx = qc * lnx - qs * lny; ny = qs * lnx + qc * lny;
+            const float ppx = (qc * lpx - qs * lpy) + px, ppy = (qs * lpx + qc * lpy) + py;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const float clx = lds.mf(s, MF_P0 + 5 * k + P_LPX), cly = lds.mf(s, MF_P0 + 5 * k + P_LPY);
+              const float d = kPolyRadius - dot2(clx - ppx, cly - ppy, nx, ny);
+              const float cBx = clx + d * nx, cBy = cly + d * ny;
+              const float cAx = clx - kPolyRadius * nx, cAy = cly - kPolyRadius * ny;
+              wpx[k] = 0.5f * (cAx + cBx); wpy[k] = 0.5f * (cAy + cBy);
+            }
+            nx = -nx; ny = -ny;
+          }
+          const float tx = ny, ty = -nx;
+          float rx[2], ry[2];
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            rx[k] = wpx[k] - me.cx; ry[k] = wpy[k] - me.cy;
+            const float rn = cross2(rx[k], ry[k], nx, ny);
+            const float kn = mB_ + iB_ * rn * rn;
+            vcf[s][VC_NM0 - 1 + k] = kn > 0.0f ? 1.0f / kn : 0.0f;
+            const float rt = cross2(rx[k], ry[k], tx, ty);
+            const float kt = mB_ + iB_ * rt * rt;
+            vcf[s][VC_TM0 - 1 + k] = kt > 0.0f ? 1.0f / kt : 0.0f;
+            vcf[s][VC_RX0 - 1 + 2 * k] = rx[k]; vcf[s][VC_RY0 - 1 + 2 * k] = ry[k];
+          }
+          vcf[s][VC_NX - 1] = nx; vcf[s][VC_NY - 1] = ny;
+          if (count == 2) {
+            const float rn1 = cross2(rx[0], ry[0], nx, ny), rn2 = cross2(rx[1], ry[1], nx, ny);
+            const float k11 = mB_ + iB_ * rn1 * rn1, k22 = mB_ + iB_ * rn2 * rn2, k12 = mB_ + iB_ * rn1 * rn2;
+            if (k11 * k11 < 1000.0f * (k11 * k22 - k12 * k12)) {
+              float det = k11 * k22 - k12 * k12;
+              if (det != 0.0f) det = 1.0f / det;
+              vcf[s][VC_K11 - 1] = k11; vcf[s][VC_K12 - 1] = k12; vcf[s][VC_K22 - 1] = k22;
+              vcf[s][VC_I11 - 1] = det * k22; vcf[s][VC_I12 - 1] = -det * k12; vcf[s][VC_I22 - 1] = det * k11;
+            } else {
+              vcount = 1;   // nearly redundant second point: Box2D drops it from the velocity solve
+            }
+          }
+          vim[s][0] = lds.mf(s, MF_P0 + P_NI); vim[s][1] = lds.mf(s, MF_P0 + P_TI);
+          vim[s][2] = lds.mf(s, MF_P1 + P_NI); vim[s][3] = lds.mf(s, MF_P1 + P_TI);
+          // warm start
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            if (k < vcount) {
+              const float ni = vim[s][2 * k], ti = vim[s][2 * k + 1];
+              const float Px = ni * nx + ti * tx, Py = ni * ny + ti * ty;
+              me.w += iB_ * cross2(rx[k], ry[k], Px, Py);
+              me.vx += mB_ * Px; me.vy += mB_ * Py;
+            }
+          }
+        }
+        vcn[s] = vcount;
+      }
+    }
+    quad_share_velocity(B, me);
+  }
+
+  // joints: InitVelocityConstraints (island order: joint of legs[1], then legs[0]); replicated per lane
+  float jrAx[2], jrAy[2], jrBx[2], jrBy[2];
+  float K11[2], K12[2], K13[2], K22[2], K23[2], K33[2], mmass[2];
+  {
+    float qsA, qcA;
+    det_sincosf(B[0].a, &qsA, &qcA);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int L = 1 - jj;
+      const int bi = L + 1;
+      float qsB, qcB;
+      det_sincosf(B[bi].a, &qsB, &qcB);
+      const float lax = 0.0f - 0.0f, lay = 0.0f - kHullLcY;
+      const float lbx = leg_sign(L) * kLegAway, lby = kLegDown;
+      jrAx[L] = qcA * lax - qsA * lay; jrAy[L] = qsA * lax + qcA * lay;
+      jrBx[L] = qcB * lbx - qsB * lby; jrBy[L] = qsB * lbx + qcB * lby;
+      const float mA = kInvM[0], mB = kInvM[bi], iA = kInvI[0], iB = kInvI[bi];
+      K11[L] = mA + mB + jrAy[L] * jrAy[L] * iA + jrBy[L] * jrBy[L] * iB;
+      K12[L] = -jrAy[L] * jrAx[L] * iA - jrBy[L] * jrBx[L] * iB;
+      K13[L] = -jrAy[L] * iA - jrBy[L] * iB;
+      K22[L] = mA + mB + jrAx[L] * jrAx[L] * iA + jrBx[L] * jrBx[L] * iB;
+      K23[L] = jrAx[L] * iA + jrBx[L] * iB;
+      K33[L] = iA + iB;
+      mmass[L] = 1.0f / (iA + iB);
+      Joint& J = W.j[L];
+      const float ang = B[bi].a - B[0].a;
+      if (ang <= joint_lower(L)) { if (J.state != 1) J.iz = 0.0f; J.state = 1; }
+      else if (ang >= joint_upper(L)) { if (J.state != 2) J.iz = 0.0f; J.state = 2; }
+      else { J.state = 0; J.iz = 0.0f; }
+      // warm start (dtRatio = 1)
+      const float Px = J.ix, Py = J.iy;
+      B[0].vx -= mA * Px; B[0].vy -= mA * Py;
+      B[0].w -= iA * (cross2(jrAx[L], jrAy[L], Px, Py) + J.im + J.iz);
+      B[bi].vx += mB * Px; B[bi].vy += mB * Py;
+      B[bi].w += iB * (cross2(jrBx[L], jrBy[L], Px, Py) + J.im + J.iz);
+    }
+  }
+
+  // velocity iterations
+#pragma nounroll
+  for (int it = 0; it < kVelIters; ++it) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int L = 1 - jj;
+      const int bi = L + 1;
+      Joint& J = W.j[L];
+      const float mA = kInvM[0], mB = kInvM[bi], iA = kInvI[0], iB = kInvI[bi];
+      {  // motor
+        const float Cdot = B[bi].w - B[0].w - 0.3f * leg_sign(L);
+        float imp = -mmass[L] * Cdot;
+        const float old = J.im, maxImp = h * kMotorTorque;
+        J.im = clampf(old + imp, -maxImp, maxImp);
+        imp = J.im - old;
+        B[0].w -= iA * imp; B[bi].w += iB * imp;
+      }
+      const float Cx = B[bi].vx + (-B[bi].w * jrBy[L]) - B[0].vx - (-B[0].w * jrAy[L]);
+      const float Cy = B[bi].vy + (B[bi].w * jrBx[L]) - B[0].vy - (B[0].w * jrAx[L]);
+      float ipx, ipy, ipz;
+      if (J.state != 0) {
+        const float Cz = B[bi].w - B[0].w;
+        // impulse = -K^-1 * Cdot (b2Mat33::Solve33, Cramer)
+        const float a11 = K11[L], a12 = K12[L], a13 = K13[L], a22 = K22[L], a23 = K23[L], a33 = K33[L];
+        const float c1x = a22 * a33 - a23 * a23, c1y = a23 * a13 - a12 * a33, c1z = a12 * a23 - a22 * a13;
+        float det = a11 * c1x + a12 * c1y + a13 * c1z;
+        if (det != 0.0f) det = 1.0f / det;
+        const float bx = Cx, by = Cy, bz = Cz;
+        const float sx = det * (bx * c1x + by * c1y + bz * c1z);
+        const float c2x = by * a33 - bz * a23, c2y = bz * a13 - bx * a33, c2z = bx * a23 - by * a13;
+        const float sy = det * (a11 * c2x + a12 * c2y + a13 * c2z);
+        const float c3x = a22 * bz - a23 * by, c3y = a23 * bx - a12 * bz, c3z = a12 * by - a22 * bx;
+        const float sz = det * (a11 * c3x + a12 * c3y + a13 * c3z);
+        ipx = -sx; ipy = -sy; ipz = -sz;
+        const float newImp = J.iz + ipz;
+        const bool release = (J.state == 1) ? (newImp < 0.0f) : (newImp > 0.0f);
+        if (release) {
+          const float rx = -Cx + J.iz * a13, ry = -Cy + J.iz * a23;
+          float d2 = a11 * a22 - a12 * a12;
+          if (d2 != 0.0f) d2 = 1.0f / d2;
+          const float ux = d2 * (a22 * rx - a12 * ry), uy = d2 * (a11 * ry - a12 * rx);
+          ipx = ux; ipy = uy; ipz = -J.iz;
+          J.ix += ux; J.iy += uy; J.iz = 0.0f;
+        } else {
+          J.ix += ipx; J.iy += ipy; J.iz += ipz;
+        }
+      } else {
+        const float a11 = K11[L], a12 = K12[L], a22 = K22[L];
+        float d2 = a11 * a22 - a12 * a12;
+        if (d2 != 0.0f) d2 = 1.0f / d2;
+        const float rx = -Cx, ry = -Cy;
+        ipx = d2 * (a22 * rx - a12 * ry); ipy = d2 * (a11 * ry - a12 * rx); ipz = 0.0f;
+        J.ix += ipx; J.iy += ipy;
+      }
+      B[0].vx -= mA * ipx; B[0].vy -= mA * ipy;
+      B[0].w -= iA * (cross2(jrAx[L], jrAy[L], ipx, ipy) + ipz);
+      B[bi].vx += mB * ipx; B[bi].vy += mB * ipy;
+      B[bi].w += iB * (cross2(jrBx[L], jrBy[L], ipx, ipy) + ipz);
+    }
+    // contacts: each lane solves its own body's slots, then the quad exchanges velocities
+    if (any_contact) {
+      Body me = select_body(B, mb);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int vcount = vcn[s];
+        if (vcount > 0) {
+          const float nx = vcf[s][VC_NX - 1], ny = vcf[s][VC_NY - 1], tx = ny, ty = -nx;
+          const float rx0 = vcf[s][VC_RX0 - 1], ry0 = vcf[s][VC_RY0 - 1], rx1 = vcf[s][VC_RX1 - 1], ry1 = vcf[s][VC_RY1 - 1];
+          float ni0 = vim[s][0], ti0 = vim[s][1], ni1 = vim[s][2], ti1 = vim[s][3];
+          {  // friction, point 0
+            const float dvx = me.vx + (-me.w * ry0), dvy = me.vy + (me.w * rx0);
+            const float vt = dot2(dvx, dvy, tx, ty);
+            float lam = vcf[s][VC_TM0 - 1] * (-vt);
+            const float maxF = fr_ * ni0;
+            const float nw = clampf(ti0 + lam, -maxF, maxF);
+            lam = nw - ti0; ti0 = nw;
+            const float Px = lam * tx, Py = lam * ty;
+            me.vx += mB_ * Px; me.vy += mB_ * Py;
+            me.w += iB_ * cross2(rx0, ry0, Px, Py);
+          }
+          if (vcount == 2) {  // friction, point 1
+            const float dvx = me.vx + (-me.w * ry1), dvy = me.vy + (me.w * rx1);
+            const float vt = dot2(dvx, dvy, tx, ty);
+            float lam = vcf[s][VC_TM1 - 1] * (-vt);
+            const float maxF = fr_ * ni1;
+            const float nw = clampf(ti1 + lam, -maxF, maxF);
+            lam = nw - ti1; ti1 = nw;
+            const float Px = lam * tx, Py = lam * ty;
+            me.vx += mB_ * Px; me.vy += mB_ * Py;
+            me.w += iB_ * cross2(rx1, ry1, Px, Py);
+          }
+          if (vcount == 1) {
+            const float dvx = me.vx + (-me.w * ry0), dvy = me.vy + (me.w * rx0);
+            const float vn = dot2(dvx, dvy, nx, ny);
+            float lam = -vcf[s][VC_NM0 - 1] * vn;
+            const float nw = fmaxf(ni0 + lam, 0.0f);
+            lam = nw - ni0; ni0 = nw;
+            const float Px = lam * nx, Py = lam * ny;
+            me.vx += mB_ * Px; me.vy += mB_ * Py;
+            me.w += iB_ * cross2(rx0, ry0, Px, Py);
+          } else {
+            // 2-point block solver (b2ContactSolver::SolveVelocityConstraints)
+            const float k11 = vcf[s][VC_K11 - 1], k12 = vcf[s][VC_K12 - 1], k22 = vcf[s][VC_K22 - 1];
+            const float a1 = ni0, a2 = ni1;
+            const float dv1x = me.vx + (-me.w * ry0), dv1y = me.vy + (me.w * rx0);
+            const float dv2x = me.vx + (-me.w * ry1), dv2y = me.vy + (me.w * rx1);
+            float vn1 = dot2(dv1x, dv1y, nx, ny), vn2 = dot2(dv2x, dv2y, nx, ny);
+            const float b1 = vn1 - (k11 * a1 + k12 * a2);
+            const float b2 = vn2 - (k12 * a1 + k22 * a2);
+            float x1 = -(vcf[s][VC_I11 - 1] * b1 + vcf[s][VC_I12 - 1] * b2);
+            float x2 = -(vcf[s][VC_I12 - 1] * b1 + vcf[s][VC_I22 - 1] * b2);
+            bool ok = (x1 >= 0.0f && x2 >= 0.0f);
+            if (!ok) {
+              x1 = -vcf[s][VC_NM0 - 1] * b1; x2 = 0.0f;
+              vn2 = k12 * x1 + b2;
+              ok = (x1 >= 0.0f && vn2 >= 0.0f);
+            }
+            if (!ok) {
+              x1 = 0.0f; x2 = -vcf[s][VC_NM1 - 1] * b2;
+              vn1 = k12 * x2 + b1;
+              ok = (x2 >= 0.0f && vn1 >= 0.0f);
+            }
+            if (!ok) {
+              x1 = 0.0f; x2 = 0.0f;
+              ok = (b1 >= 0.0f && b2 >= 0.0f);
+            }
+            if (ok) {
+              const float d1 = x1 - a1, d2 = x2 - a2;
+              const float P1x = d1 * nx, P1y = d1 * ny, P2x = d2 * nx, P2y = d2 * ny;
+              me.vx += mB_ * (P1x + P2x); me.vy += mB_ * (P1y + P2y);
+              me.w += iB_ * (cross2(rx0, ry0, P1x, P1y) + cross2(rx1, ry1, P2x, P2y));
+              ni0 = x1; ni1 = x2;
+            }
+          }
+          vim[s][0] = ni0; vim[s][1] = ti0;
+          if (vcount == 2) { vim[s][2] = ni1; vim[s][3] = ti1; }
+        }
+      }
+      quad_share_velocity(B, me);
+    }
+  }
+  // b2ContactSolver::StoreImpulses
+  if (my_contact) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (vcn[s] > 0) {
+        lds.mf(s, MF_P0 + P_NI) = vim[s][0]; lds.mf(s, MF_P0 + P_TI) = vim[s][1];
+        if (vcn[s] == 2) { lds.mf(s, MF_P1 + P_NI) = vim[s][2]; lds.mf(s, MF_P1 + P_TI) = vim[s][3]; }
+      }
+    }
+  }
+
+  // integrate positions
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    float tx = h * B[b].vx, ty = h * B[b].vy;
+    if (dot2(tx, ty, tx, ty) > kMaxTranslation * kMaxTranslation) {
+      const float ratio = kMaxTranslation / sqrtf(dot2(tx, ty, tx, ty));
+      B[b].vx *= ratio; B[b].vy *= ratio;
+    }
+    const float rot = h * B[b].w;
+    if (rot * rot > kMaxRotation * kMaxRotation) {
+      const float ratio = kMaxRotation / fabsf(rot);
+      B[b].w *= ratio;
+    }
+    B[b].cx += h * B[b].vx; B[b].cy += h * B[b].vy; B[b].a += h * B[b].w;
+  }
+
+  // position iterations
+  bool position_solved = false;
+#pragma nounroll
+  for (int it = 0; it < kPosIters; ++it) {
+    float min_sep = 0.0f;
+    if (any_contact) {
+      Body me = select_body(B, mb);
+      float my_min = 0.0f;
+#pragma nounroll
+      for (int s = 0; s < 2; ++s) {
+        const int cnt = my_contact ? (int)lds.mu(s, MF_COUNT) : 0;   // the position solver keeps every manifold point
+        if (cnt > 0) {
+          const bool faceB = lds.mu(s, MF_FACEB) != 0u;
+          const float lnx = lds.mf(s, MF_LNX), lny = lds.mf(s, MF_LNY);
+          const float lpx = lds.mf(s, MF_LPX), lpy = lds.mf(s, MF_LPY);
+#pragma nounroll
+          for (int k = 0; k < cnt; ++k) {
+            const float qx = lds.mf(s, MF_P0 + 5 * k + P_LPX), qy = lds.mf(s, MF_P0 + 5 * k + P_LPY);
+            float px, py, qs, qc;
+            body_xf(me, lcy_, px, py, qs, qc);
+            float nx, ny, ptx, pty, sep;
+            if (!faceB) {
+              nx = lnx; ny = lny;
+              const float clx = (qc * qx - qs * qy) + px, cly = (qs * qx + qc * qy) + py;
+              sep = dot2(clx - lpx, cly - lpy, nx, ny) - kPolyRadius - kPolyRadius;
+              ptx = clx; pty = cly;
+            } else {
+              nx = qc * lnx - qs * lny; ny = qs * lnx + qc * lny;
+              const float ppx = (qc * lpx - qs * lpy) + px, ppy = (qs * lpx + qc * lpy) + py;
+              sep = dot2(qx - ppx, qy - ppy, nx, ny) - kPolyRadius - kPolyRadius;
+              ptx = qx; pty = qy;
+              nx = -nx; ny = -ny;
+            }
+            const float rx = ptx - me.cx, ry = pty - me.cy;
+            my_min = fminf(my_min, sep);
+            const float C = clampf(kBaumgarte * (sep + kLinearSlop), -kMaxLinCorr, 0.0f);
+            const float rn = cross2(rx, ry, nx, ny);
+            const float K = mB_ + iB_ * rn * rn;
+            const float imp = K > 0.0f ? -C / K : 0.0f;
+            const float Px = imp * nx, Py = imp * ny;
+            me.cx += mB_ * Px; me.cy += mB_ * Py;
+            me.a += iB_ * cross2(rx, ry, Px, Py);
+          }
+        }
+      }
+      quad_share_position(B, me);
+      min_sep = fminf(fminf(quad_bcast<0>(my_min), quad_bcast<1>(my_min)), quad_bcast<2>(my_min));
+    }
+    const bool contacts_ok = min_sep >= -3.0f * kLinearSlop;
+    bool joints_ok = true;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int L = 1 - jj;
+      const int bi = L + 1;
+      const Joint& J = W.j[L];
+      const float mA = kInvM[0], mB = kInvM[bi], iA = kInvI[0], iB = kInvI[bi];
+      float angErr = 0.0f;
+      if (J.state != 0) {
+        const float ang = B[bi].a - B[0].a;
+        float limImp = 0.0f;
+        if (J.state == 1) {
+          float C = ang - joint_lower(L);
+          angErr = -C;
+          C = clampf(C + kAngularSlop, -kMaxAngCorr, 0.0f);
+          limImp = -mmass[L] * C;
+        } else {
+          float C = ang - joint_upper(L);
+          angErr = C;
+          C = clampf(C - kAngularSlop, 0.0f, kMaxAngCorr);
+          limImp = -mmass[L] * C;
+        }
+        B[0].a -= iA * limImp; B[bi].a += iB * limImp;
+      }
+      float qsA, qcA, qsB, qcB;
+      det_sincosf(B[0].a, &qsA, &qcA);
+      det_sincosf(B[bi].a, &qsB, &qcB);
+      const float lax = 0.0f, lay = 0.0f - kHullLcY;
+      const float lbx = leg_sign(L) * kLegAway, lby = kLegDown;
+      const float rAx = qcA * lax - qsA * lay, rAy = qsA * lax + qcA * lay;
+      const float rBx = qcB * lbx - qsB * lby, rBy = qsB * lbx + qcB * lby;
+      const float Cx = B[bi].cx + rBx - B[0].cx - rAx, Cy = B[bi].cy + rBy - B[0].cy - rAy;
+      const float posErr = sqrtf(Cx * Cx + Cy * Cy);
+      const float k11 = mA + mB + iA * rAy * rAy + iB * rBy * rBy;
+      const float k12 = -iA * rAx * rAy - iB * rBx * rBy;
+      const float k22 = mA + mB + iA * rAx * rAx + iB * rBx * rBx;
+      float det = k11 * k22 - k12 * k12;
+      if (det != 0.0f) det = 1.0f / det;
+      const float impx = -(det * (k22 * Cx - k12 * Cy)), impy = -(det * (k11 * Cy - k12 * Cx));
+      B[0].cx -= mA * impx; B[0].cy -= mA * impy;
+      B[0].a -= iA * cross2(rAx, rAy, impx, impy);
+      B[bi].cx += mB * impx; B[bi].cy += mB * impy;
+      B[bi].a += iB * cross2(rBx, rBy, impx, impy);
+      joints_ok = joints_ok && (posErr <= kLinearSlop) && (angErr <= kAngularSlop);
+    }
+    if (contacts_ok && joints_ok) { position_solved = true; break; }
+  }
+
+  // sleep management (island = hull + both legs)
+  float min_sleep = 3.4e38f;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    if (B[b].w * B[b].w > kAngSleepTol * kAngSleepTol ||
+        dot2(B[b].vx, B[b].vy, B[b].vx, B[b].vy) > kLinSleepTol * kLinSleepTol) {
+      W.sleep[b] = 0.0f; min_sleep = 0.0f;
+    } else {
+      W.sleep[b] += h;
+      min_sleep = fminf(min_sleep, W.sleep[b]);
+    }
+  }
+  if (min_sleep >= kTimeToSleep && position_solved) W.flags |= 16u;
+}
+
+// ------------------------------------------------------------------ gymnasium layer
+__device__ __forceinline__ void lander_obs(const World& W, float (&o)[8]) {
+  float sn, cs;
+  det_sincosf(W.b[0].a, &sn, &cs);
+  const float posx = W.b[0].cx - (cs * 0.0f - sn * kHullLcY);
+  const float posy = W.b[0].cy - (sn * 0.0f + cs * kHullLcY);
+  o[0] = (posx - kW / 2.0f) / (kW / 2.0f);
+  o[1] = (posy - (kHelipadY + kLegDown)) / (kH / 2.0f);
+  o[2] = W.b[0].vx * (kW / 2.0f) / 50.0f;
+  o[3] = W.b[0].vy * (kH / 2.0f) / 50.0f;
+  o[4] = W.b[0].a;
+  o[5] = 20.0f * W.b[0].w / 50.0f;
+  o[6] = (W.flags & 1u) ? 1.0f : 0.0f;
+  o[7] = (W.flags & 2u) ? 1.0f : 0.0f;
+}
+
+__device__ __forceinline__ float shaping_of(const float (&o)[8]) {
+  return -100.0f * sqrtf(o[0] * o[0] + o[1] * o[1]) - 100.0f * sqrtf(o[2] * o[2] + o[3] * o[3]) -
+         100.0f * fabsf(o[4]) + 10.0f * o[6] + 10.0f * o[7];
+}
+
+// gymnasium step(): returns reward / terminated, fills o (replicated on the quad's lanes).
+__device__ __forceinline__ void env_step_once(World& W, const Lds& lds, int role, int action, uint64_t seed,
+                                              uint64_t env, uint32_t episode, uint32_t step_idx, float fx,
+                                              float fy, float (&o)[8], float& reward, bool& terminated) {
+  const u32x4 r = philox4x32(seed, (uint32_t)env, (uint32_t)(env >> 32), episode, RNG_ENV_STEP | step_idx);
+  const float d0 = (-1.0f + 2.0f * u01f(r.x)) / kScale, d1 = (-1.0f + 2.0f * u01f(r.y)) / kScale;
+  float mp, sp;
+  world_step(W, lds, role, action, d0, d1, fx, fy, mp, sp);
+  lander_obs(W, o);
+  const float shaping = shaping_of(o);
+  reward = 0.0f;
+  if (W.flags & 8u) reward = shaping - W.prev_shaping;
+  W.prev_shaping = shaping; W.flags |= 8u;
+  reward -= mp * 0.30f;
+  reward -= sp * 0.03f;
+  terminated = false;
+  if ((W.flags & 4u) || fabsf(o[0]) >= 1.0f) { terminated = true; reward = -100.0f; }
+  if (W.flags & 16u) { terminated = true; reward = 100.0f; }
+}
+
+// gymnasium reset() minus its trailing step(0): terrain, bodies, random initial force
+// (fx, fy) that the caller feeds to the first world_step.
+__device__ __forceinline__ void init_episode(World& W, const Lds& lds, uint64_t seed, uint64_t env,
+                                             uint32_t episode, float& fx, float& fy) {
+  float hgt[12];
+#pragma unroll
+  for (int blk = 0; blk < 3; ++blk) {
+    const u32x4 r = philox4x32(seed, (uint32_t)env, (uint32_t)(env >> 32), episode, RNG_ENV_RESET | (uint32_t)blk);
+    hgt[4 * blk + 0] = (kH / 2.0f) * u01f(r.x); hgt[4 * blk + 1] = (kH / 2.0f) * u01f(r.y);
+    hgt[4 * blk + 2] = (kH / 2.0f) * u01f(r.z); hgt[4 * blk + 3] = (kH / 2.0f) * u01f(r.w);
+  }
+#pragma unroll
+  for (int i = 3; i <= 7; ++i) hgt[i] = kHelipadY;
+#pragma unroll
+  for (int i = 0; i < 11; ++i) {
+    const float prev = hgt[i == 0 ? 11 : i - 1];   // python's height[-1] wrap at i = 0
+    W.ty[i] = 0.33f * (prev + hgt[i] + hgt[i + 1]);
+  }
+  const u32x4 rf = philox4x32(seed, (uint32_t)env, (uint32_t)(env >> 32), episode, RNG_ENV_RESET | 3u);
+  fx = -1000.0f + 2000.0f * u01f(rf.x); fy = -1000.0f + 2000.0f * u01f(rf.y);
+  // hull at (W/2, H) angle 0: centre of mass = origin + localCenter
+  W.b[0] = Body{kW / 2.0f, kH + kHullLcY, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int L = 0; L < 2; ++L) {
+    const float i = leg_sign(L);
+    W.b[L + 1] = Body{kW / 2.0f - i * kLegAway, kH, i * 0.05f, 0.0f, 0.0f, 0.0f};
+    W.j[L] = Joint{0.0f, 0.0f, 0.0f, 0.0f, 0};
+  }
+#pragma unroll
+  for (int b = 0; b < 3; ++b) W.sleep[b] = 0.0f;
+  W.edge0 = 0;
+#pragma nounroll
+  for (int k = 0; k < 2 * kMfWords; ++k) lds.w[k * kEnvBlock] = 0u;
+  W.touching = 0u; W.flags = 0u; W.prev_shaping = 0.0f;
+}
+
+// ------------------------------------------------------------------ SoA state in HBM
+// Everything an env needs between steps; [field][N] dword arrays.  Word order:
+//   bodies 18 | sleep 3 | joints 10 | manifolds 3 bodies x 2 slots x 16 | edge0 3 | touching |
+//   terrain 11 | flags | prev_shaping
+constexpr int kWorldWords = 18 + 3 + 10 + 3 * 2 * kMfWords + 3 + 1 + 11 + 1 + 1;   // 144
+constexpr int kWMf = 31, kWEdge0 = 31 + 96, kWTail = 31 + 96 + 3;
+
+// A second world per env ("spare") holds the NEXT episode's post-reset state, computed by
+// gymrl_env_refill off the critical path (reset() costs a full solver pass because it ends
+// with step(0)); the step kernel swaps it in when an episode ends and falls back to the
+// inline reset when the spare is not ready.  Bit-identical either way: the spare is a pure
+// function of (seed, env id, episode).
+constexpr uint32_t kNoSpare = 0xFFFFFFFFu;
+
+struct LunarState {
+  uint32_t* words;     // [kWorldWords][N]
+  EpisodeFields ep;
+  uint32_t* spare_words;    // [kWorldWords][N]
+  float* spare_obs;         // [8][N]
+  uint32_t* spare_episode;  // episode index the spare was built for, or kNoSpare
+  size_t bytes;
+  __host__ __device__ LunarState(void* buf, int n) {
+    Carver c(buf, n);
+    words = c.take<uint32_t>(kWorldWords);
+    ep.ep_ret = c.take<double>(); ep.ep_len = c.take<int32_t>(); ep.episode = c.take<uint32_t>();
+    spare_words = c.take<uint32_t>(kWorldWords);
+    spare_obs = c.take<float>(8);
+    spare_episode = c.take<uint32_t>();
+    bytes = c.off;
+  }
+};
+
+struct WordIO {
+  uint32_t* base; int n; int i; int k; bool wr;   // wr: this lane performs stores
+  __device__ __forceinline__ void f(float& x, bool store) {
+    if (store) { if (wr) base[(size_t)k * n + i] = __float_as_uint(x); } else x = __uint_as_float(base[(size_t)k * n + i]);
+    ++k;
+  }
+  __device__ __forceinline__ void u(uint32_t& x, bool store) {
+    if (store) { if (wr) base[(size_t)k * n + i] = x; } else x = base[(size_t)k * n + i];
+    ++k;
+  }
+  __device__ __forceinline__ void d(int& x, bool store) {
+    if (store) { if (wr) base[(size_t)k * n + i] = (uint32_t)x; } else x = (int)base[(size_t)k * n + i];
+    ++k;
+  }
+};
+
+// Loads: every lane of the quad reads the replicated words and its own body's manifolds.
+// Stores: lane 0 writes the replicated words, lanes 0..2 their body's manifolds + edge0.
+__device__ __forceinline__ void world_io(World& W, const Lds& lds, int role, uint32_t* base, int n, int i,
+                                         bool store) {
+  const int mb = role == 3 ? 0 : role;
+  WordIO io{base, n, i, 0, role == 0};
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    io.f(W.b[b].cx, store); io.f(W.b[b].cy, store); io.f(W.b[b].a, store);
+    io.f(W.b[b].vx, store); io.f(W.b[b].vy, store); io.f(W.b[b].w, store);
+  }
+#pragma unroll
+  for (int b = 0; b < 3; ++b) io.f(W.sleep[b], store);
+#pragma unroll
+  for (int L = 0; L < 2; ++L) {
+    io.f(W.j[L].ix, store); io.f(W.j[L].iy, store); io.f(W.j[L].iz, store); io.f(W.j[L].im, store);
+    io.d(W.j[L].state, store);
+  }
+  // own body's manifold words stream HBM <-> LDS without touching the register file
+  {
+    WordIO mo{base, n, i, kWMf + mb * 2 * kMfWords, role < 3};
+#pragma nounroll
+    for (int k = 0; k < 2 * kMfWords; ++k) mo.u(lds.w[k * kEnvBlock], store);
+    WordIO eo{base, n, i, kWEdge0 + mb, role < 3};
+    eo.d(W.edge0, store);
+  }
+  io.k = kWTail;
+  io.u(W.touching, store);
+#pragma unroll
+  for (int k = 0; k < 11; ++k) io.f(W.ty[k], store);
+  io.u(W.flags, store);
+  io.f(W.prev_shaping, store);
+}
+
+// obs [N][8]: lanes 0/1 of each quad write the two 16-B halves of their env's row, so a
+// wave's 32 storing lanes cover 512 contiguous bytes.
+__device__ __forceinline__ void store_obs_quad(float* __restrict__ dst, int env, int role, const float (&o)[8]) {
+  if (role == 0) reinterpret_cast<float4*>(dst)[2 * (size_t)env] = make_float4(o[0], o[1], o[2], o[3]);
+  if (role == 1) reinterpret_cast<float4*>(dst)[2 * (size_t)env + 1] = make_float4(o[4], o[5], o[6], o[7]);
+}
+
+// One env.step() of env i by its quad (ppo_lunarlander.py:211 + the reset-on-done of :220-223): the body of
+// lunar_step_kernel, shared with the persistent rollout kernel.  `act` is the already loaded action;
+// o_next receives the next policy input (post-reset where the episode ended).
+struct StepOut {
+  float* obs_out; float* term_obs_out; float* rew_out; uint8_t* terminated_out; uint8_t* truncated_out;
+  uint8_t* done_out; float* ep_ret_out; int32_t* ep_len_out; double* ep_stats;
+};
+
+__device__ __forceinline__ void lunar_step_quad(const LunarState& st, const Lds& lds, int n, int i, int role, bool valid,
+                                                int action_in, uint64_t seed, int64_t env_id0, const StepOut& out,
+                                                float (&o_next)[8]) {
+  float* __restrict__ obs_out = out.obs_out; float* __restrict__ term_obs_out = out.term_obs_out;
+  float* __restrict__ rew_out = out.rew_out; uint8_t* __restrict__ terminated_out = out.terminated_out;
+  uint8_t* __restrict__ truncated_out = out.truncated_out; uint8_t* __restrict__ done_out = out.done_out;
+  float* __restrict__ ep_ret_out = out.ep_ret_out; int32_t* __restrict__ ep_len_out = out.ep_len_out;
+  double* __restrict__ ep_stats = out.ep_stats;
+  const bool lead = role == 0;
+  bool done = false;
+  double ret = 0.0; int len = 0;
+  if (valid) {
+    World W;
+    float o_term[8];
+    world_io(W, lds, role, st.words, n, i, false);
+    const uint64_t env = (uint64_t)(env_id0 + i);
+    const uint32_t episode = st.ep.episode[i];
+    len = st.ep.ep_len[i];
+    const double ret0 = st.ep.ep_ret[i];
+    int act = action_in;
+    act = act < 0 ? 0 : (act > 3 ? 3 : act);
+    uint32_t ep = episode, step_idx = (uint32_t)len;
+    float fx = 0.0f, fy = 0.0f;
+    // pass 0 = the requested step; pass 1 (only where the episode ended and no spare world is
+    // ready) = the new episode's reset(), whose trailing step(0) reuses the one inlined solver.
+#pragma nounroll
+    for (int pass = 0; pass < 2; ++pass) {
+      float o[8], reward; bool terminated;
+      env_step_once(W, lds, role, act, seed, env, ep, step_idx, fx, fy, o, reward, terminated);
+      if (pass == 0) {
+        len += 1;
+        const bool truncated = len >= kMaxSteps;
+        done = terminated || truncated;
+        ret = ret0 + (double)reward;
+        if (lead) {
+          rew_out[i] = reward;
+          if (terminated_out) terminated_out[i] = terminated;
+          if (truncated_out) truncated_out[i] = truncated;
+          if (done_out) done_out[i] = done;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { o_term[k] = o[k]; o_next[k] = o[k]; }
+        if (!done) { if (lead) { st.ep.ep_ret[i] = ret; st.ep.ep_len[i] = len; } break; }
+        ep = episode + 1u; step_idx = 0u; act = 0;
+        // every lane reads the spare flag BEFORE lane 0 rewrites the episode bookkeeping
+        const bool have_spare = st.spare_episode[i] == ep;
+        if (lead) {
+          if (ep_ret_out) ep_ret_out[i] = (float)ret;
+          if (ep_len_out) ep_len_out[i] = len;
+          st.ep.ep_ret[i] = 0.0; st.ep.ep_len[i] = 0; st.ep.episode[i] = ep;
+        }
+        if (have_spare) {                            // next episode already prepared off the critical path
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          world_io(W, lds, role, st.spare_words, n, i, false);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o_next[k] = st.spare_obs[(size_t)k * n + i];
+          break;
+        }
+        init_episode(W, lds, seed, env, ep, fx, fy);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o_next[k] = o[k];
+      }
+    }
+    world_io(W, lds, role, st.words, n, i, true);
+    store_obs_quad(obs_out, i, role, o_next);
+    if (term_obs_out) store_obs_quad(term_obs_out, i, role, o_term);
+  }
+  accumulate_ep_stats(ep_stats, done && lead, ret, len);
+}
+
+}  // namespace lunar
+}  // namespace gymrl

@@ -12,6 +12,7 @@
 // exp/log are the bit-reproducible det_* forms so that the CPU oracle can
 // reproduce integer action draws exactly.
 #include "gymrl_device.hpp"
+#include "policy_device.hpp"
 #include "../../include/gymrl.h"
 
 using namespace gymrl;
@@ -19,52 +20,6 @@ using namespace gymrl;
 namespace {
 
 constexpr int kBlock = 256;
-
-template <int A>
-__device__ __forceinline__ void load_row(const float* __restrict__ p, size_t row, float (&z)[A]) {
-  if constexpr (A == 4) {
-    const float4 v = reinterpret_cast<const float4*>(p)[row];
-    z[0] = v.x; z[1] = v.y; z[2] = v.z; z[3] = v.w;
-  } else if constexpr (A == 2) {
-    const float2 v = reinterpret_cast<const float2*>(p)[row];
-    z[0] = v.x; z[1] = v.y;
-  } else {
-#pragma unroll
-    for (int k = 0; k < A; ++k) z[k] = p[row * A + k];
-  }
-}
-template <int A>
-__device__ __forceinline__ void store_row(float* __restrict__ p, size_t row, const float (&z)[A]) {
-  if constexpr (A == 4) {
-    reinterpret_cast<float4*>(p)[row] = make_float4(z[0], z[1], z[2], z[3]);
-  } else if constexpr (A == 2) {
-    reinterpret_cast<float2*>(p)[row] = make_float2(z[0], z[1]);
-  } else {
-#pragma unroll
-    for (int k = 0; k < A; ++k) p[row * A + k] = z[k];
-  }
-}
-
-// log-softmax pieces shared by all kernels: ln_k = z_k - lse, p_k = e_k / s.
-template <int A>
-__device__ __forceinline__ void log_softmax(const float (&z)[A], float (&ln)[A], float (&p)[A],
-                                            float& H) {
-  float m = z[0];
-#pragma unroll
-  for (int k = 1; k < A; ++k) m = fmaxf(m, z[k]);
-  float e[A];
-  float s = 0.0f;
-#pragma unroll
-  for (int k = 0; k < A; ++k) { e[k] = det_expf(z[k] - m); s += e[k]; }
-  const float lse = m + det_logf(s);
-  H = 0.0f;
-#pragma unroll
-  for (int k = 0; k < A; ++k) {
-    ln[k] = z[k] - lse;
-    p[k] = e[k] / s;
-    H -= p[k] * ln[k];
-  }
-}
 
 // K per-thread doubles -> one row of K doubles per block in partials[block][K].
 template <int K, int BLOCK>
@@ -103,40 +58,10 @@ __global__ __launch_bounds__(kBlock) void categorical_sample_kernel(
   if (og.rew_prev)
     gae_online_compose(og.rew_prev[i], og.done_prev[i], og.val_prev[i], value_in[i], og.gamma, og.gl, og.first,
                        og.last, og.running, og.agg_row, n, i);
-  float z[A], ln[A], p[A], H;
+  float z[A], H, lp;
   load_row<A>(logits, i, z);
-  log_softmax<A>(z, ln, p, H);
-  int a = 0;
-  if (deterministic) {
-    float best = z[0];
-#pragma unroll
-    for (int k = 1; k < A; ++k) if (z[k] > best) { best = z[k]; a = k; }
-  } else {
-    float q[A];
-    if (noise_exp) {
-      load_row<A>(noise_exp, i, q);
-    } else {
-      const uint64_t env = (uint64_t)(env_id0 + i);
-#pragma unroll
-      for (int blk = 0; blk < (A + 3) / 4; ++blk) {
-        const u32x4 r = philox4x32(seed, (uint32_t)env, (uint32_t)(env >> 32), (uint32_t)counter,
-                                   RNG_POLICY | ((uint32_t)((counter >> 32) & 0x3FFFFFu) << 2) | (uint32_t)blk);
-        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (blk * 4 + k < A) q[blk * 4 + k] = -det_logf(u01f_open0(w[k]));
-      }
-    }
-    float best = p[0] / q[0];
-#pragma unroll
-    for (int k = 1; k < A; ++k) {
-      const float c = p[k] / q[k];
-      if (c > best) { best = c; a = k; }
-    }
-  }
-  float lp = ln[0];
-#pragma unroll
-  for (int k = 1; k < A; ++k) if (a == k) lp = ln[k];
+  const int a = categorical_pick<A>(z, noise_exp ? noise_exp + (size_t)i * A : nullptr, seed, (uint64_t)(env_id0 + i),
+                                    counter, deterministic, lp, H);
   act_out[i] = a;
   logp_out[i] = lp;
   if (ent_out) ent_out[i] = H;

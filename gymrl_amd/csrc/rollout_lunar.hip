@@ -1,0 +1,146 @@
+// rollout_lunar.hip — PPO's collect_rollout (ppo_lunarlander.py:198-231) for LunarLander as ONE
+// persistent launch per chunk of vector steps.
+//
+// Launched step by step, a vector step is `lunar_step_kernel` (one wave per 16 envs, 256 waves at
+// N = 4096, every wave on its own SIMD) + the policy forward + the sample kernel, and each launch
+// lasts as long as its SLOWEST wave: with 4096 envs some wave always holds the worst contact
+// configuration (two manifolds x two points on a body), so every step costs ~350 us although the
+// average wave needs ~150 us (`tools/micro_lunar.py 16`).  Nothing couples two workgroups inside
+// a rollout — the policy weights are frozen, envs are independent — so here a workgroup owns its
+// 16 envs for `nsteps` steps and never waits for another one: the rollout costs the mean wave time
+// per step instead of the max.  Per step, inside the workgroup:
+//
+//   all 4 waves  policy forward of the 16 observations (mlp_device.hpp: f32 MFMA, activations and
+//                now also logits/value stay in LDS)
+//   wave 0       folds step t-1 into its GAE chunk map (gae_online_compose), draws the action
+//                (policy_device.hpp: same Philox keys / explicit noise as gymrl_categorical_sample),
+//                writes act/logp/val[t], runs the Box2D step of its 16 envs four lanes per env
+//                (env_lunar_device.hpp, inline reset pass where an episode ended), writes
+//                rew/done/ep_ret[t] and obs[t+1] to the slab and the next observation tile
+//                straight into the forward's LDS input
+//
+// Every arithmetic piece is the same device function the step-by-step path launches, so the slab
+// is bit-identical to `collect_rollout()` without this kernel (tests/test_hip_parity.py).
+#include "env_lunar_device.hpp"
+#include "mlp_device.hpp"
+#include "policy_device.hpp"
+
+using namespace gymrl;
+using namespace gymrl::lunar;
+namespace M = gymrl::mlp;
+
+namespace {
+
+constexpr int kThreads = M::kWaves * 64;
+constexpr int kActions = 4, kObs = 8;
+constexpr int kGaeChunk = 16;        // == gymrl_gae_chunk() (gae.hip kBlkTC)
+constexpr int kDynFloats = M::kBufs * M::kRows * M::kStride + M::kRows * M::kInStride + M::kRows * M::kHeadStride;
+constexpr int kDynBytes = 96 * 1024; // > 80 KB: one workgroup per CU (as mlp_forward_kernel)
+static_assert(kDynFloats * 4 <= kDynBytes, "LDS carve-up");
+
+__global__ __launch_bounds__(kThreads) void rollout_lunar_kernel(gymrl_rollout_lunar_args a, gymrl_mlp_desc d) {
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+  __shared__ uint32_t lds_words[kLdsWords * kEnvBlock];            // the solver's per-lane columns (wave 0)
+  float (*lds)[M::kRows * M::kStride] = reinterpret_cast<float (*)[M::kRows * M::kStride]>(dyn_lds);
+  float* xin = dyn_lds + M::kBufs * M::kRows * M::kStride;
+  float* head = xin + M::kRows * M::kInStride;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int N = a.n_envs, T = a.T;
+  const int m0 = blockIdx.x * M::kRows;
+  const int t_end = a.t0 + a.nsteps;
+  // wave 0's view: four lanes per env
+  const int role = lane & 3, row = lane >> 2, i = m0 + row;
+  const bool valid = i < N;
+  const LunarState st(a.env_state, N);
+  const Lds slds{lds_words + lane};
+  const double gl = (double)(float)(a.gamma * a.lam);              // NEP-50 float32 decay (see gae.hip)
+  if (a.wg_ticks && tid == 0) a.wg_ticks[2 * blockIdx.x] = wall_clock64();   // profiling: 100 MHz ticks
+
+  // observation tile of step t0 -> xin (zero padded to 64 columns once; later steps rewrite columns 0..7)
+  for (int e = tid; e < M::kRows * M::kInStride; e += kThreads) xin[e] = 0.0f;
+  __syncthreads();
+  for (int e = tid; e < M::kRows * kObs; e += kThreads) {
+    const int r = e / kObs, c = e - r * kObs;
+    if (m0 + r < N) xin[r * M::kInStride + c] = a.obs[((size_t)a.t0 * N + m0 + r) * kObs + c];
+  }
+  for (int t = a.t0; t <= t_end; ++t) {
+    const bool tail = t == t_end;                   // only the bootstrap value of the finished rollout is left
+    if (tail && t_end != T) break;
+    __syncthreads();                                // xin of step t is complete
+    M::forward_tile(d, lds, xin, head, m0, N, tid); // logits -> head[row][0..3], value -> head[row][4]
+    if (wave == 0) {
+      float z[kActions];
+#pragma unroll
+      for (int k = 0; k < kActions; ++k) z[k] = head[row * M::kHeadStride + k];
+      const float v = head[row * M::kHeadStride + kActions];
+      if (valid && role == 0) {
+        if (a.gae_running && t > 0) {               // V_t completes step t-1's delta
+          const int tp = t - 1;
+          const size_t o = (size_t)tp * N + i;
+          double2* agg = reinterpret_cast<double2*>(a.gae_workspace) + (size_t)(tp / kGaeChunk) * N;
+          gae_online_compose(a.rew[o], a.done[o], a.val[o], v, a.gamma, gl, (tp % kGaeChunk) == 0,
+                             (tp % kGaeChunk) == kGaeChunk - 1 || tp == T - 1, a.gae_running, agg, N, i);
+        }
+        if (tail) a.next_value[i] = v;
+      }
+      if (!tail) {
+        float lp, H;
+        const size_t o = (size_t)t * N + (valid ? i : 0);
+        const int act = categorical_pick<kActions>(z, a.noise_exp ? a.noise_exp + o * kActions : nullptr, a.seed,
+                                                   (uint64_t)(a.env_id0 + i), a.counter0 + (uint64_t)t, 0, lp, H);
+        if (valid && role == 0) { a.act[o] = act; a.logp[o] = lp; a.val[o] = v; }
+        const StepOut out{a.obs + (size_t)(t + 1) * N * kObs, nullptr, a.rew + (size_t)t * N, nullptr, nullptr,
+                          a.done + (size_t)t * N, a.ep_ret ? a.ep_ret + (size_t)t * N : nullptr, nullptr, a.ep_stats};
+        float o_next[8];
+        lunar_step_quad(st, slds, N, i, role, valid, act, a.seed, a.env_id0, out, o_next);
+        if (valid && role < 2) {                    // next policy input: straight into the forward's LDS tile
+#pragma unroll
+          for (int k = 0; k < 4; ++k) xin[row * M::kInStride + 4 * role + k] = o_next[4 * role + k];
+        }
+      }
+    }
+    if (tail) break;
+  }
+  if (a.wg_ticks && tid == 0) a.wg_ticks[2 * blockIdx.x + 1] = wall_clock64();
+}
+
+}  // namespace
+
+extern "C" {
+
+int gymrl_rollout_lunar(const gymrl_rollout_lunar_args* a, const gymrl_mlp_desc* policy, void* stream) {
+  if (!a || !policy || !a->env_state || !a->obs || !a->act || !a->logp || !a->val || !a->rew || !a->done ||
+      !a->next_value || a->n_envs <= 0 || a->T <= 0 || a->t0 < 0 || a->nsteps < 0 || a->t0 + a->nsteps > a->T)
+    return -22;
+  if (a->gae_running && !a->gae_workspace) return -22;
+  // the policy must be a 2-output network on the LunarLander observation: logits [4] then value [1]
+  int outs = 0, cols = 0;
+  if (policy->n_stages <= 0 || policy->n_stages > GYMRL_MLP_MAX_STAGES) return -22;
+  for (int s = 0; s < policy->n_stages; ++s) {
+    const gymrl_mlp_stage& st = policy->stage[s];
+    if (!st.W || st.in_dim <= 0 || st.out_dim <= 0 || st.in_dim > GYMRL_MLP_MAX_WIDTH || st.src < -1 || st.src > 2 ||
+        st.dst < -1 || st.dst > 2 || (st.dst >= 0 && (st.dst == st.src || st.out_dim > GYMRL_MLP_MAX_WIDTH)) ||
+        (st.src < 0 && st.in_dim != kObs) || st.act < GYMRL_ACT_NONE || st.act > GYMRL_ACT_RELU ||
+        (reinterpret_cast<uintptr_t>(st.W) & 15))
+      return -22;
+    if (st.dst < 0) {
+      if ((outs == 0 && st.out_dim != kActions) || (outs == 1 && st.out_dim != 1) || outs > 1) return -22;
+      ++outs; cols += st.out_dim;
+    }
+  }
+  if (outs != 2 || cols > M::kHeadStride) return -22;
+  if (a->nsteps == 0 && a->t0 != a->T) return 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)rollout_lunar_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDynBytes) !=
+        hipSuccess)
+      return -1000 - (int)hipGetLastError();
+    attr_set = true;
+  }
+  const int blocks = (a->n_envs + M::kRows - 1) / M::kRows;
+  hipLaunchKernelGGL(rollout_lunar_kernel, dim3(blocks), dim3(kThreads), kDynBytes, (hipStream_t)stream, *a, *policy);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

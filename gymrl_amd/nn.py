@@ -92,6 +92,16 @@ class FusedMLP:
         ptrs = tuple(m.bias.data_ptr() for m, _, _, _ in self.stages if m.bias is not None)
         return ops.mlp_desc(table), outs, ptrs
 
+    def descriptor(self, n, device):
+        """The gymrl_mlp_desc of this network for n rows (packs the weights on first use)."""
+        if self._packed is None:
+            self.refresh()
+        key = (n, device)
+        ent = self._cache.get(key)
+        if ent is None or ent[2] != tuple(m.bias.data_ptr() for m, _, _, _ in self.stages if m.bias is not None):
+            ent = self._cache[key] = self._build(n, device)
+        return ent[0]
+
     @torch.no_grad()
     def __call__(self, x, refresh=False):
         from . import ops

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from ._lib import (ACT_NONE, ACT_RELU, ACT_TANH, MLP_MAX_INPUT, MLP_MAX_STAGES, MLP_MAX_WIDTH, GaeOnline,
-                   MlpDesc, PPOCfg, PPOFullCfg, check, lib)
+                   MlpDesc, PPOCfg, PPOFullCfg, RolloutLunarArgs, check, lib)
 
 _vp = C.c_void_p
 
@@ -567,3 +567,21 @@ def heads_bwd(Hac, dlogits, dv, Wa2, Wc2, dZac, dbac, dWa2, dba2, dWc2, dbc2, wo
                                 _ptr(Wc2, torch.float32), _ptr(dZac, torch.float32), _ptr(dbac, torch.float32),
                                 _ptr(dWa2, torch.float32), _ptr(dba2, torch.float32), _ptr(dWc2, torch.float32),
                                 _ptr(dbc2, torch.float32), _ptr(workspace), _stream()), "gymrl_heads_bwd")
+
+
+# ------------------------------------------------------ persistent rollout ---
+def rollout_lunar(env_state, n_envs, seed, env_id0, counter0, obs, act, logp, val, rew, done, ep_ret, next_value, policy_desc,
+                  T, t0, nsteps, gamma, lam, noise_exp=None, gae_running=None, gae_workspace=None, ep_stats=None, wg_ticks=None):
+    """gymrl_rollout_lunar: `nsteps` vector steps of collect_rollout (policy forward, draw, env step, slab writes,
+    online GAE) in one launch; see include/gymrl.h for the slab layout."""
+    a = RolloutLunarArgs()
+    a.env_state, a.n_envs, a.seed, a.env_id0, a.counter0 = _ptr(env_state).value, n_envs, seed, env_id0, counter0
+    a.obs, a.act, a.logp = _ptr(obs, torch.float32).value, _ptr(act, torch.int32).value, _ptr(logp, torch.float32).value
+    a.val, a.rew, a.done = _ptr(val, torch.float32).value, _ptr(rew, torch.float32).value, _ptr(done, torch.uint8).value
+    a.ep_ret, a.next_value = _ptr(ep_ret, torch.float32, True).value, _ptr(next_value, torch.float32).value
+    a.noise_exp = _ptr(noise_exp, torch.float32, True).value
+    a.gae_running, a.gae_workspace = _ptr(gae_running, torch.float64, True).value, _ptr(gae_workspace, None, True).value
+    a.gamma, a.lam, a.ep_stats = gamma, lam, _ptr(ep_stats, torch.float64, True).value
+    a.wg_ticks = _ptr(wg_ticks, torch.int64, True).value
+    a.T, a.t0, a.nsteps = T, t0, nsteps
+    check(lib().gymrl_rollout_lunar(C.byref(a), C.byref(policy_desc), _stream()), "gymrl_rollout_lunar")

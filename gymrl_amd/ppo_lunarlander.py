@@ -59,6 +59,9 @@ class Config:
         self.gae_variant = 1             # 1 = time-blocked scan, 0 = sequential reference order
         self.fused_policy_forward = True  # rollout forward = one gymrl_mlp_forward launch (False: per-layer torch)
         self.fused_update = True          # update forward/backward scheduled by ppo_net (False: torch autograd)
+        self.persistent_rollout = True    # LunarLander: whole chunks of vector steps in one launch (gymrl_rollout_lunar)
+        self.rollout_chunk = 0            # vector steps per persistent launch (0: the whole rollout in one launch —
+                                          # every extra launch boundary waits for the slowest workgroup again)
         self.solved_reward = 200.0
 
 
@@ -233,6 +236,7 @@ class PPOTrainer:
         self._agg_ready = False
         self._parity_noise = None      # tests: f32[rollouts, T, N, A] Exp(1) draws (ops.categorical_sample noise_exp)
         self._parity_indices = []      # tests: per-update [num_epochs, T*N] shuffle orders consumed by update()
+        self._wg_ticks = None          # profiling: i64[2 * ceil(N/16)] start/end ticks of the last persistent launch
         self._eval_env_factory = None  # tests: num_episodes -> env object for eval() (default: a fresh VecEnv)
         self._gae_running = torch.zeros(2, N, dtype=torch.float64, device=self.device)
         self._packed = None      # [T*N, 16] packed rollout records (allocated on first update)
@@ -283,6 +287,8 @@ class PPOTrainer:
         fuse_gae = cfg.gae_variant == 1 and b.N % 4 == 0
         # parity mode: explicit Exp(1) draws f32[rollouts, T, N, A] replace the Philox stream
         noise = None if self._parity_noise is None else self._parity_noise[self.rollout_count]
+        if self._persistent_ok():
+            return self._collect_rollout_persistent(counter0, noise, fuse_gae)
         if cfg.fused_policy_forward:
             self.model.refresh_act()                     # pack the current weights once per rollout
             fwd = lambda o: self.model.act_forward(o, refresh=False)   # noqa: E731
@@ -314,6 +320,39 @@ class PPOTrainer:
             self._agg_ready = True
         # :220-221 episode_rewards.append on done: compacted on the device here, read back by
         # _drain_episode_returns() once the update's kernels are queued (no sync in the rollout)
+        self._finished = True
+        return self._next_value
+
+    def _persistent_ok(self):
+        """gymrl_rollout_lunar covers: the built-in LunarLander env, a policy the one-launch forward supports."""
+        cfg, env = self.cfg, self.env
+        return (cfg.persistent_rollout and cfg.fused_policy_forward and isinstance(env, VecEnv)
+                and env.kind == ops.LUNARLANDER and self.action_dim == 4 and bool(self.model._act_net()))
+
+    def _collect_rollout_persistent(self, counter0, noise, fuse_gae):
+        """:198-231 as ceil(T / rollout_chunk) launches: every workgroup runs its 16 envs through the whole chunk
+        (policy forward, draw, GAE chunk maps, env step + reset-on-done, slab writes) without waiting for the others."""
+        cfg, b, env = self.cfg, self.buffer, self.env
+        net = self.model._act_net()
+        net.refresh()                                  # pack the current weights once per rollout
+        desc = net.descriptor(b.N, self.device)
+        tm = self._timers
+        chunk = int(cfg.rollout_chunk) if int(cfg.rollout_chunk) > 0 else b.T
+        for t0 in range(0, b.T, chunk):
+            n = min(chunk, b.T - t0)
+            if tm is not None:
+                tm.start("rollout_chunk")
+            ops.rollout_lunar(env.state, b.N, env.seed, env.env_id0, counter0, b.states, b.actions, b.log_probs, b.values,
+                              b.rewards, b.dones, b.ep_returns, self._next_value, desc, b.T, t0, n, cfg.gamma,
+                              cfg.gae_lambda, noise_exp=noise, gae_running=self._gae_running if fuse_gae else None,
+                              gae_workspace=self._gae_ws if fuse_gae else None, ep_stats=env.ep_stats,
+                              wg_ticks=self._wg_ticks)
+            if tm is not None:
+                tm.stop("rollout_chunk", n * b.N)
+        b.pos = b.T
+        self.step_count += b.T * b.N
+        self.rollout_count += 1
+        self._agg_ready = bool(fuse_gae)
         self._finished = True
         return self._next_value
 

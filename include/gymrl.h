@@ -323,6 +323,45 @@ int gymrl_mlp_pack(const float* W, int out_dim, int in_dim, float* packed, void*
 int gymrl_mlp_forward(const float* x, int n_rows, int in_dim, const gymrl_mlp_desc* desc,
                       void* stream);
 
+/* ======================================================== persistent rollout */
+/*
+ * P4: PPOTrainer.collect_rollout — ppo_lunarlander.py:198-231 — for LunarLander-v3 as one launch per
+ * chunk of vector steps: policy forward (gymrl_mlp_forward's stages, logits [4] then value [1] as the two
+ * dst == -1 stages; their `out` pointers are ignored), categorical draw, GAE chunk-map composition, env
+ * step with reset-on-done, slab writes.  A workgroup owns 16 envs for all `nsteps` steps and never waits
+ * for another workgroup, so a step costs the mean per-wavefront solver time instead of the slowest
+ * wavefront's.  Bit-identical to the step-by-step sequence gymrl_mlp_forward -> gymrl_categorical_sample
+ * (same seed / counter0 + t / env ids, or the same explicit noise) -> gymrl_env_step.
+ *   obs f32[T+1][N][8] (row t0 must hold the current observations), act i32[T][N], logp/val/rew f32[T][N],
+ *   done u8[T][N], ep_ret f32[T][N] or NULL (written where done), next_value f32[N] (written by the
+ *   launch that reaches t0 + nsteps == T: V(obs[T]), the bootstrap of :225-229), noise_exp f32[T][N][4] or
+ *   NULL, gae_running f64[2][N] + gae_workspace (gymrl_gae_workspace_bytes(T, N)) or NULL for no online
+ *   composition (then gymrl_gae variant 1), ep_stats f64[3] or NULL, wg_ticks: optional load-balance probe.
+ */
+typedef struct {
+  void* env_state;            /* gymrl_env_state_bytes(GYMRL_ENV_LUNARLANDER, n_envs)          */
+  int n_envs;
+  uint64_t seed;
+  int64_t env_id0;
+  uint64_t counter0;          /* Philox counter of step 0 of this rollout (step t uses counter0 + t) */
+  float* obs;
+  int32_t* act;
+  float* logp;
+  float* val;
+  float* rew;
+  uint8_t* done;
+  float* ep_ret;
+  float* next_value;
+  const float* noise_exp;
+  double* gae_running;
+  void* gae_workspace;
+  double gamma, lam;
+  double* ep_stats;
+  unsigned long long* wg_ticks; /* NULL, or u64[2][ceil(N/16)]: start / end of every workgroup in 100 MHz ticks */
+  int T, t0, nsteps;
+} gymrl_rollout_lunar_args;
+int gymrl_rollout_lunar(const gymrl_rollout_lunar_args* args, const gymrl_mlp_desc* policy, void* stream);
+
 /* ===================================================== MLP update path ===== */
 /*
  * The HBM-bound passes of one ActorCritic minibatch update around the library GEMMs —
