@@ -161,10 +161,17 @@ __global__ __launch_bounds__(kTB) void linear_tanh_smallk_kernel(const float* __
   }
 }
 
-__global__ __launch_bounds__(kTB) void tanh_inplace_kernel(float* __restrict__ z, int64_t n4) {
+// z <- tanh(z + bias[col]) (bias == nullptr: no bias); C4 = columns / 4, a power of two.
+__global__ __launch_bounds__(kTB) void tanh_inplace_kernel(float* __restrict__ z, int64_t n4, const float* __restrict__ bias,
+                                                           int C4) {
   f32x4* p = reinterpret_cast<f32x4*>(z);
   for (int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kTB) {
     f32x4 v = p[i];
+    if (bias) {
+      const f32x4 b = reinterpret_cast<const f32x4*>(bias)[i & (C4 - 1)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += b[j];
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = fast_tanhf(v[j]);
     p[i] = v;
@@ -179,6 +186,7 @@ __global__ __launch_bounds__(kTB) void tanh_inplace_kernel(float* __restrict__ z
 // xor butterfly (fixed order).
 template <int A>
 __global__ __launch_bounds__(kTB) void heads_fwd_tanh_kernel(float* __restrict__ Zac, int64_t B, int C,
+                                                             const float* __restrict__ bac,
                                                              const float* __restrict__ Wa2, const float* __restrict__ ba2,
                                                              const float* __restrict__ Wc2, const float* __restrict__ bc2,
                                                              float* __restrict__ logits, float* __restrict__ value) {
@@ -194,6 +202,11 @@ __global__ __launch_bounds__(kTB) void heads_fwd_tanh_kernel(float* __restrict__
 #pragma unroll
   for (int a = 0; a < A; ++a) bias[a] = ba2 ? ba2[a] : 0.0f;
   bias[A] = bc2 ? bc2[0] : 0.0f;
+  f32x4 pa = {0.0f, 0.0f, 0.0f, 0.0f}, pc = {0.0f, 0.0f, 0.0f, 0.0f};      // pre-activation biases of my 4 + 4 columns
+  if (bac) {
+    pa = *reinterpret_cast<const f32x4*>(bac + 4 * m.c4);
+    pc = *reinterpret_cast<const f32x4*>(bac + C + 4 * m.c4);
+  }
   const int64_t stride = (int64_t)gridDim.x * (kTB / 64) * m.rpw;
   const int64_t r0 = ((int64_t)blockIdx.x * (kTB / 64) + (threadIdx.x >> 6)) * m.rpw + m.r_in;
   // every lane of a wave runs the same number of iterations (the butterfly needs all lanes)
@@ -206,7 +219,7 @@ __global__ __launch_bounds__(kTB) void heads_fwd_tanh_kernel(float* __restrict__
       ha = *reinterpret_cast<const f32x4*>(Zac + o);
       hc = *reinterpret_cast<const f32x4*>(Zac + o + C);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { ha[j] = fast_tanhf(ha[j]); hc[j] = fast_tanhf(hc[j]); }
+      for (int j = 0; j < 4; ++j) { ha[j] = fast_tanhf(ha[j] + pa[j]); hc[j] = fast_tanhf(hc[j] + pc[j]); }
       *reinterpret_cast<f32x4*>(Zac + o) = ha;
       *reinterpret_cast<f32x4*>(Zac + o + C) = hc;
     }
@@ -416,13 +429,14 @@ int gymrl_linear_tanh_smallk(const float* x, const float* W, const float* b, int
   return 0;
 }
 
-int gymrl_tanh_inplace(float* z, int64_t n, void* stream) {
+int gymrl_tanh_inplace(float* z, int64_t n, const float* bias, int C, void* stream) {
   if (!z || n < 0 || (n & 3) || !al16(z)) return -22;
+  if (bias && (C < 4 || (C & (C - 1)) || (n % C) || !al16(bias))) return -22;
   if (n == 0) return 0;
   const int64_t n4 = n / 4;
   int64_t nb = (n4 + kTB - 1) / kTB;
   if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(tanh_inplace_kernel, dim3((unsigned)nb), dim3(kTB), 0, (hipStream_t)stream, z, n4);
+  hipLaunchKernelGGL(tanh_inplace_kernel, dim3((unsigned)nb), dim3(kTB), 0, (hipStream_t)stream, z, n4, bias, bias ? C / 4 : 1);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
@@ -459,14 +473,14 @@ int gymrl_linear_smallk_bwd(const float* dH, const float* H, const float* x, int
   return 0;
 }
 
-int gymrl_heads_fwd_tanh(float* Zac, int64_t B, int C, int A, const float* Wa2, const float* ba2, const float* Wc2,
-                         const float* bc2, float* logits, float* value, void* stream) {
-  if (!Zac || !Wa2 || !Wc2 || !logits || !value || B < 0 || !pow2_cols(C) || !al16(Zac)) return -22;
+int gymrl_heads_fwd_tanh(float* Zac, int64_t B, int C, int A, const float* bac, const float* Wa2, const float* ba2,
+                         const float* Wc2, const float* bc2, float* logits, float* value, void* stream) {
+  if (!Zac || !Wa2 || !Wc2 || !logits || !value || B < 0 || !pow2_cols(C) || !al16(Zac) || (bac && !al16(bac))) return -22;
   if (B == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(grid_for(B, C)), block(kTB);
-  if (A == 4) hipLaunchKernelGGL(heads_fwd_tanh_kernel<4>, grid, block, 0, s, Zac, B, C, Wa2, ba2, Wc2, bc2, logits, value);
-  else if (A == 2) hipLaunchKernelGGL(heads_fwd_tanh_kernel<2>, grid, block, 0, s, Zac, B, C, Wa2, ba2, Wc2, bc2, logits, value);
+  if (A == 4) hipLaunchKernelGGL(heads_fwd_tanh_kernel<4>, grid, block, 0, s, Zac, B, C, bac, Wa2, ba2, Wc2, bc2, logits, value);
+  else if (A == 2) hipLaunchKernelGGL(heads_fwd_tanh_kernel<2>, grid, block, 0, s, Zac, B, C, bac, Wa2, ba2, Wc2, bc2, logits, value);
   else return -22;
   GYMRL_CHECK_LAUNCH();
   return 0;

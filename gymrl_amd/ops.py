@@ -528,8 +528,10 @@ def linear_tanh_smallk(x, W, b, out):
     return out
 
 
-def tanh_inplace(z):
-    check(lib().gymrl_tanh_inplace(_ptr(z, torch.float32), C.c_int64(z.numel()), _stream()), "gymrl_tanh_inplace")
+def tanh_inplace(z, bias=None):
+    """z <- tanh(z + bias) in place; bias [C] broadcasts over the rows of z [..., C]."""
+    check(lib().gymrl_tanh_inplace(_ptr(z, torch.float32), C.c_int64(z.numel()), _ptr(bias, torch.float32, True),
+                                   C.c_int(z.shape[-1]), _stream()), "gymrl_tanh_inplace")
     return z
 
 
@@ -550,11 +552,11 @@ def linear_smallk_bwd(dH, H, x, dW, db, workspace):
                                         _ptr(db, torch.float32), _ptr(workspace), _stream()), "gymrl_linear_smallk_bwd")
 
 
-def heads_fwd_tanh(Zac, Wa2, ba2, Wc2, bc2, logits, value):
+def heads_fwd_tanh(Zac, Wa2, ba2, Wc2, bc2, logits, value, bac=None):
     """Zac [B, 2C] -> tanh in place + logits [B, A] + value [B] (include/gymrl.h gymrl_heads_fwd_tanh)."""
     B, C2 = Zac.shape
     check(lib().gymrl_heads_fwd_tanh(_ptr(Zac, torch.float32), C.c_int64(B), C.c_int(C2 // 2), C.c_int(Wa2.shape[0]),
-                                     _ptr(Wa2, torch.float32), _ptr(ba2, torch.float32, True), _ptr(Wc2, torch.float32),
+                                     _ptr(bac, torch.float32, True), _ptr(Wa2, torch.float32), _ptr(ba2, torch.float32, True), _ptr(Wc2, torch.float32),
                                      _ptr(bc2, torch.float32, True), _ptr(logits, torch.float32),
                                      _ptr(value, torch.float32), _stream()), "gymrl_heads_fwd_tanh")
 

@@ -78,6 +78,7 @@ class FusedActorCriticUpdate:
         self._x = None
         self.timers = None      # bench.py: KernelTimers bracketing the hand-written HBM passes
         self.fused_heads_forward = True
+        self.bias_in_gemm = False
 
     def _timed(self, name, units, fn, *args):
         tm = self.timers
@@ -96,15 +97,22 @@ class FusedActorCriticUpdate:
             raise ValueError("minibatch larger than the buffers")
         H1, H2, Hac = self.H1[:B], self.H2[:B], self.Hac[:B]
         self._timed("linear_tanh_smallk", B, ops.linear_tanh_smallk, x, m.shared[0].weight, m.shared[0].bias, H1)
-        torch.addmm(m.shared[2].bias, H1, m.shared[2].weight.t(), out=H2)
-        self._timed("tanh_inplace", H2.numel(), ops.tanh_inplace, H2)
-        torch.addmm(self.bac, H2, self.Wac.t(), out=Hac)
+        if self.bias_in_gemm:                     # library GEMM with its bias epilogue
+            torch.addmm(m.shared[2].bias, H1, m.shared[2].weight.t(), out=H2)
+            self._timed("tanh_inplace", H2.numel(), ops.tanh_inplace, H2)
+            torch.addmm(self.bac, H2, self.Wac.t(), out=Hac)
+            bac = None
+        else:                                     # plain GEMMs; the biases ride on the passes that follow anyway
+            torch.mm(H1, m.shared[2].weight.t(), out=H2)
+            self._timed("tanh_inplace", H2.numel(), ops.tanh_inplace, H2, m.shared[2].bias)
+            torch.mm(H2, self.Wac.t(), out=Hac)
+            bac = self.bac
         logits, value = self.logits[:B], self.value[:B]
         if self.fused_heads_forward:
             self._timed("heads_fwd_tanh", B, ops.heads_fwd_tanh, Hac, m.actor[2].weight, m.actor[2].bias,
-                        m.critic[2].weight, m.critic[2].bias, logits, value)
+                        m.critic[2].weight, m.critic[2].bias, logits, value, bac)
         else:                                     # tanh pass + two skinny library GEMMs on views of Hac
-            self._timed("tanh_inplace", Hac.numel(), ops.tanh_inplace, Hac)
+            self._timed("tanh_inplace", Hac.numel(), ops.tanh_inplace, Hac, bac)
             torch.addmm(m.actor[2].bias, Hac[:, :H], m.actor[2].weight.t(), out=logits)
             torch.addmm(m.critic[2].bias, Hac[:, H:], m.critic[2].weight.t(), out=value)
         self._x = x

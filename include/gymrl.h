@@ -372,12 +372,13 @@ int gymrl_rollout_lunar(const gymrl_rollout_lunar_args* args, const gymrl_mlp_de
  *
  *   linear_tanh_smallk : out = tanh(x W^T + b), x [B, D], W [C, D], D in {2,3,4,8}
  *                        (shared.0: Linear(obs, hidden) + Tanh)
- *   tanh_inplace       : z <- tanh(z) on n floats (after a library GEMM with bias)
+ *   tanh_inplace       : z <- tanh(z + bias[col]) on n floats = rows of C columns (bias NULL: none) after a
+ *                        library GEMM; the bias rides on this pass, the GEMM runs without an epilogue
  *   tanh_bwd_colsum    : dH <- dH * (1 - H^2) in place; colsum_out[c] = sum_r dH[r][c]
  *                        (Tanh backward + the bias gradient of the Linear below it)
  *   linear_smallk_bwd  : dZ = dH * (1 - H^2) (never stored); dW [C, D] = dZ^T x; db [C] = colsum dZ
- *   heads_fwd_tanh     : Zac [B, 2C] = pre-activations of actor.0 | critic.0 (one N = 2C GEMM, bias
- *                        included) -> Hac = tanh(Zac) in place AND logits [B, A] = Ha Wa2^T + ba2,
+ *   heads_fwd_tanh     : Zac [B, 2C] = pre-activations of actor.0 | critic.0 (one N = 2C GEMM; their biases
+ *                        bac [2C] are added here, NULL if the GEMM already did) -> Hac = tanh(Zac + bac) in place AND logits [B, A] = Ha Wa2^T + ba2,
  *                        value [B] = Hc Wc2^T + bc2 from the tanh values still in registers
  *                        (actor.0/critic.0's Tanh + actor.2 + critic.2 forward in one pass)
  *   heads_bwd          : Hac [B, 2C] = [Ha | Hc], the Tanh outputs of actor.0 / critic.0;
@@ -393,13 +394,14 @@ int gymrl_rollout_lunar(const gymrl_rollout_lunar_args* args, const gymrl_mlp_de
 size_t gymrl_mlp_train_workspace_bytes(int C, int D, int A);
 int gymrl_linear_tanh_smallk(const float* x, const float* W, const float* b, int64_t B, int D, int C,
                              float* out, void* stream);
-int gymrl_tanh_inplace(float* z, int64_t n, void* stream);
+int gymrl_tanh_inplace(float* z, int64_t n, const float* bias, int C, void* stream);
 int gymrl_tanh_bwd_colsum(float* dH, const float* H, int64_t B, int C, float* colsum_out,
                           void* workspace, void* stream);
 int gymrl_linear_smallk_bwd(const float* dH, const float* H, const float* x, int64_t B, int D, int C,
                             float* dW, float* db, void* workspace, void* stream);
-int gymrl_heads_fwd_tanh(float* Zac, int64_t B, int C, int A, const float* Wa2, const float* ba2,
-                         const float* Wc2, const float* bc2, float* logits, float* value, void* stream);
+int gymrl_heads_fwd_tanh(float* Zac, int64_t B, int C, int A, const float* bac, const float* Wa2,
+                         const float* ba2, const float* Wc2, const float* bc2, float* logits, float* value,
+                         void* stream);
 int gymrl_heads_bwd(const float* Hac, const float* dlogits, const float* dv, int64_t B, int C, int A,
                     const float* Wa2, const float* Wc2, float* dZac, float* dbac, float* dWa2,
                     float* dba2, float* dWc2, float* dbc2, void* workspace, void* stream);

@@ -63,7 +63,22 @@ def main():
         out.setdefault("fused_update_ms(heads_fwd_tanh)", []).append(round(timeit(fused_step), 3))
         fu.fused_heads_forward = False
         out.setdefault("fused_update_ms(tanh + 2 head GEMMs)", []).append(round(timeit(fused_step), 3))
+        fu.fused_heads_forward, fu.bias_in_gemm = True, True
+        out.setdefault("fused_update_ms(bias in the GEMM epilogue)", []).append(round(timeit(fused_step), 3))
+        fu.bias_in_gemm = False
     out["autograd_update_ms"] = [round(timeit(autograd_step), 3)]
+    if os.environ.get("GYMRL_TRY_TUNABLE"):
+        import torch.cuda.tunable as tn
+        tn.enable(True)
+        tn.tuning_enable(True)
+        tn.set_max_tuning_duration(50)
+        tn.set_max_tuning_iterations(20)
+        tn.set_filename("/tmp/tunableop.csv")
+        fu.fused_heads_forward = True
+        fused_step()
+        torch.cuda.synchronize()
+        tn.tuning_enable(False)
+        out["fused_update_ms(tunable GEMMs)"] = [round(timeit(fused_step), 3) for _ in range(2)]
     print(json.dumps(out, indent=1))
 
 
