@@ -38,21 +38,7 @@ __global__ __launch_bounds__(kEnvBlock) void lunar_refill_kernel(void* buf, int 
   const int i = blockIdx.x * kEnvsPerBlock + (threadIdx.x >> 2);
   if (i >= n) return;
   const uint32_t want = st.ep.episode[i] + 1u;
-  if (st.spare_episode[i] == want) return;  // uniform across the quad
-  World W;
-  float fx, fy, rew, o[8]; bool term;
-  const uint64_t env = (uint64_t)(env_id0 + i);
-  init_episode(W, lds, seed, env, want, fx, fy);
-  env_step_once(W, lds, role, 0, seed, env, want, 0u, fx, fy, o, rew, term);
-  world_io(W, lds, role, st.spare_words, n, i, true);
-  if (role < 2) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) st.spare_obs[(size_t)(4 * role + k) * n + i] = o[4 * role + k];
-  }
-  __threadfence();                      // world before flag (a concurrent step kernel may poll it)
-  // the flag must follow every lane's stores: lanes 1,2 wrote manifold words
-  __builtin_amdgcn_wave_barrier();
-  if (role == 0) st.spare_episode[i] = want;
+  lunar_refill_quad(st, lds, n, i, role, st.spare_episode[i] != want, want, seed, env_id0);
 }
 
 __global__ __launch_bounds__(kEnvBlock) void lunar_step_kernel(

@@ -1057,6 +1057,29 @@ __device__ __forceinline__ void store_obs_quad(float* __restrict__ dst, int env,
   if (role == 1) reinterpret_cast<float4*>(dst)[2 * (size_t)env + 1] = make_float4(o[4], o[5], o[6], o[7]);
 }
 
+// Builds the spare world of episode `want` of env i (reset() of that episode incl. its trailing step(0)) and
+// publishes it: the body of lunar_refill_kernel, shared with the persistent rollout kernel (whose wave 1
+// runs it while wave 0 steps).  Call with a quad-uniform `need`.
+__device__ __forceinline__ void lunar_refill_quad(const LunarState& st, const Lds& lds, int n, int i, int role, bool need,
+                                                  uint32_t want, uint64_t seed, int64_t env_id0) {
+  if (need) {
+    World W;
+    float fx, fy, rew, o[8]; bool term;
+    const uint64_t env = (uint64_t)(env_id0 + i);
+    init_episode(W, lds, seed, env, want, fx, fy);
+    env_step_once(W, lds, role, 0, seed, env, want, 0u, fx, fy, o, rew, term);
+    world_io(W, lds, role, st.spare_words, n, i, true);
+    if (role < 2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) st.spare_obs[(size_t)(4 * role + k) * n + i] = o[4 * role + k];
+    }
+    __threadfence();                      // world before flag (a concurrent step may poll it)
+  }
+  // the flag must follow every lane's stores: lanes 1,2 wrote manifold words
+  __builtin_amdgcn_wave_barrier();
+  if (need && role == 0) st.spare_episode[i] = want;
+}
+
 // One env.step() of env i by its quad (ppo_lunarlander.py:211 + the reset-on-done of :220-223): the body of
 // lunar_step_kernel, shared with the persistent rollout kernel.  `act` is the already loaded action;
 // o_next receives the next policy input (post-reset where the episode ended).
