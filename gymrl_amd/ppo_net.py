@@ -79,6 +79,8 @@ class FusedActorCriticUpdate:
         self.timers = None      # bench.py: KernelTimers bracketing the hand-written HBM passes
         self.fused_heads_forward = True
         self.bias_in_gemm = False
+        self.overlap_dw = False     # dW GEMMs on a side stream under the HBM passes: measured 3.255 vs 3.23 ms, no gain
+        self._side = torch.cuda.Stream(device=dev)
 
     def _timed(self, name, units, fn, *args):
         tm = self.timers
@@ -141,10 +143,31 @@ class FusedActorCriticUpdate:
         self._timed("heads_bwd", B, ops.heads_bwd, Hac, dlogits, dvalues.view(-1), m.actor[2].weight,
                     m.critic[2].weight, dZac, self.dbac, m.actor[2].weight.grad, m.actor[2].bias.grad,
                     m.critic[2].weight.grad, m.critic[2].bias.grad, self.ws)
-        self._dw(dZac, H2, self.dWac)
+        if not self.overlap_dw:
+            self._dw(dZac, H2, self.dWac)
+            torch.mm(dZac, self.Wac, out=dH2)
+            self._timed("tanh_bwd_colsum", B, ops.tanh_bwd_colsum, dH2, H2, m.shared[2].bias.grad, self.ws)
+            self._dw(dH2, H1, m.shared[2].weight.grad)
+            torch.mm(dH2, m.shared[2].weight, out=dH1)
+            self._timed("linear_smallk_bwd", B, ops.linear_smallk_bwd, dH1, H1, x, m.shared[0].weight.grad,
+                        m.shared[0].bias.grad, self.ws)
+            return
+        # The weight-gradient GEMMs (MFMA-bound, off the critical path) run on a side stream under the
+        # HBM-bound passes of the main stream: dWac under tanh_bwd_colsum, dW2 under linear_smallk_bwd.
+        main, side = torch.cuda.current_stream(), self._side
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            self._dw(dZac, H2, self.dWac)
         torch.mm(dZac, self.Wac, out=dH2)
         self._timed("tanh_bwd_colsum", B, ops.tanh_bwd_colsum, dH2, H2, m.shared[2].bias.grad, self.ws)
-        self._dw(dH2, H1, m.shared[2].weight.grad)
+        ev2 = torch.cuda.Event()
+        ev2.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev2)
+            self._dw(dH2, H1, m.shared[2].weight.grad)
         torch.mm(dH2, m.shared[2].weight, out=dH1)
         self._timed("linear_smallk_bwd", B, ops.linear_smallk_bwd, dH1, H1, x, m.shared[0].weight.grad,
                     m.shared[0].bias.grad, self.ws)
+        main.wait_stream(side)                     # the optimiser and the next forward see every gradient / free buffer

@@ -63,6 +63,9 @@ def main():
         out.setdefault("fused_update_ms(heads_fwd_tanh)", []).append(round(timeit(fused_step), 3))
         fu.fused_heads_forward = False
         out.setdefault("fused_update_ms(tanh + 2 head GEMMs)", []).append(round(timeit(fused_step), 3))
+        fu.fused_heads_forward, fu.overlap_dw = True, False
+        out.setdefault("fused_update_ms(dW GEMMs on the main stream)", []).append(round(timeit(fused_step), 3))
+        fu.overlap_dw = True
         fu.fused_heads_forward, fu.bias_in_gemm = True, True
         out.setdefault("fused_update_ms(bias in the GEMM epilogue)", []).append(round(timeit(fused_step), 3))
         fu.bias_in_gemm = False
