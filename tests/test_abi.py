@@ -44,6 +44,40 @@ def test_bad_arguments_return_einval_without_gpu():
     assert L.gymrl_soft_update(null, null, ctypes.c_int64(8), ctypes.c_double(0.005), null) == -22
 
 
+def test_new_entry_points_validate_arguments_without_gpu():
+    """Argument validation happens before any HIP call: NULL pointers, unsupported shapes and
+    inconsistent descriptors return -EINVAL (22) on a machine with no GPU at all."""
+    from gymrl_amd import _lib
+    L = _lib.lib()
+    null, i64, dbl = ctypes.c_void_p(None), ctypes.c_int64, ctypes.c_double
+    assert L.gymrl_mlp_packed_floats(4, 8) == 1 * 4 * 256 and L.gymrl_mlp_packed_floats(256, 256) == 16 * 16 * 256
+    assert L.gymrl_mlp_packed_floats(0, 8) == 0
+    assert L.gymrl_mlp_pack(null, 4, 8, null, null) == -22
+    desc = _lib.MlpDesc()
+    desc.n_stages = 0
+    fake = ctypes.c_void_p(256)                       # never dereferenced: validation fails first
+    assert L.gymrl_mlp_forward(fake, 16, 8, ctypes.byref(desc), null) == -22          # no stages
+    desc.n_stages = 1
+    desc.stage[0].W, desc.stage[0].in_dim, desc.stage[0].out_dim = 256, 8, 4
+    desc.stage[0].src, desc.stage[0].dst, desc.stage[0].act = -1, 1, 7
+    assert L.gymrl_mlp_forward(fake, 16, 8, ctypes.byref(desc), null) == -22          # unknown activation
+    desc.stage[0].act, desc.stage[0].dst = 0, -1
+    assert L.gymrl_mlp_forward(fake, 16, 8, ctypes.byref(desc), null) == -22          # dst == -1 without `out`
+    assert L.gymrl_mlp_forward(fake, 16, 100, ctypes.byref(desc), null) == -22         # input wider than supported
+    assert L.gymrl_mlp_train_workspace_bytes(256, 8, 4) >= 4 * 1024 * 9 * 256
+    assert L.gymrl_linear_tanh_smallk(fake, fake, null, i64(8), 8, 48, fake, null) == -22     # C not a power of two
+    assert L.gymrl_linear_tanh_smallk(fake, fake, null, i64(8), 5, 64, fake, null) == -22     # unsupported input width
+    assert L.gymrl_tanh_inplace(fake, i64(6), null, 0, null) == -22                            # n % 4 != 0
+    assert L.gymrl_heads_bwd(fake, fake, fake, i64(8), 64, 3, fake, fake, fake, fake, fake, fake, fake, fake, fake,
+                             null) == -22                                                      # A not in {2, 4}
+    assert L.gymrl_heads_fwd_tanh(null, i64(8), 64, 4, null, fake, null, fake, null, fake, fake, null) == -22
+    args = _lib.RolloutLunarArgs()
+    assert L.gymrl_rollout_lunar(ctypes.byref(args), ctypes.byref(desc), null) == -22          # NULL slabs
+    # empty work is a no-op that returns 0 without launching anything
+    assert L.gymrl_tanh_inplace(fake, i64(0), null, 0, null) == 0
+    assert L.gymrl_linear_tanh_smallk(fake, fake, null, i64(0), 8, 64, fake, null) == 0
+
+
 def test_ops_refuse_cpu_tensors():
     import pytest
     import torch
