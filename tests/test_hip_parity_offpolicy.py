@@ -139,6 +139,29 @@ def test_sumtree_update_order_exact(dev, oracle, cap):
         assert np.array_equal(idx.cpu().numpy(), i_ref)
 
 
+@pytest.mark.parametrize("cap,B", [(4096, 513), (5000, 3000), (20000, 8192), (1 << 20, 8192)])
+def test_sumtree_large_batches_exact(dev, oracle, cap, B):
+    """The LDS-staged and sort-based passes (512 < B <= 8192 with explicit indices; 8192-row consecutive stores)
+    keep the reference's per-node addition order: float64 tree bit-identical to the sequential loop, with heavy
+    duplication (indices from a narrow range), a non-power-of-two and the Rainbow-sized 2^20 capacity."""
+    from gymrl_amd import ops
+    rng = np.random.default_rng(cap + B)
+    tree = torch.zeros(2 * cap - 1, dtype=torch.float64, device=dev)
+    ref = oracle.SumTree(cap)
+    ws = ops.per_workspace(8192, dev)
+    for rnd, spread in enumerate((cap, max(8, B // 50), cap)):
+        start = int(rng.integers(0, cap))
+        n = min(8192, cap)
+        ops.per_update(tree, cap, n, ws, idx_start=start, prio_scalar=0.5 + rnd)       # N-row store (may wrap)
+        ref.update_many(idx_start=start, prio_scalar=0.5 + rnd, B=n)
+        assert np.array_equal(tree.cpu().numpy(), ref.tree), ("store", rnd)
+        idx = rng.integers(0, spread, size=B).astype(np.int32)
+        pr = rng.random(B) * 3 + 1e-3
+        ops.per_update(tree, cap, B, ws, idx=t(idx, dev), prio=t(pr, dev))
+        ref.update_many(idx=idx, prio=pr)
+        assert np.array_equal(tree.cpu().numpy(), ref.tree), ("update", rnd)
+
+
 def test_sumtree_golden(dev):
     from gymrl_amd import ops
     g = load_golden("sumtree")
