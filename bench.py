@@ -222,6 +222,9 @@ def report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev)
     if head is None:
         head = dict(kernel=gae_loss["kernel"], achieved=gae_loss["in_run"]["achieved"], frac=gae_loss["in_run"]["frac"],
                     traffic=traffic, bytes_per_launch=pass_bytes, launch_s=gae_s + loss_s_per_pass)
+    if pm is not None and "rollout_lunar" in pm and "rollout_chunk" in kernels:
+        # the largest single kernel of the step is ALU-latency bound, not HBM / MFMA bound: its PMC evidence
+        kernels["rollout_chunk"]["pmc"] = {k: pm["rollout_lunar"][k] for k in ("valu_issue_slots_used", "bound")}
     roofline = dict(bound="hbm", achieved=head["achieved"], peak=HBM_PEAK / 1e9, unit="GB/s", frac=head["frac"],
                     traffic=head["traffic"], kernel=head["kernel"], bytes_per_launch=head["bytes_per_launch"],
                     launch_s=head["launch_s"], gae_loss_pass=gae_loss, kernels=kernels)

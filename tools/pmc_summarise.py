@@ -4,7 +4,11 @@
 every hand-written HBM-bound kernel.  FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled on
 gfx950 (MI355X_MICROARCH.md, section HBM: wide coalesced reads are tallied at half their bytes).
 
-    python tools/pmc_summarise.py <fetch.csv> <write.csv> <out.json>
+    python tools/pmc_summarise.py <fetch.csv> <write.csv> <out.json> [<rollout_sq.csv> <rollout_trace.csv>]
+
+The optional pair is the SQ-counter pass over the persistent rollout kernel (profiles/README.md): it adds
+`rollout_lunar` = wave-instruction counts, duration and the fraction of the chip's VALU issue slots used
+(a wave64 VALU instruction holds its SIMD for 4 cycles; 1024 SIMDs).
 """
 import csv
 import json
@@ -64,6 +68,18 @@ def main():
     # keys bench.py reads
     res["gae"]["hbm_bytes_per_transition"] = res["gae"]["hbm_bytes_per_unit"]
     res["ppo_loss"]["hbm_bytes_per_sample"] = res["ppo_loss"]["hbm_bytes_per_unit"]
+    if len(sys.argv) >= 6:
+        sq = defaultdict(list)
+        for r in csv.DictReader(open(sys.argv[4])):
+            sq[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        tr = [r for r in csv.DictReader(open(sys.argv[5])) if "rollout_lunar" in r["Kernel_Name"]]
+        dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9 for r in tr]
+        valu, cyc = sq["SQ_INSTS_VALU"][0], sq["GRBM_GUI_ACTIVE"][0] / 8.0          # GRBM_GUI_ACTIVE sums the 8 XCDs
+        res["rollout_lunar"] = {"launch": "T = 512 vector steps x 4096 envs", "duration_s": dur[0], "cycles": cyc,
+                                "wave_insts_valu": valu, "wave_insts_salu": sq["SQ_INSTS_SALU"][0],
+                                "wave_insts_lds": sq["SQ_INSTS_LDS"][0],
+                                "valu_issue_slots_used": valu * 4.0 / (1024.0 * cyc),
+                                "bound": "ALU latency: one dependent chain per workgroup, ~7 cycles per instruction"}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: (round(v["hbm_bytes_per_unit"], 2), v["algorithmic_bytes_per_unit"]) for k, v in res.items()
                       if isinstance(v, dict) and "hbm_bytes_per_unit" in v}, indent=1))
