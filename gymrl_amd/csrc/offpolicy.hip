@@ -7,6 +7,7 @@
 //   A1  gymrl_sac_sample_fwd/bwd sac_pendulum.py:76-87
 //   A4  gymrl_sac_target / _critic_loss / _actor_loss / _alpha_step   sac_pendulum.py:233-263
 //   N1-N3 gymrl_running_norm / gymrl_reward_scaling   utils/normalization.py:4-52
+//   8f.3 gymrl_noisy_action / gymrl_mse_loss / gymrl_neg_mean_loss   ddpg_pendulum.py:143-185, td3_pendulum.py:164-213
 //
 // All of these are per-sample elementwise maps over B <= a few thousand rows of <= 8
 // words: launch-latency bound at the reference batch sizes, HBM-streaming at large B.
@@ -321,6 +322,55 @@ __global__ void reward_scaling_kernel(const float* __restrict__ r, const uint8_t
   stats[0] = n; stats[2] = (double)mean; stats[3] = S; stats[4] = std;
 }
 
+// ---------------------------------------------------------------- TD3 / DDPG ---
+// Gaussian action noise.  mode 0 = exploration in select_action (ddpg_pendulum.py:143-147,
+// td3_pendulum.py:164-168): numpy float64 — clip(float64(mu) + eps * std, -bound, bound), stored as
+// float32 when the transition is batched (:163).  mode 1 = target-policy smoothing
+// (td3_pendulum.py:191-196): torch float32 — n = clamp(eps * std, -clip, clip); clamp(mu + n, +-bound).
+// eps: explicit N(0,1) draws (f64, parity mode) or NULL -> Box-Muller on Philox(seed, counter, element).
+__global__ __launch_bounds__(kBlock) void noisy_action_kernel(const float* __restrict__ mu, const double* __restrict__ eps,
+                                                              uint64_t seed, uint64_t counter, int64_t n, int mode,
+                                                              double std, float noise_clip, float bound,
+                                                              float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const double e = eps ? eps[i] : (double)box_muller(seed, counter, 2u, (uint32_t)i);
+  if (mode == 0) {
+    double a = (double)mu[i] + e * std;
+    a = a < -(double)bound ? -(double)bound : (a > (double)bound ? (double)bound : a);
+    out[i] = (float)a;
+  } else {
+    float nz = (float)e * (float)std;
+    nz = fminf(fmaxf(nz, -noise_clip), noise_clip);
+    out[i] = fminf(fmaxf(mu[i] + nz, -bound), bound);
+  }
+}
+
+// F.mse_loss(q, y) forward + backward for one critic (ddpg_pendulum.py:178-179): dq = 2 (q - y) / B.
+__global__ __launch_bounds__(kBlock) void mse_kernel(const float* __restrict__ q, const float* __restrict__ y, int B,
+                                                     float* __restrict__ dq, double* __restrict__ partials) {
+  double acc[1] = {0.0};
+  const float invB = 1.0f / (float)B;
+  for (int b = blockIdx.x * kBlock + threadIdx.x; b < B; b += gridDim.x * kBlock) {
+    const float e = q[b] - y[b];
+    dq[b] = 2.0f * e * invB;
+    acc[0] += (double)(e * e);
+  }
+  block_partials<1>(acc, partials);
+}
+
+// actor loss -mean(Q(s, mu(s))) (ddpg_pendulum.py:185, td3_pendulum.py:213): dq = -1/B, sum = sum q.
+__global__ __launch_bounds__(kBlock) void neg_mean_kernel(const float* __restrict__ q, int B, float* __restrict__ dq,
+                                                          double* __restrict__ partials) {
+  double acc[1] = {0.0};
+  const float g = -1.0f / (float)B;
+  for (int b = blockIdx.x * kBlock + threadIdx.x; b < B; b += gridDim.x * kBlock) {
+    dq[b] = g;
+    acc[0] += (double)q[b];
+  }
+  block_partials<1>(acc, partials);
+}
+
 }  // namespace
 
 extern "C" {
@@ -449,6 +499,38 @@ int gymrl_reward_scaling(const float* r, const uint8_t* done, int N, double gamm
   if (N == 0) return 0;
   hipLaunchKernelGGL(reward_scaling_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, r, done, N, gamma, R,
                      stats, y_out);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_noisy_action(const float* mu, const double* eps, uint64_t seed, uint64_t counter, int64_t n, int mode,
+                       double std, double noise_clip, double bound, float* out, void* stream_) {
+  if (!mu || !out || n < 0 || (mode != 0 && mode != 1) || std < 0.0 || bound <= 0.0 || (mode == 1 && noise_clip <= 0.0))
+    return -22;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(noisy_action_kernel, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream_, mu, eps, seed,
+                     counter, n, mode, std, (float)noise_clip, (float)bound, out);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_mse_loss(const float* q, const float* y, int B, float* dq_out, double* sum_out, void* workspace,
+                   void* stream_) {
+  if (!q || !y || !dq_out || !sum_out || !workspace || B <= 0) return -22;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int nb = grid_for(B);
+  hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(kBlock), 0, stream, q, y, B, dq_out, (double*)workspace);
+  hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(kBlock), 0, stream, (const double*)workspace, nb, sum_out);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_neg_mean_loss(const float* q, int B, float* dq_out, double* sum_out, void* workspace, void* stream_) {
+  if (!q || !dq_out || !sum_out || !workspace || B <= 0) return -22;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int nb = grid_for(B);
+  hipLaunchKernelGGL(neg_mean_kernel, dim3(nb), dim3(kBlock), 0, stream, q, B, dq_out, (double*)workspace);
+  hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(kBlock), 0, stream, (const double*)workspace, nb, sum_out);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

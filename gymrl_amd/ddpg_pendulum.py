@@ -1,0 +1,80 @@
+"""DDPG — MI355X engine behind the reference's algorithms/ddpg_pendulum.py surface: Config :28-41,
+Actor :44-58, Critic :62-73 (one Q network), ReplayBuffer :76-97, DDPGTrainer :100-296 (soft_update
+:128-133, select_action :135-148, update :150-194, train / eval / test).
+
+Same kernels as td3_pendulum.py; the single critic's loss is `gymrl_mse_loss` and the Bellman target
+is `gymrl_sac_target` fed the one target Q twice with a zero log-prob term.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .td3_pendulum import Actor, _ActorCriticBase  # noqa: F401  (Actor is part of this module's surface)
+
+
+class Config:
+    def __init__(self):
+        self.env_name = "Pendulum-v1"
+        self.seed = None
+        self.max_episodes = 500
+        self.max_steps = 200
+        self.batch_size = 128
+        self.gamma = 0.99
+        self.lr_actor = 1e-3
+        self.lr_critic = 1e-3
+        self.tau = 0.005
+        self.noise_std = 0.1
+        self.memory_capacity = 100000
+        self.hidden_dim = 256
+        self.device = "cuda"
+        # --- vectorised-engine additions ---
+        self.num_envs = 1
+        self.updates_per_step = 1
+
+
+class Critic(nn.Module):
+    def __init__(self, state_dim, action_dim, hidden_dim):
+        super().__init__()
+        self.fc1 = nn.Linear(state_dim + action_dim, hidden_dim)
+        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
+        self.fc3 = nn.Linear(hidden_dim, 1)
+
+    def forward(self, state, action):
+        x = torch.cat([state, action], dim=1)
+        return self.fc3(F.relu(self.fc2(F.relu(self.fc1(x)))))
+
+
+class DDPGTrainer(_ActorCriticBase):
+    def __init__(self, config):
+        self._setup(config, Critic)
+
+    def _exploration_std(self):
+        return self.cfg.noise_std
+
+    def update(self, indices=None):
+        """:150-194 -> (actor_loss, critic_loss) python floats."""
+        cfg = self.cfg
+        if len(self.memory) < cfg.batch_size:
+            return 0.0, 0.0
+        if indices is None and self._parity_updates is not None:
+            indices = next(self._parity_updates)
+        states, actions, rewards, next_states, dones = self.memory.sample(cfg.batch_size, indices)
+        B = states.shape[0]
+        with torch.no_grad():                                          # :171-174
+            tq = self.critic_target(next_states, self.actor_target(next_states)).view(-1)
+            y = ops.sac_target(rewards, dones, tq, tq, torch.zeros_like(rewards), self._log_alpha0, cfg.gamma)
+        q = self.critic(states, actions)                               # :176-181
+        self._sum_c.zero_()
+        dq = ops.mse_loss(q.view(-1), y, self._sum_c)
+        self.critic_grads.zero_()
+        torch.autograd.backward([q], [dq.view_as(q)])
+        self.critic_optimizer.step()
+        qa = self.critic(states, self.actor(states))                   # :183-187
+        self._sum_a.zero_()
+        dqa = ops.neg_mean_loss(qa.view(-1), self._sum_a)
+        torch.autograd.backward([qa], [dqa.view_as(qa)])
+        self.actor_optimizer.step()
+        self.soft_update(self.actor_target_flat, self.actor_flat)      # :189-190
+        self.soft_update(self.critic_target_flat, self.critic_flat)
+        return -float(self._sum_a.item()) / B, float(self._sum_c.item()) / B

@@ -403,6 +403,33 @@ def dqn_td_loss(q, q_next_target, act, rew, flag, gamma_n, q_next_online=None, w
     return td, dq
 
 
+def noisy_action(mu, std, bound, eps=None, mode=0, noise_clip=0.0, seed=0, counter=0, out=None):
+    """gymrl_noisy_action: Gaussian exploration noise (mode 0, numpy-float64 semantics) or TD3 target-policy
+    smoothing (mode 1, torch-float32 semantics) on an action tensor; eps = explicit f64 N(0,1) draws."""
+    out = torch.empty_like(mu) if out is None else out
+    check(lib().gymrl_noisy_action(_ptr(mu, torch.float32), _ptr(eps, torch.float64, True), C.c_uint64(seed),
+                                   C.c_uint64(counter), C.c_int64(mu.numel()), C.c_int(mode), C.c_double(std),
+                                   C.c_double(noise_clip), C.c_double(bound), _ptr(out, torch.float32), _stream()),
+          "gymrl_noisy_action")
+    return out
+
+
+def mse_loss(q, y, sum_out):
+    """One critic's F.mse_loss forward+backward: returns dq; sum_out (f64[1]) += sum (q - y)^2."""
+    dq = torch.empty_like(q)
+    check(lib().gymrl_mse_loss(_ptr(q, torch.float32), _ptr(y, torch.float32), C.c_int(q.numel()), _ptr(dq),
+                               _ptr(sum_out, torch.float64), _ptr(_reduce_ws(q.device)), _stream()), "gymrl_mse_loss")
+    return dq
+
+
+def neg_mean_loss(q, sum_out):
+    """Actor loss -mean(q): returns dq = -1/B; sum_out (f64[1]) += sum q."""
+    dq = torch.empty_like(q)
+    check(lib().gymrl_neg_mean_loss(_ptr(q, torch.float32), C.c_int(q.numel()), _ptr(dq), _ptr(sum_out, torch.float64),
+                                    _ptr(_reduce_ws(q.device)), _stream()), "gymrl_neg_mean_loss")
+    return dq
+
+
 def sac_sample_fwd(mean, log_std, eps, bound):
     B, A = mean.shape
     action, logp = torch.empty_like(mean), torch.empty(B, device=mean.device)

@@ -549,6 +549,24 @@ int gymrl_sac_alpha_step(double* log_alpha, double* m, double* v, const double* 
                          double* alpha_loss_out, void* stream);
 
 /*
+ * TD3 / DDPG — ddpg_pendulum.py:135-195, td3_pendulum.py:156-228.  Their Bellman target is
+ * gymrl_sac_target with logp_n == 0 (r + gamma (1 - done) min(Q1', Q2'); DDPG passes Q' twice), TD3's critic
+ * loss is gymrl_sac_critic_loss, the Polyak updates gymrl_soft_update; what is new:
+ *   noisy_action : mode 0 = exploration noise of select_action (numpy float64: clip(mu + eps*std, +-bound),
+ *                  :143-147 / :164-168), mode 1 = TD3 target-policy smoothing (torch float32:
+ *                  clamp(mu + clamp(eps*std, +-noise_clip), +-bound), :191-196).  eps f64[n] explicit N(0,1)
+ *                  draws or NULL -> Box-Muller on Philox(seed, counter, element).
+ *   mse_loss     : one critic's F.mse_loss(q, y): dq = 2 (q - y)/B, sum_out += sum (q - y)^2   (ddpg :178-179)
+ *   neg_mean_loss: actor loss -mean(Q(s, mu(s))): dq = -1/B, sum_out += sum q                  (ddpg :185, td3 :213)
+ * sum_out f64[1] is accumulated into (zero it first); workspace as for the SAC losses.
+ */
+int gymrl_noisy_action(const float* mu, const double* eps, uint64_t seed, uint64_t counter, int64_t n,
+                       int mode, double std, double noise_clip, double bound, float* out, void* stream);
+int gymrl_mse_loss(const float* q, const float* y, int B, float* dq_out, double* sum_out, void* workspace,
+                   void* stream);
+int gymrl_neg_mean_loss(const float* q, int B, float* dq_out, double* sum_out, void* workspace, void* stream);
+
+/*
  * N1-N3: utils/normalization.py — RunningMeanStd.update :12-22 (Welford, population
  * std, n == 1 sets std = x), Normalization.__call__ :29-35, RewardScaling :38-52.
  * stats f64[2 + 3*D] = (n, unused, mean[D] (float32 values), S[D], std[D]).

@@ -313,3 +313,36 @@ void orc_reward_scaling(const float* r, const uint8_t* done, int N, double gamma
     if (done && done[i]) R[i] = 0.0;
   }
 }
+
+/* ============================================================ TD3 / DDPG === */
+/* gymrl_noisy_action — ddpg_pendulum.py:143-147, td3_pendulum.py:164-168 (mode 0, numpy float64) and
+ * td3_pendulum.py:191-196 (mode 1, torch float32 target-policy smoothing). */
+void orc_noisy_action(const float* mu, const double* eps, uint64_t seed, uint64_t counter, int64_t n, int mode,
+                      double std, double noise_clip, double bound, float* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    double e = eps ? eps[i] : (double)box_muller(seed, counter, 2u, (uint32_t)i);
+    if (mode == 0) {
+      double a = (double)mu[i] + e * std;
+      a = a < -(double)(float)bound ? -(double)(float)bound : (a > (double)(float)bound ? (double)(float)bound : a);
+      out[i] = (float)a;
+    } else {
+      float nz = (float)e * (float)std, c = (float)noise_clip, b = (float)bound;
+      nz = fminf(fmaxf(nz, -c), c);
+      out[i] = fminf(fmaxf(mu[i] + nz, -b), b);
+    }
+  }
+}
+
+/* gymrl_mse_loss — F.mse_loss(current_q, target_q), ddpg_pendulum.py:178-179. */
+void orc_mse_loss(const float* q, const float* y, int B, float* dq, double* sum) {
+  double acc = 0.0; float invB = 1.0f / (float)B;
+  for (int b = 0; b < B; ++b) { float e = q[b] - y[b]; dq[b] = 2.0f * e * invB; acc += (double)(e * e); }
+  *sum += acc;
+}
+
+/* gymrl_neg_mean_loss — -critic(states, actor(states)).mean(), ddpg_pendulum.py:185, td3_pendulum.py:213. */
+void orc_neg_mean_loss(const float* q, int B, float* dq, double* sum) {
+  double acc = 0.0; float g = -1.0f / (float)B;
+  for (int b = 0; b < B; ++b) { dq[b] = g; acc += (double)q[b]; }
+  *sum += acc;
+}

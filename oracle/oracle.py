@@ -398,6 +398,29 @@ def noisy_noise(nin, nout, eps_in=None, eps_out=None, seed=0, counter=0):
     return w, b
 
 
+def noisy_action(mu, std, bound, eps=None, mode=0, noise_clip=0.0, seed=0, counter=0):
+    mu = _f32(mu)
+    e = None if eps is None else np.ascontiguousarray(eps, dtype=np.float64)
+    out = np.empty_like(mu)
+    lib().orc_noisy_action(_p(mu), _p(e), C.c_uint64(seed), C.c_uint64(counter), C.c_int64(mu.size), C.c_int(mode),
+                           C.c_double(std), C.c_double(noise_clip), C.c_double(bound), _p(out))
+    return out
+
+
+def mse_loss(q, y):
+    q, y = _f32(q), _f32(y)
+    dq, s = np.empty_like(q), np.zeros(1, np.float64)
+    lib().orc_mse_loss(_p(q), _p(y), C.c_int(q.size), _p(dq), _p(s))
+    return dq, s[0]
+
+
+def neg_mean_loss(q):
+    q = _f32(q)
+    dq, s = np.empty_like(q), np.zeros(1, np.float64)
+    lib().orc_neg_mean_loss(_p(q), C.c_int(q.size), _p(dq), _p(s))
+    return dq, s[0]
+
+
 def epsilon_greedy(q, epsilon, u=None, seed=0, counter=0, env_id0=0):
     q = _f32(q)
     n, A = q.shape

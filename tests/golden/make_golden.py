@@ -993,8 +993,62 @@ def gen_rainbow_trace():
     save("rainbow_trace", **out)
 
 
+def gen_td3_ddpg():
+    """one DDPGTrainer.update() (ddpg_pendulum.py:150-194), two consecutive TD3Trainer.update()
+    calls (td3_pendulum.py:171-228: the second one runs the delayed actor + target updates), and the
+    exploration noise of both select_action()s, on memories whose whole content is the batch."""
+    out = {}
+    rng = np.random.default_rng(95)
+    for name, path, cls in (("ddpg", "algorithms/ddpg_pendulum.py", "DDPGTrainer"), ("td3", "algorithms/td3_pendulum.py", "TD3Trainer")):
+        mod = load_ref(path, "ref_" + name)
+        cfg = mod.Config()
+        cfg.device, cfg.batch_size, cfg.hidden_dim = "cpu", 24, 32
+        seed_all(96)
+        tr = getattr(mod, cls)(cfg)
+        trans = []
+        for i in range(cfg.batch_size):
+            trans.append((rng.normal(size=3).astype(np.float32), rng.uniform(-2, 2, size=1),       # actions are float64 arrays
+                          float(rng.normal()), rng.normal(size=3).astype(np.float32), bool(rng.random() < 0.15)))
+            tr.memory.push(*trans[-1])
+        with torch.no_grad():
+            for net in (tr.actor_target, tr.critic_target):
+                for p in net.parameters():
+                    p.add_(0.05 * torch.randn_like(p))
+        nets = (("actor", "actor"), ("critic", "critic"), ("actor_target", "actor_target"), ("critic_target", "critic_target"))
+        for key, attr in nets:
+            for k, v in getattr(tr, attr).state_dict().items():
+                out[f"{name}_u0_{key}_{k}"] = v.numpy().copy()
+        # exploration: action = clip(actor(s) + N(0, std*bound)) with numpy's global generator
+        st = rng.normal(size=3).astype(np.float32)
+        np.random.seed(31)
+        a = tr.select_action(st)
+        np.random.seed(31)
+        e = np.random.standard_normal(1)
+        out.update({f"{name}_sel_state": st, f"{name}_sel_action": np.asarray(a, np.float64), f"{name}_sel_eps": e,
+                    f"{name}_sel_det": np.asarray(tr.select_action(st, deterministic=True), np.float64)})
+        losses, orders, epss = [], [], []
+        for k in range(1 if name == "ddpg" else 2):
+            random.seed(40 + k)
+            torch.manual_seed(50 + k)
+            losses.append(tr.update())
+            random.seed(40 + k)
+            orders.append(random.sample(range(cfg.batch_size), cfg.batch_size))
+            torch.manual_seed(50 + k)
+            epss.append(torch.randn(cfg.batch_size, 1).numpy().astype(np.float64))
+        for key, attr in nets:
+            for k, v in getattr(tr, attr).state_dict().items():
+                out[f"{name}_u1_{key}_{k}"] = v.numpy().copy()
+        out.update({f"{name}_orders": np.array(orders, np.int32), f"{name}_eps": np.stack(epss),
+                    f"{name}_losses": np.array(losses, np.float64),
+                    f"{name}_states": np.stack([t[0] for t in trans]), f"{name}_actions": np.stack([t[1] for t in trans]),
+                    f"{name}_rewards": np.array([t[2] for t in trans], np.float32),
+                    f"{name}_next_states": np.stack([t[3] for t in trans]),
+                    f"{name}_dones": np.array([t[4] for t in trans], np.uint8)})
+    save("td3_ddpg", **out)
+
+
 if __name__ == "__main__":
     names = sys.argv[1:]
-    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2, gen_dqn_trace, gen_sac_trace, gen_rainbow_trace]:
+    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2, gen_dqn_trace, gen_sac_trace, gen_rainbow_trace, gen_td3_ddpg]:
         if not names or g.__name__ in names:
             g()

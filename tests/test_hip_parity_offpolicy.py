@@ -285,3 +285,28 @@ def test_running_norm_and_reward_scaling(dev, oracle):
     out = ops.reward_scaling(t(r, dev), t(g["done"], dev), 0.99, R, st)
     ref = oracle.reward_scaling(r, g["done"], 0.99, rR, rst)
     assert np.array_equal(out.cpu().numpy(), ref) and np.array_equal(R.cpu().numpy(), rR)
+
+
+def test_td3_ddpg_kernels_vs_oracle(dev, oracle):
+    """gymrl_noisy_action (both modes, explicit draws and the Philox/Box-Muller stream), gymrl_mse_loss and
+    gymrl_neg_mean_loss vs the oracle: bit-exact maps, sums to 1e-12 relative."""
+    from gymrl_amd import ops
+    rng = np.random.default_rng(8)
+    mu = (rng.normal(size=(4097, 1)) * 1.5).astype(np.float32)
+    eps = rng.normal(size=(4097, 1))
+    for mode, clip in ((0, 0.0), (1, 0.5)):
+        got = ops.noisy_action(t(mu, dev), 0.2, 2.0, eps=t(eps, dev), mode=mode, noise_clip=clip)
+        assert np.array_equal(got.cpu().numpy(), oracle.noisy_action(mu, 0.2, 2.0, eps=eps, mode=mode, noise_clip=clip))
+        got = ops.noisy_action(t(mu, dev), 0.2, 2.0, mode=mode, noise_clip=clip, seed=5, counter=9)
+        assert np.array_equal(got.cpu().numpy(), oracle.noisy_action(mu, 0.2, 2.0, mode=mode, noise_clip=clip, seed=5, counter=9))
+    noise = ops.noisy_action(torch.zeros(200000, 1, device=dev), 1.0, 100.0, mode=0, seed=1, counter=2).cpu().numpy()
+    assert abs(noise.mean()) < 0.01 and abs(noise.std() - 1.0) < 0.01          # the stream is N(0, 1)
+    q, y = rng.normal(size=5000).astype(np.float32), rng.normal(size=5000).astype(np.float32)
+    s = torch.zeros(1, dtype=torch.float64, device=dev)
+    dq = ops.mse_loss(t(q, dev), t(y, dev), s)
+    dq_ref, s_ref = oracle.mse_loss(q, y)
+    assert np.array_equal(dq.cpu().numpy(), dq_ref) and abs(s.item() - s_ref) <= 1e-12 * abs(s_ref)
+    s.zero_()
+    dq = ops.neg_mean_loss(t(q, dev), s)
+    dq_ref, s_ref = oracle.neg_mean_loss(q)
+    assert np.array_equal(dq.cpu().numpy(), dq_ref) and abs(s.item() - s_ref) <= 1e-9

@@ -109,3 +109,28 @@ def test_normalization_matches_reference(oracle):
         outs.append(oracle.reward_scaling(np.array([r]), np.array([d]), float(g["gamma"]), R, st)[0])
     assert rel_close(np.array(outs), g["r_scaled"], 1e-6) <= 1e-6
     assert abs(outs[0] - 1.0) < 1e-6
+
+
+def test_td3_ddpg_noise_and_losses(oracle):
+    """SURVEY 8f.3 kernels' restatement vs the reference: exploration noise of select_action (numpy float64
+    arithmetic, stored float32), and the TD target / MSE / -mean pieces on the golden batch are exercised by
+    the GPU trainer test; here the elementary maps."""
+    g = load_golden("td3_ddpg")
+    for name, std in (("ddpg", 0.1), ("td3", 0.1)):
+        det = g[f"{name}_sel_det"].astype(np.float32)
+        got = oracle.noisy_action(det, std * 2.0, 2.0, eps=g[f"{name}_sel_eps"], mode=0)
+        assert np.array_equal(got, g[f"{name}_sel_action"].astype(np.float32)), name
+    # target-policy smoothing (td3_pendulum.py:191-196) against torch's float32 clamp arithmetic
+    import torch
+    mu = torch.linspace(-2, 2, 41)
+    eps = torch.linspace(-4, 4, 41).flip(0).double()
+    want = (mu + (eps.float() * 0.2).clamp(-0.5, 0.5)).clamp(-2.0, 2.0).numpy()
+    assert np.array_equal(oracle.noisy_action(mu.numpy(), 0.2, 2.0, eps=eps.numpy(), mode=1, noise_clip=0.5), want)
+    q, y = torch.randn(50), torch.randn(50)
+    q.requires_grad_(True)
+    loss = torch.nn.functional.mse_loss(q, y)
+    loss.backward()
+    dq, s = oracle.mse_loss(q.detach().numpy(), y.numpy())
+    assert np.allclose(dq, q.grad.numpy(), rtol=1e-6, atol=1e-8) and abs(s / 50 - loss.item()) <= 1e-6
+    dq, s = oracle.neg_mean_loss(q.detach().numpy())
+    assert np.array_equal(dq, np.full(50, -1.0 / 50, np.float32)) and abs(-s / 50 + q.mean().item()) <= 1e-6

@@ -97,6 +97,21 @@ def test_dqn_rainbow_sac_smoke():
     assert all(np.isfinite(x) for x in (a, cr, al)) and 0.0 < tr.alpha.item() < 1.0
 
 
+def test_td3_ddpg_smoke():
+    """A few hundred vector steps of the TD3 / DDPG trainers on Pendulum: finite losses, buffers fill, targets move."""
+    from gymrl_amd import ddpg_pendulum, td3_pendulum
+    for mod, cls in ((td3_pendulum, "TD3Trainer"), (ddpg_pendulum, "DDPGTrainer")):
+        c = mod.Config()
+        c.num_envs, c.max_episodes = 32, 10**9
+        tr = getattr(mod, cls)(c)
+        t0 = tr.actor_target_flat.clone()
+        tr.train(max_vector_steps=220)
+        al, cl = tr.update()
+        assert np.isfinite(al) and np.isfinite(cl) and len(tr.memory) == 32 * 220
+        assert not torch.equal(t0, tr.actor_target_flat) and len(tr.episode_rewards) > 0
+        assert all(np.isfinite(r) for r in tr.eval(4))
+
+
 def test_ppo_full_iterations():
     """PPO-full (config 5's algorithm) on the HIP path: mHC network through PyTorch, G3 GAE, L3 loss."""
     from gymrl_amd.ppo_full_lunarlander import Config, PPOTrainer
@@ -266,7 +281,8 @@ def test_sac_train_trace_matches_reference():
     dev = tr.device
     for name, net in (("actor", tr.actor), ("critic", tr.critic)):
         pre = f"p0_{name}_"
-        net.load_state_dict({k[len(pre):]: torch.from_numpy(np.array(g[k])) for k in g.files if k.startswith(pre)})
+        net.load_state_dict({k[len(pre):]: torch.from_numpy(np.array(g[k])) for k in g.files
+                         if k.startswith(pre) and not k[len(pre):].startswith("target_")})
     tr.critic_target_flat.copy_(tr.critic_flat)                       # deepcopy(critic) (:169)
     tr.env = ScriptedVecEnv(1, dev, obs_dim=3, continuous=True)
     td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
@@ -349,3 +365,43 @@ def test_rainbow_train_trace_matches_reference():
     tree = tr.memory.sum_tree.tree.cpu().numpy()
     assert np.max(np.abs(tree - g["tree"]) / np.maximum(1.0, np.abs(g["tree"]))) <= 1e-3
     assert abs(tr.optimizer.param_groups[0]["lr"] - float(g["lr_now"])) <= 1e-12
+
+
+def _load_prefixed(net, g, pre):
+    net.load_state_dict({k[len(pre):]: torch.from_numpy(np.array(g[k])) for k in g.files
+                         if k.startswith(pre) and not k[len(pre):].startswith("target_")})
+
+
+@pytest.mark.parametrize("name", ["ddpg", "td3"])
+def test_td3_ddpg_update_matches_reference(name):
+    """the reference DDPGTrainer.update() / two consecutive TD3Trainer.update() calls (the second
+    runs the delayed actor + target updates) reproduced from the same weights, batch order and smoothing noise;
+    exploration noise of select_action bit-exact through gymrl_noisy_action."""
+    from gymrl_amd import ddpg_pendulum, ops, td3_pendulum
+    from conftest import load_golden as lg
+    g = lg("td3_ddpg")
+    mod, cls = (ddpg_pendulum, "DDPGTrainer") if name == "ddpg" else (td3_pendulum, "TD3Trainer")
+    cfg = mod.Config()
+    cfg.batch_size, cfg.hidden_dim, cfg.num_envs = 24, 32, 1
+    tr = getattr(mod, cls)(cfg)
+    dev = tr.device
+    for key in ("actor", "critic", "actor_target", "critic_target"):
+        _load_prefixed(getattr(tr, key), g, f"{name}_u0_{key}_")
+    td = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a if dt is None else a.astype(dt))).to(dev)  # noqa: E731
+    # exploration noise: float64 numpy arithmetic, float32 storage
+    det = td(g[f"{name}_sel_det"], np.float32).view(1, 1)
+    got = ops.noisy_action(det, 0.1 * 2.0, 2.0, eps=td(g[f"{name}_sel_eps"]).view(1, 1), mode=0)
+    assert np.array_equal(got.cpu().numpy().ravel(), g[f"{name}_sel_action"].astype(np.float32))
+    a_gpu = tr.select_action(td(g[f"{name}_sel_state"]).view(1, 3), eps=td(g[f"{name}_sel_eps"]).view(1, 1))
+    assert abs(float(a_gpu) - float(g[f"{name}_sel_action"][0])) <= 1e-5
+    tr.memory.push(td(g[f"{name}_states"]), td(g[f"{name}_actions"], np.float32), td(g[f"{name}_rewards"]),
+                   td(g[f"{name}_next_states"]), td(g[f"{name}_dones"]))
+    for k, order in enumerate(g[f"{name}_orders"]):
+        if name == "ddpg":
+            al, cl = tr.update(indices=td(order))
+        else:
+            al, cl = tr.update(indices=td(order), eps=td(g["td3_eps"][k]))
+        want = g[f"{name}_losses"][k]
+        assert abs(al - want[0]) <= 1e-5 * max(1.0, abs(want[0])) and abs(cl - want[1]) <= 1e-5 * max(1.0, abs(want[1]))
+    for key in ("actor", "critic", "actor_target", "critic_target"):
+        assert _maxdiff(getattr(tr, key), g, f"{name}_u1_{key}_") <= 5e-6, key
