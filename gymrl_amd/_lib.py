@@ -35,6 +35,7 @@ SYMBOLS = [
     "gymrl_sac_sample_fwd", "gymrl_sac_sample_bwd", "gymrl_sac_target", "gymrl_sac_critic_loss",
     "gymrl_sac_actor_loss", "gymrl_sac_alpha_step", "gymrl_running_norm", "gymrl_reward_scaling",
     "gymrl_noisy_action", "gymrl_mse_loss", "gymrl_neg_mean_loss",
+    "gymrl_dsac_target", "gymrl_dsac_critic_loss", "gymrl_dsac_actor_loss", "gymrl_dsac_alpha_step",
     "gymrl_mlp_packed_floats", "gymrl_mlp_pack", "gymrl_mlp_forward",
     "gymrl_mlp_train_workspace_bytes", "gymrl_linear_tanh_smallk", "gymrl_tanh_inplace", "gymrl_tanh_bwd_colsum",
     "gymrl_linear_smallk_bwd", "gymrl_heads_fwd_tanh", "gymrl_heads_bwd", "gymrl_rollout_lunar",

@@ -371,6 +371,92 @@ __global__ __launch_bounds__(kBlock) void neg_mean_kernel(const float* __restric
   block_partials<1>(acc, partials);
 }
 
+// ------------------------------------------------------------ discrete SAC ---
+// sac_cartpole.py:148-227 — expectation over the A actions instead of a reparameterised sample.  All float32
+// (log_alpha is a float32 scalar there, :118-120).  A <= 8; sums over actions run in index order.
+constexpr int kMaxA = 8;
+
+// :171-181  y = r + gamma (1 - done) (sum_a p'(a) min(Q1', Q2')(a) + alpha H(p')),  log p = log(p + 1e-8)
+__global__ __launch_bounds__(kBlock) void dsac_target_kernel(const float* __restrict__ probs_n, const float* __restrict__ q1n,
+                                                             const float* __restrict__ q2n, const float* __restrict__ rew,
+                                                             const float* __restrict__ done, const float* __restrict__ log_alpha,
+                                                             int B, int A, float gamma, float* __restrict__ y) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= B) return;
+  const float alpha = det_expf(log_alpha[0]);
+  float ent = 0.0f, minq = 0.0f;
+  for (int k = 0; k < A; ++k) {
+    const float p = probs_n[(size_t)b * A + k];
+    ent += p * det_logf(p + 1e-8f);
+    minq += p * fminf(q1n[(size_t)b * A + k], q2n[(size_t)b * A + k]);
+  }
+  const float nv = minq + alpha * (-ent);
+  y[b] = rew[b] + gamma * (1.0f - done[b]) * nv;
+}
+
+// :183-186  F.mse_loss(q.gather(1, a), y) for both critics: dq[b, k] = (k == a_b) 2 (q - y) / B
+__global__ __launch_bounds__(kBlock) void dsac_critic_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
+                                                             const int32_t* __restrict__ act, const float* __restrict__ y, int B,
+                                                             int A, float* __restrict__ dq1, float* __restrict__ dq2,
+                                                             double* __restrict__ partials) {
+  double acc[2] = {0.0, 0.0};
+  const float invB = 1.0f / (float)B;
+  for (int b = blockIdx.x * kBlock + threadIdx.x; b < B; b += gridDim.x * kBlock) {
+    const int a = act[b];
+    const float e1 = q1[(size_t)b * A + a] - y[b], e2 = q2[(size_t)b * A + a] - y[b];
+    for (int k = 0; k < A; ++k) {
+      dq1[(size_t)b * A + k] = k == a ? 2.0f * e1 * invB : 0.0f;
+      dq2[(size_t)b * A + k] = k == a ? 2.0f * e2 * invB : 0.0f;
+    }
+    acc[0] += (double)(e1 * e1); acc[1] += (double)(e2 * e2);
+  }
+  block_partials<2>(acc, partials);
+}
+
+// :196-203  L = mean(-alpha H(p) - sum_a p(a) min(Q1, Q2)(a));  dL/dp_k = (alpha (log(p_k + 1e-8) + p_k/(p_k + 1e-8)) - m_k)/B
+// sums: [sum (-alpha H - min_q), sum H]   (the second feeds the temperature loss :209-211)
+__global__ __launch_bounds__(kBlock) void dsac_actor_kernel(const float* __restrict__ probs, const float* __restrict__ q1,
+                                                            const float* __restrict__ q2, const float* __restrict__ log_alpha,
+                                                            int B, int A, float* __restrict__ dprobs,
+                                                            double* __restrict__ partials) {
+  double acc[2] = {0.0, 0.0};
+  const float invB = 1.0f / (float)B;
+  const float alpha = det_expf(log_alpha[0]);
+  for (int b = blockIdx.x * kBlock + threadIdx.x; b < B; b += gridDim.x * kBlock) {
+    float ent = 0.0f, minq = 0.0f;
+    for (int k = 0; k < A; ++k) {
+      const float p = probs[(size_t)b * A + k];
+      const float lp = det_logf(p + 1e-8f);
+      const float m = fminf(q1[(size_t)b * A + k], q2[(size_t)b * A + k]);
+      ent += p * lp;
+      minq += p * m;
+      dprobs[(size_t)b * A + k] = (alpha * (lp + p / (p + 1e-8f)) - m) * invB;
+    }
+    ent = -ent;
+    acc[0] += (double)(-alpha * ent - minq);
+    acc[1] += (double)ent;
+  }
+  block_partials<2>(acc, partials);
+}
+
+// :209-215  L_alpha = mean(exp(log_alpha) (H - H_target).detach()); Adam on the float32 scalar.
+__global__ void dsac_alpha_kernel(float* __restrict__ log_alpha, float* __restrict__ m, float* __restrict__ v,
+                                  const double* __restrict__ sums, int B, float target_entropy, float lr, float b1,
+                                  float b2, float eps, int64_t step, double* __restrict__ loss_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float alpha = det_expf(log_alpha[0]);
+  const float mean_gap = (float)(sums[1] / (double)B) - target_entropy;
+  if (loss_out) loss_out[0] = (double)(alpha * mean_gap);
+  const float g = alpha * mean_gap;                       // d/d log_alpha of exp(log_alpha) * c
+  const float mm = b1 * m[0] + (1.0f - b1) * g;
+  const float vv = b2 * v[0] + (1.0f - b2) * g * g;
+  m[0] = mm; v[0] = vv;
+  const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float denom = (float)(sqrt((double)vv) / sqrt(bc2)) + eps;
+  log_alpha[0] = log_alpha[0] - step_size * (mm / denom);
+}
+
 }  // namespace
 
 extern "C" {
@@ -531,6 +617,49 @@ int gymrl_neg_mean_loss(const float* q, int B, float* dq_out, double* sum_out, v
   const int nb = grid_for(B);
   hipLaunchKernelGGL(neg_mean_kernel, dim3(nb), dim3(kBlock), 0, stream, q, B, dq_out, (double*)workspace);
   hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(kBlock), 0, stream, (const double*)workspace, nb, sum_out);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_dsac_target(const float* probs_n, const float* q1n, const float* q2n, const float* rew, const float* done,
+                      const float* log_alpha, int B, int A, double gamma, float* y_out, void* stream_) {
+  if (!probs_n || !q1n || !q2n || !rew || !done || !log_alpha || !y_out || B <= 0 || A <= 0 || A > kMaxA) return -22;
+  hipLaunchKernelGGL(dsac_target_kernel, dim3(cdiv(B, kBlock)), dim3(kBlock), 0, (hipStream_t)stream_, probs_n, q1n, q2n,
+                     rew, done, log_alpha, B, A, (float)gamma, y_out);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_dsac_critic_loss(const float* q1, const float* q2, const int32_t* act, const float* y, int B, int A,
+                           float* dq1_out, float* dq2_out, double* sums, void* workspace, void* stream_) {
+  if (!q1 || !q2 || !act || !y || !dq1_out || !dq2_out || !sums || !workspace || B <= 0 || A <= 0 || A > kMaxA) return -22;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int nb = grid_for(B);
+  hipLaunchKernelGGL(dsac_critic_kernel, dim3(nb), dim3(kBlock), 0, stream, q1, q2, act, y, B, A, dq1_out, dq2_out,
+                     (double*)workspace);
+  hipLaunchKernelGGL(finalize_kernel<2>, dim3(1), dim3(kBlock), 0, stream, (const double*)workspace, nb, sums);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_dsac_actor_loss(const float* probs, const float* q1, const float* q2, const float* log_alpha, int B, int A,
+                          float* dprobs_out, double* sums, void* workspace, void* stream_) {
+  if (!probs || !q1 || !q2 || !log_alpha || !dprobs_out || !sums || !workspace || B <= 0 || A <= 0 || A > kMaxA) return -22;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int nb = grid_for(B);
+  hipLaunchKernelGGL(dsac_actor_kernel, dim3(nb), dim3(kBlock), 0, stream, probs, q1, q2, log_alpha, B, A, dprobs_out,
+                     (double*)workspace);
+  hipLaunchKernelGGL(finalize_kernel<2>, dim3(1), dim3(kBlock), 0, stream, (const double*)workspace, nb, sums);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_dsac_alpha_step(float* log_alpha, float* m, float* v, const double* sums, int B, double target_entropy,
+                          double lr, double beta1, double beta2, double eps, int64_t step, double* alpha_loss_out,
+                          void* stream_) {
+  if (!log_alpha || !m || !v || !sums || B <= 0 || step <= 0) return -22;
+  hipLaunchKernelGGL(dsac_alpha_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, log_alpha, m, v, sums, B,
+                     (float)target_entropy, (float)lr, (float)beta1, (float)beta2, (float)eps, step, alpha_loss_out);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

@@ -430,6 +430,42 @@ def neg_mean_loss(q, sum_out):
     return dq
 
 
+def dsac_target(probs_n, q1n, q2n, rew, done, log_alpha, gamma):
+    y = torch.empty_like(rew)
+    B, A = probs_n.shape
+    check(lib().gymrl_dsac_target(_ptr(probs_n, torch.float32), _ptr(q1n, torch.float32), _ptr(q2n, torch.float32),
+                                  _ptr(rew, torch.float32), _ptr(done, torch.float32), _ptr(log_alpha, torch.float32),
+                                  C.c_int(B), C.c_int(A), C.c_double(gamma), _ptr(y), _stream()), "gymrl_dsac_target")
+    return y
+
+
+def dsac_critic_loss(q1, q2, act, y, sums):
+    B, A = q1.shape
+    d1, d2 = torch.empty_like(q1), torch.empty_like(q2)
+    check(lib().gymrl_dsac_critic_loss(_ptr(q1, torch.float32), _ptr(q2, torch.float32), _ptr(act, torch.int32),
+                                       _ptr(y, torch.float32), C.c_int(B), C.c_int(A), _ptr(d1), _ptr(d2),
+                                       _ptr(sums, torch.float64), _ptr(_reduce_ws(q1.device)), _stream()),
+          "gymrl_dsac_critic_loss")
+    return d1, d2
+
+
+def dsac_actor_loss(probs, q1, q2, log_alpha, sums):
+    B, A = probs.shape
+    dp = torch.empty_like(probs)
+    check(lib().gymrl_dsac_actor_loss(_ptr(probs, torch.float32), _ptr(q1, torch.float32), _ptr(q2, torch.float32),
+                                      _ptr(log_alpha, torch.float32), C.c_int(B), C.c_int(A), _ptr(dp),
+                                      _ptr(sums, torch.float64), _ptr(_reduce_ws(probs.device)), _stream()),
+          "gymrl_dsac_actor_loss")
+    return dp
+
+
+def dsac_alpha_step(log_alpha, m, v, sums, B, target_entropy, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, loss_out=None):
+    check(lib().gymrl_dsac_alpha_step(_ptr(log_alpha, torch.float32), _ptr(m, torch.float32), _ptr(v, torch.float32),
+                                      _ptr(sums, torch.float64), C.c_int(B), C.c_double(target_entropy), C.c_double(lr),
+                                      C.c_double(beta1), C.c_double(beta2), C.c_double(eps), C.c_int64(step),
+                                      _ptr(loss_out, torch.float64, True), _stream()), "gymrl_dsac_alpha_step")
+
+
 def sac_sample_fwd(mean, log_std, eps, bound):
     B, A = mean.shape
     action, logp = torch.empty_like(mean), torch.empty(B, device=mean.device)

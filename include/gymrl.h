@@ -567,6 +567,27 @@ int gymrl_mse_loss(const float* q, const float* y, int B, float* dq_out, double*
 int gymrl_neg_mean_loss(const float* q, int B, float* dq_out, double* sum_out, void* workspace, void* stream);
 
 /*
+ * Discrete SAC — sac_cartpole.py:148-227: expectation over the A <= 8 actions, float32 throughout
+ * (log_alpha is a float32 scalar there).  probs = the actor's softmax output [B, A]; q* [B, A].
+ *   dsac_target      : y = r + gamma (1 - done) (sum_a p'(a) min(Q1', Q2')(a) + alpha H(p')), log p = log(p + 1e-8)   :171-181
+ *   dsac_critic_loss : F.mse_loss(q.gather(1, a), y) for both critics; dq [B, A] non-zero at the taken action;
+ *                      sums f64[2] += (sum e1^2, sum e2^2)                                                         :183-186
+ *   dsac_actor_loss  : L = mean(-alpha H(p) - sum_a p(a) min(Q1, Q2)(a)); dprobs = dL/dp (backprop through the
+ *                      softmax by the caller); sums f64[2] += (sum (-alpha H - min_q), sum H)                      :196-203
+ *   dsac_alpha_step  : L_alpha = exp(log_alpha) mean(H - H_target) from sums[1]; one float32 Adam step on log_alpha :209-215
+ */
+int gymrl_dsac_target(const float* probs_n, const float* q1n, const float* q2n, const float* rew,
+                      const float* done, const float* log_alpha, int B, int A, double gamma, float* y_out,
+                      void* stream);
+int gymrl_dsac_critic_loss(const float* q1, const float* q2, const int32_t* act, const float* y, int B, int A,
+                           float* dq1_out, float* dq2_out, double* sums, void* workspace, void* stream);
+int gymrl_dsac_actor_loss(const float* probs, const float* q1, const float* q2, const float* log_alpha, int B,
+                          int A, float* dprobs_out, double* sums, void* workspace, void* stream);
+int gymrl_dsac_alpha_step(float* log_alpha, float* m, float* v, const double* sums, int B,
+                          double target_entropy, double lr, double beta1, double beta2, double eps,
+                          int64_t step, double* alpha_loss_out, void* stream);
+
+/*
  * N1-N3: utils/normalization.py — RunningMeanStd.update :12-22 (Welford, population
  * std, n == 1 sets std = x), Normalization.__call__ :29-35, RewardScaling :38-52.
  * stats f64[2 + 3*D] = (n, unused, mean[D] (float32 values), S[D], std[D]).

@@ -346,3 +346,67 @@ void orc_neg_mean_loss(const float* q, int B, float* dq, double* sum) {
   for (int b = 0; b < B; ++b) { dq[b] = g; acc += (double)q[b]; }
   *sum += acc;
 }
+
+/* ========================================================= discrete SAC === */
+/* sac_cartpole.py:171-181 */
+void orc_dsac_target(const float* probs_n, const float* q1n, const float* q2n, const float* rew, const float* done,
+                     const float* log_alpha, int B, int A, float gamma, float* y) {
+  float alpha = orc_expf(log_alpha[0]);
+  for (int b = 0; b < B; ++b) {
+    float ent = 0.0f, minq = 0.0f;
+    for (int k = 0; k < A; ++k) {
+      float p = probs_n[(size_t)b * A + k];
+      ent += p * orc_logf(p + 1e-8f);
+      minq += p * fminf(q1n[(size_t)b * A + k], q2n[(size_t)b * A + k]);
+    }
+    float nv = minq + alpha * (-ent);
+    y[b] = rew[b] + gamma * (1.0f - done[b]) * nv;
+  }
+}
+
+/* :183-186 */
+void orc_dsac_critic_loss(const float* q1, const float* q2, const int32_t* act, const float* y, int B, int A, float* dq1,
+                          float* dq2, double* sums) {
+  float invB = 1.0f / (float)B;
+  for (int b = 0; b < B; ++b) {
+    int a = act[b];
+    float e1 = q1[(size_t)b * A + a] - y[b], e2 = q2[(size_t)b * A + a] - y[b];
+    for (int k = 0; k < A; ++k) {
+      dq1[(size_t)b * A + k] = k == a ? 2.0f * e1 * invB : 0.0f;
+      dq2[(size_t)b * A + k] = k == a ? 2.0f * e2 * invB : 0.0f;
+    }
+    sums[0] += (double)(e1 * e1); sums[1] += (double)(e2 * e2);
+  }
+}
+
+/* :196-203 */
+void orc_dsac_actor_loss(const float* probs, const float* q1, const float* q2, const float* log_alpha, int B, int A,
+                         float* dprobs, double* sums) {
+  float invB = 1.0f / (float)B, alpha = orc_expf(log_alpha[0]);
+  for (int b = 0; b < B; ++b) {
+    float ent = 0.0f, minq = 0.0f;
+    for (int k = 0; k < A; ++k) {
+      float p = probs[(size_t)b * A + k], lp = orc_logf(p + 1e-8f);
+      float m = fminf(q1[(size_t)b * A + k], q2[(size_t)b * A + k]);
+      ent += p * lp; minq += p * m;
+      dprobs[(size_t)b * A + k] = (alpha * (lp + p / (p + 1e-8f)) - m) * invB;
+    }
+    ent = -ent;
+    sums[0] += (double)(-alpha * ent - minq); sums[1] += (double)ent;
+  }
+}
+
+/* :209-215 — float32 Adam step on log_alpha */
+void orc_dsac_alpha_step(float* log_alpha, float* m, float* v, const double* sums, int B, float target_entropy, float lr,
+                         float b1, float b2, float eps, int64_t step, double* loss_out) {
+  float alpha = orc_expf(log_alpha[0]);
+  float mean_gap = (float)(sums[1] / (double)B) - target_entropy;
+  if (loss_out) loss_out[0] = (double)(alpha * mean_gap);
+  float g = alpha * mean_gap;
+  float mm = b1 * m[0] + (1.0f - b1) * g, vv = b2 * v[0] + (1.0f - b2) * g * g;
+  m[0] = mm; v[0] = vv;
+  double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+  float step_size = (float)((double)lr / bc1);
+  float denom = (float)(sqrt((double)vv) / sqrt(bc2)) + eps;
+  log_alpha[0] = log_alpha[0] - step_size * (mm / denom);
+}

@@ -421,6 +421,38 @@ def neg_mean_loss(q):
     return dq, s[0]
 
 
+def dsac_target(probs_n, q1n, q2n, rew, done, log_alpha, gamma):
+    probs_n, q1n, q2n, rew, done = (_f32(a) for a in (probs_n, q1n, q2n, rew, done))
+    B, A = probs_n.shape
+    y, la = np.empty(B, np.float32), np.array([log_alpha], np.float32)
+    lib().orc_dsac_target(_p(probs_n), _p(q1n), _p(q2n), _p(rew), _p(done), _p(la), B, A, C.c_float(gamma), _p(y))
+    return y
+
+
+def dsac_critic_loss(q1, q2, act, y):
+    q1, q2, y, act = _f32(q1), _f32(q2), _f32(y), _i32(act)
+    B, A = q1.shape
+    d1, d2, s = np.empty_like(q1), np.empty_like(q2), np.zeros(2, np.float64)
+    lib().orc_dsac_critic_loss(_p(q1), _p(q2), _p(act), _p(y), B, A, _p(d1), _p(d2), _p(s))
+    return d1, d2, s
+
+
+def dsac_actor_loss(probs, q1, q2, log_alpha):
+    probs, q1, q2 = _f32(probs), _f32(q1), _f32(q2)
+    B, A = probs.shape
+    dp, s, la = np.empty_like(probs), np.zeros(2, np.float64), np.array([log_alpha], np.float32)
+    lib().orc_dsac_actor_loss(_p(probs), _p(q1), _p(q2), _p(la), B, A, _p(dp), _p(s))
+    return dp, s
+
+
+def dsac_alpha_step(log_alpha, m, v, sums, B, target_entropy, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    la, mm, vv = np.array([log_alpha], np.float32), np.array([m], np.float32), np.array([v], np.float32)
+    loss = np.zeros(1, np.float64)
+    lib().orc_dsac_alpha_step(_p(la), _p(mm), _p(vv), _p(np.ascontiguousarray(sums, np.float64)), B, C.c_float(target_entropy),
+                              C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_int64(step), _p(loss))
+    return float(la[0]), float(mm[0]), float(vv[0]), float(loss[0])
+
+
 def epsilon_greedy(q, epsilon, u=None, seed=0, counter=0, env_id0=0):
     q = _f32(q)
     n, A = q.shape

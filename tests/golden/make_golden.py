@@ -18,6 +18,7 @@ import types
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 REF = "/root/reference"
 OUT = os.path.dirname(os.path.abspath(__file__))
@@ -1047,8 +1048,76 @@ def gen_td3_ddpg():
     save("td3_ddpg", **out)
 
 
+def gen_dsac():
+    """two consecutive SACTrainer.update() calls of the discrete SAC (sac_cartpole.py:148-227) on a
+    memory whose whole content is the batch, plus the intermediate tensors of the first call (recomputed here
+    from the reference's own networks with the reference's expressions) for the oracle's kernel restatements."""
+    mod = load_ref("algorithms/sac_cartpole.py", "ref_dsac")
+    cfg = mod.Config()
+    cfg.device, cfg.batch_size, cfg.hidden_dim = "cpu", 32, 32
+    seed_all(97)
+    tr = mod.SACTrainer(cfg)
+    rng = np.random.default_rng(98)
+    trans = []
+    for i in range(cfg.batch_size):
+        trans.append((rng.normal(size=4).astype(np.float32), int(rng.integers(0, 2)), float(rng.normal()),
+                      rng.normal(size=4).astype(np.float32), bool(rng.random() < 0.15)))
+        tr.memory.push(*trans[-1])
+    with torch.no_grad():
+        for net in (tr.critic1_target, tr.critic2_target):
+            for p in net.parameters():
+                p.add_(0.05 * torch.randn_like(p))
+        tr.log_alpha.fill_(float(np.log(0.2)))          # a temperature at which the entropy terms are visible in f32
+    nets = ("actor", "critic1", "critic2", "critic1_target", "critic2_target")
+    out = {"states": np.stack([t[0] for t in trans]), "actions": np.array([t[1] for t in trans], np.int32),
+           "rewards": np.array([t[2] for t in trans], np.float32), "next_states": np.stack([t[3] for t in trans]),
+           "dones": np.array([t[4] for t in trans], np.uint8), "log_alpha0": tr.log_alpha.detach().numpy().copy().reshape(1),
+           "gamma": np.float32(cfg.gamma), "target_entropy": np.float32(cfg.target_entropy)}
+    for key in nets:
+        for k, v in getattr(tr, key).state_dict().items():
+            out[f"u0_{key}_{k}"] = v.numpy().copy()
+    st = rng.normal(size=4).astype(np.float32)
+    out.update({"sel_state": st, "sel_det": np.int32(tr.select_action(st, deterministic=True))})
+    # intermediates of the first update, in the batch's storage order
+    with torch.no_grad():
+        S, S2 = torch.tensor(out["states"]), torch.tensor(out["next_states"])
+        R, Dn = torch.tensor(out["rewards"]).unsqueeze(1), torch.tensor(out["dones"], dtype=torch.float32).unsqueeze(1)
+        alpha = tr.log_alpha.exp()
+        npb = tr.actor(S2)
+        nent = -torch.sum(npb * torch.log(npb + 1e-8), dim=1, keepdim=True)
+        nq1, nq2 = tr.critic1_target(S2), tr.critic2_target(S2)
+        y = R + cfg.gamma * (1 - Dn) * (torch.sum(npb * torch.min(nq1, nq2), dim=1, keepdim=True) + alpha * nent)
+        out.update({"k_next_probs": npb.numpy(), "k_next_q1": nq1.numpy(), "k_next_q2": nq2.numpy(), "k_target_q": y.numpy().reshape(-1),
+                    "k_q1": tr.critic1(S).numpy(), "k_q2": tr.critic2(S).numpy()})
+    q1 = torch.tensor(out["k_q1"], requires_grad=True)
+    q2 = torch.tensor(out["k_q2"], requires_grad=True)
+    A = torch.tensor(out["actions"], dtype=torch.long).unsqueeze(1)
+    l1, l2 = F.mse_loss(q1.gather(1, A), y), F.mse_loss(q2.gather(1, A), y)
+    (l1 + l2).backward()
+    out.update({"k_dq1": q1.grad.numpy(), "k_dq2": q2.grad.numpy(), "k_critic_losses": np.array([l1.item(), l2.item()])})
+    pr = tr.actor(S).detach().requires_grad_(True)
+    ent = -torch.sum(pr * torch.log(pr + 1e-8), dim=1, keepdim=True)
+    la = torch.sum(pr * torch.min(q1.detach(), q2.detach()), dim=1, keepdim=True)
+    al = torch.mean(-alpha.detach() * ent - la)
+    al.backward()
+    out.update({"k_probs": pr.detach().numpy(), "k_dprobs": pr.grad.numpy(), "k_actor_loss": np.float64(al.item()),
+                "k_entropy_mean": np.float64(ent.mean().item())})
+    losses, orders, las = [], [], []
+    for k in range(2):
+        random.seed(60 + k)
+        losses.append(tr.update())
+        random.seed(60 + k)
+        orders.append(random.sample(range(cfg.batch_size), cfg.batch_size))
+        las.append(float(tr.log_alpha.item()))
+    for key in nets:
+        for k, v in getattr(tr, key).state_dict().items():
+            out[f"u2_{key}_{k}"] = v.numpy().copy()
+    out.update({"orders": np.array(orders, np.int32), "losses": np.array(losses, np.float64), "log_alphas": np.array(las, np.float32)})
+    save("dsac", **out)
+
+
 if __name__ == "__main__":
     names = sys.argv[1:]
-    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2, gen_dqn_trace, gen_sac_trace, gen_rainbow_trace, gen_td3_ddpg]:
+    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2, gen_dqn_trace, gen_sac_trace, gen_rainbow_trace, gen_td3_ddpg, gen_dsac]:
         if not names or g.__name__ in names:
             g()

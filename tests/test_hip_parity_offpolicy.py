@@ -310,3 +310,40 @@ def test_td3_ddpg_kernels_vs_oracle(dev, oracle):
     dq = ops.neg_mean_loss(t(q, dev), s)
     dq_ref, s_ref = oracle.neg_mean_loss(q)
     assert np.array_equal(dq.cpu().numpy(), dq_ref) and abs(s.item() - s_ref) <= 1e-9
+
+
+def test_dsac_kernels_vs_oracle(dev, oracle):
+    """gymrl_dsac_target / _critic_loss / _actor_loss / _alpha_step vs the oracle: element maps bit-exact
+    (same det_expf / det_logf), sums to 1e-12 relative, the scalar Adam step bit-exact over several steps."""
+    from gymrl_amd import ops
+    rng = np.random.default_rng(12)
+    for B, A in ((1, 2), (257, 2), (5000, 4), (4096, 8)):
+        z = rng.normal(size=(B, A)) * 2
+        p = (np.exp(z) / np.exp(z).sum(1, keepdims=True)).astype(np.float32)
+        q1, q2 = (rng.normal(size=(B, A)).astype(np.float32) for _ in range(2))
+        rew = rng.normal(size=B).astype(np.float32)
+        done = (rng.random(B) < 0.2).astype(np.float32)
+        act = rng.integers(0, A, B).astype(np.int32)
+        la = np.float32(np.log(0.2))
+        la_t = t(np.array([la]), dev)
+        y = ops.dsac_target(t(p, dev), t(q1, dev), t(q2, dev), t(rew, dev), t(done, dev), la_t, 0.9)
+        y_ref = oracle.dsac_target(p, q1, q2, rew, done, float(la), 0.9)
+        assert np.array_equal(y.cpu().numpy(), y_ref), (B, A)
+        s = torch.zeros(2, dtype=torch.float64, device=dev)
+        d1, d2 = ops.dsac_critic_loss(t(q1, dev), t(q2, dev), t(act, dev), y, s)
+        r1, r2, rs = oracle.dsac_critic_loss(q1, q2, act, y_ref)
+        assert np.array_equal(d1.cpu().numpy(), r1) and np.array_equal(d2.cpu().numpy(), r2)
+        assert np.all(np.abs(s.cpu().numpy() - rs) <= 1e-12 * np.abs(rs))
+        s.zero_()
+        dp = ops.dsac_actor_loss(t(p, dev), t(q1, dev), t(q2, dev), la_t, s)
+        rp, rs = oracle.dsac_actor_loss(p, q1, q2, float(la))
+        assert np.array_equal(dp.cpu().numpy(), rp)
+        assert np.all(np.abs(s.cpu().numpy() - rs) <= 1e-12 * np.maximum(1.0, np.abs(rs)))
+        m, v = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        cur, mm, vv = float(la), 0.0, 0.0
+        for step in range(1, 5):
+            ops.dsac_alpha_step(la_t, m, v, s, B, -1.0, 1e-3, step, loss_out=loss)
+            cur, mm, vv, lo = oracle.dsac_alpha_step(cur, mm, vv, rs, B, -1.0, 1e-3, step)
+            assert la_t.item() == np.float32(cur) and m.item() == np.float32(mm) and v.item() == np.float32(vv)
+            assert abs(loss.item() - lo) <= 1e-12 * max(1.0, abs(lo))

@@ -134,3 +134,36 @@ def test_td3_ddpg_noise_and_losses(oracle):
     assert np.allclose(dq, q.grad.numpy(), rtol=1e-6, atol=1e-8) and abs(s / 50 - loss.item()) <= 1e-6
     dq, s = oracle.neg_mean_loss(q.detach().numpy())
     assert np.array_equal(dq, np.full(50, -1.0 / 50, np.float32)) and abs(-s / 50 + q.mean().item()) <= 1e-6
+
+
+def test_dsac_pieces_match_reference(oracle):
+    """SURVEY 8f.3 discrete SAC: soft-Bellman target, both critic losses + dL/dQ, actor loss + dL/dprobs and the
+    float32 log_alpha Adam step vs tensors computed by the reference's own networks / optimiser (dsac.npz)."""
+    g = load_golden("dsac")
+    la0 = float(g["log_alpha0"][0])
+    y = oracle.dsac_target(g["k_next_probs"], g["k_next_q1"], g["k_next_q2"], g["rewards"], g["dones"].astype(np.float32),
+                           la0, float(g["gamma"]))
+    assert rel_close(y, g["k_target_q"], 1e-6) <= 1e-6
+    d1, d2, s = oracle.dsac_critic_loss(g["k_q1"], g["k_q2"], g["actions"], g["k_target_q"])
+    B = len(y)
+    assert np.allclose(d1, g["k_dq1"], rtol=1e-6, atol=1e-9) and np.allclose(d2, g["k_dq2"], rtol=1e-6, atol=1e-9)
+    assert rel_close(s / B, g["k_critic_losses"], 1e-6) <= 1e-6
+    dp, sa = oracle.dsac_actor_loss(g["k_probs"], g["k_q1"], g["k_q2"], la0)
+    assert np.allclose(dp, g["k_dprobs"], rtol=2e-6, atol=1e-8)
+    assert abs(sa[0] / B - float(g["k_actor_loss"])) <= 1e-6 and abs(sa[1] / B - float(g["k_entropy_mean"])) <= 1e-6
+    # first alpha step of the reference run: the actor has moved by then, so only the Adam arithmetic is pinned:
+    # with m = v = 0, step 1 moves log_alpha by -lr * sign(g) (up to eps)
+    la1, m, v, loss = oracle.dsac_alpha_step(la0, 0.0, 0.0, sa, B, float(g["target_entropy"]), 1e-3, 1)
+    assert abs(loss - float(g["losses"][0][3])) <= 2e-3          # same entropy up to one actor step
+    assert abs(la1 - float(g["log_alphas"][0])) <= 1e-6
+    import torch
+    p = torch.tensor([la0], requires_grad=True)
+    opt = torch.optim.Adam([p], lr=1e-3)
+    mm = vv = 0.0
+    cur = la0
+    for step, ent in enumerate((0.61, 0.35, 0.5), 1):
+        opt.zero_grad()
+        (p.exp() * (torch.tensor(ent) - float(g["target_entropy"]))).sum().backward()
+        opt.step()
+        cur, mm, vv, _ = oracle.dsac_alpha_step(cur, mm, vv, np.array([0.0, ent * 8]), 8, float(g["target_entropy"]), 1e-3, step)
+        assert abs(cur - p.item()) <= 2e-7, step

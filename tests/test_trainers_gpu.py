@@ -405,3 +405,47 @@ def test_td3_ddpg_update_matches_reference(name):
         assert abs(al - want[0]) <= 1e-5 * max(1.0, abs(want[0])) and abs(cl - want[1]) <= 1e-5 * max(1.0, abs(want[1]))
     for key in ("actor", "critic", "actor_target", "critic_target"):
         assert _maxdiff(getattr(tr, key), g, f"{name}_u1_{key}_") <= 5e-6, key
+
+
+def test_dsac_update_matches_reference():
+    """two consecutive reference SACTrainer.update() calls of the discrete SAC (sac_cartpole.py:148-227)
+    reproduced from the same weights, temperature and batch order: four losses, log_alpha, all five networks."""
+    from gymrl_amd import sac_cartpole
+    from conftest import load_golden as lg
+    g = lg("dsac")
+    cfg = sac_cartpole.Config()
+    cfg.batch_size, cfg.hidden_dim, cfg.num_envs = 32, 32, 1
+    tr = sac_cartpole.SACTrainer(cfg)
+    dev = tr.device
+    nets = ("actor", "critic1", "critic2", "critic1_target", "critic2_target")
+    for key in nets:
+        _load_prefixed(getattr(tr, key), g, f"u0_{key}_")
+    tr.log_alpha.copy_(torch.from_numpy(g["log_alpha0"]))
+    td = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a if dt is None else a.astype(dt))).to(dev)  # noqa: E731
+    assert int(tr.select_action(td(g["sel_state"]).view(1, 4), deterministic=True)) == int(g["sel_det"])
+    tr.memory.push(td(g["states"]), td(g["actions"]), td(g["rewards"]), td(g["next_states"]), td(g["dones"]))
+    for k, order in enumerate(g["orders"]):
+        got = tr.update(indices=td(order))
+        want = g["losses"][k]
+        for a, b in zip(got, want):
+            assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (k, got, want)
+        assert abs(tr.log_alpha.item() - float(g["log_alphas"][k])) <= 1e-6
+    for key in nets:
+        sd = getattr(tr, key).state_dict()
+        diff = max(float(np.max(np.abs(v.detach().cpu().numpy() - g[f"u2_{key}_{k}"]))) for k, v in sd.items())
+        assert diff <= 5e-6, (key, diff)
+
+
+def test_dsac_smoke():
+    """A few hundred vector steps of the discrete-SAC trainer on CartPole: finite losses, the ring fills,
+    targets move, the temperature stays positive, evaluation returns episode returns."""
+    from gymrl_amd import sac_cartpole
+    c = sac_cartpole.Config()
+    c.num_envs, c.max_episodes = 32, 10**9
+    tr = sac_cartpole.SACTrainer(c)
+    t0 = tr.c1_target_flat.clone()
+    tr.train(max_vector_steps=150)
+    out = tr.update()
+    assert all(np.isfinite(x) for x in out) and len(tr.memory) == 32 * 150
+    assert not torch.equal(t0, tr.c1_target_flat) and len(tr.episode_rewards) > 0
+    assert all(np.isfinite(r) and r >= 1 for r in tr.eval(4))
