@@ -213,6 +213,102 @@ __global__ __launch_bounds__(kBlock) void ppo_full_loss_kernel(
   if (partials) block_partials<9, kBlock>(met, partials);
 }
 
+// ------------------------------------------------- recurrent-PPO (L4) loss ---
+// ppo_lstm_lunarlander.py:716-776: the L3 terms, but every mean is a masked mean over the
+// entropy-ratio mask (sum / count, 0 when the mask is empty :646-655) and the value loss is the
+// clipped one (:763-770).  The count is an integer, so pass 1 adds it up with atomics
+// (order-independent); pass 2 reads it.
+template <int A>
+__global__ __launch_bounds__(kBlock) void erc_count_kernel(const float* __restrict__ logits,
+                                                           const int32_t* __restrict__ idx,
+                                                           const float* __restrict__ ent_old, int B,
+                                                           gymrl_ppo_full_cfg cfg, uint32_t* __restrict__ count) {
+  uint32_t c = 0;
+  for (int b = blockIdx.x * kBlock + threadIdx.x; b < B; b += gridDim.x * kBlock) {
+    float z[A], ln[A], p[A], H;
+    load_row<A>(logits, b, z);
+    log_softmax<A>(z, ln, p, H);
+    const float er = H / (ent_old[idx ? idx[b] : b] + 1e-8f);
+    c += (er > (1.0f - cfg.erc_beta_low) && er < (1.0f + cfg.erc_beta_high)) ? 1u : 0u;
+  }
+  const uint64_t m = __ballot(c & 1u);               // at most a few rows per thread: add them bit by bit
+  uint32_t w = (uint32_t)__popcll(m);
+  for (uint32_t bit = 1; bit < 16; ++bit) w += (uint32_t)__popcll(__ballot((c >> bit) & 1u)) << bit;
+  if ((threadIdx.x & 63) == 0 && w) atomicAdd(count, w);
+}
+
+template <int A>
+__global__ __launch_bounds__(kBlock) void ppo_rnn_loss_kernel(
+    const float* __restrict__ logits, const float* __restrict__ value,
+    const int32_t* __restrict__ idx, const int32_t* __restrict__ act,
+    const float* __restrict__ logp_old, const float* __restrict__ ent_old,
+    const float* __restrict__ val_old, const float* __restrict__ adv, const float* __restrict__ ret,
+    int B, gymrl_ppo_full_cfg cfg, const uint32_t* __restrict__ count,
+    float* __restrict__ dlogits_out, float* __restrict__ dvalue_out, double* __restrict__ partials) {
+  double met[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const uint32_t cnt = *count;
+  const float inv = cnt ? 1.0f / (float)cnt : 0.0f;
+  for (int b = blockIdx.x * kBlock + threadIdx.x; b < B; b += gridDim.x * kBlock) {
+    float z[A], ln[A], p[A], H;
+    load_row<A>(logits, b, z);
+    const float v = value[b];
+    const int i = idx ? idx[b] : b;
+    const int a = act[i];
+    const float lpo = logp_old[i];
+    const float eo = ent_old[i];
+    const float vo = val_old[i];
+    const float ad = adv[i];
+    const float rt = ret[i];
+    log_softmax<A>(z, ln, p, H);
+    float lp = ln[0];
+#pragma unroll
+    for (int k = 1; k < A; ++k) if (a == k) lp = ln[k];
+
+    const float er = H / (eo + 1e-8f);
+    const float corr = (er > (1.0f - cfg.erc_beta_low) && er < (1.0f + cfg.erc_beta_high)) ? 1.0f : 0.0f;
+    const float ratio = det_expf(lp - lpo);
+    const float lo = 1.0f - cfg.clip_eps_min, hi = 1.0f + cfg.clip_eps_max;
+    const float r1 = fminf(fmaxf(ratio, 0.0f), cfg.dual_clip);
+    const float r2 = fminf(fmaxf(ratio, lo), hi);
+    const float s1 = r1 * ad, s2 = r2 * ad;
+    const float in1 = (ratio >= 0.0f && ratio <= cfg.dual_clip) ? 1.0f : 0.0f;
+    const float in2 = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
+    const float w1 = s1 < s2 ? 1.0f : (s1 == s2 ? 0.5f : 0.0f);
+    const float ms = fminf(s1, s2);
+    const float dms_dr = w1 * ad * in1 + (1.0f - w1) * ad * in2;
+    const float scale = corr * inv;
+    const float g_lp = -scale * dms_dr * ratio;
+    const float g_H = -cfg.entropy_coef * scale;
+    float dz[A];
+#pragma unroll
+    for (int k = 0; k < A; ++k) {
+      const float onehot = (a == k) ? 1.0f : 0.0f;
+      dz[k] = g_lp * (onehot - p[k]) + g_H * (-p[k] * (ln[k] + H));
+    }
+    store_row<A>(dlogits_out, b, dz);
+    // clipped value loss: 0.5 * max((v - ret)^2, (v_old + clamp(v - v_old, -eps_min, eps_max) - ret)^2)
+    const float dv = v - vo;
+    const float vc = vo + fminf(fmaxf(dv, -cfg.clip_eps_min), cfg.clip_eps_max);
+    const float inv_ = (dv >= -cfg.clip_eps_min && dv <= cfg.clip_eps_max) ? 1.0f : 0.0f;
+    const float e1 = v - rt, e2 = vc - rt;
+    const float l1 = e1 * e1, l2 = e2 * e2;
+    const float wv = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f);       // torch.max tie: 1/2, 1/2
+    dvalue_out[b] = 0.5f * scale * (wv * 2.0f * e1 + (1.0f - wv) * 2.0f * e2 * inv_);
+
+    met[0] += (double)(-ms * corr);
+    met[1] += (double)(0.5f * corr * fmaxf(l1, l2));
+    met[2] += (double)(H * corr);
+    met[3] += (ratio < lo || ratio > hi) ? (double)corr : 0.0;
+    met[4] += (double)(lpo - lp);
+    met[5] += 1.0 - (double)corr;
+    met[6] += (double)lp;
+    met[7] += (double)ad;
+    met[8] += (double)lp * (double)ad;
+    met[9] += (double)corr;
+  }
+  if (partials) block_partials<10, kBlock>(met, partials);
+}
+
 // metrics_sum[k] += sum over blocks of partials[block][k], fixed order (no atomics:
 // 32k same-address f64 atomics cost ~400 us at B = 8.4M, more than the kernel itself).
 template <int K>
@@ -382,6 +478,35 @@ int gymrl_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const i
                                 dlogits_out, dvalue_out, parts));
   if (metrics_sum)
     hipLaunchKernelGGL(metrics_finalize_kernel<9>, dim3(1), dim3(kBlock), 0, stream, parts, nb,
+                       metrics_sum);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_ppo_rnn_loss_fwd_bwd(const float* logits, const float* value, const int32_t* idx,
+                               const int32_t* act, const float* logp_old, const float* ent_old,
+                               const float* val_old, const float* adv, const float* ret, int B, int n_actions,
+                               const gymrl_ppo_full_cfg* cfg_host, float* dlogits_out,
+                               float* dvalue_out, double* metrics_sum, void* workspace, void* stream_) {
+  if (!logits || !value || !act || !logp_old || !ent_old || !val_old || !adv || !ret || !cfg_host ||
+      !dlogits_out || !dvalue_out || !workspace || B < 0 || B > (1 << 24))
+    return -22;
+  if (B == 0) return 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  const gymrl_ppo_full_cfg cfg = *cfg_host;
+  const int nb = cdiv(B, kBlock) < kMaxLossBlocks ? cdiv(B, kBlock) : kMaxLossBlocks;
+  double* parts = (double*)workspace;
+  uint32_t* count = reinterpret_cast<uint32_t*>(parts + kMaxLossBlocks * 10);
+  if (hipMemsetAsync(count, 0, sizeof(uint32_t), stream) != hipSuccess) return -1000 - (int)hipGetLastError();
+  DISPATCH_A(n_actions,
+             hipLaunchKernelGGL(erc_count_kernel<A>, dim3(nb), dim3(kBlock), 0, stream, logits, idx, ent_old, B,
+                                cfg, count));
+  DISPATCH_A(n_actions,
+             hipLaunchKernelGGL(ppo_rnn_loss_kernel<A>, dim3(nb), dim3(kBlock), 0, stream, logits, value, idx,
+                                act, logp_old, ent_old, val_old, adv, ret, B, cfg, count, dlogits_out,
+                                dvalue_out, metrics_sum ? parts : nullptr));
+  if (metrics_sum)
+    hipLaunchKernelGGL(metrics_finalize_kernel<10>, dim3(1), dim3(kBlock), 0, stream, parts, nb,
                        metrics_sum);
   GYMRL_CHECK_LAUNCH();
   return 0;

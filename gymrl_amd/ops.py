@@ -184,6 +184,45 @@ def ppo_full_loss_fwd_bwd(logits, value, act, logp_old, ent_old, adv, ret, cfg, 
     return dlogits_out, dvalue_out
 
 
+def ppo_rnn_loss_fwd_bwd(logits, value, act, logp_old, ent_old, val_old, adv, ret, cfg, idx=None, metrics_sum=None):
+    """L4 (ppo_lstm_lunarlander.py:716-776): masked means + clipped value loss.  metrics_sum f64[10]."""
+    B, A = logits.shape
+    dlogits, dvalue = torch.empty_like(logits), torch.empty(B, dtype=torch.float32, device=logits.device)
+    c = PPOFullCfg(*cfg)
+    check(lib().gymrl_ppo_rnn_loss_fwd_bwd(_ptr(logits, torch.float32), _ptr(value, torch.float32),
+                                           _ptr(idx, torch.int32, True), _ptr(act, torch.int32),
+                                           _ptr(logp_old, torch.float32), _ptr(ent_old, torch.float32),
+                                           _ptr(val_old, torch.float32), _ptr(adv, torch.float32),
+                                           _ptr(ret, torch.float32), C.c_int(B), C.c_int(A), C.byref(c), _ptr(dlogits),
+                                           _ptr(dvalue), _ptr(metrics_sum, torch.float64, True),
+                                           _ptr(_reduce_ws(logits.device)), _stream()), "gymrl_ppo_rnn_loss_fwd_bwd")
+    return dlogits, dvalue
+
+
+def gru_cell_fwd(gi, gh, h, out=None):
+    B, H = h.shape
+    out = torch.empty_like(h) if out is None else out
+    check(lib().gymrl_gru_cell_fwd(_ptr(gi, torch.float32), _ptr(gh, torch.float32), _ptr(h, torch.float32), C.c_int(B),
+                                   C.c_int(H), _ptr(out, torch.float32), _stream()), "gymrl_gru_cell_fwd")
+    return out
+
+
+def gru_cell_bwd(gi, gh, h, dh_out):
+    B, H = h.shape
+    dgi, dgh, dh = torch.empty_like(gi), torch.empty_like(gh), torch.empty_like(h)
+    check(lib().gymrl_gru_cell_bwd(_ptr(gi, torch.float32), _ptr(gh, torch.float32), _ptr(h, torch.float32),
+                                   _ptr(dh_out, torch.float32), C.c_int(B), C.c_int(H), _ptr(dgi), _ptr(dgh), _ptr(dh),
+                                   _stream()), "gymrl_gru_cell_bwd")
+    return dgi, dgh, dh
+
+
+def rnd_reward(predict, target, rew_inout=None, rnd_out=None):
+    B, E = predict.shape
+    check(lib().gymrl_rnd_reward(_ptr(predict, torch.float32), _ptr(target, torch.float32), C.c_int(B), C.c_int(E),
+                                 _ptr(rew_inout, torch.float32, True), _ptr(rnd_out, torch.float32, True), _stream()),
+          "gymrl_rnd_reward")
+
+
 def loss_blocks(B):
     return int(lib().gymrl_loss_blocks(C.c_int(B)))
 

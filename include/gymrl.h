@@ -237,6 +237,37 @@ int gymrl_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const i
                                 float* dlogits_out, float* dvalue_out,
                                 double* metrics_sum, void* workspace, void* stream);
 
+/* L4: recurrent-PPO minibatch loss — ppo_lstm_lunarlander.py:716-776.  The L3 terms with
+ * (a) every mean a masked mean over the entropy-ratio mask `corr`: sum(x*corr)/sum(corr), 0 when the mask is
+ * empty (masked_mean :646-655), and (b) the clipped value loss :763-770
+ *   0.5 * masked_mean(max((v - ret)^2, (v_old + clamp(v - v_old, -clip_eps_min, +clip_eps_max) - ret)^2)).
+ * val_old f32[*] = values stored at collection.  The RND loss (:775) is a plain mean of squares and stays with
+ * the network's autograd.  metrics_sum f64[10]: the nine L3 sums (index 1 = sum 0.5*corr*max(...)) followed by
+ * sum(corr); the caller divides sums 0..3 by metrics_sum[9] (or reports 0 when it is 0).
+ * workspace >= gymrl_reduce_workspace_bytes(). */
+int gymrl_ppo_rnn_loss_fwd_bwd(const float* logits, const float* value, const int32_t* idx,
+                               const int32_t* act, const float* logp_old, const float* ent_old,
+                               const float* val_old, const float* adv, const float* ret, int B, int A,
+                               const gymrl_ppo_full_cfg* cfg_host, float* dlogits_out, float* dvalue_out,
+                               double* metrics_sum, void* workspace, void* stream);
+
+/* Pointwise half of torch.nn.GRU's cell as used by URNN — ppo_lstm_lunarlander.py:449-491 (nn.GRU,
+ * batch_first, one layer).  gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh, both f32[B,3H] in PyTorch's gate
+ * order (r, z, n); h f32[B,H]:
+ *   r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r*gh_n), h_out = (1 - z)*n + z*h.
+ * _bwd recomputes the gates from (gi, gh) and writes dgi, dgh f32[B,3H] and the direct dh f32[B,H]
+ * (dh_out * z; the path through gh is the caller's GEMM).  H % 4 == 0, 16-byte aligned pointers. */
+int gymrl_gru_cell_fwd(const float* gi, const float* gh, const float* h, int B, int H, float* h_out,
+                       void* stream);
+int gymrl_gru_cell_bwd(const float* gi, const float* gh, const float* h, const float* dh_out, int B, int H,
+                       float* dgi, float* dgh, float* dh, void* stream);
+
+/* RND intrinsic reward — ppo_lstm_lunarlander.py:588-590: rnd[b] = mean_e (predict[b,e] - target[b,e])^2
+ * (float32, as numpy's mean of a float32 array), rew_inout[b] += rnd[b] when given, rnd_out[b] = rnd[b]
+ * when given.  One wave per row: lane l adds columns l, l+64, ... in order, then a shfl_down tree. */
+int gymrl_rnd_reward(const float* predict, const float* target, int B, int E, float* rew_inout,
+                     float* rnd_out, void* stream);
+
 /*
  * P6/P7: minibatch staging — ppo_lunarlander.py:238-272 (lists -> tensors, shuffled
  * index slices).  gymrl_pack_rollout writes one 64-B record per transition

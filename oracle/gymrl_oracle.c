@@ -397,6 +397,116 @@ void orc_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const in
   if (metrics_sum) for (int k = 0; k < 9; ++k) metrics_sum[k] += met[k];
 }
 
+/* L4 — recurrent PPO minibatch, ppo_lstm_lunarlander.py:716-776: L3 with masked means (:646-655)
+ * and the clipped value loss (:763-770).  metrics_sum f64[10] (last = sum corr). */
+void orc_ppo_rnn_loss_fwd_bwd(const float* logits, const float* value, const int32_t* idx,
+                              const int32_t* act, const float* logp_old, const float* ent_old,
+                              const float* val_old, const float* adv, const float* ret, int B, int A,
+                              const orc_ppo_full_cfg* cfg, float* dlogits_out, float* dvalue_out,
+                              double* metrics_sum) {
+  double met[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const float lo = 1.0f - cfg->clip_eps_min, hi = 1.0f + cfg->clip_eps_max;
+  unsigned cnt = 0;
+  for (int b = 0; b < B; ++b) {                                       /* erc_mask :722-726 */
+    float ln[8], p[8], H;
+    log_softmax(logits + (size_t)b * A, A, ln, p, &H);
+    float er = H / (ent_old[idx ? idx[b] : b] + 1e-8f);
+    cnt += (er > (1.0f - cfg->erc_beta_low) && er < (1.0f + cfg->erc_beta_high)) ? 1u : 0u;
+  }
+  const float inv = cnt ? 1.0f / (float)cnt : 0.0f;                   /* masked_mean: sum / count, 0 if empty */
+  for (int b = 0; b < B; ++b) {
+    const float* z = logits + (size_t)b * A;
+    int i = idx ? idx[b] : b;
+    int a = act[i];
+    float ad = adv[i], v = value[b], vo = val_old[i], rt = ret[i];
+    float ln[8], p[8], H;
+    log_softmax(z, A, ln, p, &H);
+    float lp = ln[a];
+    float er = H / (ent_old[i] + 1e-8f);
+    float corr = (er > (1.0f - cfg->erc_beta_low) && er < (1.0f + cfg->erc_beta_high)) ? 1.0f : 0.0f;
+    float ratio = orc_expf(lp - logp_old[i]);                         /* :728 */
+    float r1 = fminf(fmaxf(ratio, 0.0f), cfg->dual_clip);             /* :734 */
+    float r2 = fminf(fmaxf(ratio, lo), hi);                           /* :736-741 */
+    float s1 = r1 * ad, s2 = r2 * ad;
+    float in1 = (ratio >= 0.0f && ratio <= cfg->dual_clip) ? 1.0f : 0.0f;
+    float in2 = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
+    float w1 = s1 < s2 ? 1.0f : (s1 == s2 ? 0.5f : 0.0f);
+    float ms = fminf(s1, s2);
+    float dms_dr = w1 * ad * in1 + (1.0f - w1) * ad * in2;
+    float scale = corr * inv;
+    float g_lp = -scale * dms_dr * ratio;                             /* :761 */
+    float g_H = -cfg->entropy_coef * scale;                           /* :772-773 */
+    for (int k = 0; k < A; ++k) {
+      float onehot = (a == k) ? 1.0f : 0.0f;
+      dlogits_out[(size_t)b * A + k] = g_lp * (onehot - p[k]) + g_H * (-p[k] * (ln[k] + H));
+    }
+    float dv = v - vo;                                                /* :763-770 */
+    float vc = vo + fminf(fmaxf(dv, -cfg->clip_eps_min), cfg->clip_eps_max);
+    float inr = (dv >= -cfg->clip_eps_min && dv <= cfg->clip_eps_max) ? 1.0f : 0.0f;
+    float e1 = v - rt, e2 = vc - rt;
+    float l1 = e1 * e1, l2 = e2 * e2;
+    float wv = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f);
+    dvalue_out[b] = 0.5f * scale * (wv * 2.0f * e1 + (1.0f - wv) * 2.0f * e2 * inr);
+    met[0] += (double)(-ms * corr);
+    met[1] += (double)(0.5f * corr * fmaxf(l1, l2));
+    met[2] += (double)(H * corr);
+    met[3] += (ratio < lo || ratio > hi) ? (double)corr : 0.0;
+    met[4] += (double)(logp_old[i] - lp);
+    met[5] += 1.0 - (double)corr;
+    met[6] += (double)lp; met[7] += (double)ad; met[8] += (double)lp * (double)ad;
+    met[9] += (double)corr;
+  }
+  if (metrics_sum) for (int k = 0; k < 10; ++k) metrics_sum[k] += met[k];
+}
+
+/* URNN's GRU cell, pointwise half — ppo_lstm_lunarlander.py:449-491 (torch.nn.GRU gate order r, z, n). */
+static float orc_sigmoidf(float x) { return 1.0f / (1.0f + orc_expf(-x)); }
+void orc_gru_cell_fwd(const float* gi, const float* gh, const float* h, int B, int H, float* h_out) {
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < H; ++c) {
+      const float* i3 = gi + (size_t)b * 3 * H; const float* h3 = gh + (size_t)b * 3 * H;
+      float r = orc_sigmoidf(i3[c] + h3[c]);
+      float z = orc_sigmoidf(i3[H + c] + h3[H + c]);
+      float n = orc_tanhf(i3[2 * H + c] + r * h3[2 * H + c]);
+      h_out[(size_t)b * H + c] = (1.0f - z) * n + z * h[(size_t)b * H + c];
+    }
+}
+void orc_gru_cell_bwd(const float* gi, const float* gh, const float* h, const float* dh_out, int B, int H,
+                      float* dgi, float* dgh, float* dh) {
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < H; ++c) {
+      size_t g0 = (size_t)b * 3 * H + c, h0 = (size_t)b * H + c;
+      float r = orc_sigmoidf(gi[g0] + gh[g0]);
+      float z = orc_sigmoidf(gi[g0 + H] + gh[g0 + H]);
+      float hn = gh[g0 + 2 * H];
+      float n = orc_tanhf(gi[g0 + 2 * H] + r * hn);
+      float go = dh_out[h0];
+      float dn = go * (1.0f - z), dz = go * (h[h0] - n);
+      float dnp = dn * (1.0f - n * n);
+      float dr = (dnp * hn) * (r * (1.0f - r)), dzp = dz * (z * (1.0f - z));
+      dgi[g0] = dr; dgi[g0 + H] = dzp; dgi[g0 + 2 * H] = dnp;
+      dgh[g0] = dr; dgh[g0 + H] = dzp; dgh[g0 + 2 * H] = dnp * r;
+      dh[h0] = go * z;
+    }
+}
+
+/* RND reward — :588-590: float32 mean of squares; summation order of the device kernel (64 strided
+ * partial sums, then a halving tree). */
+void orc_rnd_reward(const float* predict, const float* target, int B, int E, float* rew_inout, float* rnd_out) {
+  for (int b = 0; b < B; ++b) {
+    float part[64];
+    for (int l = 0; l < 64; ++l) {
+      float s = 0.0f;
+      for (int c = l; c < E; c += 64) { float d = predict[(size_t)b * E + c] - target[(size_t)b * E + c]; s += d * d; }
+      part[l] = s;
+    }
+    for (int off = 32; off > 0; off >>= 1) for (int l = 0; l < off; ++l) part[l] += part[l + off];
+    float m = part[0] / (float)E;
+    if (rnd_out) rnd_out[b] = m;
+    if (rew_inout) rew_inout[b] = rew_inout[b] + m;
+  }
+}
+
 /* =========================================================== optimiser ==== */
 /* O1 — clip_grad_norm_ + torch.optim.Adam step, ppo_lunarlander.py:169,302-307. */
 void orc_sqnorm(const float* g, int64_t n, float grad_scale, double* out) {

@@ -211,6 +211,56 @@ def ppo_full_loss_fwd_bwd(logits, value, act, logp_old, ent_old, adv, ret, cfg, 
     return dl, dv, met
 
 
+def ppo_rnn_loss_fwd_bwd(logits, value, act, logp_old, ent_old, val_old, adv, ret, cfg, idx=None):
+    logits, value = _f32(logits), _f32(value)
+    B, A = logits.shape
+    act, logp_old, ent_old, val_old, adv, ret = _i32(act), _f32(logp_old), _f32(ent_old), _f32(val_old), _f32(adv), _f32(ret)
+    idx_ = None if idx is None else _i32(idx)
+    dl, dv = np.empty((B, A), np.float32), np.empty(B, np.float32)
+    met = np.zeros(10, np.float64)
+    c = PPOFullCfg(*cfg)
+    lib().orc_ppo_rnn_loss_fwd_bwd(_p(logits), _p(value), _p(idx_), _p(act), _p(logp_old), _p(ent_old), _p(val_old),
+                                   _p(adv), _p(ret), C.c_int(B), C.c_int(A), C.byref(c), _p(dl), _p(dv), _p(met))
+    return dl, dv, met
+
+
+def gru_cell_fwd(gi, gh, h):
+    gi, gh, h = _f32(gi), _f32(gh), _f32(h)
+    B, H = h.shape
+    out = np.empty_like(h)
+    lib().orc_gru_cell_fwd(_p(gi), _p(gh), _p(h), C.c_int(B), C.c_int(H), _p(out))
+    return out
+
+
+def gru_cell_bwd(gi, gh, h, dh_out):
+    gi, gh, h, dh_out = _f32(gi), _f32(gh), _f32(h), _f32(dh_out)
+    B, H = h.shape
+    dgi, dgh, dh = np.empty_like(gi), np.empty_like(gh), np.empty_like(h)
+    lib().orc_gru_cell_bwd(_p(gi), _p(gh), _p(h), _p(dh_out), C.c_int(B), C.c_int(H), _p(dgi), _p(dgh), _p(dh))
+    return dgi, dgh, dh
+
+
+def gru_forward(x, h0, w_ih, w_hh, b_ih, b_hh):
+    """torch.nn.GRU(batch_first=True, one layer) over x [B, L, D] from h0 [B, H] -> (out [B, L, H], h_L)."""
+    x, h = _f32(x), _f32(h0)
+    outs = []
+    for l in range(x.shape[1]):
+        gi = (x[:, l].astype(np.float64) @ _f32(w_ih).T.astype(np.float64) + b_ih).astype(np.float32)
+        gh = (h.astype(np.float64) @ _f32(w_hh).T.astype(np.float64) + b_hh).astype(np.float32)
+        h = gru_cell_fwd(gi, gh, h)
+        outs.append(h)
+    return np.stack(outs, 1), h
+
+
+def rnd_reward(predict, target, rew=None):
+    predict, target = _f32(predict), _f32(target)
+    B, E = predict.shape
+    rnd = np.empty(B, np.float32)
+    rew_ = None if rew is None else _f32(rew).copy()
+    lib().orc_rnd_reward(_p(predict), _p(target), C.c_int(B), C.c_int(E), _p(rew_), _p(rnd))
+    return rnd, rew_
+
+
 def pack_rollout(obs, act, logp, adv, ret):
     """ppo_lunarlander.py:238-250 staging as one 64-B record per transition (numpy restatement)."""
     obs = _f32(obs)

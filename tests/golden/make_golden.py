@@ -1116,8 +1116,182 @@ def gen_dsac():
     save("dsac", **out)
 
 
+def _small_lstm_ref(mod, hidden=32, head=32, embed=64):
+    """The reference's ActorCritic with its hard-coded 512s (ppo_lstm_lunarlander.py:84-95) replaced by small
+    widths so that fixtures stay small; forward / get_action / get_value are the reference's own methods."""
+    import torch.nn as nn
+
+    class SmallActorCritic(mod.ActorCritic):
+        def __init__(self, state_dim, action_dim, config=None):
+            nn.Module.__init__(self)
+            self.shared = mod.MHCBackbone(input_dim=state_dim, output_dim=config.mhc_dim, rate=config.mhc_rate,
+                                          num_layers=config.mhc_layers, max_sk_it=config.mhc_sk_it)
+            self.rnn = mod.URNN(input_size=config.mhc_dim, hidden_size=hidden, layer=nn.GRU)
+            self.actor = mod.MLP([hidden, head, action_dim], last_std=0.001)
+            self.critic = mod.MLP([hidden, head, 1], last_std=1.0)
+            self.rnd = mod.RND(input_dim=state_dim, embed_dim=embed)
+    return SmallActorCritic
+
+
+def gen_ppo_lstm_parts():
+    """SURVEY 8f.2 pieces: the reference URNN (nn.GRU) forward + gradients on a short window, the RND reward
+    arithmetic (:588-590), and the L4 minibatch loss (:716-776: masked means via the reference's masked_mean,
+    clipped value loss) on given logits/values, including a minibatch whose entropy-ratio mask is empty."""
+    mod = load_ref("algorithms/ppo_lstm_lunarlander.py", "ref_ppo_lstm")
+    cfg = mod.Config()
+    from torch.distributions import Categorical
+    out = {}
+    seed_all(41)
+    rnn = mod.URNN(input_size=12, hidden_size=16, layer=torch.nn.GRU)
+    x = torch.randn(5, 6, 12, requires_grad=True)
+    h0 = (0.5 * torch.randn(5, 16)).requires_grad_(True)
+    w_out, w_h = torch.randn(5, 6, 16), torch.randn(5, 16)
+    ro, hn = rnn(x, h0)
+    ((ro * w_out).sum() + (hn * w_h).sum()).backward()
+    out.update({"gru_x": x.detach().numpy(), "gru_h0": h0.detach().numpy(), "gru_w_out": w_out.numpy(), "gru_w_h": w_h.numpy(),
+                "gru_out": ro.detach().numpy(), "gru_hn": hn.detach().numpy(), "gru_dx": x.grad.numpy(), "gru_dh0": h0.grad.numpy()})
+    for k, v in rnn.state_dict().items():
+        out["gru_sd_" + k] = v.numpy().copy()
+    for k, p_ in rnn.named_parameters():
+        out["gru_grad_" + k] = p_.grad.numpy().copy()
+    pred, targ = torch.randn(7, 64).numpy(), torch.randn(7, 64).numpy()
+    out.update({"rnd_predict": pred, "rnd_target": targ,
+                "rnd_reward": np.array([np.mean((pred[i:i + 1] - targ[i:i + 1]) ** 2) for i in range(7)], np.float32)})
+    mm = lambda x_, m_: mod.PPOTrainer.masked_mean(None, x_, m_)          # noqa: E731
+    for case, (B, ent_shift) in enumerate(((256, 0.4), (1024, 0.15), (64, 3.0))):
+        seed_all(50 + case)
+        logits = (torch.randn(B, 4) * 1.5).requires_grad_(True)
+        values = torch.randn(B, requires_grad=True)
+        with torch.no_grad():
+            old_logits = logits * (1.0 + (ent_shift if case == 2 else 0.0)) + ent_shift * torch.randn(B, 4) * (case != 2)
+            d_old = Categorical(logits=old_logits)
+            a_batch = d_old.sample()
+            old_lp, old_ent = d_old.log_prob(a_batch), d_old.entropy()
+            old_values = values + 0.3 * torch.randn(B)
+        adv_batch, ret_batch = torch.randn(B) * 2, torch.randn(B) * 3
+        ent_coef = 0.0123
+        dist = Categorical(logits=logits)
+        new_lp, new_ent = dist.log_prob(a_batch), dist.entropy()
+        entropy_ratio = new_ent / (old_ent + 1e-8)
+        erc_mask = ((entropy_ratio > (1 - cfg.erc_beta_low)) & (entropy_ratio < (1 + cfg.erc_beta_high))).float()
+        ratio = (new_lp - old_lp).exp()
+        covs = (new_lp - new_lp.mean()) * (adv_batch - adv_batch.mean())
+        corr = torch.ones_like(adv_batch) * erc_mask
+        surr1 = ratio.clamp(0.0, cfg.dual_clip) * adv_batch
+        surr2 = torch.clamp(ratio, 1 - cfg.clip_eps_min, 1 + cfg.clip_eps_max) * adv_batch
+        clip_frac = mm(((ratio < (1 - cfg.clip_eps_min)) | (ratio > (1 + cfg.clip_eps_max))).float(), corr)
+        policy_loss = mm(-torch.min(surr1, surr2), corr)
+        value_clip = old_values + (values - old_values).clamp(-cfg.clip_eps_min, cfg.clip_eps_max)
+        value_loss = 0.5 * mm(torch.max((values - ret_batch).pow(2), (value_clip - ret_batch).pow(2)), corr)
+        entropy = mm(dist.entropy(), corr)
+        loss = policy_loss + value_loss + ent_coef * -entropy
+        if loss.requires_grad:
+            loss.backward()
+        zero = lambda t_: torch.zeros_like(t_) if t_.grad is None else t_.grad       # noqa: E731
+        pre = f"l{case}_"
+        out.update({pre + "logits": logits.detach().numpy(), pre + "values": values.detach().numpy(),
+                    pre + "actions": a_batch.numpy().astype(np.int32), pre + "old_lp": old_lp.numpy(),
+                    pre + "old_ent": old_ent.numpy(), pre + "old_values": old_values.numpy(), pre + "adv": adv_batch.numpy(),
+                    pre + "ret": ret_batch.numpy(), pre + "dlogits": zero(logits).numpy(), pre + "dvalues": zero(values).numpy(),
+                    pre + "metrics": np.array([float(policy_loss), float(value_loss), float(entropy), float(clip_frac),
+                                               (old_lp - new_lp).mean().item(), 1.0 - erc_mask.mean().item(),
+                                               covs.mean().item(), erc_mask.sum().item()], np.float64)})
+    out["n_cases"] = np.int64(3)
+    out["cfg"] = np.array([cfg.clip_eps_min, cfg.clip_eps_max, cfg.dual_clip, cfg.erc_beta_low, cfg.erc_beta_high, 0.0123], np.float64)
+    save("ppo_lstm_parts", **out)
+
+
+def gen_ppo_lstm_trace():
+    """Row H1 for the recurrent trainer: the reference PPOTrainer.train() (ppo_lstm_lunarlander.py:814-822) run
+    for two collect -> advantages -> update iterations on the scripted env with the small-width ActorCritic.
+    Records the Exp(1) draws Categorical.sample consumed, the sequence permutations torch.randperm produced,
+    every buffer field incl. the stored hidden states and the RND-augmented rewards, adv/returns, per-minibatch
+    gradient norms and mask counts, lr / ent_coef / step_count / episode_rewards and the weights after each update."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from scripted_env import ScriptedEnv
+    mod = load_ref("algorithms/ppo_lstm_lunarlander.py", "ref_ppo_lstm_trace")
+    sys.modules["gymnasium"].make = lambda name, **kw: ScriptedEnv(8, 4)
+    mod.ActorCritic = _small_lstm_ref(mod)
+    cfg = mod.Config()
+    cfg.update_freq, cfg.seq_len, cfg.batch_size, cfg.num_epochs = 64, 8, 4, 2
+    cfg.mhc_dim, cfg.mhc_layers, cfg.mhc_sk_it = 16, 1, 4
+    cfg.max_train_steps, cfg.lr, cfg.seed = 2 * cfg.update_freq, 5e-3, 3
+    seed_all(0)
+    tr = mod.PPOTrainer(cfg)
+    with torch.no_grad():                                   # away from the near-uniform init policy (last_std = 0.001)
+        for n_, p_ in tr.model.named_parameters():
+            if n_.startswith("actor") or n_.endswith(".w") or n_.endswith(".alpha"):
+                p_.add_(0.25 * torch.randn_like(p_))
+    out = {"init_" + k: v.numpy().copy() for k, v in tr.model.state_dict().items()}
+    noise, perms, gnorms, counts, rollouts, upd = [], [], [], [], [], []
+    orig_get_action = tr.model.get_action
+
+    def get_action(x, hidden_state, deterministic=False):
+        st = torch.get_rng_state()
+        res = orig_get_action(x, hidden_state, deterministic)
+        after = torch.get_rng_state()
+        torch.set_rng_state(st)
+        q = torch.empty(1, 4).exponential_(1.0)
+        torch.set_rng_state(after)
+        noise.append(q.numpy()[0].copy())
+        return res
+    tr.model.get_action = get_action
+    orig_randperm, orig_clip, orig_mm = torch.randperm, mod.nn.utils.clip_grad_norm_, tr.masked_mean
+
+    def randperm(n, *a, **k):
+        r = orig_randperm(n, *a, **k)
+        if n == tr.num_sequences:
+            perms.append(r.numpy().astype(np.int32))
+        return r
+
+    def clip(params, max_norm, *a, **k):
+        tn = orig_clip(params, max_norm, *a, **k)
+        gnorms.append(float(tn))
+        return tn
+
+    def masked_mean(x, mask=None):
+        counts.append(float(mask.sum()))
+        return orig_mm(x, mask)
+    orig_update = tr.update_model
+
+    def update_model(adv, ret):
+        b = tr.buffer
+        rollouts.append(dict(states=np.array(b.states, np.float32), actions=np.array(b.actions, np.int32),
+                             log_probs=np.array(b.log_probs, np.float32), values=np.array(b.values, np.float32),
+                             rewards=np.array(b.rewards, np.float64), dones=np.array(b.dones, np.uint8),
+                             old_entropies=np.array(b.old_entropies, np.float32),
+                             hidden_states=np.array(b.hidden_states, np.float32), next_value=np.float64(b.next_value),
+                             adv=np.asarray(adv, np.float64), ret=np.asarray(ret, np.float64)))
+        orig_update(adv, ret)
+        upd.append(dict(lr=np.float64(tr.lr), ent_coef=np.float64(tr.ent_coef), step_count=np.int64(tr.step_count),
+                        episode_rewards=np.array(tr.episode_rewards, np.float64),
+                        **{"sd_" + k: v.numpy().copy() for k, v in tr.model.state_dict().items()}))
+    tr.update_model = update_model
+    tr.masked_mean = masked_mean
+    torch.randperm, mod.nn.utils.clip_grad_norm_ = randperm, clip
+    try:
+        tr.train()
+    finally:
+        torch.randperm, mod.nn.utils.clip_grad_norm_ = orig_randperm, orig_clip
+    T, n_mb = cfg.update_freq, tr.num_sequences // cfg.batch_size
+    assert len(rollouts) == 2 and len(perms) == 2 * cfg.num_epochs and len(gnorms) == 2 * cfg.num_epochs * n_mb
+    out["noise_exp"] = np.stack(noise).reshape(2, T, 1, 4).astype(np.float32)
+    out["perms"] = np.stack(perms).reshape(2, cfg.num_epochs, tr.num_sequences)
+    out["grad_norms"] = np.array(gnorms, np.float64).reshape(2, cfg.num_epochs * n_mb)
+    out["mask_counts"] = np.array(counts, np.float64).reshape(2, cfg.num_epochs * n_mb, 4)[:, :, 0]
+    for r in range(2):
+        for k, v in rollouts[r].items():
+            out[f"r{r}_{k}"] = v
+        for k, v in upd[r].items():
+            out[f"r{r}_{k}"] = v
+    out["cfg"] = np.array([cfg.update_freq, cfg.seq_len, cfg.batch_size, cfg.num_epochs, cfg.mhc_dim, cfg.mhc_layers,
+                           cfg.mhc_sk_it, cfg.max_train_steps, cfg.seed], np.int64)
+    out["lr0"] = np.float64(cfg.lr)
+    save("ppo_lstm_trace", **out)
+
+
 if __name__ == "__main__":
     names = sys.argv[1:]
-    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2, gen_dqn_trace, gen_sac_trace, gen_rainbow_trace, gen_td3_ddpg, gen_dsac]:
+    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2, gen_dqn_trace, gen_sac_trace, gen_rainbow_trace, gen_td3_ddpg, gen_dsac, gen_ppo_lstm_parts, gen_ppo_lstm_trace]:
         if not names or g.__name__ in names:
             g()

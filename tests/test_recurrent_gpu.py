@@ -1,0 +1,179 @@
+"""GPU parity for the recurrent-PPO row: GRU cell / RND reward / L4 loss kernels vs the oracle
+(bit-exact), the URNN module vs the reference's nn.GRU golden, and the reference PPOTrainer.train() trace."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_close
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_gru_cell_and_rnd_kernels_vs_oracle(dev, oracle):
+    from gymrl_amd import ops
+    rng = np.random.default_rng(21)
+    for B, H in ((1, 4), (37, 16), (300, 512), (4096, 64)):
+        gi, gh = (rng.normal(size=(B, 3 * H)) * 2).astype(np.float32), (rng.normal(size=(B, 3 * H)) * 2).astype(np.float32)
+        h, dho = rng.normal(size=(B, H)).astype(np.float32), rng.normal(size=(B, H)).astype(np.float32)
+        gi[0, :4] = (-100.0, 100.0, 0.0, -0.0)                         # saturated gates
+        out = ops.gru_cell_fwd(t(gi, dev), t(gh, dev), t(h, dev))
+        assert np.array_equal(out.cpu().numpy(), oracle.gru_cell_fwd(gi, gh, h)), (B, H)
+        got = ops.gru_cell_bwd(t(gi, dev), t(gh, dev), t(h, dev), t(dho, dev))
+        for a, b in zip(got, oracle.gru_cell_bwd(gi, gh, h, dho)):
+            assert np.array_equal(a.cpu().numpy(), b), (B, H)
+    for B, E in ((1, 64), (7, 512), (1000, 96), (5, 33)):
+        p, q = rng.normal(size=(B, E)).astype(np.float32), rng.normal(size=(B, E)).astype(np.float32)
+        rew = rng.normal(size=B).astype(np.float32)
+        r_dev, rnd_dev = t(rew, dev), torch.empty(B, device=dev)
+        ops.rnd_reward(t(p, dev), t(q, dev), rew_inout=r_dev, rnd_out=rnd_dev)
+        rnd, rew_ref = oracle.rnd_reward(p, q, rew=rew)
+        assert np.array_equal(rnd_dev.cpu().numpy(), rnd) and np.array_equal(r_dev.cpu().numpy(), rew_ref), (B, E)
+
+
+def test_rnn_loss_kernel_vs_oracle_and_reference(dev, oracle):
+    """gymrl_ppo_rnn_loss_fwd_bwd: gradients bit-exact vs the oracle, metric sums to 1e-12; on the golden cases
+    also directly against the reference's autograd gradients (incl. the empty-mask minibatch)."""
+    from gymrl_amd import ops
+    g = load_golden("ppo_lstm_parts")
+    cfg = tuple(float(x) for x in g["cfg"])
+    rng = np.random.default_rng(22)
+    cases = [tuple(g[f"l{c}_{k}"] for k in ("logits", "values", "actions", "old_lp", "old_ent", "old_values", "adv", "ret"))
+             + (None, c) for c in range(int(g["n_cases"]))]
+    for B, A, M in ((1, 2, 5), (1000, 4, 3000), (70001, 3, 70001)):          # with an index indirection
+        z = (rng.normal(size=(B, A)) * 1.5).astype(np.float32)
+        zo = z + 0.3 * rng.normal(size=(B, A)).astype(np.float32)
+        po = np.exp(zo - zo.max(1, keepdims=True)); po /= po.sum(1, keepdims=True)
+        idx = rng.permutation(M)[:B].astype(np.int32)
+        act, lpo, eo = (np.zeros(M, np.int32), np.zeros(M, np.float32), np.ones(M, np.float32))
+        a = np.array([rng.choice(A, p=pp / pp.sum()) for pp in po.astype(np.float64)], np.int32)
+        act[idx], lpo[idx], eo[idx] = a, np.log(po[np.arange(B), a]), -(po * np.log(po)).sum(1)
+        v = rng.normal(size=B).astype(np.float32)
+        vo, adv, ret = (rng.normal(size=M).astype(np.float32) for _ in range(3))
+        vo[idx] = v + 0.3 * rng.normal(size=B).astype(np.float32)
+        cases.append((z, v, act, lpo, eo, vo, adv, ret, idx, None))
+    for z, v, act, lpo, eo, vo, adv, ret, idx, gc in cases:
+        met = torch.zeros(10, dtype=torch.float64, device=dev)
+        dl, dv = ops.ppo_rnn_loss_fwd_bwd(t(z, dev), t(v, dev), t(act, dev), t(lpo, dev), t(eo, dev), t(vo, dev), t(adv, dev),
+                                          t(ret, dev), cfg, idx=None if idx is None else t(idx, dev), metrics_sum=met)
+        rl, rv, rm = oracle.ppo_rnn_loss_fwd_bwd(z, v, act, lpo, eo, vo, adv, ret, cfg, idx=idx)
+        assert np.array_equal(dl.cpu().numpy(), rl) and np.array_equal(dv.cpu().numpy(), rv)
+        assert np.all(np.abs(met.cpu().numpy() - rm) <= 1e-12 * np.maximum(1.0, np.abs(rm)))
+        if gc is not None:
+            assert np.allclose(dl.cpu().numpy(), g[f"l{gc}_dlogits"], rtol=2e-5, atol=2e-7)
+            assert np.allclose(dv.cpu().numpy(), g[f"l{gc}_dvalues"], rtol=2e-5, atol=2e-7)
+
+
+def test_urnn_module_matches_reference_gru(dev):
+    """URNN (F.linear gate GEMMs + the HIP cell behind autograd) vs the reference's torch.nn.GRU: outputs, final
+    state and every gradient of the golden window."""
+    from gymrl_amd.ppo_lstm_lunarlander import URNN
+    g = load_golden("ppo_lstm_parts")
+    rnn = URNN(12, 16).to(dev)
+    rnn.load_state_dict({k[len("gru_sd_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("gru_sd_")})
+    x, h0 = t(g["gru_x"], dev).requires_grad_(True), t(g["gru_h0"], dev).requires_grad_(True)
+    out, hn = rnn(x, h0)
+    ((out * t(g["gru_w_out"], dev)).sum() + (hn * t(g["gru_w_h"], dev)).sum()).backward()
+    assert rel_close(out.detach().cpu().numpy(), g["gru_out"], 2e-6) <= 2e-6
+    assert rel_close(hn.detach().cpu().numpy(), g["gru_hn"], 2e-6) <= 2e-6
+    assert rel_close(x.grad.cpu().numpy(), g["gru_dx"], 1e-5) <= 1e-5 and rel_close(h0.grad.cpu().numpy(), g["gru_dh0"], 1e-5) <= 1e-5
+    for k, p in rnn.named_parameters():
+        assert rel_close(p.grad.cpu().numpy(), g["gru_grad_" + k], 1e-5) <= 1e-5, k
+
+
+def _trainer_from_trace(g):
+    from gymrl_amd.ppo_lstm_lunarlander import Config, PPOTrainer
+    from scripted_env import ScriptedVecEnv
+    T, L, mb, epochs, mhc_dim, mhc_layers, sk_it, max_steps, seed = (int(x) for x in g["cfg"])
+    cfg = Config()
+    cfg.update_freq, cfg.seq_len, cfg.batch_size, cfg.num_epochs = T, L, mb, epochs
+    cfg.mhc_dim, cfg.mhc_layers, cfg.mhc_sk_it, cfg.max_train_steps, cfg.seed = mhc_dim, mhc_layers, sk_it, max_steps, seed
+    cfg.lr, cfg.num_envs = float(g["lr0"]), 1
+    cfg.rnn_hidden, cfg.head_hidden, cfg.rnd_embed = 32, 32, 64
+    tr = PPOTrainer(cfg)
+    sd = {k[len("init_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("init_")}
+    assert set(sd) == set(tr.model.state_dict())                          # the reference's parameter names
+    tr.model.load_state_dict(sd)
+    tr.env = ScriptedVecEnv(1, tr.device)
+    return tr, cfg
+
+
+def test_ppo_lstm_train_trace_matches_reference():
+    """Row H1 for the recurrent trainer: the reference PPOTrainer.train() (two collect -> advantages -> update
+    iterations on the scripted env, small-width network) replayed from the same weights, Exp(1) draws and
+    sequence permutations.  Integers (actions, dones, mask counts, step_count) exact; floats to 1e-5."""
+    g = load_golden("ppo_lstm_trace")
+    tr, cfg = _trainer_from_trace(g)
+    tr._parity_noise = [torch.from_numpy(g["noise_exp"][r]).to(tr.device) for r in range(2)]
+    tr._parity_perms = iter([torch.from_numpy(p.astype(np.int64)) for p in g["perms"].reshape(-1, g["perms"].shape[-1])])
+    tr.grad_norms = []
+    snaps = []
+    orig_update = tr.update_model
+
+    def update_model(adv, ret):
+        b = tr.buffer
+        snap = dict(states=b.states[:b.T, 0].cpu().numpy(), actions=b.actions[:, 0].cpu().numpy(),
+                    log_probs=b.log_probs[:, 0].cpu().numpy(), values=b.values[:, 0].cpu().numpy(),
+                    rewards=b.rewards[:, 0].cpu().numpy(), dones=b.dones[:, 0].cpu().numpy(),
+                    old_entropies=b.old_entropies[:, 0].cpu().numpy(), hidden_states=b.hidden_states[:, 0].cpu().numpy(),
+                    next_value=float(b.next_value[0]), adv=adv[:, 0].cpu().numpy(), ret=ret[:, 0].cpu().numpy())
+        n0 = len(tr.grad_norms)
+        m = orig_update(adv, ret)
+        snap.update(grad_norms=np.array(tr.grad_norms[n0:]), mask_counts=tr._last_metrics[:, 9].copy(), lr=tr.lr,
+                    ent_coef=tr.ent_coef, step_count=tr.step_count, episode_rewards=list(tr.episode_rewards),
+                    sd={k: v.detach().cpu().numpy().copy() for k, v in tr.model.state_dict().items()})
+        snaps.append(snap)
+        return m
+    tr.update_model = update_model
+    tr.train()
+    assert len(snaps) == 2
+    for r, s in enumerate(snaps):
+        assert np.array_equal(s["actions"], g[f"r{r}_actions"]) and np.array_equal(s["dones"], g[f"r{r}_dones"]), r
+        assert np.array_equal(s["states"], g[f"r{r}_states"]), r
+        for k in ("log_probs", "values", "rewards", "old_entropies", "hidden_states", "adv", "ret"):
+            assert rel_close(s[k], g[f"r{r}_{k}"], 1e-5) <= 1e-5, (r, k)
+        assert abs(s["next_value"] - float(g[f"r{r}_next_value"])) <= 1e-5 * max(1.0, abs(float(g[f"r{r}_next_value"])))
+        assert np.array_equal(s["mask_counts"], g["mask_counts"][r]), (r, s["mask_counts"], g["mask_counts"][r])
+        assert rel_close(s["grad_norms"], g["grad_norms"][r], 1e-4) <= 1e-4, (r, s["grad_norms"], g["grad_norms"][r])
+        assert abs(s["lr"] - float(g[f"r{r}_lr"])) <= 1e-12 and abs(s["ent_coef"] - float(g[f"r{r}_ent_coef"])) <= 1e-12
+        assert s["step_count"] == int(g[f"r{r}_step_count"])
+        assert np.array_equal(np.array(s["episode_rewards"]), g[f"r{r}_episode_rewards"]), r
+        worst = max(float(np.max(np.abs(v - g[f"r{r}_sd_{k}"]) / np.maximum(1.0, np.abs(g[f"r{r}_sd_{k}"])))) for k, v in s["sd"].items())
+        assert worst <= 2e-4, (r, worst)
+
+
+def test_ppo_lstm_smoke_and_checkpoint(tmp_path):
+    """The recurrent trainer on the real LunarLander stepper, default 512-wide network at small T: finite metrics,
+    RND reward added on top of the extrinsic one, hidden state zeroed at episode ends, checkpoint round trip."""
+    from gymrl_amd.ppo_lstm_lunarlander import Config, PPOTrainer
+    cfg = Config()
+    cfg.num_envs, cfg.update_freq, cfg.seq_len, cfg.batch_size, cfg.num_epochs, cfg.seed = 64, 128, 8, 256, 1, 2
+    cfg.mhc_dim = 64
+    tr = PPOTrainer(cfg)
+    tr.collect_experience()
+    b = tr.buffer
+    done = b.dones.bool()
+    assert done.any() and torch.all(b.hidden_states[0] == 0)
+    assert torch.all(b.hidden_states[1:][done[:-1]] == 0) and (b.hidden_states[1:][~done[:-1]] != 0).any()
+    adv, ret = tr.compute_advantages()
+    m = tr.update_model(adv, ret)
+    assert all(np.isfinite(v) for v in m.values()), m
+    assert 0.0 <= m["erc_clip_frac"] <= 1.0 and m["rnd_loss"] > 0
+    path = str(tmp_path / "rnn.pt")
+    tr.save_checkpoint(path)
+    ck = torch.load(path, weights_only=False)
+    assert {"net_state_dict", "optimizer_state_dict", "learn_step"} <= set(ck)
+    tr2 = PPOTrainer(cfg)
+    tr2.load_checkpoint(path)
+    assert torch.equal(tr2.flat_params, tr.flat_params) and torch.equal(tr2.optimizer.m, tr.optimizer.m)
+    assert tr2.rollout_count == 1 and tr2.step_count == tr.step_count
+    assert all(np.isfinite(r) for r in tr.eval(3))
