@@ -256,8 +256,10 @@ __global__ __launch_bounds__(kBlock) void sac_actor_kernel(const float* __restri
 __global__ void sac_alpha_step_kernel(double* __restrict__ log_alpha, double* __restrict__ m,
                                       double* __restrict__ v, const double* __restrict__ sums, int B,
                                       double lr, double beta1, double beta2, double eps, double bc1,
-                                      double bc2_sqrt, double* __restrict__ loss_out) {
+                                      double bc2_sqrt, const double* __restrict__ bias_dev,
+                                      double* __restrict__ loss_out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (bias_dev) { bc1 = bias_dev[0]; bc2_sqrt = sqrt(bias_dev[1]); }     // graph replay
   // alpha_loss = -(log_alpha * (logp + target_entropy).detach()).mean()
   const double mean_term = sums[2] / (double)B;
   if (loss_out) loss_out[0] = -(log_alpha[0] * mean_term);
@@ -442,7 +444,8 @@ __global__ __launch_bounds__(kBlock) void dsac_actor_kernel(const float* __restr
 // :209-215  L_alpha = mean(exp(log_alpha) (H - H_target).detach()); Adam on the float32 scalar.
 __global__ void dsac_alpha_kernel(float* __restrict__ log_alpha, float* __restrict__ m, float* __restrict__ v,
                                   const double* __restrict__ sums, int B, float target_entropy, float lr, float b1,
-                                  float b2, float eps, int64_t step, double* __restrict__ loss_out) {
+                                  float b2, float eps, int64_t step, const double* __restrict__ bias_dev,
+                                  double* __restrict__ loss_out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float alpha = det_expf(log_alpha[0]);
   const float mean_gap = (float)(sums[1] / (double)B) - target_entropy;
@@ -451,7 +454,8 @@ __global__ void dsac_alpha_kernel(float* __restrict__ log_alpha, float* __restri
   const float mm = b1 * m[0] + (1.0f - b1) * g;
   const float vv = b2 * v[0] + (1.0f - b2) * g * g;
   m[0] = mm; v[0] = vv;
-  const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+  const double bc1 = bias_dev ? bias_dev[0] : 1.0 - pow((double)b1, (double)step);
+  const double bc2 = bias_dev ? bias_dev[1] : 1.0 - pow((double)b2, (double)step);
   const float step_size = (float)((double)lr / bc1);
   const float denom = (float)(sqrt((double)vv) / sqrt(bc2)) + eps;
   log_alpha[0] = log_alpha[0] - step_size * (mm / denom);
@@ -559,13 +563,14 @@ int gymrl_sac_actor_loss(const float* logp, const float* q1, const float* q2, co
 }
 
 int gymrl_sac_alpha_step(double* log_alpha, double* m, double* v, const double* sums, int B, double lr,
-                         double beta1, double beta2, double eps, int64_t step, double* alpha_loss_out,
-                         void* stream_) {
-  if (!log_alpha || !m || !v || !sums || B <= 0 || step < 1) return -22;
+                         double beta1, double beta2, double eps, int64_t step, const double* bias_dev,
+                         double* alpha_loss_out, void* stream_) {
+  if (!log_alpha || !m || !v || !sums || B <= 0 || (step < 1 && !bias_dev)) return -22;
+  if (bias_dev) step = 1;
   const double bc1 = 1.0 - __builtin_pow(beta1, (double)step);
   const double bc2_sqrt = __builtin_sqrt(1.0 - __builtin_pow(beta2, (double)step));
   hipLaunchKernelGGL(sac_alpha_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, log_alpha, m, v, sums,
-                     B, lr, beta1, beta2, eps, bc1, bc2_sqrt, alpha_loss_out);
+                     B, lr, beta1, beta2, eps, bc1, bc2_sqrt, bias_dev, alpha_loss_out);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
@@ -655,11 +660,11 @@ int gymrl_dsac_actor_loss(const float* probs, const float* q1, const float* q2, 
 }
 
 int gymrl_dsac_alpha_step(float* log_alpha, float* m, float* v, const double* sums, int B, double target_entropy,
-                          double lr, double beta1, double beta2, double eps, int64_t step, double* alpha_loss_out,
-                          void* stream_) {
-  if (!log_alpha || !m || !v || !sums || B <= 0 || step <= 0) return -22;
+                          double lr, double beta1, double beta2, double eps, int64_t step, const double* bias_dev,
+                          double* alpha_loss_out, void* stream_) {
+  if (!log_alpha || !m || !v || !sums || B <= 0 || (step <= 0 && !bias_dev)) return -22;
   hipLaunchKernelGGL(dsac_alpha_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, log_alpha, m, v, sums, B,
-                     (float)target_entropy, (float)lr, (float)beta1, (float)beta2, (float)eps, step, alpha_loss_out);
+                     (float)target_entropy, (float)lr, (float)beta1, (float)beta2, (float)eps, step, bias_dev, alpha_loss_out);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

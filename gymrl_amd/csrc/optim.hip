@@ -63,6 +63,13 @@ __global__ __launch_bounds__(kBlock) void sqnorm_final_kernel(const double* __re
   if (threadIdx.x == 0) out[0] = sm[0];
 }
 
+// Up to 256 bytes of host scalars travel as a kernel argument and land in device memory: no
+// staging buffer whose reuse would have to be fenced, and stream-ordered like any launch.
+struct ScalarBlock { uint32_t w[64]; };
+__global__ void store_scalars_kernel(uint32_t* __restrict__ dst, ScalarBlock blk, int nwords) {
+  if (blockIdx.x == 0 && (int)threadIdx.x < nwords) dst[threadIdx.x] = blk.w[threadIdx.x];
+}
+
 struct AdamArgs {
   float step_size_host;  // (float)(lr / (1 - beta1^t)), python-double arithmetic
   float inv_bc1;         // 1 / (1 - beta1^t)   (used with a device-resident lr)
@@ -88,7 +95,11 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ p, flo
                                                       float* __restrict__ m, float* __restrict__ v,
                                                       int64_t n, AdamArgs a,
                                                       const float* __restrict__ lr_dev,
+                                                      const float* __restrict__ bias_dev,
                                                       const double* __restrict__ sqnorm) {
+  if (bias_dev) {          // graph replay: the step-dependent scalars live in device memory
+    a.step_size_host = bias_dev[0]; a.inv_bc1 = bias_dev[1]; a.bc2_sqrt = bias_dev[2];
+  }
   float scale = 1.0f;
   if (a.max_grad_norm > 0.0f && sqnorm) {
     const float total = (float)sqrt(sqnorm[0]);
@@ -164,11 +175,36 @@ int gymrl_sqnorm(const float* g, int64_t n, float grad_scale, double* sqnorm_out
   return 0;
 }
 
+// Host arithmetic of the step-dependent scalars, exactly as gymrl_adam_step does it.
+int gymrl_adam_bias(double lr, double beta1, double beta2, int64_t step, float* out_host) {
+  if (!out_host || step < 1) return -22;
+  const double bc1 = 1.0 - __builtin_pow(beta1, (double)step);
+  const double bc2 = 1.0 - __builtin_pow(beta2, (double)step);
+  out_host[0] = (float)(lr / bc1);
+  out_host[1] = (float)(1.0 / bc1);
+  out_host[2] = (float)__builtin_sqrt(bc2);
+  out_host[3] = 0.0f;
+  return 0;
+}
+
+int gymrl_store_scalars(void* dst_dev, const void* src_host, int nbytes, void* stream_) {
+  if (!dst_dev || !src_host || nbytes <= 0 || nbytes > (int)sizeof(ScalarBlock) || (nbytes & 3) ||
+      (reinterpret_cast<uintptr_t>(dst_dev) & 3))
+    return -22;
+  ScalarBlock blk;
+  __builtin_memcpy(blk.w, src_host, (size_t)nbytes);
+  hipLaunchKernelGGL(store_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, (uint32_t*)dst_dev, blk,
+                     nbytes >> 2);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
 int gymrl_adam_step(float* p, float* g, float* m, float* v, int64_t n, double lr_host,
                     const float* lr_dev, double beta1, double beta2, double eps, int64_t step,
-                    float grad_scale, float max_grad_norm, const double* sqnorm, float clamp_abs,
-                    int zero_grad, void* stream_) {
-  if (!p || !g || !m || !v || n < 0 || step < 1) return -22;
+                    const float* bias_dev, float grad_scale, float max_grad_norm, const double* sqnorm,
+                    float clamp_abs, int zero_grad, void* stream_) {
+  if (!p || !g || !m || !v || n < 0 || (step < 1 && !bias_dev)) return -22;
+  if (bias_dev) step = 1;   // unused: the kernel takes step_size / bc2_sqrt from bias_dev
   if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return -22;
   if (max_grad_norm > 0.0f && !sqnorm) return -22;
   if (n == 0) return 0;
@@ -184,7 +220,7 @@ int gymrl_adam_step(float* p, float* g, float* m, float* v, int64_t n, double lr
   a.grad_scale = grad_scale; a.max_grad_norm = max_grad_norm; a.clamp_abs = clamp_abs;
   a.zero_grad = zero_grad;
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4)), dim3(kBlock), 0, (hipStream_t)stream_, p, g,
-                     m, v, n, a, lr_dev, sqnorm);
+                     m, v, n, a, lr_dev, bias_dev, sqnorm);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

@@ -81,13 +81,18 @@ class ReplayBuffer:
         self.cursor = (self.cursor + n) % self.capacity
         self.size = min(self.size + n, self.capacity)
 
+    def draw_indices(self, batch_size, out=None):
+        """random.sample's role: one uniform index draw per call (counter-keyed Philox); `out` = fixed buffer."""
+        idx = ops.uniform_indices(self.seed, self.draws, self.size, min(batch_size, self.size), self.device, out=out)
+        self.draws += 1
+        return idx
+
+    def gather(self, indices):
+        return ops.replay_gather(self.ring, indices, self.action_dtype)
+
     def sample(self, batch_size, indices=None):
         """-> (states, actions, rewards, next_states, dones f32).  `indices` replays an explicit draw."""
-        batch_size = min(batch_size, self.size)
-        if indices is None:
-            indices = ops.uniform_indices(self.seed, self.draws, self.size, batch_size, self.device)
-            self.draws += 1
-        return ops.replay_gather(self.ring, indices, self.action_dtype)
+        return self.gather(self.draw_indices(batch_size) if indices is None else indices)
 
     def __len__(self):
         return self.size

@@ -58,14 +58,23 @@ class FusedAdam:
     def zero_grad(self):
         """No-op: gymrl_adam_step zeroes the gradient buffer it just consumed."""
 
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, bias_dev=None):
+        """bias_dev (f32[4] device view, hipGraph replay): the step-dependent scalars come from the device and
+        the caller advances the step with next_bias()."""
         g = self.param_groups[0]
-        self.step_count += 1
+        if bias_dev is None:
+            self.step_count += 1
         if self.max_grad_norm > 0:
             ops.sqnorm(self.g, self._sq, self._ws, grad_scale)
         ops.adam_step(self.p, self.g, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                      self.step_count, grad_scale=grad_scale, max_grad_norm=self.max_grad_norm,
-                      sqnorm_buf=self._sq, clamp_abs=self.clamp_abs, zero_grad=True)
+                      max(self.step_count, 1), grad_scale=grad_scale, max_grad_norm=self.max_grad_norm,
+                      sqnorm_buf=self._sq, clamp_abs=self.clamp_abs, zero_grad=True, bias_dev=bias_dev)
+
+    def next_bias(self):
+        """Advance the step count and return the 16-byte payload of gymrl_adam_bias for it."""
+        g = self.param_groups[0]
+        self.step_count += 1
+        return ops.adam_bias(g["lr"], g["betas"][0], g["betas"][1], self.step_count)
 
     def state_dict(self):
         return dict(m=self.m, v=self.v, step=self.step_count, param_groups=self.param_groups)

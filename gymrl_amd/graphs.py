@@ -1,0 +1,72 @@
+"""hipGraph capture of the launch-bound update loops (DQN / Rainbow / SAC at BASELINE configs 3-4).
+
+One off-policy update at batch 128-256 is ~150 launches of a few microseconds each: the GPU idles between
+them while Python and the HIP runtime issue the next one.  Captured once as a hipGraph (through
+torch.cuda.CUDAGraph, which drives hipStreamBeginCapture on the stream every gymrl_* entry point is handed)
+the whole update is ONE graph launch.  What makes a captured update replayable:
+
+  * every tensor it touches has a fixed address: minibatch indices land in a preallocated buffer, the batch
+    is gathered from the ring inside the graph, intermediates live in the graph's private pool;
+  * the few host scalars that change per step — Adam's bias corrections, the temperature optimiser's — are
+    read from a 256-byte device block (`StepScalars`) that the host refreshes with ONE eager launch
+    (gymrl_store_scalars: the payload travels as the kernel argument) before each replay;
+  * kernels keyed by a host counter (index sampling, ring append, exploration noise) stay eager, in front of
+    the replay.
+
+The arithmetic is the eager path's, kernel for kernel, so a graphed run reproduces an eager run bit for bit
+(tests/test_graphs_gpu.py).
+"""
+import struct
+
+import torch
+
+from . import ops
+
+
+class StepScalars:
+    """Up to 256 bytes of per-step host scalars mirrored into device memory with one launch."""
+
+    SIZE = 256
+
+    def __init__(self, device):
+        self.dev = torch.zeros(self.SIZE // 4, dtype=torch.float32, device=device)
+        self.host = bytearray(self.SIZE)
+        self.used = 0
+
+    def slot(self, nbytes, dtype):
+        """Reserve `nbytes` (8-byte aligned) -> (device view of that dtype, byte offset)."""
+        off = (self.used + 7) & ~7
+        if off + nbytes > self.SIZE:
+            raise ValueError("StepScalars block full")
+        self.used = off + nbytes
+        view = self.dev.view(torch.uint8)[off:off + nbytes].view(dtype)
+        return view, off
+
+    def set(self, off, payload):
+        self.host[off:off + len(payload)] = payload
+
+    def set_doubles(self, off, *vals):
+        self.set(off, struct.pack(f"{len(vals)}d", *vals))
+
+    def flush(self):
+        n = (self.used + 3) & ~3
+        if n:
+            ops.store_scalars(self.dev, bytes(self.host[:n]))
+
+
+class GraphedStep:
+    """fn() run eagerly `warmup` times, then captured once and replayed.  fn must read its per-step inputs
+    from fixed device buffers and must not synchronise with the host."""
+
+    def __init__(self, fn, warmup=2):
+        self.fn, self.warmup, self.calls, self.graph = fn, warmup, 0, None
+
+    def __call__(self):
+        if self.graph is None:
+            if self.calls < self.warmup:
+                self.calls += 1
+                return self.fn()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.fn()
+        self.graph.replay()

@@ -267,14 +267,30 @@ def sqnorm(g, out, workspace, grad_scale=1.0):
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, max_grad_norm=0.0, sqnorm_buf=None,
-              clamp_abs=0.0, zero_grad=True, lr_dev=None):
+              clamp_abs=0.0, zero_grad=True, lr_dev=None, bias_dev=None):
     """O1: Adam on one flat buffer (ppo_lunarlander.py:302-307); call sqnorm() first when clipping."""
     check(lib().gymrl_adam_step(_ptr(p, torch.float32), _ptr(g, torch.float32), _ptr(m, torch.float32),
                                 _ptr(v, torch.float32), C.c_int64(p.numel()), C.c_double(lr),
                                 _ptr(lr_dev, torch.float32, True), C.c_double(beta1), C.c_double(beta2),
-                                C.c_double(eps), C.c_int64(step), C.c_float(grad_scale),
+                                C.c_double(eps), C.c_int64(step), _ptr(bias_dev, torch.float32, True),
+                                C.c_float(grad_scale),
                                 C.c_float(max_grad_norm), _ptr(sqnorm_buf, torch.float64, True),
                                 C.c_float(clamp_abs), C.c_int(int(zero_grad)), _stream()), "gymrl_adam_step")
+
+
+def adam_bias(lr, beta1, beta2, step):
+    """Host arithmetic of Adam's step-dependent scalars -> 4 float32 (gymrl_adam_bias)."""
+    out = (C.c_float * 4)()
+    check(lib().gymrl_adam_bias(C.c_double(lr), C.c_double(beta1), C.c_double(beta2), C.c_int64(step), out), "gymrl_adam_bias")
+    return bytes(out)
+
+
+def store_scalars(dst, payload):
+    """payload: bytes (<= 256, multiple of 4) -> device tensor `dst`, one launch."""
+    if len(payload) > dst.numel() * dst.element_size():
+        raise ValueError("payload larger than the destination block")
+    buf = C.create_string_buffer(payload, len(payload))
+    check(lib().gymrl_store_scalars(_ptr(dst), buf, C.c_int(len(payload)), _stream()), "gymrl_store_scalars")
 
 
 def soft_update(target, source, tau):
@@ -351,8 +367,8 @@ def replay_gather(ring, idx, action_dtype=torch.int32):
     return out
 
 
-def uniform_indices(seed, counter, size, B, device):
-    idx = torch.empty(B, dtype=torch.int32, device=device)
+def uniform_indices(seed, counter, size, B, device, out=None):
+    idx = torch.empty(B, dtype=torch.int32, device=device) if out is None else out
     check(lib().gymrl_uniform_indices(C.c_uint64(seed), C.c_uint64(counter), C.c_int64(size), C.c_int(B),
                                       _ptr(idx), _stream()), "gymrl_uniform_indices")
     return idx
@@ -498,11 +514,13 @@ def dsac_actor_loss(probs, q1, q2, log_alpha, sums):
     return dp
 
 
-def dsac_alpha_step(log_alpha, m, v, sums, B, target_entropy, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, loss_out=None):
+def dsac_alpha_step(log_alpha, m, v, sums, B, target_entropy, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, loss_out=None,
+                    bias_dev=None):
     check(lib().gymrl_dsac_alpha_step(_ptr(log_alpha, torch.float32), _ptr(m, torch.float32), _ptr(v, torch.float32),
                                       _ptr(sums, torch.float64), C.c_int(B), C.c_double(target_entropy), C.c_double(lr),
                                       C.c_double(beta1), C.c_double(beta2), C.c_double(eps), C.c_int64(step),
-                                      _ptr(loss_out, torch.float64, True), _stream()), "gymrl_dsac_alpha_step")
+                                      _ptr(bias_dev, torch.float64, True), _ptr(loss_out, torch.float64, True), _stream()),
+          "gymrl_dsac_alpha_step")
 
 
 def sac_sample_fwd(mean, log_std, eps, bound):
@@ -548,11 +566,12 @@ def sac_actor_loss(logp, q1, q2, log_alpha, target_entropy, sums):
     return dl, d1, d2
 
 
-def sac_alpha_step(log_alpha, m, v, sums, B, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, loss_out=None):
+def sac_alpha_step(log_alpha, m, v, sums, B, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, loss_out=None, bias_dev=None):
     check(lib().gymrl_sac_alpha_step(_ptr(log_alpha, torch.float64), _ptr(m, torch.float64), _ptr(v, torch.float64),
                                      _ptr(sums, torch.float64), C.c_int(B), C.c_double(lr), C.c_double(beta1),
                                      C.c_double(beta2), C.c_double(eps), C.c_int64(step),
-                                     _ptr(loss_out, torch.float64, True), _stream()), "gymrl_sac_alpha_step")
+                                     _ptr(bias_dev, torch.float64, True), _ptr(loss_out, torch.float64, True), _stream()),
+          "gymrl_sac_alpha_step")
 
 
 def running_norm(x, stats, update=True, out=None):

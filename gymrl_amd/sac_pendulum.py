@@ -43,6 +43,7 @@ class Config:
         # --- vectorised-engine additions ---
         self.num_envs = 1
         self.updates_per_step = 1
+        self.use_graphs = True             # replay the update as one captured hipGraph (train(); update() stays eager)
 
 
 class _SacSample(torch.autograd.Function):
@@ -156,6 +157,7 @@ class SACTrainer:
         self.memory = ReplayBuffer(config.memory_capacity, state_dim, action_dim, self.device, seed=self.base_seed)
         self.episode_rewards = deque(maxlen=100)
         self._parity_eps = None        # tests: iterator of f32[N, A] N(0,1) draws for select_action
+        self._graph = None             # hipGraph of the update, captured on first use (update_async)
         self._parity_updates = None    # tests: iterator of (indices i32[B], eps_next [B, A], eps_cur [B, A]) for update()
 
     @property
@@ -179,7 +181,17 @@ class SACTrainer:
             return 0.0, 0.0, 0.0
         if indices is None and self._parity_updates is not None:
             indices, eps_next, eps_cur = next(self._parity_updates)
-        states, actions, rewards, next_states, dones = self.memory.sample(cfg.batch_size, indices)
+        if indices is None:
+            indices = self.memory.draw_indices(cfg.batch_size)
+        B = self._update_body(indices, eps_next, eps_cur)
+        s = self._sums.tolist()
+        return s[1] / B, s[0] / B, float(self._alpha_loss.item())
+
+    def _update_body(self, indices, eps_next=None, eps_cur=None, bias=None):
+        """Everything after the index draw.  bias = (critic f32[4], actor f32[4], alpha f64[2]) device views when
+        the body runs inside / ahead of a hipGraph; None on the eager path."""
+        cfg = self.cfg
+        states, actions, rewards, next_states, dones = self.memory.gather(indices)
         B = states.shape[0]
         self._sums.zero_()
         with torch.no_grad():                                                  # :233-237
@@ -191,21 +203,43 @@ class SACTrainer:
         dq1, dq2 = ops.sac_critic_loss(q1.view(-1), q2.view(-1), y, self._sums)
         self.critic_grads.zero_()                                              # critic_optimizer.zero_grad()
         torch.autograd.backward([q1, q2], [dq1.view_as(q1), dq2.view_as(q2)])
-        self.critic_optimizer.step()
+        self.critic_optimizer.step(bias_dev=None if bias is None else bias[0])
 
         new_actions, logp = self.actor.sample(states, eps_cur)                 # :248-255
         q1, q2 = self.critic(states, new_actions)
         dlogp, dq1, dq2 = ops.sac_actor_loss(logp.view(-1).contiguous(), q1.view(-1), q2.view(-1), self.log_alpha,
                                              self.target_entropy, self._sums)
         torch.autograd.backward([q1, q2, logp], [dq1.view_as(q1), dq2.view_as(q2), dlogp.view_as(logp)])
-        self.actor_optimizer.step()
+        self.actor_optimizer.step(bias_dev=None if bias is None else bias[1])
 
-        self._alpha_steps += 1                                                 # :257-263
+        if bias is None:                                                       # :257-263
+            self._alpha_steps += 1
         ops.sac_alpha_step(self.log_alpha, self._alpha_m, self._alpha_v, self._sums, B, cfg.lr_alpha,
-                           self._alpha_steps, loss_out=self._alpha_loss)
+                           max(self._alpha_steps, 1), loss_out=self._alpha_loss, bias_dev=None if bias is None else bias[2])
         self.soft_update()                                                     # :265
-        s = self._sums.tolist()
-        return s[1] / B, s[0] / B, float(self._alpha_loss.item())
+        return B
+
+    def update_async(self):
+        """The same update without a host round trip: one eager index draw + one scalar store, then the captured
+        hipGraph of `_update_body` (gymrl_amd/graphs.py).  Losses stay on the device (`_sums`, `_alpha_loss`)."""
+        cfg, m = self.cfg, self.memory
+        if len(m) < cfg.batch_size:
+            return
+        if self._graph is None:
+            from .graphs import GraphedStep, StepScalars
+            sc = self._scalars = StepScalars(self.device)
+            (bc, self._off_c), (ba, self._off_a), (bl, self._off_l) = (sc.slot(16, torch.float32), sc.slot(16, torch.float32),
+                                                                     sc.slot(16, torch.float64))
+            self._g_idx = torch.empty(cfg.batch_size, dtype=torch.int32, device=self.device)
+            self._graph = GraphedStep(lambda: self._update_body(self._g_idx, bias=(bc, ba, bl)))
+        m.draw_indices(cfg.batch_size, out=self._g_idx)
+        sc = self._scalars
+        sc.set(self._off_c, self.critic_optimizer.next_bias())
+        sc.set(self._off_a, self.actor_optimizer.next_bias())
+        self._alpha_steps += 1
+        sc.set_doubles(self._off_l, 1.0 - 0.9 ** self._alpha_steps, 1.0 - 0.999 ** self._alpha_steps)
+        sc.flush()
+        self._graph()
 
     def train(self, max_vector_steps=None):
         """:269-310 with N lock-stepped envs."""
@@ -216,6 +250,7 @@ class SACTrainer:
         tracker = EpisodeTracker(N, self.device, flush_every=1 if N == 1 else 16)
         env.reset(obs)
         step = 0
+        graphed = bool(getattr(cfg, "use_graphs", True)) and self._parity_updates is None
         limit = max_vector_steps or (cfg.max_episodes * cfg.max_steps // N + 1)
         while tracker.episodes < cfg.max_episodes and step < limit:
             action = self.select_action(obs, eps=None if self._parity_eps is None else next(self._parity_eps))
@@ -223,7 +258,10 @@ class SACTrainer:
             env.step(action, nxt, rew, done_out=done, term_obs_out=tobs, ep_ret_out=ep_ret)
             self.memory.push(obs, action, rew, tobs, done)                     # done = terminated or truncated (:283)
             for _ in range(cfg.updates_per_step):
-                self.update()
+                if graphed:
+                    self.update_async()
+                else:
+                    self.update()
             obs, nxt = nxt, obs
             step += 1
             tracker.advance(self.episode_rewards)

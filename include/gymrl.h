@@ -297,13 +297,22 @@ int gymrl_gather_minibatch(const float* packed, const int32_t* idx, int B, int o
  *   lr_dev f32[1] or NULL (then lr_host is used): device-resident lr lets LR
  *   annealing change the rate without re-capturing a graph.
  *   grad_scale multiplies g first (1/world_size after an all-reduce SUM).
+ *   bias_dev f32[4] or NULL: device-resident {lr/(1-b1^t), 1/(1-b1^t), sqrt(1-b2^t), 0} — the only
+ *   step-dependent scalars of the update.  With it (and `step` ignored) a hipGraph captured around the
+ *   optimiser step replays unchanged; the host refreshes the block before each replay with
+ *   gymrl_adam_bias (host arithmetic, identical to the eager path's) + gymrl_store_scalars.
+ *   gymrl_store_scalars: copies nbytes <= 256 (multiple of 4) of host scalars into device memory as ONE
+ *   launch whose payload is the kernel argument (stream-ordered, nothing to fence, not capturable state).
  */
 int gymrl_sqnorm(const float* g, int64_t n, float grad_scale, double* sqnorm_out,
                  void* workspace, void* stream);
 int gymrl_adam_step(float* p, float* g, float* m, float* v, int64_t n,
                     double lr_host, const float* lr_dev, double beta1, double beta2,
-                    double eps, int64_t step, float grad_scale, float max_grad_norm,
-                    const double* sqnorm, float clamp_abs, int zero_grad, void* stream);
+                    double eps, int64_t step, const float* bias_dev, float grad_scale,
+                    float max_grad_norm, const double* sqnorm, float clamp_abs, int zero_grad,
+                    void* stream);
+int gymrl_adam_bias(double lr, double beta1, double beta2, int64_t step, float* out_host4);
+int gymrl_store_scalars(void* dst_dev, const void* src_host, int nbytes, void* stream);
 
 /* R4 / A4: theta' <- tau*theta + (1-tau)*theta' on flat buffers —
  * rainbow_dqn_cartpole.py:347-352, sac_pendulum.py:194-199. */
@@ -564,6 +573,8 @@ int gymrl_sac_sample_bwd(const float* mean, const float* log_std, const float* e
  *            float64 scalar log_alpha (state m, v f64[1])                     (:257-263)
  * log_alpha f64[1] lives on the device; alpha = (float)exp(log_alpha) inside the kernels.
  * sums f64[4] += (critic loss sum, actor loss sum, sum(logp + target_entropy), 0).
+ * alpha steps: bias_dev f64[2] or NULL = device-resident {1 - beta1^step, 1 - beta2^step}; with it `step`
+ * is ignored and a captured hipGraph of the update replays unchanged (see gymrl_adam_step).
  */
 int gymrl_sac_target(const float* rew, const float* done, const float* q1n, const float* q2n,
                      const float* logp_n, const double* log_alpha, int B, double gamma,
@@ -577,7 +588,7 @@ int gymrl_sac_actor_loss(const float* logp, const float* q1, const float* q2,
                          void* workspace, void* stream);
 int gymrl_sac_alpha_step(double* log_alpha, double* m, double* v, const double* sums, int B,
                          double lr, double beta1, double beta2, double eps, int64_t step,
-                         double* alpha_loss_out, void* stream);
+                         const double* bias_dev, double* alpha_loss_out, void* stream);
 
 /*
  * TD3 / DDPG — ddpg_pendulum.py:135-195, td3_pendulum.py:156-228.  Their Bellman target is
@@ -616,7 +627,7 @@ int gymrl_dsac_actor_loss(const float* probs, const float* q1, const float* q2, 
                           int A, float* dprobs_out, double* sums, void* workspace, void* stream);
 int gymrl_dsac_alpha_step(float* log_alpha, float* m, float* v, const double* sums, int B,
                           double target_entropy, double lr, double beta1, double beta2, double eps,
-                          int64_t step, double* alpha_loss_out, void* stream);
+                          int64_t step, const double* bias_dev, double* alpha_loss_out, void* stream);
 
 /*
  * N1-N3: utils/normalization.py — RunningMeanStd.update :12-22 (Welford, population
