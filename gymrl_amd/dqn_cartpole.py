@@ -38,6 +38,7 @@ class Config:
         # --- vectorised-engine additions (defaults keep the reference's per-step cadence) ---
         self.num_envs = 1
         self.updates_per_step = 1            # reference: one update() per env step (:184)
+        self.use_graphs = True               # replay the update as one captured hipGraph (train(); update() stays eager)
 
 
 def layer_init(layer, std=np.sqrt(2)):
@@ -125,6 +126,7 @@ class DQNTrainer:
         self._act_counter = 0
         self._parity_u = None          # tests: iterator of f32[N, 2] uniforms for select_action (explore?, which action)
         self._parity_indices = None    # tests: iterator of i32[B] replay indices for update()
+        self._graph = None             # hipGraph of the update, captured on first use (update_async)
 
     def get_epsilon(self):
         """:117-122 — advanced once per (vector) action selection."""
@@ -150,15 +152,39 @@ class DQNTrainer:
             return 0.0
         if indices is None and self._parity_indices is not None:
             indices = next(self._parity_indices)
-        states, actions, rewards, next_states, dones = self.memory.sample(self.cfg.batch_size, indices)
+        if indices is None:
+            indices = self.memory.draw_indices(self.cfg.batch_size)
+        B = self._update_body(indices)
+        return float(self._loss.item()) / B
+
+    def _update_body(self, indices, bias=None):
+        """Everything after the index draw; bias = f32[4] device view of Adam's step scalars under a hipGraph."""
+        states, actions, rewards, next_states, dones = self.memory.gather(indices)
         q = self.policy_net(states)
         with torch.no_grad():
             qn = self.target_net(next_states)
         self._loss.zero_()
         td, dq = ops.dqn_td_loss(q, qn, actions.view(-1), rewards, dones, self.cfg.gamma, loss_sum=self._loss)
         q.backward(dq)
-        self.optimizer.step()                            # grad clamp +-1 (:163-165) fused into the Adam kernel
-        return float(self._loss.item()) / states.shape[0]
+        self.optimizer.step(bias_dev=bias)               # grad clamp +-1 (:163-165) fused into the Adam kernel
+        return states.shape[0]
+
+    def update_async(self):
+        """update() without the host round trip: eager index draw + scalar store, then the captured hipGraph of
+        `_update_body` (gymrl_amd/graphs.py).  The loss sum stays on the device (`_loss`)."""
+        cfg, m = self.cfg, self.memory
+        if len(m) < cfg.batch_size:
+            return
+        if self._graph is None:
+            from .graphs import GraphedStep, StepScalars
+            self._scalars = StepScalars(self.device)
+            bias, self._off = self._scalars.slot(16, torch.float32)
+            self._g_idx = torch.empty(cfg.batch_size, dtype=torch.int32, device=self.device)
+            self._graph = GraphedStep(lambda: self._update_body(self._g_idx, bias=bias))
+        m.draw_indices(cfg.batch_size, out=self._g_idx)
+        self._scalars.set(self._off, self.optimizer.next_bias())
+        self._scalars.flush()
+        self._graph()
 
     def train(self, max_vector_steps=None):
         """:170-212 with N lock-stepped envs; "episodes" counts finished episodes over all envs."""
@@ -169,6 +195,7 @@ class DQNTrainer:
         tracker = EpisodeTracker(N, self.device, flush_every=1 if N == 1 else 16)
         env.reset(obs)
         step, last_target = 0, 0
+        graphed = bool(getattr(cfg, "use_graphs", True)) and self._parity_indices is None
         limit = max_vector_steps or (cfg.max_episodes * cfg.max_steps // N + 1)
         while tracker.episodes < cfg.max_episodes and step < limit:
             action = self.select_action(obs, u=None if self._parity_u is None else next(self._parity_u))
@@ -176,7 +203,10 @@ class DQNTrainer:
             env.step(action, nxt, rew, done_out=done, term_obs_out=tobs, ep_ret_out=ep_ret)
             self.memory.push(obs, action, rew, tobs, done)      # next_state = pre-reset observation (:183)
             for _ in range(cfg.updates_per_step):
-                self.update()
+                if graphed:
+                    self.update_async()
+                else:
+                    self.update()
             obs, nxt = nxt, obs
             step += 1
             tracker.advance(self.episode_rewards)

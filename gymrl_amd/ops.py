@@ -418,11 +418,14 @@ def per_priorities(td, alpha, eps, clip=0.0, out=None):
     return out
 
 
-def per_sample(tree, cap, B, size, beta, workspace, u=None, seed=0, counter=0, variant_b=False):
+def per_sample(tree, cap, B, size, beta, workspace, u=None, seed=0, counter=0, variant_b=False, out=None):
     dev = tree.device
-    idx = torch.empty(B, dtype=torch.int32, device=dev)
-    prio = torch.empty(B, dtype=torch.float64, device=dev)
-    w = torch.empty(B, dtype=torch.float32, device=dev)
+    if out is None:
+        idx = torch.empty(B, dtype=torch.int32, device=dev)
+        prio = torch.empty(B, dtype=torch.float64, device=dev)
+        w = torch.empty(B, dtype=torch.float32, device=dev)
+    else:
+        idx, prio, w = out
     check(lib().gymrl_per_sample(_ptr(tree, torch.float64), C.c_int64(cap), _ptr(u, torch.float64, True),
                                  C.c_uint64(seed), C.c_uint64(counter), C.c_int(B), C.c_int64(size), C.c_double(beta),
                                  C.c_int(int(variant_b)), _ptr(idx), _ptr(prio), _ptr(w), _ptr(workspace), _stream()),

@@ -43,6 +43,7 @@ class Config:
         # --- vectorised-engine additions ---
         self.num_envs = 1
         self.updates_per_step = 1
+        self.use_graphs = True             # replay the update as one captured hipGraph (train(); update() stays eager)
 
 
 class NoisyLinear(nn.Module):
@@ -61,6 +62,8 @@ class NoisyLinear(nn.Module):
         self.bias_sigma = nn.Parameter(torch.empty(out_features))
         self.register_buffer("bias_epsilon", torch.zeros(out_features))
         self.raw_noise = None            # parity mode: iterator of (eps_in_raw, eps_out_raw) device tensors
+        self.staged = None               # hipGraph mode: [(w_eps, b_eps), ...] drawn ahead of the replay, consumed in order
+        self._staged_k = 0
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -70,10 +73,25 @@ class NoisyLinear(nn.Module):
         self.weight_sigma.data.fill_(self.sigma_init / math.sqrt(self.in_features))
         self.bias_sigma.data.fill_(self.sigma_init / math.sqrt(self.out_features))
 
+    def draw_staged_at(self, counters):
+        """hipGraph mode: draw the noise of the next len(counters) training-mode forwards with the given Philox
+        counters (these counter-keyed launches stay outside the graph); reset_noise() then copies them in, in
+        order, inside the graph."""
+        if self.staged is None:
+            self.staged = [(torch.zeros_like(self.weight_epsilon), torch.zeros_like(self.bias_epsilon)) for _ in counters]
+        for (w_eps, b_eps), c in zip(self.staged, counters):
+            ops.noisy_noise(self.in_features, self.out_features, w_eps, b_eps, seed=self.seed, counter=c)
+        self._staged_k = 0
+
     def reset_noise(self):
         if not self.weight_epsilon.is_cuda:
             return                        # CPU construction time: the buffers are filled on first GPU forward
-        if self.raw_noise is not None:
+        if self.staged is not None and self._staged_k < len(self.staged):
+            w_eps, b_eps = self.staged[self._staged_k]
+            self._staged_k += 1
+            self.weight_epsilon.copy_(w_eps)
+            self.bias_epsilon.copy_(b_eps)
+        elif self.raw_noise is not None:
             ei, eo = next(self.raw_noise)
             ops.noisy_noise(self.in_features, self.out_features, self.weight_epsilon, self.bias_epsilon, ei, eo)
         else:
@@ -170,14 +188,22 @@ class PrioritizedNStepBuffer:
             self.count = (self.count + self.N) % self.capacity
             self.current_size = min(self.current_size + self.N, self.capacity)
 
-    def sample(self, total_steps, max_train_steps, u=None):
-        """:220-256 -> (batch dict, batch_index i32[B], is_weight f32[B])."""
+    def draw(self, total_steps, max_train_steps, u=None, out=None):
+        """The proportional draw of :220-243 -> (batch_index i32[B], is_weight f32[B]); `out` = fixed (idx, prio, w)."""
         self.beta = self.beta_init + (1 - self.beta_init) * (total_steps / max_train_steps)
         self.draws += 1
         idx, _, w = ops.per_sample(self.sum_tree.tree, self.capacity, self.batch_size, self.current_size, self.beta,
-                                   self.sum_tree._ws, u=u, seed=self.seed, counter=self.draws)
+                                   self.sum_tree._ws, u=u, seed=self.seed, counter=self.draws, out=out)
+        return idx, w
+
+    def gather(self, idx):
         s, a, r, s2, f = ops.replay_gather(self.ring, idx)
-        return {"state": s, "action": a.long(), "reward": r, "next_state": s2, "terminal": f}, idx, w
+        return {"state": s, "action": a.long(), "reward": r, "next_state": s2, "terminal": f}
+
+    def sample(self, total_steps, max_train_steps, u=None):
+        """:220-256 -> (batch dict, batch_index i32[B], is_weight f32[B])."""
+        idx, w = self.draw(total_steps, max_train_steps, u=u)
+        return self.gather(idx), idx, w
 
     def update_priorities(self, batch_index, td_errors):
         """:258-261: p = (|td| + 0.01)^alpha, applied in batch order."""
@@ -214,6 +240,7 @@ class RainbowDQNTrainer:
         self.episode_rewards = deque(maxlen=100)
         self._loss = torch.zeros(1, dtype=torch.float64, device=self.device)
         self._parity_u = None          # tests: iterator of f64[B] PER uniforms for update()
+        self._graph = None             # hipGraph of the update, captured on first use (update_async)
 
     @torch.no_grad()
     def select_action(self, state, deterministic=False):
@@ -234,7 +261,15 @@ class RainbowDQNTrainer:
             return 0.0
         if u is None and self._parity_u is not None:
             u = next(self._parity_u)
-        batch, batch_index, is_weight = self.memory.sample(self.total_steps, self.max_train_steps, u=u)
+        batch_index, is_weight = self.memory.draw(self.total_steps, self.max_train_steps, u=u)
+        self._update_body(batch_index, is_weight)
+        self._anneal_lr()
+        return float(self._loss.item()) / cfg.batch_size
+
+    def _update_body(self, batch_index, is_weight, bias=None):
+        """Everything after the proportional draw; bias = f32[4] device view of Adam's step scalars under a hipGraph."""
+        cfg = self.cfg
+        batch = self.memory.gather(batch_index)
         with torch.no_grad():
             q_next_online = self.policy_net(batch["next_state"])          # fresh noise (:320)
             q_next_target = self.target_net(batch["next_state"])          # eval mode: mu weights only
@@ -245,12 +280,41 @@ class RainbowDQNTrainer:
                                  w=is_weight, loss_sum=self._loss)
         self.memory.update_priorities(batch_index, td)                    # before backward (:340)
         q.backward(dq)
-        self.optimizer.step()                                             # clip_grad_norm_(10) + Adam
+        self.optimizer.step(bias_dev=bias)                                # clip_grad_norm_(10) + Adam
         ops.soft_update(self.target_flat, self.flat_params, cfg.tau)      # :347-352 (parameters only)
-        lr_now = 0.9 * cfg.lr * (1 - self.total_steps / self.max_train_steps) + 0.1 * cfg.lr
+
+    def _anneal_lr(self):
+        cfg = self.cfg
+        lr_now = 0.9 * cfg.lr * (1 - self.total_steps / self.max_train_steps) + 0.1 * cfg.lr     # :354-356
         for param_group in self.optimizer.param_groups:
             param_group["lr"] = lr_now
-        return float(self._loss.item()) / cfg.batch_size
+
+    def update_async(self):
+        """update() without the host round trip: the counter-keyed launches (proportional draw, NoisyNet noise of the
+        two training-mode forwards) and one scalar store run eagerly, then the captured hipGraph of `_update_body`."""
+        cfg, m = self.cfg, self.memory
+        if len(m) < cfg.batch_size:
+            return
+        if self._graph is None:
+            from .graphs import GraphedStep, StepScalars
+            self._scalars = StepScalars(self.device)
+            bias, self._off = self._scalars.slot(16, torch.float32)
+            B, d = cfg.batch_size, self.device
+            self._g_draw = (torch.empty(B, dtype=torch.int32, device=d), torch.empty(B, dtype=torch.float64, device=d),
+                            torch.empty(B, dtype=torch.float32, device=d))
+            self._graph = GraphedStep(lambda: self._update_body(self._g_draw[0], self._g_draw[2], bias=bias))
+        m.draw(self.total_steps, self.max_train_steps, out=self._g_draw)
+        layers = (self.policy_net.advantage, self.policy_net.value)
+        c0 = NoisyLinear._counter                            # the eager path's order: (advantage, value) per forward
+        NoisyLinear._counter += 4
+        for j, layer in enumerate(layers):
+            layer.draw_staged_at([c0 + 1 + j, c0 + 3 + j])
+        self._scalars.set(self._off, self.optimizer.next_bias())
+        self._scalars.flush()
+        self._graph()
+        for layer in layers:
+            layer._staged_k = len(layer.staged)              # consumed by the replay; later forwards draw their own
+        self._anneal_lr()
 
     def train(self, max_vector_steps=None):
         """:363-405 with N lock-stepped envs."""
@@ -264,6 +328,8 @@ class RainbowDQNTrainer:
         tracker = EpisodeTracker(N, self.device, flush_every=1 if N == 1 else 16)
         env.reset(obs)
         step = 0
+        graphed = (bool(getattr(cfg, "use_graphs", True)) and self._parity_u is None
+                   and self.policy_net.advantage.raw_noise is None)
         limit = max_vector_steps or (cfg.max_episodes * cfg.max_steps // N + 1)
         while tracker.episodes < cfg.max_episodes and step < limit:
             action = self.select_action(obs)
@@ -276,7 +342,10 @@ class RainbowDQNTrainer:
             term.copy_(term_b)
             self.memory.store_transition(obs, action, rew, tobs, term, done)
             for _ in range(cfg.updates_per_step):
-                self.update()
+                if graphed:
+                    self.update_async()
+                else:
+                    self.update()
             obs, nxt = nxt, obs
             step += 1
             tracker.advance(self.episode_rewards)
