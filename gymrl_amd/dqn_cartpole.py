@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import ops
 from .envs import EpisodeTracker, VecEnv
-from .flat import FusedAdam, flatten_module
+from .flat import FusedAdam, GradSink, flatten_module
 
 
 class Config:
@@ -38,6 +38,8 @@ class Config:
         # --- vectorised-engine additions (defaults keep the reference's per-step cadence) ---
         self.num_envs = 1
         self.updates_per_step = 1            # reference: one update() per env step (:184)
+        self.gemm_backend = "auto"            # library for the update's small-M GEMMs: auto | rocblas | hipblaslt | default (gymrl_amd/blas.py)
+        self.tune_gemms = False              # opt-in TunableOp search per GEMM shape at start-up
         self.use_graphs = True               # replay the update as one captured hipGraph (train(); update() stays eager)
 
 
@@ -117,6 +119,7 @@ class DQNTrainer:
         self.flat_params, self.flat_grads = flatten_module(self.policy_net, self.device)
         self.target_flat, _ = flatten_module(self.target_net, self.device)
         self.target_net.eval()
+        self._sink = GradSink(self.policy_net)
         self.optimizer = FusedAdam(self.flat_params, self.flat_grads, lr=config.lr, eps=1e-8, clamp_abs=1.0)
         self.memory = ReplayBuffer(config.memory_capacity, state_dim, self.device, seed=self.base_seed)
         self.epsilon = config.epsilon_start
@@ -165,7 +168,9 @@ class DQNTrainer:
             qn = self.target_net(next_states)
         self._loss.zero_()
         td, dq = ops.dqn_td_loss(q, qn, actions.view(-1), rewards, dones, self.cfg.gamma, loss_sum=self._loss)
+        self._sink.arm()
         q.backward(dq)
+        self._sink.collect()
         self.optimizer.step(bias_dev=bias)               # grad clamp +-1 (:163-165) fused into the Adam kernel
         return states.shape[0]
 
@@ -187,6 +192,16 @@ class DQNTrainer:
         self._graph()
 
     def train(self, max_vector_steps=None):
+        """The reference's train() loop; the small-M GEMMs of the update run on the library that answers them
+        fastest (gymrl_amd/blas.py)."""
+        from .blas import small_gemm_backend
+        backend = getattr(self.cfg, "gemm_backend", "auto")
+        if backend == "auto":                    # measured: rocBLAS wins up to 4096-row minibatches, hipBLASLt above
+            backend = "rocblas" if self.cfg.batch_size <= 4096 else "default"
+        with small_gemm_backend(backend, getattr(self.cfg, "tune_gemms", False)):
+            return self._train(max_vector_steps)
+
+    def _train(self, max_vector_steps=None):
         """:170-212 with N lock-stepped envs; "episodes" counts finished episodes over all envs."""
         cfg, env = self.cfg, self.env
         N, D = env.n, env.obs_dim

@@ -39,6 +39,34 @@ def flatten_module(module, device, order=None):
     return flat, grad
 
 
+class GradSink:
+    """Lets autograd hand back FRESH gradient tensors and lands them in the flat buffer with one multi-tensor
+    copy.  With `p.grad` pre-set to a view of the flat buffer, autograd accumulates (`grad += new`, one launch
+    per parameter per backward: 34 launches in one SAC update); with `p.grad = None` it just stores the new
+    tensor.  arm() before backward, collect() after it (or drop() when the gradients are not wanted)."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.views = [p.grad for p in self.params]
+
+    def arm(self):
+        for p in self.params:
+            p.grad = None
+
+    def collect(self):
+        got = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
+        for v, p in zip(self.views, self.params):
+            if p.grad is None:
+                v.zero_()
+        if got:
+            torch._foreach_copy_([v for v, _ in got], [g for _, g in got])
+        self.drop()
+
+    def drop(self):
+        for v, p in zip(self.views, self.params):
+            p.grad = v
+
+
 class FusedAdam:
     """torch.optim.Adam(lr, betas, eps) + clip_grad_norm_ + zero_grad over one flat
     buffer, through gymrl_sqnorm / gymrl_adam_step.  Keeps the `param_groups[i]["lr"]`

@@ -20,7 +20,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .envs import EpisodeTracker, VecEnv
-from .flat import FusedAdam, flatten_module
+from .flat import FusedAdam, GradSink, flatten_module
 
 
 class Config:
@@ -43,6 +43,8 @@ class Config:
         # --- vectorised-engine additions ---
         self.num_envs = 1
         self.updates_per_step = 1
+        self.gemm_backend = "auto"            # library for the update's small-M GEMMs: auto | rocblas | hipblaslt | default (gymrl_amd/blas.py)
+        self.tune_gemms = False              # opt-in TunableOp search per GEMM shape at start-up
         self.use_graphs = True             # replay the update as one captured hipGraph (train(); update() stays eager)
 
 
@@ -233,6 +235,7 @@ class RainbowDQNTrainer:
         self.flat_params, self.flat_grads = flatten_module(self.policy_net, self.device)
         self.target_flat, _ = flatten_module(self.target_net, self.device)
         self.target_net.eval()
+        self._sink = GradSink(self.policy_net)
         self.optimizer = FusedAdam(self.flat_params, self.flat_grads, lr=config.lr, eps=1e-8,
                                    max_grad_norm=config.grad_clip)
         self.memory = PrioritizedNStepBuffer(config, self.state_dim, config.num_envs, self.device, seed=self.base_seed)
@@ -279,7 +282,9 @@ class RainbowDQNTrainer:
                                  batch["terminal"], cfg.gamma ** cfg.n_steps, q_next_online=q_next_online,
                                  w=is_weight, loss_sum=self._loss)
         self.memory.update_priorities(batch_index, td)                    # before backward (:340)
+        self._sink.arm()
         q.backward(dq)
+        self._sink.collect()
         self.optimizer.step(bias_dev=bias)                                # clip_grad_norm_(10) + Adam
         ops.soft_update(self.target_flat, self.flat_params, cfg.tau)      # :347-352 (parameters only)
 
@@ -317,6 +322,16 @@ class RainbowDQNTrainer:
         self._anneal_lr()
 
     def train(self, max_vector_steps=None):
+        """The reference's train() loop; the small-M GEMMs of the update run on the library that answers them
+        fastest (gymrl_amd/blas.py)."""
+        from .blas import small_gemm_backend
+        backend = getattr(self.cfg, "gemm_backend", "auto")
+        if backend == "auto":                    # measured: rocBLAS wins up to 4096-row minibatches, hipBLASLt above
+            backend = "rocblas" if self.cfg.batch_size <= 4096 else "default"
+        with small_gemm_backend(backend, getattr(self.cfg, "tune_gemms", False)):
+            return self._train(max_vector_steps)
+
+    def _train(self, max_vector_steps=None):
         """:363-405 with N lock-stepped envs."""
         cfg, env = self.cfg, self.env
         N, D = env.n, env.obs_dim

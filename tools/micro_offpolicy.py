@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Throughput of the off-policy trainers at BASELINE configs 3 and 4 (Rainbow 8192 CartPole envs with a 2^20 PER
 ring, SAC 4096 Pendulum envs), one update per vector step as in the reference loops.  Supplementary numbers:
-bench.py's headline is config 2."""
+bench.py's headline is config 2.  A/B in one process: per-launch issue vs hipGraph replay of the update, and the
+library answering the update's small-M GEMMs (gymrl_amd/blas.py)."""
 import json
 import os
 import sys
@@ -26,24 +27,26 @@ def run(tr, steps, warm):
     return dt
 
 
+MODES = (("eager hipblaslt-default", False, "default", False), ("graph hipblaslt-default", True, "default", False),
+         ("graph rocblas", True, "rocblas", False), ("graph auto (default config)", True, "auto", False),
+         ("graph rocblas+tunableop", True, "rocblas", True))
+
+
 def main():
     out = {}
-    c = rainbow_dqn_cartpole.Config()
-    c.num_envs, c.memory_capacity, c.max_episodes = 8192, 1 << 20, 10**9
-    for B in (256, 8192):
-        c.batch_size = B
-        tr = rainbow_dqn_cartpole.RainbowDQNTrainer(c)
-        steps = 300
-        dt = run(tr, steps, 60)
-        out[f"rainbow N=8192 cap=2^20 B={B}"] = dict(env_steps_per_s=round(8192 * steps / dt), ms_per_vector_step=round(dt / steps * 1e3, 3))
-    c = sac_pendulum.Config()
-    c.num_envs, c.memory_capacity, c.max_episodes = 4096, 1 << 20, 10**9
-    for B in (128, 4096):
-        c.batch_size = B
-        tr = sac_pendulum.SACTrainer(c)
-        steps = 300
-        dt = run(tr, steps, 60)
-        out[f"sac N=4096 cap=2^20 B={B}"] = dict(env_steps_per_s=round(4096 * steps / dt), ms_per_vector_step=round(dt / steps * 1e3, 3))
+    torch.cuda.tunable.set_filename("/tmp/gymrl_tunable.csv")
+    for mod, cls, N, B in ((rainbow_dqn_cartpole, "RainbowDQNTrainer", 8192, 256), (rainbow_dqn_cartpole, "RainbowDQNTrainer", 8192, 8192),
+                           (sac_pendulum, "SACTrainer", 4096, 128), (sac_pendulum, "SACTrainer", 4096, 4096)):
+        row = {}
+        for name, graphs, backend, tune in MODES:
+            c = mod.Config()
+            c.num_envs, c.memory_capacity, c.max_episodes, c.batch_size = N, 1 << 20, 10**9, B
+            c.use_graphs, c.gemm_backend, c.tune_gemms = graphs, backend, tune
+            tr = getattr(mod, cls)(c)
+            steps = 300
+            dt = run(tr, steps, 60)
+            row[name] = dict(env_steps_per_s=round(N * steps / dt), ms_per_vector_step=round(dt / steps * 1e3, 3))
+        out[f"{cls} N={N} cap=2^20 B={B}"] = row
     print(json.dumps(out, indent=1))
 
 
