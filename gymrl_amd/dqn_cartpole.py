@@ -100,6 +100,15 @@ class ReplayBuffer:
     def __len__(self):
         return self.size
 
+    def state_dict(self):
+        """Ring contents + cursors, so that a resumed run samples what the interrupted one would have."""
+        return {"ring": [t.detach().cpu() for t in self.ring], "cursor": self.cursor, "size": self.size, "draws": self.draws}
+
+    def load_state_dict(self, sd):
+        for dst, src in zip(self.ring, sd["ring"]):
+            dst.copy_(src.to(dst.device))
+        self.cursor, self.size, self.draws = int(sd["cursor"]), int(sd["size"]), int(sd["draws"])
+
 
 class DQNTrainer:
     def __init__(self, config):
@@ -190,6 +199,28 @@ class DQNTrainer:
         self._scalars.set(self._off, self.optimizer.next_bias())
         self._scalars.flush()
         self._graph()
+
+    def save_checkpoint(self, path, include_memory=True):
+        """ModelLoader-style dict: networks, the optimiser in torch.optim.Adam's layout, the
+        schedule counters and — unlike the reference, which skips `memory` — the replay ring."""
+        from .utils import checkpoint
+        extra = {"memory_state_dict": self.memory.state_dict()} if include_memory else {}
+        return checkpoint.save_agent(path, {"policy_net": self.policy_net, "target_net": self.target_net},
+                                     {"optimizer": (self.policy_net, self.optimizer)}, epsilon=self.epsilon,
+                                     sample_count=self.sample_count, _act_counter=self._act_counter,
+                                     episode_rewards=list(self.episode_rewards), **extra)
+
+    def load_checkpoint(self, path):
+        from .utils import checkpoint
+        rest = checkpoint.load_agent(path, {"policy_net": self.policy_net, "target_net": self.target_net},
+                                     {"optimizer": (self.policy_net, self.optimizer)})
+        self.epsilon, self.sample_count = float(rest["epsilon"]), int(rest["sample_count"])
+        self._act_counter = int(rest["_act_counter"])
+        self.episode_rewards.clear()
+        self.episode_rewards.extend(rest.get("episode_rewards", []))
+        if "memory_state_dict" in rest:
+            self.memory.load_state_dict(rest["memory_state_dict"])
+        return rest
 
     def train(self, max_vector_steps=None):
         """The reference's train() loop; the small-M GEMMs of the update run on the library that answers them

@@ -73,8 +73,9 @@ class FusedAdam:
     interface the reference's LR annealing writes to (ppo_lunarlander.py:337-341)."""
 
     def __init__(self, flat_params, flat_grads, lr, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=0.0,
-                 clamp_abs=0.0):
+                 clamp_abs=0.0, module=None):
         self.p, self.g = flat_params, flat_grads
+        self.module = module       # when given, state_dict() / load_state_dict() speak torch.optim.Adam's layout
         self.m = torch.zeros_like(flat_params)
         self.v = torch.zeros_like(flat_params)
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps)]
@@ -105,4 +106,16 @@ class FusedAdam:
         return ops.adam_bias(g["lr"], g["betas"][0], g["betas"][1], self.step_count)
 
     def state_dict(self):
+        if self.module is not None:
+            from .utils.checkpoint import adam_state_dict
+            return adam_state_dict(self.module, self)
         return dict(m=self.m, v=self.v, step=self.step_count, param_groups=self.param_groups)
+
+    def load_state_dict(self, sd):
+        if "state" in sd and self.module is not None:
+            from .utils.checkpoint import load_adam_state_dict
+            return load_adam_state_dict(self.module, self, sd)
+        self.m.copy_(sd["m"].to(self.m.device))
+        self.v.copy_(sd["v"].to(self.v.device))
+        self.step_count = int(sd["step"])
+        self.param_groups[0].update(sd["param_groups"][0])

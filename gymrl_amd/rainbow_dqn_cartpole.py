@@ -215,6 +215,19 @@ class PrioritizedNStepBuffer:
     def __len__(self):
         return self.current_size
 
+    def state_dict(self):
+        """Ring, open n-step windows, the float64 sum tree and every cursor (PER tree state)."""
+        return {"ring": [t.detach().cpu() for t in self.ring], "win": [t.detach().cpu() for t in self.win],
+                "tree": self.sum_tree.tree.detach().cpu(), "current_size": self.current_size, "count": self.count,
+                "pushes": self.pushes, "draws": self.draws, "beta": self.beta}
+
+    def load_state_dict(self, sd):
+        for dst, src in zip(self.ring + self.win, list(sd["ring"]) + list(sd["win"])):
+            dst.copy_(src.to(dst.device))
+        self.sum_tree.tree.copy_(sd["tree"].to(self.device))
+        self.current_size, self.count, self.pushes = int(sd["current_size"]), int(sd["count"]), int(sd["pushes"])
+        self.draws, self.beta = int(sd["draws"]), float(sd["beta"])
+
 
 class RainbowDQNTrainer:
     def __init__(self, config):
@@ -320,6 +333,27 @@ class RainbowDQNTrainer:
         for layer in layers:
             layer._staged_k = len(layer.staged)              # consumed by the replay; later forwards draw their own
         self._anneal_lr()
+
+    def save_checkpoint(self, path, include_memory=True):
+        """ModelLoader-style dict incl. the NoisyNet draw counter and — unlike the reference, which
+        skips `memory` — the prioritised n-step buffer with its sum tree."""
+        from .utils import checkpoint
+        extra = {"memory_state_dict": self.memory.state_dict()} if include_memory else {}
+        return checkpoint.save_agent(path, {"policy_net": self.policy_net, "target_net": self.target_net},
+                                     {"optimizer": (self.policy_net, self.optimizer)}, total_steps=self.total_steps,
+                                     noisy_counter=NoisyLinear._counter, episode_rewards=list(self.episode_rewards), **extra)
+
+    def load_checkpoint(self, path):
+        from .utils import checkpoint
+        rest = checkpoint.load_agent(path, {"policy_net": self.policy_net, "target_net": self.target_net},
+                                     {"optimizer": (self.policy_net, self.optimizer)})
+        self.total_steps = int(rest["total_steps"])
+        NoisyLinear._counter = int(rest["noisy_counter"])
+        self.episode_rewards.clear()
+        self.episode_rewards.extend(rest.get("episode_rewards", []))
+        if "memory_state_dict" in rest:
+            self.memory.load_state_dict(rest["memory_state_dict"])
+        return rest
 
     def train(self, max_vector_steps=None):
         """The reference's train() loop; the small-M GEMMs of the update run on the library that answers them

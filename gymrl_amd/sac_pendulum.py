@@ -249,6 +249,33 @@ class SACTrainer:
         sc.flush()
         self._graph()
 
+    def save_checkpoint(self, path, include_memory=True):
+        """ModelLoader-style dict: three networks, both optimisers in torch.optim.Adam's layout, the
+        float64 temperature with its Adam state and — unlike the reference, which skips `memory` — the replay ring."""
+        from .utils import checkpoint
+        extra = {"memory_state_dict": self.memory.state_dict()} if include_memory else {}
+        return checkpoint.save_agent(path, {"actor": self.actor, "critic": self.critic, "critic_target": self.critic_target},
+                                     {"actor_optimizer": (self.actor, self.actor_optimizer),
+                                      "critic_optimizer": (self.critic, self.critic_optimizer)},
+                                     log_alpha=self.log_alpha.detach().cpu(), alpha_m=self._alpha_m.cpu(),
+                                     alpha_v=self._alpha_v.cpu(), alpha_steps=self._alpha_steps,
+                                     episode_rewards=list(self.episode_rewards), **extra)
+
+    def load_checkpoint(self, path):
+        from .utils import checkpoint
+        rest = checkpoint.load_agent(path, {"actor": self.actor, "critic": self.critic, "critic_target": self.critic_target},
+                                     {"actor_optimizer": (self.actor, self.actor_optimizer),
+                                      "critic_optimizer": (self.critic, self.critic_optimizer)})
+        self.log_alpha.copy_(rest["log_alpha"].to(self.device))
+        self._alpha_m.copy_(rest["alpha_m"].to(self.device))
+        self._alpha_v.copy_(rest["alpha_v"].to(self.device))
+        self._alpha_steps = int(rest["alpha_steps"])
+        self.episode_rewards.clear()
+        self.episode_rewards.extend(rest.get("episode_rewards", []))
+        if "memory_state_dict" in rest:
+            self.memory.load_state_dict(rest["memory_state_dict"])
+        return rest
+
     def train(self, max_vector_steps=None):
         """The reference's train() loop; the small-M GEMMs of the update run on the library that answers them
         fastest (gymrl_amd/blas.py)."""

@@ -35,6 +35,12 @@ class RunningMeanStd:
     def update(self, x):
         ops.running_norm(x.view(-1, self.D), self.stats, update=True)
 
+    def state_dict(self):
+        return {"stats": self.stats.detach().cpu().clone()}
+
+    def load_state_dict(self, sd):
+        self.stats.copy_(sd["stats"].to(self.stats.device, torch.float64))
+
 
 class Normalization:
     def __init__(self, shape, device="cuda"):
@@ -44,6 +50,13 @@ class Normalization:
         """x f32[N, D] (or [D]) -> (x - mean) / (std + 1e-8); update=False for evaluation (:29-35)."""
         flat = x.reshape(-1, self.running_ms.D).contiguous()
         return ops.running_norm(flat, self.running_ms.stats, update=update).view_as(x)
+
+    def state_dict(self):
+        """Checkpoints carry the running statistics (the reference pickles the object itself)."""
+        return self.running_ms.state_dict()
+
+    def load_state_dict(self, sd):
+        self.running_ms.load_state_dict(sd)
 
 
 class RewardScaling:
@@ -59,3 +72,10 @@ class RewardScaling:
 
     def reset(self):
         self.R.zero_()
+
+    def state_dict(self):
+        return {"stats": self.running_ms.stats.detach().cpu().clone(), "R": self.R.detach().cpu().clone()}
+
+    def load_state_dict(self, sd):
+        self.running_ms.load_state_dict(sd)
+        self.R.copy_(sd["R"].to(self.R.device, torch.float64))

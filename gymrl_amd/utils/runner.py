@@ -70,6 +70,10 @@ def train(env, agent, cfg, max_vector_steps=None):
         agent.state_norm = Normalization(shape=cfg.n_states, device=cfg.device)
     if cfg.use_reward_scale and not hasattr(agent, 'reward_scaler'):
         agent.reward_scaler = RewardScaling(shape=1, gamma=cfg.gamma, num_envs=env.n, device=cfg.device)
+    pending = getattr(agent, "_pending_state", {})          # statistics a checkpoint carried for objects created just above
+    for attr in ("state_norm", "reward_scaler"):
+        if attr in pending and hasattr(agent, attr):
+            getattr(agent, attr).load_state_dict(pending.pop(attr))
     on_policy = isinstance(agent.memory, ReplayBuffer_on_policy)
     N, D, dev = env.n, env.obs_dim, env.device
     obs, nxt, tobs = (torch.empty(N, D, device=dev) for _ in range(3))
@@ -83,7 +87,7 @@ def train(env, agent, cfg, max_vector_steps=None):
     if on_policy:
         action, log_prob, value = agent.choose_action(state)
     step, limit = 0, max_vector_steps or (cfg.train_eps * cfg.max_steps // N + 1)
-    metrics = {}
+    metrics, saved = {}, 0
     while tracker.episodes < cfg.train_eps and step < limit:
         if not on_policy:
             action = agent.choose_action(state)
@@ -104,7 +108,12 @@ def train(env, agent, cfg, max_vector_steps=None):
         if agent.memory.size() >= cfg.batch_size:                                      # :142-144
             metrics = agent.update()
         tracker.advance(returns)
+        if hasattr(agent, "save_model") and tracker.episodes // cfg.save_freq > saved:  # :160-161, every save_freq episodes
+            saved = tracker.episodes // cfg.save_freq
+            agent.save_model()
     tracker.flush(returns)
+    if hasattr(agent, "save_model"):                                                   # :164
+        agent.save_model()
     return returns, metrics
 
 

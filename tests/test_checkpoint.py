@@ -79,3 +79,47 @@ def test_ppo_trainer_resumes_bit_exactly(tmp_path):
     ma, mb = a.update(a.collect_rollout()), b.update(b.collect_rollout())
     assert torch.equal(a.flat_params, b.flat_params)
     assert np.allclose([ma[k] for k in sorted(ma)], [mb[k] for k in sorted(mb)], rtol=0, atol=0)
+
+
+def _fresh_env(tr):
+    tr.env = type(tr.env)(tr.cfg.env_name, tr.cfg.num_envs, device=tr.device, seed=tr.base_seed)      # train() closed it
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", ["dqn", "rainbow", "sac"])
+def test_off_policy_trainers_resume_bit_exactly(tmp_path, algo):
+    """a checkpoint carries networks, optimiser moments, schedule counters, the replay ring and (Rainbow)
+    the PER sum tree + open n-step windows + NoisyNet draw counter; an interrupted run and its resumed copy then take
+    identical steps (same env seed), graphs on."""
+    from gymrl_amd import dqn_cartpole, rainbow_dqn_cartpole, sac_pendulum
+    mod, cls = {"dqn": (dqn_cartpole, "DQNTrainer"), "rainbow": (rainbow_dqn_cartpole, "RainbowDQNTrainer"),
+                "sac": (sac_pendulum, "SACTrainer")}[algo]
+
+    def make():
+        cfg = mod.Config()
+        cfg.num_envs, cfg.max_episodes, cfg.batch_size, cfg.seed, cfg.memory_capacity = 32, 10**9, 64, 4, 4096
+        return getattr(mod, cls)(cfg)
+    if algo == "rainbow":
+        rainbow_dqn_cartpole.NoisyLinear._counter = 0
+    torch.manual_seed(3)
+    a = make()
+    a.train(max_vector_steps=30)
+    path = str(tmp_path / f"{algo}.pth")
+    a.save_checkpoint(path)
+    ck = torch.load(path, weights_only=False)
+    assert "memory_state_dict" in ck and any(k.endswith("optimizer_state_dict") for k in ck)
+    rng = torch.cuda.get_rng_state()
+    _fresh_env(a)
+    a.train(max_vector_steps=20)
+    b = make()
+    b.load_checkpoint(path)
+    torch.cuda.set_rng_state(rng)
+    b.train(max_vector_steps=20)
+    flat = "actor_flat" if algo == "sac" else "flat_params"
+    assert torch.equal(getattr(a, flat), getattr(b, flat))
+    opt = "critic_optimizer" if algo == "sac" else "optimizer"
+    assert torch.equal(getattr(a, opt).v, getattr(b, opt).v) and getattr(a, opt).step_count == getattr(b, opt).step_count
+    if algo == "rainbow":
+        assert torch.equal(a.memory.sum_tree.tree, b.memory.sum_tree.tree)
+    if algo == "sac":
+        assert torch.equal(a.log_alpha, b.log_alpha)

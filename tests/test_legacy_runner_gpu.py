@@ -8,8 +8,10 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 
-def test_on_policy_runner_with_legacy_style_agent():
+def test_on_policy_runner_with_legacy_style_agent(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)                                   # ModelLoader writes ./checkpoints/<algo>_<env>.pth
     from torch import nn
+    from gymrl_amd.utils.model import ModelLoader
     from torch.distributions import Categorical
     from gymrl_amd import ops
     from gymrl_amd.utils.buffer import ReplayBuffer_on_policy
@@ -23,9 +25,9 @@ def test_on_policy_runner_with_legacy_style_agent():
             self.batch_size, self.mini_batch, self.epochs = 128 * 64, 2048, 4
             self.lr = 1e-3
 
-    class PPO:
+    class PPO(ModelLoader):
         def __init__(self, cfg):
-            self.cfg = cfg
+            super().__init__(cfg)
             self.net = nn.Sequential(nn.Linear(cfg.n_states, 64), nn.Tanh()).to(cfg.device)
             self.pi, self.v = nn.Linear(64, cfg.n_actions).to(cfg.device), nn.Linear(64, 1).to(cfg.device)
             params = list(self.net.parameters()) + list(self.pi.parameters()) + list(self.v.parameters())
@@ -72,6 +74,17 @@ def test_on_policy_runner_with_legacy_style_agent():
     assert hasattr(agent, "state_norm") and agent.state_norm.running_ms.n == 64 * 12 * 128 + 128
     assert np.mean(returns[-50:]) > np.mean(returns[:50])          # reward-scaled PPO improves on CartPole
     assert evaluate(cfg.env_name, agent, cfg, episodes=8) > 60
+    # runner.train() saved through ModelLoader (every save_freq episodes and at the end, utils/runner.py:160-164)
+    ck = torch.load(cfg.save_path, weights_only=False)
+    assert {"net_state_dict", "pi_state_dict", "v_state_dict", "optimizer_state_dict", "learn_step",
+            "state_norm_state_dict", "reward_scaler_state_dict"} <= set(ck) and "memory" not in ck
+    fresh = PPO(cfg)
+    cfg.load_model = True
+    train(make_env(cfg), fresh, cfg, max_vector_steps=1)           # load_model(), then one vector step
+    assert fresh.learn_step == agent.learn_step
+    assert fresh.state_norm.running_ms.n == agent.state_norm.running_ms.n + 2 * 128      # restored, then reset + 1 step
+    for a, b in zip(fresh.pi.parameters(), agent.pi.parameters()):
+        assert torch.equal(a, b)
 
 
 def test_off_policy_buffer_contract():
