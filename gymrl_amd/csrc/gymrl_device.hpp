@@ -58,7 +58,29 @@ enum : uint32_t {
   RNG_POLICY    = 0x30000000u,
   RNG_REPLAY    = 0x40000000u,
   RNG_NOISE     = 0x50000000u,
+  RNG_SHUFFLE   = 0x60000000u,
 };
+
+// ------------------------------------------------------ keyed permutation ---
+// A bijection of [0, M) evaluated per element: 6 alternating Feistel rounds on ceil(log2 M) bits (low half a
+// bits, high half b bits, round function = Philox4x32-10 keyed by (seed, counter)), cycle-walked back into
+// [0, M) (at most 2 evaluations on average since 2^bits < 2M).  No sort, no table, nothing read from memory.
+__device__ __forceinline__ uint32_t feistel_once(uint32_t x, int a, int b, uint64_t seed, uint64_t counter) {
+  const uint32_t mask_lo = (1u << a) - 1u, mask_hi = (1u << b) - 1u;
+  uint32_t lo = x & mask_lo, hi = x >> a;
+  const uint32_t c2 = (uint32_t)counter, c3 = RNG_SHUFFLE | ((uint32_t)(counter >> 32) & 0x0FFFFFFFu);
+#pragma unroll
+  for (uint32_t r = 0; r < 6; ++r) {
+    if ((r & 1u) == 0u) lo ^= philox4x32(seed, hi, r, c2, c3).x & mask_lo;
+    else                hi ^= philox4x32(seed, lo, r, c2, c3).x & mask_hi;
+  }
+  return (hi << a) | lo;
+}
+__device__ __forceinline__ uint32_t keyed_permute(uint32_t i, uint32_t M, int a, int b, uint64_t seed, uint64_t counter) {
+  uint32_t x = feistel_once(i, a, b, seed, counter);
+  while (x >= M) x = feistel_once(x, a, b, seed, counter);
+  return x;
+}
 
 // ------------------------------------------------- reproducible f32 math ---
 // exp: Cody-Waite reduction by ln2 (hi/lo), degree-6 polynomial (Cephes expf

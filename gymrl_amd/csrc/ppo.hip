@@ -350,6 +350,13 @@ constexpr int kMaxLossBlocks = 1024;
 // kernel then stream.
 constexpr int kRecF = 16;   // floats per packed record (64 B)
 
+// P6 epoch shuffle (ppo_lunarlander.py:262 np.random.shuffle): perm[i] = keyed bijection of i.
+__global__ __launch_bounds__(kBlock) void permutation_kernel(uint64_t seed, uint64_t counter, uint32_t M, int a, int b,
+                                                             int32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < M) out[i] = (int32_t)keyed_permute(i, M, a, b, seed, counter);
+}
+
 __global__ __launch_bounds__(kBlock) void pack_rollout_kernel(
     const float* __restrict__ obs, const int32_t* __restrict__ act, const float* __restrict__ logp,
     const float* __restrict__ adv, const float* __restrict__ ret, int64_t M, int D,
@@ -479,6 +486,18 @@ int gymrl_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const i
   if (metrics_sum)
     hipLaunchKernelGGL(metrics_finalize_kernel<9>, dim3(1), dim3(kBlock), 0, stream, parts, nb,
                        metrics_sum);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_permutation(uint64_t seed, uint64_t counter, int64_t M, int32_t* perm_out, void* stream_) {
+  if (!perm_out || M < 0 || M > (int64_t)1 << 30) return -22;
+  if (M == 0) return 0;
+  int bits = 2;
+  while (((int64_t)1 << bits) < M) ++bits;
+  const int a = bits / 2, b = bits - a;
+  hipLaunchKernelGGL(permutation_kernel, dim3((unsigned)((M + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream_, seed, counter, (uint32_t)M, a, b, perm_out);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

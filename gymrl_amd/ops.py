@@ -235,6 +235,14 @@ def reduce_rows(partials, rows, blocks_per_row, K):
     return out
 
 
+def permutation(seed, counter, M, device, out=None):
+    """P6 epoch shuffle: i32[M] keyed bijection of [0, M) (gymrl_permutation)."""
+    out = torch.empty(M, dtype=torch.int32, device=device) if out is None else out
+    check(lib().gymrl_permutation(C.c_uint64(seed), C.c_uint64(counter), C.c_int64(M), _ptr(out, torch.int32), _stream()),
+          "gymrl_permutation")
+    return out
+
+
 def pack_rollout(obs, act, logp, adv, ret, packed=None):
     """P6: one 64-B record per transition (ppo_lunarlander.py:238-250).  obs [M, D]."""
     M, D = obs.shape

@@ -228,8 +228,7 @@ class PPOTrainer:
         self._gae_ws = ops.gae_workspace(T, N, self.device)
         self._moments = torch.zeros(3, dtype=torch.float64, device=self.device)
         self._next_value = torch.zeros(N, device=self.device)
-        self._perm_gen = torch.Generator(device=self.device)
-        self._perm_gen.manual_seed(self.base_seed * 7919 + 13 + self.rank)
+        self._perm_seed, self._perm_draws, self._perm = self.base_seed * 7919 + 13 + self.rank, 0, None   # epoch shuffles
         self._loss_cfg = (config.clip_eps, config.dual_clip, config.value_coef, config.entropy_coef)
         self._finished = None
         self._metric_parts = None
@@ -376,7 +375,7 @@ class PPOTrainer:
     def update(self, next_value=None, indices=None):
         """:233-330.  (next_value is accepted for signature compatibility; when it is the tensor
         collect_rollout() returned, the GAE maps composed during the rollout are reused.)  `indices` (optional i32/i64 [num_epochs, T*N]) replays an explicit
-        shuffle order (parity mode); by default a device randperm per epoch (:262)."""
+        shuffle order (parity mode); by default one keyed device permutation per epoch (gymrl_permutation, :262)."""
         cfg, b = self.cfg, self.buffer
         if indices is None and self._parity_indices:
             indices = self._parity_indices.pop(0)
@@ -410,7 +409,10 @@ class PPOTrainer:
             if indices is not None:
                 perm = torch.as_tensor(indices[epoch], device=self.device).to(torch.int32)
             else:
-                perm = torch.randperm(total, device=self.device, generator=self._perm_gen).to(torch.int32)
+                self._perm_draws += 1
+                self._perm = ops.permutation(self._perm_seed, self._perm_draws, total, self.device,
+                                             out=self._perm if self._perm is not None and self._perm.numel() == total else None)
+                perm = self._perm
             for start in range(0, total, mb):
                 mb_idx = perm[start:start + mb]
                 B = mb_idx.numel()
@@ -460,13 +462,14 @@ class PPOTrainer:
         from .utils import checkpoint
         return checkpoint.save_agent(path, {"model": self.model}, {"optimizer": (self.model, self.optimizer)},
                                      step_count=self.step_count, rollout_count=self.rollout_count,
-                                     episode_rewards=list(self.episode_rewards))
+                                     perm_draws=self._perm_draws, episode_rewards=list(self.episode_rewards))
 
     def load_checkpoint(self, path):
         from .utils import checkpoint
         rest = checkpoint.load_agent(path, {"model": self.model}, {"optimizer": (self.model, self.optimizer)})
         self.step_count = int(rest.get("step_count", 0))
         self.rollout_count = int(rest.get("rollout_count", 0))
+        self._perm_draws = int(rest.get("perm_draws", 0))
         self.episode_rewards.clear()
         self.episode_rewards.extend(rest.get("episode_rewards", []))
         gdist.broadcast(self.flat_params)

@@ -507,6 +507,29 @@ void orc_rnd_reward(const float* predict, const float* target, int B, int E, flo
   }
 }
 
+/* P6 epoch shuffle — ppo_lunarlander.py:262: the keyed bijection gymrl_permutation evaluates (6 alternating
+ * Feistel rounds with a Philox round function, cycle-walked into [0, M)). */
+static uint32_t feistel_once(uint32_t x, int a, int b, uint64_t seed, uint64_t counter) {
+  const uint32_t mask_lo = (1u << a) - 1u, mask_hi = (1u << b) - 1u;
+  uint32_t lo = x & mask_lo, hi = x >> a, o[4];
+  const uint32_t c2 = (uint32_t)counter, c3 = 0x60000000u | ((uint32_t)(counter >> 32) & 0x0FFFFFFFu);
+  for (uint32_t r = 0; r < 6; ++r) {
+    if ((r & 1u) == 0u) { orc_philox(seed, hi, r, c2, c3, o); lo ^= o[0] & mask_lo; }
+    else                { orc_philox(seed, lo, r, c2, c3, o); hi ^= o[0] & mask_hi; }
+  }
+  return (hi << a) | lo;
+}
+void orc_permutation(uint64_t seed, uint64_t counter, int64_t M, int32_t* out) {
+  int bits = 2;
+  while (((int64_t)1 << bits) < M) ++bits;
+  const int a = bits / 2, b = bits - a;
+  for (int64_t i = 0; i < M; ++i) {
+    uint32_t x = feistel_once((uint32_t)i, a, b, seed, counter);
+    while (x >= (uint32_t)M) x = feistel_once(x, a, b, seed, counter);
+    out[i] = (int32_t)x;
+  }
+}
+
 /* =========================================================== optimiser ==== */
 /* O1 — clip_grad_norm_ + torch.optim.Adam step, ppo_lunarlander.py:169,302-307. */
 void orc_sqnorm(const float* g, int64_t n, float grad_scale, double* out) {

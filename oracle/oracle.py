@@ -261,6 +261,12 @@ def rnd_reward(predict, target, rew=None):
     return rnd, rew_
 
 
+def permutation(seed, counter, M):
+    out = np.empty(M, np.int32)
+    lib().orc_permutation(C.c_uint64(seed), C.c_uint64(counter), C.c_int64(M), _p(out))
+    return out
+
+
 def pack_rollout(obs, act, logp, adv, ret):
     """ppo_lunarlander.py:238-250 staging as one 64-B record per transition (numpy restatement)."""
     obs = _f32(obs)

@@ -524,3 +524,16 @@ def test_persistent_rollout_bit_identical_to_stepwise(dev, N, T, chunk):
         adv_a, ret_a = a.compute_gae()
         adv_b, ret_b = b.compute_gae()
         assert torch.equal(adv_a, adv_b) and torch.equal(ret_a, ret_b) and torch.equal(a._moments, b._moments)
+
+
+def test_permutation_bit_exact_vs_oracle(dev, oracle):
+    """gymrl_permutation: integer work, bit-exact against the restatement; at BASELINE's rollout size (2^23) checked
+    through the size-independent property instead (a bijection: every index exactly once)."""
+    from gymrl_amd import ops
+    for M in (1, 2, 3, 64, 1000, 4097, 100003, 1 << 18):
+        got = ops.permutation(11, 5, M, dev)
+        assert np.array_equal(got.cpu().numpy(), oracle.permutation(11, 5, M)), M
+    big = ops.permutation(3, 1 << 40, 1 << 23, dev)
+    assert torch.equal(torch.sort(big.long()).values, torch.arange(1 << 23, device=dev))
+    buf = torch.empty(1 << 23, dtype=torch.int32, device=dev)
+    assert ops.permutation(3, (1 << 40) + 1, 1 << 23, dev, out=buf) is buf and not torch.equal(buf, big)

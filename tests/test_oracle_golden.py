@@ -163,3 +163,21 @@ def test_ppo_trace_fixture_is_self_consistent(oracle):
     assert rel_close(logp, g["r0_log_probs"]) <= TOL and rel_close(value, g["r0_values"]) <= TOL
     # O2: lr = lr0 * (1 - step_count / max_train_steps) before each rollout (:337-341)
     assert np.allclose(g["lr"], [float(g["lr0"]), float(g["lr0"]) * 0.5])
+
+
+def test_permutation_is_a_keyed_bijection(oracle):
+    """P6 epoch shuffle restatement: a bijection of [0, M) for every M (powers of two, odd sizes, tiny sizes),
+    a different one per counter, with no visible structure (fixed points ~ 1, |perm[i+1] - perm[i]| ~ M/3)."""
+    for M in (1, 2, 3, 5, 64, 100, 4097, 100003, 1 << 18):
+        p = oracle.permutation(11, 5, M)
+        assert np.array_equal(np.sort(p), np.arange(M, dtype=np.int32)), M
+    M = 1 << 18
+    p1, p2 = oracle.permutation(11, 5, M), oracle.permutation(11, 6, M)
+    assert np.array_equal(p1, oracle.permutation(11, 5, M))
+    assert (p1 == p2).sum() < 20 and (p1 == np.arange(M)).sum() < 20
+    assert abs(np.abs(np.diff(p1.astype(np.int64))).mean() / M - 1 / 3) < 0.01
+    assert abs(np.corrcoef(p1, np.arange(M))[0, 1]) < 0.01
+    # every minibatch slice sees the rollout uniformly: slice means within 4 sigma of (M - 1) / 2
+    mb = p1.reshape(32, -1).astype(np.float64).mean(1)
+    sigma = M / np.sqrt(12.0 * (M // 32))
+    assert np.all(np.abs(mb - (M - 1) / 2) < 4 * sigma)
