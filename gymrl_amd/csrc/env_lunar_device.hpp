@@ -91,8 +91,20 @@ constexpr int kLdsWords = 2 * kMfWords + 2 * kVcWords;   // per lane: its own bo
 constexpr int kQuad = 4;                                  // lanes per env
 constexpr int kEnvsPerBlock = kEnvBlock / kQuad;          // 16
 
+// Section timers of the probe build (make prof): 100 MHz ticks summed per workgroup by its first lane.
+#ifdef GYMRL_LUNAR_PROF
+#define LUNAR_PROF_MARK(var) const unsigned long long var = wall_clock64()
+#define LUNAR_PROF_ADD(lds, slot, t0, t1) do { if ((lds).prof && (threadIdx.x & 63) == 0) (lds).prof[slot] += (t1) - (t0); } while (0)
+#else
+#define LUNAR_PROF_MARK(var)
+#define LUNAR_PROF_ADD(lds, slot, t0, t1)
+#endif
+
 struct Lds {
   uint32_t* w;   // base + lane
+#ifdef GYMRL_LUNAR_PROF
+  unsigned long long* prof;
+#endif
   __device__ __forceinline__ float& mf(int s, int f) const { return reinterpret_cast<float*>(w)[(s * kMfWords + f) * kEnvBlock]; }
   __device__ __forceinline__ uint32_t& mu(int s, int f) const { return w[(s * kMfWords + f) * kEnvBlock]; }
   __device__ __forceinline__ float& vc(int s, int f) const { return reinterpret_cast<float*>(w)[(2 * kMfWords + s * kVcWords + f) * kEnvBlock]; }
@@ -335,6 +347,7 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
   const float mB_ = is_hull ? kInvM[0] : kInvM[1], iB_ = is_hull ? kInvI[0] : kInvI[1];
   const float lcy_ = is_hull ? kHullLcY : 0.0f;
   const float fr_ = is_hull ? sqrtf(0.1f * 0.1f) : sqrtf(0.2f * 0.1f);     // b2MixFriction with the terrain
+  LUNAR_PROF_MARK(pt0);
   // ---- engines (gymnasium LunarLander.step) ----
   m_power = 0.0f; s_power = 0.0f;
   {
@@ -471,6 +484,8 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
     W.touching = touching_now;
   }
 
+  LUNAR_PROF_MARK(pt1);
+  LUNAR_PROF_ADD(lds, 0, pt0, pt1);          // engines + collide + listener
   // ---- Solve (b2Island::Solve) ----
   const float h = kDt;
   // integrate velocities: gravity (0,-10) + the pending reset force on the hull
@@ -611,6 +626,8 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
     }
   }
 
+  LUNAR_PROF_MARK(pt2);
+  LUNAR_PROF_ADD(lds, 1, pt1, pt2);          // constraint initialisation + warm start
   // velocity iterations
 #pragma nounroll
   for (int it = 0; it < kVelIters; ++it) {
@@ -752,6 +769,9 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
       quad_share_velocity(B, me);
     }
   }
+  LUNAR_PROF_MARK(pt3);
+  LUNAR_PROF_ADD(lds, 2, pt2, pt3);          // 180 velocity sweeps
+  LUNAR_PROF_ADD(lds, any_contact ? 6 : 7, pt2, pt3);
   // b2ContactSolver::StoreImpulses
   if (my_contact) {
 #pragma unroll
@@ -779,48 +799,75 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
     B[b].cx += h * B[b].vx; B[b].cy += h * B[b].vy; B[b].a += h * B[b].w;
   }
 
+  LUNAR_PROF_MARK(pt4);
+  LUNAR_PROF_ADD(lds, 3, pt3, pt4);          // store impulses + integrate positions
   // position iterations
+#ifdef GYMRL_LUNAR_PROF
+  int prof_pos_iters = 0;
+#endif
   bool position_solved = false;
+  // The manifolds do not change during the position sweeps: read them from LDS once (a wave runs as many sweeps
+  // as its slowest env needs — 19 on average, 49 in the slowest workgroup — and every LDS read in the sweep is
+  // a dependent ~100-clock round trip).
+  int pcnt[2] = {0, 0};
+  bool pfaceB[2] = {false, false};
+  float plnx[2], plny[2], plpx[2], plpy[2], pqx[2][2], pqy[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    plnx[s] = plny[s] = plpx[s] = plpy[s] = 0.0f;
+    pqx[s][0] = pqx[s][1] = pqy[s][0] = pqy[s][1] = 0.0f;
+    if (my_contact) {
+      pcnt[s] = (int)lds.mu(s, MF_COUNT);                        // the position solver keeps every manifold point
+      pfaceB[s] = lds.mu(s, MF_FACEB) != 0u;
+      plnx[s] = lds.mf(s, MF_LNX); plny[s] = lds.mf(s, MF_LNY);
+      plpx[s] = lds.mf(s, MF_LPX); plpy[s] = lds.mf(s, MF_LPY);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        pqx[s][k] = lds.mf(s, MF_P0 + 5 * k + P_LPX); pqy[s][k] = lds.mf(s, MF_P0 + 5 * k + P_LPY);
+      }
+    }
+  }
 #pragma nounroll
   for (int it = 0; it < kPosIters; ++it) {
     float min_sep = 0.0f;
     if (any_contact) {
       Body me = select_body(B, mb);
       float my_min = 0.0f;
-#pragma nounroll
+#pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const int cnt = my_contact ? (int)lds.mu(s, MF_COUNT) : 0;   // the position solver keeps every manifold point
+        const int cnt = pcnt[s];
         if (cnt > 0) {
-          const bool faceB = lds.mu(s, MF_FACEB) != 0u;
-          const float lnx = lds.mf(s, MF_LNX), lny = lds.mf(s, MF_LNY);
-          const float lpx = lds.mf(s, MF_LPX), lpy = lds.mf(s, MF_LPY);
-#pragma nounroll
-          for (int k = 0; k < cnt; ++k) {
-            const float qx = lds.mf(s, MF_P0 + 5 * k + P_LPX), qy = lds.mf(s, MF_P0 + 5 * k + P_LPY);
-            float px, py, qs, qc;
-            body_xf(me, lcy_, px, py, qs, qc);
-            float nx, ny, ptx, pty, sep;
-            if (!faceB) {
-              nx = lnx; ny = lny;
-              const float clx = (qc * qx - qs * qy) + px, cly = (qs * qx + qc * qy) + py;
-              sep = dot2(clx - lpx, cly - lpy, nx, ny) - kPolyRadius - kPolyRadius;
-              ptx = clx; pty = cly;
-            } else {
-              nx = qc * lnx - qs * lny; ny = qs * lnx + qc * lny;
-              const float ppx = (qc * lpx - qs * lpy) + px, ppy = (qs * lpx + qc * lpy) + py;
-              sep = dot2(qx - ppx, qy - ppy, nx, ny) - kPolyRadius - kPolyRadius;
-              ptx = qx; pty = qy;
-              nx = -nx; ny = -ny;
+          const bool faceB = pfaceB[s];
+          const float lnx = plnx[s], lny = plny[s], lpx = plpx[s], lpy = plpy[s];
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            if (k < cnt) {
+              const float qx = pqx[s][k], qy = pqy[s][k];
+              float px, py, qs, qc;
+              body_xf(me, lcy_, px, py, qs, qc);
+              float nx, ny, ptx, pty, sep;
+              if (!faceB) {
+                nx = lnx; ny = lny;
+                const float clx = (qc * qx - qs * qy) + px, cly = (qs * qx + qc * qy) + py;
+                sep = dot2(clx - lpx, cly - lpy, nx, ny) - kPolyRadius - kPolyRadius;
+                ptx = clx; pty = cly;
+              } else {
+                nx = qc * lnx - qs * lny; ny = qs * lnx + qc * lny;
+                const float ppx = (qc * lpx - qs * lpy) + px, ppy = (qs * lpx + qc * lpy) + py;
+                sep = dot2(qx - ppx, qy - ppy, nx, ny) - kPolyRadius - kPolyRadius;
+                ptx = qx; pty = qy;
+                nx = -nx; ny = -ny;
+              }
+              const float rx = ptx - me.cx, ry = pty - me.cy;
+              my_min = fminf(my_min, sep);
+              const float C = clampf(kBaumgarte * (sep + kLinearSlop), -kMaxLinCorr, 0.0f);
+              const float rn = cross2(rx, ry, nx, ny);
+              const float K = mB_ + iB_ * rn * rn;
+              const float imp = K > 0.0f ? -C / K : 0.0f;
+              const float Px = imp * nx, Py = imp * ny;
+              me.cx += mB_ * Px; me.cy += mB_ * Py;
+              me.a += iB_ * cross2(rx, ry, Px, Py);
             }
-            const float rx = ptx - me.cx, ry = pty - me.cy;
-            my_min = fminf(my_min, sep);
-            const float C = clampf(kBaumgarte * (sep + kLinearSlop), -kMaxLinCorr, 0.0f);
-            const float rn = cross2(rx, ry, nx, ny);
-            const float K = mB_ + iB_ * rn * rn;
-            const float imp = K > 0.0f ? -C / K : 0.0f;
-            const float Px = imp * nx, Py = imp * ny;
-            me.cx += mB_ * Px; me.cy += mB_ * Py;
-            me.a += iB_ * cross2(rx, ry, Px, Py);
           }
         }
       }
@@ -872,10 +919,34 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
       B[bi].cx += mB * impx; B[bi].cy += mB * impy;
       B[bi].a += iB * cross2(rBx, rBy, impx, impy);
       joints_ok = joints_ok && (posErr <= kLinearSlop) && (angErr <= kAngularSlop);
+#ifdef GYMRL_LUNAR_PROF
+      if (it == 10 && lds.prof && role == 0) {       // what keeps an env iterating: per cause, summed over envs
+        if (!(posErr <= kLinearSlop)) atomicAdd(&lds.prof[14], 1ull);
+        if (!(angErr <= kAngularSlop)) atomicAdd(&lds.prof[15], 1ull);
+      }
+#endif
     }
+#ifdef GYMRL_LUNAR_PROF
+    if (it == 10 && lds.prof && role == 0) {
+      if (!contacts_ok) atomicAdd(&lds.prof[13], 1ull);
+      atomicAdd(&lds.prof[5], 1ull);                  // env-steps still iterating at iteration 10
+    }
+#endif
     if (contacts_ok && joints_ok) { position_solved = true; break; }
+#ifdef GYMRL_LUNAR_PROF
+    ++prof_pos_iters;
+#endif
   }
+#ifdef GYMRL_LUNAR_PROF
+  {
+    int wmax = prof_pos_iters + (position_solved ? 1 : 0), mine = wmax;
+    for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
+    if (lds.prof && (threadIdx.x & 63) == 0) { lds.prof[11] += (unsigned long long)wmax; lds.prof[12] += (unsigned long long)mine; }
+  }
+#endif
 
+  LUNAR_PROF_MARK(pt5);
+  LUNAR_PROF_ADD(lds, 4, pt4, pt5);          // position iterations (until every env of the wave is solved)
   // sleep management (island = hull + both legs)
   float min_sleep = 3.4e38f;
 #pragma unroll

@@ -52,7 +52,11 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_kernel(gymrl_rollout_l
   const int role = lane & 3, row = lane >> 2, i = m0 + row;
   const bool valid = i < N;
   const LunarState st(a.env_state, N);
+#ifdef GYMRL_LUNAR_PROF
+  const Lds slds{lds_words + lane, a.wg_ticks ? reinterpret_cast<unsigned long long*>(a.wg_ticks) + 2 * gridDim.x + 16 * blockIdx.x : nullptr};
+#else
   const Lds slds{lds_words + lane};
+#endif
   const double gl = (double)(float)(a.gamma * a.lam);              // NEP-50 float32 decay (see gae.hip)
   if (a.wg_ticks && tid == 0) a.wg_ticks[2 * blockIdx.x] = wall_clock64();   // profiling: 100 MHz ticks
 
@@ -67,7 +71,10 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_kernel(gymrl_rollout_l
     const bool tail = t == t_end;                   // only the bootstrap value of the finished rollout is left
     if (tail && t_end != T) break;
     __syncthreads();                                // xin of step t is complete
+    LUNAR_PROF_MARK(rt0);
     M::forward_tile(d, lds, xin, head, m0, N, tid); // logits -> head[row][0..3], value -> head[row][4]
+    LUNAR_PROF_MARK(rt1);
+    if (wave == 0) LUNAR_PROF_ADD(slds, 8, rt0, rt1);   // policy forward
     if (wave == 0) {
       float z[kActions];
 #pragma unroll
@@ -92,7 +99,11 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_kernel(gymrl_rollout_l
         const StepOut out{a.obs + (size_t)(t + 1) * N * kObs, nullptr, a.rew + (size_t)t * N, nullptr, nullptr,
                           a.done + (size_t)t * N, a.ep_ret ? a.ep_ret + (size_t)t * N : nullptr, nullptr, a.ep_stats};
         float o_next[8];
+        LUNAR_PROF_MARK(rt2);
+        LUNAR_PROF_ADD(slds, 9, rt1, rt2);              // GAE compose + draw + slab writes
         lunar_step_quad(st, slds, N, i, role, valid, act, a.seed, a.env_id0, out, o_next);
+        LUNAR_PROF_MARK(rt3);
+        LUNAR_PROF_ADD(slds, 10, rt2, rt3);             // whole env step (state load, world_step, reward, reset, store)
         if (valid && role < 2) {                    // next policy input: straight into the forward's LDS tile
 #pragma unroll
           for (int k = 0; k < 4; ++k) xin[row * M::kInStride + 4 * role + k] = o_next[4 * role + k];
