@@ -67,6 +67,7 @@ __device__ constexpr float kLegVy[4] = {-8.f / 30, -8.f / 30, 8.f / 30, 8.f / 30
 __device__ constexpr float kLegNx[4] = {0.0f, 1.0f, 0.0f, -1.0f};
 __device__ constexpr float kLegNy[4] = {-1.0f, 0.0f, 1.0f, 0.0f};
 
+typedef float v2f __attribute__((ext_vector_type(2)));
 struct Body { float cx, cy, a, vx, vy, w; };   // centre of mass, angle, velocities
 
 struct Joint {              // revolute joint hull(A) -> leg(B)
@@ -628,6 +629,28 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
 
   LUNAR_PROF_MARK(pt2);
   LUNAR_PROF_ADD(lds, 1, pt1, pt2);          // constraint initialisation + warm start
+  // Per-joint invariants of the sweeps, hoisted by hand (same operations, same order as b2Mat33::Solve33 /
+  // b2Mat22 inside the sweep): first Cramer cofactor column and the two reciprocal determinants; the joint arms
+  // as (x, y) pairs and as their perpendiculars so that w x r is one packed multiply.
+  v2f jrA[2], jrB[2], jpA[2], jpB[2], kdiag[2];
+  float c1x[2], c1y[2], c1z[2], det3i[2], det2i[2];
+#pragma unroll
+  for (int L = 0; L < 2; ++L) {
+    const float a11 = K11[L], a12 = K12[L], a13 = K13[L], a22 = K22[L], a23 = K23[L], a33 = K33[L];
+    c1x[L] = a22 * a33 - a23 * a23; c1y[L] = a23 * a13 - a12 * a33; c1z[L] = a12 * a23 - a22 * a13;
+    float det = a11 * c1x[L] + a12 * c1y[L] + a13 * c1z[L];
+    if (det != 0.0f) det = 1.0f / det;
+    det3i[L] = det;
+    float d2 = a11 * a22 - a12 * a12;
+    if (d2 != 0.0f) d2 = 1.0f / d2;
+    det2i[L] = d2;
+    jrA[L] = v2f{jrAx[L], jrAy[L]}; jrB[L] = v2f{jrBx[L], jrBy[L]};
+    jpA[L] = v2f{-jrAy[L], jrAx[L]}; jpB[L] = v2f{-jrBy[L], jrBx[L]};
+    kdiag[L] = v2f{a22, a11};
+  }
+  // velocities as (x, y) pairs for the duration of the sweeps
+  v2f vel[3] = {v2f{B[0].vx, B[0].vy}, v2f{B[1].vx, B[1].vy}, v2f{B[2].vx, B[2].vy}};
+  float om[3] = {B[0].w, B[1].w, B[2].w};
   // velocity iterations
 #pragma nounroll
   for (int it = 0; it < kVelIters; ++it) {
@@ -638,58 +661,58 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
       Joint& J = W.j[L];
       const float mA = kInvM[0], mB = kInvM[bi], iA = kInvI[0], iB = kInvI[bi];
       {  // motor
-        const float Cdot = B[bi].w - B[0].w - 0.3f * leg_sign(L);
+        const float Cdot = om[bi] - om[0] - 0.3f * leg_sign(L);
         float imp = -mmass[L] * Cdot;
         const float old = J.im, maxImp = h * kMotorTorque;
         J.im = clampf(old + imp, -maxImp, maxImp);
         imp = J.im - old;
-        B[0].w -= iA * imp; B[bi].w += iB * imp;
+        om[0] -= iA * imp; om[bi] += iB * imp;
       }
-      const float Cx = B[bi].vx + (-B[bi].w * jrBy[L]) - B[0].vx - (-B[0].w * jrAy[L]);
-      const float Cy = B[bi].vy + (B[bi].w * jrBx[L]) - B[0].vy - (B[0].w * jrAx[L]);
-      float ipx, ipy, ipz;
+      // Cdot = vB + wB x rB - vA - wA x rA, with w x r = w * (-ry, rx)
+      const v2f C = ((vel[bi] + om[bi] * jpB[L]) - vel[0]) - om[0] * jpA[L];
+      v2f ip;
+      float ipz;
       if (J.state != 0) {
-        const float Cz = B[bi].w - B[0].w;
+        const float Cz = om[bi] - om[0];
         // impulse = -K^-1 * Cdot (b2Mat33::Solve33, Cramer)
         const float a11 = K11[L], a12 = K12[L], a13 = K13[L], a22 = K22[L], a23 = K23[L], a33 = K33[L];
-        const float c1x = a22 * a33 - a23 * a23, c1y = a23 * a13 - a12 * a33, c1z = a12 * a23 - a22 * a13;
-        float det = a11 * c1x + a12 * c1y + a13 * c1z;
-        if (det != 0.0f) det = 1.0f / det;
-        const float bx = Cx, by = Cy, bz = Cz;
-        const float sx = det * (bx * c1x + by * c1y + bz * c1z);
+        const float det = det3i[L];
+        const float bx = C.x, by = C.y, bz = Cz;
+        const float sx = det * (bx * c1x[L] + by * c1y[L] + bz * c1z[L]);
         const float c2x = by * a33 - bz * a23, c2y = bz * a13 - bx * a33, c2z = bx * a23 - by * a13;
         const float sy = det * (a11 * c2x + a12 * c2y + a13 * c2z);
         const float c3x = a22 * bz - a23 * by, c3y = a23 * bx - a12 * bz, c3z = a12 * by - a22 * bx;
         const float sz = det * (a11 * c3x + a12 * c3y + a13 * c3z);
-        ipx = -sx; ipy = -sy; ipz = -sz;
+        ip = v2f{-sx, -sy}; ipz = -sz;
         const float newImp = J.iz + ipz;
         const bool release = (J.state == 1) ? (newImp < 0.0f) : (newImp > 0.0f);
         if (release) {
-          const float rx = -Cx + J.iz * a13, ry = -Cy + J.iz * a23;
-          float d2 = a11 * a22 - a12 * a12;
-          if (d2 != 0.0f) d2 = 1.0f / d2;
+          const float rx = -C.x + J.iz * a13, ry = -C.y + J.iz * a23;
+          const float d2 = det2i[L];
           const float ux = d2 * (a22 * rx - a12 * ry), uy = d2 * (a11 * ry - a12 * rx);
-          ipx = ux; ipy = uy; ipz = -J.iz;
+          ip = v2f{ux, uy}; ipz = -J.iz;
           J.ix += ux; J.iy += uy; J.iz = 0.0f;
         } else {
-          J.ix += ipx; J.iy += ipy; J.iz += ipz;
+          J.ix += ip.x; J.iy += ip.y; J.iz += ipz;
         }
       } else {
-        const float a11 = K11[L], a12 = K12[L], a22 = K22[L];
-        float d2 = a11 * a22 - a12 * a12;
-        if (d2 != 0.0f) d2 = 1.0f / d2;
-        const float rx = -Cx, ry = -Cy;
-        ipx = d2 * (a22 * rx - a12 * ry); ipy = d2 * (a11 * ry - a12 * rx); ipz = 0.0f;
-        J.ix += ipx; J.iy += ipy;
+        const v2f r = -C;
+        ip = det2i[L] * (kdiag[L] * r - K12[L] * r.yx);       // (d2 (a22 rx - a12 ry), d2 (a11 ry - a12 rx))
+        ipz = 0.0f;
+        J.ix += ip.x; J.iy += ip.y;
       }
-      B[0].vx -= mA * ipx; B[0].vy -= mA * ipy;
-      B[0].w -= iA * (cross2(jrAx[L], jrAy[L], ipx, ipy) + ipz);
-      B[bi].vx += mB * ipx; B[bi].vy += mB * ipy;
-      B[bi].w += iB * (cross2(jrBx[L], jrBy[L], ipx, ipy) + ipz);
+      vel[0] -= mA * ip;
+      const v2f tA = jrA[L] * ip.yx, tB = jrB[L] * ip.yx;     // (rx ipy, ry ipx)
+      om[0] -= iA * ((tA.x - tA.y) + ipz);
+      vel[bi] += mB * ip;
+      om[bi] += iB * ((tB.x - tB.y) + ipz);
     }
     // contacts: each lane solves its own body's slots, then the quad exchanges velocities
     if (any_contact) {
-      Body me = select_body(B, mb);
+      Body me;                                  // only the velocities are touched in a sweep
+      me.cx = me.cy = me.a = 0.0f;
+      me.vx = sel3(mb, vel[0].x, vel[1].x, vel[2].x); me.vy = sel3(mb, vel[0].y, vel[1].y, vel[2].y);
+      me.w = sel3(mb, om[0], om[1], om[2]);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int vcount = vcn[s];
@@ -766,9 +789,13 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
           if (vcount == 2) { vim[s][2] = ni1; vim[s][3] = ti1; }
         }
       }
-      quad_share_velocity(B, me);
+      vel[0] = v2f{quad_bcast<0>(me.vx), quad_bcast<0>(me.vy)}; om[0] = quad_bcast<0>(me.w);
+      vel[1] = v2f{quad_bcast<1>(me.vx), quad_bcast<1>(me.vy)}; om[1] = quad_bcast<1>(me.w);
+      vel[2] = v2f{quad_bcast<2>(me.vx), quad_bcast<2>(me.vy)}; om[2] = quad_bcast<2>(me.w);
     }
   }
+#pragma unroll
+  for (int b = 0; b < 3; ++b) { B[b].vx = vel[b].x; B[b].vy = vel[b].y; B[b].w = om[b]; }
   LUNAR_PROF_MARK(pt3);
   LUNAR_PROF_ADD(lds, 2, pt2, pt3);          // 180 velocity sweeps
   LUNAR_PROF_ADD(lds, any_contact ? 6 : 7, pt2, pt3);
