@@ -135,6 +135,14 @@ __device__ __forceinline__ void run_stage(const gymrl_mlp_stage& st, const float
   }
 }
 
+// Two consecutive stages that touch disjoint buffers (e.g. the actor's and the critic's hidden layer, both reading
+// the shared trunk; or the two heads) need no barrier between them.
+__device__ __forceinline__ bool stages_independent(const gymrl_mlp_stage& a, const gymrl_mlp_stage& b) {
+  const bool b_reads_a = a.dst >= 0 && b.src == a.dst;
+  const bool b_overwrites_a_input = b.dst >= 0 && b.dst == a.src;
+  const bool same_dst = a.dst >= 0 && b.dst == a.dst;
+  return !b_reads_a && !b_overwrites_a_input && !same_dst;
+}
 
 // One whole network on the 16 rows whose input tile is already in `xin` (zero padded to 64 columns):
 // stages ping-pong through `lds`; dst == -1 stages go to HBM (head_lds == nullptr) or to the head tile.
@@ -142,12 +150,15 @@ __device__ __forceinline__ void forward_tile(const gymrl_mlp_desc& d, float (*ld
                                              float* head_lds, int m0, int n_rows, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   int head_col = 0;
+  bool paired = false;                  // this stage runs in the previous stage's barrier interval
   for (int s = 0; s < d.n_stages; ++s) {
     const gymrl_mlp_stage st = d.stage[s];
     const float* A = st.src < 0 ? xin : lds[st.src];
     const int a_stride = st.src < 0 ? kInStride : kStride;
     float* dst_lds = st.dst >= 0 ? lds[st.dst] : nullptr;
-    run_stage(st, A, a_stride, dst_lds, head_lds, head_col, m0, n_rows, lane, wave);
+    // the second stage of a pair starts its tile assignment one wave further on, so two single-tile stages
+    // (the heads) run side by side on two SIMDs instead of back to back on one
+    run_stage(st, A, a_stride, dst_lds, head_lds, head_col, m0, n_rows, lane, paired ? (wave + kWaves - 1) % kWaves : wave);
     if (st.dst < 0) head_col += st.out_dim;
     // columns between out_dim and the next multiple of 64 must read as zero: they are the next stage's K padding
     if (st.dst >= 0 && (st.out_dim & 63)) {
@@ -157,7 +168,9 @@ __device__ __forceinline__ void forward_tile(const gymrl_mlp_desc& d, float (*ld
         lds[st.dst][r * kStride + c] = 0.0f;
       }
     }
-    __syncthreads();
+    const bool pair_next = !paired && s + 1 < d.n_stages && stages_independent(st, d.stage[s + 1]);
+    if (!pair_next) __syncthreads();
+    paired = pair_next;
   }
 }
 

@@ -100,9 +100,11 @@ class ActorCritic(nn.Module):
 
     def _act_net(self):
         if self._fused is None:
+            # actor.0 / critic.0 (both read the trunk, disjoint outputs) and the two heads are independent pairs:
+            # the kernel runs each pair in one barrier interval
             stages = [(self.shared[0], "tanh", -1, 0), (self.shared[2], "tanh", 0, 1),
-                      (self.actor[0], "tanh", 1, 0), (self.actor[2], None, 0, -1),
-                      (self.critic[0], "tanh", 1, 0), (self.critic[2], None, 0, -1)]
+                      (self.actor[0], "tanh", 1, 0), (self.critic[0], "tanh", 1, 2),
+                      (self.actor[2], None, 0, -1), (self.critic[2], None, 2, -1)]
             # wider-than-LDS networks keep the per-layer library path
             ok = FusedMLP.supported(stages, self.shared[0].in_features)
             self._fused = FusedMLP(stages) if ok else False
