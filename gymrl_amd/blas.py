@@ -4,7 +4,8 @@ The DQN / Rainbow / SAC networks are 256-wide MLPs updated on 128-256 row miniba
 heuristic answers those shapes with its 256 x 128 macro tile: a 128 x 256 x 256 GEMM becomes TWO workgroups on
 two of the 256 CUs and takes 27-36 us — the same as at 4096 rows (rocprofv3:
 profiles/r01_sac_graph_kernel_stats.csv, 59 GEMMs = 0.93 ms of a 1.5 ms SAC step).  rocBLAS answers the same
-shapes in 6-15 us.  `small_gemm_backend()` scopes that preference (and, opt-in, PyTorch's TunableOp search
+shapes in 6-15 us (and `nn.SmallLinear` keeps the bias out of the GEMM call, because addmm's fused-bias form goes
+to hipBLASLt whatever the preference).  `small_gemm_backend()` scopes that preference (and, opt-in, PyTorch's TunableOp search
 over both libraries) to the off-policy train() loops; the PPO path's 262 144-row GEMMs keep the default
 (hipBLASLt at 0.85 of the f32 MFMA peak).  A hipGraph captured inside the scope keeps the kernels chosen in it.
 """

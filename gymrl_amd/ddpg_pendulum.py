@@ -10,6 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .nn import SmallLinear
 from .td3_pendulum import Actor, _ActorCriticBase  # noqa: F401  (Actor is part of this module's surface)
 
 
@@ -36,9 +37,9 @@ class Config:
 class Critic(nn.Module):
     def __init__(self, state_dim, action_dim, hidden_dim):
         super().__init__()
-        self.fc1 = nn.Linear(state_dim + action_dim, hidden_dim)
-        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
-        self.fc3 = nn.Linear(hidden_dim, 1)
+        self.fc1 = SmallLinear(state_dim + action_dim, hidden_dim)
+        self.fc2 = SmallLinear(hidden_dim, hidden_dim)
+        self.fc3 = SmallLinear(hidden_dim, 1)
 
     def forward(self, state, action):
         x = torch.cat([state, action], dim=1)

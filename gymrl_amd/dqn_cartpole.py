@@ -17,6 +17,7 @@ import torch.nn as nn
 from . import ops
 from .envs import EpisodeTracker, VecEnv
 from .flat import FusedAdam, GradSink, flatten_module
+from .nn import SmallLinear
 
 
 class Config:
@@ -58,9 +59,9 @@ class QNetwork(nn.Module):
     def __init__(self, state_dim, action_dim, hidden_dim=256):
         super().__init__()
         self.net = nn.Sequential(
-            layer_init(nn.Linear(state_dim, hidden_dim)), nn.ReLU(),
-            layer_init(nn.Linear(hidden_dim, hidden_dim)), nn.ReLU(),
-            layer_init(nn.Linear(hidden_dim, action_dim), std=0.01),
+            layer_init(SmallLinear(state_dim, hidden_dim)), nn.ReLU(),
+            layer_init(SmallLinear(hidden_dim, hidden_dim)), nn.ReLU(),
+            layer_init(SmallLinear(hidden_dim, action_dim), std=0.01),
         )
 
     def forward(self, x):

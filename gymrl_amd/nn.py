@@ -42,6 +42,27 @@ class Linear(nn.Linear):
         return F.linear(x, self.weight, self.bias)
 
 
+SPLIT_BIAS = True      # tools/micro_offpolicy.py flips this for its A/B
+
+
+def small_linear(x, weight, bias):
+    """F.linear for the 128-8192 row batches of the off-policy networks as a plain GEMM + in-place bias add.
+    torch.addmm's fused-bias form always goes to hipBLASLt, whose default pick for these shapes is one
+    256 x 256 macro tile (37 us at 256 or 8192 rows x 256 x 256, rocprofv3: 6 such calls = a quarter of a Rainbow
+    vector step); the plain GEMM follows gymrl_amd/blas.py's library preference (rocBLAS: 6-15 us) and the bias
+    costs one 4 us elementwise launch."""
+    if SPLIT_BIAS and x.dim() == 2 and bias is not None:
+        return torch.mm(x, weight.t()).add_(bias)
+    return F.linear(x, weight, bias)
+
+
+class SmallLinear(nn.Linear):
+    """nn.Linear (same parameters, same state_dict keys) with `small_linear` as its forward."""
+
+    def forward(self, x):
+        return small_linear(x, self.weight, self.bias)
+
+
 class FusedMLP:
     """Inference forward of a Linear(+Tanh|ReLU) network as ONE launch (`gymrl_mlp_forward`,
     csrc/mlp.hip: 16 rows per workgroup, activations in LDS, f32 MFMA).  Built from a list of

@@ -21,6 +21,7 @@ import torch.nn.functional as F
 from . import ops
 from .envs import EpisodeTracker, VecEnv
 from .flat import FusedAdam, GradSink, flatten_module
+from .nn import SmallLinear, small_linear
 
 
 class Config:
@@ -108,14 +109,14 @@ class NoisyLinear(nn.Module):
             bias = self.bias_mu + self.bias_sigma.mul(self.bias_epsilon)
         else:
             weight, bias = self.weight_mu, self.bias_mu
-        return F.linear(x, weight, bias)
+        return small_linear(x, weight, bias)
 
 
 class DuelingNoisyNetwork(nn.Module):
     def __init__(self, state_dim, action_dim, hidden_dim=256, seed=0):
         super().__init__()
-        self.fc1 = nn.Linear(state_dim, hidden_dim)
-        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
+        self.fc1 = SmallLinear(state_dim, hidden_dim)
+        self.fc2 = SmallLinear(hidden_dim, hidden_dim)
         self.advantage = NoisyLinear(hidden_dim, action_dim, seed=seed)
         self.value = NoisyLinear(hidden_dim, 1, seed=seed + 1)
 

@@ -19,6 +19,7 @@ from . import ops
 from .dqn_cartpole import ReplayBuffer
 from .envs import EpisodeTracker, VecEnv
 from .flat import FusedAdam, flatten_module
+from .nn import SmallLinear
 
 
 class Config:
@@ -45,9 +46,9 @@ class Config:
 class Actor(nn.Module):
     def __init__(self, state_dim, action_dim, hidden_dim=256):
         super().__init__()
-        self.fc1 = nn.Linear(state_dim, hidden_dim)
-        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
-        self.fc3 = nn.Linear(hidden_dim, action_dim)
+        self.fc1 = SmallLinear(state_dim, hidden_dim)
+        self.fc2 = SmallLinear(hidden_dim, hidden_dim)
+        self.fc3 = SmallLinear(hidden_dim, action_dim)
 
     def logits(self, x):
         return self.fc3(F.relu(self.fc2(F.relu(self.fc1(x)))))
@@ -59,9 +60,9 @@ class Actor(nn.Module):
 class Critic(nn.Module):
     def __init__(self, state_dim, action_dim, hidden_dim=256):
         super().__init__()
-        self.fc1 = nn.Linear(state_dim, hidden_dim)
-        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
-        self.fc3 = nn.Linear(hidden_dim, action_dim)
+        self.fc1 = SmallLinear(state_dim, hidden_dim)
+        self.fc2 = SmallLinear(hidden_dim, hidden_dim)
+        self.fc3 = SmallLinear(hidden_dim, action_dim)
 
     def forward(self, x):
         return self.fc3(F.relu(self.fc2(F.relu(self.fc1(x)))))

@@ -20,6 +20,7 @@ from . import ops
 from .dqn_cartpole import ReplayBuffer as _Ring
 from .envs import EpisodeTracker, VecEnv
 from .flat import FusedAdam, GradSink, flatten_module
+from .nn import SmallLinear
 
 
 class Config:
@@ -72,10 +73,10 @@ class Actor(nn.Module):
     def __init__(self, state_dim, action_dim, hidden_dim, action_bound, log_std_min, log_std_max):
         super().__init__()
         self.action_bound, self.log_std_min, self.log_std_max = action_bound, log_std_min, log_std_max
-        self.fc1 = nn.Linear(state_dim, hidden_dim)
-        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
-        self.mean = nn.Linear(hidden_dim, action_dim)
-        self.log_std = nn.Linear(hidden_dim, action_dim)
+        self.fc1 = SmallLinear(state_dim, hidden_dim)
+        self.fc2 = SmallLinear(hidden_dim, hidden_dim)
+        self.mean = SmallLinear(hidden_dim, action_dim)
+        self.log_std = SmallLinear(hidden_dim, action_dim)
 
     def forward(self, x):
         x = F.relu(self.fc2(F.relu(self.fc1(x))))
@@ -103,12 +104,12 @@ class Critic(nn.Module):
 
     def __init__(self, state_dim, action_dim, hidden_dim):
         super().__init__()
-        self.fc1 = nn.Linear(state_dim + action_dim, hidden_dim)
-        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
-        self.fc3 = nn.Linear(hidden_dim, 1)
-        self.fc4 = nn.Linear(state_dim + action_dim, hidden_dim)
-        self.fc5 = nn.Linear(hidden_dim, hidden_dim)
-        self.fc6 = nn.Linear(hidden_dim, 1)
+        self.fc1 = SmallLinear(state_dim + action_dim, hidden_dim)
+        self.fc2 = SmallLinear(hidden_dim, hidden_dim)
+        self.fc3 = SmallLinear(hidden_dim, 1)
+        self.fc4 = SmallLinear(state_dim + action_dim, hidden_dim)
+        self.fc5 = SmallLinear(hidden_dim, hidden_dim)
+        self.fc6 = SmallLinear(hidden_dim, 1)
 
     def forward(self, state, action):
         x = torch.cat([state, action], dim=1)

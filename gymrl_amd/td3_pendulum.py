@@ -19,6 +19,7 @@ import torch.nn.functional as F
 from . import ops
 from .envs import EpisodeTracker, VecEnv
 from .flat import FusedAdam, flatten_module
+from .nn import SmallLinear
 from .sac_pendulum import ReplayBuffer
 
 
@@ -49,9 +50,9 @@ class Actor(nn.Module):
     def __init__(self, state_dim, action_dim, hidden_dim, action_bound):
         super().__init__()
         self.action_bound = action_bound
-        self.fc1 = nn.Linear(state_dim, hidden_dim)
-        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
-        self.fc3 = nn.Linear(hidden_dim, action_dim)
+        self.fc1 = SmallLinear(state_dim, hidden_dim)
+        self.fc2 = SmallLinear(hidden_dim, hidden_dim)
+        self.fc3 = SmallLinear(hidden_dim, action_dim)
 
     def forward(self, x):
         x = F.relu(self.fc2(F.relu(self.fc1(x))))
@@ -61,12 +62,12 @@ class Actor(nn.Module):
 class Critic(nn.Module):
     def __init__(self, state_dim, action_dim, hidden_dim):
         super().__init__()
-        self.fc1 = nn.Linear(state_dim + action_dim, hidden_dim)
-        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
-        self.fc3 = nn.Linear(hidden_dim, 1)
-        self.fc4 = nn.Linear(state_dim + action_dim, hidden_dim)
-        self.fc5 = nn.Linear(hidden_dim, hidden_dim)
-        self.fc6 = nn.Linear(hidden_dim, 1)
+        self.fc1 = SmallLinear(state_dim + action_dim, hidden_dim)
+        self.fc2 = SmallLinear(hidden_dim, hidden_dim)
+        self.fc3 = SmallLinear(hidden_dim, 1)
+        self.fc4 = SmallLinear(state_dim + action_dim, hidden_dim)
+        self.fc5 = SmallLinear(hidden_dim, hidden_dim)
+        self.fc6 = SmallLinear(hidden_dim, 1)
 
     def forward(self, state, action):
         x = torch.cat([state, action], dim=1)

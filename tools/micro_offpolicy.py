@@ -27,8 +27,10 @@ def run(tr, steps, warm):
     return dt
 
 
+from gymrl_amd import nn as gnn  # noqa: E402
+
 MODES = (("eager hipblaslt-default", False, "default", False), ("graph hipblaslt-default", True, "default", False),
-         ("graph rocblas", True, "rocblas", False), ("graph auto (default config)", True, "auto", False),
+         ("graph rocblas", True, "rocblas", False), ("graph auto, bias fused in the GEMM", True, "auto", False), ("graph auto (default config)", True, "auto", False),
          ("graph rocblas+tunableop", True, "rocblas", True))
 
 
@@ -42,6 +44,7 @@ def main():
             c = mod.Config()
             c.num_envs, c.memory_capacity, c.max_episodes, c.batch_size = N, 1 << 20, 10**9, B
             c.use_graphs, c.gemm_backend, c.tune_gemms = graphs, backend, tune
+            gnn.SPLIT_BIAS = name in ("graph auto (default config)", "graph rocblas+tunableop")
             tr = getattr(mod, cls)(c)
             steps = 300
             dt = run(tr, steps, 60)
