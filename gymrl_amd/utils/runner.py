@@ -82,35 +82,54 @@ def train(env, agent, cfg, max_vector_steps=None):
     trunc = torch.zeros(N, dtype=torch.uint8, device=dev)
     returns = []
     tracker = EpisodeTracker(N, dev)
+    norm = (lambda x, **k: agent.state_norm(x, **k)) if cfg.use_state_norm else (lambda x, **k: x.clone())
     env.reset(obs, seed=int(np.random.randint(1, 2 ** 31 - 1)))
-    state = agent.state_norm(obs) if cfg.use_state_norm else obs
+    state = norm(obs)                                                                   # :107
     if on_policy:
-        action, log_prob, value = agent.choose_action(state)
+        action, log_prob, value = agent.choose_action(state)                            # :109-110
+    else:
+        action = agent.choose_action(state)                                             # :112
     step, limit = 0, max_vector_steps or (cfg.train_eps * cfg.max_steps // N + 1)
-    metrics, saved = {}, 0
-    while tracker.episodes < cfg.train_eps and step < limit:
-        if not on_policy:
-            action = agent.choose_action(state)
+    metrics, saved, episodes = {}, 0, 0
+    while episodes < cfg.train_eps and step < limit:
         ep_ret, done = tracker.slot()
         env.step(action, nxt, rew, done_out=done, term_obs_out=tobs, ep_ret_out=ep_ret, terminated_out=term,
                  truncated_out=trunc)
-        r = agent.reward_scaler(rew, done) if cfg.use_reward_scale else rew
-        next_state = agent.state_norm(nxt) if cfg.use_state_norm else nxt.clone()
+        r = agent.reward_scaler(rew, done) if cfg.use_reward_scale else rew               # :121 (R zeroed after use where done = reset() :99)
+        next_state = norm(tobs)                              # :122 — the TERMINAL observation where an episode ended
         if on_policy:
-            next_action, next_log_prob, next_value = agent.choose_action(next_state)   # chosen before storing (:129)
+            next_action, next_log_prob, next_value = agent.choose_action(next_state)     # chosen before storing (:125)
             agent.memory.store((state, action, r.clone(), done.clone(), term.clone(), log_prob, value, next_value))
             action, log_prob, value = next_action, next_log_prob, next_value
         else:
-            agent.memory.store((state, action, r.clone(), next_state, done.clone()))
+            agent.memory.store((state, action, r.clone(), next_state, done.clone()))     # :133
+            action = agent.choose_action(next_state)                                     # :134, before the update
         state = next_state
-        obs, nxt = nxt, obs
         step += 1
-        if agent.memory.size() >= cfg.batch_size:                                      # :142-144
+        if agent.memory.size() >= cfg.batch_size:                                        # :138-140
             metrics = agent.update()
+        # envs whose episode ended start a new one (:97-112 of the next loop turn): normalise the reset observation
+        # (a second statistics update, as in the reference) and choose its first action.  One small host read per
+        # vector step; this runner is the legacy contract, not the throughput path.
         tracker.advance(returns)
-        if hasattr(agent, "save_model") and tracker.episodes // cfg.save_freq > saved:  # :160-161, every save_freq episodes
-            saved = tracker.episodes // cfg.save_freq
-            agent.save_model()
+        if bool(done.any()):
+            idx = done.nonzero().view(-1)
+            episodes += idx.numel()
+            if hasattr(agent, "save_model") and episodes // cfg.save_freq > saved:       # :160-161, every save_freq episodes
+                saved = episodes // cfg.save_freq
+                agent.save_model()
+            if episodes >= cfg.train_eps:
+                break
+            fresh = norm(nxt.index_select(0, idx))
+            state = state.clone()
+            state[idx] = fresh
+            if on_policy:
+                a2, l2, v2 = agent.choose_action(fresh)
+                action, log_prob, value = action.clone(), log_prob.clone(), value.clone()
+                action[idx], log_prob[idx], value[idx] = a2, l2, v2
+            else:
+                action = action.clone()
+                action[idx] = agent.choose_action(fresh)
     tracker.flush(returns)
     if hasattr(agent, "save_model"):                                                   # :164
         agent.save_model()

@@ -1290,8 +1290,109 @@ def gen_ppo_lstm_trace():
     save("ppo_lstm_trace", **out)
 
 
+def gen_runner_trace():
+    """Row H1/U1: the reference utils/runner.py `train()` run unmodified on the scripted env with toy
+    agents written to the legacy duck-type (outputs are a function of the call index only, so that they are exact
+    on both sides): the on-policy branch (choose-next-action-before-store, V(next) of the terminal observation,
+    :119-131) and the off-policy branch (store, choose, then update, :132-140).  Records every stored transition
+    (normalised states, scaled rewards), the order of choose_action / update / save_model calls, and the final
+    running statistics."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from scripted_env import ScriptedEnv
+    _install_stub_gym()
+    g = sys.modules["gymnasium"]
+
+    class _Box:
+        pass
+    g.spaces = types.SimpleNamespace(Box=_Box)
+    g.ObservationWrapper = object
+    wrappers = types.ModuleType("gymnasium.wrappers")
+    wrappers.AtariPreprocessing = object
+    sys.modules["gymnasium.wrappers"] = wrappers
+    tb = types.ModuleType("torch.utils.tensorboard")
+
+    class SummaryWriter:
+        def __init__(self, *a, **k):
+            pass
+
+        def add_scalar(self, *a, **k):
+            pass
+
+        def close(self):
+            pass
+    tb.SummaryWriter = SummaryWriter
+    sys.modules["torch.utils.tensorboard"] = tb
+    lg = types.ModuleType("loguru")
+
+    class _Logger:
+        def __getattr__(self, name):
+            if name == "catch":
+                return lambda *a, **k: (lambda f: f)
+            return lambda *a, **k: None
+    lg.logger = _Logger()
+    sys.modules["loguru"] = lg
+    sys.path.insert(0, REF)
+    for m in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
+        del sys.modules[m]
+    import utils.runner as rr                                   # the reference's runner, unmodified
+    out = {}
+    for kind in ("on", "off"):
+        env = ScriptedEnv(8, 4)
+        cfg = rr.BasicConfig()
+        cfg.env_name, cfg.algo_name, cfg.train_eps, cfg.eval_freq, cfg.save_freq = "Scripted", "toy", 7, 10 ** 9, 3
+        cfg.max_steps, cfg.batch_size, cfg.gamma, cfg.lamda, cfg.device = 500, 20, 0.99, 0.95, "cpu"
+        cfg.memory_capacity = 10 ** 6
+        calls, stored = [], []
+
+        class Toy:
+            def __init__(self):
+                self.cfg, self.k, self.learn_step = cfg, 0, 0
+                self.net = object()
+                self.memory = rr.ReplayBuffer_on_policy(cfg) if kind == "on" else rr.ReplayBuffer_off_policy(cfg)
+
+            def choose_action(self, state):
+                self.k += 1
+                calls.append(1)
+                a = (self.k * 5 + 1) % 4
+                return (a, -0.125 * self.k, 0.25 * self.k) if kind == "on" else a
+
+            def update(self):
+                calls.append(2)
+                if kind == "on":
+                    self.memory.clear()
+                self.learn_step += 1
+                return {}
+
+            def save_model(self):
+                calls.append(3)
+        agent = Toy()
+        store = agent.memory.store
+
+        def rec(tr):
+            stored.append(tr)
+            store(tr)
+        agent.memory.store = rec
+        np.random.seed(5)
+        rr.train(env, agent, cfg)
+        if kind == "on":
+            out["on_state"] = np.array([t[0] for t in stored], np.float64)
+            for j, name in ((1, "action"), (2, "reward"), (3, "done"), (4, "dw"), (5, "log_prob"), (6, "value"), (7, "next_value")):
+                out["on_" + name] = np.array([t[j] for t in stored], np.float64)
+        else:
+            out["off_state"] = np.array([t[0] for t in stored], np.float64)
+            out["off_next_state"] = np.array([t[3] for t in stored], np.float64)
+            for j, name in ((1, "action"), (2, "reward"), (4, "done")):
+                out["off_" + name] = np.array([t[j] for t in stored], np.float64)
+        out[kind + "_calls"] = np.array(calls, np.int8)
+        ms, rs = agent.state_norm.running_ms, agent.reward_scaler.running_ms
+        out[kind + "_norm"] = np.concatenate([[ms.n], np.asarray(ms.mean, np.float64), np.asarray(ms.std, np.float64)])
+        out[kind + "_rscale"] = np.array([rs.n, float(np.asarray(rs.mean).reshape(-1)[0]), float(np.asarray(rs.std).reshape(-1)[0])])
+        out[kind + "_learn_step"] = np.int64(agent.learn_step)
+    save("runner_trace", **out)
+
+
 if __name__ == "__main__":
     names = sys.argv[1:]
-    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2, gen_dqn_trace, gen_sac_trace, gen_rainbow_trace, gen_td3_ddpg, gen_dsac, gen_ppo_lstm_parts, gen_ppo_lstm_trace]:
+    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2, gen_dqn_trace, gen_sac_trace, gen_rainbow_trace, gen_td3_ddpg, gen_dsac, gen_ppo_lstm_parts, gen_ppo_lstm_trace, gen_runner_trace]:
         if not names or g.__name__ in names:
             g()

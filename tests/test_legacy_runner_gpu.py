@@ -71,7 +71,8 @@ def test_on_policy_runner_with_legacy_style_agent(tmp_path, monkeypatch):
     agent = PPO(cfg)
     returns, metrics = train(env, agent, cfg, max_vector_steps=64 * 12)
     assert agent.learn_step >= 10 and np.isfinite(metrics["total_loss"])
-    assert hasattr(agent, "state_norm") and agent.state_norm.running_ms.n == 64 * 12 * 128 + 128
+    # every vector step normalises N observations; every finished episode one more (its reset observation, :107)
+    assert hasattr(agent, "state_norm") and agent.state_norm.running_ms.n == 64 * 12 * 128 + 128 + len(returns)
     assert np.mean(returns[-50:]) > np.mean(returns[:50])          # reward-scaled PPO improves on CartPole
     assert evaluate(cfg.env_name, agent, cfg, episodes=8) > 60
     # runner.train() saved through ModelLoader (every save_freq episodes and at the end, utils/runner.py:160-164)
@@ -104,3 +105,73 @@ def test_off_policy_buffer_contract():
     assert s.shape == (64, 3) and a.dtype == torch.float32 and a.shape == (64, 1)
     assert torch.equal(s2, s + 1) and torch.equal(r, -s[:, 0]) and torch.allclose(a[:, 0], 0.5 * s[:, 0])
     assert s.min().item() >= 10.0            # rows 0..9 were overwritten by the ring
+
+
+@pytest.mark.parametrize("kind", ["on", "off"])
+def test_runner_trace_matches_reference(kind):
+    """Row H1/U1: the reference utils/runner.py train() on the scripted env (tests/golden/runner_trace.npz) replayed
+    by gymrl_amd.utils.runner.train() with num_envs = 1: the order of choose_action / update / save_model calls, every
+    stored transition (normalised states incl. the TERMINAL observation as next state, scaled rewards, done /
+    terminated flags, log-prob, V and V(next)) and the final running statistics."""
+    from conftest import load_golden, rel_close
+    from scripted_env import ScriptedVecEnv
+    from gymrl_amd.utils.buffer import ReplayBuffer_off_policy, ReplayBuffer_on_policy
+    from gymrl_amd.utils.runner import BasicConfig, train
+    g = load_golden("runner_trace")
+    dev = torch.device("cuda:0")
+    cfg = BasicConfig()
+    cfg.env_name, cfg.algo_name, cfg.train_eps, cfg.save_freq, cfg.num_envs = "Scripted", "toy", 7, 3, 1
+    cfg.max_steps, cfg.batch_size, cfg.gamma, cfg.lamda, cfg.device = 500, 20, 0.99, 0.95, "cuda:0"
+    cfg.memory_capacity, cfg.n_states, cfg.n_actions, cfg.seed = 10 ** 6, 8, 4, 0
+    calls, stored = [], []
+
+    class Toy:
+        def __init__(self):
+            self.cfg, self.k, self.learn_step = cfg, 0, 0
+            self.memory = ReplayBuffer_on_policy(cfg) if kind == "on" else ReplayBuffer_off_policy(cfg)
+
+        def choose_action(self, state):
+            assert state.shape == (1, 8)
+            self.k += 1
+            calls.append(1)
+            a = torch.tensor([(self.k * 5 + 1) % 4], dtype=torch.int32, device=dev)
+            if kind == "off":
+                return a
+            return a, torch.tensor([-0.125 * self.k], device=dev), torch.tensor([0.25 * self.k], device=dev)
+
+        def update(self):
+            calls.append(2)
+            if kind == "on":
+                self.memory.clear()
+            self.learn_step += 1
+            return {}
+
+        def save_model(self):
+            calls.append(3)
+    agent = Toy()
+    store = agent.memory.store
+
+    def rec(tr):
+        stored.append(tuple(x.clone() for x in tr))
+        store(tr)
+    agent.memory.store = rec
+    train(ScriptedVecEnv(1, dev), agent, cfg)
+    assert calls == g[kind + "_calls"].tolist()
+    assert agent.learn_step == int(g[kind + "_learn_step"])
+    col = lambda j: np.stack([t[j].cpu().numpy().reshape(-1) for t in stored]).astype(np.float64)     # noqa: E731
+    assert len(stored) == len(g[kind + "_action"])
+    assert rel_close(col(0), g[kind + "_state"], 1e-5) <= 1e-5
+    assert np.array_equal(col(1).ravel(), g[kind + "_action"])
+    assert rel_close(col(2).ravel(), g[kind + "_reward"], 1e-5) <= 1e-5
+    if kind == "on":
+        assert np.array_equal(col(3).ravel(), g["on_done"]) and np.array_equal(col(4).ravel(), g["on_dw"])
+        for j, name in ((5, "log_prob"), (6, "value"), (7, "next_value")):
+            assert np.array_equal(col(j).ravel(), g["on_" + name]), name
+    else:
+        assert rel_close(col(3), g["off_next_state"], 1e-5) <= 1e-5 and np.array_equal(col(4).ravel(), g["off_done"])
+    ms = agent.state_norm.running_ms
+    assert ms.n == int(g[kind + "_norm"][0])
+    assert rel_close(ms.mean.cpu().numpy(), g[kind + "_norm"][1:9], 1e-6) <= 1e-6
+    assert rel_close(ms.std.cpu().numpy(), g[kind + "_norm"][9:17], 1e-6) <= 1e-6
+    rs = agent.reward_scaler.running_ms
+    assert rs.n == int(g[kind + "_rscale"][0]) and rel_close(rs.std.cpu().numpy(), g[kind + "_rscale"][2:3], 1e-6) <= 1e-6
