@@ -22,7 +22,8 @@ import torch.nn as nn
 from . import dist as gdist
 from . import ops
 from .envs import VecEnv
-from .flat import FusedAdam, flatten_module
+from .flat import FusedAdam, GradSink, flatten_module
+from .nn import SmallLinear
 
 
 class Config:
@@ -56,6 +57,7 @@ class Config:
         self.anneal = True
         self.device = "cuda"
         self.num_envs = 1
+        self.use_graphs = True             # replay the minibatch update as a captured hipGraph (1 GPU, equal minibatches)
 
 
 def _ortho(layer, std):
@@ -114,9 +116,9 @@ class ManifoldHyperConnectionFuse(nn.Module):
 class MHCBlock(nn.Module):
     def __init__(self, dim, rate, max_sk_it):
         super().__init__()
-        self.linear1 = nn.Linear(dim, dim)
+        self.linear1 = SmallLinear(dim, dim)
         self.mhc1 = ManifoldHyperConnectionFuse(dim, rate, max_sk_it)
-        self.linear2 = nn.Linear(dim, dim)
+        self.linear2 = SmallLinear(dim, dim)
         self.mhc2 = ManifoldHyperConnectionFuse(dim, rate, max_sk_it)
         self.act = nn.SiLU()
 
@@ -136,7 +138,7 @@ class MHCBackbone(nn.Module):
     def __init__(self, input_dim, output_dim, rate, num_layers, max_sk_it):
         super().__init__()
         self.rate = rate
-        self.input_proj = nn.Linear(input_dim, output_dim)
+        self.input_proj = SmallLinear(input_dim, output_dim)
         self.layers = nn.ModuleList([MHCBlock(output_dim, rate, max_sk_it) for _ in range(num_layers)])
         self.final_norm = RMSNorm(output_dim)
 
@@ -155,7 +157,7 @@ class MLP(nn.Module):
         layers = []
         for i in range(len(dims) - 1):
             last = i == len(dims) - 2
-            layers.append(_ortho(nn.Linear(dims[i], dims[i + 1]), last_std if (last and last_std) else np.sqrt(2)))
+            layers.append(_ortho(SmallLinear(dims[i], dims[i + 1]), last_std if (last and last_std) else np.sqrt(2)))
             if not last:
                 layers += [nn.SiLU(), RMSNorm(dims[i + 1])]
         self.mlp = nn.Sequential(*layers)
@@ -236,6 +238,9 @@ class PPOTrainer:
         self.buffer = RolloutBuffer(int(config.update_freq), N, state_dim, self.device)
         self._perm_gen = torch.Generator(device=self.device)
         self._perm_gen.manual_seed(self.base_seed * 7919 + 17 + self.rank)
+        self._sink = GradSink(self.model)
+        self._g_idx, self._g_warm = None, 0          # hipGraph replay of the minibatch body (update_model)
+        self._fwd_graph, self._fwd_in, self._fwd_out, self._fwd_warm = None, None, None, 0
 
     @torch.no_grad()
     def collect_experience(self):
@@ -244,8 +249,12 @@ class PPOTrainer:
         seed = (self.base_seed if cfg.seed is not None else self.base_seed + 0x9E3779B1 * (self.rollout_count + 1))
         env.reset(b.states[0], seed=seed & 0x7FFFFFFFFFFFFFFF)
         c0 = self.rollout_count * b.T
+        graphed = bool(getattr(cfg, "use_graphs", True))
         for t in range(b.T):
-            logits, value = self.model(b.states[t])
+            if graphed:                                   # the ~100-launch mHC forward as one graph launch
+                logits, value = self._forward_graphed(b.states[t])
+            else:
+                logits, value = self.model(b.states[t])
             ops.categorical_sample(logits, value=value.view(-1), seed=env.seed, counter=c0 + t, env_id0=env.env_id0,
                                    act_out=b.actions[t], logp_out=b.log_probs[t], ent_out=b.old_entropies[t],
                                    value_out=b.values[t])
@@ -253,6 +262,23 @@ class PPOTrainer:
         self.step_count += b.T * b.N
         self.rollout_count += 1
         b.next_value.copy_(self.model.get_value(b.states[b.T]))
+
+    @torch.no_grad()
+    def _forward_graphed(self, x):
+        """model(x) for the rollout through a captured hipGraph: fixed input / output buffers; the parameters are
+        views of the flat buffer the optimiser updates in place, so one capture serves the whole run."""
+        if self._fwd_in is None:
+            self._fwd_in = torch.empty_like(x)
+        self._fwd_in.copy_(x)
+        if self._fwd_graph is None:
+            if self._fwd_warm < 2:
+                self._fwd_warm += 1
+                return self.model(self._fwd_in)
+            self._fwd_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._fwd_graph):
+                self._fwd_out = self.model(self._fwd_in)
+        self._fwd_graph.replay()
+        return self._fwd_out
 
     def compute_advantages(self):
         """:507-535 -> (adv_actor [T,N] un-normalised, returns [T,N])."""
@@ -270,23 +296,58 @@ class PPOTrainer:
         adv, ret = advantages.reshape(-1), returns.reshape(-1)
         metrics = torch.zeros(cfg.num_epochs * n_mb, 9, dtype=torch.float64, device=self.device)
         sizes, row = [], 0
+        lcfg = (cfg.clip_eps_min, cfg.clip_eps_max, cfg.dual_clip, cfg.erc_beta_low, cfg.erc_beta_high, self.ent_coef)
+
+        def minibatch(idx, metrics_row, bias=None):
+            logits, values = self.model(states.index_select(0, idx))
+            values = values.view(-1)
+            dlogits, dvalues = ops.ppo_full_loss_fwd_bwd(logits, values, act, lp, ent_old, adv, ret, lcfg, idx=idx,
+                                                         metrics_sum=metrics_row)
+            self._sink.arm()
+            torch.autograd.backward([logits, values], [dlogits, dvalues])
+            self._sink.collect()
+            if self.world_size > 1:
+                gdist.all_reduce_sum(self.flat_grads)
+            self.optimizer.step(grad_scale=1.0 / self.world_size, bias_dev=bias)
+
+        # One minibatch of the mHC network is ~400 launches of a few microseconds (8 ms at 1024 rows): with equal
+        # minibatches and no collective inside, the minibatch body is captured once per update_model() call
+        # (rollout tensors and the annealed entropy coefficient are constants of that call) and replayed
+        # (gymrl_amd/graphs.py).  The first two minibatches ever run eagerly (library warm-up).
+        graphed = (bool(getattr(cfg, "use_graphs", True)) and self.world_size == 1 and total % mb == 0
+                   and cfg.num_epochs * n_mb > 2)
+        graph = None
+        if graphed and self._g_idx is None:
+            from .graphs import StepScalars
+            self._scalars = StepScalars(self.device)
+            self._g_bias, self._g_off = self._scalars.slot(16, torch.float32)
+            self._g_idx = torch.empty(mb, dtype=torch.int32, device=self.device)
+            self._g_row = torch.zeros(9, dtype=torch.float64, device=self.device)
         for _ in range(cfg.num_epochs):
             perm = torch.randperm(total, device=self.device, generator=self._perm_gen).to(torch.int32)   # shuffle=True
             for start in range(0, total, mb):
                 idx = perm[start:start + mb]
                 B = idx.numel()
-                logits, values = self.model(states.index_select(0, idx))
-                values = values.view(-1)
-                lcfg = (cfg.clip_eps_min, cfg.clip_eps_max, cfg.dual_clip, cfg.erc_beta_low, cfg.erc_beta_high,
-                        self.ent_coef)
-                dlogits, dvalues = ops.ppo_full_loss_fwd_bwd(logits, values, act, lp, ent_old, adv, ret, lcfg, idx=idx,
-                                                             metrics_sum=metrics[row])
-                torch.autograd.backward([logits, values], [dlogits, dvalues])
-                if self.world_size > 1:
-                    gdist.all_reduce_sum(self.flat_grads)
-                self.optimizer.step(grad_scale=1.0 / self.world_size)
+                if not graphed:
+                    minibatch(idx, metrics[row])
+                else:
+                    self._g_idx.copy_(idx)
+                    self._g_row.zero_()
+                    self._scalars.set(self._g_off, self.optimizer.next_bias())
+                    self._scalars.flush()
+                    if self._g_warm < 2:
+                        self._g_warm += 1
+                        minibatch(self._g_idx, self._g_row, self._g_bias)
+                    else:
+                        if graph is None:
+                            graph = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(graph):
+                                minibatch(self._g_idx, self._g_row, self._g_bias)
+                        graph.replay()
+                    metrics[row].copy_(self._g_row)
                 sizes.append(B)
                 row += 1
+        del graph
         if cfg.anneal:                                                     # :660-666 (after the update)
             frac = 1 - self.step_count * self.world_size / cfg.max_train_steps
             self.lr = cfg.lr * frac
@@ -305,6 +366,16 @@ class PPOTrainer:
                 "cov": float(cov.mean())}
 
     def train(self):
+        """:681-700; minibatches of a few thousand rows run their GEMMs on the library that answers them fastest
+        (gymrl_amd/blas.py)."""
+        from .blas import small_gemm_backend
+        cfg, b = self.cfg, self.buffer
+        total = b.T * b.N
+        mb = max(1, total // int(cfg.num_minibatches)) if cfg.num_minibatches else min(int(cfg.batch_size), total)
+        with small_gemm_backend("rocblas" if mb <= 4096 else "default"):
+            return self._train()
+
+    def _train(self):
         update_count = 0
         while self.step_count * self.world_size < self.cfg.max_train_steps:
             self.collect_experience()

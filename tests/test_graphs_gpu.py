@@ -84,3 +84,27 @@ def test_rainbow_graphed_update_equals_eager():
     assert torch.equal(eager.flat_params, graph.flat_params) and torch.equal(eager.target_flat, graph.target_flat)
     assert torch.equal(eager.memory.sum_tree.tree, graph.memory.sum_tree.tree)
     assert eager.optimizer.param_groups[0]["lr"] == graph.optimizer.param_groups[0]["lr"]
+
+
+def test_ppo_full_graphed_minibatch_equals_eager():
+    """PPO-full: the minibatch body (mHC forward, L3 loss, backward, clip + Adam) captured per update_model() call and
+    replayed == the eager loop, over three iterations (entropy coefficient and lr annealed between the captures)."""
+    from gymrl_amd.ppo_full_lunarlander import Config, PPOTrainer
+
+    def run(graphs):
+        cfg = Config()
+        cfg.num_envs, cfg.update_freq, cfg.num_epochs, cfg.batch_size, cfg.seed, cfg.mhc_dim = 64, 32, 2, 256, 1, 32
+        cfg.use_graphs = graphs
+        torch.manual_seed(5)
+        tr = PPOTrainer(cfg)
+        ms = []
+        for _ in range(3):
+            tr.collect_experience()
+            adv, ret = tr.compute_advantages()
+            ms.append(tr.update_model(adv, ret))
+        return tr, ms
+    (a, ma), (b, mb) = run(False), run(True)
+    assert b._g_idx is not None and b.optimizer.step_count == a.optimizer.step_count == 3 * 2 * 8
+    assert torch.equal(a.flat_params, b.flat_params) and torch.equal(a.optimizer.v, b.optimizer.v)
+    for x, y in zip(ma, mb):
+        assert x == y
