@@ -26,7 +26,7 @@ import torch.nn.functional as F
 from . import dist as gdist
 from . import ops
 from .envs import VecEnv
-from .flat import FusedAdam, flatten_module
+from .flat import FusedAdam, GradSink, flatten_module
 from .ppo_full_lunarlander import MHCBackbone, RMSNorm, _ortho
 
 
@@ -62,6 +62,7 @@ class Config:
         self.device = "cuda"
         # --- vectorised-engine additions ---
         self.num_envs = 1
+        self.use_graphs = True             # replay the rollout forward and the minibatch body as captured hipGraphs (1 GPU)
         self.rnn_hidden = 512              # the reference hard-codes these three (:84-95)
         self.head_hidden = 512
         self.rnd_embed = 512
@@ -263,6 +264,9 @@ class PPOTrainer:
         self.buffer = RolloutBuffer(T, N, state_dim, self.hidden_size, self.device)
         self._perm_gen = torch.Generator(device=self.device)
         self._perm_gen.manual_seed(self.base_seed * 7919 + 23 + self.rank)
+        self._sink = GradSink(self.model)
+        self._g_seq, self._g_warm = None, 0            # hipGraph replay of the minibatch body (update_model)
+        self._fwd_graph, self._fwd_in, self._fwd_out, self._fwd_warm = None, None, None, 0
         self._parity_noise = None      # tests: f32[T, N, A] Exp(1) draws of one rollout (list of them, popped per rollout)
         self._parity_perms = None      # tests: iterator of i32[num_sequences] permutations, one per epoch
         self.grad_norms = None         # tests: set to [] to record the pre-clip gradient norm of every minibatch
@@ -276,9 +280,13 @@ class PPOTrainer:
         noise = self._parity_noise.pop(0) if self._parity_noise else None
         hidden = torch.zeros(b.N, self.hidden_size, device=self.device)
         c0 = self.rollout_count * b.T
+        graphed = bool(getattr(cfg, "use_graphs", True)) and self._parity_noise is None
         for t in range(b.T):
             b.hidden_states[t].copy_(hidden)
-            logits, value, hidden, predict, target = self.model(b.states[t], hidden)
+            if graphed:                                   # the ~150-launch forward as one graph launch
+                logits, value, hidden, predict, target = self._forward_graphed(b.states[t], hidden)
+            else:
+                logits, value, hidden, predict, target = self.model(b.states[t], hidden)
             ops.categorical_sample(logits, value=value.reshape(-1), noise_exp=None if noise is None else noise[t],
                                    seed=env.seed, counter=c0 + t, env_id0=env.env_id0, act_out=b.actions[t],
                                    logp_out=b.log_probs[t], ent_out=b.old_entropies[t], value_out=b.values[t])
@@ -289,6 +297,24 @@ class PPOTrainer:
         self.rollout_count += 1
         b.next_value.copy_(self.model.get_value(b.states[b.T], hidden))
         self._last_hidden = hidden
+
+    @torch.no_grad()
+    def _forward_graphed(self, x, hidden):
+        """model(x, hidden) for the rollout through a captured hipGraph (fixed input / output buffers; the parameters
+        are views of the flat buffer the optimiser updates in place, so one capture serves the whole run)."""
+        if self._fwd_in is None:
+            self._fwd_in = (torch.empty_like(x), torch.empty_like(hidden))
+        self._fwd_in[0].copy_(x)
+        self._fwd_in[1].copy_(hidden)
+        if self._fwd_graph is None:
+            if self._fwd_warm < 2:
+                self._fwd_warm += 1
+                return self.model(*self._fwd_in)
+            self._fwd_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._fwd_graph):
+                self._fwd_out = self.model(*self._fwd_in)
+        self._fwd_graph.replay()
+        return self._fwd_out
 
     def compute_advantages(self):
         """:619-644 -> (adv_actor [T,N] un-normalised, returns [T,N])."""
@@ -306,8 +332,38 @@ class PPOTrainer:
         steps = torch.arange(L, device=self.device, dtype=torch.int64)
         n_mb = S // mb
         metrics = torch.zeros(cfg.num_epochs * n_mb, 10, dtype=torch.float64, device=self.device)
-        rnd_losses, row = [], 0
+        row = 0
         lcfg = (cfg.clip_eps_min, cfg.clip_eps_max, cfg.dual_clip, cfg.erc_beta_low, cfg.erc_beta_high, self.ent_coef)
+        def minibatch(seq, metrics_row, rnd_out, bias=None):
+            first = (seq // N) * (L * N) + seq % N                         # flat row of each window's first step
+            rows = first.unsqueeze(1) + steps * N                          # [mb, L]
+            idx = rows.reshape(-1).to(torch.int32)
+            s_batch = states.index_select(0, rows.reshape(-1)).view(mb, L, -1)
+            logits, values, _, predict, target = self.model(s_batch, hidden_flat.index_select(0, first))
+            logits_flat, values_flat = logits.reshape(mb * L, -1), values.reshape(-1)
+            dlogits, dvalues = ops.ppo_rnn_loss_fwd_bwd(logits_flat.detach(), values_flat.detach(), act, lp, ent_old,
+                                                        val_old, adv, ret, lcfg, idx=idx, metrics_sum=metrics_row)
+            rnd_loss = (predict - target).pow(2).mean()                    # :775
+            self._sink.arm()
+            torch.autograd.backward([logits_flat, values_flat, rnd_loss], [dlogits, dvalues, None])
+            self._sink.collect()
+            if self.world_size > 1:
+                gdist.all_reduce_sum(self.flat_grads)
+            self.optimizer.step(grad_scale=1.0 / self.world_size, bias_dev=bias)
+            rnd_out.copy_(rnd_loss.detach())
+
+        # Same scheme as PPO-full: the minibatch body is captured once per update_model() call and replayed.
+        graphed = (bool(getattr(cfg, "use_graphs", True)) and self.world_size == 1 and self.grad_norms is None
+                   and cfg.num_epochs * n_mb > 2)
+        graph = None
+        if graphed and self._g_seq is None:
+            from .graphs import StepScalars
+            self._scalars = StepScalars(self.device)
+            self._g_bias, self._g_off = self._scalars.slot(16, torch.float32)
+            self._g_seq = torch.empty(mb, dtype=torch.int64, device=self.device)
+            self._g_row = torch.zeros(10, dtype=torch.float64, device=self.device)
+            self._g_rnd = torch.zeros((), device=self.device)
+        rnd_all = torch.zeros(cfg.num_epochs * n_mb, device=self.device)
         for _ in range(cfg.num_epochs):
             if self._parity_perms is not None:
                 perm = next(self._parity_perms).to(self.device, torch.int64)
@@ -315,23 +371,28 @@ class PPOTrainer:
                 perm = torch.randperm(S, device=self.device, generator=self._perm_gen)
             for start in range(0, S, mb):
                 seq = perm[start:start + mb]
-                first = (seq // N) * (L * N) + seq % N                     # flat row of each window's first step
-                rows = first.unsqueeze(1) + steps * N                      # [mb, L]
-                idx = rows.reshape(-1).to(torch.int32)
-                s_batch = states.index_select(0, rows.reshape(-1)).view(mb, L, -1)
-                logits, values, _, predict, target = self.model(s_batch, hidden_flat.index_select(0, first))
-                logits_flat, values_flat = logits.reshape(mb * L, -1), values.reshape(-1)
-                dlogits, dvalues = ops.ppo_rnn_loss_fwd_bwd(logits_flat.detach(), values_flat.detach(), act, lp, ent_old,
-                                                            val_old, adv, ret, lcfg, idx=idx, metrics_sum=metrics[row])
-                rnd_loss = (predict - target).pow(2).mean()                # :775
-                torch.autograd.backward([logits_flat, values_flat, rnd_loss], [dlogits, dvalues, None])
-                if self.world_size > 1:
-                    gdist.all_reduce_sum(self.flat_grads)
-                self.optimizer.step(grad_scale=1.0 / self.world_size)
-                if self.grad_norms is not None:
-                    self.grad_norms.append(float(self.optimizer._sq.sqrt().item()))
-                rnd_losses.append(rnd_loss.detach())
+                if not graphed:
+                    minibatch(seq, metrics[row], rnd_all[row])
+                    if self.grad_norms is not None:
+                        self.grad_norms.append(float(self.optimizer._sq.sqrt().item()))
+                else:
+                    self._g_seq.copy_(seq)
+                    self._g_row.zero_()
+                    self._scalars.set(self._g_off, self.optimizer.next_bias())
+                    self._scalars.flush()
+                    if self._g_warm < 2:
+                        self._g_warm += 1
+                        minibatch(self._g_seq, self._g_row, self._g_rnd, self._g_bias)
+                    else:
+                        if graph is None:
+                            graph = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(graph):
+                                minibatch(self._g_seq, self._g_row, self._g_rnd, self._g_bias)
+                        graph.replay()
+                    metrics[row].copy_(self._g_row)
+                    rnd_all[row].copy_(self._g_rnd)
                 row += 1
+        del graph
         if cfg.anneal:                                                     # :794-800 (after the update)
             frac = 1 - self.step_count * self.world_size / cfg.max_train_steps
             self.lr = cfg.lr * frac
@@ -350,7 +411,7 @@ class PPOTrainer:
         return {"policy_loss": float((m[:, 0] / cnt * live).mean()), "value_loss": float((m[:, 1] / cnt * live).mean()),
                 "entropy": float((m[:, 2] / cnt * live).mean()), "clip_frac": float((m[:, 3] / cnt * live).mean()),
                 "approx_kl": float((m[:, 4] / Bs).mean()), "erc_clip_frac": float((m[:, 5] / Bs).mean()),
-                "cov": float(cov.mean()), "rnd_loss": float(torch.stack(rnd_losses).mean().item())}
+                "cov": float(cov.mean()), "rnd_loss": float(rnd_all.mean().item())}
 
     def train(self):
         update_count = 0

@@ -108,3 +108,29 @@ def test_ppo_full_graphed_minibatch_equals_eager():
     assert torch.equal(a.flat_params, b.flat_params) and torch.equal(a.optimizer.v, b.optimizer.v)
     for x, y in zip(ma, mb):
         assert x == y
+
+
+def test_ppo_lstm_graphed_equals_eager():
+    """Recurrent PPO: rollout forward (GRU state in / out) and the sequence-minibatch body (GRU unrolled over the
+    window, masked loss with its count pass, RND loss, backward, clip + Adam) replayed as hipGraphs == eager."""
+    from gymrl_amd.ppo_lstm_lunarlander import Config, PPOTrainer
+
+    def run(graphs):
+        cfg = Config()
+        cfg.num_envs, cfg.update_freq, cfg.seq_len, cfg.batch_size, cfg.num_epochs, cfg.seed = 32, 64, 8, 64, 2, 2
+        cfg.mhc_dim, cfg.rnn_hidden, cfg.head_hidden, cfg.rnd_embed, cfg.use_graphs = 32, 64, 64, 64, graphs
+        torch.manual_seed(6)
+        tr = PPOTrainer(cfg)
+        ms = []
+        for _ in range(3):
+            tr.collect_experience()
+            adv, ret = tr.compute_advantages()
+            ms.append(tr.update_model(adv, ret))
+        return tr, ms
+    (a, ma), (b, mb) = run(False), run(True)
+    assert b._g_seq is not None and b._fwd_graph is not None
+    assert b.optimizer.step_count == a.optimizer.step_count == 3 * 2 * 4
+    assert torch.equal(a.buffer.hidden_states, b.buffer.hidden_states) and torch.equal(a.buffer.rewards, b.buffer.rewards)
+    assert torch.equal(a.flat_params, b.flat_params) and torch.equal(a.optimizer.v, b.optimizer.v)
+    for x, y in zip(ma, mb):
+        assert x == y
