@@ -60,7 +60,17 @@ class DDPGTrainer(_ActorCriticBase):
             return 0.0, 0.0
         if indices is None and self._parity_updates is not None:
             indices = next(self._parity_updates)
-        states, actions, rewards, next_states, dones = self.memory.sample(cfg.batch_size, indices)
+        if indices is None:
+            indices = self.memory.draw_indices(cfg.batch_size)
+        B = self._update_body(indices)
+        return -float(self._sum_a.item()) / B, float(self._sum_c.item()) / B
+
+    def _update_body(self, indices, biases=None, alpha_bias=None):
+        """Everything after the index draw; biases = device views of the (critic, actor) Adams' step scalars when the
+        body runs inside / ahead of a hipGraph."""
+        cfg = self.cfg
+        bc, ba = biases if biases is not None else (None, None)
+        states, actions, rewards, next_states, dones = self.memory.gather(indices)
         B = states.shape[0]
         with torch.no_grad():                                          # :171-174
             tq = self.critic_target(next_states, self.actor_target(next_states)).view(-1)
@@ -70,12 +80,23 @@ class DDPGTrainer(_ActorCriticBase):
         dq = ops.mse_loss(q.view(-1), y, self._sum_c)
         self.critic_grads.zero_()
         torch.autograd.backward([q], [dq.view_as(q)])
-        self.critic_optimizer.step()
+        self.critic_optimizer.step(bias_dev=bc)
         qa = self.critic(states, self.actor(states))                   # :183-187
         self._sum_a.zero_()
         dqa = ops.neg_mean_loss(qa.view(-1), self._sum_a)
         torch.autograd.backward([qa], [dqa.view_as(qa)])
-        self.actor_optimizer.step()
+        self.actor_optimizer.step(bias_dev=ba)
         self.soft_update(self.actor_target_flat, self.actor_flat)      # :189-190
         self.soft_update(self.critic_target_flat, self.critic_flat)
-        return -float(self._sum_a.item()) / B, float(self._sum_c.item()) / B
+        return B
+
+    def update_async(self):
+        """update() without the host round trip, replayed as a captured hipGraph (gymrl_amd/graphs.py)."""
+        cfg = self.cfg
+        if len(self.memory) < cfg.batch_size:
+            return
+        if self._graph is None:
+            from .graphs import GraphedUpdate
+            self._graph = GraphedUpdate(self.device, cfg.batch_size, [self.critic_optimizer, self.actor_optimizer],
+                                        lambda idx, biases, ab: self._update_body(idx, biases, ab))
+        self._graph(self.memory, cfg.batch_size)

@@ -70,3 +70,33 @@ class GraphedStep:
             with torch.cuda.graph(self.graph):
                 self.fn()
         self.graph.replay()
+
+
+class GraphedUpdate:
+    """The pattern the off-policy trainers share: draw the minibatch indices into a fixed buffer (eager, counter-keyed),
+    stage every optimiser's bias block (one launch), replay `body(idx, adam_biases, alpha_bias)`.
+
+    optimizers: FusedAdam list (their step counts advance here); alpha = (owner, attr, beta1, beta2) advances the
+    integer attribute `attr` of `owner` and stages {1 - beta1^t, 1 - beta2^t} as float64 for a temperature step."""
+
+    def __init__(self, device, batch_size, optimizers, body, alpha=None):
+        self.sc = StepScalars(device)
+        self.optimizers = list(optimizers)
+        slots = [self.sc.slot(16, torch.float32) for _ in self.optimizers]
+        self.biases, self.offs = [v for v, _ in slots], [o for _, o in slots]
+        self.alpha = alpha
+        self.alpha_bias, self.alpha_off = self.sc.slot(16, torch.float64) if alpha else (None, None)
+        self.idx = torch.empty(batch_size, dtype=torch.int32, device=device)
+        self.step_fn = GraphedStep(lambda: body(self.idx, self.biases, self.alpha_bias))
+
+    def __call__(self, memory, batch_size):
+        memory.draw_indices(batch_size, out=self.idx)
+        for opt, off in zip(self.optimizers, self.offs):
+            self.sc.set(off, opt.next_bias())
+        if self.alpha:
+            owner, attr, b1, b2 = self.alpha
+            t = getattr(owner, attr) + 1
+            setattr(owner, attr, t)
+            self.sc.set_doubles(self.alpha_off, 1.0 - b1 ** t, 1.0 - b2 ** t)
+        self.sc.flush()
+        self.step_fn()

@@ -41,6 +41,7 @@ class Config:
         # --- vectorised-engine additions ---
         self.num_envs = 1
         self.updates_per_step = 1
+        self.use_graphs = True             # replay the update as one captured hipGraph (train(); update() stays eager)
 
 
 class Actor(nn.Module):
@@ -104,6 +105,7 @@ class SACTrainer:
         self._act_counter = 0
         self._parity_noise = None      # tests: iterator of f32[N, A] Exp(1) draws for select_action
         self._parity_indices = None    # tests: iterator of i32[B] replay indices for update()
+        self._graph = None             # hipGraph of the update, captured on first use (update_async)
 
     @torch.no_grad()
     def select_action(self, state, deterministic=False, noise_exp=None):
@@ -125,7 +127,18 @@ class SACTrainer:
             return 0.0, 0.0, 0.0, 0.0
         if indices is None and self._parity_indices is not None:
             indices = next(self._parity_indices)
-        states, actions, rewards, next_states, dones = self.memory.sample(cfg.batch_size, indices)
+        if indices is None:
+            indices = self.memory.draw_indices(cfg.batch_size)
+        B = self._update_body(indices)
+        sc, sa = self._sums_c.tolist(), self._sums_a.tolist()
+        return sa[0] / B, sc[0] / B, sc[1] / B, float(self._alpha_loss.item())
+
+    def _update_body(self, indices, biases=None, alpha_bias=None):
+        """Everything after the index draw; biases = device views of the three Adams' step scalars (critic1, critic2,
+        actor) and alpha_bias the temperature's, when the body runs inside / ahead of a hipGraph."""
+        cfg = self.cfg
+        bc1, bc2, ba = biases if biases is not None else (None, None, None)
+        states, actions, rewards, next_states, dones = self.memory.gather(indices)
         B = states.shape[0]
         with torch.no_grad():                                                  # :171-181
             y = ops.dsac_target(self.actor(next_states), self.critic1_target(next_states),
@@ -136,22 +149,35 @@ class SACTrainer:
         self.c1_grads.zero_()
         self.c2_grads.zero_()
         torch.autograd.backward([q1, q2], [dq1, dq2])
-        self.critic1_optim.step()
-        self.critic2_optim.step()
+        self.critic1_optim.step(bias_dev=bc1)
+        self.critic2_optim.step(bias_dev=bc2)
         probs = self.actor(states)                                             # :196-207
         with torch.no_grad():
             q1n, q2n = self.critic1(states), self.critic2(states)              # the critics' gradients of this loss are discarded
         self._sums_a.zero_()
         dprobs = ops.dsac_actor_loss(probs.detach(), q1n, q2n, self.log_alpha, self._sums_a)
         torch.autograd.backward([probs], [dprobs])
-        self.actor_optim.step()
-        self._alpha_steps += 1                                                 # :209-215
+        self.actor_optim.step(bias_dev=ba)
+        if alpha_bias is None:                                                 # :209-215
+            self._alpha_steps += 1
         ops.dsac_alpha_step(self.log_alpha, self._alpha_m, self._alpha_v, self._sums_a, B, cfg.target_entropy,
-                            cfg.lr_alpha, self._alpha_steps, loss_out=self._alpha_loss)
+                            cfg.lr_alpha, max(self._alpha_steps, 1), loss_out=self._alpha_loss, bias_dev=alpha_bias)
         self.soft_update(self.c1_target_flat, self.c1_flat)                    # :217-218
         self.soft_update(self.c2_target_flat, self.c2_flat)
-        sc, sa = self._sums_c.tolist(), self._sums_a.tolist()
-        return sa[0] / B, sc[0] / B, sc[1] / B, float(self._alpha_loss.item())
+        return B
+
+    def update_async(self):
+        """update() without the host round trip, replayed as a captured hipGraph (gymrl_amd/graphs.py)."""
+        cfg = self.cfg
+        if len(self.memory) < cfg.batch_size:
+            return
+        if self._graph is None:
+            from .graphs import GraphedUpdate
+            b1, b2 = float(np.float32(0.9)), float(np.float32(0.999))          # the kernel's float32 betas, as doubles
+            self._graph = GraphedUpdate(self.device, cfg.batch_size, [self.critic1_optim, self.critic2_optim, self.actor_optim],
+                                        lambda idx, biases, ab: self._update_body(idx, biases, ab),
+                                        alpha=(self, "_alpha_steps", b1, b2))
+        self._graph(self.memory, cfg.batch_size)
 
     def train(self, max_vector_steps=None):
         """The reference's train() loop; the small-M GEMMs of the update run on the library that answers them
@@ -172,6 +198,7 @@ class SACTrainer:
         tracker = EpisodeTracker(N, self.device, flush_every=1 if N == 1 else 16)
         env.reset(obs)
         step = 0
+        graphed = bool(getattr(cfg, "use_graphs", True)) and self._parity_indices is None
         limit = max_vector_steps or (cfg.max_episodes * cfg.max_steps // N + 1)
         while tracker.episodes < cfg.max_episodes and step < limit:
             action = self.select_action(obs, noise_exp=None if self._parity_noise is None else next(self._parity_noise))
@@ -179,7 +206,10 @@ class SACTrainer:
             env.step(action, nxt, rew, done_out=done, term_obs_out=tobs, ep_ret_out=ep_ret)
             self.memory.push(obs, action, rew, tobs, done)
             for _ in range(cfg.updates_per_step):
-                self.update()
+                if graphed:
+                    self.update_async()
+                else:
+                    self.update()
             obs, nxt = nxt, obs
             step += 1
             tracker.advance(self.episode_rewards)

@@ -114,6 +114,7 @@ class _ActorCriticBase:
         self._noise_counter = 0
         self._parity_eps = None        # tests: iterator of f64[N, A] N(0,1) draws for select_action
         self._parity_updates = None    # tests: iterator of per-update tuples (see update())
+        self._graph = None             # hipGraph of the update (trainers that define update_async)
 
     def soft_update(self, target_flat, source_flat):
         """:149-154 on the flat parameter buffers."""
@@ -148,6 +149,9 @@ class _ActorCriticBase:
         tracker = EpisodeTracker(N, self.device, flush_every=1 if N == 1 else 16)
         env.reset(obs)
         step = 0
+        # DDPG replays its update as a captured hipGraph; TD3's update draws its target-smoothing noise from a host
+        # counter and alternates between two bodies (policy delay), and stays eager
+        graphed = (bool(getattr(cfg, "use_graphs", True)) and self._parity_updates is None and hasattr(self, "update_async"))
         limit = max_vector_steps or (cfg.max_episodes * cfg.max_steps // N + 1)
         while tracker.episodes < cfg.max_episodes and step < limit:
             action = self.select_action(obs, eps=None if self._parity_eps is None else next(self._parity_eps))
@@ -155,7 +159,10 @@ class _ActorCriticBase:
             env.step(action, nxt, rew, done_out=done, term_obs_out=tobs, ep_ret_out=ep_ret)
             self.memory.push(obs, action, rew, tobs, done)             # done = terminated or truncated
             for _ in range(cfg.updates_per_step):
-                self.update()
+                if graphed:
+                    self.update_async()
+                else:
+                    self.update()
             obs, nxt = nxt, obs
             step += 1
             tracker.advance(self.episode_rewards)

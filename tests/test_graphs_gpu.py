@@ -134,3 +134,17 @@ def test_ppo_lstm_graphed_equals_eager():
     assert torch.equal(a.flat_params, b.flat_params) and torch.equal(a.optimizer.v, b.optimizer.v)
     for x, y in zip(ma, mb):
         assert x == y
+
+
+@pytest.mark.parametrize("algo", ["ddpg", "dsac"])
+def test_ddpg_dsac_graphed_update_equals_eager(algo):
+    from gymrl_amd import ddpg_pendulum, sac_cartpole
+    mod, cls = {"ddpg": (ddpg_pendulum, "DDPGTrainer"), "dsac": (sac_cartpole, "SACTrainer")}[algo]
+    eager = _run(mod, cls, False, 40)
+    graph = _run(mod, cls, True, 40)
+    assert graph._graph is not None and graph._graph.step_fn.graph is not None
+    for name in ("actor_flat",) + (("critic_flat", "critic_target_flat", "actor_target_flat") if algo == "ddpg"
+                                   else ("c1_flat", "c2_flat", "c1_target_flat", "log_alpha", "_alpha_v")):
+        assert torch.equal(getattr(eager, name), getattr(graph, name)), name
+    opt = "critic_optimizer" if algo == "ddpg" else "critic1_optim"
+    assert getattr(eager, opt).step_count == getattr(graph, opt).step_count > 30
