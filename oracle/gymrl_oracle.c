@@ -147,7 +147,6 @@ void orc_philox(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 static float u01f_open0(uint32_t x) { return (float)((x >> 8) + 1u) * 0x1p-24f; }
-static float u01f(uint32_t x) { return (float)(x >> 8) * 0x1p-24f; }
 static double u01d(uint32_t a, uint32_t b) {
   return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * 0x1p-53;
 }
