@@ -57,15 +57,15 @@ __global__ __launch_bounds__(kBlock) void replay_gather_kernel(
   }
 }
 
+// random.sample(buffer, B) draws B DISTINCT rows: idx[b] = the b-th element of a keyed permutation of [0, size)
+// (gymrl_device.hpp keyed_permute, tag RNG_REPLAY folded into the key) — a uniform sample without replacement
+// with no rejection loop and no bookkeeping between lanes.
 __global__ __launch_bounds__(kBlock) void uniform_indices_kernel(uint64_t seed, uint64_t counter,
-                                                                 int64_t size, int B,
+                                                                 uint32_t size, int B, int a, int bbits,
                                                                  int32_t* __restrict__ idx) {
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= B) return;
-  const u32x4 r = philox4x32(seed, (uint32_t)b, 0u, (uint32_t)counter,
-                             RNG_REPLAY | (uint32_t)((counter >> 32) & 0x0FFFFFFFu));
-  int64_t i = (int64_t)(u01d(r.x, r.y) * (double)size);
-  idx[b] = (int32_t)(i >= size ? size - 1 : i);
+  idx[b] = (int32_t)keyed_permute((uint32_t)b, size, a, bbits, seed ^ 0x5265706C61794944ull, counter);
 }
 
 // One lane = one env.  Window slot of entry "i-th oldest" once full: (slot + 1 + i) % n.
@@ -154,10 +154,12 @@ int gymrl_replay_gather(const float* state, const uint32_t* action, const float*
 
 int gymrl_uniform_indices(uint64_t seed, uint64_t counter, int64_t size, int B, int32_t* idx_out,
                           void* stream_) {
-  if (!idx_out || size <= 0 || size > 0x7FFFFFFF || B < 0) return -22;
+  if (!idx_out || size <= 0 || size > 0x7FFFFFFF || B < 0 || B > size) return -22;
   if (B == 0) return 0;
+  int bits = 2;
+  while (((int64_t)1 << bits) < size) ++bits;
   hipLaunchKernelGGL(uniform_indices_kernel, dim3(cdiv(B, kBlock)), dim3(kBlock), 0,
-                     (hipStream_t)stream_, seed, counter, size, B, idx_out);
+                     (hipStream_t)stream_, seed, counter, (uint32_t)size, B, bits / 2, bits - bits / 2, idx_out);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

@@ -471,8 +471,9 @@ int gymrl_replay_gather(const float* state, const uint32_t* action, const float*
                         const float* next_state, const uint8_t* flag, const int32_t* idx, int B,
                         int D, int AW, float* state_out, void* action_out, float* reward_out,
                         float* next_state_out, float* flag_out, void* stream);
-/* idx[b] = floor(U[0,1) * size), Philox(seed, counter, b) — the vectorised stand-in for
- * random.sample (dqn_cartpole.py:76; with replacement). */
+/* random.sample(buffer, B) (dqn_cartpole.py:76) / np.random.choice(size, B, replace=False)
+ * (utils/buffer.py:127): B DISTINCT uniform rows — idx[b] = the b-th element of a keyed permutation of
+ * [0, size) (the Feistel/Philox bijection of gymrl_permutation, keyed by (seed, counter)); B <= size. */
 int gymrl_uniform_indices(uint64_t seed, uint64_t counter, int64_t size, int B,
                           int32_t* idx_out, void* stream);
 

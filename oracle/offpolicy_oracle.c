@@ -121,12 +121,27 @@ int orc_nstep_push(float* w_state, int32_t* w_action, float* w_reward, float* w_
   return emit;
 }
 
+/* random.sample / np.random.choice(replace=False): the first B elements of a keyed permutation of [0, size)
+ * (the bijection of orc_permutation, gymrl_oracle.c, with the replay tag folded into the key). */
+static uint32_t replay_feistel(uint32_t x, int a, int b, uint64_t seed, uint64_t counter) {
+  const uint32_t mask_lo = (1u << a) - 1u, mask_hi = (1u << b) - 1u;
+  uint32_t lo = x & mask_lo, hi = x >> a, o[4];
+  const uint32_t c2 = (uint32_t)counter, c3 = 0x60000000u | ((uint32_t)(counter >> 32) & 0x0FFFFFFFu);
+  for (uint32_t r = 0; r < 6; ++r) {
+    if ((r & 1u) == 0u) { orc_philox(seed, hi, r, c2, c3, o); lo ^= o[0] & mask_lo; }
+    else                { orc_philox(seed, lo, r, c2, c3, o); hi ^= o[0] & mask_hi; }
+  }
+  return (hi << a) | lo;
+}
 void orc_uniform_indices(uint64_t seed, uint64_t counter, int64_t size, int B, int32_t* idx) {
+  int bits = 2;
+  while (((int64_t)1 << bits) < size) ++bits;
+  const int a = bits / 2, bb = bits - a;
+  const uint64_t key = seed ^ 0x5265706C61794944ull;
   for (int b = 0; b < B; ++b) {
-    uint32_t r[4];
-    orc_philox(seed, (uint32_t)b, 0u, (uint32_t)counter, RNG_REPLAY | (uint32_t)((counter >> 32) & 0x0FFFFFFFu), r);
-    int64_t i = (int64_t)(u01d(r[0], r[1]) * (double)size);
-    idx[b] = (int32_t)(i >= size ? size - 1 : i);
+    uint32_t x = replay_feistel((uint32_t)b, a, bb, key, counter);
+    while (x >= (uint32_t)size) x = replay_feistel(x, a, bb, key, counter);
+    idx[b] = (int32_t)x;
   }
 }
 

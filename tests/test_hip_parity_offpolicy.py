@@ -43,6 +43,9 @@ def test_replay_append_gather_uniform(dev, oracle):
     assert np.array_equal(ring[0].cpu().numpy(), ref.state) and np.array_equal(ring[2].cpu().numpy(), ref.reward)
     idx = ops.uniform_indices(7, 123456789012, ref.size, 512, dev)
     assert np.array_equal(idx.cpu().numpy(), oracle.uniform_indices(7, 123456789012, ref.size, 512))
+    assert len(set(idx.cpu().numpy().tolist())) == 512 and 0 <= int(idx.min()) and int(idx.max()) < ref.size   # random.sample: distinct rows
+    full = ops.uniform_indices(7, 5, ref.size, ref.size, dev).cpu().numpy()       # B == size: a permutation of the ring
+    assert np.array_equal(np.sort(full), np.arange(ref.size)) and np.array_equal(full, oracle.uniform_indices(7, 5, ref.size, ref.size))
     got = ops.replay_gather(ring, idx)
     for g, r in zip(got, ref.gather(idx.cpu().numpy())):
         assert np.array_equal(g.cpu().numpy().astype(np.float64), np.asarray(r).astype(np.float64))

@@ -167,3 +167,18 @@ def test_dsac_pieces_match_reference(oracle):
         opt.step()
         cur, mm, vv, _ = oracle.dsac_alpha_step(cur, mm, vv, np.array([0.0, ent * 8]), 8, float(g["target_entropy"]), 1e-3, step)
         assert abs(cur - p.item()) <= 2e-7, step
+
+
+def test_uniform_indices_are_a_sample_without_replacement(oracle):
+    """random.sample / np.random.choice(replace=False) semantics of the replay draw: B distinct rows, every row
+    equally likely (chi-square over many draws), a different draw per counter."""
+    size, B = 1000, 64
+    counts = np.zeros(size)
+    for c in range(2000):
+        idx = oracle.uniform_indices(3, c, size, B)
+        assert len(set(idx.tolist())) == B and idx.min() >= 0 and idx.max() < size
+        counts[idx] += 1
+    expected = 2000 * B / size
+    chi2 = ((counts - expected) ** 2 / expected).sum()
+    assert abs(chi2 - size) < 6 * np.sqrt(2 * size), chi2                 # ~ chi-square with ~size degrees of freedom
+    assert not np.array_equal(oracle.uniform_indices(3, 1, size, B), oracle.uniform_indices(3, 2, size, B))
