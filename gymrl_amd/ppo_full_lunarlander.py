@@ -150,15 +150,15 @@ class MHCBackbone(nn.Module):
 
 
 class MLP(nn.Module):
-    """Linear -> SiLU -> RMSNorm -> ... -> Linear (last gain = last_std), keys `mlp.<i>` (:287-318)."""
+    """Linear -> SiLU -> RMSNorm -> ... -> Linear [-> SiLU -> RMSNorm when last_act]; keys `mlp.<i>` (:371-402)."""
 
-    def __init__(self, dims, last_std=None):
+    def __init__(self, dims, last_act=False, last_std=None):
         super().__init__()
         layers = []
         for i in range(len(dims) - 1):
             last = i == len(dims) - 2
             layers.append(_ortho(SmallLinear(dims[i], dims[i + 1]), last_std if (last and last_std) else np.sqrt(2)))
-            if not last:
+            if not last or last_act:
                 layers += [nn.SiLU(), RMSNorm(dims[i + 1])]
         self.mlp = nn.Sequential(*layers)
 
@@ -166,15 +166,48 @@ class MLP(nn.Module):
         return self.mlp(x)
 
 
+class PSCN(nn.Module):
+    """Parallel split-and-concatenate tower: layer i maps to width/2^i, half of its output is emitted and the
+    other half feeds layer i+1 (:405-446)."""
+
+    def __init__(self, input_dim, output_dim, depth):
+        super().__init__()
+        min_dim = 2 ** (depth - 1)
+        if depth < 1 or output_dim < min_dim or output_dim % min_dim:
+            raise ValueError("PSCN: output_dim must be a multiple of 2^(depth-1)")
+        self.output_dim = output_dim
+        self.layers = nn.ModuleList()
+        in_dim, out_dim = input_dim, output_dim
+        for _ in range(depth):
+            self.layers.append(MLP([in_dim, out_dim], last_act=True))
+            in_dim = out_dim // 2
+            out_dim //= 2
+
+    def forward(self, x):
+        parts = []
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            if i < len(self.layers) - 1:
+                half = self.output_dim // (2 ** (i + 1))
+                parts.append(x[..., :half])
+                x = x[..., half:]
+            else:
+                parts.append(x)
+        return torch.cat(parts, dim=-1)
+
+
 class ActorCritic(nn.Module):
     def __init__(self, state_dim, action_dim, config=None):
         super().__init__()
         cfg = config or Config()
-        if not getattr(cfg, "use_mhc", True):
-            raise NotImplementedError("the PSCN backbone (use_mhc=False) is outside the hot-path scope")
-        self.shared = MHCBackbone(state_dim, cfg.mhc_dim, cfg.mhc_rate, cfg.mhc_layers, cfg.mhc_sk_it)
-        self.actor = MLP([cfg.mhc_dim, 256, action_dim], last_std=0.001)
-        self.critic = MLP([cfg.mhc_dim, 256, 1], last_std=1.0)
+        if getattr(cfg, "use_mhc", True):
+            self.shared = MHCBackbone(state_dim, cfg.mhc_dim, cfg.mhc_rate, cfg.mhc_layers, cfg.mhc_sk_it)
+            shared_out = cfg.mhc_dim
+        else:                                                     # :377-384
+            self.shared = PSCN(state_dim, 256, 4)
+            shared_out = 256
+        self.actor = MLP([shared_out, 256, action_dim], last_std=0.001)
+        self.critic = MLP([shared_out, 256, 1], last_std=1.0)
 
     def forward(self, x):
         x = self.shared(x)

@@ -27,7 +27,7 @@ from . import dist as gdist
 from . import ops
 from .envs import VecEnv
 from .flat import FusedAdam, GradSink, flatten_module
-from .ppo_full_lunarlander import MHCBackbone, RMSNorm, _ortho
+from .ppo_full_lunarlander import MLP, PSCN, MHCBackbone, RMSNorm  # noqa: F401  (part of this module's surface)
 
 
 class Config:
@@ -66,53 +66,6 @@ class Config:
         self.rnn_hidden = 512              # the reference hard-codes these three (:84-95)
         self.head_hidden = 512
         self.rnd_embed = 512
-
-
-class MLP(nn.Module):
-    """Linear -> SiLU -> RMSNorm -> ... -> Linear [-> SiLU -> RMSNorm when last_act]; keys `mlp.<i>` (:371-402)."""
-
-    def __init__(self, dims, last_act=False, last_std=None):
-        super().__init__()
-        layers = []
-        for i in range(len(dims) - 1):
-            last = i == len(dims) - 2
-            layers.append(_ortho(nn.Linear(dims[i], dims[i + 1]), last_std if (last and last_std) else np.sqrt(2)))
-            if not last or last_act:
-                layers += [nn.SiLU(), RMSNorm(dims[i + 1])]
-        self.mlp = nn.Sequential(*layers)
-
-    def forward(self, x):
-        return self.mlp(x)
-
-
-class PSCN(nn.Module):
-    """Parallel split-and-concatenate tower: layer i maps to width/2^i, half of its output is emitted and the
-    other half feeds layer i+1 (:405-446)."""
-
-    def __init__(self, input_dim, output_dim, depth):
-        super().__init__()
-        min_dim = 2 ** (depth - 1)
-        if depth < 1 or output_dim < min_dim or output_dim % min_dim:
-            raise ValueError("PSCN: output_dim must be a multiple of 2^(depth-1)")
-        self.output_dim = output_dim
-        self.layers = nn.ModuleList()
-        in_dim, out_dim = input_dim, output_dim
-        for _ in range(depth):
-            self.layers.append(MLP([in_dim, out_dim], last_act=True))
-            in_dim = out_dim // 2
-            out_dim //= 2
-
-    def forward(self, x):
-        parts = []
-        for i, layer in enumerate(self.layers):
-            x = layer(x)
-            if i < len(self.layers) - 1:
-                half = self.output_dim // (2 ** (i + 1))
-                parts.append(x[..., :half])
-                x = x[..., half:]
-            else:
-                parts.append(x)
-        return torch.cat(parts, dim=-1)
 
 
 class _GRUCell(torch.autograd.Function):

@@ -1391,8 +1391,24 @@ def gen_runner_trace():
     save("runner_trace", **out)
 
 
+def gen_ppo_full_pscn():
+    """ppo_full ActorCritic with use_mhc = False (PSCN trunk, ppo_full_lunarlander.py:377-384): forward of the
+    network as initialised under torch seed 77 — the fixture holds no weights, the test rebuilds them from the seed
+    (same construction order = same draws) and checks a checksum of them."""
+    pf = load_ref("algorithms/ppo_full_lunarlander.py", "ref_ppo_full_pscn")
+    cfg = pf.Config()
+    cfg.use_mhc = False
+    torch.manual_seed(77)
+    net = pf.ActorCritic(8, 4, config=cfg)
+    x = torch.randn(16, 8)
+    logits, values = net(x)
+    chk = np.array([float(v.double().sum()) for v in net.state_dict().values()], np.float64)
+    save("ppo_full_pscn", x=x.numpy(), logits=logits.detach().numpy(), values=values.detach().numpy(), checksum=chk,
+         keys=np.array(list(net.state_dict().keys())))
+
+
 if __name__ == "__main__":
     names = sys.argv[1:]
-    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2, gen_dqn_trace, gen_sac_trace, gen_rainbow_trace, gen_td3_ddpg, gen_dsac, gen_ppo_lstm_parts, gen_ppo_lstm_trace, gen_runner_trace]:
+    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2, gen_dqn_trace, gen_sac_trace, gen_rainbow_trace, gen_td3_ddpg, gen_dsac, gen_ppo_lstm_parts, gen_ppo_lstm_trace, gen_runner_trace, gen_ppo_full_pscn]:
         if not names or g.__name__ in names:
             g()

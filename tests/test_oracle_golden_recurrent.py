@@ -67,3 +67,20 @@ def test_rnn_loss_matches_reference(oracle):
                         (met[8] - met[6] * met[7] / B) / B])
         assert rel_close(got, want[:7], 1e-5) <= 1e-5, (c, got, want)
     assert float(g["l2_metrics"][7]) == 0.0 and not g["l2_dlogits"].any()
+
+
+def test_ppo_full_pscn_network_matches_reference():
+    """ppo_full's ActorCritic with use_mhc = False (PSCN trunk): same parameter names, same initial weights from the
+    same torch seed (construction order), bit-identical forward on CPU."""
+    import torch
+    from gymrl_amd.ppo_full_lunarlander import ActorCritic, Config
+    g = load_golden("ppo_full_pscn")
+    cfg = Config()
+    cfg.use_mhc = False
+    torch.manual_seed(77)
+    net = ActorCritic(8, 4, cfg)
+    assert list(net.state_dict().keys()) == [str(k) for k in g["keys"]]
+    chk = np.array([float(v.double().sum()) for v in net.state_dict().values()])
+    assert np.array_equal(chk, g["checksum"])
+    logits, values = net(torch.from_numpy(g["x"]))
+    assert np.array_equal(logits.detach().numpy(), g["logits"]) and np.array_equal(values.detach().numpy(), g["values"])
