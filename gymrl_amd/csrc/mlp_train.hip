@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kTB) void linear_tanh_smallk_kernel(const float* __
       for (int d = 0; d < D; ++d) acc = fmaf(xv[d], w[j][d], acc);
       o[j] = fast_tanhf(acc + bias[j]);
     }
-    *reinterpret_cast<f32x4*>(out + r * C + 4 * m.c4) = o;
+    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(out + r * C + 4 * m.c4));
   }
 }
 
@@ -216,12 +216,12 @@ __global__ __launch_bounds__(kTB) void heads_fwd_tanh_kernel(float* __restrict__
     const size_t o = (size_t)(live ? r : 0) * 2 * C + 4 * m.c4;
     f32x4 ha = {0.0f, 0.0f, 0.0f, 0.0f}, hc = {0.0f, 0.0f, 0.0f, 0.0f};
     if (live) {
-      ha = *reinterpret_cast<const f32x4*>(Zac + o);
-      hc = *reinterpret_cast<const f32x4*>(Zac + o + C);
+      ha = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Zac + o));
+      hc = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Zac + o + C));
 #pragma unroll
       for (int j = 0; j < 4; ++j) { ha[j] = fast_tanhf(ha[j] + pa[j]); hc[j] = fast_tanhf(hc[j] + pc[j]); }
-      *reinterpret_cast<f32x4*>(Zac + o) = ha;
-      *reinterpret_cast<f32x4*>(Zac + o + C) = hc;
+      __builtin_nontemporal_store(ha, reinterpret_cast<f32x4*>(Zac + o));
+      __builtin_nontemporal_store(hc, reinterpret_cast<f32x4*>(Zac + o + C));
     }
     float p[A + 1];
 #pragma unroll
@@ -258,14 +258,14 @@ __global__ __launch_bounds__(kTB) void tanh_bwd_colsum_kernel(float* __restrict_
   const int64_t stride = (int64_t)gridDim.x * (kTB / 64) * m.rpw;
   for (int64_t r = ((int64_t)blockIdx.x * (kTB / 64) + (threadIdx.x >> 6)) * m.rpw + m.r_in; r < B; r += stride) {
     const size_t o = (size_t)r * C + 4 * m.c4;
-    const f32x4 h = *reinterpret_cast<const f32x4*>(H + o);
-    f32x4 g = *reinterpret_cast<const f32x4*>(dH + o);
+    const f32x4 h = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(H + o));
+    f32x4 g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dH + o));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       g[j] = g[j] * (1.0f - h[j] * h[j]);
       acc[j] += g[j];
     }
-    *reinterpret_cast<f32x4*>(dH + o) = g;
+    __builtin_nontemporal_store(g, reinterpret_cast<f32x4*>(dH + o));
   }
   block_colsum<4>(acc, C, m, sm, partials);
 }
@@ -284,8 +284,8 @@ __global__ __launch_bounds__(kTB) void linear_smallk_bwd_kernel(const float* __r
   const int64_t stride = (int64_t)gridDim.x * (kTB / 64) * m.rpw;
   for (int64_t r = ((int64_t)blockIdx.x * (kTB / 64) + (threadIdx.x >> 6)) * m.rpw + m.r_in; r < B; r += stride) {
     const size_t o = (size_t)r * C + 4 * m.c4;
-    const f32x4 h = *reinterpret_cast<const f32x4*>(H + o);
-    const f32x4 g = *reinterpret_cast<const f32x4*>(dH + o);
+    const f32x4 h = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(H + o));
+    const f32x4 g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dH + o));
     float xv[D];
     load_row<D>(xv, x + r * D);
 #pragma unroll
@@ -338,8 +338,8 @@ __global__ __launch_bounds__(kTB) void heads_bwd_kernel(const float* __restrict_
   const int64_t stride = (int64_t)gridDim.x * (kTB / 64) * m.rpw;
   for (int64_t r = ((int64_t)blockIdx.x * (kTB / 64) + (threadIdx.x >> 6)) * m.rpw + m.r_in; r < B; r += stride) {
     const size_t o = (size_t)r * 2 * C + 4 * m.c4;
-    const f32x4 ha = *reinterpret_cast<const f32x4*>(Hac + o);
-    const f32x4 hc = *reinterpret_cast<const f32x4*>(Hac + o + C);
+    const f32x4 ha = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Hac + o));
+    const f32x4 hc = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Hac + o + C));
     float dl[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) dl[a] = dlogits[r * A + a];
@@ -362,8 +362,8 @@ __global__ __launch_bounds__(kTB) void heads_bwd_kernel(const float* __restrict_
 #pragma unroll
     for (int a = 0; a < A; ++a) acc[12 + 4 * A + a] += dl[a];
     acc[12 + 4 * A + A] += dvr;
-    *reinterpret_cast<f32x4*>(dZac + o) = za;
-    *reinterpret_cast<f32x4*>(dZac + o + C) = zc;
+    __builtin_nontemporal_store(za, reinterpret_cast<f32x4*>(dZac + o));
+    __builtin_nontemporal_store(zc, reinterpret_cast<f32x4*>(dZac + o + C));
   }
   // only the c4 == 0 lane of a row group contributes the dlogits / dv sums (they are lane-redundant)
   if (m.c4 != 0) {
