@@ -70,6 +70,11 @@ def main():
         out.setdefault("fused_update_ms(bias in the GEMM epilogue)", []).append(round(timeit(fused_step), 3))
         fu.bias_in_gemm = False
     out["autograd_update_ms"] = [round(timeit(autograd_step), 3)]
+    prev = torch.backends.cuda.preferred_blas_library()
+    torch.backends.cuda.preferred_blas_library("cublas")          # rocBLAS for the 262 144-row GEMMs
+    fu.fused_heads_forward, fu.overlap_dw, fu.bias_in_gemm = True, False, False
+    out["fused_update_ms(GEMMs on rocBLAS)"] = [round(timeit(fused_step), 3) for _ in range(2)]
+    torch.backends.cuda.preferred_blas_library(prev)
     if os.environ.get("GYMRL_TRY_TUNABLE"):
         import torch.cuda.tunable as tn
         tn.enable(True)
