@@ -170,13 +170,13 @@ def report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev)
     # algorithmic bytes: GAE 17 B/elt, loss fwd+bwd 56 B/sample,
     # gather 64 B line in + 48 B out + 4 B index, Adam 36 B/param incl. norm pre-pass + zero_grad
     # update-path passes (csrc/mlp_train.hip), per row of a [B, C=256] activation (obs D=8, A=4):
-    #   linear_tanh_smallk read 4D + write 4C; heads_fwd_tanh read 8C, write 8C + 4(A+1); heads_bwd read 8C + 4(A+1),
+    #   linear_tanh_smallk read 4D + write 4C; heads_fwd_tanh read 8C, write 4(A+1) (tanh is recomputed by heads_bwd, not stored); heads_bwd read 8C + 4(A+1),
     #   write 8C; tanh_bwd_colsum
     #   read 8C, write 4C; linear_smallk_bwd read 8C + 4D; tanh_inplace 8 B per element
     Cw, Dw, Aw = cfg.hidden_dim, 8, 4
     bytes_per_unit = {"gae": 17.0, "ppo_loss_fwd_bwd": 56.0, "gather_minibatch": 116.0, "adam_step": 36.0,
                       "linear_tanh_smallk": 4.0 * (Dw + Cw), "tanh_inplace": 8.0,
-                      "heads_fwd_tanh": 16.0 * Cw + 4.0 * (Aw + 1),
+                      "heads_fwd_tanh": (8.0 if getattr(getattr(trainer, "_fused_update", None), "recompute_tanh", True) else 16.0) * Cw + 4.0 * (Aw + 1),
                       "heads_bwd": 16.0 * Cw + 4.0 * (Aw + 1), "tanh_bwd_colsum": 12.0 * Cw,
                       "linear_smallk_bwd": 8.0 * Cw + 4.0 * Dw}
     kernels = {}

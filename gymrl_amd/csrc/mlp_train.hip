@@ -189,7 +189,8 @@ __global__ __launch_bounds__(kTB) void heads_fwd_tanh_kernel(float* __restrict__
                                                              const float* __restrict__ bac,
                                                              const float* __restrict__ Wa2, const float* __restrict__ ba2,
                                                              const float* __restrict__ Wc2, const float* __restrict__ bc2,
-                                                             float* __restrict__ logits, float* __restrict__ value) {
+                                                             float* __restrict__ logits, float* __restrict__ value,
+                                                             int store_h) {
   const RowMap m(C, threadIdx.x & 63);
   float wa[A][4], wc[4];
 #pragma unroll
@@ -220,8 +221,10 @@ __global__ __launch_bounds__(kTB) void heads_fwd_tanh_kernel(float* __restrict__
       hc = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Zac + o + C));
 #pragma unroll
       for (int j = 0; j < 4; ++j) { ha[j] = fast_tanhf(ha[j] + pa[j]); hc[j] = fast_tanhf(hc[j] + pc[j]); }
-      __builtin_nontemporal_store(ha, reinterpret_cast<f32x4*>(Zac + o));
-      __builtin_nontemporal_store(hc, reinterpret_cast<f32x4*>(Zac + o + C));
+      if (store_h) {      // store_h == 0: Zac keeps the pre-activations and heads_bwd recomputes the same tanh
+        __builtin_nontemporal_store(ha, reinterpret_cast<f32x4*>(Zac + o));
+        __builtin_nontemporal_store(hc, reinterpret_cast<f32x4*>(Zac + o + C));
+      }
     }
     float p[A + 1];
 #pragma unroll
@@ -319,9 +322,15 @@ template <int A>
 __global__ __launch_bounds__(kTB) void heads_bwd_kernel(const float* __restrict__ Hac, const float* __restrict__ dlogits,
                                                         const float* __restrict__ dv, int64_t B, int C,
                                                         const float* __restrict__ Wa2, const float* __restrict__ Wc2,
-                                                        float* __restrict__ dZac, float* __restrict__ partials) {
+                                                        float* __restrict__ dZac, float* __restrict__ partials,
+                                                        int pre_activation, const float* __restrict__ bac) {
   extern __shared__ float sm[];
   const RowMap m(C, threadIdx.x & 63);
+  f32x4 pa = {0.0f, 0.0f, 0.0f, 0.0f}, pc = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (pre_activation && bac) {
+    pa = *reinterpret_cast<const f32x4*>(bac + 4 * m.c4);
+    pc = *reinterpret_cast<const f32x4*>(bac + C + 4 * m.c4);
+  }
   float wa[A][4], wc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -338,8 +347,12 @@ __global__ __launch_bounds__(kTB) void heads_bwd_kernel(const float* __restrict_
   const int64_t stride = (int64_t)gridDim.x * (kTB / 64) * m.rpw;
   for (int64_t r = ((int64_t)blockIdx.x * (kTB / 64) + (threadIdx.x >> 6)) * m.rpw + m.r_in; r < B; r += stride) {
     const size_t o = (size_t)r * 2 * C + 4 * m.c4;
-    const f32x4 ha = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Hac + o));
-    const f32x4 hc = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Hac + o + C));
+    f32x4 ha = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Hac + o));
+    f32x4 hc = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Hac + o + C));
+    if (pre_activation) {   // Hac holds actor.0 / critic.0 pre-activations: the forward's tanh, bit for bit
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ha[j] = fast_tanhf(ha[j] + pa[j]); hc[j] = fast_tanhf(hc[j] + pc[j]); }
+    }
     float dl[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) dl[a] = dlogits[r * A + a];
@@ -474,13 +487,17 @@ int gymrl_linear_smallk_bwd(const float* dH, const float* H, const float* x, int
 }
 
 int gymrl_heads_fwd_tanh(float* Zac, int64_t B, int C, int A, const float* bac, const float* Wa2, const float* ba2,
-                         const float* Wc2, const float* bc2, float* logits, float* value, void* stream) {
+                         const float* Wc2, const float* bc2, float* logits, float* value, int store_h, void* stream) {
   if (!Zac || !Wa2 || !Wc2 || !logits || !value || B < 0 || !pow2_cols(C) || !al16(Zac) || (bac && !al16(bac))) return -22;
   if (B == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(grid_for(B, C)), block(kTB);
-  if (A == 4) hipLaunchKernelGGL(heads_fwd_tanh_kernel<4>, grid, block, 0, s, Zac, B, C, bac, Wa2, ba2, Wc2, bc2, logits, value);
-  else if (A == 2) hipLaunchKernelGGL(heads_fwd_tanh_kernel<2>, grid, block, 0, s, Zac, B, C, bac, Wa2, ba2, Wc2, bc2, logits, value);
+  // read-only stream with a per-row butterfly: latency-bound per wave, so more resident waves than the kernels
+  // that write block partials (no workspace bounds the grid here)
+  const int64_t rows_per_block = (kTB / 64) * (64 / (C / 4));
+  const int64_t want = (B + rows_per_block - 1) / rows_per_block;
+  const dim3 grid((unsigned)(want < 4 * kMaxBlocks ? (want < 1 ? 1 : want) : 4 * kMaxBlocks)), block(kTB);
+  if (A == 4) hipLaunchKernelGGL(heads_fwd_tanh_kernel<4>, grid, block, 0, s, Zac, B, C, bac, Wa2, ba2, Wc2, bc2, logits, value, store_h);
+  else if (A == 2) hipLaunchKernelGGL(heads_fwd_tanh_kernel<2>, grid, block, 0, s, Zac, B, C, bac, Wa2, ba2, Wc2, bc2, logits, value, store_h);
   else return -22;
   GYMRL_CHECK_LAUNCH();
   return 0;
@@ -488,7 +505,7 @@ int gymrl_heads_fwd_tanh(float* Zac, int64_t B, int C, int A, const float* bac, 
 
 int gymrl_heads_bwd(const float* Hac, const float* dlogits, const float* dv, int64_t B, int C, int A,
                     const float* Wa2, const float* Wc2, float* dZac, float* dbac, float* dWa2, float* dba2,
-                    float* dWc2, float* dbc2, void* workspace, void* stream) {
+                    float* dWc2, float* dbc2, int pre_activation, const float* bac, void* workspace, void* stream) {
   if (!Hac || !dlogits || !dv || !Wa2 || !Wc2 || !dZac || !dbac || !dWa2 || !dba2 || !dWc2 || !dbc2 || !workspace ||
       B < 0 || !pow2_cols(C) || !al16(Hac) || !al16(dZac))
     return -22;
@@ -498,12 +515,12 @@ int gymrl_heads_bwd(const float* Hac, const float* dlogits, const float* dv, int
   const dim3 grid(nb), block(kTB);
   if (A == 4) {
     constexpr int NV = (8 + 16 + 4 + 8) / 4;
-    hipLaunchKernelGGL(heads_bwd_kernel<4>, grid, block, sm_bytes(C, NV), s, Hac, dlogits, dv, B, C, Wa2, Wc2, dZac, parts);
+    hipLaunchKernelGGL(heads_bwd_kernel<4>, grid, block, sm_bytes(C, NV), s, Hac, dlogits, dv, B, C, Wa2, Wc2, dZac, parts, pre_activation, bac);
     hipLaunchKernelGGL(heads_finalize_kernel<4>, dim3((NV * C + kFinE - 1) / kFinE), block, 0, s, parts, nb, C, dbac, dWa2,
                        dWc2, dba2, dbc2);
   } else if (A == 2) {
     constexpr int NV = (8 + 8 + 4 + 4) / 4;
-    hipLaunchKernelGGL(heads_bwd_kernel<2>, grid, block, sm_bytes(C, NV), s, Hac, dlogits, dv, B, C, Wa2, Wc2, dZac, parts);
+    hipLaunchKernelGGL(heads_bwd_kernel<2>, grid, block, sm_bytes(C, NV), s, Hac, dlogits, dv, B, C, Wa2, Wc2, dZac, parts, pre_activation, bac);
     hipLaunchKernelGGL(heads_finalize_kernel<2>, dim3((NV * C + kFinE - 1) / kFinE), block, 0, s, parts, nb, C, dbac, dWa2,
                        dWc2, dba2, dbc2);
   } else {

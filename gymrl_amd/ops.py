@@ -684,23 +684,24 @@ def linear_smallk_bwd(dH, H, x, dW, db, workspace):
                                         _ptr(db, torch.float32), _ptr(workspace), _stream()), "gymrl_linear_smallk_bwd")
 
 
-def heads_fwd_tanh(Zac, Wa2, ba2, Wc2, bc2, logits, value, bac=None):
+def heads_fwd_tanh(Zac, Wa2, ba2, Wc2, bc2, logits, value, bac=None, store_h=True):
     """Zac [B, 2C] -> tanh in place + logits [B, A] + value [B] (include/gymrl.h gymrl_heads_fwd_tanh)."""
     B, C2 = Zac.shape
     check(lib().gymrl_heads_fwd_tanh(_ptr(Zac, torch.float32), C.c_int64(B), C.c_int(C2 // 2), C.c_int(Wa2.shape[0]),
                                      _ptr(bac, torch.float32, True), _ptr(Wa2, torch.float32), _ptr(ba2, torch.float32, True), _ptr(Wc2, torch.float32),
                                      _ptr(bc2, torch.float32, True), _ptr(logits, torch.float32),
-                                     _ptr(value, torch.float32), _stream()), "gymrl_heads_fwd_tanh")
+                                     _ptr(value, torch.float32), C.c_int(int(store_h)), _stream()), "gymrl_heads_fwd_tanh")
 
 
-def heads_bwd(Hac, dlogits, dv, Wa2, Wc2, dZac, dbac, dWa2, dba2, dWc2, dbc2, workspace):
+def heads_bwd(Hac, dlogits, dv, Wa2, Wc2, dZac, dbac, dWa2, dba2, dWc2, dbc2, workspace, pre_activation=False, bac=None):
     """Backward of both heads in one pass over Hac = [Ha | Hc] (include/gymrl.h gymrl_heads_bwd)."""
     B, C2 = Hac.shape
     check(lib().gymrl_heads_bwd(_ptr(Hac, torch.float32), _ptr(dlogits, torch.float32), _ptr(dv, torch.float32),
                                 C.c_int64(B), C.c_int(C2 // 2), C.c_int(dlogits.shape[1]), _ptr(Wa2, torch.float32),
                                 _ptr(Wc2, torch.float32), _ptr(dZac, torch.float32), _ptr(dbac, torch.float32),
                                 _ptr(dWa2, torch.float32), _ptr(dba2, torch.float32), _ptr(dWc2, torch.float32),
-                                _ptr(dbc2, torch.float32), _ptr(workspace), _stream()), "gymrl_heads_bwd")
+                                _ptr(dbc2, torch.float32), C.c_int(int(pre_activation)), _ptr(bac, torch.float32, True),
+                                _ptr(workspace), _stream()), "gymrl_heads_bwd")
 
 
 # ------------------------------------------------------ persistent rollout ---

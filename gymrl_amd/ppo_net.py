@@ -76,8 +76,10 @@ class FusedActorCriticUpdate:
         self.logits = torch.empty(R, self.A, device=dev)
         self.value = torch.empty(R, 1, device=dev)
         self._x = None
+        self._pre, self._pre_bias = False, None
         self.timers = None      # bench.py: KernelTimers bracketing the hand-written HBM passes
         self.fused_heads_forward = True
+        self.recompute_tanh = True      # heads_fwd does not store tanh(Zac); heads_bwd recomputes it (2 KB/row less traffic)
         self.bias_in_gemm = False
         self.overlap_dw = False     # dW GEMMs on a side stream under the HBM passes: measured 3.255 vs 3.23 ms, no gain
         self._side = torch.cuda.Stream(device=dev)
@@ -111,9 +113,12 @@ class FusedActorCriticUpdate:
             bac = self.bac
         logits, value = self.logits[:B], self.value[:B]
         if self.fused_heads_forward:
+            self._pre = self.recompute_tanh
             self._timed("heads_fwd_tanh", B, ops.heads_fwd_tanh, Hac, m.actor[2].weight, m.actor[2].bias,
-                        m.critic[2].weight, m.critic[2].bias, logits, value, bac)
+                        m.critic[2].weight, m.critic[2].bias, logits, value, bac, not self._pre)
+            self._pre_bias = bac
         else:                                     # tanh pass + two skinny library GEMMs on views of Hac
+            self._pre = False
             self._timed("tanh_inplace", Hac.numel(), ops.tanh_inplace, Hac, bac)
             torch.addmm(m.actor[2].bias, Hac[:, :H], m.actor[2].weight.t(), out=logits)
             torch.addmm(m.critic[2].bias, Hac[:, H:], m.critic[2].weight.t(), out=value)
@@ -142,7 +147,8 @@ class FusedActorCriticUpdate:
         dZac, dH2, dH1 = self.dZac[:B], self.dH2[:B], self.dH1[:B]
         self._timed("heads_bwd", B, ops.heads_bwd, Hac, dlogits, dvalues.view(-1), m.actor[2].weight,
                     m.critic[2].weight, dZac, self.dbac, m.actor[2].weight.grad, m.actor[2].bias.grad,
-                    m.critic[2].weight.grad, m.critic[2].bias.grad, self.ws)
+                    m.critic[2].weight.grad, m.critic[2].bias.grad, self.ws, self._pre,
+                    self._pre_bias if self._pre else None)
         if not self.overlap_dw:
             self._dw(dZac, H2, self.dWac)
             torch.mm(dZac, self.Wac, out=dH2)

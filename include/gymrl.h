@@ -426,7 +426,9 @@ int gymrl_rollout_lunar(const gymrl_rollout_lunar_args* args, const gymrl_mlp_de
  *   heads_fwd_tanh     : Zac [B, 2C] = pre-activations of actor.0 | critic.0 (one N = 2C GEMM; their biases
  *                        bac [2C] are added here, NULL if the GEMM already did) -> Hac = tanh(Zac + bac) in place AND logits [B, A] = Ha Wa2^T + ba2,
  *                        value [B] = Hc Wc2^T + bc2 from the tanh values still in registers
- *                        (actor.0/critic.0's Tanh + actor.2 + critic.2 forward in one pass)
+ *                        (actor.0/critic.0's Tanh + actor.2 + critic.2 forward in one pass).
+ *                        store_h == 0: Zac is NOT rewritten (it keeps the pre-activations; 2 KB/row less HBM
+ *                        traffic) — then call heads_bwd with pre_activation = 1, which recomputes the same tanh
  *   heads_bwd          : Hac [B, 2C] = [Ha | Hc], the Tanh outputs of actor.0 / critic.0;
  *                        dlogits [B, A] (A in {2,4}), dv [B] from gymrl_ppo_loss_fwd_bwd;
  *                        Wa2 [A, C] = actor.2.weight, Wc2 [1, C] = critic.2.weight.  Writes
@@ -434,6 +436,8 @@ int gymrl_rollout_lunar(const gymrl_rollout_lunar_args* args, const gymrl_mlp_de
  *                        dbac [2C] = colsum dZac, dWa2 = dlogits^T Ha, dba2 = colsum dlogits,
  *                        dWc2 = dv^T Hc, dbc2 = sum dv — one pass over Hac instead of four
  *                        skinny GEMMs, two tanh' passes and four reductions.
+ *                        pre_activation != 0: `Hac` holds the pre-activations instead and the kernel applies
+ *                        tanh(. + bac[col]) (bac NULL: no bias) first — bit for bit the forward's values
  * tanh here is |x| < 0.625 ? odd polynomial : 1 - 2/(exp(2x)+1) on the hardware exp2/rcp
  * units (device-deterministic, ~2 ulp; compared with torch at 1e-5, not bit for bit).
  */
@@ -447,10 +451,11 @@ int gymrl_linear_smallk_bwd(const float* dH, const float* H, const float* x, int
                             float* dW, float* db, void* workspace, void* stream);
 int gymrl_heads_fwd_tanh(float* Zac, int64_t B, int C, int A, const float* bac, const float* Wa2,
                          const float* ba2, const float* Wc2, const float* bc2, float* logits, float* value,
-                         void* stream);
+                         int store_h, void* stream);
 int gymrl_heads_bwd(const float* Hac, const float* dlogits, const float* dv, int64_t B, int C, int A,
                     const float* Wa2, const float* Wc2, float* dZac, float* dbac, float* dWa2,
-                    float* dba2, float* dWc2, float* dbc2, void* workspace, void* stream);
+                    float* dba2, float* dWc2, float* dbc2, int pre_activation, const float* bac,
+                    void* workspace, void* stream);
 
 /* ========================================================= off-policy ===== */
 /*

@@ -68,9 +68,9 @@ def test_new_entry_points_validate_arguments_without_gpu():
     assert L.gymrl_linear_tanh_smallk(fake, fake, null, i64(8), 8, 48, fake, null) == -22     # C not a power of two
     assert L.gymrl_linear_tanh_smallk(fake, fake, null, i64(8), 5, 64, fake, null) == -22     # unsupported input width
     assert L.gymrl_tanh_inplace(fake, i64(6), null, 0, null) == -22                            # n % 4 != 0
-    assert L.gymrl_heads_bwd(fake, fake, fake, i64(8), 64, 3, fake, fake, fake, fake, fake, fake, fake, fake, fake,
-                             null) == -22                                                      # A not in {2, 4}
-    assert L.gymrl_heads_fwd_tanh(null, i64(8), 64, 4, null, fake, null, fake, null, fake, fake, null) == -22
+    assert L.gymrl_heads_bwd(fake, fake, fake, i64(8), 64, 3, fake, fake, fake, fake, fake, fake, fake, fake, 0, null,
+                             fake, null) == -22                                                # A not in {2, 4}
+    assert L.gymrl_heads_fwd_tanh(null, i64(8), 64, 4, null, fake, null, fake, null, fake, fake, 1, null) == -22
     args = _lib.RolloutLunarArgs()
     assert L.gymrl_rollout_lunar(ctypes.byref(args), ctypes.byref(desc), null) == -22          # NULL slabs
     # empty work is a no-op that returns 0 without launching anything

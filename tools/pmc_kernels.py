@@ -47,9 +47,10 @@ for it in range(3):
     junk.zero_()
     ops.tanh_inplace(dZac.copy_(Hac))
     junk.zero_()
-    ops.heads_fwd_tanh(dZac.copy_(Hac), Wa2, dba2, Wc2, dbc2, dlg, dvv, dbac)
+    ops.heads_fwd_tanh(dZac.copy_(Hac), Wa2, dba2, Wc2, dbc2, dlg, dvv, dbac, store_h=False)
     junk.zero_()
-    ops.heads_bwd(Hac, dlg, dvv, Wa2, Wc2, dZac, dbac, dWa2.view(A, C), dba2, dWc2.view(1, C), dbc2, gws)
+    ops.heads_bwd(Hac, dlg, dvv, Wa2, Wc2, dZac, dbac, dWa2.view(A, C), dba2, dWc2.view(1, C), dbc2, gws, pre_activation=True,
+                  bac=dbac.clone())
     junk.zero_()
     ops.tanh_bwd_colsum(dH, H1, db1, gws)
     junk.zero_()

@@ -22,7 +22,7 @@ UNITS = {   # kernel-name fragment -> (label, work units per launch, algorithmic
     "ppo_loss_kernel": ("ppo_loss", None, 56.0),
     "linear_tanh_smallk_kernel": ("linear_tanh_smallk", MB, 4.0 * (8 + 256)),
     "tanh_inplace_kernel": ("tanh_inplace", MB * 512, 8.0),
-    "heads_fwd_tanh_kernel": ("heads_fwd_tanh", MB, 16.0 * 256 + 20.0),
+    "heads_fwd_tanh_kernel": ("heads_fwd_tanh", MB, 8.0 * 256 + 20.0),
     "heads_bwd_kernel": ("heads_bwd", MB, 16.0 * 256 + 20.0),
     "tanh_bwd_colsum_kernel": ("tanh_bwd_colsum", MB, 12.0 * 256),
     "linear_smallk_bwd_kernel": ("linear_smallk_bwd", MB, 8.0 * 256 + 32.0),
