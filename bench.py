@@ -178,7 +178,7 @@ def report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev)
                       "linear_tanh_smallk": 4.0 * (Dw + Cw), "tanh_inplace": 8.0,
                       "heads_fwd_tanh": (8.0 if getattr(getattr(trainer, "_fused_update", None), "recompute_tanh", True) else 16.0) * Cw + 4.0 * (Aw + 1),
                       "heads_bwd": 16.0 * Cw + 4.0 * (Aw + 1), "tanh_bwd_colsum": 12.0 * Cw,
-                      "linear_smallk_bwd": 8.0 * Cw + 4.0 * Dw}
+                      "linear_smallk_bwd": (4.0 if getattr(getattr(trainer, "_fused_update", None), "recompute_h1", False) else 8.0) * Cw + 4.0 * Dw}
     kernels = {}
     for k, v in ks.items():
         ent = dict(launches=v["launches"], avg_us=round(v["avg_us"], 2))

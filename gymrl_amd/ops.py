@@ -676,12 +676,14 @@ def tanh_bwd_colsum(dH, H, colsum_out, workspace):
     return dH
 
 
-def linear_smallk_bwd(dH, H, x, dW, db, workspace):
-    """First layer backward without materialising dZ: dW = (dH (1 - H^2))^T x, db = colsum."""
+def linear_smallk_bwd(dH, H, x, dW, db, workspace, W=None, b=None):
+    """First layer backward without materialising dZ: dW = (dH (1 - H^2))^T x, db = colsum.  With the layer's own
+    (W, b) the kernel recomputes H = tanh(x W^T + b) instead of reading it (H may then be None)."""
     B, Cc = dH.shape
-    check(lib().gymrl_linear_smallk_bwd(_ptr(dH, torch.float32), _ptr(H, torch.float32), _ptr(x, torch.float32),
+    check(lib().gymrl_linear_smallk_bwd(_ptr(dH, torch.float32), _ptr(H, torch.float32, True), _ptr(x, torch.float32),
                                         C.c_int64(B), C.c_int(x.shape[1]), C.c_int(Cc), _ptr(dW, torch.float32),
-                                        _ptr(db, torch.float32), _ptr(workspace), _stream()), "gymrl_linear_smallk_bwd")
+                                        _ptr(db, torch.float32), _ptr(W, torch.float32, True), _ptr(b, torch.float32, True),
+                                        _ptr(workspace), _stream()), "gymrl_linear_smallk_bwd")
 
 
 def heads_fwd_tanh(Zac, Wa2, ba2, Wc2, bc2, logits, value, bac=None, store_h=True):

@@ -80,6 +80,8 @@ class FusedActorCriticUpdate:
         self.timers = None      # bench.py: KernelTimers bracketing the hand-written HBM passes
         self.fused_heads_forward = True
         self.recompute_tanh = True      # heads_fwd does not store tanh(Zac); heads_bwd recomputes it (2 KB/row less traffic)
+        self.recompute_h1 = False       # linear_smallk_bwd recomputing H1 from x: 1 KB/row less traffic but 102 -> 115 us
+                                        # (the pass is issue-bound once H1 is not read), measured and left off
         self.bias_in_gemm = False
         self.overlap_dw = False     # dW GEMMs on a side stream under the HBM passes: measured 3.255 vs 3.23 ms, no gain
         self._side = torch.cuda.Stream(device=dev)
@@ -125,6 +127,11 @@ class FusedActorCriticUpdate:
         self._x = x
         return logits, value.view(-1)
 
+    def _recompute_h1(self):
+        """(W1, b1) when linear_smallk_bwd recomputes H1 from the observations instead of reading it."""
+        m = self.m
+        return (m.shared[0].weight, m.shared[0].bias) if self.recompute_h1 else (None, None)
+
     @staticmethod
     def _dw(dy, x, out):
         """out = dy^T x with the reduction dimension (rows) split into independent slices."""
@@ -156,7 +163,7 @@ class FusedActorCriticUpdate:
             self._dw(dH2, H1, m.shared[2].weight.grad)
             torch.mm(dH2, m.shared[2].weight, out=dH1)
             self._timed("linear_smallk_bwd", B, ops.linear_smallk_bwd, dH1, H1, x, m.shared[0].weight.grad,
-                        m.shared[0].bias.grad, self.ws)
+                        m.shared[0].bias.grad, self.ws, *self._recompute_h1())
             return
         # The weight-gradient GEMMs (MFMA-bound, off the critical path) run on a side stream under the
         # HBM-bound passes of the main stream: dWac under tanh_bwd_colsum, dW2 under linear_smallk_bwd.
@@ -175,5 +182,5 @@ class FusedActorCriticUpdate:
             self._dw(dH2, H1, m.shared[2].weight.grad)
         torch.mm(dH2, m.shared[2].weight, out=dH1)
         self._timed("linear_smallk_bwd", B, ops.linear_smallk_bwd, dH1, H1, x, m.shared[0].weight.grad,
-                    m.shared[0].bias.grad, self.ws)
+                    m.shared[0].bias.grad, self.ws, *self._recompute_h1())
         main.wait_stream(side)                     # the optimiser and the next forward see every gradient / free buffer

@@ -422,7 +422,9 @@ int gymrl_rollout_lunar(const gymrl_rollout_lunar_args* args, const gymrl_mlp_de
  *                        library GEMM; the bias rides on this pass, the GEMM runs without an epilogue
  *   tanh_bwd_colsum    : dH <- dH * (1 - H^2) in place; colsum_out[c] = sum_r dH[r][c]
  *                        (Tanh backward + the bias gradient of the Linear below it)
- *   linear_smallk_bwd  : dZ = dH * (1 - H^2) (never stored); dW [C, D] = dZ^T x; db [C] = colsum dZ
+ *   linear_smallk_bwd  : dZ = dH * (1 - H^2) (never stored); dW [C, D] = dZ^T x; db [C] = colsum dZ.
+ *                        W, b non-NULL (the layer's own weight [C, D] / bias): H is not read (may be NULL) —
+ *                        H = tanh(x W^T + b) is recomputed exactly as linear_tanh_smallk computed it
  *   heads_fwd_tanh     : Zac [B, 2C] = pre-activations of actor.0 | critic.0 (one N = 2C GEMM; their biases
  *                        bac [2C] are added here, NULL if the GEMM already did) -> Hac = tanh(Zac + bac) in place AND logits [B, A] = Ha Wa2^T + ba2,
  *                        value [B] = Hc Wc2^T + bc2 from the tanh values still in registers
@@ -448,7 +450,8 @@ int gymrl_tanh_inplace(float* z, int64_t n, const float* bias, int C, void* stre
 int gymrl_tanh_bwd_colsum(float* dH, const float* H, int64_t B, int C, float* colsum_out,
                           void* workspace, void* stream);
 int gymrl_linear_smallk_bwd(const float* dH, const float* H, const float* x, int64_t B, int D, int C,
-                            float* dW, float* db, void* workspace, void* stream);
+                            float* dW, float* db, const float* W, const float* b, void* workspace,
+                            void* stream);
 int gymrl_heads_fwd_tanh(float* Zac, int64_t B, int C, int A, const float* bac, const float* Wa2,
                          const float* ba2, const float* Wc2, const float* bc2, float* logits, float* value,
                          int store_h, void* stream);

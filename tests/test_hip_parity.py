@@ -482,13 +482,20 @@ def test_fused_actor_critic_update_matches_autograd(dev, hidden, B, A, D):
     ref_logits, ref_value = logits.detach().clone(), value.detach().view(-1).clone()
     net._flat_grads.zero_()
     fu = ppo_net.FusedActorCriticUpdate(net, B)
-    lg, vl = fu.forward(x)
-    assert torch.allclose(lg, ref_logits, atol=1e-5, rtol=1e-5) and torch.allclose(vl, ref_value, atol=1e-5, rtol=1e-5)
-    fu.backward(dl, dv)
-    for k, p in net.named_parameters():
-        scale = float(ref[k].abs().max()) + 1e-12
-        err = float((p.grad - ref[k]).abs().max()) / scale
-        assert err <= 2e-4, (k, err)
+    grads = {}
+    for recompute in ((True, False), (False, False), (True, True)):     # (tanh of the heads, H1) recomputed in backward or stored
+        fu.recompute_tanh, fu.recompute_h1 = recompute
+        net._flat_grads.zero_()
+        lg, vl = fu.forward(x)
+        assert torch.allclose(lg, ref_logits, atol=1e-5, rtol=1e-5) and torch.allclose(vl, ref_value, atol=1e-5, rtol=1e-5)
+        fu.backward(dl, dv)
+        for k, p in net.named_parameters():
+            scale = float(ref[k].abs().max()) + 1e-12
+            err = float((p.grad - ref[k]).abs().max()) / scale
+            assert err <= 2e-4, (k, err, recompute)
+        grads[recompute] = net._flat_grads.clone()
+    # recomputing an activation in backward reproduces the stored one bit for bit
+    assert torch.equal(grads[(True, False)], grads[(False, False)]) and torch.equal(grads[(True, True)], grads[(False, False)])
 
 
 # ---------------------------------------------------------- persistent rollout ---
