@@ -340,13 +340,14 @@ __global__ __launch_bounds__(kTB) void smallk_finalize_kernel(const float* __res
 // dZac [B, 2C] = [ (dlogits Wa2) * (1 - Ha^2) | (dv Wc2) * (1 - Hc^2) ]
 // partial row: [dbac (2C) | dWa2 (A*C) | dWc2 (C) | dba2.. (C: only first A+1 used)]
 template <int A>
-__global__ __launch_bounds__(kTB) void heads_bwd_kernel(const float* __restrict__ Hac, const float* __restrict__ dlogits,
+__global__ __launch_bounds__(kTB) void heads_bwd_kernel(const float* Hac, const float* __restrict__ dlogits,
                                                         const float* __restrict__ dv, int64_t B, int C,
                                                         const float* __restrict__ Wa2, const float* __restrict__ Wc2,
-                                                        float* __restrict__ dZac, float* __restrict__ partials,
+                                                        float* dZac, float* __restrict__ partials,
                                                         int pre_activation, const float* __restrict__ bac) {
   extern __shared__ float sm[];
   const RowMap m(C, threadIdx.x & 63);
+  const bool in_place = dZac == Hac;
   f32x4 pa = {0.0f, 0.0f, 0.0f, 0.0f}, pc = {0.0f, 0.0f, 0.0f, 0.0f};
   if (pre_activation && bac) {
     pa = *reinterpret_cast<const f32x4*>(bac + 4 * m.c4);
@@ -368,8 +369,14 @@ __global__ __launch_bounds__(kTB) void heads_bwd_kernel(const float* __restrict_
   const int64_t stride = (int64_t)gridDim.x * (kTB / 64) * m.rpw;
   for (int64_t r = ((int64_t)blockIdx.x * (kTB / 64) + (threadIdx.x >> 6)) * m.rpw + m.r_in; r < B; r += stride) {
     const size_t o = (size_t)r * 2 * C + 4 * m.c4;
-    f32x4 ha = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Hac + o));
-    f32x4 hc = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Hac + o + C));
+    f32x4 ha, hc;
+    if (in_place) {       // dZac overwrites Hac: read-modify-write of the same lines, regular accesses (as tanh_inplace)
+      ha = *reinterpret_cast<const f32x4*>(Hac + o);
+      hc = *reinterpret_cast<const f32x4*>(Hac + o + C);
+    } else {
+      ha = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Hac + o));
+      hc = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Hac + o + C));
+    }
     if (pre_activation) {   // Hac holds actor.0 / critic.0 pre-activations: the forward's tanh, bit for bit
 #pragma unroll
       for (int j = 0; j < 4; ++j) { ha[j] = fast_tanhf(ha[j] + pa[j]); hc[j] = fast_tanhf(hc[j] + pc[j]); }
@@ -396,8 +403,13 @@ __global__ __launch_bounds__(kTB) void heads_bwd_kernel(const float* __restrict_
 #pragma unroll
     for (int a = 0; a < A; ++a) acc[12 + 4 * A + a] += dl[a];
     acc[12 + 4 * A + A] += dvr;
-    __builtin_nontemporal_store(za, reinterpret_cast<f32x4*>(dZac + o));
-    __builtin_nontemporal_store(zc, reinterpret_cast<f32x4*>(dZac + o + C));
+    if (in_place) {
+      *reinterpret_cast<f32x4*>(dZac + o) = za;
+      *reinterpret_cast<f32x4*>(dZac + o + C) = zc;
+    } else {
+      __builtin_nontemporal_store(za, reinterpret_cast<f32x4*>(dZac + o));
+      __builtin_nontemporal_store(zc, reinterpret_cast<f32x4*>(dZac + o + C));
+    }
   }
   // only the c4 == 0 lane of a row group contributes the dlogits / dv sums (they are lane-redundant)
   if (m.c4 != 0) {
@@ -518,7 +530,7 @@ int gymrl_heads_fwd_tanh(float* Zac, int64_t B, int C, int A, const float* bac, 
   // that write block partials (no workspace bounds the grid here)
   const int64_t rows_per_block = (kTB / 64) * (64 / (C / 4));
   const int64_t want = (B + rows_per_block - 1) / rows_per_block;
-  const dim3 grid((unsigned)(want < 4 * kMaxBlocks ? (want < 1 ? 1 : want) : 4 * kMaxBlocks)), block(kTB);
+  const dim3 grid((unsigned)(want < 8 * kMaxBlocks ? (want < 1 ? 1 : want) : 8 * kMaxBlocks)), block(kTB);
   if (A == 4) hipLaunchKernelGGL(heads_fwd_tanh_kernel<4>, grid, block, 0, s, Zac, B, C, bac, Wa2, ba2, Wc2, bc2, logits, value, store_h);
   else if (A == 2) hipLaunchKernelGGL(heads_fwd_tanh_kernel<2>, grid, block, 0, s, Zac, B, C, bac, Wa2, ba2, Wc2, bc2, logits, value, store_h);
   else return -22;

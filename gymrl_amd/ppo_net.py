@@ -70,7 +70,7 @@ class FusedActorCriticUpdate:
         self.H1 = torch.empty(R, H, device=dev)
         self.H2 = torch.empty(R, H, device=dev)
         self.Hac = torch.empty(R, 2 * H, device=dev)
-        self.dZac = torch.empty(R, 2 * H, device=dev)
+        self._dZac = None            # only allocated when heads_bwd does not run in place
         self.dH2 = torch.empty(R, H, device=dev)
         self.dH1 = torch.empty(R, H, device=dev)
         self.logits = torch.empty(R, self.A, device=dev)
@@ -80,6 +80,7 @@ class FusedActorCriticUpdate:
         self.timers = None      # bench.py: KernelTimers bracketing the hand-written HBM passes
         self.fused_heads_forward = True
         self.recompute_tanh = True      # heads_fwd does not store tanh(Zac); heads_bwd recomputes it (2 KB/row less traffic)
+        self.bwd_in_place = True        # heads_bwd writes dZac over the pre-activations it just read (they are dead after it)
         self.recompute_h1 = False       # linear_smallk_bwd recomputing H1 from x: 1 KB/row less traffic but 102 -> 115 us
                                         # (the pass is issue-bound once H1 is not read), measured and left off
         self.bias_in_gemm = False
@@ -151,7 +152,9 @@ class FusedActorCriticUpdate:
         m, x, H = self.m, self._x, self.H
         B = x.shape[0]
         H1, H2, Hac = self.H1[:B], self.H2[:B], self.Hac[:B]
-        dZac, dH2, dH1 = self.dZac[:B], self.dH2[:B], self.dH1[:B]
+        if not self.bwd_in_place and self._dZac is None:
+            self._dZac = torch.empty_like(self.Hac)
+        dZac, dH2, dH1 = (Hac if self.bwd_in_place else self._dZac[:B]), self.dH2[:B], self.dH1[:B]
         self._timed("heads_bwd", B, ops.heads_bwd, Hac, dlogits, dvalues.view(-1), m.actor[2].weight,
                     m.critic[2].weight, dZac, self.dbac, m.actor[2].weight.grad, m.actor[2].bias.grad,
                     m.critic[2].weight.grad, m.critic[2].bias.grad, self.ws, self._pre,
