@@ -8,9 +8,11 @@ is scheduled by hand:
     forward   H1  = tanh(X W1^T + b1)                 gymrl_linear_tanh_smallk   (K = obs_dim)
               H2  = tanh(H1 W2^T + b2)                addmm (hipBLASLt) + gymrl_tanh_inplace
               Zac = H2 [Wa1;Wc1]^T + [ba1;bc1]        ONE GEMM for actor.0 and critic.0 (N = 512)
-              Hac = tanh(Zac), logits = Ha Wa2^T + ba2, v = Hc Wc2^T + bc2
-                                                      gymrl_heads_fwd_tanh: one pass, heads from registers
-    backward  dZac, dbac, dWa2, dba2, dWc2, dbc2      gymrl_heads_bwd: one pass over Hac
+              logits = tanh(Za) Wa2^T + ba2, v = tanh(Zc) Wc2^T + bc2
+                                                      gymrl_heads_fwd_tanh: one READ-ONLY pass over Zac, heads from
+                                                      registers; tanh(Zac) is not written back
+    backward  dZac, dbac, dWa2, dba2, dWc2, dbc2      gymrl_heads_bwd: one pass over Zac (recomputes the same tanh,
+                                                      writes dZac in place over the pre-activations)
               d[Wa1;Wc1] = dZac^T H2                  split-K batched GEMM
               dH2 = dZac [Wa1;Wc1]                    ONE GEMM (K = 512): no gradient accumulation
               dZ2 = dH2 (1 - H2^2), db2               gymrl_tanh_bwd_colsum (in place)
