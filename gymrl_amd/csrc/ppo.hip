@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kBlock) void ppo_full_loss_kernel(
     const int32_t* __restrict__ idx, const int32_t* __restrict__ act,
     const float* __restrict__ logp_old, const float* __restrict__ ent_old,
     const float* __restrict__ adv, const float* __restrict__ ret, int B, gymrl_ppo_full_cfg cfg,
-    float* __restrict__ dlogits_out, float* __restrict__ dvalue_out,
+    const float* __restrict__ corr_mul, float* __restrict__ dlogits_out, float* __restrict__ dvalue_out,
     double* __restrict__ partials) {
   double met[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int b = blockIdx.x * kBlock + threadIdx.x; b < B; b += gridDim.x * kBlock) {
@@ -177,7 +177,9 @@ __global__ __launch_bounds__(kBlock) void ppo_full_loss_kernel(
     const float invB = 1.0f / (float)B;
     // entropy-ratio mask (no gradient) — :586-590
     const float er = H / (eo + 1e-8f);
-    const float corr = (er > (1.0f - cfg.erc_beta_low) && er < (1.0f + cfg.erc_beta_high)) ? 1.0f : 0.0f;
+    const float erc = (er > (1.0f - cfg.erc_beta_low) && er < (1.0f + cfg.erc_beta_high)) ? 1.0f : 0.0f;
+    float corr = erc;
+    if (corr_mul) corr *= corr_mul[b];               // covariance clip (:611-616): rows picked on the host side of the API
     const float ratio = det_expf(lp - lpo);
     const float lo = 1.0f - cfg.clip_eps_min, hi = 1.0f + cfg.clip_eps_max;
     const float r1 = fminf(fmaxf(ratio, 0.0f), cfg.dual_clip);
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void ppo_full_loss_kernel(
     met[2] += (double)(H * corr);
     met[3] += (ratio < lo || ratio > hi) ? (double)corr : 0.0;
     met[4] += (double)(lpo - lp);
-    met[5] += 1.0 - (double)corr;
+    met[5] += 1.0 - (double)erc;                     // erc_clip_frac is over the entropy-ratio mask alone (:652)
     met[6] += (double)lp;
     met[7] += (double)ad;
     met[8] += (double)lp * (double)ad;
@@ -222,14 +224,16 @@ template <int A>
 __global__ __launch_bounds__(kBlock) void erc_count_kernel(const float* __restrict__ logits,
                                                            const int32_t* __restrict__ idx,
                                                            const float* __restrict__ ent_old, int B,
-                                                           gymrl_ppo_full_cfg cfg, uint32_t* __restrict__ count) {
+                                                           gymrl_ppo_full_cfg cfg, const float* __restrict__ corr_mul,
+                                                           uint32_t* __restrict__ count) {
   uint32_t c = 0;
   for (int b = blockIdx.x * kBlock + threadIdx.x; b < B; b += gridDim.x * kBlock) {
     float z[A], ln[A], p[A], H;
     load_row<A>(logits, b, z);
     log_softmax<A>(z, ln, p, H);
     const float er = H / (ent_old[idx ? idx[b] : b] + 1e-8f);
-    c += (er > (1.0f - cfg.erc_beta_low) && er < (1.0f + cfg.erc_beta_high)) ? 1u : 0u;
+    const bool in = er > (1.0f - cfg.erc_beta_low) && er < (1.0f + cfg.erc_beta_high);
+    c += (in && (!corr_mul || corr_mul[b] != 0.0f)) ? 1u : 0u;
   }
   const uint64_t m = __ballot(c & 1u);               // at most a few rows per thread: add them bit by bit
   uint32_t w = (uint32_t)__popcll(m);
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void ppo_rnn_loss_kernel(
     const int32_t* __restrict__ idx, const int32_t* __restrict__ act,
     const float* __restrict__ logp_old, const float* __restrict__ ent_old,
     const float* __restrict__ val_old, const float* __restrict__ adv, const float* __restrict__ ret,
-    int B, gymrl_ppo_full_cfg cfg, const uint32_t* __restrict__ count,
+    int B, gymrl_ppo_full_cfg cfg, const uint32_t* __restrict__ count, const float* __restrict__ corr_mul,
     float* __restrict__ dlogits_out, float* __restrict__ dvalue_out, double* __restrict__ partials) {
   double met[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const uint32_t cnt = *count;
@@ -265,7 +269,9 @@ __global__ __launch_bounds__(kBlock) void ppo_rnn_loss_kernel(
     for (int k = 1; k < A; ++k) if (a == k) lp = ln[k];
 
     const float er = H / (eo + 1e-8f);
-    const float corr = (er > (1.0f - cfg.erc_beta_low) && er < (1.0f + cfg.erc_beta_high)) ? 1.0f : 0.0f;
+    const float erc = (er > (1.0f - cfg.erc_beta_low) && er < (1.0f + cfg.erc_beta_high)) ? 1.0f : 0.0f;
+    float corr = erc;
+    if (corr_mul) corr *= corr_mul[b];               // covariance clip (:611-616): rows picked on the host side of the API
     const float ratio = det_expf(lp - lpo);
     const float lo = 1.0f - cfg.clip_eps_min, hi = 1.0f + cfg.clip_eps_max;
     const float r1 = fminf(fmaxf(ratio, 0.0f), cfg.dual_clip);
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void ppo_rnn_loss_kernel(
     met[2] += (double)(H * corr);
     met[3] += (ratio < lo || ratio > hi) ? (double)corr : 0.0;
     met[4] += (double)(lpo - lp);
-    met[5] += 1.0 - (double)corr;
+    met[5] += 1.0 - (double)erc;                     // erc_clip_frac is over the entropy-ratio mask alone (:652)
     met[6] += (double)lp;
     met[7] += (double)ad;
     met[8] += (double)lp * (double)ad;
@@ -468,7 +474,7 @@ int gymrl_ppo_loss_fwd_bwd(const float* logits, const float* value, const int32_
 int gymrl_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const int32_t* idx,
                                 const int32_t* act, const float* logp_old, const float* ent_old,
                                 const float* adv, const float* ret, int B, int n_actions,
-                                const gymrl_ppo_full_cfg* cfg_host, float* dlogits_out,
+                                const gymrl_ppo_full_cfg* cfg_host, const float* corr_mul, float* dlogits_out,
                                 float* dvalue_out, double* metrics_sum, void* workspace,
                                 void* stream_) {
   if (!logits || !value || !act || !logp_old || !ent_old || !adv || !ret || !cfg_host ||
@@ -481,7 +487,7 @@ int gymrl_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const i
   double* parts = (double*)workspace;
   DISPATCH_A(n_actions,
              hipLaunchKernelGGL(ppo_full_loss_kernel<A>, dim3(nb), dim3(kBlock), 0,
-                                stream, logits, value, idx, act, logp_old, ent_old, adv, ret, B, cfg,
+                                stream, logits, value, idx, act, logp_old, ent_old, adv, ret, B, cfg, corr_mul,
                                 dlogits_out, dvalue_out, parts));
   if (metrics_sum)
     hipLaunchKernelGGL(metrics_finalize_kernel<9>, dim3(1), dim3(kBlock), 0, stream, parts, nb,
@@ -505,7 +511,7 @@ int gymrl_permutation(uint64_t seed, uint64_t counter, int64_t M, int32_t* perm_
 int gymrl_ppo_rnn_loss_fwd_bwd(const float* logits, const float* value, const int32_t* idx,
                                const int32_t* act, const float* logp_old, const float* ent_old,
                                const float* val_old, const float* adv, const float* ret, int B, int n_actions,
-                               const gymrl_ppo_full_cfg* cfg_host, float* dlogits_out,
+                               const gymrl_ppo_full_cfg* cfg_host, const float* corr_mul, float* dlogits_out,
                                float* dvalue_out, double* metrics_sum, void* workspace, void* stream_) {
   if (!logits || !value || !act || !logp_old || !ent_old || !val_old || !adv || !ret || !cfg_host ||
       !dlogits_out || !dvalue_out || !workspace || B < 0 || B > (1 << 24))
@@ -519,10 +525,10 @@ int gymrl_ppo_rnn_loss_fwd_bwd(const float* logits, const float* value, const in
   if (hipMemsetAsync(count, 0, sizeof(uint32_t), stream) != hipSuccess) return -1000 - (int)hipGetLastError();
   DISPATCH_A(n_actions,
              hipLaunchKernelGGL(erc_count_kernel<A>, dim3(nb), dim3(kBlock), 0, stream, logits, idx, ent_old, B,
-                                cfg, count));
+                                cfg, corr_mul, count));
   DISPATCH_A(n_actions,
              hipLaunchKernelGGL(ppo_rnn_loss_kernel<A>, dim3(nb), dim3(kBlock), 0, stream, logits, value, idx,
-                                act, logp_old, ent_old, val_old, adv, ret, B, cfg, count, dlogits_out,
+                                act, logp_old, ent_old, val_old, adv, ret, B, cfg, count, corr_mul, dlogits_out,
                                 dvalue_out, metrics_sum ? parts : nullptr));
   if (metrics_sum)
     hipLaunchKernelGGL(metrics_finalize_kernel<10>, dim3(1), dim3(kBlock), 0, stream, parts, nb,

@@ -165,7 +165,7 @@ def ppo_loss_fwd_bwd(logits, value, act, logp_old, adv, ret, cfg, idx=None, adv_
 
 
 def ppo_full_loss_fwd_bwd(logits, value, act, logp_old, ent_old, adv, ret, cfg, idx=None, dlogits_out=None,
-                          dvalue_out=None, metrics_sum=None, workspace=None):
+                          dvalue_out=None, metrics_sum=None, workspace=None, corr_mul=None):
     """L3 (ppo_full_lunarlander.py:575-652)."""
     B, A = logits.shape
     dlogits_out = torch.empty_like(logits) if dlogits_out is None else dlogits_out
@@ -177,14 +177,15 @@ def ppo_full_loss_fwd_bwd(logits, value, act, logp_old, ent_old, adv, ret, cfg, 
                                             _ptr(idx, torch.int32, True), _ptr(act, torch.int32),
                                             _ptr(logp_old, torch.float32), _ptr(ent_old, torch.float32),
                                             _ptr(adv, torch.float32), _ptr(ret, torch.float32), C.c_int(B),
-                                            C.c_int(A), C.byref(c), _ptr(dlogits_out), _ptr(dvalue_out),
-                                            _ptr(metrics_sum, torch.float64, True),
+                                            C.c_int(A), C.byref(c), _ptr(corr_mul, torch.float32, True), _ptr(dlogits_out),
+                                            _ptr(dvalue_out), _ptr(metrics_sum, torch.float64, True),
                                             _ptr(workspace, None, True), _stream()),
           "gymrl_ppo_full_loss_fwd_bwd")
     return dlogits_out, dvalue_out
 
 
-def ppo_rnn_loss_fwd_bwd(logits, value, act, logp_old, ent_old, val_old, adv, ret, cfg, idx=None, metrics_sum=None):
+def ppo_rnn_loss_fwd_bwd(logits, value, act, logp_old, ent_old, val_old, adv, ret, cfg, idx=None, metrics_sum=None,
+                         corr_mul=None):
     """L4 (ppo_lstm_lunarlander.py:716-776): masked means + clipped value loss.  metrics_sum f64[10]."""
     B, A = logits.shape
     dlogits, dvalue = torch.empty_like(logits), torch.empty(B, dtype=torch.float32, device=logits.device)
@@ -193,7 +194,8 @@ def ppo_rnn_loss_fwd_bwd(logits, value, act, logp_old, ent_old, val_old, adv, re
                                            _ptr(idx, torch.int32, True), _ptr(act, torch.int32),
                                            _ptr(logp_old, torch.float32), _ptr(ent_old, torch.float32),
                                            _ptr(val_old, torch.float32), _ptr(adv, torch.float32),
-                                           _ptr(ret, torch.float32), C.c_int(B), C.c_int(A), C.byref(c), _ptr(dlogits),
+                                           _ptr(ret, torch.float32), C.c_int(B), C.c_int(A), C.byref(c),
+                                           _ptr(corr_mul, torch.float32, True), _ptr(dlogits),
                                            _ptr(dvalue), _ptr(metrics_sum, torch.float64, True),
                                            _ptr(_reduce_ws(logits.device)), _stream()), "gymrl_ppo_rnn_loss_fwd_bwd")
     return dlogits, dvalue

@@ -149,6 +149,27 @@ class MHCBackbone(nn.Module):
         return self.final_norm(h.sum(dim=1))
 
 
+@torch.no_grad()
+def cov_clip_mask(cfg, logits, act_b, adv_b, generator=None, perm=None):
+    """Covariance clip of ppo_full_lunarlander.py:594-616 (ppo_lstm :729-753): among the minibatch rows whose
+    (log-prob - mean) * (advantage - mean) lies in (clip_cov_min, clip_cov_max), a random clip_cov_ratio of them
+    (at least one) is taken out of every masked mean.  Returns the f32[B] multiplier the loss kernels take as
+    `corr_mul`, or None when the branch is off.  `perm` replays an explicit torch.randperm (parity tests)."""
+    if cfg.clip_cov_ratio <= 0:
+        return None
+    lp = torch.log_softmax(logits, dim=-1).gather(1, act_b.long().unsqueeze(1)).squeeze(1)
+    covs = (lp - lp.mean()) * (adv_b - adv_b.mean())
+    cand = torch.where((covs > cfg.clip_cov_min) & (covs < cfg.clip_cov_max))[0]     # one host read: the branch is optional
+    mul = torch.ones_like(adv_b)
+    n = int(cand.numel())
+    if n > 0:
+        k = min(max(int(n * cfg.clip_cov_ratio), 1), n)
+        if perm is None:
+            perm = torch.randperm(n, device=logits.device, generator=generator)
+        mul[cand[torch.as_tensor(perm, device=logits.device).long()[:k]]] = 0.0
+    return mul
+
+
 class MLP(nn.Module):
     """Linear -> SiLU -> RMSNorm -> ... -> Linear [-> SiLU -> RMSNorm when last_act]; keys `mlp.<i>` (:371-402)."""
 
@@ -246,8 +267,6 @@ class RolloutBuffer:
 class PPOTrainer:
     def __init__(self, config):
         self.cfg = config
-        if config.clip_cov_ratio != 0:
-            raise NotImplementedError("clip_cov_ratio > 0 (the covariance-clip branch, :611-616) is not built")
         if not torch.cuda.is_available() or not ops.device_ok():
             raise RuntimeError("gymrl_amd PPO-full needs an MI355X and libgymrl_hip.so; no CPU fallback")
         self.rank, self.world_size = gdist.rank(), gdist.world_size()
@@ -334,8 +353,12 @@ class PPOTrainer:
         def minibatch(idx, metrics_row, bias=None):
             logits, values = self.model(states.index_select(0, idx))
             values = values.view(-1)
+            mul = None
+            if cfg.clip_cov_ratio > 0:                                     # :594-616 (off by default)
+                li = idx.long()
+                mul = cov_clip_mask(cfg, logits.detach(), act.index_select(0, li), adv.index_select(0, li), self._perm_gen)
             dlogits, dvalues = ops.ppo_full_loss_fwd_bwd(logits, values, act, lp, ent_old, adv, ret, lcfg, idx=idx,
-                                                         metrics_sum=metrics_row)
+                                                         metrics_sum=metrics_row, corr_mul=mul)
             self._sink.arm()
             torch.autograd.backward([logits, values], [dlogits, dvalues])
             self._sink.collect()
@@ -348,7 +371,7 @@ class PPOTrainer:
         # (rollout tensors and the annealed entropy coefficient are constants of that call) and replayed
         # (gymrl_amd/graphs.py).  The first two minibatches ever run eagerly (library warm-up).
         graphed = (bool(getattr(cfg, "use_graphs", True)) and self.world_size == 1 and total % mb == 0
-                   and cfg.num_epochs * n_mb > 2)
+                   and cfg.num_epochs * n_mb > 2 and cfg.clip_cov_ratio <= 0)      # the covariance clip reads the host
         graph = None
         if graphed and self._g_idx is None:
             from .graphs import StepScalars

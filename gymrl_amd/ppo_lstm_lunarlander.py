@@ -27,7 +27,7 @@ from . import dist as gdist
 from . import ops
 from .envs import VecEnv
 from .flat import FusedAdam, GradSink, flatten_module
-from .ppo_full_lunarlander import MLP, PSCN, MHCBackbone, RMSNorm  # noqa: F401  (part of this module's surface)
+from .ppo_full_lunarlander import MLP, PSCN, MHCBackbone, RMSNorm, cov_clip_mask  # noqa: F401  (part of this module's surface)
 
 
 class Config:
@@ -188,8 +188,6 @@ class RolloutBuffer:
 class PPOTrainer:
     def __init__(self, config):
         self.cfg = config
-        if config.clip_cov_ratio != 0:
-            raise NotImplementedError("clip_cov_ratio > 0 (the covariance-clip branch, :747-753) is not built")
         if not torch.cuda.is_available() or not ops.device_ok():
             raise RuntimeError("gymrl_amd recurrent PPO needs an MI355X and libgymrl_hip.so; no CPU fallback")
         N, T, L = int(config.num_envs), int(config.update_freq), int(config.seq_len)
@@ -294,8 +292,12 @@ class PPOTrainer:
             s_batch = states.index_select(0, rows.reshape(-1)).view(mb, L, -1)
             logits, values, _, predict, target = self.model(s_batch, hidden_flat.index_select(0, first))
             logits_flat, values_flat = logits.reshape(mb * L, -1), values.reshape(-1)
+            mul = None
+            if cfg.clip_cov_ratio > 0:                                     # :729-753 (off by default)
+                li = idx.long()
+                mul = cov_clip_mask(cfg, logits_flat.detach(), act.index_select(0, li), adv.index_select(0, li), self._perm_gen)
             dlogits, dvalues = ops.ppo_rnn_loss_fwd_bwd(logits_flat.detach(), values_flat.detach(), act, lp, ent_old,
-                                                        val_old, adv, ret, lcfg, idx=idx, metrics_sum=metrics_row)
+                                                        val_old, adv, ret, lcfg, idx=idx, metrics_sum=metrics_row, corr_mul=mul)
             rnd_loss = (predict - target).pow(2).mean()                    # :775
             self._sink.arm()
             torch.autograd.backward([logits_flat, values_flat, rnd_loss], [dlogits, dvalues, None])
@@ -307,7 +309,7 @@ class PPOTrainer:
 
         # Same scheme as PPO-full: the minibatch body is captured once per update_model() call and replayed.
         graphed = (bool(getattr(cfg, "use_graphs", True)) and self.world_size == 1 and self.grad_norms is None
-                   and cfg.num_epochs * n_mb > 2)
+                   and cfg.num_epochs * n_mb > 2 and cfg.clip_cov_ratio <= 0)
         graph = None
         if graphed and self._g_seq is None:
             from .graphs import StepScalars

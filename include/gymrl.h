@@ -225,15 +225,16 @@ typedef struct {
 
 /* L3: ppo_full update_model minibatch loss — ppo_full_lunarlander.py:575-652.
  * ent_old f32[*] = behaviour-policy entropy stored at collection (:488).
- * clip_cov_ratio must be 0 (the reference default, :44) — the cov-clip branch
- * :611-616 is then dead and is not implemented.
+ * corr_mul f32[B] or NULL: per-row multiplier of the entropy-ratio mask — the covariance clip :611-616
+ * (clip_cov_ratio > 0; dead under the reference default :44): the caller picks the rows (covs window, random
+ * subset of clip_cov_ratio of them) and passes 0 for those, 1 elsewhere.
  * metrics_sum f64[9]: += (sum policy term, sum 0.5*corr*(v-ret)^2, sum H*corr,
  * sum clipped*corr, sum (logp_old-logp), #erc-masked, sum logp, sum adv,
  * sum logp*adv) — the last three give covs.mean() (:594-596) per minibatch. */
 int gymrl_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const int32_t* idx,
                                 const int32_t* act, const float* logp_old,
                                 const float* ent_old, const float* adv, const float* ret,
-                                int B, int A, const gymrl_ppo_full_cfg* cfg_host,
+                                int B, int A, const gymrl_ppo_full_cfg* cfg_host, const float* corr_mul,
                                 float* dlogits_out, float* dvalue_out,
                                 double* metrics_sum, void* workspace, void* stream);
 
@@ -244,12 +245,13 @@ int gymrl_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const i
  * val_old f32[*] = values stored at collection.  The RND loss (:775) is a plain mean of squares and stays with
  * the network's autograd.  metrics_sum f64[10]: the nine L3 sums (index 1 = sum 0.5*corr*max(...)) followed by
  * sum(corr); the caller divides sums 0..3 by metrics_sum[9] (or reports 0 when it is 0).
+ * corr_mul as in gymrl_ppo_full_loss_fwd_bwd (:747-753).
  * workspace >= gymrl_reduce_workspace_bytes(). */
 int gymrl_ppo_rnn_loss_fwd_bwd(const float* logits, const float* value, const int32_t* idx,
                                const int32_t* act, const float* logp_old, const float* ent_old,
                                const float* val_old, const float* adv, const float* ret, int B, int A,
-                               const gymrl_ppo_full_cfg* cfg_host, float* dlogits_out, float* dvalue_out,
-                               double* metrics_sum, void* workspace, void* stream);
+                               const gymrl_ppo_full_cfg* cfg_host, const float* corr_mul, float* dlogits_out,
+                               float* dvalue_out, double* metrics_sum, void* workspace, void* stream);
 
 /* Pointwise half of torch.nn.GRU's cell as used by URNN — ppo_lstm_lunarlander.py:449-491 (nn.GRU,
  * batch_first, one layer).  gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh, both f32[B,3H] in PyTorch's gate

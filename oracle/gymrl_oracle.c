@@ -353,7 +353,7 @@ typedef struct {
 void orc_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const int32_t* idx,
                                const int32_t* act, const float* logp_old, const float* ent_old,
                                const float* adv, const float* ret, int B, int A,
-                               const orc_ppo_full_cfg* cfg, float* dlogits_out,
+                               const orc_ppo_full_cfg* cfg, const float* corr_mul, float* dlogits_out,
                                float* dvalue_out, double* metrics_sum) {
   double met[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const float invB = 1.0f / (float)B;
@@ -367,7 +367,9 @@ void orc_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const in
     log_softmax(z, A, ln, p, &H);
     float lp = ln[a];
     float er = H / (ent_old[i] + 1e-8f);                              /* :586 */
-    float corr = (er > (1.0f - cfg->erc_beta_low) && er < (1.0f + cfg->erc_beta_high)) ? 1.0f : 0.0f;
+    float erc = (er > (1.0f - cfg->erc_beta_low) && er < (1.0f + cfg->erc_beta_high)) ? 1.0f : 0.0f;
+    float corr = erc;
+    if (corr_mul) corr *= corr_mul[b];                                /* covariance clip :611-616 / :747-753 */
     float ratio = orc_expf(lp - logp_old[i]);                         /* :593 */
     float r1 = fminf(fmaxf(ratio, 0.0f), cfg->dual_clip);             /* :600 */
     float r2 = fminf(fmaxf(ratio, lo), hi);                           /* :603-607 */
@@ -390,7 +392,7 @@ void orc_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const in
     met[2] += (double)(H * corr);
     met[3] += (ratio < lo || ratio > hi) ? (double)corr : 0.0;        /* :617-623 */
     met[4] += (double)(logp_old[i] - lp);
-    met[5] += 1.0 - (double)corr;                                     /* :652 */
+    met[5] += 1.0 - (double)erc;                                     /* :652 */
     met[6] += (double)lp; met[7] += (double)ad; met[8] += (double)lp * (double)ad;
   }
   if (metrics_sum) for (int k = 0; k < 9; ++k) metrics_sum[k] += met[k];
@@ -401,8 +403,8 @@ void orc_ppo_full_loss_fwd_bwd(const float* logits, const float* value, const in
 void orc_ppo_rnn_loss_fwd_bwd(const float* logits, const float* value, const int32_t* idx,
                               const int32_t* act, const float* logp_old, const float* ent_old,
                               const float* val_old, const float* adv, const float* ret, int B, int A,
-                              const orc_ppo_full_cfg* cfg, float* dlogits_out, float* dvalue_out,
-                              double* metrics_sum) {
+                              const orc_ppo_full_cfg* cfg, const float* corr_mul, float* dlogits_out,
+                              float* dvalue_out, double* metrics_sum) {
   double met[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const float lo = 1.0f - cfg->clip_eps_min, hi = 1.0f + cfg->clip_eps_max;
   unsigned cnt = 0;
@@ -410,7 +412,7 @@ void orc_ppo_rnn_loss_fwd_bwd(const float* logits, const float* value, const int
     float ln[8], p[8], H;
     log_softmax(logits + (size_t)b * A, A, ln, p, &H);
     float er = H / (ent_old[idx ? idx[b] : b] + 1e-8f);
-    cnt += (er > (1.0f - cfg->erc_beta_low) && er < (1.0f + cfg->erc_beta_high)) ? 1u : 0u;
+    cnt += (er > (1.0f - cfg->erc_beta_low) && er < (1.0f + cfg->erc_beta_high) && (!corr_mul || corr_mul[b] != 0.0f)) ? 1u : 0u;
   }
   const float inv = cnt ? 1.0f / (float)cnt : 0.0f;                   /* masked_mean: sum / count, 0 if empty */
   for (int b = 0; b < B; ++b) {
@@ -422,7 +424,9 @@ void orc_ppo_rnn_loss_fwd_bwd(const float* logits, const float* value, const int
     log_softmax(z, A, ln, p, &H);
     float lp = ln[a];
     float er = H / (ent_old[i] + 1e-8f);
-    float corr = (er > (1.0f - cfg->erc_beta_low) && er < (1.0f + cfg->erc_beta_high)) ? 1.0f : 0.0f;
+    float erc = (er > (1.0f - cfg->erc_beta_low) && er < (1.0f + cfg->erc_beta_high)) ? 1.0f : 0.0f;
+    float corr = erc;
+    if (corr_mul) corr *= corr_mul[b];                                /* covariance clip :611-616 / :747-753 */
     float ratio = orc_expf(lp - logp_old[i]);                         /* :728 */
     float r1 = fminf(fmaxf(ratio, 0.0f), cfg->dual_clip);             /* :734 */
     float r2 = fminf(fmaxf(ratio, lo), hi);                           /* :736-741 */
@@ -451,7 +455,7 @@ void orc_ppo_rnn_loss_fwd_bwd(const float* logits, const float* value, const int
     met[2] += (double)(H * corr);
     met[3] += (ratio < lo || ratio > hi) ? (double)corr : 0.0;
     met[4] += (double)(logp_old[i] - lp);
-    met[5] += 1.0 - (double)corr;
+    met[5] += 1.0 - (double)erc;
     met[6] += (double)lp; met[7] += (double)ad; met[8] += (double)lp * (double)ad;
     met[9] += (double)corr;
   }

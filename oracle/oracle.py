@@ -198,7 +198,7 @@ def ppo_loss_fwd_bwd(logits, value, act, logp_old, adv, ret, cfg, idx=None, adv_
     return dl, dv, met
 
 
-def ppo_full_loss_fwd_bwd(logits, value, act, logp_old, ent_old, adv, ret, cfg, idx=None):
+def ppo_full_loss_fwd_bwd(logits, value, act, logp_old, ent_old, adv, ret, cfg, idx=None, corr_mul=None):
     logits, value = _f32(logits), _f32(value)
     B, A = logits.shape
     act, logp_old, ent_old, adv, ret = _i32(act), _f32(logp_old), _f32(ent_old), _f32(adv), _f32(ret)
@@ -207,11 +207,12 @@ def ppo_full_loss_fwd_bwd(logits, value, act, logp_old, ent_old, adv, ret, cfg, 
     met = np.zeros(9, np.float64)
     c = PPOFullCfg(*cfg)
     lib().orc_ppo_full_loss_fwd_bwd(_p(logits), _p(value), _p(idx_), _p(act), _p(logp_old), _p(ent_old),
-                                    _p(adv), _p(ret), C.c_int(B), C.c_int(A), C.byref(c), _p(dl), _p(dv), _p(met))
+                                    _p(adv), _p(ret), C.c_int(B), C.c_int(A), C.byref(c),
+                                    _p(None if corr_mul is None else _f32(corr_mul)), _p(dl), _p(dv), _p(met))
     return dl, dv, met
 
 
-def ppo_rnn_loss_fwd_bwd(logits, value, act, logp_old, ent_old, val_old, adv, ret, cfg, idx=None):
+def ppo_rnn_loss_fwd_bwd(logits, value, act, logp_old, ent_old, val_old, adv, ret, cfg, idx=None, corr_mul=None):
     logits, value = _f32(logits), _f32(value)
     B, A = logits.shape
     act, logp_old, ent_old, val_old, adv, ret = _i32(act), _f32(logp_old), _f32(ent_old), _f32(val_old), _f32(adv), _f32(ret)
@@ -220,7 +221,8 @@ def ppo_rnn_loss_fwd_bwd(logits, value, act, logp_old, ent_old, val_old, adv, re
     met = np.zeros(10, np.float64)
     c = PPOFullCfg(*cfg)
     lib().orc_ppo_rnn_loss_fwd_bwd(_p(logits), _p(value), _p(idx_), _p(act), _p(logp_old), _p(ent_old), _p(val_old),
-                                   _p(adv), _p(ret), C.c_int(B), C.c_int(A), C.byref(c), _p(dl), _p(dv), _p(met))
+                                   _p(adv), _p(ret), C.c_int(B), C.c_int(A), C.byref(c),
+                                   _p(None if corr_mul is None else _f32(corr_mul)), _p(dl), _p(dv), _p(met))
     return dl, dv, met
 
 

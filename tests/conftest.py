@@ -38,3 +38,17 @@ def rel_close(a, b, tol=1e-5):
     b = np.asarray(b, np.float64)
     err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
     return float(err.max()) if err.size else 0.0
+
+
+def cov_clip_mul(g, k):
+    """corr_mul of golden case k of ppo_full_loss.npz: None unless the case ran the covariance clip, else the rows
+    gymrl_amd's cov_clip_mask picks when fed the reference's own randperm."""
+    if g[f"c{k}_cov_perm"].size == 0:
+        return None
+    import types
+    import torch
+    from gymrl_amd.ppo_full_lunarlander import cov_clip_mask
+    ratio, cmin, cmax = (float(x) for x in g[f"c{k}_cov_cfg"])
+    cfg = types.SimpleNamespace(clip_cov_ratio=ratio, clip_cov_min=cmin, clip_cov_max=cmax)
+    return cov_clip_mask(cfg, torch.from_numpy(g[f"c{k}_logits"]), torch.from_numpy(g[f"c{k}_actions"]),
+                         torch.from_numpy(g[f"c{k}_adv"]), perm=g[f"c{k}_cov_perm"]).numpy()

@@ -310,8 +310,9 @@ def gen_ppo_full_loss():
     cfg = pf.Config()
     from torch.distributions import Categorical
     out = {}
-    for case, B in enumerate((128, 1024)):
+    for case, B in enumerate((128, 1024, 512)):
         seed_all(30 + case)
+        cov_ratio, cov_min, cov_max = (0.5, 0.2, 5.0) if case == 2 else (cfg.clip_cov_ratio, cfg.clip_cov_min, cfg.clip_cov_max)
         logits = (torch.randn(B, 4) * 1.5).requires_grad_(True)
         values = torch.randn(B, 1, requires_grad=True)
         with torch.no_grad():
@@ -334,6 +335,14 @@ def gen_ppo_full_loss():
         clip_ratio = ratio.clamp(0.0, cfg.dual_clip)
         surr1 = clip_ratio * adv_batch
         surr2 = torch.clamp(ratio, 1 - cfg.clip_eps_min, 1 + cfg.clip_eps_max) * adv_batch
+        cov_perm = np.zeros(0, np.int64)
+        clip_idx = torch.where((covs > cov_min) & (covs < cov_max))[0]                       # :611-616
+        if len(clip_idx) > 0 and cov_ratio > 0:
+            clip_num = max(int(len(clip_idx) * cov_ratio), 1)
+            perm_ = torch.randperm(len(clip_idx))
+            cov_perm = perm_.numpy().copy()
+            clip_idx = clip_idx[perm_[: min(clip_num, len(clip_idx))]]
+            corr[clip_idx] = 0.0
         clip_frac = torch.mean(((ratio < (1 - cfg.clip_eps_min)) | (ratio > (1 + cfg.clip_eps_max))).float() * corr)
         policy_loss = torch.mean(-torch.min(surr1, surr2) * corr)
         value_loss = torch.mean(0.5 * corr * (values.squeeze() - ret_batch).pow(2))
@@ -347,11 +356,13 @@ def gen_ppo_full_loss():
             pre + "actions": a_batch.numpy().astype(np.int32), pre + "old_lp": old_lp.numpy(),
             pre + "old_ent": old_ent.numpy(), pre + "adv": adv_batch.numpy(), pre + "ret": ret_batch.numpy(),
             pre + "dlogits": logits.grad.numpy(), pre + "dvalues": values.grad.squeeze(-1).numpy(),
+            pre + "cov_perm": cov_perm, pre + "cov_cfg": np.array([cov_ratio, cov_min, cov_max], np.float64),
+            pre + "corr": corr.numpy(),
             pre + "metrics": np.array([policy_loss.item(), value_loss.item(), entropy.item(), clip_frac.item(),
                                        (old_lp - new_lp).mean().item(), 1.0 - erc_mask.mean().item(),
                                        covs.mean().item()], np.float64),
         })
-    out["n_cases"] = np.int64(2)
+    out["n_cases"] = np.int64(3)
     out["cfg"] = np.array([cfg.clip_eps_min, cfg.clip_eps_max, cfg.dual_clip, cfg.erc_beta_low,
                            cfg.erc_beta_high, 0.0077], np.float64)
     save("ppo_full_loss", **out)

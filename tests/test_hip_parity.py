@@ -3,7 +3,7 @@ the same seeded inputs, and vs the golden fixtures captured from the reference."
 import numpy as np
 import pytest
 
-from conftest import load_golden, rel_close
+from conftest import cov_clip_mul, load_golden, rel_close
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -196,9 +196,11 @@ def test_ppo_full_loss_vs_oracle_and_golden(dev, oracle):
     for k in range(int(g["n_cases"])):
         args = [g[f"c{k}_{n}"] for n in ("logits", "values", "actions", "old_lp", "old_ent", "adv", "ret")]
         B = args[0].shape[0]
-        dl_ref, dv_ref, met_ref = oracle.ppo_full_loss_fwd_bwd(*args, cfg)
+        mul = cov_clip_mul(g, k)                                   # case 2 runs the covariance clip (:611-616)
+        dl_ref, dv_ref, met_ref = oracle.ppo_full_loss_fwd_bwd(*args, cfg, corr_mul=mul)
         met = torch.zeros(9, dtype=torch.float64, device=dev)
-        dl, dv = ops.ppo_full_loss_fwd_bwd(*[t(a, dev) for a in args], cfg, metrics_sum=met)
+        dl, dv = ops.ppo_full_loss_fwd_bwd(*[t(a, dev) for a in args], cfg, metrics_sum=met,
+                                           corr_mul=None if mul is None else t(mul, dev))
         assert np.array_equal(dl.cpu().numpy(), dl_ref) and np.array_equal(dv.cpu().numpy(), dv_ref)
         assert rel_close(met.cpu().numpy(), met_ref, 1e-9) <= 1e-9
         assert np.max(np.abs(dl.cpu().numpy() - g[f"c{k}_dlogits"])) <= TOL * np.abs(g[f"c{k}_dlogits"]).max()

@@ -3,7 +3,7 @@ Python (tests/golden/make_golden.py).  CPU-only; runs in the build container."""
 import numpy as np
 import pytest
 
-from conftest import load_golden, rel_close
+from conftest import cov_clip_mul, load_golden, rel_close
 
 TOL = 1e-5  # BASELINE.json north_star: returns/advantages within 1e-5 (relative form)
 
@@ -86,7 +86,7 @@ def test_ppo_full_loss_matches_autograd(oracle):
     for k in range(int(g["n_cases"])):
         dl, dv, met = oracle.ppo_full_loss_fwd_bwd(g[f"c{k}_logits"], g[f"c{k}_values"], g[f"c{k}_actions"],
                                                    g[f"c{k}_old_lp"], g[f"c{k}_old_ent"], g[f"c{k}_adv"],
-                                                   g[f"c{k}_ret"], cfg)
+                                                   g[f"c{k}_ret"], cfg, corr_mul=cov_clip_mul(g, k))
         B = g[f"c{k}_logits"].shape[0]
         assert np.max(np.abs(dl - g[f"c{k}_dlogits"])) <= TOL * np.abs(g[f"c{k}_dlogits"]).max()
         assert np.max(np.abs(dv - g[f"c{k}_dvalues"])) <= TOL * np.abs(g[f"c{k}_dvalues"]).max()
@@ -181,3 +181,15 @@ def test_permutation_is_a_keyed_bijection(oracle):
     mb = p1.reshape(32, -1).astype(np.float64).mean(1)
     sigma = M / np.sqrt(12.0 * (M // 32))
     assert np.all(np.abs(mb - (M - 1) / 2) < 4 * sigma)
+
+
+def test_ppo_full_cov_clip_branch_matches_reference(oracle):
+    """L3 with clip_cov_ratio > 0 (ppo_full_lunarlander.py:594-616): the rows gymrl_amd's cov_clip_mask takes out,
+    fed the reference's own randperm, are exactly the rows the reference zeroed (golden case 2); the gradients and
+    metrics with that mask are covered by test_ppo_full_loss_matches_autograd."""
+    g = load_golden("ppo_full_loss")
+    mul = cov_clip_mul(g, 2)
+    ratio = float(g["c2_cov_cfg"][0])
+    assert (mul == 0).sum() == max(int(len(g["c2_cov_perm"]) * ratio), 1)
+    assert np.all(g["c2_corr"][mul == 0] == 0)                               # every picked row is out of the means
+    assert cov_clip_mul(g, 0) is None and cov_clip_mul(g, 1) is None         # default ratio 0: branch dead
