@@ -40,6 +40,8 @@ SYMBOLS = [
     "gymrl_mlp_packed_floats", "gymrl_mlp_pack", "gymrl_mlp_forward",
     "gymrl_mlp_train_workspace_bytes", "gymrl_linear_tanh_smallk", "gymrl_tanh_inplace", "gymrl_tanh_bwd_colsum",
     "gymrl_linear_smallk_bwd", "gymrl_heads_fwd_tanh", "gymrl_heads_bwd", "gymrl_rollout_lunar",
+    "gymrl_gemm_workspace_bytes", "gymrl_gemm_config", "gymrl_linear_fwd", "gymrl_linear_bwd_input",
+    "gymrl_linear_bwd_weight_geometry", "gymrl_linear_bwd_weight",
 ]
 
 
@@ -104,6 +106,7 @@ def lib():
         L.gymrl_per_workspace_bytes.restype = C.c_size_t
         L.gymrl_mlp_packed_floats.restype = C.c_size_t
         L.gymrl_mlp_train_workspace_bytes.restype = C.c_size_t
+        L.gymrl_gemm_workspace_bytes.restype = C.c_size_t
         for name in SYMBOLS:
             if name.endswith(("_bytes", "_floats")):
                 continue

@@ -708,6 +708,50 @@ def heads_bwd(Hac, dlogits, dv, Wa2, Wc2, dZac, dbac, dWa2, dba2, dWc2, dbc2, wo
                                 _ptr(workspace), _stream()), "gymrl_heads_bwd")
 
 
+# ------------------------------------------------------ update-path GEMMs ---
+def gemm_workspace(device):
+    return torch.empty(int(lib().gymrl_gemm_workspace_bytes()), dtype=torch.uint8, device=device)
+
+
+def gemm_config(key, value):
+    """A/B knobs of the hand-written GEMMs (include/gymrl.h gymrl_gemm_config)."""
+    check(lib().gymrl_gemm_config(C.c_int(key), C.c_int(value)), "gymrl_gemm_config")
+
+
+def linear_fwd(x, W, b, out, act=True):
+    """out [B, N] = tanh(x [B, 256] W[N, 256]^T + b) (act=False: no tanh) — exact-f32 MFMA, fused epilogue."""
+    B, K = x.shape
+    check(lib().gymrl_linear_fwd(_ptr(x, torch.float32), _ptr(W, torch.float32), _ptr(b, torch.float32, True),
+                                 C.c_int64(B), C.c_int(K), C.c_int(W.shape[0]), C.c_int(int(act)), _ptr(out, torch.float32),
+                                 _stream()), "gymrl_linear_fwd")
+    return out
+
+
+def linear_bwd_input(dy, W, H, dx):
+    """dx [B, 256] = (dy [B, N] W[N, 256]) * (1 - H^2)  (H None: no factor)."""
+    B, N = dy.shape
+    check(lib().gymrl_linear_bwd_input(_ptr(dy, torch.float32), _ptr(W, torch.float32), _ptr(H, torch.float32, True),
+                                       C.c_int64(B), C.c_int(N), C.c_int(W.shape[1]), _ptr(dx, torch.float32), _stream()),
+          "gymrl_linear_bwd_input")
+    return dx
+
+
+def linear_bwd_weight_geometry(B, N):
+    s, r = C.c_int(0), C.c_int64(0)
+    check(lib().gymrl_linear_bwd_weight_geometry(C.c_int64(B), C.c_int(N), C.byref(s), C.byref(r)),
+          "gymrl_linear_bwd_weight_geometry")
+    return s.value, r.value
+
+
+def linear_bwd_weight(dy, x, dW, workspace, db=None):
+    """dW [N, 256] = dy [B, N]^T x [B, 256]; db [N] = column sums of dy (None: skipped).  Overwrites."""
+    B, N = dy.shape
+    check(lib().gymrl_linear_bwd_weight(_ptr(dy, torch.float32), _ptr(x, torch.float32), C.c_int64(B), C.c_int(N),
+                                        C.c_int(x.shape[1]), _ptr(dW, torch.float32), _ptr(db, torch.float32, True),
+                                        _ptr(workspace), _stream()), "gymrl_linear_bwd_weight")
+    return dW
+
+
 # ------------------------------------------------------ persistent rollout ---
 def rollout_lunar(env_state, n_envs, seed, env_id0, counter0, obs, act, logp, val, rew, done, ep_ret, next_value, policy_desc,
                   T, t0, nsteps, gamma, lam, noise_exp=None, gae_running=None, gae_workspace=None, ep_stats=None, wg_ticks=None):

@@ -462,6 +462,44 @@ int gymrl_heads_bwd(const float* Hac, const float* dlogits, const float* dv, int
                     float* dba2, float* dWc2, float* dbc2, int pre_activation, const float* bac,
                     void* workspace, void* stream);
 
+/* ===================================================== update-path GEMMs === */
+/*
+ * The 256-wide contractions of one ActorCritic minibatch update — ppo_lunarlander.py:274-307:
+ * shared.2 / actor.0 / critic.0 of evaluate_actions' forward (:67-84, :110-117) and their
+ * input / weight gradients under loss.backward() (:303) — as hand-written exact-f32 MFMA kernels
+ * (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bit for bit an fmaf chain; the reference computes
+ * in f32 and gfx950 has no TF32) with the layer's elementwise work in the epilogue.  Row-major f32,
+ * K = 256 (hidden_dim), B rows.  workspace: gymrl_gemm_workspace_bytes() bytes, 16-B aligned.
+ *
+ *   linear_fwd         Y [B, N] = act(X [B, K] W[N, K]^T + b[N]);  N in {256, 512}; act 0 none, 1 tanh
+ *                      (b NULL: no bias).  Linear + Tanh of shared.2 (N = 256) and of actor.0 | critic.0
+ *                      as one N = 512 layer over their adjacent weights.
+ *   linear_bwd_input   dX [B, K] = (dY [B, N] W[N, K]) * (1 - H^2), H [B, K] = the tanh output of the layer
+ *                      BELOW (H NULL: no factor); colsum_out [K] = sum_rows dX (that layer's bias
+ *                      gradient; NULL: skipped).  N in {256, 512}.
+ *   linear_bwd_weight  dW [N, K] = dY [B, N]^T X [B, K];  N in {256, 512}.
+ *
+ * Accumulation order (part of the contract — oracle/gymrl_oracle.c restates it and tests compare bit for
+ * bit).  fwd / bwd_input: one fmaf chain per output from +0 over the reduction index r in chunks of 8
+ * ascending, inside a chunk in the order 0, 4, 1, 5, 2, 6, 3, 7; bias / factor applied after the chain in
+ * f32 ((acc + b), acc * (1 - h*h)).  bwd_weight: the rows are cut into `slices` slices of
+ * `rows_per_slice` rows (gymrl_linear_bwd_weight_geometry); inside a slice one fmaf chain from +0 over
+ * the rows ascending; dW = ((g0 + g1) + g2) + g3 in f64, g_j = the f64 sum of the slice results s = j
+ * (mod 4) ascending, rounded once to f32.  colsum_out is a fixed-order sum (device-deterministic,
+ * compared at 1e-5).  act = tanh uses the same hardware-exp2 form as the passes above.
+ * gymrl_gemm_config(key, value): knobs of tools/micro_gemm.py / tools/abl_gemm.py (2: prefetch ring depth of
+ * bwd_weight 4|8; 4: ablation mode of bwd_weight, 0 = the product kernel); results do not depend on key 2.
+ */
+size_t gymrl_gemm_workspace_bytes(void);
+int gymrl_gemm_config(int key, int value);
+int gymrl_linear_fwd(const float* X, const float* W, const float* b, int64_t B, int K, int N, int act,
+                     float* Y, void* stream);
+int gymrl_linear_bwd_input(const float* dY, const float* W, const float* H, int64_t B, int N, int K,
+                           float* dX, void* stream);
+int gymrl_linear_bwd_weight_geometry(int64_t B, int N, int* slices, int64_t* rows_per_slice);
+int gymrl_linear_bwd_weight(const float* dY, const float* X, int64_t B, int N, int K, float* dW,
+                            float* db, void* workspace, void* stream);
+
 /* ========================================================= off-policy ===== */
 /*
  * D2 / A3 / S2: device-resident replay ring, SoA rows [cap]:

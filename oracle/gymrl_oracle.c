@@ -129,6 +129,78 @@ void orc_linear_act(const float* x, const float* W, const float* b, int n, int i
     }
 }
 
+/* ---------------------------------------------------- update-path GEMMs ---
+ * The 256-wide layers of ActorCritic's training forward / backward (ppo_lunarlander.py:67-84,
+ * :110-117, :303) in the accumulation order include/gymrl.h documents for gymrl_linear_fwd /
+ * _bwd_input / _bwd_weight: one fmaf chain per output from +0; reduction index in chunks of 8
+ * ascending, inside a chunk 0, 4, 1, 5, 2, 6, 3, 7. */
+static const int kChunkOrder[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+
+/* Y [B, N] = X [B, K] W[N, K]^T + b (no activation) */
+void orc_linear_fwd(const float* X, const float* W, const float* b, int B, int K, int N, float* Y) {
+  for (int r = 0; r < B; ++r)
+    for (int n = 0; n < N; ++n) {
+      float acc = 0.0f;
+      for (int c = 0; c < K; c += 8)
+        for (int j = 0; j < 8; ++j) {
+          const int k = c + kChunkOrder[j];
+          acc = fmaf(X[(size_t)r * K + k], W[(size_t)n * K + k], acc);
+        }
+      Y[(size_t)r * N + n] = acc + (b ? b[n] : 0.0f);
+    }
+}
+
+/* dX [B, K] = (dY [B, N] W[N, K]) * (1 - H^2)   (H NULL: no factor) */
+void orc_linear_bwd_input(const float* dY, const float* W, const float* H, int B, int N, int K, float* dX) {
+  for (int r = 0; r < B; ++r)
+    for (int k = 0; k < K; ++k) {
+      float acc = 0.0f;
+      for (int c = 0; c < N; c += 8)
+        for (int j = 0; j < 8; ++j) {
+          const int n = c + kChunkOrder[j];
+          acc = fmaf(dY[(size_t)r * N + n], W[(size_t)n * K + k], acc);
+        }
+      if (H) {
+        const float h = H[(size_t)r * K + k];
+        acc = acc * (1.0f - h * h);
+      }
+      dX[(size_t)r * K + k] = acc;
+    }
+}
+
+/* dW [N, K] = dY^T X: rows in `slices` slices of `rps` rows, fmaf chain over the rows of a slice from +0,
+ * slices combined as ((g0 + g1) + g2) + g3 in double, g_j = sum of slices s = j (mod 4) ascending. */
+void orc_linear_bwd_weight(const float* dY, const float* X, int64_t B, int N, int K, int slices, int64_t rps,
+                           float* dW) {
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k) {
+      double g[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int s = 0; s < slices; ++s) {
+        const int64_t m0 = (int64_t)s * rps, m1 = m0 + rps < B ? m0 + rps : B;
+        float acc = 0.0f;
+        for (int64_t m = m0; m < m1; ++m) acc = fmaf(dY[(size_t)m * N + n], X[(size_t)m * K + k], acc);
+        g[s & 3] += (double)acc;
+      }
+      dW[(size_t)n * K + k] = (float)(((g[0] + g[1]) + g[2]) + g[3]);
+    }
+}
+
+/* db [N] of gymrl_linear_bwd_weight: per slice the even-offset rows and the odd-offset rows are summed
+ * sequentially in f32 and added (f32); slices combine like the weight tiles. */
+void orc_linear_bwd_bias(const float* dY, int64_t B, int N, int slices, int64_t rps, float* db) {
+  for (int n = 0; n < N; ++n) {
+    double g[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int s = 0; s < slices; ++s) {
+      const int64_t m0 = (int64_t)s * rps, m1 = m0 + rps < B ? m0 + rps : B;
+      float ev = 0.0f, od = 0.0f;
+      for (int64_t m = m0; m < m1; m += 2) ev += dY[(size_t)m * N + n];
+      for (int64_t m = m0 + 1; m < m1; m += 2) od += dY[(size_t)m * N + n];
+      g[s & 3] += (double)(ev + od);
+    }
+    db[n] = (float)(((g[0] + g[1]) + g[2]) + g[3]);
+  }
+}
+
 /* ============================================================== Philox ==== */
 /* Philox4x32-10 (Salmon et al. 2011), the build's own counter-based env/policy
  * stream; integer only. */

@@ -83,6 +83,47 @@ def linear_act(x, W, b, act=0):
     return y
 
 
+def linear_fwd(x, W, b=None):
+    """x W^T + b in gymrl_linear_fwd's accumulation order (no activation)."""
+    x, W = _f32(x), _f32(W)
+    B, K = x.shape
+    N = W.shape[0]
+    b = None if b is None else _f32(b)
+    y = np.empty((B, N), np.float32)
+    lib().orc_linear_fwd(_p(x), _p(W), _p(b), B, K, N, _p(y))
+    return y
+
+
+def linear_bwd_input(dy, W, H=None):
+    """(dy W) * (1 - H^2) in gymrl_linear_bwd_input's accumulation order."""
+    dy, W = _f32(dy), _f32(W)
+    B, N = dy.shape
+    K = W.shape[1]
+    H = None if H is None else _f32(H)
+    dx = np.empty((B, K), np.float32)
+    lib().orc_linear_bwd_input(_p(dy), _p(W), _p(H), B, N, K, _p(dx))
+    return dx
+
+
+def linear_bwd_weight(dy, x, slices, rows_per_slice):
+    """dy^T x in gymrl_linear_bwd_weight's slice / chain order."""
+    dy, x = _f32(dy), _f32(x)
+    B, N = dy.shape
+    K = x.shape[1]
+    dW = np.empty((N, K), np.float32)
+    lib().orc_linear_bwd_weight(_p(dy), _p(x), C.c_int64(B), N, K, int(slices), C.c_int64(int(rows_per_slice)), _p(dW))
+    return dW
+
+
+def linear_bwd_bias(dy, slices, rows_per_slice):
+    """Column sums of dy in gymrl_linear_bwd_weight's order (its `db` output)."""
+    dy = _f32(dy)
+    B, N = dy.shape
+    db = np.empty(N, np.float32)
+    lib().orc_linear_bwd_bias(_p(dy), C.c_int64(B), N, int(slices), C.c_int64(int(rows_per_slice)), _p(db))
+    return db
+
+
 def mlp_forward(x, stages):
     """stages: list of (W, b, act, src, dst); src -1 = x, dst -1 = network output.  Returns the list of
     outputs of the dst == -1 stages in order (include/gymrl.h gymrl_mlp_forward)."""
