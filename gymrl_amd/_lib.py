@@ -42,6 +42,7 @@ SYMBOLS = [
     "gymrl_linear_smallk_bwd", "gymrl_heads_fwd_tanh", "gymrl_heads_bwd", "gymrl_rollout_lunar",
     "gymrl_gemm_workspace_bytes", "gymrl_gemm_config", "gymrl_linear_fwd", "gymrl_linear_bwd_input",
     "gymrl_linear_bwd_weight_geometry", "gymrl_linear_bwd_weight",
+    "gymrl_heads_loss_blocks", "gymrl_heads_loss_fwd_bwd",
 ]
 
 

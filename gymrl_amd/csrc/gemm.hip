@@ -87,18 +87,19 @@ __device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, uint32_t off, 
 //    instructions do not hide in an MFMA's 64 cycles, neither from the same wave nor from a second wave on the SIMD
 //    (every VALU instruction of the epilogue costs ~7 cycles of matrix time; two MFMA-bound waves per SIMD run no
 //    faster than one).  So: ONE wave per SIMD with 128 accumulator registers, and an epilogue of as few VALU
-//    instructions as the layer's arithmetic allows (tanh as 1 - 2 / (exp2(x * 2 log2 e) + 1): 6 per element);
+//    instructions as the layer's arithmetic allows (tanh as train_tanhf's 1 - 2 / (exp2(x * 2 log2 e) + 1): 6 per element with the bias add);
 //  * with the epilogue removed the loop below runs at 98 % of the MFMA peak (A straight from HBM, B from LDS);
 //  * dword stores are issue-bound (4 per chunk cost 10 % of the kernel): the MFMA operands are swapped
 //    (D = W_tile * X_tile^T) so that a lane holds 4 ADJACENT output columns of one row per accumulator quad and
 //    stores / loads 16 bytes at a time.
-// A wave owns 32*RT rows x BN columns.  The epilogue of row tile t is spread over the MFMA stream of row tile t+1 —
+// A wave owns 32*RT rows x BN columns (64 x 128 at RED = 256, 64 x 64 at RED = 512: the fully unrolled reduction
+// loop must stay within hipcc's 16 K-instruction unroll budget and the instruction cache).  The epilogue of row tile t is spread over the MFMA stream of row tile t+1 —
 // not for the VALU (see above) but so that its loads (H) and stores are never waited for: the finished accumulators
 // move to `pend`; every chunk of the next tile carries a few epilogue instructions behind each MFMA, pinned by
 // sched_barrier (left alone, hipcc emits them as one block in front of a vmcnt(0)).
 template <int RED, int NT, int RT, bool TRANS_W, int EPI, int LDO, int ABL = 0>
 __global__ __launch_bounds__(256) void gemm_ws_kernel(WsArgs p) {
-  constexpr int BN = 32 * NT, NCH = RED / 8, PF = 4, NGR = RT * NT * 4, CPG = NCH / NGR, SPAN = 32 * CPG;
+  constexpr int BN = 32 * NT, NCH = RED / 8, PF = 4, NGR = RT * NT * 4, CPG = NCH / NGR, REG = 4 * RT * NT, SPAN = REG * CPG;
   constexpr int kWaves = 4, kThreads = 256, ROWS = 32 * RT;
   constexpr int NST = EPI == EPI_TANH ? 6 : (EPI == EPI_TANHBWD ? 3 : 1);    // VALU stages per output element
   static_assert(NCH % PF == 0 && NCH % NGR == 0 && CPG >= 1 && 4 * NST <= SPAN - 1, "epilogue groups per chunk");
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(WsArgs p) {
   // stage k of one output element; x carries the element through the stages
   auto stage = [&](int k, float x, float v, float bv, float hval) {
     if constexpr (EPI == EPI_NONE) x = v + bv;
-    if constexpr (EPI == EPI_TANH) {       // tanh(x) = 1 - 2 / (exp(2x) + 1); |abs error| < 2e-7 (include/gymrl.h)
+    if constexpr (EPI == EPI_TANH) {       // train_tanhf(v + bias), one instruction per stage
       if (k == 0) x = v + bv;
       if (k == 1) x = x * 2.885390081777927f;
       if (k == 2) x = __builtin_amdgcn_exp2f(x);
@@ -197,7 +198,13 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(WsArgs p) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) pend[rt][nt][r] = 0.0f;
-  f32x4 hv = {0.0f, 0.0f, 0.0f, 0.0f}, hn = hv, bv = hv, xs = hv;
+  const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 bv = zero4, xs = zero4;
+  // H of epilogue group G lives in hring[G % HD]; it is loaded HD - 1 groups (>= 3 us of MFMAs) before its use —
+  // one group ahead (0.7 us) was less than an HBM miss and stalled the dX kernels by 30 %
+  constexpr int HD = 4;
+  static_assert(NGR % HD == 0, "ring slots line up across row tiles");
+  f32x4 hring[HD] = {zero4, zero4, zero4, zero4};
   f32x4 bc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bc[nt] = bl[32 * nt];
@@ -212,19 +219,19 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(WsArgs p) {
       const int u = c % PF;
       const int G = c / CPG;                            // epilogue group of the previous row tile on this chunk
       f32x4 bn[NT];
-      // A chunk = 4 k-pairs x (RT*NT = 8) MFMAs = 32 pinned regions of ONE MFMA.  Region R of a group's span also
+      // A chunk = 4 k-pairs x RT*NT MFMAs = REG pinned regions of ONE MFMA.  Region R of a group's span also
       // carries stage R / 4 of the group's element R % 4, or one of the loads / the group's 16-byte store.
 #pragma unroll
-      for (int r = 0; r < 32; ++r) {
-        const int e = r / 8, m = r % 8, rt = m / NT, nt = m % NT;
-        const int R = (c % CPG) * 32 + r;
+      for (int r = 0; r < REG; ++r) {
+        const int e = r / (RT * NT), m = r % (RT * NT), rt = m / NT, nt = m % NT;
+        const int R = (c % CPG) * REG + r;
         if (r == 0) {            // operands of the next chunk (chunk 0 of the next tile is the same LDS data)
 #pragma unroll
           for (int n2 = 0; n2 < NT; ++n2) bn[n2] = (ABL & 2) ? bc[n2] : bl[(size_t)((c + 1) % NCH) * 2 * BN + 32 * n2];
         }
         if (R == 0 && EPI != EPI_TANHBWD) bv = bias4[(32 * ((G / 4) % NT) + 8 * (G % 4)) / 4];
-        if (EPI == EPI_TANHBWD && R == 8)           // H of the NEXT group (the first group of a tile: this tile's own)
-          hn = (G + 1 < NGR) ? bload4(ph, group_off(G + 1)) : bload4(chh, group_off(0));
+        if (EPI == EPI_TANHBWD && R == 8)           // H of group G + HD - 1 (past the tile's last group: this tile's own)
+          hring[(G + HD - 1) % HD] = (G + HD - 1 < NGR) ? bload4(ph, group_off(G + HD - 1)) : bload4(chh, group_off(G + HD - 1 - NGR));
         if (c == 0 && e == 0) {
           f32x16 z;
 #pragma unroll
@@ -235,12 +242,12 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(WsArgs p) {
         }
         if (!(ABL & 4) && R < 4 * NST) {
           const int q = R % 4;
-          xs[q] = stage(R / 4, xs[q], pend[G / (NT * 4)][(G / 4) % NT][4 * (G % 4) + q], bv[q], hv[q]);
+          xs[q] = stage(R / 4, xs[q], pend[G / (NT * 4)][(G / 4) % NT][4 * (G % 4) + q], bv[q], hring[G % HD][q]);
         }
         if (!(ABL & 4) && R == SPAN - 1) {
           if (ABL & 8) asm volatile("" :: "v"(xs)); else bstore4(po, group_off(G), xs);
         }
-        if (r == 31 && !(ABL & 1)) {     // refill the ring slot just consumed: chunk c + PF, or the next tile's head
+        if (r == REG - 1 && !(ABL & 1)) {     // refill the ring slot just consumed: chunk c + PF, or the next tile's head
 #pragma unroll
           for (int r2 = 0; r2 < RT; ++r2)
             abuf[u][r2] = (c + PF < NCH) ? bload4(cur, aoff[r2] + 32u * (c + PF)) : bload4(nxt, aoff[r2] + 32u * (c + PF - NCH));
@@ -249,7 +256,6 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(WsArgs p) {
       }
 #pragma unroll
       for (int n2 = 0; n2 < NT; ++n2) bc[n2] = bn[n2];
-      if (EPI == EPI_TANHBWD && c % CPG == CPG - 1) hv = hn;
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -262,8 +268,8 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(WsArgs p) {
   // the last row tile's epilogue has no MFMA stream to ride on
 #pragma unroll
   for (int G = 0; G < NGR; ++G) {
-    f32x4 hq = hv, x4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (EPI == EPI_TANHBWD && G > 0) hq = bload4(ph, group_off(G));
+    f32x4 hq = hring[G % HD], x4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (EPI == EPI_TANHBWD && G >= HD - 1) hq = bload4(ph, group_off(G));
     const f32x4 b4 = bias4[(32 * ((G / 4) % NT) + 8 * (G % 4)) / 4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -516,7 +522,7 @@ int gymrl_linear_bwd_input(const float* dY, const float* W, const float* H, int6
     launch_ws<256, 4, 2, true, EPI_TANHBWD, 256>(a, ws_row_groups(B, 64, 2), s);
   } else {
     a.slices = 4;
-    launch_ws<512, 2, 4, true, EPI_TANHBWD, 256>(a, ws_row_groups(B, 128, 4), s);
+    launch_ws<512, 2, 2, true, EPI_TANHBWD, 256>(a, ws_row_groups(B, 64, 4), s);
   }
   GYMRL_CHECK_LAUNCH();
   return 0;

@@ -23,6 +23,7 @@
 // per-lane serial f32 sums over the rows a lane visits, LDS tree inside the workgroup, one f32
 // partial row per workgroup, fixed-order f64 finalize.
 #include "train_device.hpp"
+#include "policy_device.hpp"
 #include "../../include/gymrl.h"
 
 namespace {
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(kTB) void linear_tanh_smallk_kernel(const float* __
       float acc = 0.0f;
 #pragma unroll
       for (int d = 0; d < D; ++d) acc = fmaf(xv[d], w[j][d], acc);
-      o[j] = fast_tanhf(acc + bias[j]);
+      o[j] = train_tanhf(acc + bias[j]);
     }
     __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(out + r * C + 4 * m.c4));
   }
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(kTB) void tanh_inplace_kernel(float* __restrict__ z
       for (int j = 0; j < 4; ++j) v[j] += b[j];
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = fast_tanhf(v[j]);
+    for (int j = 0; j < 4; ++j) v[j] = train_tanhf(v[j]);
     p[i] = v;
   }
 }
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(kTB) void heads_fwd_tanh_kernel(float* __restrict__
       ha = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Zac + o));
       hc = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Zac + o + C));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { ha[j] = fast_tanhf(ha[j] + pa[j]); hc[j] = fast_tanhf(hc[j] + pc[j]); }
+      for (int j = 0; j < 4; ++j) { ha[j] = train_tanhf(ha[j] + pa[j]); hc[j] = train_tanhf(hc[j] + pc[j]); }
       if (store_h) {      // store_h == 0: Zac keeps the pre-activations and heads_bwd recomputes the same tanh
         __builtin_nontemporal_store(ha, reinterpret_cast<f32x4*>(Zac + o));
         __builtin_nontemporal_store(hc, reinterpret_cast<f32x4*>(Zac + o + C));
@@ -286,10 +287,12 @@ __global__ __launch_bounds__(kTB) void linear_smallk_bwd_kernel(const float* __r
         float a = 0.0f;
 #pragma unroll
         for (int d = 0; d < D; ++d) a = fmaf(xv[d], w[j][d], a);
-        h[j] = fast_tanhf(a + bias[j]);
+        h[j] = train_tanhf(a + bias[j]);
       }
-    } else {
+    } else if (H) {
       h = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(H + o));
+    } else {
+      h = f32x4{0.0f, 0.0f, 0.0f, 0.0f};          // dH is dZ already: g * (1 - 0) == g
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(kTB) void heads_bwd_kernel(const float* Hac, const 
     }
     if (pre_activation) {   // Hac holds actor.0 / critic.0 pre-activations: the forward's tanh, bit for bit
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { ha[j] = fast_tanhf(ha[j] + pa[j]); hc[j] = fast_tanhf(hc[j] + pc[j]); }
+      for (int j = 0; j < 4; ++j) { ha[j] = train_tanhf(ha[j] + pa[j]); hc[j] = train_tanhf(hc[j] + pc[j]); }
     }
     float dl[A];
 #pragma unroll
@@ -423,6 +426,175 @@ __global__ __launch_bounds__(kTB) void heads_finalize_kernel(const float* __rest
   }
 }
 
+// ------------------------------------------------------------------ F3+L1+B4 -
+// heads_fwd_tanh + ppo_loss + heads_bwd as ONE pass over Zac [B, 512] (pre-activations of actor.0 | critic.0,
+// C = 256: a row is one wavefront x float4 + float4).  A wave takes kRB rows at a time: tanh, the A + 1 head dot
+// products reduced with the forward pass's butterfly, lane k keeps row k's logits and value; then ONE evaluation of
+// the clipped-surrogate loss for the kRB rows (ppo_loss_row, one row per lane: the bits of ppo_loss_kernel — done
+// per row it would be 250 instructions replicated over the row's 64 lanes, more than the rest of the pass); then row
+// k's dlogits / dv are read back from lane k (v_readlane) and turned into dZac — written in place over the
+// pre-activations — and into heads_bwd's register accumulators.  One read and one write of 2 KB per row instead of
+// two reads and a write plus the logits / dlogits round trip.  partial row: as heads_bwd_kernel;
+// met_parts[block][5] (f64).
+constexpr int kRB = 8;
+__device__ __forceinline__ float lane_bcast(float v, int k) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+}
+template <int A>
+__global__ __launch_bounds__(kTB) void heads_loss_kernel(float* Zac, int64_t B, const float* __restrict__ bac,
+                                                         const float* __restrict__ Wa2, const float* __restrict__ ba2,
+                                                         const float* __restrict__ Wc2, const float* __restrict__ bc2,
+                                                         const int32_t* __restrict__ act, const float* __restrict__ logp_old,
+                                                         const float* __restrict__ adv, const float* __restrict__ ret,
+                                                         const double* __restrict__ adv_moments, gymrl_ppo_cfg cfg,
+                                                         float* __restrict__ partials, double* __restrict__ met_parts) {
+  constexpr int C = 256;
+  extern __shared__ float sm[];
+  __shared__ double s_norm[2];
+  __shared__ double s_met[5][kTB / 64];
+  if (threadIdx.x == 0) {
+    double mean = 0.0, sd = 1.0;
+    if (adv_moments) {      // whole-rollout advantage normalisation (ppo_lunarlander.py:236), as ppo_loss_kernel
+      const double cnt = adv_moments[0];
+      mean = adv_moments[1] / cnt;
+      double var = adv_moments[2] / cnt - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      sd = sqrt(var) + 1e-8;
+    }
+    s_norm[0] = mean; s_norm[1] = sd;
+  }
+  __syncthreads();
+  const RowMap m(C, threadIdx.x & 63);               // lpr = 64: c4 = lane, one row per wave-load
+  const int lane = threadIdx.x & 63;
+  float wa[A][4], wc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    wc[j] = Wc2[4 * m.c4 + j];
+#pragma unroll
+    for (int a = 0; a < A; ++a) wa[a][j] = Wa2[(size_t)a * C + 4 * m.c4 + j];
+  }
+  float hb[A + 1];
+#pragma unroll
+  for (int a = 0; a < A; ++a) hb[a] = ba2 ? ba2[a] : 0.0f;
+  hb[A] = bc2 ? bc2[0] : 0.0f;
+  f32x4 pa = {0.0f, 0.0f, 0.0f, 0.0f}, pc = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (bac) {
+    pa = *reinterpret_cast<const f32x4*>(bac + 4 * m.c4);
+    pc = *reinterpret_cast<const f32x4*>(bac + C + 4 * m.c4);
+  }
+  constexpr int NACC = 8 + 4 * A + 4 + 4 * ((A + 1 + 3) / 4);
+  float acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+  double met[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  const float invB = 1.0f / (float)B;
+  const int64_t nbatch = (B + kRB - 1) / kRB;
+  for (int64_t bt = (int64_t)blockIdx.x * (kTB / 64) + (threadIdx.x >> 6); bt < nbatch; bt += (int64_t)gridDim.x * (kTB / 64)) {
+    const int64_t r0 = bt * kRB;
+    f32x4 ha[kRB], hc[kRB];
+#pragma unroll
+    for (int k = 0; k < kRB; ++k) {
+      const int64_t rr = r0 + k < B ? r0 + k : B - 1;
+      const size_t o = (size_t)rr * 2 * C + 4 * m.c4;
+      ha[k] = *reinterpret_cast<const f32x4*>(Zac + o);
+      hc[k] = *reinterpret_cast<const f32x4*>(Zac + o + C);
+    }
+    // the loss inputs of row r0 + lane (lanes >= kRB and rows past the end: a valid row, results unused)
+    const int64_t rl = (lane < kRB && r0 + lane < B) ? r0 + lane : r0;
+    const int a_r = act[rl];
+    const float lpo = logp_old[rl], rt = ret[rl];
+    float ad = adv[rl];
+    float z[A], v = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; ++a) z[a] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kRB; ++k) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ha[k][j] = train_tanhf(ha[k][j] + pa[j]); hc[k][j] = train_tanhf(hc[k][j] + pc[j]); }
+      float p[A + 1];
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s = fmaf(ha[k][j], wa[a][j], s);
+        p[a] = s;
+      }
+      {
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s = fmaf(hc[k][j], wc[j], s);
+        p[A] = s;
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int a = 0; a <= A; ++a) p[a] += __shfl_xor(p[a], off, 64);
+      }
+      if (lane == k) {
+#pragma unroll
+        for (int a = 0; a < A; ++a) z[a] = p[a] + hb[a];
+        v = p[A] + hb[A];
+      }
+    }
+    float dl[A], dvr, m_obj, m_val, m_ent, m_clip, m_kl;
+    if (adv_moments) ad = (float)(((double)ad - s_norm[0]) / s_norm[1]);
+    ppo_loss_row<A>(z, v, a_r, lpo, ad, rt, invB, cfg, dl, dvr, m_obj, m_val, m_ent, m_clip, m_kl);
+    if (lane < kRB && r0 + lane < B) {
+      met[0] += -(double)m_obj; met[1] += (double)m_val; met[2] += (double)m_ent;
+      met[3] += (double)m_clip; met[4] += (double)m_kl;
+    }
+#pragma unroll
+    for (int k = 0; k < kRB; ++k) {
+      if (r0 + k < B) {                      // wave-uniform
+        float dk[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) dk[a] = lane_bcast(dl[a], k);
+        const float dvk = lane_bcast(dvr, k);
+        f32x4 za, zc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float s = 0.0f;
+#pragma unroll
+          for (int a = 0; a < A; ++a) {
+            s = fmaf(dk[a], wa[a][j], s);
+            acc[8 + 4 * a + j] = fmaf(dk[a], ha[k][j], acc[8 + 4 * a + j]);
+          }
+          za[j] = s * (1.0f - ha[k][j] * ha[k][j]);
+          zc[j] = (dvk * wc[j]) * (1.0f - hc[k][j] * hc[k][j]);
+          acc[j] += za[j];
+          acc[4 + j] += zc[j];
+          acc[8 + 4 * A + j] = fmaf(dvk, hc[k][j], acc[8 + 4 * A + j]);
+        }
+#pragma unroll
+        for (int a = 0; a < A; ++a) acc[12 + 4 * A + a] += dk[a];
+        acc[12 + 4 * A + A] += dvk;
+        const size_t o = (size_t)(r0 + k) * 2 * C + 4 * m.c4;
+        *reinterpret_cast<f32x4*>(Zac + o) = za;
+        *reinterpret_cast<f32x4*>(Zac + o + C) = zc;
+      }
+    }
+  }
+  if (m.c4 != 0) {
+#pragma unroll
+    for (int i = 12 + 4 * A; i < NACC; ++i) acc[i] = 0.0f;
+  }
+  // metrics: wave sums -> LDS -> one f64 row per workgroup
+  {
+    const int wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const double s = wave_sum(met[k]);
+      if (lane == 0) s_met[k][wid] = s;
+    }
+  }
+  block_colsum<NACC>(acc, C, m, sm, partials);          // (its barrier also publishes s_met)
+  if (threadIdx.x < 5) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kTB / 64; ++w) s += s_met[threadIdx.x][w];
+    met_parts[(size_t)blockIdx.x * 5 + threadIdx.x] = s;
+  }
+}
+
 inline bool pow2_cols(int C) { return C >= 16 && C <= 256 && (C & (C - 1)) == 0; }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline size_t sm_bytes(int C, int nv4) { return sizeof(float) * (size_t)(kTB / 64) * (64 / (C / 4)) * nv4 * C; }
@@ -481,7 +653,7 @@ int gymrl_tanh_bwd_colsum(float* dH, const float* H, int64_t B, int C, float* co
 
 int gymrl_linear_smallk_bwd(const float* dH, const float* H, const float* x, int64_t B, int D, int C, float* dW,
                             float* db, const float* W, const float* b, void* workspace, void* stream) {
-  if (!dH || (!H && !W) || !x || !dW || !db || !workspace || B < 0 || !pow2_cols(C) || !al16(dH) || (H && !al16(H)) ||
+  if (!dH || !x || !dW || !db || !workspace || B < 0 || !pow2_cols(C) || !al16(dH) || (H && !al16(H)) ||
       !al16(x))
     return -22;
   hipStream_t s = (hipStream_t)stream;
@@ -535,6 +707,47 @@ int gymrl_heads_bwd(const float* Hac, const float* dlogits, const float* dv, int
   } else if (A == 2) {
     constexpr int NV = (8 + 8 + 4 + 4) / 4;
     hipLaunchKernelGGL(heads_bwd_kernel<2>, grid, block, sm_bytes(C, NV), s, Hac, dlogits, dv, B, C, Wa2, Wc2, dZac, parts, pre_activation, bac);
+    hipLaunchKernelGGL(heads_finalize_kernel<2>, dim3((NV * C + kFinE - 1) / kFinE), block, 0, s, parts, nb, C, dbac, dWa2,
+                       dWc2, dba2, dbc2);
+  } else {
+    return -22;
+  }
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+static int heads_loss_grid(int64_t B) {
+  const int64_t nb = ((B + kRB - 1) / kRB + (kTB / 64) - 1) / (kTB / 64);
+  return (int)(nb < kMaxBlocks ? (nb < 1 ? 1 : nb) : kMaxBlocks);
+}
+
+int gymrl_heads_loss_blocks(int64_t B, int C) {
+  if (B <= 0 || C != 256) return 0;
+  return heads_loss_grid(B);
+}
+
+int gymrl_heads_loss_fwd_bwd(float* Zac, int64_t B, int C, int A, const float* bac, const float* Wa2, const float* ba2,
+                             const float* Wc2, const float* bc2, const int32_t* act, const float* logp_old,
+                             const float* adv, const float* ret, const double* adv_moments, const gymrl_ppo_cfg* cfg,
+                             float* dbac, float* dWa2, float* dba2, float* dWc2, float* dbc2, double* metric_parts,
+                             void* workspace, void* stream) {
+  if (!Zac || !Wa2 || !Wc2 || !act || !logp_old || !adv || !ret || !cfg || !dbac || !dWa2 || !dba2 || !dWc2 || !dbc2 ||
+      !metric_parts || !workspace || B <= 0 || C != 256 || !al16(Zac) || (bac && !al16(bac)))
+    return -22;
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = heads_loss_grid(B);
+  float* parts = (float*)workspace;
+  const dim3 grid(nb), block(kTB);
+  if (A == 4) {
+    constexpr int NV = (8 + 16 + 4 + 8) / 4;
+    hipLaunchKernelGGL(heads_loss_kernel<4>, grid, block, sm_bytes(C, NV), s, Zac, B, bac, Wa2, ba2, Wc2, bc2, act,
+                       logp_old, adv, ret, adv_moments, *cfg, parts, metric_parts);
+    hipLaunchKernelGGL(heads_finalize_kernel<4>, dim3((NV * C + kFinE - 1) / kFinE), block, 0, s, parts, nb, C, dbac, dWa2,
+                       dWc2, dba2, dbc2);
+  } else if (A == 2) {
+    constexpr int NV = (8 + 8 + 4 + 4) / 4;
+    hipLaunchKernelGGL(heads_loss_kernel<2>, grid, block, sm_bytes(C, NV), s, Zac, B, bac, Wa2, ba2, Wc2, bc2, act,
+                       logp_old, adv, ret, adv_moments, *cfg, parts, metric_parts);
     hipLaunchKernelGGL(heads_finalize_kernel<2>, dim3((NV * C + kFinE - 1) / kFinE), block, 0, s, parts, nb, C, dbac, dWa2,
                        dWc2, dba2, dbc2);
   } else {

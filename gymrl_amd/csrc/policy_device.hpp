@@ -2,6 +2,7 @@
 // persistent rollout kernel.
 #pragma once
 #include "gymrl_device.hpp"
+#include "../../include/gymrl.h"
 
 namespace gymrl {
 
@@ -49,6 +50,52 @@ __device__ __forceinline__ void log_softmax(const float (&z)[A], float (&ln)[A],
     p[k] = e[k] / s;
     H -= p[k] * ln[k];
   }
+}
+
+// L1 (ppo_lunarlander.py:278-300, :309-322) for ONE sample: clipped surrogate with dual clip, value and entropy
+// terms, their gradient w.r.t. the logits row and the value, and the five metric terms.  Shared by ppo_loss_kernel
+// and the fused heads + loss + backward pass, so both produce the same bits.  `ad` is the (already normalised)
+// advantage, invB = 1 / minibatch size.
+template <int A>
+__device__ __forceinline__ void ppo_loss_row(const float (&z)[A], float v, int a, float lpo, float ad, float rt,
+                                             float invB, const gymrl_ppo_cfg& cfg, float (&dz)[A], float& dv,
+                                             float& m_obj, float& m_val, float& m_ent, float& m_clip, float& m_kl) {
+  float ln[A], p[A], H;
+  log_softmax<A>(z, ln, p, H);
+  float lp = ln[0];
+#pragma unroll
+  for (int k = 1; k < A; ++k) if (a == k) lp = ln[k];
+  const float lo = 1.0f - cfg.clip_eps, hi = 1.0f + cfg.clip_eps;
+  const float ratio = det_expf(lp - lpo);
+  const float s1 = ratio * ad;
+  const float rc = fminf(fmaxf(ratio, lo), hi);
+  const float s2 = rc * ad;
+  const float inr = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;   // clamp passes grad on [lo, hi]
+  const float w1 = s1 < s2 ? 1.0f : (s1 == s2 ? 0.5f : 0.0f);     // torch.min tie: 1/2, 1/2
+  const float ms = fminf(s1, s2);
+  float dms_dr = w1 * ad + (1.0f - w1) * ad * inr;
+  float obj = ms;
+  if (ad < 0.0f) {
+    const float dc = cfg.dual_clip * ad;
+    obj = fmaxf(ms, dc);
+    const float wm = ms > dc ? 1.0f : (ms == dc ? 0.5f : 0.0f);   // torch.max tie
+    dms_dr *= wm;
+  }
+  // dL/dlp = -(1/B) * dobj/dr * r
+  const float g_lp = -invB * dms_dr * ratio;
+  const float g_H = -cfg.entropy_coef * invB;
+#pragma unroll
+  for (int k = 0; k < A; ++k) {
+    const float onehot = (a == k) ? 1.0f : 0.0f;
+    dz[k] = g_lp * (onehot - p[k]) + g_H * (-p[k] * (ln[k] + H));
+  }
+  const float dvr = v - rt;
+  dv = cfg.value_coef * 2.0f * dvr * invB;
+  m_obj = obj;
+  m_val = cfg.value_coef * (dvr * dvr);
+  m_ent = H;
+  m_clip = (ratio < lo || ratio > hi) ? 1.0f : 0.0f;
+  m_kl = lpo - lp;
 }
 
 // P2 (ppo_lunarlander.py:92-104): Categorical(logits) -> (action, log_prob, entropy).  sample =

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_kernel(
   for (int b = blockIdx.x * kBlock + threadIdx.x; b < B || !synced; b += gridDim.x * kBlock) {
     const bool live = b < B;
     const int bb = live ? b : 0;
-    float z[A], ln[A], p[A], H;
+    float z[A];
     load_row<A>(logits, bb, z);
     const float v = value[bb];
     const int i = idx ? idx[bb] : bb;
@@ -105,46 +105,16 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_kernel(
     if (!synced) { __syncthreads(); synced = true; }
     if (!live) break;
     if (adv_moments) ad = (float)(((double)ad - s_norm[0]) / s_norm[1]);
-    log_softmax<A>(z, ln, p, H);
-    float lp = ln[0];
-#pragma unroll
-    for (int k = 1; k < A; ++k) if (a == k) lp = ln[k];
-
     const float invB = 1.0f / (float)B;
-    const float lo = 1.0f - cfg.clip_eps, hi = 1.0f + cfg.clip_eps;
-    const float ratio = det_expf(lp - lpo);
-    const float s1 = ratio * ad;
-    const float rc = fminf(fmaxf(ratio, lo), hi);
-    const float s2 = rc * ad;
-    const float inr = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;   // clamp passes grad on [lo, hi]
-    const float w1 = s1 < s2 ? 1.0f : (s1 == s2 ? 0.5f : 0.0f);     // torch.min tie: 1/2, 1/2
-    const float ms = fminf(s1, s2);
-    float dms_dr = w1 * ad + (1.0f - w1) * ad * inr;
-    float obj = ms;
-    if (ad < 0.0f) {
-      const float dc = cfg.dual_clip * ad;
-      obj = fmaxf(ms, dc);
-      const float wm = ms > dc ? 1.0f : (ms == dc ? 0.5f : 0.0f);   // torch.max tie
-      dms_dr *= wm;
-    }
-    // dL/dlp = -(1/B) * dobj/dr * r
-    const float g_lp = -invB * dms_dr * ratio;
-    const float g_H = -cfg.entropy_coef * invB;
-    float dz[A];
-#pragma unroll
-    for (int k = 0; k < A; ++k) {
-      const float onehot = (a == k) ? 1.0f : 0.0f;
-      dz[k] = g_lp * (onehot - p[k]) + g_H * (-p[k] * (ln[k] + H));
-    }
+    float dz[A], dvo, m_obj, m_val, m_ent, m_clip, m_kl;
+    ppo_loss_row<A>(z, v, a, lpo, ad, rt, invB, cfg, dz, dvo, m_obj, m_val, m_ent, m_clip, m_kl);
     store_row<A>(dlogits_out, b, dz);
-    const float dvr = v - rt;
-    dvalue_out[b] = cfg.value_coef * 2.0f * dvr * invB;
-
-    met[0] += -(double)obj;
-    met[1] += (double)(cfg.value_coef * (dvr * dvr));
-    met[2] += (double)H;
-    met[3] += (ratio < lo || ratio > hi) ? 1.0 : 0.0;
-    met[4] += (double)(lpo - lp);
+    dvalue_out[b] = dvo;
+    met[0] += -(double)m_obj;
+    met[1] += (double)m_val;
+    met[2] += (double)m_ent;
+    met[3] += (double)m_clip;
+    met[4] += (double)m_kl;
   }
   if (partials) block_partials<5, kBlock>(met, partials);
 }

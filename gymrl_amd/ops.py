@@ -708,6 +708,24 @@ def heads_bwd(Hac, dlogits, dv, Wa2, Wc2, dZac, dbac, dWa2, dba2, dWc2, dbc2, wo
                                 _ptr(workspace), _stream()), "gymrl_heads_bwd")
 
 
+def heads_loss_blocks(B, C_=256):
+    return int(lib().gymrl_heads_loss_blocks(C.c_int64(B), C.c_int(C_)))
+
+
+def heads_loss_fwd_bwd(Zac, bac, Wa2, ba2, Wc2, bc2, act, logp_old, adv, ret, cfg, adv_moments, dbac, dWa2, dba2, dWc2,
+                       dbc2, metric_parts, workspace):
+    """Heads forward + PPO loss + heads backward in one pass; dZac overwrites Zac (include/gymrl.h)."""
+    B, C2 = Zac.shape
+    c = PPOCfg(*[float(v) for v in cfg])
+    check(lib().gymrl_heads_loss_fwd_bwd(
+        _ptr(Zac, torch.float32), C.c_int64(B), C.c_int(C2 // 2), C.c_int(Wa2.shape[0]), _ptr(bac, torch.float32, True),
+        _ptr(Wa2, torch.float32), _ptr(ba2, torch.float32, True), _ptr(Wc2, torch.float32), _ptr(bc2, torch.float32, True),
+        _ptr(act, torch.int32), _ptr(logp_old, torch.float32), _ptr(adv, torch.float32), _ptr(ret, torch.float32),
+        _ptr(adv_moments, torch.float64, True), C.byref(c), _ptr(dbac, torch.float32), _ptr(dWa2, torch.float32),
+        _ptr(dba2, torch.float32), _ptr(dWc2, torch.float32), _ptr(dbc2, torch.float32), _ptr(metric_parts, torch.float64),
+        _ptr(workspace), _stream()), "gymrl_heads_loss_fwd_bwd")
+
+
 # ------------------------------------------------------ update-path GEMMs ---
 def gemm_workspace(device):
     return torch.empty(int(lib().gymrl_gemm_workspace_bytes()), dtype=torch.uint8, device=device)

@@ -59,6 +59,8 @@ class Config:
         self.gae_variant = 1             # 1 = time-blocked scan, 0 = sequential reference order
         self.fused_policy_forward = True  # rollout forward = one gymrl_mlp_forward launch (False: per-layer torch)
         self.fused_update = True          # update forward/backward scheduled by ppo_net (False: torch autograd)
+        self.hip_gemm = True              # hidden_dim 256: hand-written f32-MFMA GEMMs + loss inside the heads pass
+                                          # (False: round-1 path — library GEMMs + separate HBM passes)
         self.persistent_rollout = True    # LunarLander: whole chunks of vector steps in one launch (gymrl_rollout_lunar)
         self.rollout_chunk = 0            # vector steps per persistent launch (0: the whole rollout in one launch —
                                           # every extra launch boundary waits for the slowest workgroup again)
@@ -393,20 +395,21 @@ class PPOTrainer:
         self._packed = ops.pack_rollout(b.states[:b.T].reshape(total, obs_dim), b.actions.view(-1),
                                         b.log_probs.view(-1), b.advantages.view(-1), b.returns.view(-1),
                                         self._packed)
-        # block partials of every minibatch's 5 metric sums; reduced by ONE launch after the last step
-        nblk = ops.loss_blocks(mb)
-        if self._metric_parts is None or self._metric_parts.shape[:2] != (cfg.num_epochs * n_mb, nblk):
-            self._metric_parts = torch.zeros(cfg.num_epochs * n_mb, nblk, 5, dtype=torch.float64, device=self.device)
-        else:
-            self._metric_parts.zero_()
-        sizes = []
-        row = 0
         fu = None
         if cfg.fused_update and ppo_net.supported(self.model):
             if self._fused_update is None or self._fused_update.R < mb:
                 self._fused_update = ppo_net.FusedActorCriticUpdate(self.model, mb)
             fu = self._fused_update
             fu.timers = tm
+        one_pass = fu is not None and fu.hip_gemm and getattr(cfg, "hip_gemm", True)
+        # block partials of every minibatch's 5 metric sums; reduced by ONE launch after the last step
+        nblk = fu.metric_blocks(mb) if one_pass else ops.loss_blocks(mb)
+        if self._metric_parts is None or self._metric_parts.shape[:2] != (cfg.num_epochs * n_mb, nblk):
+            self._metric_parts = torch.zeros(cfg.num_epochs * n_mb, nblk, 5, dtype=torch.float64, device=self.device)
+        else:
+            self._metric_parts.zero_()
+        sizes = []
+        row = 0
         for epoch in range(cfg.num_epochs):
             if indices is not None:
                 perm = torch.as_tensor(indices[epoch], device=self.device).to(torch.int32)
@@ -424,24 +427,27 @@ class PPOTrainer:
                 mb_obs, mb_act, mb_lp, mb_adv, mb_ret = ops.gather_minibatch(self._packed, mb_idx, obs_dim, stage)
                 if tm is not None:
                     tm.stop("gather_minibatch", B)
-                if fu is not None:
-                    logits, values = fu.forward(mb_obs)
+                if one_pass:
+                    fu.step(mb_obs, mb_act, mb_lp, mb_adv, mb_ret, self._loss_cfg, self._moments, self._metric_parts[row])
                 else:
-                    logits, values = self.model(mb_obs)
-                    values = values.view(-1)
-                dlogits = torch.empty_like(logits)
-                dvalues = torch.empty_like(values)
-                if tm is not None:
-                    tm.start("ppo_loss_fwd_bwd")
-                ops.ppo_loss_fwd_bwd(logits, values, mb_act, mb_lp, mb_adv, mb_ret, self._loss_cfg,
-                                     adv_moments=self._moments, dlogits_out=dlogits, dvalue_out=dvalues,
-                                     workspace=self._metric_parts[row])
-                if tm is not None:
-                    tm.stop("ppo_loss_fwd_bwd", B)
-                if fu is not None:
-                    fu.backward(dlogits, dvalues)
-                else:
-                    torch.autograd.backward([logits, values], [dlogits, dvalues])
+                    if fu is not None:
+                        logits, values = fu.forward(mb_obs)
+                    else:
+                        logits, values = self.model(mb_obs)
+                        values = values.view(-1)
+                    dlogits = torch.empty_like(logits)
+                    dvalues = torch.empty_like(values)
+                    if tm is not None:
+                        tm.start("ppo_loss_fwd_bwd")
+                    ops.ppo_loss_fwd_bwd(logits, values, mb_act, mb_lp, mb_adv, mb_ret, self._loss_cfg,
+                                         adv_moments=self._moments, dlogits_out=dlogits, dvalue_out=dvalues,
+                                         workspace=self._metric_parts[row])
+                    if tm is not None:
+                        tm.stop("ppo_loss_fwd_bwd", B)
+                    if fu is not None:
+                        fu.backward(dlogits, dvalues)
+                    else:
+                        torch.autograd.backward([logits, values], [dlogits, dvalues])
                 if self.world_size > 1:
                     gdist.all_reduce_sum(self.flat_grads)
                 if tm is not None:

@@ -1,5 +1,23 @@
 """Hand-scheduled forward/backward of the PPO ActorCritic for the update phase.
 
+Default path (hidden_dim 256, `hip_gemm = True`): every contraction is a hand-written exact-f32 MFMA kernel of
+csrc/gemm.hip and the loss sits inside the heads pass — `step()`:
+
+    forward   H1  = tanh(X W1^T + b1)                 gymrl_linear_tanh_smallk   (K = obs_dim)
+              H2  = tanh(H1 W2^T + b2)                gymrl_linear_fwd, tanh in the MFMA epilogue
+              Zac = H2 [Wa1;Wc1]^T + [ba1;bc1]        gymrl_linear_fwd (N = 512, bias only: the heads pass applies
+                                                      the tanh where the VALU is idle)
+    loss+heads  dZac (in place), dbac, dWa2, dba2, dWc2, dbc2, metrics
+                                                      gymrl_heads_loss_fwd_bwd: ONE pass over Zac
+    backward  d[Wa1;Wc1] = dZac^T H2                  gymrl_linear_bwd_weight (N = 512)
+              dZ2 = (dZac [Wa1;Wc1]) (1 - H2^2)       gymrl_linear_bwd_input, tanh' in the epilogue
+              dW2 = dZ2^T H1, db2 = colsum dZ2        gymrl_linear_bwd_weight (+ bias gradient from the same pass)
+              dZ1 = (dZ2 W2) (1 - H1^2)               gymrl_linear_bwd_input
+              dW1 = dZ1^T X, db1 = colsum dZ1         gymrl_linear_smallk_bwd (dZ given)
+
+The round-1 path below (library GEMMs + separate HBM passes, `forward()` / `backward()`) stays for other widths and
+as the A/B baseline of tools/micro_update.py.
+
 `ActorCritic.evaluate_actions` + `loss.backward()` (ppo_lunarlander.py:110-117, :303) on a
 B = 262,144-row minibatch is, under autograd, 10 library GEMMs plus ~30 elementwise /
 reduction launches that each stream a [B, 256] activation through HBM.  Here the same math
@@ -88,6 +106,9 @@ class FusedActorCriticUpdate:
         self.bias_in_gemm = False
         self.overlap_dw = False     # dW GEMMs on a side stream under the HBM passes: measured 3.255 vs 3.23 ms, no gain
         self._side = torch.cuda.Stream(device=dev)
+        # hand-written MFMA GEMMs + loss inside the heads pass (module docstring); needs hidden_dim == 256
+        self.hip_gemm = H == 256 and self.A in (2, 4)
+        self.gemm_ws = ops.gemm_workspace(dev) if self.hip_gemm else None
 
     def _timed(self, name, units, fn, *args):
         tm = self.timers
@@ -129,6 +150,33 @@ class FusedActorCriticUpdate:
             torch.addmm(m.critic[2].bias, Hac[:, H:], m.critic[2].weight.t(), out=value)
         self._x = x
         return logits, value.view(-1)
+
+    def metric_blocks(self, B):
+        """Rows of the f64[blocks, 5] metric-partials buffer step() fills for a minibatch of B rows."""
+        return ops.heads_loss_blocks(B, self.H)
+
+    @torch.no_grad()
+    def step(self, x, act, logp_old, adv, ret, loss_cfg, adv_moments, metric_parts):
+        """Forward, loss and backward of one minibatch (module docstring): writes every parameter gradient
+        (overwrite) and the f64[metric_blocks(B), 5] partial metric sums."""
+        m, B = self.m, x.shape[0]
+        if B > self.R:
+            raise ValueError("minibatch larger than the buffers")
+        t = self._timed
+        H1, H2, Zac, dZ2, dZ1 = self.H1[:B], self.H2[:B], self.Hac[:B], self.dH2[:B], self.dH1[:B]
+        W2, ws = m.shared[2].weight, self.gemm_ws
+        t("linear_tanh_smallk", B, ops.linear_tanh_smallk, x, m.shared[0].weight, m.shared[0].bias, H1)
+        t("gemm_fwd_256_tanh", B, ops.linear_fwd, H1, W2, m.shared[2].bias, H2, True)
+        t("gemm_fwd_512", B, ops.linear_fwd, H2, self.Wac, self.bac, Zac, False)
+        t("heads_loss_fwd_bwd", B, ops.heads_loss_fwd_bwd, Zac, None, m.actor[2].weight, m.actor[2].bias,
+          m.critic[2].weight, m.critic[2].bias, act, logp_old, adv, ret, loss_cfg, adv_moments, self.dbac,
+          m.actor[2].weight.grad, m.actor[2].bias.grad, m.critic[2].weight.grad, m.critic[2].bias.grad, metric_parts, self.ws)
+        t("gemm_dw_512", B, ops.linear_bwd_weight, Zac, H2, self.dWac, ws)
+        t("gemm_dx_512_tanhbwd", B, ops.linear_bwd_input, Zac, self.Wac, H2, dZ2)
+        t("gemm_dw_256_db", B, ops.linear_bwd_weight, dZ2, H1, W2.grad, ws, m.shared[2].bias.grad)
+        t("gemm_dx_256_tanhbwd", B, ops.linear_bwd_input, dZ2, W2, H1, dZ1)
+        t("linear_smallk_bwd", B, ops.linear_smallk_bwd, dZ1, None, x, m.shared[0].weight.grad, m.shared[0].bias.grad,
+          self.ws)
 
     def _recompute_h1(self):
         """(W1, b1) when linear_smallk_bwd recomputes H1 from the observations instead of reading it."""

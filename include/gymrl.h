@@ -442,8 +442,10 @@ int gymrl_rollout_lunar(const gymrl_rollout_lunar_args* args, const gymrl_mlp_de
  *                        skinny GEMMs, two tanh' passes and four reductions.
  *                        pre_activation != 0: `Hac` holds the pre-activations instead and the kernel applies
  *                        tanh(. + bac[col]) (bac NULL: no bias) first — bit for bit the forward's values
- * tanh here is |x| < 0.625 ? odd polynomial : 1 - 2/(exp(2x)+1) on the hardware exp2/rcp
- * units (device-deterministic, ~2 ulp; compared with torch at 1e-5, not bit for bit).
+ * tanh here (and in gymrl_linear_fwd's epilogue) is 1 - 2/(exp(2x)+1) on the hardware exp2/rcp units:
+ * device-deterministic, absolute error < 2e-7, exact +-1 limits; compared with torch at 1e-5, not bit for bit.
+ * linear_smallk_bwd with H == NULL and W == NULL takes dH as dZ itself (the tanh' factor was applied upstream,
+ * gymrl_linear_bwd_input).
  */
 size_t gymrl_mlp_train_workspace_bytes(int C, int D, int A);
 int gymrl_linear_tanh_smallk(const float* x, const float* W, const float* b, int64_t B, int D, int C,
@@ -461,6 +463,24 @@ int gymrl_heads_bwd(const float* Hac, const float* dlogits, const float* dv, int
                     const float* Wa2, const float* Wc2, float* dZac, float* dbac, float* dWa2,
                     float* dba2, float* dWc2, float* dbc2, int pre_activation, const float* bac,
                     void* workspace, void* stream);
+
+/*
+ * heads_loss_fwd_bwd : gymrl_heads_fwd_tanh + gymrl_ppo_loss_fwd_bwd + gymrl_heads_bwd as ONE pass over
+ *   Zac [B, 512] (C == 256): per row tanh(Zac + bac), logits / value from the two heads, the clipped-surrogate loss of
+ *   ppo_lunarlander.py:278-300 (advantage normalised on load from adv_moments as in gymrl_ppo_loss_fwd_bwd; act /
+ *   logp_old / adv / ret are the minibatch's rows in order, i.e. already gathered), and the heads' backward: dZac
+ *   overwrites Zac in place; dbac [512], dWa2 [A, 256], dba2 [A], dWc2 [256], dbc2 [1] as gymrl_heads_bwd.
+ *   metric_parts: f64[gymrl_heads_loss_blocks(B, C)][5] block partials of (policy loss, value loss, entropy,
+ *   clip fraction, approx KL) sums — reduce with gymrl_reduce_rows.  Same arithmetic per row as the three
+ *   separate passes (one shared device function each), so gradients and metrics are bit-identical to them.
+ */
+int gymrl_heads_loss_blocks(int64_t B, int C);
+int gymrl_heads_loss_fwd_bwd(float* Zac, int64_t B, int C, int A, const float* bac, const float* Wa2,
+                             const float* ba2, const float* Wc2, const float* bc2, const int32_t* act,
+                             const float* logp_old, const float* adv, const float* ret,
+                             const double* adv_moments, const gymrl_ppo_cfg* cfg, float* dbac, float* dWa2,
+                             float* dba2, float* dWc2, float* dbc2, double* metric_parts, void* workspace,
+                             void* stream);
 
 /* ===================================================== update-path GEMMs === */
 /*
@@ -486,7 +506,9 @@ int gymrl_heads_bwd(const float* Hac, const float* dlogits, const float* dv, int
  * `rows_per_slice` rows (gymrl_linear_bwd_weight_geometry); inside a slice one fmaf chain from +0 over
  * the rows ascending; dW = ((g0 + g1) + g2) + g3 in f64, g_j = the f64 sum of the slice results s = j
  * (mod 4) ascending, rounded once to f32.  colsum_out is a fixed-order sum (device-deterministic,
- * compared at 1e-5).  act = tanh uses the same hardware-exp2 form as the passes above.
+ * compared at 1e-5).  act = tanh uses the same hardware-exp2 form as the passes above.  bwd_weight's db [N]
+ * (NULL: skipped) = column sums of dY — the bias gradient of the same layer: per slice the even- and the odd-offset
+ * rows are summed sequentially in f32 and added, slices combine like the weight tiles (bit for bit in the oracle).
  * gymrl_gemm_config(key, value): knobs of tools/micro_gemm.py / tools/abl_gemm.py (2: prefetch ring depth of
  * bwd_weight 4|8; 4: ablation mode of bwd_weight, 0 = the product kernel); results do not depend on key 2.
  */

@@ -483,7 +483,7 @@ def test_fused_actor_critic_update_matches_autograd(dev, hidden, B, A, D):
     ref = {k: p.grad.clone() for k, p in net.named_parameters()}
     ref_logits, ref_value = logits.detach().clone(), value.detach().view(-1).clone()
     net._flat_grads.zero_()
-    fu = ppo_net.FusedActorCriticUpdate(net, B)
+    fu = ppo_net.FusedActorCriticUpdate(net, B)          # the round-1 path: library GEMMs + separate HBM passes
     grads = {}
     for recompute in ((True, False), (False, False), (True, True)):     # (tanh of the heads, H1) recomputed in backward or stored
         fu.recompute_tanh, fu.recompute_h1 = recompute

@@ -57,36 +57,28 @@ def main():
         torch.cuda.synchronize()
         return s.elapsed_time(e) / iters
 
+    parts1 = torch.zeros(fu.metric_blocks(B), 5, dtype=torch.float64, device=dev)
+
+    def hip_step():        # round 2: hand-written MFMA GEMMs + the loss inside the heads pass
+        fu.step(x, act, lpo, adv, ret, (0.2, 3.0, 0.5, 0.01), mom, parts1)
+        opt.step()
+
     out = {}
     for rep in range(3):
-        fu.fused_heads_forward = True
-        out.setdefault("fused_update_ms(heads_fwd_tanh)", []).append(round(timeit(fused_step), 3))
-        fu.fused_heads_forward = False
-        out.setdefault("fused_update_ms(tanh + 2 head GEMMs)", []).append(round(timeit(fused_step), 3))
-        fu.fused_heads_forward, fu.overlap_dw = True, False
-        out.setdefault("fused_update_ms(dW GEMMs on the main stream)", []).append(round(timeit(fused_step), 3))
-        fu.overlap_dw = True
-        fu.fused_heads_forward, fu.bias_in_gemm = True, True
-        out.setdefault("fused_update_ms(bias in the GEMM epilogue)", []).append(round(timeit(fused_step), 3))
-        fu.bias_in_gemm = False
+        out.setdefault("hip_gemm_one_pass_update_ms", []).append(round(timeit(hip_step), 3))
+        fu.fused_heads_forward, fu.overlap_dw, fu.bias_in_gemm = True, False, False
+        out.setdefault("library_gemm_update_ms (round 1)", []).append(round(timeit(fused_step), 3))
     out["autograd_update_ms"] = [round(timeit(autograd_step), 3)]
-    prev = torch.backends.cuda.preferred_blas_library()
-    torch.backends.cuda.preferred_blas_library("cublas")          # rocBLAS for the 262 144-row GEMMs
-    fu.fused_heads_forward, fu.overlap_dw, fu.bias_in_gemm = True, False, False
-    out["fused_update_ms(GEMMs on rocBLAS)"] = [round(timeit(fused_step), 3) for _ in range(2)]
-    torch.backends.cuda.preferred_blas_library(prev)
-    if os.environ.get("GYMRL_TRY_TUNABLE"):
-        import torch.cuda.tunable as tn
-        tn.enable(True)
-        tn.tuning_enable(True)
-        tn.set_max_tuning_duration(50)
-        tn.set_max_tuning_iterations(20)
-        tn.set_filename("/tmp/tunableop.csv")
-        fu.fused_heads_forward = True
-        fused_step()
-        torch.cuda.synchronize()
-        tn.tuning_enable(False)
-        out["fused_update_ms(tunable GEMMs)"] = [round(timeit(fused_step), 3) for _ in range(2)]
+    # per-kernel event times of the round-2 path
+    from gymrl_amd.ppo_lunarlander import KernelTimers
+    fu.timers = KernelTimers()
+    for _ in range(10):
+        hip_step()
+    out["kernels_us"] = {k: round(v["avg_us"], 1) for k, v in fu.timers.summary().items()}
+    fu.timers = None
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/micro_update.json", "w") as f:
+        json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
 
 
