@@ -116,6 +116,7 @@ def main():
         sys.stdout = open(os.devnull, "w")
     trainer = PPOTrainer(cfg)
     T, N = cfg.update_freq, cfg.num_envs
+    init_params = trainer.flat_params.clone()
 
     phase_events = []
 
@@ -157,91 +158,101 @@ def main():
         return
     sys.stdout = sys.__stdout__
     try:
-        report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev)
+        # rollout under the initial policy (outside the timed region; the trained parameters are put back)
+        trained = trainer.flat_params.clone()
+        trainer.flat_params.copy_(init_params)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sc, rc = trainer.step_count, trainer.rollout_count
+        e0.record()
+        trainer.collect_rollout()
+        e1.record()
+        torch.cuda.synchronize()
+        frozen_ms = round(e0.elapsed_time(e1), 1)
+        trainer.flat_params.copy_(trained)
+        trainer.step_count, trainer.rollout_count = sc, rc
+        report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev, frozen_ms)
     finally:
         gdist.shutdown()               # always release the other ranks, even if the report fails
 
 
-def report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev):
+def report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev, frozen_ms=None):
     ks = timers.summary()
     transitions = T * N
     rollout_s = sum(e[0].elapsed_time(e[1]) for e in phase_events) * 1e-3 / a.steps
     update_s = sum(e[1].elapsed_time(e[2]) for e in phase_events) * 1e-3 / a.steps
-    # algorithmic bytes: GAE 17 B/elt, loss fwd+bwd 56 B/sample,
-    # gather 64 B line in + 48 B out + 4 B index, Adam 36 B/param incl. norm pre-pass + zero_grad
-    # update-path passes (csrc/mlp_train.hip), per row of a [B, C=256] activation (obs D=8, A=4):
-    #   linear_tanh_smallk read 4D + write 4C; heads_fwd_tanh read 8C, write 4(A+1) (tanh is recomputed by heads_bwd, not stored); heads_bwd read 8C + 4(A+1),
-    #   write 8C; tanh_bwd_colsum
-    #   read 8C, write 4C; linear_smallk_bwd read 8C + 4D; tanh_inplace 8 B per element
     Cw, Dw, Aw = cfg.hidden_dim, 8, 4
+    fu = getattr(trainer, "_fused_update", None)
+    # algorithmic bytes per unit of the HBM-bound kernels: GAE 17 B/elt, loss
+    # fwd+bwd 56 B/sample, gather 64 B line in + 48 B out + 4 B index, Adam 36 B/param incl. norm pre-pass + zero_grad;
+    # per row of a [B, C = 256] activation: linear_tanh_smallk read 4D, write 4C; heads_loss_fwd_bwd read 8C + 16 (act,
+    # logp_old, adv, ret), write 8C; linear_smallk_bwd (dZ given) read 4C + 4D; round-1 passes as in round 1
     bytes_per_unit = {"gae": 17.0, "ppo_loss_fwd_bwd": 56.0, "gather_minibatch": 116.0, "adam_step": 36.0,
                       "linear_tanh_smallk": 4.0 * (Dw + Cw), "tanh_inplace": 8.0,
-                      "heads_fwd_tanh": (8.0 if getattr(getattr(trainer, "_fused_update", None), "recompute_tanh", True) else 16.0) * Cw + 4.0 * (Aw + 1),
-                      "heads_bwd": 16.0 * Cw + 4.0 * (Aw + 1), "tanh_bwd_colsum": 12.0 * Cw,
-                      "linear_smallk_bwd": (4.0 if getattr(getattr(trainer, "_fused_update", None), "recompute_h1", False) else 8.0) * Cw + 4.0 * Dw}
+                      "heads_loss_fwd_bwd": 16.0 * Cw + 16.0,
+                      "heads_fwd_tanh": 8.0 * Cw + 4.0 * (Aw + 1), "heads_bwd": 16.0 * Cw + 4.0 * (Aw + 1),
+                      "tanh_bwd_colsum": 12.0 * Cw,
+                      "linear_smallk_bwd": (4.0 if "gemm_dx_256_tanhbwd" in ks else 8.0) * Cw + 4.0 * Dw}
+    # flops per row of the hand-written f32-MFMA GEMMs (csrc/gemm.hip)
+    flops_per_unit = {"gemm_fwd_256_tanh": 2.0 * Cw * Cw, "gemm_fwd_512": 4.0 * Cw * Cw, "gemm_dw_512": 4.0 * Cw * Cw,
+                      "gemm_dx_512_tanhbwd": 4.0 * Cw * Cw, "gemm_dw_256_db": 2.0 * Cw * Cw, "gemm_dx_256_tanhbwd": 2.0 * Cw * Cw}
     kernels = {}
     for k, v in ks.items():
         ent = dict(launches=v["launches"], avg_us=round(v["avg_us"], 2))
         if k in bytes_per_unit:
             gbps = bytes_per_unit[k] * v["units"] / v["total_s"] / 1e9
-            ent.update(bytes_per_unit=bytes_per_unit[k], achieved_GBps=round(gbps, 1), frac=round(gbps * 1e9 / HBM_PEAK, 4))
+            ent.update(bound="hbm", bytes_per_unit=bytes_per_unit[k], achieved_GBps=round(gbps, 1), frac=round(gbps * 1e9 / HBM_PEAK, 4))
+        if k in flops_per_unit:
+            tf = flops_per_unit[k] * v["units"] / v["total_s"] / 1e12
+            ent.update(bound="mfma", flops_per_unit=flops_per_unit[k], achieved_TFLOPs=round(tf, 1), frac=round(tf * 1e12 / MFMA_F32_PEAK, 4))
         kernels[k] = ent
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    pm = json.load(open(pmc)) if os.path.exists(pmc) else None
-    # (1) The dominant hand-written HBM-bound work of the timed region: the five update passes of
-    # csrc/mlp_train.hip, launched once per minibatch around the library GEMMs (14 % of the step).
-    # achieved = their algorithmic bytes per minibatch / the sum of their average launch durations,
-    # HIP events on the launch stream inside the timed region; traffic = PMC bytes of the same launches.
-    upd = ["linear_tanh_smallk", "tanh_inplace", "heads_fwd_tanh", "heads_bwd", "tanh_bwd_colsum", "linear_smallk_bwd"]
-    if all(k in ks for k in upd):
-        n_mb = ks["heads_bwd"]["launches"]
-        upd_bytes = sum(bytes_per_unit[k] * ks[k]["units"] for k in upd) / n_mb
-        upd_s = sum(ks[k]["total_s"] for k in upd) / n_mb
-        upd_traffic = None
-        if pm is not None and all(k in pm for k in upd):
-            upd_traffic = round(sum(pm[k]["hbm_bytes_per_unit"] * ks[k]["units"] for k in upd) / n_mb)
-        head = dict(kernel="update passes of one minibatch (csrc/mlp_train.hip): linear_tanh_smallk + tanh_inplace + "
-                           "heads_fwd_tanh + heads_bwd + tanh_bwd_colsum + linear_smallk_bwd",
-                    achieved=round(upd_bytes / upd_s / 1e9, 1), frac=round(upd_bytes / upd_s / HBM_PEAK, 4),
-                    traffic=upd_traffic, bytes_per_launch=upd_bytes, launch_s=upd_s)
-    else:
-        head = None
-    # (2) The pass BASELINE.json's metric names: GAE (moments fused) + one clipped-surrogate loss pass over
-    # the rollout = 17 + 56 = 73 algorithmic bytes per transition.  In the run the loss is 32 minibatch
-    # launches per pass (14.7 MB each: launch-latency bound); SURVEY 8(d) defines the pass at T*N in one launch.
+    prof = None
+    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            prof = (name, json.load(open(path)))
+            break
+    gemms = [k for k in flops_per_unit if k in ks]
+    n_upd = a.steps * cfg.num_epochs * cfg.num_minibatches
+    if gemms:
+        # The dominant hand-written work of the step: the six exact-f32 MFMA GEMM launches of every minibatch update
+        # (csrc/gemm.hip), event-timed on the launch stream inside the timed region.
+        fl = sum(flops_per_unit[k] * ks[k]["units"] for k in gemms) / n_upd
+        sec = sum(ks[k]["total_s"] for k in gemms) / n_upd
+        head = dict(bound="mfma", unit="TFLOP/s", peak=MFMA_F32_PEAK / 1e12, achieved=round(fl / sec / 1e12, 1),
+                    frac=round(fl / sec / MFMA_F32_PEAK, 4),
+                    kernel="the six f32-MFMA GEMM launches of one minibatch update (csrc/gemm.hip: gemm_ws_kernel x4, gemm_tn_kernel x2 "
+                           "+ their reductions), algorithmic flops / summed average launch durations",
+                    flops_per_launch_group=fl, launch_s=sec, share_of_step=round(sec * n_upd / a.steps / (rollout_s + update_s), 3))
+    else:      # round-1 path (cfg.hip_gemm = False / other widths): the HBM-bound passes around the library GEMMs
+        upd = [k for k in ("linear_tanh_smallk", "tanh_inplace", "heads_fwd_tanh", "heads_bwd", "tanh_bwd_colsum", "linear_smallk_bwd") if k in ks]
+        by = sum(bytes_per_unit[k] * ks[k]["units"] for k in upd) / n_upd
+        sec = sum(ks[k]["total_s"] for k in upd) / n_upd
+        head = dict(bound="hbm", unit="GB/s", peak=HBM_PEAK / 1e9, achieved=round(by / sec / 1e9, 1), frac=round(by / sec / HBM_PEAK, 4),
+                    kernel="update passes of one minibatch (csrc/mlp_train.hip)", bytes_per_launch_group=by, launch_s=sec)
+    # The pass BASELINE.json's metric names (GAE + clipped-surrogate loss).  In the run the loss is no longer a pass of its
+    # own: it is evaluated inside gymrl_heads_loss_fwd_bwd on values that never leave registers, so `in_run` reports the GAE
+    # launch (17 B per transition) and the heads+loss pass (its own 4112 B per row) separately; `at_rollout_size` is
+    # SURVEY 8(d)'s definition — one launch of each stand-alone kernel over T*N transitions, measured live.
     gae_s = ks["gae"]["total_s"] / ks["gae"]["launches"]
-    loss_s_per_pass = ks["ppo_loss_fwd_bwd"]["total_s"] / (a.steps * cfg.num_epochs)
-    pass_bytes = 73.0 * transitions
-    achieved = pass_bytes / (gae_s + loss_s_per_pass)
-    traffic = None
-    if pm is not None:
-        traffic = round((pm["gae"]["hbm_bytes_per_transition"] + pm["ppo_loss"]["hbm_bytes_per_sample"]) * transitions)
+    in_run = dict(gae=dict(launch_s=gae_s, achieved=round(17.0 * transitions / gae_s / 1e9, 1), frac=round(17.0 * transitions / gae_s / HBM_PEAK, 4)))
+    if "heads_loss_fwd_bwd" in ks:
+        hl = ks["heads_loss_fwd_bwd"]
+        in_run["heads_loss_fwd_bwd"] = dict(launch_s=hl["total_s"] / hl["launches"], achieved=kernels["heads_loss_fwd_bwd"]["achieved_GBps"],
+                                            frac=kernels["heads_loss_fwd_bwd"]["frac"], note="loss inside the heads pass: 4112 B per row")
+    elif "ppo_loss_fwd_bwd" in ks:
+        loss_s = ks["ppo_loss_fwd_bwd"]["total_s"] / (a.steps * cfg.num_epochs)
+        in_run["ppo_loss_fwd_bwd"] = dict(launch_s=loss_s, achieved=round(56.0 * transitions / loss_s / 1e9, 1),
+                                          frac=round(56.0 * transitions / loss_s / HBM_PEAK, 4), note="32 minibatch launches per pass")
     gae_loss = dict(kernel="gae(G1: chunk maps fused in the rollout + carry + apply + moments) + ppo_loss_fwd_bwd",
-                    in_run=dict(achieved=round(achieved / 1e9, 1), frac=round(achieved / HBM_PEAK, 4),
-                                launch_s=gae_s + loss_s_per_pass, note="1 GAE launch + 32 minibatch loss launches per pass"),
-                    at_rollout_size=full_pass(trainer, T, N, dev), traffic=traffic, bytes_per_pass=pass_bytes)
-    if head is None:
-        head = dict(kernel=gae_loss["kernel"], achieved=gae_loss["in_run"]["achieved"], frac=gae_loss["in_run"]["frac"],
-                    traffic=traffic, bytes_per_launch=pass_bytes, launch_s=gae_s + loss_s_per_pass)
-    if pm is not None and "rollout_lunar" in pm and "rollout_chunk" in kernels:
-        # the largest single kernel of the step is ALU-latency bound, not HBM / MFMA bound: its PMC evidence
-        kernels["rollout_chunk"]["pmc"] = {k: pm["rollout_lunar"][k] for k in ("valu_issue_slots_used", "bound")}
-    # (3) The rest of the update is library work: 9 H^2 multiply-adds per row per minibatch in six f32 GEMMs
-    # (hipBLASLt).  Derived, not event-timed: update time minus every hand-written kernel timed above, so it
-    # still contains the split-K partial sums and the launch gaps — a lower bound on the GEMMs' own rate.
-    lib = None
-    own = [k for k in ("gather_minibatch", "ppo_loss_fwd_bwd", "adam_step") + tuple(upd) if k in ks]
-    if all(k in ks for k in upd) and update_s > 0:
-        n_upd = a.steps * cfg.num_epochs * cfg.num_minibatches
-        rest_s = update_s * a.steps / n_upd - sum(ks[k]["total_s"] for k in own) / n_upd
-        flops = 2.0 * (transitions // cfg.num_minibatches) * 9.0 * Cw * Cw
-        lib = dict(bound="mfma", dtype="f32", flops_per_minibatch=flops, seconds_per_minibatch=rest_s,
-                   achieved=round(flops / rest_s / 1e12, 1), peak=MFMA_F32_PEAK / 1e12, unit="TFLOP/s",
-                   frac=round(flops / rest_s / MFMA_F32_PEAK, 4),
-                   note="derived: update time minus the event-timed hand-written kernels (includes split-K sums and launch gaps)")
-    roofline = dict(bound="hbm", achieved=head["achieved"], peak=HBM_PEAK / 1e9, unit="GB/s", frac=head["frac"],
-                    traffic=head["traffic"], kernel=head["kernel"], bytes_per_launch=head["bytes_per_launch"],
-                    launch_s=head["launch_s"], gae_loss_pass=gae_loss, library_gemms=lib, kernels=kernels)
+                    in_run=in_run, at_rollout_size=full_pass(trainer, T, N, dev), bytes_per_pass=73.0 * transitions)
+    roofline = dict(bound=head["bound"], achieved=head["achieved"], peak=head["peak"], unit=head["unit"], frac=head["frac"],
+                    traffic=None, kernel=head["kernel"], launch_s=head["launch_s"],
+                    traffic_from_profiles=(dict(file="profiles/" + prof[0], note="PMC byte counts of separate rocprofv3 --pmc passes over the "
+                                                "same kernels (tools/pmc_kernels.py), not measured in this run", summary=prof[1]) if prof else None),
+                    gae_loss_pass=gae_loss, kernels=kernels)
+    for k in ("flops_per_launch_group", "bytes_per_launch_group", "share_of_step"):
+        if k in head:
+            roofline[k] = head[k]
 
     out = {
         "metric": "env-steps/sec at N envs/GPU (PPO LunarLander), 1/2/4/8 GPUs + %HBM roofline",
@@ -258,7 +269,10 @@ def report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev)
                    "parallelism": f"dp{world} (env shards + flat-gradient all-reduce)" if world > 1 else "single GPU"},
         "roofline": roofline,
         "phases": {"rollout_ms": round(rollout_s * 1e3, 1), "update_ms": round(update_s * 1e3, 1),
-                   "rollout_only_env_steps_per_s": round(transitions / rollout_s)},
+                   "rollout_only_env_steps_per_s": round(transitions / rollout_s),
+                   # one rollout under the initial (frozen) policy, outside the timed region: the in-run figure moves with
+                   # what the policy has learned (contact mix), this one does not
+                   "rollout_frozen_policy_ms": frozen_ms},
         "train_metrics": {k: float(v) for k, v in (metrics or {}).items()},
         "avg_episode_return": (sum(trainer.episode_rewards) / len(trainer.episode_rewards)) if trainer.episode_rewards else None,
     }

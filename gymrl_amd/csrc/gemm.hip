@@ -114,20 +114,29 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(WsArgs p) {
   else { slice = b % S; rg = b / S; }
   const int n0 = slice * BN;
 
-  // ---- weight slice (+ bias slice) -> LDS, once per workgroup
-  if constexpr (!TRANS_W) {
-    for (int idx = tid; idx < BN * (RED / 4); idx += kThreads) {
-      const int n = idx % BN, q = idx / BN;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p.W + (size_t)(n0 + n) * p.ldw + 4 * q);
-      *reinterpret_cast<f32x4*>(&lds[((size_t)q * BN + n) * 4]) = v;
-    }
-  } else {
-    // thread (q, n) gathers W[4q .. 4q+3][n0 + n] (four coalesced row reads across the wave) into one 16-byte LDS word
-    for (int idx = tid; idx < BN * (RED / 4); idx += kThreads) {
-      const int n = idx % BN, q = idx / BN;
-      const float* w = p.W + (size_t)(4 * q) * p.ldw + n0 + n;
-      const f32x4 v = {w[0], w[p.ldw], w[2 * (size_t)p.ldw], w[3 * (size_t)p.ldw]};
-      *reinterpret_cast<f32x4*>(&lds[((size_t)q * BN + n) * 4]) = v;
+  // ---- weight slice (+ bias slice) -> LDS, once per workgroup: all loads of a batch are issued before the first
+  // LDS store (the fill is ~10 us of every launch; left rolled it is one L2 round trip per iteration)
+  {
+    constexpr int ITER = BN * (RED / 4) / kThreads, BATCH = 8;
+    static_assert(BN * (RED / 4) % kThreads == 0 && ITER % BATCH == 0, "fill tiling");
+#pragma unroll 1
+    for (int it0 = 0; it0 < ITER; it0 += BATCH) {
+      f32x4 v[BATCH];
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        const int idx = tid + (it0 + k) * kThreads, n = idx % BN, q = idx / BN;
+        if constexpr (!TRANS_W) {
+          v[k] = *reinterpret_cast<const f32x4*>(p.W + (size_t)(n0 + n) * p.ldw + 4 * q);
+        } else {      // thread (q, n) gathers W[4q .. 4q+3][n0 + n]: four row reads, coalesced across the wave
+          const float* w = p.W + (size_t)(4 * q) * p.ldw + n0 + n;
+          v[k] = f32x4{w[0], w[p.ldw], w[2 * (size_t)p.ldw], w[3 * (size_t)p.ldw]};
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        const int idx = tid + (it0 + k) * kThreads, n = idx % BN, q = idx / BN;
+        *reinterpret_cast<f32x4*>(&lds[((size_t)q * BN + n) * 4]) = v[k];
+      }
     }
   }
   if (tid < BN) lds[RED * BN + tid] = (EPI != EPI_TANHBWD && p.bias) ? p.bias[n0 + tid] : 0.0f;
