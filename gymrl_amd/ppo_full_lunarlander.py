@@ -57,7 +57,7 @@ class Config:
         self.anneal = True
         self.device = "cuda"
         self.num_envs = 1
-        self.use_graphs = True             # replay the minibatch update as a captured hipGraph (1 GPU, equal minibatches)
+        self.use_graphs = True             # replay the minibatch update as captured hipGraphs (equal minibatches)
 
 
 def _ortho(layer, std):
@@ -288,8 +288,12 @@ class PPOTrainer:
         self.episode_rewards = deque(maxlen=10)
         self.lr, self.ent_coef = config.lr, config.entropy_coef
         self.buffer = RolloutBuffer(int(config.update_freq), N, state_dim, self.device)
-        self._perm_gen = torch.Generator(device=self.device)
+        self._perm_gen = torch.Generator(device=self.device)            # covariance-clip row draws (:607)
         self._perm_gen.manual_seed(self.base_seed * 7919 + 17 + self.rank)
+        self._perm_seed, self._perm_draws, self._perm = self.base_seed * 7919 + 17 + self.rank, 0, None   # epoch shuffles
+        self._parity_noise = None      # tests: list of f32[T, N, A] Exp(1) draws, one per rollout (popped)
+        self._parity_perms = None      # tests: iterator of i32[T*N] shuffle orders, one per epoch (DataLoader's RandomSampler)
+        self.grad_norms = None         # tests: set to [] to record the pre-clip gradient norm of every minibatch
         self._sink = GradSink(self.model)
         self._g_idx, self._g_warm = None, 0          # hipGraph replay of the minibatch body (update_model)
         self._fwd_graph, self._fwd_in, self._fwd_out, self._fwd_warm = None, None, None, 0
@@ -302,12 +306,14 @@ class PPOTrainer:
         env.reset(b.states[0], seed=seed & 0x7FFFFFFFFFFFFFFF)
         c0 = self.rollout_count * b.T
         graphed = bool(getattr(cfg, "use_graphs", True))
+        noise = self._parity_noise.pop(0) if self._parity_noise else None
         for t in range(b.T):
             if graphed:                                   # the ~100-launch mHC forward as one graph launch
                 logits, value = self._forward_graphed(b.states[t])
             else:
                 logits, value = self.model(b.states[t])
-            ops.categorical_sample(logits, value=value.view(-1), seed=env.seed, counter=c0 + t, env_id0=env.env_id0,
+            ops.categorical_sample(logits, value=value.view(-1), noise_exp=None if noise is None else noise[t],
+                                   seed=env.seed, counter=c0 + t, env_id0=env.env_id0,
                                    act_out=b.actions[t], logp_out=b.log_probs[t], ent_out=b.old_entropies[t],
                                    value_out=b.values[t])
             env.step(b.actions[t], b.states[t + 1], b.rewards[t], done_out=b.dones[t], ep_ret_out=b.ep_returns[t])
@@ -350,7 +356,7 @@ class PPOTrainer:
         sizes, row = [], 0
         lcfg = (cfg.clip_eps_min, cfg.clip_eps_max, cfg.dual_clip, cfg.erc_beta_low, cfg.erc_beta_high, self.ent_coef)
 
-        def minibatch(idx, metrics_row, bias=None):
+        def fwd_bwd(idx, metrics_row):
             logits, values = self.model(states.index_select(0, idx))
             values = values.view(-1)
             mul = None
@@ -362,17 +368,28 @@ class PPOTrainer:
             self._sink.arm()
             torch.autograd.backward([logits, values], [dlogits, dvalues])
             self._sink.collect()
-            if self.world_size > 1:
-                gdist.all_reduce_sum(self.flat_grads)
+
+        def opt_step(bias=None):
             self.optimizer.step(grad_scale=1.0 / self.world_size, bias_dev=bias)
 
+        def minibatch(idx, metrics_row, bias=None):
+            fwd_bwd(idx, metrics_row)
+            if self.world_size > 1:
+                gdist.all_reduce_sum(self.flat_grads)
+            if self.grad_norms is not None:                                # tests: the norm clip_grad_norm_ would return
+                ops.sqnorm(self.flat_grads, self.optimizer._sq, self.optimizer._ws, 1.0 / self.world_size)
+                self.grad_norms.append(float(self.optimizer._sq.sqrt().item()))
+            opt_step(bias)
+
         # One minibatch of the mHC network is ~400 launches of a few microseconds (8 ms at 1024 rows): with equal
-        # minibatches and no collective inside, the minibatch body is captured once per update_model() call
-        # (rollout tensors and the annealed entropy coefficient are constants of that call) and replayed
-        # (gymrl_amd/graphs.py).  The first two minibatches ever run eagerly (library warm-up).
-        graphed = (bool(getattr(cfg, "use_graphs", True)) and self.world_size == 1 and total % mb == 0
-                   and cfg.num_epochs * n_mb > 2 and cfg.clip_cov_ratio <= 0)      # the covariance clip reads the host
-        graph = None
+        # minibatches the minibatch body is captured once per update_model() call (rollout tensors and the annealed
+        # entropy coefficient are constants of that call) and replayed (gymrl_amd/graphs.py).  With more than one rank
+        # it is TWO graphs around the eager gradient all-reduce — forward/loss/backward, then clip + Adam — so the
+        # 8-GPU configuration runs the same replayed kernels as one GPU.  The first two minibatches ever run eagerly
+        # (library warm-up).
+        graphed = (bool(getattr(cfg, "use_graphs", True)) and total % mb == 0 and cfg.num_epochs * n_mb > 2
+                   and cfg.clip_cov_ratio <= 0 and self.grad_norms is None)      # the covariance clip reads the host
+        graph = graph2 = None
         if graphed and self._g_idx is None:
             from .graphs import StepScalars
             self._scalars = StepScalars(self.device)
@@ -380,7 +397,13 @@ class PPOTrainer:
             self._g_idx = torch.empty(mb, dtype=torch.int32, device=self.device)
             self._g_row = torch.zeros(9, dtype=torch.float64, device=self.device)
         for _ in range(cfg.num_epochs):
-            perm = torch.randperm(total, device=self.device, generator=self._perm_gen).to(torch.int32)   # shuffle=True
+            if self._parity_perms is not None:                             # parity mode: the DataLoader's shuffle order
+                perm = torch.as_tensor(next(self._parity_perms), device=self.device).to(torch.int32)
+            else:                                                          # shuffle=True: keyed bijection, no sort (:561-563)
+                self._perm_draws += 1
+                self._perm = ops.permutation(self._perm_seed, self._perm_draws, total, self.device,
+                                             out=self._perm if self._perm is not None and self._perm.numel() == total else None)
+                perm = self._perm
             for start in range(0, total, mb):
                 idx = perm[start:start + mb]
                 B = idx.numel()
@@ -394,15 +417,26 @@ class PPOTrainer:
                     if self._g_warm < 2:
                         self._g_warm += 1
                         minibatch(self._g_idx, self._g_row, self._g_bias)
-                    else:
+                    elif self.world_size == 1:
                         if graph is None:
                             graph = torch.cuda.CUDAGraph()
                             with torch.cuda.graph(graph):
                                 minibatch(self._g_idx, self._g_row, self._g_bias)
                         graph.replay()
+                    else:
+                        if graph is None:                                  # (capturing does not execute)
+                            graph, graph2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(graph):
+                                fwd_bwd(self._g_idx, self._g_row)
+                            with torch.cuda.graph(graph2):
+                                opt_step(self._g_bias)
+                        graph.replay()
+                        gdist.all_reduce_sum(self.flat_grads)
+                        graph2.replay()
                     metrics[row].copy_(self._g_row)
                 sizes.append(B)
                 row += 1
+        del graph2
         del graph
         if cfg.anneal:                                                     # :660-666 (after the update)
             frac = 1 - self.step_count * self.world_size / cfg.max_train_steps

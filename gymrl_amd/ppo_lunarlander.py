@@ -503,7 +503,14 @@ class PPOTrainer:
                       f"Avg Reward: {avg_reward:.1f} | Policy Loss: {metrics['policy_loss']:.4f} | "
                       f"Value Loss: {metrics['value_loss']:.4f} | Entropy: {metrics['entropy']:.4f} | "
                       f"KL: {metrics['approx_kl']:.4f} | Clip: {metrics['clip_frac']:.2%}")
-            if len(self.episode_rewards) >= 100 and np.mean(self.episode_rewards) >= self.cfg.solved_reward:
+            # the stop decision is collective: every rank sees different episodes, and a rank that left alone would
+            # strand the others in the next all-reduce
+            solved = len(self.episode_rewards) >= 100 and np.mean(self.episode_rewards) >= self.cfg.solved_reward
+            if self.world_size > 1:
+                flag = torch.tensor([1.0 if solved else 0.0], device=self.device)
+                gdist.all_reduce_max(flag)
+                solved = bool(flag.item() > 0)
+            if solved:
                 if self.rank == 0:
                     print(f"\nEnvironment solved at step {self.step_count * self.world_size:,}!")
                 break

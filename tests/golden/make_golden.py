@@ -1301,6 +1301,91 @@ def gen_ppo_lstm_trace():
     save("ppo_lstm_trace", **out)
 
 
+def gen_ppo_full_trace():
+    """Row F3 / H1 for PPO-full: the reference PPOTrainer.train() (ppo_full_lunarlander.py:681-700) run unmodified for two
+    collect_experience -> compute_advantages -> update_model iterations on the scripted env at small mHC widths.
+    Records the Exp(1) draws Categorical.sample consumed, the DataLoader's shuffle orders (RandomSampler's torch.randperm),
+    every buffer field incl. old_entropies, next_value, adv / returns, per-minibatch gradient norms, lr / ent_coef
+    (annealed AFTER the update, :660-666), step_count, episode_rewards and the weights after each update."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from scripted_env import ScriptedEnv
+    mod = load_ref("algorithms/ppo_full_lunarlander.py", "ref_ppo_full_trace")
+    sys.modules["gymnasium"].make = lambda name, **kw: ScriptedEnv(8, 4)
+    cfg = mod.Config()
+    cfg.update_freq, cfg.batch_size, cfg.num_epochs = 96, 40, 2          # 96 / 40: a short last minibatch
+    cfg.mhc_dim, cfg.mhc_layers, cfg.mhc_sk_it = 16, 1, 4
+    cfg.max_train_steps, cfg.lr, cfg.seed = 2 * cfg.update_freq, 5e-3, 3
+    seed_all(0)
+    tr = mod.PPOTrainer(cfg)
+    with torch.no_grad():                                   # away from the near-uniform init policy (last_std = 0.001)
+        for n_, p_ in tr.model.named_parameters():
+            if n_.startswith("actor") or n_.endswith(".w") or n_.endswith(".alpha"):
+                p_.add_(0.25 * torch.randn_like(p_))
+    out = {"init_" + k: v.numpy().copy() for k, v in tr.model.state_dict().items()}
+    noise, perms, gnorms, rollouts, upd = [], [], [], [], []
+    orig_get_action = tr.model.get_action
+
+    def get_action(x, deterministic=False):
+        st = torch.get_rng_state()
+        res = orig_get_action(x, deterministic)
+        after = torch.get_rng_state()
+        torch.set_rng_state(st)
+        q = torch.empty(1, 4).exponential_(1.0)
+        torch.set_rng_state(after)
+        noise.append(q.numpy()[0].copy())
+        return res
+    tr.model.get_action = get_action
+    orig_randperm, orig_clip = torch.randperm, mod.nn.utils.clip_grad_norm_
+
+    def randperm(n, *a, **k):
+        r = orig_randperm(n, *a, **k)
+        if n == cfg.update_freq:
+            perms.append(r.numpy().astype(np.int32))
+        return r
+
+    def clip(params, max_norm, *a, **k):
+        tn = orig_clip(params, max_norm, *a, **k)
+        gnorms.append(float(tn))
+        return tn
+    orig_update = tr.update_model
+
+    def update_model(adv, ret):
+        b = tr.buffer
+        rollouts.append(dict(states=np.array(b.states, np.float32), actions=np.array(b.actions, np.int32),
+                             log_probs=np.array(b.log_probs, np.float32), values=np.array(b.values, np.float32),
+                             rewards=np.array(b.rewards, np.float64), dones=np.array(b.dones, np.uint8),
+                             old_entropies=np.array(b.old_entropies, np.float32), next_value=np.float64(b.next_value),
+                             adv=np.asarray(adv, np.float64), ret=np.asarray(ret, np.float64)))
+        orig_update(adv, ret)
+        upd.append(dict(lr=np.float64(tr.lr), ent_coef=np.float64(tr.ent_coef), step_count=np.int64(tr.step_count),
+                        episode_rewards=np.array(tr.episode_rewards, np.float64),
+                        **{"sd_" + k: v.numpy().copy() for k, v in tr.model.state_dict().items()}))
+    tr.update_model = update_model
+    torch.randperm, mod.nn.utils.clip_grad_norm_ = randperm, clip
+    try:
+        tr.train()
+    finally:
+        torch.randperm, mod.nn.utils.clip_grad_norm_ = orig_randperm, orig_clip
+    T = cfg.update_freq
+    n_mb = (T + cfg.batch_size - 1) // cfg.batch_size
+    # RandomSampler.__iter__ draws a second, unused randperm(n) at the end of every epoch (its `num_samples % n` tail)
+    assert (len(rollouts), len(perms), len(gnorms)) == (2, 4 * cfg.num_epochs, 2 * cfg.num_epochs * n_mb), \
+        (len(rollouts), len(perms), len(gnorms))
+    perms = perms[::2]
+    out["noise_exp"] = np.stack(noise).reshape(2, T, 1, 4).astype(np.float32)
+    out["perms"] = np.stack(perms).reshape(2, cfg.num_epochs, T)
+    out["grad_norms"] = np.array(gnorms, np.float64).reshape(2, cfg.num_epochs * n_mb)
+    for r in range(2):
+        for k, v in rollouts[r].items():
+            out[f"r{r}_{k}"] = v
+        for k, v in upd[r].items():
+            out[f"r{r}_{k}"] = v
+    out["cfg"] = np.array([cfg.update_freq, cfg.batch_size, cfg.num_epochs, cfg.mhc_dim, cfg.mhc_layers, cfg.mhc_sk_it,
+                           cfg.max_train_steps, cfg.seed], np.int64)
+    out["lr0"] = np.float64(cfg.lr)
+    save("ppo_full_trace", **out)
+
+
 def gen_runner_trace():
     """Row H1/U1: the reference utils/runner.py `train()` run unmodified on the scripted env with toy
     agents written to the legacy duck-type (outputs are a function of the call index only, so that they are exact
@@ -1420,6 +1505,6 @@ def gen_ppo_full_pscn():
 
 if __name__ == "__main__":
     names = sys.argv[1:]
-    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2, gen_dqn_trace, gen_sac_trace, gen_rainbow_trace, gen_td3_ddpg, gen_dsac, gen_ppo_lstm_parts, gen_ppo_lstm_trace, gen_runner_trace, gen_ppo_full_pscn]:
+    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2, gen_dqn_trace, gen_sac_trace, gen_rainbow_trace, gen_td3_ddpg, gen_dsac, gen_ppo_lstm_parts, gen_ppo_lstm_trace, gen_runner_trace, gen_ppo_full_pscn, gen_ppo_full_trace]:
         if not names or g.__name__ in names:
             g()

@@ -1,0 +1,63 @@
+"""Worker of tests/test_multirank_gpu.py: one of `world` gloo ranks sharing cuda:0 (the 1-GPU lease has no second
+device; RCCL needs one device per rank, gloo does not).  Runs one iteration of a trainer with world_size > 1 and
+leaves what the parent checks in `outdir`."""
+import os
+import sys
+
+import torch
+import torch.distributed as td
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def ppo_cfg(n_envs):
+    from gymrl_amd.ppo_lunarlander import Config
+    cfg = Config()
+    cfg.num_envs, cfg.update_freq, cfg.num_epochs, cfg.num_minibatches, cfg.seed = n_envs, 48, 2, 4, 5
+    return cfg
+
+
+def ppo_full_cfg(n_envs):
+    from gymrl_amd.ppo_full_lunarlander import Config
+    cfg = Config()
+    cfg.num_envs, cfg.update_freq, cfg.num_epochs, cfg.batch_size, cfg.seed, cfg.mhc_dim = n_envs, 32, 2, 256, 1, 32
+    return cfg
+
+
+def run(rank, world, port, outdir, n_envs):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gymrl_amd.ppo_lunarlander import PPOTrainer
+        tr = PPOTrainer(ppo_cfg(n_envs))
+        assert tr.world_size == world and tr.env.env_id0 == rank * n_envs
+        p0 = tr.flat_params.clone()
+        nv = tr.collect_rollout()
+        m = tr.update(nv)
+        b = tr.buffer
+        out = dict(p0=p0.cpu(), params=tr.flat_params.cpu(), moments=tr._moments.cpu(), adv=b.advantages.cpu(),
+                   metrics={k: float(v) for k, v in m.items()},
+                   **{k: getattr(b, k).cpu() for k in ("states", "actions", "log_probs", "values", "rewards", "dones")})
+        # PPO-full: two iterations (the second replays the two hipGraphs around the eager all-reduce)
+        from gymrl_amd.ppo_full_lunarlander import PPOTrainer as FullTrainer
+        torch.manual_seed(5)
+        ft = FullTrainer(ppo_full_cfg(n_envs))
+        fm = []
+        for _ in range(2):
+            ft.collect_experience()
+            adv, ret = ft.compute_advantages()
+            fm.append(ft.update_model(adv, ret))
+        out.update(full_params=ft.flat_params.cpu(), full_metrics=fm, full_graphed=ft._g_idx is not None,
+                   full_actions=ft.buffer.actions.cpu(), full_steps=ft.optimizer.step_count)
+        torch.save(out, os.path.join(outdir, f"rank{rank}.pt"))
+    finally:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]))

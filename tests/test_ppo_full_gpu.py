@@ -1,0 +1,89 @@
+"""Row F3 / H1 for PPO-full (config 5's algorithm): the reference PPOTrainer.train() trace replayed through
+gymrl_amd.ppo_full_lunarlander.PPOTrainer, and the trainer at BASELINE's per-GPU size."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_close
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def test_ppo_full_train_trace_matches_reference():
+    """The reference PPOTrainer.train() (ppo_full_lunarlander.py:681-700: two collect_experience ->
+    compute_advantages -> update_model iterations on the scripted env, tests/golden/ppo_full_trace.npz) replayed from
+    the same weights, Exp(1) draws and DataLoader shuffle orders.  Pins the control flow: forced reset with cfg.seed at
+    every rollout, reset observation as the next policy input, bootstrap from the post-rollout state, shuffled
+    minibatches with a short last one (96 / 40), lr AND entropy coefficient annealed after the update, episode returns.
+    Integers exact; floats to 1e-5; gradient norms 1e-4; weights after 6 clipped Adam steps 2e-4."""
+    from gymrl_amd.ppo_full_lunarlander import Config, PPOTrainer
+    from scripted_env import ScriptedVecEnv
+    g = load_golden("ppo_full_trace")
+    T, mb, epochs, mhc_dim, mhc_layers, sk_it, max_steps, seed = (int(x) for x in g["cfg"])
+    cfg = Config()
+    cfg.update_freq, cfg.batch_size, cfg.num_epochs = T, mb, epochs
+    cfg.mhc_dim, cfg.mhc_layers, cfg.mhc_sk_it = mhc_dim, mhc_layers, sk_it
+    cfg.max_train_steps, cfg.lr, cfg.seed, cfg.num_envs = max_steps, float(g["lr0"]), seed, 1
+    tr = PPOTrainer(cfg)
+    sd = {k[len("init_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("init_")}
+    assert set(sd) == set(tr.model.state_dict())                          # the reference's parameter names
+    tr.model.load_state_dict(sd)
+    tr.env = ScriptedVecEnv(1, tr.device)
+    tr._parity_noise = [torch.from_numpy(g["noise_exp"][r]).to(tr.device) for r in range(2)]
+    tr._parity_perms = iter(list(g["perms"].reshape(-1, T)))
+    tr.grad_norms = []
+    snaps = []
+    orig_update = tr.update_model
+
+    def update_model(adv, ret):
+        b = tr.buffer
+        snap = dict(states=b.states[:b.T, 0].cpu().numpy(), actions=b.actions[:, 0].cpu().numpy(),
+                    log_probs=b.log_probs[:, 0].cpu().numpy(), values=b.values[:, 0].cpu().numpy(),
+                    rewards=b.rewards[:, 0].cpu().numpy(), dones=b.dones[:, 0].cpu().numpy(),
+                    old_entropies=b.old_entropies[:, 0].cpu().numpy(), next_value=float(b.next_value[0]),
+                    adv=adv[:, 0].cpu().numpy(), ret=ret[:, 0].cpu().numpy())
+        n0 = len(tr.grad_norms)
+        m = orig_update(adv, ret)
+        snap.update(grad_norms=np.array(tr.grad_norms[n0:]), lr=tr.lr, ent_coef=tr.ent_coef, step_count=tr.step_count,
+                    episode_rewards=list(tr.episode_rewards),
+                    sd={k: v.detach().cpu().numpy().copy() for k, v in tr.model.state_dict().items()})
+        snaps.append(snap)
+        return m
+    tr.update_model = update_model
+    tr.train()
+    assert len(snaps) == 2
+    for r, s in enumerate(snaps):
+        assert np.array_equal(s["actions"], g[f"r{r}_actions"]) and np.array_equal(s["dones"], g[f"r{r}_dones"]), r
+        assert np.array_equal(s["states"], g[f"r{r}_states"]), r
+        assert np.array_equal(s["rewards"].astype(np.float64), g[f"r{r}_rewards"]), r
+        for k in ("log_probs", "values", "old_entropies", "adv", "ret"):
+            assert rel_close(s[k], g[f"r{r}_{k}"], 1e-5) <= 1e-5, (r, k)
+        assert abs(s["next_value"] - float(g[f"r{r}_next_value"])) <= 1e-5 * max(1.0, abs(float(g[f"r{r}_next_value"])))
+        assert rel_close(s["grad_norms"], g["grad_norms"][r], 1e-4) <= 1e-4, (r, s["grad_norms"], g["grad_norms"][r])
+        assert abs(s["lr"] - float(g[f"r{r}_lr"])) <= 1e-12 and abs(s["ent_coef"] - float(g[f"r{r}_ent_coef"])) <= 1e-12
+        assert s["step_count"] == int(g[f"r{r}_step_count"])
+        assert np.array_equal(np.array(s["episode_rewards"]), g[f"r{r}_episode_rewards"]), r
+        worst = max(float(np.max(np.abs(v - g[f"r{r}_sd_{k}"]) / np.maximum(1.0, np.abs(g[f"r{r}_sd_{k}"])))) for k, v in s["sd"].items())
+        assert worst <= 2e-4, (r, worst)
+
+
+def test_ppo_full_at_config5_per_gpu_size():
+    """BASELINE config 5's per-GPU shape — 4096 LunarLander envs, F0's network and minibatch (1024 rows), keyed
+    shuffle, blocked G3 — for a short rollout: finite metrics, every transition used once per epoch, hipGraph replay
+    identical to the eager loop."""
+    from gymrl_amd.ppo_full_lunarlander import Config, PPOTrainer
+
+    def run(graphs):
+        cfg = Config()
+        cfg.num_envs, cfg.update_freq, cfg.num_epochs, cfg.seed, cfg.use_graphs = 4096, 4, 1, 2, graphs
+        torch.manual_seed(3)
+        tr = PPOTrainer(cfg)
+        tr.collect_experience()
+        adv, ret = tr.compute_advantages()
+        return tr, tr.update_model(adv, ret), adv, ret
+    (a, ma, adv_a, ret_a), (b, mb_, adv_b, ret_b) = run(False), run(True)
+    assert torch.equal(adv_a, adv_b) and torch.equal(ret_a, ret_b)
+    assert all(np.isfinite(v) for v in ma.values()) and ma == mb_
+    assert torch.equal(a.flat_params, b.flat_params) and a.optimizer.step_count == 16
+    perm = a._perm.long()
+    assert torch.equal(torch.sort(perm).values, torch.arange(4096 * 4, device=perm.device))
