@@ -24,7 +24,7 @@ SYMBOLS = [
     "gymrl_env_obs_dim", "gymrl_env_act_dim", "gymrl_env_is_discrete", "gymrl_env_max_steps",
     "gymrl_env_state_bytes", "gymrl_env_reset", "gymrl_env_step", "gymrl_env_refill",
     "gymrl_categorical_sample",
-    "gymrl_gae_workspace_bytes", "gymrl_gae", "gymrl_gae_online_flush", "gymrl_gae_chunk", "gymrl_gae_dw", "gymrl_gae_decoupled",
+    "gymrl_gae_workspace_bytes", "gymrl_gae", "gymrl_gae_online_flush", "gymrl_gae_chunk", "gymrl_gae_dw", "gymrl_gae_decoupled", "gymrl_gae_decoupled_workspace_bytes",
     "gymrl_reduce_workspace_bytes", "gymrl_moments", "gymrl_normalize",
     "gymrl_ppo_loss_fwd_bwd", "gymrl_ppo_full_loss_fwd_bwd", "gymrl_ppo_rnn_loss_fwd_bwd",
     "gymrl_gru_cell_fwd", "gymrl_gru_cell_bwd", "gymrl_rnd_reward", "gymrl_permutation",
@@ -62,7 +62,7 @@ class PPOCfg(C.Structure):
 class GaeOnline(C.Structure):
     _fields_ = [("rew_prev", C.c_void_p), ("done_prev", C.c_void_p), ("val_prev", C.c_void_p),
                 ("running", C.c_void_p), ("gae_workspace", C.c_void_p), ("t_prev", C.c_int), ("T", C.c_int),
-                ("gamma", C.c_double), ("lam", C.c_double)]
+                ("gamma", C.c_double), ("lam", C.c_double), ("lam2", C.c_double), ("running2", C.c_void_p)]
 
 
 MLP_MAX_STAGES, MLP_MAX_WIDTH, MLP_MAX_INPUT = 8, 256, 64
@@ -103,6 +103,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.gymrl_env_state_bytes.restype = C.c_size_t
         L.gymrl_gae_workspace_bytes.restype = C.c_size_t
+        L.gymrl_gae_decoupled_workspace_bytes.restype = C.c_size_t
         L.gymrl_reduce_workspace_bytes.restype = C.c_size_t
         L.gymrl_per_workspace_bytes.restype = C.c_size_t
         L.gymrl_mlp_packed_floats.restype = C.c_size_t

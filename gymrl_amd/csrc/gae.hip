@@ -278,11 +278,15 @@ __global__ __launch_bounds__(kBlkBlock) void gae_blk_apply_kernel(
 __global__ __launch_bounds__(kRedBlock) void gae_online_kernel(
     const float* __restrict__ rew_prev, const uint8_t* __restrict__ done_prev,
     const float* __restrict__ val_prev, const float* __restrict__ val_cur, int N, double gamma,
-    double gl, int first, int last, double* __restrict__ running, double2* __restrict__ agg_row) {
+    double gl, int first, int last, double* __restrict__ running, double2* __restrict__ agg_row,
+    double gl2, double* __restrict__ running2, double2* __restrict__ agg_row2) {
   const int i = blockIdx.x * kRedBlock + threadIdx.x;
   if (i >= N) return;
   gymrl::gae_online_compose(rew_prev[i], done_prev[i], val_prev[i], val_cur[i], gamma, gl, first, last,
                             running, agg_row, N, i);
+  if (running2)
+    gymrl::gae_online_compose(rew_prev[i], done_prev[i], val_prev[i], val_cur[i], gamma, gl2, first, last,
+                              running2, agg_row2, N, i);
 }
 
 // Deterministic final reduction of (s1, s2) partials -> moments (count, sum, sumsq).
@@ -378,6 +382,83 @@ __global__ __launch_bounds__(kSeqBlock) void gae_decoupled_kernel(
         ret_out[o] = (float)(lc + vv);
         vnext = vv;
       }
+    }
+  }
+}
+
+// G3 blocked: the G1 machinery with two affine maps per chunk (same delta, decay factors gla / glc).
+// agg / carry layout: [actor: C][N] then [critic: C][N].
+template <int TC, int V>
+__global__ __launch_bounds__(kBlkBlock) void gae2_blk_aggregate_kernel(
+    const float* __restrict__ rew, const float* __restrict__ val,
+    const uint8_t* __restrict__ done, const float* __restrict__ next_val, int T, int N,
+    double gamma, double gla, double glc, double2* __restrict__ agg_a, double2* __restrict__ agg_c) {
+  const int q = blockIdx.x * kBlkBlock + threadIdx.x;
+  const int c = blockIdx.y;
+  if (V * q >= N) return;
+  const int t0 = c * TC;
+  Chunk<TC, V> ch;
+  load_chunk<TC, V>(ch, rew, val, done, next_val, T, N, q, t0);
+  const int len = min(TC, T - t0);
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    double Aa = 1.0, ba = 0.0, Ac = 1.0, bc = 0.0;
+    double vnext = (double)ch.vend[k];
+#pragma unroll
+    for (int j = TC - 1; j >= 0; --j) {
+      if (j < len) {
+        const double nd = 1.0 - (double)(ch.d[j][k] != 0);
+        const double vv = (double)ch.v[j][k];
+        const double delta = ((double)ch.r[j][k] + (gamma * vnext) * nd) - vv;
+        const double a = gla * nd, cc = glc * nd;
+        ba = delta + a * ba;  Aa = a * Aa;
+        bc = delta + cc * bc; Ac = cc * Ac;
+        vnext = vv;
+      }
+    }
+    agg_a[(size_t)c * N + V * (size_t)q + k] = make_double2(Aa, ba);
+    agg_c[(size_t)c * N + V * (size_t)q + k] = make_double2(Ac, bc);
+  }
+}
+
+template <int TC, int V>
+__global__ __launch_bounds__(kBlkBlock) void gae2_blk_apply_kernel(
+    const float* __restrict__ rew, const float* __restrict__ val,
+    const uint8_t* __restrict__ done, const float* __restrict__ next_val, int T, int N,
+    double gamma, double gla, double glc, const double* __restrict__ carry_a, const double* __restrict__ carry_c,
+    float* __restrict__ adv_out, float* __restrict__ ret_out) {
+  const int q = blockIdx.x * kBlkBlock + threadIdx.x;
+  const int c = blockIdx.y;
+  if (V * q >= N) return;
+  const int t0 = c * TC;
+  Chunk<TC, V> ch;
+  load_chunk<TC, V>(ch, rew, val, done, next_val, T, N, q, t0);
+  const int len = min(TC, T - t0);
+  double xa[V], xc[V], vnext[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    xa[k] = carry_a[(size_t)c * N + V * (size_t)q + k];
+    xc[k] = carry_c[(size_t)c * N + V * (size_t)q + k];
+    vnext[k] = (double)ch.vend[k];
+  }
+#pragma unroll
+  for (int j = TC - 1; j >= 0; --j) {
+    if (j < len) {
+      float a4[V], r4[V];
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        const double nd = 1.0 - (double)(ch.d[j][k] != 0);
+        const double vv = (double)ch.v[j][k];
+        const double delta = ((double)ch.r[j][k] + (gamma * vnext[k]) * nd) - vv;
+        xa[k] = delta + (gla * nd) * xa[k];
+        xc[k] = delta + (glc * nd) * xc[k];
+        a4[k] = (float)xa[k];
+        r4[k] = (float)(xc[k] + vv);
+        vnext[k] = vv;
+      }
+      const size_t o = (size_t)(t0 + j) * N + V * (size_t)q;
+      *reinterpret_cast<float2*>(adv_out + o) = make_float2(a4[0], a4[1]);
+      *reinterpret_cast<float2*>(ret_out + o) = make_float2(r4[0], r4[1]);
     }
   }
 }
@@ -492,9 +573,12 @@ int gymrl_gae_online_flush(const gymrl_gae_online* o, const float* val_cur, int 
   const int c = o->t_prev / kBlkTC;
   const int first = (o->t_prev % kBlkTC) == 0, last = (o->t_prev % kBlkTC) == kBlkTC - 1 || o->t_prev == o->T - 1;
   double2* agg = (double2*)o->gae_workspace + (size_t)c * N;
+  const bool two = o->lam2 > 0.0 && o->running2;
+  const size_t C = (size_t)cdiv(o->T, kBlkTC);
   hipLaunchKernelGGL(gae_online_kernel, dim3(cdiv(N, kRedBlock)), dim3(kRedBlock), 0, (hipStream_t)stream_,
                      o->rew_prev, o->done_prev, o->val_prev, val_cur, N, o->gamma,
-                     (double)(float)(o->gamma * o->lam), first, last, o->running, agg);
+                     two ? o->gamma * o->lam : (double)(float)(o->gamma * o->lam), first, last, o->running, agg,
+                     o->gamma * o->lam2, two ? o->running2 : (double*)nullptr, two ? agg + C * (size_t)N : (double2*)nullptr);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
@@ -517,14 +601,44 @@ int gymrl_gae_dw(const float* rew, const float* val, const float* next_val, cons
   return 0;
 }
 
+size_t gymrl_gae_decoupled_workspace_bytes(int T, int N) {
+  if (T <= 0 || N <= 0) return 0;
+  const size_t C = (size_t)cdiv(T, kBlkTC);
+  return 2 * C * (size_t)N * (sizeof(double2) + sizeof(double)) + 1024;
+}
+
 int gymrl_gae_decoupled(const float* rew, const float* val, const uint8_t* done,
                         const float* next_val, int T, int N, double gamma, double lam_actor,
-                        double lam_critic, float* adv_actor_out, float* ret_out, void* stream_) {
+                        double lam_critic, float* adv_actor_out, float* ret_out, int variant, void* workspace,
+                        void* stream_) {
   if (!rew || !val || !done || !next_val || !adv_actor_out || !ret_out || T < 0 || N < 0) return -22;
   if (T == 0 || N == 0) return 0;
-  hipLaunchKernelGGL(gae_decoupled_kernel, dim3(cdiv(N, kSeqBlock)), dim3(kSeqBlock), 0,
-                     (hipStream_t)stream_, rew, val, done, next_val, T, N, gamma,
-                     gamma * lam_actor, gamma * lam_critic, adv_actor_out, ret_out);
+  hipStream_t stream = (hipStream_t)stream_;
+  const double gla = gamma * lam_actor, glc = gamma * lam_critic;
+  const bool vec_ok = (N % 4 == 0) && aligned16(rew) && aligned16(val) && aligned16(adv_actor_out) &&
+                      aligned16(ret_out) && aligned16(next_val) &&
+                      ((reinterpret_cast<uintptr_t>(done) & 3) == 0);
+  if ((variant == 1 || variant == 2) && vec_ok && workspace) {
+    const int C = cdiv(T, kBlkTC);
+    const size_t CN = (size_t)C * N;
+    double2* agg_a = (double2*)workspace;
+    double2* agg_c = agg_a + CN;
+    double* carry_a = (double*)(agg_c + CN);
+    double* carry_c = carry_a + CN;
+    dim3 grid(cdiv(N / kBlkV, kBlkBlock), C);
+    if (variant == 1)
+      hipLaunchKernelGGL((gae2_blk_aggregate_kernel<kBlkTC, kBlkV>), grid, dim3(kBlkBlock), 0, stream, rew, val, done,
+                         next_val, T, N, gamma, gla, glc, agg_a, agg_c);
+    hipLaunchKernelGGL(gae_blk_carry_kernel, dim3(cdiv(N, kSeqBlock)), dim3(kSeqBlock * kCarrySeg), 0, stream, agg_a, C, N,
+                       carry_a);
+    hipLaunchKernelGGL(gae_blk_carry_kernel, dim3(cdiv(N, kSeqBlock)), dim3(kSeqBlock * kCarrySeg), 0, stream, agg_c, C, N,
+                       carry_c);
+    hipLaunchKernelGGL((gae2_blk_apply_kernel<kBlkTC, kBlkV>), grid, dim3(kBlkBlock), 0, stream, rew, val, done, next_val,
+                       T, N, gamma, gla, glc, carry_a, carry_c, adv_actor_out, ret_out);
+  } else {
+    hipLaunchKernelGGL(gae_decoupled_kernel, dim3(cdiv(N, kSeqBlock)), dim3(kSeqBlock), 0, stream, rew, val, done,
+                       next_val, T, N, gamma, gla, glc, adv_actor_out, ret_out);
+  }
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

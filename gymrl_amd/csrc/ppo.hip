@@ -44,6 +44,7 @@ __device__ __forceinline__ void block_partials(double (&v)[K], double* __restric
 struct OnlineGae {   // device-side view of gymrl_gae_online (rew_prev == nullptr: disabled)
   const float* rew_prev; const uint8_t* done_prev; const float* val_prev;
   double* running; double2* agg_row; double gamma, gl; int first, last;
+  double* running2; double2* agg_row2; double gl2;      // decoupled-lambda mode (G3): second map, nullptr = off
 };
 
 template <int A>
@@ -56,8 +57,13 @@ __global__ __launch_bounds__(kBlock) void categorical_sample_kernel(
   if (i >= n) return;
   // fused producer side of GAE: value_in is V_t, which completes step t-1's delta
   if (og.rew_prev)
+  {
     gae_online_compose(og.rew_prev[i], og.done_prev[i], og.val_prev[i], value_in[i], og.gamma, og.gl, og.first,
                        og.last, og.running, og.agg_row, n, i);
+    if (og.running2)
+      gae_online_compose(og.rew_prev[i], og.done_prev[i], og.val_prev[i], value_in[i], og.gamma, og.gl2, og.first,
+                         og.last, og.running2, og.agg_row2, n, i);
+  }
   float z[A], H, lp;
   load_row<A>(logits, i, z);
   const int a = categorical_pick<A>(z, noise_exp ? noise_exp + (size_t)i * A : nullptr, seed, (uint64_t)(env_id0 + i),
@@ -406,6 +412,13 @@ int gymrl_categorical_sample(const float* logits, const float* value_in, const f
     og.running = online->running;
     og.agg_row = (double2*)online->gae_workspace + (size_t)(online->t_prev / tc) * n;
     og.gamma = online->gamma; og.gl = (double)(float)(online->gamma * online->lam);
+    if (online->lam2 > 0.0 && online->running2) {      // G3: float64 decay factors, critic maps after the actor's
+      const size_t C = (size_t)((online->T + tc - 1) / tc);
+      og.gl = online->gamma * online->lam;
+      og.gl2 = online->gamma * online->lam2;
+      og.running2 = online->running2;
+      og.agg_row2 = og.agg_row + C * (size_t)n;
+    }
     og.first = (online->t_prev % tc) == 0;
     og.last = (online->t_prev % tc) == tc - 1 || online->t_prev == online->T - 1;
   }

@@ -76,14 +76,24 @@ def gae_dw(rew, val, next_val, done, dw, gamma, lam, moments_out=None, workspace
     return adv, vt
 
 
-def gae_decoupled(rew, val, done, next_val, gamma, lam_actor, lam_critic):
-    """G3 (ppo_full_lunarlander.py:507-535).  Returns (adv_actor, returns)."""
+def gae_decoupled_workspace(T, N, device):
+    nbytes = lib().gymrl_gae_decoupled_workspace_bytes(C.c_int(T), C.c_int(N))
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def gae_decoupled(rew, val, done, next_val, gamma, lam_actor, lam_critic, variant=0, workspace=None, adv_out=None,
+                  ret_out=None):
+    """G3 (ppo_full_lunarlander.py:507-535).  Returns (adv_actor, returns).  variant 1 / 2: time-blocked scan
+    (2: chunk maps composed during the rollout), needs gae_decoupled_workspace(T, N)."""
     T, N = rew.shape
-    adv, ret = torch.empty_like(rew), torch.empty_like(rew)
+    adv = torch.empty_like(rew) if adv_out is None else adv_out
+    ret = torch.empty_like(rew) if ret_out is None else ret_out
+    if variant and workspace is None:
+        workspace = gae_decoupled_workspace(T, N, rew.device)
     check(lib().gymrl_gae_decoupled(_ptr(rew, torch.float32), _ptr(val, torch.float32), _ptr(done, torch.uint8),
                                     _ptr(next_val, torch.float32), C.c_int(T), C.c_int(N), C.c_double(gamma),
                                     C.c_double(lam_actor), C.c_double(lam_critic), _ptr(adv), _ptr(ret),
-                                    _stream()), "gymrl_gae_decoupled")
+                                    C.c_int(variant), _ptr(workspace, None, True), _stream()), "gymrl_gae_decoupled")
     return adv, ret
 
 
@@ -102,10 +112,12 @@ def normalize_(x, mom, ddof=0, eps=1e-8):
 
 
 # ------------------------------------------------------------ categorical ---
-def gae_online(rew_prev, done_prev, val_prev, running, workspace, t_prev, T, gamma, lam):
-    """Descriptor for the producer-side GAE fusion (gymrl_gae_online): rows t-1 of the slab."""
+def gae_online(rew_prev, done_prev, val_prev, running, workspace, t_prev, T, gamma, lam, lam2=0.0, running2=None):
+    """Descriptor for the producer-side GAE fusion (gymrl_gae_online): rows t-1 of the slab.  lam2 / running2: the
+    decoupled-lambda mode of G3 (lam = lam_actor, lam2 = lam_critic)."""
     return GaeOnline(rew_prev.data_ptr(), done_prev.data_ptr(), val_prev.data_ptr(), running.data_ptr(),
-                     workspace.data_ptr(), int(t_prev), int(T), float(gamma), float(lam))
+                     workspace.data_ptr(), int(t_prev), int(T), float(gamma), float(lam), float(lam2),
+                     running2.data_ptr() if running2 is not None else None)
 
 
 def gae_online_flush(online, val_cur):

@@ -58,6 +58,7 @@ class Config:
         self.device = "cuda"
         self.num_envs = 1
         self.use_graphs = True             # replay the minibatch update as captured hipGraphs (equal minibatches)
+        self.gae_variant = 1               # 1 = time-blocked G3 with the chunk maps composed during the rollout, 0 = sequential
 
 
 def _ortho(layer, std):
@@ -295,6 +296,12 @@ class PPOTrainer:
         self._parity_perms = None      # tests: iterator of i32[T*N] shuffle orders, one per epoch (DataLoader's RandomSampler)
         self.grad_norms = None         # tests: set to [] to record the pre-clip gradient norm of every minibatch
         self._sink = GradSink(self.model)
+        T = int(config.update_freq)
+        self._gae_ws = ops.gae_decoupled_workspace(T, N, self.device)
+        self._gae_run = torch.zeros(2, 2, N, dtype=torch.float64, device=self.device)   # running maps: actor, critic
+        self._adv = torch.empty(T, N, device=self.device)
+        self._ret = torch.empty(T, N, device=self.device)
+        self._agg_ready = False
         self._g_idx, self._g_warm = None, 0          # hipGraph replay of the minibatch body (update_model)
         self._fwd_graph, self._fwd_in, self._fwd_out, self._fwd_warm = None, None, None, 0
 
@@ -307,6 +314,11 @@ class PPOTrainer:
         c0 = self.rollout_count * b.T
         graphed = bool(getattr(cfg, "use_graphs", True))
         noise = self._parity_noise.pop(0) if self._parity_noise else None
+        fuse_gae = getattr(cfg, "gae_variant", 1) == 1 and b.N % 4 == 0
+
+        def online(t_prev):      # fold step t_prev (whose delta needs V_{t_prev + 1}) into its chunk's two affine maps
+            return ops.gae_online(b.rewards[t_prev], b.dones[t_prev], b.values[t_prev], self._gae_run[0], self._gae_ws,
+                                  t_prev, b.T, cfg.gamma, cfg.lam_actor, cfg.lam_critic, self._gae_run[1])
         for t in range(b.T):
             if graphed:                                   # the ~100-launch mHC forward as one graph launch
                 logits, value = self._forward_graphed(b.states[t])
@@ -315,11 +327,14 @@ class PPOTrainer:
             ops.categorical_sample(logits, value=value.view(-1), noise_exp=None if noise is None else noise[t],
                                    seed=env.seed, counter=c0 + t, env_id0=env.env_id0,
                                    act_out=b.actions[t], logp_out=b.log_probs[t], ent_out=b.old_entropies[t],
-                                   value_out=b.values[t])
+                                   value_out=b.values[t], online=online(t - 1) if fuse_gae and t > 0 else None)
             env.step(b.actions[t], b.states[t + 1], b.rewards[t], done_out=b.dones[t], ep_ret_out=b.ep_returns[t])
         self.step_count += b.T * b.N
         self.rollout_count += 1
         b.next_value.copy_(self.model.get_value(b.states[b.T]))
+        if fuse_gae:
+            ops.gae_online_flush(online(b.T - 1), b.next_value)
+        self._agg_ready = fuse_gae
 
     @torch.no_grad()
     def _forward_graphed(self, x):
@@ -341,7 +356,12 @@ class PPOTrainer:
     def compute_advantages(self):
         """:507-535 -> (adv_actor [T,N] un-normalised, returns [T,N])."""
         b, cfg = self.buffer, self.cfg
-        return ops.gae_decoupled(b.rewards, b.values, b.dones, b.next_value, cfg.gamma, cfg.lam_actor, cfg.lam_critic)
+        variant = getattr(cfg, "gae_variant", 1)
+        if variant == 1 and self._agg_ready:
+            variant = 2                                   # the rollout composed both chunk maps
+        self._agg_ready = False
+        return ops.gae_decoupled(b.rewards, b.values, b.dones, b.next_value, cfg.gamma, cfg.lam_actor, cfg.lam_critic,
+                                 variant, self._gae_ws, self._adv, self._ret)
 
     def update_model(self, advantages, returns):
         """:537-679.  Returns the metric means the reference prints."""

@@ -111,6 +111,10 @@ typedef struct {
   int t_prev;                 /* t-1, 0-based                                        */
   int T;                      /* rollout length                                      */
   double gamma, lam;
+  double lam2;                /* > 0 with running2 != NULL: decoupled-lambda mode (G3) — `lam` is lam_actor,   */
+  double* running2;           /* `lam2` lam_critic; both decay factors are the float64 products gamma * lam;   */
+                              /* the critic's chunk maps follow the actor's in the workspace of                */
+                              /* gymrl_gae_decoupled(variant 2); running2 f64[2][N] scratch                    */
 } gymrl_gae_online;
 
 int gymrl_categorical_sample(const float* logits, const float* value_in,
@@ -156,11 +160,18 @@ int gymrl_gae_dw(const float* rew, const float* val, const float* next_val,
                  double* moments_out, void* workspace, void* stream);
 
 /* G3: ppo_full compute_advantages — ppo_full_lunarlander.py:507-535: two scans
- * sharing delta (lam_actor, lam_critic); ret = adv_critic + V; adv_actor raw. */
+ * sharing delta (lam_actor, lam_critic); ret = adv_critic + V; adv_actor raw.
+ * variant 0 = one lane walks one env sequentially (the reference's operation order);
+ * variant 1 = time-blocked affine scan with two (A, b) maps per chunk (same layout rules as gymrl_gae variant 1,
+ *             falls back to variant 0 when they do not hold);
+ * variant 2 = variant 1 without its first pass: both chunk maps were composed during the rollout
+ *             (gymrl_gae_online with lam2 / running2).
+ * workspace: gymrl_gae_decoupled_workspace_bytes(T, N) bytes, 256-B aligned (variants 1, 2; NULL: variant 0). */
+size_t gymrl_gae_decoupled_workspace_bytes(int T, int N);
 int gymrl_gae_decoupled(const float* rew, const float* val, const uint8_t* done,
                         const float* next_val, int T, int N, double gamma,
-                        double lam_actor, double lam_critic,
-                        float* adv_actor_out, float* ret_out, void* stream);
+                        double lam_actor, double lam_critic, float* adv_actor_out,
+                        float* ret_out, int variant, void* workspace, void* stream);
 
 /* Whole-rollout advantage normalisation — ppo_lunarlander.py:236 (ddof 0) and
  * utils/buffer.py:33 (ddof 1).  moments f64[3] = (count, sum, sumsq) on device.
