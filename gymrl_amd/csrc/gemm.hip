@@ -383,12 +383,29 @@ __global__ __launch_bounds__(kTnThreads) void gemm_tn_kernel(TnArgs p) {
   }
 }
 
-// db[ntile*256 + n] from the per-slice column sums, same slice grouping as the weight tiles
+// db[ntile*256 + n] from the per-slice column sums, same slice grouping as the weight tiles: thread (n, j) adds the
+// slices s = j (mod 4) ascending (independent loads, 8 in flight), the four group sums combine as ((g0 + g1) + g2) + g3
 __global__ __launch_bounds__(256) void tn_colsum_kernel(const float* __restrict__ parts, int slices, float* __restrict__ db) {
-  const int ntile = blockIdx.x, n = threadIdx.x;
-  double g[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int s = 0; s < slices; ++s) g[s & 3] += (double)parts[((size_t)ntile * slices + s) * 256 + n];
-  db[ntile * 256 + n] = (float)(((g[0] + g[1]) + g[2]) + g[3]);
+  __shared__ double sm[4][64];
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63), j = threadIdx.x >> 6;     // n: column over all tiles
+  const int ntile = n >> 8, nl = n & 255;
+  const float* src = parts + (size_t)ntile * slices * 256 + nl;
+  double g = 0.0;
+  int s = j;
+  for (; s + 28 < slices; s += 32) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(s + 4 * k) * 256];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g += (double)v[k];
+  }
+  for (; s < slices; s += 4) g += (double)src[(size_t)s * 256];
+  sm[j][threadIdx.x & 63] = g;
+  __syncthreads();
+  if (j == 0) {
+    const int l = threadIdx.x;
+    db[n] = (float)(((sm[0][l] + sm[1][l]) + sm[2][l]) + sm[3][l]);
+  }
 }
 
 // dW[ntile*256 + n][k] = ((g0 + g1) + g2) + g3, g_j = sum over slices s = j (mod 4) ascending (f64)
@@ -563,7 +580,7 @@ int gymrl_linear_bwd_weight(const float* dY, const float* X, int64_t B, int N, i
     else hipLaunchKernelGGL((gemm_tn_kernel<8, 512>), grid, block, 0, s, a);
   }
   hipLaunchKernelGGL(tn_reduce_kernel, dim3(a.ntiles * 256), dim3(256), 0, s, a.parts, a.slices, K, dW);
-  if (db) hipLaunchKernelGGL(tn_colsum_kernel, dim3(a.ntiles), dim3(256), 0, s, a.cs_parts, a.slices, db);
+  if (db) hipLaunchKernelGGL(tn_colsum_kernel, dim3(a.ntiles * 4), dim3(256), 0, s, a.cs_parts, a.slices, db);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

@@ -53,13 +53,16 @@ class GradSink:
         for p in self.params:
             p.grad = None
 
-    def collect(self):
+    def collect(self, add=False):
+        """add=True accumulates into the flat buffer (gradient accumulation over micro-batches: the buffer was zeroed
+        by the optimiser step) instead of overwriting it."""
         got = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
-        for v, p in zip(self.views, self.params):
-            if p.grad is None:
-                v.zero_()
+        if not add:
+            for v, p in zip(self.views, self.params):
+                if p.grad is None:
+                    v.zero_()
         if got:
-            torch._foreach_copy_([v for v, _ in got], [g for _, g in got])
+            (torch._foreach_add_ if add else torch._foreach_copy_)([v for v, _ in got], [g for _, g in got])
         self.drop()
 
     def drop(self):

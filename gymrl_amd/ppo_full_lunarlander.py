@@ -58,6 +58,9 @@ class Config:
         self.device = "cuda"
         self.num_envs = 1
         self.use_graphs = True             # replay the minibatch update as captured hipGraphs (equal minibatches)
+        self.micro_batch = 0               # rows per forward/backward pass (0: the whole minibatch); a minibatch larger than
+                                           # this is accumulated over equal micro-batches before ONE optimiser step — the
+                                           # same gradient, bounded activation memory (4096 envs x F0's ratio = 4.2 M rows)
         self.gae_variant = 1               # 1 = time-blocked G3 with the chunk maps composed during the rollout, 0 = sequential
 
 
@@ -376,6 +379,11 @@ class PPOTrainer:
         sizes, row = [], 0
         lcfg = (cfg.clip_eps_min, cfg.clip_eps_max, cfg.dual_clip, cfg.erc_beta_low, cfg.erc_beta_high, self.ent_coef)
 
+        micro = int(getattr(cfg, "micro_batch", 0) or 0)
+        n_micro = mb // micro if (0 < micro < mb and mb % micro == 0 and total % mb == 0) else 1
+        rows = mb // n_micro                                               # rows per forward/backward pass
+        acc = n_micro > 1
+
         def fwd_bwd(idx, metrics_row):
             logits, values = self.model(states.index_select(0, idx))
             values = values.view(-1)
@@ -387,34 +395,33 @@ class PPOTrainer:
                                                          metrics_sum=metrics_row, corr_mul=mul)
             self._sink.arm()
             torch.autograd.backward([logits, values], [dlogits, dvalues])
-            self._sink.collect()
+            self._sink.collect(add=acc)           # accumulating: the optimiser step left the buffer zeroed
 
         def opt_step(bias=None):
-            self.optimizer.step(grad_scale=1.0 / self.world_size, bias_dev=bias)
+            # every pass scaled its loss by 1 / rows: the mean over the minibatch is their average
+            self.optimizer.step(grad_scale=1.0 / (self.world_size * n_micro), bias_dev=bias)
 
-        def minibatch(idx, metrics_row, bias=None):
-            fwd_bwd(idx, metrics_row)
+        def finish(bias=None):
             if self.world_size > 1:
                 gdist.all_reduce_sum(self.flat_grads)
             if self.grad_norms is not None:                                # tests: the norm clip_grad_norm_ would return
-                ops.sqnorm(self.flat_grads, self.optimizer._sq, self.optimizer._ws, 1.0 / self.world_size)
+                ops.sqnorm(self.flat_grads, self.optimizer._sq, self.optimizer._ws, 1.0 / (self.world_size * n_micro))
                 self.grad_norms.append(float(self.optimizer._sq.sqrt().item()))
             opt_step(bias)
 
-        # One minibatch of the mHC network is ~400 launches of a few microseconds (8 ms at 1024 rows): with equal
-        # minibatches the minibatch body is captured once per update_model() call (rollout tensors and the annealed
-        # entropy coefficient are constants of that call) and replayed (gymrl_amd/graphs.py).  With more than one rank
-        # it is TWO graphs around the eager gradient all-reduce — forward/loss/backward, then clip + Adam — so the
-        # 8-GPU configuration runs the same replayed kernels as one GPU.  The first two minibatches ever run eagerly
-        # (library warm-up).
-        graphed = (bool(getattr(cfg, "use_graphs", True)) and total % mb == 0 and cfg.num_epochs * n_mb > 2
+        # One pass of the mHC network is ~400 launches of a few microseconds (8 ms at 1024 rows): with equal
+        # minibatches the forward/loss/backward body is captured once per update_model() call (rollout tensors and the
+        # annealed entropy coefficient are constants of that call) and replayed once per micro-batch, then clip + Adam as
+        # a second graph; the gradient all-reduce of a multi-rank run sits between the two, eager, so the 8-GPU
+        # configuration runs the same replayed kernels as one GPU.  The first two passes ever run eagerly (library warm-up).
+        graphed = (bool(getattr(cfg, "use_graphs", True)) and total % mb == 0 and cfg.num_epochs * n_mb * n_micro > 2
                    and cfg.clip_cov_ratio <= 0 and self.grad_norms is None)      # the covariance clip reads the host
         graph = graph2 = None
-        if graphed and self._g_idx is None:
+        if graphed and (self._g_idx is None or self._g_idx.numel() != rows):
             from .graphs import StepScalars
             self._scalars = StepScalars(self.device)
             self._g_bias, self._g_off = self._scalars.slot(16, torch.float32)
-            self._g_idx = torch.empty(mb, dtype=torch.int32, device=self.device)
+            self._g_idx = torch.empty(rows, dtype=torch.int32, device=self.device)
             self._g_row = torch.zeros(9, dtype=torch.float64, device=self.device)
         for _ in range(cfg.num_epochs):
             if self._parity_perms is not None:                             # parity mode: the DataLoader's shuffle order
@@ -428,36 +435,40 @@ class PPOTrainer:
                 idx = perm[start:start + mb]
                 B = idx.numel()
                 if not graphed:
-                    minibatch(idx, metrics[row])
+                    for j in range(n_micro):
+                        fwd_bwd(idx[j * rows:(j + 1) * rows] if acc else idx, metrics[row])
+                    finish()
                 else:
-                    self._g_idx.copy_(idx)
                     self._g_row.zero_()
                     self._scalars.set(self._g_off, self.optimizer.next_bias())
                     self._scalars.flush()
-                    if self._g_warm < 2:
-                        self._g_warm += 1
-                        minibatch(self._g_idx, self._g_row, self._g_bias)
-                    elif self.world_size == 1:
+                    for j in range(n_micro):
+                        self._g_idx.copy_(idx[j * rows:(j + 1) * rows])
+                        if self._g_warm < 2:
+                            self._g_warm += 1
+                            fwd_bwd(self._g_idx, self._g_row)
+                        else:
+                            if graph is None:                              # (capturing does not execute)
+                                graph = torch.cuda.CUDAGraph()
+                                with torch.cuda.graph(graph):
+                                    fwd_bwd(self._g_idx, self._g_row)
+                            graph.replay()
+                    if self.world_size > 1:
+                        gdist.all_reduce_sum(self.flat_grads)
+                    if graph2 is None:
                         if graph is None:
-                            graph = torch.cuda.CUDAGraph()
-                            with torch.cuda.graph(graph):
-                                minibatch(self._g_idx, self._g_row, self._g_bias)
-                        graph.replay()
-                    else:
-                        if graph is None:                                  # (capturing does not execute)
-                            graph, graph2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                            with torch.cuda.graph(graph):
-                                fwd_bwd(self._g_idx, self._g_row)
+                            opt_step(self._g_bias)                         # still warming up
+                        else:
+                            graph2 = torch.cuda.CUDAGraph()
                             with torch.cuda.graph(graph2):
                                 opt_step(self._g_bias)
-                        graph.replay()
-                        gdist.all_reduce_sum(self.flat_grads)
+                            graph2.replay()
+                    else:
                         graph2.replay()
                     metrics[row].copy_(self._g_row)
                 sizes.append(B)
                 row += 1
-        del graph2
-        del graph
+        del graph, graph2
         if cfg.anneal:                                                     # :660-666 (after the update)
             frac = 1 - self.step_count * self.world_size / cfg.max_train_steps
             self.lr = cfg.lr * frac
