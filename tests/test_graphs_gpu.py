@@ -148,3 +148,39 @@ def test_ddpg_dsac_graphed_update_equals_eager(algo):
         assert torch.equal(getattr(eager, name), getattr(graph, name)), name
     opt = "critic_optimizer" if algo == "ddpg" else "critic1_optim"
     assert getattr(eager, opt).step_count == getattr(graph, opt).step_count > 30
+
+
+@pytest.mark.parametrize("algo", ["rainbow", "sac"])
+def test_baseline_config_sizes_graphed_equals_eager(algo):
+    """BASELINE configs 3 and 4 at their own sizes — Rainbow DQN CartPole-v1 with 8192 envs (2^20-leaf PER tree, n-step
+    windows, NoisyNet) and SAC Pendulum-v1 with 4096 envs — for 12 vector steps: the hipGraph-replayed update equals the
+    eager one bit for bit and every network / the float64 sum tree is finite."""
+    if algo == "rainbow":
+        from gymrl_amd import rainbow_dqn_cartpole as mod
+        cls, n_envs = "RainbowDQNTrainer", 8192
+
+        def setup(cfg):
+            cfg.num_envs, cfg.memory_capacity = n_envs, 1 << 20
+    else:
+        from gymrl_amd import sac_pendulum as mod
+        cls, n_envs = "SACTrainer", 4096
+
+        def setup(cfg):
+            cfg.num_envs, cfg.memory_capacity = n_envs, 1 << 20
+    outs = []
+    for graphs in (False, True):
+        if algo == "rainbow":
+            mod.NoisyLinear._counter = 0
+        outs.append(_run(mod, cls, graphs, 12, setup))
+    eager, graph = outs
+    assert graph._graph is not None and graph._graph.graph is not None
+    if algo == "rainbow":
+        assert eager.optimizer.step_count == graph.optimizer.step_count >= 4
+        assert torch.equal(eager.flat_params, graph.flat_params) and torch.equal(eager.target_flat, graph.target_flat)
+        assert torch.equal(eager.memory.sum_tree.tree, graph.memory.sum_tree.tree)
+        assert bool(torch.isfinite(graph.memory.sum_tree.tree).all()) and len(graph.memory) == len(eager.memory) > n_envs
+    else:
+        assert eager.critic_optimizer.step_count == graph.critic_optimizer.step_count >= 4
+        for name in ("actor_flat", "critic_flat", "critic_target_flat", "log_alpha"):
+            assert torch.equal(getattr(eager, name), getattr(graph, name)), name
+        assert bool(torch.isfinite(graph.actor_flat).all()) and len(graph.memory) == len(eager.memory) > n_envs

@@ -165,6 +165,53 @@ def test_sumtree_large_batches_exact(dev, oracle, cap, B):
         assert np.array_equal(tree.cpu().numpy(), ref.tree), ("update", rnd)
 
 
+def test_per_variant_b_on_the_gpu(dev, oracle):
+    """PER variant B (ddqn_per_cartpole.py:67-147) through the C-ABI: max-priority pushes (:113-117), stratified
+    sampling that returns TREE indices (:95-108), priorities min(|err| + eps, error_max)^alpha (:142-147) and the
+    tree-index update (:75-80) — against the reference's own fixture and, over random rounds with duplicates, the
+    oracle's sequential loop (float64 tree bit for bit)."""
+    from gymrl_amd import ops
+    g = load_golden("per_variant_b")
+    cap = int(g["cap"])
+    tree = torch.zeros(2 * cap - 1, dtype=torch.float64, device=dev)
+    ws = ops.per_workspace(1024, dev)
+    mx = torch.zeros(1, dtype=torch.float64, device=dev)
+    cursor = 0
+    for _ in range(int(g["n_push"])):
+        m = float(ops.per_max_leaf(tree, cap, mx, ws).item())
+        ops.per_update(tree, cap, 1, ws, idx_start=cursor, prio_scalar=(m if m != 0 else 1.0))
+        cursor = (cursor + 1) % cap
+    assert np.array_equal(tree.cpu().numpy(), g["tree_after_push"])
+    idx, prio, w = ops.per_sample(tree, cap, len(g["u"]), int(g["size"]), float(g["beta"]), ws, u=t(g["u"], dev), variant_b=True)
+    assert np.array_equal(idx.cpu().numpy(), g["indices"])                          # tree indices, exact
+    assert rel_close(w.cpu().numpy(), g["is_weight"], 1e-6) <= 1e-6
+    pr = ops.per_priorities(t(g["errs"].astype(np.float32), dev), float(g["alpha"]), float(g["eps"]), clip=float(g["error_max"]))
+    want = oracle.per_priorities(g["errs"], float(g["alpha"]), float(g["eps"]), float(g["error_max"]))
+    assert np.array_equal(pr.cpu().numpy(), want)
+    ops.per_update(tree, cap, len(g["indices"]), ws, idx=t(g["indices"].astype(np.int32), dev), idx_is_tree=True, prio=pr)
+    assert rel_close(tree.cpu().numpy(), g["tree_after_update"], 2e-6) <= 2e-6      # float32 pow: numpy's powf vs exp(a log x)
+    # random rounds: clipped priorities + tree-index updates with duplicate leaves vs the oracle's sequential loop
+    rng = np.random.default_rng(9)
+    for cap2, B in ((20, 64), (1000, 700), (4096, 3000)):
+        tree = torch.zeros(2 * cap2 - 1, dtype=torch.float64, device=dev)
+        ref = oracle.SumTree(cap2)
+        ops.per_update(tree, cap2, cap2, ws if cap2 <= 1024 else ops.per_workspace(8192, dev), idx_start=0, prio_scalar=1.0)
+        ref.update_many(idx_start=0, prio_scalar=1.0, B=cap2)
+        ws2 = ops.per_workspace(8192, dev)
+        for _ in range(4):
+            u = rng.random(B)
+            i_ref, _, _ = ref.sample(B, cap2, 0.4, u=u, variant_b=True)
+            idx, _, _ = ops.per_sample(tree, cap2, B, cap2, 0.4, ws2, u=t(u, dev), variant_b=True)
+            assert np.array_equal(idx.cpu().numpy(), i_ref) and i_ref.min() >= cap2 - 1
+            err = (rng.normal(size=B) * 2).astype(np.float32)
+            pr = ops.per_priorities(t(err, dev), 0.6, 1e-4, clip=1.0)
+            p_ref = oracle.per_priorities(err, 0.6, 1e-4, 1.0)
+            assert np.array_equal(pr.cpu().numpy(), p_ref) and p_ref.max() <= 1.0
+            ops.per_update(tree, cap2, B, ws2, idx=idx, idx_is_tree=True, prio=pr)
+            ref.update_many(idx=i_ref, prio=p_ref, idx_is_tree=True)
+            assert np.array_equal(tree.cpu().numpy(), ref.tree)
+
+
 def test_sumtree_golden(dev):
     from gymrl_amd import ops
     g = load_golden("sumtree")
