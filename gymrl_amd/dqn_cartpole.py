@@ -152,7 +152,9 @@ class DQNTrainer:
     def select_action(self, state, deterministic=False, u=None):
         """:124-133 for a batch of states [N, D] -> i32[N]."""
         q = self.policy_net(state)
-        eps = 0.0 if deterministic else self.get_epsilon()
+        if deterministic:       # eval(): greedy, and the exploration stream must not move (bit-exact resume / replay)
+            return ops.epsilon_greedy(q, 0.0, u=u, seed=self.base_seed, counter=0, env_id0=self.env.env_id0)
+        eps = self.get_epsilon()
         self._act_counter += 1
         return ops.epsilon_greedy(q, eps, u=u, seed=self.base_seed, counter=self._act_counter, env_id0=self.env.env_id0)
 

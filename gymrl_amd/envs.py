@@ -90,8 +90,16 @@ class EpisodeTracker:
         self.K = flush_every
         self.ret = torch.zeros(flush_every, num_envs, device=device)
         self.done = torch.zeros(flush_every, num_envs, dtype=torch.uint8, device=device)
+        self.len = torch.zeros(flush_every, num_envs, dtype=torch.int32, device=device)
+        self.lengths = []              # finished-episode lengths, parallel to the sink (filled when len_slot() is used)
+        self._want_len = False
         self.k = 0
         self.episodes = 0
+
+    def len_slot(self):
+        """-> ep_len_out[N] view for the current vector step (optional: the legacy runner logs episode lengths)."""
+        self._want_len = True
+        return self.len[self.k]
 
     def slot(self):
         """-> (ep_ret_out[N], done_out[N]) views for the current vector step."""
@@ -104,8 +112,11 @@ class EpisodeTracker:
 
     def flush(self, sink):
         if self.k:
-            fin = self.ret[:self.k][self.done[:self.k].bool()].tolist()
+            mask = self.done[:self.k].bool()
+            fin = self.ret[:self.k][mask].tolist()
             for r in fin:
                 sink.append(r)
+            if self._want_len:
+                self.lengths.extend(self.len[:self.k][mask].tolist())
             self.episodes += len(fin)
             self.k = 0

@@ -111,7 +111,8 @@ class SACTrainer:
     def select_action(self, state, deterministic=False, noise_exp=None):
         """:127-138 for a batch [N, D] -> i32[N]: argmax of the probabilities or a Categorical draw."""
         logits = self.actor.logits(state)
-        self._act_counter += 1
+        if not deterministic:                        # argmax draws nothing: eval() must not move the exploration stream
+            self._act_counter += 1
         act, _, _, _ = ops.categorical_sample(logits, noise_exp=noise_exp, seed=self.base_seed, counter=self._act_counter,
                                               env_id0=self.env.env_id0, deterministic=deterministic)
         return act

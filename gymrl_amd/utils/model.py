@@ -7,6 +7,7 @@ torch.optim.Adam's layout, `Normalization` / `RewardScaling` statistics) and the
 calls `save_model()` every `cfg.save_freq` finished episodes and `load_model()` when `cfg.load_model` is set.
 """
 import os
+import pickle
 
 import torch
 
@@ -40,6 +41,12 @@ class ModelLoader:
                 state[key] = value.detach().cpu()
             elif isinstance(value, (int, float, str, bool, list, tuple, dict, type(None))):
                 state[key] = value
+            else:       # the reference keeps every non-excluded attribute (numpy arrays, deques of returns, ...)
+                try:
+                    pickle.dumps(value)
+                    state[key] = value
+                except Exception:                     # locks, open files, compiled graphs: say so instead of dropping silently
+                    print(f"[save_model] skipping attribute {key!r} ({type(value).__name__}: not picklable)")
         torch.save(state, self.cfg.save_path)
         return state
 

@@ -78,4 +78,8 @@ class RewardScaling:
 
     def load_state_dict(self, sd):
         self.running_ms.load_state_dict(sd)
-        self.R.copy_(sd["R"].to(self.R.device, torch.float64))
+        R = sd.get("R")
+        if R is not None and tuple(R.shape) == tuple(self.R.shape):
+            self.R.copy_(R.to(self.R.device, torch.float64))
+        else:               # a different num_envs: the running statistics carry over, the per-env returns restart (= reset())
+            self.R.zero_()

@@ -12,6 +12,7 @@ import torch
 
 from ..envs import EpisodeTracker, VecEnv
 from .buffer import ReplayBuffer_on_policy
+from .metrics import ScalarWriter, log_monitors
 from .normalization import Normalization, RewardScaling
 
 
@@ -62,18 +63,36 @@ def make_env(cfg):
     return env
 
 
-def train(env, agent, cfg, max_vector_steps=None):
-    """:81-166.  Returns the list of finished-episode returns."""
-    if cfg.load_model:
-        agent.load_model()
-    if cfg.use_state_norm and not hasattr(agent, 'state_norm'):
+def ensure_normalizers(agent, cfg, num_envs):
+    """Create `agent.state_norm` / `agent.reward_scaler` when the config asks for them and the agent has none yet, and
+    hand them the statistics a checkpoint carried (ModelLoader.load_model parks them in `agent._pending_state` when the
+    object does not exist at load time).  The reference pickles the objects themselves (utils/model.py:337-366), so its
+    test() path finds them after load_model(); here train(), evaluate() and test() all go through this."""
+    if getattr(cfg, "use_state_norm", False) and not hasattr(agent, 'state_norm'):
         agent.state_norm = Normalization(shape=cfg.n_states, device=cfg.device)
-    if cfg.use_reward_scale and not hasattr(agent, 'reward_scaler'):
-        agent.reward_scaler = RewardScaling(shape=1, gamma=cfg.gamma, num_envs=env.n, device=cfg.device)
-    pending = getattr(agent, "_pending_state", {})          # statistics a checkpoint carried for objects created just above
+    if getattr(cfg, "use_reward_scale", False) and not hasattr(agent, 'reward_scaler'):
+        agent.reward_scaler = RewardScaling(shape=1, gamma=cfg.gamma, num_envs=num_envs, device=cfg.device)
+    pending = getattr(agent, "_pending_state", {})
     for attr in ("state_norm", "reward_scaler"):
         if attr in pending and hasattr(agent, attr):
             getattr(agent, attr).load_state_dict(pending.pop(attr))
+
+
+def make_writer(cfg):
+    """:101 — `./exp/<algo>_<env>_<timestamp>` (cfg.log_dir overrides the root; cfg.log_metrics = False: no sink)."""
+    if not getattr(cfg, "log_metrics", True):
+        return None
+    root = getattr(cfg, "log_dir", "./exp")
+    stamp = time.strftime("%Y%m%d-%H%M%S")
+    return ScalarWriter(f'{root}/{getattr(cfg, "algo_name", "agent")}_{cfg.env_name.replace("/", "-")}_{stamp}')
+
+
+def train(env, agent, cfg, max_vector_steps=None):
+    """:81-166.  Returns (finished-episode returns, the last update()'s metrics dict)."""
+    if cfg.load_model:
+        agent.load_model()
+    ensure_normalizers(agent, cfg, env.n)
+    writer = make_writer(cfg)
     on_policy = isinstance(agent.memory, ReplayBuffer_on_policy)
     N, D, dev = env.n, env.obs_dim, env.device
     obs, nxt, tobs = (torch.empty(N, D, device=dev) for _ in range(3))
@@ -94,7 +113,7 @@ def train(env, agent, cfg, max_vector_steps=None):
     while episodes < cfg.train_eps and step < limit:
         ep_ret, done = tracker.slot()
         env.step(action, nxt, rew, done_out=done, term_obs_out=tobs, ep_ret_out=ep_ret, terminated_out=term,
-                 truncated_out=trunc)
+                 truncated_out=trunc, ep_len_out=tracker.len_slot() if writer is not None else None)
         r = agent.reward_scaler(rew, done) if cfg.use_reward_scale else rew               # :121 (R zeroed after use where done = reset() :99)
         next_state = norm(tobs)                              # :122 — the TERMINAL observation where an episode ended
         if on_policy:
@@ -108,12 +127,19 @@ def train(env, agent, cfg, max_vector_steps=None):
         step += 1
         if agent.memory.size() >= cfg.batch_size:                                        # :138-140
             metrics = agent.update()
+            log_monitors(writer, metrics, agent, 'train', getattr(agent, "learn_step", step))   # :146-147
         # envs whose episode ended start a new one (:97-112 of the next loop turn): normalise the reset observation
         # (a second statistics update, as in the reference) and choose its first action.  One small host read per
         # vector step; this runner is the legacy contract, not the throughput path.
-        tracker.advance(returns)
+        n_before = len(returns)
+        tracker.advance(returns)                 # drains finished episodes every 16 vector steps (no per-step host sync)
+        for k in range(n_before, len(returns)):                                          # :157, per finished episode
+            log_monitors(writer, {'reward': returns[k], 'step': tracker.lengths[k]}, agent, 'train', k)
         if bool(done.any()):
             idx = done.nonzero().view(-1)
+            period = cfg.eval_freq * N            # :160-162 every eval_freq episodes of ONE env: eval_freq * N of the vector
+            if (episodes + idx.numel()) // period > episodes // period and writer is not None:
+                log_monitors(writer, {'reward': evaluate(cfg.env_name, agent, cfg)}, agent, 'eval', episodes + idx.numel())
             episodes += idx.numel()
             if hasattr(agent, "save_model") and episodes // cfg.save_freq > saved:       # :160-161, every save_freq episodes
                 saved = episodes // cfg.save_freq
@@ -130,9 +156,14 @@ def train(env, agent, cfg, max_vector_steps=None):
             else:
                 action = action.clone()
                 action[idx] = agent.choose_action(fresh)
+    n_before = len(returns)
     tracker.flush(returns)
+    for k in range(n_before, len(returns)):
+        log_monitors(writer, {'reward': returns[k], 'step': tracker.lengths[k]}, agent, 'train', k)
     if hasattr(agent, "save_model"):                                                   # :164
         agent.save_model()
+    if writer is not None:
+        writer.close()                                                                 # :166
     return returns, metrics
 
 
@@ -140,6 +171,7 @@ def train(env, agent, cfg, max_vector_steps=None):
 def evaluate(env_name, agent, cfg, episodes=None):
     """:169-184: deterministic episodes on a fresh env vector; mean return."""
     n = episodes or cfg.eval_eps
+    ensure_normalizers(agent, cfg, n)            # a freshly built agent after load_model(): statistics from the checkpoint
     env = VecEnv(env_name, n, device=cfg.device, seed=12345, env_id0=1 << 40)
     obs = env.reset()
     nxt, rew = torch.empty_like(obs), torch.empty(n, device=env.device)

@@ -86,6 +86,24 @@ def test_on_policy_runner_with_legacy_style_agent(tmp_path, monkeypatch):
     assert fresh.state_norm.running_ms.n == agent.state_norm.running_ms.n + 2 * 128      # restored, then reset + 1 step
     for a, b in zip(fresh.pi.parameters(), agent.pi.parameters()):
         assert torch.equal(a, b)
+    # test() on a freshly built agent (utils/runner.py:187-206): load_model() parks the normalisation statistics until
+    # evaluate() creates the object — the saved running mean / std are applied, not fresh ones
+    from gymrl_amd.utils.runner import test as run_test
+    fresh2 = PPO(cfg)
+    assert not hasattr(fresh2, "state_norm")
+    scores = run_test(cfg.env_name, fresh2, cfg)
+    assert len(scores) == cfg.test_eps and all(np.isfinite(x) for x in scores)
+    assert fresh2.state_norm.running_ms.n == fresh.state_norm.running_ms.n
+    # the metrics sink (utils/runner.py:46-49, :101, :145-158): one run directory per train() call with an event file
+    import glob
+    from gymrl_amd.utils.metrics import read_events
+    runs = sorted(glob.glob("exp/PPO_CartPole-v1_*"))
+    assert len(runs) >= 1
+    ev = read_events(glob.glob(runs[0] + "/events.out.tfevents.*")[0])
+    tags = {t for _, _, t, _ in ev}
+    assert {"train/total_loss", "train/reward", "train/step"} <= tags
+    n_rew = sum(1 for _, _, t, _ in ev if t == "train/reward")
+    assert n_rew == len(returns) and sum(1 for _, _, t, _ in ev if t == "train/total_loss") == agent.learn_step
 
 
 def test_off_policy_buffer_contract():
