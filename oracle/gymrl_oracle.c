@@ -674,6 +674,8 @@ orc_env* orc_env_create(int kind, int n, uint64_t seed, int64_t env_id0) {
   return e;
 }
 void orc_env_destroy(orc_env* e) { if (e) { free(e->classic); free(e->lunar); free(e); } }
+void orc_lunar_get_words(void* st, int i, uint32_t* out144);
+void orc_env_lunar_words(orc_env* e, int i, uint32_t* out144) { orc_lunar_get_words(e->lunar, i, out144); }
 
 static void cartpole_draw(uint64_t seed, uint64_t env, uint32_t episode, double* s) {
   uint32_t a[4], b[4];

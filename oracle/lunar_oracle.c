@@ -738,3 +738,33 @@ void orc_lunar_step_one(void* st, int i, uint64_t seed, uint64_t env, int action
 
 /* debug/inspection: raw body state of env i (18 floats) */
 void orc_lunar_get_bodies(void* st, int i, float* out18) { memcpy(out18, ((lander_t*)st)[i].b, sizeof(float) * 18); }
+
+/* debug/inspection: the whole world of env i in the 144-word order of the HIP state (env_lunar_device.hpp world_io):
+ * bodies 18 | sleep 3 | joints 10 | manifolds 3 x 2 x 16 | edge0 3 | touching | terrain 11 | flags | prev_shaping */
+void orc_lunar_get_words(void* st, int i, uint32_t* out144) {
+  const lander_t* W = &((lander_t*)st)[i];
+  int k = 0;
+#define PUTF(x) do { float f__ = (x); memcpy(&out144[k++], &f__, 4); } while (0)
+#define PUTU(x) do { out144[k++] = (uint32_t)(x); } while (0)
+  for (int b = 0; b < 3; ++b) { PUTF(W->b[b].cx); PUTF(W->b[b].cy); PUTF(W->b[b].a); PUTF(W->b[b].vx); PUTF(W->b[b].vy); PUTF(W->b[b].w); }
+  for (int b = 0; b < 3; ++b) PUTF(W->sleep[b]);
+  for (int L = 0; L < 2; ++L) { PUTF(W->j[L].ix); PUTF(W->j[L].iy); PUTF(W->j[L].iz); PUTF(W->j[L].im); PUTU(W->j[L].state); }
+  for (int b = 0; b < 3; ++b)
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const manifold_t* m = &W->m[b][s2];
+      PUTU(m->count); PUTU(m->faceB); PUTF(m->lnx); PUTF(m->lny); PUTF(m->lpx); PUTF(m->lpy);
+      for (int q = 0; q < 2; ++q) { PUTF(m->p[q].lpx); PUTF(m->p[q].lpy); PUTU(m->p[q].key); PUTF(m->p[q].ni); PUTF(m->p[q].ti); }
+    }
+  for (int b = 0; b < 3; ++b) PUTU(W->edge0[b]);
+  PUTU(W->touching);
+  for (int t = 0; t < 11; ++t) PUTF(W->ty[t]);
+  PUTU(W->flags);
+  PUTF(W->prev_shaping);
+#undef PUTF
+#undef PUTU
+}
+
+/* the mass constants the solver uses: 1/m and 1/I of hull, leg, leg (tests derive them from the shapes) */
+void orc_lunar_constants(float* out6) {
+  for (int b = 0; b < 3; ++b) { out6[b] = INV_M[b]; out6[3 + b] = INV_I[b]; }
+}

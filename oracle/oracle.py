@@ -83,6 +83,12 @@ def linear_act(x, W, b, act=0):
     return y
 
 
+def lunar_constants():
+    out = np.zeros(6, np.float32)
+    lib().orc_lunar_constants(_p(out))
+    return out
+
+
 def linear_fwd(x, W, b=None):
     """x W^T + b in gymrl_linear_fwd's accumulation order (no activation)."""
     x, W = _f32(x), _f32(W)
@@ -376,6 +382,15 @@ class Env:
         obs = np.zeros((self.n, self.D), np.float32)
         lib().orc_env_reset(self._h, _p(obs))
         return obs
+
+    def lunar_words(self):
+        """u32[144, n]: every LunarLander world in the word order of the HIP state buffer (tests/box2d_micro.py)."""
+        out = np.zeros((self.n, 144), np.uint32)
+        row = np.zeros(144, np.uint32)
+        for i in range(self.n):
+            lib().orc_env_lunar_words(self._h, i, _p(row))
+            out[i] = row
+        return np.ascontiguousarray(out.T)
 
     def step(self, action):
         action = _i32(action) if self.kind != PENDULUM else _f32(action)
