@@ -1,26 +1,30 @@
 #!/usr/bin/env python3
-"""A few launches of each update-path GEMM (library and hand-written) at B = 262,144 for rocprofv3 --pmc passes:
-MFMA busy cycles, wave cycles and GRBM_GUI_ACTIVE (effective clock = GUI_ACTIVE / duration)."""
+"""Three minibatch updates of the round-2 PPO path at bench shape (B = 262,144: ppo_net.step() = every kernel of one
+minibatch) plus the library GEMMs of the same shapes, for rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ / GRBM
+counters, each in its own run with --kernel-trace only)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gymrl_amd import ops
+from gymrl_amd import ops, ppo_net
+from gymrl_amd.flat import flatten_module
+from gymrl_amd.ppo_lunarlander import ActorCritic
 dev = torch.device("cuda:0")
 B = 262144
-g = torch.Generator(device=dev).manual_seed(0)
-x = torch.randn(B, 256, device=dev, generator=g)
-h = torch.tanh(torch.randn(B, 256, device=dev, generator=g))
-dy2, dy5 = torch.randn(B, 256, device=dev, generator=g), torch.randn(B, 512, device=dev, generator=g)
-W2, W5 = torch.randn(256, 256, device=dev, generator=g) / 16, torch.randn(512, 256, device=dev, generator=g) / 16
-b2 = torch.randn(256, device=dev, generator=g)
-y2, dx, cs = torch.empty(B, 256, device=dev), torch.empty(B, 256, device=dev), torch.empty(256, device=dev)
-dW2, dW5 = torch.empty(256, 256, device=dev), torch.empty(512, 256, device=dev)
-ws = ops.gemm_workspace(dev)
-for _ in range(3):
-    torch.mm(x, W2.t(), out=y2)
-    torch.mm(dy5, W5, out=dx)
-    ops.linear_fwd(x, W2, b2, y2, act=True)
-    ops.linear_bwd_input(dy5, W5, h, dx)
-    ops.linear_bwd_input(dy2, W2, h, dx)
-    ops.linear_bwd_weight(dy2, x, dW2, ws)
-    ops.linear_bwd_weight(dy5, x, dW5, ws)
+torch.manual_seed(0)
+net = ActorCritic(8, 4, 256)
+flatten_module(net, dev, order=ppo_net.LAYOUT)
+fu = ppo_net.FusedActorCriticUpdate(net, B)
+g = torch.Generator(device=dev).manual_seed(1)
+x = torch.randn(B, 8, device=dev, generator=g)
+act = torch.randint(0, 4, (B,), device=dev, generator=g, dtype=torch.int32)
+lpo = torch.full((B,), -1.386, device=dev)
+adv, ret = torch.randn(B, device=dev, generator=g), torch.randn(B, device=dev, generator=g)
+mom = torch.tensor([float(B), 0.0, float(B)], dtype=torch.float64, device=dev)
+parts = torch.zeros(fu.metric_blocks(B), 5, dtype=torch.float64, device=dev)
+h1, w2 = torch.randn(B, 256, device=dev, generator=g), torch.randn(256, 256, device=dev, generator=g) / 16
+y = torch.empty(B, 256, device=dev)
+junk = torch.empty(512 << 20, dtype=torch.uint8, device=dev)     # evict the 256 MiB Infinity Cache between updates
+for _ in range(4):
+    junk.zero_()
+    fu.step(x, act, lpo, adv, ret, (0.2, 3.0, 0.5, 0.01), mom, parts)
+    torch.mm(h1, w2.t(), out=y)
 torch.cuda.synchronize()
