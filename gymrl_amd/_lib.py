@@ -22,7 +22,7 @@ _lib = None
 SYMBOLS = [
     "gymrl_abi_version", "gymrl_device_ok",
     "gymrl_env_obs_dim", "gymrl_env_act_dim", "gymrl_env_is_discrete", "gymrl_env_max_steps",
-    "gymrl_env_state_bytes", "gymrl_env_reset", "gymrl_env_step", "gymrl_env_refill",
+    "gymrl_env_state_bytes", "gymrl_env_reset", "gymrl_env_step", "gymrl_env_refill", "gymrl_env_abandon",
     "gymrl_categorical_sample",
     "gymrl_gae_workspace_bytes", "gymrl_gae", "gymrl_gae_online_flush", "gymrl_gae_chunk", "gymrl_gae_dw", "gymrl_gae_decoupled", "gymrl_gae_decoupled_workspace_bytes",
     "gymrl_reduce_workspace_bytes", "gymrl_moments", "gymrl_normalize",

@@ -201,6 +201,47 @@ __global__ __launch_bounds__(kEnvBlock) void pendulum_step_kernel(
   accumulate_ep_stats(ep_stats, done, ret, len);
 }
 
+// Episodes a trainer abandons at its own step cap (dqn_cartpole.py:178 `for step in range(cfg.max_steps)` below the
+// env's TimeLimit): an env whose running episode has reached `cap` steps starts its next episode — no done flag, the
+// transition just stored keeps the real next observation — and reports the abandoned episode's return / length.
+__global__ __launch_bounds__(kEnvBlock) void classic_abandon_kernel(int kind, void* buf, int n, uint64_t seed, int64_t env_id0,
+                                                                    int cap, float* __restrict__ obs, uint8_t* __restrict__ flag_out,
+                                                                    float* __restrict__ ep_ret_out, int32_t* __restrict__ ep_len_out,
+                                                                    double* __restrict__ ep_stats) {
+  const int i = blockIdx.x * kEnvBlock + threadIdx.x;
+  bool hit = false;
+  double ret = 0.0; int len = 0;
+  if (i < n) {
+    EpisodeFields ep = kind == GYMRL_ENV_CARTPOLE ? CartPoleState(buf, n).ep : PendulumState(buf, n).ep;
+    len = ep.ep_len[i];
+    hit = len >= cap;
+    if (hit) {
+      ret = ep.ep_ret[i];
+      const uint32_t e = ep.episode[i] + 1u;
+      if (kind == GYMRL_ENV_CARTPOLE) {
+        CartPoleState st(buf, n);
+        double r[4];
+        cartpole_draw(seed, (uint64_t)(env_id0 + i), e, r);
+        st.x[i] = r[0]; st.xd[i] = r[1]; st.th[i] = r[2]; st.thd[i] = r[3];
+        reinterpret_cast<float4*>(obs)[i] = make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
+      } else {
+        PendulumState st(buf, n);
+        double th, thd;
+        pendulum_draw(seed, (uint64_t)(env_id0 + i), e, th, thd);
+        st.th[i] = th; st.thd[i] = thd;
+        float o[3];
+        pendulum_obs(th, thd, o);
+        obs[3 * (size_t)i] = o[0]; obs[3 * (size_t)i + 1] = o[1]; obs[3 * (size_t)i + 2] = o[2];
+      }
+      ep.ep_ret[i] = 0.0; ep.ep_len[i] = 0; ep.episode[i] = e;
+      if (ep_ret_out) ep_ret_out[i] = (float)ret;
+      if (ep_len_out) ep_len_out[i] = len;
+    }
+    if (flag_out) flag_out[i] = flag_out[i] | (uint8_t)hit;
+  }
+  accumulate_ep_stats(ep_stats, hit, ret, len);
+}
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
@@ -261,6 +302,17 @@ int gymrl_env_reset(int kind, void* state, int n, uint64_t seed, int64_t env_id0
       return lunar_reset(state, n, seed, env_id0, obs_out, s);
     default: return -22;
   }
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_env_abandon(int kind, void* state, int n, uint64_t seed, int64_t env_id0, int cap, float* obs_inout,
+                      uint8_t* flag_inout, float* ep_ret_out, int32_t* ep_len_out, double* ep_stats, void* stream_) {
+  if (!state || !obs_inout || n < 0 || cap <= 0 || !aligned(state, 256) || !aligned(obs_inout, 16)) return -22;
+  if (kind != GYMRL_ENV_CARTPOLE && kind != GYMRL_ENV_PENDULUM) return -22;    // no reference off-policy script runs LunarLander
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(classic_abandon_kernel, dim3(cdiv(n, kEnvBlock)), dim3(kEnvBlock), 0, (hipStream_t)stream_, kind, state,
+                     n, seed, env_id0, cap, obs_inout, flag_inout, ep_ret_out, ep_len_out, ep_stats);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

@@ -66,6 +66,12 @@ class VecEnv:
                      ep_len_out=ep_len_out, ep_stats=self.ep_stats)
         self._refill()
 
+    def abandon(self, cap, obs_inout, flag_inout=None, ep_ret_out=None, ep_len_out=None):
+        """A trainer's own step cap below the env's TimeLimit (`for step in range(cfg.max_steps)`): envs whose episode
+        reached `cap` steps start their next one without a done flag; `flag_inout` (the tracker's done row) gets them too."""
+        ops.env_abandon(self.kind, self.state, self.n, self.seed, self.env_id0, int(cap), obs_inout, flag_inout, ep_ret_out,
+                        ep_len_out, self.ep_stats)
+
     def close(self):
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)

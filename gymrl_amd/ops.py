@@ -360,6 +360,15 @@ def env_step(kind, state, n, seed, env_id0, action, obs_out, rew_out, terminated
 
 
 # ============================================================== off-policy ===
+def env_abandon(kind, state, n, seed, env_id0, cap, obs_inout, flag_inout=None, ep_ret_out=None, ep_len_out=None,
+                ep_stats=None):
+    """Start the next episode of every env whose running episode reached `cap` steps (include/gymrl.h)."""
+    check(lib().gymrl_env_abandon(C.c_int(kind), _ptr(state), C.c_int(n), C.c_uint64(seed), C.c_int64(env_id0), C.c_int(cap),
+                                  _ptr(obs_inout, torch.float32), _ptr(flag_inout, torch.uint8, True),
+                                  _ptr(ep_ret_out, torch.float32, True), _ptr(ep_len_out, torch.int32, True),
+                                  _ptr(ep_stats, torch.float64, True), _stream()), "gymrl_env_abandon")
+
+
 def replay_append(ring, cursor, src_state, src_action, src_reward, src_next_state, src_flag):
     """D2/A3: write n rows at (cursor + i) % cap.  ring = (state, action_words, reward, next_state, flag)."""
     state, action, reward, next_state, flag = ring

@@ -206,6 +206,8 @@ class SACTrainer:
             ep_ret, done = tracker.slot()
             env.step(action, nxt, rew, done_out=done, term_obs_out=tobs, ep_ret_out=ep_ret)
             self.memory.push(obs, action, rew, tobs, done)
+            if cfg.max_steps < env.max_steps:       # the reference's `for step in range(cfg.max_steps)`: abandoned, no done flag
+                env.abandon(cfg.max_steps, nxt, done, ep_ret)
             for _ in range(cfg.updates_per_step):
                 if graphed:
                     self.update_async()

@@ -303,6 +303,8 @@ class SACTrainer:
             ep_ret, done = tracker.slot()
             env.step(action, nxt, rew, done_out=done, term_obs_out=tobs, ep_ret_out=ep_ret)
             self.memory.push(obs, action, rew, tobs, done)                     # done = terminated or truncated (:283)
+            if cfg.max_steps < env.max_steps:       # :278 `for step in range(cfg.max_steps)`: the episode is abandoned without a
+                env.abandon(cfg.max_steps, nxt, done, ep_ret)     # done flag (stored above) and the next one starts
             for _ in range(cfg.updates_per_step):
                 if graphed:
                     self.update_async()

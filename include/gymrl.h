@@ -80,6 +80,16 @@ int gymrl_env_step(int kind, void* state, int n_envs, uint64_t seed, int64_t env
                    uint8_t* done_out, float* ep_ret_out, int32_t* ep_len_out,
                    double* ep_stats, void* stream);
 
+/* Episodes a trainer abandons at its own step cap below the env's TimeLimit — `for step in range(cfg.max_steps)`
+ * of dqn_cartpole.py:178, sac_pendulum.py:278 (no done flag is stored; the next loop turn calls env.reset()).
+ * Call after gymrl_env_step: every env whose running episode has reached `cap` steps starts its next episode;
+ * obs_inout [N, obs] rows of those envs become the reset observation, flag_inout u8[N] (or NULL) is OR-ed with 1
+ * for them, ep_ret_out / ep_len_out / ep_stats receive the abandoned episode as gymrl_env_step would for a
+ * finished one.  CartPole-v1 and Pendulum-v1 (no reference off-policy script runs LunarLander: -EINVAL). */
+int gymrl_env_abandon(int kind, void* state, int n_envs, uint64_t seed, int64_t env_id0, int cap,
+                      float* obs_inout, uint8_t* flag_inout, float* ep_ret_out, int32_t* ep_len_out,
+                      double* ep_stats, void* stream);
+
 /* Optional latency hiding for expensive resets (LunarLander's reset() ends with a full
  * physics step): prepares, for every env that lacks one, the post-reset world of its NEXT
  * episode in a spare slot of `state`; gymrl_env_step then swaps it in when the episode ends

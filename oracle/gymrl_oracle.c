@@ -711,6 +711,23 @@ void orc_env_reset(orc_env* e, float* obs_out) {
 }
 
 /* One vector step with auto-reset (semantics of gymrl_env_step in include/gymrl.h). */
+/* gymrl_env_abandon: classic envs whose running episode reached `cap` steps start the next one. */
+void orc_env_abandon(orc_env* e, int cap, float* obs_inout, uint8_t* flag_inout, float* ep_ret_out, int32_t* ep_len_out) {
+  const int D = e->kind == ORC_CARTPOLE ? 4 : 3;
+  if (e->kind == ORC_LUNARLANDER) return;
+  for (int i = 0; i < e->n; ++i) {
+    orc_classic_env* c = &e->classic[i];
+    if (c->ep_len < cap) continue;
+    if (ep_ret_out) ep_ret_out[i] = (float)c->ep_ret;
+    if (ep_len_out) ep_len_out[i] = c->ep_len;
+    if (flag_inout) flag_inout[i] |= 1;
+    c->episode += 1u; c->ep_ret = 0.0; c->ep_len = 0;
+    if (e->kind == ORC_CARTPOLE) cartpole_draw(e->seed, (uint64_t)(e->env_id0 + i), c->episode, c->s);
+    else pendulum_draw(e->seed, (uint64_t)(e->env_id0 + i), c->episode, c->s);
+    classic_obs(e->kind, c->s, obs_inout + (size_t)i * D);
+  }
+}
+
 void orc_env_step(orc_env* e, const void* action, float* obs_out, float* term_obs_out,
                   float* rew_out, uint8_t* terminated_out, uint8_t* truncated_out,
                   uint8_t* done_out, float* ep_ret_out, int32_t* ep_len_out, double* ep_stats) {

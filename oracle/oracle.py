@@ -383,6 +383,13 @@ class Env:
         lib().orc_env_reset(self._h, _p(obs))
         return obs
 
+    def abandon(self, cap, obs):
+        """gymrl_env_abandon: returns (obs with the restarted envs' rows replaced, flag u8[n], ep_ret, ep_len)."""
+        obs = np.ascontiguousarray(obs, np.float32).copy()
+        flag, ep_ret, ep_len = np.zeros(self.n, np.uint8), np.zeros(self.n, np.float32), np.zeros(self.n, np.int32)
+        lib().orc_env_abandon(self._h, int(cap), _p(obs), _p(flag), _p(ep_ret), _p(ep_len))
+        return obs, flag, ep_ret, ep_len
+
     def lunar_words(self):
         """u32[144, n]: every LunarLander world in the word order of the HIP state buffer (tests/box2d_micro.py)."""
         out = np.zeros((self.n, 144), np.uint32)

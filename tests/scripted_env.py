@@ -117,5 +117,9 @@ class ScriptedVecEnv:
             if dst is not None:
                 dst.copy_(T.from_numpy(src).to(self.device))
 
+    def abandon(self, cap, obs_inout, flag_inout=None, ep_ret_out=None, ep_len_out=None):
+        """VecEnv.abandon: the scripted episodes (9..21 steps) never reach a trainer's step cap."""
+        assert max(self.ep_len) < cap
+
     def close(self):
         pass

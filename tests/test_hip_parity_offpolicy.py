@@ -397,3 +397,38 @@ def test_dsac_kernels_vs_oracle(dev, oracle):
             cur, mm, vv, lo = oracle.dsac_alpha_step(cur, mm, vv, rs, B, -1.0, 1e-3, step)
             assert la_t.item() == np.float32(cur) and m.item() == np.float32(mm) and v.item() == np.float32(vv)
             assert abs(loss.item() - lo) <= 1e-12 * max(1.0, abs(lo))
+
+
+@pytest.mark.parametrize("kind_name", ["CARTPOLE", "PENDULUM"])
+def test_env_abandon_vs_oracle(dev, oracle, kind_name):
+    """gymrl_env_abandon (a trainer's `for step in range(cfg.max_steps)` below the env's TimeLimit): envs whose episode
+    reached the cap restart without a done flag; observations, flags, returns and lengths equal the oracle's, and the
+    following steps continue bit for bit on the new episodes' Philox streams."""
+    from gymrl_amd import ops
+    kind = getattr(ops, kind_name)
+    okind = getattr(oracle, kind_name)
+    n, seed, cap = 96, 21, 7
+    D = 4 if kind_name == "CARTPOLE" else 3
+    env = oracle.Env(okind, n, seed=seed)
+    o_ref = env.reset()
+    state = ops.env_state(kind, n, dev)
+    obs, rew = torch.empty(n, D, device=dev), torch.empty(n, device=dev)
+    term, trunc, done = (torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(3))
+    ops.env_reset(kind, state, n, seed, 0, obs)
+    assert np.array_equal(obs.cpu().numpy(), o_ref)
+    rng = np.random.default_rng(2)
+    hits = 0
+    for _ in range(40):
+        act = rng.integers(0, 2, size=n).astype(np.int32) if kind_name == "CARTPOLE" else rng.uniform(-2, 2, size=(n, 1)).astype(np.float32)
+        r = env.step(act)
+        ops.env_step(kind, state, n, seed, 0, t(act, dev), obs, rew, term, trunc, done_out=done)
+        assert np.array_equal(obs.cpu().numpy(), r["obs"]) and np.array_equal(done.cpu().numpy(), r["done"])
+        o2, flag, ep_ret, ep_len = env.abandon(cap, r["obs"])
+        g_ret, g_len = torch.zeros(n, device=dev), torch.zeros(n, dtype=torch.int32, device=dev)
+        ops.env_abandon(kind, state, n, seed, 0, cap, obs, done, g_ret, g_len)
+        assert np.array_equal(obs.cpu().numpy(), o2)
+        assert np.array_equal(done.cpu().numpy(), r["done"] | flag)
+        assert np.array_equal(g_len.cpu().numpy(), ep_len) and np.allclose(g_ret.cpu().numpy(), ep_ret, rtol=0, atol=0)
+        assert np.all(ep_len[flag.astype(bool)] == cap)
+        hits += int(flag.sum())
+    assert hits > n
