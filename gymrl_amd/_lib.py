@@ -43,6 +43,7 @@ SYMBOLS = [
     "gymrl_gemm_workspace_bytes", "gymrl_gemm_config", "gymrl_linear_fwd", "gymrl_linear_bwd_input",
     "gymrl_linear_bwd_weight_geometry", "gymrl_linear_bwd_weight",
     "gymrl_heads_loss_blocks", "gymrl_heads_loss_fwd_bwd",
+    "gymrl_lin_workspace_bytes", "gymrl_lin_fwd", "gymrl_lin_bwd_input", "gymrl_lin_bwd_weight",
 ]
 
 
@@ -52,6 +53,12 @@ def build(force=False):
         subprocess.check_call(["make", "-C", CSRC, "-s", "clean"])
     subprocess.check_call(["make", "-C", CSRC, "-s", "-j8"])
     return LIB_PATH
+
+
+class LinItem(C.Structure):
+    """gymrl_lin_item (include/gymrl.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("x", "x2", "w", "b", "y", "dy", "dx", "dx2", "dw", "db")] +
+                [("act", C.c_int), ("lo", C.c_float), ("hi", C.c_float)])
 
 
 class PPOCfg(C.Structure):
@@ -109,6 +116,7 @@ def lib():
         L.gymrl_mlp_packed_floats.restype = C.c_size_t
         L.gymrl_mlp_train_workspace_bytes.restype = C.c_size_t
         L.gymrl_gemm_workspace_bytes.restype = C.c_size_t
+        L.gymrl_lin_workspace_bytes.restype = C.c_size_t
         for name in SYMBOLS:
             if name.endswith(("_bytes", "_floats")):
                 continue

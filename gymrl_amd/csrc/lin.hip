@@ -1,0 +1,475 @@
+// lin.hip — low-latency Linear(+activation) layers for the off-policy networks' update and acting path.
+//
+// The reference's DQN / Rainbow / SAC / TD3 / DDPG updates (dqn_cartpole.py:164-196, rainbow_dqn_cartpole.py:311-361,
+// sac_pendulum.py:213-267, td3_pendulum.py:204-250) push 64-256 rows through 256-wide torch Linear layers; vectorised,
+// the acting forward runs on 4096-8192 rows.  At these sizes a layer is a few MFLOP: a library GEMM plus its bias
+// add, activation, activation-gradient, bias-gradient and gradient-copy launches is 3-6 launches of 3-5 us each per
+// layer and direction, and a SAC update was 187 launches (`profiles/r01_sac_graph_kernel_stats.csv`).  Here a layer is
+// ONE launch per direction:
+//
+//   lin_fwd         Y  = act(X W^T + b)                       (X may be the concatenation [X | X2] of two row blocks)
+//   lin_bwd_input   dX = (dY * act'(Y)) W                     (split back into dX | dX2; either may be skipped)
+//   lin_bwd_weight  dW (+)= (dY * act'(Y))^T X,  db (+)= column sums of dY * act'(Y)
+//
+// and up to GYMRL_LIN_MAX_ITEMS independent layers of one shape (the twin Q networks, the actor's mean / log_std heads,
+// online + target networks) share a launch (blockIdx.y).
+//
+// Mapping: one wavefront owns a 16 x 16 (NT = 1) or 16 x 64 (NT = 4) output tile and walks the whole reduction with
+// v_mfma_f32_16x16x4_f32 (exact f32 products, f32 accumulation, 8 passes); operands come straight from global memory
+// (everything is L2-resident: a 256 x 256 weight is 256 KiB) — 16-byte loads along the reduction where it is the
+// contiguous dimension (lin_fwd: both operands; lin_bwd_input: dY and Y), dword loads of 64-byte row segments otherwise.
+// No LDS, no barriers: with 128-rows x 256 outputs = 128 independent waves a launch lasts one wave's ~2 us chain.
+// Tiles are 16-row granular so ragged B / N / K are handled by predicated loads (zeros) and stores.
+//
+// Accumulation order (documented for the tests; all sums are f32 fma chains inside the MFMA unit):
+//   lin_fwd:        for k0 = 0, 16, ...: for e = 0..3: the MFMA adds the four products k = k0 + 4 q + e, q = 0..3 in order
+//   lin_bwd_input:  the same with n in place of k
+//   lin_bwd_weight: for b0 = lo, lo + 16, ...: for e = 0..3: rows b = b0 + 4 e + q, q = 0..3; B > 512 rows are cut into
+//                   slices whose partial tiles are added in slice order by a second launch (fixed order, no atomics)
+#include "train_device.hpp"
+#include "../../include/gymrl.h"
+
+namespace {
+
+using namespace gymrl;
+
+constexpr int kItems = GYMRL_LIN_MAX_ITEMS;
+constexpr int kWavesPerBlock = 4;
+constexpr int kChunk = 8;       // reduction steps (of 16) whose loads are in flight together
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float act_fwd(float z, int act, float lo, float hi) {
+  if (act == GYMRL_ACT_RELU) return fmaxf(z, 0.0f);
+  if (act == GYMRL_ACT_TANH) return train_tanhf(z);
+  if (act == GYMRL_ACT_CLAMP) return fminf(fmaxf(z, lo), hi);
+  return z;
+}
+// d act / d z as a function of the saved OUTPUT y
+__device__ __forceinline__ float act_bwd(float y, int act, float lo, float hi) {
+  if (act == GYMRL_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
+  if (act == GYMRL_ACT_TANH) return 1.0f - y * y;
+  if (act == GYMRL_ACT_CLAMP) return (y > lo && y < hi) ? 1.0f : 0.0f;
+  return 1.0f;
+}
+
+struct LinFwd {
+  const float* X[kItems]; const float* X2[kItems]; const float* W[kItems]; const float* b[kItems]; float* Y[kItems];
+  int act[kItems]; float lo[kItems], hi[kItems];
+  int B, K, K1, N, ldx, ldx2, ldy, col_groups;
+};
+
+template <int NT, bool VEC>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void lin_fwd_kernel(const LinFwd a) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int item = blockIdx.y;
+  const int rt = wave / a.col_groups, cg = wave - rt * a.col_groups;
+  if (rt * 16 >= a.B) return;
+  const float* __restrict__ X = a.X[item];
+  const float* __restrict__ X2 = a.X2[item];
+  const float* __restrict__ W = a.W[item];
+  const int act = a.act[item];
+  const float lo = a.lo[item], hi = a.hi[item];
+  const int row = rt * 16 + r;
+  const bool row_ok = row < a.B;
+  const int nb = cg * 16 * NT;
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = zero;
+  const float* xrow = X + (size_t)(row_ok ? row : 0) * a.ldx;
+  const float* x2row = X2 ? X2 + (size_t)(row_ok ? row : 0) * a.ldx2 : nullptr;
+  if constexpr (VEC) {
+    // all of a chunk's loads (unconditional, clamped addresses) are in flight before its first MFMA
+    const float* wrow[NT];
+    bool n_ok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = nb + 16 * t + r;
+      n_ok[t] = n < a.N;
+      wrow[t] = W + (size_t)(n_ok[t] ? n : 0) * a.K;
+    }
+    for (int kc0 = 0; kc0 < a.K; kc0 += 16 * kChunk) {
+      f32x4 xa[kChunk], wb[kChunk][NT];
+#pragma unroll
+      for (int c = 0; c < kChunk; ++c) {
+        const int k = kc0 + 16 * c + 4 * q;
+        const int ks = k < a.K ? k : 0;
+        xa[c] = *reinterpret_cast<const f32x4*>(xrow + ks);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wb[c][t] = *reinterpret_cast<const f32x4*>(wrow[t] + ks);
+      }
+#pragma unroll
+      for (int c = 0; c < kChunk; ++c) {
+        const bool k_ok = kc0 + 16 * c + 4 * q < a.K;
+        const f32x4 x = (row_ok && k_ok) ? xa[c] : zero;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const f32x4 w = (n_ok[t] && k_ok) ? wb[c][t] : zero;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[t] = mfma16(x[e], w[e], acc[t]);
+        }
+      }
+    }
+  } else {
+    for (int k0 = 0; k0 < a.K; k0 += 16) {
+      const int k = k0 + 4 * q;
+      f32x4 xa, wb[NT];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kk = k + e;
+        float v = 0.0f;
+        if (row_ok && kk < a.K) v = kk < a.K1 ? xrow[kk] : x2row[kk - a.K1];
+        xa[e] = v;
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int n = nb + 16 * t + r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wb[t][e] = (n < a.N && k + e < a.K) ? W[(size_t)n * a.K + k + e] : 0.0f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma16(xa[e], wb[t][e], acc[t]);
+    }
+  }
+  const float* __restrict__ bias = a.b[item];
+  float* __restrict__ Y = a.Y[item];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = nb + 16 * t + r;
+    if (n >= a.N) continue;
+    const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ro = rt * 16 + 4 * q + g;
+      if (ro < a.B) Y[(size_t)ro * a.ldy + n] = act_fwd(acc[t][g] + bv, act, lo, hi);
+    }
+  }
+}
+
+struct LinBwdIn {
+  const float* dY[kItems]; const float* Y[kItems]; const float* W[kItems]; float* dX[kItems]; float* dX2[kItems];
+  int act[kItems]; float lo[kItems], hi[kItems];
+  int B, N, K, K1, ldy, lddx, lddx2, accumulate, col_groups, n_sum;
+};
+
+template <int NT, bool VEC>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void lin_bwd_input_kernel(const LinBwdIn a) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int item = blockIdx.y;
+  const int rt = wave / a.col_groups, cg = wave - rt * a.col_groups;
+  if (rt * 16 >= a.B) return;
+  const int row = rt * 16 + r;
+  const bool row_ok = row < a.B;
+  const int kb = cg * 16 * NT;
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = zero;
+  const size_t roff = (size_t)(row_ok ? row : 0) * a.ldy;
+  // n_sum > 1: the items' products are summed (layers fed by ONE input: the gradient of that input) — the
+  // reduction simply runs on over the next item's dY / W
+  for (int it = item; it < item + a.n_sum; ++it) {
+  const float* __restrict__ dY = a.dY[it];
+  const float* __restrict__ Yv = a.Y[it];
+  const float* __restrict__ W = a.W[it];
+  const int act = a.act[it];
+  const float lo = a.lo[it], hi = a.hi[it];
+  if constexpr (VEC) {
+    int kcol[NT];
+    bool k_ok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int kc = kb + 16 * t + r;
+      k_ok[t] = kc < a.K;
+      kcol[t] = k_ok[t] ? kc : 0;
+    }
+    for (int nc0 = 0; nc0 < a.N; nc0 += 16 * kChunk) {
+      f32x4 dy[kChunk], yv[kChunk], wb[kChunk][NT];
+#pragma unroll
+      for (int c = 0; c < kChunk; ++c) {
+        const int n = nc0 + 16 * c + 4 * q;
+        const int ns = n < a.N ? n : 0;
+        dy[c] = *reinterpret_cast<const f32x4*>(dY + roff + ns);
+        if (act != GYMRL_ACT_NONE) yv[c] = *reinterpret_cast<const f32x4*>(Yv + roff + ns);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) wb[c][t][e] = W[(size_t)(ns + e) * a.K + kcol[t]];
+      }
+#pragma unroll
+      for (int c = 0; c < kChunk; ++c) {
+        const bool ok = row_ok && nc0 + 16 * c + 4 * q < a.N;
+        f32x4 dz = ok ? dy[c] : zero;
+        if (act != GYMRL_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dz[e] *= act_bwd(yv[c][e], act, lo, hi);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[t] = mfma16(dz[e], k_ok[t] ? wb[c][t][e] : 0.0f, acc[t]);
+      }
+    }
+  } else {
+    for (int n0 = 0; n0 < a.N; n0 += 16) {
+      const int n = n0 + 4 * q;
+      f32x4 dz;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = 0.0f;
+        if (row_ok && n + e < a.N) {
+          v = dY[roff + n + e];
+          if (act != GYMRL_ACT_NONE) v *= act_bwd(Yv[roff + n + e], act, lo, hi);
+        }
+        dz[e] = v;
+      }
+      f32x4 wb[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int kc = kb + 16 * t + r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wb[t][e] = (n + e < a.N && kc < a.K) ? W[(size_t)(n + e) * a.K + kc] : 0.0f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma16(dz[e], wb[t][e], acc[t]);
+    }
+  }
+  }
+  float* __restrict__ dX = a.dX[item];
+  float* __restrict__ dX2 = a.dX2[item];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int kc = kb + 16 * t + r;
+    if (kc >= a.K) continue;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ro = rt * 16 + 4 * q + g;
+      if (ro >= a.B) continue;
+      float* dst = kc < a.K1 ? (dX ? dX + (size_t)ro * a.lddx + kc : nullptr)
+                             : (dX2 ? dX2 + (size_t)ro * a.lddx2 + (kc - a.K1) : nullptr);
+      if (dst) *dst = a.accumulate ? *dst + acc[t][g] : acc[t][g];
+    }
+  }
+}
+
+struct LinBwdW {
+  const float* dY[kItems]; const float* Y[kItems]; const float* X[kItems]; const float* X2[kItems];
+  float* dW[kItems]; float* db[kItems];
+  float* partial;              // slices > 1: [item][slice][N*K + N]
+  int act[kItems]; float lo[kItems], hi[kItems];
+  int B, N, K, K1, ldy, ldx, ldx2, accumulate, col_groups, slices, rows_per_slice;
+};
+
+template <int NT>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void lin_bwd_weight_kernel(const LinBwdW a) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int item = blockIdx.y, slice = blockIdx.z;
+  const int nt = wave / a.col_groups, cg = wave - nt * a.col_groups;
+  if (nt * 16 >= a.N) return;
+  const float* __restrict__ dY = a.dY[item];
+  const float* __restrict__ Yv = a.Y[item];
+  const float* __restrict__ X = a.X[item];
+  const float* __restrict__ X2 = a.X2[item];
+  const int act = a.act[item];
+  const float lo = a.lo[item], hi = a.hi[item];
+  const int n = nt * 16 + r;
+  const bool n_ok = n < a.N;
+  const int kb = cg * 16 * NT;
+  const int b_lo = slice * a.rows_per_slice;
+  const int b_hi = min(a.B, b_lo + a.rows_per_slice);
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = zero;
+  float colsum = 0.0f;
+  // chunks of kChunk 16-row steps: every load of a chunk (unconditional, clamped addresses) is issued before its first MFMA
+  const int ns = n_ok ? n : 0;
+  for (int bc0 = b_lo; bc0 < b_hi; bc0 += 16 * kChunk) {
+    float dy[kChunk][4], yv[kChunk][4], xb[kChunk][NT][4];
+#pragma unroll
+    for (int c = 0; c < kChunk; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int b = bc0 + 16 * c + 4 * e + q;
+        const size_t bs = (size_t)(b < b_hi ? b : b_lo);
+        dy[c][e] = dY[bs * a.ldy + ns];
+        if (act != GYMRL_ACT_NONE) yv[c][e] = Yv[bs * a.ldy + ns];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int kc = kb + 16 * t + r;
+          const int ks = kc < a.K ? kc : 0;
+          const float* px = ks < a.K1 ? X + bs * a.ldx + ks : X2 + bs * a.ldx2 + (ks - a.K1);
+          xb[c][t][e] = *px;
+        }
+      }
+#pragma unroll
+    for (int c = 0; c < kChunk; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = n_ok && bc0 + 16 * c + 4 * e + q < b_hi;
+        float dz = ok ? dy[c][e] : 0.0f;
+        if (act != GYMRL_ACT_NONE) dz *= ok ? act_bwd(yv[c][e], act, lo, hi) : 0.0f;
+        colsum += dz;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma16(dz, kb + 16 * t + r < a.K ? xb[c][t][e] : 0.0f, acc[t]);
+      }
+  }
+  // bias gradient: the four row groups' serial sums, added pairwise (q0 + q1) + (q2 + q3)
+  colsum += __shfl_xor(colsum, 16, 64);
+  colsum += __shfl_xor(colsum, 32, 64);
+  const size_t wk = (size_t)a.N * a.K;
+  float* __restrict__ dW = a.dW[item];
+  float* __restrict__ db = a.db[item];
+  float* part = a.slices > 1 ? a.partial + ((size_t)item * a.slices + slice) * (wk + a.N) : nullptr;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int kc = kb + 16 * t + r;
+    if (kc >= a.K) continue;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int no = nt * 16 + 4 * q + g;
+      if (no >= a.N) continue;
+      const size_t o = (size_t)no * a.K + kc;
+      if (part) part[o] = acc[t][g];
+      else dW[o] = a.accumulate ? dW[o] + acc[t][g] : acc[t][g];
+    }
+  }
+  if (cg == 0 && q == 0 && n_ok) {
+    if (part) part[wk + n] = colsum;
+    else if (db) db[n] = a.accumulate ? db[n] + colsum : colsum;
+  }
+}
+
+__global__ __launch_bounds__(256) void lin_slice_reduce_kernel(const LinBwdW a) {
+  const int item = blockIdx.y;
+  const size_t wk = (size_t)a.N * a.K, per = wk + a.N;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= per) return;
+  const float* p = a.partial + (size_t)item * a.slices * per + i;
+  float s = p[0];
+  for (int k = 1; k < a.slices; ++k) s += p[(size_t)k * per];
+  float* dst = i < wk ? a.dW[item] + i : (a.db[item] ? a.db[item] + (i - wk) : nullptr);
+  if (dst) *dst = a.accumulate ? *dst + s : s;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// 16 x 64 tiles per wave once 16 x 16 tiles would be more waves than the chip has SIMDs twice over
+inline int pick_nt(int row_tiles, int cols) { return (int64_t)row_tiles * cdiv(cols, 16) > 2048 ? 4 : 1; }
+inline int slices_for(int B) { return B <= 512 ? 1 : (cdiv(B, 256) < 16 ? cdiv(B, 256) : 16); }
+
+}  // namespace
+
+extern "C" {
+
+size_t gymrl_lin_workspace_bytes(int B, int N, int K, int n_items) {
+  const int s = slices_for(B);
+  return s > 1 ? sizeof(float) * (size_t)n_items * s * ((size_t)N * K + N) : 0;
+}
+
+int gymrl_lin_fwd(const gymrl_lin_item* items, int n_items, int B, int K, int K1, int N, int ldx, int ldx2, int ldy,
+                  void* stream_) {
+  if (!items || n_items < 1 || n_items > kItems || B < 0 || K < 1 || N < 1 || K1 < 0 || K1 > K) return -22;
+  if (B == 0) return 0;
+  LinFwd a{};
+  bool vec = K1 == K && K % 4 == 0 && ldx % 4 == 0;
+  for (int i = 0; i < kItems; ++i) {
+    const gymrl_lin_item& it = items[i < n_items ? i : 0];
+    if (!it.x || !it.w || !it.y || (K1 < K && !it.x2) || it.act < GYMRL_ACT_NONE || it.act > GYMRL_ACT_CLAMP) return -22;
+    a.act[i] = it.act; a.lo[i] = it.lo; a.hi[i] = it.hi;
+    a.X[i] = it.x; a.X2[i] = K1 < K ? it.x2 : nullptr; a.W[i] = it.w; a.b[i] = it.b; a.Y[i] = it.y;
+    vec = vec && aligned16(it.x) && aligned16(it.w);
+  }
+  a.B = B; a.K = K; a.K1 = K1; a.N = N; a.ldx = ldx; a.ldx2 = ldx2; a.ldy = ldy;
+  const int row_tiles = cdiv(B, 16), nt = pick_nt(row_tiles, N);
+  a.col_groups = cdiv(N, 16 * nt);
+  const dim3 grid(cdiv(row_tiles * a.col_groups, kWavesPerBlock), n_items), block(64 * kWavesPerBlock);
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  if (nt == 4) {
+    if (vec) hipLaunchKernelGGL((lin_fwd_kernel<4, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((lin_fwd_kernel<4, false>), grid, block, 0, s, a);
+  } else {
+    if (vec) hipLaunchKernelGGL((lin_fwd_kernel<1, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((lin_fwd_kernel<1, false>), grid, block, 0, s, a);
+  }
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_lin_bwd_input(const gymrl_lin_item* items, int n_items, int B, int N, int K, int K1, int ldy, int lddx,
+                        int lddx2, int accumulate, int sum_items, void* stream_) {
+  if (!items || n_items < 1 || n_items > kItems || B < 0 || K < 1 || N < 1 || K1 < 0 || K1 > K) return -22;
+  if (B == 0) return 0;
+  LinBwdIn a{};
+  bool vec = N % 4 == 0 && ldy % 4 == 0;
+  for (int i = 0; i < kItems; ++i) {
+    const gymrl_lin_item& it = items[i < n_items ? i : 0];
+    if (!it.dy || !it.w || it.act < GYMRL_ACT_NONE || it.act > GYMRL_ACT_CLAMP || (it.act != GYMRL_ACT_NONE && !it.y) ||
+        (!it.dx && !it.dx2))
+      return -22;
+    a.act[i] = it.act; a.lo[i] = it.lo; a.hi[i] = it.hi;
+    a.dY[i] = it.dy; a.Y[i] = it.y; a.W[i] = it.w; a.dX[i] = it.dx; a.dX2[i] = it.dx2;
+    vec = vec && aligned16(it.dy) && (it.act == GYMRL_ACT_NONE || aligned16(it.y));
+  }
+  a.B = B; a.N = N; a.K = K; a.K1 = K1; a.ldy = ldy; a.lddx = lddx; a.lddx2 = lddx2;
+  a.accumulate = accumulate;
+  a.n_sum = sum_items ? n_items : 1;
+  const int row_tiles = cdiv(B, 16), nt = pick_nt(row_tiles, K);
+  a.col_groups = cdiv(K, 16 * nt);
+  const dim3 grid(cdiv(row_tiles * a.col_groups, kWavesPerBlock), sum_items ? 1 : n_items), block(64 * kWavesPerBlock);
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  if (nt == 4) {
+    if (vec) hipLaunchKernelGGL((lin_bwd_input_kernel<4, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((lin_bwd_input_kernel<4, false>), grid, block, 0, s, a);
+  } else {
+    if (vec) hipLaunchKernelGGL((lin_bwd_input_kernel<1, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((lin_bwd_input_kernel<1, false>), grid, block, 0, s, a);
+  }
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_lin_bwd_weight(const gymrl_lin_item* items, int n_items, int B, int N, int K, int K1, int ldy, int ldx,
+                         int ldx2, int accumulate, void* workspace, void* stream_) {
+  if (!items || n_items < 1 || n_items > kItems || B < 0 || K < 1 || N < 1 || K1 < 0 || K1 > K) return -22;
+  LinBwdW a{};
+  for (int i = 0; i < kItems; ++i) {
+    const gymrl_lin_item& it = items[i < n_items ? i : 0];
+    if (!it.dy || !it.x || !it.dw || it.act < GYMRL_ACT_NONE || it.act > GYMRL_ACT_CLAMP ||
+        (it.act != GYMRL_ACT_NONE && !it.y) || (K1 < K && !it.x2))
+      return -22;
+    a.act[i] = it.act; a.lo[i] = it.lo; a.hi[i] = it.hi;
+    a.dY[i] = it.dy; a.Y[i] = it.y; a.X[i] = it.x; a.X2[i] = K1 < K ? it.x2 : nullptr; a.dW[i] = it.dw; a.db[i] = it.db;
+  }
+  a.B = B; a.N = N; a.K = K; a.K1 = K1; a.ldy = ldy; a.ldx = ldx; a.ldx2 = ldx2;
+  a.accumulate = accumulate;
+  a.slices = slices_for(B);
+  a.rows_per_slice = cdiv(cdiv(B, a.slices), 16) * 16;
+  if (a.slices > 1 && !workspace) return -22;
+  a.partial = static_cast<float*>(workspace);
+  const int n_tiles = cdiv(N, 16);
+  const int nt = (int64_t)n_tiles * cdiv(K, 16) * a.slices > 4096 ? 4 : 1;
+  a.col_groups = cdiv(K, 16 * nt);
+  const dim3 grid(cdiv(n_tiles * a.col_groups, kWavesPerBlock), n_items, a.slices), block(64 * kWavesPerBlock);
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  if (nt == 4) hipLaunchKernelGGL((lin_bwd_weight_kernel<4>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((lin_bwd_weight_kernel<1>), grid, block, 0, s, a);
+  if (a.slices > 1) {
+    const size_t per = (size_t)N * K + N;
+    hipLaunchKernelGGL(lin_slice_reduce_kernel, dim3((unsigned)((per + 255) / 256), n_items), dim3(256), 0, s, a);
+  }
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

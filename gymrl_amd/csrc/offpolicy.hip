@@ -25,7 +25,8 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 inline int grid_for(int n) { int nb = cdiv(n, kBlock); return nb < 1 ? 1 : (nb > kMaxBlocks ? kMaxBlocks : nb); }
 
 template <int K>
-__device__ __forceinline__ void block_partials(double (&v)[K], double* __restrict__ partials) {
+__device__ __forceinline__ void block_partials(double (&v)[K], double* __restrict__ partials,
+                                               double* __restrict__ direct = nullptr) {
   __shared__ double sm[K][kBlock / 64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
@@ -38,7 +39,10 @@ __device__ __forceinline__ void block_partials(double (&v)[K], double* __restric
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < kBlock / 64; ++w) s += sm[threadIdx.x][w];
-    partials[(size_t)blockIdx.x * K + threadIdx.x] = s;
+    // a single-block launch adds to the destination itself (what finalize_kernel would do with its one partial,
+    // bit for bit) and the finalize launch is skipped
+    if (direct) direct[threadIdx.x] += s;
+    else partials[(size_t)blockIdx.x * K + threadIdx.x] = s;
   }
 }
 
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void dqn_td_kernel(
     const float* __restrict__ q, const float* __restrict__ qn_online, const float* __restrict__ qn_target,
     const int32_t* __restrict__ act, const float* __restrict__ rew, const float* __restrict__ flag,
     const float* __restrict__ w, int B, int A, float gamma_n, float* __restrict__ td_out,
-    float* __restrict__ dq_out, double* __restrict__ partials) {
+    float* __restrict__ dq_out, double* __restrict__ partials, double* __restrict__ direct) {
   double acc[1] = {0.0};
   const float invB = 1.0f / (float)B;
   for (int b = blockIdx.x * kBlock + threadIdx.x; b < B; b += gridDim.x * kBlock) {
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void dqn_td_kernel(
     for (int k = 0; k < A; ++k) dq_out[(size_t)b * A + k] = (k == a) ? (2.0f * td) * wb * invB : 0.0f;
     acc[0] += (double)((td * td) * wb);
   }
-  if (partials) block_partials<1>(acc, partials);
+  if (partials) block_partials<1>(acc, partials, direct);
 }
 
 // ------------------------------------------------------------------ A1 -------
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void sac_critic_kernel(const float* __restr
                                                             const float* __restrict__ q2,
                                                             const float* __restrict__ y, int B,
                                                             float* __restrict__ dq1, float* __restrict__ dq2,
-                                                            double* __restrict__ partials) {
+                                                            double* __restrict__ partials, double* __restrict__ direct) {
   double acc[1] = {0.0};
   const float invB = 1.0f / (float)B;
   for (int b = blockIdx.x * kBlock + threadIdx.x; b < B; b += gridDim.x * kBlock) {
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void sac_critic_kernel(const float* __restr
     dq1[b] = 2.0f * e1 * invB; dq2[b] = 2.0f * e2 * invB;
     acc[0] += (double)(e1 * e1) + (double)(e2 * e2);
   }
-  block_partials<1>(acc, partials);
+  block_partials<1>(acc, partials, direct);
 }
 
 __global__ __launch_bounds__(kBlock) void sac_actor_kernel(const float* __restrict__ logp,
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void sac_actor_kernel(const float* __restri
                                                            const double* __restrict__ log_alpha, int B,
                                                            float target_entropy, float* __restrict__ dlogp,
                                                            float* __restrict__ dq1, float* __restrict__ dq2,
-                                                           double* __restrict__ partials) {
+                                                           double* __restrict__ partials, double* __restrict__ direct) {
   double acc[2] = {0.0, 0.0};
   const float invB = 1.0f / (float)B;
   const float alpha = (float)exp(log_alpha[0]);
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void sac_actor_kernel(const float* __restri
     acc[0] += (double)(alpha * logp[b] - fminf(a, c));
     acc[1] += (double)(logp[b] + target_entropy);
   }
-  block_partials<2>(acc, partials);
+  block_partials<2>(acc, partials, direct);
 }
 
 __global__ void sac_alpha_step_kernel(double* __restrict__ log_alpha, double* __restrict__ m,
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(kBlock) void noisy_action_kernel(const float* __res
 
 // F.mse_loss(q, y) forward + backward for one critic (ddpg_pendulum.py:178-179): dq = 2 (q - y) / B.
 __global__ __launch_bounds__(kBlock) void mse_kernel(const float* __restrict__ q, const float* __restrict__ y, int B,
-                                                     float* __restrict__ dq, double* __restrict__ partials) {
+                                                     float* __restrict__ dq, double* __restrict__ partials, double* __restrict__ direct) {
   double acc[1] = {0.0};
   const float invB = 1.0f / (float)B;
   for (int b = blockIdx.x * kBlock + threadIdx.x; b < B; b += gridDim.x * kBlock) {
@@ -358,19 +362,19 @@ __global__ __launch_bounds__(kBlock) void mse_kernel(const float* __restrict__ q
     dq[b] = 2.0f * e * invB;
     acc[0] += (double)(e * e);
   }
-  block_partials<1>(acc, partials);
+  block_partials<1>(acc, partials, direct);
 }
 
 // actor loss -mean(Q(s, mu(s))) (ddpg_pendulum.py:185, td3_pendulum.py:213): dq = -1/B, sum = sum q.
 __global__ __launch_bounds__(kBlock) void neg_mean_kernel(const float* __restrict__ q, int B, float* __restrict__ dq,
-                                                          double* __restrict__ partials) {
+                                                          double* __restrict__ partials, double* __restrict__ direct) {
   double acc[1] = {0.0};
   const float g = -1.0f / (float)B;
   for (int b = blockIdx.x * kBlock + threadIdx.x; b < B; b += gridDim.x * kBlock) {
     dq[b] = g;
     acc[0] += (double)q[b];
   }
-  block_partials<1>(acc, partials);
+  block_partials<1>(acc, partials, direct);
 }
 
 // ------------------------------------------------------------ discrete SAC ---
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(kBlock) void dsac_target_kernel(const float* __rest
 __global__ __launch_bounds__(kBlock) void dsac_critic_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
                                                              const int32_t* __restrict__ act, const float* __restrict__ y, int B,
                                                              int A, float* __restrict__ dq1, float* __restrict__ dq2,
-                                                             double* __restrict__ partials) {
+                                                             double* __restrict__ partials, double* __restrict__ direct) {
   double acc[2] = {0.0, 0.0};
   const float invB = 1.0f / (float)B;
   for (int b = blockIdx.x * kBlock + threadIdx.x; b < B; b += gridDim.x * kBlock) {
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(kBlock) void dsac_critic_kernel(const float* __rest
     }
     acc[0] += (double)(e1 * e1); acc[1] += (double)(e2 * e2);
   }
-  block_partials<2>(acc, partials);
+  block_partials<2>(acc, partials, direct);
 }
 
 // :196-203  L = mean(-alpha H(p) - sum_a p(a) min(Q1, Q2)(a));  dL/dp_k = (alpha (log(p_k + 1e-8) + p_k/(p_k + 1e-8)) - m_k)/B
@@ -420,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void dsac_critic_kernel(const float* __rest
 __global__ __launch_bounds__(kBlock) void dsac_actor_kernel(const float* __restrict__ probs, const float* __restrict__ q1,
                                                             const float* __restrict__ q2, const float* __restrict__ log_alpha,
                                                             int B, int A, float* __restrict__ dprobs,
-                                                            double* __restrict__ partials) {
+                                                            double* __restrict__ partials, double* __restrict__ direct) {
   double acc[2] = {0.0, 0.0};
   const float invB = 1.0f / (float)B;
   const float alpha = det_expf(log_alpha[0]);
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void dsac_actor_kernel(const float* __restr
     acc[0] += (double)(-alpha * ent - minq);
     acc[1] += (double)ent;
   }
-  block_partials<2>(acc, partials);
+  block_partials<2>(acc, partials, direct);
 }
 
 // :209-215  L_alpha = mean(exp(log_alpha) (H - H_target).detach()); Adam on the float32 scalar.
@@ -497,8 +501,8 @@ int gymrl_dqn_td_loss(const float* q, const float* q_next_online, const float* q
   const int nb = grid_for(B);
   double* parts = loss_sum ? (double*)workspace : nullptr;
   hipLaunchKernelGGL(dqn_td_kernel, dim3(nb), dim3(kBlock), 0, stream, q, q_next_online, q_next_target, act,
-                     rew, flag, w, B, A, (float)gamma_n, td_out, dq_out, parts);
-  if (loss_sum) hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(kBlock), 0, stream, parts, nb, loss_sum);
+                     rew, flag, w, B, A, (float)gamma_n, td_out, dq_out, parts, (loss_sum && nb == 1) ? loss_sum : nullptr);
+  if (loss_sum && nb > 1) hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(kBlock), 0, stream, parts, nb, loss_sum);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
@@ -541,8 +545,9 @@ int gymrl_sac_critic_loss(const float* q1, const float* q2, const float* y, int 
   hipStream_t stream = (hipStream_t)stream_;
   const int nb = grid_for(B);
   hipLaunchKernelGGL(sac_critic_kernel, dim3(nb), dim3(kBlock), 0, stream, q1, q2, y, B, dq1_out, dq2_out,
-                     (double*)workspace);
-  hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(kBlock), 0, stream, (const double*)workspace, nb, sums);
+                     (double*)workspace, nb == 1 ? sums : nullptr);
+  if (nb > 1)
+    hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(kBlock), 0, stream, (const double*)workspace, nb, sums);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
@@ -555,9 +560,9 @@ int gymrl_sac_actor_loss(const float* logp, const float* q1, const float* q2, co
   hipStream_t stream = (hipStream_t)stream_;
   const int nb = grid_for(B);
   hipLaunchKernelGGL(sac_actor_kernel, dim3(nb), dim3(kBlock), 0, stream, logp, q1, q2, log_alpha, B,
-                     (float)target_entropy, dlogp_out, dq1_out, dq2_out, (double*)workspace);
-  hipLaunchKernelGGL(finalize_kernel<2>, dim3(1), dim3(kBlock), 0, stream, (const double*)workspace, nb,
-                     sums + 1);
+                     (float)target_entropy, dlogp_out, dq1_out, dq2_out, (double*)workspace, nb == 1 ? sums + 1 : nullptr);
+  if (nb > 1)
+    hipLaunchKernelGGL(finalize_kernel<2>, dim3(1), dim3(kBlock), 0, stream, (const double*)workspace, nb, sums + 1);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
@@ -610,8 +615,9 @@ int gymrl_mse_loss(const float* q, const float* y, int B, float* dq_out, double*
   if (!q || !y || !dq_out || !sum_out || !workspace || B <= 0) return -22;
   hipStream_t stream = (hipStream_t)stream_;
   const int nb = grid_for(B);
-  hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(kBlock), 0, stream, q, y, B, dq_out, (double*)workspace);
-  hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(kBlock), 0, stream, (const double*)workspace, nb, sum_out);
+  hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(kBlock), 0, stream, q, y, B, dq_out, (double*)workspace, nb == 1 ? sum_out : nullptr);
+  if (nb > 1)
+    hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(kBlock), 0, stream, (const double*)workspace, nb, sum_out);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
@@ -620,8 +626,9 @@ int gymrl_neg_mean_loss(const float* q, int B, float* dq_out, double* sum_out, v
   if (!q || !dq_out || !sum_out || !workspace || B <= 0) return -22;
   hipStream_t stream = (hipStream_t)stream_;
   const int nb = grid_for(B);
-  hipLaunchKernelGGL(neg_mean_kernel, dim3(nb), dim3(kBlock), 0, stream, q, B, dq_out, (double*)workspace);
-  hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(kBlock), 0, stream, (const double*)workspace, nb, sum_out);
+  hipLaunchKernelGGL(neg_mean_kernel, dim3(nb), dim3(kBlock), 0, stream, q, B, dq_out, (double*)workspace, nb == 1 ? sum_out : nullptr);
+  if (nb > 1)
+    hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(kBlock), 0, stream, (const double*)workspace, nb, sum_out);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
@@ -641,8 +648,9 @@ int gymrl_dsac_critic_loss(const float* q1, const float* q2, const int32_t* act,
   hipStream_t stream = (hipStream_t)stream_;
   const int nb = grid_for(B);
   hipLaunchKernelGGL(dsac_critic_kernel, dim3(nb), dim3(kBlock), 0, stream, q1, q2, act, y, B, A, dq1_out, dq2_out,
-                     (double*)workspace);
-  hipLaunchKernelGGL(finalize_kernel<2>, dim3(1), dim3(kBlock), 0, stream, (const double*)workspace, nb, sums);
+                     (double*)workspace, nb == 1 ? sums : nullptr);
+  if (nb > 1)
+    hipLaunchKernelGGL(finalize_kernel<2>, dim3(1), dim3(kBlock), 0, stream, (const double*)workspace, nb, sums);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
@@ -653,8 +661,9 @@ int gymrl_dsac_actor_loss(const float* probs, const float* q1, const float* q2, 
   hipStream_t stream = (hipStream_t)stream_;
   const int nb = grid_for(B);
   hipLaunchKernelGGL(dsac_actor_kernel, dim3(nb), dim3(kBlock), 0, stream, probs, q1, q2, log_alpha, B, A, dprobs_out,
-                     (double*)workspace);
-  hipLaunchKernelGGL(finalize_kernel<2>, dim3(1), dim3(kBlock), 0, stream, (const double*)workspace, nb, sums);
+                     (double*)workspace, nb == 1 ? sums : nullptr);
+  if (nb > 1)
+    hipLaunchKernelGGL(finalize_kernel<2>, dim3(1), dim3(kBlock), 0, stream, (const double*)workspace, nb, sums);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

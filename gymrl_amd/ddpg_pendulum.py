@@ -7,10 +7,9 @@ is `gymrl_sac_target` fed the one target Q twice with a zero log-prob term.
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
-from .nn import SmallLinear
+from .nn import SmallLinear, frozen_parameters
 from .td3_pendulum import Actor, _ActorCriticBase  # noqa: F401  (Actor is part of this module's surface)
 
 
@@ -37,13 +36,12 @@ class Config:
 class Critic(nn.Module):
     def __init__(self, state_dim, action_dim, hidden_dim):
         super().__init__()
-        self.fc1 = SmallLinear(state_dim + action_dim, hidden_dim)
-        self.fc2 = SmallLinear(hidden_dim, hidden_dim)
+        self.fc1 = SmallLinear(state_dim + action_dim, hidden_dim, act="relu")
+        self.fc2 = SmallLinear(hidden_dim, hidden_dim, act="relu")
         self.fc3 = SmallLinear(hidden_dim, 1)
 
     def forward(self, state, action):
-        x = torch.cat([state, action], dim=1)
-        return self.fc3(F.relu(self.fc2(F.relu(self.fc1(x)))))
+        return self.fc3(self.fc2(self.fc1(state, action)))       # cat([state, action]) happens inside the first launch
 
 
 class DDPGTrainer(_ActorCriticBase):
@@ -78,13 +76,17 @@ class DDPGTrainer(_ActorCriticBase):
         q = self.critic(states, actions)                               # :176-181
         self._sum_c.zero_()
         dq = ops.mse_loss(q.view(-1), y, self._sum_c)
-        self.critic_grads.zero_()
+        self._critic_sink.arm()                                        # critic_optimizer.zero_grad()
         torch.autograd.backward([q], [dq.view_as(q)])
+        self._critic_sink.collect()
         self.critic_optimizer.step(bias_dev=bc)
-        qa = self.critic(states, self.actor(states))                   # :183-187
+        with frozen_parameters(self.critic):                           # its gradients of this loss are never used
+            qa = self.critic(states, self.actor(states))               # :183-187
         self._sum_a.zero_()
         dqa = ops.neg_mean_loss(qa.view(-1), self._sum_a)
+        self._actor_sink.arm()
         torch.autograd.backward([qa], [dqa.view_as(qa)])
+        self._actor_sink.collect()
         self.actor_optimizer.step(bias_dev=ba)
         self.soft_update(self.actor_target_flat, self.actor_flat)      # :189-190
         self.soft_update(self.critic_target_flat, self.critic_flat)

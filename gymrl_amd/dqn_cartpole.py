@@ -59,8 +59,8 @@ class QNetwork(nn.Module):
     def __init__(self, state_dim, action_dim, hidden_dim=256):
         super().__init__()
         self.net = nn.Sequential(
-            layer_init(SmallLinear(state_dim, hidden_dim)), nn.ReLU(),
-            layer_init(SmallLinear(hidden_dim, hidden_dim)), nn.ReLU(),
+            layer_init(SmallLinear(state_dim, hidden_dim, act="relu")), nn.Identity(),      # the ReLUs run inside the layers'
+            layer_init(SmallLinear(hidden_dim, hidden_dim, act="relu")), nn.Identity(),     # launches (csrc/lin.hip)
             layer_init(SmallLinear(hidden_dim, action_dim), std=0.01),
         )
 

@@ -48,26 +48,51 @@ class GradSink:
     def __init__(self, module):
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.views = [p.grad for p in self.params]
+        self.armed, self.add, self.written = False, False, {}
+        for i, p in enumerate(self.params):
+            p._gymrl_sink = (self, i)        # the fused layers (gymrl_amd/nn.py) write their gradients straight into the view
 
-    def arm(self):
+    def arm(self, add=False):
+        """add=True: this backward accumulates on top of the flat buffer (pass the same flag to collect())."""
         for p in self.params:
             p.grad = None
+        self.armed, self.add, self.written = True, add, {}
+
+    def direct(self, i):
+        """A fused layer's backward asks where parameter i's gradient goes: (view, accumulate).  The first write of a
+        backward overwrites (the buffer may hold anything), later ones — the layer used twice — accumulate."""
+        k = self.written.get(i, 0)
+        self.written[i] = k + 1
+        return self.views[i], bool(self.add or k)
+
+    def undo(self, i):
+        k = self.written.get(i, 0) - 1
+        if k > 0:
+            self.written[i] = k
+        else:
+            self.written.pop(i, None)
 
     def collect(self, add=False):
         """add=True accumulates into the flat buffer (gradient accumulation over micro-batches: the buffer was zeroed
         by the optimiser step) instead of overwriting it."""
-        got = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
+        got = [(v, p.grad, i) for i, (v, p) in enumerate(zip(self.views, self.params)) if p.grad is not None]
         if not add:
-            for v, p in zip(self.views, self.params):
-                if p.grad is None:
+            for i, (v, p) in enumerate(zip(self.views, self.params)):
+                if p.grad is None and i not in self.written:
                     v.zero_()
         if got:
-            (torch._foreach_add_ if add else torch._foreach_copy_)([v for v, _ in got], [g for _, g in got])
+            first = [(v, g) for v, g, i in got if not (add or i in self.written)]
+            more = [(v, g) for v, g, i in got if add or i in self.written]
+            if first:
+                torch._foreach_copy_([v for v, _ in first], [g for _, g in first])
+            if more:
+                torch._foreach_add_([v for v, _ in more], [g for _, g in more])
         self.drop()
 
     def drop(self):
         for v, p in zip(self.views, self.params):
             p.grad = v
+        self.armed, self.written = False, {}
 
 
 class FusedAdam:

@@ -56,11 +56,161 @@ def small_linear(x, weight, bias):
     return F.linear(x, weight, bias)
 
 
-class SmallLinear(nn.Linear):
-    """nn.Linear (same parameters, same state_dict keys) with `small_linear` as its forward."""
+FUSED_LINEAR = True    # tools/micro_offpolicy.py flips this for its A/B (False: library GEMM + elementwise launches)
+_FUSED_MAX_ROWS = 16384
 
-    def forward(self, x):
-        return small_linear(x, self.weight, self.bias)
+
+class _FusedLinear(torch.autograd.Function):
+    """n Linear(+activation) layers of one shape as ONE launch per direction (csrc/lin.hip): forward
+    y_i = act_i(cat(x_i, x2_i) W_i^T + b_i); backward one launch for every input gradient and one for every weight +
+    bias gradient, the activation's derivative taken from the saved outputs inside those launches."""
+
+    @staticmethod
+    def forward(ctx, spec, *tensors):
+        from . import ops
+        n, has_x2, acts, los, his = spec
+        xs = list(tensors[:n])
+        x2s = list(tensors[n:2 * n]) if has_x2 else [None] * n
+        rest = tensors[(2 if has_x2 else 1) * n:]
+        ws, bs = list(rest[:n]), list(rest[n:2 * n])
+        # one input feeding every item (two heads on a trunk, the twin critics' first layers): its gradient is the sum
+        ctx.shared = n > 1 and all(x is xs[0] for x in xs) and all(x is x2s[0] for x in x2s)
+        x0 = xs[0].contiguous()
+        xs = [x0] * n if ctx.shared else [x.contiguous() for x in xs]
+        if has_x2:
+            x20 = x2s[0].contiguous()
+            x2s = [x20] * n if ctx.shared else [x.contiguous() for x in x2s]
+        ys = ops.lin_fwd(xs, ws, bs, list(acts), x2=x2s, lo=list(los), hi=list(his))
+        ctx.spec = spec
+        ctx.save_for_backward(*xs, *[x for x in x2s if x is not None], *ws, *ys)
+        ctx.has_bias = [b is not None for b in bs]
+        ctx.sinks = [(getattr(w, "_gymrl_sink", None), None if b is None else getattr(b, "_gymrl_sink", None))
+                     for w, b in zip(ws, bs)]
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        from . import ops
+        n, has_x2, acts, los, his = ctx.spec
+        saved = ctx.saved_tensors
+        xs = list(saved[:n])
+        x2s = list(saved[n:2 * n]) if has_x2 else [None] * n
+        o = (2 if has_x2 else 1) * n
+        ws, ys = list(saved[o:o + n]), list(saved[o + n:o + 2 * n])
+        dys = [torch.zeros_like(y) if d is None else d.contiguous() for d, y in zip(dys, ys)]
+        need = ctx.needs_input_grad[1:]
+        need_x, need_x2 = any(need[:n]), has_x2 and any(need[n:2 * n])
+        need_w = any(need[o:o + n])
+        dxs, dx2s = [None] * n, [None] * n
+        if need_x or need_x2:
+            got = ops.lin_bwd_input(dys, ys, ws, list(acts), K1=xs[0].shape[1], want=(need_x, need_x2),
+                                    lo=list(los), hi=list(his), sum_items=ctx.shared)
+            if ctx.shared:
+                dxs[0], dx2s[0] = got
+            else:
+                dxs, dx2s = got
+        dws, dbs = [None] * n, [None] * n
+        if need_w:
+            # straight into the flat gradient buffer where the parameters' GradSink is armed (no fresh tensors, no
+            # gather launch afterwards); fresh tensors handed to autograd otherwise
+            slots = [GradSink_direct(sw, sb, hb) for (sw, sb), hb in zip(ctx.sinks, ctx.has_bias)]
+            if all(s is not None for s in slots) and len({s[2] for s in slots}) == 1:
+                ops.lin_bwd_weight(dys, ys, xs, [s[0] for s in slots], [s[1] for s in slots], list(acts), x2=x2s,
+                                   lo=list(los), hi=list(his), accumulate=slots[0][2])
+            else:
+                for s, (sw, sb) in zip(slots, ctx.sinks):
+                    if s is not None:
+                        GradSink_undo(sw, sb)
+                dws = [torch.empty_like(w) for w in ws]
+                dbs = [torch.empty(w.shape[0], dtype=w.dtype, device=w.device) if hb else None
+                       for w, hb in zip(ws, ctx.has_bias)]
+                ops.lin_bwd_weight(dys, ys, xs, dws, dbs, list(acts), x2=x2s, lo=list(los), hi=list(his))
+        return (None, *dxs, *(dx2s if has_x2 else ()), *dws, *dbs)
+
+
+def GradSink_direct(sw, sb, has_bias):
+    """(weight view, bias view | None, accumulate) of a layer whose parameters belong to an armed GradSink
+    (gymrl_amd/flat.py), else None."""
+    if sw is None or (has_bias and sb is None) or not sw[0].armed or (has_bias and sb[0] is not sw[0]):
+        return None
+    sink = sw[0]
+    vw, aw = sink.direct(sw[1])
+    if not has_bias:
+        return vw, None, aw
+    vb, ab = sink.direct(sb[1])
+    if ab != aw:
+        sink.undo(sw[1]), sink.undo(sb[1])
+        return None
+    return vw, vb, aw
+
+
+def GradSink_undo(sw, sb):
+    sw[0].undo(sw[1])
+    if sb is not None:
+        sb[0].undo(sb[1])
+
+
+def _fusable(x, weight):
+    return (FUSED_LINEAR and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and 0 < x.shape[0] <= _FUSED_MAX_ROWS)
+
+
+def _act_torch(z, act, clamp):
+    if act == "relu":
+        return F.relu(z)
+    if act == "tanh":
+        return torch.tanh(z)
+    if act == "clamp":
+        return z.clamp(clamp[0], clamp[1])
+    return z
+
+
+def fused_linears(layers, xs, x2s=None):
+    """[layer_i(cat(x_i, x2_i))] for `SmallLinear` layers of one shape in one launch per direction — the twin Q
+    networks' parallel layers, two heads on one trunk (pass the same x twice).  x2s: second input blocks (the critic's
+    action columns) so that torch.cat never materialises."""
+    from .ops import LIN_ACT
+    n = len(layers)
+    if not _fusable(xs[0], layers[0].weight):
+        outs = []
+        for i, (layer, x) in enumerate(zip(layers, xs)):
+            xin = x if x2s is None else torch.cat([x, x2s[i]], dim=1)
+            outs.append(_act_torch(small_linear(xin, layer.weight, layer.bias), layer.act, layer.clamp))
+        return outs
+    spec = (n, x2s is not None, tuple(LIN_ACT[l.act] for l in layers), tuple(float(l.clamp[0]) for l in layers),
+            tuple(float(l.clamp[1]) for l in layers))
+    args = list(xs) + (list(x2s) if x2s is not None else []) + [l.weight for l in layers] + [l.bias for l in layers]
+    return list(_FusedLinear.apply(spec, *args))
+
+
+class SmallLinear(nn.Linear):
+    """nn.Linear (same parameters, same state_dict keys) for the 64-8192 row batches of the off-policy networks, with
+    an optional fused activation: act in (None, "relu", "tanh", "clamp"); clamp = (lo, hi).  On the GPU the layer is one
+    launch per direction (`_FusedLinear`, csrc/lin.hip); `FUSED_LINEAR = False` (the A/B in tools/micro_offpolicy.py) and
+    CPU tensors (module construction, state_dict round trips) take the library path `small_linear` + activation."""
+
+    def __init__(self, in_features, out_features, bias=True, act=None, clamp=(0.0, 0.0)):
+        super().__init__(in_features, out_features, bias=bias)
+        self.act, self.clamp = act, clamp
+
+    def forward(self, x, x2=None):
+        return fused_linears([self], [x], None if x2 is None else [x2])[0]
+
+
+class frozen_parameters:
+    """Context: the module's parameters do not require gradients inside (the critic during SAC's / TD3's actor step:
+    sac_pendulum.py:248-255 computes and then discards them; here the weight-gradient launches are never issued)."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+
+    def __enter__(self):
+        for p in self.params:
+            p.requires_grad_(False)
+
+    def __exit__(self, *exc):
+        for p in self.params:
+            p.requires_grad_(True)
 
 
 class FusedMLP:

@@ -807,3 +807,143 @@ def rollout_lunar(env_state, n_envs, seed, env_id0, counter0, obs, act, logp, va
     a.wg_ticks = _ptr(wg_ticks, torch.int64, True).value
     a.T, a.t0, a.nsteps = T, t0, nsteps
     check(lib().gymrl_rollout_lunar(C.byref(a), C.byref(policy_desc), _stream()), "gymrl_rollout_lunar")
+
+
+# ------------------------------------------------ low-latency Linear layers --
+LIN_ACT = {None: 0, "none": 0, "tanh": 1, "relu": 2, "clamp": 3}
+LIN_MAX_ITEMS = 4
+
+
+def _rows(t, allow_none=False):
+    """(pointer, row stride) of a 2-D f32 device tensor whose rows are contiguous (column slices are fine)."""
+    if t is None:
+        if allow_none:
+            return None, 0
+        raise ValueError("tensor required")
+    if not t.is_cuda:
+        raise RuntimeError("gymrl_amd ops run on the MI355X only: got a CPU tensor (there is no CPU fallback)")
+    if t.dtype != torch.float32 or t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError("expected a 2-D float32 tensor with contiguous rows")
+    return t.data_ptr(), (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
+
+
+def _as_items(v, n):
+    if isinstance(v, (list, tuple)):
+        if len(v) != n:
+            raise ValueError("every per-item argument needs the same number of items")
+        return list(v)
+    return [v] * n
+
+
+def _lin_pack(n, **cols):
+    """Build the gymrl_lin_item array; cols: field -> list of (ptr | None).  Returns the ctypes array."""
+    from ._lib import LinItem
+    arr = (LinItem * n)()
+    for f, vals in cols.items():
+        for i, v in enumerate(vals):
+            setattr(arr[i], f, v)
+    return arr
+
+
+def _same(vals, what):
+    if any(v != vals[0] for v in vals):
+        raise ValueError(f"items of one launch must share {what}")
+    return vals[0]
+
+
+def lin_workspace(B, N, K, n_items, device):
+    n = lib().gymrl_lin_workspace_bytes(C.c_int(B), C.c_int(N), C.c_int(K), C.c_int(n_items))
+    return torch.empty(max(n // 4, 1), dtype=torch.float32, device=device) if n else None
+
+
+def lin_fwd(x, w, b, act=0, x2=None, out=None, lo=0.0, hi=0.0):
+    """gymrl_lin_fwd: y = act(cat(x, x2) w^T + b) in one launch.  Every tensor argument may be a list (<= 4 layers of one
+    shape in the same launch: twin critics, two heads on one input); returns y or the list of ys."""
+    multi = isinstance(w, (list, tuple))
+    n = len(w) if multi else 1
+    xs, x2s, ws, bs = _as_items(x, n), _as_items(x2, n), _as_items(w, n), _as_items(b, n)
+    B = xs[0].shape[0]
+    N, K = ws[0].shape
+    K1 = xs[0].shape[1]
+    outs = _as_items(out, n) if out is not None else [torch.empty(B, N, dtype=torch.float32, device=xs[0].device)
+                                                      for _ in range(n)]
+    px, ldx = zip(*(_rows(t) for t in xs))
+    px2, ldx2 = zip(*(_rows(t, True) for t in x2s))
+    py, ldy = zip(*(_rows(t) for t in outs))
+    for wt, xt, x2t in zip(ws, xs, x2s):
+        if tuple(wt.shape) != (N, K) or xt.shape != (B, K1) or K1 + (0 if x2t is None else x2t.shape[1]) != K:
+            raise ValueError("lin_fwd: shape mismatch between the items of one launch")
+    items = _lin_pack(n, x=px, x2=px2, w=[_ptr(t, torch.float32).value for t in ws],
+                      b=[None if t is None else _ptr(t, torch.float32).value for t in bs], y=py,
+                      act=_as_items(act, n), lo=_as_items(lo, n), hi=_as_items(hi, n))
+    check(lib().gymrl_lin_fwd(items, C.c_int(n), C.c_int(B), C.c_int(K), C.c_int(K1), C.c_int(N),
+                              C.c_int(_same(ldx, "a row stride")), C.c_int(_same(ldx2, "a row stride")),
+                              C.c_int(_same(ldy, "a row stride")), _stream()), "gymrl_lin_fwd")
+    return outs if multi else outs[0]
+
+
+def lin_bwd_input(dy, y, w, act=0, K1=None, dx=None, dx2=None, want=(True, True), lo=0.0, hi=0.0, accumulate=False,
+                  sum_items=False):
+    """gymrl_lin_bwd_input: (dx | dx2) = (dy * act'(y)) w.  K1 = columns of the first input block (None: all of K);
+    want = which of the two blocks to compute.  Lists batch up to 4 layers; sum_items: the layers share their input and
+    ONE gradient (the sum) is returned.  Returns (dx, dx2) (None where skipped)."""
+    multi = isinstance(w, (list, tuple))
+    n = len(w) if multi else 1
+    dys, ys, ws = _as_items(dy, n), _as_items(y, n), _as_items(w, n)
+    B, N = dys[0].shape
+    K = ws[0].shape[1]
+    K1 = K if K1 is None else K1
+    dev = dys[0].device
+    want1, want2 = want[0] and K1 > 0, want[1] and K1 < K
+    n_out = 1 if sum_items else n
+    dxs = _as_items(dx, n) if dx is not None else [torch.empty(B, K1, dtype=torch.float32, device=dev)
+                                                   if want1 and i < n_out else None for i in range(n)]
+    dx2s = _as_items(dx2, n) if dx2 is not None else [torch.empty(B, K - K1, dtype=torch.float32, device=dev)
+                                                      if want2 and i < n_out else None for i in range(n)]
+    if sum_items:                       # the C side reads item 0's destinations only; keep the strides uniform
+        dxs, dx2s = [dxs[0]] * n, [dx2s[0]] * n
+    pdy, ldy = zip(*(_rows(t) for t in dys))
+    acts = _as_items(act, n)
+    py, ldyy = zip(*(_rows(t, a == 0) for t, a in zip(ys, acts)))
+    if any(a != 0 and l1 != l2 for a, l1, l2 in zip(acts, ldyy, ldy)):
+        raise ValueError("lin_bwd_input: dy and y need the same row stride")
+    pdx, lddx = zip(*(_rows(t, True) for t in dxs))
+    pdx2, lddx2 = zip(*(_rows(t, True) for t in dx2s))
+    items = _lin_pack(n, dy=pdy, y=py, w=[_ptr(t, torch.float32).value for t in ws], dx=pdx, dx2=pdx2,
+                      act=acts, lo=_as_items(lo, n), hi=_as_items(hi, n))
+    check(lib().gymrl_lin_bwd_input(items, C.c_int(n), C.c_int(B), C.c_int(N), C.c_int(K), C.c_int(K1),
+                                    C.c_int(_same(ldy, "a row stride")), C.c_int(_same(lddx, "a row stride")),
+                                    C.c_int(_same(lddx2, "a row stride")), C.c_int(int(accumulate)),
+                                    C.c_int(int(sum_items)), _stream()), "gymrl_lin_bwd_input")
+    if sum_items:
+        return dxs[0], dx2s[0]
+    return (dxs, dx2s) if multi else (dxs[0], dx2s[0])
+
+
+def lin_bwd_weight(dy, y, x, dw, db=None, act=0, x2=None, lo=0.0, hi=0.0, accumulate=False, workspace=None):
+    """gymrl_lin_bwd_weight: dw (+)= (dy * act'(y))^T cat(x, x2), db (+)= its column sums, written straight into dw / db
+    (e.g. the views of a flat gradient buffer).  Lists batch up to 4 layers."""
+    multi = isinstance(dw, (list, tuple))
+    n = len(dw) if multi else 1
+    dys, ys, xs, x2s, dws, dbs = (_as_items(v, n) for v in (dy, y, x, x2, dw, db))
+    B, N = dys[0].shape
+    K1 = xs[0].shape[1]
+    K = dws[0].shape[1]
+    pdy, ldy = zip(*(_rows(t) for t in dys))
+    acts = _as_items(act, n)
+    py, ldyy = zip(*(_rows(t, a == 0) for t, a in zip(ys, acts)))
+    if any(a != 0 and l1 != l2 for a, l1, l2 in zip(acts, ldyy, ldy)):
+        raise ValueError("lin_bwd_weight: dy and y need the same row stride")
+    px, ldx = zip(*(_rows(t) for t in xs))
+    px2, ldx2 = zip(*(_rows(t, True) for t in x2s))
+    if workspace is None and B > 512:
+        workspace = lin_workspace(B, N, K, n, dys[0].device)
+    items = _lin_pack(n, dy=pdy, y=py, x=px, x2=px2, dw=[_ptr(t, torch.float32).value for t in dws],
+                      db=[None if t is None else _ptr(t, torch.float32).value for t in dbs],
+                      act=acts, lo=_as_items(lo, n), hi=_as_items(hi, n))
+    check(lib().gymrl_lin_bwd_weight(items, C.c_int(n), C.c_int(B), C.c_int(N), C.c_int(K), C.c_int(K1),
+                                     C.c_int(_same(ldy, "a row stride")), C.c_int(_same(ldx, "a row stride")),
+                                     C.c_int(_same(ldx2, "a row stride")), C.c_int(int(accumulate)),
+                                     _ptr(workspace, torch.float32, True), _stream()),
+          "gymrl_lin_bwd_weight")
+    return dw

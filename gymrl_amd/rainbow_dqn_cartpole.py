@@ -115,13 +115,13 @@ class NoisyLinear(nn.Module):
 class DuelingNoisyNetwork(nn.Module):
     def __init__(self, state_dim, action_dim, hidden_dim=256, seed=0):
         super().__init__()
-        self.fc1 = SmallLinear(state_dim, hidden_dim)
-        self.fc2 = SmallLinear(hidden_dim, hidden_dim)
+        self.fc1 = SmallLinear(state_dim, hidden_dim, act="relu")
+        self.fc2 = SmallLinear(hidden_dim, hidden_dim, act="relu")
         self.advantage = NoisyLinear(hidden_dim, action_dim, seed=seed)
         self.value = NoisyLinear(hidden_dim, 1, seed=seed + 1)
 
     def forward(self, x):
-        x = F.relu(self.fc2(F.relu(self.fc1(x))))
+        x = self.fc2(self.fc1(x))
         advantage, value = self.advantage(x), self.value(x)
         return value + (advantage - advantage.mean(dim=-1, keepdim=True))
 

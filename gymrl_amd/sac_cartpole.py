@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from . import ops
 from .dqn_cartpole import ReplayBuffer
 from .envs import EpisodeTracker, VecEnv
-from .flat import FusedAdam, flatten_module
+from .flat import FusedAdam, GradSink, flatten_module
 from .nn import SmallLinear
 
 
@@ -47,12 +47,12 @@ class Config:
 class Actor(nn.Module):
     def __init__(self, state_dim, action_dim, hidden_dim=256):
         super().__init__()
-        self.fc1 = SmallLinear(state_dim, hidden_dim)
-        self.fc2 = SmallLinear(hidden_dim, hidden_dim)
+        self.fc1 = SmallLinear(state_dim, hidden_dim, act="relu")
+        self.fc2 = SmallLinear(hidden_dim, hidden_dim, act="relu")
         self.fc3 = SmallLinear(hidden_dim, action_dim)
 
     def logits(self, x):
-        return self.fc3(F.relu(self.fc2(F.relu(self.fc1(x)))))
+        return self.fc3(self.fc2(self.fc1(x)))
 
     def forward(self, x):
         return F.softmax(self.logits(x), dim=-1)
@@ -61,12 +61,12 @@ class Actor(nn.Module):
 class Critic(nn.Module):
     def __init__(self, state_dim, action_dim, hidden_dim=256):
         super().__init__()
-        self.fc1 = SmallLinear(state_dim, hidden_dim)
-        self.fc2 = SmallLinear(hidden_dim, hidden_dim)
+        self.fc1 = SmallLinear(state_dim, hidden_dim, act="relu")
+        self.fc2 = SmallLinear(hidden_dim, hidden_dim, act="relu")
         self.fc3 = SmallLinear(hidden_dim, action_dim)
 
     def forward(self, x):
-        return self.fc3(F.relu(self.fc2(F.relu(self.fc1(x)))))
+        return self.fc3(self.fc2(self.fc1(x)))
 
 
 class SACTrainer:
@@ -91,6 +91,7 @@ class SACTrainer:
         self.c2_flat, self.c2_grads = flatten_module(self.critic2, self.device)
         self.c1_target_flat, _ = flatten_module(self.critic1_target, self.device)
         self.c2_target_flat, _ = flatten_module(self.critic2_target, self.device)
+        self._actor_sink, self._c1_sink, self._c2_sink = GradSink(self.actor), GradSink(self.critic1), GradSink(self.critic2)
         self.actor_optim = FusedAdam(self.actor_flat, self.actor_grads, lr=config.lr_actor)
         self.critic1_optim = FusedAdam(self.c1_flat, self.c1_grads, lr=config.lr_critic)
         self.critic2_optim = FusedAdam(self.c2_flat, self.c2_grads, lr=config.lr_critic)
@@ -147,9 +148,11 @@ class SACTrainer:
         q1, q2 = self.critic1(states), self.critic2(states)                    # :183-194
         self._sums_c.zero_()
         dq1, dq2 = ops.dsac_critic_loss(q1.detach(), q2.detach(), actions.view(-1).to(torch.int32), y, self._sums_c)
-        self.c1_grads.zero_()
-        self.c2_grads.zero_()
+        self._c1_sink.arm()
+        self._c2_sink.arm()
         torch.autograd.backward([q1, q2], [dq1, dq2])
+        self._c1_sink.collect()
+        self._c2_sink.collect()
         self.critic1_optim.step(bias_dev=bc1)
         self.critic2_optim.step(bias_dev=bc2)
         probs = self.actor(states)                                             # :196-207
@@ -157,7 +160,9 @@ class SACTrainer:
             q1n, q2n = self.critic1(states), self.critic2(states)              # the critics' gradients of this loss are discarded
         self._sums_a.zero_()
         dprobs = ops.dsac_actor_loss(probs.detach(), q1n, q2n, self.log_alpha, self._sums_a)
+        self._actor_sink.arm()
         torch.autograd.backward([probs], [dprobs])
+        self._actor_sink.collect()
         self.actor_optim.step(bias_dev=ba)
         if alpha_bias is None:                                                 # :209-215
             self._alpha_steps += 1

@@ -14,13 +14,12 @@ from collections import deque
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
 from .dqn_cartpole import ReplayBuffer as _Ring
 from .envs import EpisodeTracker, VecEnv
 from .flat import FusedAdam, GradSink, flatten_module
-from .nn import SmallLinear
+from .nn import SmallLinear, frozen_parameters, fused_linears
 
 
 class Config:
@@ -73,14 +72,15 @@ class Actor(nn.Module):
     def __init__(self, state_dim, action_dim, hidden_dim, action_bound, log_std_min, log_std_max):
         super().__init__()
         self.action_bound, self.log_std_min, self.log_std_max = action_bound, log_std_min, log_std_max
-        self.fc1 = SmallLinear(state_dim, hidden_dim)
-        self.fc2 = SmallLinear(hidden_dim, hidden_dim)
+        self.fc1 = SmallLinear(state_dim, hidden_dim, act="relu")
+        self.fc2 = SmallLinear(hidden_dim, hidden_dim, act="relu")
         self.mean = SmallLinear(hidden_dim, action_dim)
-        self.log_std = SmallLinear(hidden_dim, action_dim)
+        self.log_std = SmallLinear(hidden_dim, action_dim, act="clamp", clamp=(log_std_min, log_std_max))
 
     def forward(self, x):
-        x = F.relu(self.fc2(F.relu(self.fc1(x))))
-        return self.mean(x), self.log_std(x).clamp(self.log_std_min, self.log_std_max)
+        x = self.fc2(self.fc1(x))                                   # Linear + ReLU per launch (csrc/lin.hip)
+        mean, log_std = fused_linears([self.mean, self.log_std], [x, x])      # both heads (log_std clamped) in one launch
+        return mean, log_std
 
     def sample(self, state, eps=None):
         """:76-87 -> (action [B, A], log_prob [B, 1]).  eps: explicit N(0,1) draws (parity mode)."""
@@ -104,17 +104,18 @@ class Critic(nn.Module):
 
     def __init__(self, state_dim, action_dim, hidden_dim):
         super().__init__()
-        self.fc1 = SmallLinear(state_dim + action_dim, hidden_dim)
-        self.fc2 = SmallLinear(hidden_dim, hidden_dim)
+        self.fc1 = SmallLinear(state_dim + action_dim, hidden_dim, act="relu")
+        self.fc2 = SmallLinear(hidden_dim, hidden_dim, act="relu")
         self.fc3 = SmallLinear(hidden_dim, 1)
-        self.fc4 = SmallLinear(state_dim + action_dim, hidden_dim)
-        self.fc5 = SmallLinear(hidden_dim, hidden_dim)
+        self.fc4 = SmallLinear(state_dim + action_dim, hidden_dim, act="relu")
+        self.fc5 = SmallLinear(hidden_dim, hidden_dim, act="relu")
         self.fc6 = SmallLinear(hidden_dim, 1)
 
     def forward(self, state, action):
-        x = torch.cat([state, action], dim=1)
-        q1 = self.fc3(F.relu(self.fc2(F.relu(self.fc1(x)))))
-        q2 = self.fc6(F.relu(self.fc5(F.relu(self.fc4(x)))))
+        """Both Q networks layer by layer, the twins sharing each launch; cat([state, action]) is never materialised."""
+        h1, h4 = fused_linears([self.fc1, self.fc4], [state, state], [action, action])
+        h2, h5 = fused_linears([self.fc2, self.fc5], [h1, h4])
+        q1, q2 = fused_linears([self.fc3, self.fc6], [h2, h5])
         return q1, q2
 
 
@@ -198,6 +199,8 @@ class SACTrainer:
         states, actions, rewards, next_states, dones = self.memory.gather(indices)
         B = states.shape[0]
         self._sums.zero_()
+        if eps_next is None and eps_cur is None:                               # both N(0,1) draws of the update in one launch
+            eps_next, eps_cur = torch.randn(2, B, actions.shape[1], device=self.device)
         with torch.no_grad():                                                  # :233-237
             next_actions, next_logp = self.actor.sample(next_states, eps_next)
             tq1, tq2 = self.critic_target(next_states, next_actions)
@@ -211,14 +214,13 @@ class SACTrainer:
         self.critic_optimizer.step(bias_dev=None if bias is None else bias[0])
 
         new_actions, logp = self.actor.sample(states, eps_cur)                 # :248-255
-        q1, q2 = self.critic(states, new_actions)
+        with frozen_parameters(self.critic):                                   # its share of this backward is never computed
+            q1, q2 = self.critic(states, new_actions)
         dlogp, dq1, dq2 = ops.sac_actor_loss(logp.view(-1).contiguous(), q1.view(-1), q2.view(-1), self.log_alpha,
                                              self.target_entropy, self._sums)
         self._actor_sink.arm()
-        self._critic_sink.arm()                                                # the critic's share of this backward is discarded
         torch.autograd.backward([q1, q2, logp], [dq1.view_as(q1), dq2.view_as(q2), dlogp.view_as(logp)])
         self._actor_sink.collect()
-        self._critic_sink.drop()
         self.actor_optimizer.step(bias_dev=None if bias is None else bias[1])
 
         if bias is None:                                                       # :257-263

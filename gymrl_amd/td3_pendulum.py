@@ -14,12 +14,11 @@ from collections import deque
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
 from .envs import EpisodeTracker, VecEnv
-from .flat import FusedAdam, flatten_module
-from .nn import SmallLinear
+from .flat import FusedAdam, GradSink, flatten_module
+from .nn import SmallLinear, frozen_parameters, fused_linears
 from .sac_pendulum import ReplayBuffer
 
 
@@ -50,34 +49,33 @@ class Actor(nn.Module):
     def __init__(self, state_dim, action_dim, hidden_dim, action_bound):
         super().__init__()
         self.action_bound = action_bound
-        self.fc1 = SmallLinear(state_dim, hidden_dim)
-        self.fc2 = SmallLinear(hidden_dim, hidden_dim)
-        self.fc3 = SmallLinear(hidden_dim, action_dim)
+        self.fc1 = SmallLinear(state_dim, hidden_dim, act="relu")
+        self.fc2 = SmallLinear(hidden_dim, hidden_dim, act="relu")
+        self.fc3 = SmallLinear(hidden_dim, action_dim, act="tanh")
 
     def forward(self, x):
-        x = F.relu(self.fc2(F.relu(self.fc1(x))))
-        return torch.tanh(self.fc3(x)) * self.action_bound
+        return self.fc3(self.fc2(self.fc1(x))) * self.action_bound
 
 
 class Critic(nn.Module):
     def __init__(self, state_dim, action_dim, hidden_dim):
         super().__init__()
-        self.fc1 = SmallLinear(state_dim + action_dim, hidden_dim)
-        self.fc2 = SmallLinear(hidden_dim, hidden_dim)
+        self.fc1 = SmallLinear(state_dim + action_dim, hidden_dim, act="relu")
+        self.fc2 = SmallLinear(hidden_dim, hidden_dim, act="relu")
         self.fc3 = SmallLinear(hidden_dim, 1)
-        self.fc4 = SmallLinear(state_dim + action_dim, hidden_dim)
-        self.fc5 = SmallLinear(hidden_dim, hidden_dim)
+        self.fc4 = SmallLinear(state_dim + action_dim, hidden_dim, act="relu")
+        self.fc5 = SmallLinear(hidden_dim, hidden_dim, act="relu")
         self.fc6 = SmallLinear(hidden_dim, 1)
 
     def forward(self, state, action):
-        x = torch.cat([state, action], dim=1)
-        q1 = self.fc3(F.relu(self.fc2(F.relu(self.fc1(x)))))
-        q2 = self.fc6(F.relu(self.fc5(F.relu(self.fc4(x)))))
+        """Both Q networks, the twins sharing each layer's launch; cat([state, action]) is never materialised."""
+        h1, h4 = fused_linears([self.fc1, self.fc4], [state, state], [action, action])
+        h2, h5 = fused_linears([self.fc2, self.fc5], [h1, h4])
+        q1, q2 = fused_linears([self.fc3, self.fc6], [h2, h5])
         return q1, q2
 
     def q1(self, state, action):
-        x = torch.cat([state, action], dim=1)
-        return self.fc3(F.relu(self.fc2(F.relu(self.fc1(x)))))
+        return self.fc3(self.fc2(self.fc1(state, action)))
 
 
 class _ActorCriticBase:
@@ -103,6 +101,7 @@ class _ActorCriticBase:
         self.critic_flat, self.critic_grads = flatten_module(self.critic, self.device)
         self.actor_target_flat, _ = flatten_module(self.actor_target, self.device)
         self.critic_target_flat, _ = flatten_module(self.critic_target, self.device)
+        self._actor_sink, self._critic_sink = GradSink(self.actor), GradSink(self.critic)
         self.actor_optimizer = FusedAdam(self.actor_flat, self.actor_grads, lr=config.lr_actor)
         self.critic_optimizer = FusedAdam(self.critic_flat, self.critic_grads, lr=config.lr_critic)
         self.memory = ReplayBuffer(config.memory_capacity, state_dim, action_dim, self.device, seed=self.base_seed)
@@ -222,15 +221,19 @@ class TD3Trainer(_ActorCriticBase):
         q1, q2 = self.critic(states, actions)                          # :201-208
         self._sum_c.zero_()
         dq1, dq2 = ops.sac_critic_loss(q1.view(-1), q2.view(-1), y, self._sum_c)
-        self.critic_grads.zero_()
+        self._critic_sink.arm()                                        # critic_optimizer.zero_grad()
         torch.autograd.backward([q1, q2], [dq1.view_as(q1), dq2.view_as(q2)])
+        self._critic_sink.collect()
         self.critic_optimizer.step()
         actor_loss = 0.0
         if self.total_updates % cfg.policy_freq == 0:                  # :210-224
-            q = self.critic.q1(states, self.actor(states))
+            with frozen_parameters(self.critic):                       # its gradients of this loss are never used (:218 zero_grad)
+                q = self.critic.q1(states, self.actor(states))
             self._sum_a.zero_()
             dq = ops.neg_mean_loss(q.view(-1), self._sum_a)
+            self._actor_sink.arm()
             torch.autograd.backward([q], [dq.view_as(q)])
+            self._actor_sink.collect()
             self.actor_optimizer.step()
             self.soft_update(self.actor_target_flat, self.actor_flat)
             self.soft_update(self.critic_target_flat, self.critic_flat)

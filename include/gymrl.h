@@ -376,7 +376,7 @@ int gymrl_soft_update(float* target, const float* source, int64_t n, double tau,
 #define GYMRL_MLP_MAX_STAGES 8
 #define GYMRL_MLP_MAX_WIDTH 256
 #define GYMRL_MLP_MAX_INPUT 64
-enum { GYMRL_ACT_NONE = 0, GYMRL_ACT_TANH = 1, GYMRL_ACT_RELU = 2 };
+enum { GYMRL_ACT_NONE = 0, GYMRL_ACT_TANH = 1, GYMRL_ACT_RELU = 2, GYMRL_ACT_CLAMP = 3 /* gymrl_lin_* only */ };
 typedef struct {
   const float* W;
   const float* b;
@@ -430,6 +430,56 @@ typedef struct {
   int T, t0, nsteps;
 } gymrl_rollout_lunar_args;
 int gymrl_rollout_lunar(const gymrl_rollout_lunar_args* args, const gymrl_mlp_desc* policy, void* stream);
+
+/* ================================================ low-latency Linear layers == */
+/*
+ * D2 / A2 / T1 update path and the vectorised acting forward of the off-policy trainers: every
+ * nn.Linear (+ ReLU / Tanh / clamp) of QNetwork dqn_cartpole.py:56-65, DuelingNoisyNetwork
+ * rainbow_dqn_cartpole.py:97-113, Actor / Critic sac_pendulum.py:49-125, td3_pendulum.py:49-83,
+ * ddpg_pendulum.py:37-48, sac_cartpole.py:47-70 — forward as called in update() / select_action(), and the
+ * backward loss.backward() runs through it.  The reference issues a GEMM, a bias add, an activation, and in
+ * backward an activation-gradient, two GEMMs and a bias reduction per layer; here a layer is ONE launch per
+ * direction (csrc/lin.hip: one wavefront per 16-row output tile, v_mfma_f32_16x16x4_f32, operands from L2),
+ * for batches up to a few thousand rows.  Up to GYMRL_LIN_MAX_ITEMS layers of one shape share a launch
+ * (twin critics, mean / log_std heads, online + target network); the activation is per item.
+ *
+ *   fwd         y  = act(cat(x, x2) w^T + b)       x [B, K1] (row stride ldx), x2 [B, K - K1] (ldx2; K1 == K: unused),
+ *                                                  w [N, K] row-major = nn.Linear.weight, b [N] or NULL, y [B, N] (ldy)
+ *   bwd_input   (dx | dx2) (+)= (dy * act'(y)) w   dy, y [B, N] (ldy); dx [B, K1] (lddx), dx2 [B, K - K1] (lddx2);
+ *                                                  a NULL dx / dx2 skips that part (at least one is required);
+ *                                                  sum_items != 0: ONE result, the sum over the items (layers fed by the
+ *                                                  same input), written to item 0's dx / dx2
+ *   bwd_weight  dw (+)= (dy * act'(y))^T cat(x, x2),  db (+)= column sums of dy * act'(y)   (db NULL: skipped)
+ *
+ * act' is taken from the saved OUTPUT y: ReLU y > 0; Tanh 1 - y^2 (tanh = 1 - 2/(exp(2z)+1) on the exp2/rcp
+ * units, as in gymrl_linear_fwd); clamp(lo, hi) lo < y < hi (torch passes the gradient AT the bounds as well — a
+ * measure-zero difference).  accumulate != 0 adds to the destination (torch's .grad +=).  Sums are f32 fma chains
+ * in the order given at the top of csrc/lin.hip; bwd_weight cuts B > 512 into <= 16 row slices whose partial
+ * results are added in slice order by a second launch (workspace: gymrl_lin_workspace_bytes, else NULL).
+ * Compared with torch float64 at 1e-5 relative (tests/test_lin_gpu.py), not bit for bit.
+ */
+#define GYMRL_LIN_MAX_ITEMS 4
+typedef struct {
+  const float* x;
+  const float* x2;
+  const float* w;
+  const float* b;
+  float* y;           /* fwd: output; bwd: the saved output (NULL allowed when act == GYMRL_ACT_NONE) */
+  const float* dy;
+  float* dx;
+  float* dx2;
+  float* dw;
+  float* db;
+  int act;            /* GYMRL_ACT_*; clamp bounds in lo / hi */
+  float lo, hi;
+} gymrl_lin_item;
+size_t gymrl_lin_workspace_bytes(int B, int N, int K, int n_items);
+int gymrl_lin_fwd(const gymrl_lin_item* items, int n_items, int B, int K, int K1, int N, int ldx, int ldx2, int ldy,
+                  void* stream);
+int gymrl_lin_bwd_input(const gymrl_lin_item* items, int n_items, int B, int N, int K, int K1, int ldy, int lddx,
+                        int lddx2, int accumulate, int sum_items, void* stream);
+int gymrl_lin_bwd_weight(const gymrl_lin_item* items, int n_items, int B, int N, int K, int K1, int ldy, int ldx,
+                         int ldx2, int accumulate, void* workspace, void* stream);
 
 /* ===================================================== MLP update path ===== */
 /*

@@ -29,22 +29,31 @@ def run(tr, steps, warm):
 
 from gymrl_amd import nn as gnn  # noqa: E402
 
-MODES = (("eager hipblaslt-default", False, "default", False), ("graph hipblaslt-default", True, "default", False),
-         ("graph rocblas", True, "rocblas", False), ("graph auto, bias fused in the GEMM", True, "auto", False), ("graph auto (default config)", True, "auto", False),
-         ("graph rocblas+tunableop", True, "rocblas", True))
+# name, hipGraph, GEMM library of the non-fused path, TunableOp, fused layers (csrc/lin.hip)
+MODES = (("eager, library GEMM + elementwise launches (round 1)", False, "auto", False, False),
+         ("graph, library GEMM + elementwise launches (round 1)", True, "auto", False, False),
+         ("eager, one launch per layer and direction", False, "auto", False, True),
+         ("graph, one launch per layer and direction (default config)", True, "auto", False, True))
+if os.environ.get("GYMRL_MICRO_ALL"):
+    MODES = (("eager hipblaslt-default", False, "default", False, False), ("graph hipblaslt-default", True, "default", False, False),
+             ("graph rocblas", True, "rocblas", False, False), ("graph rocblas+tunableop", True, "rocblas", True, False)) + MODES
 
 
 def main():
     out = {}
     torch.cuda.tunable.set_filename("/tmp/gymrl_tunable.csv")
-    for mod, cls, N, B in ((rainbow_dqn_cartpole, "RainbowDQNTrainer", 8192, 256), (rainbow_dqn_cartpole, "RainbowDQNTrainer", 8192, 8192),
-                           (sac_pendulum, "SACTrainer", 4096, 128), (sac_pendulum, "SACTrainer", 4096, 4096)):
+    cases = ((rainbow_dqn_cartpole, "RainbowDQNTrainer", 8192, 256), (rainbow_dqn_cartpole, "RainbowDQNTrainer", 8192, 8192),
+             (sac_pendulum, "SACTrainer", 4096, 128), (sac_pendulum, "SACTrainer", 4096, 4096))
+    only = os.environ.get("GYMRL_MICRO_ONLY")
+    for mod, cls, N, B in cases:
+        if only and only not in cls:
+            continue
         row = {}
-        for name, graphs, backend, tune in MODES:
+        for name, graphs, backend, tune, fused in MODES:
             c = mod.Config()
             c.num_envs, c.memory_capacity, c.max_episodes, c.batch_size = N, 1 << 20, 10**9, B
             c.use_graphs, c.gemm_backend, c.tune_gemms = graphs, backend, tune
-            gnn.SPLIT_BIAS = name in ("graph auto (default config)", "graph rocblas+tunableop")
+            gnn.SPLIT_BIAS, gnn.FUSED_LINEAR = True, fused
             tr = getattr(mod, cls)(c)
             steps = 300
             dt = run(tr, steps, 60)
