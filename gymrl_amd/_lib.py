@@ -44,6 +44,7 @@ SYMBOLS = [
     "gymrl_linear_bwd_weight_geometry", "gymrl_linear_bwd_weight",
     "gymrl_heads_loss_blocks", "gymrl_heads_loss_fwd_bwd",
     "gymrl_lin_workspace_bytes", "gymrl_lin_fwd", "gymrl_lin_bwd_input", "gymrl_lin_bwd_weight",
+    "gymrl_noisy_combine", "gymrl_noisy_split", "gymrl_dueling_bwd",
 ]
 
 
@@ -59,6 +60,12 @@ class LinItem(C.Structure):
     """gymrl_lin_item (include/gymrl.h)."""
     _fields_ = ([(n, C.c_void_p) for n in ("x", "x2", "w", "b", "y", "dy", "dx", "dx2", "dw", "db")] +
                 [("act", C.c_int), ("lo", C.c_float), ("hi", C.c_float)])
+
+
+class NoisyLayer(C.Structure):
+    """gymrl_noisy_layer (include/gymrl.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("w_mu", "w_sigma", "w_eps", "b_mu", "b_sigma", "b_eps", "w_eps_copy", "b_eps_copy",
+                                          "dw_mu", "dw_sigma", "db_mu", "db_sigma")] + [("n_out", C.c_int)])
 
 
 class PPOCfg(C.Structure):

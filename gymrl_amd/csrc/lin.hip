@@ -139,6 +139,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lin_fwd_kernel(const LinF
   }
   const float* __restrict__ bias = a.b[item];
   float* __restrict__ Y = a.Y[item];
+  if (act == GYMRL_ACT_DUELING) {
+    // columns 0..A-1 = advantage stream, column A = value stream (N = A + 1 <= 16: all in this wave's first tile):
+    // q = value + advantage - mean(advantage) (rainbow_dqn_cartpole.py:112), written as [B, A]
+    if (cg != 0) return;
+    const int A = a.N - 1;
+    const float bv = (bias && r < a.N) ? bias[r] : 0.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float z = acc[0][g] + bv;
+      float s = r < A ? z : 0.0f;
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+      const float v = __shfl(z, (lane & 48) | A, 64);
+      const int ro = rt * 16 + 4 * q + g;
+      if (r < A && ro < a.B) Y[(size_t)ro * a.ldy + r] = v + (z - s / (float)A);
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int n = nb + 16 * t + r;
@@ -362,6 +379,88 @@ __global__ __launch_bounds__(256) void lin_slice_reduce_kernel(const LinBwdW a) 
   if (dst) *dst = a.accumulate ? *dst + s : s;
 }
 
+// ---- NoisyLinear heads (rainbow_dqn_cartpole.py:60-95): effective weights and the gradients' way back -------------
+constexpr int kNoisyLayers = GYMRL_NOISY_MAX_LAYERS;
+struct NoisyArgs {
+  const float* w_mu[kNoisyLayers]; const float* w_sigma[kNoisyLayers]; const float* w_eps[kNoisyLayers];
+  const float* b_mu[kNoisyLayers]; const float* b_sigma[kNoisyLayers]; const float* b_eps[kNoisyLayers];
+  float* w_eps_copy[kNoisyLayers]; float* b_eps_copy[kNoisyLayers];
+  float* dw_mu[kNoisyLayers]; float* dw_sigma[kNoisyLayers]; float* db_mu[kNoisyLayers]; float* db_sigma[kNoisyLayers];
+  int row0[kNoisyLayers + 1];       // first stacked row of each layer
+  int n_layers, K, training, accumulate;
+  float* W; float* b;               // stacked [rows, K], [rows]
+  const float* dW; const float* db;
+};
+
+// W[row0 + n] = mu + sigma * eps (training) | mu (eval); the noise is also copied through to the module's buffers
+__global__ __launch_bounds__(256) void noisy_combine_kernel(const NoisyArgs a) {
+  const int rows = a.row0[a.n_layers];
+  const int64_t total = (int64_t)rows * (a.K + 1);
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int row = (int)(t / (a.K + 1)), k = (int)(t % (a.K + 1));
+    int l = 0;
+    while (l + 1 < a.n_layers && row >= a.row0[l + 1]) ++l;
+    const int n = row - a.row0[l];
+    if (k < a.K) {
+      const size_t o = (size_t)n * a.K + k;
+      float w = a.w_mu[l][o];
+      if (a.training) {
+        const float e = a.w_eps[l][o];
+        w = w + a.w_sigma[l][o] * e;
+        if (a.w_eps_copy[l]) a.w_eps_copy[l][o] = e;
+      }
+      a.W[(size_t)row * a.K + k] = w;
+    } else {
+      float bv = a.b_mu[l][n];
+      if (a.training) {
+        const float e = a.b_eps[l][n];
+        bv = bv + a.b_sigma[l][n] * e;
+        if (a.b_eps_copy[l]) a.b_eps_copy[l][n] = e;
+      }
+      a.b[row] = bv;
+    }
+  }
+}
+
+// d mu = dW, d sigma = dW * eps (and the biases alike), straight into the parameters' gradient views
+__global__ __launch_bounds__(256) void noisy_split_kernel(const NoisyArgs a) {
+  const int rows = a.row0[a.n_layers];
+  const int64_t total = (int64_t)rows * (a.K + 1);
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int row = (int)(t / (a.K + 1)), k = (int)(t % (a.K + 1));
+    int l = 0;
+    while (l + 1 < a.n_layers && row >= a.row0[l + 1]) ++l;
+    const int n = row - a.row0[l];
+    if (k < a.K) {
+      const size_t o = (size_t)n * a.K + k;
+      const float g = a.dW[(size_t)row * a.K + k];
+      a.dw_mu[l][o] = a.accumulate ? a.dw_mu[l][o] + g : g;
+      if (a.dw_sigma[l]) {
+        const float gs = a.training ? g * a.w_eps[l][o] : 0.0f;
+        a.dw_sigma[l][o] = a.accumulate ? a.dw_sigma[l][o] + gs : gs;
+      }
+    } else {
+      const float g = a.db[row];
+      a.db_mu[l][n] = a.accumulate ? a.db_mu[l][n] + g : g;
+      if (a.db_sigma[l]) {
+        const float gs = a.training ? g * a.b_eps[l][n] : 0.0f;
+        a.db_sigma[l][n] = a.accumulate ? a.db_sigma[l][n] + gs : gs;
+      }
+    }
+  }
+}
+
+// backward of q = v + a - mean(a): dS[:, j < A] = dq_j - mean(dq), dS[:, A] = sum(dq)
+__global__ __launch_bounds__(256) void dueling_bwd_kernel(const float* __restrict__ dq, int B, int A, float* __restrict__ dS) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  float s = 0.0f;
+  for (int j = 0; j < A; ++j) s += dq[(size_t)b * A + j];
+  const float m = s / (float)A;
+  for (int j = 0; j < A; ++j) dS[(size_t)b * (A + 1) + j] = dq[(size_t)b * A + j] - m;
+  dS[(size_t)b * (A + 1) + A] = s;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // 16 x 64 tiles per wave once 16 x 16 tiles would be more waves than the chip has SIMDs twice over
@@ -385,7 +484,9 @@ int gymrl_lin_fwd(const gymrl_lin_item* items, int n_items, int B, int K, int K1
   bool vec = K1 == K && K % 4 == 0 && ldx % 4 == 0;
   for (int i = 0; i < kItems; ++i) {
     const gymrl_lin_item& it = items[i < n_items ? i : 0];
-    if (!it.x || !it.w || !it.y || (K1 < K && !it.x2) || it.act < GYMRL_ACT_NONE || it.act > GYMRL_ACT_CLAMP) return -22;
+    if (!it.x || !it.w || !it.y || (K1 < K && !it.x2) || it.act < GYMRL_ACT_NONE || it.act > GYMRL_ACT_DUELING ||
+        (it.act == GYMRL_ACT_DUELING && (N < 2 || N > 16)))
+      return -22;
     a.act[i] = it.act; a.lo[i] = it.lo; a.hi[i] = it.hi;
     a.X[i] = it.x; a.X2[i] = K1 < K ? it.x2 : nullptr; a.W[i] = it.w; a.b[i] = it.b; a.Y[i] = it.y;
     vec = vec && aligned16(it.x) && aligned16(it.w);
@@ -468,6 +569,61 @@ int gymrl_lin_bwd_weight(const gymrl_lin_item* items, int n_items, int B, int N,
     const size_t per = (size_t)N * K + N;
     hipLaunchKernelGGL(lin_slice_reduce_kernel, dim3((unsigned)((per + 255) / 256), n_items), dim3(256), 0, s, a);
   }
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+static int noisy_fill(NoisyArgs& a, const gymrl_noisy_layer* layers, int n_layers, int K, int training) {
+  if (!layers || n_layers < 1 || n_layers > kNoisyLayers || K < 1) return -22;
+  int rows = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    const gymrl_noisy_layer& L = layers[l];
+    if (!L.w_mu || !L.b_mu || L.n_out < 1 || (training && (!L.w_sigma || !L.b_sigma || !L.w_eps || !L.b_eps))) return -22;
+    a.w_mu[l] = L.w_mu; a.w_sigma[l] = L.w_sigma; a.w_eps[l] = L.w_eps;
+    a.b_mu[l] = L.b_mu; a.b_sigma[l] = L.b_sigma; a.b_eps[l] = L.b_eps;
+    a.w_eps_copy[l] = L.w_eps_copy; a.b_eps_copy[l] = L.b_eps_copy;
+    a.dw_mu[l] = L.dw_mu; a.dw_sigma[l] = L.dw_sigma; a.db_mu[l] = L.db_mu; a.db_sigma[l] = L.db_sigma;
+    a.row0[l] = rows;
+    rows += L.n_out;
+  }
+  a.row0[n_layers] = rows;
+  a.n_layers = n_layers; a.K = K; a.training = training;
+  return rows;
+}
+
+int gymrl_noisy_combine(const gymrl_noisy_layer* layers, int n_layers, int K, int training, float* W_out, float* b_out,
+                        void* stream_) {
+  NoisyArgs a{};
+  const int rows = noisy_fill(a, layers, n_layers, K, training);
+  if (rows < 0 || !W_out || !b_out) return -22;
+  a.W = W_out; a.b = b_out;
+  const int64_t total = (int64_t)rows * (K + 1);
+  hipLaunchKernelGGL(noisy_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), a);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_noisy_split(const gymrl_noisy_layer* layers, int n_layers, int K, int training, const float* dW, const float* db,
+                      int accumulate, void* stream_) {
+  NoisyArgs a{};
+  const int rows = noisy_fill(a, layers, n_layers, K, training);
+  if (rows < 0 || !dW || !db) return -22;
+  for (int l = 0; l < n_layers; ++l)
+    if (!layers[l].dw_mu || !layers[l].db_mu || (!layers[l].dw_sigma) != (!layers[l].db_sigma)) return -22;
+  a.dW = dW; a.db = db; a.accumulate = accumulate;
+  const int64_t total = (int64_t)rows * (K + 1);
+  hipLaunchKernelGGL(noisy_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), a);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_dueling_bwd(const float* dq, int B, int A, float* dS_out, void* stream_) {
+  if (!dq || !dS_out || B < 0 || A < 1) return -22;
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(dueling_bwd_kernel, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_), dq, B, A,
+                     dS_out);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

@@ -810,7 +810,7 @@ def rollout_lunar(env_state, n_envs, seed, env_id0, counter0, obs, act, logp, va
 
 
 # ------------------------------------------------ low-latency Linear layers --
-LIN_ACT = {None: 0, "none": 0, "tanh": 1, "relu": 2, "clamp": 3}
+LIN_ACT = {None: 0, "none": 0, "tanh": 1, "relu": 2, "clamp": 3, "dueling": 4}
 LIN_MAX_ITEMS = 4
 
 
@@ -865,8 +865,9 @@ def lin_fwd(x, w, b, act=0, x2=None, out=None, lo=0.0, hi=0.0):
     B = xs[0].shape[0]
     N, K = ws[0].shape
     K1 = xs[0].shape[1]
-    outs = _as_items(out, n) if out is not None else [torch.empty(B, N, dtype=torch.float32, device=xs[0].device)
-                                                      for _ in range(n)]
+    acts = _as_items(act, n)
+    outs = _as_items(out, n) if out is not None else [torch.empty(B, N - 1 if a == 4 else N, dtype=torch.float32,
+                                                                  device=xs[0].device) for a in acts]
     px, ldx = zip(*(_rows(t) for t in xs))
     px2, ldx2 = zip(*(_rows(t, True) for t in x2s))
     py, ldy = zip(*(_rows(t) for t in outs))
@@ -875,7 +876,7 @@ def lin_fwd(x, w, b, act=0, x2=None, out=None, lo=0.0, hi=0.0):
             raise ValueError("lin_fwd: shape mismatch between the items of one launch")
     items = _lin_pack(n, x=px, x2=px2, w=[_ptr(t, torch.float32).value for t in ws],
                       b=[None if t is None else _ptr(t, torch.float32).value for t in bs], y=py,
-                      act=_as_items(act, n), lo=_as_items(lo, n), hi=_as_items(hi, n))
+                      act=acts, lo=_as_items(lo, n), hi=_as_items(hi, n))
     check(lib().gymrl_lin_fwd(items, C.c_int(n), C.c_int(B), C.c_int(K), C.c_int(K1), C.c_int(N),
                               C.c_int(_same(ldx, "a row stride")), C.c_int(_same(ldx2, "a row stride")),
                               C.c_int(_same(ldy, "a row stride")), _stream()), "gymrl_lin_fwd")
@@ -947,3 +948,48 @@ def lin_bwd_weight(dy, y, x, dw, db=None, act=0, x2=None, lo=0.0, hi=0.0, accumu
                                      _ptr(workspace, torch.float32, True), _stream()),
           "gymrl_lin_bwd_weight")
     return dw
+
+
+def _noisy_layers(layers):
+    """layers: list of dicts with w_mu, w_sigma, w_eps, b_mu, b_sigma, b_eps (+ optional w_eps_copy, b_eps_copy, dw_mu,
+    dw_sigma, db_mu, db_sigma) tensors -> (ctypes array, K, total rows)."""
+    from ._lib import NoisyLayer
+    arr = (NoisyLayer * len(layers))()
+    K = layers[0]["w_mu"].shape[1]
+    rows = 0
+    for i, L in enumerate(layers):
+        if L["w_mu"].shape[1] != K:
+            raise ValueError("noisy layers of one launch share their input width")
+        for f, _ in NoisyLayer._fields_[:-1]:
+            t = L.get(f)
+            setattr(arr[i], f, None if t is None else _ptr(t, torch.float32).value)
+        arr[i].n_out = L["w_mu"].shape[0]
+        rows += L["w_mu"].shape[0]
+    return arr, K, rows
+
+
+def noisy_combine(layers, training=True):
+    """gymrl_noisy_combine: stacked effective parameters (W [rows, K], b [rows]) of NoisyLinear layers in one launch."""
+    arr, K, rows = _noisy_layers(layers)
+    dev = layers[0]["w_mu"].device
+    W, b = torch.empty(rows, K, dtype=torch.float32, device=dev), torch.empty(rows, dtype=torch.float32, device=dev)
+    check(lib().gymrl_noisy_combine(arr, C.c_int(len(layers)), C.c_int(K), C.c_int(int(training)), _ptr(W), _ptr(b), _stream()),
+          "gymrl_noisy_combine")
+    return W, b
+
+
+def noisy_split(layers, dW, db, training=True, accumulate=False):
+    """gymrl_noisy_split: the stacked gradient back to every layer's dw_mu / dw_sigma / db_mu / db_sigma tensors."""
+    arr, K, rows = _noisy_layers(layers)
+    if tuple(dW.shape) != (rows, K):
+        raise ValueError("noisy_split: stacked gradient shape mismatch")
+    check(lib().gymrl_noisy_split(arr, C.c_int(len(layers)), C.c_int(K), C.c_int(int(training)), _ptr(dW, torch.float32),
+                                  _ptr(db, torch.float32), C.c_int(int(accumulate)), _stream()), "gymrl_noisy_split")
+
+
+def dueling_bwd(dq):
+    """gymrl_dueling_bwd: dq [B, A] -> dS [B, A + 1] (advantage columns, then the value column)."""
+    B, A = dq.shape
+    dS = torch.empty(B, A + 1, dtype=torch.float32, device=dq.device)
+    check(lib().gymrl_dueling_bwd(_ptr(dq, torch.float32), C.c_int(B), C.c_int(A), _ptr(dS), _stream()), "gymrl_dueling_bwd")
+    return dS

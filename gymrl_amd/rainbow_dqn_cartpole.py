@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import nn as gnn
 from . import ops
 from .envs import EpisodeTracker, VecEnv
 from .flat import FusedAdam, GradSink, flatten_module
@@ -102,6 +103,17 @@ class NoisyLinear(nn.Module):
             ops.noisy_noise(self.in_features, self.out_features, self.weight_epsilon, self.bias_epsilon,
                             seed=self.seed, counter=NoisyLinear._counter)
 
+    def next_noise(self):
+        """The noise of the next training-mode forward WITHOUT touching the module's buffers where it already sits in a
+        staged tensor (hipGraph mode): -> (weight_eps, bias_eps, copy_through).  copy_through: the fused head's
+        combine launch also writes it into weight_epsilon / bias_epsilon, as reset_noise() would have."""
+        if self.staged is not None and self._staged_k < len(self.staged):
+            w_eps, b_eps = self.staged[self._staged_k]
+            self._staged_k += 1
+            return w_eps, b_eps, True
+        self.reset_noise()
+        return self.weight_epsilon, self.bias_epsilon, False
+
     def forward(self, x):
         if self.training:
             self.reset_noise()            # new noise on every training-mode forward (:90-91)
@@ -110,6 +122,69 @@ class NoisyLinear(nn.Module):
         else:
             weight, bias = self.weight_mu, self.bias_mu
         return small_linear(x, weight, bias)
+
+
+class _NoisyDuelingHead(torch.autograd.Function):
+    """advantage / value NoisyLinear streams + the dueling combination (:108-113) on the fused layer kernels
+    (csrc/lin.hip): forward = one launch building both layers' effective parameters (stacked [A + 1, K]) + one Linear
+    launch whose epilogue forms q = v + a - mean(a); backward = dq -> stacked dS, input gradient, weight gradient, and
+    one launch sending d mu = dW, d sigma = dW * eps of both layers into the flat gradient buffer.  The reference's
+    op-by-op version of the same is ~35 launches per training-mode forward + backward."""
+
+    @staticmethod
+    def forward(ctx, x, adv, val, *params):
+        training = adv.training
+        a_wmu, a_wsig, a_bmu, a_bsig, v_wmu, v_wsig, v_bmu, v_bsig = params
+        layers = [dict(w_mu=a_wmu, w_sigma=a_wsig, b_mu=a_bmu, b_sigma=a_bsig),
+                  dict(w_mu=v_wmu, w_sigma=v_wsig, b_mu=v_bmu, b_sigma=v_bsig)]
+        eps = []
+        if training:
+            for L, m in zip(layers, (adv, val)):
+                w_eps, b_eps, through = m.next_noise()
+                L.update(w_eps=w_eps, b_eps=b_eps)
+                if through:
+                    L.update(w_eps_copy=m.weight_epsilon, b_eps_copy=m.bias_epsilon)
+                eps += [w_eps, b_eps]
+        W, b = ops.noisy_combine(layers, training)
+        x = x.contiguous()
+        q = ops.lin_fwd(x, W, b, ops.LIN_ACT["dueling"])
+        ctx.training = training
+        ctx.save_for_backward(x, W, *eps)
+        ctx.sinks = [getattr(p, "_gymrl_sink", None) for p in params]
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return q
+
+    @staticmethod
+    def backward(ctx, dq):
+        x, W, *eps = ctx.saved_tensors
+        dS = ops.dueling_bwd(dq.contiguous())
+        dx = ops.lin_bwd_input(dS, None, W)[0] if ctx.needs_input_grad[0] else None
+        grads = [None] * 8
+        if any(ctx.needs_input_grad[3:]):
+            dW, db = torch.empty_like(W), torch.empty(W.shape[0], dtype=W.dtype, device=W.device)
+            ops.lin_bwd_weight(dS, None, x, dW, db)
+            # destinations: the flat gradient buffer's views when every parameter's GradSink is armed, fresh tensors otherwise
+            slots = None
+            if all(s is not None and s[0].armed for s in ctx.sinks):
+                slots = [s[0].direct(s[1]) for s in ctx.sinks]
+                if len({a for _, a in slots}) != 1:
+                    for s in ctx.sinks:
+                        s[0].undo(s[1])
+                    slots = None
+            if slots is None:
+                grads = [torch.empty(shape, dtype=W.dtype, device=W.device) for shape in ctx.shapes]
+                dst, acc = grads, False
+            else:
+                dst, acc = [v for v, _ in slots], slots[0][1]
+            layers = []
+            for i in range(2):
+                L = dict(w_mu=dst[4 * i], b_mu=dst[4 * i + 2],                 # (only their shapes are read by the split)
+                         dw_mu=dst[4 * i], dw_sigma=dst[4 * i + 1], db_mu=dst[4 * i + 2], db_sigma=dst[4 * i + 3])
+                if ctx.training:
+                    L.update(w_sigma=dst[4 * i + 1], b_sigma=dst[4 * i + 3], w_eps=eps[2 * i], b_eps=eps[2 * i + 1])
+                layers.append(L)
+            ops.noisy_split(layers, dW, db, ctx.training, accumulate=acc)
+        return (dx, None, None, *grads)
 
 
 class DuelingNoisyNetwork(nn.Module):
@@ -122,6 +197,10 @@ class DuelingNoisyNetwork(nn.Module):
 
     def forward(self, x):
         x = self.fc2(self.fc1(x))
+        a, v = self.advantage, self.value
+        if gnn.FUSED_LINEAR and x.is_cuda and a.out_features + 1 <= 16:
+            return _NoisyDuelingHead.apply(x, a, v, a.weight_mu, a.weight_sigma, a.bias_mu, a.bias_sigma,
+                                           v.weight_mu, v.weight_sigma, v.bias_mu, v.bias_sigma)
         advantage, value = self.advantage(x), self.value(x)
         return value + (advantage - advantage.mean(dim=-1, keepdim=True))
 

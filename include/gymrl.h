@@ -376,7 +376,7 @@ int gymrl_soft_update(float* target, const float* source, int64_t n, double tau,
 #define GYMRL_MLP_MAX_STAGES 8
 #define GYMRL_MLP_MAX_WIDTH 256
 #define GYMRL_MLP_MAX_INPUT 64
-enum { GYMRL_ACT_NONE = 0, GYMRL_ACT_TANH = 1, GYMRL_ACT_RELU = 2, GYMRL_ACT_CLAMP = 3 /* gymrl_lin_* only */ };
+enum { GYMRL_ACT_NONE = 0, GYMRL_ACT_TANH = 1, GYMRL_ACT_RELU = 2, GYMRL_ACT_CLAMP = 3, GYMRL_ACT_DUELING = 4 /* 3, 4: gymrl_lin_* only */ };
 typedef struct {
   const float* W;
   const float* b;
@@ -480,6 +480,31 @@ int gymrl_lin_bwd_input(const gymrl_lin_item* items, int n_items, int B, int N, 
                         int lddx2, int accumulate, int sum_items, void* stream);
 int gymrl_lin_bwd_weight(const gymrl_lin_item* items, int n_items, int B, int N, int K, int K1, int ldy, int ldx,
                          int ldx2, int accumulate, void* workspace, void* stream);
+
+/*
+ * gymrl_lin_fwd with act == GYMRL_ACT_DUELING (N = A + 1 <= 16 stacked rows: A advantage rows, then the value row)
+ * writes q [B, A] = value + advantage - mean(advantage) — DuelingNoisyNetwork.forward rainbow_dqn_cartpole.py:108-113 —
+ * instead of the N raw columns; gymrl_dueling_bwd maps dq [B, A] back to the stacked dS [B, A + 1].
+ *
+ * NoisyLinear (rainbow_dqn_cartpole.py:60-95): gymrl_noisy_combine stacks the effective parameters of up to
+ * GYMRL_NOISY_MAX_LAYERS layers that share K — W[row] = w_mu + w_sigma * w_eps, b likewise (training == 0: mu only) —
+ * into W_out [sum n_out, K] / b_out [sum n_out] and copies the noise through to w_eps_copy / b_eps_copy (the
+ * module's weight_epsilon / bias_epsilon buffers) when given; gymrl_noisy_split sends the stacked gradient back:
+ * d mu (+)= dW, d sigma (+)= dW * eps (zeros when training == 0; NULL d*_sigma: skipped).
+ */
+#define GYMRL_NOISY_MAX_LAYERS 4
+typedef struct {
+  const float* w_mu; const float* w_sigma; const float* w_eps;      /* [n_out, K] */
+  const float* b_mu; const float* b_sigma; const float* b_eps;      /* [n_out] */
+  float* w_eps_copy; float* b_eps_copy;                             /* combine only, NULL: no copy */
+  float* dw_mu; float* dw_sigma; float* db_mu; float* db_sigma;     /* split only */
+  int n_out;
+} gymrl_noisy_layer;
+int gymrl_noisy_combine(const gymrl_noisy_layer* layers, int n_layers, int K, int training, float* W_out, float* b_out,
+                        void* stream);
+int gymrl_noisy_split(const gymrl_noisy_layer* layers, int n_layers, int K, int training, const float* dW, const float* db,
+                      int accumulate, void* stream);
+int gymrl_dueling_bwd(const float* dq, int B, int A, float* dS_out, void* stream);
 
 /* ===================================================== MLP update path ===== */
 /*
