@@ -59,13 +59,15 @@ def build(force=False):
 class LinItem(C.Structure):
     """gymrl_lin_item (include/gymrl.h)."""
     _fields_ = ([(n, C.c_void_p) for n in ("x", "x2", "w", "b", "y", "dy", "dx", "dx2", "dw", "db")] +
-                [("act", C.c_int), ("lo", C.c_float), ("hi", C.c_float)])
+                [("act", C.c_int), ("lo", C.c_float), ("hi", C.c_float), ("argmax", C.c_void_p)])
 
 
 class NoisyLayer(C.Structure):
     """gymrl_noisy_layer (include/gymrl.h)."""
     _fields_ = ([(n, C.c_void_p) for n in ("w_mu", "w_sigma", "w_eps", "b_mu", "b_sigma", "b_eps", "w_eps_copy", "b_eps_copy",
-                                          "dw_mu", "dw_sigma", "db_mu", "db_sigma")] + [("n_out", C.c_int)])
+                                          "dw_mu", "dw_sigma", "db_mu", "db_sigma")] +
+                [("seed", C.c_uint64), ("counter", C.c_uint64), ("counter_dev", C.c_void_p), ("draw", C.c_int),
+                 ("n_out", C.c_int)])
 
 
 class PPOCfg(C.Structure):

@@ -244,4 +244,19 @@ __device__ __forceinline__ void block_atomic_add(double (&v)[K], double* out) {
   }
 }
 
+// NoisyLinear's factorised noise (rainbow_dqn_cartpole.py:77-87): f(x) = sign(x) sqrt(|x|) of N(0,1) draws, Box-Muller on
+// Philox(seed, counter; stream 0 = input side, 1 = output side, element index).  Shared by gymrl_noisy_noise
+// (offpolicy.hip) and the fused head's gymrl_noisy_combine (lin.hip), which must produce the same bits.
+__device__ __forceinline__ float scale_noise(float x) {            // x.sign().mul(x.abs().sqrt())
+  const float s = x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);
+  return s * sqrtf(fabsf(x));
+}
+__device__ __forceinline__ float box_muller(uint64_t seed, uint64_t counter, uint32_t stream, uint32_t i) {
+  const u32x4 r = philox4x32(seed, i, stream, (uint32_t)counter, RNG_NOISE | (uint32_t)((counter >> 32) & 0x0FFFFFFFu));
+  const float u1 = u01f_open0(r.x), u2 = u01f(r.y);
+  float s, c;
+  det_sincosf(6.28318530717958647692f * u2, &s, &c);
+  return sqrtf(-2.0f * det_logf(u1)) * c;
+}
+
 }  // namespace gymrl

@@ -57,6 +57,7 @@ __device__ __forceinline__ float act_bwd(float y, int act, float lo, float hi) {
 
 struct LinFwd {
   const float* X[kItems]; const float* X2[kItems]; const float* W[kItems]; const float* b[kItems]; float* Y[kItems];
+  int32_t* argmax[kItems];
   int act[kItems]; float lo[kItems], hi[kItems];
   int B, K, K1, N, ldx, ldx2, ldy, col_groups;
 };
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lin_fwd_kernel(const LinF
       f32x4 xa[kChunk], wb[kChunk][NT];
 #pragma unroll
       for (int c = 0; c < kChunk; ++c) {
+        if (kc0 + 16 * c >= a.K) break;                     // (wave-uniform) short reductions: K = 4 is one step, not eight
         const int k = kc0 + 16 * c + 4 * q;
         const int ks = k < a.K ? k : 0;
         xa[c] = *reinterpret_cast<const f32x4*>(xrow + ks);
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lin_fwd_kernel(const LinF
       }
 #pragma unroll
       for (int c = 0; c < kChunk; ++c) {
+        if (kc0 + 16 * c >= a.K) break;
         const bool k_ok = kc0 + 16 * c + 4 * q < a.K;
         const f32x4 x = (row_ok && k_ok) ? xa[c] : zero;
 #pragma unroll
@@ -152,7 +155,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lin_fwd_kernel(const LinF
       s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
       const float v = __shfl(z, (lane & 48) | A, 64);
       const int ro = rt * 16 + 4 * q + g;
-      if (r < A && ro < a.B) Y[(size_t)ro * a.ldy + r] = v + (z - s / (float)A);
+      const float qv = v + (z - s / (float)A);
+      if (r < A && ro < a.B) Y[(size_t)ro * a.ldy + r] = qv;
+      if (a.argmax[item]) {                        // greedy action: first index of the maximum
+        float best = r < A ? qv : -3.4e38f;
+        int bi = r < A ? r : 16;
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+          const float ov = __shfl_xor(best, m, 64);
+          const int oi = __shfl_xor(bi, m, 64);
+          if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (r == 0 && ro < a.B) a.argmax[item][ro] = bi;
+      }
     }
     return;
   }
@@ -211,6 +226,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lin_bwd_input_kernel(cons
       f32x4 dy[kChunk], yv[kChunk], wb[kChunk][NT];
 #pragma unroll
       for (int c = 0; c < kChunk; ++c) {
+        if (nc0 + 16 * c >= a.N) break;
         const int n = nc0 + 16 * c + 4 * q;
         const int ns = n < a.N ? n : 0;
         dy[c] = *reinterpret_cast<const f32x4*>(dY + roff + ns);
@@ -222,6 +238,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lin_bwd_input_kernel(cons
       }
 #pragma unroll
       for (int c = 0; c < kChunk; ++c) {
+        if (nc0 + 16 * c >= a.N) break;
         const bool ok = row_ok && nc0 + 16 * c + 4 * q < a.N;
         f32x4 dz = ok ? dy[c] : zero;
         if (act != GYMRL_ACT_NONE) {
@@ -314,7 +331,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lin_bwd_weight_kernel(con
   for (int bc0 = b_lo; bc0 < b_hi; bc0 += 16 * kChunk) {
     float dy[kChunk][4], yv[kChunk][4], xb[kChunk][NT][4];
 #pragma unroll
-    for (int c = 0; c < kChunk; ++c)
+    for (int c = 0; c < kChunk; ++c) {
+      if (bc0 + 16 * c >= b_hi) break;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int b = bc0 + 16 * c + 4 * e + q;
@@ -329,8 +347,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lin_bwd_weight_kernel(con
           xb[c][t][e] = *px;
         }
       }
+    }
 #pragma unroll
-    for (int c = 0; c < kChunk; ++c)
+    for (int c = 0; c < kChunk; ++c) {
+      if (bc0 + 16 * c >= b_hi) break;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const bool ok = n_ok && bc0 + 16 * c + 4 * e + q < b_hi;
@@ -340,6 +360,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lin_bwd_weight_kernel(con
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = mfma16(dz, kb + 16 * t + r < a.K ? xb[c][t][e] : 0.0f, acc[t]);
       }
+    }
   }
   // bias gradient: the four row groups' serial sums, added pairwise (q0 + q1) + (q2 + q3)
   colsum += __shfl_xor(colsum, 16, 64);
@@ -385,6 +406,8 @@ struct NoisyArgs {
   const float* w_mu[kNoisyLayers]; const float* w_sigma[kNoisyLayers]; const float* w_eps[kNoisyLayers];
   const float* b_mu[kNoisyLayers]; const float* b_sigma[kNoisyLayers]; const float* b_eps[kNoisyLayers];
   float* w_eps_copy[kNoisyLayers]; float* b_eps_copy[kNoisyLayers];
+  uint64_t seed[kNoisyLayers], counter[kNoisyLayers]; const uint64_t* counter_dev[kNoisyLayers];
+  int draw[kNoisyLayers];           // combine: generate this layer's noise here (w_eps / b_eps are not read)
   float* dw_mu[kNoisyLayers]; float* dw_sigma[kNoisyLayers]; float* db_mu[kNoisyLayers]; float* db_sigma[kNoisyLayers];
   int row0[kNoisyLayers + 1];       // first stacked row of each layer
   int n_layers, K, training, accumulate;
@@ -401,11 +424,18 @@ __global__ __launch_bounds__(256) void noisy_combine_kernel(const NoisyArgs a) {
     int l = 0;
     while (l + 1 < a.n_layers && row >= a.row0[l + 1]) ++l;
     const int n = row - a.row0[l];
+    // draw: NoisyLinear.reset_noise() of this forward happens here — the very values gymrl_noisy_noise writes
+    float fj = 0.0f;
+    uint64_t ctr = 0;
+    if (a.training && a.draw[l]) {
+      ctr = a.counter_dev[l] ? a.counter_dev[l][0] : a.counter[l];
+      fj = scale_noise(box_muller(a.seed[l], ctr, 1u, (uint32_t)n));
+    }
     if (k < a.K) {
       const size_t o = (size_t)n * a.K + k;
       float w = a.w_mu[l][o];
       if (a.training) {
-        const float e = a.w_eps[l][o];
+        const float e = a.draw[l] ? fj * scale_noise(box_muller(a.seed[l], ctr, 0u, (uint32_t)k)) : a.w_eps[l][o];
         w = w + a.w_sigma[l][o] * e;
         if (a.w_eps_copy[l]) a.w_eps_copy[l][o] = e;
       }
@@ -413,7 +443,7 @@ __global__ __launch_bounds__(256) void noisy_combine_kernel(const NoisyArgs a) {
     } else {
       float bv = a.b_mu[l][n];
       if (a.training) {
-        const float e = a.b_eps[l][n];
+        const float e = a.draw[l] ? fj : a.b_eps[l][n];
         bv = bv + a.b_sigma[l][n] * e;
         if (a.b_eps_copy[l]) a.b_eps_copy[l][n] = e;
       }
@@ -489,6 +519,7 @@ int gymrl_lin_fwd(const gymrl_lin_item* items, int n_items, int B, int K, int K1
       return -22;
     a.act[i] = it.act; a.lo[i] = it.lo; a.hi[i] = it.hi;
     a.X[i] = it.x; a.X2[i] = K1 < K ? it.x2 : nullptr; a.W[i] = it.w; a.b[i] = it.b; a.Y[i] = it.y;
+    a.argmax[i] = it.act == GYMRL_ACT_DUELING ? it.argmax : nullptr;
     vec = vec && aligned16(it.x) && aligned16(it.w);
   }
   a.B = B; a.K = K; a.K1 = K1; a.N = N; a.ldx = ldx; a.ldx2 = ldx2; a.ldy = ldy;
@@ -578,7 +609,10 @@ static int noisy_fill(NoisyArgs& a, const gymrl_noisy_layer* layers, int n_layer
   int rows = 0;
   for (int l = 0; l < n_layers; ++l) {
     const gymrl_noisy_layer& L = layers[l];
-    if (!L.w_mu || !L.b_mu || L.n_out < 1 || (training && (!L.w_sigma || !L.b_sigma || !L.w_eps || !L.b_eps))) return -22;
+    if (!L.w_mu || !L.b_mu || L.n_out < 1 || (training && (!L.w_sigma || !L.b_sigma))) return -22;
+    if (training && !L.draw && (!L.w_eps || !L.b_eps)) return -22;
+    if (training && L.draw && (!L.w_eps_copy || !L.b_eps_copy)) return -22;      // the drawn noise must land somewhere
+    a.seed[l] = L.seed; a.counter[l] = L.counter; a.counter_dev[l] = L.counter_dev; a.draw[l] = L.draw;
     a.w_mu[l] = L.w_mu; a.w_sigma[l] = L.w_sigma; a.w_eps[l] = L.w_eps;
     a.b_mu[l] = L.b_mu; a.b_sigma[l] = L.b_sigma; a.b_eps[l] = L.b_eps;
     a.w_eps_copy[l] = L.w_eps_copy; a.b_eps_copy[l] = L.b_eps_copy;

@@ -74,23 +74,14 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const double* __restri
 }
 
 // ------------------------------------------------------------------ R1 -------
-__device__ __forceinline__ float scale_noise(float x) {            // x.sign().mul(x.abs().sqrt())
-  const float s = x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);
-  return s * sqrtf(fabsf(x));
-}
-__device__ __forceinline__ float box_muller(uint64_t seed, uint64_t counter, uint32_t stream, uint32_t i) {
-  const u32x4 r = philox4x32(seed, i, stream, (uint32_t)counter, RNG_NOISE | (uint32_t)((counter >> 32) & 0x0FFFFFFFu));
-  const float u1 = u01f_open0(r.x), u2 = u01f(r.y);
-  float s, c;
-  det_sincosf(6.28318530717958647692f * u2, &s, &c);
-  return sqrtf(-2.0f * det_logf(u1)) * c;
-}
-
+// scale_noise / box_muller: gymrl_device.hpp (shared with the fused NoisyLinear head, lin.hip)
 __global__ __launch_bounds__(kBlock) void noisy_noise_kernel(const float* __restrict__ eps_in,
                                                              const float* __restrict__ eps_out,
                                                              uint64_t seed, uint64_t counter, int nin,
                                                              int nout, float* __restrict__ w_eps,
-                                                             float* __restrict__ b_eps) {
+                                                             float* __restrict__ b_eps,
+                                                             const uint64_t* __restrict__ counter_dev) {
+  if (counter_dev) counter = counter_dev[0];   // recorded into a hipGraph: this replay's draw counter lives on the device
   const int64_t total = (int64_t)nin * nout;
   for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
     const int j = (int)(t / nin), i = (int)(t % nin);
@@ -470,12 +461,13 @@ __global__ void dsac_alpha_kernel(float* __restrict__ log_alpha, float* __restri
 extern "C" {
 
 int gymrl_noisy_noise(const float* eps_in_raw, const float* eps_out_raw, uint64_t seed, uint64_t counter,
-                      int in_features, int out_features, float* w_eps_out, float* b_eps_out, void* stream_) {
+                      int in_features, int out_features, float* w_eps_out, float* b_eps_out,
+                      const uint64_t* counter_dev, void* stream_) {
   if (!w_eps_out || !b_eps_out || in_features <= 0 || out_features <= 0) return -22;
   if ((eps_in_raw == nullptr) != (eps_out_raw == nullptr)) return -22;
   hipLaunchKernelGGL(noisy_noise_kernel, dim3(grid_for(in_features * out_features)), dim3(kBlock), 0,
                      (hipStream_t)stream_, eps_in_raw, eps_out_raw, seed, counter, in_features, out_features,
-                     w_eps_out, b_eps_out);
+                     w_eps_out, b_eps_out, counter_dev);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

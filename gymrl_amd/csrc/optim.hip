@@ -70,6 +70,12 @@ __global__ void store_scalars_kernel(uint32_t* __restrict__ dst, ScalarBlock blk
   if (blockIdx.x == 0 && (int)threadIdx.x < nwords) dst[threadIdx.x] = blk.w[threadIdx.x];
 }
 
+// A chunk of vector steps replayed as one hipGraph stages every step's scalars at once: up to 3840 bytes.
+struct ScalarBlockBig { uint32_t w[960]; };
+__global__ void store_scalars_big_kernel(uint32_t* __restrict__ dst, ScalarBlockBig blk, int nwords) {
+  for (int i = threadIdx.x; i < nwords; i += blockDim.x) dst[i] = blk.w[i];
+}
+
 struct AdamArgs {
   float step_size_host;  // (float)(lr / (1 - beta1^t)), python-double arithmetic
   float inv_bc1;         // 1 / (1 - beta1^t)   (used with a device-resident lr)
@@ -188,9 +194,17 @@ int gymrl_adam_bias(double lr, double beta1, double beta2, int64_t step, float* 
 }
 
 int gymrl_store_scalars(void* dst_dev, const void* src_host, int nbytes, void* stream_) {
-  if (!dst_dev || !src_host || nbytes <= 0 || nbytes > (int)sizeof(ScalarBlock) || (nbytes & 3) ||
+  if (!dst_dev || !src_host || nbytes <= 0 || nbytes > (int)sizeof(ScalarBlockBig) || (nbytes & 3) ||
       (reinterpret_cast<uintptr_t>(dst_dev) & 3))
     return -22;
+  if (nbytes > (int)sizeof(ScalarBlock)) {
+    ScalarBlockBig big;
+    __builtin_memcpy(big.w, src_host, (size_t)nbytes);
+    hipLaunchKernelGGL(store_scalars_big_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, (uint32_t*)dst_dev, big,
+                       nbytes >> 2);
+    GYMRL_CHECK_LAUNCH();
+    return 0;
+  }
   ScalarBlock blk;
   __builtin_memcpy(blk.w, src_host, (size_t)nbytes);
   hipLaunchKernelGGL(store_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, (uint32_t*)dst_dev, blk,

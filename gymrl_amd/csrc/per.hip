@@ -54,8 +54,10 @@ __global__ __launch_bounds__(1024) void per_leaf_kernel(double* __restrict__ tre
                                                         const double* __restrict__ prio,
                                                         const double* __restrict__ ps_dev, double ps,
                                                         int B, int64_t* __restrict__ leaf_out,
-                                                        double* __restrict__ change_out, int use_lds) {
+                                                        double* __restrict__ change_out, int use_lds,
+                                                        const int64_t* __restrict__ idx_start_dev) {
   extern __shared__ int64_t s_leaf_dyn[];
+  if (idx_start_dev) idx_start = idx_start_dev[0];     // recorded into a hipGraph: this replay's ring cursor
   const int64_t* lf = use_lds ? s_leaf_dyn : leaf_out;
   // phase A: leaf index of every element
   for (int i = threadIdx.x; i < B; i += blockDim.x) {
@@ -107,6 +109,7 @@ __global__ __launch_bounds__(1024) void per_ancestor_kernel(double* __restrict__
     __syncthreads();
     leaf = sl; change = sc;
   }
+  if (sorted == 2) sorted = leaf[B - 1] - leaf[0] == (int64_t)(B - 1) ? 1 : 0;   // device-side cursor: a run unless it wrapped
   for (int i = threadIdx.x; i < B; i += blockDim.x) {
     const int64_t lf = leaf[i];
     const int L = depth_of(lf);
@@ -135,10 +138,19 @@ __global__ __launch_bounds__(1024) void per_ancestor_kernel(double* __restrict__
       const int64_t e64 = (int64_t)i + (last_leaf - lf) + 1;
       const int e = e64 < (int64_t)B ? (int)e64 : B;
       int j = i;
-      for (; j + 8 <= e; j += 8) {                          // loads first, then the ordered chain of adds
-        const double c0 = change[j], c1 = change[j + 1], c2 = change[j + 2], c3 = change[j + 3];
-        const double c4 = change[j + 4], c5 = change[j + 5], c6 = change[j + 6], c7 = change[j + 7];
+      // The ordered chain of adds is the kernel (the root's run is the whole batch): the next group's loads are in
+      // flight while the current group's eight dependent adds retire.
+      if (j + 8 <= e) {
+        double c0 = change[j], c1 = change[j + 1], c2 = change[j + 2], c3 = change[j + 3];
+        double c4 = change[j + 4], c5 = change[j + 5], c6 = change[j + 6], c7 = change[j + 7];
+        for (; j + 16 <= e; j += 8) {
+          const double n0 = change[j + 8], n1 = change[j + 9], n2 = change[j + 10], n3 = change[j + 11];
+          const double n4 = change[j + 12], n5 = change[j + 13], n6 = change[j + 14], n7 = change[j + 15];
+          acc += c0; acc += c1; acc += c2; acc += c3; acc += c4; acc += c5; acc += c6; acc += c7;
+          c0 = n0; c1 = n1; c2 = n2; c3 = n3; c4 = n4; c5 = n5; c6 = n6; c7 = n7;
+        }
         acc += c0; acc += c1; acc += c2; acc += c3; acc += c4; acc += c5; acc += c6; acc += c7;
+        j += 8;
       }
       for (; j < e; ++j) acc += change[j];
     } else {
@@ -300,14 +312,16 @@ __global__ __launch_bounds__(kBlock) void per_priorities_kernel(const float* __r
   out[i] = (double)det_expf((float)alpha * det_logf(e));
 }
 
+struct PerSampleDev { uint64_t counter; int64_t size; double beta; };
 // stratified descent + un-normalised IS weights; per-block max of the weights.
 __global__ __launch_bounds__(kBlock) void per_sample_kernel(
     const double* __restrict__ tree, int64_t cap, const double* __restrict__ u, uint64_t seed,
     uint64_t counter, int B, int64_t size, double beta, int variant_b, int32_t* __restrict__ idx_out,
     double* __restrict__ prio_out, float* __restrict__ w32, double* __restrict__ w64,
-    double* __restrict__ blockmax) {
+    double* __restrict__ blockmax, const PerSampleDev* __restrict__ dev) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const int64_t tcap = 2 * cap - 1;
+  if (dev) { counter = dev->counter; size = dev->size; beta = dev->beta; }     // this replay's draw scalars
   double w = 0.0;
   if (i < B) {
     const double total = tree[0];
@@ -371,8 +385,8 @@ size_t gymrl_per_workspace_bytes(int B) {
 
 int gymrl_per_update(double* tree, int64_t cap, const int32_t* idx, int64_t idx_start,
                      int idx_is_tree, const double* prio, const double* prio_scalar_dev,
-                     double prio_scalar, int B, void* workspace, void* stream_) {
-  if (!tree || !workspace || cap <= 0 || B < 0 || (!idx && (idx_start < 0 || B > cap))) return -22;
+                     double prio_scalar, int B, const int64_t* idx_start_dev, void* workspace, void* stream_) {
+  if (!tree || !workspace || cap <= 0 || B < 0 || (!idx && (idx_start < 0 || B > cap)) || (idx && idx_start_dev)) return -22;
   if (B == 0) return 0;
   hipStream_t stream = (hipStream_t)stream_;
   Ws ws(workspace, B);
@@ -401,10 +415,12 @@ int gymrl_per_update(double* tree, int64_t cap, const int32_t* idx, int64_t idx_
     return 0;
   }
   hipLaunchKernelGGL(per_leaf_kernel, dim3(1), dim3(1024), use_lds ? (size_t)B * 8 : 0, stream, tree, cap, idx,
-                     idx_start, idx_is_tree, prio, prio_scalar_dev, prio_scalar, B, ws.leaf, ws.change, use_lds);
+                     idx_start, idx_is_tree, prio, prio_scalar_dev, prio_scalar, B, ws.leaf, ws.change, use_lds,
+                     idx_start_dev);
   // consecutive rows form one run per node only when all leaves share a depth (cap = 2^k) and
   // the row range does not wrap; otherwise the general ordered search is used
-  const int sorted = (!idx && (cap & (cap - 1)) == 0 && (idx_start % cap) + B <= cap) ? 1 : 0;
+  // (a cursor read from the device: the kernel tests the staged leaves for a wrap itself)
+  const int sorted = (!idx && (cap & (cap - 1)) == 0) ? (idx_start_dev ? 2 : ((idx_start % cap) + B <= cap ? 1 : 0)) : 0;
   if (depth > 0)
     hipLaunchKernelGGL(per_ancestor_kernel, dim3(depth), dim3(1024), use_lds ? (size_t)B * 16 : 0, stream, tree,
                        ws.leaf, ws.change, B, sorted, use_lds);
@@ -435,7 +451,7 @@ int gymrl_per_priorities(const float* td, int B, double alpha, double eps, doubl
 
 int gymrl_per_sample(const double* tree, int64_t cap, const double* u, uint64_t seed, uint64_t counter,
                      int B, int64_t size, double beta, int variant_b, int32_t* idx_out, double* prio_out,
-                     float* w_out, void* workspace, void* stream_) {
+                     float* w_out, const void* dev, void* workspace, void* stream_) {
   if (!tree || !idx_out || !w_out || !workspace || cap <= 0 || B <= 0 || size <= 0) return -22;
   hipStream_t stream = (hipStream_t)stream_;
   Ws ws(workspace, B);
@@ -443,7 +459,7 @@ int gymrl_per_sample(const double* tree, int64_t cap, const double* u, uint64_t 
   double* w64 = ws.change;                 // reuse: f64[B]
   double* bmax = ws.partial;               // f64[nb]
   hipLaunchKernelGGL(per_sample_kernel, dim3(nb), dim3(kBlock), 0, stream, tree, cap, u, seed, counter, B,
-                     size, beta, variant_b, idx_out, prio_out, w_out, w64, bmax);
+                     size, beta, variant_b, idx_out, prio_out, w_out, w64, bmax, static_cast<const PerSampleDev*>(dev));
   hipLaunchKernelGGL(per_normalize_kernel, dim3(nb), dim3(kBlock), 0, stream, w_out, w64, B, bmax, nb,
                      variant_b);
   GYMRL_CHECK_LAUNCH();

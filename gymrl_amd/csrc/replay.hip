@@ -23,7 +23,8 @@ __global__ __launch_bounds__(kBlock) void replay_append_kernel(
     float* __restrict__ next_state, uint8_t* __restrict__ flag, int64_t cap, int64_t cursor, int D,
     int AW, int n, const float* __restrict__ s_state, const uint32_t* __restrict__ s_action,
     const float* __restrict__ s_reward, const float* __restrict__ s_next,
-    const uint8_t* __restrict__ s_flag) {
+    const uint8_t* __restrict__ s_flag, const int64_t* __restrict__ cursor_dev) {
+  if (cursor_dev) cursor = cursor_dev[0];      // recorded into a hipGraph: the cursor of this replay lives on the device
   // one thread per (row, word): words = D state + D next + AW action + reward + flag
   const int W = 2 * D + AW + 2;
   const int64_t total = (int64_t)n * W;
@@ -60,11 +61,20 @@ __global__ __launch_bounds__(kBlock) void replay_gather_kernel(
 // random.sample(buffer, B) draws B DISTINCT rows: idx[b] = the b-th element of a keyed permutation of [0, size)
 // (gymrl_device.hpp keyed_permute, tag RNG_REPLAY folded into the key) — a uniform sample without replacement
 // with no rejection loop and no bookkeeping between lanes.
+struct UniformDev { uint64_t counter; int64_t size; };
 __global__ __launch_bounds__(kBlock) void uniform_indices_kernel(uint64_t seed, uint64_t counter,
                                                                  uint32_t size, int B, int a, int bbits,
-                                                                 int32_t* __restrict__ idx) {
+                                                                 int32_t* __restrict__ idx,
+                                                                 const UniformDev* __restrict__ dev) {
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= B) return;
+  if (dev) {                                   // per-replay (counter, size) from the device; same split of the bits as the host's
+    counter = dev->counter;
+    size = (uint32_t)dev->size;
+    int bits = 2;
+    while (((int64_t)1 << bits) < (int64_t)size) ++bits;
+    a = bits / 2; bbits = bits - bits / 2;
+  }
   idx[b] = (int32_t)keyed_permute((uint32_t)b, size, a, bbits, seed ^ 0x5265706C61794944ull, counter);
 }
 
@@ -77,9 +87,16 @@ __global__ __launch_bounds__(kBlock) void nstep_push_kernel(
     const float* __restrict__ next_obs, const uint8_t* __restrict__ terminal,
     const uint8_t* __restrict__ done, float* __restrict__ r_state, uint32_t* __restrict__ r_action,
     float* __restrict__ r_reward, float* __restrict__ r_next, uint8_t* __restrict__ r_flag,
-    int64_t cap, int64_t cursor) {
+    int64_t cap, int64_t cursor, const int64_t* __restrict__ dev, const int32_t* __restrict__ ep_len,
+    int max_episode_steps) {
   const int e = blockIdx.x * kBlock + threadIdx.x;
   if (e >= N) return;
+  if (dev) {                                   // {pushes, cursor} of this replay
+    const int64_t pushes = dev[0];
+    slot = (int)(pushes % n_steps);
+    emit = pushes + 1 >= n_steps ? 1 : 0;
+    cursor = dev[1];
+  }
   // deque.append(transition) — :186-187
   const size_t so = ((size_t)slot * N + e);
   for (int k = 0; k < D; ++k) {
@@ -87,7 +104,9 @@ __global__ __launch_bounds__(kBlock) void nstep_push_kernel(
     w_next[so * D + k] = next_obs[(size_t)e * D + k];
   }
   w_action[so] = action[e]; w_reward[so] = reward[e];
-  w_terminal[so] = terminal[e]; w_done[so] = done[e];
+  // terminal NULL: rainbow_dqn_cartpole.py:376 — done and not the last step of the time limit, by the step INDEX
+  w_terminal[so] = terminal ? terminal[e] : (uint8_t)((done[e] != 0 && ep_len[e] != max_episode_steps) ? 1 : 0);
+  w_done[so] = done[e];
   if (!emit) return;
   // _get_n_step_transition — :207-218
   const int oldest = (slot + 1) % n_steps;
@@ -118,7 +137,8 @@ extern "C" {
 int gymrl_replay_append(float* state, uint32_t* action, float* reward, float* next_state,
                         uint8_t* flag, int64_t cap, int64_t cursor, int D, int AW, int n,
                         const float* src_state, const void* src_action, const float* src_reward,
-                        const float* src_next_state, const uint8_t* src_flag, void* stream_) {
+                        const float* src_next_state, const uint8_t* src_flag, const int64_t* cursor_dev,
+                        void* stream_) {
   if (!state || !action || !reward || !next_state || !flag || !src_state || !src_action ||
       !src_reward || !src_next_state || !src_flag || cap <= 0 || cursor < 0 || D <= 0 || AW <= 0 ||
       n < 0 || n > cap)
@@ -129,7 +149,7 @@ int gymrl_replay_append(float* state, uint32_t* action, float* reward, float* ne
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(replay_append_kernel, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream_, state, action,
                      reward, next_state, flag, cap, cursor, D, AW, n, src_state,
-                     (const uint32_t*)src_action, src_reward, src_next_state, src_flag);
+                     (const uint32_t*)src_action, src_reward, src_next_state, src_flag, cursor_dev);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
@@ -153,13 +173,14 @@ int gymrl_replay_gather(const float* state, const uint32_t* action, const float*
 }
 
 int gymrl_uniform_indices(uint64_t seed, uint64_t counter, int64_t size, int B, int32_t* idx_out,
-                          void* stream_) {
+                          const void* dev, void* stream_) {
   if (!idx_out || size <= 0 || size > 0x7FFFFFFF || B < 0 || B > size) return -22;
   if (B == 0) return 0;
   int bits = 2;
   while (((int64_t)1 << bits) < size) ++bits;
   hipLaunchKernelGGL(uniform_indices_kernel, dim3(cdiv(B, kBlock)), dim3(kBlock), 0,
-                     (hipStream_t)stream_, seed, counter, (uint32_t)size, B, bits / 2, bits - bits / 2, idx_out);
+                     (hipStream_t)stream_, seed, counter, (uint32_t)size, B, bits / 2, bits - bits / 2, idx_out,
+                     static_cast<const UniformDev*>(dev));
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
@@ -169,9 +190,10 @@ int gymrl_nstep_push(float* w_state, int32_t* w_action, float* w_reward, float* 
                      double gamma, const float* obs, const int32_t* action, const float* reward,
                      const float* next_obs, const uint8_t* terminal, const uint8_t* done,
                      float* r_state, uint32_t* r_action, float* r_reward, float* r_next,
-                     uint8_t* r_flag, int64_t cap, int64_t cursor, void* stream_) {
+                     uint8_t* r_flag, int64_t cap, int64_t cursor, const int64_t* dev, const int32_t* ep_len,
+                     int max_episode_steps, void* stream_) {
   if (!w_state || !w_action || !w_reward || !w_next || !w_terminal || !w_done || !obs || !action ||
-      !reward || !next_obs || !terminal || !done || !r_state || !r_action || !r_reward || !r_next ||
+      !reward || !next_obs || (!terminal && !ep_len) || !done || !r_state || !r_action || !r_reward || !r_next ||
       !r_flag || n_steps <= 0 || pushes < 0 || N < 0 || D <= 0 || cap < N || cursor < 0)
     return -22;
   if (N == 0) return 0;
@@ -180,7 +202,7 @@ int gymrl_nstep_push(float* w_state, int32_t* w_action, float* w_reward, float* 
   hipLaunchKernelGGL(nstep_push_kernel, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream_,
                      w_state, w_action, w_reward, w_next, w_terminal, w_done, n_steps, slot, emit, N, D,
                      gamma, obs, action, reward, next_obs, terminal, done, r_state, r_action, r_reward,
-                     r_next, r_flag, cap, cursor);
+                     r_next, r_flag, cap, cursor, dev, ep_len, max_episode_steps);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return -1000 - (int)e;
   return emit;

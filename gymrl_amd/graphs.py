@@ -100,3 +100,61 @@ class GraphedUpdate:
             self.sc.set_doubles(self.alpha_off, 1.0 - b1 ** t, 1.0 - b2 ** t)
         self.sc.flush()
         self.step_fn()
+
+
+class StepChunk:
+    """K whole vector steps — acting forward, env step, ring append, index draw, update — as ONE hipGraph.
+
+    A graphed update alone leaves ~25 eager launches per vector step (acting, env, append, draw, noise) whose
+    host cost (Python + HIP launch, ~20 us each) is what a step then lasts: 0.50 ms enqueue = 0.50 ms total at
+    Rainbow's config 4 (`tools/probe_cpu_bound.py`).  Every one of those launches takes its per-step values —
+    ring cursors, Philox counters, PER exponent, Adam's bias corrections — from a record in DEVICE memory instead
+    (the `*_dev` arguments of include/gymrl.h), the host walks its own bookkeeping K steps ahead and stages the K
+    records with one gymrl_store_scalars, and the K steps replay as one graph: two launches per K vector steps.
+
+    fields: [(name, struct format)] of ONE step's record, e.g. [("noise", "6Q"), ("push", "2q"), ("adam", "4f")];
+    every field is 8-byte aligned.  view(j, name) -> the device bytes of that field (a uint8 tensor: pass it as a
+    `*_dev` pointer, or .view(dtype) it); set(j, name, *values) writes the host copy; flush() stages all K records.
+    """
+
+    LIMIT = 3840
+
+    def __init__(self, device, K, fields):
+        self.K, self.fmt, self.off = K, {}, {}
+        off = 0
+        for name, fmt in fields:
+            off = (off + 7) & ~7
+            self.fmt[name], self.off[name] = fmt, off
+            off += struct.calcsize("=" + fmt)
+        self.rec = (off + 7) & ~7
+        if K * self.rec > self.LIMIT:
+            raise ValueError(f"{K} records of {self.rec} bytes exceed one scalar store ({self.LIMIT} bytes)")
+        self.dev = torch.zeros(K * self.rec, dtype=torch.uint8, device=device)
+        self.host = bytearray(K * self.rec)
+        self.graph = None
+        self.key = None
+
+    def view(self, j, name, dtype=None):
+        o = j * self.rec + self.off[name]
+        v = self.dev[o:o + struct.calcsize("=" + self.fmt[name])]
+        return v if dtype is None else v.view(dtype)
+
+    def set(self, j, name, *vals):
+        struct.pack_into("=" + self.fmt[name], self.host, j * self.rec + self.off[name], *vals)
+
+    def set_bytes(self, j, name, payload):
+        o = j * self.rec + self.off[name]
+        self.host[o:o + len(payload)] = payload
+
+    def flush(self):
+        ops.store_scalars(self.dev, bytes(self.host))
+
+    def run(self, body, key=None):
+        """Replay the captured K-step graph; (re)capture `for j in range(K): body(j)` first when there is none yet or
+        `key` (identity of the buffers the body touches) changed.  The records must have been flush()ed."""
+        if self.graph is None or key != self.key:
+            self.graph, self.key = torch.cuda.CUDAGraph(), key
+            with torch.cuda.graph(self.graph):
+                for j in range(self.K):
+                    body(j)
+        self.graph.replay()

@@ -308,7 +308,7 @@ def adam_bias(lr, beta1, beta2, step):
 
 
 def store_scalars(dst, payload):
-    """payload: bytes (<= 256, multiple of 4) -> device tensor `dst`, one launch."""
+    """payload: bytes (<= 3840, multiple of 4) -> device tensor `dst`, one launch."""
     if len(payload) > dst.numel() * dst.element_size():
         raise ValueError("payload larger than the destination block")
     buf = C.create_string_buffer(payload, len(payload))
@@ -369,7 +369,12 @@ def env_abandon(kind, state, n, seed, env_id0, cap, obs_inout, flag_inout=None, 
                                   _ptr(ep_stats, torch.float64, True), _stream()), "gymrl_env_abandon")
 
 
-def replay_append(ring, cursor, src_state, src_action, src_reward, src_next_state, src_flag):
+def _dev(t):
+    """Pointer to a block of per-step scalars on the device (see "Per-step scalars on the device", include/gymrl.h)."""
+    return _vp(None) if t is None else _ptr(t)
+
+
+def replay_append(ring, cursor, src_state, src_action, src_reward, src_next_state, src_flag, cursor_dev=None):
     """D2/A3: write n rows at (cursor + i) % cap.  ring = (state, action_words, reward, next_state, flag)."""
     state, action, reward, next_state, flag = ring
     cap, D = state.shape
@@ -379,8 +384,8 @@ def replay_append(ring, cursor, src_state, src_action, src_reward, src_next_stat
                                     _ptr(next_state, torch.float32), _ptr(flag, torch.uint8), C.c_int64(cap),
                                     C.c_int64(cursor), C.c_int(D), C.c_int(AW), C.c_int(n),
                                     _ptr(src_state, torch.float32), _ptr(src_action), _ptr(src_reward, torch.float32),
-                                    _ptr(src_next_state, torch.float32), _ptr(src_flag, torch.uint8), _stream()),
-          "gymrl_replay_append")
+                                    _ptr(src_next_state, torch.float32), _ptr(src_flag, torch.uint8), _dev(cursor_dev),
+                                    _stream()), "gymrl_replay_append")
 
 
 def replay_gather(ring, idx, action_dtype=torch.int32):
@@ -398,14 +403,15 @@ def replay_gather(ring, idx, action_dtype=torch.int32):
     return out
 
 
-def uniform_indices(seed, counter, size, B, device, out=None):
+def uniform_indices(seed, counter, size, B, device, out=None, dev=None):
     idx = torch.empty(B, dtype=torch.int32, device=device) if out is None else out
     check(lib().gymrl_uniform_indices(C.c_uint64(seed), C.c_uint64(counter), C.c_int64(size), C.c_int(B),
-                                      _ptr(idx), _stream()), "gymrl_uniform_indices")
+                                      _ptr(idx), _dev(dev), _stream()), "gymrl_uniform_indices")
     return idx
 
 
-def nstep_push(win, n_steps, pushes, gamma, obs, action, reward, next_obs, terminal, done, ring, cursor):
+def nstep_push(win, n_steps, pushes, gamma, obs, action, reward, next_obs, terminal, done, ring, cursor, dev=None,
+               ep_len=None, max_episode_steps=0):
     """S2.  win = (w_state[n,N,D], w_action i32[n,N], w_reward[n,N], w_next[n,N,D], w_terminal u8, w_done u8).
     Returns True when N rows were emitted into the ring at (cursor + env) % cap."""
     w_state, w_action, w_reward, w_next, w_term, w_done = win
@@ -415,10 +421,11 @@ def nstep_push(win, n_steps, pushes, gamma, obs, action, reward, next_obs, termi
                                 _ptr(w_next, torch.float32), _ptr(w_term, torch.uint8), _ptr(w_done, torch.uint8),
                                 C.c_int(n_steps), C.c_int64(pushes), C.c_int(N), C.c_int(D), C.c_double(gamma),
                                 _ptr(obs, torch.float32), _ptr(action, torch.int32), _ptr(reward, torch.float32),
-                                _ptr(next_obs, torch.float32), _ptr(terminal, torch.uint8), _ptr(done, torch.uint8),
+                                _ptr(next_obs, torch.float32), _ptr(terminal, torch.uint8, True), _ptr(done, torch.uint8),
                                 _ptr(state, torch.float32), _ptr(act_w), _ptr(rew, torch.float32),
                                 _ptr(nxt, torch.float32), _ptr(flag, torch.uint8), C.c_int64(state.shape[0]),
-                                C.c_int64(cursor), _stream())
+                                C.c_int64(cursor), _dev(dev), _ptr(ep_len, torch.int32, True), C.c_int(max_episode_steps),
+                                _stream())
     if rc < 0:
         check(rc, "gymrl_nstep_push")
     return rc == 1
@@ -429,11 +436,11 @@ def per_workspace(B, device):
 
 
 def per_update(tree, cap, B, workspace, idx=None, idx_start=0, idx_is_tree=False, prio=None, prio_scalar_dev=None,
-               prio_scalar=0.0):
+               prio_scalar=0.0, idx_start_dev=None):
     check(lib().gymrl_per_update(_ptr(tree, torch.float64), C.c_int64(cap), _ptr(idx, torch.int32, True),
                                  C.c_int64(idx_start), C.c_int(int(idx_is_tree)), _ptr(prio, torch.float64, True),
                                  _ptr(prio_scalar_dev, torch.float64, True), C.c_double(prio_scalar), C.c_int(B),
-                                 _ptr(workspace), _stream()), "gymrl_per_update")
+                                 _dev(idx_start_dev), _ptr(workspace), _stream()), "gymrl_per_update")
 
 
 def per_max_leaf(tree, cap, out, workspace):
@@ -449,25 +456,25 @@ def per_priorities(td, alpha, eps, clip=0.0, out=None):
     return out
 
 
-def per_sample(tree, cap, B, size, beta, workspace, u=None, seed=0, counter=0, variant_b=False, out=None):
-    dev = tree.device
+def per_sample(tree, cap, B, size, beta, workspace, u=None, seed=0, counter=0, variant_b=False, out=None, dev=None):
     if out is None:
-        idx = torch.empty(B, dtype=torch.int32, device=dev)
-        prio = torch.empty(B, dtype=torch.float64, device=dev)
-        w = torch.empty(B, dtype=torch.float32, device=dev)
+        idx = torch.empty(B, dtype=torch.int32, device=tree.device)
+        prio = torch.empty(B, dtype=torch.float64, device=tree.device)
+        w = torch.empty(B, dtype=torch.float32, device=tree.device)
     else:
         idx, prio, w = out
     check(lib().gymrl_per_sample(_ptr(tree, torch.float64), C.c_int64(cap), _ptr(u, torch.float64, True),
                                  C.c_uint64(seed), C.c_uint64(counter), C.c_int(B), C.c_int64(size), C.c_double(beta),
-                                 C.c_int(int(variant_b)), _ptr(idx), _ptr(prio), _ptr(w), _ptr(workspace), _stream()),
-          "gymrl_per_sample")
+                                 C.c_int(int(variant_b)), _ptr(idx), _ptr(prio), _ptr(w), _dev(dev), _ptr(workspace),
+                                 _stream()), "gymrl_per_sample")
     return idx, prio, w
 
 
-def noisy_noise(nin, nout, w_eps, b_eps, eps_in=None, eps_out=None, seed=0, counter=0):
+def noisy_noise(nin, nout, w_eps, b_eps, eps_in=None, eps_out=None, seed=0, counter=0, counter_dev=None):
     check(lib().gymrl_noisy_noise(_ptr(eps_in, torch.float32, True), _ptr(eps_out, torch.float32, True),
                                   C.c_uint64(seed), C.c_uint64(counter), C.c_int(nin), C.c_int(nout),
-                                  _ptr(w_eps, torch.float32), _ptr(b_eps, torch.float32), _stream()), "gymrl_noisy_noise")
+                                  _ptr(w_eps, torch.float32), _ptr(b_eps, torch.float32), _dev(counter_dev), _stream()),
+          "gymrl_noisy_noise")
 
 
 def epsilon_greedy(q, epsilon, u=None, seed=0, counter=0, env_id0=0, act_out=None):
@@ -856,7 +863,7 @@ def lin_workspace(B, N, K, n_items, device):
     return torch.empty(max(n // 4, 1), dtype=torch.float32, device=device) if n else None
 
 
-def lin_fwd(x, w, b, act=0, x2=None, out=None, lo=0.0, hi=0.0):
+def lin_fwd(x, w, b, act=0, x2=None, out=None, lo=0.0, hi=0.0, argmax=None):
     """gymrl_lin_fwd: y = act(cat(x, x2) w^T + b) in one launch.  Every tensor argument may be a list (<= 4 layers of one
     shape in the same launch: twin critics, two heads on one input); returns y or the list of ys."""
     multi = isinstance(w, (list, tuple))
@@ -876,7 +883,8 @@ def lin_fwd(x, w, b, act=0, x2=None, out=None, lo=0.0, hi=0.0):
             raise ValueError("lin_fwd: shape mismatch between the items of one launch")
     items = _lin_pack(n, x=px, x2=px2, w=[_ptr(t, torch.float32).value for t in ws],
                       b=[None if t is None else _ptr(t, torch.float32).value for t in bs], y=py,
-                      act=acts, lo=_as_items(lo, n), hi=_as_items(hi, n))
+                      act=acts, lo=_as_items(lo, n), hi=_as_items(hi, n),
+                      argmax=[None if t is None else _ptr(t, torch.int32).value for t in _as_items(argmax, n)])
     check(lib().gymrl_lin_fwd(items, C.c_int(n), C.c_int(B), C.c_int(K), C.c_int(K1), C.c_int(N),
                               C.c_int(_same(ldx, "a row stride")), C.c_int(_same(ldx2, "a row stride")),
                               C.c_int(_same(ldy, "a row stride")), _stream()), "gymrl_lin_fwd")
@@ -960,9 +968,13 @@ def _noisy_layers(layers):
     for i, L in enumerate(layers):
         if L["w_mu"].shape[1] != K:
             raise ValueError("noisy layers of one launch share their input width")
-        for f, _ in NoisyLayer._fields_[:-1]:
-            t = L.get(f)
-            setattr(arr[i], f, None if t is None else _ptr(t, torch.float32).value)
+        for f, ct in NoisyLayer._fields_:
+            if ct is C.c_void_p and f != "counter_dev":
+                t = L.get(f)
+                setattr(arr[i], f, None if t is None else _ptr(t, torch.float32).value)
+        arr[i].seed, arr[i].counter, arr[i].draw = int(L.get("seed", 0)), int(L.get("counter", 0)), int(bool(L.get("draw")))
+        cd = L.get("counter_dev")
+        arr[i].counter_dev = None if cd is None else _ptr(cd).value
         arr[i].n_out = L["w_mu"].shape[0]
         rows += L["w_mu"].shape[0]
     return arr, K, rows

@@ -66,6 +66,7 @@ class NoisyLinear(nn.Module):
         self.bias_sigma = nn.Parameter(torch.empty(out_features))
         self.register_buffer("bias_epsilon", torch.zeros(out_features))
         self.raw_noise = None            # parity mode: iterator of (eps_in_raw, eps_out_raw) device tensors
+        self.dev_counters = None         # StepChunk capture: iterator of device uint64[1] draw counters (no host counter)
         self.staged = None               # hipGraph mode: [(w_eps, b_eps), ...] drawn ahead of the replay, consumed in order
         self._staged_k = 0
         self.reset_parameters()
@@ -90,7 +91,10 @@ class NoisyLinear(nn.Module):
     def reset_noise(self):
         if not self.weight_epsilon.is_cuda:
             return                        # CPU construction time: the buffers are filled on first GPU forward
-        if self.staged is not None and self._staged_k < len(self.staged):
+        if self.dev_counters is not None:
+            ops.noisy_noise(self.in_features, self.out_features, self.weight_epsilon, self.bias_epsilon, seed=self.seed,
+                            counter_dev=next(self.dev_counters))
+        elif self.staged is not None and self._staged_k < len(self.staged):
             w_eps, b_eps = self.staged[self._staged_k]
             self._staged_k += 1
             self.weight_epsilon.copy_(w_eps)
@@ -103,16 +107,26 @@ class NoisyLinear(nn.Module):
             ops.noisy_noise(self.in_features, self.out_features, self.weight_epsilon, self.bias_epsilon,
                             seed=self.seed, counter=NoisyLinear._counter)
 
-    def next_noise(self):
-        """The noise of the next training-mode forward WITHOUT touching the module's buffers where it already sits in a
-        staged tensor (hipGraph mode): -> (weight_eps, bias_eps, copy_through).  copy_through: the fused head's
-        combine launch also writes it into weight_epsilon / bias_epsilon, as reset_noise() would have."""
+    def noise_source(self):
+        """Where the next training-mode forward's noise comes from, as gymrl_noisy_combine fields — the fused head's
+        version of reset_noise(): drawn INSIDE the combine launch (Philox counter from the host, or from the device
+        while a StepChunk is being captured) and written to weight_epsilon / bias_epsilon there; copied through from a
+        staged tensor (per-update hipGraph); or, in parity mode, produced by reset_noise() from the raw draws.
+        -> (fields, (weight_eps, bias_eps) tensors the backward reads)."""
+        through = dict(w_eps_copy=self.weight_epsilon, b_eps_copy=self.bias_epsilon)
+        if self.dev_counters is not None:
+            return dict(draw=True, seed=self.seed, counter_dev=next(self.dev_counters), **through), \
+                (self.weight_epsilon, self.bias_epsilon)
         if self.staged is not None and self._staged_k < len(self.staged):
             w_eps, b_eps = self.staged[self._staged_k]
             self._staged_k += 1
-            return w_eps, b_eps, True
-        self.reset_noise()
-        return self.weight_epsilon, self.bias_epsilon, False
+            return dict(w_eps=w_eps, b_eps=b_eps, **through), (w_eps, b_eps)
+        if self.raw_noise is not None:
+            self.reset_noise()
+            return dict(w_eps=self.weight_epsilon, b_eps=self.bias_epsilon), (self.weight_epsilon, self.bias_epsilon)
+        NoisyLinear._counter += 1
+        return dict(draw=True, seed=self.seed, counter=NoisyLinear._counter, **through), \
+            (self.weight_epsilon, self.bias_epsilon)
 
     def forward(self, x):
         if self.training:
@@ -124,6 +138,9 @@ class NoisyLinear(nn.Module):
         return small_linear(x, weight, bias)
 
 
+OVERLAP_TREE = True     # sum-tree updates on a side stream beside the forward / backward passes (tools/micro_offpolicy.py A/B)
+
+
 class _NoisyDuelingHead(torch.autograd.Function):
     """advantage / value NoisyLinear streams + the dueling combination (:108-113) on the fused layer kernels
     (csrc/lin.hip): forward = one launch building both layers' effective parameters (stacked [A + 1, K]) + one Linear
@@ -132,7 +149,7 @@ class _NoisyDuelingHead(torch.autograd.Function):
     op-by-op version of the same is ~35 launches per training-mode forward + backward."""
 
     @staticmethod
-    def forward(ctx, x, adv, val, *params):
+    def forward(ctx, x, adv, val, greedy_out, *params):
         training = adv.training
         a_wmu, a_wsig, a_bmu, a_bsig, v_wmu, v_wsig, v_bmu, v_bsig = params
         layers = [dict(w_mu=a_wmu, w_sigma=a_wsig, b_mu=a_bmu, b_sigma=a_bsig),
@@ -140,14 +157,12 @@ class _NoisyDuelingHead(torch.autograd.Function):
         eps = []
         if training:
             for L, m in zip(layers, (adv, val)):
-                w_eps, b_eps, through = m.next_noise()
-                L.update(w_eps=w_eps, b_eps=b_eps)
-                if through:
-                    L.update(w_eps_copy=m.weight_epsilon, b_eps_copy=m.bias_epsilon)
-                eps += [w_eps, b_eps]
+                fields, saved = m.noise_source()
+                L.update(fields)
+                eps += list(saved)
         W, b = ops.noisy_combine(layers, training)
         x = x.contiguous()
-        q = ops.lin_fwd(x, W, b, ops.LIN_ACT["dueling"])
+        q = ops.lin_fwd(x, W, b, ops.LIN_ACT["dueling"], argmax=greedy_out)      # greedy_out i32[B]: argmax(q) on the way
         ctx.training = training
         ctx.save_for_backward(x, W, *eps)
         ctx.sinks = [getattr(p, "_gymrl_sink", None) for p in params]
@@ -160,7 +175,7 @@ class _NoisyDuelingHead(torch.autograd.Function):
         dS = ops.dueling_bwd(dq.contiguous())
         dx = ops.lin_bwd_input(dS, None, W)[0] if ctx.needs_input_grad[0] else None
         grads = [None] * 8
-        if any(ctx.needs_input_grad[3:]):
+        if any(ctx.needs_input_grad[4:]):
             dW, db = torch.empty_like(W), torch.empty(W.shape[0], dtype=W.dtype, device=W.device)
             ops.lin_bwd_weight(dS, None, x, dW, db)
             # destinations: the flat gradient buffer's views when every parameter's GradSink is armed, fresh tensors otherwise
@@ -184,7 +199,7 @@ class _NoisyDuelingHead(torch.autograd.Function):
                     L.update(w_sigma=dst[4 * i + 1], b_sigma=dst[4 * i + 3], w_eps=eps[2 * i], b_eps=eps[2 * i + 1])
                 layers.append(L)
             ops.noisy_split(layers, dW, db, ctx.training, accumulate=acc)
-        return (dx, None, None, *grads)
+        return (dx, None, None, None, *grads)
 
 
 class DuelingNoisyNetwork(nn.Module):
@@ -195,14 +210,18 @@ class DuelingNoisyNetwork(nn.Module):
         self.advantage = NoisyLinear(hidden_dim, action_dim, seed=seed)
         self.value = NoisyLinear(hidden_dim, 1, seed=seed + 1)
 
-    def forward(self, x):
+    def forward(self, x, greedy_out=None):
+        """greedy_out: optional i32[B] that receives argmax(q) (select_action's greedy action) from the head's launch."""
         x = self.fc2(self.fc1(x))
         a, v = self.advantage, self.value
         if gnn.FUSED_LINEAR and x.is_cuda and a.out_features + 1 <= 16:
-            return _NoisyDuelingHead.apply(x, a, v, a.weight_mu, a.weight_sigma, a.bias_mu, a.bias_sigma,
+            return _NoisyDuelingHead.apply(x, a, v, greedy_out, a.weight_mu, a.weight_sigma, a.bias_mu, a.bias_sigma,
                                            v.weight_mu, v.weight_sigma, v.bias_mu, v.bias_sigma)
         advantage, value = self.advantage(x), self.value(x)
-        return value + (advantage - advantage.mean(dim=-1, keepdim=True))
+        q = value + (advantage - advantage.mean(dim=-1, keepdim=True))
+        if greedy_out is not None:
+            greedy_out.copy_(q.argmax(dim=-1))
+        return q
 
 
 class SumTree:
@@ -222,9 +241,9 @@ class SumTree:
     def update_batch(self, idx, prio):
         ops.per_update(self.tree, self.capacity, idx.numel(), self._ws, idx=idx, prio=prio)
 
-    def update_range(self, start, n, priority=None, priority_dev=None):
+    def update_range(self, start, n, priority=None, priority_dev=None, start_dev=None):
         ops.per_update(self.tree, self.capacity, n, self._ws, idx_start=start, prio_scalar=priority or 0.0,
-                       prio_scalar_dev=priority_dev)
+                       prio_scalar_dev=priority_dev, idx_start_dev=start_dev)
 
     @property
     def priority_sum(self):
@@ -256,22 +275,63 @@ class PrioritizedNStepBuffer:
                      torch.zeros(self.capacity, dtype=torch.uint8, device=d))
         self.current_size, self.count, self.pushes = 0, 0, 0
         self.seed, self.draws = seed, 0
+        self._tree_ahead = None        # side stream on which stage_tree() wrote the next store's priorities
 
-    def store_transition(self, state, action, reward, next_state, terminal, done):
-        """:179-205 for N rows [N, ...]; new rows get priority 1.0 (empty buffer) or priority_max."""
+    def _new_rows_priorities(self, dev=None):
+        if dev is not None:                       # StepChunk capture: the cursor of each replay lives on the device
+            self.sum_tree.update_range(0, self.N, priority_dev=self.sum_tree.priority_max, start_dev=dev)
+        elif self.current_size == 0:
+            self.sum_tree.update_range(self.count, self.N, priority=1.0)
+        else:
+            self.sum_tree.update_range(self.count, self.N, priority_dev=self.sum_tree.priority_max)
+
+    def stage_tree(self, stream, dev=None, chain=False):
+        """The sum-tree half of the NEXT store_transition() — priority_max and the N new leaves with their ancestors,
+        which depend on the ring cursor but not on the transitions themselves — issued now on `stream`, so that it
+        runs beside the acting forward + env step + n-step push of the same vector step (the root's additions are one
+        dependent chain of N float64 adds by the reference's order: ~0.1 ms on one CU at N = 8192)."""
+        if self._tree_ahead is not None or (dev is None and self.pushes + 1 < self.n_steps) or not OVERLAP_TREE:
+            return
+        if not chain:      # chain: the tree's previous writer (update_priorities) ran on `stream` itself, after the last reader
+            stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            self._new_rows_priorities(None if dev is None else dev[8:16])
+        self._tree_ahead = stream
+
+    def store_transition(self, state, action, reward, next_state, terminal, done, dev=None, ep_len=None, max_len=0):
+        """:179-205 for N rows [N, ...]; new rows get priority 1.0 (empty buffer) or priority_max.
+        dev (StepChunk capture): device record {pushes, cursor} of the replayed step; the host cursors are advanced by
+        the trainer's staging loop instead, and the window is known to be full."""
+        if dev is not None:
+            ops.nstep_push(self.win, self.n_steps, self.n_steps, self.gamma, state, action, reward, next_state,
+                           terminal, done, self.ring, 0, dev=dev, ep_len=ep_len, max_episode_steps=max_len)
+            if self._tree_ahead is not None:
+                torch.cuda.current_stream().wait_stream(self._tree_ahead)
+                self._tree_ahead = None
+            else:
+                self._new_rows_priorities(dev[8:16])
+            return
         emitted = ops.nstep_push(self.win, self.n_steps, self.pushes, self.gamma, state, action, reward, next_state,
                                  terminal, done, self.ring, self.count)
         self.pushes += 1
         if emitted:
-            if self.current_size == 0:
-                self.sum_tree.update_range(self.count, self.N, priority=1.0)
+            if self._tree_ahead is not None:
+                torch.cuda.current_stream().wait_stream(self._tree_ahead)
+                self._tree_ahead = None
             else:
-                self.sum_tree.update_range(self.count, self.N, priority_dev=self.sum_tree.priority_max)
+                self._new_rows_priorities()
             self.count = (self.count + self.N) % self.capacity
             self.current_size = min(self.current_size + self.N, self.capacity)
+        elif self._tree_ahead is not None:
+            raise RuntimeError("stage_tree() ran ahead of a push that emitted nothing")
 
-    def draw(self, total_steps, max_train_steps, u=None, out=None):
-        """The proportional draw of :220-243 -> (batch_index i32[B], is_weight f32[B]); `out` = fixed (idx, prio, w)."""
+    def draw(self, total_steps, max_train_steps, u=None, out=None, dev=None):
+        """The proportional draw of :220-243 -> (batch_index i32[B], is_weight f32[B]); `out` = fixed (idx, prio, w).
+        dev (StepChunk capture): device record {counter, size, beta} of the replayed step."""
+        if dev is not None:
+            idx, _, w = ops.per_sample(self.sum_tree.tree, self.capacity, self.batch_size, 1, 0.0, self.sum_tree._ws,
+                                       seed=self.seed, out=out, dev=dev)
+            return idx, w
         self.beta = self.beta_init + (1 - self.beta_init) * (total_steps / max_train_steps)
         self.draws += 1
         idx, _, w = ops.per_sample(self.sum_tree.tree, self.capacity, self.batch_size, self.current_size, self.beta,
@@ -328,6 +388,7 @@ class RainbowDQNTrainer:
         self.flat_params, self.flat_grads = flatten_module(self.policy_net, self.device)
         self.target_flat, _ = flatten_module(self.target_net, self.device)
         self.target_net.eval()
+        self._side = torch.cuda.Stream(device=self.device)
         self._sink = GradSink(self.policy_net)
         self.optimizer = FusedAdam(self.flat_params, self.flat_grads, lr=config.lr, eps=1e-8,
                                    max_grad_norm=config.grad_clip)
@@ -339,16 +400,18 @@ class RainbowDQNTrainer:
         self._graph = None             # hipGraph of the update, captured on first use (update_async)
 
     @torch.no_grad()
-    def select_action(self, state, deterministic=False):
-        """:293-309 for a batch [N, D]: greedy on the noisy Q (no epsilon)."""
-        if not deterministic:
+    def select_action(self, state, deterministic=False, count=True):
+        """:293-309 for a batch [N, D]: greedy on the noisy Q (no epsilon).  count=False: the caller advances
+        total_steps itself (StepChunk staging)."""
+        if not deterministic and count:
             self.total_steps += state.shape[0]
         if deterministic:
             self.policy_net.eval()
-        q = self.policy_net(state)
+        action = torch.empty(state.shape[0], dtype=torch.int32, device=state.device)
+        self.policy_net(state, greedy_out=action)
         if deterministic:
             self.policy_net.train()
-        return q.argmax(dim=-1).to(torch.int32)
+        return action
 
     def update(self, u=None):
         """:311-361.  Returns the loss as a python float."""
@@ -362,30 +425,52 @@ class RainbowDQNTrainer:
         self._anneal_lr()
         return float(self._loss.item()) / cfg.batch_size
 
-    def _update_body(self, batch_index, is_weight, bias=None):
-        """Everything after the proportional draw; bias = f32[4] device view of Adam's step scalars under a hipGraph."""
+    def _update_body(self, batch_index, is_weight, bias=None, join=True):
+        """Everything after the proportional draw; bias = f32[4] device view of Adam's step scalars under a hipGraph.
+        join=False (inside a StepChunk): the side stream keeps the sum tree — it goes straight on to the next vector
+        step's new rows (stage_tree(chain=True)) and is joined when that step stores its transitions."""
         cfg = self.cfg
-        batch = self.memory.gather(batch_index)
+        state, action, reward, next_state, terminal = ops.replay_gather(self.memory.ring, batch_index)
         with torch.no_grad():
-            q_next_online = self.policy_net(batch["next_state"])          # fresh noise (:320)
-            q_next_target = self.target_net(batch["next_state"])          # eval mode: mu weights only
-        q = self.policy_net(batch["state"])                               # fresh noise again (:334)
+            q_next_online = self.policy_net(next_state)                   # fresh noise (:320)
+            q_next_target = self.target_net(next_state)                   # eval mode: mu weights only
+        q = self.policy_net(state)                                        # fresh noise again (:334)
         self._loss.zero_()
-        td, dq = ops.dqn_td_loss(q, q_next_target, batch["action"].view(-1).to(torch.int32), batch["reward"],
-                                 batch["terminal"], cfg.gamma ** cfg.n_steps, q_next_online=q_next_online,
-                                 w=is_weight, loss_sum=self._loss)
-        self.memory.update_priorities(batch_index, td)                    # before backward (:340)
+        td, dq = ops.dqn_td_loss(q, q_next_target, action.view(-1), reward, terminal, cfg.gamma ** cfg.n_steps,
+                                 q_next_online=q_next_online, w=is_weight, loss_sum=self._loss)
+        # :340 update_priorities before backward — nothing below reads the tree, so it runs on a side stream (a fork
+        # inside the captured graph) beside the backward pass, Adam and the Polyak update, and joins at the end
+        # (the main path's launches are issued first: the graph executor keeps the first-recorded branch on the
+        # queue it was on and wakes another queue for the second, which costs that branch 30-60 us)
+        main, side = torch.cuda.current_stream(), self._side if OVERLAP_TREE else torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(main)
         self._sink.arm()
         q.backward(dq)
         self._sink.collect()
         self.optimizer.step(bias_dev=bias)                                # clip_grad_norm_(10) + Adam
         ops.soft_update(self.target_flat, self.flat_params, cfg.tau)      # :347-352 (parameters only)
+        with torch.cuda.stream(side):
+            side.wait_event(fork)
+            self.memory.update_priorities(batch_index, td)
+        if join:
+            main.wait_stream(side)
+        else:
+            self._tree_keep = (td, batch_index)       # read on the side stream: alive until the next join
 
     def _anneal_lr(self):
         cfg = self.cfg
         lr_now = 0.9 * cfg.lr * (1 - self.total_steps / self.max_train_steps) + 0.1 * cfg.lr     # :354-356
         for param_group in self.optimizer.param_groups:
             param_group["lr"] = lr_now
+
+    def _draw_buffers(self):
+        """Fixed (index, priority, weight) buffers of the proportional draw: captured graphs hold their addresses."""
+        if getattr(self, "_g_draw", None) is None:
+            B, d = self.cfg.batch_size, self.device
+            self._g_draw = (torch.empty(B, dtype=torch.int32, device=d), torch.empty(B, dtype=torch.float64, device=d),
+                            torch.empty(B, dtype=torch.float32, device=d))
+        return self._g_draw
 
     def update_async(self):
         """update() without the host round trip: the counter-keyed launches (proportional draw, NoisyNet noise of the
@@ -397,9 +482,7 @@ class RainbowDQNTrainer:
             from .graphs import GraphedStep, StepScalars
             self._scalars = StepScalars(self.device)
             bias, self._off = self._scalars.slot(16, torch.float32)
-            B, d = cfg.batch_size, self.device
-            self._g_draw = (torch.empty(B, dtype=torch.int32, device=d), torch.empty(B, dtype=torch.float64, device=d),
-                            torch.empty(B, dtype=torch.float32, device=d))
+            self._draw_buffers()
             self._graph = GraphedStep(lambda: self._update_body(self._g_draw[0], self._g_draw[2], bias=bias))
         m.draw(self.total_steps, self.max_train_steps, out=self._g_draw)
         layers = (self.policy_net.advantage, self.policy_net.value)
@@ -445,31 +528,113 @@ class RainbowDQNTrainer:
         with small_gemm_backend(backend, getattr(self.cfg, "tune_gemms", False)):
             return self._train(max_vector_steps)
 
+    CHUNK = 16     # vector steps per StepChunk replay (= the episode tracker's flush period)
+
+    def _loop_buffers(self, N, D):
+        """Step buffers that outlive one train() call: the captured StepChunk graph holds their addresses."""
+        lb = getattr(self, "_loop", None)
+        if lb is None or lb["N"] != N:
+            d = self.device
+            lb = self._loop = dict(N=N, obs=torch.empty(N, D, device=d), nxt=torch.empty(N, D, device=d),
+                                   tobs=torch.empty(N, D, device=d), rew=torch.empty(N, device=d),
+                                   term=torch.zeros(N, dtype=torch.uint8, device=d),
+                                   ep_len=torch.zeros(N, dtype=torch.int32, device=d),
+                                   term_b=torch.zeros(N, dtype=torch.bool, device=d),
+                                   tracker=EpisodeTracker(N, d, flush_every=1 if N == 1 else self.CHUNK))
+        lb["tracker"].k, lb["tracker"].episodes = 0, 0
+        return lb
+
+    def _vector_step(self, lb, obs, nxt, ep_ret, done, rec=None, chain=False):
+        """One vector step of :363-405 up to (not including) the update.  rec: this step's StepChunk record views
+        when the step is being captured (every per-step scalar then comes from the device)."""
+        env, m = self.env, self.memory
+        push = None if rec is None else rec["push"]
+        m.stage_tree(self._side, dev=push, chain=chain)   # this step's new priorities, beside the acting forward + env step
+        if rec is not None:
+            for layer, c in ((self.policy_net.advantage, rec["noise"][0:8]), (self.policy_net.value, rec["noise"][8:16])):
+                layer.dev_counters = iter([c])
+        action = self.select_action(obs) if rec is None else self.select_action(obs, count=False)
+        env.step(action, nxt, lb["rew"], done_out=done, term_obs_out=lb["tobs"], ep_ret_out=ep_ret, ep_len_out=lb["ep_len"])
+        # :376 terminal = done and step != max_steps_per_episode - 1: decided by the step INDEX inside the
+        # episode, not by gymnasium's terminated flag (a pole that falls exactly on the last step of the
+        # time limit is stored as non-terminal, an early truncation as terminal)
+        if rec is None:
+            torch.logical_and(done.bool(), lb["ep_len"] != self.max_steps_per_episode, out=lb["term_b"])
+            lb["term"].copy_(lb["term_b"])
+            m.store_transition(obs, action, lb["rew"], lb["tobs"], lb["term"], done)
+        else:                                                        # the same flag, formed inside the n-step push
+            m.store_transition(obs, action, lb["rew"], lb["tobs"], None, done, dev=push, ep_len=lb["ep_len"],
+                               max_len=self.max_steps_per_episode)
+
+    def _chunk_body(self, lb, j):
+        """Vector step j of a StepChunk capture: acting + env + store + proportional draw + update, every per-step
+        scalar read from record j."""
+        ch, tr = self._chunk, lb["tracker"]
+        rec = {"noise": ch.view(j, "noise"), "push": ch.view(j, "push")}
+        obs, nxt = (lb["obs"], lb["nxt"]) if j % 2 == 0 else (lb["nxt"], lb["obs"])
+        self._vector_step(lb, obs, nxt, tr.ret[j], tr.done[j], rec, chain=j > 0 and OVERLAP_TREE)
+        self.memory.draw(0, 1, out=self._g_draw, dev=ch.view(j, "sample"))
+        noise = ch.view(j, "noise")
+        layers = (self.policy_net.advantage, self.policy_net.value)
+        for i, layer in enumerate(layers):             # the eager order: (advantage, value) per training-mode forward
+            layer.dev_counters = iter([noise[16 + 8 * i:24 + 8 * i], noise[32 + 8 * i:40 + 8 * i]])
+        self._update_body(self._g_draw[0], self._g_draw[2], bias=ch.view(j, "adam", torch.float32),
+                          join=j == ch.K - 1 or not OVERLAP_TREE)
+        for layer in layers:
+            layer.dev_counters = None
+
+    def _stage_chunk(self):
+        """The host's bookkeeping of the next CHUNK vector steps, in the eager loop's order, written into the records."""
+        ch, m, N = self._chunk, self.memory, self.env.n
+        for j in range(ch.K):
+            c = NoisyLinear._counter                     # acting forward: +1, +2; the update's two forwards: +3 .. +6
+            ch.set(j, "noise", *(c + 1 + i for i in range(6)))
+            NoisyLinear._counter += 6
+            self.total_steps += N                        # select_action
+            ch.set(j, "push", m.pushes, m.count)         # store_transition
+            m.pushes += 1
+            m.count = (m.count + N) % m.capacity
+            m.current_size = min(m.current_size + N, m.capacity)
+            m.beta = m.beta_init + (1 - m.beta_init) * (self.total_steps / self.max_train_steps)      # draw
+            m.draws += 1
+            ch.set(j, "sample", m.draws, m.current_size, m.beta)
+            ch.set_bytes(j, "adam", self.optimizer.next_bias())      # update: Adam with the current rate, then the anneal
+            self._anneal_lr()
+        ch.flush()
+
     def _train(self, max_vector_steps=None):
-        """:363-405 with N lock-stepped envs."""
+        """:363-405 with N lock-stepped envs.  With hipGraphs on, CHUNK whole vector steps (acting, env step, n-step
+        store, sum-tree updates, proportional draw, update) replay as one graph (gymrl_amd/graphs.py StepChunk)."""
         cfg, env = self.cfg, self.env
         N, D = env.n, env.obs_dim
-        obs, nxt, tobs = (torch.empty(N, D, device=self.device) for _ in range(3))
-        rew = torch.empty(N, device=self.device)
-        term = torch.zeros(N, dtype=torch.uint8, device=self.device)
-        ep_len = torch.zeros(N, dtype=torch.int32, device=self.device)
-        term_b = torch.zeros(N, dtype=torch.bool, device=self.device)
-        tracker = EpisodeTracker(N, self.device, flush_every=1 if N == 1 else 16)
+        lb = self._loop_buffers(N, D)
+        obs, nxt, tracker = lb["obs"], lb["nxt"], lb["tracker"]
         env.reset(obs)
         step = 0
         graphed = (bool(getattr(cfg, "use_graphs", True)) and self._parity_u is None
                    and self.policy_net.advantage.raw_noise is None)
+        chunked = graphed and N > 1 and cfg.updates_per_step == 1 and (self.memory.capacity & (self.memory.capacity - 1)) == 0 \
+            and self.memory.capacity % N == 0
         limit = max_vector_steps or (cfg.max_episodes * cfg.max_steps // N + 1)
         while tracker.episodes < cfg.max_episodes and step < limit:
-            action = self.select_action(obs)
+            m = self.memory
+            if (chunked and tracker.k == 0 and limit - step >= self.CHUNK and obs is lb["obs"] and m.pushes + 1 >= m.n_steps
+                    and m.current_size >= max(cfg.batch_size, 1) and m.count % N == 0):
+                if getattr(self, "_chunk", None) is None:
+                    from .graphs import StepChunk
+                    self._chunk = StepChunk(self.device, self.CHUNK, [("noise", "6Q"), ("push", "2q"), ("sample", "Qqd"),
+                                                                      ("adam", "4f")])
+                    self._draw_buffers()
+                self._stage_chunk()
+                self._chunk.run(lambda j: self._chunk_body(lb, j), key=(id(env), env.state.data_ptr()))
+                step += self.CHUNK
+                tracker.k = self.CHUNK
+                tracker.flush(self.episode_rewards)
+                if len(self.episode_rewards) >= 100 and np.mean(self.episode_rewards) >= 495.0:
+                    break
+                continue
             ep_ret, done = tracker.slot()
-            env.step(action, nxt, rew, done_out=done, term_obs_out=tobs, ep_ret_out=ep_ret, ep_len_out=ep_len)
-            # :376 terminal = done and step != max_steps_per_episode - 1: decided by the step INDEX inside the
-            # episode, not by gymnasium's terminated flag (a pole that falls exactly on the last step of the
-            # time limit is stored as non-terminal, an early truncation as terminal)
-            torch.logical_and(done.bool(), ep_len != self.max_steps_per_episode, out=term_b)
-            term.copy_(term_b)
-            self.memory.store_transition(obs, action, rew, tobs, term, done)
+            self._vector_step(lb, obs, nxt, ep_ret, done)
             for _ in range(cfg.updates_per_step):
                 if graphed:
                     self.update_async()

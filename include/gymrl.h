@@ -330,8 +330,21 @@ int gymrl_gather_minibatch(const float* packed, const int32_t* idx, int B, int o
  *   step-dependent scalars of the update.  With it (and `step` ignored) a hipGraph captured around the
  *   optimiser step replays unchanged; the host refreshes the block before each replay with
  *   gymrl_adam_bias (host arithmetic, identical to the eager path's) + gymrl_store_scalars.
- *   gymrl_store_scalars: copies nbytes <= 256 (multiple of 4) of host scalars into device memory as ONE
+ *   gymrl_store_scalars: copies nbytes <= 3840 (multiple of 4) of host scalars into device memory as ONE
  *   launch whose payload is the kernel argument (stream-ordered, nothing to fence, not capturable state).
+ *
+ * Per-step scalars on the device.  Entry points whose arguments change every vector step — ring cursors, Philox
+ * draw counters, the PER exponent — take a trailing `*_dev` / `dev` pointer (NULL on the plain path): when given,
+ * the kernel reads those values from DEVICE memory instead of its host arguments, so the launch can be recorded
+ * into a hipGraph and replayed with new values that the host stages beforehand with ONE gymrl_store_scalars for a
+ * whole chunk of vector steps (gymrl_amd/graphs.py StepChunk: acting, env step, ring append, index draw and update
+ * of 16 vector steps = one scalar store + one graph launch).  Layouts (8-byte aligned):
+ *   gymrl_replay_append   cursor_dev     int64[1]  {cursor}
+ *   gymrl_uniform_indices dev            {uint64 counter; int64 size}
+ *   gymrl_nstep_push      dev            int64[2]  {pushes, cursor}   (the return value follows the HOST pushes)
+ *   gymrl_per_update      idx_start_dev  int64[1]  {idx_start}        (idx == NULL only)
+ *   gymrl_per_sample      dev            {uint64 counter; int64 size; double beta}
+ *   gymrl_noisy_noise     counter_dev    uint64[1] {counter}
  */
 int gymrl_sqnorm(const float* g, int64_t n, float grad_scale, double* sqnorm_out,
                  void* workspace, void* stream);
@@ -472,6 +485,8 @@ typedef struct {
   float* db;
   int act;            /* GYMRL_ACT_*; clamp bounds in lo / hi */
   float lo, hi;
+  int32_t* argmax;    /* fwd with GYMRL_ACT_DUELING only: NULL, or i32[B] = first index of the row maximum of q (the greedy
+                         action, torch.argmax's tie rule) */
 } gymrl_lin_item;
 size_t gymrl_lin_workspace_bytes(int B, int N, int K, int n_items);
 int gymrl_lin_fwd(const gymrl_lin_item* items, int n_items, int B, int K, int K1, int N, int ldx, int ldx2, int ldy,
@@ -498,6 +513,10 @@ typedef struct {
   const float* b_mu; const float* b_sigma; const float* b_eps;      /* [n_out] */
   float* w_eps_copy; float* b_eps_copy;                             /* combine only, NULL: no copy */
   float* dw_mu; float* dw_sigma; float* db_mu; float* db_sigma;     /* split only */
+  uint64_t seed, counter;                                           /* combine with draw != 0 */
+  const uint64_t* counter_dev;                                      /* NULL, or the counter in device memory (graphs) */
+  int draw;            /* combine: draw this layer's noise in the launch itself — bit for bit gymrl_noisy_noise(seed,
+                          counter) — instead of reading w_eps / b_eps; it is written to w_eps_copy / b_eps_copy (required) */
   int n_out;
 } gymrl_noisy_layer;
 int gymrl_noisy_combine(const gymrl_noisy_layer* layers, int n_layers, int K, int training, float* W_out, float* b_out,
@@ -631,7 +650,8 @@ int gymrl_linear_bwd_weight(const float* dY, const float* X, int64_t B, int N, i
 int gymrl_replay_append(float* state, uint32_t* action, float* reward, float* next_state,
                         uint8_t* flag, int64_t cap, int64_t cursor, int D, int AW, int n,
                         const float* src_state, const void* src_action, const float* src_reward,
-                        const float* src_next_state, const uint8_t* src_flag, void* stream);
+                        const float* src_next_state, const uint8_t* src_flag, const int64_t* cursor_dev,
+                        void* stream);
 /* rows idx[b] -> contiguous batch (torch.tensor(np.array(...)) of dqn_cartpole.py:143-155) */
 int gymrl_replay_gather(const float* state, const uint32_t* action, const float* reward,
                         const float* next_state, const uint8_t* flag, const int32_t* idx, int B,
@@ -641,7 +661,7 @@ int gymrl_replay_gather(const float* state, const uint32_t* action, const float*
  * (utils/buffer.py:127): B DISTINCT uniform rows — idx[b] = the b-th element of a keyed permutation of
  * [0, size) (the Feistel/Philox bijection of gymrl_permutation, keyed by (seed, counter)); B <= size. */
 int gymrl_uniform_indices(uint64_t seed, uint64_t counter, int64_t size, int B,
-                          int32_t* idx_out, void* stream);
+                          int32_t* idx_out, const void* dev, void* stream);
 
 /*
  * S2: PrioritizedNStepBuffer.store_transition + _get_n_step_transition —
@@ -654,6 +674,8 @@ int gymrl_uniform_indices(uint64_t seed, uint64_t counter, int64_t size, int B,
  *   R = sum via R = r_i + gamma*(1-d_i)*R (float64, newest to oldest, :212-214),
  *   (next_state, terminal) from the newest entry unless some d_i, then from the
  *   EARLIEST done (:215-216).  Returns 1 if rows were emitted, 0 if still filling, <0 error.
+ * terminal NULL: the flag is formed here as the reference's loop does (:376): done[e] && ep_len[e] != max_episode_steps
+ * (ep_len i32[N] = the env's step index inside its episode, as gymrl_env_step reports it).
  */
 int gymrl_nstep_push(float* w_state, int32_t* w_action, float* w_reward, float* w_next,
                      uint8_t* w_terminal, uint8_t* w_done, int n_steps, int64_t pushes,
@@ -661,7 +683,8 @@ int gymrl_nstep_push(float* w_state, int32_t* w_action, float* w_reward, float* 
                      const float* obs, const int32_t* action, const float* reward,
                      const float* next_obs, const uint8_t* terminal, const uint8_t* done,
                      float* r_state, uint32_t* r_action, float* r_reward, float* r_next,
-                     uint8_t* r_flag, int64_t cap, int64_t cursor, void* stream);
+                     uint8_t* r_flag, int64_t cap, int64_t cursor, const int64_t* dev, const int32_t* ep_len,
+                     int max_episode_steps, void* stream);
 
 /*
  * S1 / S1': SumTree — rainbow_dqn_cartpole.py:116-152 (variant A) and
@@ -687,14 +710,14 @@ int gymrl_nstep_push(float* w_state, int32_t* w_action, float* w_reward, float* 
 size_t gymrl_per_workspace_bytes(int B);
 int gymrl_per_update(double* tree, int64_t cap, const int32_t* idx, int64_t idx_start,
                      int idx_is_tree, const double* prio, const double* prio_scalar_dev,
-                     double prio_scalar, int B, void* workspace, void* stream);
+                     double prio_scalar, int B, const int64_t* idx_start_dev, void* workspace, void* stream);
 int gymrl_per_max_leaf(const double* tree, int64_t cap, double* out, void* workspace,
                        void* stream);
 int gymrl_per_priorities(const float* td, int B, double alpha, double eps, double clip,
                          double* prio_out, void* stream);
 int gymrl_per_sample(const double* tree, int64_t cap, const double* u, uint64_t seed,
                      uint64_t counter, int B, int64_t size, double beta, int variant_b,
-                     int32_t* idx_out, double* prio_out, float* w_out, void* workspace,
+                     int32_t* idx_out, double* prio_out, float* w_out, const void* dev, void* workspace,
                      void* stream);
 
 /* R1: NoisyLinear.scale_noise + reset_noise — rainbow_dqn_cartpole.py:77-87.
@@ -702,7 +725,7 @@ int gymrl_per_sample(const double* tree, int64_t cap, const double* u, uint64_t 
  * eps_in/eps_out raw N(0,1) f32 (parity mode) or NULL -> Box-Muller on Philox(seed, counter). */
 int gymrl_noisy_noise(const float* eps_in_raw, const float* eps_out_raw, uint64_t seed,
                       uint64_t counter, int in_features, int out_features, float* w_eps_out,
-                      float* b_eps_out, void* stream);
+                      float* b_eps_out, const uint64_t* counter_dev, void* stream);
 
 /* D3: epsilon-greedy action selection for N envs — dqn_cartpole.py:117-133.
  * u f32[N,2] uniforms (or NULL -> Philox): u[.,0] < eps -> action = floor(u[.,1]*A) else argmax q. */

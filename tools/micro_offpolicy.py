@@ -54,6 +54,7 @@ def main():
             c.num_envs, c.memory_capacity, c.max_episodes, c.batch_size = N, 1 << 20, 10**9, B
             c.use_graphs, c.gemm_backend, c.tune_gemms = graphs, backend, tune
             gnn.SPLIT_BIAS, gnn.FUSED_LINEAR = True, fused
+            rainbow_dqn_cartpole.OVERLAP_TREE = not os.environ.get("GYMRL_NO_OVERLAP")
             tr = getattr(mod, cls)(c)
             steps = 300
             dt = run(tr, steps, 60)
