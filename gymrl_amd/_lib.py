@@ -67,7 +67,7 @@ class NoisyLayer(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ("w_mu", "w_sigma", "w_eps", "b_mu", "b_sigma", "b_eps", "w_eps_copy", "b_eps_copy",
                                           "dw_mu", "dw_sigma", "db_mu", "db_sigma")] +
                 [("seed", C.c_uint64), ("counter", C.c_uint64), ("counter_dev", C.c_void_p), ("draw", C.c_int),
-                 ("n_out", C.c_int)])
+                 ("eval", C.c_int), ("n_out", C.c_int)])
 
 
 class PPOCfg(C.Structure):

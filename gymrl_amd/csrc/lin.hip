@@ -408,6 +408,7 @@ struct NoisyArgs {
   float* w_eps_copy[kNoisyLayers]; float* b_eps_copy[kNoisyLayers];
   uint64_t seed[kNoisyLayers], counter[kNoisyLayers]; const uint64_t* counter_dev[kNoisyLayers];
   int draw[kNoisyLayers];           // combine: generate this layer's noise here (w_eps / b_eps are not read)
+  int eval[kNoisyLayers];           // this layer contributes its mu only (a target network beside training-mode layers)
   float* dw_mu[kNoisyLayers]; float* dw_sigma[kNoisyLayers]; float* db_mu[kNoisyLayers]; float* db_sigma[kNoisyLayers];
   int row0[kNoisyLayers + 1];       // first stacked row of each layer
   int n_layers, K, training, accumulate;
@@ -427,14 +428,15 @@ __global__ __launch_bounds__(256) void noisy_combine_kernel(const NoisyArgs a) {
     // draw: NoisyLinear.reset_noise() of this forward happens here — the very values gymrl_noisy_noise writes
     float fj = 0.0f;
     uint64_t ctr = 0;
-    if (a.training && a.draw[l]) {
+    const bool training = a.training && !a.eval[l];
+    if (training && a.draw[l]) {
       ctr = a.counter_dev[l] ? a.counter_dev[l][0] : a.counter[l];
       fj = scale_noise(box_muller(a.seed[l], ctr, 1u, (uint32_t)n));
     }
     if (k < a.K) {
       const size_t o = (size_t)n * a.K + k;
       float w = a.w_mu[l][o];
-      if (a.training) {
+      if (training) {
         const float e = a.draw[l] ? fj * scale_noise(box_muller(a.seed[l], ctr, 0u, (uint32_t)k)) : a.w_eps[l][o];
         w = w + a.w_sigma[l][o] * e;
         if (a.w_eps_copy[l]) a.w_eps_copy[l][o] = e;
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(256) void noisy_combine_kernel(const NoisyArgs a) {
       a.W[(size_t)row * a.K + k] = w;
     } else {
       float bv = a.b_mu[l][n];
-      if (a.training) {
+      if (training) {
         const float e = a.draw[l] ? fj : a.b_eps[l][n];
         bv = bv + a.b_sigma[l][n] * e;
         if (a.b_eps_copy[l]) a.b_eps_copy[l][n] = e;
@@ -609,10 +611,11 @@ static int noisy_fill(NoisyArgs& a, const gymrl_noisy_layer* layers, int n_layer
   int rows = 0;
   for (int l = 0; l < n_layers; ++l) {
     const gymrl_noisy_layer& L = layers[l];
-    if (!L.w_mu || !L.b_mu || L.n_out < 1 || (training && (!L.w_sigma || !L.b_sigma))) return -22;
-    if (training && !L.draw && (!L.w_eps || !L.b_eps)) return -22;
-    if (training && L.draw && (!L.w_eps_copy || !L.b_eps_copy)) return -22;      // the drawn noise must land somewhere
-    a.seed[l] = L.seed; a.counter[l] = L.counter; a.counter_dev[l] = L.counter_dev; a.draw[l] = L.draw;
+    const bool tr = training && !L.eval;
+    if (!L.w_mu || !L.b_mu || L.n_out < 1 || (tr && (!L.w_sigma || !L.b_sigma))) return -22;
+    if (tr && !L.draw && (!L.w_eps || !L.b_eps)) return -22;
+    if ((L.w_eps_copy == nullptr) != (L.b_eps_copy == nullptr)) return -22;
+    a.seed[l] = L.seed; a.counter[l] = L.counter; a.counter_dev[l] = L.counter_dev; a.draw[l] = L.draw; a.eval[l] = L.eval;
     a.w_mu[l] = L.w_mu; a.w_sigma[l] = L.w_sigma; a.w_eps[l] = L.w_eps;
     a.b_mu[l] = L.b_mu; a.b_sigma[l] = L.b_sigma; a.b_eps[l] = L.b_eps;
     a.w_eps_copy[l] = L.w_eps_copy; a.b_eps_copy[l] = L.b_eps_copy;

@@ -79,14 +79,23 @@ class ReplayBuffer:
                      torch.zeros(capacity, dtype=torch.uint8, device=device))
         self.cursor, self.size, self.seed, self.draws = 0, 0, seed, 0
 
-    def push(self, state, action, reward, next_state, done):
+    def push(self, state, action, reward, next_state, done, cursor_dev=None):
+        """cursor_dev (StepChunk capture): device int64[1] cursor of the replayed step; the host cursor is advanced by
+        the trainer's staging loop (advance()) instead."""
         n = reward.numel()
-        ops.replay_append(self.ring, self.cursor, state, action.view(n, -1), reward, next_state, done)
+        ops.replay_append(self.ring, self.cursor, state, action.view(n, -1), reward, next_state, done, cursor_dev=cursor_dev)
+        if cursor_dev is None:
+            self.advance(n)
+
+    def advance(self, n):
         self.cursor = (self.cursor + n) % self.capacity
         self.size = min(self.size + n, self.capacity)
 
-    def draw_indices(self, batch_size, out=None):
-        """random.sample's role: one uniform index draw per call (counter-keyed Philox); `out` = fixed buffer."""
+    def draw_indices(self, batch_size, out=None, dev=None):
+        """random.sample's role: one uniform index draw per call (counter-keyed Philox); `out` = fixed buffer.
+        dev (StepChunk capture): device record {counter, size} of the replayed step."""
+        if dev is not None:
+            return ops.uniform_indices(self.seed, 0, self.capacity, batch_size, self.device, out=out, dev=dev)
         idx = ops.uniform_indices(self.seed, self.draws, self.size, min(batch_size, self.size), self.device, out=out)
         self.draws += 1
         return idx

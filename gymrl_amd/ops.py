@@ -973,6 +973,7 @@ def _noisy_layers(layers):
                 t = L.get(f)
                 setattr(arr[i], f, None if t is None else _ptr(t, torch.float32).value)
         arr[i].seed, arr[i].counter, arr[i].draw = int(L.get("seed", 0)), int(L.get("counter", 0)), int(bool(L.get("draw")))
+        arr[i].eval = int(bool(L.get("eval")))
         cd = L.get("counter_dev")
         arr[i].counter_dev = None if cd is None else _ptr(cd).value
         arr[i].n_out = L["w_mu"].shape[0]

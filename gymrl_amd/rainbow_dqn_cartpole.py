@@ -48,6 +48,9 @@ class Config:
         self.gemm_backend = "auto"            # library for the update's small-M GEMMs: auto | rocblas | hipblaslt | default (gymrl_amd/blas.py)
         self.tune_gemms = False              # opt-in TunableOp search per GEMM shape at start-up
         self.use_graphs = True             # replay the update as one captured hipGraph (train(); update() stays eager)
+        self.chunk_steps = 16              # whole vector steps (acting, env, n-step store, sum tree, draw, update) as one
+        #                                    hipGraph per 16 (graphs.StepChunk); 0: eager acting + a graph per update.  The
+        #                                    eager launches of a step cost the host 0.46 ms at N = 8192 — more than the GPU needs
 
 
 class NoisyLinear(nn.Module):
@@ -431,10 +434,14 @@ class RainbowDQNTrainer:
         step's new rows (stage_tree(chain=True)) and is joined when that step stores its transitions."""
         cfg = self.cfg
         state, action, reward, next_state, terminal = ops.replay_gather(self.memory.ring, batch_index)
-        with torch.no_grad():
-            q_next_online = self.policy_net(next_state)                   # fresh noise (:320)
-            q_next_target = self.target_net(next_state)                   # eval mode: mu weights only
-        q = self.policy_net(state)                                        # fresh noise again (:334)
+        fused = gnn.FUSED_LINEAR and self.policy_net.advantage.out_features + 1 <= 16
+        if fused:
+            q_next_online, q_next_target, q, saved = self._three_forwards(next_state, state)
+        else:
+            with torch.no_grad():
+                q_next_online = self.policy_net(next_state)               # fresh noise (:320)
+                q_next_target = self.target_net(next_state)               # eval mode: mu weights only
+            q = self.policy_net(state)                                    # fresh noise again (:334)
         self._loss.zero_()
         td, dq = ops.dqn_td_loss(q, q_next_target, action.view(-1), reward, terminal, cfg.gamma ** cfg.n_steps,
                                  q_next_online=q_next_online, w=is_weight, loss_sum=self._loss)
@@ -445,9 +452,12 @@ class RainbowDQNTrainer:
         main, side = torch.cuda.current_stream(), self._side if OVERLAP_TREE else torch.cuda.current_stream()
         fork = torch.cuda.Event()
         fork.record(main)
-        self._sink.arm()
-        q.backward(dq)
-        self._sink.collect()
+        if fused:
+            self._backward(dq, saved)
+        else:
+            self._sink.arm()
+            q.backward(dq)
+            self._sink.collect()
         self.optimizer.step(bias_dev=bias)                                # clip_grad_norm_(10) + Adam
         ops.soft_update(self.target_flat, self.flat_params, cfg.tau)      # :347-352 (parameters only)
         with torch.cuda.stream(side):
@@ -457,6 +467,61 @@ class RainbowDQNTrainer:
             main.wait_stream(side)
         else:
             self._tree_keep = (td, batch_index)       # read on the side stream: alive until the next join
+
+    @torch.no_grad()
+    def _three_forwards(self, next_state, state):
+        """policy_net(next_state) [fresh noise, :320], target_net(next_state) [eval: mu only] and policy_net(state)
+        [fresh noise again, :334] layer by layer, the three passes sharing every launch (csrc/lin.hip items): 2 trunk
+        launches, one launch building the six NoisyLinear layers' effective parameters (both training-mode draws made
+        inside it, in the eager order), one head launch with the dueling epilogue.  -> q_next_online, q_next_target, q
+        and what _backward() needs of the third pass.  Same arithmetic as the module path, kernel for kernel."""
+        p, t = self.policy_net, self.target_net
+        relu, duel = ops.LIN_ACT["relu"], ops.LIN_ACT["dueling"]
+        h1 = ops.lin_fwd([next_state, next_state, state], [p.fc1.weight, t.fc1.weight, p.fc1.weight],
+                         [p.fc1.bias, t.fc1.bias, p.fc1.bias], relu)
+        h2 = ops.lin_fwd(h1, [p.fc2.weight, t.fc2.weight, p.fc2.weight], [p.fc2.bias, t.fc2.bias, p.fc2.bias], relu)
+
+        def fields(m, **kw):
+            return dict(w_mu=m.weight_mu, w_sigma=m.weight_sigma, b_mu=m.bias_mu, b_sigma=m.bias_sigma, **kw)
+        first = []
+        for m in (p.advantage, p.value):
+            f = {k: v for k, v in m.noise_source()[0].items() if not k.endswith("_copy")}   # not needed after the launch
+            if f.get("w_eps") is m.weight_epsilon:        # parity mode: raw draws land in the module's buffers, which the
+                f["w_eps"], f["b_eps"] = f["w_eps"].clone(), f["b_eps"].clone()      # second draw below overwrites
+            first.append(fields(m, **f))
+        target = [fields(m, eval=True) for m in (t.advantage, t.value)]
+        second, eps = [], []
+        for m in (p.advantage, p.value):
+            f, saved = m.noise_source()
+            second.append(fields(m, **f))
+            eps += list(saved)
+        W, b = ops.noisy_combine(first + target + second, training=True)
+        A1 = p.advantage.out_features + 1
+        Ws, bs = [W[i * A1:(i + 1) * A1] for i in range(3)], [b[i * A1:(i + 1) * A1] for i in range(3)]
+        q_no, q_nt, q = ops.lin_fwd(h2, Ws, bs, duel)
+        return q_no, q_nt, q, (state, h1[2], h2[2], Ws[2], eps)
+
+    @torch.no_grad()
+    def _backward(self, dq, saved):
+        """loss.backward() (:342) of the third pass, by hand on the layer kernels: every gradient lands in its view of
+        the flat gradient buffer (overwritten: the optimiser step left it zeroed or stale)."""
+        state, h1, h2, W, eps = saved
+        p = self.policy_net
+        relu = ops.LIN_ACT["relu"]
+        dS = ops.dueling_bwd(dq)
+        dh2 = ops.lin_bwd_input(dS, None, W)[0]
+        dW, db = torch.empty_like(W), torch.empty(W.shape[0], dtype=W.dtype, device=W.device)
+        ops.lin_bwd_weight(dS, None, h2, dW, db)
+        layers = []
+        for i, m in enumerate((p.advantage, p.value)):
+            layers.append(dict(w_mu=m.weight_mu.grad, b_mu=m.bias_mu.grad, w_sigma=m.weight_sigma.grad,
+                               b_sigma=m.bias_sigma.grad, w_eps=eps[2 * i], b_eps=eps[2 * i + 1],
+                               dw_mu=m.weight_mu.grad, dw_sigma=m.weight_sigma.grad, db_mu=m.bias_mu.grad,
+                               db_sigma=m.bias_sigma.grad))
+        ops.noisy_split(layers, dW, db, training=True)
+        dh1 = ops.lin_bwd_input(dh2, h2, p.fc2.weight, relu)[0]
+        ops.lin_bwd_weight(dh2, h2, h1, p.fc2.weight.grad, p.fc2.bias.grad, relu)
+        ops.lin_bwd_weight(dh1, h1, state, p.fc1.weight.grad, p.fc1.bias.grad, relu)
 
     def _anneal_lr(self):
         cfg = self.cfg
@@ -613,7 +678,7 @@ class RainbowDQNTrainer:
         step = 0
         graphed = (bool(getattr(cfg, "use_graphs", True)) and self._parity_u is None
                    and self.policy_net.advantage.raw_noise is None)
-        chunked = graphed and N > 1 and cfg.updates_per_step == 1 and (self.memory.capacity & (self.memory.capacity - 1)) == 0 \
+        chunked = graphed and N > 1 and cfg.updates_per_step == 1 and getattr(cfg, "chunk_steps", self.CHUNK) > 0 and (self.memory.capacity & (self.memory.capacity - 1)) == 0 \
             and self.memory.capacity % N == 0
         limit = max_vector_steps or (cfg.max_episodes * cfg.max_steps // N + 1)
         while tracker.episodes < cfg.max_episodes and step < limit:

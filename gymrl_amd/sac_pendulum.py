@@ -46,6 +46,9 @@ class Config:
         self.gemm_backend = "auto"            # library for the update's small-M GEMMs: auto | rocblas | hipblaslt | default (gymrl_amd/blas.py)
         self.tune_gemms = False              # opt-in TunableOp search per GEMM shape at start-up
         self.use_graphs = True             # replay the update as one captured hipGraph (train(); update() stays eager)
+        self.chunk_steps = 0               # 16: whole vector steps as one hipGraph per 16 (graphs.StepChunk).  Measured slower
+        #                                    here (0.37 vs 0.29 ms per step at N = 4096, B = 128): SAC's step is GPU-bound, and
+        #                                    the executor's cost per graph node grows with the graph (944 nodes per chunk)
 
 
 class _SacSample(torch.autograd.Function):
@@ -125,8 +128,8 @@ class ReplayBuffer(_Ring):
     def __init__(self, capacity, state_dim, action_dim, device, seed=0):
         super().__init__(capacity, state_dim, device, action_words=action_dim, action_dtype=torch.float32, seed=seed)
 
-    def push(self, state, action, reward, next_state, done):
-        super().push(state, action.contiguous().view(torch.int32), reward, next_state, done)
+    def push(self, state, action, reward, next_state, done, cursor_dev=None):
+        super().push(state, action.contiguous().view(torch.int32), reward, next_state, done, cursor_dev=cursor_dev)
 
 
 class SACTrainer:
@@ -241,7 +244,8 @@ class SACTrainer:
             sc = self._scalars = StepScalars(self.device)
             (bc, self._off_c), (ba, self._off_a), (bl, self._off_l) = (sc.slot(16, torch.float32), sc.slot(16, torch.float32),
                                                                      sc.slot(16, torch.float64))
-            self._g_idx = torch.empty(cfg.batch_size, dtype=torch.int32, device=self.device)
+            if getattr(self, "_g_idx", None) is None:
+                self._g_idx = torch.empty(cfg.batch_size, dtype=torch.int32, device=self.device)
             self._graph = GraphedStep(lambda: self._update_body(self._g_idx, bias=(bc, ba, bl)))
         m.draw_indices(cfg.batch_size, out=self._g_idx)
         sc = self._scalars
@@ -289,24 +293,84 @@ class SACTrainer:
         with small_gemm_backend(backend, getattr(self.cfg, "tune_gemms", False)):
             return self._train(max_vector_steps)
 
+    CHUNK = 16     # vector steps per StepChunk replay (= the episode tracker's flush period)
+
+    def _loop_buffers(self, N, D):
+        """Step buffers that outlive one train() call: the captured StepChunk graph holds their addresses."""
+        lb = getattr(self, "_loop", None)
+        if lb is None or lb["N"] != N:
+            d = self.device
+            lb = self._loop = dict(N=N, obs=torch.empty(N, D, device=d), nxt=torch.empty(N, D, device=d),
+                                   tobs=torch.empty(N, D, device=d), rew=torch.empty(N, device=d),
+                                   tracker=EpisodeTracker(N, d, flush_every=1 if N == 1 else self.CHUNK))
+        lb["tracker"].k, lb["tracker"].episodes = 0, 0
+        return lb
+
+    def _vector_step(self, lb, obs, nxt, ep_ret, done, cursor_dev=None):
+        """One vector step of :269-310 up to (not including) the update."""
+        cfg, env = self.cfg, self.env
+        action = self.select_action(obs, eps=None if self._parity_eps is None else next(self._parity_eps))
+        env.step(action, nxt, lb["rew"], done_out=done, term_obs_out=lb["tobs"], ep_ret_out=ep_ret)
+        if cursor_dev is None:
+            self.memory.push(obs, action, lb["rew"], lb["tobs"], done)           # done = terminated or truncated (:283)
+        else:
+            self.memory.push(obs, action, lb["rew"], lb["tobs"], done, cursor_dev=cursor_dev)
+        if cfg.max_steps < env.max_steps:           # :278 `for step in range(cfg.max_steps)`: the episode is abandoned without a
+            env.abandon(cfg.max_steps, nxt, done, ep_ret)         # done flag (stored above) and the next one starts
+
+    def _chunk_body(self, lb, j):
+        """Vector step j of a StepChunk capture: acting + env + ring append + index draw + update, every per-step scalar
+        read from record j."""
+        ch, tr = self._chunk, lb["tracker"]
+        obs, nxt = (lb["obs"], lb["nxt"]) if j % 2 == 0 else (lb["nxt"], lb["obs"])
+        self._vector_step(lb, obs, nxt, tr.ret[j], tr.done[j], cursor_dev=ch.view(j, "push"))
+        self.memory.draw_indices(self.cfg.batch_size, out=self._g_idx, dev=ch.view(j, "draw"))
+        self._update_body(self._g_idx, bias=(ch.view(j, "adam_c", torch.float32), ch.view(j, "adam_a", torch.float32),
+                                             ch.view(j, "alpha", torch.float64)))
+
+    def _stage_chunk(self):
+        """The host's bookkeeping of the next CHUNK vector steps, in the eager loop's order, written into the records."""
+        ch, m, N = self._chunk, self.memory, self.env.n
+        for j in range(ch.K):
+            ch.set(j, "push", m.cursor)
+            m.advance(N)
+            ch.set(j, "draw", m.draws, m.size)
+            m.draws += 1
+            ch.set_bytes(j, "adam_c", self.critic_optimizer.next_bias())
+            ch.set_bytes(j, "adam_a", self.actor_optimizer.next_bias())
+            self._alpha_steps += 1
+            ch.set(j, "alpha", 1.0 - 0.9 ** self._alpha_steps, 1.0 - 0.999 ** self._alpha_steps)
+        ch.flush()
+
     def _train(self, max_vector_steps=None):
-        """:269-310 with N lock-stepped envs."""
+        """:269-310 with N lock-stepped envs.  With hipGraphs on, CHUNK whole vector steps (acting, env step, ring append,
+        index draw, update) replay as one graph (gymrl_amd/graphs.py StepChunk)."""
         cfg, env = self.cfg, self.env
         N, D = env.n, env.obs_dim
-        obs, nxt, tobs = (torch.empty(N, D, device=self.device) for _ in range(3))
-        rew = torch.empty(N, device=self.device)
-        tracker = EpisodeTracker(N, self.device, flush_every=1 if N == 1 else 16)
+        lb = self._loop_buffers(N, D)
+        obs, nxt, tracker = lb["obs"], lb["nxt"], lb["tracker"]
         env.reset(obs)
         step = 0
         graphed = bool(getattr(cfg, "use_graphs", True)) and self._parity_updates is None
+        chunked = graphed and N > 1 and cfg.updates_per_step == 1 and getattr(cfg, "chunk_steps", self.CHUNK) > 0 and self._parity_eps is None
         limit = max_vector_steps or (cfg.max_episodes * cfg.max_steps // N + 1)
         while tracker.episodes < cfg.max_episodes and step < limit:
-            action = self.select_action(obs, eps=None if self._parity_eps is None else next(self._parity_eps))
+            if (chunked and tracker.k == 0 and limit - step >= self.CHUNK and obs is lb["obs"]
+                    and len(self.memory) >= cfg.batch_size):
+                if getattr(self, "_chunk", None) is None:
+                    from .graphs import StepChunk
+                    self._chunk = StepChunk(self.device, self.CHUNK, [("push", "q"), ("draw", "Qq"), ("adam_c", "4f"),
+                                                                      ("adam_a", "4f"), ("alpha", "2d")])
+                    if getattr(self, "_g_idx", None) is None:
+                        self._g_idx = torch.empty(cfg.batch_size, dtype=torch.int32, device=self.device)
+                self._stage_chunk()
+                self._chunk.run(lambda j: self._chunk_body(lb, j), key=(id(env), env.state.data_ptr()))
+                step += self.CHUNK
+                tracker.k = self.CHUNK
+                tracker.flush(self.episode_rewards)
+                continue
             ep_ret, done = tracker.slot()
-            env.step(action, nxt, rew, done_out=done, term_obs_out=tobs, ep_ret_out=ep_ret)
-            self.memory.push(obs, action, rew, tobs, done)                     # done = terminated or truncated (:283)
-            if cfg.max_steps < env.max_steps:       # :278 `for step in range(cfg.max_steps)`: the episode is abandoned without a
-                env.abandon(cfg.max_steps, nxt, done, ep_ret)     # done flag (stored above) and the next one starts
+            self._vector_step(lb, obs, nxt, ep_ret, done)
             for _ in range(cfg.updates_per_step):
                 if graphed:
                     self.update_async()

@@ -507,7 +507,7 @@ int gymrl_lin_bwd_weight(const gymrl_lin_item* items, int n_items, int B, int N,
  * module's weight_epsilon / bias_epsilon buffers) when given; gymrl_noisy_split sends the stacked gradient back:
  * d mu (+)= dW, d sigma (+)= dW * eps (zeros when training == 0; NULL d*_sigma: skipped).
  */
-#define GYMRL_NOISY_MAX_LAYERS 4
+#define GYMRL_NOISY_MAX_LAYERS 8
 typedef struct {
   const float* w_mu; const float* w_sigma; const float* w_eps;      /* [n_out, K] */
   const float* b_mu; const float* b_sigma; const float* b_eps;      /* [n_out] */
@@ -516,7 +516,9 @@ typedef struct {
   uint64_t seed, counter;                                           /* combine with draw != 0 */
   const uint64_t* counter_dev;                                      /* NULL, or the counter in device memory (graphs) */
   int draw;            /* combine: draw this layer's noise in the launch itself — bit for bit gymrl_noisy_noise(seed,
-                          counter) — instead of reading w_eps / b_eps; it is written to w_eps_copy / b_eps_copy (required) */
+                          counter) — instead of reading w_eps / b_eps; it is written to w_eps_copy / b_eps_copy when given */
+  int eval;            /* combine: this layer contributes its mu only even when training != 0 (a target network's layer
+                          stacked beside training-mode ones) */
   int n_out;
 } gymrl_noisy_layer;
 int gymrl_noisy_combine(const gymrl_noisy_layer* layers, int n_layers, int K, int training, float* W_out, float* b_out,

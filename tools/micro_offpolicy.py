@@ -53,6 +53,8 @@ def main():
             c = mod.Config()
             c.num_envs, c.memory_capacity, c.max_episodes, c.batch_size = N, 1 << 20, 10**9, B
             c.use_graphs, c.gemm_backend, c.tune_gemms = graphs, backend, tune
+            if os.environ.get("GYMRL_NO_CHUNK"):
+                c.chunk_steps = 0
             gnn.SPLIT_BIAS, gnn.FUSED_LINEAR = True, fused
             rainbow_dqn_cartpole.OVERLAP_TREE = not os.environ.get("GYMRL_NO_OVERLAP")
             tr = getattr(mod, cls)(c)
