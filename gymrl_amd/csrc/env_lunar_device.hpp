@@ -630,10 +630,11 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
   LUNAR_PROF_MARK(pt2);
   LUNAR_PROF_ADD(lds, 1, pt1, pt2);          // constraint initialisation + warm start
   // Per-joint invariants of the sweeps, hoisted by hand (same operations, same order as b2Mat33::Solve33 /
-  // b2Mat22 inside the sweep): first Cramer cofactor column and the two reciprocal determinants; the joint arms
-  // as (x, y) pairs and as their perpendiculars so that w x r is one packed multiply.
-  v2f jrA[2], jrB[2], jpA[2], jpB[2], kdiag[2];
-  float c1x[2], c1y[2], c1z[2], det3i[2], det2i[2];
+  // b2Mat22 inside the sweep): first Cramer cofactor column, the two reciprocal determinants, the joint arms'
+  // perpendiculars (w x r = w * (-ry, rx)), the limit state as a mask and the side of the limit as a sign.
+  float jpAx[2], jpAy[2], jpBx[2], jpBy[2];
+  float c1x[2], c1y[2], c1z[2], det3i[2], det2i[2], lim_sign[2];
+  bool at_limit[2];
 #pragma unroll
   for (int L = 0; L < 2; ++L) {
     const float a11 = K11[L], a12 = K12[L], a13 = K13[L], a22 = K22[L], a23 = K23[L], a33 = K33[L];
@@ -644,14 +645,18 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
     float d2 = a11 * a22 - a12 * a12;
     if (d2 != 0.0f) d2 = 1.0f / d2;
     det2i[L] = d2;
-    jrA[L] = v2f{jrAx[L], jrAy[L]}; jrB[L] = v2f{jrBx[L], jrBy[L]};
-    jpA[L] = v2f{-jrAy[L], jrAx[L]}; jpB[L] = v2f{-jrBy[L], jrBx[L]};
-    kdiag[L] = v2f{a22, a11};
+    jpAx[L] = -jrAy[L]; jpAy[L] = jrAx[L]; jpBx[L] = -jrBy[L]; jpBy[L] = jrBx[L];
+    at_limit[L] = W.j[L].state != 0;                 // the state is fixed for the whole velocity solve
+    lim_sign[L] = W.j[L].state == 1 ? 1.0f : -1.0f;  // lower limit: release when the impulse turns negative; upper: positive
   }
-  // velocities as (x, y) pairs for the duration of the sweeps
+  v2f jpA[2] = {v2f{jpAx[0], jpAy[0]}, v2f{jpAx[1], jpAy[1]}}, jpB[2] = {v2f{jpBx[0], jpBy[0]}, v2f{jpBx[1], jpBy[1]}};
   v2f vel[3] = {v2f{B[0].vx, B[0].vy}, v2f{B[1].vx, B[1].vy}, v2f{B[2].vx, B[2].vy}};
   float om[3] = {B[0].w, B[1].w, B[2].w};
-  // velocity iterations
+  // velocity iterations.  One wavefront issues one VALU instruction per 4 clocks however many lanes are live, and a
+  // sweep is 180 x per step: the joint solve is written branch-free on scalars — the 3 x 3 (at a limit) and 2 x 2
+  // solutions are both formed and selected per lane, exactly the values the branches of b2RevoluteJoint::
+  // SolveVelocityConstraints produce — which costs ~210 instructions per sweep instead of ~295 with exec-mask
+  // branches, packed-register shuffles and their hazard no-ops.
 #pragma nounroll
   for (int it = 0; it < kVelIters; ++it) {
 #pragma unroll
@@ -668,44 +673,36 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
         imp = J.im - old;
         om[0] -= iA * imp; om[bi] += iB * imp;
       }
-      // Cdot = vB + wB x rB - vA - wA x rA, with w x r = w * (-ry, rx)
+      // Cdot = vB + wB x rB - vA - wA x rA
       const v2f C = ((vel[bi] + om[bi] * jpB[L]) - vel[0]) - om[0] * jpA[L];
-      v2f ip;
-      float ipz;
-      if (J.state != 0) {
-        const float Cz = om[bi] - om[0];
-        // impulse = -K^-1 * Cdot (b2Mat33::Solve33, Cramer)
-        const float a11 = K11[L], a12 = K12[L], a13 = K13[L], a22 = K22[L], a23 = K23[L], a33 = K33[L];
-        const float det = det3i[L];
-        const float bx = C.x, by = C.y, bz = Cz;
-        const float sx = det * (bx * c1x[L] + by * c1y[L] + bz * c1z[L]);
-        const float c2x = by * a33 - bz * a23, c2y = bz * a13 - bx * a33, c2z = bx * a23 - by * a13;
-        const float sy = det * (a11 * c2x + a12 * c2y + a13 * c2z);
-        const float c3x = a22 * bz - a23 * by, c3y = a23 * bx - a12 * bz, c3z = a12 * by - a22 * bx;
-        const float sz = det * (a11 * c3x + a12 * c3y + a13 * c3z);
-        ip = v2f{-sx, -sy}; ipz = -sz;
-        const float newImp = J.iz + ipz;
-        const bool release = (J.state == 1) ? (newImp < 0.0f) : (newImp > 0.0f);
-        if (release) {
-          const float rx = -C.x + J.iz * a13, ry = -C.y + J.iz * a23;
-          const float d2 = det2i[L];
-          const float ux = d2 * (a22 * rx - a12 * ry), uy = d2 * (a11 * ry - a12 * rx);
-          ip = v2f{ux, uy}; ipz = -J.iz;
-          J.ix += ux; J.iy += uy; J.iz = 0.0f;
-        } else {
-          J.ix += ip.x; J.iy += ip.y; J.iz += ipz;
-        }
-      } else {
-        const v2f r = -C;
-        ip = det2i[L] * (kdiag[L] * r - K12[L] * r.yx);       // (d2 (a22 rx - a12 ry), d2 (a11 ry - a12 rx))
-        ipz = 0.0f;
-        J.ix += ip.x; J.iy += ip.y;
-      }
+      const float Cx = C.x, Cy = C.y;
+      const float Cz = om[bi] - om[0];
+      const float a11 = K11[L], a12 = K12[L], a13 = K13[L], a22 = K22[L], a23 = K23[L], a33 = K33[L];
+      // impulse = -K^-1 * Cdot (b2Mat33::Solve33, Cramer)
+      const float det = det3i[L];
+      const float sx = det * (Cx * c1x[L] + Cy * c1y[L] + Cz * c1z[L]);
+      const float c2x = Cy * a33 - Cz * a23, c2y = Cz * a13 - Cx * a33, c2z = Cx * a23 - Cy * a13;
+      const float sy = det * (a11 * c2x + a12 * c2y + a13 * c2z);
+      const float c3x = a22 * Cz - a23 * Cy, c3y = a23 * Cx - a12 * Cz, c3z = a12 * Cy - a22 * Cx;
+      const float sz = det * (a11 * c3x + a12 * c3y + a13 * c3z);
+      const float newImp = J.iz + (-sz);
+      const bool lim = at_limit[L];
+      const bool release = lim && (lim_sign[L] * newImp < 0.0f);
+      // the 2 x 2 solution: the point constraint alone (no limit), or after the limit impulse is taken back (release)
+      const float rx = lim ? (-Cx + J.iz * a13) : -Cx;
+      const float ry = lim ? (-Cy + J.iz * a23) : -Cy;
+      const float d2 = det2i[L];
+      const float ux = d2 * (a22 * rx - a12 * ry), uy = d2 * (a11 * ry - a12 * rx);
+      const bool two = !lim || release;
+      const float ipx = two ? ux : -sx, ipy = two ? uy : -sy;
+      const float ipz = lim ? (release ? -J.iz : -sz) : 0.0f;
+      J.ix += ipx; J.iy += ipy;
+      J.iz = lim ? (release ? 0.0f : newImp) : J.iz;
+      const v2f ip = v2f{ipx, ipy};
       vel[0] -= mA * ip;
-      const v2f tA = jrA[L] * ip.yx, tB = jrB[L] * ip.yx;     // (rx ipy, ry ipx)
-      om[0] -= iA * ((tA.x - tA.y) + ipz);
+      om[0] -= iA * ((jrAx[L] * ipy - jrAy[L] * ipx) + ipz);
       vel[bi] += mB * ip;
-      om[bi] += iB * ((tB.x - tB.y) + ipz);
+      om[bi] += iB * ((jrBx[L] * ipy - jrBy[L] * ipx) + ipz);
     }
     // contacts: each lane solves its own body's slots, then the quad exchanges velocities
     if (any_contact) {
