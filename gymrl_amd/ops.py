@@ -1006,3 +1006,4 @@ def dueling_bwd(dq):
     dS = torch.empty(B, A + 1, dtype=torch.float32, device=dq.device)
     check(lib().gymrl_dueling_bwd(_ptr(dq, torch.float32), C.c_int(B), C.c_int(A), _ptr(dS), _stream()), "gymrl_dueling_bwd")
     return dS
+
