@@ -830,6 +830,15 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
   int prof_pos_iters = 0;
 #endif
   bool position_solved = false;
+  float plim_value[2], plim_slop[2], plim_lo[2], plim_hi[2];
+#pragma unroll
+  for (int L = 0; L < 2; ++L) {
+    const bool lower = W.j[L].state == 1;
+    plim_value[L] = lower ? joint_lower(L) : joint_upper(L);
+    plim_slop[L] = lower ? kAngularSlop : -kAngularSlop;             // C - slop == C + (-slop), exactly
+    plim_lo[L] = lower ? -kMaxAngCorr : 0.0f;
+    plim_hi[L] = lower ? 0.0f : kMaxAngCorr;
+  }
   // The manifolds do not change during the position sweeps: read them from LDS once (a wave runs as many sweeps
   // as its slowest env needs — 19 on average, 49 in the slowest workgroup — and every LDS read in the sweep is
   // a dependent ~100-clock round trip).
@@ -904,25 +913,15 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
     for (int jj = 0; jj < 2; ++jj) {
       const int L = 1 - jj;
       const int bi = L + 1;
-      const Joint& J = W.j[L];
       const float mA = kInvM[0], mB = kInvM[bi], iA = kInvI[0], iB = kInvI[bi];
-      float angErr = 0.0f;
-      if (J.state != 0) {
-        const float ang = B[bi].a - B[0].a;
-        float limImp = 0.0f;
-        if (J.state == 1) {
-          float C = ang - joint_lower(L);
-          angErr = -C;
-          C = clampf(C + kAngularSlop, -kMaxAngCorr, 0.0f);
-          limImp = -mmass[L] * C;
-        } else {
-          float C = ang - joint_upper(L);
-          angErr = C;
-          C = clampf(C - kAngularSlop, 0.0f, kMaxAngCorr);
-          limImp = -mmass[L] * C;
-        }
-        B[0].a -= iA * limImp; B[bi].a += iB * limImp;
-      }
+      // limit part of b2RevoluteJoint::SolvePositionConstraints, branch-free: the limit's value, the slop's sign and the
+      // clamp's bounds are per-lane constants of the step (plim_*), the very operations of the two branches follow
+      const bool lim = at_limit[L];
+      const float Cang = (B[bi].a - B[0].a) - plim_value[L];
+      const float angErr = lim ? -(lim_sign[L] * Cang) : 0.0f;                 // lower: -C, upper: C
+      const float Cc = clampf(Cang + plim_slop[L], plim_lo[L], plim_hi[L]);
+      const float limImp = lim ? -mmass[L] * Cc : 0.0f;
+      B[0].a -= iA * limImp; B[bi].a += iB * limImp;
       float qsA, qcA, qsB, qcB;
       det_sincosf(B[0].a, &qsA, &qcA);
       det_sincosf(B[bi].a, &qsB, &qcB);
