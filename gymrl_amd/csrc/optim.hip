@@ -102,7 +102,8 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ p, flo
                                                       int64_t n, AdamArgs a,
                                                       const float* __restrict__ lr_dev,
                                                       const float* __restrict__ bias_dev,
-                                                      const double* __restrict__ sqnorm) {
+                                                      const double* __restrict__ sqnorm,
+                                                      float* __restrict__ polyak, float tau, float omt) {
   if (bias_dev) {          // graph replay: the step-dependent scalars live in device memory
     a.step_size_host = bias_dev[0]; a.inv_bc1 = bias_dev[1]; a.bc2_sqrt = bias_dev[2];
   }
@@ -126,6 +127,12 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ p, flo
     reinterpret_cast<float4*>(m)[i] = M;
     reinterpret_cast<float4*>(v)[i] = V;
     if (a.zero_grad) reinterpret_cast<float4*>(g)[i] = G;
+    if (polyak) {            // the soft target update of the parameters just written (soft_update_kernel's expression)
+      float4 t = reinterpret_cast<float4*>(polyak)[i];
+      t.x = tau * P.x + omt * t.x; t.y = tau * P.y + omt * t.y;
+      t.z = tau * P.z + omt * t.z; t.w = tau * P.w + omt * t.w;
+      reinterpret_cast<float4*>(polyak)[i] = t;
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t i = (n4 << 2) + threadIdx.x;
@@ -133,6 +140,7 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ p, flo
     adam_one(P, G, M, V, a, scale, step_size);
     p[i] = P; m[i] = M; v[i] = V;
     if (a.zero_grad) g[i] = G;
+    if (polyak) polyak[i] = tau * P + omt * polyak[i];
   }
 }
 
@@ -216,8 +224,8 @@ int gymrl_store_scalars(void* dst_dev, const void* src_host, int nbytes, void* s
 int gymrl_adam_step(float* p, float* g, float* m, float* v, int64_t n, double lr_host,
                     const float* lr_dev, double beta1, double beta2, double eps, int64_t step,
                     const float* bias_dev, float grad_scale, float max_grad_norm, const double* sqnorm,
-                    float clamp_abs, int zero_grad, void* stream_) {
-  if (!p || !g || !m || !v || n < 0 || (step < 1 && !bias_dev)) return -22;
+                    float clamp_abs, int zero_grad, float* polyak_target, double tau, void* stream_) {
+  if (!p || !g || !m || !v || n < 0 || (step < 1 && !bias_dev) || (polyak_target && !aligned16(polyak_target))) return -22;
   if (bias_dev) step = 1;   // unused: the kernel takes step_size / bc2_sqrt from bias_dev
   if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return -22;
   if (max_grad_norm > 0.0f && !sqnorm) return -22;
@@ -234,7 +242,7 @@ int gymrl_adam_step(float* p, float* g, float* m, float* v, int64_t n, double lr
   a.grad_scale = grad_scale; a.max_grad_norm = max_grad_norm; a.clamp_abs = clamp_abs;
   a.zero_grad = zero_grad;
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4)), dim3(kBlock), 0, (hipStream_t)stream_, p, g,
-                     m, v, n, a, lr_dev, bias_dev, sqnorm);
+                     m, v, n, a, lr_dev, bias_dev, sqnorm, polyak_target, (float)tau, (float)(1.0 - tau));
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

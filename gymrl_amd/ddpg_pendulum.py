@@ -79,7 +79,7 @@ class DDPGTrainer(_ActorCriticBase):
         self._critic_sink.arm()                                        # critic_optimizer.zero_grad()
         torch.autograd.backward([q], [dq.view_as(q)])
         self._critic_sink.collect()
-        self.critic_optimizer.step(bias_dev=bc)
+        self.critic_optimizer.step(bias_dev=bc, polyak=(self.critic_target_flat, cfg.tau))      # + soft update :190 in the launch
         with frozen_parameters(self.critic):                           # its gradients of this loss are never used
             qa = self.critic(states, self.actor(states))               # :183-187
         self._sum_a.zero_()
@@ -87,9 +87,7 @@ class DDPGTrainer(_ActorCriticBase):
         self._actor_sink.arm()
         torch.autograd.backward([qa], [dqa.view_as(qa)])
         self._actor_sink.collect()
-        self.actor_optimizer.step(bias_dev=ba)
-        self.soft_update(self.actor_target_flat, self.actor_flat)      # :189-190
-        self.soft_update(self.critic_target_flat, self.critic_flat)
+        self.actor_optimizer.step(bias_dev=ba, polyak=(self.actor_target_flat, cfg.tau))        # + soft update :189
         return B
 
     def update_async(self):

@@ -75,6 +75,8 @@ class GradSink:
     def collect(self, add=False):
         """add=True accumulates into the flat buffer (gradient accumulation over micro-batches: the buffer was zeroed
         by the optimiser step) instead of overwriting it."""
+        if add != self.add and self.written:
+            raise RuntimeError("GradSink: arm(add=...) and collect(add=...) disagree while gradients were written in place")
         got = [(v, p.grad, i) for i, (v, p) in enumerate(zip(self.views, self.params)) if p.grad is not None]
         if not add:
             for i, (v, p) in enumerate(zip(self.views, self.params)):
@@ -115,9 +117,10 @@ class FusedAdam:
     def zero_grad(self):
         """No-op: gymrl_adam_step zeroes the gradient buffer it just consumed."""
 
-    def step(self, grad_scale=1.0, bias_dev=None):
+    def step(self, grad_scale=1.0, bias_dev=None, polyak=None):
         """bias_dev (f32[4] device view, hipGraph replay): the step-dependent scalars come from the device and
-        the caller advances the step with next_bias()."""
+        the caller advances the step with next_bias().  polyak = (target_flat, tau): the soft target update of the
+        freshly written parameters in the same launch."""
         g = self.param_groups[0]
         if bias_dev is None:
             self.step_count += 1
@@ -125,7 +128,8 @@ class FusedAdam:
             ops.sqnorm(self.g, self._sq, self._ws, grad_scale)
         ops.adam_step(self.p, self.g, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                       max(self.step_count, 1), grad_scale=grad_scale, max_grad_norm=self.max_grad_norm,
-                      sqnorm_buf=self._sq, clamp_abs=self.clamp_abs, zero_grad=True, bias_dev=bias_dev)
+                      sqnorm_buf=self._sq, clamp_abs=self.clamp_abs, zero_grad=True, bias_dev=bias_dev,
+                      polyak_target=None if polyak is None else polyak[0], tau=0.0 if polyak is None else polyak[1])
 
     def next_bias(self):
         """Advance the step count and return the 16-byte payload of gymrl_adam_bias for it."""

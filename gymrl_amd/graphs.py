@@ -16,11 +16,31 @@ the whole update is ONE graph launch.  What makes a captured update replayable:
 The arithmetic is the eager path's, kernel for kernel, so a graphed run reproduces an eager run bit for bit
 (tests/test_graphs_gpu.py).
 """
+import contextlib
+import gc
 import struct
 
 import torch
 
 from . import ops
+
+
+@contextlib.contextmanager
+def capture(graph):
+    """`torch.cuda.graph(graph)` with Python's cycle collector held off for the duration of the capture.  A collection
+    that runs in the middle of a capture can finalise an OLD trainer (a reference cycle through its closures, kept alive
+    until then by a caller's frame); destroying that trainer's captured graphs releases their private memory pool, and a
+    device free while a stream is capturing is an error that surfaces inside a destructor — the process aborts.  Garbage is
+    collected once right before the capture instead."""
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 class StepScalars:
@@ -67,7 +87,7 @@ class GraphedStep:
                 self.calls += 1
                 return self.fn()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with capture(self.graph):
                 self.fn()
         self.graph.replay()
 
@@ -154,7 +174,7 @@ class StepChunk:
         `key` (identity of the buffers the body touches) changed.  The records must have been flush()ed."""
         if self.graph is None or key != self.key:
             self.graph, self.key = torch.cuda.CUDAGraph(), key
-            with torch.cuda.graph(self.graph):
+            with capture(self.graph):
                 for j in range(self.K):
                     body(j)
         self.graph.replay()

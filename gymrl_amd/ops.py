@@ -289,7 +289,7 @@ def sqnorm(g, out, workspace, grad_scale=1.0):
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, max_grad_norm=0.0, sqnorm_buf=None,
-              clamp_abs=0.0, zero_grad=True, lr_dev=None, bias_dev=None):
+              clamp_abs=0.0, zero_grad=True, lr_dev=None, bias_dev=None, polyak_target=None, tau=0.0):
     """O1: Adam on one flat buffer (ppo_lunarlander.py:302-307); call sqnorm() first when clipping."""
     check(lib().gymrl_adam_step(_ptr(p, torch.float32), _ptr(g, torch.float32), _ptr(m, torch.float32),
                                 _ptr(v, torch.float32), C.c_int64(p.numel()), C.c_double(lr),
@@ -297,7 +297,8 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, max_grad_
                                 C.c_double(eps), C.c_int64(step), _ptr(bias_dev, torch.float32, True),
                                 C.c_float(grad_scale),
                                 C.c_float(max_grad_norm), _ptr(sqnorm_buf, torch.float64, True),
-                                C.c_float(clamp_abs), C.c_int(int(zero_grad)), _stream()), "gymrl_adam_step")
+                                C.c_float(clamp_abs), C.c_int(int(zero_grad)), _ptr(polyak_target, torch.float32, True),
+                                C.c_double(tau), _stream()), "gymrl_adam_step")
 
 
 def adam_bias(lr, beta1, beta2, step):

@@ -21,6 +21,7 @@ import torch.nn as nn
 
 from . import dist as gdist
 from . import ops
+from .graphs import capture as gcapture
 from .envs import VecEnv
 from .flat import FusedAdam, GradSink, flatten_module
 from .nn import SmallLinear
@@ -351,7 +352,7 @@ class PPOTrainer:
                 self._fwd_warm += 1
                 return self.model(self._fwd_in)
             self._fwd_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._fwd_graph):
+            with gcapture(self._fwd_graph):
                 self._fwd_out = self.model(self._fwd_in)
         self._fwd_graph.replay()
         return self._fwd_out
@@ -393,7 +394,7 @@ class PPOTrainer:
                 mul = cov_clip_mask(cfg, logits.detach(), act.index_select(0, li), adv.index_select(0, li), self._perm_gen)
             dlogits, dvalues = ops.ppo_full_loss_fwd_bwd(logits, values, act, lp, ent_old, adv, ret, lcfg, idx=idx,
                                                          metrics_sum=metrics_row, corr_mul=mul)
-            self._sink.arm()
+            self._sink.arm(add=acc)               # (the fused layers write their gradients straight into the flat buffer)
             torch.autograd.backward([logits, values], [dlogits, dvalues])
             self._sink.collect(add=acc)           # accumulating: the optimiser step left the buffer zeroed
 
@@ -450,7 +451,7 @@ class PPOTrainer:
                         else:
                             if graph is None:                              # (capturing does not execute)
                                 graph = torch.cuda.CUDAGraph()
-                                with torch.cuda.graph(graph):
+                                with gcapture(graph):
                                     fwd_bwd(self._g_idx, self._g_row)
                             graph.replay()
                     if self.world_size > 1:
@@ -460,7 +461,7 @@ class PPOTrainer:
                             opt_step(self._g_bias)                         # still warming up
                         else:
                             graph2 = torch.cuda.CUDAGraph()
-                            with torch.cuda.graph(graph2):
+                            with gcapture(graph2):
                                 opt_step(self._g_bias)
                             graph2.replay()
                     else:

@@ -25,6 +25,7 @@ import torch.nn.functional as F
 
 from . import dist as gdist
 from . import ops
+from .graphs import capture as gcapture
 from .envs import VecEnv
 from .flat import FusedAdam, GradSink, flatten_module
 from .ppo_full_lunarlander import MLP, PSCN, MHCBackbone, RMSNorm, cov_clip_mask  # noqa: F401  (part of this module's surface)
@@ -262,7 +263,7 @@ class PPOTrainer:
                 self._fwd_warm += 1
                 return self.model(*self._fwd_in)
             self._fwd_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._fwd_graph):
+            with gcapture(self._fwd_graph):
                 self._fwd_out = self.model(*self._fwd_in)
         self._fwd_graph.replay()
         return self._fwd_out
@@ -341,7 +342,7 @@ class PPOTrainer:
                     else:
                         if graph is None:
                             graph = torch.cuda.CUDAGraph()
-                            with torch.cuda.graph(graph):
+                            with gcapture(graph):
                                 minibatch(self._g_seq, self._g_row, self._g_rnd, self._g_bias)
                         graph.replay()
                     metrics[row].copy_(self._g_row)

@@ -458,8 +458,8 @@ class RainbowDQNTrainer:
             self._sink.arm()
             q.backward(dq)
             self._sink.collect()
-        self.optimizer.step(bias_dev=bias)                                # clip_grad_norm_(10) + Adam
-        ops.soft_update(self.target_flat, self.flat_params, cfg.tau)      # :347-352 (parameters only)
+        self.optimizer.step(bias_dev=bias, polyak=(self.target_flat, cfg.tau))   # clip_grad_norm_(10) + Adam, then the soft
+        #                                                                    target update :347-352 (parameters only) in the launch
         with torch.cuda.stream(side):
             side.wait_event(fork)
             self.memory.update_priorities(batch_index, td)

@@ -153,8 +153,8 @@ class SACTrainer:
         torch.autograd.backward([q1, q2], [dq1, dq2])
         self._c1_sink.collect()
         self._c2_sink.collect()
-        self.critic1_optim.step(bias_dev=bc1)
-        self.critic2_optim.step(bias_dev=bc2)
+        self.critic1_optim.step(bias_dev=bc1, polyak=(self.c1_target_flat, cfg.tau))             # + soft updates :217-218
+        self.critic2_optim.step(bias_dev=bc2, polyak=(self.c2_target_flat, cfg.tau))
         probs = self.actor(states)                                             # :196-207
         with torch.no_grad():
             q1n, q2n = self.critic1(states), self.critic2(states)              # the critics' gradients of this loss are discarded
@@ -168,8 +168,6 @@ class SACTrainer:
             self._alpha_steps += 1
         ops.dsac_alpha_step(self.log_alpha, self._alpha_m, self._alpha_v, self._sums_a, B, cfg.target_entropy,
                             cfg.lr_alpha, max(self._alpha_steps, 1), loss_out=self._alpha_loss, bias_dev=alpha_bias)
-        self.soft_update(self.c1_target_flat, self.c1_flat)                    # :217-218
-        self.soft_update(self.c2_target_flat, self.c2_flat)
         return B
 
     def update_async(self):

@@ -214,7 +214,8 @@ class SACTrainer:
         self._critic_sink.arm()                                                # critic_optimizer.zero_grad()
         torch.autograd.backward([q1, q2], [dq1.view_as(q1), dq2.view_as(q2)])
         self._critic_sink.collect()
-        self.critic_optimizer.step(bias_dev=None if bias is None else bias[0])
+        # (+ the soft target update :265 of the critic just written, in the same launch: nothing reads the target before it)
+        self.critic_optimizer.step(bias_dev=None if bias is None else bias[0], polyak=(self.critic_target_flat, cfg.tau))
 
         new_actions, logp = self.actor.sample(states, eps_cur)                 # :248-255
         with frozen_parameters(self.critic):                                   # its share of this backward is never computed
@@ -230,7 +231,6 @@ class SACTrainer:
             self._alpha_steps += 1
         ops.sac_alpha_step(self.log_alpha, self._alpha_m, self._alpha_v, self._sums, B, cfg.lr_alpha,
                            max(self._alpha_steps, 1), loss_out=self._alpha_loss, bias_dev=None if bias is None else bias[2])
-        self.soft_update()                                                     # :265
         return B
 
     def update_async(self):

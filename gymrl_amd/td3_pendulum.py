@@ -224,9 +224,10 @@ class TD3Trainer(_ActorCriticBase):
         self._critic_sink.arm()                                        # critic_optimizer.zero_grad()
         torch.autograd.backward([q1, q2], [dq1.view_as(q1), dq2.view_as(q2)])
         self._critic_sink.collect()
-        self.critic_optimizer.step()
+        delayed = self.total_updates % cfg.policy_freq == 0
+        self.critic_optimizer.step(polyak=(self.critic_target_flat, cfg.tau) if delayed else None)   # + soft update :223 when due
         actor_loss = 0.0
-        if self.total_updates % cfg.policy_freq == 0:                  # :210-224
+        if delayed:                                                    # :210-224
             with frozen_parameters(self.critic):                       # its gradients of this loss are never used (:218 zero_grad)
                 q = self.critic.q1(states, self.actor(states))
             self._sum_a.zero_()
@@ -234,8 +235,6 @@ class TD3Trainer(_ActorCriticBase):
             self._actor_sink.arm()
             torch.autograd.backward([q], [dq.view_as(q)])
             self._actor_sink.collect()
-            self.actor_optimizer.step()
-            self.soft_update(self.actor_target_flat, self.actor_flat)
-            self.soft_update(self.critic_target_flat, self.critic_flat)
+            self.actor_optimizer.step(polyak=(self.actor_target_flat, cfg.tau))
             actor_loss = -float(self._sum_a.item()) / B
         return actor_loss, float(self._sum_c.item()) / B

@@ -75,10 +75,13 @@ def tfrecord(payload):
 class ScalarWriter:
     """`SummaryWriter(logdir)` for scalars: a TensorBoard event file + scalars.csv in `logdir`."""
 
+    _serial = -1
+
     def __init__(self, logdir):
         os.makedirs(logdir, exist_ok=True)
         self.logdir = logdir
-        name = f"events.out.tfevents.{int(time.time())}.{socket.gethostname()}.{os.getpid()}.0"
+        ScalarWriter._serial += 1             # (SummaryWriter's own suffix: unique per writer of this process)
+        name = f"events.out.tfevents.{int(time.time())}.{socket.gethostname()}.{os.getpid()}.{ScalarWriter._serial}"
         self._ev = open(os.path.join(logdir, name), "wb")
         self._ev.write(tfrecord(encode_event(time.time(), file_version="brain.Event:2")))
         self._csv = open(os.path.join(logdir, "scalars.csv"), "w")

@@ -5,6 +5,7 @@ on/off-policy), `agent.choose_action(state)` -> (a, logp, v) on-policy or a off-
 `agent.reward_scaler`, `agent.save_model()` / `agent.load_model()`, `agent.learn_step`.
 States, actions and rewards are [N, ...] device tensors (one vector step per loop turn).
 """
+import os
 import time
 
 import numpy as np
@@ -84,7 +85,11 @@ def make_writer(cfg):
         return None
     root = getattr(cfg, "log_dir", "./exp")
     stamp = time.strftime("%Y%m%d-%H%M%S")
-    return ScalarWriter(f'{root}/{getattr(cfg, "algo_name", "agent")}_{cfg.env_name.replace("/", "-")}_{stamp}')
+    logdir = f'{root}/{getattr(cfg, "algo_name", "agent")}_{cfg.env_name.replace("/", "-")}_{stamp}'
+    k = 0
+    while os.path.exists(logdir if k == 0 else f"{logdir}-{k}"):      # two train() calls within one second: separate runs
+        k += 1
+    return ScalarWriter(logdir if k == 0 else f"{logdir}-{k}")
 
 
 def train(env, agent, cfg, max_vector_steps=None):

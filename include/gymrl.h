@@ -330,6 +330,8 @@ int gymrl_gather_minibatch(const float* packed, const int32_t* idx, int B, int o
  *   step-dependent scalars of the update.  With it (and `step` ignored) a hipGraph captured around the
  *   optimiser step replays unchanged; the host refreshes the block before each replay with
  *   gymrl_adam_bias (host arithmetic, identical to the eager path's) + gymrl_store_scalars.
+ *   polyak_target f32[n] or NULL: theta' <- tau*theta + (1-tau)*theta' (gymrl_soft_update's expression) on the
+ *   parameters this launch has just written — optimiser step + soft target update in one pass.
  *   gymrl_store_scalars: copies nbytes <= 3840 (multiple of 4) of host scalars into device memory as ONE
  *   launch whose payload is the kernel argument (stream-ordered, nothing to fence, not capturable state).
  *
@@ -352,7 +354,7 @@ int gymrl_adam_step(float* p, float* g, float* m, float* v, int64_t n,
                     double lr_host, const float* lr_dev, double beta1, double beta2,
                     double eps, int64_t step, const float* bias_dev, float grad_scale,
                     float max_grad_norm, const double* sqnorm, float clamp_abs, int zero_grad,
-                    void* stream);
+                    float* polyak_target, double tau, void* stream);
 int gymrl_adam_bias(double lr, double beta1, double beta2, int64_t step, float* out_host4);
 int gymrl_store_scalars(void* dst_dev, const void* src_host, int nbytes, void* stream);
 
