@@ -45,6 +45,7 @@ __device__ __forceinline__ float act_fwd(float z, int act, float lo, float hi) {
   if (act == GYMRL_ACT_RELU) return fmaxf(z, 0.0f);
   if (act == GYMRL_ACT_TANH) return train_tanhf(z);
   if (act == GYMRL_ACT_CLAMP) return fminf(fmaxf(z, lo), hi);
+  if (act == GYMRL_ACT_SILU) return z / (1.0f + expf(-z));          // forward only (its derivative needs z, not y)
   return z;
 }
 // d act / d z as a function of the saved OUTPUT y
@@ -516,7 +517,7 @@ int gymrl_lin_fwd(const gymrl_lin_item* items, int n_items, int B, int K, int K1
   bool vec = K1 == K && K % 4 == 0 && ldx % 4 == 0;
   for (int i = 0; i < kItems; ++i) {
     const gymrl_lin_item& it = items[i < n_items ? i : 0];
-    if (!it.x || !it.w || !it.y || (K1 < K && !it.x2) || it.act < GYMRL_ACT_NONE || it.act > GYMRL_ACT_DUELING ||
+    if (!it.x || !it.w || !it.y || (K1 < K && !it.x2) || it.act < GYMRL_ACT_NONE || it.act > GYMRL_ACT_SILU ||
         (it.act == GYMRL_ACT_DUELING && (N < 2 || N > 16)))
       return -22;
     a.act[i] = it.act; a.lo[i] = it.lo; a.hi[i] = it.hi;

@@ -1,0 +1,193 @@
+// mhc.hip — inference-side pieces of PPO-full's manifold-hyper-connection backbone (rollout forward only).
+//
+// ppo_full_lunarlander.py:106-250: every MHCBlock half reads the branch stack h [B, n, D] through per-sample gates —
+// an RMS-fused linear read-out (n*D -> n*n + 2n numbers per row), two sigmoids, an exp and `max_sk_it` Sinkhorn-Knopp
+// sweeps on an n x n matrix — mixes the branches, runs ONE D x D Linear + SiLU on the weighted branch sum and writes
+// the stack back.  Through PyTorch that is ~95 launches per half (each Sinkhorn sweep alone is 6), ~400 per rollout
+// forward at 4096 rows: 3 ms per vector step of pure launch cost, 12 of the 47 s of a config-5 iteration.  For the
+// rollout (no gradients) a half is three launches here:
+//
+//   gymrl_mhc_gates     h -> pre [B, n], post [B, n], mix [B, n, n] and read [B, D] = sum_i pre_i h_i   (one wave per row)
+//   gymrl_lin_fwd       out = SiLU(read W^T + b)                                                        (csrc/lin.hip)
+//   gymrl_mhc_combine   h'[b, i, :] = post_i out + sum_j mix_ij h[b, j, :]
+//
+// plus gymrl_rmsnorm (optionally over the branch sum: MHCBackbone.final_norm(h.sum(1)), and the RMSNorm of the actor /
+// critic MLPs).  The training pass keeps the torch modules (SURVEY 8a F1 leaves the network to PyTorch-ROCm); these
+// kernels are compared with them at 1e-5 (tests/test_mhc_fused_gpu.py).
+#include "train_device.hpp"
+#include "../../include/gymrl.h"
+
+namespace {
+
+using namespace gymrl;
+
+constexpr int kWaves = 4;
+constexpr int kMaxN = 4;                         // branches (mhc_rate)
+
+struct GatesArgs {
+  const float* h; const float* norm_w; const float* w; const float* alpha; const float* beta;
+  float* pre; float* post; float* mix; float* read;
+  int B, D, sk_it;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int N>
+__global__ __launch_bounds__(64 * kWaves) void mhc_gates_kernel(const GatesArgs a) {
+  constexpr int G = N * N + 2 * N;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (row >= a.B) return;
+  const int nc = N * a.D;
+  const float* __restrict__ hr = a.h + (size_t)row * nc;
+  float Hs[G], sq = 0.0f;
+#pragma unroll
+  for (int j = 0; j < G; ++j) Hs[j] = 0.0f;
+  for (int c = 4 * lane; c < nc; c += 256) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(hr + c);
+    const f32x4 nw = *reinterpret_cast<const f32x4*>(a.norm_w + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float t = nw[e] * x[e];
+      sq += x[e] * x[e];
+      const float* wr = a.w + (size_t)(c + e) * G;
+#pragma unroll
+      for (int j = 0; j < G; ++j) Hs[j] += t * wr[j];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    sq += __shfl_xor(sq, off, 64);
+#pragma unroll
+    for (int j = 0; j < G; ++j) Hs[j] += __shfl_xor(Hs[j], off, 64);
+  }
+  // every lane now holds the row's sums: r_inv = 1 / (|flat| / sqrt(nc) + 1e-6)
+  const float r_inv = 1.0f / (sqrtf(sq) / sqrtf((float)nc) + 1e-6f);
+  const float a0 = a.alpha[0], a1 = a.alpha[1], a2 = a.alpha[2];
+  float pre[N], post[N], A[N][N], u[N], v[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    pre[i] = sigmoidf_(r_inv * Hs[i] * a0 + a.beta[i]);
+    post[i] = 2.0f * sigmoidf_(r_inv * Hs[N + i] * a1 + a.beta[N + i]);
+    u[i] = 1.0f; v[i] = 1.0f;
+#pragma unroll
+    for (int j = 0; j < N; ++j) A[i][j] = expf(r_inv * Hs[2 * N + i * N + j] * a2 + a.beta[2 * N + i * N + j]);
+  }
+  for (int it = 0; it < a.sk_it; ++it) {                   // Sinkhorn-Knopp scalings (:141-146)
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      float s = 0.0f;
+#pragma unroll
+      for (int j = 0; j < N; ++j) s += A[i][j] * v[j];
+      u[i] = 1.0f / (s + 1e-8f);
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < N; ++i) s += A[i][j] * u[i];
+      v[j] = 1.0f / (s + 1e-8f);
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      a.pre[(size_t)row * N + i] = pre[i];
+      a.post[(size_t)row * N + i] = post[i];
+#pragma unroll
+      for (int j = 0; j < N; ++j) a.mix[((size_t)row * N + i) * N + j] = u[i] * A[i][j] * v[j];
+    }
+  }
+  for (int d = lane; d < a.D; d += 64) {                   // read = bmm(pre, h): the weighted sum of the branches
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) s += pre[i] * hr[i * a.D + d];
+    a.read[(size_t)row * a.D + d] = s;
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void mhc_combine_kernel(const float* __restrict__ post, const float* __restrict__ mix,
+                                                          const float* __restrict__ out, const float* __restrict__ h, int B,
+                                                          int D, float* __restrict__ h_out) {
+  const int64_t total = (int64_t)B * D;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t b = t / D;
+    const int d = (int)(t % D);
+    float hv[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) hv[j] = h[(b * N + j) * D + d];
+    const float o = out[b * D + d];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      float s = 0.0f;
+#pragma unroll
+      for (int j = 0; j < N; ++j) s += mix[(b * N + i) * N + j] * hv[j];
+      h_out[(b * N + i) * D + d] = post[b * N + i] * o + s;
+    }
+  }
+}
+
+// y = x * rsqrt(mean(x^2) + eps) * w per row; n_sum > 1: x = the sum of n_sum consecutive [D] blocks of the row
+__global__ __launch_bounds__(64 * kWaves) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             int B, int D, int n_sum, float eps, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float* xr = x + (size_t)row * n_sum * D;
+  float sq = 0.0f;
+  for (int d = lane; d < D; d += 64) {
+    float s = xr[d];
+    for (int k = 1; k < n_sum; ++k) s += xr[k * D + d];
+    sq += s * s;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+  const float r = rsqrtf(sq / (float)D + eps);
+  for (int d = lane; d < D; d += 64) {
+    float s = xr[d];
+    for (int k = 1; k < n_sum; ++k) s += xr[k * D + d];
+    y[(size_t)row * D + d] = s * r * w[d];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gymrl_mhc_gates(const float* h, const float* norm_w, const float* w, const float* alpha, const float* beta, int B, int n,
+                    int D, int sk_it, float* pre_out, float* post_out, float* mix_out, float* read_out, void* stream) {
+  if (!h || !norm_w || !w || !alpha || !beta || !pre_out || !post_out || !mix_out || !read_out || B < 0 || D < 4 || D % 4 ||
+      sk_it < 0 || (n != 2 && n != 4))
+    return -22;
+  if (B == 0) return 0;
+  GatesArgs a{h, norm_w, w, alpha, beta, pre_out, post_out, mix_out, read_out, B, D, sk_it};
+  const dim3 grid((B + kWaves - 1) / kWaves), block(64 * kWaves);
+  if (n == 2) hipLaunchKernelGGL(mhc_gates_kernel<2>, grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(mhc_gates_kernel<4>, grid, block, 0, (hipStream_t)stream, a);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_mhc_combine(const float* post, const float* mix, const float* out, const float* h, int B, int n, int D, float* h_out,
+                      void* stream) {
+  if (!post || !mix || !out || !h || !h_out || B < 0 || D < 1 || (n != 2 && n != 4)) return -22;
+  if (B == 0) return 0;
+  int64_t nb = ((int64_t)B * D + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  if (n == 2) hipLaunchKernelGGL(mhc_combine_kernel<2>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, post, mix, out, h, B, D, h_out);
+  else hipLaunchKernelGGL(mhc_combine_kernel<4>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, post, mix, out, h, B, D, h_out);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_rmsnorm(const float* x, const float* w, int B, int D, int n_sum, float eps, float* y, void* stream) {
+  if (!x || !w || !y || B < 0 || D < 1 || n_sum < 1) return -22;
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3((B + kWaves - 1) / kWaves), dim3(64 * kWaves), 0, (hipStream_t)stream, x, w, B, D, n_sum,
+                     eps, y);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

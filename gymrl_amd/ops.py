@@ -818,7 +818,7 @@ def rollout_lunar(env_state, n_envs, seed, env_id0, counter0, obs, act, logp, va
 
 
 # ------------------------------------------------ low-latency Linear layers --
-LIN_ACT = {None: 0, "none": 0, "tanh": 1, "relu": 2, "clamp": 3, "dueling": 4}
+LIN_ACT = {None: 0, "none": 0, "tanh": 1, "relu": 2, "clamp": 3, "dueling": 4, "silu": 5}
 LIN_MAX_ITEMS = 4
 
 
@@ -1008,3 +1008,35 @@ def dueling_bwd(dq):
     check(lib().gymrl_dueling_bwd(_ptr(dq, torch.float32), C.c_int(B), C.c_int(A), _ptr(dS), _stream()), "gymrl_dueling_bwd")
     return dS
 
+
+
+# ------------------------------------------------ mHC backbone (inference) --
+def mhc_gates(h, norm_w, w, alpha, beta, sk_it):
+    """gymrl_mhc_gates: h [B, n, D] -> (pre [B, n], post [B, n], mix [B, n, n], read [B, D])."""
+    B, n, D = h.shape
+    dev = h.device
+    pre, post = torch.empty(B, n, device=dev), torch.empty(B, n, device=dev)
+    mix, read = torch.empty(B, n, n, device=dev), torch.empty(B, D, device=dev)
+    check(lib().gymrl_mhc_gates(_ptr(h, torch.float32), _ptr(norm_w, torch.float32), _ptr(w, torch.float32),
+                                _ptr(alpha, torch.float32), _ptr(beta, torch.float32), C.c_int(B), C.c_int(n), C.c_int(D),
+                                C.c_int(sk_it), _ptr(pre), _ptr(post), _ptr(mix), _ptr(read), _stream()), "gymrl_mhc_gates")
+    return pre, post, mix, read
+
+
+def mhc_combine(post, mix, out, h):
+    """gymrl_mhc_combine: h'[b, i] = post[b, i] out[b] + sum_j mix[b, i, j] h[b, j]."""
+    B, n, D = h.shape
+    h_out = torch.empty_like(h)
+    check(lib().gymrl_mhc_combine(_ptr(post, torch.float32), _ptr(mix, torch.float32), _ptr(out, torch.float32),
+                                  _ptr(h, torch.float32), C.c_int(B), C.c_int(n), C.c_int(D), _ptr(h_out), _stream()),
+          "gymrl_mhc_combine")
+    return h_out
+
+
+def rmsnorm(x, w, eps, n_sum=1):
+    """gymrl_rmsnorm: x [B, n_sum * D] (or [B, n_sum, D]) -> y [B, D] = s rsqrt(mean(s^2) + eps) w, s = the sum of the blocks."""
+    B, D = x.shape[0], w.numel()
+    y = torch.empty(B, D, device=x.device)
+    check(lib().gymrl_rmsnorm(_ptr(x, torch.float32), _ptr(w, torch.float32), C.c_int(B), C.c_int(D), C.c_int(n_sum),
+                              C.c_float(eps), _ptr(y), _stream()), "gymrl_rmsnorm")
+    return y

@@ -65,6 +65,9 @@ class Config:
         self.gae_variant = 1               # 1 = time-blocked G3 with the chunk maps composed during the rollout, 0 = sequential
 
 
+FUSED_INFERENCE = True      # rollout forward on the inference kernels (tools A/B; False: the torch modules)
+
+
 def _ortho(layer, std):
     nn.init.orthogonal_(layer.weight, gain=std)
     if layer.bias is not None:
@@ -240,16 +243,41 @@ class ActorCritic(nn.Module):
         return self.actor(x), self.critic(x)
 
     @torch.no_grad()
+    def forward_fused(self, x):
+        """forward(x) without gradients on the inference kernels (csrc/mhc.hip, csrc/lin.hip): ~20 launches instead of
+        ~400 — one per Linear (+ SiLU), three per hyper-connection (gates + read, Linear + SiLU, combine), the RMSNorms.
+        Same values as the modules to 1e-5 (tests/test_mhc_fused_gpu.py).  None when the network is not the mHC one."""
+        bb = self.shared
+        if not isinstance(bb, MHCBackbone) or not x.is_cuda or bb.rate not in (2, 4):
+            return None
+        silu = ops.LIN_ACT["silu"]
+        z = ops.lin_fwd(x.contiguous(), bb.input_proj.weight, bb.input_proj.bias)
+        h = z.unsqueeze(1).repeat(1, bb.rate, 1)
+        for layer in bb.layers:
+            for fuse, linear in ((layer.mhc1, layer.linear1), (layer.mhc2, layer.linear2)):
+                _, post, mix, read = ops.mhc_gates(h, fuse.norm.weight, fuse.w, fuse.alpha, fuse.beta, fuse.max_sk_it)
+                h = ops.mhc_combine(post, mix, ops.lin_fwd(read, linear.weight, linear.bias, silu), h)
+        feat = ops.rmsnorm(h, bb.final_norm.weight, bb.final_norm.eps, n_sum=bb.rate)
+        a, c = self.actor.mlp, self.critic.mlp
+        if len(a) != 4 or len(c) != 4:
+            return None
+        ha, hc = ops.lin_fwd([feat, feat], [a[0].weight, c[0].weight], [a[0].bias, c[0].bias], silu)
+        ha, hc = ops.rmsnorm(ha, a[2].weight, a[2].eps), ops.rmsnorm(hc, c[2].weight, c[2].eps)
+        return ops.lin_fwd(ha, a[3].weight, a[3].bias), ops.lin_fwd(hc, c[3].weight, c[3].bias)
+
+    @torch.no_grad()
     def get_action(self, x, deterministic=False, seed=0, counter=0, env_id0=0):
         """:395-407 batched -> (action i32[N], logp[N], value[N], entropy[N])."""
-        logits, value = self.forward(x)
+        out = self.forward_fused(x) if FUSED_INFERENCE else None
+        logits, value = self.forward(x) if out is None else out
         act, logp, ent, val = ops.categorical_sample(logits, value=value.view(-1), seed=seed, counter=counter,
                                                      env_id0=env_id0, deterministic=deterministic)
         return act, logp, val, ent
 
     @torch.no_grad()
     def get_value(self, x):
-        return self.forward(x)[1].view(-1)
+        out = self.forward_fused(x) if FUSED_INFERENCE else None
+        return (self.forward(x) if out is None else out)[1].view(-1)
 
 
 class RolloutBuffer:
@@ -327,7 +355,8 @@ class PPOTrainer:
             if graphed:                                   # the ~100-launch mHC forward as one graph launch
                 logits, value = self._forward_graphed(b.states[t])
             else:
-                logits, value = self.model(b.states[t])
+                out = self.model.forward_fused(b.states[t]) if FUSED_INFERENCE else None
+                logits, value = self.model(b.states[t]) if out is None else out
             ops.categorical_sample(logits, value=value.view(-1), noise_exp=None if noise is None else noise[t],
                                    seed=env.seed, counter=c0 + t, env_id0=env.env_id0,
                                    act_out=b.actions[t], logp_out=b.log_probs[t], ent_out=b.old_entropies[t],
@@ -350,10 +379,12 @@ class PPOTrainer:
         if self._fwd_graph is None:
             if self._fwd_warm < 2:
                 self._fwd_warm += 1
-                return self.model(self._fwd_in)
+                out = self.model.forward_fused(self._fwd_in) if FUSED_INFERENCE else None
+                return self.model(self._fwd_in) if out is None else out
             self._fwd_graph = torch.cuda.CUDAGraph()
             with gcapture(self._fwd_graph):
-                self._fwd_out = self.model(self._fwd_in)
+                out = self.model.forward_fused(self._fwd_in) if FUSED_INFERENCE else None
+                self._fwd_out = self.model(self._fwd_in) if out is None else out
         self._fwd_graph.replay()
         return self._fwd_out
 

@@ -391,7 +391,7 @@ int gymrl_soft_update(float* target, const float* source, int64_t n, double tau,
 #define GYMRL_MLP_MAX_STAGES 8
 #define GYMRL_MLP_MAX_WIDTH 256
 #define GYMRL_MLP_MAX_INPUT 64
-enum { GYMRL_ACT_NONE = 0, GYMRL_ACT_TANH = 1, GYMRL_ACT_RELU = 2, GYMRL_ACT_CLAMP = 3, GYMRL_ACT_DUELING = 4 /* 3, 4: gymrl_lin_* only */ };
+enum { GYMRL_ACT_NONE = 0, GYMRL_ACT_TANH = 1, GYMRL_ACT_RELU = 2, GYMRL_ACT_CLAMP = 3, GYMRL_ACT_DUELING = 4, GYMRL_ACT_SILU = 5 /* 3-5: gymrl_lin_* only; 4, 5: forward only */ };
 typedef struct {
   const float* W;
   const float* b;
@@ -528,6 +528,27 @@ int gymrl_noisy_combine(const gymrl_noisy_layer* layers, int n_layers, int K, in
 int gymrl_noisy_split(const gymrl_noisy_layer* layers, int n_layers, int K, int training, const float* dW, const float* db,
                       int accumulate, void* stream);
 int gymrl_dueling_bwd(const float* dq, int B, int A, float* dS_out, void* stream);
+
+/* ================================================ mHC backbone, inference == */
+/*
+ * F1 (rollout forward only): ManifoldHyperConnectionFuse.gates + MHCBlock._sub + RMSNorm of PPO-full's network —
+ * ppo_full_lunarlander.py:106-194 (gates :125-147, sub-block :160-165), RMSNorm :96-104, MHCBackbone.forward :178-183 —
+ * as called from get_action :395-407 / get_value once per env step.  The reference issues ~95 torch launches per
+ * hyper-connection; here a sub-block is gymrl_mhc_gates + gymrl_lin_fwd(act = GYMRL_ACT_SILU) + gymrl_mhc_combine.
+ *   gymrl_mhc_gates: h [B, n, D] (n = 2 or 4 branches) -> pre [B, n] = sigmoid(r H[:n] a0 + beta), post [B, n] =
+ *     2 sigmoid(r H[n:2n] a1 + beta), mix [B, n, n] = u A v with A = exp(r H[2n:] a2 + beta) and u, v from sk_it
+ *     Sinkhorn-Knopp sweeps, where H = (norm_w * flat) w, r = 1 / (|flat| / sqrt(nD) + 1e-6); read [B, D] = sum_i pre_i h_i.
+ *     norm_w [nD] = fuse.norm.weight, w [nD, n*n + 2n], alpha [3], beta [n*n + 2n].
+ *   gymrl_mhc_combine: h_out[b, i, :] = post[b, i] out[b, :] + sum_j mix[b, i, j] h[b, j, :].
+ *   gymrl_rmsnorm: y [B, D] = x rsqrt(mean(x^2) + eps) w, x = the sum of the row's n_sum consecutive [D] blocks
+ *     (n_sum = n: final_norm(h.sum(1)); 1: the MLPs' RMSNorm).
+ * Floating point, compared with the torch modules at 1e-5 (tests/test_mhc_fused_gpu.py); the training pass keeps the modules.
+ */
+int gymrl_mhc_gates(const float* h, const float* norm_w, const float* w, const float* alpha, const float* beta, int B, int n,
+                    int D, int sk_it, float* pre_out, float* post_out, float* mix_out, float* read_out, void* stream);
+int gymrl_mhc_combine(const float* post, const float* mix, const float* out, const float* h, int B, int n, int D, float* h_out,
+                      void* stream);
+int gymrl_rmsnorm(const float* x, const float* w, int B, int D, int n_sum, float eps, float* y, void* stream);
 
 /* ===================================================== MLP update path ===== */
 /*

@@ -1,0 +1,66 @@
+"""PPO-full's rollout forward on the inference kernels (csrc/mhc.hip + csrc/lin.hip) against the torch modules in float64."""
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, ref, tol):
+    ref = ref.to(got.device)
+    err = float((got.detach().double() - ref).abs().max())
+    assert err <= tol * max(1.0, float(ref.abs().max())), err
+
+
+@pytest.mark.parametrize("rate,dim,B", [(2, 128, 4096), (2, 64, 37), (4, 32, 300)])
+def test_mhc_gates_combine_rmsnorm_match_modules(rate, dim, B):
+    from gymrl_amd import ops
+    from gymrl_amd.ppo_full_lunarlander import ManifoldHyperConnectionFuse, RMSNorm
+    torch.manual_seed(rate * 100 + dim)
+    fuse = ManifoldHyperConnectionFuse(dim, rate, 10)
+    with torch.no_grad():                                   # the module starts with w = 0: make the read-out matter
+        fuse.w.normal_(0, 0.5)
+        fuse.alpha.copy_(torch.tensor([0.7, -0.4, 0.9]))
+        fuse.norm.weight.uniform_(0.5, 1.5)
+    h = torch.randn(B, rate, dim) * 2
+    ref = ManifoldHyperConnectionFuse(dim, rate, 10).double()
+    ref.load_state_dict({k: v.double() for k, v in fuse.state_dict().items()})
+    pre64, post64, mix64 = ref.gates(h.double())
+    fuse, hd = fuse.cuda(), h.cuda()
+    pre, post, mix, read = ops.mhc_gates(hd, fuse.norm.weight, fuse.w, fuse.alpha, fuse.beta, 10)
+    _close(pre, pre64, 1e-5)
+    _close(post, post64, 1e-5)
+    _close(mix, mix64, 1e-5)
+    _close(read, torch.bmm(pre64.unsqueeze(1), h.double()).squeeze(1), 1e-5)
+    out = torch.randn(B, dim)
+    got = ops.mhc_combine(post, mix, out.cuda(), hd)
+    want = torch.bmm(post64.unsqueeze(2), out.double().unsqueeze(1)) + torch.bmm(mix64, h.double())
+    _close(got, want, 1e-5)
+    norm = RMSNorm(dim)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+    _close(ops.rmsnorm(hd, norm.weight.cuda(), norm.eps, n_sum=rate), norm.double()(h.double().sum(1)), 1e-5)
+    _close(ops.rmsnorm(out.cuda(), norm.float().weight.cuda(), norm.eps), norm.double()(out.double()), 1e-5)
+
+
+@pytest.mark.parametrize("rate,dim,layers", [(2, 128, 2), (4, 32, 1)])
+def test_fused_forward_matches_actor_critic(rate, dim, layers):
+    from gymrl_amd.ppo_full_lunarlander import ActorCritic, Config
+    cfg = Config()
+    cfg.mhc_rate, cfg.mhc_dim, cfg.mhc_layers = rate, dim, layers
+    torch.manual_seed(5)
+    net = ActorCritic(8, 4, config=cfg)
+    with torch.no_grad():
+        for m in net.modules():
+            if hasattr(m, "w") and hasattr(m, "alpha"):
+                m.w.normal_(0, 0.3)
+    ref = ActorCritic(8, 4, config=cfg).double()
+    ref.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    x = torch.randn(1000, 8)
+    logits64, value64 = ref(x.double())
+    net = net.cuda()
+    logits, value = net.forward_fused(x.cuda())
+    _close(logits, logits64, 1e-5)
+    _close(value, value64, 1e-5)
+    lm, vm = net(x.cuda())                                   # and against the float32 modules themselves
+    _close(logits, lm.double(), 2e-5)
+    _close(value, vm.double(), 2e-5)
