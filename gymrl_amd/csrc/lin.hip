@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void dueling_bwd_kernel(const float* __restric
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // 16 x 64 tiles per wave once 16 x 16 tiles would be more waves than the chip has SIMDs twice over
-inline int pick_nt(int row_tiles, int cols) { return (int64_t)row_tiles * cdiv(cols, 16) > 2048 ? 4 : 1; }
+inline int pick_nt(int row_tiles, int cols) { return (cols > 16 && (int64_t)row_tiles * cdiv(cols, 16) > 2048) ? 4 : 1; }
 inline int slices_for(int B) { return B <= 512 ? 1 : (cdiv(B, 256) < 16 ? cdiv(B, 256) : 16); }
 
 }  // namespace

@@ -151,8 +151,11 @@ def GradSink_undo(sw, sb):
 
 
 def _fusable(x, weight):
+    """Batches up to a few thousand rows — and skinny layers (<= 16 inputs or outputs) at ANY row count: the library answers
+    a [262144, 256] x [256, 8] product with a 256 x 16 macro tile in 3.6 ms (PPO-full's gate read-outs and heads: 78 % of its
+    update, `profiles/r02_ppo_full_kernel_stats.csv`), where the operands' 268 MB are 60 us of HBM time."""
     return (FUSED_LINEAR and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32
-            and 0 < x.shape[0] <= _FUSED_MAX_ROWS)
+            and x.shape[0] > 0 and (x.shape[0] <= _FUSED_MAX_ROWS or min(weight.shape) <= 16))
 
 
 def _act_torch(z, act, clamp):
@@ -195,6 +198,39 @@ class SmallLinear(nn.Linear):
 
     def forward(self, x, x2=None):
         return fused_linears([self], [x], None if x2 is None else [x2])[0]
+
+
+class _SkinnyMatmul(torch.autograd.Function):
+    """x [B, K] @ w [K, G] with G <= 16 (the mHC gates' read-out, ppo_full_lunarlander.py:129) on the layer kernels:
+    forward, input gradient and weight gradient are one HBM-bound launch each at any B."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        from . import ops
+        x = x.contiguous()
+        wt = w.t().contiguous()                      # [G, K] = the nn.Linear layout the kernels take
+        ctx.save_for_backward(x, wt)
+        return ops.lin_fwd(x, wt, None)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        x, wt = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.lin_bwd_input(dy, None, wt)[0] if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dwt = torch.empty_like(wt)
+            ops.lin_bwd_weight(dy, None, x, dwt, None)
+            dw = dwt.t()
+        return dx, dw
+
+
+def skinny_matmul(x, w):
+    """x @ w for a narrow w ([K, G], G <= 16) — fused kernels on the GPU, torch elsewhere."""
+    if FUSED_LINEAR and x.is_cuda and x.dim() == 2 and w.shape[1] <= 16 and x.dtype == torch.float32:
+        return _SkinnyMatmul.apply(x, w)
+    return x @ w
 
 
 class frozen_parameters:

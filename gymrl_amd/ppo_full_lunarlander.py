@@ -24,7 +24,7 @@ from . import ops
 from .graphs import capture as gcapture
 from .envs import VecEnv
 from .flat import FusedAdam, GradSink, flatten_module
-from .nn import SmallLinear
+from .nn import SmallLinear, skinny_matmul
 
 
 class Config:
@@ -107,7 +107,7 @@ class ManifoldHyperConnectionFuse(nn.Module):
         """h [B, n, D] -> (pre [B, n], post [B, n], mix [B, n, n])."""
         B, n = h.shape[0], self.n
         flat = h.reshape(B, self.nc)
-        H = (self.norm.weight * flat) @ self.w
+        H = skinny_matmul(self.norm.weight * flat, self.w)       # [B, nc] x [nc, n*n + 2n]: HBM-bound kernels (gymrl_amd/nn.py)
         r_inv = 1.0 / (flat.norm(dim=-1, keepdim=True) / math.sqrt(self.nc) + 1e-6)
         pre = torch.sigmoid(r_inv * H[:, :n] * self.alpha[0] + self.beta[:n])
         post = 2 * torch.sigmoid(r_inv * H[:, n:2 * n] * self.alpha[1] + self.beta[n:2 * n])
@@ -133,6 +133,16 @@ class MHCBlock(nn.Module):
     @staticmethod
     def _sub(h, fuse, linear, act):
         pre, post, mix = fuse.gates(h)
+        if h.is_cuda:
+            # the same three products as broadcast multiplies: the library answers 262144 batched 1 x n x D GEMMs (one per
+            # row of a micro-batch) in 2.5-3.6 ms each way — 78 % of a PPO-full update (`profiles/r02_ppo_full_kernel_stats.csv`)
+            # — where the operands are ~0.1 ms of HBM time
+            read = (pre.unsqueeze(2) * h).sum(1, keepdim=True)                 # weighted sum of branches  [B, 1, D]
+            out = act(linear(read))
+            mixed = mix[:, :, 0:1] * h[:, 0:1, :]
+            for j in range(1, h.shape[1]):
+                mixed = mixed + mix[:, :, j:j + 1] * h[:, j:j + 1, :]
+            return post.unsqueeze(2) * out + mixed                             # broadcast back + inter-branch mixing
         read = torch.bmm(pre.unsqueeze(1), h)                    # weighted sum of branches  [B, 1, D]
         out = act(linear(read))
         return torch.bmm(post.unsqueeze(2), out) + torch.bmm(mix, h)   # broadcast back + inter-branch mixing
