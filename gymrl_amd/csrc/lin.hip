@@ -494,18 +494,61 @@ __global__ __launch_bounds__(256) void dueling_bwd_kernel(const float* __restric
   dS[(size_t)b * (A + 1) + A] = s;
 }
 
+// ---- skinny shapes at large B: a 16 x 16 MFMA tile per wave is store-issue bound there (dword stores of 64-byte row
+// segments); with <= 16 terms per output the products fit the VALU and a lane writes 16 bytes ----------------------
+constexpr int kSkinny = 16;
+
+// dX[b][k .. k+3] = sum_n (dY[b][n] * act'(Y[b][n])) W[n][k .. k+3],  N <= 16
+__global__ __launch_bounds__(256) void lin_bwd_input_skinny_kernel(const LinBwdIn a) {
+  const int item = blockIdx.y;
+  const float* __restrict__ dY = a.dY[item];
+  const float* __restrict__ Yv = a.Y[item];
+  const float* __restrict__ W = a.W[item];
+  float* __restrict__ dX = a.dX[item];
+  const int act = a.act[item];
+  const float lo = a.lo[item], hi = a.hi[item];
+  const int k4 = a.K >> 2;
+  const int64_t total = (int64_t)a.B * k4;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t b = t / k4;
+    const int k = (int)(t % k4) * 4;
+    f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int n = 0; n < a.N; ++n) {
+      float dz = dY[b * a.ldy + n];
+      if (act != GYMRL_ACT_NONE) dz *= act_bwd(Yv[b * a.ldy + n], act, lo, hi);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(W + (size_t)n * a.K + k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += dz * w[e];
+    }
+    f32x4* dst = reinterpret_cast<f32x4*>(dX + b * a.lddx + k);
+    if (a.accumulate) { const f32x4 o = *dst; s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3]; }
+    *dst = s;
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // 16 x 64 tiles per wave once 16 x 16 tiles would be more waves than the chip has SIMDs twice over
 inline int pick_nt(int row_tiles, int cols) { return (cols > 16 && (int64_t)row_tiles * cdiv(cols, 16) > 2048) ? 4 : 1; }
-inline int slices_for(int B) { return B <= 512 ? 1 : (cdiv(B, 256) < 16 ? cdiv(B, 256) : 16); }
+// row slices of the weight gradient: enough (tile, slice) waves to fill the chip — a skinny layer has few output tiles, so
+// at 262144 rows its reduction is cut 128 ways (16 slices left 256 waves walking 16384 rows each: 440 us) — and never
+// fewer than 256 rows per slice
+inline int slices_for(int B, int N, int K) {
+  if (B <= 512) return 1;
+  const int tiles = cdiv(N, 16) * cdiv(K, 16);
+  int s = cdiv(2048, tiles);
+  if (s < 16) s = 16;
+  if (s > 256) s = 256;
+  const int by_rows = cdiv(B, 256);
+  return s < by_rows ? s : by_rows;
+}
 
 }  // namespace
 
 extern "C" {
 
 size_t gymrl_lin_workspace_bytes(int B, int N, int K, int n_items) {
-  const int s = slices_for(B);
+  const int s = slices_for(B, N, K);
   return s > 1 ? sizeof(float) * (size_t)n_items * s * ((size_t)N * K + N) : 0;
 }
 
@@ -563,6 +606,15 @@ int gymrl_lin_bwd_input(const gymrl_lin_item* items, int n_items, int B, int N, 
   a.col_groups = cdiv(K, 16 * nt);
   const dim3 grid(cdiv(row_tiles * a.col_groups, kWavesPerBlock), sum_items ? 1 : n_items), block(64 * kWavesPerBlock);
   hipStream_t s = static_cast<hipStream_t>(stream_);
+  bool skinny = N <= kSkinny && K1 == K && K % 4 == 0 && lddx % 4 == 0 && B > 8192 && !(sum_items && n_items > 1);
+  for (int i = 0; i < n_items; ++i) skinny = skinny && items[i].dx && aligned16(items[i].dx) && aligned16(items[i].w);
+  if (skinny) {
+    int64_t nb = ((int64_t)B * (K / 4) + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(lin_bwd_input_skinny_kernel, dim3((unsigned)nb, n_items), dim3(256), 0, s, a);
+    GYMRL_CHECK_LAUNCH();
+    return 0;
+  }
   if (nt == 4) {
     if (vec) hipLaunchKernelGGL((lin_bwd_input_kernel<4, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((lin_bwd_input_kernel<4, false>), grid, block, 0, s, a);
@@ -588,7 +640,7 @@ int gymrl_lin_bwd_weight(const gymrl_lin_item* items, int n_items, int B, int N,
   }
   a.B = B; a.N = N; a.K = K; a.K1 = K1; a.ldy = ldy; a.ldx = ldx; a.ldx2 = ldx2;
   a.accumulate = accumulate;
-  a.slices = slices_for(B);
+  a.slices = slices_for(B, N, K);
   a.rows_per_slice = cdiv(cdiv(B, a.slices), 16) * 16;
   if (a.slices > 1 && !workspace) return -22;
   a.partial = static_cast<float*>(workspace);

@@ -44,6 +44,7 @@ def _close(got, ref, scale=None, tol=1e-5):
 SHAPES = [  # B, K1, K2, N
     (128, 256, 0, 256), (128, 3, 1, 256), (128, 256, 0, 1), (256, 4, 0, 128), (100, 8, 0, 51), (37, 130, 5, 70),
     (4096, 256, 0, 256), (1, 3, 0, 256), (4096, 3, 0, 256), (8192, 128, 0, 2),
+    (20000, 256, 0, 8), (20000, 8, 0, 128), (16385, 12, 0, 4),          # skinny shapes at large B: the VALU kernels
 ]
 
 
