@@ -58,6 +58,7 @@ def small_linear(x, weight, bias):
 
 FUSED_LINEAR = True    # tools/micro_offpolicy.py flips this for its A/B (False: library GEMM + elementwise launches)
 _FUSED_MAX_ROWS = 16384
+_FUSED_ANY_ROWS_WIDTH = 128      # layers up to this wide take the layer kernels at any row count (PPO-full's 128 x 128 Linears)
 
 
 class _FusedLinear(torch.autograd.Function):
@@ -155,7 +156,7 @@ def _fusable(x, weight):
     a [262144, 256] x [256, 8] product with a 256 x 16 macro tile in 3.6 ms (PPO-full's gate read-outs and heads: 78 % of its
     update, `profiles/r02_ppo_full_kernel_stats.csv`), where the operands' 268 MB are 60 us of HBM time."""
     return (FUSED_LINEAR and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32
-            and x.shape[0] > 0 and (x.shape[0] <= _FUSED_MAX_ROWS or min(weight.shape) <= 16))
+            and x.shape[0] > 0 and (x.shape[0] <= _FUSED_MAX_ROWS or min(weight.shape) <= 16 or max(weight.shape) <= _FUSED_ANY_ROWS_WIDTH))
 
 
 def _act_torch(z, act, clamp):

@@ -137,8 +137,8 @@ class MHCBlock(nn.Module):
             # the same three products as broadcast multiplies: the library answers 262144 batched 1 x n x D GEMMs (one per
             # row of a micro-batch) in 2.5-3.6 ms each way — 78 % of a PPO-full update (`profiles/r02_ppo_full_kernel_stats.csv`)
             # — where the operands are ~0.1 ms of HBM time
-            read = (pre.unsqueeze(2) * h).sum(1, keepdim=True)                 # weighted sum of branches  [B, 1, D]
-            out = act(linear(read))
+            read = (pre.unsqueeze(2) * h).sum(1)                               # weighted sum of branches  [B, D]
+            out = act(linear(read)).unsqueeze(1)                               # (2-D: the layer kernels take it)
             mixed = mix[:, :, 0:1] * h[:, 0:1, :]
             for j in range(1, h.shape[1]):
                 mixed = mixed + mix[:, :, j:j + 1] * h[:, j:j + 1, :]
