@@ -30,9 +30,9 @@ def capture(graph):
     """`torch.cuda.graph(graph)` with Python's cycle collector held off for the duration of the capture.  A collection
     that runs in the middle of a capture can finalise an OLD trainer (a reference cycle through its closures, kept alive
     until then by a caller's frame); destroying that trainer's captured graphs releases their private memory pool, and a
-    device free while a stream is capturing is an error that surfaces inside a destructor — the process aborts.  Garbage is
-    collected once right before the capture instead."""
-    gc.collect()
+    device free while a stream is capturing is an error that surfaces inside a destructor — the process aborts.
+    (torch's context manager collects once on entry; an additional explicit gc.collect() in front of it was measured to
+    make the graph captured afterwards 35 % slower to replay — Rainbow 0.36 -> 0.49 ms per vector step — so there is none.)"""
     was_enabled = gc.isenabled()
     gc.disable()
     try:
