@@ -16,7 +16,6 @@ from collections import deque
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import nn as gnn
 from . import ops

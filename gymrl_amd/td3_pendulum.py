@@ -11,7 +11,6 @@ the Polyak updates are HIP kernels behind the C-ABI; Linear layers run through P
 import copy
 from collections import deque
 
-import numpy as np
 import torch
 import torch.nn as nn
 
