@@ -1040,3 +1040,12 @@ def rmsnorm(x, w, eps, n_sum=1):
     check(lib().gymrl_rmsnorm(_ptr(x, torch.float32), _ptr(w, torch.float32), C.c_int(B), C.c_int(D), C.c_int(n_sum),
                               C.c_float(eps), _ptr(y), _stream()), "gymrl_rmsnorm")
     return y
+
+
+def sinkhorn(A, sk_it):
+    """gymrl_sinkhorn: A [B, n, n] -> (u [B, n], v [B, n])."""
+    B, n, _ = A.shape
+    u, v = torch.empty(B, n, device=A.device), torch.empty(B, n, device=A.device)
+    check(lib().gymrl_sinkhorn(_ptr(A, torch.float32), C.c_int(B), C.c_int(n), C.c_int(sk_it), _ptr(u), _ptr(v), _stream()),
+          "gymrl_sinkhorn")
+    return u, v

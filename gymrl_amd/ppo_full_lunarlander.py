@@ -112,6 +112,9 @@ class ManifoldHyperConnectionFuse(nn.Module):
         pre = torch.sigmoid(r_inv * H[:, :n] * self.alpha[0] + self.beta[:n])
         post = 2 * torch.sigmoid(r_inv * H[:, n:2 * n] * self.alpha[1] + self.beta[n:2 * n])
         A = (r_inv * H[:, 2 * n:] * self.alpha[2] + self.beta[2 * n:]).reshape(B, n, n).exp()
+        if A.is_cuda and n in (2, 4):                # the sweeps in one launch (~6 launches per sweep through torch)
+            u, v = ops.sinkhorn(A.detach().contiguous(), self.max_sk_it)
+            return pre, post, u.unsqueeze(2) * A * v.unsqueeze(1)
         with torch.no_grad():                        # Sinkhorn-Knopp scalings, treated as constants
             u = torch.ones(B, n, device=h.device)
             v = torch.ones(B, n, device=h.device)

@@ -549,6 +549,10 @@ int gymrl_mhc_gates(const float* h, const float* norm_w, const float* w, const f
 int gymrl_mhc_combine(const float* post, const float* mix, const float* out, const float* h, int B, int n, int D, float* h_out,
                       void* stream);
 int gymrl_rmsnorm(const float* x, const float* w, int B, int D, int n_sum, float eps, float* y, void* stream);
+/* The Sinkhorn-Knopp sweeps alone (:141-146; constants of the backward pass in the reference): A f32[B, n, n] > 0 ->
+ * u [B, n], v [B, n] after sk_it sweeps u = 1/(A v + 1e-8), v = 1/(A^T u + 1e-8) from u = v = 1 — used by the TRAINING
+ * pass, whose other gate operations stay with autograd. */
+int gymrl_sinkhorn(const float* A, int B, int n, int sk_it, float* u_out, float* v_out, void* stream);
 
 /* ===================================================== MLP update path ===== */
 /*
