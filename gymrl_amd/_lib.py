@@ -46,6 +46,7 @@ SYMBOLS = [
     "gymrl_lin_workspace_bytes", "gymrl_lin_fwd", "gymrl_lin_bwd_input", "gymrl_lin_bwd_weight",
     "gymrl_noisy_combine", "gymrl_noisy_split", "gymrl_dueling_bwd",
     "gymrl_mhc_gates", "gymrl_mhc_combine", "gymrl_rmsnorm", "gymrl_sinkhorn",
+    "gymrl_mhc_read_fwd", "gymrl_mhc_read_bwd", "gymrl_mhc_combine_bwd",
 ]
 
 

@@ -128,6 +128,109 @@ __global__ __launch_bounds__(256) void mhc_combine_kernel(const float* __restric
   }
 }
 
+// ---- training pass: the two branch-mixing products of a hyper-connection with their backward, one launch each way ----
+// read[b, :] = sum_i pre[b, i] h[b, i, :]                        (MHCBlock._sub :161)
+template <int N>
+__global__ __launch_bounds__(256) void mhc_read_fwd_kernel(const float* __restrict__ pre, const float* __restrict__ h, int B, int D,
+                                                           float* __restrict__ read) {
+  const int64_t total = (int64_t)B * (D >> 2);
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t b = t / (D >> 2);
+    const int d = (int)(t % (D >> 2)) * 4;
+    f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const float p = pre[b * N + i];
+      const f32x4 x = *reinterpret_cast<const f32x4*>(h + (b * N + i) * D + d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += p * x[e];
+    }
+    *reinterpret_cast<f32x4*>(read + b * D + d) = s;
+  }
+}
+
+// one wave per row: d_pre[b, i] = sum_d g[b, d] h[b, i, d];  d_h[b, i, d] (+)= pre[b, i] g[b, d]
+template <int N>
+__global__ __launch_bounds__(64 * kWaves) void mhc_read_bwd_kernel(const float* __restrict__ g, const float* __restrict__ pre,
+                                                                 const float* __restrict__ h, int B, int D,
+                                                                 float* __restrict__ d_pre, float* __restrict__ d_h, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (row >= B) return;
+  float p[N], acc[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { p[i] = pre[row * N + i]; acc[i] = 0.0f; }
+  for (int d = lane; d < D; d += 64) {
+    const float gv = g[row * D + d];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int64_t o = (row * N + i) * D + d;
+      acc[i] += gv * h[o];
+      d_h[o] = accumulate ? d_h[o] + p[i] * gv : p[i] * gv;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[i] += __shfl_xor(acc[i], off, 64);
+    if (lane == 0) d_pre[row * N + i] = acc[i];
+  }
+}
+
+// backward of h'[b, i, :] = post[b, i] out[b, :] + sum_j mix[b, i, j] h[b, j, :], one wave per row:
+//   d_post[i] = sum_d g[i, d] out[d];  d_out[d] = sum_i post[i] g[i, d];  d_mix[i, j] = sum_d g[i, d] h[j, d];  d_h[j, d] = sum_i mix[i, j] g[i, d]
+template <int N>
+__global__ __launch_bounds__(64 * kWaves) void mhc_combine_bwd_kernel(const float* __restrict__ g, const float* __restrict__ post,
+                                                                    const float* __restrict__ mix, const float* __restrict__ out,
+                                                                    const float* __restrict__ h, int B, int D,
+                                                                    float* __restrict__ d_post, float* __restrict__ d_mix,
+                                                                    float* __restrict__ d_out, float* __restrict__ d_h) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (row >= B) return;
+  float po[N], mx[N][N], a_post[N], a_mix[N][N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    po[i] = post[row * N + i]; a_post[i] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < N; ++j) { mx[i][j] = mix[(row * N + i) * N + j]; a_mix[i][j] = 0.0f; }
+  }
+  for (int d = lane; d < D; d += 64) {
+    float gv[N], hv[N];
+    const float o = out[row * D + d];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { gv[i] = g[(row * N + i) * D + d]; hv[i] = h[(row * N + i) * D + d]; }
+    float so = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      so += po[i] * gv[i];
+      a_post[i] += gv[i] * o;
+#pragma unroll
+      for (int j = 0; j < N; ++j) a_mix[i][j] += gv[i] * hv[j];
+    }
+    d_out[row * D + d] = so;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      float sh = 0.0f;
+#pragma unroll
+      for (int i = 0; i < N; ++i) sh += mx[i][j] * gv[i];
+      d_h[(row * N + j) * D + d] = sh;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a_post[i] += __shfl_xor(a_post[i], off, 64);
+    if (lane == 0) d_post[row * N + i] = a_post[i];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) a_mix[i][j] += __shfl_xor(a_mix[i][j], off, 64);
+      if (lane == 0) d_mix[(row * N + i) * N + j] = a_mix[i][j];
+    }
+  }
+}
+
 // Sinkhorn-Knopp scalings of B positive n x n matrices (ManifoldHyperConnectionFuse.gates :141-146, under no_grad in the
 // reference: u, v are constants of the backward pass): one lane per matrix instead of ~6 launches per sweep.
 template <int N>
@@ -211,6 +314,39 @@ int gymrl_mhc_combine(const float* post, const float* mix, const float* out, con
   if (nb > 4096) nb = 4096;
   if (n == 2) hipLaunchKernelGGL(mhc_combine_kernel<2>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, post, mix, out, h, B, D, h_out);
   else hipLaunchKernelGGL(mhc_combine_kernel<4>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, post, mix, out, h, B, D, h_out);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_mhc_read_fwd(const float* pre, const float* h, int B, int n, int D, float* read_out, void* stream) {
+  if (!pre || !h || !read_out || B < 0 || D < 4 || D % 4 || (n != 2 && n != 4)) return -22;
+  if (B == 0) return 0;
+  int64_t nb = ((int64_t)B * (D / 4) + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  if (n == 2) hipLaunchKernelGGL(mhc_read_fwd_kernel<2>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, pre, h, B, D, read_out);
+  else hipLaunchKernelGGL(mhc_read_fwd_kernel<4>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, pre, h, B, D, read_out);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_mhc_read_bwd(const float* g, const float* pre, const float* h, int B, int n, int D, float* d_pre, float* d_h,
+                       int accumulate, void* stream) {
+  if (!g || !pre || !h || !d_pre || !d_h || B < 0 || D < 1 || (n != 2 && n != 4)) return -22;
+  if (B == 0) return 0;
+  const dim3 grid((B + kWaves - 1) / kWaves), block(64 * kWaves);
+  if (n == 2) hipLaunchKernelGGL(mhc_read_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, g, pre, h, B, D, d_pre, d_h, accumulate);
+  else hipLaunchKernelGGL(mhc_read_bwd_kernel<4>, grid, block, 0, (hipStream_t)stream, g, pre, h, B, D, d_pre, d_h, accumulate);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_mhc_combine_bwd(const float* g, const float* post, const float* mix, const float* out, const float* h, int B, int n, int D,
+                          float* d_post, float* d_mix, float* d_out, float* d_h, void* stream) {
+  if (!g || !post || !mix || !out || !h || !d_post || !d_mix || !d_out || !d_h || B < 0 || D < 1 || (n != 2 && n != 4)) return -22;
+  if (B == 0) return 0;
+  const dim3 grid((B + kWaves - 1) / kWaves), block(64 * kWaves);
+  if (n == 2) hipLaunchKernelGGL(mhc_combine_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, g, post, mix, out, h, B, D, d_post, d_mix, d_out, d_h);
+  else hipLaunchKernelGGL(mhc_combine_bwd_kernel<4>, grid, block, 0, (hipStream_t)stream, g, post, mix, out, h, B, D, d_post, d_mix, d_out, d_h);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

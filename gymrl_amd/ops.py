@@ -1049,3 +1049,30 @@ def sinkhorn(A, sk_it):
     check(lib().gymrl_sinkhorn(_ptr(A, torch.float32), C.c_int(B), C.c_int(n), C.c_int(sk_it), _ptr(u), _ptr(v), _stream()),
           "gymrl_sinkhorn")
     return u, v
+
+
+def mhc_read_fwd(pre, h):
+    B, n, D = h.shape
+    read = torch.empty(B, D, device=h.device)
+    check(lib().gymrl_mhc_read_fwd(_ptr(pre, torch.float32), _ptr(h, torch.float32), C.c_int(B), C.c_int(n), C.c_int(D), _ptr(read),
+                                   _stream()), "gymrl_mhc_read_fwd")
+    return read
+
+
+def mhc_read_bwd(g, pre, h):
+    B, n, D = h.shape
+    d_pre, d_h = torch.empty(B, n, device=h.device), torch.empty_like(h)
+    check(lib().gymrl_mhc_read_bwd(_ptr(g, torch.float32), _ptr(pre, torch.float32), _ptr(h, torch.float32), C.c_int(B), C.c_int(n),
+                                   C.c_int(D), _ptr(d_pre), _ptr(d_h), C.c_int(0), _stream()), "gymrl_mhc_read_bwd")
+    return d_pre, d_h
+
+
+def mhc_combine_bwd(g, post, mix, out, h):
+    B, n, D = h.shape
+    dev = h.device
+    d_post, d_mix = torch.empty(B, n, device=dev), torch.empty(B, n, n, device=dev)
+    d_out, d_h = torch.empty(B, D, device=dev), torch.empty_like(h)
+    check(lib().gymrl_mhc_combine_bwd(_ptr(g, torch.float32), _ptr(post, torch.float32), _ptr(mix, torch.float32),
+                                      _ptr(out, torch.float32), _ptr(h, torch.float32), C.c_int(B), C.c_int(n), C.c_int(D),
+                                      _ptr(d_post), _ptr(d_mix), _ptr(d_out), _ptr(d_h), _stream()), "gymrl_mhc_combine_bwd")
+    return d_post, d_mix, d_out, d_h

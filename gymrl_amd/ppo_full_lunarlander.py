@@ -65,6 +65,7 @@ class Config:
         self.gae_variant = 1               # 1 = time-blocked G3 with the chunk maps composed during the rollout, 0 = sequential
 
 
+FUSED_MIXING = True         # training pass: read / combine products as fused forward + backward launches (False: broadcast multiplies)
 FUSED_INFERENCE = True      # rollout forward on the inference kernels (tools A/B; False: the torch modules)
 
 
@@ -124,6 +125,36 @@ class ManifoldHyperConnectionFuse(nn.Module):
         return pre, post, u.unsqueeze(2) * A * v.unsqueeze(1)
 
 
+class _MhcRead(torch.autograd.Function):
+    """read = sum_i pre_i h_i (:161) with its backward, one launch each way (csrc/mhc.hip)."""
+
+    @staticmethod
+    def forward(ctx, pre, h):
+        pre, h = pre.contiguous(), h.contiguous()
+        ctx.save_for_backward(pre, h)
+        return ops.mhc_read_fwd(pre, h)
+
+    @staticmethod
+    def backward(ctx, g):
+        pre, h = ctx.saved_tensors
+        return ops.mhc_read_bwd(g.contiguous(), pre, h)
+
+
+class _MhcCombine(torch.autograd.Function):
+    """h' = post (x) out + mix h (:165) with its backward, one launch each way."""
+
+    @staticmethod
+    def forward(ctx, post, mix, out, h):
+        post, mix, out, h = post.contiguous(), mix.contiguous(), out.contiguous(), h.contiguous()
+        ctx.save_for_backward(post, mix, out, h)
+        return ops.mhc_combine(post, mix, out, h)
+
+    @staticmethod
+    def backward(ctx, g):
+        post, mix, out, h = ctx.saved_tensors
+        return ops.mhc_combine_bwd(g.contiguous(), post, mix, out, h)
+
+
 class MHCBlock(nn.Module):
     def __init__(self, dim, rate, max_sk_it):
         super().__init__()
@@ -136,6 +167,10 @@ class MHCBlock(nn.Module):
     @staticmethod
     def _sub(h, fuse, linear, act):
         pre, post, mix = fuse.gates(h)
+        if h.is_cuda and h.shape[1] in (2, 4) and h.shape[2] % 4 == 0 and FUSED_MIXING:
+            # the three products and their backward as four launches instead of ~25 elementwise passes over [B, n, D]
+            out = act(linear(_MhcRead.apply(pre, h)))
+            return _MhcCombine.apply(post, mix, out, h)
         if h.is_cuda:
             # the same three products as broadcast multiplies: the library answers 262144 batched 1 x n x D GEMMs (one per
             # row of a micro-batch) in 2.5-3.6 ms each way — 78 % of a PPO-full update (`profiles/r02_ppo_full_kernel_stats.csv`)

@@ -553,6 +553,17 @@ int gymrl_rmsnorm(const float* x, const float* w, int B, int D, int n_sum, float
  * u [B, n], v [B, n] after sk_it sweeps u = 1/(A v + 1e-8), v = 1/(A^T u + 1e-8) from u = v = 1 — used by the TRAINING
  * pass, whose other gate operations stay with autograd. */
 int gymrl_sinkhorn(const float* A, int B, int n, int sk_it, float* u_out, float* v_out, void* stream);
+/* Training pass of MHCBlock._sub (:160-165): the two branch products with their backward, one launch each way (autograd
+ * wraps them: gymrl_amd/ppo_full_lunarlander.py _MhcRead / _MhcCombine).
+ *   read_fwd:     read [B, D] = sum_i pre[b, i] h[b, i, :]
+ *   read_bwd:     d_pre [B, n] = sum_d g[b, d] h[b, i, d];  d_h [B, n, D] (+)= pre[b, i] g[b, d]
+ *   combine (forward = gymrl_mhc_combine) backward, g = dL/dh' [B, n, D]:
+ *                 d_post [B, n], d_mix [B, n, n], d_out [B, D], d_h [B, n, D] (overwritten) */
+int gymrl_mhc_read_fwd(const float* pre, const float* h, int B, int n, int D, float* read_out, void* stream);
+int gymrl_mhc_read_bwd(const float* g, const float* pre, const float* h, int B, int n, int D, float* d_pre, float* d_h,
+                       int accumulate, void* stream);
+int gymrl_mhc_combine_bwd(const float* g, const float* post, const float* mix, const float* out, const float* h, int B, int n, int D,
+                          float* d_post, float* d_mix, float* d_out, float* d_h, void* stream);
 
 /* ===================================================== MLP update path ===== */
 /*

@@ -64,3 +64,26 @@ def test_fused_forward_matches_actor_critic(rate, dim, layers):
     lm, vm = net(x.cuda())                                   # and against the float32 modules themselves
     _close(logits, lm.double(), 2e-5)
     _close(value, vm.double(), 2e-5)
+
+
+@pytest.mark.parametrize("rate,dim,B", [(2, 128, 1000), (4, 32, 257)])
+def test_read_and_combine_backward_match_autograd(rate, dim, B):
+    """The training pass's fused read / combine launches: forward and every gradient against the torch expressions in
+    float64 (bmm form, ppo_full_lunarlander.py:160-165)."""
+    from gymrl_amd.ppo_full_lunarlander import _MhcCombine, _MhcRead
+    torch.manual_seed(rate + dim)
+    pre, post = torch.rand(B, rate), torch.rand(B, rate) * 2
+    mix, out, h = torch.rand(B, rate, rate), torch.randn(B, dim), torch.randn(B, rate, dim)
+    g_read, g_h = torch.randn(B, dim), torch.randn(B, rate, dim)
+    ref = [t.double().requires_grad_(True) for t in (pre, post, mix, out, h)]
+    r_read = torch.bmm(ref[0].unsqueeze(1), ref[4]).squeeze(1)
+    r_comb = torch.bmm(ref[1].unsqueeze(2), ref[3].unsqueeze(1)) + torch.bmm(ref[2], ref[4])
+    torch.autograd.backward([r_read, r_comb], [g_read.double(), g_h.double()])
+    dev = [t.cuda().requires_grad_(True) for t in (pre, post, mix, out, h)]
+    read = _MhcRead.apply(dev[0], dev[4])
+    comb = _MhcCombine.apply(dev[1], dev[2], dev[3], dev[4])
+    torch.autograd.backward([read, comb], [g_read.cuda(), g_h.cuda()])
+    _close(read, r_read.detach(), 1e-5)
+    _close(comb, r_comb.detach(), 1e-5)
+    for d, r in zip(dev, ref):
+        _close(d.grad, r.grad, 1e-5)
