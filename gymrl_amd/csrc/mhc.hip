@@ -231,6 +231,155 @@ __global__ __launch_bounds__(64 * kWaves) void mhc_combine_bwd_kernel(const floa
   }
 }
 
+// ---- training pass: backward of the gates (n = 2 branches) -----------------------------------------------------------
+// z = r H alpha + beta with H = (norm_w * flat) w, r = 1 / (|flat| / sqrt(nc) + 1e-6);  pre = sigmoid(z[:n]), post = 2 sigmoid(z[n:2n]),
+// mix = u exp(z[2n:]) v with u, v constants (the reference computes them under no_grad).  Given dL/d(pre, post, mix) one wave per
+// row recomputes H and r, forms dz (sigmoid' / exp' from the saved outputs), dH = dz r alpha, d r = sum dz H alpha, and in a second
+// pass over the row writes d flat = norm_w (dH w^T) + d|flat| flat / |flat|; the parameter gradients (d norm_w, d w, d alpha,
+// d beta: sums over rows) are accumulated in registers over the rows a wave visits, added across the workgroup's waves through
+// LDS in a fixed order, and written as one partial vector per workgroup for gates_bwd_reduce_kernel: no atomics.
+struct GatesBwdArgs {
+  const float* h; const float* norm_w; const float* w; const float* alpha;
+  const float* pre; const float* post; const float* mix;
+  const float* d_pre; const float* d_post; const float* d_mix;
+  float* d_h; float* partial;
+  int B, D;
+};
+
+template <int CH>        // nc = 256 * CH columns, n = 2
+__global__ __launch_bounds__(64 * kWaves) void mhc_gates_bwd_kernel(const GatesBwdArgs a) {
+  constexpr int N = 2, G = N * N + 2 * N;
+  extern __shared__ float red[];                           // [kWaves][len]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nc = 256 * CH, len = nc + nc * G + 3 + G;
+  f32x4 nw[CH];
+  float wr[CH][4][G];                                      // this lane's rows of w: constants of the launch
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) {
+    const int c = 256 * ch + 4 * lane;
+    nw[ch] = *reinterpret_cast<const f32x4*>(a.norm_w + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int k = 0; k < G; ++k) wr[ch][e][k] = a.w[(size_t)(c + e) * G + k];
+  }
+  const float al[3] = {a.alpha[0], a.alpha[1], a.alpha[2]};
+  float acc_nw[CH][4], acc_w[CH][4][G], acc_al[3] = {0.0f, 0.0f, 0.0f}, acc_be[G];
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc_nw[ch][e] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < G; ++k) acc_w[ch][e][k] = 0.0f;
+    }
+#pragma unroll
+  for (int k = 0; k < G; ++k) acc_be[k] = 0.0f;
+  const float inv_sqrt_nc = 1.0f / sqrtf((float)nc);
+  for (int64_t row = (int64_t)blockIdx.x * kWaves + wave; row < a.B; row += (int64_t)gridDim.x * kWaves) {
+    const float* hr = a.h + row * nc;
+    f32x4 x[CH];
+    float Hs[G], sq = 0.0f;
+#pragma unroll
+    for (int k = 0; k < G; ++k) Hs[k] = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+      x[ch] = *reinterpret_cast<const f32x4*>(hr + 256 * ch + 4 * lane);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t = nw[ch][e] * x[ch][e];
+        sq += x[ch][e] * x[ch][e];
+#pragma unroll
+        for (int k = 0; k < G; ++k) Hs[k] += t * wr[ch][e][k];
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sq += __shfl_xor(sq, off, 64);
+#pragma unroll
+      for (int k = 0; k < G; ++k) Hs[k] += __shfl_xor(Hs[k], off, 64);
+    }
+    const float norm = sqrtf(sq);
+    const float r = 1.0f / (norm * inv_sqrt_nc + 1e-6f);
+    float dz[G];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const float p = a.pre[row * N + i], q = a.post[row * N + i];
+      dz[i] = a.d_pre[row * N + i] * p * (1.0f - p);
+      dz[N + i] = a.d_post[row * N + i] * q * (1.0f - 0.5f * q);
+#pragma unroll
+      for (int j = 0; j < N; ++j) dz[2 * N + i * N + j] = a.d_mix[(row * N + i) * N + j] * a.mix[(row * N + i) * N + j];
+    }
+    float dH[G], d_r = 0.0f;
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const float ag = al[k < N ? 0 : (k < 2 * N ? 1 : 2)];
+      dH[k] = dz[k] * r * ag;
+      d_r += dz[k] * Hs[k] * ag;
+      acc_al[k < N ? 0 : (k < 2 * N ? 1 : 2)] += dz[k] * r * Hs[k];
+      acc_be[k] += dz[k];
+    }
+    const float d_norm = d_r * (-r * r * inv_sqrt_nc);
+    const float dn_over = norm > 0.0f ? d_norm / norm : 0.0f;
+    float* dhr = a.d_h + row * nc;
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+      f32x4 dx;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < G; ++k) t2 += dH[k] * wr[ch][e][k];
+        dx[e] = nw[ch][e] * t2 + dn_over * x[ch][e];
+        acc_nw[ch][e] += x[ch][e] * t2;
+        const float t = nw[ch][e] * x[ch][e];
+#pragma unroll
+        for (int k = 0; k < G; ++k) acc_w[ch][e][k] += t * dH[k];
+      }
+      *reinterpret_cast<f32x4*>(dhr + 256 * ch + 4 * lane) = dx;
+    }
+  }
+  // workgroup reduction in a fixed order, one partial vector per workgroup
+  float* mine = red + (size_t)wave * len;
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = 256 * ch + 4 * lane + e;
+      mine[c] = acc_nw[ch][e];
+#pragma unroll
+      for (int k = 0; k < G; ++k) mine[nc + c * G + k] = acc_w[ch][e][k];
+    }
+  if (lane == 0) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) mine[nc + nc * G + g] = acc_al[g];
+#pragma unroll
+    for (int k = 0; k < G; ++k) mine[nc + nc * G + 3 + k] = acc_be[k];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < len; i += 64 * kWaves) {
+    float sum = red[i];
+#pragma unroll
+    for (int w2 = 1; w2 < kWaves; ++w2) sum += red[(size_t)w2 * len + i];
+    a.partial[(size_t)blockIdx.x * len + i] = sum;
+  }
+}
+
+// out[i] = sum over workgroups (ascending) of partial[b][i], scattered to the four gradient tensors
+__global__ __launch_bounds__(256) void gates_bwd_reduce_kernel(const float* __restrict__ partial, int blocks, int nc, int G,
+                                                              float* __restrict__ d_nw, float* __restrict__ d_w,
+                                                              float* __restrict__ d_alpha, float* __restrict__ d_beta) {
+  const int len = nc + nc * G + 3 + G;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= len) return;
+  float s = 0.0f;
+  for (int b = 0; b < blocks; ++b) s += partial[(size_t)b * len + i];
+  if (i < nc) d_nw[i] = s;
+  else if (i < nc + nc * G) d_w[i - nc] = s;
+  else if (i < nc + nc * G + 3) d_alpha[i - nc - nc * G] = s;
+  else d_beta[i - nc - nc * G - 3] = s;
+}
+
 // Sinkhorn-Knopp scalings of B positive n x n matrices (ManifoldHyperConnectionFuse.gates :141-146, under no_grad in the
 // reference: u, v are constants of the backward pass): one lane per matrix instead of ~6 launches per sweep.
 template <int N>
@@ -347,6 +496,36 @@ int gymrl_mhc_combine_bwd(const float* g, const float* post, const float* mix, c
   const dim3 grid((B + kWaves - 1) / kWaves), block(64 * kWaves);
   if (n == 2) hipLaunchKernelGGL(mhc_combine_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, g, post, mix, out, h, B, D, d_post, d_mix, d_out, d_h);
   else hipLaunchKernelGGL(mhc_combine_bwd_kernel<4>, grid, block, 0, (hipStream_t)stream, g, post, mix, out, h, B, D, d_post, d_mix, d_out, d_h);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+size_t gymrl_mhc_gates_bwd_workspace_bytes(int n, int D) {
+  const int nc = n * D, G = n * n + 2 * n;
+  return sizeof(float) * 1024 * ((size_t)nc + (size_t)nc * G + 3 + G);
+}
+
+int gymrl_mhc_gates_bwd(const float* h, const float* norm_w, const float* w, const float* alpha, const float* pre, const float* post,
+                        const float* mix, const float* d_pre, const float* d_post, const float* d_mix, int B, int n, int D,
+                        float* d_h, float* d_norm_w, float* d_w, float* d_alpha, float* d_beta, void* workspace, void* stream) {
+  if (!h || !norm_w || !w || !alpha || !pre || !post || !mix || !d_pre || !d_post || !d_mix || !d_h || !d_norm_w || !d_w ||
+      !d_alpha || !d_beta || !workspace || B < 1 || n != 2 || (n * D != 256 && n * D != 512))
+    return -22;
+  const int nc = n * D, G = n * n + 2 * n, len = nc + nc * G + 3 + G;
+  int blocks = (B + kWaves - 1) / kWaves;
+  if (blocks > 1024) blocks = 1024;
+  GatesBwdArgs a{h, norm_w, w, alpha, pre, post, mix, d_pre, d_post, d_mix, d_h, static_cast<float*>(workspace), B, D};
+  const size_t lds = sizeof(float) * kWaves * len;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)mhc_gates_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+      return -1000 - (int)hipGetLastError();
+    attr = true;
+  }
+  if (nc == 256) hipLaunchKernelGGL(mhc_gates_bwd_kernel<1>, dim3(blocks), dim3(64 * kWaves), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(mhc_gates_bwd_kernel<2>, dim3(blocks), dim3(64 * kWaves), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(gates_bwd_reduce_kernel, dim3((len + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const float*>(workspace), blocks, nc, G, d_norm_w, d_w, d_alpha, d_beta);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

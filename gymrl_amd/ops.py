@@ -1076,3 +1076,25 @@ def mhc_combine_bwd(g, post, mix, out, h):
                                       _ptr(out, torch.float32), _ptr(h, torch.float32), C.c_int(B), C.c_int(n), C.c_int(D),
                                       _ptr(d_post), _ptr(d_mix), _ptr(d_out), _ptr(d_h), _stream()), "gymrl_mhc_combine_bwd")
     return d_post, d_mix, d_out, d_h
+
+
+_gates_ws = {}
+
+
+def mhc_gates_bwd(h, norm_w, w, alpha, pre, post, mix, d_pre, d_post, d_mix):
+    """gymrl_mhc_gates_bwd -> (d_h, d_norm_w, d_w, d_alpha, d_beta); n = 2 branches, n * D in (256, 512)."""
+    B, n, D = h.shape
+    dev = h.device
+    key = (n, D, dev)
+    ws = _gates_ws.get(key)
+    if ws is None:
+        nbytes = lib().gymrl_mhc_gates_bwd_workspace_bytes(C.c_int(n), C.c_int(D))
+        ws = _gates_ws[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    d_h, d_nw, d_w = torch.empty_like(h), torch.empty_like(norm_w), torch.empty_like(w)
+    d_alpha, d_beta = torch.empty(3, device=dev), torch.empty(w.shape[1], device=dev)
+    check(lib().gymrl_mhc_gates_bwd(_ptr(h, torch.float32), _ptr(norm_w, torch.float32), _ptr(w, torch.float32),
+                                    _ptr(alpha, torch.float32), _ptr(pre, torch.float32), _ptr(post, torch.float32),
+                                    _ptr(mix, torch.float32), _ptr(d_pre, torch.float32), _ptr(d_post, torch.float32),
+                                    _ptr(d_mix, torch.float32), C.c_int(B), C.c_int(n), C.c_int(D), _ptr(d_h), _ptr(d_nw),
+                                    _ptr(d_w), _ptr(d_alpha), _ptr(d_beta), _ptr(ws), _stream()), "gymrl_mhc_gates_bwd")
+    return d_h, d_nw, d_w, d_alpha, d_beta

@@ -65,6 +65,7 @@ class Config:
         self.gae_variant = 1               # 1 = time-blocked G3 with the chunk maps composed during the rollout, 0 = sequential
 
 
+FUSED_GATES = True          # training pass: the gates as one forward + one backward launch (False: torch ops + gymrl_sinkhorn)
 FUSED_MIXING = True         # training pass: read / combine products as fused forward + backward launches (False: broadcast multiplies)
 FUSED_INFERENCE = True      # rollout forward on the inference kernels (tools A/B; False: the torch modules)
 
@@ -107,6 +108,8 @@ class ManifoldHyperConnectionFuse(nn.Module):
     def gates(self, h):
         """h [B, n, D] -> (pre [B, n], post [B, n], mix [B, n, n])."""
         B, n = h.shape[0], self.n
+        if h.is_cuda and FUSED_GATES and n == 2 and self.nc in (256, 512) and h.dtype == torch.float32:
+            return _MhcGates.apply(h, self.norm.weight, self.w, self.alpha, self.beta, self.max_sk_it)
         flat = h.reshape(B, self.nc)
         H = skinny_matmul(self.norm.weight * flat, self.w)       # [B, nc] x [nc, n*n + 2n]: HBM-bound kernels (gymrl_amd/nn.py)
         r_inv = 1.0 / (flat.norm(dim=-1, keepdim=True) / math.sqrt(self.nc) + 1e-6)
@@ -123,6 +126,26 @@ class ManifoldHyperConnectionFuse(nn.Module):
                 u = 1.0 / ((A * v.unsqueeze(1)).sum(-1) + 1e-8)
                 v = 1.0 / ((A * u.unsqueeze(2)).sum(1) + 1e-8)
         return pre, post, u.unsqueeze(2) * A * v.unsqueeze(1)
+
+
+class _MhcGates(torch.autograd.Function):
+    """ManifoldHyperConnectionFuse.gates (:125-147) as one launch forward (gymrl_mhc_gates: read-out, sigmoids, exp, Sinkhorn
+    sweeps) and one backward (gymrl_mhc_gates_bwd: the Sinkhorn scalings are constants, as under the reference's no_grad)."""
+
+    @staticmethod
+    def forward(ctx, h, norm_w, w, alpha, beta, sk_it):
+        h = h.contiguous()
+        pre, post, mix, _ = ops.mhc_gates(h, norm_w, w, alpha, beta, sk_it)
+        ctx.save_for_backward(h, norm_w, w, alpha, pre, post, mix)
+        return pre, post, mix
+
+    @staticmethod
+    def backward(ctx, d_pre, d_post, d_mix):
+        h, norm_w, w, alpha, pre, post, mix = ctx.saved_tensors
+        z = lambda g, ref: torch.zeros_like(ref) if g is None else g.contiguous()   # noqa: E731
+        d_h, d_nw, d_w, d_alpha, d_beta = ops.mhc_gates_bwd(h, norm_w, w, alpha, pre, post, mix, z(d_pre, pre), z(d_post, post),
+                                                            z(d_mix, mix))
+        return d_h, d_nw, d_w, d_alpha, d_beta, None
 
 
 class _MhcRead(torch.autograd.Function):

@@ -559,6 +559,14 @@ int gymrl_sinkhorn(const float* A, int B, int n, int sk_it, float* u_out, float*
  *   read_bwd:     d_pre [B, n] = sum_d g[b, d] h[b, i, d];  d_h [B, n, D] (+)= pre[b, i] g[b, d]
  *   combine (forward = gymrl_mhc_combine) backward, g = dL/dh' [B, n, D]:
  *                 d_post [B, n], d_mix [B, n, n], d_out [B, D], d_h [B, n, D] (overwritten) */
+/* Backward of the gates (n = 2, n*D = 256 or 512; forward = gymrl_mhc_gates): given dL/d pre, post, mix — u, v of the Sinkhorn
+ * sweeps are constants, as in the reference — writes d_h [B, n, D] (overwritten) and the parameter gradients d_norm_w [nD],
+ * d_w [nD, n*n + 2n], d_alpha [3], d_beta [n*n + 2n] (overwritten; sums over rows in a fixed order: per-workgroup partial
+ * vectors in `workspace`, gymrl_mhc_gates_bwd_workspace_bytes, added ascending — no atomics). */
+size_t gymrl_mhc_gates_bwd_workspace_bytes(int n, int D);
+int gymrl_mhc_gates_bwd(const float* h, const float* norm_w, const float* w, const float* alpha, const float* pre, const float* post,
+                        const float* mix, const float* d_pre, const float* d_post, const float* d_mix, int B, int n, int D,
+                        float* d_h, float* d_norm_w, float* d_w, float* d_alpha, float* d_beta, void* workspace, void* stream);
 int gymrl_mhc_read_fwd(const float* pre, const float* h, int B, int n, int D, float* read_out, void* stream);
 int gymrl_mhc_read_bwd(const float* g, const float* pre, const float* h, int B, int n, int D, float* d_pre, float* d_h,
                        int accumulate, void* stream);

@@ -87,3 +87,39 @@ def test_read_and_combine_backward_match_autograd(rate, dim, B):
     _close(comb, r_comb.detach(), 1e-5)
     for d, r in zip(dev, ref):
         _close(d.grad, r.grad, 1e-5)
+
+
+@pytest.mark.parametrize("dim,B", [(128, 3000), (256, 517)])
+def test_gates_backward_matches_autograd(dim, B):
+    """The training pass's fused gates (forward gymrl_mhc_gates, backward gymrl_mhc_gates_bwd) against the module's torch
+    expression under float64 autograd: the three outputs and the gradients of h, norm.weight, w, alpha, beta; and the
+    parameter gradients do not depend on the launch (no atomics)."""
+    from gymrl_amd.ppo_full_lunarlander import ManifoldHyperConnectionFuse, _MhcGates
+    torch.manual_seed(dim)
+    fuse = ManifoldHyperConnectionFuse(dim, 2, 10)
+    with torch.no_grad():
+        fuse.w.normal_(0, 0.3)
+        fuse.alpha.copy_(torch.tensor([0.7, -0.4, 0.9]))
+        fuse.norm.weight.uniform_(0.5, 1.5)
+    h = torch.randn(B, 2, dim)
+    gs = [torch.randn(B, 2), torch.randn(B, 2), torch.randn(B, 2, 2)]
+    ref = ManifoldHyperConnectionFuse(dim, 2, 10).double()
+    ref.load_state_dict({k: v.double() for k, v in fuse.state_dict().items()})
+    h64 = h.double().requires_grad_(True)
+    torch.autograd.backward(list(ref.gates(h64)), [g.double() for g in gs])
+    fuse = fuse.cuda()
+    outs = []
+    for _ in range(2):
+        for p in fuse.parameters():
+            p.grad = None
+        hd = h.cuda().requires_grad_(True)
+        res = _MhcGates.apply(hd, fuse.norm.weight, fuse.w, fuse.alpha, fuse.beta, 10)
+        torch.autograd.backward(list(res), [g.cuda() for g in gs])
+        outs.append([hd.grad.clone()] + [p.grad.clone() for p in (fuse.norm.weight, fuse.w, fuse.alpha, fuse.beta)])
+    for got, want in zip(res, ref.gates(h64.detach())):
+        _close(got, want, 1e-5)
+    wants = [h64.grad, ref.norm.weight.grad, ref.w.grad, ref.alpha.grad, ref.beta.grad]
+    for got, want in zip(outs[0], wants):
+        _close(got, want, 2e-5)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
