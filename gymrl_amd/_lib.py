@@ -47,7 +47,7 @@ SYMBOLS = [
     "gymrl_noisy_combine", "gymrl_noisy_split", "gymrl_dueling_bwd",
     "gymrl_mhc_gates", "gymrl_mhc_combine", "gymrl_rmsnorm", "gymrl_sinkhorn",
     "gymrl_mhc_read_fwd", "gymrl_mhc_read_bwd", "gymrl_mhc_combine_bwd",
-    "gymrl_mhc_gates_bwd_workspace_bytes", "gymrl_mhc_gates_bwd",
+    "gymrl_mhc_gates_bwd_workspace_bytes", "gymrl_mhc_gates_bwd", "gymrl_rmsnorm_bwd_workspace_bytes", "gymrl_rmsnorm_bwd",
 ]
 
 
@@ -130,6 +130,7 @@ def lib():
         L.gymrl_gemm_workspace_bytes.restype = C.c_size_t
         L.gymrl_lin_workspace_bytes.restype = C.c_size_t
         L.gymrl_mhc_gates_bwd_workspace_bytes.restype = C.c_size_t
+        L.gymrl_rmsnorm_bwd_workspace_bytes.restype = C.c_size_t
         for name in SYMBOLS:
             if name.endswith(("_bytes", "_floats")):
                 continue

@@ -26,7 +26,7 @@ constexpr int kMaxN = 4;                         // branches (mhc_rate)
 
 struct GatesArgs {
   const float* h; const float* norm_w; const float* w; const float* alpha; const float* beta;
-  float* pre; float* post; float* mix; float* read;
+  float* pre; float* post; float* mix; float* read; float* stats;
   int B, D, sk_it;
 };
 
@@ -106,10 +106,132 @@ __global__ __launch_bounds__(64 * kWaves) void mhc_gates_kernel(const GatesArgs 
   }
 }
 
+// sum over the 16 lanes of a DPP row, every lane ending with the same bits: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror,
+// row_mirror — four v_add_f32_dpp, no LDS traffic (a 64-lane __shfl_xor tree is six ds_bpermute round trips)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
+  return v;
+}
+
+// The n = 2 gates at nc = 256 * CH columns.  The one-wave-per-row kernel above spends ~1100 of its ~1500 instructions per row on
+// the Sinkhorn sweeps, every lane repeating them (0.3 ms at 131072 rows against 50 us of HBM time; 23 us per rollout call at 4096
+// rows).  Here a wave takes RB = 16 / CH rows: 16 lanes per row (a 256-byte segment per load, all of the batch's loads issued up
+// front and kept in registers for the read-out), the read-out sums through DPP, then ONE lane per row does the sigmoids, the exp
+// and the sweeps, and the branch sum is formed from the registers.  stats [B, 9] (optional) = the eight read-out sums and
+// |flat|^2 of the row, for gymrl_mhc_gates_bwd.
+template <int CH>
+__global__ __launch_bounds__(64) void mhc_gates2_kernel(const GatesArgs a) {
+  constexpr int N = 2, G = 8, IT = 4 / CH, RB = 4 * IT, Q = 4 * CH;
+  const int lane = threadIdx.x, sub = lane & 15, grp = lane >> 4;
+  const int nc = 256 * CH;
+  const int64_t base = (int64_t)blockIdx.x * RB;
+  f32x4 x[IT][Q];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    int64_t row = base + grp * IT + it;
+    if (row > a.B - 1) row = a.B - 1;
+    const float* hr = a.h + row * nc + 4 * sub;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) x[it][q] = *reinterpret_cast<const f32x4*>(hr + 64 * q);
+  }
+  float Hs[IT][G + 1];
+#pragma unroll
+  for (int it = 0; it < IT; ++it)
+#pragma unroll
+    for (int k = 0; k <= G; ++k) Hs[it][k] = 0.0f;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int c = 64 * q + 4 * sub;
+    const f32x4 nw = *reinterpret_cast<const f32x4*>(a.norm_w + c);
+    float wq[4][G];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(a.w + (size_t)(c + e) * G);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(a.w + (size_t)(c + e) * G + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { wq[e][k] = lo[k]; wq[e][4 + k] = hi[k]; }
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xv = x[it][q][e], t = nw[e] * xv;
+        Hs[it][G] += xv * xv;
+#pragma unroll
+        for (int k = 0; k < G; ++k) Hs[it][k] += t * wq[e][k];
+      }
+  }
+  float mine[G + 1];                                       // lane `sub` of a group keeps the sums of the group's row `sub`
+#pragma unroll
+  for (int k = 0; k <= G; ++k) mine[k] = 0.0f;
+#pragma unroll
+  for (int it = 0; it < IT; ++it)
+#pragma unroll
+    for (int k = 0; k <= G; ++k) {
+      const float s = row16_sum(Hs[it][k]);
+      mine[k] = sub == it ? s : mine[k];
+    }
+  const int64_t my_row = base + grp * IT + sub;
+  float pre[N] = {0.0f, 0.0f};
+  if (sub < IT && my_row < a.B) {
+    const float r_inv = 1.0f / (sqrtf(mine[G]) / sqrtf((float)nc) + 1e-6f);
+    const float a0 = a.alpha[0], a1 = a.alpha[1], a2 = a.alpha[2];
+    float post[N], A[N][N], u[N], v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      pre[i] = sigmoidf_(r_inv * mine[i] * a0 + a.beta[i]);
+      post[i] = 2.0f * sigmoidf_(r_inv * mine[N + i] * a1 + a.beta[N + i]);
+      u[i] = 1.0f; v[i] = 1.0f;
+#pragma unroll
+      for (int j = 0; j < N; ++j) A[i][j] = expf(r_inv * mine[2 * N + i * N + j] * a2 + a.beta[2 * N + i * N + j]);
+    }
+    for (int it = 0; it < a.sk_it; ++it) {                 // Sinkhorn-Knopp scalings (:141-146)
+#pragma unroll
+      for (int i = 0; i < N; ++i) u[i] = 1.0f / (A[i][0] * v[0] + A[i][1] * v[1] + 1e-8f);
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = 1.0f / (A[0][j] * u[0] + A[1][j] * u[1] + 1e-8f);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      a.pre[my_row * N + i] = pre[i];
+      a.post[my_row * N + i] = post[i];
+#pragma unroll
+      for (int j = 0; j < N; ++j) a.mix[(my_row * N + i) * N + j] = u[i] * A[i][j] * v[j];
+    }
+    if (a.stats) {
+#pragma unroll
+      for (int k = 0; k <= G; ++k) a.stats[my_row * (G + 1) + k] = mine[k];
+    }
+  }
+  // read = pre_0 h_0 + pre_1 h_1 from the registers: row (grp, it)'s gates live in lane 16 grp + it
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int src = ((lane & 48) + it) << 2;
+    const float p0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(pre[0])));
+    const float p1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(pre[1])));
+    const int64_t row = base + grp * IT + it;
+    if (row < a.B) {
+#pragma unroll
+      for (int q = 0; q < Q / 2; ++q) {
+        f32x4 s;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = p0 * x[it][q][e] + p1 * x[it][q + Q / 2][e];
+        *reinterpret_cast<f32x4*>(a.read + row * (nc / 2) + 64 * q + 4 * sub) = s;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float silu_(float z) { return z * sigmoidf_(z); }
+__device__ __forceinline__ float silu_grad_(float z) { const float s = sigmoidf_(z); return s * (1.0f + z * (1.0f - s)); }
+
 template <int N>
 __global__ __launch_bounds__(256) void mhc_combine_kernel(const float* __restrict__ post, const float* __restrict__ mix,
                                                           const float* __restrict__ out, const float* __restrict__ h, int B,
-                                                          int D, float* __restrict__ h_out) {
+                                                          int D, int silu, float* __restrict__ h_out) {
   const int64_t total = (int64_t)B * D;
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
     const int64_t b = t / D;
@@ -117,7 +239,8 @@ __global__ __launch_bounds__(256) void mhc_combine_kernel(const float* __restric
     float hv[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) hv[j] = h[(b * N + j) * D + d];
-    const float o = out[b * D + d];
+    float o = out[b * D + d];
+    if (silu) o = silu_(o);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       float s = 0.0f;
@@ -149,7 +272,7 @@ __global__ __launch_bounds__(256) void mhc_read_fwd_kernel(const float* __restri
   }
 }
 
-// one wave per row: d_pre[b, i] = sum_d g[b, d] h[b, i, d];  d_h[b, i, d] (+)= pre[b, i] g[b, d]
+// one wave per row: d_pre[b, i] = sum_d g[b, d] h[b, i, d];  d_h[b, i, d] (+)= pre[b, i] g[b, d]  (d_h == nullptr: d_pre only)
 template <int N>
 __global__ __launch_bounds__(64 * kWaves) void mhc_read_bwd_kernel(const float* __restrict__ g, const float* __restrict__ pre,
                                                                  const float* __restrict__ h, int B, int D,
@@ -166,7 +289,7 @@ __global__ __launch_bounds__(64 * kWaves) void mhc_read_bwd_kernel(const float* 
     for (int i = 0; i < N; ++i) {
       const int64_t o = (row * N + i) * D + d;
       acc[i] += gv * h[o];
-      d_h[o] = accumulate ? d_h[o] + p[i] * gv : p[i] * gv;
+      if (d_h) d_h[o] = accumulate ? d_h[o] + p[i] * gv : p[i] * gv;
     }
   }
 #pragma unroll
@@ -182,7 +305,7 @@ __global__ __launch_bounds__(64 * kWaves) void mhc_read_bwd_kernel(const float* 
 template <int N>
 __global__ __launch_bounds__(64 * kWaves) void mhc_combine_bwd_kernel(const float* __restrict__ g, const float* __restrict__ post,
                                                                     const float* __restrict__ mix, const float* __restrict__ out,
-                                                                    const float* __restrict__ h, int B, int D,
+                                                                    const float* __restrict__ h, int B, int D, int silu,
                                                                     float* __restrict__ d_post, float* __restrict__ d_mix,
                                                                     float* __restrict__ d_out, float* __restrict__ d_h) {
   const int lane = threadIdx.x & 63;
@@ -197,7 +320,8 @@ __global__ __launch_bounds__(64 * kWaves) void mhc_combine_bwd_kernel(const floa
   }
   for (int d = lane; d < D; d += 64) {
     float gv[N], hv[N];
-    const float o = out[row * D + d];
+    const float z = out[row * D + d];
+    const float o = silu ? silu_(z) : z;
 #pragma unroll
     for (int i = 0; i < N; ++i) { gv[i] = g[(row * N + i) * D + d]; hv[i] = h[(row * N + i) * D + d]; }
     float so = 0.0f;
@@ -208,13 +332,15 @@ __global__ __launch_bounds__(64 * kWaves) void mhc_combine_bwd_kernel(const floa
 #pragma unroll
       for (int j = 0; j < N; ++j) a_mix[i][j] += gv[i] * hv[j];
     }
-    d_out[row * D + d] = so;
+    d_out[row * D + d] = silu ? so * silu_grad_(z) : so;        // silu: `out` holds z and d_out is dL/dz
+    if (d_h) {
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-      float sh = 0.0f;
+      for (int j = 0; j < N; ++j) {
+        float sh = 0.0f;
 #pragma unroll
-      for (int i = 0; i < N; ++i) sh += mx[i][j] * gv[i];
-      d_h[(row * N + j) * D + d] = sh;
+        for (int i = 0; i < N; ++i) sh += mx[i][j] * gv[i];
+        d_h[(row * N + j) * D + d] = sh;
+      }
     }
   }
 #pragma unroll
@@ -233,151 +359,209 @@ __global__ __launch_bounds__(64 * kWaves) void mhc_combine_bwd_kernel(const floa
 
 // ---- training pass: backward of the gates (n = 2 branches) -----------------------------------------------------------
 // z = r H alpha + beta with H = (norm_w * flat) w, r = 1 / (|flat| / sqrt(nc) + 1e-6);  pre = sigmoid(z[:n]), post = 2 sigmoid(z[n:2n]),
-// mix = u exp(z[2n:]) v with u, v constants (the reference computes them under no_grad).  Given dL/d(pre, post, mix) one wave per
-// row recomputes H and r, forms dz (sigmoid' / exp' from the saved outputs), dH = dz r alpha, d r = sum dz H alpha, and in a second
-// pass over the row writes d flat = norm_w (dH w^T) + d|flat| flat / |flat|; the parameter gradients (d norm_w, d w, d alpha,
-// d beta: sums over rows) are accumulated in registers over the rows a wave visits, added across the workgroup's waves through
-// LDS in a fixed order, and written as one partial vector per workgroup for gates_bwd_reduce_kernel: no atomics.
+// mix = u exp(z[2n:]) v with u, v constants (the reference computes them under no_grad).  The forward saved H and |flat|^2 per row
+// (stats), so nothing here needs a reduction over a row's columns:
+//   phase A, one LANE per row, 64 rows per wave step: dz (sigmoid' / exp' from the saved outputs), dH = dz r alpha,
+//            d|flat| / |flat| from d r = sum dz H alpha, and the row's terms of d alpha, d beta;
+//   phase B, one lane per 4 columns (a wave covers 256; blockIdx.y picks the 256-column block when nc = 512), streaming the
+//            wave's rows two at a time with row r's nine scalars read from lane r (v_readlane -> SGPRs):
+//            d flat = norm_w (dH w^T) + d|flat| flat / |flat|   [+ pre_j d_read + sum_i mix_ij g_i: the sub-block's other two
+//            consumers of h, folded in so that autograd has nothing to add], and the columns' terms of d norm_w, d w in registers.
+// The first version recomputed H with 54 ds_bpermute per row at 2 waves per SIMD and ran 0.44 ms at 131072 rows (0.6 TB/s).
+// Parameter gradients: added across the workgroup's waves through LDS in a fixed order, one partial vector per workgroup,
+// summed ascending by partial_reduce_kernel: no atomics.
 struct GatesBwdArgs {
   const float* h; const float* norm_w; const float* w; const float* alpha;
-  const float* pre; const float* post; const float* mix;
+  const float* pre; const float* post; const float* mix; const float* stats;
   const float* d_pre; const float* d_post; const float* d_mix;
+  const float* d_read;                                     // nullable [B, D]: d_h[b, j] += pre[b, j] d_read[b]
+  const float* g_out;                                      // nullable [B, 2, D]: d_h[b, j] += sum_i mix[b, i, j] g_out[b, i]
   float* d_h; float* partial;
   int B, D;
 };
 
-template <int CH>        // nc = 256 * CH columns, n = 2
+constexpr int kGatesLen = 256 + 256 * 8 + 3 + 8;           // one 256-column block's partial: d norm_w, d w, d alpha, d beta
+
+__device__ __forceinline__ float lane_value(float v, int k) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k));
+}
+
 __global__ __launch_bounds__(64 * kWaves) void mhc_gates_bwd_kernel(const GatesBwdArgs a) {
-  constexpr int N = 2, G = N * N + 2 * N;
-  extern __shared__ float red[];                           // [kWaves][len]
+  constexpr int N = 2, G = N * N + 2 * N, U = 2;
+  extern __shared__ float red[];                           // [kWaves][kGatesLen]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nc = 256 * CH, len = nc + nc * G + 3 + G;
-  f32x4 nw[CH];
-  float wr[CH][4][G];                                      // this lane's rows of w: constants of the launch
+  const int nc = N * a.D;
+  const int c0 = 256 * blockIdx.y + 4 * lane;              // this lane's four columns of flat
+  const int j = c0 / a.D, d0 = c0 % a.D;                   // = branch j, columns d0 .. d0 + 3
+  const f32x4 nw = *reinterpret_cast<const f32x4*>(a.norm_w + c0);
+  float wr[4][G];
 #pragma unroll
-  for (int ch = 0; ch < CH; ++ch) {
-    const int c = 256 * ch + 4 * lane;
-    nw[ch] = *reinterpret_cast<const f32x4*>(a.norm_w + c);
+  for (int e = 0; e < 4; ++e) {
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(a.w + (size_t)(c0 + e) * G);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(a.w + (size_t)(c0 + e) * G + 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int k = 0; k < G; ++k) wr[ch][e][k] = a.w[(size_t)(c + e) * G + k];
+    for (int k = 0; k < 4; ++k) { wr[e][k] = lo[k]; wr[e][4 + k] = hi[k]; }
   }
   const float al[3] = {a.alpha[0], a.alpha[1], a.alpha[2]};
-  float acc_nw[CH][4], acc_w[CH][4][G], acc_al[3] = {0.0f, 0.0f, 0.0f}, acc_be[G];
+  float acc_nw[4], acc_w[4][G], acc_al[3] = {0.0f, 0.0f, 0.0f}, acc_be[G];
 #pragma unroll
-  for (int ch = 0; ch < CH; ++ch)
+  for (int e = 0; e < 4; ++e) {
+    acc_nw[e] = 0.0f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      acc_nw[ch][e] = 0.0f;
-#pragma unroll
-      for (int k = 0; k < G; ++k) acc_w[ch][e][k] = 0.0f;
-    }
+    for (int k = 0; k < G; ++k) acc_w[e][k] = 0.0f;
+  }
 #pragma unroll
   for (int k = 0; k < G; ++k) acc_be[k] = 0.0f;
   const float inv_sqrt_nc = 1.0f / sqrtf((float)nc);
-  for (int64_t row = (int64_t)blockIdx.x * kWaves + wave; row < a.B; row += (int64_t)gridDim.x * kWaves) {
-    const float* hr = a.h + row * nc;
-    f32x4 x[CH];
-    float Hs[G], sq = 0.0f;
+  for (int64_t base = ((int64_t)blockIdx.x * kWaves + wave) * 64; base < a.B; base += (int64_t)gridDim.x * kWaves * 64) {
+    // ---- phase A: lane = row
+    const int64_t row = base + lane;
+    float dH[G], dn_over = 0.0f, p0 = 0.0f, p1 = 0.0f, m00 = 0.0f, m01 = 0.0f, m10 = 0.0f, m11 = 0.0f;
 #pragma unroll
-    for (int k = 0; k < G; ++k) Hs[k] = 0.0f;
+    for (int k = 0; k < G; ++k) dH[k] = 0.0f;
+    if (row < a.B) {
+      float Hs[G], dz[G];
 #pragma unroll
-    for (int ch = 0; ch < CH; ++ch) {
-      x[ch] = *reinterpret_cast<const f32x4*>(hr + 256 * ch + 4 * lane);
+      for (int k = 0; k < G; ++k) Hs[k] = a.stats[row * (G + 1) + k];
+      const float norm = sqrtf(a.stats[row * (G + 1) + G]);
+      const float r = 1.0f / (norm * inv_sqrt_nc + 1e-6f);
+      p0 = a.pre[row * N]; p1 = a.pre[row * N + 1];
+      const float q0 = a.post[row * N], q1 = a.post[row * N + 1];
+      m00 = a.mix[row * 4]; m01 = a.mix[row * 4 + 1]; m10 = a.mix[row * 4 + 2]; m11 = a.mix[row * 4 + 3];
+      dz[0] = a.d_pre[row * N] * p0 * (1.0f - p0);
+      dz[1] = a.d_pre[row * N + 1] * p1 * (1.0f - p1);
+      dz[2] = a.d_post[row * N] * q0 * (1.0f - 0.5f * q0);
+      dz[3] = a.d_post[row * N + 1] * q1 * (1.0f - 0.5f * q1);
+      dz[4] = a.d_mix[row * 4] * m00; dz[5] = a.d_mix[row * 4 + 1] * m01;
+      dz[6] = a.d_mix[row * 4 + 2] * m10; dz[7] = a.d_mix[row * 4 + 3] * m11;
+      float d_r = 0.0f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float t = nw[ch][e] * x[ch][e];
-        sq += x[ch][e] * x[ch][e];
-#pragma unroll
-        for (int k = 0; k < G; ++k) Hs[k] += t * wr[ch][e][k];
+      for (int k = 0; k < G; ++k) {
+        const int gi = k < N ? 0 : (k < 2 * N ? 1 : 2);
+        dH[k] = dz[k] * r * al[gi];
+        d_r += dz[k] * Hs[k] * al[gi];
+        acc_al[gi] += dz[k] * r * Hs[k];
+        acc_be[k] += dz[k];
       }
+      const float d_norm = d_r * (-r * r * inv_sqrt_nc);
+      dn_over = norm > 0.0f ? d_norm / norm : 0.0f;
     }
+    // ---- phase B: lane = 4 columns, the wave's rows in pairs
+    const int nrows = (int)((a.B - base) < 64 ? (a.B - base) : 64);
+    for (int r0 = 0; r0 < nrows; r0 += U) {
+      f32x4 x[U], gr[U], g0[U], g1[U];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      sq += __shfl_xor(sq, off, 64);
-#pragma unroll
-      for (int k = 0; k < G; ++k) Hs[k] += __shfl_xor(Hs[k], off, 64);
-    }
-    const float norm = sqrtf(sq);
-    const float r = 1.0f / (norm * inv_sqrt_nc + 1e-6f);
-    float dz[G];
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const float p = a.pre[row * N + i], q = a.post[row * N + i];
-      dz[i] = a.d_pre[row * N + i] * p * (1.0f - p);
-      dz[N + i] = a.d_post[row * N + i] * q * (1.0f - 0.5f * q);
-#pragma unroll
-      for (int j = 0; j < N; ++j) dz[2 * N + i * N + j] = a.d_mix[(row * N + i) * N + j] * a.mix[(row * N + i) * N + j];
-    }
-    float dH[G], d_r = 0.0f;
-#pragma unroll
-    for (int k = 0; k < G; ++k) {
-      const float ag = al[k < N ? 0 : (k < 2 * N ? 1 : 2)];
-      dH[k] = dz[k] * r * ag;
-      d_r += dz[k] * Hs[k] * ag;
-      acc_al[k < N ? 0 : (k < 2 * N ? 1 : 2)] += dz[k] * r * Hs[k];
-      acc_be[k] += dz[k];
-    }
-    const float d_norm = d_r * (-r * r * inv_sqrt_nc);
-    const float dn_over = norm > 0.0f ? d_norm / norm : 0.0f;
-    float* dhr = a.d_h + row * nc;
-#pragma unroll
-    for (int ch = 0; ch < CH; ++ch) {
-      f32x4 dx;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t2 = 0.0f;
-#pragma unroll
-        for (int k = 0; k < G; ++k) t2 += dH[k] * wr[ch][e][k];
-        dx[e] = nw[ch][e] * t2 + dn_over * x[ch][e];
-        acc_nw[ch][e] += x[ch][e] * t2;
-        const float t = nw[ch][e] * x[ch][e];
-#pragma unroll
-        for (int k = 0; k < G; ++k) acc_w[ch][e][k] += t * dH[k];
+      for (int u = 0; u < U; ++u) {
+        const int rr = r0 + u < nrows ? r0 + u : nrows - 1;
+        const int64_t rw = base + rr;
+        x[u] = *reinterpret_cast<const f32x4*>(a.h + rw * nc + c0);
+        if (a.d_read) gr[u] = *reinterpret_cast<const f32x4*>(a.d_read + rw * a.D + d0);
+        if (a.g_out) {
+          g0[u] = *reinterpret_cast<const f32x4*>(a.g_out + (rw * N) * a.D + d0);
+          g1[u] = *reinterpret_cast<const f32x4*>(a.g_out + (rw * N + 1) * a.D + d0);
+        }
       }
-      *reinterpret_cast<f32x4*>(dhr + 256 * ch + 4 * lane) = dx;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int rr = r0 + u;
+        if (rr < nrows) {
+          float sH[G];
+#pragma unroll
+          for (int k = 0; k < G; ++k) sH[k] = lane_value(dH[k], rr);
+          const float s_dn = lane_value(dn_over, rr);
+          f32x4 dx;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t2 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < G; ++k) t2 += sH[k] * wr[e][k];
+            dx[e] = nw[e] * t2 + s_dn * x[u][e];
+            acc_nw[e] += x[u][e] * t2;
+            const float t = nw[e] * x[u][e];
+#pragma unroll
+            for (int k = 0; k < G; ++k) acc_w[e][k] += t * sH[k];
+          }
+          if (a.d_read) {
+            const float pj = j ? lane_value(p1, rr) : lane_value(p0, rr);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dx[e] += pj * gr[u][e];
+          }
+          if (a.g_out) {
+            const float m0j = j ? lane_value(m01, rr) : lane_value(m00, rr);
+            const float m1j = j ? lane_value(m11, rr) : lane_value(m10, rr);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dx[e] += m0j * g0[u][e] + m1j * g1[u][e];
+          }
+          *reinterpret_cast<f32x4*>(a.d_h + (base + rr) * nc + c0) = dx;
+        }
+      }
     }
   }
-  // workgroup reduction in a fixed order, one partial vector per workgroup
-  float* mine = red + (size_t)wave * len;
+  // d alpha / d beta: the lanes' row sums added across the wave (fixed tree), then everything across the workgroup's waves
 #pragma unroll
-  for (int ch = 0; ch < CH; ++ch)
+  for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = 256 * ch + 4 * lane + e;
-      mine[c] = acc_nw[ch][e];
+    for (int g = 0; g < 3; ++g) acc_al[g] += __shfl_xor(acc_al[g], off, 64);
 #pragma unroll
-      for (int k = 0; k < G; ++k) mine[nc + c * G + k] = acc_w[ch][e][k];
-    }
+    for (int k = 0; k < G; ++k) acc_be[k] += __shfl_xor(acc_be[k], off, 64);
+  }
+  float* mine = red + (size_t)wave * kGatesLen;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = 4 * lane + e;
+    mine[c] = acc_nw[e];
+#pragma unroll
+    for (int k = 0; k < G; ++k) mine[256 + c * G + k] = acc_w[e][k];
+  }
   if (lane == 0) {
 #pragma unroll
-    for (int g = 0; g < 3; ++g) mine[nc + nc * G + g] = acc_al[g];
+    for (int g = 0; g < 3; ++g) mine[256 + 256 * G + g] = acc_al[g];
 #pragma unroll
-    for (int k = 0; k < G; ++k) mine[nc + nc * G + 3 + k] = acc_be[k];
+    for (int k = 0; k < G; ++k) mine[256 + 256 * G + 3 + k] = acc_be[k];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < len; i += 64 * kWaves) {
+  float* out = a.partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kGatesLen;
+  for (int i = threadIdx.x; i < kGatesLen; i += 64 * kWaves) {
     float sum = red[i];
 #pragma unroll
-    for (int w2 = 1; w2 < kWaves; ++w2) sum += red[(size_t)w2 * len + i];
-    a.partial[(size_t)blockIdx.x * len + i] = sum;
+    for (int w2 = 1; w2 < kWaves; ++w2) sum += red[(size_t)w2 * kGatesLen + i];
+    out[i] = sum;
   }
 }
 
-// out[i] = sum over workgroups (ascending) of partial[b][i], scattered to the four gradient tensors
-__global__ __launch_bounds__(256) void gates_bwd_reduce_kernel(const float* __restrict__ partial, int blocks, int nc, int G,
-                                                              float* __restrict__ d_nw, float* __restrict__ d_w,
-                                                              float* __restrict__ d_alpha, float* __restrict__ d_beta) {
-  const int len = nc + nc * G + 3 + G;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= len) return;
+// out[i] = sum over b < blocks (ascending within eight fixed slices, the slices ascending) of partial[(y * blocks + b) * len + i];
+// the destination of element i of column block y is the segment it falls in: seg_end[s - 1] <= i < seg_end[s] ->
+// dst[s][y * seg_stride[s] + i - seg_end[s - 1]]  (seg_stride 0: only column block 0 writes the segment)
+struct ReduceArgs {
+  const float* partial; int blocks, len, n_seg;
+  int seg_end[4]; int seg_stride[4]; float* dst[4];
+};
+
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const ReduceArgs a) {
+  __shared__ float part[8][32];
+  const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + col, y = blockIdx.y;
   float s = 0.0f;
-  for (int b = 0; b < blocks; ++b) s += partial[(size_t)b * len + i];
-  if (i < nc) d_nw[i] = s;
-  else if (i < nc + nc * G) d_w[i - nc] = s;
-  else if (i < nc + nc * G + 3) d_alpha[i - nc - nc * G] = s;
-  else d_beta[i - nc - nc * G - 3] = s;
+  if (i < a.len) {
+    const int per = (a.blocks + 7) / 8;
+    const int b0 = sl * per, b1 = b0 + per < a.blocks ? b0 + per : a.blocks;
+    const float* p = a.partial + (size_t)y * a.blocks * a.len + i;
+    for (int b = b0; b < b1; ++b) s += p[(size_t)b * a.len];
+  }
+  part[sl][col] = s;
+  __syncthreads();
+  if (sl == 0 && i < a.len) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += part[k][col];
+    int lo = 0;
+    for (int sg = 0; sg < a.n_seg; ++sg) {
+      if (i < a.seg_end[sg]) {
+        if (a.seg_stride[sg] || y == 0) a.dst[sg][(size_t)y * a.seg_stride[sg] + (i - lo)] = s;
+        break;
+      }
+      lo = a.seg_end[sg];
+    }
+  }
 }
 
 // Sinkhorn-Knopp scalings of B positive n x n matrices (ManifoldHyperConnectionFuse.gates :141-146, under no_grad in the
@@ -414,9 +598,10 @@ __global__ __launch_bounds__(256) void sinkhorn_kernel(const float* __restrict__
   for (int i = 0; i < N; ++i) { u_out[(size_t)b * N + i] = u[i]; v_out[(size_t)b * N + i] = v[i]; }
 }
 
-// y = x * rsqrt(mean(x^2) + eps) * w per row; n_sum > 1: x = the sum of n_sum consecutive [D] blocks of the row
+// y = s * rsqrt(mean(s^2) + eps) * w per row; n_sum > 1: s = the sum of n_sum consecutive [D] blocks of the row;
+// silu: s = SiLU(x) (the MLPs' Linear -> SiLU -> RMSNorm: the activation rides in the norm's two launches)
 __global__ __launch_bounds__(64 * kWaves) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                             int B, int D, int n_sum, float eps, float* __restrict__ y) {
+                                                             int B, int D, int n_sum, float eps, int silu, float* __restrict__ y) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * kWaves + (threadIdx.x >> 6);
   if (row >= B) return;
@@ -425,6 +610,7 @@ __global__ __launch_bounds__(64 * kWaves) void rmsnorm_kernel(const float* __res
   for (int d = lane; d < D; d += 64) {
     float s = xr[d];
     for (int k = 1; k < n_sum; ++k) s += xr[k * D + d];
+    if (silu) s = silu_(s);
     sq += s * s;
   }
 #pragma unroll
@@ -433,7 +619,68 @@ __global__ __launch_bounds__(64 * kWaves) void rmsnorm_kernel(const float* __res
   for (int d = lane; d < D; d += 64) {
     float s = xr[d];
     for (int k = 1; k < n_sum; ++k) s += xr[k * D + d];
+    if (silu) s = silu_(s);
     y[(size_t)row * D + d] = s * r * w[d];
+  }
+}
+
+// backward of y = s r w, s = x or SiLU(x), r = rsqrt(mean(s^2) + eps), one wave per row (D <= 512, lane l holds columns l + 64 q):
+//   d s = r (w g) - s r^3 / D sum_d(w g s);  d x = d s [SiLU'(x)];  d w[d] = sum over rows g s r — per-lane column sums over the rows
+// the wave visits, added across the workgroup's waves through LDS, one partial vector per workgroup for partial_reduce_kernel.
+template <int kNormQ>
+__global__ __launch_bounds__(64 * kWaves) void rmsnorm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                                 const float* __restrict__ w, int B, int D, float eps, int silu,
+                                                                 float* __restrict__ d_x, float* __restrict__ partial) {
+  __shared__ float red[kWaves][64 * kNormQ];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float wv[kNormQ], acc[kNormQ];
+#pragma unroll
+  for (int q = 0; q < kNormQ; ++q) {
+    const int d = lane + 64 * q;
+    wv[q] = d < D ? w[d] : 0.0f;
+    acc[q] = 0.0f;
+  }
+  const float inv_d = 1.0f / (float)D;
+  for (int64_t row = (int64_t)blockIdx.x * kWaves + wave; row < B; row += (int64_t)gridDim.x * kWaves) {
+    float xv[kNormQ], gv[kNormQ], sv[kNormQ], sq = 0.0f, dot = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kNormQ; ++q) {
+      const int d = lane + 64 * q;
+      xv[q] = d < D ? x[row * D + d] : 0.0f;
+      gv[q] = d < D ? g[row * D + d] : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < kNormQ; ++q) {
+      sv[q] = silu ? silu_(xv[q]) : xv[q];
+      sq += sv[q] * sv[q];
+      dot += wv[q] * gv[q] * sv[q];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sq += __shfl_xor(sq, off, 64);
+      dot += __shfl_xor(dot, off, 64);
+    }
+    const float r = rsqrtf(sq * inv_d + eps);
+    const float k3 = r * r * r * inv_d * dot;
+#pragma unroll
+    for (int q = 0; q < kNormQ; ++q) {
+      const int d = lane + 64 * q;
+      if (d < D) {
+        float ds = r * wv[q] * gv[q] - sv[q] * k3;
+        if (silu) ds *= silu_grad_(xv[q]);
+        d_x[row * D + d] = ds;
+        acc[q] += gv[q] * sv[q] * r;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kNormQ; ++q) red[wave][lane + 64 * q] = acc[q];
+  __syncthreads();
+  for (int i = threadIdx.x; i < D; i += 64 * kWaves) {
+    float sum = red[0][i];
+#pragma unroll
+    for (int w2 = 1; w2 < kWaves; ++w2) sum += red[w2][i];
+    partial[(size_t)blockIdx.x * D + i] = sum;
   }
 }
 
@@ -442,27 +689,39 @@ __global__ __launch_bounds__(64 * kWaves) void rmsnorm_kernel(const float* __res
 extern "C" {
 
 int gymrl_mhc_gates(const float* h, const float* norm_w, const float* w, const float* alpha, const float* beta, int B, int n,
-                    int D, int sk_it, float* pre_out, float* post_out, float* mix_out, float* read_out, void* stream) {
+                    int D, int sk_it, float* pre_out, float* post_out, float* mix_out, float* read_out, float* stats_out,
+                    void* stream) {
   if (!h || !norm_w || !w || !alpha || !beta || !pre_out || !post_out || !mix_out || !read_out || B < 0 || D < 4 || D % 4 ||
       sk_it < 0 || (n != 2 && n != 4))
     return -22;
+  const bool batched = n == 2 && (n * D == 256 || n * D == 512);
+  if (stats_out && !batched) return -22;
   if (B == 0) return 0;
-  GatesArgs a{h, norm_w, w, alpha, beta, pre_out, post_out, mix_out, read_out, B, D, sk_it};
-  const dim3 grid((B + kWaves - 1) / kWaves), block(64 * kWaves);
-  if (n == 2) hipLaunchKernelGGL(mhc_gates_kernel<2>, grid, block, 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(mhc_gates_kernel<4>, grid, block, 0, (hipStream_t)stream, a);
+  GatesArgs a{h, norm_w, w, alpha, beta, pre_out, post_out, mix_out, read_out, stats_out, B, D, sk_it};
+  if (batched) {
+    const int rb = n * D == 256 ? 16 : 8;                  // rows per wave
+    const dim3 grid((B + rb - 1) / rb), block(64);
+    if (n * D == 256) hipLaunchKernelGGL(mhc_gates2_kernel<1>, grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(mhc_gates2_kernel<2>, grid, block, 0, (hipStream_t)stream, a);
+  } else {
+    const dim3 grid((B + kWaves - 1) / kWaves), block(64 * kWaves);
+    if (n == 2) hipLaunchKernelGGL(mhc_gates_kernel<2>, grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(mhc_gates_kernel<4>, grid, block, 0, (hipStream_t)stream, a);
+  }
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
 
-int gymrl_mhc_combine(const float* post, const float* mix, const float* out, const float* h, int B, int n, int D, float* h_out,
-                      void* stream) {
-  if (!post || !mix || !out || !h || !h_out || B < 0 || D < 1 || (n != 2 && n != 4)) return -22;
+int gymrl_mhc_combine(const float* post, const float* mix, const float* out, const float* h, int B, int n, int D, int act,
+                      float* h_out, void* stream) {
+  if (!post || !mix || !out || !h || !h_out || B < 0 || D < 1 || (n != 2 && n != 4) || (act != GYMRL_ACT_NONE && act != GYMRL_ACT_SILU))
+    return -22;
   if (B == 0) return 0;
   int64_t nb = ((int64_t)B * D + 255) / 256;
   if (nb > 4096) nb = 4096;
-  if (n == 2) hipLaunchKernelGGL(mhc_combine_kernel<2>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, post, mix, out, h, B, D, h_out);
-  else hipLaunchKernelGGL(mhc_combine_kernel<4>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, post, mix, out, h, B, D, h_out);
+  const int silu = act == GYMRL_ACT_SILU;
+  if (n == 2) hipLaunchKernelGGL(mhc_combine_kernel<2>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, post, mix, out, h, B, D, silu, h_out);
+  else hipLaunchKernelGGL(mhc_combine_kernel<4>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, post, mix, out, h, B, D, silu, h_out);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
@@ -480,7 +739,7 @@ int gymrl_mhc_read_fwd(const float* pre, const float* h, int B, int n, int D, fl
 
 int gymrl_mhc_read_bwd(const float* g, const float* pre, const float* h, int B, int n, int D, float* d_pre, float* d_h,
                        int accumulate, void* stream) {
-  if (!g || !pre || !h || !d_pre || !d_h || B < 0 || D < 1 || (n != 2 && n != 4)) return -22;
+  if (!g || !pre || !h || !d_pre || B < 0 || D < 1 || (n != 2 && n != 4)) return -22;
   if (B == 0) return 0;
   const dim3 grid((B + kWaves - 1) / kWaves), block(64 * kWaves);
   if (n == 2) hipLaunchKernelGGL(mhc_read_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, g, pre, h, B, D, d_pre, d_h, accumulate);
@@ -490,42 +749,44 @@ int gymrl_mhc_read_bwd(const float* g, const float* pre, const float* h, int B, 
 }
 
 int gymrl_mhc_combine_bwd(const float* g, const float* post, const float* mix, const float* out, const float* h, int B, int n, int D,
-                          float* d_post, float* d_mix, float* d_out, float* d_h, void* stream) {
-  if (!g || !post || !mix || !out || !h || !d_post || !d_mix || !d_out || !d_h || B < 0 || D < 1 || (n != 2 && n != 4)) return -22;
+                          int act, float* d_post, float* d_mix, float* d_out, float* d_h, void* stream) {
+  if (!g || !post || !mix || !out || !h || !d_post || !d_mix || !d_out || B < 0 || D < 1 || (n != 2 && n != 4) ||
+      (act != GYMRL_ACT_NONE && act != GYMRL_ACT_SILU))
+    return -22;
   if (B == 0) return 0;
   const dim3 grid((B + kWaves - 1) / kWaves), block(64 * kWaves);
-  if (n == 2) hipLaunchKernelGGL(mhc_combine_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, g, post, mix, out, h, B, D, d_post, d_mix, d_out, d_h);
-  else hipLaunchKernelGGL(mhc_combine_bwd_kernel<4>, grid, block, 0, (hipStream_t)stream, g, post, mix, out, h, B, D, d_post, d_mix, d_out, d_h);
+  const int silu = act == GYMRL_ACT_SILU;
+  if (n == 2) hipLaunchKernelGGL(mhc_combine_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, g, post, mix, out, h, B, D, silu, d_post, d_mix, d_out, d_h);
+  else hipLaunchKernelGGL(mhc_combine_bwd_kernel<4>, grid, block, 0, (hipStream_t)stream, g, post, mix, out, h, B, D, silu, d_post, d_mix, d_out, d_h);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
 
+static int gates_bwd_blocks(int B) {
+  int blocks = (B + 64 * kWaves - 1) / (64 * kWaves);
+  return blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks);
+}
+
 size_t gymrl_mhc_gates_bwd_workspace_bytes(int n, int D) {
-  const int nc = n * D, G = n * n + 2 * n;
-  return sizeof(float) * 1024 * ((size_t)nc + (size_t)nc * G + 3 + G);
+  const int ch = n * D / 256;
+  return sizeof(float) * 1024 * (size_t)(ch < 1 ? 1 : ch) * kGatesLen;
 }
 
 int gymrl_mhc_gates_bwd(const float* h, const float* norm_w, const float* w, const float* alpha, const float* pre, const float* post,
-                        const float* mix, const float* d_pre, const float* d_post, const float* d_mix, int B, int n, int D,
-                        float* d_h, float* d_norm_w, float* d_w, float* d_alpha, float* d_beta, void* workspace, void* stream) {
-  if (!h || !norm_w || !w || !alpha || !pre || !post || !mix || !d_pre || !d_post || !d_mix || !d_h || !d_norm_w || !d_w ||
+                        const float* mix, const float* stats, const float* d_pre, const float* d_post, const float* d_mix,
+                        const float* d_read, const float* g_out, int B, int n, int D, float* d_h, float* d_norm_w, float* d_w,
+                        float* d_alpha, float* d_beta, void* workspace, void* stream) {
+  if (!h || !norm_w || !w || !alpha || !pre || !post || !mix || !stats || !d_pre || !d_post || !d_mix || !d_h || !d_norm_w || !d_w ||
       !d_alpha || !d_beta || !workspace || B < 1 || n != 2 || (n * D != 256 && n * D != 512))
     return -22;
-  const int nc = n * D, G = n * n + 2 * n, len = nc + nc * G + 3 + G;
-  int blocks = (B + kWaves - 1) / kWaves;
-  if (blocks > 1024) blocks = 1024;
-  GatesBwdArgs a{h, norm_w, w, alpha, pre, post, mix, d_pre, d_post, d_mix, d_h, static_cast<float*>(workspace), B, D};
-  const size_t lds = sizeof(float) * kWaves * len;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)mhc_gates_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
-      return -1000 - (int)hipGetLastError();
-    attr = true;
-  }
-  if (nc == 256) hipLaunchKernelGGL(mhc_gates_bwd_kernel<1>, dim3(blocks), dim3(64 * kWaves), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(mhc_gates_bwd_kernel<2>, dim3(blocks), dim3(64 * kWaves), lds, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(gates_bwd_reduce_kernel, dim3((len + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                     static_cast<const float*>(workspace), blocks, nc, G, d_norm_w, d_w, d_alpha, d_beta);
+  const int ch = n * D / 256, blocks = gates_bwd_blocks(B);
+  GatesBwdArgs a{h, norm_w, w, alpha, pre, post, mix, stats, d_pre, d_post, d_mix, d_read, g_out, d_h, static_cast<float*>(workspace),
+                 B, D};
+  hipLaunchKernelGGL(mhc_gates_bwd_kernel, dim3(blocks, ch), dim3(64 * kWaves), sizeof(float) * kWaves * kGatesLen,
+                     (hipStream_t)stream, a);
+  ReduceArgs r{static_cast<const float*>(workspace), blocks, kGatesLen, 4,
+               {256, 256 + 256 * 8, 256 + 256 * 8 + 3, kGatesLen}, {256, 256 * 8, 0, 0}, {d_norm_w, d_w, d_alpha, d_beta}};
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((kGatesLen + 31) / 32, ch), dim3(256), 0, (hipStream_t)stream, r);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
@@ -540,11 +801,34 @@ int gymrl_sinkhorn(const float* A, int B, int n, int sk_it, float* u_out, float*
   return 0;
 }
 
-int gymrl_rmsnorm(const float* x, const float* w, int B, int D, int n_sum, float eps, float* y, void* stream) {
-  if (!x || !w || !y || B < 0 || D < 1 || n_sum < 1) return -22;
+int gymrl_rmsnorm(const float* x, const float* w, int B, int D, int n_sum, float eps, int act, float* y, void* stream) {
+  if (!x || !w || !y || B < 0 || D < 1 || n_sum < 1 || (act != GYMRL_ACT_NONE && act != GYMRL_ACT_SILU)) return -22;
   if (B == 0) return 0;
   hipLaunchKernelGGL(rmsnorm_kernel, dim3((B + kWaves - 1) / kWaves), dim3(64 * kWaves), 0, (hipStream_t)stream, x, w, B, D, n_sum,
-                     eps, y);
+                     eps, act == GYMRL_ACT_SILU, y);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+static int rmsnorm_bwd_blocks(int B) {
+  int blocks = (B + kWaves - 1) / kWaves;
+  return blocks > 2048 ? 2048 : (blocks < 1 ? 1 : blocks);
+}
+
+size_t gymrl_rmsnorm_bwd_workspace_bytes(int D) { return sizeof(float) * 2048 * (size_t)(D < 1 ? 1 : D); }
+
+int gymrl_rmsnorm_bwd(const float* g, const float* x, const float* w, int B, int D, float eps, int act, float* d_x, float* d_w,
+                      void* workspace, void* stream) {
+  if (!g || !x || !w || !d_x || !d_w || !workspace || B < 1 || D < 1 || D > 512 || (act != GYMRL_ACT_NONE && act != GYMRL_ACT_SILU))
+    return -22;
+  const int blocks = rmsnorm_bwd_blocks(B), silu = act == GYMRL_ACT_SILU;
+  float* part = static_cast<float*>(workspace);
+  const dim3 grid(blocks), block(64 * kWaves);
+  if (D <= 128) hipLaunchKernelGGL(rmsnorm_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, g, x, w, B, D, eps, silu, d_x, part);
+  else if (D <= 256) hipLaunchKernelGGL(rmsnorm_bwd_kernel<4>, grid, block, 0, (hipStream_t)stream, g, x, w, B, D, eps, silu, d_x, part);
+  else hipLaunchKernelGGL(rmsnorm_bwd_kernel<8>, grid, block, 0, (hipStream_t)stream, g, x, w, B, D, eps, silu, d_x, part);
+  ReduceArgs r{part, blocks, D, 1, {D, 0, 0, 0}, {0, 0, 0, 0}, {d_w, nullptr, nullptr, nullptr}};
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((D + 31) / 32, 1), dim3(256), 0, (hipStream_t)stream, r);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

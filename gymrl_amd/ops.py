@@ -1011,35 +1011,55 @@ def dueling_bwd(dq):
 
 
 # ------------------------------------------------ mHC backbone (inference) --
-def mhc_gates(h, norm_w, w, alpha, beta, sk_it):
-    """gymrl_mhc_gates: h [B, n, D] -> (pre [B, n], post [B, n], mix [B, n, n], read [B, D])."""
+def mhc_gates(h, norm_w, w, alpha, beta, sk_it, stats=False):
+    """gymrl_mhc_gates: h [B, n, D] -> (pre [B, n], post [B, n], mix [B, n, n], read [B, D]); stats=True appends the per-row
+    read-out sums f32[B, n*n + 2n + 1] gymrl_mhc_gates_bwd takes (n = 2, n*D in (256, 512))."""
     B, n, D = h.shape
     dev = h.device
     pre, post = torch.empty(B, n, device=dev), torch.empty(B, n, device=dev)
     mix, read = torch.empty(B, n, n, device=dev), torch.empty(B, D, device=dev)
+    st = torch.empty(B, n * n + 2 * n + 1, device=dev) if stats else None
     check(lib().gymrl_mhc_gates(_ptr(h, torch.float32), _ptr(norm_w, torch.float32), _ptr(w, torch.float32),
                                 _ptr(alpha, torch.float32), _ptr(beta, torch.float32), C.c_int(B), C.c_int(n), C.c_int(D),
-                                C.c_int(sk_it), _ptr(pre), _ptr(post), _ptr(mix), _ptr(read), _stream()), "gymrl_mhc_gates")
-    return pre, post, mix, read
+                                C.c_int(sk_it), _ptr(pre), _ptr(post), _ptr(mix), _ptr(read), None if st is None else _ptr(st),
+                                _stream()), "gymrl_mhc_gates")
+    return (pre, post, mix, read, st) if stats else (pre, post, mix, read)
 
 
-def mhc_combine(post, mix, out, h):
-    """gymrl_mhc_combine: h'[b, i] = post[b, i] out[b] + sum_j mix[b, i, j] h[b, j]."""
+def mhc_combine(post, mix, out, h, act=0):
+    """gymrl_mhc_combine: h'[b, i] = post[b, i] act(out[b]) + sum_j mix[b, i, j] h[b, j]; act = 0 or LIN_ACT["silu"]."""
     B, n, D = h.shape
     h_out = torch.empty_like(h)
     check(lib().gymrl_mhc_combine(_ptr(post, torch.float32), _ptr(mix, torch.float32), _ptr(out, torch.float32),
-                                  _ptr(h, torch.float32), C.c_int(B), C.c_int(n), C.c_int(D), _ptr(h_out), _stream()),
-          "gymrl_mhc_combine")
+                                  _ptr(h, torch.float32), C.c_int(B), C.c_int(n), C.c_int(D), C.c_int(act), _ptr(h_out),
+                                  _stream()), "gymrl_mhc_combine")
     return h_out
 
 
-def rmsnorm(x, w, eps, n_sum=1):
-    """gymrl_rmsnorm: x [B, n_sum * D] (or [B, n_sum, D]) -> y [B, D] = s rsqrt(mean(s^2) + eps) w, s = the sum of the blocks."""
+def rmsnorm(x, w, eps, n_sum=1, act=0):
+    """gymrl_rmsnorm: x [B, n_sum * D] (or [B, n_sum, D]) -> y [B, D] = s rsqrt(mean(s^2) + eps) w, s = act(the sum of the blocks)."""
     B, D = x.shape[0], w.numel()
     y = torch.empty(B, D, device=x.device)
     check(lib().gymrl_rmsnorm(_ptr(x, torch.float32), _ptr(w, torch.float32), C.c_int(B), C.c_int(D), C.c_int(n_sum),
-                              C.c_float(eps), _ptr(y), _stream()), "gymrl_rmsnorm")
+                              C.c_float(eps), C.c_int(act), _ptr(y), _stream()), "gymrl_rmsnorm")
     return y
+
+
+_norm_ws = {}
+
+
+def rmsnorm_bwd(g, x, w, eps, act=0):
+    """gymrl_rmsnorm_bwd: (dL/dx [B, D], dL/dw [D]) of y = rmsnorm(x, w, eps, act=act); D <= 512."""
+    B, D = x.shape
+    key = (D, x.device)
+    ws = _norm_ws.get(key)
+    if ws is None:
+        ws = _norm_ws[key] = torch.empty(lib().gymrl_rmsnorm_bwd_workspace_bytes(C.c_int(D)) // 4, dtype=torch.float32,
+                                         device=x.device)
+    d_x, d_w = torch.empty_like(x), torch.empty_like(w)
+    check(lib().gymrl_rmsnorm_bwd(_ptr(g, torch.float32), _ptr(x, torch.float32), _ptr(w, torch.float32), C.c_int(B), C.c_int(D),
+                                  C.c_float(eps), C.c_int(act), _ptr(d_x), _ptr(d_w), _ptr(ws), _stream()), "gymrl_rmsnorm_bwd")
+    return d_x, d_w
 
 
 def sinkhorn(A, sk_it):
@@ -1059,30 +1079,38 @@ def mhc_read_fwd(pre, h):
     return read
 
 
-def mhc_read_bwd(g, pre, h):
+def mhc_read_bwd(g, pre, h, want_dh=True):
+    """(d_pre, d_h); want_dh=False: d_pre only (the d_h term goes through gymrl_mhc_gates_bwd's d_read)."""
     B, n, D = h.shape
-    d_pre, d_h = torch.empty(B, n, device=h.device), torch.empty_like(h)
+    d_pre = torch.empty(B, n, device=h.device)
+    d_h = torch.empty_like(h) if want_dh else None
     check(lib().gymrl_mhc_read_bwd(_ptr(g, torch.float32), _ptr(pre, torch.float32), _ptr(h, torch.float32), C.c_int(B), C.c_int(n),
-                                   C.c_int(D), _ptr(d_pre), _ptr(d_h), C.c_int(0), _stream()), "gymrl_mhc_read_bwd")
+                                   C.c_int(D), _ptr(d_pre), None if d_h is None else _ptr(d_h), C.c_int(0), _stream()),
+          "gymrl_mhc_read_bwd")
     return d_pre, d_h
 
 
-def mhc_combine_bwd(g, post, mix, out, h):
+def mhc_combine_bwd(g, post, mix, out, h, act=0, want_dh=True):
+    """(d_post, d_mix, d_out, d_h) of gymrl_mhc_combine with the same act (silu: `out` is the raw z and d_out is dL/dz);
+    want_dh=False: d_h = None (left to gymrl_mhc_gates_bwd's g_out term)."""
     B, n, D = h.shape
     dev = h.device
     d_post, d_mix = torch.empty(B, n, device=dev), torch.empty(B, n, n, device=dev)
-    d_out, d_h = torch.empty(B, D, device=dev), torch.empty_like(h)
+    d_out = torch.empty(B, D, device=dev)
+    d_h = torch.empty_like(h) if want_dh else None
     check(lib().gymrl_mhc_combine_bwd(_ptr(g, torch.float32), _ptr(post, torch.float32), _ptr(mix, torch.float32),
                                       _ptr(out, torch.float32), _ptr(h, torch.float32), C.c_int(B), C.c_int(n), C.c_int(D),
-                                      _ptr(d_post), _ptr(d_mix), _ptr(d_out), _ptr(d_h), _stream()), "gymrl_mhc_combine_bwd")
+                                      C.c_int(act), _ptr(d_post), _ptr(d_mix), _ptr(d_out), None if d_h is None else _ptr(d_h),
+                                      _stream()), "gymrl_mhc_combine_bwd")
     return d_post, d_mix, d_out, d_h
 
 
 _gates_ws = {}
 
 
-def mhc_gates_bwd(h, norm_w, w, alpha, pre, post, mix, d_pre, d_post, d_mix):
-    """gymrl_mhc_gates_bwd -> (d_h, d_norm_w, d_w, d_alpha, d_beta); n = 2 branches, n * D in (256, 512)."""
+def mhc_gates_bwd(h, norm_w, w, alpha, pre, post, mix, stats, d_pre, d_post, d_mix, d_read=None, g_out=None):
+    """gymrl_mhc_gates_bwd -> (d_h, d_norm_w, d_w, d_alpha, d_beta); n = 2 branches, n * D in (256, 512).  d_read [B, D] /
+    g_out [B, n, D]: the read's and the combine's gradient paths into h, folded into d_h in the same pass."""
     B, n, D = h.shape
     dev = h.device
     key = (n, D, dev)
@@ -1092,9 +1120,11 @@ def mhc_gates_bwd(h, norm_w, w, alpha, pre, post, mix, d_pre, d_post, d_mix):
         ws = _gates_ws[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     d_h, d_nw, d_w = torch.empty_like(h), torch.empty_like(norm_w), torch.empty_like(w)
     d_alpha, d_beta = torch.empty(3, device=dev), torch.empty(w.shape[1], device=dev)
+    opt = lambda t: None if t is None else _ptr(t, torch.float32)   # noqa: E731
     check(lib().gymrl_mhc_gates_bwd(_ptr(h, torch.float32), _ptr(norm_w, torch.float32), _ptr(w, torch.float32),
                                     _ptr(alpha, torch.float32), _ptr(pre, torch.float32), _ptr(post, torch.float32),
-                                    _ptr(mix, torch.float32), _ptr(d_pre, torch.float32), _ptr(d_post, torch.float32),
-                                    _ptr(d_mix, torch.float32), C.c_int(B), C.c_int(n), C.c_int(D), _ptr(d_h), _ptr(d_nw),
-                                    _ptr(d_w), _ptr(d_alpha), _ptr(d_beta), _ptr(ws), _stream()), "gymrl_mhc_gates_bwd")
+                                    _ptr(mix, torch.float32), _ptr(stats, torch.float32), _ptr(d_pre, torch.float32),
+                                    _ptr(d_post, torch.float32), _ptr(d_mix, torch.float32), opt(d_read), opt(g_out),
+                                    C.c_int(B), C.c_int(n), C.c_int(D), _ptr(d_h), _ptr(d_nw), _ptr(d_w), _ptr(d_alpha),
+                                    _ptr(d_beta), _ptr(ws), _stream()), "gymrl_mhc_gates_bwd")
     return d_h, d_nw, d_w, d_alpha, d_beta

@@ -24,7 +24,7 @@ from . import ops
 from .graphs import capture as gcapture
 from .envs import VecEnv
 from .flat import FusedAdam, GradSink, flatten_module
-from .nn import SmallLinear, skinny_matmul
+from .nn import GradSink_direct, SmallLinear, skinny_matmul
 
 
 class Config:
@@ -68,6 +68,8 @@ class Config:
 FUSED_GATES = True          # training pass: the gates as one forward + one backward launch (False: torch ops + gymrl_sinkhorn)
 FUSED_MIXING = True         # training pass: read / combine products as fused forward + backward launches (False: broadcast multiplies)
 FUSED_INFERENCE = True      # rollout forward on the inference kernels (tools A/B; False: the torch modules)
+FUSED_SUB = True            # training pass: a whole hyper-connection sub-block as one autograd node (3 launches forward, 7 backward)
+FUSED_NORM = True           # training pass: RMSNorm (+ the SiLU before it) as one launch each way
 
 
 def _ortho(layer, std):
@@ -83,8 +85,30 @@ class RMSNorm(nn.Module):
         self.eps = eps
         self.weight = nn.Parameter(torch.ones(dim))
 
-    def forward(self, x):
+    def forward(self, x, silu=False):
+        """silu=True: the norm of SiLU(x) (the MLPs' Linear -> SiLU -> RMSNorm)."""
+        if (FUSED_NORM and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] <= 512 and x.shape[0] > 0):
+            return _RmsNorm.apply(x, self.weight, self.eps, silu)          # one launch each way (~20 through torch)
+        if silu:
+            x = torch.nn.functional.silu(x)
         return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.eps) * self.weight
+
+
+class _RmsNorm(torch.autograd.Function):
+    """RMSNorm (:96-104), optionally of SiLU(x), as gymrl_rmsnorm / gymrl_rmsnorm_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, w, eps, silu):
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.eps, ctx.act = eps, ops.LIN_ACT["silu"] if silu else 0
+        return ops.rmsnorm(x, w, eps, act=ctx.act)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        d_x, d_w = ops.rmsnorm_bwd(g.contiguous(), x, w, ctx.eps, ctx.act)
+        return d_x, d_w, None, None
 
 
 class ManifoldHyperConnectionFuse(nn.Module):
@@ -135,17 +159,52 @@ class _MhcGates(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, norm_w, w, alpha, beta, sk_it):
         h = h.contiguous()
-        pre, post, mix, _ = ops.mhc_gates(h, norm_w, w, alpha, beta, sk_it)
-        ctx.save_for_backward(h, norm_w, w, alpha, pre, post, mix)
+        pre, post, mix, _, stats = ops.mhc_gates(h, norm_w, w, alpha, beta, sk_it, stats=True)
+        ctx.save_for_backward(h, norm_w, w, alpha, pre, post, mix, stats)
         return pre, post, mix
 
     @staticmethod
     def backward(ctx, d_pre, d_post, d_mix):
-        h, norm_w, w, alpha, pre, post, mix = ctx.saved_tensors
+        h, norm_w, w, alpha, pre, post, mix, stats = ctx.saved_tensors
         z = lambda g, ref: torch.zeros_like(ref) if g is None else g.contiguous()   # noqa: E731
-        d_h, d_nw, d_w, d_alpha, d_beta = ops.mhc_gates_bwd(h, norm_w, w, alpha, pre, post, mix, z(d_pre, pre), z(d_post, post),
-                                                            z(d_mix, mix))
+        d_h, d_nw, d_w, d_alpha, d_beta = ops.mhc_gates_bwd(h, norm_w, w, alpha, pre, post, mix, stats, z(d_pre, pre),
+                                                            z(d_post, post), z(d_mix, mix))
         return d_h, d_nw, d_w, d_alpha, d_beta, None
+
+
+class _MhcSub(torch.autograd.Function):
+    """One hyper-connection sub-block h -> post (x) SiLU(Linear(sum_i pre_i h_i)) + mix h (MHCBlock._sub :160-165 with the gates
+    :125-147) as ONE autograd node.  Forward: gymrl_mhc_gates (gates + read-out sums + branch sum), gymrl_lin_fwd, gymrl_mhc_combine
+    (SiLU applied on load).  Backward: combine -> (d post, d mix, d z), the Linear's two gradient launches, the read's d pre, and
+    gymrl_mhc_gates_bwd, which also folds the read's and the combine's paths into d h: the three consumers of h hand autograd one
+    gradient tensor (as separate nodes they cost two [B, n, D] additions, the SiLU's two passes and a second read of h)."""
+
+    @staticmethod
+    def forward(ctx, h, norm_w, w, alpha, beta, W, b, sk_it):
+        h = h.contiguous()
+        pre, post, mix, read, stats = ops.mhc_gates(h, norm_w, w, alpha, beta, sk_it, stats=True)
+        z = ops.lin_fwd(read, W, b)
+        ctx.save_for_backward(h, norm_w, w, alpha, pre, post, mix, stats, read, z, W)
+        ctx.sinks = (getattr(W, "_gymrl_sink", None), getattr(b, "_gymrl_sink", None))
+        return ops.mhc_combine(post, mix, z, h, act=ops.LIN_ACT["silu"])
+
+    @staticmethod
+    def backward(ctx, g):
+        h, norm_w, w, alpha, pre, post, mix, stats, read, z, W = ctx.saved_tensors
+        g = g.contiguous()
+        d_post, d_mix, d_z, _ = ops.mhc_combine_bwd(g, post, mix, z, h, act=ops.LIN_ACT["silu"], want_dh=False)
+        d_read, _ = ops.lin_bwd_input(d_z, z, W)
+        slot = GradSink_direct(ctx.sinks[0], ctx.sinks[1], True)
+        if slot is not None:                         # straight into the flat gradient buffer (gymrl_amd/flat.py GradSink)
+            ops.lin_bwd_weight(d_z, z, read, slot[0], slot[1], accumulate=slot[2])
+            d_W = d_b = None
+        else:
+            d_W, d_b = torch.empty_like(W), torch.empty(W.shape[0], dtype=W.dtype, device=W.device)
+            ops.lin_bwd_weight(d_z, z, read, d_W, d_b)
+        d_pre, _ = ops.mhc_read_bwd(d_read, pre, h, want_dh=False)
+        d_h, d_nw, d_w, d_alpha, d_beta = ops.mhc_gates_bwd(h, norm_w, w, alpha, pre, post, mix, stats, d_pre, d_post, d_mix,
+                                                            d_read=d_read, g_out=g)
+        return d_h, d_nw, d_w, d_alpha, d_beta, d_W, d_b, None
 
 
 class _MhcRead(torch.autograd.Function):
@@ -189,6 +248,10 @@ class MHCBlock(nn.Module):
 
     @staticmethod
     def _sub(h, fuse, linear, act):
+        if (FUSED_SUB and FUSED_GATES and FUSED_MIXING and h.is_cuda and h.dtype == torch.float32 and fuse.n == 2
+                and fuse.nc in (256, 512) and isinstance(act, nn.SiLU) and isinstance(linear, SmallLinear)
+                and linear.bias is not None and getattr(linear, "act", None) in (None, "none")):
+            return _MhcSub.apply(h, fuse.norm.weight, fuse.w, fuse.alpha, fuse.beta, linear.weight, linear.bias, fuse.max_sk_it)
         pre, post, mix = fuse.gates(h)
         if h.is_cuda and h.shape[1] in (2, 4) and h.shape[2] % 4 == 0 and FUSED_MIXING:
             # the three products and their backward as four launches instead of ~25 elementwise passes over [B, n, D]
@@ -263,7 +326,16 @@ class MLP(nn.Module):
         self.mlp = nn.Sequential(*layers)
 
     def forward(self, x):
-        return self.mlp(x)
+        mods = list(self.mlp)
+        i = 0
+        while i < len(mods):
+            if i + 1 < len(mods) and isinstance(mods[i], nn.SiLU) and isinstance(mods[i + 1], RMSNorm):
+                x = mods[i + 1](x, silu=True)        # SiLU rides in the norm's launches on the GPU
+                i += 2
+            else:
+                x = mods[i](x)
+                i += 1
+        return x
 
 
 class PSCN(nn.Module):

@@ -11,7 +11,7 @@ def _close(got, ref, tol):
     assert err <= tol * max(1.0, float(ref.abs().max())), err
 
 
-@pytest.mark.parametrize("rate,dim,B", [(2, 128, 4096), (2, 64, 37), (4, 32, 300)])
+@pytest.mark.parametrize("rate,dim,B", [(2, 128, 4096), (2, 128, 1), (2, 128, 17), (2, 256, 1003), (2, 64, 37), (4, 32, 300)])
 def test_mhc_gates_combine_rmsnorm_match_modules(rate, dim, B):
     from gymrl_amd import ops
     from gymrl_amd.ppo_full_lunarlander import ManifoldHyperConnectionFuse, RMSNorm
@@ -40,6 +40,11 @@ def test_mhc_gates_combine_rmsnorm_match_modules(rate, dim, B):
         norm.weight.uniform_(0.5, 1.5)
     _close(ops.rmsnorm(hd, norm.weight.cuda(), norm.eps, n_sum=rate), norm.double()(h.double().sum(1)), 1e-5)
     _close(ops.rmsnorm(out.cuda(), norm.float().weight.cuda(), norm.eps), norm.double()(out.double()), 1e-5)
+    if rate == 2 and rate * dim in (256, 512):              # the read-out sums the backward takes
+        stats = ops.mhc_gates(hd, fuse.norm.weight, fuse.w, fuse.alpha, fuse.beta, 10, stats=True)[4]
+        flat = h.double().reshape(B, -1)
+        _close(stats[:, :8], (ref.norm.weight * flat) @ ref.w, 1e-5)
+        _close(stats[:, 8], flat.pow(2).sum(1), 1e-5)
 
 
 @pytest.mark.parametrize("rate,dim,layers", [(2, 128, 2), (4, 32, 1)])
@@ -123,3 +128,66 @@ def test_gates_backward_matches_autograd(dim, B):
         _close(got, want, 2e-5)
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dim,B", [(128, 2500), (256, 300), (128, 1)])
+def test_sub_block_node_matches_autograd(dim, B):
+    """A whole MHCBlock (two sub-blocks, each ONE autograd node: _MhcSub) against the module's torch expression in float64:
+    output, the gradient of h and of every parameter — incl. the read's and the combine's paths into h that
+    gymrl_mhc_gates_bwd folds in, and the Linear's gradients written by the node itself."""
+    import gymrl_amd.ppo_full_lunarlander as pf
+    torch.manual_seed(dim + B)
+    block = pf.MHCBlock(dim, 2, 10)
+    with torch.no_grad():
+        for m in (block.mhc1, block.mhc2):
+            m.w.normal_(0, 0.3)
+            m.alpha.copy_(torch.tensor([0.7, -0.4, 0.9]))
+            m.norm.weight.uniform_(0.5, 1.5)
+    ref = pf.MHCBlock(dim, 2, 10).double()
+    ref.load_state_dict({k: v.double() for k, v in block.state_dict().items()})
+    h, g = torch.randn(B, 2, dim), torch.randn(B, 2, dim)
+    h64 = h.double().requires_grad_(True)
+    out64 = ref(h64)
+    out64.backward(g.double())
+    block = block.cuda()
+    hd = h.cuda().requires_grad_(True)
+    assert pf.FUSED_SUB
+    out = block(hd)
+    assert type(out.grad_fn).__name__ == "_MhcSubBackward"
+    out.backward(g.cuda())
+    _close(out, out64.detach(), 1e-5)
+    _close(hd.grad, h64.grad, 3e-5)
+    for (k, p), (_, q) in zip(block.named_parameters(), ref.named_parameters()):
+        _close(p.grad, q.grad, 3e-5)
+    first = [p.grad.clone() for p in block.parameters()]     # fixed-order sums: a second pass gives the same bits
+    for p in block.parameters():
+        p.grad = None
+    hd2 = h.cuda().requires_grad_(True)
+    block(hd2).backward(g.cuda())
+    assert torch.equal(hd2.grad, hd.grad)
+    for a, p in zip(first, block.parameters()):
+        assert torch.equal(a, p.grad)
+
+
+@pytest.mark.parametrize("dim,B,silu", [(128, 3000, False), (256, 700, True), (512, 65, True), (96, 130, False), (256, 1, True)])
+def test_rmsnorm_node_matches_autograd(dim, B, silu):
+    """RMSNorm (optionally of SiLU(x): the MLPs' Linear -> SiLU -> RMSNorm) as one launch each way against float64 autograd."""
+    from gymrl_amd.ppo_full_lunarlander import RMSNorm
+    torch.manual_seed(dim)
+    norm = RMSNorm(dim)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+    ref = RMSNorm(dim).double()
+    ref.load_state_dict({k: v.double() for k, v in norm.state_dict().items()})
+    x, g = torch.randn(B, dim) * 2, torch.randn(B, dim)
+    x64 = x.double().requires_grad_(True)
+    y64 = ref(x64, silu=silu)
+    y64.backward(g.double())
+    norm = norm.cuda()
+    xd = x.cuda().requires_grad_(True)
+    y = norm(xd, silu=silu)
+    assert type(y.grad_fn).__name__ == "_RmsNormBackward"
+    y.backward(g.cuda())
+    _close(y, y64.detach(), 1e-5)
+    _close(xd.grad, x64.grad, 2e-5)
+    _close(norm.weight.grad, ref.weight.grad, 2e-5)
