@@ -389,14 +389,122 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lin_bwd_weight_kernel(con
   }
 }
 
+// Large batches (>= 16384 rows), N and K multiples of 64, no activation (PPO-full's 128- and 256-wide layers at 262144-row
+// micro-batches).  The 16 x 16 tiles above re-read dY and X once per tile pair — at N = K = 128 eight times the operands
+// through L2, 1 GB per launch at 131072 rows: 189 us.  Here a wave owns a 64 x 64 block of dW for one row slice: lane r of
+// a quarter-wave holds columns 4r .. 4r + 3 of the block (sub-tile a = column 4r + a), so ONE 16-byte load of dY and one
+// of X per lane and 4-row step feed 16 MFMAs, and the next 16 rows are in flight while the current 16 multiply.
+// acc[a][t][g] = dW[n0 + 4 (4q + g) + a][k0 + 4r + t].
+constexpr int kBigSteps = 4;     // 4-row MFMA steps per buffer (16 rows)
+__global__ __launch_bounds__(64 * kWavesPerBlock) void lin_bwd_weight_big_kernel(const LinBwdW a) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int item = blockIdx.y, slice = blockIdx.z;
+  const int kgroups = a.K >> 6;
+  const int ng = wave / kgroups, kg = wave - ng * kgroups;
+  if (ng * 64 >= a.N) return;
+  const int n0 = ng * 64, k0 = kg * 64;
+  const float* __restrict__ dY = a.dY[item] + n0 + 4 * r;
+  const float* __restrict__ X = a.X[item] + k0 + 4 * r;
+  const int b_lo = slice * a.rows_per_slice;
+  const int b_hi = min(a.B, b_lo + a.rows_per_slice);
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[i][t] = zero;
+  f32x4 colsum = zero;
+  f32x4 dyA[kBigSteps], xA[kBigSteps], dyB[kBigSteps], xB[kBigSteps];
+  auto load = [&](f32x4* dy, f32x4* x, int bc0) {
+#pragma unroll
+    for (int s = 0; s < kBigSteps; ++s) {
+      const int bb = bc0 + 4 * s + q;
+      const size_t bs = (size_t)(bb < b_hi ? bb : b_lo);
+      dy[s] = *reinterpret_cast<const f32x4*>(dY + bs * a.ldy);
+      x[s] = *reinterpret_cast<const f32x4*>(X + bs * a.ldx);
+    }
+  };
+  auto mul = [&](const f32x4* dy, const f32x4* x, int bc0) {
+#pragma unroll
+    for (int s = 0; s < kBigSteps; ++s) {
+      const f32x4 dz = bc0 + 4 * s + q < b_hi ? dy[s] : zero;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        colsum[i] += dz[i];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(dz[i], x[s][t], acc[i][t]);
+      }
+    }
+  };
+  if (b_lo < b_hi) {
+    int bc0 = b_lo;
+    load(dyA, xA, bc0);
+    while (true) {
+      const int nb = bc0 + 4 * kBigSteps;
+      if (nb < b_hi) load(dyB, xB, nb);
+      mul(dyA, xA, bc0);
+      if (nb >= b_hi) break;
+      const int nb2 = nb + 4 * kBigSteps;
+      if (nb2 < b_hi) load(dyA, xA, nb2);
+      mul(dyB, xB, nb);
+      if (nb2 >= b_hi) break;
+      bc0 = nb2;
+    }
+  }
+  // bias gradient: the four row groups' serial sums, added pairwise (q0 + q1) + (q2 + q3)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    colsum[i] += __shfl_xor(colsum[i], 16, 64);
+    colsum[i] += __shfl_xor(colsum[i], 32, 64);
+  }
+  const size_t wk = (size_t)a.N * a.K;
+  float* __restrict__ dW = a.dW[item];
+  float* __restrict__ db = a.db[item];
+  float* part = a.slices > 1 ? a.partial + ((size_t)item * a.slices + slice) * (wk + a.N) : nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const size_t o = (size_t)(n0 + 4 * (4 * q + g) + i) * a.K + k0 + 4 * r;
+      f32x4 v = {acc[i][0][g], acc[i][1][g], acc[i][2][g], acc[i][3][g]};
+      if (part) *reinterpret_cast<f32x4*>(part + o) = v;
+      else {
+        if (a.accumulate) {
+          const f32x4 old = *reinterpret_cast<const f32x4*>(dW + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += old[e];
+        }
+        *reinterpret_cast<f32x4*>(dW + o) = v;
+      }
+    }
+  if (kg == 0 && q == 0) {
+    if (part) *reinterpret_cast<f32x4*>(part + wk + n0 + 4 * r) = colsum;
+    else if (db) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) db[n0 + 4 * r + e] = a.accumulate ? db[n0 + 4 * r + e] + colsum[e] : colsum[e];
+    }
+  }
+}
+
+// dW / db = the slices' partials added in a fixed order: eight groups of consecutive slices, each ascending, then the groups ascending
 __global__ __launch_bounds__(256) void lin_slice_reduce_kernel(const LinBwdW a) {
-  const int item = blockIdx.y;
+  __shared__ float grp[8][32];
+  const int item = blockIdx.y, col = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const size_t wk = (size_t)a.N * a.K, per = wk + a.N;
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= per) return;
-  const float* p = a.partial + (size_t)item * a.slices * per + i;
-  float s = p[0];
-  for (int k = 1; k < a.slices; ++k) s += p[(size_t)k * per];
+  const size_t i = (size_t)blockIdx.x * 32 + col;
+  float s = 0.0f;
+  if (i < per) {
+    const int each = (a.slices + 7) / 8;
+    const int k0 = sl * each, k1 = min(a.slices, k0 + each);
+    const float* p = a.partial + (size_t)item * a.slices * per + i;
+    for (int k = k0; k < k1; ++k) s += p[(size_t)k * per];
+  }
+  grp[sl][col] = s;
+  __syncthreads();
+  if (sl != 0 || i >= per) return;
+#pragma unroll
+  for (int k = 1; k < 8; ++k) s += grp[k][col];
   float* dst = i < wk ? a.dW[item] + i : (a.db[item] ? a.db[item] + (i - wk) : nullptr);
   if (dst) *dst = a.accumulate ? *dst + s : s;
 }
@@ -533,8 +641,15 @@ inline int pick_nt(int row_tiles, int cols) { return (cols > 16 && (int64_t)row_
 // row slices of the weight gradient: enough (tile, slice) waves to fill the chip — a skinny layer has few output tiles, so
 // at 262144 rows its reduction is cut 128 ways (16 slices left 256 waves walking 16384 rows each: 440 us) — and never
 // fewer than 256 rows per slice
+inline bool big_shape(int B, int N, int K) { return B >= 16384 && N % 64 == 0 && K % 64 == 0; }
 inline int slices_for(int B, int N, int K) {
   if (B <= 512) return 1;
+  if (big_shape(B, N, K)) {      // 64 x 64 blocks: ~2048 waves, never fewer than 256 rows per slice
+    int s = cdiv(2048, (N / 64) * (K / 64));
+    if (s > 512) s = 512;
+    const int by_rows = cdiv(B, 256);
+    return s < by_rows ? s : by_rows;
+  }
   const int tiles = cdiv(N, 16) * cdiv(K, 16);
   int s = cdiv(2048, tiles);
   if (s < 16) s = 16;
@@ -641,19 +756,32 @@ int gymrl_lin_bwd_weight(const gymrl_lin_item* items, int n_items, int B, int N,
   a.B = B; a.N = N; a.K = K; a.K1 = K1; a.ldy = ldy; a.ldx = ldx; a.ldx2 = ldx2;
   a.accumulate = accumulate;
   a.slices = slices_for(B, N, K);
-  a.rows_per_slice = cdiv(cdiv(B, a.slices), 16) * 16;
+  a.rows_per_slice = cdiv(cdiv(B, a.slices), 32) * 32;
   if (a.slices > 1 && !workspace) return -22;
   a.partial = static_cast<float*>(workspace);
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  bool big = big_shape(B, N, K) && K1 == K && ldy % 4 == 0 && ldx % 4 == 0;
+  for (int i = 0; i < n_items; ++i)
+    big = big && items[i].act == GYMRL_ACT_NONE && aligned16(items[i].dy) && aligned16(items[i].x) && aligned16(items[i].dw);
+  if (big) {
+    const dim3 grid(cdiv((N / 64) * (K / 64), kWavesPerBlock), n_items, a.slices), block(64 * kWavesPerBlock);
+    hipLaunchKernelGGL(lin_bwd_weight_big_kernel, grid, block, 0, s, a);
+    if (a.slices > 1) {
+      const size_t per = (size_t)N * K + N;
+      hipLaunchKernelGGL(lin_slice_reduce_kernel, dim3((unsigned)((per + 31) / 32), n_items), dim3(256), 0, s, a);
+    }
+    GYMRL_CHECK_LAUNCH();
+    return 0;
+  }
   const int n_tiles = cdiv(N, 16);
   const int nt = (int64_t)n_tiles * cdiv(K, 16) * a.slices > 4096 ? 4 : 1;
   a.col_groups = cdiv(K, 16 * nt);
   const dim3 grid(cdiv(n_tiles * a.col_groups, kWavesPerBlock), n_items, a.slices), block(64 * kWavesPerBlock);
-  hipStream_t s = static_cast<hipStream_t>(stream_);
   if (nt == 4) hipLaunchKernelGGL((lin_bwd_weight_kernel<4>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((lin_bwd_weight_kernel<1>), grid, block, 0, s, a);
   if (a.slices > 1) {
     const size_t per = (size_t)N * K + N;
-    hipLaunchKernelGGL(lin_slice_reduce_kernel, dim3((unsigned)((per + 255) / 256), n_items), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(lin_slice_reduce_kernel, dim3((unsigned)((per + 31) / 32), n_items), dim3(256), 0, s, a);
   }
   GYMRL_CHECK_LAUNCH();
   return 0;

@@ -22,7 +22,6 @@ namespace {
 using namespace gymrl;
 
 constexpr int kWaves = 4;
-constexpr int kMaxN = 4;                         // branches (mhc_rate)
 
 struct GatesArgs {
   const float* h; const float* norm_w; const float* w; const float* alpha; const float* beta;
@@ -624,6 +623,37 @@ __global__ __launch_bounds__(64 * kWaves) void rmsnorm_kernel(const float* __res
   }
 }
 
+// the same with the row in registers (D <= 64 Q): one read of x, SiLU evaluated once
+template <int Q>
+__global__ __launch_bounds__(64 * kWaves) void rmsnorm_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 int B, int D, int n_sum, float eps, int silu, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float* xr = x + (size_t)row * n_sum * D;
+  float sv[Q], sq = 0.0f;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int d = lane + 64 * q;
+    float s = 0.0f;
+    if (d < D) {
+      s = xr[d];
+      for (int k = 1; k < n_sum; ++k) s += xr[k * D + d];
+      if (silu) s = silu_(s);
+    }
+    sv[q] = s;
+    sq += s * s;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+  const float r = rsqrtf(sq / (float)D + eps);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int d = lane + 64 * q;
+    if (d < D) y[(size_t)row * D + d] = sv[q] * r * w[d];
+  }
+}
+
 // backward of y = s r w, s = x or SiLU(x), r = rsqrt(mean(s^2) + eps), one wave per row (D <= 512, lane l holds columns l + 64 q):
 //   d s = r (w g) - s r^3 / D sum_d(w g s);  d x = d s [SiLU'(x)];  d w[d] = sum over rows g s r — per-lane column sums over the rows
 // the wave visits, added across the workgroup's waves through LDS, one partial vector per workgroup for partial_reduce_kernel.
@@ -804,8 +834,13 @@ int gymrl_sinkhorn(const float* A, int B, int n, int sk_it, float* u_out, float*
 int gymrl_rmsnorm(const float* x, const float* w, int B, int D, int n_sum, float eps, int act, float* y, void* stream) {
   if (!x || !w || !y || B < 0 || D < 1 || n_sum < 1 || (act != GYMRL_ACT_NONE && act != GYMRL_ACT_SILU)) return -22;
   if (B == 0) return 0;
-  hipLaunchKernelGGL(rmsnorm_kernel, dim3((B + kWaves - 1) / kWaves), dim3(64 * kWaves), 0, (hipStream_t)stream, x, w, B, D, n_sum,
-                     eps, act == GYMRL_ACT_SILU, y);
+  const dim3 grid((B + kWaves - 1) / kWaves), block(64 * kWaves);
+  const int silu = act == GYMRL_ACT_SILU;
+  hipStream_t s = (hipStream_t)stream;
+  if (D <= 128) hipLaunchKernelGGL(rmsnorm_reg_kernel<2>, grid, block, 0, s, x, w, B, D, n_sum, eps, silu, y);
+  else if (D <= 256) hipLaunchKernelGGL(rmsnorm_reg_kernel<4>, grid, block, 0, s, x, w, B, D, n_sum, eps, silu, y);
+  else if (D <= 512) hipLaunchKernelGGL(rmsnorm_reg_kernel<8>, grid, block, 0, s, x, w, B, D, n_sum, eps, silu, y);
+  else hipLaunchKernelGGL(rmsnorm_kernel, grid, block, 0, s, x, w, B, D, n_sum, eps, silu, y);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

@@ -58,7 +58,6 @@ def small_linear(x, weight, bias):
 
 FUSED_LINEAR = True    # tools/micro_offpolicy.py flips this for its A/B (False: library GEMM + elementwise launches)
 _FUSED_MAX_ROWS = 16384
-_FUSED_ANY_ROWS_WIDTH = 128      # layers up to this wide take the layer kernels at any row count (PPO-full's 128 x 128 Linears)
 
 
 class _FusedLinear(torch.autograd.Function):
@@ -156,7 +155,47 @@ def _fusable(x, weight):
     a [262144, 256] x [256, 8] product with a 256 x 16 macro tile in 3.6 ms (PPO-full's gate read-outs and heads: 78 % of its
     update, `profiles/r02_ppo_full_kernel_stats.csv`), where the operands' 268 MB are 60 us of HBM time."""
     return (FUSED_LINEAR and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32
-            and x.shape[0] > 0 and (x.shape[0] <= _FUSED_MAX_ROWS or min(weight.shape) <= 16 or max(weight.shape) <= _FUSED_ANY_ROWS_WIDTH))
+            and x.shape[0] > 0 and (x.shape[0] <= _FUSED_MAX_ROWS or min(weight.shape) <= 16))
+
+
+def _wide(x, weight):
+    """Layers too wide for the layer kernels at >= 16384 rows whose weight gradient gymrl_lin_bwd_weight's 64 x 64-block
+    kernel takes (rows >= 16384, both widths multiples of 64)."""
+    return (FUSED_LINEAR and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and x.shape[0] >= 16384 and weight.shape[0] % 64 == 0 and weight.shape[1] % 64 == 0)
+
+
+class _WideLinear(torch.autograd.Function):
+    """A Linear layer beyond `_fusable` at a large batch (PPO-full's 128 -> 256 head layers at 262144-row micro-batches):
+    forward and input gradient stay with the library GEMM (97 / 96 us at 262144 x 128 x 128, where the one-wave-per-tile
+    layer kernels need 250: `profiles/r02_micro_lin_large.json`); the weight + bias gradient — a [N, B] x [B, K] product
+    the library answers with a 32 x 32 x 256 macro tile in 491 us plus a column-sum launch — is one gymrl_lin_bwd_weight
+    call (64 x 64 blocks per wave: 110 us), written straight into an armed GradSink's buffer."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        ctx.sinks = (getattr(w, "_gymrl_sink", None), None if b is None else getattr(b, "_gymrl_sink", None))
+        return F.linear(x, w, b)                     # bias in the GEMM's epilogue: a separate add is a 270 MB pass at 262144 rows
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.mm(dy, w) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            slot = GradSink_direct(ctx.sinks[0], ctx.sinks[1], ctx.has_bias)
+            if slot is not None:
+                ops.lin_bwd_weight(dy, None, x, slot[0], slot[1], accumulate=slot[2])
+            else:
+                dw = torch.empty_like(w)
+                db = torch.empty(w.shape[0], dtype=w.dtype, device=w.device) if ctx.has_bias else None
+                ops.lin_bwd_weight(dy, None, x, dw, db)
+        return dx, dw, db
 
 
 def _act_torch(z, act, clamp):
@@ -179,7 +218,11 @@ def fused_linears(layers, xs, x2s=None):
         outs = []
         for i, (layer, x) in enumerate(zip(layers, xs)):
             xin = x if x2s is None else torch.cat([x, x2s[i]], dim=1)
-            outs.append(_act_torch(small_linear(xin, layer.weight, layer.bias), layer.act, layer.clamp))
+            if _wide(xin, layer.weight):
+                z = _WideLinear.apply(xin, layer.weight, layer.bias)
+            else:
+                z = small_linear(xin, layer.weight, layer.bias)
+            outs.append(_act_torch(z, layer.act, layer.clamp))
         return outs
     spec = (n, x2s is not None, tuple(LIN_ACT[l.act] for l in layers), tuple(float(l.clamp[0]) for l in layers),
             tuple(float(l.clamp[1]) for l in layers))

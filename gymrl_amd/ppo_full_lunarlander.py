@@ -172,6 +172,9 @@ class _MhcGates(torch.autograd.Function):
         return d_h, d_nw, d_w, d_alpha, d_beta, None
 
 
+_LIBRARY_ROWS = 16384       # rows from which a 128-wide GEMM is the library's (forward / input gradient only)
+
+
 class _MhcSub(torch.autograd.Function):
     """One hyper-connection sub-block h -> post (x) SiLU(Linear(sum_i pre_i h_i)) + mix h (MHCBlock._sub :160-165 with the gates
     :125-147) as ONE autograd node.  Forward: gymrl_mhc_gates (gates + read-out sums + branch sum), gymrl_lin_fwd, gymrl_mhc_combine
@@ -183,7 +186,9 @@ class _MhcSub(torch.autograd.Function):
     def forward(ctx, h, norm_w, w, alpha, beta, W, b, sk_it):
         h = h.contiguous()
         pre, post, mix, read, stats = ops.mhc_gates(h, norm_w, w, alpha, beta, sk_it, stats=True)
-        z = ops.lin_fwd(read, W, b)
+        # the Linear: the layer kernels below _LIBRARY_ROWS rows (one launch, bias inside), the library GEMM above (97 us at
+        # 262144 x 128 x 128 against 256: profiles/r02_micro_lin_large.json)
+        z = torch.addmm(b, read, W.t()) if h.shape[0] >= _LIBRARY_ROWS else ops.lin_fwd(read, W, b)
         ctx.save_for_backward(h, norm_w, w, alpha, pre, post, mix, stats, read, z, W)
         ctx.sinks = (getattr(W, "_gymrl_sink", None), getattr(b, "_gymrl_sink", None))
         return ops.mhc_combine(post, mix, z, h, act=ops.LIN_ACT["silu"])
@@ -193,7 +198,10 @@ class _MhcSub(torch.autograd.Function):
         h, norm_w, w, alpha, pre, post, mix, stats, read, z, W = ctx.saved_tensors
         g = g.contiguous()
         d_post, d_mix, d_z, _ = ops.mhc_combine_bwd(g, post, mix, z, h, act=ops.LIN_ACT["silu"], want_dh=False)
-        d_read, _ = ops.lin_bwd_input(d_z, z, W)
+        if h.shape[0] >= _LIBRARY_ROWS:
+            d_read = torch.mm(d_z, W)
+        else:
+            d_read, _ = ops.lin_bwd_input(d_z, z, W)
         slot = GradSink_direct(ctx.sinks[0], ctx.sinks[1], True)
         if slot is not None:                         # straight into the flat gradient buffer (gymrl_amd/flat.py GradSink)
             ops.lin_bwd_weight(d_z, z, read, slot[0], slot[1], accumulate=slot[2])

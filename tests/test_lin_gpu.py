@@ -110,7 +110,10 @@ def test_lin_bwd_input(B, K1, K2, N, act):
         _close(acc, ref[:, K1:] + 1.0, scale=float(ref.abs().max()) + 1.0, tol=2e-6)
 
 
-@pytest.mark.parametrize("B,K1,K2,N", SHAPES + [(1024, 256, 0, 256), (700, 4, 2, 33)])
+BIG = [(40013, 128, 0, 128), (16384, 128, 0, 256), (33000, 64, 0, 192)]   # >= 16384 rows, widths % 64: the 64 x 64-block kernel
+
+
+@pytest.mark.parametrize("B,K1,K2,N", SHAPES + [(1024, 256, 0, 256), (700, 4, 2, 33)] + BIG)
 @pytest.mark.parametrize("act", ["none", "relu", "tanh"])
 def test_lin_bwd_weight(B, K1, K2, N, act):
     from gymrl_amd import ops
@@ -245,6 +248,28 @@ def test_noisy_dueling_head_matches_autograd():
         for (name, p), r in zip(net.named_parameters(), ref.parameters()):
             want = torch.zeros_like(r) if r.grad is None else r.grad
             _close(p.grad, want, scale=float(want.abs().max()) + 1e-2, tol=5e-6)
+
+
+def test_wide_linear_at_large_batch_matches_autograd():
+    """SmallLinear(128, 256) at 20000 rows (beyond the layer kernels' forward range): library GEMMs forward / input gradient,
+    gymrl_lin_bwd_weight for the weight + bias gradient (nn._WideLinear) against float64 autograd."""
+    from gymrl_amd.nn import SmallLinear
+    torch.manual_seed(3)
+    layer = SmallLinear(128, 256)
+    ref = torch.nn.Linear(128, 256).double()
+    ref.load_state_dict({k: v.double() for k, v in layer.state_dict().items()})
+    x, g = torch.randn(20000, 128), torch.randn(20000, 256)
+    x64 = x.double().requires_grad_(True)
+    ref(x64).backward(g.double())
+    layer = layer.cuda()
+    xd = x.cuda().requires_grad_(True)
+    y = layer(xd)
+    assert type(y.grad_fn).__name__ == "_WideLinearBackward"
+    y.backward(g.cuda())
+    _close(y.detach(), ref(x64).detach(), tol=5e-6)
+    _close(xd.grad, x64.grad, tol=5e-6)
+    _close(layer.weight.grad, ref.weight.grad, tol=5e-6)
+    _close(layer.bias.grad, ref.bias.grad, tol=5e-6)
 
 
 def test_lin_bwd_weight_is_deterministic():

@@ -130,7 +130,7 @@ def test_gates_backward_matches_autograd(dim, B):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("dim,B", [(128, 2500), (256, 300), (128, 1)])
+@pytest.mark.parametrize("dim,B", [(128, 2500), (256, 300), (128, 1), (128, 16500)])   # >= 16384 rows: library GEMMs inside
 def test_sub_block_node_matches_autograd(dim, B):
     """A whole MHCBlock (two sub-blocks, each ONE autograd node: _MhcSub) against the module's torch expression in float64:
     output, the gradient of h and of every parameter — incl. the read's and the combine's paths into h that
@@ -191,3 +191,14 @@ def test_rmsnorm_node_matches_autograd(dim, B, silu):
     _close(y, y64.detach(), 1e-5)
     _close(xd.grad, x64.grad, 2e-5)
     _close(norm.weight.grad, ref.weight.grad, 2e-5)
+
+
+@pytest.mark.parametrize("dim,silu", [(640, False), (640, True), (64, True)])
+def test_rmsnorm_forward_other_widths(dim, silu):
+    """gymrl_rmsnorm beyond the register-resident widths (D > 512: the two-pass kernel) and below one wave's 64 columns."""
+    from gymrl_amd import ops
+    torch.manual_seed(dim)
+    x, w = torch.randn(33, dim) * 2, torch.rand(dim) + 0.5
+    s = torch.nn.functional.silu(x.double()) if silu else x.double()
+    want = s * torch.rsqrt(s.pow(2).mean(-1, keepdim=True) + 1e-6) * w.double()
+    _close(ops.rmsnorm(x.cuda(), w.cuda(), 1e-6, act=ops.LIN_ACT["silu"] if silu else 0), want, 1e-5)
