@@ -48,6 +48,7 @@ SYMBOLS = [
     "gymrl_mhc_gates", "gymrl_mhc_combine", "gymrl_rmsnorm", "gymrl_sinkhorn",
     "gymrl_mhc_read_fwd", "gymrl_mhc_read_bwd", "gymrl_mhc_combine_bwd",
     "gymrl_mhc_gates_bwd_workspace_bytes", "gymrl_mhc_gates_bwd", "gymrl_rmsnorm_bwd_workspace_bytes", "gymrl_rmsnorm_bwd",
+    "gymrl_mhc_policy_forward",
 ]
 
 
@@ -71,6 +72,24 @@ class NoisyLayer(C.Structure):
                                           "dw_mu", "dw_sigma", "db_mu", "db_sigma")] +
                 [("seed", C.c_uint64), ("counter", C.c_uint64), ("counter_dev", C.c_void_p), ("draw", C.c_int),
                  ("eval", C.c_int), ("n_out", C.c_int)])
+
+
+class MhcSub(C.Structure):
+    """gymrl_mhc_sub (include/gymrl.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("norm_w", "w", "alpha", "beta", "lin_w", "lin_b")]
+
+
+class MhcHead(C.Structure):
+    """gymrl_mhc_head (include/gymrl.h)."""
+    _fields_ = [("w1", C.c_void_p), ("b1", C.c_void_p), ("norm_w", C.c_void_p), ("norm_eps", C.c_float), ("w2", C.c_void_p),
+                ("b2", C.c_void_p)]
+
+
+class MhcPolicy(C.Structure):
+    """gymrl_mhc_policy (include/gymrl.h)."""
+    _fields_ = [("obs_dim", C.c_int), ("n_sub", C.c_int), ("n_act", C.c_int), ("sk_it", C.c_int), ("in_w", C.c_void_p),
+                ("in_b", C.c_void_p), ("sub", MhcSub * 8), ("final_norm_w", C.c_void_p), ("final_norm_eps", C.c_float),
+                ("head", MhcHead * 2)]
 
 
 class PPOCfg(C.Structure):

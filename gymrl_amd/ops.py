@@ -1062,6 +1062,17 @@ def rmsnorm_bwd(g, x, w, eps, act=0):
     return d_x, d_w
 
 
+def mhc_policy(desc, obs, logits_out=None, value_out=None):
+    """gymrl_mhc_policy_forward: PPO-full's whole rollout forward in one launch.  desc: a filled _lib.MhcPolicy (its pointers
+    must stay alive: they are the modules' parameters); obs [B, obs_dim] -> (logits [B, n_act], value [B])."""
+    B = obs.shape[0]
+    logits = torch.empty(B, desc.n_act, device=obs.device) if logits_out is None else logits_out
+    value = torch.empty(B, device=obs.device) if value_out is None else value_out
+    check(lib().gymrl_mhc_policy_forward(C.byref(desc), _ptr(obs, torch.float32), C.c_int(B), _ptr(logits, torch.float32),
+                                         _ptr(value, torch.float32), _stream()), "gymrl_mhc_policy_forward")
+    return logits, value
+
+
 def sinkhorn(A, sk_it):
     """gymrl_sinkhorn: A [B, n, n] -> (u [B, n], v [B, n])."""
     B, n, _ = A.shape

@@ -68,6 +68,7 @@ class Config:
 FUSED_GATES = True          # training pass: the gates as one forward + one backward launch (False: torch ops + gymrl_sinkhorn)
 FUSED_MIXING = True         # training pass: read / combine products as fused forward + backward launches (False: broadcast multiplies)
 FUSED_INFERENCE = True      # rollout forward on the inference kernels (tools A/B; False: the torch modules)
+FUSED_POLICY = True         # rollout forward as ONE launch (gymrl_mhc_policy_forward) when the network has the default shape
 FUSED_SUB = True            # training pass: a whole hyper-connection sub-block as one autograd node (3 launches forward, 7 backward)
 FUSED_NORM = True           # training pass: RMSNorm (+ the SiLU before it) as one launch each way
 
@@ -416,10 +417,67 @@ class ActorCritic(nn.Module):
         ha, hc = ops.rmsnorm(ha, a[2].weight, a[2].eps), ops.rmsnorm(hc, c[2].weight, c[2].eps)
         return ops.lin_fwd(ha, a[3].weight, a[3].bias), ops.lin_fwd(hc, c[3].weight, c[3].bias)
 
+    def _policy_desc(self):
+        """The gymrl_mhc_policy descriptor of this network (None when its shape is not the one-launch kernel's: n = 2 branches
+        of 128, 256-wide heads, <= 16 observations, <= 8 actions, <= 8 sub-blocks), rebuilt when a parameter moved."""
+        bb = self.shared
+        a, c = self.actor.mlp, self.critic.mlp
+        if (not isinstance(bb, MHCBackbone) or bb.rate != 2 or len(a) != 4 or len(c) != 4 or len(bb.layers) > 4
+                or tuple(bb.input_proj.weight.shape) != (128, bb.input_proj.in_features) or bb.input_proj.in_features > 16
+                or tuple(a[0].weight.shape) != (256, 128) or tuple(c[0].weight.shape) != (256, 128) or a[3].out_features > 8
+                or c[3].out_features != 1 or bb.input_proj.bias is None):
+            return None
+        params = [bb.input_proj.weight, bb.input_proj.bias, bb.final_norm.weight]
+        for layer in bb.layers:
+            for fuse, linear in ((layer.mhc1, layer.linear1), (layer.mhc2, layer.linear2)):
+                if linear.bias is None or fuse.nc != 256:
+                    return None
+                params += [fuse.norm.weight, fuse.w, fuse.alpha, fuse.beta, linear.weight, linear.bias]
+        for m in (a, c):
+            if m[0].bias is None or m[3].bias is None:
+                return None
+            params += [m[0].weight, m[0].bias, m[2].weight, m[3].weight, m[3].bias]
+        if any(p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() for p in params):
+            return None
+        key = tuple(p.data_ptr() for p in params)
+        if getattr(self, "_desc_key", None) != key:
+            from ._lib import MhcPolicy
+            d = MhcPolicy()
+            d.obs_dim, d.n_sub, d.n_act = bb.input_proj.in_features, 2 * len(bb.layers), a[3].out_features
+            d.sk_it = bb.layers[0].mhc1.max_sk_it if len(bb.layers) else 0
+            it = iter(key)
+            d.in_w, d.in_b, d.final_norm_w, d.final_norm_eps = next(it), next(it), next(it), bb.final_norm.eps
+            for s in range(d.n_sub):
+                for f in ("norm_w", "w", "alpha", "beta", "lin_w", "lin_b"):
+                    setattr(d.sub[s], f, next(it))
+            for h, m in enumerate((a, c)):
+                for f in ("w1", "b1", "norm_w", "w2", "b2"):
+                    setattr(d.head[h], f, next(it))
+                d.head[h].norm_eps = m[2].eps
+            self._desc, self._desc_key = d, key
+        return self._desc
+
+    @torch.no_grad()
+    def forward_policy(self, x, logits_out=None, value_out=None):
+        """forward(x) without gradients as ONE launch (gymrl_mhc_policy_forward: 16 rows per workgroup through every layer);
+        None when the network is not the shape that kernel is written for (then: forward_fused)."""
+        if not (FUSED_POLICY and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous()):
+            return None
+        d = self._policy_desc()
+        if d is None or any(layer.mhc1.max_sk_it != d.sk_it or layer.mhc2.max_sk_it != d.sk_it for layer in self.shared.layers):
+            return None
+        logits, value = ops.mhc_policy(d, x, logits_out, value_out)
+        return logits, value.view(-1, 1)
+
+    def forward_inference(self, x):
+        """The rollout forward on the hand-written kernels: one launch when the shape allows, else one per layer; None: neither."""
+        out = self.forward_policy(x)
+        return self.forward_fused(x) if out is None else out
+
     @torch.no_grad()
     def get_action(self, x, deterministic=False, seed=0, counter=0, env_id0=0):
         """:395-407 batched -> (action i32[N], logp[N], value[N], entropy[N])."""
-        out = self.forward_fused(x) if FUSED_INFERENCE else None
+        out = self.forward_inference(x) if FUSED_INFERENCE else None
         logits, value = self.forward(x) if out is None else out
         act, logp, ent, val = ops.categorical_sample(logits, value=value.view(-1), seed=seed, counter=counter,
                                                      env_id0=env_id0, deterministic=deterministic)
@@ -427,7 +485,7 @@ class ActorCritic(nn.Module):
 
     @torch.no_grad()
     def get_value(self, x):
-        out = self.forward_fused(x) if FUSED_INFERENCE else None
+        out = self.forward_inference(x) if FUSED_INFERENCE else None
         return (self.forward(x) if out is None else out)[1].view(-1)
 
 
@@ -503,10 +561,13 @@ class PPOTrainer:
             return ops.gae_online(b.rewards[t_prev], b.dones[t_prev], b.values[t_prev], self._gae_run[0], self._gae_ws,
                                   t_prev, b.T, cfg.gamma, cfg.lam_actor, cfg.lam_critic, self._gae_run[1])
         for t in range(b.T):
-            if graphed:                                   # the ~100-launch mHC forward as one graph launch
+            out = self.model.forward_policy(b.states[t]) if FUSED_INFERENCE else None
+            if out is not None:                           # the whole forward is one launch: nothing for a graph to save
+                logits, value = out
+            elif graphed:                                 # the ~20-launch mHC forward as one graph launch
                 logits, value = self._forward_graphed(b.states[t])
             else:
-                out = self.model.forward_fused(b.states[t]) if FUSED_INFERENCE else None
+                out = self.model.forward_inference(b.states[t]) if FUSED_INFERENCE else None
                 logits, value = self.model(b.states[t]) if out is None else out
             ops.categorical_sample(logits, value=value.view(-1), noise_exp=None if noise is None else noise[t],
                                    seed=env.seed, counter=c0 + t, env_id0=env.env_id0,
@@ -530,11 +591,11 @@ class PPOTrainer:
         if self._fwd_graph is None:
             if self._fwd_warm < 2:
                 self._fwd_warm += 1
-                out = self.model.forward_fused(self._fwd_in) if FUSED_INFERENCE else None
+                out = self.model.forward_inference(self._fwd_in) if FUSED_INFERENCE else None
                 return self.model(self._fwd_in) if out is None else out
             self._fwd_graph = torch.cuda.CUDAGraph()
             with gcapture(self._fwd_graph):
-                out = self.model.forward_fused(self._fwd_in) if FUSED_INFERENCE else None
+                out = self.model.forward_inference(self._fwd_in) if FUSED_INFERENCE else None
                 self._fwd_out = self.model(self._fwd_in) if out is None else out
         self._fwd_graph.replay()
         return self._fwd_out

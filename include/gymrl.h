@@ -588,6 +588,39 @@ int gymrl_mhc_read_bwd(const float* g, const float* pre, const float* h, int B, 
 int gymrl_mhc_combine_bwd(const float* g, const float* post, const float* mix, const float* out, const float* h, int B, int n, int D,
                           int act, float* d_post, float* d_mix, float* d_out, float* d_h, void* stream);
 
+/* The whole rollout forward of PPO-full's network (ActorCritic.forward :377-407 as called by get_action / get_value) in ONE
+ * launch, for the reference's default shape: n = 2 branches of D = 128 (mhc_rate, mhc_dim), 256-wide heads
+ * (MLP([128, 256, n_out]) :371-402), obs_dim <= 16, n_act <= 8, n_sub = 2 * mhc_layers <= 8 sub-blocks.  Rows are
+ * independent, so 16 of them travel through every layer inside one workgroup (branch stack in registers, the Linears on
+ * v_mfma_f32_16x16x4_f32).  Pointers are the modules' own parameters (nn.Linear layout [out, in]); logits_out [B, n_act],
+ * value_out [B].  Same values as the per-layer entry points above to 1e-5 (tests/test_mhc_fused_gpu.py). */
+typedef struct {
+  const float* norm_w;   /* fuse.norm.weight [256] */
+  const float* w;        /* fuse.w [256, 8] */
+  const float* alpha;    /* [3] */
+  const float* beta;     /* [8] */
+  const float* lin_w;    /* the sub-block's Linear [128, 128] */
+  const float* lin_b;    /* [128] */
+} gymrl_mhc_sub;
+typedef struct {
+  const float* w1;       /* mlp.0.weight [256, 128] */
+  const float* b1;       /* [256] */
+  const float* norm_w;   /* mlp.2.weight [256] */
+  float norm_eps;
+  const float* w2;       /* mlp.3.weight [n_out, 256] (n_out = n_act for head 0, 1 for head 1) */
+  const float* b2;       /* [n_out] */
+} gymrl_mhc_head;
+typedef struct {
+  int obs_dim, n_sub, n_act, sk_it;
+  const float* in_w;     /* input_proj.weight [128, obs_dim] */
+  const float* in_b;     /* [128] */
+  gymrl_mhc_sub sub[8];
+  const float* final_norm_w;   /* [128] */
+  float final_norm_eps;
+  gymrl_mhc_head head[2];      /* 0 = actor, 1 = critic */
+} gymrl_mhc_policy;
+int gymrl_mhc_policy_forward(const gymrl_mhc_policy* p, const float* obs, int B, float* logits_out, float* value_out, void* stream);
+
 /* ===================================================== MLP update path ===== */
 /*
  * The HBM-bound passes of one ActorCritic minibatch update around the library GEMMs —

@@ -202,3 +202,34 @@ def test_rmsnorm_forward_other_widths(dim, silu):
     s = torch.nn.functional.silu(x.double()) if silu else x.double()
     want = s * torch.rsqrt(s.pow(2).mean(-1, keepdim=True) + 1e-6) * w.double()
     _close(ops.rmsnorm(x.cuda(), w.cuda(), 1e-6, act=ops.LIN_ACT["silu"] if silu else 0), want, 1e-5)
+
+
+@pytest.mark.parametrize("B,layers,obs", [(4096, 2, 8), (1, 2, 8), (37, 1, 8), (1000, 4, 16), (50, 0, 3)])
+def test_one_launch_policy_forward_matches_actor_critic(B, layers, obs):
+    """gymrl_mhc_policy_forward (the whole rollout forward, 16 rows per workgroup) against the float64 modules, and against
+    the per-layer inference kernels it replaces."""
+    from gymrl_amd.ppo_full_lunarlander import ActorCritic, Config
+    cfg = Config()
+    cfg.mhc_layers = layers
+    torch.manual_seed(11 + B)
+    net = ActorCritic(obs, 4, config=cfg)
+    with torch.no_grad():
+        for m in net.modules():
+            if hasattr(m, "w") and hasattr(m, "alpha"):
+                m.w.normal_(0, 0.3)
+                m.alpha.copy_(torch.tensor([0.7, -0.4, 0.9]))
+                m.norm.weight.uniform_(0.5, 1.5)
+        net.actor.mlp[3].weight.normal_(0, 0.1)              # (initialised at std 0.001: make the logits matter)
+    ref = ActorCritic(obs, 4, config=cfg).double()
+    ref.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    x = torch.randn(B, obs)
+    logits64, value64 = ref(x.double())
+    net = net.cuda()
+    out = net.forward_policy(x.cuda())
+    assert out is not None
+    _close(out[0], logits64, 1e-5)
+    _close(out[1], value64, 1e-5)
+    fused = net.forward_fused(x.cuda())
+    _close(out[0], fused[0].double(), 2e-5)
+    _close(out[1], fused[1].double(), 2e-5)
+    assert net.forward_inference(x.cuda())[0].shape == (B, 4)
