@@ -498,6 +498,7 @@ __global__ __launch_bounds__(256) void lin_slice_reduce_kernel(const LinBwdW a) 
     const int each = (a.slices + 7) / 8;
     const int k0 = sl * each, k1 = min(a.slices, k0 + each);
     const float* p = a.partial + (size_t)item * a.slices * per + i;
+#pragma unroll 8
     for (int k = k0; k < k1; ++k) s += p[(size_t)k * per];
   }
   grp[sl][col] = s;

@@ -545,6 +545,7 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(const ReduceArgs a)
     const int per = (a.blocks + 7) / 8;
     const int b0 = sl * per, b1 = b0 + per < a.blocks ? b0 + per : a.blocks;
     const float* p = a.partial + (size_t)y * a.blocks * a.len + i;
+#pragma unroll 8                                           // eight loads in flight (one at a time: 64 us for 512 partials)
     for (int b = b0; b < b1; ++b) s += p[(size_t)b * a.len];
   }
   part[sl][col] = s;
@@ -769,6 +770,14 @@ __global__ __launch_bounds__(256) void mhc_policy_kernel(const PolicyArgs a) {
   }
 
   for (int s = 0; s < a.n_sub; ++s) {
+    // this wave's two weight tiles of the sub-block's Linear: requested now, needed after the gates (their L2 latency hides there)
+    f32x4 wv[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float* wrow = a.lw[s] + (size_t)(16 * (2 * wave + t) + r) * D + 4 * qq;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wv[t][j] = *reinterpret_cast<const f32x4*>(wrow + 16 * j);
+    }
     // gates (:125-147): every lane of a row's 16 ends with the row's nine sums and evaluates the gates itself
     float Hs[G + 1];
 #pragma unroll
@@ -827,18 +836,12 @@ __global__ __launch_bounds__(256) void mhc_policy_kernel(const PolicyArgs a) {
       f32x4 av[8], acc[2] = {zero, zero};
 #pragma unroll
       for (int j = 0; j < 8; ++j) av[j] = *reinterpret_cast<const f32x4*>(&rbuf[r][16 * j + 4 * qq]);
-      const float* __restrict__ W = a.lw[s];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const float* wrow = W + (size_t)(16 * (2 * wave + t) + r) * D + 4 * qq;
-        f32x4 wv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) wv[j] = *reinterpret_cast<const f32x4*>(wrow + 16 * j);
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][e], wv[j][e], acc[t], 0, 0, 0);
-      }
+          for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][e], wv[t][j][e], acc[t], 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int col = 16 * (2 * wave + t) + r;
@@ -864,6 +867,11 @@ __global__ __launch_bounds__(256) void mhc_policy_kernel(const PolicyArgs a) {
     }
   }
 
+  // the heads' first weight tile is requested before the final norm (wave = (head wave / 2, column half wave % 2))
+  const float* __restrict__ W1 = a.h1_w[wave >> 1] + (size_t)(128 * (wave & 1) + r) * D + 4 * qq;
+  f32x4 wA[8], wB[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) wA[j] = *reinterpret_cast<const f32x4*>(W1 + 16 * j);
   // final_norm(h.sum(1)) (:182-183) -> the heads' input rows
   {
     f32x4 sv[2];
@@ -897,14 +905,10 @@ __global__ __launch_bounds__(256) void mhc_policy_kernel(const PolicyArgs a) {
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int o = 0; o < kPolMaxOut; ++o) dot[g][o] = 0.0f;
-    const float* __restrict__ W1 = a.h1_w[hd];
     const float* __restrict__ W2 = a.h2_w[hd];
-    for (int t = 0; t < 8; ++t) {
+    auto tile = [&](const f32x4* wv, int t) {              // one 16-column tile: MFMAs, SiLU, this tile's share of the sums
       const int col = 128 * half + 16 * t + r;             // column of this head's hidden layer
-      const float* wrow = W1 + (size_t)col * D + 4 * qq;
-      f32x4 wv[8], acc = zero;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) wv[j] = *reinterpret_cast<const f32x4*>(wrow + 16 * j);
+      f32x4 acc = zero;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -920,6 +924,16 @@ __global__ __launch_bounds__(256) void mhc_policy_kernel(const PolicyArgs a) {
 #pragma unroll
         for (int o = 0; o < kPolMaxOut; ++o) dot[g][o] += sv * w2[o];
       }
+    };
+    for (int t = 0; t < 8; t += 2) {                       // the next tile's weights are in flight while this one multiplies
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wB[j] = *reinterpret_cast<const f32x4*>(W1 + (size_t)(16 * (t + 1)) * D + 16 * j);
+      tile(wA, t);
+      if (t + 2 < 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wA[j] = *reinterpret_cast<const f32x4*>(W1 + (size_t)(16 * (t + 2)) * D + 16 * j);
+      }
+      tile(wB, t + 1);
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -1031,8 +1045,8 @@ int gymrl_mhc_combine_bwd(const float* g, const float* post, const float* mix, c
 }
 
 static int gates_bwd_blocks(int B) {
-  int blocks = (B + 64 * kWaves - 1) / (64 * kWaves);
-  return blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks);
+  int blocks = (B + 64 * kWaves - 1) / (64 * kWaves);     // 512 = every wave slot of the chip at the kernel's 2 waves per SIMD
+  return blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);
 }
 
 size_t gymrl_mhc_gates_bwd_workspace_bytes(int n, int D) {
