@@ -1,19 +1,19 @@
-// mhc.hip — inference-side pieces of PPO-full's manifold-hyper-connection backbone (rollout forward only).
+// mhc.hip — PPO-full's manifold-hyper-connection backbone: the rollout forward and the pieces of the training pass.
 //
 // ppo_full_lunarlander.py:106-250: every MHCBlock half reads the branch stack h [B, n, D] through per-sample gates —
 // an RMS-fused linear read-out (n*D -> n*n + 2n numbers per row), two sigmoids, an exp and `max_sk_it` Sinkhorn-Knopp
 // sweeps on an n x n matrix — mixes the branches, runs ONE D x D Linear + SiLU on the weighted branch sum and writes
 // the stack back.  Through PyTorch that is ~95 launches per half (each Sinkhorn sweep alone is 6), ~400 per rollout
-// forward at 4096 rows: 3 ms per vector step of pure launch cost, 12 of the 47 s of a config-5 iteration.  For the
-// rollout (no gradients) a half is three launches here:
+// forward at 4096 rows: 3 ms per vector step of pure launch cost, 12 of the 47 s of a config-5 iteration.
 //
-//   gymrl_mhc_gates     h -> pre [B, n], post [B, n], mix [B, n, n] and read [B, D] = sum_i pre_i h_i   (one wave per row)
-//   gymrl_lin_fwd       out = SiLU(read W^T + b)                                                        (csrc/lin.hip)
-//   gymrl_mhc_combine   h'[b, i, :] = post_i out + sum_j mix_ij h[b, j, :]
-//
-// plus gymrl_rmsnorm (optionally over the branch sum: MHCBackbone.final_norm(h.sum(1)), and the RMSNorm of the actor /
-// critic MLPs).  The training pass keeps the torch modules (SURVEY 8a F1 leaves the network to PyTorch-ROCm); these
-// kernels are compared with them at 1e-5 (tests/test_mhc_fused_gpu.py).
+// Rollout (no gradients):
+//   gymrl_mhc_policy_forward   the whole ActorCritic.forward in one launch for the default shape (n = 2, D = 128, 256-wide heads)
+//   per layer, any other shape: gymrl_mhc_gates (gates + read = sum_i pre_i h_i), gymrl_lin_fwd (csrc/lin.hip), gymrl_mhc_combine
+//   (h'[b, i, :] = post_i out + sum_j mix_ij h[b, j, :]), gymrl_rmsnorm (optionally over the branch sum / of SiLU(x))
+// Training pass (autograd nodes in gymrl_amd/ppo_full_lunarlander.py: _MhcSub, _RmsNorm; _MhcGates / _MhcRead / _MhcCombine):
+//   gymrl_mhc_gates (+ stats) / gymrl_mhc_gates_bwd, gymrl_mhc_combine(_bwd) with SiLU on load, gymrl_mhc_read_fwd/_bwd,
+//   gymrl_rmsnorm / gymrl_rmsnorm_bwd, gymrl_sinkhorn; parameter gradients are per-workgroup partial sums added in a fixed order.
+// All floating point, compared with the torch modules in float64 at 1e-5 (gradients 2-3e-5): tests/test_mhc_fused_gpu.py.
 #include "train_device.hpp"
 #include "../../include/gymrl.h"
 
