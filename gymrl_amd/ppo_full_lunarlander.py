@@ -430,7 +430,7 @@ class ActorCritic(nn.Module):
         params = [bb.input_proj.weight, bb.input_proj.bias, bb.final_norm.weight]
         for layer in bb.layers:
             for fuse, linear in ((layer.mhc1, layer.linear1), (layer.mhc2, layer.linear2)):
-                if linear.bias is None or fuse.nc != 256:
+                if linear.bias is None or fuse.nc != 256 or fuse.max_sk_it != bb.layers[0].mhc1.max_sk_it:
                     return None
                 params += [fuse.norm.weight, fuse.w, fuse.alpha, fuse.beta, linear.weight, linear.bias]
         for m in (a, c):
@@ -464,7 +464,7 @@ class ActorCritic(nn.Module):
         if not (FUSED_POLICY and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous()):
             return None
         d = self._policy_desc()
-        if d is None or any(layer.mhc1.max_sk_it != d.sk_it or layer.mhc2.max_sk_it != d.sk_it for layer in self.shared.layers):
+        if d is None:
             return None
         logits, value = ops.mhc_policy(d, x, logits_out, value_out)
         return logits, value.view(-1, 1)
@@ -545,6 +545,7 @@ class PPOTrainer:
         self._agg_ready = False
         self._g_idx, self._g_warm = None, 0          # hipGraph replay of the minibatch body (update_model)
         self._fwd_graph, self._fwd_in, self._fwd_out, self._fwd_warm = None, None, None, 0
+        self._pol_out = None
 
     @torch.no_grad()
     def collect_experience(self):
@@ -560,10 +561,14 @@ class PPOTrainer:
         def online(t_prev):      # fold step t_prev (whose delta needs V_{t_prev + 1}) into its chunk's two affine maps
             return ops.gae_online(b.rewards[t_prev], b.dones[t_prev], b.values[t_prev], self._gae_run[0], self._gae_ws,
                                   t_prev, b.T, cfg.gamma, cfg.lam_actor, cfg.lam_critic, self._gae_run[1])
+        # the whole forward as one launch when the network has the kernel's shape (the parameters do not move during a rollout:
+        # one descriptor, fixed output buffers — nothing for a graph to save)
+        desc = self.model._policy_desc() if (FUSED_INFERENCE and FUSED_POLICY and b.states.is_cuda) else None
+        if desc is not None and self._pol_out is None:
+            self._pol_out = (torch.empty(b.N, desc.n_act, device=b.states.device), torch.empty(b.N, device=b.states.device))
         for t in range(b.T):
-            out = self.model.forward_policy(b.states[t]) if FUSED_INFERENCE else None
-            if out is not None:                           # the whole forward is one launch: nothing for a graph to save
-                logits, value = out
+            if desc is not None:
+                logits, value = ops.mhc_policy(desc, b.states[t], *self._pol_out)
             elif graphed:                                 # the ~20-launch mHC forward as one graph launch
                 logits, value = self._forward_graphed(b.states[t])
             else:
