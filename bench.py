@@ -180,13 +180,37 @@ def main():
         gdist.shutdown()               # always release the other ranks, even if the report fails
 
 
+def _gates_bwd_launch(rows, D, sk_it, dev, reps=5):
+    """Average duration (HIP events on the launch stream) of gymrl_mhc_gates_bwd at `rows` rows of a 2 x D branch stack, and its
+    algorithmic bytes: h, g_out, d_h [rows, 2, D] + d_read [rows, D] + the row's saved sums and gates (9 + 8 + 8 floats)."""
+    from gymrl_amd import ops
+    n = 2
+    h, g = torch.randn(rows, n, D, device=dev), torch.randn(rows, n, D, device=dev)
+    nw, w = torch.rand(n * D, device=dev) + 0.5, torch.randn(n * D, 8, device=dev) * 0.3
+    alpha, beta = torch.tensor([0.7, -0.4, 0.9], device=dev), torch.randn(8, device=dev) * 0.1
+    pre, post, mix, read, stats = ops.mhc_gates(h, nw, w, alpha, beta, sk_it, stats=True)
+    d_pre, d_post, d_mix = torch.randn_like(pre), torch.randn_like(post), torch.randn_like(mix)
+    run = lambda: ops.mhc_gates_bwd(h, nw, w, alpha, pre, post, mix, stats, d_pre, d_post, d_mix, d_read=read, g_out=g)  # noqa: E731
+    run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    per_row = 4 * (3 * n * D + D + 25)
+    return {"s": e0.elapsed_time(e1) * 1e-3 / reps, "rows": rows, "bytes_per_row": per_row, "bytes": per_row * rows}
+
+
 def main_ppo_full(a, rank, world, local_rank):
     """BASELINE.json configs[4]: PPO-full (mHC network, decoupled-lambda GAE, entropy-ratio mask) on LunarLander-v3 at
     4096 envs per GPU with the flat-gradient all-reduce.  One step = one iteration of ppo_full_lunarlander.py:681-700 on
     every rank: collect_experience (T vector steps: mHC forward replayed as a hipGraph, categorical draw + behaviour
     entropy + both GAE chunk maps, LunarLander step), G3 (carry + apply), F0's 4 epochs x 4 minibatches (the reference's
     4096 / 1024 ratio: T*N/4 rows each, accumulated over micro-batches of --micro-batch rows) with the L3 loss kernel,
-    clip + Adam.  The network itself is PyTorch-ROCm library work."""
+    clip + Adam.  The network's rollout forward is one hand-written launch per vector step; its training pass is autograd over the
+    C-ABI's HBM-bound kernels (csrc/mhc.hip, csrc/lin.hip) with the library's GEMMs for the 128-wide forward / input gradients.
+    `roofline` = the largest of those kernels, the gates backward, event-timed at the micro-batch size after the timed region."""
     from gymrl_amd import dist as gdist
     from gymrl_amd.ppo_full_lunarlander import Config, PPOTrainer
     dev = torch.device(f"cuda:{local_rank}")
@@ -237,6 +261,7 @@ def main_ppo_full(a, rank, world, local_rank):
         ph = [sum(e[i].elapsed_time(e[i + 1]) for e in ev_all) / a.steps for i in range(3)]
         gae_s = ph[1] * 1e-3
         mb = T * N // cfg.num_minibatches
+        gates = _gates_bwd_launch(min(cfg.micro_batch, mb), cfg.mhc_dim, cfg.mhc_sk_it, dev) if (cfg.mhc_rate == 2 and cfg.mhc_dim in (128, 256)) else None
         out = {
             "metric": "env-steps/sec at N envs/GPU (PPO-full LunarLander), 1/2/4/8 GPUs + %HBM roofline",
             "value": T * N * world * a.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps,
@@ -247,11 +272,15 @@ def main_ppo_full(a, rank, world, local_rank):
                        "minibatch": mb, "micro_batch": min(cfg.micro_batch, mb),
                        "optimizer_steps_per_iteration": cfg.num_epochs * cfg.num_minibatches,
                        "parallelism": f"dp{world} (env shards + flat-gradient all-reduce)" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK / 1e9,
-                         "kernel": "G3: gymrl_gae_decoupled variant 2 (two carry scans + apply; both chunk maps composed in the rollout)",
-                         "achieved": round(17.0 * T * N / gae_s / 1e9, 1), "frac": round(17.0 * T * N / gae_s / HBM_PEAK, 4),
-                         "traffic": None, "launch_s": gae_s,
-                         "note": "the step is dominated by the mHC network's library kernels (PyTorch-ROCm), not by a hand-written kernel"},
+            "roofline": ({"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK / 1e9,
+                          "kernel": "gymrl_mhc_gates_bwd with the read's and the combine's paths folded in (csrc/mhc.hip): the largest "
+                                    "kernel of the training pass, one launch per hyper-connection sub-block and micro-batch",
+                          "achieved": round(gates["bytes"] / gates["s"] / 1e9, 1), "frac": round(gates["bytes"] / gates["s"] / HBM_PEAK, 4),
+                          "traffic": None, "launch_s": gates["s"], "rows": gates["rows"], "bytes_per_row": gates["bytes_per_row"],
+                          "note": "event-timed after the timed region at the micro-batch size (cold inputs of that size: 0.9 GB)"}
+                         if gates else None),
+            "gae_pass": {"kernel": "G3: gymrl_gae_decoupled variant 2 (two carry scans + apply; both chunk maps composed in the rollout)",
+                         "GBps": round(17.0 * T * N / gae_s / 1e9, 1), "frac": round(17.0 * T * N / gae_s / HBM_PEAK, 4), "launch_s": gae_s},
             "phases": {"rollout_ms": round(ph[0], 1), "gae_ms": round(ph[1], 3), "update_ms": round(ph[2], 1)},
             "train_metrics": {k: float(v) for k, v in (m or {}).items()},
         }
