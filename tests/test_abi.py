@@ -78,6 +78,47 @@ def test_new_entry_points_validate_arguments_without_gpu():
     assert L.gymrl_linear_tanh_smallk(fake, fake, null, i64(0), 8, 64, fake, null) == 0
 
 
+def test_mhc_entry_points_validate_arguments_without_gpu():
+    """PPO-full's mHC kernels: shapes outside what a kernel is written for are -EINVAL before any HIP call."""
+    from gymrl_amd import _lib
+    L = _lib.lib()
+    null, f32 = ctypes.c_void_p(None), ctypes.c_float
+    fake = ctypes.c_void_p(256)                       # never dereferenced: validation fails first
+    gates = lambda n, D, stats: L.gymrl_mhc_gates(fake, fake, fake, fake, fake, 8, n, D, 10, fake, fake, fake, fake, stats, null)  # noqa: E731
+    assert gates(3, 128, null) == -22                  # branches: 2 or 4
+    assert gates(2, 6, null) == -22                    # D % 4
+    assert gates(4, 64, fake) == -22                   # the read-out sums exist for n = 2, n * D in (256, 512) only
+    assert gates(2, 64, fake) == -22
+    assert L.gymrl_mhc_gates(fake, fake, fake, fake, fake, 0, 2, 128, 10, fake, fake, fake, fake, fake, null) == 0   # empty batch
+    assert L.gymrl_mhc_combine(fake, fake, fake, fake, 8, 2, 128, 1, fake, null) == -22          # act: none or SiLU
+    assert L.gymrl_mhc_combine_bwd(fake, fake, fake, fake, fake, 8, 2, 128, 2, fake, fake, fake, null, null) == -22
+    assert L.gymrl_mhc_combine_bwd(fake, fake, fake, fake, fake, 0, 2, 128, 5, fake, fake, fake, null, null) == 0    # d_h may be NULL
+    assert L.gymrl_mhc_read_bwd(fake, fake, fake, 8, 3, 128, fake, null, 0, null) == -22
+    bwd = lambda n, D, stats, ws: L.gymrl_mhc_gates_bwd(fake, fake, fake, fake, fake, fake, fake, stats, fake, fake, fake, null, null,  # noqa: E731
+                                                        8, n, D, fake, fake, fake, fake, fake, ws, null)
+    assert bwd(4, 64, fake, fake) == -22 and bwd(2, 64, fake, fake) == -22 and bwd(2, 128, null, fake) == -22
+    assert bwd(2, 128, fake, null) == -22              # workspace required
+    assert L.gymrl_mhc_gates_bwd_workspace_bytes(2, 128) >= 512 * 2315 * 4
+    assert L.gymrl_mhc_gates_bwd_workspace_bytes(2, 256) >= 2 * 512 * 2315 * 4
+    assert L.gymrl_rmsnorm(fake, fake, 8, 128, 1, f32(1e-6), 3, fake, null) == -22
+    assert L.gymrl_rmsnorm_bwd(fake, fake, fake, 8, 513, f32(1e-6), 0, fake, fake, fake, null) == -22      # D <= 512
+    assert L.gymrl_rmsnorm_bwd(fake, fake, fake, 8, 128, f32(1e-6), 0, fake, fake, null, null) == -22      # workspace required
+    assert L.gymrl_rmsnorm_bwd_workspace_bytes(256) >= 2048 * 256 * 4
+    pol = _lib.MhcPolicy()
+    assert L.gymrl_mhc_policy_forward(null, fake, 8, fake, fake, null) == -22
+    pol.obs_dim, pol.n_sub, pol.n_act, pol.sk_it = 8, 2, 4, 10
+    assert L.gymrl_mhc_policy_forward(ctypes.byref(pol), fake, 8, fake, fake, null) == -22       # NULL parameters
+    pol.in_w = pol.in_b = pol.final_norm_w = 256
+    assert L.gymrl_mhc_policy_forward(ctypes.byref(pol), fake, 8, fake, fake, null) == -22       # NULL sub-block parameters
+    pol.n_sub, pol.obs_dim = 9, 8
+    assert L.gymrl_mhc_policy_forward(ctypes.byref(pol), fake, 8, fake, fake, null) == -22       # more than 8 sub-blocks
+    pol.n_sub, pol.obs_dim = 0, 17
+    assert L.gymrl_mhc_policy_forward(ctypes.byref(pol), fake, 8, fake, fake, null) == -22       # more than 16 observations
+    # the weight gradient's slice count follows the shape (64 x 64 blocks from 16384 rows on): the workspace query says so
+    small, big = L.gymrl_lin_workspace_bytes(8192, 128, 128, 1), L.gymrl_lin_workspace_bytes(262144, 128, 128, 1)
+    assert small == 32 * (128 * 128 + 128) * 4 and big == 512 * (128 * 128 + 128) * 4
+
+
 def test_ops_refuse_cpu_tensors():
     import pytest
     import torch
