@@ -48,7 +48,7 @@ SYMBOLS = [
     "gymrl_mhc_gates", "gymrl_mhc_combine", "gymrl_rmsnorm", "gymrl_sinkhorn",
     "gymrl_mhc_read_fwd", "gymrl_mhc_read_bwd", "gymrl_mhc_combine_bwd",
     "gymrl_mhc_gates_bwd_workspace_bytes", "gymrl_mhc_gates_bwd", "gymrl_rmsnorm_bwd_workspace_bytes", "gymrl_rmsnorm_bwd",
-    "gymrl_mhc_policy_forward",
+    "gymrl_mhc_policy_forward", "gymrl_mhc_sub_forward",
 ]
 
 

@@ -715,6 +715,200 @@ __global__ __launch_bounds__(64 * kWaves) void rmsnorm_bwd_kernel(const float* _
   }
 }
 
+// ---- training pass: a whole sub-block forward in one launch (n = 2, D = 128) ----------------------------------------------
+// gates + Linear + combine of MHCBlock._sub as three launches move 1.34 GB per 262144-row micro-batch (h is read twice, the
+// branch sum and the Linear's output make a round trip each: 120 + 97 + 140 us).  Here a wave carries a 16-row tile through all
+// three: the rows' branch stack is loaded once and stays in registers (mhc_gates2_kernel's layout), the Linear's weights and
+// the gates' read-out weights are staged in LDS ONCE per workgroup (weight-stationary: 256 workgroups x 77 KB instead of 64 KB
+// per tile through L2), the tile's 16 x 128 branch sum / output cross the wave's own LDS tile, and what the backward needs
+// (pre, post, mix, the read-out sums, read, the raw Linear output z) is written on the way: 0.8 GB.  Waves never wait for
+// each other after the staging barrier.
+constexpr int kSubPad = 132, kSubWaves = 8;
+constexpr size_t kSubLdsBytes = sizeof(float) * ((size_t)128 * kSubPad + (size_t)kSubWaves * 16 * kSubPad + 256 * 8 + 256 + 128);
+struct SubFwdArgs {
+  const float* h; const float* norm_w; const float* gw; const float* alpha; const float* beta; const float* lw; const float* lb;
+  float* pre; float* post; float* mix; float* stats; float* read; float* z; float* h_out;
+  int B, sk_it;
+};
+
+__global__ __launch_bounds__(64 * kSubWaves) void mhc_sub_fwd_kernel(const SubFwdArgs a) {
+  constexpr int D = 128, NC = 256, G = 8;
+  extern __shared__ float sub_lds[];
+  float* Wl = sub_lds;                                     // [128][kSubPad]   the Linear's weight, nn.Linear layout
+  float* tiles = Wl + 128 * kSubPad;                       // [kSubWaves][16][kSubPad]
+  float* gwl = tiles + kSubWaves * 16 * kSubPad;           // [256][8]         the gates' read-out weight
+  float* nwl = gwl + 256 * G;                              // [256]            the gates' RMS weight
+  float* bl = nwl + 256;                                   // [128]            the Linear's bias
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 128 * 32; i += 64 * kSubWaves)
+    *reinterpret_cast<f32x4*>(&Wl[(i >> 5) * kSubPad + 4 * (i & 31)]) = *reinterpret_cast<const f32x4*>(a.lw + (size_t)(i >> 5) * D + 4 * (i & 31));
+  for (int i = threadIdx.x; i < 256 * G / 4; i += 64 * kSubWaves)
+    *reinterpret_cast<f32x4*>(&gwl[4 * i]) = *reinterpret_cast<const f32x4*>(a.gw + 4 * i);
+  for (int i = threadIdx.x; i < 256; i += 64 * kSubWaves) nwl[i] = a.norm_w[i];
+  for (int i = threadIdx.x; i < 128; i += 64 * kSubWaves) bl[i] = a.lb[i];
+  __syncthreads();
+  float* tb = tiles + (size_t)wave * 16 * kSubPad;
+  const int sub = lane & 15, grp = lane >> 4, r = sub, qq = grp;
+  const float a0 = a.alpha[0], a1 = a.alpha[1], a2 = a.alpha[2];
+  float be[G];
+#pragma unroll
+  for (int k = 0; k < G; ++k) be[k] = a.beta[k];
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  const int n_tiles = (a.B + 15) >> 4;
+  for (int tile = blockIdx.x * kSubWaves + wave; tile < n_tiles; tile += gridDim.x * kSubWaves) {
+    const int64_t base = (int64_t)tile * 16;
+    // the tile's rows: lane (grp, sub) holds columns 64 q + 4 sub .. + 3 of rows 4 grp + it
+    f32x4 x[4][4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      int64_t row = base + 4 * grp + it;
+      if (row > a.B - 1) row = a.B - 1;
+      const float* hr = a.h + row * NC + 4 * sub;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x[it][q] = *reinterpret_cast<const f32x4*>(hr + 64 * q);
+    }
+    float mine[G + 1];
+#pragma unroll
+    for (int k = 0; k <= G; ++k) mine[k] = 0.0f;
+    {
+      float Hs[4][G + 1];
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int k = 0; k <= G; ++k) Hs[it][k] = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 64 * q + 4 * sub;
+        const f32x4 nw = *reinterpret_cast<const f32x4*>(&nwl[c]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(&gwl[(c + e) * G]);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(&gwl[(c + e) * G + 4]);
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const float xv = x[it][q][e], t = nw[e] * xv;
+            Hs[it][G] += xv * xv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { Hs[it][k] += t * lo[k]; Hs[it][4 + k] += t * hi[k]; }
+          }
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int k = 0; k <= G; ++k) {
+          const float sm = row16_sum(Hs[it][k]);
+          mine[k] = sub == it ? sm : mine[k];
+        }
+    }
+    // one lane per row (sub < 4: row 4 grp + sub): the gates; the other lanes compute on zeros
+    float gt[8];                                           // pre0 pre1 post0 post1 m00 m01 m10 m11
+    {
+      const float r_inv = 1.0f / (sqrtf(mine[G]) / sqrtf((float)NC) + 1e-6f);
+      float A[2][2], u[2] = {1.0f, 1.0f}, v[2] = {1.0f, 1.0f};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        gt[i] = sigmoidf_(r_inv * mine[i] * a0 + be[i]);
+        gt[2 + i] = 2.0f * sigmoidf_(r_inv * mine[2 + i] * a1 + be[2 + i]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) A[i][j] = expf(r_inv * mine[4 + 2 * i + j] * a2 + be[4 + 2 * i + j]);
+      }
+      for (int it = 0; it < a.sk_it; ++it) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) u[i] = 1.0f / (A[i][0] * v[0] + A[i][1] * v[1] + 1e-8f);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) v[j] = 1.0f / (A[0][j] * u[0] + A[1][j] * u[1] + 1e-8f);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) gt[4 + 2 * i + j] = u[i] * A[i][j] * v[j];
+      const int64_t my_row = base + 4 * grp + sub;
+      if (sub < 4 && my_row < a.B) {
+        a.pre[my_row * 2] = gt[0]; a.pre[my_row * 2 + 1] = gt[1];
+        a.post[my_row * 2] = gt[2]; a.post[my_row * 2 + 1] = gt[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a.mix[my_row * 4 + k] = gt[4 + k];
+#pragma unroll
+        for (int k = 0; k <= G; ++k) a.stats[my_row * (G + 1) + k] = mine[k];
+      }
+    }
+    // row (grp, it)'s gates live in lane 16 grp + it; read = pre_0 h_0 + pre_1 h_1 -> the Linear's input tile (LDS) and HBM
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int lr = 4 * grp + it, src = ((lane & 48) + it) << 2;
+      const float p0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(gt[0])));
+      const float p1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(gt[1])));
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        f32x4 rd;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rd[e] = p0 * x[it][q][e] + p1 * x[it][q + 2][e];
+        *reinterpret_cast<f32x4*>(&tb[lr * kSubPad + 64 * q + 4 * sub]) = rd;
+        if (base + lr < a.B) *reinterpret_cast<f32x4*>(a.read + (base + lr) * D + 64 * q + 4 * sub) = rd;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // z = read W^T + b: all eight 16-column tiles, A and B operands from LDS
+    f32x4 acc[8];
+    {
+      f32x4 av[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) av[j] = *reinterpret_cast<const f32x4*>(&tb[r * kSubPad + 16 * j + 4 * qq]);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        acc[t] = zero;
+        const float* wrow = &Wl[(16 * t + r) * kSubPad + 4 * qq];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + 16 * j);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][e], wv[e], acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);                 // one column tile's 32 weight registers at a time
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float bv = bl[16 * t + r];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) tb[(4 * qq + g) * kSubPad + 16 * t + r] = acc[t][g] + bv;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // back in the row view: z out, h'_i = post_i SiLU(z) + mix_i0 h_0 + mix_i1 h_1
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int lr = 4 * grp + it, src = ((lane & 48) + it) << 2;
+      const bool ok = base + lr < a.B;
+      float gr[8];                                         // (the row's post and mix; [0], [1] unused)
+#pragma unroll
+      for (int k = 2; k < 8; ++k) gr[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(gt[k])));
+      f32x4 o[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 zt = *reinterpret_cast<const f32x4*>(&tb[lr * kSubPad + 64 * q + 4 * sub]);
+        if (ok) *reinterpret_cast<f32x4*>(a.z + (base + lr) * D + 64 * q + 4 * sub) = zt;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[q][e] = silu_(zt[e]);
+      }
+      if (ok) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            f32x4 hn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              hn[e] = gr[2 + i] * o[q][e] + (gr[4 + 2 * i] * x[it][q][e] + gr[5 + 2 * i] * x[it][q + 2][e]);
+            *reinterpret_cast<f32x4*>(a.h_out + ((base + lr) * 2 + i) * D + 64 * q + 4 * sub) = hn;
+          }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                       // the next tile's branch sums overwrite this wave's LDS tile
+  }
+}
+
 // ---- the whole rollout forward of PPO-full's network in ONE launch ------------------------------------------------------
 // ActorCritic.forward (:377-407) for n = 2 branches of D = 128 and 256-wide heads: input projection, every hyper-connection
 // sub-block, final_norm(h.sum(1)), both heads (Linear -> SiLU -> RMSNorm -> Linear).  Nothing couples two rows of the batch,
@@ -1116,6 +1310,27 @@ int gymrl_rmsnorm_bwd(const float* g, const float* x, const float* w, int B, int
   else hipLaunchKernelGGL(rmsnorm_bwd_kernel<8>, grid, block, 0, (hipStream_t)stream, g, x, w, B, D, eps, silu, d_x, part);
   ReduceArgs r{part, blocks, D, 1, {D, 0, 0, 0}, {0, 0, 0, 0}, {d_w, nullptr, nullptr, nullptr}};
   hipLaunchKernelGGL(partial_reduce_kernel, dim3((D + 31) / 32, 1), dim3(256), 0, (hipStream_t)stream, r);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_mhc_sub_forward(const float* h, const float* norm_w, const float* w, const float* alpha, const float* beta,
+                          const float* lin_w, const float* lin_b, int B, int n, int D, int sk_it, float* pre_out, float* post_out,
+                          float* mix_out, float* stats_out, float* read_out, float* z_out, float* h_out, void* stream) {
+  if (!h || !norm_w || !w || !alpha || !beta || !lin_w || !lin_b || !pre_out || !post_out || !mix_out || !stats_out || !read_out ||
+      !z_out || !h_out || B < 0 || n != 2 || D != 128 || sk_it < 0)
+    return -22;
+  if (B == 0) return 0;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)mhc_sub_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSubLdsBytes) != hipSuccess)
+      return -1000 - (int)hipGetLastError();
+    attr = true;
+  }
+  SubFwdArgs a{h, norm_w, w, alpha, beta, lin_w, lin_b, pre_out, post_out, mix_out, stats_out, read_out, z_out, h_out, B, sk_it};
+  int blocks = ((B + 15) / 16 + kSubWaves - 1) / kSubWaves;
+  if (blocks > 256) blocks = 256;                          // one workgroup per CU (145 KB of LDS), its waves walk the tiles
+  hipLaunchKernelGGL(mhc_sub_fwd_kernel, dim3(blocks), dim3(64 * kSubWaves), kSubLdsBytes, (hipStream_t)stream, a);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

@@ -1062,6 +1062,21 @@ def rmsnorm_bwd(g, x, w, eps, act=0):
     return d_x, d_w
 
 
+def mhc_sub_forward(h, norm_w, w, alpha, beta, lin_w, lin_b, sk_it):
+    """gymrl_mhc_sub_forward: one hyper-connection sub-block forward (n = 2, D = 128) in one launch ->
+    (pre, post, mix, stats, read, z, h_out)."""
+    B, n, D = h.shape
+    dev = h.device
+    pre, post, mix = torch.empty(B, n, device=dev), torch.empty(B, n, device=dev), torch.empty(B, n, n, device=dev)
+    stats, read, z = torch.empty(B, n * n + 2 * n + 1, device=dev), torch.empty(B, D, device=dev), torch.empty(B, D, device=dev)
+    h_out = torch.empty_like(h)
+    f = torch.float32
+    check(lib().gymrl_mhc_sub_forward(_ptr(h, f), _ptr(norm_w, f), _ptr(w, f), _ptr(alpha, f), _ptr(beta, f), _ptr(lin_w, f),
+                                      _ptr(lin_b, f), C.c_int(B), C.c_int(n), C.c_int(D), C.c_int(sk_it), _ptr(pre), _ptr(post),
+                                      _ptr(mix), _ptr(stats), _ptr(read), _ptr(z), _ptr(h_out), _stream()), "gymrl_mhc_sub_forward")
+    return pre, post, mix, stats, read, z, h_out
+
+
 def mhc_policy(desc, obs, logits_out=None, value_out=None):
     """gymrl_mhc_policy_forward: PPO-full's whole rollout forward in one launch.  desc: a filled _lib.MhcPolicy (its pointers
     must stay alive: they are the modules' parameters); obs [B, obs_dim] -> (logits [B, n_act], value [B])."""

@@ -69,6 +69,7 @@ FUSED_GATES = True          # training pass: the gates as one forward + one back
 FUSED_MIXING = True         # training pass: read / combine products as fused forward + backward launches (False: broadcast multiplies)
 FUSED_INFERENCE = True      # rollout forward on the inference kernels (tools A/B; False: the torch modules)
 FUSED_POLICY = True         # rollout forward as ONE launch (gymrl_mhc_policy_forward) when the network has the default shape
+FUSED_SUB_FORWARD = True    # ... and its forward as ONE launch when D = 128 (False: gates + Linear + combine launches)
 FUSED_SUB = True            # training pass: a whole hyper-connection sub-block as one autograd node (3 launches forward, 7 backward)
 FUSED_NORM = True           # training pass: RMSNorm (+ the SiLU before it) as one launch each way
 
@@ -186,12 +187,16 @@ class _MhcSub(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, norm_w, w, alpha, beta, W, b, sk_it):
         h = h.contiguous()
+        ctx.sinks = (getattr(W, "_gymrl_sink", None), getattr(b, "_gymrl_sink", None))
+        if FUSED_SUB_FORWARD and h.shape[2] == 128:          # gates + Linear + combine in one launch (csrc/mhc.hip mhc_sub_fwd_kernel)
+            pre, post, mix, stats, read, z, h_out = ops.mhc_sub_forward(h, norm_w, w, alpha, beta, W, b, sk_it)
+            ctx.save_for_backward(h, norm_w, w, alpha, pre, post, mix, stats, read, z, W)
+            return h_out
         pre, post, mix, read, stats = ops.mhc_gates(h, norm_w, w, alpha, beta, sk_it, stats=True)
         # the Linear: the layer kernels below _LIBRARY_ROWS rows (one launch, bias inside), the library GEMM above (97 us at
         # 262144 x 128 x 128 against 256: profiles/r02_micro_lin_large.json)
         z = torch.addmm(b, read, W.t()) if h.shape[0] >= _LIBRARY_ROWS else ops.lin_fwd(read, W, b)
         ctx.save_for_backward(h, norm_w, w, alpha, pre, post, mix, stats, read, z, W)
-        ctx.sinks = (getattr(W, "_gymrl_sink", None), getattr(b, "_gymrl_sink", None))
         return ops.mhc_combine(post, mix, z, h, act=ops.LIN_ACT["silu"])
 
     @staticmethod

@@ -588,6 +588,14 @@ int gymrl_mhc_read_bwd(const float* g, const float* pre, const float* h, int B, 
 int gymrl_mhc_combine_bwd(const float* g, const float* post, const float* mix, const float* out, const float* h, int B, int n, int D,
                           int act, float* d_post, float* d_mix, float* d_out, float* d_h, void* stream);
 
+/* Training pass: the forward of one hyper-connection sub-block (MHCBlock._sub :160-165 with the gates :125-147) in ONE launch for
+ * n = 2 branches of D = 128: h [B, 2, 128] -> h_out = post (x) SiLU(z) + mix h with z = read lin_w^T + lin_b, read = sum_i pre_i h_i,
+ * and everything the backward takes: pre_out [B, 2], post_out [B, 2], mix_out [B, 2, 2], stats_out [B, 9] (as gymrl_mhc_gates),
+ * read_out [B, 128], z_out [B, 128].  The same values as gymrl_mhc_gates + gymrl_lin_fwd + gymrl_mhc_combine(GYMRL_ACT_SILU) up to
+ * the order of the Linear's sums; 16-row tiles per wave, the weights staged in LDS once per workgroup. */
+int gymrl_mhc_sub_forward(const float* h, const float* norm_w, const float* w, const float* alpha, const float* beta,
+                          const float* lin_w, const float* lin_b, int B, int n, int D, int sk_it, float* pre_out, float* post_out,
+                          float* mix_out, float* stats_out, float* read_out, float* z_out, float* h_out, void* stream);
 /* The whole rollout forward of PPO-full's network (ActorCritic.forward :377-407 as called by get_action / get_value) in ONE
  * launch, for the reference's default shape: n = 2 branches of D = 128 (mhc_rate, mhc_dim), 256-wide heads
  * (MLP([128, 256, n_out]) :371-402), obs_dim <= 16, n_act <= 8, n_sub = 2 * mhc_layers <= 8 sub-blocks.  Rows are

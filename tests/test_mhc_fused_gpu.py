@@ -130,12 +130,14 @@ def test_gates_backward_matches_autograd(dim, B):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("one_launch", [True, False])
 @pytest.mark.parametrize("dim,B", [(128, 2500), (256, 300), (128, 1), (128, 16500)])   # >= 16384 rows: library GEMMs inside
-def test_sub_block_node_matches_autograd(dim, B):
+def test_sub_block_node_matches_autograd(dim, B, one_launch, monkeypatch):
     """A whole MHCBlock (two sub-blocks, each ONE autograd node: _MhcSub) against the module's torch expression in float64:
     output, the gradient of h and of every parameter — incl. the read's and the combine's paths into h that
     gymrl_mhc_gates_bwd folds in, and the Linear's gradients written by the node itself."""
     import gymrl_amd.ppo_full_lunarlander as pf
+    monkeypatch.setattr(pf, "FUSED_SUB_FORWARD", one_launch)    # gymrl_mhc_sub_forward (D = 128) / the three forward launches
     torch.manual_seed(dim + B)
     block = pf.MHCBlock(dim, 2, 10)
     with torch.no_grad():
@@ -233,3 +235,23 @@ def test_one_launch_policy_forward_matches_actor_critic(B, layers, obs):
     _close(out[0], fused[0].double(), 2e-5)
     _close(out[1], fused[1].double(), 2e-5)
     assert net.forward_inference(x.cuda())[0].shape == (B, 4)
+
+
+@pytest.mark.parametrize("B", [1, 16, 100, 5000, 40000])
+def test_one_launch_sub_block_forward_matches_its_three_launches(B):
+    """gymrl_mhc_sub_forward against gymrl_mhc_gates + gymrl_lin_fwd + gymrl_mhc_combine(SiLU): gates, read-out sums and branch
+    sum bit for bit (same arithmetic), z and h' to the Linear's summation order."""
+    from gymrl_amd import ops
+    torch.manual_seed(B)
+    d = "cuda"
+    h = torch.randn(B, 2, 128, device=d) * 2
+    nw, w = torch.rand(256, device=d) + 0.5, torch.randn(256, 8, device=d) * 0.3
+    alpha, beta = torch.tensor([0.7, -0.4, 0.9], device=d), torch.randn(8, device=d) * 0.1
+    W, b = torch.randn(128, 128, device=d) * 0.1, torch.randn(128, device=d) * 0.1
+    pre, post, mix, stats, read, z, h_out = ops.mhc_sub_forward(h, nw, w, alpha, beta, W, b, 10)
+    pre2, post2, mix2, read2, stats2 = ops.mhc_gates(h, nw, w, alpha, beta, 10, stats=True)
+    for got, want in ((pre, pre2), (post, post2), (mix, mix2), (stats, stats2), (read, read2)):
+        assert torch.equal(got, want)
+    z64 = read.double() @ W.double().t() + b.double()
+    _close(z, z64, 2e-6)
+    _close(h_out, ops.mhc_combine(post, mix, z, h, act=ops.LIN_ACT["silu"]).double(), 1e-6)
