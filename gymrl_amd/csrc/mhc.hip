@@ -755,18 +755,22 @@ __global__ __launch_bounds__(64 * kSubWaves) void mhc_sub_fwd_kernel(const SubFw
   for (int k = 0; k < G; ++k) be[k] = a.beta[k];
   const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
   const int n_tiles = (a.B + 15) >> 4;
-  for (int tile = blockIdx.x * kSubWaves + wave; tile < n_tiles; tile += gridDim.x * kSubWaves) {
-    const int64_t base = (int64_t)tile * 16;
-    // the tile's rows: lane (grp, sub) holds columns 64 q + 4 sub .. + 3 of rows 4 grp + it
-    f32x4 x[4][4];
+  // a tile's rows: lane (grp, sub) holds columns 64 q + 4 sub .. + 3 of rows 4 grp + it
+  auto load_tile = [&](f32x4 (&dst)[4][4], int tile) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      int64_t row = base + 4 * grp + it;
+      int64_t row = (int64_t)tile * 16 + 4 * grp + it;
       if (row > a.B - 1) row = a.B - 1;
       const float* hr = a.h + row * NC + 4 * sub;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) x[it][q] = *reinterpret_cast<const f32x4*>(hr + 64 * q);
+      for (int q = 0; q < 4; ++q) dst[it][q] = *reinterpret_cast<const f32x4*>(hr + 64 * q);
     }
+  };
+  const int tile0 = blockIdx.x * kSubWaves + wave, tstride = gridDim.x * kSubWaves;
+  f32x4 x[4][4], xn[4][4];
+  if (tile0 < n_tiles) load_tile(x, tile0);
+  for (int tile = tile0; tile < n_tiles; tile += tstride) {
+    const int64_t base = (int64_t)tile * 16;
     float mine[G + 1];
 #pragma unroll
     for (int k = 0; k <= G; ++k) mine[k] = 0.0f;
@@ -876,6 +880,9 @@ __global__ __launch_bounds__(64 * kSubWaves) void mhc_sub_fwd_kernel(const SubFw
       for (int g = 0; g < 4; ++g) tb[(4 * qq + g) * kSubPad + 16 * t + r] = acc[t][g] + bv;
     }
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);                     // (not earlier: with the MFMA phase's registers live it would spill)
+    load_tile(xn, min(tile + tstride, n_tiles - 1));       // the next tile's rows travel during this tile's epilogue
+    __builtin_amdgcn_sched_barrier(0);
     // back in the row view: z out, h'_i = post_i SiLU(z) + mix_i0 h_0 + mix_i1 h_1
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -906,6 +913,10 @@ __global__ __launch_bounds__(64 * kSubWaves) void mhc_sub_fwd_kernel(const SubFw
       }
     }
     __builtin_amdgcn_wave_barrier();                       // the next tile's branch sums overwrite this wave's LDS tile
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x[it][q] = xn[it][q];
   }
 }
 

@@ -59,6 +59,9 @@ m = {"gates_fwd": timeit(lambda: ops.mhc_gates(h, nw, w, alpha, beta, 20, stats=
      "combine_bwd": timeit(lambda: ops.mhc_combine_bwd(g, post, mix, z, h, act=silu, want_dh=False)),
      "read_bwd": timeit(lambda: ops.mhc_read_bwd(z, pre, h, want_dh=False)),
      "gates_bwd": timeit(lambda: ops.mhc_gates_bwd(h, nw, w, alpha, pre, post, mix, stats, d_pre, d_post, d_mix, d_read=z, g_out=g))}
+Wl, bl = torch.randn(D, D, device=dev) * 0.1, torch.zeros(D, device=dev)
+m["sub_forward_one_launch"] = timeit(lambda: ops.mhc_sub_forward(h, nw, w, alpha, beta, Wl, bl, 20))
+m["sub_forward_GBps"] = hb * 3.0 / m["sub_forward_one_launch"] * 1e3      # h in; h', read, z out
 m["h_MB"] = hb
 m["gates_fwd_GBps"] = hb * 1.5 / m["gates_fwd"] * 1e3              # h in, read out
 m["gates_bwd_GBps"] = hb * 3.5 / m["gates_bwd"] * 1e3              # h, g, d_read in, d_h out
