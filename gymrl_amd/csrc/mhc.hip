@@ -29,7 +29,17 @@ struct GatesArgs {
   int B, D, sk_it;
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// exp and 1/x on the hardware units (v_exp_f32, v_rcp_f32: 1 ulp each).  The gate arithmetic and the SiLUs are what these kernels
+// issue most — a correctly rounded division is ~12 instructions, libm's expf ~15 — and every result is held to 1e-5 of the
+// float64 modules, not to torch's bits.  exp_: x log2(e) in two pieces, so that the product's rounding (up to |x| 2^-24 relative
+// in the result) is folded back in.
+__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float exp_(float x) {
+  const float t = x * 1.44269504088896341f;
+  const float lo = fmaf(x, 1.44269504088896341f, -t) + x * 1.92596299112661746e-8f;
+  return __builtin_amdgcn_exp2f(t) * (1.0f + lo * 0.693147180559945309f);
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return rcp_(1.0f + exp_(-x)); }
 
 template <int N>
 __global__ __launch_bounds__(64 * kWaves) void mhc_gates_kernel(const GatesArgs a) {
@@ -70,7 +80,7 @@ __global__ __launch_bounds__(64 * kWaves) void mhc_gates_kernel(const GatesArgs 
     post[i] = 2.0f * sigmoidf_(r_inv * Hs[N + i] * a1 + a.beta[N + i]);
     u[i] = 1.0f; v[i] = 1.0f;
 #pragma unroll
-    for (int j = 0; j < N; ++j) A[i][j] = expf(r_inv * Hs[2 * N + i * N + j] * a2 + a.beta[2 * N + i * N + j]);
+    for (int j = 0; j < N; ++j) A[i][j] = exp_(r_inv * Hs[2 * N + i * N + j] * a2 + a.beta[2 * N + i * N + j]);
   }
   for (int it = 0; it < a.sk_it; ++it) {                   // Sinkhorn-Knopp scalings (:141-146)
 #pragma unroll
@@ -78,14 +88,14 @@ __global__ __launch_bounds__(64 * kWaves) void mhc_gates_kernel(const GatesArgs 
       float s = 0.0f;
 #pragma unroll
       for (int j = 0; j < N; ++j) s += A[i][j] * v[j];
-      u[i] = 1.0f / (s + 1e-8f);
+      u[i] = rcp_(s + 1e-8f);
     }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       float s = 0.0f;
 #pragma unroll
       for (int i = 0; i < N; ++i) s += A[i][j] * u[i];
-      v[j] = 1.0f / (s + 1e-8f);
+      v[j] = rcp_(s + 1e-8f);
     }
   }
   if (lane == 0) {
@@ -185,13 +195,13 @@ __global__ __launch_bounds__(64) void mhc_gates2_kernel(const GatesArgs a) {
       post[i] = 2.0f * sigmoidf_(r_inv * mine[N + i] * a1 + a.beta[N + i]);
       u[i] = 1.0f; v[i] = 1.0f;
 #pragma unroll
-      for (int j = 0; j < N; ++j) A[i][j] = expf(r_inv * mine[2 * N + i * N + j] * a2 + a.beta[2 * N + i * N + j]);
+      for (int j = 0; j < N; ++j) A[i][j] = exp_(r_inv * mine[2 * N + i * N + j] * a2 + a.beta[2 * N + i * N + j]);
     }
     for (int it = 0; it < a.sk_it; ++it) {                 // Sinkhorn-Knopp scalings (:141-146)
 #pragma unroll
-      for (int i = 0; i < N; ++i) u[i] = 1.0f / (A[i][0] * v[0] + A[i][1] * v[1] + 1e-8f);
+      for (int i = 0; i < N; ++i) u[i] = rcp_(A[i][0] * v[0] + A[i][1] * v[1] + 1e-8f);
 #pragma unroll
-      for (int j = 0; j < N; ++j) v[j] = 1.0f / (A[0][j] * u[0] + A[1][j] * u[1] + 1e-8f);
+      for (int j = 0; j < N; ++j) v[j] = rcp_(A[0][j] * u[0] + A[1][j] * u[1] + 1e-8f);
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -584,14 +594,14 @@ __global__ __launch_bounds__(256) void sinkhorn_kernel(const float* __restrict__
       float s = 0.0f;
 #pragma unroll
       for (int j = 0; j < N; ++j) s += a[i][j] * v[j];
-      u[i] = 1.0f / (s + 1e-8f);
+      u[i] = rcp_(s + 1e-8f);
     }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       float s = 0.0f;
 #pragma unroll
       for (int i = 0; i < N; ++i) s += a[i][j] * u[i];
-      v[j] = 1.0f / (s + 1e-8f);
+      v[j] = rcp_(s + 1e-8f);
     }
   }
 #pragma unroll
@@ -815,13 +825,13 @@ __global__ __launch_bounds__(64 * kSubWaves) void mhc_sub_fwd_kernel(const SubFw
         gt[i] = sigmoidf_(r_inv * mine[i] * a0 + be[i]);
         gt[2 + i] = 2.0f * sigmoidf_(r_inv * mine[2 + i] * a1 + be[2 + i]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) A[i][j] = expf(r_inv * mine[4 + 2 * i + j] * a2 + be[4 + 2 * i + j]);
+        for (int j = 0; j < 2; ++j) A[i][j] = exp_(r_inv * mine[4 + 2 * i + j] * a2 + be[4 + 2 * i + j]);
       }
       for (int it = 0; it < a.sk_it; ++it) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) u[i] = 1.0f / (A[i][0] * v[0] + A[i][1] * v[1] + 1e-8f);
+        for (int i = 0; i < 2; ++i) u[i] = rcp_(A[i][0] * v[0] + A[i][1] * v[1] + 1e-8f);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) v[j] = 1.0f / (A[0][j] * u[0] + A[1][j] * u[1] + 1e-8f);
+        for (int j = 0; j < 2; ++j) v[j] = rcp_(A[0][j] * u[0] + A[1][j] * u[1] + 1e-8f);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -1014,13 +1024,13 @@ __global__ __launch_bounds__(256) void mhc_policy_kernel(const PolicyArgs a) {
       pre[i] = sigmoidf_(r_inv * Hs[i] * a0 + be[i]);
       post[i] = 2.0f * sigmoidf_(r_inv * Hs[2 + i] * a1 + be[2 + i]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) A[i][j] = expf(r_inv * Hs[4 + 2 * i + j] * a2 + be[4 + 2 * i + j]);
+      for (int j = 0; j < 2; ++j) A[i][j] = exp_(r_inv * Hs[4 + 2 * i + j] * a2 + be[4 + 2 * i + j]);
     }
     for (int it = 0; it < a.sk_it; ++it) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) u[i] = 1.0f / (A[i][0] * v[0] + A[i][1] * v[1] + 1e-8f);
+      for (int i = 0; i < 2; ++i) u[i] = rcp_(A[i][0] * v[0] + A[i][1] * v[1] + 1e-8f);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) v[j] = 1.0f / (A[0][j] * u[0] + A[1][j] * u[1] + 1e-8f);
+      for (int j = 0; j < 2; ++j) v[j] = rcp_(A[0][j] * u[0] + A[1][j] * u[1] + 1e-8f);
     }
     float mix[2][2];
 #pragma unroll
