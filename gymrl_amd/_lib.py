@@ -48,7 +48,7 @@ SYMBOLS = [
     "gymrl_mhc_gates", "gymrl_mhc_combine", "gymrl_rmsnorm", "gymrl_sinkhorn",
     "gymrl_mhc_read_fwd", "gymrl_mhc_read_bwd", "gymrl_mhc_combine_bwd",
     "gymrl_mhc_gates_bwd_workspace_bytes", "gymrl_mhc_gates_bwd", "gymrl_rmsnorm_bwd_workspace_bytes", "gymrl_rmsnorm_bwd",
-    "gymrl_mhc_policy_forward", "gymrl_mhc_sub_forward",
+    "gymrl_mhc_policy_forward", "gymrl_mhc_sub_forward", "gymrl_rollout_lunar_mhc",
 ]
 
 
@@ -122,7 +122,8 @@ class RolloutLunarArgs(C.Structure):
                 ("val", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p), ("ep_ret", C.c_void_p),
                 ("next_value", C.c_void_p), ("noise_exp", C.c_void_p), ("gae_running", C.c_void_p),
                 ("gae_workspace", C.c_void_p), ("gamma", C.c_double), ("lam", C.c_double), ("ep_stats", C.c_void_p),
-                ("wg_ticks", C.c_void_p), ("T", C.c_int), ("t0", C.c_int), ("nsteps", C.c_int)]
+                ("wg_ticks", C.c_void_p), ("T", C.c_int), ("t0", C.c_int), ("nsteps", C.c_int),
+                ("ent", C.c_void_p), ("lam2", C.c_double), ("gae_running2", C.c_void_p)]   # gymrl_rollout_lunar_mhc only
 
 
 class PPOFullCfg(C.Structure):

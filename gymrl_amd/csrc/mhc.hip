@@ -14,12 +14,12 @@
 //   gymrl_mhc_gates (+ stats) / gymrl_mhc_gates_bwd, gymrl_mhc_combine(_bwd) with SiLU on load, gymrl_mhc_read_fwd/_bwd,
 //   gymrl_rmsnorm / gymrl_rmsnorm_bwd, gymrl_sinkhorn; parameter gradients are per-workgroup partial sums added in a fixed order.
 // All floating point, compared with the torch modules in float64 at 1e-5 (gradients 2-3e-5): tests/test_mhc_fused_gpu.py.
-#include "train_device.hpp"
-#include "../../include/gymrl.h"
+#include "mhc_policy_device.hpp"
 
 namespace {
 
 using namespace gymrl;
+using namespace gymrl::mhc;
 
 constexpr int kWaves = 4;
 
@@ -28,18 +28,6 @@ struct GatesArgs {
   float* pre; float* post; float* mix; float* read; float* stats;
   int B, D, sk_it;
 };
-
-// exp and 1/x on the hardware units (v_exp_f32, v_rcp_f32: 1 ulp each).  The gate arithmetic and the SiLUs are what these kernels
-// issue most — a correctly rounded division is ~12 instructions, libm's expf ~15 — and every result is held to 1e-5 of the
-// float64 modules, not to torch's bits.  exp_: x log2(e) in two pieces, so that the product's rounding (up to |x| 2^-24 relative
-// in the result) is folded back in.
-__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float exp_(float x) {
-  const float t = x * 1.44269504088896341f;
-  const float lo = fmaf(x, 1.44269504088896341f, -t) + x * 1.92596299112661746e-8f;
-  return __builtin_amdgcn_exp2f(t) * (1.0f + lo * 0.693147180559945309f);
-}
-__device__ __forceinline__ float sigmoidf_(float x) { return rcp_(1.0f + exp_(-x)); }
 
 template <int N>
 __global__ __launch_bounds__(64 * kWaves) void mhc_gates_kernel(const GatesArgs a) {
@@ -113,16 +101,6 @@ __global__ __launch_bounds__(64 * kWaves) void mhc_gates_kernel(const GatesArgs 
     for (int i = 0; i < N; ++i) s += pre[i] * hr[i * a.D + d];
     a.read[(size_t)row * a.D + d] = s;
   }
-}
-
-// sum over the 16 lanes of a DPP row, every lane ending with the same bits: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror,
-// row_mirror — four v_add_f32_dpp, no LDS traffic (a 64-lane __shfl_xor tree is six ds_bpermute round trips)
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
-  return v;
 }
 
 // The n = 2 gates at nc = 256 * CH columns.  The one-wave-per-row kernel above spends ~1100 of its ~1500 instructions per row on
@@ -233,9 +211,6 @@ __global__ __launch_bounds__(64) void mhc_gates2_kernel(const GatesArgs a) {
     }
   }
 }
-
-__device__ __forceinline__ float silu_(float z) { return z * sigmoidf_(z); }
-__device__ __forceinline__ float silu_grad_(float z) { const float s = sigmoidf_(z); return s * (1.0f + z * (1.0f - s)); }
 
 template <int N>
 __global__ __launch_bounds__(256) void mhc_combine_kernel(const float* __restrict__ post, const float* __restrict__ mix,
@@ -930,255 +905,15 @@ __global__ __launch_bounds__(64 * kSubWaves) void mhc_sub_fwd_kernel(const SubFw
   }
 }
 
-// ---- the whole rollout forward of PPO-full's network in ONE launch ------------------------------------------------------
-// ActorCritic.forward (:377-407) for n = 2 branches of D = 128 and 256-wide heads: input projection, every hyper-connection
-// sub-block, final_norm(h.sum(1)), both heads (Linear -> SiLU -> RMSNorm -> Linear).  Nothing couples two rows of the batch,
-// so a workgroup of four waves carries 16 rows through the network: the branch stack stays in registers from the first
-// layer to the last (lane (row, sub) holds columns 64 q + 4 sub .. + 3 of its row, as in mhc_gates2_kernel), only the
-// 16 x 128 operand of each Linear and its output cross LDS, and the waves split the Linear's column tiles
-// (v_mfma_f32_16x16x4_f32, weights from L2).  As 19 launches the forward is 177 us per 4096-row vector step (each launch
-// 6-14 us of latency: 256 waves on 1024 SIMDs); the per-row work is ~30 us.
-constexpr int kPolMaxSub = 8, kPolMaxOut = 8, kPolPad = 132;
-struct PolicyArgs {
-  const float* obs; float* logits; float* value;
-  const float* in_w; const float* in_b;
-  const float* norm_w[kPolMaxSub]; const float* gw[kPolMaxSub]; const float* alpha[kPolMaxSub]; const float* beta[kPolMaxSub];
-  const float* lw[kPolMaxSub]; const float* lb[kPolMaxSub];
-  const float* fn_w;
-  const float* h1_w[2]; const float* h1_b[2]; const float* hn_w[2]; const float* h2_w[2]; const float* h2_b[2];
-  float fn_eps, hn_eps[2];
-  int B, obs_dim, n_sub, n_act, sk_it;
-};
-
-__global__ __launch_bounds__(256) void mhc_policy_kernel(const PolicyArgs a) {
-  constexpr int D = 128, NC = 256, G = 8, H = 256;
-  __shared__ float rbuf[16][kPolPad];                      // a Linear's input rows (the MFMA A operand)
-  __shared__ float obuf[16][kPolPad];                      // its activated output rows
-  __shared__ float psq[4][16];                             // heads: per wave (head, half) the rows' sums of squares
-  __shared__ float pdot[4][16][kPolMaxOut];                //        and partial output dot products
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane & 15, grp = lane >> 4;              // row view: lane = (row 4 wave + grp, 16-column slot sub)
-  const int r = sub, qq = grp;                             // MFMA view: lane = (row / column r, k-quarter qq)
-  const int lrow = 4 * wave + grp;
-  int64_t row = (int64_t)blockIdx.x * 16 + lrow;
-  if (row > a.B - 1) row = a.B - 1;
-  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-
-  // input projection (:178-181): z = obs W^T + b, both branches start as z
-  f32x4 x[4];
-  {
-    float ob[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) ob[k] = k < a.obs_dim ? a.obs[row * a.obs_dim + k] : 0.0f;
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int c = 64 * q + 4 * sub + e;
-        float z = a.in_b[c];
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if (k < a.obs_dim) z += ob[k] * a.in_w[c * a.obs_dim + k];
-        x[q][e] = z;
-      }
-    x[2] = x[0]; x[3] = x[1];
-  }
-
-  for (int s = 0; s < a.n_sub; ++s) {
-    // this wave's two weight tiles of the sub-block's Linear: requested now, needed after the gates (their L2 latency hides there)
-    f32x4 wv[2][8];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const float* wrow = a.lw[s] + (size_t)(16 * (2 * wave + t) + r) * D + 4 * qq;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) wv[t][j] = *reinterpret_cast<const f32x4*>(wrow + 16 * j);
-    }
-    // gates (:125-147): every lane of a row's 16 ends with the row's nine sums and evaluates the gates itself
-    float Hs[G + 1];
-#pragma unroll
-    for (int k = 0; k <= G; ++k) Hs[k] = 0.0f;
-    const float* __restrict__ nwp = a.norm_w[s];
-    const float* __restrict__ gwp = a.gw[s];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = 64 * q + 4 * sub;
-      const f32x4 nw = *reinterpret_cast<const f32x4*>(nwp + c);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(gwp + (size_t)(c + e) * G);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(gwp + (size_t)(c + e) * G + 4);
-        const float xv = x[q][e], t = nw[e] * xv;
-        Hs[G] += xv * xv;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { Hs[k] += t * lo[k]; Hs[4 + k] += t * hi[k]; }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k <= G; ++k) Hs[k] = row16_sum(Hs[k]);
-    const float r_inv = 1.0f / (sqrtf(Hs[G]) / sqrtf((float)NC) + 1e-6f);
-    const float a0 = a.alpha[s][0], a1 = a.alpha[s][1], a2 = a.alpha[s][2];
-    const float* __restrict__ be = a.beta[s];
-    float pre[2], post[2], A[2][2], u[2] = {1.0f, 1.0f}, v[2] = {1.0f, 1.0f};
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      pre[i] = sigmoidf_(r_inv * Hs[i] * a0 + be[i]);
-      post[i] = 2.0f * sigmoidf_(r_inv * Hs[2 + i] * a1 + be[2 + i]);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) A[i][j] = exp_(r_inv * Hs[4 + 2 * i + j] * a2 + be[4 + 2 * i + j]);
-    }
-    for (int it = 0; it < a.sk_it; ++it) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) u[i] = rcp_(A[i][0] * v[0] + A[i][1] * v[1] + 1e-8f);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) v[j] = rcp_(A[0][j] * u[0] + A[1][j] * u[1] + 1e-8f);
-    }
-    float mix[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) mix[i][j] = u[i] * A[i][j] * v[j];
-    // read = pre_0 h_0 + pre_1 h_1 -> the Linear's input rows
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      f32x4 rd;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) rd[e] = pre[0] * x[q][e] + pre[1] * x[q + 2][e];
-      *reinterpret_cast<f32x4*>(&rbuf[lrow][64 * q + 4 * sub]) = rd;
-    }
-    __syncthreads();
-    // out = SiLU(read W^T + b): this wave's two 16-column tiles
-    {
-      f32x4 av[8], acc[2] = {zero, zero};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) av[j] = *reinterpret_cast<const f32x4*>(&rbuf[r][16 * j + 4 * qq]);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][e], wv[t][j][e], acc[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int col = 16 * (2 * wave + t) + r;
-        const float bv = a.lb[s][col];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) obuf[4 * qq + g][col] = silu_(acc[t][g] + bv);
-      }
-    }
-    __syncthreads();
-    // h'_i = post_i out + mix_i0 h_0 + mix_i1 h_1 (:165), back in the row view
-    {
-      f32x4 o[2], nx[4];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) o[q] = *reinterpret_cast<const f32x4*>(&obuf[lrow][64 * q + 4 * sub]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) nx[2 * i + q][e] = post[i] * o[q][e] + (mix[i][0] * x[q][e] + mix[i][1] * x[q + 2][e]);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) x[q] = nx[q];
-    }
-  }
-
-  // the heads' first weight tile is requested before the final norm (wave = (head wave / 2, column half wave % 2))
-  const float* __restrict__ W1 = a.h1_w[wave >> 1] + (size_t)(128 * (wave & 1) + r) * D + 4 * qq;
-  f32x4 wA[8], wB[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) wA[j] = *reinterpret_cast<const f32x4*>(W1 + 16 * j);
-  // final_norm(h.sum(1)) (:182-183) -> the heads' input rows
-  {
-    f32x4 sv[2];
-    float sq = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { sv[q][e] = x[q][e] + x[q + 2][e]; sq += sv[q][e] * sv[q][e]; }
-    sq = row16_sum(sq);
-    const float rr = rsqrtf(sq / (float)D + a.fn_eps);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(a.fn_w + 64 * q + 4 * sub);
-      f32x4 f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) f[e] = sv[q][e] * rr * w[e];
-      *reinterpret_cast<f32x4*>(&rbuf[lrow][64 * q + 4 * sub]) = f;
-    }
-  }
-  __syncthreads();
-  // heads (:371-402): wave = (head wave / 2, column half wave % 2) of Linear(128, 256) -> SiLU; the RMSNorm's scale is a per-row
-  // factor of the last Linear, so each wave hands over its half's sum of squares and norm-weighted dot products
-  {
-    const int hd = wave >> 1, half = wave & 1;
-    const int n_out = hd == 0 ? a.n_act : 1;
-    f32x4 av[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) av[j] = *reinterpret_cast<const f32x4*>(&rbuf[r][16 * j + 4 * qq]);
-    float sq[4] = {0.0f, 0.0f, 0.0f, 0.0f}, dot[4][kPolMaxOut];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int o = 0; o < kPolMaxOut; ++o) dot[g][o] = 0.0f;
-    const float* __restrict__ W2 = a.h2_w[hd];
-    auto tile = [&](const f32x4* wv, int t) {              // one 16-column tile: MFMAs, SiLU, this tile's share of the sums
-      const int col = 128 * half + 16 * t + r;             // column of this head's hidden layer
-      f32x4 acc = zero;
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][e], wv[j][e], acc, 0, 0, 0);
-      const float bv = a.h1_b[hd][col], nwv = a.hn_w[hd][col];
-      float w2[kPolMaxOut];
-#pragma unroll
-      for (int o = 0; o < kPolMaxOut; ++o) w2[o] = o < n_out ? nwv * W2[(size_t)o * H + col] : 0.0f;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float sv = silu_(acc[g] + bv);
-        sq[g] += sv * sv;
-#pragma unroll
-        for (int o = 0; o < kPolMaxOut; ++o) dot[g][o] += sv * w2[o];
-      }
-    };
-    for (int t = 0; t < 8; t += 2) {                       // the next tile's weights are in flight while this one multiplies
-#pragma unroll
-      for (int j = 0; j < 8; ++j) wB[j] = *reinterpret_cast<const f32x4*>(W1 + (size_t)(16 * (t + 1)) * D + 16 * j);
-      tile(wA, t);
-      if (t + 2 < 8) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) wA[j] = *reinterpret_cast<const f32x4*>(W1 + (size_t)(16 * (t + 2)) * D + 16 * j);
-      }
-      tile(wB, t + 1);
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      sq[g] = row16_sum(sq[g]);
-#pragma unroll
-      for (int o = 0; o < kPolMaxOut; ++o) dot[g][o] = row16_sum(dot[g][o]);
-    }
-    if (r == 0) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        psq[wave][4 * qq + g] = sq[g];
-#pragma unroll
-        for (int o = 0; o < kPolMaxOut; ++o) pdot[wave][4 * qq + g][o] = dot[g][o];
-      }
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 32) {                                  // thread = (head, row)
-    const int hd = threadIdx.x >> 4, lr = threadIdx.x & 15;
-    const int64_t orow = (int64_t)blockIdx.x * 16 + lr;
-    if (orow < a.B) {
-      const float rr = rsqrtf((psq[2 * hd][lr] + psq[2 * hd + 1][lr]) / (float)H + a.hn_eps[hd]);
-      const int n_out = hd == 0 ? a.n_act : 1;
-      for (int o = 0; o < n_out; ++o) {
-        const float y = (pdot[2 * hd][lr][o] + pdot[2 * hd + 1][lr][o]) * rr + a.h2_b[hd][o];
-        if (hd == 0) a.logits[orow * a.n_act + o] = y;
-        else a.value[orow] = y;
-      }
-    }
-  }
+// ---- the whole rollout forward of PPO-full's network in ONE launch: mhc_policy_device.hpp's 16-row tile per workgroup --------
+__global__ __launch_bounds__(256) void mhc_policy_kernel(const PolicyArgs a, const float* __restrict__ obs, int B,
+                                                         float* __restrict__ logits, float* __restrict__ value) {
+  __shared__ PolicyLds L;
+  int64_t row = (int64_t)blockIdx.x * 16 + 4 * (threadIdx.x >> 6) + ((threadIdx.x & 63) >> 4);
+  if (row > B - 1) row = B - 1;
+  const int left = B - (int)blockIdx.x * 16;
+  policy_tile(a, L, obs + row * a.obs_dim, logits + (size_t)blockIdx.x * 16 * a.n_act, a.n_act, value + (size_t)blockIdx.x * 16, 1,
+              left < 16 ? left : 16);
 }
 
 }  // namespace
@@ -1357,24 +1092,11 @@ int gymrl_mhc_sub_forward(const float* h, const float* norm_w, const float* w, c
 }
 
 int gymrl_mhc_policy_forward(const gymrl_mhc_policy* p, const float* obs, int B, float* logits_out, float* value_out, void* stream) {
-  if (!p || !obs || !logits_out || !value_out || B < 0 || p->obs_dim < 1 || p->obs_dim > 16 || p->n_sub < 0 || p->n_sub > kPolMaxSub ||
-      p->n_act < 1 || p->n_act > kPolMaxOut || p->sk_it < 0 || !p->in_w || !p->in_b || !p->final_norm_w)
-    return -22;
+  if (!obs || !logits_out || !value_out || B < 0) return -22;
   PolicyArgs a{};
-  for (int s = 0; s < p->n_sub; ++s) {
-    const gymrl_mhc_sub& sb = p->sub[s];
-    if (!sb.norm_w || !sb.w || !sb.alpha || !sb.beta || !sb.lin_w || !sb.lin_b) return -22;
-    a.norm_w[s] = sb.norm_w; a.gw[s] = sb.w; a.alpha[s] = sb.alpha; a.beta[s] = sb.beta; a.lw[s] = sb.lin_w; a.lb[s] = sb.lin_b;
-  }
-  for (int h = 0; h < 2; ++h) {
-    const gymrl_mhc_head& hd = p->head[h];
-    if (!hd.w1 || !hd.b1 || !hd.norm_w || !hd.w2 || !hd.b2) return -22;
-    a.h1_w[h] = hd.w1; a.h1_b[h] = hd.b1; a.hn_w[h] = hd.norm_w; a.h2_w[h] = hd.w2; a.h2_b[h] = hd.b2; a.hn_eps[h] = hd.norm_eps;
-  }
+  if (const int rc = policy_fill(a, p)) return rc;
   if (B == 0) return 0;
-  a.obs = obs; a.logits = logits_out; a.value = value_out; a.in_w = p->in_w; a.in_b = p->in_b; a.fn_w = p->final_norm_w;
-  a.fn_eps = p->final_norm_eps; a.B = B; a.obs_dim = p->obs_dim; a.n_sub = p->n_sub; a.n_act = p->n_act; a.sk_it = p->sk_it;
-  hipLaunchKernelGGL(mhc_policy_kernel, dim3((B + 15) / 16), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(mhc_policy_kernel, dim3((B + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, obs, B, logits_out, value_out);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

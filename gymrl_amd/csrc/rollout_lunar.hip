@@ -24,6 +24,7 @@
 #include "env_lunar_device.hpp"
 #include "mlp_device.hpp"
 #include "policy_device.hpp"
+#include "mhc_policy_device.hpp"
 
 using namespace gymrl;
 using namespace gymrl::lunar;
@@ -115,6 +116,83 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_kernel(gymrl_rollout_l
   if (a.wg_ticks && tid == 0) a.wg_ticks[2 * blockIdx.x + 1] = wall_clock64();
 }
 
+// The same rollout with PPO-full's mHC network as the policy (ppo_full_lunarlander.py collect_experience :440-505): the
+// forward is mhc_policy_device.hpp's 16-row tile (the workgroup IS that kernel's workgroup), the behaviour policy's entropy is
+// kept (`ent`, the entropy-ratio mask's reference :594), and with `gae_running2` both decoupled-lambda chunk maps are composed
+// (G3: actor then critic, float64 decay factors, as gymrl_categorical_sample's online mode does step by step).
+constexpr int kXStride = 16;
+__global__ __launch_bounds__(kThreads) void rollout_lunar_mhc_kernel(gymrl_rollout_lunar_args a, mhc::PolicyArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];  // (its size keeps one workgroup per CU)
+  __shared__ mhc::PolicyLds L;
+  __shared__ uint32_t lds_words[kLdsWords * kEnvBlock];            // the solver's per-lane columns (wave 0)
+  float* xin = dyn_lds;                                            // [16][kXStride] observations
+  float* head = xin + M::kRows * kXStride;                         // [16][kHeadStride]: logits 0..3, value 4
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int N = a.n_envs, T = a.T;
+  const int m0 = blockIdx.x * M::kRows;
+  const int t_end = a.t0 + a.nsteps;
+  const int role = lane & 3, row = lane >> 2, i = m0 + row;        // wave 0's view: four lanes per env
+  const bool valid = i < N;
+  const int prow = 4 * wave + (lane >> 4);                         // the policy tile's view: this lane's row
+  const LunarState st(a.env_state, N);
+  const Lds slds{lds_words + lane};
+  const bool two = a.gae_running2 != nullptr;
+  const double gl = two ? a.gamma * a.lam : (double)(float)(a.gamma * a.lam);
+  const double gl2 = a.gamma * a.lam2;
+  const size_t chunks = (size_t)((T + kGaeChunk - 1) / kGaeChunk);
+  if (a.wg_ticks && tid == 0) a.wg_ticks[2 * blockIdx.x] = wall_clock64();
+  for (int e = tid; e < M::kRows * kXStride; e += kThreads) xin[e] = 0.0f;
+  __syncthreads();
+  for (int e = tid; e < M::kRows * kObs; e += kThreads) {
+    const int r = e / kObs, c = e - r * kObs;
+    if (m0 + r < N) xin[r * kXStride + c] = a.obs[((size_t)a.t0 * N + m0 + r) * kObs + c];
+  }
+  for (int t = a.t0; t <= t_end; ++t) {
+    const bool tail = t == t_end;                   // only the bootstrap value of the finished rollout is left
+    if (tail && t_end != T) break;
+    __syncthreads();                                // xin of step t is complete (and the previous step's head reads are done)
+    mhc::policy_tile(p, L, xin + prow * kXStride, head, M::kHeadStride, head + kActions, M::kHeadStride, M::kRows);
+    __syncthreads();                                // logits -> head[row][0..3], value -> head[row][4]
+    if (wave == 0) {
+      float z[kActions];
+#pragma unroll
+      for (int k = 0; k < kActions; ++k) z[k] = head[row * M::kHeadStride + k];
+      const float v = head[row * M::kHeadStride + kActions];
+      if (valid && role == 0) {
+        if (a.gae_running && t > 0) {               // V_t completes step t-1's delta
+          const int tp = t - 1;
+          const size_t o = (size_t)tp * N + i;
+          double2* agg = reinterpret_cast<double2*>(a.gae_workspace) + (size_t)(tp / kGaeChunk) * N;
+          const int first = (tp % kGaeChunk) == 0, last = (tp % kGaeChunk) == kGaeChunk - 1 || tp == T - 1;
+          gae_online_compose(a.rew[o], a.done[o], a.val[o], v, a.gamma, gl, first, last, a.gae_running, agg, N, i);
+          if (two) gae_online_compose(a.rew[o], a.done[o], a.val[o], v, a.gamma, gl2, first, last, a.gae_running2, agg + chunks * N, N, i);
+        }
+        if (tail) a.next_value[i] = v;
+      }
+      if (!tail) {
+        float lp, H;
+        const size_t o = (size_t)t * N + (valid ? i : 0);
+        const int act = categorical_pick<kActions>(z, a.noise_exp ? a.noise_exp + o * kActions : nullptr, a.seed,
+                                                   (uint64_t)(a.env_id0 + i), a.counter0 + (uint64_t)t, 0, lp, H);
+        if (valid && role == 0) {
+          a.act[o] = act; a.logp[o] = lp; a.val[o] = v;
+          if (a.ent) a.ent[o] = H;
+        }
+        const StepOut out{a.obs + (size_t)(t + 1) * N * kObs, nullptr, a.rew + (size_t)t * N, nullptr, nullptr,
+                          a.done + (size_t)t * N, a.ep_ret ? a.ep_ret + (size_t)t * N : nullptr, nullptr, a.ep_stats};
+        float o_next[8];
+        lunar_step_quad(st, slds, N, i, role, valid, act, a.seed, a.env_id0, out, o_next);
+        if (valid && role < 2) {                    // next policy input: straight into the forward's LDS tile
+#pragma unroll
+          for (int k = 0; k < 4; ++k) xin[row * kXStride + 4 * role + k] = o_next[4 * role + k];
+        }
+      }
+    }
+    if (tail) break;
+  }
+  if (a.wg_ticks && tid == 0) a.wg_ticks[2 * blockIdx.x + 1] = wall_clock64();
+}
+
 }  // namespace
 
 extern "C" {
@@ -150,6 +228,28 @@ int gymrl_rollout_lunar(const gymrl_rollout_lunar_args* a, const gymrl_mlp_desc*
   }
   const int blocks = (a->n_envs + M::kRows - 1) / M::kRows;
   hipLaunchKernelGGL(rollout_lunar_kernel, dim3(blocks), dim3(kThreads), kDynBytes, (hipStream_t)stream, *a, *policy);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_rollout_lunar_mhc(const gymrl_rollout_lunar_args* a, const gymrl_mhc_policy* policy, void* stream) {
+  if (!a || !policy || !a->env_state || !a->obs || !a->act || !a->logp || !a->val || !a->rew || !a->done ||
+      !a->next_value || a->n_envs <= 0 || a->T <= 0 || a->t0 < 0 || a->nsteps < 0 || a->t0 + a->nsteps > a->T)
+    return -22;
+  if (a->gae_running && !a->gae_workspace) return -22;
+  if (a->gae_running2 && (!a->gae_running || !(a->lam2 > 0.0))) return -22;
+  mhc::PolicyArgs p{};
+  if (const int rc = mhc::policy_fill(p, policy)) return rc;
+  if (p.obs_dim != kObs || p.n_act != kActions) return -22;       // LunarLander: 8 observations, 4 actions
+  if (a->nsteps == 0 && a->t0 != a->T) return 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)rollout_lunar_mhc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDynBytes) != hipSuccess)
+      return -1000 - (int)hipGetLastError();
+    attr_set = true;
+  }
+  const int blocks = (a->n_envs + M::kRows - 1) / M::kRows;
+  hipLaunchKernelGGL(rollout_lunar_mhc_kernel, dim3(blocks), dim3(kThreads), kDynBytes, (hipStream_t)stream, *a, p);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

@@ -36,6 +36,7 @@ class Config:
         self.mhc_rate = 2
         self.mhc_layers = 2
         self.mhc_sk_it = 10
+        self.persistent_rollout = True    # LunarLander + the default network shape: the rollout as one launch (gymrl_rollout_lunar_mhc)
         self.max_train_steps = 5e6
         self.update_freq = 4096            # steps PER ENV per rollout
         self.num_epochs = 4
@@ -571,6 +572,21 @@ class PPOTrainer:
         desc = self.model._policy_desc() if (FUSED_INFERENCE and FUSED_POLICY and b.states.is_cuda) else None
         if desc is not None and self._pol_out is None:
             self._pol_out = (torch.empty(b.N, desc.n_act, device=b.states.device), torch.empty(b.N, device=b.states.device))
+        if (desc is not None and getattr(cfg, "persistent_rollout", True) and isinstance(env, VecEnv)
+                and env.kind == ops.LUNARLANDER and desc.obs_dim == 8 and desc.n_act == 4):
+            # the whole rollout as ONE launch: a workgroup owns 16 envs for all T steps (policy tile, draw, both GAE chunk maps,
+            # Box2D step, slab writes) and never waits for another one — a step costs the mean wave's solver time, not the
+            # slowest wave's of 256 (csrc/rollout_lunar.hip; bit-identical to the loop below)
+            ops.rollout_lunar_mhc(env.state, b.N, env.seed, env.env_id0, c0, b.states, b.actions, b.log_probs, b.values, b.rewards,
+                                  b.dones, b.ep_returns, b.next_value, desc, b.T, 0, b.T, cfg.gamma, cfg.lam_actor,
+                                  ent=b.old_entropies, lam2=cfg.lam_critic, noise_exp=noise,
+                                  gae_running=self._gae_run[0] if fuse_gae else None,
+                                  gae_running2=self._gae_run[1] if fuse_gae else None,
+                                  gae_workspace=self._gae_ws if fuse_gae else None, ep_stats=env.ep_stats)
+            self.step_count += b.T * b.N
+            self.rollout_count += 1
+            self._agg_ready = fuse_gae
+            return
         for t in range(b.T):
             if desc is not None:
                 logits, value = ops.mhc_policy(desc, b.states[t], *self._pol_out)

@@ -443,8 +443,18 @@ typedef struct {
   double* ep_stats;
   unsigned long long* wg_ticks; /* NULL, or u64[2][ceil(N/16)]: start / end of every workgroup in 100 MHz ticks */
   int T, t0, nsteps;
+  /* gymrl_rollout_lunar_mhc only (gymrl_rollout_lunar ignores them): */
+  float* ent;                 /* f32[T][N] or NULL: entropy of the behaviour policy at every step             */
+  double lam2;                /* decoupled-lambda GAE (G3): the critic's lambda, with gae_running2             */
+  double* gae_running2;       /* f64[2][N] or NULL; with it gae_workspace is gymrl_gae_decoupled_workspace_bytes(T, N) */
 } gymrl_rollout_lunar_args;
 int gymrl_rollout_lunar(const gymrl_rollout_lunar_args* args, const gymrl_mlp_desc* policy, void* stream);
+/* The same persistent rollout for PPO-full (ppo_full_lunarlander.py collect_experience :440-505): the policy is the mHC network
+ * (gymrl_mhc_policy, declared with gymrl_mhc_policy_forward below; obs_dim 8, n_act 4), `ent` receives the behaviour policy's
+ * entropy, and with gae_running2 / lam2 both decoupled-lambda chunk maps are composed (the actor's with `lam`, then the critic's).
+ * Bit-identical to the step-by-step sequence gymrl_mhc_policy_forward -> gymrl_categorical_sample(online) -> gymrl_env_step. */
+struct gymrl_mhc_policy_s;
+int gymrl_rollout_lunar_mhc(const gymrl_rollout_lunar_args* args, const struct gymrl_mhc_policy_s* policy, void* stream);
 
 /* ================================================ low-latency Linear layers == */
 /*
@@ -618,7 +628,7 @@ typedef struct {
   const float* w2;       /* mlp.3.weight [n_out, 256] (n_out = n_act for head 0, 1 for head 1) */
   const float* b2;       /* [n_out] */
 } gymrl_mhc_head;
-typedef struct {
+typedef struct gymrl_mhc_policy_s {
   int obs_dim, n_sub, n_act, sk_it;
   const float* in_w;     /* input_proj.weight [128, obs_dim] */
   const float* in_b;     /* [128] */

@@ -90,3 +90,36 @@ def test_ppo_full_at_config5_per_gpu_size():
     assert torch.equal(a.flat_params, b.flat_params) and a.optimizer.step_count == 16
     perm = a._perm.long()
     assert torch.equal(torch.sort(perm).values, torch.arange(4096 * 4, device=perm.device))
+
+
+@pytest.mark.parametrize("N,T,variant", [(48, 150, 1), (37, 40, 1), (64, 33, 0)])
+def test_persistent_rollout_is_bit_identical_to_the_step_loop(N, T, variant):
+    """gymrl_rollout_lunar_mhc (one launch: the mHC policy tile, draw, both decoupled-lambda chunk maps, Box2D step with
+    reset-on-done, slab writes, per workgroup of 16 envs) against the step-by-step loop gymrl_mhc_policy_forward ->
+    gymrl_categorical_sample(online) -> gymrl_env_step: every slab, the bootstrap value, the episode statistics and the
+    advantages / returns bit for bit — incl. a ragged last workgroup (N = 37) and episodes that end inside the rollout."""
+    from gymrl_amd.ppo_full_lunarlander import Config, PPOTrainer
+
+    def run(persistent):
+        cfg = Config()
+        cfg.num_envs, cfg.update_freq, cfg.seed, cfg.persistent_rollout, cfg.gae_variant = N, T, 5, persistent, variant
+        torch.manual_seed(1)
+        tr = PPOTrainer(cfg)
+        with torch.no_grad():
+            tr.model.actor.mlp[3].weight.normal_(0, 0.5)     # (initialised at std 0.001: make the policy matter)
+            for m in tr.model.modules():
+                if hasattr(m, "w") and hasattr(m, "alpha"):
+                    m.w.normal_(0, 0.3)
+        tr.collect_experience()
+        adv, ret = tr.compute_advantages()
+        return tr, adv, ret
+    (a, adv_a, ret_a), (b, adv_b, ret_b) = run(False), run(True)
+    ba, bb = a.buffer, b.buffer
+    assert int(ba.dones.sum()) > 0 or T < 100               # the long case sees episode ends (and inline resets)
+    for k in ("states", "actions", "log_probs", "values", "rewards", "dones", "old_entropies", "next_value"):
+        assert torch.equal(getattr(ba, k), getattr(bb, k)), k
+    done = ba.dones.bool()
+    assert torch.equal(ba.ep_returns[done], bb.ep_returns[done])
+    assert torch.equal(a.env.ep_stats, b.env.ep_stats)
+    assert torch.equal(adv_a, adv_b) and torch.equal(ret_a, ret_b)
+    assert a.step_count == b.step_count and a.rollout_count == b.rollout_count
