@@ -121,6 +121,11 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_kernel(gymrl_rollout_l
 // kept (`ent`, the entropy-ratio mask's reference :594), and with `gae_running2` both decoupled-lambda chunk maps are composed
 // (G3: actor then critic, float64 decay factors, as gymrl_categorical_sample's online mode does step by step).
 constexpr int kXStride = 16;
+// its own function: the tile's ~170 registers and the solver's are allocated separately (inlined, the kernel spilled 396 B per lane)
+__device__ __noinline__ void policy_tile_call(const mhc::PolicyArgs& p, mhc::PolicyLds& L, const float* obs_row, float* head) {
+  mhc::policy_tile(p, L, obs_row, head, M::kHeadStride, head + kActions, M::kHeadStride, M::kRows);
+}
+
 __global__ __launch_bounds__(kThreads) void rollout_lunar_mhc_kernel(gymrl_rollout_lunar_args a, mhc::PolicyArgs p) {
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];  // (its size keeps one workgroup per CU)
   __shared__ mhc::PolicyLds L;
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_mhc_kernel(gymrl_rollo
     const bool tail = t == t_end;                   // only the bootstrap value of the finished rollout is left
     if (tail && t_end != T) break;
     __syncthreads();                                // xin of step t is complete (and the previous step's head reads are done)
-    mhc::policy_tile(p, L, xin + prow * kXStride, head, M::kHeadStride, head + kActions, M::kHeadStride, M::kRows);
+    policy_tile_call(p, L, xin + prow * kXStride, head);
     __syncthreads();                                // logits -> head[row][0..3], value -> head[row][4]
     if (wave == 0) {
       float z[kActions];
