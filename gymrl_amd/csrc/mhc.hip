@@ -614,29 +614,33 @@ template <int Q>
 __global__ __launch_bounds__(64 * kWaves) void rmsnorm_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                  int B, int D, int n_sum, float eps, int silu, float* __restrict__ y) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * kWaves + (threadIdx.x >> 6);
-  if (row >= B) return;
-  const float* xr = x + (size_t)row * n_sum * D;
-  float sv[Q], sq = 0.0f;
+  float wv[Q];                                             // the norm's weight: constants of the launch
 #pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const int d = lane + 64 * q;
-    float s = 0.0f;
-    if (d < D) {
-      s = xr[d];
-      for (int k = 1; k < n_sum; ++k) s += xr[k * D + d];
-      if (silu) s = silu_(s);
+  for (int q = 0; q < Q; ++q) wv[q] = lane + 64 * q < D ? w[lane + 64 * q] : 0.0f;
+  // a wave walks rows (262144 one-row waves cost more in dispatch than in HBM time: 2.8 TB/s)
+  for (int64_t row = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6); row < B; row += (int64_t)gridDim.x * kWaves) {
+    const float* xr = x + (size_t)row * n_sum * D;
+    float sv[Q], sq = 0.0f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int d = lane + 64 * q;
+      float s = 0.0f;
+      if (d < D) {
+        s = xr[d];
+        for (int k = 1; k < n_sum; ++k) s += xr[k * D + d];
+        if (silu) s = silu_(s);
+      }
+      sv[q] = s;
+      sq += s * s;
     }
-    sv[q] = s;
-    sq += s * s;
-  }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
-  const float r = rsqrtf(sq / (float)D + eps);
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    const float r = rsqrtf(sq / (float)D + eps);
 #pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const int d = lane + 64 * q;
-    if (d < D) y[(size_t)row * D + d] = sv[q] * r * w[d];
+    for (int q = 0; q < Q; ++q) {
+      const int d = lane + 64 * q;
+      if (d < D) y[(size_t)row * D + d] = sv[q] * r * wv[q];
+    }
   }
 }
 
@@ -1037,11 +1041,12 @@ int gymrl_rmsnorm(const float* x, const float* w, int B, int D, int n_sum, float
   if (!x || !w || !y || B < 0 || D < 1 || n_sum < 1 || (act != GYMRL_ACT_NONE && act != GYMRL_ACT_SILU)) return -22;
   if (B == 0) return 0;
   const dim3 grid((B + kWaves - 1) / kWaves), block(64 * kWaves);
+  const dim3 walk(grid.x > 4096 ? 4096 : grid.x);          // the register-resident kernels: every wave slot of the chip, rows in a loop
   const int silu = act == GYMRL_ACT_SILU;
   hipStream_t s = (hipStream_t)stream;
-  if (D <= 128) hipLaunchKernelGGL(rmsnorm_reg_kernel<2>, grid, block, 0, s, x, w, B, D, n_sum, eps, silu, y);
-  else if (D <= 256) hipLaunchKernelGGL(rmsnorm_reg_kernel<4>, grid, block, 0, s, x, w, B, D, n_sum, eps, silu, y);
-  else if (D <= 512) hipLaunchKernelGGL(rmsnorm_reg_kernel<8>, grid, block, 0, s, x, w, B, D, n_sum, eps, silu, y);
+  if (D <= 128) hipLaunchKernelGGL(rmsnorm_reg_kernel<2>, walk, block, 0, s, x, w, B, D, n_sum, eps, silu, y);
+  else if (D <= 256) hipLaunchKernelGGL(rmsnorm_reg_kernel<4>, walk, block, 0, s, x, w, B, D, n_sum, eps, silu, y);
+  else if (D <= 512) hipLaunchKernelGGL(rmsnorm_reg_kernel<8>, walk, block, 0, s, x, w, B, D, n_sum, eps, silu, y);
   else hipLaunchKernelGGL(rmsnorm_kernel, grid, block, 0, s, x, w, B, D, n_sum, eps, silu, y);
   GYMRL_CHECK_LAUNCH();
   return 0;
