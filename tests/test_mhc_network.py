@@ -22,3 +22,16 @@ def test_mhc_actor_critic_matches_reference():
     for name, p in net.named_parameters():
         ref = g["grad_" + name]
         assert np.max(np.abs(p.grad.numpy() - ref)) <= 2e-5 * max(1.0, np.abs(ref).max()), name
+
+
+def test_mlp_forward_is_its_sequential_and_the_one_launch_paths_need_a_gpu():
+    """MLP.forward walks its Sequential by hand (so that SiLU can ride in the RMSNorm launches on the GPU): on CPU tensors it is
+    exactly the Sequential; the one-launch descriptor is refused for CPU parameters (there is no CPU fallback to describe)."""
+    from gymrl_amd.ppo_full_lunarlander import MLP, ActorCritic, Config
+    torch.manual_seed(0)
+    for dims, last_act in (([8, 32, 4], False), ([8, 16], True), ([5, 7, 9, 3], False)):
+        mlp = MLP(dims, last_act=last_act)
+        x = torch.randn(11, dims[0])
+        assert torch.equal(mlp(x), mlp.mlp(x))
+    net = ActorCritic(8, 4, config=Config())
+    assert net._policy_desc() is None and net.forward_policy(torch.randn(3, 8)) is None
