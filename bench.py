@@ -82,6 +82,91 @@ def full_pass(trainer, T, N, dev, iters=5):
                 note="one launch per kernel over T*N transitions, cold caches, HIP events per launch")
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without torchrun's environment: re-execute this command line as N ranks of ONE node
+    through torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and return its exit code.  Refuses,
+    loudly and before anything is launched, when the node has fewer than N devices."""
+    import subprocess
+    if a.backend != "gloo":
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            print(f"[bench] FATAL: --gpus {a.gpus} needs {a.gpus} visible MI355X devices, this node has {have}; "
+                  f"refusing to report an n_gpus={a.gpus} line from fewer devices", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL's P2P set-up needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    print(f"[bench] spawning {a.gpus} ranks: {' '.join(cmd[1:8])} ...", file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
+def verify_world(a, world, local_rank):
+    """The process group must be exactly what the command line asked for: `n_gpus` in the JSON line is the size of the
+    communicator RCCL built, never a wish.  Raises SystemExit(2) on every rank otherwise."""
+    import torch.distributed as td
+    got = td.get_world_size() if (td.is_available() and td.is_initialized()) else 1
+    problems = []
+    if got != a.gpus or world != a.gpus:
+        problems.append(f"--gpus {a.gpus} but the process group has {got} ranks (WORLD_SIZE={world})")
+    if a.backend != "gloo":
+        if got > 1 and td.get_backend() != "nccl":
+            problems.append(f"backend is {td.get_backend()}, expected nccl (RCCL)")
+        if torch.cuda.device_count() <= local_rank:
+            problems.append(f"LOCAL_RANK {local_rank} has no device (device_count = {torch.cuda.device_count()})")
+    if problems:
+        print("[bench] FATAL: " + "; ".join(problems), file=sys.stderr)
+        raise SystemExit(2)
+    return got
+
+
+def spawn_selftest(a, rank, world):
+    """--spawn-selftest: the launch + verification path without the workload (CPU-testable with --backend gloo): every
+    rank contributes rank + 1 to an all-reduce, rank 0 prints what the ranks agreed on."""
+    from gymrl_amd import dist as gdist
+    dev = torch.device(f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}") if a.backend != "gloo" else torch.device("cpu")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=dev)
+    gdist.all_reduce_sum(t)
+    devices = gdist.rank_devices()
+    if rank == 0:
+        import torch.distributed as td
+        print(json.dumps({"spawn_selftest": True, "n_gpus": world, "rccl_world_size": world,
+                          "backend": td.get_backend() if world > 1 else None, "sum": float(t.item()),
+                          "expected_sum": world * (world + 1) / 2.0, "rank_devices": devices}))
+        sys.stdout.flush()
+    gdist.shutdown()
+
+
+def comm_summary(world, reducer, ks, step_s, steps):
+    """All-reduce figures of the timed region (SURVEY.md 8(d) "Grad all-reduce" row): the collectives' own durations on the
+    communication stream, and how long the compute stream actually stalled on them."""
+    if world <= 1:
+        return {"rccl_world_size": 1, "grad_allreduce": None, "moments_allreduce": None}
+    out = {"rccl_world_size": world}
+    st = reducer.stats() if reducer is not None else None
+    if st:
+        n = max(st["collectives"], 1)
+        out["grad_allreduce"] = {
+            "collectives_per_step": st["collectives"] / steps, "bucket_bytes": st["bucket_bytes"],
+            "avg_us_per_collective": round(1e6 * st["collective_s"] / n, 2), "per_bucket_us": {k: round(v, 2) for k, v in st["per_bucket_us"].items()},
+            "us_per_step": round(1e6 * st["collective_s"] / steps, 1), "pct_of_step": round(100.0 * st["collective_s"] / steps / step_s, 3),
+            "exposed_us_per_step": round(1e6 * st["stall_s"] / steps, 1), "exposed_pct_of_step": round(100.0 * st["stall_s"] / steps / step_s, 3),
+            "note": "HIP events on the communication stream around every bucket (own duration, incl. the wait for the compute "
+                    "stream's gradient kernels to drain out of the device) / on the compute stream around GradReducer.wait() (exposed)"}
+    if ks and "moments_allreduce" in ks:
+        m = ks["moments_allreduce"]
+        out["moments_allreduce"] = {"us_per_call": round(m["avg_us"], 2), "calls_per_step": m["launches"] / steps, "bytes": 24}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,14 +181,24 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=262144, help="ppo_full: rows per forward/backward pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=24.0)
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="nccl == RCCL (default); gloo only for --spawn-selftest on CPU")
+    ap.add_argument("--spawn-selftest", action="store_true", help="launch + verify the ranks, all-reduce once, print one JSON line; no workload")
     a = ap.parse_args()
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if a.backend == "gloo" and not a.spawn_selftest:
+        ap.error("--backend gloo is only for --spawn-selftest (the benchmark itself runs on RCCL)")
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))            # N ranks re-enter main() with torchrun's environment
 
     from gymrl_amd import dist as gdist
-    rank, world, local_rank = gdist.init_from_env()
+    rank, world, local_rank = gdist.init_from_env(backend=a.backend if a.backend == "gloo" else None)
+    verify_world(a, world, local_rank)
+    if a.spawn_selftest:
+        return spawn_selftest(a, rank, world)
     if a.algo == "ppo_full":
         return main_ppo_full(a, rank, world, local_rank)
-    if world != a.gpus and rank == 0:
-        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
@@ -157,6 +252,7 @@ def main():
     gdist.all_reduce_max(dt_t)
     dt = float(dt_t.item())
     trainer._timers = None
+    devices = gdist.rank_devices()     # collective: every rank's device, as the communicator sees them
 
     if rank != 0:
         gdist.shutdown()               # waits for rank 0's post-processing, then leaves together
@@ -175,7 +271,7 @@ def main():
         frozen_ms = round(e0.elapsed_time(e1), 1)
         trainer.flat_params.copy_(trained)
         trainer.step_count, trainer.rollout_count = sc, rc
-        report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev, frozen_ms)
+        report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev, frozen_ms, devices)
     finally:
         gdist.shutdown()               # always release the other ranks, even if the report fails
 
@@ -244,6 +340,9 @@ def main_ppo_full(a, rank, world, local_rank):
         for _ in range(a.warmup):
             step()
         ev_all.clear()
+        tr._time_collectives = True
+        if tr._reducer is not None:
+            tr._reducer.reset_stats()
         gdist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -256,6 +355,7 @@ def main_ppo_full(a, rank, world, local_rank):
     dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
     gdist.all_reduce_max(dt_t)
     dt = float(dt_t.item())
+    devices = gdist.rank_devices()
     if rank == 0:
         sys.stdout = sys.__stdout__
         ph = [sum(e[i].elapsed_time(e[i + 1]) for e in ev_all) / a.steps for i in range(3)]
@@ -283,13 +383,15 @@ def main_ppo_full(a, rank, world, local_rank):
                          "GBps": round(17.0 * T * N / gae_s / 1e9, 1), "frac": round(17.0 * T * N / gae_s / HBM_PEAK, 4), "launch_s": gae_s},
             "phases": {"rollout_ms": round(ph[0], 1), "gae_ms": round(ph[1], 3), "update_ms": round(ph[2], 1)},
             "train_metrics": {k: float(v) for k, v in (m or {}).items()},
+            "comm": dict(comm_summary(world, tr._reducer, None, dt / a.steps, a.steps), backend="nccl (RCCL)" if world > 1 else None,
+                         rank_devices=devices),
         }
         print(json.dumps(out))
         sys.stdout.flush()
     gdist.shutdown()
 
 
-def report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev, frozen_ms=None):
+def report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev, frozen_ms=None, devices=None):
     ks = timers.summary()
     transitions = T * N
     rollout_s = sum(e[0].elapsed_time(e[1]) for e in phase_events) * 1e-3 / a.steps
@@ -389,6 +491,8 @@ def report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev,
                    "rollout_frozen_policy_ms": frozen_ms},
         "train_metrics": {k: float(v) for k, v in (metrics or {}).items()},
         "avg_episode_return": (sum(trainer.episode_rewards) / len(trainer.episode_rewards)) if trainer.episode_rewards else None,
+        "comm": dict(comm_summary(world, trainer._reducer, ks, dt / a.steps, a.steps), backend="nccl (RCCL)" if world > 1 else None,
+                     rank_devices=devices),
     }
     if world == 1 and not a.no_cpu_baseline:
         from oracle.ref_ppo_cpu import time_cpu_baseline

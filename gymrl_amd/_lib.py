@@ -16,6 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GYMRL_HIP_LIB") or os.path.join(_HERE, "libgymrl_hip.so")   # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
 
+ABI_VERSION = 2      # == GYMRL_ABI_VERSION of the include/gymrl.h this front-end was written against
+
 _lib = None
 
 # every symbol include/gymrl.h declares (tests/test_abi.py checks the export table)
@@ -40,7 +42,7 @@ SYMBOLS = [
     "gymrl_mlp_packed_floats", "gymrl_mlp_pack", "gymrl_mlp_forward",
     "gymrl_mlp_train_workspace_bytes", "gymrl_linear_tanh_smallk", "gymrl_tanh_inplace", "gymrl_tanh_bwd_colsum",
     "gymrl_linear_smallk_bwd", "gymrl_heads_fwd_tanh", "gymrl_heads_bwd", "gymrl_rollout_lunar",
-    "gymrl_gemm_workspace_bytes", "gymrl_gemm_config", "gymrl_linear_fwd", "gymrl_linear_bwd_input",
+    "gymrl_gemm_workspace_bytes", "gymrl_linear_fwd", "gymrl_linear_bwd_input",
     "gymrl_linear_bwd_weight_geometry", "gymrl_linear_bwd_weight",
     "gymrl_heads_loss_blocks", "gymrl_heads_loss_fwd_bwd",
     "gymrl_lin_workspace_bytes", "gymrl_lin_fwd", "gymrl_lin_bwd_input", "gymrl_lin_bwd_weight",
@@ -140,6 +142,11 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (or __graft_entry__.build()). "
                 "gymrl_amd has no CPU fallback.")
         L = C.CDLL(LIB_PATH)
+        L.gymrl_abi_version.restype = C.c_int
+        got = L.gymrl_abi_version()
+        if got != ABI_VERSION:       # a stale .so would take mis-aligned arguments silently
+            raise RuntimeError(f"{LIB_PATH} reports ABI version {got}, this package needs {ABI_VERSION}: rebuild it "
+                               f"with `make -C {CSRC}`")
         L.gymrl_env_state_bytes.restype = C.c_size_t
         L.gymrl_gae_workspace_bytes.restype = C.c_size_t
         L.gymrl_gae_decoupled_workspace_bytes.restype = C.c_size_t

@@ -442,9 +442,13 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// Tuning / diagnostic knobs (gymrl_gemm_config), for tools/micro_gemm.py and tools/abl_gemm.py.
-int g_tn_pf = 8;       // weight gradient: prefetch ring depth in row pairs (4 | 8)
-int g_tn_abl = 0;      // diagnostics: ablation mode of the weight-gradient kernel (0 = product kernel)
+// Diagnostic knobs exist in the probe build only (make prof: -DGYMRL_PROF_BUILD, libgymrl_hip_prof.so, loaded by
+// tools/abl_gemm.py through GYMRL_HIP_LIB).  The product library has no mutable global state and none of the
+// timing-only kernel variants (they skip loads / epilogues and produce wrong results by design).
+#ifdef GYMRL_PROF_BUILD
+int g_tn_abl = 0;      // ablation mode of the weight-gradient kernel (0 = product kernel)
+int g_ws_abl = 0;      // ablation mask of the forward kernel
+#endif
 
 // row groups of the weight-stationary kernels: at most one workgroup per CU (the weight slice fills LDS)
 inline int ws_row_groups(int64_t M, int rows_per_task, int slices) {
@@ -456,10 +460,10 @@ inline int ws_row_groups(int64_t M, int rows_per_task, int slices) {
   return (int)(rg < 1 ? 1 : rg);
 }
 
-int g_ws_abl = 0;      // diagnostics: ablation mask of the forward kernel (tools/abl_gemm.py)
 template <int RED, int NT, int RT, bool TRANS_W, int EPI, int LDO>
 void launch_ws(const WsArgs& a, int rg, hipStream_t s) {
   const dim3 grid(rg * a.slices), block(256);
+#ifdef GYMRL_PROF_BUILD
   if constexpr (EPI == EPI_TANH && LDO == 256) {
     switch (g_ws_abl) {
       case 1: hipLaunchKernelGGL((gemm_ws_kernel<RED, NT, RT, TRANS_W, EPI, LDO, 1>), grid, block, 0, s, a); return;
@@ -471,6 +475,7 @@ void launch_ws(const WsArgs& a, int rg, hipStream_t s) {
       default: break;
     }
   }
+#endif
   hipLaunchKernelGGL((gemm_ws_kernel<RED, NT, RT, TRANS_W, EPI, LDO>), grid, block, 0, s, a);
 }
 
@@ -492,14 +497,15 @@ constexpr size_t kColsumBytes = (size_t)kCUs * 512 * sizeof(float);
 
 extern "C" {
 
-int gymrl_gemm_config(int key, int value) {
+#ifdef GYMRL_PROF_BUILD
+int gymrl_gemm_config(int key, int value) {      // probe build only (include/gymrl.h)
   switch (key) {
-    case 2: if (value != 4 && value != 8) return -22; g_tn_pf = value; return 0;
     case 4: if (value < 0 || value > 2) return -22; g_tn_abl = value; return 0;
     case 5: if (value < 0 || value > 12) return -22; g_ws_abl = value; return 0;
     default: return -22;
   }
 }
+#endif
 
 size_t gymrl_gemm_workspace_bytes(void) {
   // column-sum partials of gymrl_linear_bwd_input + the partial tiles of gymrl_linear_bwd_weight
@@ -566,19 +572,16 @@ int gymrl_linear_bwd_weight(const float* dY, const float* X, int64_t B, int N, i
   a.parts = (float*)((char*)workspace + kColsumBytes);
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a.slices * a.ntiles), block(kTnThreads);
+#ifdef GYMRL_PROF_BUILD
   if (g_tn_abl) {        // timing-only variants (wrong results by design)
     if (g_tn_abl == 1) hipLaunchKernelGGL((gemm_tn_kernel<8, 256, 1>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((gemm_tn_kernel<8, 256, 2>), grid, block, 0, s, a);
     GYMRL_CHECK_LAUNCH();
     return 0;
   }
-  if (N == 256) {
-    if (g_tn_pf == 4) hipLaunchKernelGGL((gemm_tn_kernel<4, 256>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_tn_kernel<8, 256>), grid, block, 0, s, a);
-  } else {
-    if (g_tn_pf == 4) hipLaunchKernelGGL((gemm_tn_kernel<4, 512>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_tn_kernel<8, 512>), grid, block, 0, s, a);
-  }
+#endif
+  if (N == 256) hipLaunchKernelGGL((gemm_tn_kernel<8, 256>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((gemm_tn_kernel<8, 512>), grid, block, 0, s, a);
   hipLaunchKernelGGL(tn_reduce_kernel, dim3(a.ntiles * 256), dim3(256), 0, s, a.parts, a.slices, K, dW);
   if (db) hipLaunchKernelGGL(tn_colsum_kernel, dim3(a.ntiles * 4), dim3(256), 0, s, a.cs_parts, a.slices, db);
   GYMRL_CHECK_LAUNCH();

@@ -77,6 +77,105 @@ def shutdown():
         td.destroy_process_group()
 
 
+class GradReducer:
+    """Bucketed all-reduce(SUM) of a flat gradient buffer on a communication stream.
+
+    The backward pass writes the flat gradient back to front; a bucket [lo, hi) is launched as soon as the kernels that
+    write it are queued: the communication stream waits for an event of the compute stream, runs the collective (RCCL puts
+    it on its own stream; the communication stream waits for that), and records a completion event.  `wait()` makes the
+    compute stream wait for every outstanding bucket — the optimiser calls it right before it reads the gradients, so a
+    bucket's collective runs under whatever backward work was queued behind its launch (PPO: the head of the flat buffer
+    is reduced under the trunk's three GEMMs).  With `timed=True` every bucket is bracketed by HIP events on the
+    communication stream and every wait() by events on the compute stream: `stats()` returns the collectives' own
+    durations and the time the compute stream actually stalled on them (bench.py's all-reduce figures)."""
+
+    def __init__(self, flat_grads, bounds=None, timed=False):
+        n = flat_grads.numel()
+        bounds = [0, n] if bounds is None else sorted({0, n, *[int(b) for b in bounds]})
+        if bounds[0] != 0 or bounds[-1] != n:
+            raise ValueError("GradReducer: bucket bounds outside the flat buffer")
+        self.flat = flat_grads
+        self.buckets = [flat_grads[lo:hi] for lo, hi in zip(bounds[:-1], bounds[1:])]
+        self.cuda = flat_grads.is_cuda
+        self.comm = torch.cuda.Stream(device=flat_grads.device) if self.cuda else None
+        self.timed = bool(timed) and self.cuda
+        self._pending, self._spans, self._stalls = [], [], []
+
+    def launch(self, k):
+        """Reduce bucket k; everything queued on the current stream so far is ordered before it."""
+        if world_size() <= 1:
+            return
+        buf = self.buckets[k]
+        if not self.cuda:
+            td.all_reduce(buf, op=td.ReduceOp.SUM)
+            return
+        main = torch.cuda.current_stream(self.flat.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(ready)
+            e0 = None
+            if self.timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(self.comm)
+            td.all_reduce(buf, op=td.ReduceOp.SUM)
+            e1 = torch.cuda.Event(enable_timing=self.timed)
+            e1.record(self.comm)
+        if self.timed:
+            self._spans.append((k, e0, e1))
+        self._pending.append(e1)
+
+    def wait(self):
+        """The current stream waits for every bucket launched since the last wait()."""
+        if not self._pending:
+            return
+        main = torch.cuda.current_stream(self.flat.device)
+        s0 = s1 = None
+        if self.timed:
+            s0 = torch.cuda.Event(enable_timing=True)
+            s0.record(main)
+        for e in self._pending:
+            main.wait_event(e)
+        if self.timed:
+            s1 = torch.cuda.Event(enable_timing=True)
+            s1.record(main)
+            self._stalls.append((s0, s1))
+        self._pending = []
+
+    def stats(self):
+        """{"collectives", "collective_s" (sum of the buckets' own durations), "per_bucket_us", "bucket_bytes",
+        "stalls", "stall_s" (compute stream blocked in wait())}; synchronises the device."""
+        if not self.timed:
+            return None
+        torch.cuda.synchronize(self.flat.device)
+        per = {}
+        for k, e0, e1 in self._spans:
+            per.setdefault(k, []).append(e0.elapsed_time(e1) * 1e-3)
+        return {"collectives": len(self._spans), "collective_s": sum(sum(v) for v in per.values()),
+                "per_bucket_us": {str(k): 1e6 * sum(v) / len(v) for k, v in sorted(per.items())},
+                "bucket_bytes": [int(b.numel() * b.element_size()) for b in self.buckets],
+                "stalls": len(self._stalls), "stall_s": sum(a.elapsed_time(b) for a, b in self._stalls) * 1e-3}
+
+    def reset_stats(self):
+        self._spans, self._stalls = [], []
+
+
+def rank_devices():
+    """Every rank's (rank, local device index, device name, PCI bus id) gathered on all ranks — bench.py prints it so
+    that a scaling line shows which devices RCCL actually spanned."""
+    if torch.cuda.is_available():
+        i = torch.cuda.current_device()
+        pr = torch.cuda.get_device_properties(i)
+        mine = {"rank": rank(), "device": i, "name": pr.name, "pci_bus_id": getattr(pr, "pci_bus_id", None)}
+    else:
+        mine = {"rank": rank(), "device": None, "name": "cpu", "pci_bus_id": None}
+    if not is_dist() or world_size() <= 1:
+        return [mine]
+    out = [None] * world_size()
+    td.all_gather_object(out, mine)
+    return out
+
+
 def shard_env_ids(num_envs_per_rank, rk=None):
     """Global env-id range owned by a rank (the Philox stream is keyed by env id, so
     an N-GPU run steps exactly the env instances a 1-GPU run with N*num_envs would)."""

@@ -761,8 +761,12 @@ def gemm_workspace(device):
 
 
 def gemm_config(key, value):
-    """A/B knobs of the hand-written GEMMs (include/gymrl.h gymrl_gemm_config)."""
-    check(lib().gymrl_gemm_config(C.c_int(key), C.c_int(value)), "gymrl_gemm_config")
+    """Ablation variants of the hand-written GEMMs — probe build only (make -C gymrl_amd/csrc prof, GYMRL_HIP_LIB=
+    .../libgymrl_hip_prof.so); the product library does not export gymrl_gemm_config."""
+    L = lib()
+    if not hasattr(L, "gymrl_gemm_config"):
+        raise RuntimeError("gymrl_gemm_config exists in the probe build only (make -C gymrl_amd/csrc prof)")
+    check(L.gymrl_gemm_config(C.c_int(key), C.c_int(value)), "gymrl_gemm_config")
 
 
 def linear_fwd(x, W, b, out, act=True):
@@ -1063,17 +1067,27 @@ def rmsnorm(x, w, eps, n_sum=1, act=0):
     return y
 
 
-_norm_ws = {}
+_scratch_cache = {}
+
+
+def _scratch(kind, shape_key, nbytes, dev):
+    """Partial-sum scratch of the backward kernels that take one.  Cached per (kernel, shape, device, STREAM): two
+    streams never share a buffer, so concurrent backward passes cannot race on it.  While the stream is capturing a
+    hipGraph a missing buffer is allocated for this call only (it then lives in the graph's private pool like any other
+    temporary) and is NOT cached — an eager call after `del graph` must never inherit memory of a dead graph's pool."""
+    key = (kind, shape_key, dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _scratch_cache.get(key)
+    if ws is None:
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        if not torch.cuda.is_current_stream_capturing():
+            _scratch_cache[key] = ws
+    return ws
 
 
 def rmsnorm_bwd(g, x, w, eps, act=0):
     """gymrl_rmsnorm_bwd: (dL/dx [B, D], dL/dw [D]) of y = rmsnorm(x, w, eps, act=act); D <= 512."""
     B, D = x.shape
-    key = (D, x.device)
-    ws = _norm_ws.get(key)
-    if ws is None:
-        ws = _norm_ws[key] = torch.empty(lib().gymrl_rmsnorm_bwd_workspace_bytes(C.c_int(D)) // 4, dtype=torch.float32,
-                                         device=x.device)
+    ws = _scratch("rmsnorm_bwd", D, lib().gymrl_rmsnorm_bwd_workspace_bytes(C.c_int(D)), x.device)
     d_x, d_w = torch.empty_like(x), torch.empty_like(w)
     check(lib().gymrl_rmsnorm_bwd(_ptr(g, torch.float32), _ptr(x, torch.float32), _ptr(w, torch.float32), C.c_int(B), C.c_int(D),
                                   C.c_float(eps), C.c_int(act), _ptr(d_x), _ptr(d_w), _ptr(ws), _stream()), "gymrl_rmsnorm_bwd")
@@ -1149,19 +1163,12 @@ def mhc_combine_bwd(g, post, mix, out, h, act=0, want_dh=True):
     return d_post, d_mix, d_out, d_h
 
 
-_gates_ws = {}
-
-
 def mhc_gates_bwd(h, norm_w, w, alpha, pre, post, mix, stats, d_pre, d_post, d_mix, d_read=None, g_out=None):
     """gymrl_mhc_gates_bwd -> (d_h, d_norm_w, d_w, d_alpha, d_beta); n = 2 branches, n * D in (256, 512).  d_read [B, D] /
     g_out [B, n, D]: the read's and the combine's gradient paths into h, folded into d_h in the same pass."""
     B, n, D = h.shape
     dev = h.device
-    key = (n, D, dev)
-    ws = _gates_ws.get(key)
-    if ws is None:
-        nbytes = lib().gymrl_mhc_gates_bwd_workspace_bytes(C.c_int(n), C.c_int(D))
-        ws = _gates_ws[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    ws = _scratch("mhc_gates_bwd", (n, D), lib().gymrl_mhc_gates_bwd_workspace_bytes(C.c_int(n), C.c_int(D)), dev)
     d_h, d_nw, d_w = torch.empty_like(h), torch.empty_like(norm_w), torch.empty_like(w)
     d_alpha, d_beta = torch.empty(3, device=dev), torch.empty(w.shape[1], device=dev)
     opt = lambda t: None if t is None else _ptr(t, torch.float32)   # noqa: E731

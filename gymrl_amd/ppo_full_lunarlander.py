@@ -552,6 +552,7 @@ class PPOTrainer:
         self._g_idx, self._g_warm = None, 0          # hipGraph replay of the minibatch body (update_model)
         self._fwd_graph, self._fwd_in, self._fwd_out, self._fwd_warm = None, None, None, 0
         self._pol_out = None
+        self._reducer, self._time_collectives = None, False     # gdist.GradReducer (world_size > 1); bench.py times it
 
     @torch.no_grad()
     def collect_experience(self):
@@ -671,9 +672,18 @@ class PPOTrainer:
             # every pass scaled its loss by 1 / rows: the mean over the minibatch is their average
             self.optimizer.step(grad_scale=1.0 / (self.world_size * n_micro), bias_dev=bias)
 
-        def finish(bias=None):
+        def reduce_grads():
+            # one collective over the flat gradient per optimiser step (after the last micro-batch's backward), on the
+            # reducer's communication stream so that bench.py can time it apart from the compute stream's kernels
             if self.world_size > 1:
-                gdist.all_reduce_sum(self.flat_grads)
+                if self._reducer is None:
+                    self._reducer = gdist.GradReducer(self.flat_grads)
+                self._reducer.timed = self._time_collectives
+                self._reducer.launch(0)
+                self._reducer.wait()
+
+        def finish(bias=None):
+            reduce_grads()
             if self.grad_norms is not None:                                # tests: the norm clip_grad_norm_ would return
                 ops.sqnorm(self.flat_grads, self.optimizer._sq, self.optimizer._ws, 1.0 / (self.world_size * n_micro))
                 self.grad_norms.append(float(self.optimizer._sq.sqrt().item()))
@@ -723,8 +733,7 @@ class PPOTrainer:
                                 with gcapture(graph):
                                     fwd_bwd(self._g_idx, self._g_row)
                             graph.replay()
-                    if self.world_size > 1:
-                        gdist.all_reduce_sum(self.flat_grads)
+                    reduce_grads()
                     if graph2 is None:
                         if graph is None:
                             opt_step(self._g_bias)                         # still warming up

@@ -247,6 +247,8 @@ class PPOTrainer:
         self._stage = (torch.empty(mb, state_dim, device=self.device), torch.empty(mb, dtype=torch.int32, device=self.device),
                        torch.empty(mb, device=self.device), torch.empty(mb, device=self.device),
                        torch.empty(mb, device=self.device))
+        self._stage2 = tuple(torch.empty_like(t) for t in self._stage) if self.world_size > 1 else None
+        self._reducer = None     # gdist.GradReducer over the flat gradient (world_size > 1; built on the first update)
         self._timers = None      # set to a KernelTimers() to time kernels with HIP events (bench.py)
         if self.rank == 0:
             print(f"Device: {self.device} x{self.world_size} | envs/GPU: {N} | rollout T: {T}")
@@ -385,7 +387,11 @@ class PPOTrainer:
             indices = self._parity_indices.pop(0)
         self.compute_gae(None if next_value is self._next_value else next_value)
         if self.world_size > 1:
+            if self._timers is not None:
+                self._timers.start("moments_allreduce")
             gdist.all_reduce_sum(self._moments)          # :236 mean/std over the WHOLE rollout (all ranks)
+            if self._timers is not None:
+                self._timers.stop("moments_allreduce", 3)
         total = len(b)
         mb = self._minibatch_size()
         n_mb = (total + mb - 1) // mb
@@ -408,55 +414,83 @@ class PPOTrainer:
             self._metric_parts = torch.zeros(cfg.num_epochs * n_mb, nblk, 5, dtype=torch.float64, device=self.device)
         else:
             self._metric_parts.zero_()
+        red = None
+        if self.world_size > 1:
+            # the flat gradient is all-reduced in two buckets on a communication stream.  The
+            # tail of the flat buffer (actor.0 | critic.0 and the heads: 2/3 of the bytes) is complete once the N = 512
+            # weight gradient is queued and is reduced under the trunk's three GEMMs; the head follows the last backward
+            # kernel and overlaps the next minibatch's gather.
+            if self._reducer is None:
+                split = (self.model.actor[0].weight.data_ptr() - self.flat_params.data_ptr()) // 4
+                self._reducer = gdist.GradReducer(self.flat_grads, [split] if one_pass else None)
+            red = self._reducer
+            red.timed = tm is not None
+        stages = (self._stage, self._stage2) if red is not None else (self._stage, self._stage)
+
+        def minibatches():
+            for epoch in range(cfg.num_epochs):
+                if indices is not None:
+                    perm = torch.as_tensor(indices[epoch], device=self.device).to(torch.int32)
+                else:
+                    self._perm_draws += 1
+                    self._perm = ops.permutation(self._perm_seed, self._perm_draws, total, self.device,
+                                                 out=self._perm if self._perm is not None and self._perm.numel() == total else None)
+                    perm = self._perm
+                for start in range(0, total, mb):
+                    yield perm[start:start + mb]
+
+        def gather(mb_idx, k):
+            B = mb_idx.numel()
+            if tm is not None:
+                tm.start("gather_minibatch")
+            out = ops.gather_minibatch(self._packed, mb_idx, obs_dim, stages[k & 1] if B == mb else None)
+            if tm is not None:
+                tm.stop("gather_minibatch", B)
+            return out
+
         sizes = []
         row = 0
-        for epoch in range(cfg.num_epochs):
-            if indices is not None:
-                perm = torch.as_tensor(indices[epoch], device=self.device).to(torch.int32)
+        it = minibatches()
+        cur = gather(next(it), 0)
+        while cur is not None:
+            mb_obs, mb_act, mb_lp, mb_adv, mb_ret = cur
+            B = mb_obs.shape[0]
+            if one_pass:
+                fu.step(mb_obs, mb_act, mb_lp, mb_adv, mb_ret, self._loss_cfg, self._moments, self._metric_parts[row],
+                        reducer=red)
             else:
-                self._perm_draws += 1
-                self._perm = ops.permutation(self._perm_seed, self._perm_draws, total, self.device,
-                                             out=self._perm if self._perm is not None and self._perm.numel() == total else None)
-                perm = self._perm
-            for start in range(0, total, mb):
-                mb_idx = perm[start:start + mb]
-                B = mb_idx.numel()
-                stage = self._stage if B == mb else None
-                if tm is not None:
-                    tm.start("gather_minibatch")
-                mb_obs, mb_act, mb_lp, mb_adv, mb_ret = ops.gather_minibatch(self._packed, mb_idx, obs_dim, stage)
-                if tm is not None:
-                    tm.stop("gather_minibatch", B)
-                if one_pass:
-                    fu.step(mb_obs, mb_act, mb_lp, mb_adv, mb_ret, self._loss_cfg, self._moments, self._metric_parts[row])
+                if fu is not None:
+                    logits, values = fu.forward(mb_obs)
                 else:
-                    if fu is not None:
-                        logits, values = fu.forward(mb_obs)
-                    else:
-                        logits, values = self.model(mb_obs)
-                        values = values.view(-1)
-                    dlogits = torch.empty_like(logits)
-                    dvalues = torch.empty_like(values)
-                    if tm is not None:
-                        tm.start("ppo_loss_fwd_bwd")
-                    ops.ppo_loss_fwd_bwd(logits, values, mb_act, mb_lp, mb_adv, mb_ret, self._loss_cfg,
-                                         adv_moments=self._moments, dlogits_out=dlogits, dvalue_out=dvalues,
-                                         workspace=self._metric_parts[row])
-                    if tm is not None:
-                        tm.stop("ppo_loss_fwd_bwd", B)
-                    if fu is not None:
-                        fu.backward(dlogits, dvalues)
-                    else:
-                        torch.autograd.backward([logits, values], [dlogits, dvalues])
-                if self.world_size > 1:
-                    gdist.all_reduce_sum(self.flat_grads)
+                    logits, values = self.model(mb_obs)
+                    values = values.view(-1)
+                dlogits = torch.empty_like(logits)
+                dvalues = torch.empty_like(values)
                 if tm is not None:
-                    tm.start("adam_step")
-                self.optimizer.step(grad_scale=1.0 / self.world_size)
+                    tm.start("ppo_loss_fwd_bwd")
+                ops.ppo_loss_fwd_bwd(logits, values, mb_act, mb_lp, mb_adv, mb_ret, self._loss_cfg,
+                                     adv_moments=self._moments, dlogits_out=dlogits, dvalue_out=dvalues,
+                                     workspace=self._metric_parts[row])
                 if tm is not None:
-                    tm.stop("adam_step", self.flat_params.numel())
-                sizes.append(B)
-                row += 1
+                    tm.stop("ppo_loss_fwd_bwd", B)
+                if fu is not None:
+                    fu.backward(dlogits, dvalues)
+                else:
+                    torch.autograd.backward([logits, values], [dlogits, dvalues])
+                if red is not None:
+                    red.launch(0)
+            # the next minibatch's rows do not depend on the parameters: gathered while the last bucket is in flight
+            nxt = next(it, None)
+            cur = gather(nxt, row + 1) if nxt is not None else None
+            if red is not None:
+                red.wait()
+            if tm is not None:
+                tm.start("adam_step")
+            self.optimizer.step(grad_scale=1.0 / self.world_size)
+            if tm is not None:
+                tm.stop("adam_step", self.flat_params.numel())
+            sizes.append(B)
+            row += 1
         metrics = ops.reduce_rows(self._metric_parts, row, nblk, 5)
         self._drain_episode_returns()
         m = metrics.cpu().numpy() / np.asarray(sizes, np.float64)[:, None]   # the one host sync of the update

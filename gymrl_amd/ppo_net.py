@@ -156,9 +156,11 @@ class FusedActorCriticUpdate:
         return ops.heads_loss_blocks(B, self.H)
 
     @torch.no_grad()
-    def step(self, x, act, logp_old, adv, ret, loss_cfg, adv_moments, metric_parts):
+    def step(self, x, act, logp_old, adv, ret, loss_cfg, adv_moments, metric_parts, reducer=None):
         """Forward, loss and backward of one minibatch (module docstring): writes every parameter gradient
-        (overwrite) and the f64[metric_blocks(B), 5] partial metric sums."""
+        (overwrite) and the f64[metric_blocks(B), 5] partial metric sums.  `reducer` (dist.GradReducer with its
+        split at actor.0.weight): bucket 1 = [actor.0 | critic.0, heads] is launched as soon as its last writer is
+        queued, bucket 0 = the trunk after the last kernel."""
         m, B = self.m, x.shape[0]
         if B > self.R:
             raise ValueError("minibatch larger than the buffers")
@@ -172,11 +174,15 @@ class FusedActorCriticUpdate:
           m.critic[2].weight, m.critic[2].bias, act, logp_old, adv, ret, loss_cfg, adv_moments, self.dbac,
           m.actor[2].weight.grad, m.actor[2].bias.grad, m.critic[2].weight.grad, m.critic[2].bias.grad, metric_parts, self.ws)
         t("gemm_dw_512", B, ops.linear_bwd_weight, Zac, H2, self.dWac, ws)
+        if reducer is not None:
+            reducer.launch(1)
         t("gemm_dx_512_tanhbwd", B, ops.linear_bwd_input, Zac, self.Wac, H2, dZ2)
         t("gemm_dw_256_db", B, ops.linear_bwd_weight, dZ2, H1, W2.grad, ws, m.shared[2].bias.grad)
         t("gemm_dx_256_tanhbwd", B, ops.linear_bwd_input, dZ2, W2, H1, dZ1)
         t("linear_smallk_bwd", B, ops.linear_smallk_bwd, dZ1, None, x, m.shared[0].weight.grad, m.shared[0].bias.grad,
           self.ws)
+        if reducer is not None:
+            reducer.launch(0)
 
     def _recompute_h1(self):
         """(W1, b1) when linear_smallk_bwd recomputes H1 from the observations instead of reading it."""

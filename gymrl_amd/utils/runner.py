@@ -64,15 +64,21 @@ def make_env(cfg):
     return env
 
 
-def ensure_normalizers(agent, cfg, num_envs):
+def ensure_normalizers(agent, cfg, num_envs, reward_scaler=True):
     """Create `agent.state_norm` / `agent.reward_scaler` when the config asks for them and the agent has none yet, and
     hand them the statistics a checkpoint carried (ModelLoader.load_model parks them in `agent._pending_state` when the
     object does not exist at load time).  The reference pickles the objects themselves (utils/model.py:337-366), so its
     test() path finds them after load_model(); here train(), evaluate() and test() all go through this."""
     if getattr(cfg, "use_state_norm", False) and not hasattr(agent, 'state_norm'):
         agent.state_norm = Normalization(shape=cfg.n_states, device=cfg.device)
-    if getattr(cfg, "use_reward_scale", False) and not hasattr(agent, 'reward_scaler'):
-        agent.reward_scaler = RewardScaling(shape=1, gamma=cfg.gamma, num_envs=num_envs, device=cfg.device)
+    if reward_scaler and getattr(cfg, "use_reward_scale", False):
+        # per-env running return R [num_envs]: one left behind for another env count (e.g. by an evaluation vector) is
+        # rebuilt; its running statistics travel through the state dict, which tolerates the new R shape
+        old = getattr(agent, 'reward_scaler', None)
+        if old is None or int(old.R.shape[0]) != int(num_envs):
+            agent.reward_scaler = RewardScaling(shape=1, gamma=cfg.gamma, num_envs=num_envs, device=cfg.device)
+            if old is not None:
+                agent.reward_scaler.load_state_dict(old.state_dict())
     pending = getattr(agent, "_pending_state", {})
     for attr in ("state_norm", "reward_scaler"):
         if attr in pending and hasattr(agent, attr):
@@ -138,8 +144,9 @@ def train(env, agent, cfg, max_vector_steps=None):
         # vector step; this runner is the legacy contract, not the throughput path.
         n_before = len(returns)
         tracker.advance(returns)                 # drains finished episodes every 16 vector steps (no per-step host sync)
-        for k in range(n_before, len(returns)):                                          # :157, per finished episode
-            log_monitors(writer, {'reward': returns[k], 'step': tracker.lengths[k]}, agent, 'train', k)
+        if writer is not None:                   # (episode lengths are only tracked for the sink: cfg.log_metrics = False)
+            for k in range(n_before, len(returns)):                                      # :157, per finished episode
+                log_monitors(writer, {'reward': returns[k], 'step': tracker.lengths[k]}, agent, 'train', k)
         if bool(done.any()):
             idx = done.nonzero().view(-1)
             period = cfg.eval_freq * N            # :160-162 every eval_freq episodes of ONE env: eval_freq * N of the vector
@@ -163,8 +170,9 @@ def train(env, agent, cfg, max_vector_steps=None):
                 action[idx] = agent.choose_action(fresh)
     n_before = len(returns)
     tracker.flush(returns)
-    for k in range(n_before, len(returns)):
-        log_monitors(writer, {'reward': returns[k], 'step': tracker.lengths[k]}, agent, 'train', k)
+    if writer is not None:
+        for k in range(n_before, len(returns)):
+            log_monitors(writer, {'reward': returns[k], 'step': tracker.lengths[k]}, agent, 'train', k)
     if hasattr(agent, "save_model"):                                                   # :164
         agent.save_model()
     if writer is not None:
@@ -176,7 +184,9 @@ def train(env, agent, cfg, max_vector_steps=None):
 def evaluate(env_name, agent, cfg, episodes=None):
     """:169-184: deterministic episodes on a fresh env vector; mean return."""
     n = episodes or cfg.eval_eps
-    ensure_normalizers(agent, cfg, n)            # a freshly built agent after load_model(): statistics from the checkpoint
+    # a freshly built agent after load_model(): statistics from the checkpoint.  Only the state normaliser — evaluation
+    # never scales rewards, and a scaler sized for the n evaluation episodes must not be what a later train() finds
+    ensure_normalizers(agent, cfg, n, reward_scaler=False)
     env = VecEnv(env_name, n, device=cfg.device, seed=12345, env_id0=1 << 40)
     obs = env.reset()
     nxt, rew = torch.empty_like(obs), torch.empty(n, device=env.device)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GYMRL_ABI_VERSION 1
+#define GYMRL_ABI_VERSION 2   /* 2: round-2 signature changes (adam_step, per_*, replay_append, nstep_push, gae_decoupled, rollout descriptors); gymrl_gemm_config left the product library */
 
 /* ---------------------------------------------------------------- misc --- */
 int gymrl_abi_version(void);
@@ -738,11 +738,14 @@ int gymrl_heads_loss_fwd_bwd(float* Zac, int64_t B, int C, int A, const float* b
  * compared at 1e-5).  act = tanh uses the same hardware-exp2 form as the passes above.  bwd_weight's db [N]
  * (NULL: skipped) = column sums of dY — the bias gradient of the same layer: per slice the even- and the odd-offset
  * rows are summed sequentially in f32 and added, slices combine like the weight tiles (bit for bit in the oracle).
- * gymrl_gemm_config(key, value): knobs of tools/micro_gemm.py / tools/abl_gemm.py (2: prefetch ring depth of
- * bwd_weight 4|8; 4: ablation mode of bwd_weight, 0 = the product kernel); results do not depend on key 2.
+ * gymrl_gemm_config(key, value) exists ONLY in the probe build (make -C gymrl_amd/csrc prof -> libgymrl_hip_prof.so,
+ * -DGYMRL_PROF_BUILD): it selects timing-only ablation variants of the kernels for tools/abl_gemm.py (4: bwd_weight,
+ * 5: fwd; 0 = the product kernel).  The product library exports no such switch and keeps no mutable global state.
  */
 size_t gymrl_gemm_workspace_bytes(void);
+#ifdef GYMRL_PROF_BUILD
 int gymrl_gemm_config(int key, int value);
+#endif
 int gymrl_linear_fwd(const float* X, const float* W, const float* b, int64_t B, int K, int N, int act,
                      float* Y, void* stream);
 int gymrl_linear_bwd_input(const float* dY, const float* W, const float* H, int64_t B, int N, int K,

@@ -37,10 +37,14 @@ def run(rank, world, port, outdir, n_envs):
         assert tr.world_size == world and tr.env.env_id0 == rank * n_envs
         p0 = tr.flat_params.clone()
         nv = tr.collect_rollout()
+        from gymrl_amd.ppo_lunarlander import KernelTimers
+        tr._timers = KernelTimers()                 # bench.py's mode: the reducer brackets its buckets with HIP events
         m = tr.update(nv)
+        tr._timers = None
         b = tr.buffer
+        rs = tr._reducer.stats()
         out = dict(p0=p0.cpu(), params=tr.flat_params.cpu(), moments=tr._moments.cpu(), adv=b.advantages.cpu(),
-                   metrics={k: float(v) for k, v in m.items()},
+                   metrics={k: float(v) for k, v in m.items()}, reducer=rs,
                    **{k: getattr(b, k).cpu() for k in ("states", "actions", "log_probs", "values", "rewards", "dones")})
         # PPO-full: two iterations (the second replays the two hipGraphs around the eager all-reduce)
         from gymrl_amd.ppo_full_lunarlander import PPOTrainer as FullTrainer

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/gymrl.h but not exported"
     assert sorted(_lib.SYMBOLS) == declared, "gymrl_amd/_lib.py SYMBOLS out of sync with include/gymrl.h"
-    assert L.gymrl_abi_version() == 1
+    assert L.gymrl_abi_version() == 2
 
 
 def test_size_queries_need_no_gpu():

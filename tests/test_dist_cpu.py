@@ -50,8 +50,21 @@ def _worker(rank, world, port, ret):
     gdist.all_reduce_sum(mom)
     t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
     gdist.all_reduce_max(t)
+    # bucketed reducer (the trainers' path): two buckets launched back to front, wait(), result == plain all-reduce
+    torch.manual_seed(200 + rank)
+    gb = torch.randn(1000)
+    gb_local = gb.clone()
+    red = gdist.GradReducer(gb, [640])
+    assert [b.numel() for b in red.buckets] == [640, 360]
+    red.launch(1)
+    red.launch(0)
+    red.wait()
+    assert red.stats() is None                       # untimed on CPU tensors
+    devs = gdist.rank_devices()
+    assert [d["rank"] for d in devs] == list(range(world))
     gdist.barrier()
-    ret[rank] = dict(obs=obs, params=params, g_local=g_local.numpy(), mom=mom.numpy(), adv=adv, tmax=float(t.item()))
+    ret[rank] = dict(obs=obs, params=params, g_local=g_local.numpy(), mom=mom.numpy(), adv=adv, tmax=float(t.item()),
+                     gb=gb.numpy(), gb_local=gb_local.numpy())
 
 
 @pytest.mark.timeout(300)
@@ -81,3 +94,16 @@ def test_two_rank_gloo_data_parallel_path():
     full = orc.Env(orc.LUNARLANDER, 16, seed=3, env_id0=0).reset()
     assert np.array_equal(np.concatenate([a["obs"], b["obs"]]), full)
     assert a["tmax"] == b["tmax"] == pytest.approx(0.2)
+    assert np.array_equal(a["gb"], b["gb"]) and np.array_equal(a["gb"], a["gb_local"] + b["gb_local"])
+
+
+def test_grad_reducer_rejects_bounds_outside_the_buffer():
+    sys.path.insert(0, ROOT)
+    from gymrl_amd import dist as gdist
+    g = torch.zeros(100)
+    with pytest.raises(ValueError):
+        gdist.GradReducer(g, [200])
+    r = gdist.GradReducer(g, [40, 40, 0, 100])
+    assert [b.numel() for b in r.buckets] == [40, 60]
+    r.launch(0)                                      # world_size 1: no-ops
+    r.wait()

@@ -193,3 +193,50 @@ def test_runner_trace_matches_reference(kind):
     assert rel_close(ms.std.cpu().numpy(), g[kind + "_norm"][9:17], 1e-6) <= 1e-6
     rs = agent.reward_scaler.running_ms
     assert rs.n == int(g[kind + "_rscale"][0]) and rel_close(rs.std.cpu().numpy(), g[kind + "_rscale"][2:3], 1e-6) <= 1e-6
+
+
+def test_runner_without_a_metrics_sink_and_train_after_evaluate(tmp_path, monkeypatch):
+    """cfg.log_metrics = False (no writer: finished episodes must not index the length list that only the sink fills),
+    and evaluate() on a fresh agent must not leave a reward scaler sized for the evaluation vector behind."""
+    monkeypatch.chdir(tmp_path)
+    import glob
+    from gymrl_amd.utils.buffer import ReplayBuffer_off_policy
+    from gymrl_amd.utils.runner import BasicConfig, make_env, train, evaluate
+
+    class Config(BasicConfig):
+        def __init__(self):
+            super().__init__()
+            self.env_name, self.algo_name = "CartPole-v1", "Rand"
+            self.train_eps, self.num_envs, self.batch_size = 10 ** 9, 32, 64
+            self.memory_capacity = 4096
+            self.log_metrics = False
+
+    class Rand:
+        def __init__(self, cfg):
+            self.cfg, self.memory, self.k = cfg, ReplayBuffer_off_policy(cfg), 0
+
+        def choose_action(self, state):
+            self.k += 1
+            return torch.full((state.shape[0],), self.k & 1, dtype=torch.int32, device=state.device)
+
+        evaluate = choose_action
+
+        def update(self):
+            return {"loss": 0.0}
+
+    cfg = Config()
+    env = make_env(cfg)
+    agent = Rand(cfg)
+    assert np.isfinite(evaluate(cfg.env_name, agent, cfg, episodes=5))
+    assert hasattr(agent, "state_norm") and not hasattr(agent, "reward_scaler")      # evaluation scales no rewards
+    returns, _ = train(env, agent, cfg, max_vector_steps=80)                       # alternating actions: ~20-step episodes
+    assert len(returns) > 32 and agent.reward_scaler.R.shape[0] == 32
+    assert not glob.glob("exp/*")                                                  # no sink, no run directory
+    # a scaler left behind for another env count is rebuilt for this vector, its running statistics kept
+    from gymrl_amd.utils.normalization import RewardScaling
+    n_seen = agent.reward_scaler.running_ms.n
+    old = agent.reward_scaler
+    agent.reward_scaler = RewardScaling(shape=1, gamma=cfg.gamma, num_envs=5, device=cfg.device)
+    agent.reward_scaler.load_state_dict(old.state_dict())
+    train(make_env(cfg), agent, cfg, max_vector_steps=2)
+    assert agent.reward_scaler.R.shape[0] == 32 and agent.reward_scaler.running_ms.n == n_seen + 2 * 32

@@ -34,6 +34,11 @@ def test_two_ranks_ppo_and_ppo_full(tmp_path):
     # identical initial parameters (broadcast) and bit-identical parameters after 8 all-reduced optimiser steps
     assert torch.equal(r[0]["p0"], r[1]["p0"]) and torch.equal(r[0]["params"], r[1]["params"])
     assert not torch.equal(r[0]["params"], r[0]["p0"])
+    # the gradient travelled as two buckets per optimiser step (tail of the flat buffer first), on the reducer's stream
+    for k in (0, 1):
+        rs = r[k]["reducer"]
+        assert rs["collectives"] == 2 * 8 and rs["stalls"] == 8 and len(rs["bucket_bytes"]) == 2
+        assert rs["bucket_bytes"][1] > rs["bucket_bytes"][0] > 0 and rs["collective_s"] > 0
     assert torch.equal(r[0]["moments"], r[1]["moments"])
     # rank r's slab == envs [rN, (r+1)N) of a single-rank run with 2N envs (same seed, same initial weights)
     sys.path.insert(0, HERE)
