@@ -10,6 +10,7 @@ from conftest import ROOT
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "gymrl.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    hdr = re.sub(r"#ifdef GYMRL_PROF_BUILD.*?#endif", "", hdr, flags=re.S)      # probe-build-only declarations
     return sorted(set(re.findall(r"\b(gymrl_[a-z0-9_]+)\s*\(", hdr)))
 
 
@@ -21,7 +22,21 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/gymrl.h but not exported"
     assert sorted(_lib.SYMBOLS) == declared, "gymrl_amd/_lib.py SYMBOLS out of sync with include/gymrl.h"
-    assert L.gymrl_abi_version() == 2
+    assert L.gymrl_abi_version() == 2 == _lib.ABI_VERSION
+    # the product library carries no diagnostic switches (timing-only kernel variants live in the probe build)
+    assert not hasattr(L, "gymrl_gemm_config")
+
+
+def test_stale_library_is_refused(tmp_path, monkeypatch):
+    """_lib.lib() compares the library's ABI version with the one this front-end was written against."""
+    from gymrl_amd import _lib
+    import pytest
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", 999)
+    with pytest.raises(RuntimeError, match="ABI version"):
+        _lib.lib()
+    monkeypatch.setattr(_lib, "ABI_VERSION", 2)
+    assert _lib.lib().gymrl_abi_version() == 2
 
 
 def test_size_queries_need_no_gpu():
