@@ -645,7 +645,7 @@ GENERATORS = [gen_ppo_full_net, gen_gae, gen_gae_g2, gen_gae_g3, gen_categorical
 
 
 # --------------------------------------------------------------- H1 trace ----
-def gen_ppo_trace():
+def gen_ppo_trace(hidden=32, lr=1e-2, name="ppo_trace", slim=False):
     """Row H1: the reference PPOTrainer.train() run unmodified for two
     rollout+update iterations on the build-owned scripted env (tests/scripted_env.py), python /
     numpy / torch seeded 0.  Records every buffer field, the Exp(1) draws Categorical.sample
@@ -657,9 +657,11 @@ def gen_ppo_trace():
     ppo = load_ref("algorithms/ppo_lunarlander.py", "ref_ppo_trace")
     sys.modules["gymnasium"].make = lambda name, **kw: ScriptedEnv(8, 4)
     cfg = ppo.Config()
-    cfg.update_freq, cfg.batch_size, cfg.num_epochs, cfg.hidden_dim = 96, 40, 2, 32   # 96/40: short last slice
+    cfg.update_freq, cfg.batch_size, cfg.num_epochs = 96, 40, 2                        # 96/40: short last slice
+    if hidden is not None:
+        cfg.hidden_dim = hidden        # None: the reference's own default (256, ppo_lunarlander.py:43)
     cfg.max_train_steps = 2 * cfg.update_freq
-    cfg.lr = 1e-2                      # large enough that ratios clip within two updates
+    cfg.lr = lr                        # 1e-2: large enough that ratios clip within two updates
     cfg.device = "cpu"
     seed_all(0)
     tr = ppo.PPOTrainer(cfg)
@@ -699,10 +701,13 @@ def gen_ppo_trace():
                              ret=np.asarray(ret, np.float64)))
         lrs.append(tr.optimizer.param_groups[0]["lr"])
         m = orig_update(next_value)
+        sd = {k: v.numpy().copy() for k, v in tr.model.state_dict().items()}
+        if slim and len(upd) == 0:     # 200 k parameters per snapshot: the first update keeps every 8th element of each
+            sd = {k: v.reshape(-1)[::8].copy() for k, v in sd.items()}      # tensor (the second keeps all of them)
         upd.append(dict(metrics=np.array([m["policy_loss"], m["value_loss"], m["entropy"], m["clip_frac"],
                                           m["approx_kl"]], np.float64),
                         step_count=np.int64(tr.step_count), episode_rewards=np.array(tr.episode_rewards, np.float64),
-                        **{"sd_" + k: v.numpy().copy() for k, v in tr.model.state_dict().items()}))
+                        **{"sd_" + k: v for k, v in sd.items()}))
         return m
     tr.update = update
     try:
@@ -725,7 +730,15 @@ def gen_ppo_trace():
             out[f"r{r}_{k}"] = v
     out["cfg"] = np.array([cfg.update_freq, cfg.batch_size, cfg.num_epochs, cfg.hidden_dim, cfg.max_train_steps], np.int64)
     out["lr0"] = np.float64(cfg.lr)
-    save("ppo_trace", **out)
+    out["slim_stride"] = np.int64(8 if slim else 1)
+    save(name, **out)
+
+
+def gen_ppo_trace_h256():
+    """The same harness at the reference's OWN network width (hidden_dim 256, the default of ppo_lunarlander.py:43):
+    this is the shape gymrl_amd's default update path (hand-written f32-MFMA GEMMs + the loss inside the heads pass,
+    ppo_net.FusedActorCriticUpdate.step) runs at, so the replay goes through exactly the kernels bench.py times."""
+    gen_ppo_trace(hidden=None, lr=1e-3, name="ppo_trace_h256", slim=True)
 
 
 def gen_rainbow_update():
@@ -1505,6 +1518,6 @@ def gen_ppo_full_pscn():
 
 if __name__ == "__main__":
     names = sys.argv[1:]
-    for g in GENERATORS + [gen_ppo_trace, gen_rainbow_update, gen_buffer_v2, gen_dqn_trace, gen_sac_trace, gen_rainbow_trace, gen_td3_ddpg, gen_dsac, gen_ppo_lstm_parts, gen_ppo_lstm_trace, gen_runner_trace, gen_ppo_full_pscn, gen_ppo_full_trace]:
+    for g in GENERATORS + [gen_ppo_trace, gen_ppo_trace_h256, gen_rainbow_update, gen_buffer_v2, gen_dqn_trace, gen_sac_trace, gen_rainbow_trace, gen_td3_ddpg, gen_dsac, gen_ppo_lstm_parts, gen_ppo_lstm_trace, gen_runner_trace, gen_ppo_full_pscn, gen_ppo_full_trace]:
         if not names or g.__name__ in names:
             g()
