@@ -49,6 +49,11 @@ enum {
  * utils/runner.py:53,111,123.
  * One env instance per lane; state is a caller-owned SoA byte buffer of
  * gymrl_env_state_bytes(kind, n_envs) bytes (256-B aligned base required).
+ * Classic envs: consecutive fields [n_envs], each field's byte size rounded up to a multiple of 256 —
+ *   CartPole-v1  f64 x, f64 x_dot, f64 theta, f64 theta_dot, f64 ep_ret, i32 ep_len, u32 episode
+ *   Pendulum-v1  f64 theta, f64 theta_dot, f64 ep_ret, i32 ep_len, u32 episode
+ * (float64 like gymnasium's own state; tests/test_classic_micro_gpu.py writes states through this layout, and a
+ * checkpoint of a running vector is a copy of the buffer).  LunarLander: 144 dwords per env, word-major.
  */
 int    gymrl_env_obs_dim(int kind);
 int    gymrl_env_act_dim(int kind);     /* #discrete actions, or continuous dim */

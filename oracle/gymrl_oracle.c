@@ -677,6 +677,16 @@ void orc_env_destroy(orc_env* e) { if (e) { free(e->classic); free(e->lunar); fr
 void orc_lunar_get_words(void* st, int i, uint32_t* out144);
 void orc_env_lunar_words(orc_env* e, int i, uint32_t* out144) { orc_lunar_get_words(e->lunar, i, out144); }
 
+/* Test hook (tests/classic_micro.py): put env i into a given float64 state (CartPole: x, xdot, th, thdot; Pendulum: th,
+ * thdot) with `ep_len` steps of its episode already taken — the closed-form scenarios start from hand-picked states. */
+void orc_env_set_classic(orc_env* e, int i, const double* s, int ep_len) {
+  if (e->kind == ORC_LUNARLANDER || i < 0 || i >= e->n) return;
+  const int k = e->kind == ORC_CARTPOLE ? 4 : 2;
+  for (int j = 0; j < k; ++j) e->classic[i].s[j] = s[j];
+  e->classic[i].ep_len = ep_len;
+  e->classic[i].ep_ret = 0.0;
+}
+
 static void cartpole_draw(uint64_t seed, uint64_t env, uint32_t episode, double* s) {
   uint32_t a[4], b[4];
   orc_philox(seed, (uint32_t)env, (uint32_t)(env >> 32), episode, RNG_ENV_RESET | 0u, a);

@@ -390,6 +390,14 @@ class Env:
         lib().orc_env_abandon(self._h, int(cap), _p(obs), _p(flag), _p(ep_ret), _p(ep_len))
         return obs, flag, ep_ret, ep_len
 
+    def set_classic_state(self, states, ep_len=0):
+        """Test hook: env i := states[i] (f64; CartPole x, xdot, th, thdot / Pendulum th, thdot), `ep_len` steps taken."""
+        states = np.ascontiguousarray(states, np.float64)
+        lens = np.broadcast_to(np.asarray(ep_len, np.int64), (self.n,))
+        for i in range(self.n):
+            row = np.ascontiguousarray(states[i])
+            lib().orc_env_set_classic(self._h, i, _p(row), int(lens[i]))
+
     def lunar_words(self):
         """u32[144, n]: every LunarLander world in the word order of the HIP state buffer (tests/box2d_micro.py)."""
         out = np.zeros((self.n, 144), np.uint32)
