@@ -125,7 +125,8 @@ class RolloutLunarArgs(C.Structure):
                 ("next_value", C.c_void_p), ("noise_exp", C.c_void_p), ("gae_running", C.c_void_p),
                 ("gae_workspace", C.c_void_p), ("gamma", C.c_double), ("lam", C.c_double), ("ep_stats", C.c_void_p),
                 ("wg_ticks", C.c_void_p), ("T", C.c_int), ("t0", C.c_int), ("nsteps", C.c_int),
-                ("ent", C.c_void_p), ("lam2", C.c_double), ("gae_running2", C.c_void_p)]   # gymrl_rollout_lunar_mhc only
+                ("ent", C.c_void_p), ("lam2", C.c_double), ("gae_running2", C.c_void_p),   # gymrl_rollout_lunar_mhc only
+                ("refill", C.c_int)]
 
 
 class PPOFullCfg(C.Structure):

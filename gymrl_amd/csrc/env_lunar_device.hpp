@@ -1171,7 +1171,7 @@ __device__ __forceinline__ void lunar_refill_quad(const LunarState& st, const Ld
   }
   // the flag must follow every lane's stores: lanes 1,2 wrote manifold words
   __builtin_amdgcn_wave_barrier();
-  if (need && role == 0) st.spare_episode[i] = want;
+  if (need && role == 0) __hip_atomic_store(&st.spare_episode[i], want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // One env.step() of env i by its quad (ppo_lunarlander.py:211 + the reset-on-done of :220-223): the body of
@@ -1182,9 +1182,16 @@ struct StepOut {
   uint8_t* done_out; float* ep_ret_out; int32_t* ep_len_out; double* ep_stats;
 };
 
+// `refill` (wave-uniform): instead of stepping, the wave builds the spare world of episode episode[i] + 1 of every env that
+// lacks one — the persistent rollout kernels run this on wave 1 while wave 0 steps (reset() ends with a full physics step,
+// 180 velocity sweeps, which wave 0 would otherwise run inline on the step an episode ends, every other env of the wave
+// waiting).  Both modes share ONE inlined copy of the solver (the pass loop below): the kernel's registers and code size
+// are those of the stepping path alone.  A spare is a pure function of (seed, env id, episode), so the slab is bit-identical
+// with or without it; `episode[i]` may be advanced by wave 0 in this very step — then the spare is for an episode that
+// already started, is never matched, and is rebuilt on the next step.
 __device__ __forceinline__ void lunar_step_quad(const LunarState& st, const Lds& lds, int n, int i, int role, bool valid,
                                                 int action_in, uint64_t seed, int64_t env_id0, const StepOut& out,
-                                                float (&o_next)[8]) {
+                                                float (&o_next)[8], bool refill = false) {
   float* __restrict__ obs_out = out.obs_out; float* __restrict__ term_obs_out = out.term_obs_out;
   float* __restrict__ rew_out = out.rew_out; uint8_t* __restrict__ terminated_out = out.terminated_out;
   uint8_t* __restrict__ truncated_out = out.truncated_out; uint8_t* __restrict__ done_out = out.done_out;
@@ -1193,23 +1200,40 @@ __device__ __forceinline__ void lunar_step_quad(const LunarState& st, const Lds&
   const bool lead = role == 0;
   bool done = false;
   double ret = 0.0; int len = 0;
-  if (valid) {
+  bool active = valid;
+  uint32_t want = 0u;
+  if (refill) {                                       // which envs lack the spare of their next episode (quad-uniform: lane 0's view)
+    uint32_t need = 0u;
+    if (valid) {
+      want = __hip_atomic_load(&st.ep.episode[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+      need = __hip_atomic_load(&st.spare_episode[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want ? 1u : 0u;
+    }
+    want = quad_bcast_u<0>(want);
+    active = quad_bcast_u<0>(need) != 0u;
+  }
+  if (active) {
     World W;
     float o_term[8];
-    world_io(W, lds, role, st.words, n, i, false);
     const uint64_t env = (uint64_t)(env_id0 + i);
-    const uint32_t episode = st.ep.episode[i];
-    len = st.ep.ep_len[i];
-    const double ret0 = st.ep.ep_ret[i];
-    int act = action_in;
-    act = act < 0 ? 0 : (act > 3 ? 3 : act);
-    uint32_t ep = episode, step_idx = (uint32_t)len;
+    uint32_t episode = 0u;
+    double ret0 = 0.0;
+    int act = 0;
+    if (!refill) {
+      world_io(W, lds, role, st.words, n, i, false);
+      episode = st.ep.episode[i];
+      len = st.ep.ep_len[i];
+      ret0 = st.ep.ep_ret[i];
+      act = action_in;
+      act = act < 0 ? 0 : (act > 3 ? 3 : act);
+    }
+    uint32_t ep = refill ? want : episode, step_idx = refill ? 0u : (uint32_t)len;
     float fx = 0.0f, fy = 0.0f;
-    // pass 0 = the requested step; pass 1 (only where the episode ended and no spare world is
-    // ready) = the new episode's reset(), whose trailing step(0) reuses the one inlined solver.
+    // pass 0 = the requested step; pass 1 = a new episode's reset(), whose trailing step(0) reuses the one inlined solver:
+    // stepping waves enter it only where the episode ended and no spare world is ready, a refill wave starts there.
 #pragma nounroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = refill ? 1 : 0; pass < 2; ++pass) {
       float o[8], reward; bool terminated;
+      if (pass == 1) init_episode(W, lds, seed, env, ep, fx, fy);
       env_step_once(W, lds, role, act, seed, env, ep, step_idx, fx, fy, o, reward, terminated);
       if (pass == 0) {
         len += 1;
@@ -1226,12 +1250,14 @@ __device__ __forceinline__ void lunar_step_quad(const LunarState& st, const Lds&
         for (int k = 0; k < 8; ++k) { o_term[k] = o[k]; o_next[k] = o[k]; }
         if (!done) { if (lead) { st.ep.ep_ret[i] = ret; st.ep.ep_len[i] = len; } break; }
         ep = episode + 1u; step_idx = 0u; act = 0;
-        // every lane reads the spare flag BEFORE lane 0 rewrites the episode bookkeeping
-        const bool have_spare = st.spare_episode[i] == ep;
+        // every lane reads the spare flag BEFORE lane 0 rewrites the episode bookkeeping (agent scope: the flag may have
+        // been published by the workgroup's refill wave a moment ago — a per-CU cache line from an earlier poll must not answer)
+        const bool have_spare = __hip_atomic_load(&st.spare_episode[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ep;
         if (lead) {
           if (ep_ret_out) ep_ret_out[i] = (float)ret;
           if (ep_len_out) ep_len_out[i] = len;
-          st.ep.ep_ret[i] = 0.0; st.ep.ep_len[i] = 0; st.ep.episode[i] = ep;
+          st.ep.ep_ret[i] = 0.0; st.ep.ep_len[i] = 0;
+          __hip_atomic_store(&st.ep.episode[i], ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (have_spare) {                            // next episode already prepared off the critical path
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1240,15 +1266,28 @@ __device__ __forceinline__ void lunar_step_quad(const LunarState& st, const Lds&
           for (int k = 0; k < 8; ++k) o_next[k] = st.spare_obs[(size_t)k * n + i];
           break;
         }
-        init_episode(W, lds, seed, env, ep, fx, fy);
       } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) o_next[k] = o[k];
       }
     }
-    world_io(W, lds, role, st.words, n, i, true);
-    store_obs_quad(obs_out, i, role, o_next);
-    if (term_obs_out) store_obs_quad(term_obs_out, i, role, o_term);
+    if (!refill) {
+      world_io(W, lds, role, st.words, n, i, true);
+      store_obs_quad(obs_out, i, role, o_next);
+      if (term_obs_out) store_obs_quad(term_obs_out, i, role, o_term);
+    } else {                                          // publish the spare: world, observation, then the flag
+      world_io(W, lds, role, st.spare_words, n, i, true);
+      if (role < 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st.spare_obs[(size_t)(4 * role + k) * n + i] = o_next[4 * role + k];
+      }
+      __threadfence();                                // world before flag (the stepping wave may poll it)
+    }
+  }
+  if (refill) {
+    __builtin_amdgcn_wave_barrier();                  // the flag must follow every lane's stores: lanes 1, 2 wrote manifold words
+    if (active && lead) __hip_atomic_store(&st.spare_episode[i], want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return;
   }
   accumulate_ep_stats(ep_stats, done && lead, ret, len);
 }

@@ -42,6 +42,7 @@ static_assert(kDynFloats * 4 <= kDynBytes, "LDS carve-up");
 __global__ __launch_bounds__(kThreads) void rollout_lunar_kernel(gymrl_rollout_lunar_args a, gymrl_mlp_desc d) {
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
   __shared__ uint32_t lds_words[kLdsWords * kEnvBlock];            // the solver's per-lane columns (wave 0)
+  __shared__ uint32_t lds_words_refill[kLdsWords * kEnvBlock];     // the same for the refill wave (wave 1)
   float (*lds)[M::kRows * M::kStride] = reinterpret_cast<float (*)[M::kRows * M::kStride]>(dyn_lds);
   float* xin = dyn_lds + M::kBufs * M::kRows * M::kStride;
   float* head = xin + M::kRows * M::kInStride;
@@ -57,6 +58,11 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_kernel(gymrl_rollout_l
   const Lds slds{lds_words + lane, a.wg_ticks ? reinterpret_cast<unsigned long long*>(a.wg_ticks) + 2 * gridDim.x + 16 * blockIdx.x : nullptr};
 #else
   const Lds slds{lds_words + lane};
+#endif
+#ifdef GYMRL_LUNAR_PROF
+  const Lds rlds{lds_words_refill + lane, nullptr};
+#else
+  const Lds rlds{lds_words_refill + lane};
 #endif
   const double gl = (double)(float)(a.gamma * a.lam);              // NEP-50 float32 decay (see gae.hip)
   if (a.wg_ticks && tid == 0) a.wg_ticks[2 * blockIdx.x] = wall_clock64();   // profiling: 100 MHz ticks
@@ -76,36 +82,43 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_kernel(gymrl_rollout_l
     M::forward_tile(d, lds, xin, head, m0, N, tid); // logits -> head[row][0..3], value -> head[row][4]
     LUNAR_PROF_MARK(rt1);
     if (wave == 0) LUNAR_PROF_ADD(slds, 8, rt0, rt1);   // policy forward
-    if (wave == 0) {
-      float z[kActions];
+    // wave 0 steps the envs; wave 1 (idle otherwise) keeps their next episodes prepared — ONE call site of the solver
+    const bool refill_wave = wave == 1;
+    if (wave == 0 || (refill_wave && !tail && a.refill)) {
+      int act = 0;
+      if (!refill_wave) {
+        float z[kActions];
 #pragma unroll
-      for (int k = 0; k < kActions; ++k) z[k] = head[row * M::kHeadStride + k];
-      const float v = head[row * M::kHeadStride + kActions];
-      if (valid && role == 0) {
-        if (a.gae_running && t > 0) {               // V_t completes step t-1's delta
-          const int tp = t - 1;
-          const size_t o = (size_t)tp * N + i;
-          double2* agg = reinterpret_cast<double2*>(a.gae_workspace) + (size_t)(tp / kGaeChunk) * N;
-          gae_online_compose(a.rew[o], a.done[o], a.val[o], v, a.gamma, gl, (tp % kGaeChunk) == 0,
-                             (tp % kGaeChunk) == kGaeChunk - 1 || tp == T - 1, a.gae_running, agg, N, i);
+        for (int k = 0; k < kActions; ++k) z[k] = head[row * M::kHeadStride + k];
+        const float v = head[row * M::kHeadStride + kActions];
+        if (valid && role == 0) {
+          if (a.gae_running && t > 0) {               // V_t completes step t-1's delta
+            const int tp = t - 1;
+            const size_t o = (size_t)tp * N + i;
+            double2* agg = reinterpret_cast<double2*>(a.gae_workspace) + (size_t)(tp / kGaeChunk) * N;
+            gae_online_compose(a.rew[o], a.done[o], a.val[o], v, a.gamma, gl, (tp % kGaeChunk) == 0,
+                               (tp % kGaeChunk) == kGaeChunk - 1 || tp == T - 1, a.gae_running, agg, N, i);
+          }
+          if (tail) a.next_value[i] = v;
         }
-        if (tail) a.next_value[i] = v;
+        if (!tail) {
+          float lp, H;
+          const size_t o = (size_t)t * N + (valid ? i : 0);
+          act = categorical_pick<kActions>(z, a.noise_exp ? a.noise_exp + o * kActions : nullptr, a.seed,
+                                           (uint64_t)(a.env_id0 + i), a.counter0 + (uint64_t)t, 0, lp, H);
+          if (valid && role == 0) { a.act[o] = act; a.logp[o] = lp; a.val[o] = v; }
+        }
       }
       if (!tail) {
-        float lp, H;
-        const size_t o = (size_t)t * N + (valid ? i : 0);
-        const int act = categorical_pick<kActions>(z, a.noise_exp ? a.noise_exp + o * kActions : nullptr, a.seed,
-                                                   (uint64_t)(a.env_id0 + i), a.counter0 + (uint64_t)t, 0, lp, H);
-        if (valid && role == 0) { a.act[o] = act; a.logp[o] = lp; a.val[o] = v; }
         const StepOut out{a.obs + (size_t)(t + 1) * N * kObs, nullptr, a.rew + (size_t)t * N, nullptr, nullptr,
                           a.done + (size_t)t * N, a.ep_ret ? a.ep_ret + (size_t)t * N : nullptr, nullptr, a.ep_stats};
         float o_next[8];
         LUNAR_PROF_MARK(rt2);
-        LUNAR_PROF_ADD(slds, 9, rt1, rt2);              // GAE compose + draw + slab writes
-        lunar_step_quad(st, slds, N, i, role, valid, act, a.seed, a.env_id0, out, o_next);
+        if (!refill_wave) LUNAR_PROF_ADD(slds, 9, rt1, rt2);          // GAE compose + draw + slab writes
+        lunar_step_quad(st, refill_wave ? rlds : slds, N, i, role, valid, act, a.seed, a.env_id0, out, o_next, refill_wave);
         LUNAR_PROF_MARK(rt3);
-        LUNAR_PROF_ADD(slds, 10, rt2, rt3);             // whole env step (state load, world_step, reward, reset, store)
-        if (valid && role < 2) {                    // next policy input: straight into the forward's LDS tile
+        if (!refill_wave) LUNAR_PROF_ADD(slds, 10, rt2, rt3);         // whole env step (state load, world_step, reward, reset, store)
+        if (!refill_wave && valid && role < 2) {      // next policy input: straight into the forward's LDS tile
 #pragma unroll
           for (int k = 0; k < 4; ++k) xin[row * M::kInStride + 4 * role + k] = o_next[4 * role + k];
         }
@@ -130,6 +143,7 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_mhc_kernel(gymrl_rollo
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];  // (its size keeps one workgroup per CU)
   __shared__ mhc::PolicyLds L;
   __shared__ uint32_t lds_words[kLdsWords * kEnvBlock];            // the solver's per-lane columns (wave 0)
+  __shared__ uint32_t lds_words_refill[kLdsWords * kEnvBlock];     // the same for the refill wave (wave 1)
   float* xin = dyn_lds;                                            // [16][kXStride] observations
   float* head = xin + M::kRows * kXStride;                         // [16][kHeadStride]: logits 0..3, value 4
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -140,7 +154,11 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_mhc_kernel(gymrl_rollo
   const bool valid = i < N;
   const int prow = 4 * wave + (lane >> 4);                         // the policy tile's view: this lane's row
   const LunarState st(a.env_state, N);
-  const Lds slds{lds_words + lane};
+#ifdef GYMRL_LUNAR_PROF
+  const Lds slds{lds_words + lane, nullptr}, rlds{lds_words_refill + lane, nullptr};
+#else
+  const Lds slds{lds_words + lane}, rlds{lds_words_refill + lane};
+#endif
   const bool two = a.gae_running2 != nullptr;
   const double gl = two ? a.gamma * a.lam : (double)(float)(a.gamma * a.lam);
   const double gl2 = a.gamma * a.lam2;
@@ -158,36 +176,42 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_mhc_kernel(gymrl_rollo
     __syncthreads();                                // xin of step t is complete (and the previous step's head reads are done)
     policy_tile_call(p, L, xin + prow * kXStride, head);
     __syncthreads();                                // logits -> head[row][0..3], value -> head[row][4]
-    if (wave == 0) {
-      float z[kActions];
+    const bool refill_wave = wave == 1;               // wave 1 keeps the next episodes prepared while wave 0 steps
+    if (wave == 0 || (refill_wave && !tail && a.refill)) {
+      int act = 0;
+      if (!refill_wave) {
+        float z[kActions];
 #pragma unroll
-      for (int k = 0; k < kActions; ++k) z[k] = head[row * M::kHeadStride + k];
-      const float v = head[row * M::kHeadStride + kActions];
-      if (valid && role == 0) {
-        if (a.gae_running && t > 0) {               // V_t completes step t-1's delta
-          const int tp = t - 1;
-          const size_t o = (size_t)tp * N + i;
-          double2* agg = reinterpret_cast<double2*>(a.gae_workspace) + (size_t)(tp / kGaeChunk) * N;
-          const int first = (tp % kGaeChunk) == 0, last = (tp % kGaeChunk) == kGaeChunk - 1 || tp == T - 1;
-          gae_online_compose(a.rew[o], a.done[o], a.val[o], v, a.gamma, gl, first, last, a.gae_running, agg, N, i);
-          if (two) gae_online_compose(a.rew[o], a.done[o], a.val[o], v, a.gamma, gl2, first, last, a.gae_running2, agg + chunks * N, N, i);
+        for (int k = 0; k < kActions; ++k) z[k] = head[row * M::kHeadStride + k];
+        const float v = head[row * M::kHeadStride + kActions];
+        if (valid && role == 0) {
+          if (a.gae_running && t > 0) {               // V_t completes step t-1's delta
+            const int tp = t - 1;
+            const size_t o = (size_t)tp * N + i;
+            double2* agg = reinterpret_cast<double2*>(a.gae_workspace) + (size_t)(tp / kGaeChunk) * N;
+            const int first = (tp % kGaeChunk) == 0, last = (tp % kGaeChunk) == kGaeChunk - 1 || tp == T - 1;
+            gae_online_compose(a.rew[o], a.done[o], a.val[o], v, a.gamma, gl, first, last, a.gae_running, agg, N, i);
+            if (two) gae_online_compose(a.rew[o], a.done[o], a.val[o], v, a.gamma, gl2, first, last, a.gae_running2, agg + chunks * N, N, i);
+          }
+          if (tail) a.next_value[i] = v;
         }
-        if (tail) a.next_value[i] = v;
+        if (!tail) {
+          float lp, H;
+          const size_t o = (size_t)t * N + (valid ? i : 0);
+          act = categorical_pick<kActions>(z, a.noise_exp ? a.noise_exp + o * kActions : nullptr, a.seed,
+                                           (uint64_t)(a.env_id0 + i), a.counter0 + (uint64_t)t, 0, lp, H);
+          if (valid && role == 0) {
+            a.act[o] = act; a.logp[o] = lp; a.val[o] = v;
+            if (a.ent) a.ent[o] = H;
+          }
+        }
       }
       if (!tail) {
-        float lp, H;
-        const size_t o = (size_t)t * N + (valid ? i : 0);
-        const int act = categorical_pick<kActions>(z, a.noise_exp ? a.noise_exp + o * kActions : nullptr, a.seed,
-                                                   (uint64_t)(a.env_id0 + i), a.counter0 + (uint64_t)t, 0, lp, H);
-        if (valid && role == 0) {
-          a.act[o] = act; a.logp[o] = lp; a.val[o] = v;
-          if (a.ent) a.ent[o] = H;
-        }
         const StepOut out{a.obs + (size_t)(t + 1) * N * kObs, nullptr, a.rew + (size_t)t * N, nullptr, nullptr,
                           a.done + (size_t)t * N, a.ep_ret ? a.ep_ret + (size_t)t * N : nullptr, nullptr, a.ep_stats};
         float o_next[8];
-        lunar_step_quad(st, slds, N, i, role, valid, act, a.seed, a.env_id0, out, o_next);
-        if (valid && role < 2) {                    // next policy input: straight into the forward's LDS tile
+        lunar_step_quad(st, refill_wave ? rlds : slds, N, i, role, valid, act, a.seed, a.env_id0, out, o_next, refill_wave);
+        if (!refill_wave && valid && role < 2) {      // next policy input: straight into the forward's LDS tile
 #pragma unroll
           for (int k = 0; k < 4; ++k) xin[row * kXStride + 4 * role + k] = o_next[4 * role + k];
         }

@@ -805,7 +805,8 @@ def linear_bwd_weight(dy, x, dW, workspace, db=None):
 
 # ------------------------------------------------------ persistent rollout ---
 def rollout_lunar(env_state, n_envs, seed, env_id0, counter0, obs, act, logp, val, rew, done, ep_ret, next_value, policy_desc,
-                  T, t0, nsteps, gamma, lam, noise_exp=None, gae_running=None, gae_workspace=None, ep_stats=None, wg_ticks=None):
+                  T, t0, nsteps, gamma, lam, noise_exp=None, gae_running=None, gae_workspace=None, ep_stats=None, wg_ticks=None,
+                  refill=True):
     """gymrl_rollout_lunar: `nsteps` vector steps of collect_rollout (policy forward, draw, env step, slab writes,
     online GAE) in one launch; see include/gymrl.h for the slab layout."""
     a = RolloutLunarArgs()
@@ -817,13 +818,13 @@ def rollout_lunar(env_state, n_envs, seed, env_id0, counter0, obs, act, logp, va
     a.gae_running, a.gae_workspace = _ptr(gae_running, torch.float64, True).value, _ptr(gae_workspace, None, True).value
     a.gamma, a.lam, a.ep_stats = gamma, lam, _ptr(ep_stats, torch.float64, True).value
     a.wg_ticks = _ptr(wg_ticks, torch.int64, True).value
-    a.T, a.t0, a.nsteps = T, t0, nsteps
+    a.T, a.t0, a.nsteps, a.refill = T, t0, nsteps, int(bool(refill))
     check(lib().gymrl_rollout_lunar(C.byref(a), C.byref(policy_desc), _stream()), "gymrl_rollout_lunar")
 
 
 def rollout_lunar_mhc(env_state, n_envs, seed, env_id0, counter0, obs, act, logp, val, rew, done, ep_ret, next_value, policy_desc,
                       T, t0, nsteps, gamma, lam, ent=None, lam2=0.0, noise_exp=None, gae_running=None, gae_running2=None,
-                      gae_workspace=None, ep_stats=None):
+                      gae_workspace=None, ep_stats=None, refill=True):
     """gymrl_rollout_lunar_mhc: the persistent LunarLander rollout with PPO-full's mHC network (a filled _lib.MhcPolicy) as the
     policy; `ent` [T, N] receives the behaviour entropies, gae_running2 / lam2 switch the decoupled-lambda maps on."""
     a = RolloutLunarArgs()
@@ -835,7 +836,7 @@ def rollout_lunar_mhc(env_state, n_envs, seed, env_id0, counter0, obs, act, logp
     a.gae_running, a.gae_workspace = _ptr(gae_running, torch.float64, True).value, _ptr(gae_workspace, None, True).value
     a.gae_running2, a.lam2, a.ent = _ptr(gae_running2, torch.float64, True).value, lam2, _ptr(ent, torch.float32, True).value
     a.gamma, a.lam, a.ep_stats = gamma, lam, _ptr(ep_stats, torch.float64, True).value
-    a.T, a.t0, a.nsteps = T, t0, nsteps
+    a.T, a.t0, a.nsteps, a.refill = T, t0, nsteps, int(bool(refill))
     check(lib().gymrl_rollout_lunar_mhc(C.byref(a), C.byref(policy_desc), _stream()), "gymrl_rollout_lunar_mhc")
 
 

@@ -37,6 +37,7 @@ class Config:
         self.mhc_layers = 2
         self.mhc_sk_it = 10
         self.persistent_rollout = True    # LunarLander + the default network shape: the rollout as one launch (gymrl_rollout_lunar_mhc)
+        self.rollout_refill = True        # ... whose wave 1 prepares every env's next episode while wave 0 steps
         self.max_train_steps = 5e6
         self.update_freq = 4096            # steps PER ENV per rollout
         self.num_epochs = 4
@@ -583,7 +584,8 @@ class PPOTrainer:
                                   ent=b.old_entropies, lam2=cfg.lam_critic, noise_exp=noise,
                                   gae_running=self._gae_run[0] if fuse_gae else None,
                                   gae_running2=self._gae_run[1] if fuse_gae else None,
-                                  gae_workspace=self._gae_ws if fuse_gae else None, ep_stats=env.ep_stats)
+                                  gae_workspace=self._gae_ws if fuse_gae else None, ep_stats=env.ep_stats,
+                                  refill=getattr(cfg, "rollout_refill", True))
             self.step_count += b.T * b.N
             self.rollout_count += 1
             self._agg_ready = fuse_gae

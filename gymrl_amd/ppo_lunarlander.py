@@ -64,6 +64,7 @@ class Config:
         self.persistent_rollout = True    # LunarLander: whole chunks of vector steps in one launch (gymrl_rollout_lunar)
         self.rollout_chunk = 0            # vector steps per persistent launch (0: the whole rollout in one launch —
                                           # every extra launch boundary waits for the slowest workgroup again)
+        self.rollout_refill = True        # persistent rollout: wave 1 prepares every env's next episode while wave 0 steps
         self.solved_reward = 200.0
 
 
@@ -351,7 +352,7 @@ class PPOTrainer:
                               b.rewards, b.dones, b.ep_returns, self._next_value, desc, b.T, t0, n, cfg.gamma,
                               cfg.gae_lambda, noise_exp=noise, gae_running=self._gae_running if fuse_gae else None,
                               gae_workspace=self._gae_ws if fuse_gae else None, ep_stats=env.ep_stats,
-                              wg_ticks=self._wg_ticks)
+                              wg_ticks=self._wg_ticks, refill=getattr(cfg, "rollout_refill", True))
             if tm is not None:
                 tm.stop("rollout_chunk", n * b.N)
         b.pos = b.T

@@ -452,6 +452,11 @@ typedef struct {
   float* ent;                 /* f32[T][N] or NULL: entropy of the behaviour policy at every step             */
   double lam2;                /* decoupled-lambda GAE (G3): the critic's lambda, with gae_running2             */
   double* gae_running2;       /* f64[2][N] or NULL; with it gae_workspace is gymrl_gae_decoupled_workspace_bytes(T, N) */
+  /* both kernels: */
+  int refill;                 /* != 0: while wave 0 steps the envs, wave 1 of the workgroup keeps every env's NEXT episode
+                               * prepared in the state buffer's spare world (reset() ends with a full physics step; built inline
+                               * it stalls the 15 other envs of the wave on every step an episode ends).  A spare is a pure
+                               * function of (seed, env id, episode): the slab is bit-identical either way.             */
 } gymrl_rollout_lunar_args;
 int gymrl_rollout_lunar(const gymrl_rollout_lunar_args* args, const gymrl_mlp_desc* policy, void* stream);
 /* The same persistent rollout for PPO-full (ppo_full_lunarlander.py collect_experience :440-505): the policy is the mHC network

@@ -567,6 +567,45 @@ def test_persistent_rollout_bit_identical_to_stepwise(dev, N, T, chunk, hidden):
         assert torch.equal(adv_a, adv_b) and torch.equal(ret_a, ret_b) and torch.equal(a._moments, b._moments)
 
 
+def test_persistent_rollout_refill_wave_changes_nothing(dev):
+    """The persistent kernel's wave 1 prepares every env's next episode while wave 0 steps (cfg.rollout_refill): a spare
+    world is a pure function of (seed, env id, episode), so slab, env worlds and statistics equal the inline-reset run
+    bit for bit — and the spares are really used: after the rollout every env holds the spare of its next episode."""
+    from gymrl_amd import ops
+    from gymrl_amd.ppo_lunarlander import Config, PPOTrainer
+
+    def make(refill):
+        cfg = Config()
+        cfg.num_envs, cfg.update_freq, cfg.num_epochs, cfg.num_minibatches, cfg.seed = 200, 260, 1, 2, 3
+        cfg.rollout_refill = refill
+        return PPOTrainer(cfg)
+    a, b = make(True), make(False)
+    for rollout in range(2):
+        assert torch.equal(a.collect_rollout(), b.collect_rollout())
+        for name in ("states", "actions", "log_probs", "values", "rewards", "dones"):
+            assert torch.equal(getattr(a.buffer, name), getattr(b.buffer, name)), (rollout, name)
+        assert int(a.buffer.dones.sum()) > 200                     # every env finished episodes inside the rollout
+        assert torch.equal(a.env.ep_stats, b.env.ep_stats)
+        words = 144 * 4 * 200                                      # the live worlds (first field of the state buffer)
+        pad = (words + 255) // 256 * 256
+        assert torch.equal(a.env.state[:words], b.env.state[:words])
+        # bookkeeping fields follow: ep_ret f64, ep_len i32, episode u32 — then the spare world, its obs and its episode tag
+        off = pad
+        off += (8 * 200 + 255) // 256 * 256
+        off += (4 * 200 + 255) // 256 * 256
+        episode = a.env.state[off:off + 800].view(torch.int32)
+        off += (4 * 200 + 255) // 256 * 256
+        off += pad
+        off += (4 * 8 * 200 + 255) // 256 * 256
+        spare_ep = a.env.state[off:off + 800].view(torch.int32)
+        assert off + (800 + 255) // 256 * 256 == a.env.state.numel()
+        # wave 1 keeps every spare one episode ahead (the env that ended on the very last step may still be waiting)
+        assert int((spare_ep == episode + 1).sum()) >= 190
+        # without the refill wave only VecEnv.reset()'s side-stream launch ever builds a spare (episode 1); every later
+        # episode end ran its reset inline
+        assert bool((b.env.state[off:off + 800].view(torch.int32) == 1).all()) and int(episode.min()) >= 2
+
+
 def test_permutation_bit_exact_vs_oracle(dev, oracle):
     """gymrl_permutation: integer work, bit-exact against the restatement; at BASELINE's rollout size (2^23) checked
     through the size-independent property instead (a bijection: every index exactly once)."""

@@ -15,10 +15,12 @@ from gymrl_amd.ppo_lunarlander import Config, PPOTrainer  # noqa: E402
 N, T = 4096, int(sys.argv[1]) if len(sys.argv) > 1 else 512
 cfg = Config()
 cfg.num_envs, cfg.update_freq, cfg.seed, cfg.rollout_chunk = N, T, 0, T
+cfg.rollout_refill = os.environ.get("GYMRL_REFILL", "1") != "0"
 sys.stdout = open(os.devnull, "w")
 tr = PPOTrainer(cfg)
 sys.stdout = sys.__stdout__
 tr.collect_rollout()
+tr.rollout_count = 0                                   # profile the same rollout whatever ran before
 G = N // 16
 tr._wg_ticks = torch.zeros(2 * G + 16 * G, dtype=torch.int64, device=tr.device)
 tr.collect_rollout()

@@ -15,12 +15,17 @@ cfg.num_envs, cfg.update_freq, cfg.seed, cfg.persistent_rollout, cfg.rollout_chu
 sys.stdout = open(os.devnull, "w")
 tr = PPOTrainer(cfg)
 sys.stdout = sys.__stdout__
-tr.collect_rollout()
-torch.cuda.synchronize()
-ts = []
-for _ in range(3):
-    t0 = time.perf_counter()
+for refill in (False, True, False, True):             # A/B in one process: the in-kernel refill wave off / on
+    cfg.rollout_refill = refill
+    tr.rollout_count = 0                               # the SAME rollout every time (Philox counters restart)
     tr.collect_rollout()
     torch.cuda.synchronize()
-    ts.append((time.perf_counter() - t0) / T * 1e6)
-print("us per vector step:", [round(t, 1) for t in ts])
+    ts = []
+    for _ in range(2):
+        tr.rollout_count = 0
+        t0 = time.perf_counter()
+        tr.collect_rollout()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / T * 1e6)
+    print(f"refill={refill}: us per vector step:", [round(t, 1) for t in ts], "episodes finished per rollout:",
+          int(tr.buffer.dones.sum()))
