@@ -288,6 +288,192 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(WsArgs p) {
   }
 }
 
+
+// ------------------------------------------------------------------ narrow reductions (RED = 64 / 128) ------
+// The 64- and 128-wide layers (PPO-full's mHC network at 262,144-row micro-batches: ppo_full_lunarlander.py:197-229, :287-318;
+// ActorCritic at hidden_dim 64 / 128) are as much HBM- as MFMA-bound: 1 KB of operand + result per row against 33 kFLOP at
+// 128 x 128.  Same product, same accumulation order as gemm_ws_kernel (so the oracle's fmaf chain restates both), but:
+//   * the whole weight slice [RED x BN] is at most 64 KiB, which leaves LDS for the row tiles: a wave moves its next 32-row
+//     tile from HBM with fully coalesced 16-byte loads (one contiguous 1-KiB segment per instruction: the tile is 32 * RED
+//     consecutive floats) into registers while it multiplies the current one, then parks it in its own padded LDS tile
+//     (pitch RED + 4 floats: the MFMA-layout read of 32 rows x 16 bytes is conflict free).  The direct-to-register
+//     MFMA-layout loads of gemm_ws_kernel fetch 32 separate 32-byte pieces per instruction, which a 256 / 512-long reduction
+//     amortises over its L1 hits and a 128-long one does not (the round-2 kernel without staging: 110 us against the
+//     library's 97 at 262,144 x 128 x 128);
+//   * nothing is shared between waves after the weight fill — no barrier inside the row loop, a wave's LDS traffic is
+//     ordered by the LDS queue itself.
+// A wave owns 32 rows x BN columns per tile; D = W_tile X_tile^T as above (lane (i, h) holds 4 adjacent output columns of
+// row i per accumulator quad: 16-byte stores / H loads).
+template <int RED, int NT, bool TRANS_W, int EPI, int LDO>
+__global__ __launch_bounds__(256) void gemm_ns_kernel(WsArgs p) {
+  constexpr int BN = 32 * NT, NCH = RED / 8, kWaves = 4, kThreads = 256, ROWS = 32;
+  constexpr int APITCH = RED + 4, OPITCH = BN + 4;                  // padded pitches: conflict-free MFMA-layout accesses
+  constexpr int TILE = ROWS * (APITCH > OPITCH ? APITCH : OPITCH);  // floats: the wave's tile holds A rows, then its output rows
+  constexpr int NLD = ROWS * RED / 4 / 64, NST = ROWS * BN / 4 / 64; // float4 loads / stores per lane and row tile
+  static_assert(RED % 8 == 0 && (ROWS * RED / 4) % 64 == 0 && (ROWS * BN / 4) % 64 == 0, "tile tiling");
+  static_assert((RED * BN + BN + kWaves * TILE) * 4 <= 160 * 1024, "weight slice + row tiles must fit LDS");
+  __shared__ float lds[RED * BN + BN];                 // [q = 2c + h][n][4]: value W(red = 4q + e, n); then bias[BN]
+  __shared__ float tiles[kWaves][TILE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int S = p.slices, RG = gridDim.x / S, b = blockIdx.x;
+  int slice, rg;
+  if ((RG & 7) == 0) { const int xcd = b & 7, r = b >> 3; slice = r % S; rg = (r / S) * 8 + xcd; }
+  else { slice = b % S; rg = b / S; }
+  const int n0 = slice * BN;
+
+  const int64_t M = p.M;
+  const int64_t tasks = (M + ROWS - 1) / ROWS;
+  const int64_t bt_count = (tasks + kWaves - 1) / kWaves;
+  auto rows_of = [&](int64_t task) {
+    int64_t r = M - task * ROWS;
+    return (uint32_t)(r < 0 ? 0 : (r > ROWS ? ROWS : r));
+  };
+  // the A tile is one contiguous block of 32 * RED floats: float4 number j * 64 + lane of it — a wave-wide load is one
+  // contiguous 1-KiB segment
+  auto fetch = [&](int64_t task, f32x4 (&v)[NLD]) {
+    const __amdgpu_buffer_rsrc_t r = make_rsrc(p.A + task * ROWS * RED, rows_of(task) * RED * 4u);
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) v[j] = bload4(r, (uint32_t)(j * 64 + lane) * 16u);
+  };
+  int64_t bt = rg;
+  f32x4 nxt[NLD];
+  fetch(bt * kWaves + wave, nxt);                       // in flight under the weight fill
+
+  {
+    constexpr int ITER = BN * (RED / 4) / kThreads, BATCH = ITER < 8 ? ITER : 8;
+    static_assert(BN * (RED / 4) % kThreads == 0 && ITER % BATCH == 0, "fill tiling");
+#pragma unroll 1
+    for (int it0 = 0; it0 < ITER; it0 += BATCH) {
+      f32x4 v[BATCH];
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        const int idx = tid + (it0 + k) * kThreads, n = idx % BN, q = idx / BN;
+        if constexpr (!TRANS_W) {
+          v[k] = *reinterpret_cast<const f32x4*>(p.W + (size_t)(n0 + n) * p.ldw + 4 * q);
+        } else {
+          const float* w = p.W + (size_t)(4 * q) * p.ldw + n0 + n;
+          v[k] = f32x4{w[0], w[p.ldw], w[2 * (size_t)p.ldw], w[3 * (size_t)p.ldw]};
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        const int idx = tid + (it0 + k) * kThreads, n = idx % BN, q = idx / BN;
+        *reinterpret_cast<f32x4*>(&lds[((size_t)q * BN + n) * 4]) = v[k];
+      }
+    }
+  }
+  if (tid < BN) lds[RED * BN + tid] = (EPI != EPI_TANHBWD && p.bias) ? p.bias[n0 + tid] : 0.0f;
+  __syncthreads();
+
+  float* tile = tiles[wave];
+  const f32x4* bl = reinterpret_cast<const f32x4*>(lds) + (size_t)h * BN + i;   // + c * 2 * BN + 32 * nt
+  const f32x4* bias4 = reinterpret_cast<const f32x4*>(lds + RED * BN) + h;      // + (32 nt + 8 g) / 4
+  const float* arow = tile + i * APITCH + 4 * h;                                // + 8 c
+  float* orow = tile + i * OPITCH + 4 * h;                                      // + 32 nt + 8 g
+  auto park = [&](const f32x4 (&v)[NLD]) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int f4 = j * 64 + lane, r = f4 / (RED / 4), c4 = f4 % (RED / 4);
+      *reinterpret_cast<f32x4*>(tile + r * APITCH + 4 * c4) = v[j];
+    }
+  };
+  park(nxt);
+#pragma unroll 1
+  for (; bt < bt_count; bt += RG) {
+    const int64_t task = bt * kWaves + wave;
+    const uint32_t rows = rows_of(task);
+    fetch((bt + RG) * kWaves + wave, nxt);             // past the end: zero rows, the loads return 0
+    // H (tanh' factor) of this tile's output rows, coalesced like A: float4 j * 64 + lane of the [32][BN] block at column n0
+    f32x4 hv[NST];
+    if constexpr (EPI == EPI_TANHBWD) {
+      const __amdgpu_buffer_rsrc_t chh = make_rsrc(p.H + task * ROWS * LDO + n0, p.H ? rows * LDO * 4u - (rows ? n0 * 4u : 0u) : 0u);
+#pragma unroll
+      for (int j = 0; j < NST; ++j) {
+        const int f4 = j * 64 + lane, r = f4 / (BN / 4), c4 = f4 % (BN / 4);
+        hv[j] = bload4(chh, (uint32_t)(r * LDO + 4 * c4) * 4u);
+      }
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+    // reduction: the next chunk's LDS operands are requested before the current chunk's 4 NT MFMAs (pinned: left alone, the
+    // scheduler sinks every read next to its use behind an lgkmcnt(0))
+    f32x4 a4 = *reinterpret_cast<const f32x4*>(arow), b4[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b4[nt] = bl[32 * nt];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      f32x4 an = a4, bn[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bn[nt] = b4[nt];
+      if (c + 1 < NCH) {
+        an = *reinterpret_cast<const f32x4*>(arow + 8 * (c + 1));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bn[nt] = bl[(size_t)(c + 1) * 2 * BN + 32 * nt];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(b4[nt][e], a4[e], acc[nt]);
+      __builtin_amdgcn_sched_barrier(0);
+      a4 = an;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b4[nt] = bn[nt];
+    }
+    // epilogue: the outputs go through the wave's tile (its A rows are consumed) so that the global stores are whole
+    // contiguous row segments — lane (i, h) holds 4 adjacent columns of row i per accumulator quad
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = bias4[(32 * nt + 8 * g) / 4];
+        f32x4 x4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float v = acc[nt][4 * g + q];
+          if constexpr (EPI == EPI_TANH) {                 // train_tanhf(v + bias), as gemm_ws_kernel's stages
+            float x = v + bv[q];
+            x = x * 2.885390081777927f;
+            x = __builtin_amdgcn_exp2f(x);
+            x = x + 1.0f;
+            x = __builtin_amdgcn_rcpf(x);
+            x4[q] = fmaf(-2.0f, x, 1.0f);
+          } else if constexpr (EPI == EPI_NONE) {
+            x4[q] = v + bv[q];
+          } else {
+            x4[q] = v;                                     // the tanh' factor is applied on the way out (below)
+          }
+        }
+        *reinterpret_cast<f32x4*>(orow + 32 * nt + 8 * g) = x4;
+      }
+    {
+      const __amdgpu_buffer_rsrc_t co = make_rsrc(p.out + task * ROWS * LDO + n0, rows * LDO * 4u - (rows ? n0 * 4u : 0u));
+#pragma unroll
+      for (int j = 0; j < NST; ++j) {
+        const int f4 = j * 64 + lane, r = f4 / (BN / 4), c4 = f4 % (BN / 4);
+        f32x4 x4 = *reinterpret_cast<const f32x4*>(tile + r * OPITCH + 4 * c4);
+        if constexpr (EPI == EPI_TANHBWD) {
+          if (p.H) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float x = hv[j][q] * hv[j][q];
+              x = 1.0f - x;
+              x4[q] = x4[q] * x;
+            }
+          }
+        }
+        bstore4(co, (uint32_t)(r * LDO + 4 * c4) * 4u, x4);
+      }
+    }
+    park(nxt);                                          // (the LDS queue orders these writes behind this tile's reads)
+  }
+}
+
 // ------------------------------------------------------------------ dW ------
 struct TnArgs {
   const float* dY; int ldy;
@@ -479,6 +665,18 @@ void launch_ws(const WsArgs& a, int rg, hipStream_t s) {
   hipLaunchKernelGGL((gemm_ws_kernel<RED, NT, RT, TRANS_W, EPI, LDO>), grid, block, 0, s, a);
 }
 
+template <int RED, int NT, bool TRANS_W, int EPI, int LDO>
+void launch_ns(const WsArgs& a, hipStream_t s) {
+  // 32-row tasks; up to two workgroups per CU where the LDS footprint allows (the kernel is as much HBM- as MFMA-bound)
+  constexpr int lds_bytes = (RED * 32 * NT + 32 * NT + 4 * 32 * (RED + 4)) * 4;
+  const int per_cu = lds_bytes <= 80 * 1024 ? 2 : 1;
+  const int64_t tasks = (a.M + 31) / 32, bts = (tasks + 3) / 4;
+  int64_t rg = (int64_t)kCUs * per_cu / a.slices;
+  if (bts < rg) rg = bts;
+  if (rg < 1) rg = 1;
+  hipLaunchKernelGGL((gemm_ns_kernel<RED, NT, TRANS_W, EPI, LDO>), dim3((unsigned)(rg * a.slices)), dim3(256), 0, s, a);
+}
+
 inline void tn_geometry(int64_t B, int N, int* slices, int64_t* rps) {
   const int ntiles = N / 256;
   int s = kCUs / ntiles;
@@ -521,20 +719,32 @@ int gymrl_linear_bwd_weight_geometry(int64_t B, int N, int* slices, int64_t* row
 
 int gymrl_linear_fwd(const float* X, const float* W, const float* b, int64_t B, int K, int N, int act, float* Y,
                      void* stream) {
-  if (!X || !W || !Y || B < 0 || K != 256 || (N != 256 && N != 512) || (act != 0 && act != 1) || !al16(X) || !al16(W) ||
-      !al16(Y))
+  const bool wide = K == 256 && (N == 256 || N == 512);
+  const bool narrow = (K == 64 || K == 128) && (N == K || N == 2 * K);
+  if (!X || !W || !Y || B < 0 || !(wide || narrow) || (act != 0 && act != 1) || !al16(X) || !al16(W) || !al16(Y))
     return -22;
   if (B == 0) return 0;
   WsArgs a{};
-  a.A = X; a.M = B; a.lda = K; a.W = W; a.ldw = K; a.out = Y; a.ldo = N; a.bias = b; a.slices = N / 128;
-  const int rg = ws_row_groups(B, 64, a.slices);
+  a.A = X; a.M = B; a.lda = K; a.W = W; a.ldw = K; a.out = Y; a.ldo = N; a.bias = b;
   hipStream_t s = (hipStream_t)stream;
-  if (N == 256) {
-    if (act == 1) launch_ws<256, 4, 2, false, EPI_TANH, 256>(a, rg, s);
-    else launch_ws<256, 4, 2, false, EPI_NONE, 256>(a, rg, s);
-  } else {
-    if (act == 1) launch_ws<256, 4, 2, false, EPI_TANH, 512>(a, rg, s);
-    else launch_ws<256, 4, 2, false, EPI_NONE, 512>(a, rg, s);
+  if (wide) {
+    a.slices = N / 128;
+    const int rg = ws_row_groups(B, 64, a.slices);
+    if (N == 256) {
+      if (act == 1) launch_ws<256, 4, 2, false, EPI_TANH, 256>(a, rg, s);
+      else launch_ws<256, 4, 2, false, EPI_NONE, 256>(a, rg, s);
+    } else {
+      if (act == 1) launch_ws<256, 4, 2, false, EPI_TANH, 512>(a, rg, s);
+      else launch_ws<256, 4, 2, false, EPI_NONE, 512>(a, rg, s);
+    }
+  } else if (K == 128) {                      // column slices of 128
+    a.slices = N / 128;
+    if (N == 128) { if (act == 1) launch_ns<128, 4, false, EPI_TANH, 128>(a, s); else launch_ns<128, 4, false, EPI_NONE, 128>(a, s); }
+    else { if (act == 1) launch_ns<128, 4, false, EPI_TANH, 256>(a, s); else launch_ns<128, 4, false, EPI_NONE, 256>(a, s); }
+  } else {                                    // K == 64: column slices of 64
+    a.slices = N / 64;
+    if (N == 64) { if (act == 1) launch_ns<64, 2, false, EPI_TANH, 64>(a, s); else launch_ns<64, 2, false, EPI_NONE, 64>(a, s); }
+    else { if (act == 1) launch_ns<64, 2, false, EPI_TANH, 128>(a, s); else launch_ns<64, 2, false, EPI_NONE, 128>(a, s); }
   }
   GYMRL_CHECK_LAUNCH();
   return 0;
@@ -542,19 +752,30 @@ int gymrl_linear_fwd(const float* X, const float* W, const float* b, int64_t B, 
 
 int gymrl_linear_bwd_input(const float* dY, const float* W, const float* H, int64_t B, int N, int K, float* dX,
                            void* stream) {
-  if (!dY || !W || !dX || B < 0 || K != 256 || (N != 256 && N != 512) || !al16(dY) || !al16(W) || !al16(dX) ||
-      (H && !al16(H)))
+  const bool wide = K == 256 && (N == 256 || N == 512);
+  const bool narrow = (K == 64 || K == 128) && (N == K || N == 2 * K);
+  if (!dY || !W || !dX || B < 0 || !(wide || narrow) || !al16(dY) || !al16(W) || !al16(dX) || (H && !al16(H)))
     return -22;
   if (B == 0) return 0;
   WsArgs a{};
   a.A = dY; a.M = B; a.lda = N; a.W = W; a.ldw = K; a.out = dX; a.ldo = K; a.H = H; a.ldh = K;
   hipStream_t s = (hipStream_t)stream;
-  if (N == 256) {
-    a.slices = 2;
-    launch_ws<256, 4, 2, true, EPI_TANHBWD, 256>(a, ws_row_groups(B, 64, 2), s);
+  if (wide) {
+    if (N == 256) {
+      a.slices = 2;
+      launch_ws<256, 4, 2, true, EPI_TANHBWD, 256>(a, ws_row_groups(B, 64, 2), s);
+    } else {
+      a.slices = 4;
+      launch_ws<512, 2, 2, true, EPI_TANHBWD, 256>(a, ws_row_groups(B, 64, 4), s);
+    }
+  } else if (K == 128) {
+    a.slices = 1;                             // one 128-column slice: the whole [N x 128] matrix is the workgroup's
+    if (N == 128) launch_ns<128, 4, true, EPI_TANHBWD, 128>(a, s);
+    else launch_ws<256, 4, 2, true, EPI_TANHBWD, 128>(a, ws_row_groups(B, 64, 1), s);     // reduction over 256: streamed rows
   } else {
-    a.slices = 4;
-    launch_ws<512, 2, 2, true, EPI_TANHBWD, 256>(a, ws_row_groups(B, 64, 4), s);
+    a.slices = 1;
+    if (N == 64) launch_ns<64, 2, true, EPI_TANHBWD, 64>(a, s);
+    else launch_ns<128, 2, true, EPI_TANHBWD, 64>(a, s);
   }
   GYMRL_CHECK_LAUNCH();
   return 0;

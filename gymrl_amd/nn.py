@@ -49,7 +49,7 @@ def small_linear(x, weight, bias):
     """F.linear for the 128-8192 row batches of the off-policy networks as a plain GEMM + in-place bias add.
     torch.addmm's fused-bias form always goes to hipBLASLt, whose default pick for these shapes is one
     256 x 256 macro tile (37 us at 256 or 8192 rows x 256 x 256, rocprofv3: 6 such calls = a quarter of a Rainbow
-    vector step); the plain GEMM follows gymrl_amd/blas.py's library preference (rocBLAS: 6-15 us) and the bias
+    vector step); the plain GEMM is the library's (rocBLAS answers these shapes in 6-15 us; tools/blas_pref.py scopes the preference for A/B runs) and the bias
     costs one 4 us elementwise launch."""
     if SPLIT_BIAS and x.dim() == 2 and bias is not None:
         return torch.mm(x, weight.t()).add_(bias)
@@ -167,17 +167,22 @@ def _wide(x, weight):
 
 class _WideLinear(torch.autograd.Function):
     """A Linear layer beyond `_fusable` at a large batch (PPO-full's 128 -> 256 head layers at 262144-row micro-batches):
-    forward and input gradient stay with the library GEMM (97 / 96 us at 262144 x 128 x 128, where the one-wave-per-tile
-    layer kernels need 250: `profiles/r02_micro_lin_large.json`); the weight + bias gradient — a [N, B] x [B, K] product
-    the library answers with a 32 x 32 x 256 macro tile in 491 us plus a column-sum launch — is one gymrl_lin_bwd_weight
-    call (64 x 64 blocks per wave: 110 us), written straight into an armed GradSink's buffer."""
+    forward and input gradient are gymrl_linear_fwd / gymrl_linear_bwd_input (csrc/gemm.hip: weight-stationary exact-f32
+    MFMA kernels; the 64- / 128-long reductions stage their row tiles through LDS) for the shapes they cover
+    (`ops.linear_shape_ok`), the weight + bias gradient one gymrl_lin_bwd_weight call (64 x 64 blocks per wave: 110 us
+    where the library's [N, B] x [B, K] product takes 491 plus a column-sum launch), written straight into an armed
+    GradSink's buffer.  Other shapes: the library GEMM."""
 
     @staticmethod
     def forward(ctx, x, w, b):
+        from . import ops
         x = x.contiguous()
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         ctx.sinks = (getattr(w, "_gymrl_sink", None), None if b is None else getattr(b, "_gymrl_sink", None))
+        ctx.own = ops.linear_shape_ok(w.shape[1], w.shape[0]) and w.is_contiguous() and x.data_ptr() % 16 == 0
+        if ctx.own:
+            return ops.linear_fwd(x, w, b, torch.empty(x.shape[0], w.shape[0], device=x.device), act=False)
         return F.linear(x, w, b)                     # bias in the GEMM's epilogue: a separate add is a 270 MB pass at 262144 rows
 
     @staticmethod
@@ -185,7 +190,12 @@ class _WideLinear(torch.autograd.Function):
         from . import ops
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = torch.mm(dy, w) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.own and dy.data_ptr() % 16 == 0:
+                dx = ops.linear_bwd_input(dy, w, None, torch.empty_like(x))
+            else:
+                dx = torch.mm(dy, w)
         dw = db = None
         if ctx.needs_input_grad[1]:
             slot = GradSink_direct(ctx.sinks[0], ctx.sinks[1], ctx.has_bias)

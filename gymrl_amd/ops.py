@@ -769,8 +769,14 @@ def gemm_config(key, value):
     check(L.gymrl_gemm_config(C.c_int(key), C.c_int(value)), "gymrl_gemm_config")
 
 
+def linear_shape_ok(K, N):
+    """Shapes gymrl_linear_fwd (x [B, K] -> [B, N]) and gymrl_linear_bwd_input (dy [B, N] -> [B, K]) cover: K in
+    {64, 128} with N in {K, 2K}; K = 256 with N in {256, 512}."""
+    return (K in (64, 128) and N in (K, 2 * K)) or (K == 256 and N in (256, 512))
+
+
 def linear_fwd(x, W, b, out, act=True):
-    """out [B, N] = tanh(x [B, 256] W[N, 256]^T + b) (act=False: no tanh) — exact-f32 MFMA, fused epilogue."""
+    """out [B, N] = tanh(x [B, K] W[N, K]^T + b) (act=False: no tanh; b None: no bias) — exact-f32 MFMA, fused epilogue."""
     B, K = x.shape
     check(lib().gymrl_linear_fwd(_ptr(x, torch.float32), _ptr(W, torch.float32), _ptr(b, torch.float32, True),
                                  C.c_int64(B), C.c_int(K), C.c_int(W.shape[0]), C.c_int(int(act)), _ptr(out, torch.float32),
@@ -779,7 +785,7 @@ def linear_fwd(x, W, b, out, act=True):
 
 
 def linear_bwd_input(dy, W, H, dx):
-    """dx [B, 256] = (dy [B, N] W[N, 256]) * (1 - H^2)  (H None: no factor)."""
+    """dx [B, K] = (dy [B, N] W[N, K]) * (1 - H^2)  (H None: no factor)."""
     B, N = dy.shape
     check(lib().gymrl_linear_bwd_input(_ptr(dy, torch.float32), _ptr(W, torch.float32), _ptr(H, torch.float32, True),
                                        C.c_int64(B), C.c_int(N), C.c_int(W.shape[1]), _ptr(dx, torch.float32), _stream()),

@@ -176,7 +176,8 @@ class _MhcGates(torch.autograd.Function):
         return d_h, d_nw, d_w, d_alpha, d_beta, None
 
 
-_LIBRARY_ROWS = 16384       # rows from which a 128-wide GEMM is the library's (forward / input gradient only)
+_LIBRARY_ROWS = 16384       # rows from which a 128-wide product leaves the one-wave-per-tile layer kernels for the weight-stationary
+                            # GEMM kernels of csrc/gemm.hip (forward / input gradient; other widths: the library)
 
 
 class _MhcSub(torch.autograd.Function):
@@ -197,7 +198,12 @@ class _MhcSub(torch.autograd.Function):
         pre, post, mix, read, stats = ops.mhc_gates(h, norm_w, w, alpha, beta, sk_it, stats=True)
         # the Linear: the layer kernels below _LIBRARY_ROWS rows (one launch, bias inside), the library GEMM above (97 us at
         # 262144 x 128 x 128 against 256: profiles/r02_micro_lin_large.json)
-        z = torch.addmm(b, read, W.t()) if h.shape[0] >= _LIBRARY_ROWS else ops.lin_fwd(read, W, b)
+        if h.shape[0] >= _LIBRARY_ROWS and ops.linear_shape_ok(W.shape[1], W.shape[0]):
+            z = ops.linear_fwd(read, W, b, torch.empty(read.shape[0], W.shape[0], device=read.device), act=False)
+        elif h.shape[0] >= _LIBRARY_ROWS:
+            z = torch.addmm(b, read, W.t())
+        else:
+            z = ops.lin_fwd(read, W, b)
         ctx.save_for_backward(h, norm_w, w, alpha, pre, post, mix, stats, read, z, W)
         return ops.mhc_combine(post, mix, z, h, act=ops.LIN_ACT["silu"])
 
@@ -206,7 +212,9 @@ class _MhcSub(torch.autograd.Function):
         h, norm_w, w, alpha, pre, post, mix, stats, read, z, W = ctx.saved_tensors
         g = g.contiguous()
         d_post, d_mix, d_z, _ = ops.mhc_combine_bwd(g, post, mix, z, h, act=ops.LIN_ACT["silu"], want_dh=False)
-        if h.shape[0] >= _LIBRARY_ROWS:
+        if h.shape[0] >= _LIBRARY_ROWS and ops.linear_shape_ok(W.shape[1], W.shape[0]):
+            d_read = ops.linear_bwd_input(d_z, W, None, torch.empty_like(read))      # csrc/gemm.hip, exact f32 MFMA
+        elif h.shape[0] >= _LIBRARY_ROWS:
             d_read = torch.mm(d_z, W)
         else:
             d_read, _ = ops.lin_bwd_input(d_z, z, W)
@@ -768,14 +776,8 @@ class PPOTrainer:
                 "cov": float(cov.mean())}
 
     def train(self):
-        """:681-700; minibatches of a few thousand rows run their GEMMs on the library that answers them fastest
-        (gymrl_amd/blas.py)."""
-        from .blas import small_gemm_backend
-        cfg, b = self.cfg, self.buffer
-        total = b.T * b.N
-        mb = max(1, total // int(cfg.num_minibatches)) if cfg.num_minibatches else min(int(cfg.batch_size), total)
-        with small_gemm_backend("rocblas" if mb <= 4096 else "default"):
-            return self._train()
+        """:681-700."""
+        return self._train()
 
     def _train(self):
         update_count = 0

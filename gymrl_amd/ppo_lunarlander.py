@@ -8,7 +8,7 @@ Same class / method / attribute names and return types; what changed underneath:
     one gymnasium env; the rollout is a time-major SoA slab [T][N] in HBM;
   * categorical sampling, GAE (+ advantage moments), the clipped-surrogate loss
     forward/backward (+ metrics) and clip-norm + Adam are HIP kernels behind the
-    C-ABI (include/gymrl.h); only the 256-wide MLP GEMMs go through PyTorch-ROCm;
+    C-ABI (include/gymrl.h), the update's GEMMs included (csrc/gemm.hip); PyTorch-ROCm owns memory and streams;
   * host syncs: one per rollout (episode returns) and one per update (metrics),
     instead of 3 per env step and 5 per minibatch;
   * with torch.distributed initialised every rank owns `num_envs` envs and the
@@ -58,9 +58,8 @@ class Config:
         self.reset_each_rollout = True   # ppo_lunarlander.py:200 resets the env at every rollout start
         self.gae_variant = 1             # 1 = time-blocked scan, 0 = sequential reference order
         self.fused_policy_forward = True  # rollout forward = one gymrl_mlp_forward launch (False: per-layer torch)
-        self.fused_update = True          # update forward/backward scheduled by ppo_net (False: torch autograd)
-        self.hip_gemm = True              # hidden_dim 256: hand-written f32-MFMA GEMMs + loss inside the heads pass
-                                          # (False: round-1 path — library GEMMs + separate HBM passes)
+        self.fused_update = True          # update = ppo_net.FusedActorCriticUpdate.step(): hand-written f32-MFMA GEMMs + fused
+                                          # HBM passes, hidden_dim 64 / 128 / 256 (False or another shape: torch autograd)
         self.persistent_rollout = True    # LunarLander: whole chunks of vector steps in one launch (gymrl_rollout_lunar)
         self.rollout_chunk = 0            # vector steps per persistent launch (0: the whole rollout in one launch —
                                           # every extra launch boundary waits for the slowest workgroup again)
@@ -408,7 +407,7 @@ class PPOTrainer:
                 self._fused_update = ppo_net.FusedActorCriticUpdate(self.model, mb)
             fu = self._fused_update
             fu.timers = tm
-        one_pass = fu is not None and fu.hip_gemm and getattr(cfg, "hip_gemm", True)
+        one_pass = fu is not None
         # block partials of every minibatch's 5 metric sums; reduced by ONE launch after the last step
         nblk = fu.metric_blocks(mb) if one_pass else ops.loss_blocks(mb)
         if self._metric_parts is None or self._metric_parts.shape[:2] != (cfg.num_epochs * n_mb, nblk):
@@ -459,12 +458,9 @@ class PPOTrainer:
             if one_pass:
                 fu.step(mb_obs, mb_act, mb_lp, mb_adv, mb_ret, self._loss_cfg, self._moments, self._metric_parts[row],
                         reducer=red)
-            else:
-                if fu is not None:
-                    logits, values = fu.forward(mb_obs)
-                else:
-                    logits, values = self.model(mb_obs)
-                    values = values.view(-1)
+            else:                                     # shapes ppo_net does not cover (or cfg.fused_update = False): autograd
+                logits, values = self.model(mb_obs)
+                values = values.view(-1)
                 dlogits = torch.empty_like(logits)
                 dvalues = torch.empty_like(values)
                 if tm is not None:
@@ -474,10 +470,7 @@ class PPOTrainer:
                                      workspace=self._metric_parts[row])
                 if tm is not None:
                     tm.stop("ppo_loss_fwd_bwd", B)
-                if fu is not None:
-                    fu.backward(dlogits, dvalues)
-                else:
-                    torch.autograd.backward([logits, values], [dlogits, dvalues])
+                torch.autograd.backward([logits, values], [dlogits, dvalues])
                 if red is not None:
                     red.launch(0)
             # the next minibatch's rows do not depend on the parameters: gathered while the last bucket is in flight

@@ -44,8 +44,6 @@ class Config:
         # --- vectorised-engine additions ---
         self.num_envs = 1
         self.updates_per_step = 1
-        self.gemm_backend = "auto"            # library for the update's small-M GEMMs: auto | rocblas | hipblaslt | default (gymrl_amd/blas.py)
-        self.tune_gemms = False              # opt-in TunableOp search per GEMM shape at start-up
         self.use_graphs = True             # replay the update as one captured hipGraph (train(); update() stays eager)
         self.chunk_steps = 16              # whole vector steps (acting, env, n-step store, sum tree, draw, update) as one
         #                                    hipGraph per 16 (graphs.StepChunk); 0: eager acting + a graph per update.  The
@@ -583,14 +581,8 @@ class RainbowDQNTrainer:
         return rest
 
     def train(self, max_vector_steps=None):
-        """The reference's train() loop; the small-M GEMMs of the update run on the library that answers them
-        fastest (gymrl_amd/blas.py)."""
-        from .blas import small_gemm_backend
-        backend = getattr(self.cfg, "gemm_backend", "auto")
-        if backend == "auto":                    # measured: rocBLAS wins up to 4096-row minibatches, hipBLASLt above
-            backend = "rocblas" if self.cfg.batch_size <= 4096 else "default"
-        with small_gemm_backend(backend, getattr(self.cfg, "tune_gemms", False)):
-            return self._train(max_vector_steps)
+        """The reference's train() loop (every Linear of the update and of acting is a gymrl_lin_* launch: gymrl_amd/nn.py)."""
+        return self._train(max_vector_steps)
 
     CHUNK = 16     # vector steps per StepChunk replay (= the episode tracker's flush period)
 

@@ -184,14 +184,8 @@ class SACTrainer:
         self._graph(self.memory, cfg.batch_size)
 
     def train(self, max_vector_steps=None):
-        """The reference's train() loop; the small-M GEMMs of the update run on the library that answers them
-        fastest (gymrl_amd/blas.py)."""
-        from .blas import small_gemm_backend
-        backend = getattr(self.cfg, "gemm_backend", "auto")
-        if backend == "auto":                    # measured: rocBLAS wins up to 4096-row minibatches, hipBLASLt above
-            backend = "rocblas" if self.cfg.batch_size <= 4096 else "default"
-        with small_gemm_backend(backend, getattr(self.cfg, "tune_gemms", False)):
-            return self._train(max_vector_steps)
+        """The reference's train() loop (every Linear of the update and of acting is a gymrl_lin_* launch: gymrl_amd/nn.py)."""
+        return self._train(max_vector_steps)
 
     def _train(self, max_vector_steps=None):
         """:229-262 with N lock-stepped envs."""

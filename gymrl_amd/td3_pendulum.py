@@ -129,14 +129,8 @@ class _ActorCriticBase:
                                 eps=eps, mode=0, seed=self.base_seed, counter=self._act_counter)
 
     def train(self, max_vector_steps=None):
-        """The reference's train() loop; the small-M GEMMs of the update run on the library that answers them
-        fastest (gymrl_amd/blas.py)."""
-        from .blas import small_gemm_backend
-        backend = getattr(self.cfg, "gemm_backend", "auto")
-        if backend == "auto":                    # measured: rocBLAS wins up to 4096-row minibatches, hipBLASLt above
-            backend = "rocblas" if self.cfg.batch_size <= 4096 else "default"
-        with small_gemm_backend(backend, getattr(self.cfg, "tune_gemms", False)):
-            return self._train(max_vector_steps)
+        """The reference's train() loop (every Linear of the update and of acting is a gymrl_lin_* launch: gymrl_amd/nn.py)."""
+        return self._train(max_vector_steps)
 
     def _train(self, max_vector_steps=None):
         """The reference's episode loop with N lock-stepped envs: act, step, push, update every step."""

@@ -71,6 +71,63 @@ def test_linear_bwd_weight_bit_exact(dev, oracle, B, N):
     assert np.array_equal(db.cpu().numpy(), oracle.linear_bwd_bias(dy, slices, rps))
 
 
+@pytest.mark.parametrize("K,N", [(64, 64), (64, 128), (128, 128), (128, 256)])
+@pytest.mark.parametrize("B", [1, 31, 33, 700, 4101])
+def test_narrow_linear_fwd_bit_exact(dev, oracle, K, N, B):
+    """The 64- / 128-long reductions (gemm_ns_kernel: row tiles staged through LDS; PPO-full's Linear layers at
+    262,144-row micro-batches, ActorCritic at hidden 64 / 128): the same accumulation order as the 256-wide kernels,
+    so the oracle's fmaf chain restates them bit for bit — ragged row counts, rows past the end untouched."""
+    from gymrl_amd import ops
+    rng = np.random.default_rng(1000 * K + N + B)
+    x = rng.normal(size=(B, K)).astype(np.float32)
+    W = (rng.normal(size=(N, K)) / 8).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    y = torch.full((B + 2, N), float("nan"), device=dev)
+    ops.linear_fwd(t(x, dev), t(W, dev), t(b, dev), y[:B], act=False)
+    want = oracle.linear_fwd(x, W, b)
+    assert np.array_equal(y[:B].cpu().numpy(), want) and bool(torch.isnan(y[B:]).all())
+    y0 = torch.empty(B, N, device=dev)
+    ops.linear_fwd(t(x, dev), t(W, dev), None, y0, act=False)                 # no bias
+    assert np.array_equal(y0.cpu().numpy(), oracle.linear_fwd(x, W, None))
+    h = torch.empty(B, N, device=dev)
+    ops.linear_fwd(t(x, dev), t(W, dev), t(b, dev), h, act=True)
+    assert np.max(np.abs(h.cpu().numpy().astype(np.float64) - np.tanh(want.astype(np.float64)))) <= 4e-7
+
+
+@pytest.mark.parametrize("N,K", [(64, 64), (128, 64), (128, 128), (256, 128)])
+@pytest.mark.parametrize("B", [1, 95, 1030])
+@pytest.mark.parametrize("with_h", [True, False])
+def test_narrow_linear_bwd_input_bit_exact(dev, oracle, N, K, B, with_h):
+    from gymrl_amd import ops
+    rng = np.random.default_rng(77 * N + K + B)
+    W = (rng.normal(size=(N, K)) / 8).astype(np.float32)
+    dy = rng.normal(size=(B, N)).astype(np.float32)
+    H = np.tanh(rng.normal(size=(B, K))).astype(np.float32) if with_h else None
+    dx = torch.full((B + 3, K), float("nan"), device=dev)
+    ops.linear_bwd_input(t(dy, dev), t(W, dev), None if H is None else t(H, dev), dx[:B])
+    assert np.array_equal(dx[:B].cpu().numpy(), oracle.linear_bwd_input(dy, W, H))
+    assert bool(torch.isnan(dx[B:]).all())
+
+
+def test_narrow_gemms_at_micro_batch_size_vs_fp64(dev):
+    """PPO-full's micro-batch (262,144 rows) through the 128-wide kernels, against fp64 GEMMs on the device."""
+    from gymrl_amd import ops
+    B = 262144
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.randn(B, 128, device=dev, generator=g)
+    for N in (128, 256):
+        W = torch.randn(N, 128, device=dev, generator=g) / 11
+        b = torch.randn(N, device=dev, generator=g)
+        y = ops.linear_fwd(x, W, b, torch.empty(B, N, device=dev), act=False)
+        ref = x.double() @ W.double().t() + b.double()
+        assert float((y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+        dy = torch.randn(B, N, device=dev, generator=g)
+        dx = ops.linear_bwd_input(dy, W, None, torch.empty(B, 128, device=dev))
+        ref = dy.double() @ W.double()
+        assert float((dx.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+        del ref
+
+
 def test_gemms_at_minibatch_size_vs_fp64(dev):
     """B = 262,144 (BASELINE config 2's minibatch): every output against an fp64 GEMM on the device; the error is
     f32 round-off of a 256 / 512 / 262,144-term chain, and not worse than the library's f32 GEMM."""

@@ -181,10 +181,10 @@ def test_ppo_train_trace_matches_reference(fixture):
             ppo_net.FusedActorCriticUpdate.step = orig_step
     assert len(snaps) == 2
     if hidden == 256:
-        assert tr._fused_update is not None and tr._fused_update.hip_gemm and cfg.hip_gemm
+        assert tr._fused_update is not None and tr._fused_update.one_pass_heads
         assert steps == [40, 40, 16] * (2 * epochs)              # every optimiser step of both updates, ragged tail included
     else:
-        assert tr._fused_update is None or not tr._fused_update.hip_gemm
+        assert tr._fused_update is None                           # 32-wide: the autograd path
     stride = int(g["slim_stride"]) if "slim_stride" in g else 1
 
     def close(a, b, tol=1e-5):

@@ -1,7 +1,8 @@
-"""The PPO update's default path — hand-written f32-MFMA GEMMs + the loss inside the heads pass
+"""The PPO update's path — hand-written f32-MFMA GEMMs + fused HBM passes, the loss inside the heads pass at hidden 256
 (gymrl_amd/ppo_net.FusedActorCriticUpdate.step, ppo_lunarlander.py:274-307) — against torch autograd on the same
-module in f32 and in f64, at test sizes and at BASELINE config 2's minibatch (262,144 rows); and the one-pass heads
-kernel against the three passes it replaces."""
+module in f32 and in f64, at test sizes and at BASELINE config 2's minibatch (262,144 rows), for every hidden width the
+path covers (64 / 128: the narrow-reduction GEMM kernels + the three-pass heads); and the one-pass heads kernel
+against the three passes it replaces."""
 import numpy as np
 import pytest
 
@@ -32,21 +33,21 @@ def ppo_loss_torch(logits, values, act, lpo, adv, ret, cfg):
     return pol + value_coef * torch.mean((values - ret).pow(2)) - entropy_coef * ent.mean()
 
 
-def _minibatch(B, dev, seed):
+def _minibatch(B, dev, seed, D=8, A=4):
     g = torch.Generator(device=dev).manual_seed(seed)
-    x = torch.randn(B, 8, device=dev, generator=g)
-    act = torch.randint(0, 4, (B,), device=dev, generator=g, dtype=torch.int32)
+    x = torch.randn(B, D, device=dev, generator=g)
+    act = torch.randint(0, A, (B,), device=dev, generator=g, dtype=torch.int32)
     lpo = -1.386 + 0.2 * torch.randn(B, device=dev, generator=g)
     adv, ret = torch.randn(B, device=dev, generator=g), torch.randn(B, device=dev, generator=g)
     return x, act, lpo, adv, ret
 
 
-def _net(dev, seed):
+def _net(dev, seed, hidden=256, D=8, A=4):
     from gymrl_amd import ppo_net
     from gymrl_amd.flat import flatten_module
     from gymrl_amd.ppo_lunarlander import ActorCritic
     torch.manual_seed(seed)
-    net = ActorCritic(8, 4, 256)
+    net = ActorCritic(D, A, hidden)
     with torch.no_grad():
         for p in net.parameters():           # non-zero biases, a policy with opinions: every term is exercised
             if p.dim() == 1:
@@ -56,11 +57,12 @@ def _net(dev, seed):
     return net
 
 
-@pytest.mark.parametrize("B", [300, 16384, 262144])
-def test_step_matches_autograd_f32_and_f64(dev, B):
+@pytest.mark.parametrize("B,hidden,D,A", [(300, 256, 8, 4), (16384, 256, 8, 4), (262144, 256, 8, 4),
+                                          (40, 64, 4, 2), (1000, 64, 8, 4), (4097, 128, 3, 4), (65536, 128, 8, 4)])
+def test_step_matches_autograd_f32_and_f64(dev, B, hidden, D, A):
     from gymrl_amd import ops, ppo_net
-    net = _net(dev, B)
-    x, act, lpo, adv, ret = _minibatch(B, dev, B + 1)
+    net = _net(dev, B, hidden, D, A)
+    x, act, lpo, adv, ret = _minibatch(B, dev, B + 1, D, A)
     # f32 torch autograd on the same module
     net._flat_grads.zero_()
     lg, vl = net(x)
@@ -79,7 +81,7 @@ def test_step_matches_autograd_f32_and_f64(dev, B):
     # the product path
     net._flat_grads.zero_()
     fu = ppo_net.FusedActorCriticUpdate(net, B)
-    assert fu.hip_gemm
+    assert fu.one_pass_heads == (hidden == 256)
     parts = torch.zeros(fu.metric_blocks(B), 5, dtype=torch.float64, device=dev)
     fu.step(x, act, lpo, adv, ret, LOSS_CFG, None, parts)
     worst = 0.0
@@ -92,7 +94,7 @@ def test_step_matches_autograd_f32_and_f64(dev, B):
         worst = max(worst, e_hip)
     m = parts.sum(0).cpu().numpy() / B
     assert abs((m[0] + m[1] - LOSS_CFG[3] * m[2]) - float(loss64.detach())) <= 1e-5 * max(1.0, abs(float(loss64.detach())))
-    print(f"B={B}: worst relative gradient error vs f64 = {worst:.2e}")
+    print(f"B={B} hidden={hidden}: worst relative gradient error vs f64 = {worst:.2e}")
 
 
 @pytest.mark.parametrize("B", [1, 7, 8, 1000, 40000])

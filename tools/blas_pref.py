@@ -1,4 +1,5 @@
-"""Library selection for the small-M float32 GEMMs of the off-policy updates.
+"""(tools only — A/B baselines; the product has no library GEMM on its paths since round 3.)
+Library selection for the small-M float32 GEMMs of the round-1 off-policy updates.
 
 The DQN / Rainbow / SAC networks are 256-wide MLPs updated on 128-256 row minibatches.  hipBLASLt's default
 heuristic answers those shapes with its 256 x 128 macro tile: a 128 x 256 x 256 GEMM becomes TWO workgroups on

@@ -2,7 +2,7 @@
 """Throughput of the off-policy trainers at BASELINE configs 3 and 4 (Rainbow 8192 CartPole envs with a 2^20 PER
 ring, SAC 4096 Pendulum envs), one update per vector step as in the reference loops.  Supplementary numbers:
 bench.py's headline is config 2.  A/B in one process: per-launch issue vs hipGraph replay of the update, and the
-library answering the update's small-M GEMMs (gymrl_amd/blas.py)."""
+library answering the round-1 path's small-M GEMMs (tools/blas_pref.py)."""
 import json
 import os
 import sys
@@ -11,6 +11,8 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from blas_pref import small_gemm_backend  # noqa: E402
 from gymrl_amd import rainbow_dqn_cartpole, sac_pendulum  # noqa: E402
 
 
@@ -52,14 +54,16 @@ def main():
         for name, graphs, backend, tune, fused in MODES:
             c = mod.Config()
             c.num_envs, c.memory_capacity, c.max_episodes, c.batch_size = N, 1 << 20, 10**9, B
-            c.use_graphs, c.gemm_backend, c.tune_gemms = graphs, backend, tune
+            c.use_graphs = graphs
             if os.environ.get("GYMRL_NO_CHUNK"):
                 c.chunk_steps = 0
             gnn.SPLIT_BIAS, gnn.FUSED_LINEAR = True, fused
             rainbow_dqn_cartpole.OVERLAP_TREE = not os.environ.get("GYMRL_NO_OVERLAP")
             tr = getattr(mod, cls)(c)
             steps = 300
-            dt = run(tr, steps, 60)
+            pref = ("rocblas" if B <= 4096 else "default") if backend == "auto" else backend
+            with small_gemm_backend(pref, tune):       # only the non-fused (round-1) modes reach a library GEMM
+                dt = run(tr, steps, 60)
             row[name] = dict(env_steps_per_s=round(N * steps / dt), ms_per_vector_step=round(dt / steps * 1e3, 3))
         out[f"{cls} N={N} cap=2^20 B={B}"] = row
     print(json.dumps(out, indent=1))

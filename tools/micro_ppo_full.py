@@ -10,7 +10,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gymrl_amd import nn as gnn  # noqa: E402
-from gymrl_amd.blas import small_gemm_backend  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from blas_pref import small_gemm_backend  # noqa: E402
 from gymrl_amd.ppo_full_lunarlander import Config, PPOTrainer  # noqa: E402
 
 
