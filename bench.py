@@ -167,6 +167,169 @@ def comm_summary(world, reducer, ks, step_s, steps):
     return out
 
 
+def _event_us(fn, reps=20, warm=3):
+    """Average duration of fn() in microseconds, HIP events on torch's current stream (the C-ABI's launch stream)."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def _random_access_GBps(dev, entries=1 << 21, draws=1 << 22):
+    """What this box gives 8-byte reads at random addresses of a 16-MiB float64 array (the sum tree's size at 2^20 leaves):
+    the yardstick SURVEY.md 8(d) asks PER sample / update to be priced against.  Useful bytes only (8 per access)."""
+    g = torch.Generator(device=dev).manual_seed(3)
+    table = torch.rand(entries, dtype=torch.float64, device=dev, generator=g)
+    idx = torch.randint(0, entries, (draws,), device=dev, generator=g)
+    out = torch.empty(draws, dtype=torch.float64, device=dev)
+    us = _event_us(lambda: torch.index_select(table, 0, idx, out=out), reps=10)
+    return draws * 8.0 / us / 1e3, draws / us * 1e6
+
+
+def main_offpolicy(a, rank, world, local_rank):
+    """BASELINE.json configs[2] (Rainbow DQN CartPole-v1, 8192 envs, PER sum tree + n-step + NoisyNet) and configs[3] (SAC
+    Pendulum-v1, 4096 envs, twin Q + reparameterised sample + automatic temperature), one GPU each; with --gpus N every rank
+    runs an independent replica (the off-policy path has no exchange step: DESIGN.md section 6, "replicas only").
+    One "step" = 16 vector steps = one replay of the trainer's StepChunk graph where the trainer chunks (Rainbow), 16 passes
+    of its loop otherwise: per vector step the reference loop's acting forward, env.step, n-step / ring store, proportional or
+    uniform draw and ONE update (rainbow_dqn_cartpole.py:363-405, sac_pendulum.py:275-300), ring of 2^20 rows.
+    Nothing is skipped.  After the timed region rank 0 event-times the replay memory's pieces at the run's own sizes and at
+    a throughput size, against this box's measured random-access rate."""
+    from gymrl_amd import dist as gdist
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    VS = 16
+    if a.algo == "rainbow":
+        from gymrl_amd.rainbow_dqn_cartpole import Config, RainbowDQNTrainer as Trainer
+        N, B, env_name = (a.envs if a.envs != 4096 else 8192), 256, "CartPole-v1"
+    else:
+        from gymrl_amd.sac_pendulum import Config, SACTrainer as Trainer
+        N, B, env_name = a.envs, 128, "Pendulum-v1"
+    cfg = Config()
+    cfg.num_envs, cfg.memory_capacity, cfg.max_episodes, cfg.batch_size, cfg.seed = N, 1 << 20, 10 ** 9, B, 0
+    cfg.device = str(dev)
+    sys.stdout = open(os.devnull, "w") if rank != 0 else sys.stderr
+    tr = Trainer(cfg)
+    from gymrl_amd.envs import VecEnv
+
+    def run(vector_steps):
+        tr.env = VecEnv(env_name, N, device=dev, seed=tr.base_seed, env_id0=rank * N)    # train() closes its env
+        tr.episode_rewards.clear()            # (Rainbow's loop stops at a solved running mean; the bench times a fixed count)
+        tr.train(max_vector_steps=vector_steps)
+    run(max(a.warmup, 1) * VS + 64)           # fills the n-step windows and the ring past one batch, captures the graphs
+    gdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(a.steps * VS)
+    gdist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    gdist.all_reduce_max(dt_t)
+    dt = float(dt_t.item())
+    devices = gdist.rank_devices()
+    if rank != 0:
+        gdist.shutdown()
+        return
+    sys.stdout = sys.__stdout__
+    try:
+        ra_GBps, ra_per_s = _random_access_GBps(dev)
+        mem = tr.memory
+        cap = 1 << 20
+        depth = 21                                                  # node reads of one descent through a 2^20-leaf tree
+        pieces = {}
+        if a.algo == "rainbow":
+            from gymrl_amd import ops
+            D = 4
+            row_bytes = 4 * (2 * D + 2) + 1 + 4                     # state, next_state, action, reward, flag + the index
+            for nb in (B, 65536):
+                idx = torch.empty(nb, dtype=torch.int32, device=dev)
+                pr, w = torch.empty(nb, dtype=torch.float64, device=dev), torch.empty(nb, device=dev)
+                ws = ops.per_workspace(max(8192, cap, nb), dev)
+                k = [0]
+
+                def draw():
+                    k[0] += 1
+                    ops.per_sample(mem.sum_tree.tree, cap, nb, mem.current_size, 0.5, ws, seed=7, counter=k[0], out=(idx, pr, w))
+                us = _event_us(draw)
+                pieces[f"per_sample B={nb}"] = dict(us=round(us, 2), draws_per_s=round(nb / us * 1e6), bytes_per_draw=8 * depth,
+                                                    GBps=round(8.0 * depth * nb / us / 1e3, 2),
+                                                    frac_of_random_access=round(8.0 * depth * nb / us / 1e3 / ra_GBps, 4))
+                us = _event_us(lambda: ops.replay_gather(mem.ring, idx))
+                pieces[f"ring_gather B={nb}"] = dict(us=round(us, 2), rows_per_s=round(nb / us * 1e6), bytes_per_row=row_bytes,
+                                                     GBps=round(row_bytes * nb / us / 1e3, 2), frac_hbm=round(row_bytes * nb / us / 1e3 / (HBM_PEAK / 1e9), 5))
+                td = torch.randn(nb, device=dev)
+                ws2 = ops.per_workspace(max(8192, cap, nb), dev)
+
+                def upd():
+                    ops.per_update(mem.sum_tree.tree, cap, nb, ws2, idx=idx, prio=ops.per_priorities(td, mem.alpha, 0.01))
+                if nb <= 8192:
+                    us = _event_us(upd)
+                    pieces[f"per_update B={nb} (priorities of a sampled batch, reference order per node)"] = dict(
+                        us=round(us, 2), indices_per_s=round(nb / us * 1e6), bytes_per_index=16 * (depth - 1),
+                        GBps=round(16.0 * (depth - 1) * nb / us / 1e3, 3))
+            us = _event_us(lambda: mem.sum_tree.update_range(0, N, priority=1.0))
+            store_bytes = 16.0 * (depth - 1) * N
+            pieces[f"per_update N={N} (the new rows of one vector step)"] = dict(
+                us=round(us, 2), indices_per_s=round(N / us * 1e6), bytes_per_index=16 * (depth - 1), GBps=round(store_bytes / us / 1e3, 3))
+            roof = dict(bound="hbm", unit="GB/s", peak=HBM_PEAK / 1e9, achieved=round(store_bytes / us / 1e3, 3),
+                        frac=round(store_bytes / us / 1e3 / (HBM_PEAK / 1e9), 6), traffic=None, launch_s=us * 1e-6,
+                        kernel="gymrl_per_update over the N new rows of a vector step (csrc/per.hip per_leaf + per_ancestor: the largest "
+                               "kernel group of a Rainbow step, 27 % of its kernel time): 320 algorithmic bytes per index (20 float64 "
+                               "read-modify-writes).  Bound by the REFERENCE'S ORDER, not by HBM: a node's additions are applied in batch "
+                               "order, so the root is one dependent chain of N float64 adds (DESIGN.md section 4); priced against HBM as the "
+                               "contract asks, and against this box's random-access rate below",
+                        random_access_GBps_measured=round(ra_GBps, 1), random_accesses_per_s_measured=round(ra_per_s),
+                        frac_of_random_access=round(store_bytes / us / 1e3 / ra_GBps, 5))
+        else:
+            from gymrl_amd import ops
+            D, A = 3, 1
+            row_bytes = 4 * (2 * D + A + 1) + 1 + 4
+            for nb in (B, 65536):
+                idx = ops.uniform_indices(7, 1, len(mem), min(nb, len(mem)), dev)
+                nb = idx.numel()
+                us = _event_us(lambda: ops.replay_gather(mem.ring, idx))
+                pieces[f"ring_gather B={nb}"] = dict(us=round(us, 2), rows_per_s=round(nb / us * 1e6), bytes_per_row=row_bytes,
+                                                     GBps=round(row_bytes * nb / us / 1e3, 2), frac_hbm=round(row_bytes * nb / us / 1e3 / (HBM_PEAK / 1e9), 5))
+            obs = torch.randn(N, D, device=dev)
+            us = _event_us(lambda: tr.select_action(obs))
+            H = cfg.hidden_dim
+            fl = 2.0 * N * (D * H + H * H + 2 * H * A)
+            pieces["acting forward (Actor: 3 Linear launches + the reparameterised sample)"] = dict(us=round(us, 2), TFLOPs=round(fl / us / 1e6, 2))
+            roof = dict(bound="mfma", unit="TFLOP/s", peak=MFMA_F32_PEAK / 1e12, achieved=round(fl / us / 1e6, 2),
+                        frac=round(fl / us / 1e6 / (MFMA_F32_PEAK / 1e12), 4), traffic=None, launch_s=us * 1e-6,
+                        kernel="the acting forward of one vector step (Actor.fc1, fc2, mean | log_std as gymrl_lin_fwd launches + "
+                               "gymrl_sac_sample_fwd; the 4096 x 256 x 256 layer is the largest kernel of a SAC step): launch- and "
+                               "latency-bound at this size, priced against the f32 MFMA peak as the only dense contraction of the step")
+            upd_us = _event_us(lambda: tr.update_async() if getattr(cfg, "use_graphs", True) else tr.update(), reps=50)
+            pieces[f"one update at batch {B} (twin critics, actor, temperature, Adam x3 + Polyak; replayed as a hipGraph)"] = dict(us=round(upd_us, 2))
+        vsteps = a.steps * VS
+        out = {
+            "metric": f"env-steps/sec at N envs/GPU ({'Rainbow DQN CartPole' if a.algo == 'rainbow' else 'SAC Pendulum'}), 1 update per vector step + %roofline",
+            "value": N * vsteps * world / dt, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (sum tree f64)" if a.algo == "rainbow" else "f32 (temperature f64)", "data": "synthetic",
+            "config": {"workload": (f"Rainbow DQN CartPole-v1, {N} envs, PER sum tree (2^20 leaves) + 5-step returns + NoisyNet, batch {B} "
+                                    "(BASELINE.json configs[2])" if a.algo == "rainbow" else
+                                    f"SAC Pendulum-v1, {N} envs, twin Q + reparameterised sample + automatic temperature, ring 2^20, batch {B} "
+                                    "(BASELINE.json configs[3])"),
+                       "envs_per_gpu": N, "vector_steps_per_step": VS, "updates_per_vector_step": 1, "batch": B, "replay_rows": cap,
+                       "ms_per_vector_step": round(dt / vsteps * 1e3, 4), "updates_per_s": round(vsteps * world / dt, 1),
+                       "parallelism": f"{world} independent replicas (no exchange step on this path)" if world > 1 else "single GPU"},
+            "roofline": roof, "pieces": pieces,
+            "comm": dict(rccl_world_size=world, grad_allreduce=None, backend="nccl (RCCL)" if world > 1 else None, rank_devices=devices),
+        }
+        print(json.dumps(out))
+        sys.stdout.flush()
+    finally:
+        gdist.shutdown()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,8 +339,9 @@ def main():
     ap.add_argument("--rollout", type=int, default=2048, help="T: vector steps per rollout (reference update_freq)")
     ap.add_argument("--epochs", type=int, default=10)
     ap.add_argument("--minibatches", type=int, default=32)
-    ap.add_argument("--algo", choices=("ppo", "ppo_full"), default="ppo",
-                    help="ppo = the headline benchmark (BASELINE configs[1]); ppo_full = configs[4]'s per-GPU workload")
+    ap.add_argument("--algo", choices=("ppo", "ppo_full", "rainbow", "sac"), default="ppo",
+                    help="ppo = the headline benchmark (BASELINE configs[1]); ppo_full = configs[4]'s per-GPU workload; "
+                         "rainbow / sac = configs[2] / configs[3] (a step = 16 vector steps with one update each)")
     ap.add_argument("--micro-batch", type=int, default=262144, help="ppo_full: rows per forward/backward pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=24.0)
@@ -199,6 +363,8 @@ def main():
         return spawn_selftest(a, rank, world)
     if a.algo == "ppo_full":
         return main_ppo_full(a, rank, world, local_rank)
+    if a.algo in ("rainbow", "sac"):
+        return main_offpolicy(a, rank, world, local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 

@@ -44,6 +44,11 @@ using namespace gymrl;
 
 
 constexpr int kCUs = 256;
+// Column slices of the N = 256 weight-stationary kernels.  2: a [256 x 128] slice per workgroup (128 KiB of LDS, 8 row tiles
+// per wave at 262,144 rows); 4: [256 x 64] slices (64 KiB, 16 row tiles per wave, 64 x 64 wave tiles) — the fixed cost of a
+// launch (weight fill, first loads, the last tile's exposed epilogue) is halved and spread over twice the tiles, at the
+// price of reading every activation row from L2 four times instead of twice.
+constexpr int kSlices256 = 2;
 
 enum { EPI_NONE = 0, EPI_TANH = 1, EPI_TANHBWD = 2 };
 
@@ -634,6 +639,9 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 #ifdef GYMRL_PROF_BUILD
 int g_tn_abl = 0;      // ablation mode of the weight-gradient kernel (0 = product kernel)
 int g_ws_abl = 0;      // ablation mask of the forward kernel
+int g_ws_slices256 = kSlices256;   // column slices of the 256-wide forward / input-gradient kernels (2 | 4): A/B of tools/micro_gemm.py
+#else
+constexpr int g_ws_slices256 = kSlices256;
 #endif
 
 // row groups of the weight-stationary kernels: at most one workgroup per CU (the weight slice fills LDS)
@@ -700,6 +708,7 @@ int gymrl_gemm_config(int key, int value) {      // probe build only (include/gy
   switch (key) {
     case 4: if (value < 0 || value > 2) return -22; g_tn_abl = value; return 0;
     case 5: if (value < 0 || value > 12) return -22; g_ws_abl = value; return 0;
+    case 6: if (value != 2 && value != 4) return -22; g_ws_slices256 = value; return 0;
     default: return -22;
   }
 }
@@ -730,7 +739,11 @@ int gymrl_linear_fwd(const float* X, const float* W, const float* b, int64_t B, 
   if (wide) {
     a.slices = N / 128;
     const int rg = ws_row_groups(B, 64, a.slices);
-    if (N == 256) {
+    if (N == 256 && g_ws_slices256 == 4) {
+      a.slices = 4;
+      if (act == 1) launch_ws<256, 2, 2, false, EPI_TANH, 256>(a, ws_row_groups(B, 64, 4), s);
+      else launch_ws<256, 2, 2, false, EPI_NONE, 256>(a, ws_row_groups(B, 64, 4), s);
+    } else if (N == 256) {
       if (act == 1) launch_ws<256, 4, 2, false, EPI_TANH, 256>(a, rg, s);
       else launch_ws<256, 4, 2, false, EPI_NONE, 256>(a, rg, s);
     } else {
@@ -761,7 +774,10 @@ int gymrl_linear_bwd_input(const float* dY, const float* W, const float* H, int6
   a.A = dY; a.M = B; a.lda = N; a.W = W; a.ldw = K; a.out = dX; a.ldo = K; a.H = H; a.ldh = K;
   hipStream_t s = (hipStream_t)stream;
   if (wide) {
-    if (N == 256) {
+    if (N == 256 && g_ws_slices256 == 4) {
+      a.slices = 4;
+      launch_ws<256, 2, 2, true, EPI_TANHBWD, 256>(a, ws_row_groups(B, 64, 4), s);
+    } else if (N == 256) {
       a.slices = 2;
       launch_ws<256, 4, 2, true, EPI_TANHBWD, 256>(a, ws_row_groups(B, 64, 2), s);
     } else {

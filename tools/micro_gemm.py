@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""The update-path GEMMs at bench shape (B = 262,144): gymrl_linear_fwd / _bwd_input / _bwd_weight variants
-against the library GEMM of the same shape, A/B in ONE process.  Prints TF/s per kernel and writes
-gpurun_out/micro_gemm.json.  Usage: python tools/micro_gemm.py [rows]"""
+"""The update-path GEMMs at bench shape (B = 262,144): gymrl_linear_fwd / _bwd_input / _bwd_weight against the library GEMM
+of the same shape, A/B in ONE process.  With the probe build (make -C gymrl_amd/csrc prof; GYMRL_HIP_LIB=.../libgymrl_hip_prof.so)
+also the 2- vs 4-slice variants of the 256-wide kernels.  Prints TF/s per kernel and writes gpurun_out/micro_gemm.json.
+Usage: python tools/micro_gemm.py [rows]"""
 import json
 import os
 import sys
@@ -38,34 +39,31 @@ def main():
     dx, cs = torch.empty(B, 256, device=dev), torch.empty(256, device=dev)
     dW2, dW5 = torch.empty(256, 256, device=dev), torch.empty(512, 256, device=dev)
     ws = ops.gemm_workspace(dev)
-    tws = ops.mlp_train_workspace(256, 8, 4, dev)
     out = {"rows": B}
 
     def rec(name, us, flop):
-        out[name] = {"us": round(us, 1), "tflops": round(flop / us * 1e-6, 1)}
+        out[name] = {"us": round(us, 1), "tflops": round(flop / us * 1e-6, 1), "frac_f32_mfma_peak": round(flop / us * 1e-6 / 157.3, 3)}
         print(f"{name:42s} {us:9.1f} us  {flop / us * 1e-6:7.1f} TF/s", flush=True)
 
     f2, f5 = 2.0 * B * 256 * 256, 2.0 * B * 512 * 256
-    # library baselines of the current path (GEMM + the pass it needs)
-    rec("lib fwd 256 (mm + tanh_inplace)", timeit(lambda: (torch.mm(x, W2.t(), out=y2), ops.tanh_inplace(y2, b2))), f2)
     rec("lib fwd 256 (mm only)", timeit(lambda: torch.mm(x, W2.t(), out=y2)), f2)
     rec("lib fwd 512 (mm only)", timeit(lambda: torch.mm(x, W5.t(), out=y5)), f5)
-    rec("lib dX 512 (mm + tanh_bwd_colsum)", timeit(lambda: (torch.mm(dy5, W5, out=dx), ops.tanh_bwd_colsum(dx, h, cs, tws))), f5)
     rec("lib dX 512 (mm only)", timeit(lambda: torch.mm(dy5, W5, out=dx)), f5)
     rec("lib dX 256 (mm only)", timeit(lambda: torch.mm(dy2, W2, out=dx)), f2)
-    from gymrl_amd.ppo_net import FusedActorCriticUpdate
-    rec("lib dW 512 (split-K bmm + sum)", timeit(lambda: FusedActorCriticUpdate._dw(dy5, x, dW5)), f5)
-    rec("lib dW 256 (split-K bmm + sum)", timeit(lambda: FusedActorCriticUpdate._dw(dy2, x, dW2)), f2)
-    rec("hip fwd 256 tanh", timeit(lambda: ops.linear_fwd(x, W2, b2, y2, act=True)), f2)
-    rec("hip fwd 512 tanh", timeit(lambda: ops.linear_fwd(x, W5, b5, y5, act=True)), f5)
+    prof = hasattr(ops.lib(), "gymrl_gemm_config")
+    for slices in ((2, 4, 2, 4) if prof else (None,)):
+        tag = "" if slices is None else f" [{slices} slices]"
+        if slices is not None:
+            ops.gemm_config(6, slices)
+        rec("hip fwd 256 tanh" + tag, timeit(lambda: ops.linear_fwd(x, W2, b2, y2, act=True)), f2)
+        rec("hip fwd 256 bias only" + tag, timeit(lambda: ops.linear_fwd(x, W2, b2, y2, act=False)), f2)
+        rec("hip dX 256 tanh'" + tag, timeit(lambda: ops.linear_bwd_input(dy2, W2, h, dx)), f2)
+    if prof:
+        ops.gemm_config(6, 2)
     rec("hip fwd 512 bias only", timeit(lambda: ops.linear_fwd(x, W5, b5, y5, act=False)), f5)
-    rec("hip dX 256 tanh' colsum", timeit(lambda: ops.linear_bwd_input(dy2, W2, h, dx)), f2)
-    rec("hip dX 512 tanh' colsum", timeit(lambda: ops.linear_bwd_input(dy5, W5, h, dx)), f5)
-    for pf in (4, 8):
-        ops.gemm_config(2, pf)
-        rec(f"hip dW 256 [pf{pf}]", timeit(lambda: ops.linear_bwd_weight(dy2, x, dW2, ws, cs)), f2)
-        rec(f"hip dW 512 [pf{pf}]", timeit(lambda: ops.linear_bwd_weight(dy5, x, dW5, ws, b5)), f5)
-    ops.gemm_config(2, 8)
+    rec("hip dX 512 tanh'", timeit(lambda: ops.linear_bwd_input(dy5, W5, h, dx)), f5)
+    rec("hip dW 256 + db", timeit(lambda: ops.linear_bwd_weight(dy2, x, dW2, ws, cs)), f2)
+    rec("hip dW 512", timeit(lambda: ops.linear_bwd_weight(dy5, x, dW5, ws, None)), f5)
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/micro_gemm.json", "w") as f:
         json.dump(out, f, indent=1)
