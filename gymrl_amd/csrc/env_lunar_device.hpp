@@ -922,9 +922,17 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
       const float Cc = clampf(Cang + plim_slop[L], plim_lo[L], plim_hi[L]);
       const float limImp = lim ? -mmass[L] * Cc : 0.0f;
       B[0].a -= iA * limImp; B[bi].a += iB * limImp;
+      // the two rotations of the joint in ONE evaluation: even lanes of the quad take the hull's angle, odd lanes the leg's,
+      // and the quad exchanges the results (every lane holds identical copies of both angles, so each lane gets exactly the
+      // bits it would have computed itself — 26 instructions and four quad broadcasts instead of 52 on a path that a
+      // grounded lander walks up to 60 times per step)
       float qsA, qcA, qsB, qcB;
-      det_sincosf(B[0].a, &qsA, &qcA);
-      det_sincosf(B[bi].a, &qsB, &qcB);
+      {
+        float sn, cs;
+        det_sincosf((role & 1) ? B[bi].a : B[0].a, &sn, &cs);
+        qsA = quad_bcast<0>(sn); qcA = quad_bcast<0>(cs);
+        qsB = quad_bcast<1>(sn); qcB = quad_bcast<1>(cs);
+      }
       const float lax = 0.0f, lay = 0.0f - kHullLcY;
       const float lbx = leg_sign(L) * kLegAway, lby = kLegDown;
       const float rAx = qcA * lax - qsA * lay, rAy = qsA * lax + qcA * lay;
