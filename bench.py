@@ -343,6 +343,9 @@ def main():
                     help="ppo = the headline benchmark (BASELINE configs[1]); ppo_full = configs[4]'s per-GPU workload; "
                          "rainbow / sac = configs[2] / configs[3] (a step = 16 vector steps with one update each)")
     ap.add_argument("--micro-batch", type=int, default=262144, help="ppo_full: rows per forward/backward pass")
+    ap.add_argument("--timer-every", type=int, default=8,
+                    help="ppo: HIP-event brackets around the launches of every K-th minibatch of the timed region (1: all; "
+                         "the gather of the next minibatch is issued inside the previous one's bracket window either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=24.0)
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="nccl == RCCL (default); gloo only for --spawn-selftest on CPU")
@@ -402,7 +405,7 @@ def main():
     for _ in range(a.warmup):
         step()
     phase_events.clear()
-    timers = KernelTimers()
+    timers = KernelTimers(every=max(1, a.timer_every))
     trainer._timers = timers
     gdist.barrier()
     torch.cuda.synchronize()
@@ -596,8 +599,9 @@ def report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev,
         raise SystemExit("[bench] the headline workload runs ppo_net.FusedActorCriticUpdate.step() (hidden_dim 256); no GEMM timers found")
     # The dominant hand-written work of the step: the six exact-f32 MFMA GEMM launches of every minibatch update
     # (csrc/gemm.hip), event-timed on the launch stream inside the timed region.
-    fl = sum(flops_per_unit[k] * ks[k]["units"] for k in gemms) / n_upd
-    sec = sum(ks[k]["total_s"] for k in gemms) / n_upd
+    # (per launch: the timers bracket every --timer-every-th minibatch)
+    fl = sum(flops_per_unit[k] * ks[k]["units"] / ks[k]["launches"] for k in gemms)
+    sec = sum(ks[k]["total_s"] / ks[k]["launches"] for k in gemms)
     head = dict(bound="mfma", unit="TFLOP/s", peak=MFMA_F32_PEAK / 1e12, achieved=round(fl / sec / 1e12, 1),
                 frac=round(fl / sec / MFMA_F32_PEAK, 4),
                 kernel="the six f32-MFMA GEMM launches of one minibatch update (csrc/gemm.hip: gemm_ws_kernel x4, gemm_tn_kernel x2 "
@@ -614,7 +618,7 @@ def report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev,
         in_run["heads_loss_fwd_bwd"] = dict(launch_s=hl["total_s"] / hl["launches"], achieved=kernels["heads_loss_fwd_bwd"]["achieved_GBps"],
                                             frac=kernels["heads_loss_fwd_bwd"]["frac"], note="loss inside the heads pass: 4112 B per row")
     elif "ppo_loss_fwd_bwd" in ks:
-        loss_s = ks["ppo_loss_fwd_bwd"]["total_s"] / (a.steps * cfg.num_epochs)
+        loss_s = ks["ppo_loss_fwd_bwd"]["total_s"] / ks["ppo_loss_fwd_bwd"]["launches"] * cfg.num_minibatches
         in_run["ppo_loss_fwd_bwd"] = dict(launch_s=loss_s, achieved=round(56.0 * transitions / loss_s / 1e9, 1),
                                           frac=round(56.0 * transitions / loss_s / HBM_PEAK, 4), note="32 minibatch launches per pass")
     gae_loss = dict(kernel="gae(G1: chunk maps fused in the rollout + carry + apply + moments) + ppo_loss_fwd_bwd",

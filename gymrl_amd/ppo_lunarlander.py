@@ -169,18 +169,35 @@ class RolloutBuffer:
 class KernelTimers:
     """HIP-event timers on torch's current stream (the stream the C-ABI launches on):
     per label, summed device time and work units — bench.py turns them into achieved
-    GB/s against the HBM roofline."""
+    GB/s / TFLOP/s against the roofline.  `every` > 1 samples: the update brackets the launches of every
+    `every`-th minibatch only (tick()), so that the instrumentation — two event records around each of the ~19 launches of
+    a minibatch — does not itself stretch the region it measures; launches outside the minibatch loop (rollout, GAE)
+    are always bracketed."""
 
-    def __init__(self):
+    def __init__(self, every=1):
         self.pairs = {}
         self._open = {}
+        self.every, self._n, self.live = max(1, int(every)), 0, True
+
+    def tick(self):
+        """Start of a minibatch: decides whether its launches are bracketed."""
+        self.live = self._n % self.every == 0
+        self._n += 1
+
+    def resume(self):
+        """End of the minibatch loop: everything is bracketed again."""
+        self.live = True
 
     def start(self, label):
+        if not self.live:
+            return
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         self._open[label] = e
 
     def stop(self, label, units):
+        if not self.live:
+            return
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         self.pairs.setdefault(label, []).append((self._open.pop(label), e, units))
@@ -455,6 +472,8 @@ class PPOTrainer:
         while cur is not None:
             mb_obs, mb_act, mb_lp, mb_adv, mb_ret = cur
             B = mb_obs.shape[0]
+            if tm is not None:
+                tm.tick()                            # (sampling timers: this minibatch's launches are bracketed or not)
             if one_pass:
                 fu.step(mb_obs, mb_act, mb_lp, mb_adv, mb_ret, self._loss_cfg, self._moments, self._metric_parts[row],
                         reducer=red)
@@ -485,6 +504,8 @@ class PPOTrainer:
                 tm.stop("adam_step", self.flat_params.numel())
             sizes.append(B)
             row += 1
+        if tm is not None:
+            tm.resume()
         metrics = ops.reduce_rows(self._metric_parts, row, nblk, 5)
         self._drain_episode_returns()
         m = metrics.cpu().numpy() / np.asarray(sizes, np.float64)[:, None]   # the one host sync of the update

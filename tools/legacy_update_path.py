@@ -22,6 +22,9 @@ class LibraryGemmUpdate(FusedActorCriticUpdate):
         self.bias_in_gemm = False
         self.overlap_dw = False
         self._side = torch.cuda.Stream(device=self.H1.device)
+        if not hasattr(self, "logits"):
+            self.logits = torch.empty(self.R, self.A, device=self.H1.device)
+            self.value = torch.empty(self.R, 1, device=self.H1.device)
 
     @torch.no_grad()
     def forward(self, x):
