@@ -761,6 +761,19 @@ int gymrl_linear_fwd(const float* X, const float* W, const float* b, int64_t B, 
 int gymrl_linear_bwd_input(const float* dY, const float* W, const float* H, int64_t B, int N, int K,
                            float* dX, void* stream);
 int gymrl_linear_bwd_weight_geometry(int64_t B, int N, int* slices, int64_t* rows_per_slice);
+/*
+ * OPT-IN split-bf16 variants of the three entry points above for the 256-wide layers (K = 256, N in {256, 512}): csrc/gemm_sb.hip.
+ * Every f32 operand is split exactly into three bf16 pieces (hi / mid / lo by truncation) and six bf16 MFMAs per 16-deep step
+ * (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; f32 accumulation) reproduce the f32 products to ~1.2e-7 relative at 6/16 of
+ * the exact f32-MFMA time.  f32-ACCURATE, not bit-exact: results are compared with float64 (error not above the exact
+ * kernels' on benign and adversarial inputs, tests/test_gemm_sb_gpu.py), never with the oracle's fmaf chain.  The exact kernels
+ * are the default everywhere; these are selected by Config.gemm_mode = "split_bf16" and reported by bench.py as a separate,
+ * labelled line.  Same argument meaning as the exact entry points; bwd_weight uses the same workspace and slice geometry.
+ */
+int gymrl_linear_fwd_sb(const float* X, const float* W, const float* b, int64_t B, int K, int N, int act,
+                        float* Y, void* stream);
+int gymrl_linear_bwd_input_sb(const float* dY, const float* W, const float* H, int64_t B, int N, int K,
+                              float* dX, void* stream);
 int gymrl_linear_bwd_weight(const float* dY, const float* X, int64_t B, int N, int K, float* dW,
                             float* db, void* workspace, void* stream);
 
