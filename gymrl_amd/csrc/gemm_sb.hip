@@ -113,6 +113,15 @@ struct SbArgs {
 };
 
 // ------------------------------------------------------------------ forward / input gradient ------
+// STATUS: correct and f32-accurate, but only 1.1-1.35 x faster than the exact kernels, so not used by the trainers.  Three
+// structures were measured at 262,144 x 256 x 256 (profiles/r03_gemm_sb_ablation.txt): this one — one wave per SIMD, software-
+// pipelined — 254 us; eight identical waves (two per SIMD) 283 us; four consumer + four producer waves with one barrier per
+// stage 269 us; the exact f32 kernel 285 us.  In all three the parts ADD instead of overlapping: MFMAs + operand reads alone
+// 120-155 us (the bf16 matrix pipe at full rate pulls the clock to ~1.6 GHz: 196,608 matrix cycles per SIMD), the operands'
+// split another 75-95 us EVEN WHEN IT RUNS ON THE SIMD'S OTHER WAVE — as section 4a found for the f32 MFMA, VALU work is
+// paid in matrix time on this hardware — and each of the N / 64 column slices re-splits the same activation rows (three
+// bf16 planes of a 256-long weight slice fill LDS at 64 columns), which pre-splitting in the producer kernel would only
+// trade for 1.5 x the activation bytes on kernels that are HBM-bound at this matrix rate.
 // TRANS_W == false: W is [n][red] (nn.Linear weight, forward);  true: W is [red][n] (input gradient).
 // ABL (probe build only, tools/abl_gemm_sb.py; wrong results by design): 1 no MFMAs, 2 no split / LDS parking, 4 no activation
 // loads inside the loop, 8 no stores.
