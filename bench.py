@@ -346,6 +346,7 @@ def main():
     ap.add_argument("--timer-every", type=int, default=8,
                     help="ppo: HIP-event brackets around the launches of every K-th minibatch of the timed region (1: all; "
                          "the gather of the next minibatch is issued inside the previous one's bracket window either way)")
+    ap.add_argument("--graphs", action="store_true", help="ppo: replay the minibatch body as a hipGraph (A/B; measured 1 % slower than the eager queue)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=24.0)
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="nccl == RCCL (default); gloo only for --spawn-selftest on CPU")
@@ -381,6 +382,7 @@ def main():
     cfg.num_minibatches = a.minibatches
     cfg.max_train_steps = 10**12       # keep the LR anneal well-defined for any K
     cfg.device = str(dev)
+    cfg.use_graphs = bool(a.graphs)
     sys.stdout = open(os.devnull, "w") if rank != 0 else sys.stderr       # stdout carries the JSON line only
     trainer = PPOTrainer(cfg)
     T, N = cfg.update_freq, cfg.num_envs

@@ -64,6 +64,10 @@ class Config:
         self.rollout_chunk = 0            # vector steps per persistent launch (0: the whole rollout in one launch —
                                           # every extra launch boundary waits for the slowest workgroup again)
         self.rollout_refill = True        # persistent rollout: wave 1 prepares every env's next episode while wave 0 steps
+        self.use_graphs = False           # one rank: the minibatch body (gather, step(), norm + Adam) replayed as a hipGraph.
+                                          # Bit-identical to the eager loop, but measured SLOWER at bench shape (update 889 vs 881
+                                          # ms, A/B in one call: the host already runs ~19 launches ahead of 2.8 ms of kernels,
+                                          # and the graph executor's 4-7 us per kernel node exceed the eager queue's gaps)
         self.solved_reward = 200.0
 
 
@@ -266,6 +270,7 @@ class PPOTrainer:
                        torch.empty(mb, device=self.device))
         self._stage2 = tuple(torch.empty_like(t) for t in self._stage) if self.world_size > 1 else None
         self._reducer = None     # gdist.GradReducer over the flat gradient (world_size > 1; built on the first update)
+        self._graph = None       # captured minibatch body (one rank; update())
         self._timers = None      # set to a KernelTimers() to time kernels with HIP events (bench.py)
         if self.rank == 0:
             print(f"Device: {self.device} x{self.world_size} | envs/GPU: {N} | rollout T: {T}")
@@ -465,15 +470,46 @@ class PPOTrainer:
                 tm.stop("gather_minibatch", B)
             return out
 
+        # One rank, full-size minibatches: the minibatch body (gather, the ~17 launches of step(), norm + Adam) is captured once
+        # as a hipGraph and replayed; per minibatch the host issues an index copy, one scalar store (Adam's bias corrections
+        # and learning rate travel through device memory), the replay, and the copy of the metric row.  Same kernels, same
+        # order: bit-identical to the eager loop (tests/test_graphs_gpu.py).  Minibatches whose launches bench.py's timers
+        # bracket run eagerly (events cannot be recorded into a replay).
+        graphed = (one_pass and red is None and bool(getattr(cfg, "use_graphs", False)) and total % mb == 0
+                   and cfg.num_epochs * n_mb > 3)
+        gs = self._graph_state(fu, mb, obs_dim) if graphed else None
+
         sizes = []
         row = 0
         it = minibatches()
-        cur = gather(next(it), 0)
+        first = next(it)
+        cur = gather(first, 0) if not graphed else first
         while cur is not None:
-            mb_obs, mb_act, mb_lp, mb_adv, mb_ret = cur
-            B = mb_obs.shape[0]
             if tm is not None:
                 tm.tick()                            # (sampling timers: this minibatch's launches are bracketed or not)
+            if graphed:
+                mb_idx = cur
+                B = mb_idx.numel()
+                if tm is not None and tm.live:       # a bracketed minibatch: the eager sequence (and its timers)
+                    fu.timers = tm
+                    g5 = gather(mb_idx, 0)
+                    fu.step(*g5, self._loss_cfg, self._moments, self._metric_parts[row])
+                    tm.start("adam_step")
+                    self.optimizer.step(grad_scale=1.0)
+                    tm.stop("adam_step", self.flat_params.numel())
+                else:
+                    fu.timers = None
+                    gs["idx"].copy_(mb_idx)
+                    gs["scalars"].set(gs["off"], self.optimizer.next_bias())
+                    gs["scalars"].flush()
+                    gs["step"]()                     # two eager warm-ups per trainer, then capture + replay
+                    self._metric_parts[row].copy_(gs["metric"])
+                sizes.append(B)
+                row += 1
+                cur = next(it, None)
+                continue
+            mb_obs, mb_act, mb_lp, mb_adv, mb_ret = cur
+            B = mb_obs.shape[0]
             if one_pass:
                 fu.step(mb_obs, mb_act, mb_lp, mb_adv, mb_ret, self._loss_cfg, self._moments, self._metric_parts[row],
                         reducer=red)
@@ -511,6 +547,26 @@ class PPOTrainer:
         m = metrics.cpu().numpy() / np.asarray(sizes, np.float64)[:, None]   # the one host sync of the update
         m = m.mean(axis=0)
         return {"policy_loss": m[0], "value_loss": m[1], "entropy": m[2], "clip_frac": m[3], "approx_kl": m[4]}
+
+    def _graph_state(self, fu, mb, obs_dim):
+        """Fixed buffers + the captured minibatch body (rebuilt when the update object, the minibatch size or the packed
+        rollout's address change)."""
+        key = (id(fu), mb, self._packed.data_ptr(), self._stage[0].data_ptr())
+        gs = self._graph
+        if gs is None or gs["key"] != key:
+            from .graphs import GraphedStep, StepScalars
+            sc = StepScalars(self.device)
+            bias, off = sc.slot(16, torch.float32)
+            gs = self._graph = dict(key=key, scalars=sc, bias=bias, off=off,
+                                    idx=torch.empty(mb, dtype=torch.int32, device=self.device),
+                                    metric=torch.zeros(fu.metric_blocks(mb), 5, dtype=torch.float64, device=self.device))
+
+            def body():
+                g5 = ops.gather_minibatch(self._packed, gs["idx"], obs_dim, self._stage)
+                fu.step(*g5, self._loss_cfg, self._moments, gs["metric"])
+                self.optimizer.step(grad_scale=1.0, bias_dev=gs["bias"])
+            gs["step"] = GraphedStep(body, warmup=2)
+        return gs
 
     # ----------------------------------------------------------- checkpoint --
     def save_checkpoint(self, path):

@@ -184,3 +184,36 @@ def test_baseline_config_sizes_graphed_equals_eager(algo):
         for name in ("actor_flat", "critic_flat", "critic_target_flat", "log_alpha"):
             assert torch.equal(getattr(eager, name), getattr(graph, name)), name
         assert bool(torch.isfinite(graph.actor_flat).all()) and len(graph.memory) == len(eager.memory) > n_envs
+
+
+@pytest.mark.parametrize("hidden,every", [(256, 0), (256, 3), (64, 0)])
+def test_ppo_minibatch_graph_equals_eager(hidden, every):
+    """PPOTrainer.update(): the minibatch body (gather, the hand-GEMM step(), norm + Adam with device-side bias corrections)
+    replayed as a hipGraph == the eager loop bit for bit — parameters, Adam moments, metrics; also when bench.py's sampling
+    timers pull every third minibatch out of the replay into the bracketed eager sequence, and across two iterations with
+    the annealed learning rate (it travels through the scalar block, not through the capture)."""
+    from gymrl_amd.ppo_lunarlander import Config, KernelTimers, PPOTrainer
+
+    def run(graphs):
+        cfg = Config()
+        cfg.num_envs, cfg.update_freq, cfg.num_epochs, cfg.num_minibatches, cfg.seed = 128, 32, 2, 8, 4
+        cfg.hidden_dim, cfg.use_graphs, cfg.max_train_steps = hidden, graphs, 128 * 32 * 4
+        tr = PPOTrainer(cfg)
+        if every:
+            tr._timers = KernelTimers(every=every)
+        ms = []
+        for it in range(2):
+            lr = cfg.lr * (1.0 - tr.step_count / cfg.max_train_steps)
+            for g in tr.optimizer.param_groups:
+                g["lr"] = lr
+            ms.append(tr.update(tr.collect_rollout()))
+        return tr, ms
+    (a, ma), (b, mb_) = run(False), run(True)
+    assert b._graph is not None and b._graph["step"].graph is not None and a._graph is None
+    assert a.optimizer.step_count == b.optimizer.step_count == 32
+    assert torch.equal(a.flat_params, b.flat_params)
+    assert torch.equal(a.optimizer.m, b.optimizer.m) and torch.equal(a.optimizer.v, b.optimizer.v)
+    assert ma == mb_
+    if every:
+        ks = b._timers.summary()
+        assert ks["gemm_fwd_256_tanh"]["launches"] == 11            # minibatches 0, 3, 6, ... of the 32 of both updates
