@@ -590,7 +590,7 @@ def report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev,
             ent.update(bound="mfma", flops_per_unit=flops_per_unit[k], achieved_TFLOPs=round(tf, 1), frac=round(tf * 1e12 / MFMA_F32_PEAK, 4))
         kernels[k] = ent
     prof = None
-    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             prof = (name, json.load(open(path)))
