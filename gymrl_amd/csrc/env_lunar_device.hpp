@@ -44,6 +44,9 @@ constexpr float kLegDown = 18.0f / kScale;
 constexpr float kLegAway = 20.0f / kScale;
 constexpr float kDt = 1.0f / 50.0f;
 constexpr int kVelIters = 180, kPosIters = 60, kMaxSteps = 1000;
+// kLinearSlopSqMax: the largest float whose correctly rounded square root is <= kLinearSlop (sqrtf is monotonic, so
+// sqrtf(x) <= kLinearSlop  <=>  x <= kLinearSlopSqMax, bit for bit; tests/test_lunar_constants.py re-derives it)
+constexpr float kLinearSlopSqMax = 0x1.a36e30p-16f;
 constexpr float kLinearSlop = 0.005f, kAngularSlop = 2.0f / 180.0f * 3.14159265359f;
 constexpr float kPolyRadius = 2.0f * kLinearSlop;           // b2_polygonRadius
 constexpr float kMaxLinCorr = 0.2f, kMaxAngCorr = 8.0f / 180.0f * 3.14159265359f;
@@ -112,14 +115,24 @@ struct Lds {
   __device__ __forceinline__ uint32_t& vu(int s, int f) const { return w[(2 * kMfWords + s * kVcWords + f) * kEnvBlock]; }
 };
 
-// quad broadcast: every lane of a quad reads lane R's value (v_mov_b32 dpp quad_perm:[R,R,R,R])
+// quad broadcast: every lane of a quad reads lane R's value (v_mov_b32 dpp quad_perm:[R,R,R,R]; bound_ctrl: every source
+// lane of a quad permutation is valid, and without it the compiler first zeroes the destination — one more instruction)
 template <int R>
 __device__ __forceinline__ float quad_bcast(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), R * 0x55, 0xF, 0xF, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), R * 0x55, 0xF, 0xF, true));
 }
+// general quad permutation (dpp quad_perm, CTRL = src of lane 0 | lane 1 << 2 | lane 2 << 4 | lane 3 << 6); the compiler folds
+// the move into the consuming VALU instruction's first operand (v_mul_f32_dpp ...)
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+constexpr int kRot1 = 0xC9;     // lanes (0,1,2,3) read lanes (1,2,0,3)
+constexpr int kRot2 = 0xD2;     // lanes (0,1,2,3) read lanes (2,0,1,3)
+constexpr int kSwap01 = 0xE1;   // lanes (0,1,2,3) read lanes (1,0,2,3)
 template <int R>
 __device__ __forceinline__ uint32_t quad_bcast_u(uint32_t x) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, R * 0x55, 0xF, 0xF, false);
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, R * 0x55, 0xF, 0xF, true);
 }
 enum { MF_COUNT = 0, MF_FACEB = 1, MF_LNX = 2, MF_LNY = 3, MF_LPX = 4, MF_LPY = 5, MF_P0 = 6, MF_P1 = 11,
        P_LPX = 0, P_LPY = 1, P_KEY = 2, P_NI = 3, P_TI = 4 };
@@ -649,67 +662,126 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
     at_limit[L] = W.j[L].state != 0;                 // the state is fixed for the whole velocity solve
     lim_sign[L] = W.j[L].state == 1 ? 1.0f : -1.0f;  // lower limit: release when the impulse turns negative; upper: positive
   }
-  v2f jpA[2] = {v2f{jpAx[0], jpAy[0]}, v2f{jpAx[1], jpAy[1]}}, jpB[2] = {v2f{jpBx[0], jpBy[0]}, v2f{jpBx[1], jpBy[1]}};
-  v2f vel[3] = {v2f{B[0].vx, B[0].vy}, v2f{B[1].vx, B[1].vy}, v2f{B[2].vx, B[2].vy}};
-  float om[3] = {B[0].w, B[1].w, B[2].w};
-  // velocity iterations.  One wavefront issues one VALU instruction per 4 clocks however many lanes are live, and a
-  // sweep is 180 x per step: the joint solve is written branch-free on scalars — the 3 x 3 (at a limit) and 2 x 2
-  // solutions are both formed and selected per lane, exactly the values the branches of b2RevoluteJoint::
-  // SolveVelocityConstraints produce — which costs ~210 instructions per sweep instead of ~295 with exec-mask
-  // branches, packed-register shuffles and their hazard no-ops.
+  // Velocity iterations.  The solver wave issues one VALU instruction per 4 clocks whatever it computes (measured:
+  // tools/ubench/valu_latency.hip), so a sweep costs its instruction COUNT: the joint solve is written across the quad —
+  // lane r of an env's four lanes holds component r of every 3-vector (x, y, angular) — and one instruction does for
+  // (x, y, z) what three did when each lane carried a full copy: body velocities VA / VB, the accumulated impulse JI =
+  // (ix, iy, iz), the Cramer cofactors and the 2 x 2 solve are lane vectors, dot products reduce over the quad with DPP
+  // operands IN THE ORDER b2Mat33::Solve33 adds them, and each lane applies exactly the operations, on the same values,
+  // that b2RevoluteJoint::SolveVelocityConstraints applies to its component (branch-free: the 3 x 3 solution at a limit
+  // and the 2 x 2 one are both formed and selected).  ~65 VALU instructions per joint instead of ~105.
+  const bool r0 = role == 0, r1 = role == 1, r2 = role == 2;
+  auto lane3 = [&](float x, float y, float z) { return r0 ? x : (r1 ? y : (r2 ? z : 0.0f)); };
+  float JPA[2], JPB[2], C1[2], P2[2], Q2[2], A2[2], P3[2], Q3[2], A3[2], A3C[2], D2[2], MBv[2], IBz[2];
+#pragma unroll
+  for (int L = 0; L < 2; ++L) {
+    const float a11 = K11[L], a12 = K12[L], a13 = K13[L], a22 = K22[L], a23 = K23[L], a33 = K33[L];
+    JPA[L] = lane3(jpAx[L], jpAy[L], 0.0f); JPB[L] = lane3(jpBx[L], jpBy[L], 0.0f);
+    C1[L] = lane3(c1x[L], c1y[L], c1z[L]);
+    // second / third Cramer columns, rotated so that the three-term sums end in lane 1 / lane 2 in Solve33's order
+    P2[L] = lane3(a23, a33, a13); Q2[L] = lane3(a13, a23, a33); A2[L] = lane3(a13, a11, a12);
+    P3[L] = lane3(a23, a12, a22); Q3[L] = lane3(a12, a22, a23); A3[L] = lane3(a12, a13, a11);
+    A3C[L] = lane3(a13, a23, 0.0f); D2[L] = lane3(a22, a11, 0.0f);
+    MBv[L] = lane3(kInvM[L + 1], kInvM[L + 1], kInvI[L + 1]); IBz[L] = r2 ? kInvI[L + 1] : 0.0f;
+  }
+  const float MAv = lane3(kInvM[0], kInvM[0], kInvI[0]), IAz = r2 ? kInvI[0] : 0.0f;
+  float VA = lane3(B[0].vx, B[0].vy, B[0].w);
+  float VB[2] = {lane3(B[1].vx, B[1].vy, B[1].w), lane3(B[2].vx, B[2].vy, B[2].w)};
+  float JI[2] = {lane3(W.j[0].ix, W.j[0].iy, W.j[0].iz), lane3(W.j[1].ix, W.j[1].iy, W.j[1].iz)};
+  float IM[2] = {W.j[0].im, W.j[1].im};            // motor impulse: lane 2's copy is the joint's (the chain below runs on lane 2's angular velocities)
+  const float maxImp = h * kMotorTorque;
+  // The order of the statements below IS the instruction schedule (a scheduling barrier after each one): an instruction
+  // that reads a register through DPP must not follow its producer by less than two issue slots, or the hardware wants
+  // an s_nop 1 — which costs this lone wave two of the ~5-clock issue slots every instruction costs it.  The compiler's
+  // own order had 29 of them in 125 instructions.
+#define SB __builtin_amdgcn_sched_barrier(0)
+#define USEL(c, a, b) (__builtin_unpredictable(c) ? (a) : (b))   // a select the compiler may not turn into a branch
+  float zb[2];                                     // bcast(iz) * (a13, a23, 0): the limit impulse's share of the 2 x 2 right-hand side
+  zb[1] = quad_perm<0xAA>(JI[1]) * A3C[1];
+  zb[0] = 0.0f;
+  float lim_nan[2] = {at_limit[0] ? lim_sign[0] : __builtin_nanf(""), at_limit[1] ? lim_sign[1] : __builtin_nanf("")};
+  asm volatile("" : "+v"(lim_nan[0]), "+v"(lim_nan[1]));     // keep them registers (the compiler would redo the selects in the loop)
 #pragma nounroll
   for (int it = 0; it < kVelIters; ++it) {
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int L = 1 - jj;
-      const int bi = L + 1;
-      Joint& J = W.j[L];
-      const float mA = kInvM[0], mB = kInvM[bi], iA = kInvI[0], iB = kInvI[bi];
-      {  // motor
-        const float Cdot = om[bi] - om[0] - 0.3f * leg_sign(L);
-        float imp = -mmass[L] * Cdot;
-        const float old = J.im, maxImp = h * kMotorTorque;
-        J.im = clampf(old + imp, -maxImp, maxImp);
-        imp = J.im - old;
-        om[0] -= iA * imp; om[bi] += iB * imp;
-      }
-      // Cdot = vB + wB x rB - vA - wA x rA
-      const v2f C = ((vel[bi] + om[bi] * jpB[L]) - vel[0]) - om[0] * jpA[L];
-      const float Cx = C.x, Cy = C.y;
-      const float Cz = om[bi] - om[0];
-      const float a11 = K11[L], a12 = K12[L], a13 = K13[L], a22 = K22[L], a23 = K23[L], a33 = K33[L];
-      // impulse = -K^-1 * Cdot (b2Mat33::Solve33, Cramer)
-      const float det = det3i[L];
-      const float sx = det * (Cx * c1x[L] + Cy * c1y[L] + Cz * c1z[L]);
-      const float c2x = Cy * a33 - Cz * a23, c2y = Cz * a13 - Cx * a33, c2z = Cx * a23 - Cy * a13;
-      const float sy = det * (a11 * c2x + a12 * c2y + a13 * c2z);
-      const float c3x = a22 * Cz - a23 * Cy, c3y = a23 * Cx - a12 * Cz, c3z = a12 * Cy - a22 * Cx;
-      const float sz = det * (a11 * c3x + a12 * c3y + a13 * c3z);
-      const float newImp = J.iz + (-sz);
       const bool lim = at_limit[L];
-      const bool release = lim && (lim_sign[L] * newImp < 0.0f);
-      // the 2 x 2 solution: the point constraint alone (no limit), or after the limit impulse is taken back (release)
-      const float rx = lim ? (-Cx + J.iz * a13) : -Cx;
-      const float ry = lim ? (-Cy + J.iz * a23) : -Cy;
-      const float d2 = det2i[L];
-      const float ux = d2 * (a22 * rx - a12 * ry), uy = d2 * (a11 * ry - a12 * rx);
-      const bool two = !lim || release;
-      const float ipx = two ? ux : -sx, ipy = two ? uy : -sy;
-      const float ipz = lim ? (release ? -J.iz : -sz) : 0.0f;
-      J.ix += ipx; J.iy += ipy;
-      J.iz = lim ? (release ? 0.0f : newImp) : J.iz;
-      const v2f ip = v2f{ipx, ipy};
-      vel[0] -= mA * ip;
-      om[0] -= iA * ((jrAx[L] * ipy - jrAy[L] * ipx) + ipz);
-      vel[bi] += mB * ip;
-      om[bi] += iB * ((jrBx[L] * ipy - jrBy[L] * ipx) + ipz);
+      // motor (lane 2 carries the angular velocities)
+      float t = VB[L] - VA; SB;
+      t = t - 0.3f * leg_sign(L); SB;
+      float imp = -mmass[L] * t; SB;
+      float nw = IM[L] + imp; SB;
+      nw = __builtin_amdgcn_fmed3f(nw, -maxImp, maxImp); SB;          // == clampf for lo <= hi, no NaN
+      imp = nw - IM[L]; IM[L] = nw; SB;
+      const float mb_ = IBz[L] * imp; SB;
+      VB[L] = VB[L] + mb_; SB;
+      const float ma_ = IAz * imp; SB;
+      VA = VA - ma_; SB;
+      // Cdot = vB + wB x rB - vA - wA x rA (lanes 0, 1), wB - wA (lane 2: the arms' third components are +0)
+      const float xb = quad_perm<0xAA>(VB[L]) * JPB[L]; SB;
+      float c = VB[L] + xb; SB;
+      const float xa = quad_perm<0xAA>(VA) * JPA[L]; SB;
+      c = c - VA; SB;
+      c = c - xa; SB;
+      // impulse = -K^-1 * Cdot (b2Mat33::Solve33, Cramer): x ends in lane 0, y in lane 1, z in lane 2
+      const float u1 = c * C1[L]; SB;
+      const float zc = zb[L] - c; SB;
+      const float q2 = quad_perm<kRot1>(c) * Q2[L]; SB;
+      const float q3 = quad_perm<kRot2>(c) * Q3[L]; SB;
+      const float m2 = c * P2[L] - q2; SB;
+      const float m3 = c * P3[L] - q3; SB;
+      float s1 = quad_perm<kRot1>(u1) + u1; SB;
+      const float u2 = A2[L] * m2; SB;
+      const float u3 = A3[L] * m3; SB;
+      s1 = quad_perm<kRot2>(u1) + s1; SB;
+      // right-hand side of the 2 x 2 solution: the point constraint alone (no limit), or with the limit impulse taken back
+      const float rr = USEL(lim, zc, -c); SB;
+      float s2 = quad_perm<kRot1>(u2) + u2; SB;
+      float s3 = quad_perm<kRot1>(u3) + u3; SB;
+      const float d2r = D2[L] * rr; SB;
+      s2 = quad_perm<kRot2>(u2) + s2; SB;
+      s3 = quad_perm<kRot2>(u3) + s3; SB;
+      const float r2_ = quad_perm<kSwap01>(rr) * K12[L]; SB;
+      float sel = USEL(r1, s2, s3); SB;
+      sel = USEL(r0, s1, sel); SB;
+      const float nsol = -(det3i[L] * sel); SB;
+      const float newJ = JI[L] + nsol; SB;             // lane 2: the limit impulse after this sweep
+      const float uu = d2r - r2_; SB;
+      const float u = det2i[L] * uu; SB;
+      // the limit releases when its impulse turns to the wrong side; `lim_nan` is lim_sign at a limit and NaN without one,
+      // so that ONE unordered compare says "no limit, or the limit releases" (no SALU mask arithmetic in the sweep)
+      const float rt = quad_perm<0xAA>(newJ) * lim_nan[L]; SB;
+      const float altz = USEL(lim, -JI[L], 0.0f); SB;
+      const float alt = USEL(r2, altz, u); SB;
+      float ip;                                        // (ipx, ipy, ipz) = !(rt >= 0) ? alt : nsol — through VCC: a mask in an SGPR pair costs two wait states
+      asm("v_cmp_nge_f32 vcc, %1, 0\n\tv_cndmask_b32_e32 %0, %2, %3, vcc" : "=v"(ip) : "v"(rt), "v"(nsol), "v"(alt) : "vcc"); SB;
+      JI[L] = JI[L] + ip; SB;                          // lane 2: newJ, or iz + (-iz) = 0 on release
+      zb[1 - L] = quad_perm<0xAA>(JI[1 - L]) * A3C[1 - L]; SB;           // for the OTHER joint's next solve (its JI is long written)
+      const float ay = quad_perm<0x55>(ip) * jrAx[L]; SB;
+      const float ax = quad_perm<0x00>(ip) * jrAy[L]; SB;
+      const float by = quad_perm<0x55>(ip) * jrBx[L]; SB;
+      const float bx = quad_perm<0x00>(ip) * jrBy[L]; SB;
+      const float crA = ay - ax; SB;
+      const float crB = by - bx; SB;
+      const float wA = crA + ip; SB;
+      const float wB = crB + ip; SB;
+      float tA = USEL(r2, wA, ip); SB;
+      float tB = USEL(r2, wB, ip); SB;
+      tA = MAv * tA; SB;
+      tB = MBv[L] * tB; SB;
+      VA = VA - tA; SB;
+      VB[L] = VB[L] + tB; SB;
     }
+#undef SB
+#undef USEL
     // contacts: each lane solves its own body's slots, then the quad exchanges velocities
     if (any_contact) {
       Body me;                                  // only the velocities are touched in a sweep
       me.cx = me.cy = me.a = 0.0f;
-      me.vx = sel3(mb, vel[0].x, vel[1].x, vel[2].x); me.vy = sel3(mb, vel[0].y, vel[1].y, vel[2].y);
-      me.w = sel3(mb, om[0], om[1], om[2]);
+      me.vx = sel3(mb, quad_bcast<0>(VA), quad_bcast<0>(VB[0]), quad_bcast<0>(VB[1]));
+      me.vy = sel3(mb, quad_bcast<1>(VA), quad_bcast<1>(VB[0]), quad_bcast<1>(VB[1]));
+      me.w = sel3(mb, quad_bcast<2>(VA), quad_bcast<2>(VB[0]), quad_bcast<2>(VB[1]));
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int vcount = vcn[s];
@@ -786,13 +858,18 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
           if (vcount == 2) { vim[s][2] = ni1; vim[s][3] = ti1; }
         }
       }
-      vel[0] = v2f{quad_bcast<0>(me.vx), quad_bcast<0>(me.vy)}; om[0] = quad_bcast<0>(me.w);
-      vel[1] = v2f{quad_bcast<1>(me.vx), quad_bcast<1>(me.vy)}; om[1] = quad_bcast<1>(me.w);
-      vel[2] = v2f{quad_bcast<2>(me.vx), quad_bcast<2>(me.vy)}; om[2] = quad_bcast<2>(me.w);
+      VA = lane3(quad_bcast<0>(me.vx), quad_bcast<0>(me.vy), quad_bcast<0>(me.w));
+      VB[0] = lane3(quad_bcast<1>(me.vx), quad_bcast<1>(me.vy), quad_bcast<1>(me.w));
+      VB[1] = lane3(quad_bcast<2>(me.vx), quad_bcast<2>(me.vy), quad_bcast<2>(me.w));
     }
   }
+  B[0].vx = quad_bcast<0>(VA); B[0].vy = quad_bcast<1>(VA); B[0].w = quad_bcast<2>(VA);
 #pragma unroll
-  for (int b = 0; b < 3; ++b) { B[b].vx = vel[b].x; B[b].vy = vel[b].y; B[b].w = om[b]; }
+  for (int L = 0; L < 2; ++L) {
+    B[L + 1].vx = quad_bcast<0>(VB[L]); B[L + 1].vy = quad_bcast<1>(VB[L]); B[L + 1].w = quad_bcast<2>(VB[L]);
+    W.j[L].ix = quad_bcast<0>(JI[L]); W.j[L].iy = quad_bcast<1>(JI[L]); W.j[L].iz = quad_bcast<2>(JI[L]);
+    W.j[L].im = quad_bcast<2>(IM[L]);
+  }
   LUNAR_PROF_MARK(pt3);
   LUNAR_PROF_ADD(lds, 2, pt2, pt3);          // 180 velocity sweeps
   LUNAR_PROF_ADD(lds, any_contact ? 6 : 7, pt2, pt3);
@@ -938,7 +1015,9 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
       const float rAx = qcA * lax - qsA * lay, rAy = qsA * lax + qcA * lay;
       const float rBx = qcB * lbx - qsB * lby, rBy = qsB * lbx + qcB * lby;
       const float Cx = B[bi].cx + rBx - B[0].cx - rAx, Cy = B[bi].cy + rBy - B[0].cy - rAy;
-      const float posErr = sqrtf(Cx * Cx + Cy * Cy);
+      // posErr = sqrtf(Cx * Cx + Cy * Cy) is only compared with the slop: compare the square with the exact threshold
+      // instead (the correctly rounded square root is ~20 instructions on a path a grounded lander walks 60 x per step)
+      const float posErr2 = Cx * Cx + Cy * Cy;
       const float k11 = mA + mB + iA * rAy * rAy + iB * rBy * rBy;
       const float k12 = -iA * rAx * rAy - iB * rBx * rBy;
       const float k22 = mA + mB + iA * rAx * rAx + iB * rBx * rBx;
@@ -949,10 +1028,10 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
       B[0].a -= iA * cross2(rAx, rAy, impx, impy);
       B[bi].cx += mB * impx; B[bi].cy += mB * impy;
       B[bi].a += iB * cross2(rBx, rBy, impx, impy);
-      joints_ok = joints_ok && (posErr <= kLinearSlop) && (angErr <= kAngularSlop);
+      joints_ok = joints_ok && (posErr2 <= kLinearSlopSqMax) && (angErr <= kAngularSlop);
 #ifdef GYMRL_LUNAR_PROF
       if (it == 10 && lds.prof && role == 0) {       // what keeps an env iterating: per cause, summed over envs
-        if (!(posErr <= kLinearSlop)) atomicAdd(&lds.prof[14], 1ull);
+        if (!(posErr2 <= kLinearSlopSqMax)) atomicAdd(&lds.prof[14], 1ull);
         if (!(angErr <= kAngularSlop)) atomicAdd(&lds.prof[15], 1ull);
       }
 #endif
