@@ -109,6 +109,7 @@ struct Lds {
 #ifdef GYMRL_LUNAR_PROF
   unsigned long long* prof;
 #endif
+  uint32_t* park = nullptr;   // persistent kernels: this lane's column of the parking area ([kParkWords][64 lanes]), see world_park
   __device__ __forceinline__ float& mf(int s, int f) const { return reinterpret_cast<float*>(w)[(s * kMfWords + f) * kEnvBlock]; }
   __device__ __forceinline__ uint32_t& mu(int s, int f) const { return w[(s * kMfWords + f) * kEnvBlock]; }
   __device__ __forceinline__ float& vc(int s, int f) const { return reinterpret_cast<float*>(w)[(2 * kMfWords + s * kVcWords + f) * kEnvBlock]; }
@@ -1231,6 +1232,35 @@ __device__ __forceinline__ void world_io(World& W, const Lds& lds, int role, uin
   io.f(W.prev_shaping, store);
 }
 
+// The persistent rollout kernels keep a world in LDS between the steps of one launch: the registers' part is parked in
+// this lane's column of `lds.park` (the manifold words already live in `lds.w` and simply stay there), so that only the
+// first step of a launch reads the [word][N] state from HBM and only the last one writes it back — 6.9 + 3.1 us of a
+// ~135-us vector step were that round trip through L2 (profiles/r03_rollout_state_io.txt).  The episode bookkeeping the
+// step reads (episode, length, return) is parked with it; its global copy is still written every step.
+constexpr int kParkWords = 31 + 1 + 14 + 4;
+__device__ __forceinline__ void world_park(World& W, const Lds& lds, bool store, uint32_t& episode, int& len, double& ret) {
+  int k = 0;
+  auto f = [&](float& x) { if (store) lds.park[k * kEnvBlock] = __float_as_uint(x); else x = __uint_as_float(lds.park[k * kEnvBlock]); ++k; };
+  auto u = [&](uint32_t& x) { if (store) lds.park[k * kEnvBlock] = x; else x = lds.park[k * kEnvBlock]; ++k; };
+  auto d = [&](int& x) { if (store) lds.park[k * kEnvBlock] = (uint32_t)x; else x = (int)lds.park[k * kEnvBlock]; ++k; };
+#pragma unroll
+  for (int b = 0; b < 3; ++b) { f(W.b[b].cx); f(W.b[b].cy); f(W.b[b].a); f(W.b[b].vx); f(W.b[b].vy); f(W.b[b].w); }
+#pragma unroll
+  for (int b = 0; b < 3; ++b) f(W.sleep[b]);
+#pragma unroll
+  for (int L = 0; L < 2; ++L) { f(W.j[L].ix); f(W.j[L].iy); f(W.j[L].iz); f(W.j[L].im); d(W.j[L].state); }
+  d(W.edge0);
+  u(W.touching);
+#pragma unroll
+  for (int t = 0; t < 11; ++t) f(W.ty[t]);
+  u(W.flags);
+  f(W.prev_shaping);
+  u(episode); d(len);
+  uint32_t lo = (uint32_t)(unsigned long long)__double_as_longlong(ret), hi = (uint32_t)((unsigned long long)__double_as_longlong(ret) >> 32);
+  u(lo); u(hi);
+  if (!store) ret = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // obs [N][8]: lanes 0/1 of each quad write the two 16-B halves of their env's row, so a
 // wave's 32 storing lanes cover 512 contiguous bytes.
 __device__ __forceinline__ void store_obs_quad(float* __restrict__ dst, int env, int role, const float (&o)[8]) {
@@ -1278,7 +1308,8 @@ struct StepOut {
 // already started, is never matched, and is rebuilt on the next step.
 __device__ __forceinline__ void lunar_step_quad(const LunarState& st, const Lds& lds, int n, int i, int role, bool valid,
                                                 int action_in, uint64_t seed, int64_t env_id0, const StepOut& out,
-                                                float (&o_next)[8], bool refill = false) {
+                                                float (&o_next)[8], bool refill = false, int io_mode = 0) {
+  // io_mode (stepping waves of the persistent kernels): bit 0 = the world comes from the LDS parking area, bit 1 = it goes back there
   float* __restrict__ obs_out = out.obs_out; float* __restrict__ term_obs_out = out.term_obs_out;
   float* __restrict__ rew_out = out.rew_out; uint8_t* __restrict__ terminated_out = out.terminated_out;
   uint8_t* __restrict__ truncated_out = out.truncated_out; uint8_t* __restrict__ done_out = out.done_out;
@@ -1306,10 +1337,13 @@ __device__ __forceinline__ void lunar_step_quad(const LunarState& st, const Lds&
     double ret0 = 0.0;
     int act = 0;
     if (!refill) {
-      world_io(W, lds, role, st.words, n, i, false);
-      episode = st.ep.episode[i];
-      len = st.ep.ep_len[i];
-      ret0 = st.ep.ep_ret[i];
+      if (io_mode & 1) world_park(W, lds, false, episode, len, ret0);
+      else {
+        world_io(W, lds, role, st.words, n, i, false);
+        episode = st.ep.episode[i];
+        len = st.ep.ep_len[i];
+        ret0 = st.ep.ep_ret[i];
+      }
       act = action_in;
       act = act < 0 ? 0 : (act > 3 ? 3 : act);
     }
@@ -1359,7 +1393,12 @@ __device__ __forceinline__ void lunar_step_quad(const LunarState& st, const Lds&
       }
     }
     if (!refill) {
-      world_io(W, lds, role, st.words, n, i, true);
+      if (io_mode & 2) {
+        uint32_t p_ep = done ? episode + 1u : episode;
+        int p_len = done ? 0 : len;
+        double p_ret = done ? 0.0 : ret;
+        world_park(W, lds, true, p_ep, p_len, p_ret);
+      } else world_io(W, lds, role, st.words, n, i, true);
       store_obs_quad(obs_out, i, role, o_next);
       if (term_obs_out) store_obs_quad(term_obs_out, i, role, o_term);
     } else {                                          // publish the spare: world, observation, then the flag

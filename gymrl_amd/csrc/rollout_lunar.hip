@@ -37,12 +37,14 @@ constexpr int kActions = 4, kObs = 8;
 constexpr int kGaeChunk = 16;        // == gymrl_gae_chunk() (gae.hip kBlkTC)
 constexpr int kDynFloats = M::kBufs * M::kRows * M::kStride + M::kRows * M::kInStride + M::kRows * M::kHeadStride;
 constexpr int kDynBytes = 96 * 1024; // > 80 KB: one workgroup per CU (as mlp_forward_kernel)
+constexpr int kDynBytesMhc = 32 * 1024;   // the mHC kernel's static LDS (policy tile, solver columns, parking) is already 64 KB: > 80 KB in all
 static_assert(kDynFloats * 4 <= kDynBytes, "LDS carve-up");
 
 __global__ __launch_bounds__(kThreads) void rollout_lunar_kernel(gymrl_rollout_lunar_args a, gymrl_mlp_desc d) {
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
   __shared__ uint32_t lds_words[kLdsWords * kEnvBlock];            // the solver's per-lane columns (wave 0)
   __shared__ uint32_t lds_words_refill[kLdsWords * kEnvBlock];     // the same for the refill wave (wave 1)
+  __shared__ uint32_t lds_park[kParkWords * kEnvBlock];            // wave 0's worlds between the steps of this launch
   float (*lds)[M::kRows * M::kStride] = reinterpret_cast<float (*)[M::kRows * M::kStride]>(dyn_lds);
   float* xin = dyn_lds + M::kBufs * M::kRows * M::kStride;
   float* head = xin + M::kRows * M::kInStride;
@@ -55,9 +57,9 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_kernel(gymrl_rollout_l
   const bool valid = i < N;
   const LunarState st(a.env_state, N);
 #ifdef GYMRL_LUNAR_PROF
-  const Lds slds{lds_words + lane, a.wg_ticks ? reinterpret_cast<unsigned long long*>(a.wg_ticks) + 2 * gridDim.x + 16 * blockIdx.x : nullptr};
+  const Lds slds{lds_words + lane, a.wg_ticks ? reinterpret_cast<unsigned long long*>(a.wg_ticks) + 2 * gridDim.x + 16 * blockIdx.x : nullptr, lds_park + lane};
 #else
-  const Lds slds{lds_words + lane};
+  const Lds slds{lds_words + lane, lds_park + lane};
 #endif
 #ifdef GYMRL_LUNAR_PROF
   const Lds rlds{lds_words_refill + lane, nullptr};
@@ -115,7 +117,9 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_kernel(gymrl_rollout_l
         float o_next[8];
         LUNAR_PROF_MARK(rt2);
         if (!refill_wave) LUNAR_PROF_ADD(slds, 9, rt1, rt2);          // GAE compose + draw + slab writes
-        lunar_step_quad(st, refill_wave ? rlds : slds, N, i, role, valid, act, a.seed, a.env_id0, out, o_next, refill_wave);
+        // the worlds stay in LDS between the steps of this launch: HBM is read at its first step and written at its last
+        const int io_mode = (t > a.t0 ? 1 : 0) | (t + 1 < t_end ? 2 : 0);
+        lunar_step_quad(st, refill_wave ? rlds : slds, N, i, role, valid, act, a.seed, a.env_id0, out, o_next, refill_wave, io_mode);
         LUNAR_PROF_MARK(rt3);
         if (!refill_wave) LUNAR_PROF_ADD(slds, 10, rt2, rt3);         // whole env step (state load, world_step, reward, reset, store)
         if (!refill_wave && valid && role < 2) {      // next policy input: straight into the forward's LDS tile
@@ -144,6 +148,7 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_mhc_kernel(gymrl_rollo
   __shared__ mhc::PolicyLds L;
   __shared__ uint32_t lds_words[kLdsWords * kEnvBlock];            // the solver's per-lane columns (wave 0)
   __shared__ uint32_t lds_words_refill[kLdsWords * kEnvBlock];     // the same for the refill wave (wave 1)
+  __shared__ uint32_t lds_park[kParkWords * kEnvBlock];            // wave 0's worlds between the steps of this launch
   float* xin = dyn_lds;                                            // [16][kXStride] observations
   float* head = xin + M::kRows * kXStride;                         // [16][kHeadStride]: logits 0..3, value 4
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -155,9 +160,9 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_mhc_kernel(gymrl_rollo
   const int prow = 4 * wave + (lane >> 4);                         // the policy tile's view: this lane's row
   const LunarState st(a.env_state, N);
 #ifdef GYMRL_LUNAR_PROF
-  const Lds slds{lds_words + lane, nullptr}, rlds{lds_words_refill + lane, nullptr};
+  const Lds slds{lds_words + lane, nullptr, lds_park + lane}, rlds{lds_words_refill + lane, nullptr};
 #else
-  const Lds slds{lds_words + lane}, rlds{lds_words_refill + lane};
+  const Lds slds{lds_words + lane, lds_park + lane}, rlds{lds_words_refill + lane};
 #endif
   const bool two = a.gae_running2 != nullptr;
   const double gl = two ? a.gamma * a.lam : (double)(float)(a.gamma * a.lam);
@@ -210,7 +215,9 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_mhc_kernel(gymrl_rollo
         const StepOut out{a.obs + (size_t)(t + 1) * N * kObs, nullptr, a.rew + (size_t)t * N, nullptr, nullptr,
                           a.done + (size_t)t * N, a.ep_ret ? a.ep_ret + (size_t)t * N : nullptr, nullptr, a.ep_stats};
         float o_next[8];
-        lunar_step_quad(st, refill_wave ? rlds : slds, N, i, role, valid, act, a.seed, a.env_id0, out, o_next, refill_wave);
+        // the worlds stay in LDS between the steps of this launch: HBM is read at its first step and written at its last
+        const int io_mode = (t > a.t0 ? 1 : 0) | (t + 1 < t_end ? 2 : 0);
+        lunar_step_quad(st, refill_wave ? rlds : slds, N, i, role, valid, act, a.seed, a.env_id0, out, o_next, refill_wave, io_mode);
         if (!refill_wave && valid && role < 2) {      // next policy input: straight into the forward's LDS tile
 #pragma unroll
           for (int k = 0; k < 4; ++k) xin[row * kXStride + 4 * role + k] = o_next[4 * role + k];
@@ -273,12 +280,12 @@ int gymrl_rollout_lunar_mhc(const gymrl_rollout_lunar_args* a, const gymrl_mhc_p
   if (a->nsteps == 0 && a->t0 != a->T) return 0;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)rollout_lunar_mhc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDynBytes) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)rollout_lunar_mhc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDynBytesMhc) != hipSuccess)
       return -1000 - (int)hipGetLastError();
     attr_set = true;
   }
   const int blocks = (a->n_envs + M::kRows - 1) / M::kRows;
-  hipLaunchKernelGGL(rollout_lunar_mhc_kernel, dim3(blocks), dim3(kThreads), kDynBytes, (hipStream_t)stream, *a, p);
+  hipLaunchKernelGGL(rollout_lunar_mhc_kernel, dim3(blocks), dim3(kThreads), kDynBytesMhc, (hipStream_t)stream, *a, p);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
