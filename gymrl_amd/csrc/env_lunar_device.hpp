@@ -702,8 +702,7 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
   zb[0] = 0.0f;
   float lim_nan[2] = {at_limit[0] ? lim_sign[0] : __builtin_nanf(""), at_limit[1] ? lim_sign[1] : __builtin_nanf("")};
   asm volatile("" : "+v"(lim_nan[0]), "+v"(lim_nan[1]));     // keep them registers (the compiler would redo the selects in the loop)
-#pragma nounroll
-  for (int it = 0; it < kVelIters; ++it) {
+  auto joints = [&]() {
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int L = 1 - jj;
@@ -774,8 +773,10 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
       VA = VA - tA; SB;
       VB[L] = VB[L] + tB; SB;
     }
+  };
 #undef SB
 #undef USEL
+  auto contacts = [&]() {
     // contacts: each lane solves its own body's slots, then the quad exchanges velocities
     if (any_contact) {
       Body me;                                  // only the velocities are touched in a sweep
@@ -863,6 +864,14 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
       VB[0] = lane3(quad_bcast<1>(me.vx), quad_bcast<1>(me.vy), quad_bcast<1>(me.w));
       VB[1] = lane3(quad_bcast<2>(me.vx), quad_bcast<2>(me.vy), quad_bcast<2>(me.w));
     }
+  };
+  // a wave without a single contact (most steps of most workgroups) runs the sweeps without the per-sweep test
+  if (__builtin_amdgcn_ballot_w64(any_contact) == 0ull) {
+#pragma nounroll
+    for (int it = 0; it < kVelIters; ++it) joints();
+  } else {
+#pragma nounroll
+    for (int it = 0; it < kVelIters; ++it) { joints(); contacts(); }
   }
   B[0].vx = quad_bcast<0>(VA); B[0].vy = quad_bcast<1>(VA); B[0].w = quad_bcast<2>(VA);
 #pragma unroll
