@@ -42,7 +42,6 @@ __global__ void lat(float* out, long long* cyc, int iters) {
     if (KIND == 25) { REP16(asm volatile("s_nop 1" ::);) }
     if (KIND == 26) { REP16(asm volatile("s_nop 0" ::);) }
     if (KIND == 27) { REP16(asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a) : "v"(m), "s"(msk));) }
-    if (KIND == 28) { REP16(asm volatile("v_cmp_gt_f32_e64 %1, %0, %2\n s_and_b64 %1, %1, %3\n v_cndmask_b32_e64 %0, %0, %2, %1" : "+v"(a), "+s"(msk2) : "v"(m), "s"(msk));) }
     if (KIND == 29) { REP16(asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a) : "v"(k), "v"(m));) }
     if (KIND == 30) { REP16(asm volatile("v_mul_f32_dpp %0, %0, %1 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a) : "v"(m));) }
     if (KIND == 31) { REP16(asm volatile("v_mul_f32 %0, %0, %2\n v_readlane_b32 %1, %0, 2\n v_mul_f32 %0, %0, %1" : "+v"(a), "+s"(sc) : "v"(m));) }
@@ -79,7 +78,7 @@ int main() {
   run<21>("2 independent v_mul_f32_dpp (src ready)", 2);
   run<22>("mul a, mul b, dpp-mul a (1 instr between)", 3); run<23>("mul a, mul b, mul a (reference)", 3);
   run<24>("s_nop 1 + v_mov_dpp + v_mul chain", 3); run<25>("s_nop 1 alone", 1); run<26>("s_nop 0 alone", 1);
-  run<27>("v_cndmask_b32_e64 chain (sgpr mask)", 1); run<28>("v_cmp -> s_and -> v_cndmask chain", 3); run<29>("v_med3_f32 chain", 1);
+  run<27>("v_cndmask_b32_e64 chain (sgpr mask)", 1); run<29>("v_med3_f32 chain", 1);
   run<31>("mul, v_readlane, mul (sgpr) chain", 3);
   run<12>("2 independent v_mul chains", 2); run<13>("4 independent v_mul chains", 4); run<19>("v_mul + v_pk_mul independent", 2);
   return 0;
