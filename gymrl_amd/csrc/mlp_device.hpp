@@ -122,9 +122,10 @@ __device__ __forceinline__ void run_tiles(const gymrl_mlp_stage& st, const float
 }
 
 __device__ __forceinline__ void run_stage(const gymrl_mlp_stage& st, const float* A, int a_stride, float* dst_lds,
-                                          float* head_lds, int head_col, int m0, int n_rows, int lane, int wave) {
+                                          float* head_lds, int head_col, int m0, int n_rows, int lane, int wave,
+                                          int nwaves = kWaves) {
   const int ntiles = (st.out_dim + 15) >> 4;
-  const int per_wave = (ntiles + kWaves - 1) / kWaves;
+  const int per_wave = (ntiles + nwaves - 1) / nwaves;
   for (int tb = 0; tb < per_wave; tb += kTPW) {              // one pass for widths <= 256
     const int t0 = wave * per_wave + tb;
     const int ntile = min(kTPW, min(per_wave - tb, ntiles - t0));
@@ -146,13 +147,15 @@ __device__ __forceinline__ bool stages_independent(const gymrl_mlp_stage& a, con
 
 // One whole network on the 16 rows whose input tile is already in `xin` (zero padded to 64 columns):
 // stages ping-pong through `lds`; dst == -1 stages go to HBM (head_lds == nullptr) or to the head tile.
+// Stages whose bit is set in `skip` are left out (their head columns stay reserved): forward_deferred runs them later.
 __device__ __forceinline__ void forward_tile(const gymrl_mlp_desc& d, float (*lds)[kRows * kStride], float* xin,
-                                             float* head_lds, int m0, int n_rows, int tid) {
+                                             float* head_lds, int m0, int n_rows, int tid, uint32_t skip = 0u) {
   const int lane = tid & 63, wave = tid >> 6;
   int head_col = 0;
   bool paired = false;                  // this stage runs in the previous stage's barrier interval
   for (int s = 0; s < d.n_stages; ++s) {
     const gymrl_mlp_stage st = d.stage[s];
+    if ((skip >> s) & 1u) { if (st.dst < 0) head_col += st.out_dim; continue; }
     const float* A = st.src < 0 ? xin : lds[st.src];
     const int a_stride = st.src < 0 ? kInStride : kStride;
     float* dst_lds = st.dst >= 0 ? lds[st.dst] : nullptr;
@@ -168,9 +171,56 @@ __device__ __forceinline__ void forward_tile(const gymrl_mlp_desc& d, float (*ld
         lds[st.dst][r * kStride + c] = 0.0f;
       }
     }
-    const bool pair_next = !paired && s + 1 < d.n_stages && stages_independent(st, d.stage[s + 1]);
+    int nx = s + 1;                      // the next stage that runs here
+    while (nx < d.n_stages && ((skip >> nx) & 1u)) ++nx;
+    const bool pair_next = !paired && nx < d.n_stages && stages_independent(st, d.stage[nx]);
     if (!pair_next) __syncthreads();
     paired = pair_next;
+  }
+}
+
+// Which stages only feed head columns >= first_col (for an actor-critic: the critic's layers and the value head)?  They can
+// run after the others — on another wave, beside whatever consumes the first head columns — if they do not read the network
+// input (rewritten meanwhile) and no stage that stays behind writes a buffer they read or write.  0 = nothing to defer.
+__device__ __forceinline__ uint32_t deferrable_stages(const gymrl_mlp_desc& d, int first_col) {
+  uint32_t m = 0u;
+  int col[GYMRL_MLP_MAX_STAGES], hc = 0;
+  for (int s = 0; s < d.n_stages; ++s) { col[s] = hc; if (d.stage[s].dst < 0) hc += d.stage[s].out_dim; }
+  for (int s = d.n_stages - 1; s >= 0; --s) {
+    const gymrl_mlp_stage& st = d.stage[s];
+    if (st.dst < 0) { if (col[s] >= first_col) m |= 1u << s; continue; }
+    bool any = false, all = true;
+    for (int r = s + 1; r < d.n_stages; ++r) {
+      if (d.stage[r].src == st.dst) { any = true; all = all && ((m >> r) & 1u); }
+      if (d.stage[r].dst == st.dst) break;                 // the buffer is rewritten: later readers see another value
+    }
+    if (any && all) m |= 1u << s;
+  }
+  bool ok = m != 0u && m != (1u << d.n_stages) - 1u;
+  for (int s = 0; s < d.n_stages && ok; ++s) {
+    if (!((m >> s) & 1u)) continue;
+    const gymrl_mlp_stage& st = d.stage[s];
+    if (st.src < 0 || ((st.dst >= 0) && (st.out_dim & 63))) ok = false;
+    for (int r = s + 1; r < d.n_stages && ok; ++r)
+      if (!((m >> r) & 1u) && d.stage[r].dst >= 0 && (d.stage[r].dst == st.src || d.stage[r].dst == st.dst)) ok = false;
+  }
+  return ok ? m : 0u;
+}
+
+// The stages forward_tile(..., skip) left out, by ONE wave, in order (no workgroup barrier: the wave's own LDS writes and
+// reads are in order).
+__device__ __forceinline__ void forward_deferred(const gymrl_mlp_desc& d, float (*lds)[kRows * kStride], float* head_lds,
+                                                 int m0, int n_rows, int lane, uint32_t skip) {
+  int head_col = 0;
+  for (int s = 0; s < d.n_stages; ++s) {
+    const gymrl_mlp_stage st = d.stage[s];
+    if ((skip >> s) & 1u) {
+      run_stage(st, lds[st.src], kStride, st.dst >= 0 ? lds[st.dst] : nullptr, head_lds, head_col, m0, n_rows, lane, 0, 1);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (st.dst < 0) head_col += st.out_dim;
   }
 }
 

@@ -76,14 +76,36 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_kernel(gymrl_rollout_l
     const int r = e / kObs, c = e - r * kObs;
     if (m0 + r < N) xin[r * M::kInStride + c] = a.obs[((size_t)a.t0 * N + m0 + r) * kObs + c];
   }
+  const uint32_t vdefer = M::deferrable_stages(d, kActions);
   for (int t = a.t0; t <= t_end; ++t) {
     const bool tail = t == t_end;                   // only the bootstrap value of the finished rollout is left
     if (tail && t_end != T) break;
     __syncthreads();                                // xin of step t is complete
     LUNAR_PROF_MARK(rt0);
-    M::forward_tile(d, lds, xin, head, m0, N, tid); // logits -> head[row][0..3], value -> head[row][4]
+    // logits -> head[row][0..3] by all four waves; the critic's layers and the value head (-> head[row][4]) are not on the
+    // way to the action: wave 2 runs them while wave 0 steps the envs (`vdefer` = their stage bits, 0 if the network has
+    // no such split) and does what the value is needed for — val[t], the GAE delta of step t-1, the bootstrap value
+    M::forward_tile(d, lds, xin, head, m0, N, tid, vdefer);
     LUNAR_PROF_MARK(rt1);
     if (wave == 0) LUNAR_PROF_ADD(slds, 8, rt0, rt1);   // policy forward
+    auto value_part = [&]() {
+      const float v = head[row * M::kHeadStride + kActions];
+      if (valid && role == 0) {
+        if (a.gae_running && t > 0) {               // V_t completes step t-1's delta
+          const int tp = t - 1;
+          const size_t o = (size_t)tp * N + i;
+          double2* agg = reinterpret_cast<double2*>(a.gae_workspace) + (size_t)(tp / kGaeChunk) * N;
+          gae_online_compose(a.rew[o], a.done[o], a.val[o], v, a.gamma, gl, (tp % kGaeChunk) == 0,
+                             (tp % kGaeChunk) == kGaeChunk - 1 || tp == T - 1, a.gae_running, agg, N, i);
+        }
+        if (tail) a.next_value[i] = v;
+        else a.val[(size_t)t * N + i] = v;
+      }
+    };
+    if (wave == 2 && vdefer) {
+      M::forward_deferred(d, lds, head, m0, N, lane, vdefer);
+      value_part();
+    }
     // wave 0 steps the envs; wave 1 (idle otherwise) keeps their next episodes prepared — ONE call site of the solver
     const bool refill_wave = wave == 1;
     if (wave == 0 || (refill_wave && !tail && a.refill)) {
@@ -92,23 +114,13 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_kernel(gymrl_rollout_l
         float z[kActions];
 #pragma unroll
         for (int k = 0; k < kActions; ++k) z[k] = head[row * M::kHeadStride + k];
-        const float v = head[row * M::kHeadStride + kActions];
-        if (valid && role == 0) {
-          if (a.gae_running && t > 0) {               // V_t completes step t-1's delta
-            const int tp = t - 1;
-            const size_t o = (size_t)tp * N + i;
-            double2* agg = reinterpret_cast<double2*>(a.gae_workspace) + (size_t)(tp / kGaeChunk) * N;
-            gae_online_compose(a.rew[o], a.done[o], a.val[o], v, a.gamma, gl, (tp % kGaeChunk) == 0,
-                               (tp % kGaeChunk) == kGaeChunk - 1 || tp == T - 1, a.gae_running, agg, N, i);
-          }
-          if (tail) a.next_value[i] = v;
-        }
+        if (!vdefer) value_part();
         if (!tail) {
           float lp, H;
           const size_t o = (size_t)t * N + (valid ? i : 0);
           act = categorical_pick<kActions>(z, a.noise_exp ? a.noise_exp + o * kActions : nullptr, a.seed,
                                            (uint64_t)(a.env_id0 + i), a.counter0 + (uint64_t)t, 0, lp, H);
-          if (valid && role == 0) { a.act[o] = act; a.logp[o] = lp; a.val[o] = v; }
+          if (valid && role == 0) { a.act[o] = act; a.logp[o] = lp; }
         }
       }
       if (!tail) {
