@@ -491,7 +491,8 @@ def test_mlp_forward_matches_torch_module(dev):
 
 
 # ---------------------------------------------------------- persistent rollout ---
-@pytest.mark.parametrize("N,T,chunk,hidden", [(256, 160, 256, 64), (64, 150, 23, 64), (40, 140, 16, 64), (4096, 64, 0, 256)])
+@pytest.mark.parametrize("N,T,chunk,hidden", [(256, 160, 256, 64), (64, 150, 23, 64), (40, 140, 16, 64), (4096, 64, 0, 256),
+                                              (48, 24, 1, 64), (48, 30, 2, 32)])   # 1-, 2-step launches: worlds through HBM every step; hidden 32: no deferred critic
 def test_persistent_rollout_bit_identical_to_stepwise(dev, N, T, chunk, hidden):
     """gymrl_rollout_lunar (one launch per chunk, workgroups free-running) writes the same slab, bootstrap
     value, GAE chunk maps, env state and episode statistics as the step-by-step sequence
@@ -519,7 +520,10 @@ def test_persistent_rollout_bit_identical_to_stepwise(dev, N, T, chunk, hidden):
         d = ba.dones.bool()
         assert int(d.sum()) > 0 or T < 100, "the rollout must contain episode resets"
         assert torch.equal(ba.ep_returns[d], bb.ep_returns[d])
-        assert torch.equal(a.env.state, b.env.state) or True     # spare-world words may differ (refill timing); checked via obs
+        # the live worlds ([144 words][N], first field of the state buffer): the persistent kernel keeps them in LDS between
+        # the steps of a launch and writes them back at its last step (spare-world words may differ: refill timing)
+        words = 144 * 4 * N
+        assert torch.equal(a.env.state[:words], b.env.state[:words]), rollout
         assert torch.equal(a.env.ep_stats, b.env.ep_stats)
         adv_a, ret_a = a.compute_gae()
         adv_b, ret_b = b.compute_gae()
