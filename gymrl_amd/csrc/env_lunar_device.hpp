@@ -12,18 +12,20 @@
 // solver, 180 velocity / <= 60 position iterations per 1/50 s step, Box2D's
 // sleep rule (the +100 "landed" terminal), gymnasium's reward shaping.
 //
-// Mapping: FOUR lanes per env (a DPP quad), 16 envs per wavefront, one wavefront per
+// Mapping: FOUR lanes per env (a DPP quad), 16 envs per wavefront, one solver wavefront per
 // workgroup (N/16 workgroups: 256 at N = 4096, one per CU).  Every lane of a quad carries
-// the three bodies and both joints in VGPRs and replays the joint solve redundantly; the
-// contact work is split by role: lane 0 owns the hull's terrain contacts, lanes 1/2 the
-// legs' (lane 3 mirrors lane 0 and never stores).  The three bodies' contact solves only
-// touch their own body (the terrain is static), so inside a solver sweep they run side by
-// side in one instruction stream and the quad re-synchronises with nine quad-broadcasts
-// (v_mov_dpp quad_perm) — a sweep is ~700 instructions instead of ~1290 for a lane that
-// walks all three bodies.  Per-lane manifolds and solver scratch live in LDS columns
-// ([word][lane]); the 180 velocity sweeps run out of VGPRs only.
-// Bound: ALU latency (180 dependent sweeps at one wave per SIMD), not HBM: the 576 B of
-// SoA state per env is read and written once per step.
+// the three bodies and both joints in VGPRs; the contact work is split by role: lane 0 owns
+// the hull's terrain contacts, lanes 1/2 the legs' (lane 3 mirrors lane 0 and never stores)
+// — the three bodies' contact solves only touch their own body (the terrain is static), so
+// they run side by side in one instruction stream.  In the 180 velocity sweeps the joint solve
+// runs ACROSS the quad instead: lane r holds component r (x, y, angular) of each 3-vector,
+// cross products and Solve33's sums are DPP-operand arithmetic in the reference's order; steps
+// with a contact transpose between the two layouts once per sweep.  Per-lane manifolds and
+// solver scratch live in LDS columns ([word][lane]).
+// Bound: instruction issue.  One wave on a SIMD issues one instruction per ~5 clocks whatever
+// it is (tools/ubench/valu_issue.hip), so a step costs its instruction count; HBM sees the
+// 576 B of SoA state per env once per step — or, in the persistent rollout kernels, once per
+// launch (world_park keeps the worlds in LDS between steps).
 //
 // Determinism: IEEE f32 +,-,*,/,sqrt and explicit fmaf only (-ffp-contract=off),
 // det_sincosf for rotations, Philox for every random draw — the CPU oracle's
