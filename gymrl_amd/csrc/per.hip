@@ -98,7 +98,7 @@ __global__ __launch_bounds__(1024) void per_ancestor_kernel(double* __restrict__
                                                             const int64_t* __restrict__ leaf_g,
                                                             const double* __restrict__ change_g, int B,
                                                             int sorted, int use_lds) {
-  extern __shared__ int64_t s_dyn[];
+  extern __shared__ __attribute__((aligned(16))) int64_t s_dyn[];
   const int d = blockIdx.x;
   const int64_t* leaf = leaf_g;
   const double* change = change_g;
@@ -138,19 +138,24 @@ __global__ __launch_bounds__(1024) void per_ancestor_kernel(double* __restrict__
       const int64_t e64 = (int64_t)i + (last_leaf - lf) + 1;
       const int e = e64 < (int64_t)B ? (int)e64 : B;
       int j = i;
-      // The ordered chain of adds is the kernel (the root's run is the whole batch): the next group's loads are in
-      // flight while the current group's eight dependent adds retire.
-      if (j + 8 <= e) {
-        double c0 = change[j], c1 = change[j + 1], c2 = change[j + 2], c3 = change[j + 3];
-        double c4 = change[j + 4], c5 = change[j + 5], c6 = change[j + 6], c7 = change[j + 7];
-        for (; j + 16 <= e; j += 8) {
-          const double n0 = change[j + 8], n1 = change[j + 9], n2 = change[j + 10], n3 = change[j + 11];
-          const double n4 = change[j + 12], n5 = change[j + 13], n6 = change[j + 14], n7 = change[j + 15];
-          acc += c0; acc += c1; acc += c2; acc += c3; acc += c4; acc += c5; acc += c6; acc += c7;
-          c0 = n0; c1 = n1; c2 = n2; c3 = n3; c4 = n4; c5 = n5; c6 = n6; c7 = n7;
+      // The ordered chain of adds is the kernel (the root's run is the whole batch), and ONE lane walks it: a lone wave
+      // issues an instruction per ~5 clocks, so the chain costs its instruction count per add.  Two register groups
+      // alternate (no copies), operands come as 16-byte LDS reads once the index is even: 16 adds + 8 reads + the loop.
+      if (j < e && (reinterpret_cast<uintptr_t>(change + j) & 15u)) { acc += change[j]; ++j; }
+      if (j + 16 <= e) {
+        const double2* c2 = reinterpret_cast<const double2*>(change + j);      // 16-byte aligned after the peel above
+        double2 a0 = c2[0], a1 = c2[1], a2 = c2[2], a3 = c2[3];
+        int q = 4;                                                             // next unread pair
+        const int pairs = (e - j) >> 1;
+        while (q + 8 <= pairs) {
+          const double2 b0 = c2[q], b1 = c2[q + 1], b2 = c2[q + 2], b3 = c2[q + 3];
+          acc += a0.x; acc += a0.y; acc += a1.x; acc += a1.y; acc += a2.x; acc += a2.y; acc += a3.x; acc += a3.y;
+          a0 = c2[q + 4]; a1 = c2[q + 5]; a2 = c2[q + 6]; a3 = c2[q + 7];
+          acc += b0.x; acc += b0.y; acc += b1.x; acc += b1.y; acc += b2.x; acc += b2.y; acc += b3.x; acc += b3.y;
+          q += 8;
         }
-        acc += c0; acc += c1; acc += c2; acc += c3; acc += c4; acc += c5; acc += c6; acc += c7;
-        j += 8;
+        acc += a0.x; acc += a0.y; acc += a1.x; acc += a1.y; acc += a2.x; acc += a2.y; acc += a3.x; acc += a3.y;
+        j += 2 * q;
       }
       for (; j < e; ++j) acc += change[j];
     } else {
