@@ -73,8 +73,16 @@ __global__ __launch_bounds__(1024) void per_leaf_kernel(double* __restrict__ tre
     const int64_t leaf = lf[i];
     double prev = tree[leaf];
     if (idx) {   // duplicates possible: the latest earlier element on the same leaf
-      for (int j = i - 1; j >= 0; --j)
-        if (lf[j] == leaf) { prev = prio_of(prio, ps_dev, ps, j); break; }
+      // (eight LDS reads in flight per round: one at a time, each link of the search is a dependent ~100-clock round trip)
+      int found = -1;
+      for (int j0 = i - 1; j0 >= 0 && found < 0; j0 -= 8) {
+        int64_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = j0 - u >= 0 ? lf[j0 - u] : (int64_t)-1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (found < 0 && v[u] == leaf) found = j0 - u;
+      }
+      if (found >= 0) prev = prio_of(prio, ps_dev, ps, found);
     }
     change_out[i] = prio_of(prio, ps_dev, ps, i) - prev;
   }
@@ -84,8 +92,13 @@ __global__ __launch_bounds__(1024) void per_leaf_kernel(double* __restrict__ tre
     const int64_t leaf = lf[i];
     bool last = true;
     if (idx) {
-      for (int j = i + 1; j < B; ++j)
-        if (lf[j] == leaf) { last = false; break; }
+      for (int j0 = i + 1; j0 < B && last; j0 += 8) {
+        int64_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = j0 + u < B ? lf[j0 + u] : (int64_t)-1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (v[u] == leaf) last = false;
+      }
     }
     if (last) tree[leaf] = prio_of(prio, ps_dev, ps, i);
   }
@@ -124,10 +137,15 @@ __global__ __launch_bounds__(1024) void per_ancestor_kernel(double* __restrict__
         leader = !(Lp > d && (((lp + 1) >> (Lp - d)) - 1) == node);
       }
     } else {
-      for (int j = 0; j < i; ++j) {
-        const int64_t lj = leaf[j];
-        const int Lj = depth_of(lj);
-        if (Lj > d && (((lj + 1) >> (Lj - d)) - 1) == node) { leader = false; break; }
+      for (int j0 = 0; j0 < i && leader; j0 += 8) {        // eight reads in flight per round (see per_leaf_kernel)
+        int64_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = j0 + u < i ? leaf[j0 + u] : (int64_t)0;      // 0 = the root: never has an ancestor
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int Lj = depth_of(v[u]);
+          if (Lj > d && (((v[u] + 1) >> (Lj - d)) - 1) == node) leader = false;
+        }
       }
     }
     if (!leader) continue;
@@ -159,10 +177,15 @@ __global__ __launch_bounds__(1024) void per_ancestor_kernel(double* __restrict__
       }
       for (; j < e; ++j) acc += change[j];
     } else {
-      for (int j = i; j < B; ++j) {
-        const int64_t lj = leaf[j];
-        const int Lj = depth_of(lj);
-        if (Lj > d && (((lj + 1) >> (Lj - d)) - 1) == node) acc += change[j];
+      for (int j0 = i; j0 < B; j0 += 8) {                  // the node's additions in batch order, operands fetched eight at a time
+        int64_t v[8]; double c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const bool in = j0 + u < B; v[u] = in ? leaf[j0 + u] : (int64_t)0; c[u] = in ? change[j0 + u] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int Lj = depth_of(v[u]);
+          if (Lj > d && (((v[u] + 1) >> (Lj - d)) - 1) == node) acc += c[u];
+        }
       }
     }
     tree[node] = acc;
