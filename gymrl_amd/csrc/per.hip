@@ -104,6 +104,32 @@ __global__ __launch_bounds__(1024) void per_leaf_kernel(double* __restrict__ tre
   }
 }
 
+// Ordered sum acc + ch[j] + ch[j + 1] + ... + ch[e - 1] (one dependent chain: the reference's order).  ONE lane walks it, and
+// a lone wave issues an instruction per ~5 clocks, so the chain costs its instruction count per add: two register groups
+// alternate (no copies) and the operands come as 16-byte reads once the address is 16-byte aligned — 16 adds + 8 reads + the
+// loop.  Called once with the LDS copy and once with the global one so that each call site knows its address space (a
+// pointer that may be either makes every read a FLAT load behind a full waitcnt).
+__device__ __forceinline__ double ordered_run_sum(double acc, const double* __restrict__ ch, int j, int e) {
+  if (j < e && (reinterpret_cast<uintptr_t>(ch + j) & 15u)) { acc += ch[j]; ++j; }
+  if (j + 16 <= e) {
+    const double2* c2 = reinterpret_cast<const double2*>(ch + j);
+    double2 a0 = c2[0], a1 = c2[1], a2 = c2[2], a3 = c2[3];
+    int q = 4;                                                             // next unread pair
+    const int pairs = (e - j) >> 1;
+    while (q + 8 <= pairs) {
+      const double2 b0 = c2[q], b1 = c2[q + 1], b2 = c2[q + 2], b3 = c2[q + 3];
+      acc += a0.x; acc += a0.y; acc += a1.x; acc += a1.y; acc += a2.x; acc += a2.y; acc += a3.x; acc += a3.y;
+      a0 = c2[q + 4]; a1 = c2[q + 5]; a2 = c2[q + 6]; a3 = c2[q + 7];
+      acc += b0.x; acc += b0.y; acc += b1.x; acc += b1.y; acc += b2.x; acc += b2.y; acc += b3.x; acc += b3.y;
+      q += 8;
+    }
+    acc += a0.x; acc += a0.y; acc += a1.x; acc += a1.y; acc += a2.x; acc += a2.y; acc += a3.x; acc += a3.y;
+    j += 2 * q;
+  }
+  for (; j < e; ++j) acc += ch[j];
+  return acc;
+}
+
 // pass 2: blockIdx.x = node depth d (0 = root).  A node's additions happen in batch order.
 // `sorted`: consecutive leaves of a power-of-two tree without wrap-around: a node's elements are one
 // contiguous run whose end follows from the subtree span, so the run is summed without searching.
@@ -155,27 +181,7 @@ __global__ __launch_bounds__(1024) void per_ancestor_kernel(double* __restrict__
       const int64_t last_leaf = ((node + 2) << (L - d)) - 2;
       const int64_t e64 = (int64_t)i + (last_leaf - lf) + 1;
       const int e = e64 < (int64_t)B ? (int)e64 : B;
-      int j = i;
-      // The ordered chain of adds is the kernel (the root's run is the whole batch), and ONE lane walks it: a lone wave
-      // issues an instruction per ~5 clocks, so the chain costs its instruction count per add.  Two register groups
-      // alternate (no copies), operands come as 16-byte LDS reads once the index is even: 16 adds + 8 reads + the loop.
-      if (j < e && (reinterpret_cast<uintptr_t>(change + j) & 15u)) { acc += change[j]; ++j; }
-      if (j + 16 <= e) {
-        const double2* c2 = reinterpret_cast<const double2*>(change + j);      // 16-byte aligned after the peel above
-        double2 a0 = c2[0], a1 = c2[1], a2 = c2[2], a3 = c2[3];
-        int q = 4;                                                             // next unread pair
-        const int pairs = (e - j) >> 1;
-        while (q + 8 <= pairs) {
-          const double2 b0 = c2[q], b1 = c2[q + 1], b2 = c2[q + 2], b3 = c2[q + 3];
-          acc += a0.x; acc += a0.y; acc += a1.x; acc += a1.y; acc += a2.x; acc += a2.y; acc += a3.x; acc += a3.y;
-          a0 = c2[q + 4]; a1 = c2[q + 5]; a2 = c2[q + 6]; a3 = c2[q + 7];
-          acc += b0.x; acc += b0.y; acc += b1.x; acc += b1.y; acc += b2.x; acc += b2.y; acc += b3.x; acc += b3.y;
-          q += 8;
-        }
-        acc += a0.x; acc += a0.y; acc += a1.x; acc += a1.y; acc += a2.x; acc += a2.y; acc += a3.x; acc += a3.y;
-        j += 2 * q;
-      }
-      for (; j < e; ++j) acc += change[j];
+      acc = use_lds ? ordered_run_sum(acc, reinterpret_cast<const double*>(s_dyn + B), i, e) : ordered_run_sum(acc, change_g, i, e);
     } else {
       for (int j0 = i; j0 < B; j0 += 8) {                  // the node's additions in batch order, operands fetched eight at a time
         int64_t v[8]; double c[8];

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""The sum-tree update alone, per kernel: a vector step's 8192 consecutive new rows (ordered runs) and the priorities of a
+sampled batch of 256 (unordered, duplicates possible) on a 2^20-leaf tree.  Usage: python tools/micro_per.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gymrl_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+cap = 1 << 20
+tree = torch.zeros(2 * cap - 1, dtype=torch.float64, device=dev)
+g = torch.Generator(device=dev).manual_seed(0)
+
+
+def timeit(fn, iters=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+
+
+for B, kind in ((8192, "rows"), (256, "idx"), (256, "idx_dup"), (512, "idx"), (1024, "idx")):
+    ws = ops.per_workspace(B, dev)
+    prio = torch.rand(B, dtype=torch.float64, device=dev, generator=g) + 0.1
+    if kind == "rows":
+        fn = lambda: ops.per_update(tree, cap, B, ws, idx_start=12345 * 8, prio=prio)
+    else:
+        idx = torch.randint(0, 4096 if kind == "idx_dup" else cap, (B,), device=dev, generator=g, dtype=torch.int32)
+        if kind == "idx_dup":
+            idx[::3] = idx[0]
+        fn = lambda: ops.per_update(tree, cap, B, ws, idx=idx, prio=prio)
+    print(f"B = {B:5d} {kind:8s}: {timeit(fn):7.1f} us per update (back-to-back launches)")

@@ -11,6 +11,7 @@ __global__ void k(float* out, long long* cyc, int iters) {
   float a = 1.0f + lane * 1e-3f, b = 1.5f, c = 0.7f, d = 1.1f, e = 1.2f, f = 1.3f, g = 1.4f, h = 1.6f;
   const float m = 0.999f + out[0];
   v2f pa = {a, b}, pb = {c, d}, pc = {e, f}, pd = {g, h}, pm = {m, m};
+  double da = a, db = b, dc = c, dd = d; const double dm = m;
   const unsigned long long msk = __builtin_amdgcn_ballot_w64((lane & 1) != 0);
   long long t0 = __builtin_readcyclecounter();
   for (int i = 0; i < iters; ++i) {
@@ -26,10 +27,12 @@ __global__ void k(float* out, long long* cyc, int iters) {
     if (KIND == 9) { R4(asm volatile("v_mul_f32 %0, %0, %2\n v_mul_f32 %1, %1, %2\n v_mul_f32_dpp %0, %0, %2 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mul_f32_dpp %1, %1, %2 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mul_f32_dpp %0, %0, %2 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mul_f32_dpp %1, %1, %2 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mul_f32 %0, %0, %2\n v_mul_f32 %1, %1, %2" : "+v"(a), "+v"(b) : "v"(m));) }
     if (KIND == 10) { R4(asm volatile("v_mul_f32 %0, %0, %3\n v_mul_f32 %1, %1, %3\n v_mul_f32 %2, %2, %3\n v_mul_f32 %0, %0, %3\n v_mul_f32 %1, %1, %3\n v_mul_f32 %2, %2, %3\n v_mul_f32 %0, %0, %3\n v_mul_f32 %1, %1, %3" : "+v"(a), "+v"(b), "+v"(c) : "v"(m));) }
     if (KIND == 11) { R4(asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1" : "+s"(iters) :: "scc"); iters -= 8;) }
+    if (KIND == 13) { R4(asm volatile("v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1" : "+v"(da) : "v"(dm));) }
+    if (KIND == 14) { R4(asm volatile("v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4\n v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4" : "+v"(da), "+v"(db), "+v"(dc), "+v"(dd) : "v"(dm));) }
     if (KIND == 12) { R4(asm volatile("v_mul_f32 %0, %0, %1\n s_nop 0\n v_mul_f32 %0, %0, %1\n s_nop 0\n v_mul_f32 %0, %0, %1\n s_nop 0\n v_mul_f32 %0, %0, %1\n s_nop 0" : "+v"(a) : "v"(m));) }
   }
   long long t1 = __builtin_readcyclecounter();
-  out[1 + lane] = a + b + c + d + e + f + g + h + pa.x + pa.y + pb.x + pb.y + pc.x + pc.y + pd.x + pd.y;
+  out[1 + lane] = (float)(da + db + dc + dd) + a + b + c + d + e + f + g + h + pa.x + pa.y + pb.x + pb.y + pc.x + pc.y + pd.x + pd.y;
   if (lane == 0) cyc[0] = t1 - t0;
 }
 template <int KIND>
@@ -59,5 +62,6 @@ int main() {
   run<8>("dependent v_mul_f32_dpp with s_nop 1 (8 slots: 5 VALU + 3 nops)");
   run<9>("two interleaved chains incl. v_mul_f32_dpp, no nops");
   run<11>("s_add_u32 dependent");
+  run<13>("v_add_f64, each depends on the previous"); run<14>("v_add_f64, four interleaved chains");
   return 0;
 }
