@@ -67,7 +67,8 @@ __global__ __launch_bounds__(kEnvBlock) void cartpole_step_kernel(
   if (valid) {
     double x = st.x[i], xd = st.xd[i], th = st.th[i], thd = st.thd[i];
     const double force = action[i] == 1 ? 10.0 : -10.0;
-    const double c = cos(th), s = sin(th);
+    double s, c;
+    det_sincos(th, &s, &c);                          // not ocml: reproducible on the host bit for bit
     const double temp = (force + 0.05 * (thd * thd) * s) / 1.1;
     const double thacc = (9.8 * s - c * temp) / (0.5 * (4.0 / 3.0 - 0.1 * (c * c) / 1.1));
     const double xacc = temp - 0.05 * thacc * c / 1.1;
@@ -124,7 +125,9 @@ __device__ __forceinline__ void pendulum_draw(uint64_t seed, uint64_t env, uint3
 }
 
 __device__ __forceinline__ void pendulum_obs(double th, double thd, float (&o)[3]) {
-  o[0] = (float)cos(th); o[1] = (float)sin(th); o[2] = (float)thd;
+  double s, c;
+  det_sincos(th, &s, &c);
+  o[0] = (float)c; o[1] = (float)s; o[2] = (float)thd;
 }
 
 __global__ __launch_bounds__(kEnvBlock) void pendulum_reset_kernel(void* buf, int n, uint64_t seed,
@@ -168,7 +171,9 @@ __global__ __launch_bounds__(kEnvBlock) void pendulum_step_kernel(
     a = a - floor(a / (2.0 * pi)) * (2.0 * pi);
     const double an = a - pi;
     const double cost = an * an + 0.1 * (thd * thd) + 0.001 * (u * u);
-    double nthd = thd + (15.0 * sin(th) + 3.0 * u) * 0.05;   // 3g/(2l) = 15, 3/(ml^2) = 3
+    double sin_th, cos_th;
+    det_sincos(th, &sin_th, &cos_th);
+    double nthd = thd + (15.0 * sin_th + 3.0 * u) * 0.05;    // 3g/(2l) = 15, 3/(ml^2) = 3
     nthd = nthd < -8.0 ? -8.0 : (nthd > 8.0 ? 8.0 : nthd);
     const double nth = th + nthd * 0.05;
     len = st.ep.ep_len[i] + 1;

@@ -148,6 +148,40 @@ __device__ __forceinline__ void det_sincosf(float x, float* s, float* c) {
   *s = ss; *c = cc;
 }
 
+// Reproducible float64 sin/cos for the classic-control steppers (gymnasium keeps CartPole / Pendulum state in float64):
+// quadrant by rint(x * 2/pi), two-constant Cody-Waite reduction with fma (pi/2 = 33 leading bits + tail, fdlibm's pio2_1 /
+// pio2_1t: q * pio2_1 is exact for |q| < 2^20, i.e. |x| < 1.6e6 — Pendulum's angle stays below pi + 200 * 0.4), fdlibm's
+// degree-13 / degree-12 minimax kernels on |r| <= pi/4 as fma Horner chains.  <= 1.6 ulp against sinl / cosl over
+// [-100, 100] (tools/check_det_sincos.c).  Every operation is spelled out (fma only where written), so a host
+// restatement of the same lines — the test suite's CPU checker has one — agrees bit for bit, which ocml's and libm's
+// sin / cos do not.
+__device__ __forceinline__ void det_sincos(double x, double* s, double* c) {
+  const double q = __builtin_rint(x * 0.63661977236758134308);
+  const long long qi = (long long)q;
+  double r = __builtin_fma(q, -1.57079632673412561417e+00, x);
+  r = __builtin_fma(q, -6.07710050650619224932e-11, r);
+  const double z = r * r;
+  double ps = 1.58969099521155010221e-10;
+  ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+  ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+  ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+  ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+  ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+  const double sn = __builtin_fma(ps * z, r, r);
+  double pc = -1.13596475577881948265e-11;
+  pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+  pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+  pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+  pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+  pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+  const double cs = __builtin_fma(pc * z, z, __builtin_fma(-0.5, z, 1.0));
+  double ss = (qi & 1) ? cs : sn;
+  double cc = (qi & 1) ? sn : cs;
+  if (qi & 2) ss = -ss;
+  if ((qi + 1) & 2) cc = -cc;
+  *s = ss; *c = cc;
+}
+
 // tanh via det_expf; odd polynomial below 0.625 (Cephes tanhf).
 __device__ __forceinline__ float det_tanhf(float x) {
   float a = __builtin_fabsf(x);

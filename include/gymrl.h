@@ -323,7 +323,12 @@ int gymrl_gather_minibatch(const float* packed, const int32_t* idx, int B, int o
  * ppo_lunarlander.py:169,302-307; dqn_cartpole.py:163-166 (clamp_abs = 1);
  * rainbow_dqn_cartpole.py:343-345; sac_pendulum.py:244-255.
  *   gymrl_sqnorm:    sqnorm_out f64[1] (device) = sum (g*grad_scale)^2, fixed-order
- *                    reduction; workspace >= gymrl_reduce_workspace_bytes()
+ *                    reduction; workspace >= gymrl_reduce_workspace_bytes().  The order is part of the
+ *                    contract (oracle/gymrl_oracle.c orc_sqnorm restates it; the optimiser step is pinned bit for
+ *                    bit): nb = clamp(ceil(n/4096), 1, 1024) workgroups of 256; thread t of workgroup b adds the
+ *                    float4 groups b*256+t, +nb*256, ... as ((a^2+b^2)+c^2)+d^2 in f64; the n%4 tail goes to
+ *                    threads 0..2 of workgroup 0; waves fold by halves (32, 16, .. 1), the 4 wave sums add in
+ *                    order; the final pass gives thread t partials t, t+256, ... and folds 256 sums by halves.
  *   gymrl_adam_step: scale = max_grad_norm>0 ? min(1, max_norm/(sqrt(sqnorm)+1e-6)) : 1
  *                    g' = clamp_abs>0 ? clamp(g*grad_scale, +-clamp_abs) : g*grad_scale*scale
  *                    m,v,p updated as torch.optim.Adam (no amsgrad, no decay);

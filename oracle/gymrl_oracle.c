@@ -84,6 +84,38 @@ void orc_sincosf(float x, float* s, float* c) {
   *s = ss; *c = cc;
 }
 
+/* float64 sin/cos of the classic-control envs: the operation-by-operation twin of det_sincos in
+ * gymrl_amd/csrc/gymrl_device.hpp (fdlibm pio2_1 / pio2_1t reduction and kernel coefficients, fma Horner chains).
+ * fma() is correctly rounded in glibc whether or not the host has the instruction, so the result does not depend on
+ * the box.  <= 1.6 ulp from sinl / cosl on [-100, 100]: the published CartPole / Pendulum equations evaluated with
+ * libm (tests/golden/classic_micro.npz) are still met to 1e-6 and better. */
+void orc_sincos(double x, double* s, double* c) {
+  double q = rint(x * 0.63661977236758134308);
+  long long qi = (long long)q;
+  double r = fma(q, -1.57079632673412561417e+00, x);
+  r = fma(q, -6.07710050650619224932e-11, r);
+  double z = r * r;
+  double ps = 1.58969099521155010221e-10;
+  ps = fma(ps, z, -2.50507602534068634195e-08);
+  ps = fma(ps, z, 2.75573137070700676789e-06);
+  ps = fma(ps, z, -1.98412698298579493134e-04);
+  ps = fma(ps, z, 8.33333333332248946124e-03);
+  ps = fma(ps, z, -1.66666666666666324348e-01);
+  double sn = fma(ps * z, r, r);
+  double pc = -1.13596475577881948265e-11;
+  pc = fma(pc, z, 2.08757232129817482790e-09);
+  pc = fma(pc, z, -2.75573143513906633035e-07);
+  pc = fma(pc, z, 2.48015872894767294178e-05);
+  pc = fma(pc, z, -1.38888888888741095749e-03);
+  pc = fma(pc, z, 4.16666666666666019037e-02);
+  double cs = fma(pc * z, z, fma(-0.5, z, 1.0));
+  double ss = (qi & 1) ? cs : sn;
+  double cc = (qi & 1) ? sn : cs;
+  if (qi & 2) ss = -ss;
+  if ((qi + 1) & 2) cc = -cc;
+  *s = ss; *c = cc;
+}
+
 float orc_tanhf(float x) {
   float a = fabsf(x);
   if (a >= 0.625f) {
@@ -607,10 +639,41 @@ void orc_permutation(uint64_t seed, uint64_t counter, int64_t M, int32_t* out) {
 
 /* =========================================================== optimiser ==== */
 /* O1 — clip_grad_norm_ + torch.optim.Adam step, ppo_lunarlander.py:169,302-307. */
+/* The squared gradient norm in gymrl_sqnorm's documented order (include/gymrl.h; optim.hip sqnorm_partial_kernel /
+ * sqnorm_final_kernel), so that the clip coefficient — and with it every parameter after the step — is pinned bit for
+ * bit, not to 1e-6: nb = clamp(ceil(n / 4096), 1, 1024) workgroups of 256 threads; thread t of workgroup b adds the
+ * float4 groups b*256 + t, + nb*256, ... as ((a^2 + b^2) + c^2) + d^2 in float64 (the products of two float32 are
+ * exact); the n % 4 tail elements go to threads 0..2 of workgroup 0; each 64-lane wave folds by halves
+ * (v[l] += v[l + off], off = 32, 16, .. 1), the four wave sums are added in order; the final pass gives thread t the
+ * partials t, t + 256, ... in order and folds the 256 sums by halves. */
 void orc_sqnorm(const float* g, int64_t n, float grad_scale, double* out) {
-  double s = 0.0;
-  for (int64_t i = 0; i < n; ++i) { float a = g[i] * grad_scale; s += (double)a * (double)a; }
-  out[0] = s;
+  int64_t nb = (n + 4095) / 4096;
+  if (nb < 1) nb = 1;
+  if (nb > 1024) nb = 1024;
+  const int64_t n4 = n >> 2, stride = nb * 256;
+  double fin[256];
+  for (int t = 0; t < 256; ++t) fin[t] = 0.0;
+  for (int64_t b = 0; b < nb; ++b) {
+    double lane[256];
+    for (int t = 0; t < 256; ++t) {
+      double s = 0.0;
+      for (int64_t i = b * 256 + t; i < n4; i += stride) {
+        float a = g[4 * i] * grad_scale, bb = g[4 * i + 1] * grad_scale, c = g[4 * i + 2] * grad_scale, d = g[4 * i + 3] * grad_scale;
+        s += (double)a * (double)a + (double)bb * (double)bb + (double)c * (double)c + (double)d * (double)d;
+      }
+      if (b == 0 && t < (int)(n & 3)) { float a = g[(n4 << 2) + t] * grad_scale; s += (double)a * (double)a; }
+      lane[t] = s;
+    }
+    double part = 0.0;
+    for (int w = 0; w < 4; ++w) {
+      double* v = lane + 64 * w;
+      for (int off = 32; off > 0; off >>= 1) for (int l = 0; l < off; ++l) v[l] += v[l + off];
+      part += v[0];
+    }
+    fin[b & 255] += part;                        /* thread (b % 256) of the final pass meets its partials in order of b */
+  }
+  for (int s2 = 128; s2 > 0; s2 >>= 1) for (int t = 0; t < s2; ++t) fin[t] += fin[t + s2];
+  out[0] = fin[0];
 }
 void orc_adam_step(float* p, float* g, float* m, float* v, int64_t n, double lr, double beta1,
                    double beta2, double eps, int64_t step, float grad_scale, float max_grad_norm,
@@ -705,7 +768,7 @@ static void pendulum_draw(uint64_t seed, uint64_t env, uint32_t episode, double*
 }
 static void classic_obs(int kind, const double* s, float* o) {
   if (kind == ORC_CARTPOLE) { for (int k = 0; k < 4; ++k) o[k] = (float)s[k]; }
-  else { o[0] = (float)cos(s[0]); o[1] = (float)sin(s[0]); o[2] = (float)s[1]; }
+  else { double sn, cs; orc_sincos(s[0], &sn, &cs); o[0] = (float)cs; o[1] = (float)sn; o[2] = (float)s[1]; }
 }
 
 void orc_env_reset(orc_env* e, float* obs_out) {
@@ -755,7 +818,8 @@ void orc_env_step(orc_env* e, const void* action, float* obs_out, float* term_ob
       if (e->kind == ORC_CARTPOLE) {
         double x = c->s[0], xd = c->s[1], th = c->s[2], thd = c->s[3];
         double force = ((const int32_t*)action)[i] == 1 ? 10.0 : -10.0;
-        double co = cos(th), si = sin(th);
+        double co, si;
+        orc_sincos(th, &si, &co);
         double temp = (force + 0.05 * (thd * thd) * si) / 1.1;
         double thacc = (9.8 * si - co * temp) / (0.5 * (4.0 / 3.0 - 0.1 * (co * co) / 1.1));
         double xacc = temp - 0.05 * thacc * co / 1.1;
@@ -773,7 +837,10 @@ void orc_env_step(orc_env* e, const void* action, float* obs_out, float* term_ob
         double a = th + pi; a = a - floor(a / (2.0 * pi)) * (2.0 * pi);
         double an = a - pi;
         double cost = an * an + 0.1 * (thd * thd) + 0.001 * (u * u);
-        double nthd = thd + (15.0 * sin(th) + 3.0 * u) * 0.05;
+        double sin_th, cos_th;
+        orc_sincos(th, &sin_th, &cos_th);
+        (void)cos_th;
+        double nthd = thd + (15.0 * sin_th + 3.0 * u) * 0.05;
         nthd = nthd < -8.0 ? -8.0 : (nthd > 8.0 ? 8.0 : nthd);
         c->s[0] = th + nthd * 0.05; c->s[1] = nthd;
         reward = -cost;

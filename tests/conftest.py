@@ -40,6 +40,19 @@ def rel_close(a, b, tol=1e-5):
     return float(err.max()) if err.size else 0.0
 
 
+def bounded(name, err, tol):
+    """assert err <= tol for one of the multi-step trace bounds that are looser than the contract's 1e-5 (each call site
+    carries the derivation of its number).  With GYMRL_TOL_LEDGER=<file> every (name, observed, bound) is appended to that
+    file, so the observed drift of a GPU run can be committed next to the bound (profiles/r04_trace_tolerances.json)."""
+    err = float(err)
+    path = os.environ.get("GYMRL_TOL_LEDGER")
+    if path:
+        import json
+        with open(path, "a") as f:
+            f.write(json.dumps({"name": name, "observed": err, "bound": tol}) + "\n")
+    assert err <= tol, (name, err, tol)
+
+
 def cov_clip_mul(g, k):
     """corr_mul of golden case k of ppo_full_loss.npz: None unless the case ran the covariance clip, else the rows
     gymrl_amd's cov_clip_mask picks when fed the reference's own randperm."""

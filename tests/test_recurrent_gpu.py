@@ -3,10 +3,12 @@
 import numpy as np
 import pytest
 
-from conftest import load_golden, rel_close
+from conftest import bounded, load_golden, rel_close
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
+
+TOL_PPO_LSTM_SD = 2e-4
 
 
 @pytest.fixture(scope="module")
@@ -148,7 +150,9 @@ def test_ppo_lstm_train_trace_matches_reference():
         assert s["step_count"] == int(g[f"r{r}_step_count"])
         assert np.array_equal(np.array(s["episode_rewards"]), g[f"r{r}_episode_rewards"]), r
         worst = max(float(np.max(np.abs(v - g[f"r{r}_sd_{k}"]) / np.maximum(1.0, np.abs(g[f"r{r}_sd_{k}"])))) for k, v in s["sd"].items())
-        assert worst <= 2e-4, (r, worst)
+        # the recurrent network's Adam steps at lr 3e-4: S * lr * rho as derived in tests/test_trainers_gpu.py (the GRU's
+        # gate products add a second cancellation stage); observed drift in profiles/r04_trace_tolerances.json
+        bounded(f"ppo_lstm_trace r{r} state_dict", worst, TOL_PPO_LSTM_SD)
 
 
 def test_ppo_lstm_smoke_and_checkpoint(tmp_path):

@@ -4,10 +4,31 @@ DQNTrainer.update and SACTrainer.update), plus short end-to-end learning checks.
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import bounded, load_golden
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
+
+# ---- bounds of the multi-step traces that are looser than the contract's 1e-5, and why -------------------------------
+# Single ops and single update() calls are pinned at 1e-5 or tighter (bit-exact vs the oracle) elsewhere in this suite.
+# The traces below replay S CONSECUTIVE optimiser steps against weights that torch-CPU produced: its GEMMs sum each dot
+# product in another order than the MFMA kernels (documented K-order, include/gymrl.h), so a gradient element g differs by
+# about sqrt(K) * 2^-24 * sum|terms|.  Adam divides by sqrt(v): the parameter step is lr * m_hat / (sqrt(v_hat) + eps),
+# which has magnitude ~lr whatever |g| is, so a perturbation dg moves a parameter by ~lr * dg / |g| per step — the
+# RELATIVE error of that gradient element, which is ~1e-6 for a typical element and up to ~1e-2 for the few elements
+# whose terms cancel (|g| two to four orders below sum|terms|).  Differences then feed back through the next forward
+# (and, off-policy, through the bootstrap target), so the drift grows about linearly in S:
+#     |dp| <~ S * lr * rho,     rho = worst relative error of a gradient element (observed 1e-4 .. 1e-2).
+# The bounds are ~4x the drift observed on an MI355X (profiles/r04_trace_tolerances.json: observed value next to every
+# bound, written by conftest.bounded under GYMRL_TOL_LEDGER); the integer side of every trace (actions, dones, flags,
+# step counts, shuffles) is exact, and returns / advantages stay at 1e-5.
+TOL_PPO_METRICS = 2e-5      # S = 12 steps, lr 3e-4: S*lr = 3.6e-3; metrics are means over the minibatch of 1e-5-close terms
+TOL_PPO_SD = 5e-5           # S = 12, lr 3e-4  -> S*lr*rho = 3.6e-3 * 1.4e-2
+TOL_DQN_TRACE = 2e-4        # S = 163, lr 1e-3 -> S*lr = 0.163; rho ~ 1e-3 (grad clamp +-1 keeps |g| small near convergence)
+TOL_SAC_TRACE = 5e-4        # S = 3 x 72 (critic, actor, alpha), lr 3e-4; actions = tanh of the drifting actor's mean
+TOL_SAC_LOSS = 1e-3         # losses are differences of Q values of O(10): 1e-3 relative = the Q drift above
+TOL_RAINBOW_TRACE = 5e-4    # S = 100 noisy updates, lr 1e-3 -> S*lr = 0.1
+TOL_RAINBOW_LOSS = 1e-3     # IS-weighted TD^2 and the float64 tree's priorities |td|^0.6: d(p)/p = 0.6 * d(td)/td
 
 
 def _load(module, g, prefix):
@@ -205,10 +226,10 @@ def test_ppo_train_trace_matches_reference(fixture):
         assert close(s["episode_rewards"], g[p + "episode_rewards"], 1e-6)
         want = g[p + "metrics"]
         got = [s["metrics"][k] for k in ("policy_loss", "value_loss", "entropy", "clip_frac", "approx_kl")]
-        assert np.all(np.abs(np.asarray(got) - want) <= 2e-5 * np.maximum(1.0, np.abs(want))), (got, want)
+        bounded(f"ppo_trace[h{hidden}] r{r} metrics", np.max(np.abs(np.asarray(got) - want) / np.maximum(1.0, np.abs(want))), TOL_PPO_METRICS)
         sub = stride if r == 0 else 1          # the wide fixture keeps every 8th element of the first snapshot
         err = max(float(np.max(np.abs(v.reshape(-1)[::sub] - g[p + "sd_" + k].reshape(-1)))) for k, v in s["sd"].items())
-        assert err <= 5e-5, err
+        bounded(f"ppo_trace[h{hidden}] r{r} state_dict", err, TOL_PPO_SD)
     # P8: deterministic evaluation episodes (:368-399) — copy i plays the reference's i-th eval episode
     ep0 = int(g["eval_episode0"])
     tr._eval_env_factory = lambda n: ScriptedVecEnv(n, tr.device, episode0=ep0)
@@ -286,9 +307,9 @@ def test_dqn_train_trace_matches_reference():
     assert tr.sample_count == int(g["sample_count"]) and abs(tr.epsilon - float(g["epsilon"])) <= 1e-12
     assert np.allclose(list(tr.episode_rewards), g["episode_rewards"], rtol=0, atol=1e-6)
     assert len(losses) == len(g["losses"])
-    assert np.all(np.abs(np.asarray(losses) - g["losses"]) <= 2e-4 * np.maximum(1.0, np.abs(g["losses"])))
-    assert _maxdiff(tr.policy_net, g, "p1_") <= 2e-4
-    assert _maxdiff(tr.target_net, g, "t1_") <= 2e-4
+    bounded("dqn_trace losses", np.max(np.abs(np.asarray(losses) - g["losses"]) / np.maximum(1.0, np.abs(g["losses"]))), TOL_DQN_TRACE)
+    bounded("dqn_trace policy_net", _maxdiff(tr.policy_net, g, "p1_"), TOL_DQN_TRACE)
+    bounded("dqn_trace target_net", _maxdiff(tr.target_net, g, "t1_"), TOL_DQN_TRACE)
 
 
 def test_sac_train_trace_matches_reference():
@@ -326,13 +347,14 @@ def test_sac_train_trace_matches_reference():
         return v
     tr.select_action, tr.update = select_action, update
     tr.train()
-    assert len(actions) == len(g["actions"]) and np.allclose(np.stack(actions), g["actions"], rtol=0, atol=5e-4)
+    assert len(actions) == len(g["actions"])
+    bounded("sac_trace actions", np.max(np.abs(np.stack(actions) - g["actions"])), TOL_SAC_TRACE)
     assert np.allclose(list(tr.episode_rewards), g["episode_rewards"], rtol=0, atol=1e-6)
     got = np.asarray(losses, np.float64)
     assert got.shape == g["losses"].shape
-    assert np.all(np.abs(got - g["losses"]) <= 1e-3 * np.maximum(1.0, np.abs(g["losses"])))
+    bounded("sac_trace losses", np.max(np.abs(got - g["losses"]) / np.maximum(1.0, np.abs(g["losses"]))), TOL_SAC_LOSS)
     for name, net in (("actor", tr.actor), ("critic", tr.critic), ("critic_target", tr.critic_target)):
-        assert _maxdiff(net, g, f"p1_{name}_") <= 5e-4, name
+        bounded(f"sac_trace {name}", _maxdiff(net, g, f"p1_{name}_"), TOL_SAC_TRACE)
     assert abs(float(tr.log_alpha.item()) - float(g["log_alpha"])) <= 1e-5
 
 
@@ -381,13 +403,13 @@ def test_rainbow_train_trace_matches_reference():
     assert np.allclose(list(tr.episode_rewards), g["episode_rewards"], rtol=0, atol=1e-6)
     got = np.asarray(losses, np.float64)
     assert got.shape == g["losses"].shape
-    assert np.all(np.abs(got - g["losses"]) <= 1e-3 * np.maximum(1.0, np.abs(g["losses"])))
-    assert _maxdiff(tr.policy_net, g, "p1_") <= 5e-4
+    bounded("rainbow_trace losses", np.max(np.abs(got - g["losses"]) / np.maximum(1.0, np.abs(g["losses"]))), TOL_RAINBOW_LOSS)
+    bounded("rainbow_trace policy_net", _maxdiff(tr.policy_net, g, "p1_"), TOL_RAINBOW_TRACE)
     # the target's epsilon buffers are construction-time noise that eval mode never reads: parameters only
-    assert max(float(np.max(np.abs(p.detach().cpu().numpy() - g["t1_" + k])))
-               for k, p in tr.target_net.named_parameters()) <= 5e-4
+    bounded("rainbow_trace target_net", max(float(np.max(np.abs(p.detach().cpu().numpy() - g["t1_" + k])))
+                                            for k, p in tr.target_net.named_parameters()), TOL_RAINBOW_TRACE)
     tree = tr.memory.sum_tree.tree.cpu().numpy()
-    assert np.max(np.abs(tree - g["tree"]) / np.maximum(1.0, np.abs(g["tree"]))) <= 1e-3
+    bounded("rainbow_trace sum_tree", np.max(np.abs(tree - g["tree"]) / np.maximum(1.0, np.abs(g["tree"]))), TOL_RAINBOW_LOSS)
     assert abs(tr.optimizer.param_groups[0]["lr"] - float(g["lr_now"])) <= 1e-12
 
 
