@@ -206,7 +206,7 @@ def main_offpolicy(a, rank, world, local_rank):
     VS = 16
     if a.algo == "rainbow":
         from gymrl_amd.rainbow_dqn_cartpole import Config, RainbowDQNTrainer as Trainer
-        N, B, env_name = (a.envs if a.envs != 4096 else 8192), 256, "CartPole-v1"
+        N, B, env_name = a.envs, 256, "CartPole-v1"
     else:
         from gymrl_amd.sac_pendulum import Config, SACTrainer as Trainer
         N, B, env_name = a.envs, 128, "Pendulum-v1"
@@ -335,7 +335,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--envs", type=int, default=4096, help="env instances per GPU")
+    ap.add_argument("--envs", type=int, default=None,
+                    help="env instances per GPU (default: the BASELINE config's — 4096 for ppo / ppo_full / sac, 8192 for rainbow)")
     ap.add_argument("--rollout", type=int, default=2048, help="T: vector steps per rollout (reference update_freq)")
     ap.add_argument("--epochs", type=int, default=10)
     ap.add_argument("--minibatches", type=int, default=32)
@@ -354,6 +355,10 @@ def main():
     a = ap.parse_args()
     if a.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if a.envs is None:
+        a.envs = 8192 if a.algo == "rainbow" else 4096
+    if a.envs < 1:
+        ap.error("--envs must be >= 1")
     if a.backend == "gloo" and not a.spawn_selftest:
         ap.error("--backend gloo is only for --spawn-selftest (the benchmark itself runs on RCCL)")
 

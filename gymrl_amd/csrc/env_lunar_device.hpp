@@ -1389,13 +1389,19 @@ __device__ __forceinline__ void lunar_step_quad(const LunarState& st, const Lds&
           if (ep_ret_out) ep_ret_out[i] = (float)ret;
           if (ep_len_out) ep_len_out[i] = len;
           st.ep.ep_ret[i] = 0.0; st.ep.ep_len[i] = 0;
-          __hip_atomic_store(&st.ep.episode[i], ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // without a spare nothing is read from the spare slot, so the new episode number may be published at once
+          if (!have_spare) __hip_atomic_store(&st.ep.episode[i], ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (have_spare) {                            // next episode already prepared off the critical path
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           world_io(W, lds, role, st.spare_words, n, i, false);
 #pragma unroll
           for (int k = 0; k < 8; ++k) o_next[k] = st.spare_obs[(size_t)k * n + i];
+          // consume, THEN publish: the refill wave overwrites the spare slot as soon as it reads episode == ep, so the
+          // store is a release that follows every lane's loads of the slot (one wave: the release's vmcnt(0) wait covers
+          // the other three lanes of the quad) — the handshake no longer rests on the refill taking longer than these loads
+          __builtin_amdgcn_wave_barrier();
+          if (lead) __hip_atomic_store(&st.ep.episode[i], ep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
       } else {

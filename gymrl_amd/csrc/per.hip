@@ -12,9 +12,13 @@
 // wins; pass 2 gives one workgroup to each tree depth, where every node's additions are
 // applied by the first batch element that touches it, walking the batch in order.
 // Nodes are independent of each other, so the result equals the sequential loop bit for
-// bit.  Sampling is a pointer chase (ceil(log2 cap)+1 dependent f64 loads per draw):
+// bit.  That is update_priorities (S4), whose order the reference defines.  The N-row STORE of a vector step
+// (idx == NULL) has no reference order — the reference stores one row per step — and is defined as one pairwise-summed
+// addition per ancestor (per_store_device.hpp; identical to the reference at N = 1): per_store_* below.
+// Sampling is a pointer chase (ceil(log2 cap)+1 dependent f64 loads per draw):
 // latency-bound, one lane per draw, upper tree levels stay L2-resident.
 #include "gymrl_device.hpp"
+#include "per_store_device.hpp"
 #include "../../include/gymrl.h"
 
 using namespace gymrl;
@@ -47,23 +51,18 @@ __device__ __forceinline__ double prio_of(const double* prio, const double* ps_d
 // 8192-row store cost 0.9 ms; from LDS it is the add latency (~35 us).
 constexpr int kLdsB = 8192;
 
-// pass 1 (single workgroup): leaves + per-element change.
+// pass 1 (single workgroup): leaves + per-element change of an explicit index batch (update_priorities).
 __global__ __launch_bounds__(1024) void per_leaf_kernel(double* __restrict__ tree, int64_t cap,
-                                                        const int32_t* __restrict__ idx,
-                                                        int64_t idx_start, int idx_is_tree,
+                                                        const int32_t* __restrict__ idx, int idx_is_tree,
                                                         const double* __restrict__ prio,
                                                         const double* __restrict__ ps_dev, double ps,
                                                         int B, int64_t* __restrict__ leaf_out,
-                                                        double* __restrict__ change_out, int use_lds,
-                                                        const int64_t* __restrict__ idx_start_dev) {
+                                                        double* __restrict__ change_out, int use_lds) {
   extern __shared__ int64_t s_leaf_dyn[];
-  if (idx_start_dev) idx_start = idx_start_dev[0];     // recorded into a hipGraph: this replay's ring cursor
   const int64_t* lf = use_lds ? s_leaf_dyn : leaf_out;
   // phase A: leaf index of every element
   for (int i = threadIdx.x; i < B; i += blockDim.x) {
-    int64_t leaf;
-    if (idx) leaf = idx_is_tree ? (int64_t)idx[i] : (int64_t)idx[i] + cap - 1;
-    else leaf = (idx_start + i) % cap + cap - 1;
+    const int64_t leaf = idx_is_tree ? (int64_t)idx[i] : (int64_t)idx[i] + cap - 1;
     leaf_out[i] = leaf;
     if (use_lds) s_leaf_dyn[i] = leaf;
   }
@@ -72,18 +71,17 @@ __global__ __launch_bounds__(1024) void per_leaf_kernel(double* __restrict__ tre
   for (int i = threadIdx.x; i < B; i += blockDim.x) {
     const int64_t leaf = lf[i];
     double prev = tree[leaf];
-    if (idx) {   // duplicates possible: the latest earlier element on the same leaf
-      // (eight LDS reads in flight per round: one at a time, each link of the search is a dependent ~100-clock round trip)
-      int found = -1;
-      for (int j0 = i - 1; j0 >= 0 && found < 0; j0 -= 8) {
-        int64_t v[8];
+    // duplicates possible: the latest earlier element on the same leaf
+    // (eight LDS reads in flight per round: one at a time, each link of the search is a dependent ~100-clock round trip)
+    int found = -1;
+    for (int j0 = i - 1; j0 >= 0 && found < 0; j0 -= 8) {
+      int64_t v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = j0 - u >= 0 ? lf[j0 - u] : (int64_t)-1;
+      for (int u = 0; u < 8; ++u) v[u] = j0 - u >= 0 ? lf[j0 - u] : (int64_t)-1;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (found < 0 && v[u] == leaf) found = j0 - u;
-      }
-      if (found >= 0) prev = prio_of(prio, ps_dev, ps, found);
+      for (int u = 0; u < 8; ++u) if (found < 0 && v[u] == leaf) found = j0 - u;
     }
+    if (found >= 0) prev = prio_of(prio, ps_dev, ps, found);
     change_out[i] = prio_of(prio, ps_dev, ps, i) - prev;
   }
   __syncthreads();
@@ -91,52 +89,22 @@ __global__ __launch_bounds__(1024) void per_leaf_kernel(double* __restrict__ tre
   for (int i = threadIdx.x; i < B; i += blockDim.x) {
     const int64_t leaf = lf[i];
     bool last = true;
-    if (idx) {
-      for (int j0 = i + 1; j0 < B && last; j0 += 8) {
-        int64_t v[8];
+    for (int j0 = i + 1; j0 < B && last; j0 += 8) {
+      int64_t v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = j0 + u < B ? lf[j0 + u] : (int64_t)-1;
+      for (int u = 0; u < 8; ++u) v[u] = j0 + u < B ? lf[j0 + u] : (int64_t)-1;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (v[u] == leaf) last = false;
-      }
+      for (int u = 0; u < 8; ++u) if (v[u] == leaf) last = false;
     }
     if (last) tree[leaf] = prio_of(prio, ps_dev, ps, i);
   }
 }
 
-// Ordered sum acc + ch[j] + ch[j + 1] + ... + ch[e - 1] (one dependent chain: the reference's order).  ONE lane walks it, and
-// a lone wave issues an instruction per ~5 clocks, so the chain costs its instruction count per add: two register groups
-// alternate (no copies) and the operands come as 16-byte reads once the address is 16-byte aligned — 16 adds + 8 reads + the
-// loop.  Called once with the LDS copy and once with the global one so that each call site knows its address space (a
-// pointer that may be either makes every read a FLAT load behind a full waitcnt).
-__device__ __forceinline__ double ordered_run_sum(double acc, const double* __restrict__ ch, int j, int e) {
-  if (j < e && (reinterpret_cast<uintptr_t>(ch + j) & 15u)) { acc += ch[j]; ++j; }
-  if (j + 16 <= e) {
-    const double2* c2 = reinterpret_cast<const double2*>(ch + j);
-    double2 a0 = c2[0], a1 = c2[1], a2 = c2[2], a3 = c2[3];
-    int q = 4;                                                             // next unread pair
-    const int pairs = (e - j) >> 1;
-    while (q + 8 <= pairs) {
-      const double2 b0 = c2[q], b1 = c2[q + 1], b2 = c2[q + 2], b3 = c2[q + 3];
-      acc += a0.x; acc += a0.y; acc += a1.x; acc += a1.y; acc += a2.x; acc += a2.y; acc += a3.x; acc += a3.y;
-      a0 = c2[q + 4]; a1 = c2[q + 5]; a2 = c2[q + 6]; a3 = c2[q + 7];
-      acc += b0.x; acc += b0.y; acc += b1.x; acc += b1.y; acc += b2.x; acc += b2.y; acc += b3.x; acc += b3.y;
-      q += 8;
-    }
-    acc += a0.x; acc += a0.y; acc += a1.x; acc += a1.y; acc += a2.x; acc += a2.y; acc += a3.x; acc += a3.y;
-    j += 2 * q;
-  }
-  for (; j < e; ++j) acc += ch[j];
-  return acc;
-}
-
-// pass 2: blockIdx.x = node depth d (0 = root).  A node's additions happen in batch order.
-// `sorted`: consecutive leaves of a power-of-two tree without wrap-around: a node's elements are one
-// contiguous run whose end follows from the subtree span, so the run is summed without searching.
+// pass 2: blockIdx.x = node depth d (0 = root).  A node's additions happen in batch order (the reference's loop).
 __global__ __launch_bounds__(1024) void per_ancestor_kernel(double* __restrict__ tree,
                                                             const int64_t* __restrict__ leaf_g,
                                                             const double* __restrict__ change_g, int B,
-                                                            int sorted, int use_lds) {
+                                                            int use_lds) {
   extern __shared__ __attribute__((aligned(16))) int64_t s_dyn[];
   const int d = blockIdx.x;
   const int64_t* leaf = leaf_g;
@@ -148,7 +116,6 @@ __global__ __launch_bounds__(1024) void per_ancestor_kernel(double* __restrict__
     __syncthreads();
     leaf = sl; change = sc;
   }
-  if (sorted == 2) sorted = leaf[B - 1] - leaf[0] == (int64_t)(B - 1) ? 1 : 0;   // device-side cursor: a run unless it wrapped
   for (int i = threadIdx.x; i < B; i += blockDim.x) {
     const int64_t lf = leaf[i];
     const int L = depth_of(lf);
@@ -156,45 +123,79 @@ __global__ __launch_bounds__(1024) void per_ancestor_kernel(double* __restrict__
     const int64_t node = ((lf + 1) >> (L - d)) - 1;
     // leader = first batch element reaching this node
     bool leader = true;
-    if (sorted) {
-      if (i > 0) {
-        const int64_t lp = leaf[i - 1];
-        const int Lp = depth_of(lp);
-        leader = !(Lp > d && (((lp + 1) >> (Lp - d)) - 1) == node);
-      }
-    } else {
-      for (int j0 = 0; j0 < i && leader; j0 += 8) {        // eight reads in flight per round (see per_leaf_kernel)
-        int64_t v[8];
+    for (int j0 = 0; j0 < i && leader; j0 += 8) {          // eight reads in flight per round (see per_leaf_kernel)
+      int64_t v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = j0 + u < i ? leaf[j0 + u] : (int64_t)0;      // 0 = the root: never has an ancestor
+      for (int u = 0; u < 8; ++u) v[u] = j0 + u < i ? leaf[j0 + u] : (int64_t)0;      // 0 = the root: never has an ancestor
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int Lj = depth_of(v[u]);
-          if (Lj > d && (((v[u] + 1) >> (Lj - d)) - 1) == node) leader = false;
-        }
+      for (int u = 0; u < 8; ++u) {
+        const int Lj = depth_of(v[u]);
+        if (Lj > d && (((v[u] + 1) >> (Lj - d)) - 1) == node) leader = false;
       }
     }
     if (!leader) continue;
     double acc = tree[node];
-    if (sorted) {
-      // last leaf of the node's subtree: ((node + 2) << (L - d)) - 2; the run ends there or at the batch end
-      const int64_t last_leaf = ((node + 2) << (L - d)) - 2;
-      const int64_t e64 = (int64_t)i + (last_leaf - lf) + 1;
-      const int e = e64 < (int64_t)B ? (int)e64 : B;
-      acc = use_lds ? ordered_run_sum(acc, reinterpret_cast<const double*>(s_dyn + B), i, e) : ordered_run_sum(acc, change_g, i, e);
-    } else {
-      for (int j0 = i; j0 < B; j0 += 8) {                  // the node's additions in batch order, operands fetched eight at a time
-        int64_t v[8]; double c[8];
+    for (int j0 = i; j0 < B; j0 += 8) {                    // the node's additions in batch order, operands fetched eight at a time
+      int64_t v[8]; double c[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const bool in = j0 + u < B; v[u] = in ? leaf[j0 + u] : (int64_t)0; c[u] = in ? change[j0 + u] : 0.0; }
+      for (int u = 0; u < 8; ++u) { const bool in = j0 + u < B; v[u] = in ? leaf[j0 + u] : (int64_t)0; c[u] = in ? change[j0 + u] : 0.0; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int Lj = depth_of(v[u]);
-          if (Lj > d && (((v[u] + 1) >> (Lj - d)) - 1) == node) acc += c[u];
-        }
+      for (int u = 0; u < 8; ++u) {
+        const int Lj = depth_of(v[u]);
+        if (Lj > d && (((v[u] + 1) >> (Lj - d)) - 1) == node) acc += c[u];
       }
     }
     tree[node] = acc;
+  }
+}
+
+// ---- the N-row vector store (idx == NULL): per_store_device.hpp ------------------------------------------------------
+// Launch 1: every row's leaf (no duplicates: B <= cap), change = p - old leaf, leaf := p.  Fully parallel.
+__global__ __launch_bounds__(kBlock) void per_store_leaf_kernel(double* __restrict__ tree, int64_t cap, int64_t idx_start,
+                                                                const int64_t* __restrict__ idx_start_dev, int64_t offset,
+                                                                const double* __restrict__ prio,
+                                                                const double* __restrict__ ps_dev, double ps, int B,
+                                                                double* __restrict__ change_out) {
+  if (idx_start_dev) idx_start = idx_start_dev[0];       // recorded into a hipGraph: this replay's ring cursor
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  const int64_t leaf = (idx_start + offset + i) % cap + cap - 1;
+  const double p = prio_of(prio, ps_dev, ps, i);
+  change_out[i] = p - tree[leaf];
+  tree[leaf] = p;
+}
+
+// Launch 2: blockIdx.x = node depth d.  Every workgroup builds the batch tree in LDS (2P doubles: 13 levels at 8192
+// rows), then its threads take the depth's nodes: <= 4 runs per node in closed form, <= 2 log2(P) LDS reads per run,
+// ONE addition into the node.  No chain is longer than log2(P) + 4 float64 adds.
+__global__ __launch_bounds__(1024) void per_store_ancestor_kernel(double* __restrict__ tree, int64_t cap, int64_t idx_start,
+                                                                  const int64_t* __restrict__ idx_start_dev, int64_t offset,
+                                                                  const double* __restrict__ change, int B, int P) {
+  extern __shared__ __attribute__((aligned(16))) double s_seg[];
+  if (idx_start_dev) idx_start = idx_start_dev[0];
+  const int d = blockIdx.x;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) s_seg[P + i] = i < B ? change[i] : 0.0;
+  __syncthreads();
+  for (int w = P >> 1; w >= 1; w >>= 1) {
+    for (int k = w + threadIdx.x; k < 2 * w; k += blockDim.x) s_seg[k] = s_seg[2 * k] + s_seg[2 * k + 1];
+    __syncthreads();
+  }
+  const per::StoreGeom g = per::store_geom(cap, idx_start + offset, B);
+  int64_t n0[4], n1[4];
+  const int nr = per::store_node_ranges(g, d, n0, n1);
+  for (int r = 0; r < nr; ++r) {
+    const int64_t cnt = n1[r] - n0[r] + 1;
+    for (int64_t t = threadIdx.x; t < cnt; t += blockDim.x) {
+      const int64_t node = n0[r] + t;
+      bool seen = false;                                   // a node two ranges share belongs to the first
+      for (int q = 0; q < r; ++q) seen = seen || (node >= n0[q] && node <= n1[q]);
+      if (seen) continue;
+      int a[4], e[4];
+      const int m = per::store_node_runs(g, d, node, a, e);
+      double S = 0.0;
+      for (int q = 0; q < m; ++q) S += per::store_run_sum(s_seg, P, a[q], e[q]);
+      tree[node] = tree[node] + S;
+    }
   }
 }
 
@@ -429,6 +430,7 @@ int gymrl_per_update(double* tree, int64_t cap, const int32_t* idx, int64_t idx_
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)per_leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsB * 8) != hipSuccess ||
         hipFuncSetAttribute((const void*)per_ancestor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsB * 16) != hipSuccess ||
+        hipFuncSetAttribute((const void*)per_store_ancestor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, per::kStoreChunk * 16) != hipSuccess ||
         hipFuncSetAttribute((const void*)per_leaf_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsB * 8) != hipSuccess ||
         hipFuncSetAttribute((const void*)per_ancestor_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsB * 16) != hipSuccess)
       return -1000 - (int)hipGetLastError();
@@ -437,7 +439,21 @@ int gymrl_per_update(double* tree, int64_t cap, const int32_t* idx, int64_t idx_
   // deepest leaf depth = depth of the last tree slot; ancestors live at depths 0 .. that-1
   int depth = 0;
   { int64_t t = 2 * cap - 2; while (t > 0) { t = (t - 1) / 2; ++depth; } }
-  if (idx && B > 512 && B <= kLdsB && 2 * cap < (1ll << (63 - kIdxBits))) {     // large unordered batch: sort-based passes
+  if (!idx) {                                           // the N-row vector store: sub-stores of <= 8192 rows, in order
+    for (int o = 0; o < B; o += per::kStoreChunk) {
+      const int n = B - o < per::kStoreChunk ? B - o : per::kStoreChunk;
+      int P = 1;
+      while (P < n) P <<= 1;
+      hipLaunchKernelGGL(per_store_leaf_kernel, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, stream, tree, cap, idx_start,
+                         idx_start_dev, (int64_t)o, prio ? prio + o : nullptr, prio_scalar_dev, prio_scalar, n, ws.change);
+      if (depth > 0)
+        hipLaunchKernelGGL(per_store_ancestor_kernel, dim3(depth), dim3(1024), (size_t)P * 16, stream, tree, cap, idx_start,
+                           idx_start_dev, (int64_t)o, ws.change, n, P);
+    }
+    GYMRL_CHECK_LAUNCH();
+    return 0;
+  }
+  if (B > 512 && B <= kLdsB && 2 * cap < (1ll << (63 - kIdxBits))) {     // large unordered batch: sort-based passes
     int P = 1;
     while (P < B) P <<= 1;
     hipLaunchKernelGGL(per_leaf_sorted_kernel, dim3(1), dim3(1024), (size_t)P * 8, stream, tree, cap, idx, idx_is_tree,
@@ -449,15 +465,10 @@ int gymrl_per_update(double* tree, int64_t cap, const int32_t* idx, int64_t idx_
     return 0;
   }
   hipLaunchKernelGGL(per_leaf_kernel, dim3(1), dim3(1024), use_lds ? (size_t)B * 8 : 0, stream, tree, cap, idx,
-                     idx_start, idx_is_tree, prio, prio_scalar_dev, prio_scalar, B, ws.leaf, ws.change, use_lds,
-                     idx_start_dev);
-  // consecutive rows form one run per node only when all leaves share a depth (cap = 2^k) and
-  // the row range does not wrap; otherwise the general ordered search is used
-  // (a cursor read from the device: the kernel tests the staged leaves for a wrap itself)
-  const int sorted = (!idx && (cap & (cap - 1)) == 0) ? (idx_start_dev ? 2 : ((idx_start % cap) + B <= cap ? 1 : 0)) : 0;
+                     idx_is_tree, prio, prio_scalar_dev, prio_scalar, B, ws.leaf, ws.change, use_lds);
   if (depth > 0)
     hipLaunchKernelGGL(per_ancestor_kernel, dim3(depth), dim3(1024), use_lds ? (size_t)B * 16 : 0, stream, tree,
-                       ws.leaf, ws.change, B, sorted, use_lds);
+                       ws.leaf, ws.change, B, use_lds);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

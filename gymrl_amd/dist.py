@@ -98,8 +98,18 @@ class GradReducer:
         self.buckets = [flat_grads[lo:hi] for lo, hi in zip(bounds[:-1], bounds[1:])]
         self.cuda = flat_grads.is_cuda
         self.comm = torch.cuda.Stream(device=flat_grads.device) if self.cuda else None
-        self.timed = bool(timed) and self.cuda
+        self.timed = timed
         self._pending, self._spans, self._stalls = [], [], []
+
+    @property
+    def timed(self):
+        return self._timed
+
+    @timed.setter
+    def timed(self, on):
+        """Event timing exists on the device path only: a gloo / CPU reducer stays untimed whatever a trainer assigns
+        (stats() would otherwise call torch.cuda.synchronize on a CPU tensor's device)."""
+        self._timed = bool(on) and self.cuda
 
     def launch(self, k):
         """Reduce bucket k; everything queued on the current stream so far is ordered before it."""

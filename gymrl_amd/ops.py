@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns device memory and the stream; every op below
 passes raw device pointers + the current HIP stream to libgymrl_hip.so.  No op
 has a CPU path — tensors must live on an MI355X.
 """
+import collections
 import ctypes as C
 
 import torch
@@ -1092,20 +1093,29 @@ def rmsnorm(x, w, eps, n_sum=1, act=0):
     return y
 
 
-_scratch_cache = {}
+_SCRATCH_MAX = 64
+_scratch_cache = collections.OrderedDict()
 
 
 def _scratch(kind, shape_key, nbytes, dev):
     """Partial-sum scratch of the backward kernels that take one.  Cached per (kernel, shape, device, STREAM): two
     streams never share a buffer, so concurrent backward passes cannot race on it.  While the stream is capturing a
     hipGraph a missing buffer is allocated for this call only (it then lives in the graph's private pool like any other
-    temporary) and is NOT cached — an eager call after `del graph` must never inherit memory of a dead graph's pool."""
+    temporary) and is NOT cached — an eager call after `del graph` must never inherit memory of a dead graph's pool.
+    The cache is a bounded LRU (_SCRATCH_MAX entries): code that keeps creating streams cannot grow it without limit, and
+    an evicted buffer goes back to torch's caching allocator, which hands a block to another stream only after the work
+    queued on the allocating stream (the one in the key) has been ordered before the reuse — so a raw stream handle that
+    is recycled after its stream died finds either its own old buffer (same stream-ordering domain) or none."""
     key = (kind, shape_key, dev, torch.cuda.current_stream(dev).cuda_stream)
     ws = _scratch_cache.get(key)
-    if ws is None:
-        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
-        if not torch.cuda.is_current_stream_capturing():
-            _scratch_cache[key] = ws
+    if ws is not None:
+        _scratch_cache.move_to_end(key)
+        return ws
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    if not torch.cuda.is_current_stream_capturing():
+        _scratch_cache[key] = ws
+        while len(_scratch_cache) > _SCRATCH_MAX:
+            _scratch_cache.popitem(last=False)
     return ws
 
 

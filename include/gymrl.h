@@ -767,13 +767,14 @@ int gymrl_linear_bwd_input(const float* dY, const float* W, const float* H, int6
                            float* dX, void* stream);
 int gymrl_linear_bwd_weight_geometry(int64_t B, int N, int* slices, int64_t* rows_per_slice);
 /*
- * OPT-IN split-bf16 variants of the three entry points above for the 256-wide layers (K = 256, N in {256, 512}): csrc/gemm_sb.hip.
+ * OPT-IN split-bf16 variants of the forward and the input gradient above for the 256-wide layers (K = 256, N in {256, 512}): csrc/gemm_sb.hip.
  * Every f32 operand is split exactly into three bf16 pieces (hi / mid / lo by truncation) and six bf16 MFMAs per 16-deep step
  * (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; f32 accumulation) reproduce the f32 products to ~1.2e-7 relative at 6/16 of
  * the exact f32-MFMA time.  f32-ACCURATE, not bit-exact: results are compared with float64 (error not above the exact
- * kernels' on benign and adversarial inputs, tests/test_gemm_sb_gpu.py), never with the oracle's fmaf chain.  The exact kernels
- * are the default everywhere; these are selected by Config.gemm_mode = "split_bf16" and reported by bench.py as a separate,
- * labelled line.  Same argument meaning as the exact entry points; bwd_weight uses the same workspace and slice geometry.
+ * kernels' on benign and adversarial inputs, tests/test_gemm_sb_gpu.py), never with the oracle's fmaf chain.  TWO entry points,
+ * no weight-gradient variant; no trainer selects them (there is no Config switch and no bench.py line): they are reached only
+ * from tests/test_gemm_sb_gpu.py and tools/{micro,abl,pmc}_gemm_sb.py — built and measured, not enabled.
+ * Same argument meaning as the exact entry points.
  */
 int gymrl_linear_fwd_sb(const float* X, const float* W, const float* b, int64_t B, int K, int N, int act,
                         float* Y, void* stream);
@@ -839,7 +840,16 @@ int gymrl_nstep_push(float* w_state, int32_t* w_action, float* w_reward, float* 
  *     (:258-261 / :146-147): leaf := p, every ancestor += (p - old leaf), applied in
  *     batch order — duplicates resolve last-writer-wins and every node receives its
  *     additions in the reference's order, so the float64 array matches bit for bit.
- *     idx NULL -> consecutive rows (idx_start + b) % cap (the store path :201-205).
+ *     idx NULL -> the N-ROW VECTOR STORE: consecutive rows (idx_start + b) % cap (the store path :201-205), B <= cap.
+ *       The reference stores one row per env step, so the order in which the N changes of a vector step reach an
+ *       ancestor is defined HERE (and restated by the oracle's tree_store_chunk): change_b = p_b - old leaf, leaf := p_b;
+ *       a complete binary tree over the batch index, seg[P + b] = change_b (+0.0 beyond B, P = the power of two >= B),
+ *       seg[k] = seg[2k] + seg[2k + 1]; a node's elements (ascending b) form maximal runs of consecutive b; a run [a, e)
+ *       is summed from the canonical blocks (l = a + P, r = e + P; while l < r: l odd -> sl += seg[l++]; r odd ->
+ *       sr += seg[--r]; halve both; run = sl + sr); S = +0.0 + run_1 + run_2 ...; node := node + S — ONE addition per
+ *       node, no chain longer than log2(P) + 4 float64 adds.  B > 8192: sub-stores of 8192 rows in order.  At B = 1 this
+ *       is the reference's `tree[parent] += change` (:122-128) bit for bit; the strictly ordered per-node sums above
+ *       remain for explicit index batches (update_priorities, whose order the reference does define).
  *     idx_is_tree != 0 -> idx are tree indices (variant B, :75-80).
  *     prio f64[B], or prio NULL and prio_scalar for all (store: 1.0 or priority_max).
  *     workspace >= gymrl_per_workspace_bytes(B).

@@ -30,10 +30,82 @@ void orc_tree_update(double* tree, int64_t cap, int64_t data_index, double prior
   tree[t] = priority;
   while (t != 0) { t = (t - 1) / 2; tree[t] += change; }
 }
+/* The N-ROW VECTOR STORE (gymrl_per_update with idx == NULL; include/gymrl.h "vector store").  The reference stores ONE row
+ * per env step (:201-205), so the order in which the N rows of a vector step reach an ancestor is this build's own
+ * definition, chosen so that no node needs an N-long dependent chain of float64 adds:
+ *   1. rows b = 0..B-1 go to leaves (idx_start + b) % cap (B <= cap: all distinct); change_b = p_b - old leaf; leaf := p_b;
+ *   2. a complete binary tree over the batch index: seg[P + b] = change_b (+0.0 for b >= B, P = the power of two >= B),
+ *      seg[k] = seg[2k] + seg[2k + 1];
+ *   3. for every ancestor node: its elements (the b whose leaf lies below it) in ascending b, grouped into maximal runs
+ *      of CONSECUTIVE b; a run [a, e) is summed from the canonical blocks of the batch tree
+ *      (l = a + P, r = e + P; while l < r: if l odd: sl += seg[l++]; if r odd: sr += seg[--r]; l, r >>= 1; run = sl + sr,
+ *      sl = sr = +0.0 initially); S = +0.0, S += run for the runs in ascending order; node := node + S.
+ *   4. B > 8192: consecutive sub-stores of 8192 rows, one after the other.
+ * At B = 1 this is node := node + change — the reference's SumTree.update (:122-128) bit for bit, so every fixture taken
+ * from the reference's one-row stores (sumtree.npz, per_nstep.npz, rainbow_trace.npz) pins it.  Written here with explicit
+ * member lists (no tree-position arithmetic): the HIP kernel finds the same runs in closed form. */
+static double seg_run(const double* seg, int64_t P, int64_t a, int64_t e) {
+  double sl = 0.0, sr = 0.0;
+  for (int64_t l = a + P, r = e + P; l < r; l >>= 1, r >>= 1) {
+    if (l & 1) sl += seg[l++];
+    if (r & 1) sr += seg[--r];
+  }
+  return sl + sr;
+}
+static void tree_store_chunk(double* tree, int64_t cap, int64_t start, const double* prio, double prio_scalar, int B) {
+  int64_t P = 1;
+  while (P < B) P <<= 1;
+  double* seg = (double*)calloc((size_t)(2 * P), sizeof(double));
+  for (int b = 0; b < B; ++b) {
+    int64_t t = (start + b) % cap + cap - 1;
+    double p = prio ? prio[b] : prio_scalar;
+    seg[P + b] = p - tree[t];
+    tree[t] = p;
+  }
+  for (int64_t k = P - 1; k >= 1; --k) seg[k] = seg[2 * k] + seg[2 * k + 1];
+  /* member lists: every ancestor met by the walks gets its elements in ascending b */
+  int depth = 0;
+  for (int64_t t = 2 * cap - 2; t > 0; t = (t - 1) / 2) ++depth;
+  size_t cap_pairs = (size_t)B * (size_t)(depth + 1) + 1, n_pairs = 0;
+  int64_t* pn = (int64_t*)malloc(cap_pairs * sizeof(int64_t));          /* (node, b) pairs in walk order */
+  int32_t* pb = (int32_t*)malloc(cap_pairs * sizeof(int32_t));
+  for (int b = 0; b < B; ++b)
+    for (int64_t t = (start + b) % cap + cap - 1; t != 0;) { t = (t - 1) / 2; pn[n_pairs] = t; pb[n_pairs++] = b; }
+  /* stable counting sort by node over the touched nodes: head[node] -> first pair, linked in ascending b */
+  int64_t tcap = 2 * cap - 1;
+  int64_t* first = (int64_t*)malloc((size_t)tcap * sizeof(int64_t));
+  int64_t* last = (int64_t*)malloc((size_t)tcap * sizeof(int64_t));
+  int64_t* next = (int64_t*)malloc(cap_pairs * sizeof(int64_t));
+  for (int64_t t = 0; t < tcap; ++t) first[t] = -1;
+  for (size_t k = 0; k < n_pairs; ++k) {
+    next[k] = -1;
+    if (first[pn[k]] < 0) first[pn[k]] = (int64_t)k; else next[last[pn[k]]] = (int64_t)k;
+    last[pn[k]] = (int64_t)k;
+  }
+  for (size_t k0 = 0; k0 < n_pairs; ++k0) {
+    int64_t node = pn[k0];
+    if (first[node] != (int64_t)k0) continue;                          /* each node once, at its first pair */
+    double S = 0.0;
+    int64_t k = (int64_t)k0;
+    while (k >= 0) {
+      int64_t a = pb[k], e = a + 1;
+      k = next[k];
+      while (k >= 0 && pb[k] == e) { ++e; k = next[k]; }               /* a maximal run of consecutive b */
+      S += seg_run(seg, P, a, e);
+    }
+    tree[node] = tree[node] + S;
+  }
+  free(seg); free(pn); free(pb); free(first); free(last); free(next);
+}
 void orc_tree_update_many(double* tree, int64_t cap, const int32_t* idx, int64_t idx_start, int idx_is_tree,
                           const double* prio, double prio_scalar, int B) {               /* :258-261 */
-  for (int i = 0; i < B; ++i) {
-    int64_t d = idx ? (idx_is_tree ? (int64_t)idx[i] - (cap - 1) : (int64_t)idx[i]) : (idx_start + i) % cap;
+  if (!idx) {                                   /* the vector store (see above); B <= cap */
+    for (int o = 0; o < B; o += 8192)
+      tree_store_chunk(tree, cap, idx_start + o, prio ? prio + o : 0, prio_scalar, B - o < 8192 ? B - o : 8192);
+    return;
+  }
+  for (int i = 0; i < B; ++i) {                 /* update_priorities: the reference's sequential loop, duplicates and all */
+    int64_t d = idx_is_tree ? (int64_t)idx[i] - (cap - 1) : (int64_t)idx[i];
     orc_tree_update(tree, cap, d, prio ? prio[i] : prio_scalar);
   }
 }
