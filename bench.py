@@ -594,12 +594,21 @@ def report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev,
             tf = flops_per_unit[k] * v["units"] / v["total_s"] / 1e12
             ent.update(bound="mfma", flops_per_unit=flops_per_unit[k], achieved_TFLOPs=round(tf, 1), frac=round(tf * 1e12 / MFMA_F32_PEAK, 4))
         kernels[k] = ent
-    prof = None
-    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            prof = (name, json.load(open(path)))
+    # counter-measured HBM traffic lives in a separate rocprofv3 --pmc pass (the tool cannot run inside this process); its
+    # summary is attached only when it was taken on THIS binary: the sha256 of libgymrl_hip.so stamped into the summary
+    # (tools/pmc_gemm.py -> tools/pmc_gemm_summarise.py) must equal the library loaded here, else the summary is refused
+    from gymrl_amd import _lib
+    lib_hash = _lib.lib_sha256()
+    prof, prof_refused = None, None
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json")), reverse=True):
+        summary = json.load(open(os.path.join(ROOT, "profiles", name)))
+        stamp = (summary.get("provenance") or {}).get("libgymrl_hip_sha256")
+        if stamp == lib_hash:
+            prof = (name, summary)
             break
+        if prof_refused is None:
+            prof_refused = dict(file="profiles/" + name, refused=("no provenance stamp" if stamp is None else
+                                                                  f"taken on library {stamp[:16]}..., this run loaded {lib_hash[:16]}..."))
     gemms = [k for k in flops_per_unit if k in ks]
     n_upd = a.steps * cfg.num_epochs * cfg.num_minibatches
     if not gemms:
@@ -633,7 +642,9 @@ def report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev,
     roofline = dict(bound=head["bound"], achieved=head["achieved"], peak=head["peak"], unit=head["unit"], frac=head["frac"],
                     traffic=None, kernel=head["kernel"], launch_s=head["launch_s"],
                     traffic_from_profiles=(dict(file="profiles/" + prof[0], note="PMC byte counts of separate rocprofv3 --pmc passes over the "
-                                                "same kernels (tools/pmc_kernels.py), not measured in this run", summary=prof[1]) if prof else None),
+                                                "same kernels of the SAME binary (sha256 of libgymrl_hip.so matches), not measured in this run",
+                                                summary=prof[1]) if prof else prof_refused),
+                    library_sha256=lib_hash,
                     gae_loss_pass=gae_loss, kernels=kernels)
     for k in ("flops_per_launch_group", "bytes_per_launch_group", "share_of_step"):
         if k in head:

@@ -167,6 +167,17 @@ def lib():
     return _lib
 
 
+def lib_sha256():
+    """sha256 of the library file that lib() loads — the identity of the binary a measurement was taken on
+    (profiles/*_pmc_summary.json carry it; bench.py refuses a counter summary taken on another binary)."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
 def check(rc, what):
     if rc != 0:
         raise RuntimeError(f"{what} failed with code {rc}" + (" (EINVAL)" if rc == -22 else ""))

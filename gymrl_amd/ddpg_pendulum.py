@@ -100,3 +100,8 @@ class DDPGTrainer(_ActorCriticBase):
             self._graph = GraphedUpdate(self.device, cfg.batch_size, [self.critic_optimizer, self.actor_optimizer],
                                         lambda idx, biases, ab: self._update_body(idx, biases, ab))
         self._graph(self.memory, cfg.batch_size)
+
+
+if __name__ == "__main__":       # python -m gymrl_amd.ddpg_pendulum [--<Config attribute> <value> ...]  (ddpg_pendulum.py:280-296)
+    from .utils.cli import run_script
+    run_script(Config, DDPGTrainer)

@@ -18,6 +18,7 @@ from . import ops
 from .envs import EpisodeTracker, VecEnv
 from .flat import FusedAdam, GradSink, flatten_module
 from .nn import SmallLinear
+from .utils import scalar
 
 
 class Config:
@@ -80,7 +81,16 @@ class ReplayBuffer:
     def push(self, state, action, reward, next_state, done, cursor_dev=None):
         """cursor_dev (StepChunk capture): device int64[1] cursor of the replayed step; the host cursor is advanced by
         the trainer's staging loop (advance()) instead."""
+        if not (torch.is_tensor(reward) and reward.is_cuda):
+            # host scalars / numpy rows — the reference's `memory.push(state, action, reward, next_state, done)` (:183)
+            n = int(np.size(reward.cpu().numpy() if torch.is_tensor(reward) else reward))
+            D, AW = self.ring[0].shape[1], self.ring[1].shape[1]
+            state, next_state = (scalar.rows(x, n, torch.float32, self.device, D) for x in (state, next_state))
+            action = scalar.rows(action, n, self.action_dtype, self.device, AW)
+            reward, done = scalar.rows(reward, n, torch.float32, self.device), scalar.rows(done, n, torch.uint8, self.device)
         n = reward.numel()
+        if action.dtype != torch.int32:                       # float32 action words (SAC / TD3 / DDPG rings)
+            action = action.contiguous().view(torch.int32)
         ops.replay_append(self.ring, self.cursor, state, action.view(n, -1), reward, next_state, done, cursor_dev=cursor_dev)
         if cursor_dev is None:
             self.advance(n)
@@ -157,13 +167,16 @@ class DQNTrainer:
 
     @torch.no_grad()
     def select_action(self, state, deterministic=False, u=None):
-        """:124-133 for a batch of states [N, D] -> i32[N]."""
+        """:124-133 for a batch of states [N, D] -> i32[N] (device in, device out).  The reference's scalar surface: ONE host
+        observation (np.ndarray [D]) in -> python int out, as `select_action(state) -> int` at :124-133."""
+        state, kind = scalar.obs_batch(state, self.device)
         q = self.policy_net(state)
         if deterministic:       # eval(): greedy, and the exploration stream must not move (bit-exact resume / replay)
-            return ops.epsilon_greedy(q, 0.0, u=u, seed=self.base_seed, counter=0, env_id0=self.env.env_id0)
+            return scalar.discrete_out(ops.epsilon_greedy(q, 0.0, u=u, seed=self.base_seed, counter=0, env_id0=self.env.env_id0), kind)
         eps = self.get_epsilon()
         self._act_counter += 1
-        return ops.epsilon_greedy(q, eps, u=u, seed=self.base_seed, counter=self._act_counter, env_id0=self.env.env_id0)
+        return scalar.discrete_out(ops.epsilon_greedy(q, eps, u=u, seed=self.base_seed, counter=self._act_counter,
+                                                      env_id0=self.env.env_id0), kind)
 
     def load_target(self):
         self.target_flat.copy_(self.flat_params)        # target_net.load_state_dict(policy_net.state_dict())
@@ -290,3 +303,8 @@ class DQNTrainer:
 
     def test(self):
         return self.eval(num_episodes=5)
+
+
+if __name__ == "__main__":       # python -m gymrl_amd.dqn_cartpole [--<Config attribute> <value> ...]  (dqn_cartpole.py:256-272)
+    from .utils.cli import run_script
+    run_script(Config, DQNTrainer)

@@ -72,6 +72,13 @@ class VecEnv:
         ops.env_abandon(self.kind, self.state, self.n, self.seed, self.env_id0, int(cap), obs_inout, flag_inout, ep_ret_out,
                         ep_len_out, self.ep_stats)
 
+    @property
+    def gym(self):
+        """The gymnasium single-env API over this env (num_envs == 1 only): see GymView."""
+        if getattr(self, "_gym", None) is None:
+            self._gym = GymView(self)
+        return self._gym
+
     def close(self):
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
@@ -81,6 +88,56 @@ class VecEnv:
             self.close()
         except Exception:
             pass
+
+
+class GymView:
+    """gymnasium's single-env API over a VecEnv of ONE env, for callers written against the reference's loop
+    (`state, _ = env.reset()` ... `next_state, reward, terminated, truncated, _ = env.step(action)` ... `env.reset()` after
+    a done: dqn_cartpole.py:176-189, sac_pendulum.py:275-292, ppo_lunarlander.py:200-223): numpy observations, python
+    scalars.  The stepper auto-resets inside the kernel, gymnasium does not: step() therefore returns the TERMINAL
+    observation of a finished episode and the reset() that the caller issues next hands out the first observation of the
+    episode the kernel has already started (a reset(seed=...) with an explicit seed, or one in the middle of an episode,
+    is a real reset).  `trainer.env.gym` gives the view; every call is one launch + one small D2H copy."""
+
+    def __init__(self, env):
+        if env.n != 1:
+            raise ValueError("GymView is the single-env surface: num_envs must be 1")
+        self.env = env
+        self.observation_space, self.action_space, self.spec = env.observation_space, env.action_space, env.spec
+        d = env.device
+        self._obs = torch.empty(1, env.obs_dim, device=d)
+        self._term = torch.empty(1, env.obs_dim, device=d)
+        self._rew = torch.empty(1, device=d)
+        self._flags = torch.zeros(2, 1, dtype=torch.uint8, device=d)
+        self._next_ready = False
+        self._resets = 0
+
+    def reset(self, seed=None, options=None):
+        if seed is not None or not self._next_ready:
+            if seed is None and self._resets:                        # a fresh episode, not a replay of the first one
+                seed = (self.env.seed + 0x9E3779B1 * self._resets) & 0x7FFFFFFFFFFFFFFF
+            self.env.reset(self._obs, seed=seed)
+        self._next_ready = False
+        self._resets += 1
+        return self._obs[0].cpu().numpy().copy(), {}
+
+    def step(self, action):
+        import numpy as np
+        d = self.env.device
+        if self.env.discrete:
+            act = torch.tensor([int(action)], dtype=torch.int32, device=d)
+        else:
+            act = torch.from_numpy(np.asarray(action, np.float32).reshape(1, -1)).to(d)
+        self.env.step(act, self._obs, self._rew, term_obs_out=self._term, terminated_out=self._flags[0],
+                      truncated_out=self._flags[1])
+        terminated, truncated = (bool(v) for v in self._flags.view(-1).tolist())
+        done = terminated or truncated
+        self._next_ready = done
+        obs = (self._term if done else self._obs)[0].cpu().numpy().copy()
+        return obs, float(self._rew.item()), terminated, truncated, {}
+
+    def close(self):
+        self.env.close()
 
 
 def make(env_name, num_envs=1, **kw):

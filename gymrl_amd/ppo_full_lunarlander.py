@@ -655,6 +655,9 @@ class PPOTrainer:
         n_mb = (total + mb - 1) // mb
         states = b.states[:b.T].reshape(total, -1)
         act, lp, ent_old = b.actions.view(-1), b.log_probs.view(-1), b.old_entropies.view(-1)
+        if not torch.is_tensor(advantages):        # the reference hands numpy arrays over (:537-556): one H2D copy each
+            advantages = torch.as_tensor(np.asarray(advantages, np.float32), device=self.device)
+            returns = torch.as_tensor(np.asarray(returns, np.float32), device=self.device)
         adv, ret = advantages.reshape(-1), returns.reshape(-1)
         metrics = torch.zeros(cfg.num_epochs * n_mb, 9, dtype=torch.float64, device=self.device)
         sizes, row = [], 0
@@ -812,3 +815,8 @@ class PPOTrainer:
 
     def test(self):
         return self.eval(num_episodes=5)
+
+
+if __name__ == "__main__":       # python -m gymrl_amd.ppo_full_lunarlander [--<Config attribute> <value> ...]  (ppo_full_lunarlander.py:750-767)
+    from .utils.cli import run_script
+    run_script(Config, PPOTrainer, interrupted="\nCtrl+C detected, stopping training and starting test...")

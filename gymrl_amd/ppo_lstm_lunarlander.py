@@ -425,3 +425,8 @@ class PPOTrainer:
 
     def test(self):
         return self.eval(num_episodes=5)
+
+
+if __name__ == "__main__":       # python -m gymrl_amd.ppo_lstm_lunarlander [--<Config attribute> <value> ...]  (ppo_lstm_lunarlander.py:886-903)
+    from .utils.cli import run_script
+    run_script(Config, PPOTrainer, interrupted="\nCtrl+C detected, stopping training and starting test...")

@@ -55,6 +55,7 @@ class Config:
         self.device = "cuda"             # MI355X only: there is no CPU path in this package
         # --- additions of the vectorised engine (defaults reproduce the reference loop) ---
         self.num_envs = 1
+        self.scalar_surface = True       # num_envs == 1: collect_rollout() returns the python float of :231 (False: f32[1] on the device)
         self.reset_each_rollout = True   # ppo_lunarlander.py:200 resets the env at every rollout start
         self.gae_variant = 1             # 1 = time-blocked scan, 0 = sequential reference order
         self.fused_policy_forward = True  # rollout forward = one gymrl_mlp_forward launch (False: per-layer torch)
@@ -281,7 +282,16 @@ class PPOTrainer:
     def compute_gae(self, next_value=None):
         """:179-196 over every env of the slab; returns (advantages, returns) [T, N]
         (un-normalised; the whole-rollout moments are left in self._moments).  With
-        next_value=None the bootstrap values of the last collect_rollout() are used."""
+        next_value=None the bootstrap values of the last collect_rollout() are used.
+        The reference's scalar surface (num_envs == 1): a python float / numpy bootstrap value in -> two float64
+        np.ndarray [T] out, as `compute_gae(next_value) -> (advantages, returns)` at :179-196."""
+        if next_value is not None and not torch.is_tensor(next_value):
+            nv = torch.as_tensor(np.asarray(next_value, np.float32).reshape(-1), device=self.device).expand(self.buffer.N).contiguous()
+            adv, ret = self._compute_gae(nv)
+            return adv[:, 0].double().cpu().numpy(), ret[:, 0].double().cpu().numpy()
+        return self._compute_gae(next_value)
+
+    def _compute_gae(self, next_value=None):
         b = self.buffer
         nv = self._next_value if next_value is None else next_value
         # variant 2 = the blocked scan minus its first pass: the rollout composed the chunk maps
@@ -297,9 +307,18 @@ class PPOTrainer:
         return b.advantages, b.returns
 
     # -------------------------------------------------------------- rollout --
-    @torch.no_grad()
     def collect_rollout(self):
-        """:198-231 for N envs at once.  Returns next_value f32[N] (bootstrap)."""
+        """:198-231 for N envs at once.  Returns next_value f32[N] (bootstrap) on the device — or, on the reference's
+        scalar surface (num_envs == 1 and cfg.scalar_surface), the python float `collect_rollout() -> next_value` of :231;
+        update() / compute_gae() take either."""
+        nv = self._collect_rollout()
+        if self.buffer.N == 1 and getattr(self.cfg, "scalar_surface", True):
+            self._nv_float = float(nv[0])
+            return self._nv_float
+        return nv
+
+    @torch.no_grad()
+    def _collect_rollout(self):
         cfg, b, env = self.cfg, self.buffer, self.env
         b.clear()
         if cfg.reset_each_rollout or self.rollout_count == 0:
@@ -407,7 +426,11 @@ class PPOTrainer:
         cfg, b = self.cfg, self.buffer
         if indices is None and self._parity_indices:
             indices = self._parity_indices.pop(0)
-        self.compute_gae(None if next_value is self._next_value else next_value)
+        if next_value is not None and not torch.is_tensor(next_value):
+            # scalar surface: the float collect_rollout() handed out IS the device value (f32 -> f64 is exact)
+            next_value = (None if float(next_value) == getattr(self, "_nv_float", None)
+                          else torch.full((b.N,), float(next_value), device=self.device))
+        self._compute_gae(None if next_value is self._next_value else next_value)
         if self.world_size > 1:
             if self._timers is not None:
                 self._timers.start("moments_allreduce")
@@ -656,3 +679,8 @@ class PPOTrainer:
     def test(self):
         """:401-426 without the render window (the batched env has no renderer)."""
         return self.eval(num_episodes=5)
+
+
+if __name__ == "__main__":       # python -m gymrl_amd.ppo_lunarlander [--<Config attribute> <value> ...]  (ppo_lunarlander.py:429-445)
+    from .utils.cli import run_script
+    run_script(Config, PPOTrainer)

@@ -22,6 +22,7 @@ from . import ops
 from .envs import EpisodeTracker, VecEnv
 from .flat import FusedAdam, GradSink, flatten_module
 from .nn import SmallLinear, small_linear
+from .utils import scalar
 
 
 class Config:
@@ -288,8 +289,9 @@ class PrioritizedNStepBuffer:
     def stage_tree(self, stream, dev=None, chain=False):
         """The sum-tree half of the NEXT store_transition() — priority_max and the N new leaves with their ancestors,
         which depend on the ring cursor but not on the transitions themselves — issued now on `stream`, so that it
-        runs beside the acting forward + env step + n-step push of the same vector step (the root's additions are one
-        dependent chain of N float64 adds by the reference's order: ~0.1 ms on one CU at N = 8192)."""
+        runs beside the acting forward + env step + n-step push of the same vector step (round 4: the N-row store is one
+        pairwise-summed addition per ancestor, ~16 us for its two launches at N = 8192 — it was a 72-79 us dependent chain
+        when the overlap was built)."""
         if self._tree_ahead is not None or (dev is None and self.pushes + 1 < self.n_steps) or not OVERLAP_TREE:
             return
         if not chain:      # chain: the tree's previous writer (update_priorities) ran on `stream` itself, after the last reader
@@ -311,6 +313,13 @@ class PrioritizedNStepBuffer:
             else:
                 self._new_rows_priorities(dev[8:16])
             return
+        if not (torch.is_tensor(reward) and reward.is_cuda):
+            # host scalars / numpy rows — the reference's `store_transition(state, action, reward, next_state, terminal, done)` (:380)
+            N, d_ = self.N, self.ring[0].device
+            D = self.ring[0].shape[1]
+            state, next_state = (scalar.rows(x, N, torch.float32, d_, D) for x in (state, next_state))
+            action, reward = scalar.rows(action, N, torch.int32, d_), scalar.rows(reward, N, torch.float32, d_)
+            terminal, done = scalar.rows(terminal, N, torch.uint8, d_), scalar.rows(done, N, torch.uint8, d_)
         emitted = ops.nstep_push(self.win, self.n_steps, self.pushes, self.gamma, state, action, reward, next_state,
                                  terminal, done, self.ring, self.count)
         self.pushes += 1
@@ -403,6 +412,7 @@ class RainbowDQNTrainer:
     def select_action(self, state, deterministic=False, count=True):
         """:293-309 for a batch [N, D]: greedy on the noisy Q (no epsilon).  count=False: the caller advances
         total_steps itself (StepChunk staging)."""
+        state, kind = scalar.obs_batch(state, self.device)       # ONE host observation in -> python int out (:293-309)
         if not deterministic and count:
             self.total_steps += state.shape[0]
         if deterministic:
@@ -411,7 +421,7 @@ class RainbowDQNTrainer:
         self.policy_net(state, greedy_out=action)
         if deterministic:
             self.policy_net.train()
-        return action
+        return scalar.discrete_out(action, kind)
 
     def update(self, u=None):
         """:311-361.  Returns the loss as a python float."""
@@ -724,3 +734,8 @@ class RainbowDQNTrainer:
 
     def test(self):
         return self.eval(num_episodes=5)
+
+
+if __name__ == "__main__":       # python -m gymrl_amd.rainbow_dqn_cartpole [--<Config attribute> <value> ...]  (rainbow_dqn_cartpole.py:449-465)
+    from .utils.cli import run_script
+    run_script(Config, RainbowDQNTrainer)

@@ -20,6 +20,7 @@ from .dqn_cartpole import ReplayBuffer as _Ring
 from .envs import EpisodeTracker, VecEnv
 from .flat import FusedAdam, GradSink, flatten_module
 from .nn import SmallLinear, frozen_parameters, fused_linears
+from .utils import scalar
 
 
 class Config:
@@ -127,7 +128,7 @@ class ReplayBuffer(_Ring):
         super().__init__(capacity, state_dim, device, action_words=action_dim, action_dtype=torch.float32, seed=seed)
 
     def push(self, state, action, reward, next_state, done, cursor_dev=None):
-        super().push(state, action.contiguous().view(torch.int32), reward, next_state, done, cursor_dev=cursor_dev)
+        super().push(state, action, reward, next_state, done, cursor_dev=cursor_dev)     # the ring stores the f32 bits as words
 
 
 class SACTrainer:
@@ -177,8 +178,10 @@ class SACTrainer:
 
     @torch.no_grad()
     def select_action(self, state, deterministic=False, eps=None):
-        """:202-211 for a batch [N, D] -> f32[N, A] (stays on the device)."""
-        return self.actor.get_action(state, deterministic, eps)
+        """:202-211 for a batch [N, D] -> f32[N, A] (stays on the device).  The reference's scalar surface: ONE host
+        observation (np.ndarray [D]) in -> np.ndarray [act_dim] out (`.cpu().numpy().flatten()`, :211)."""
+        state, kind = scalar.obs_batch(state, self.device)
+        return scalar.continuous_out(self.actor.get_action(state, deterministic, eps), kind)
 
     def update(self, indices=None, eps_next=None, eps_cur=None):
         """:213-267 -> (actor_loss, critic_loss, alpha_loss) python floats."""
@@ -394,3 +397,8 @@ class SACTrainer:
 
     def test(self):
         return self.eval(num_episodes=5)
+
+
+if __name__ == "__main__":       # python -m gymrl_amd.sac_pendulum [--<Config attribute> <value> ...]  (sac_pendulum.py:354-370)
+    from .utils.cli import run_script
+    run_script(Config, SACTrainer)

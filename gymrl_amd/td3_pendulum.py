@@ -19,6 +19,7 @@ from .envs import EpisodeTracker, VecEnv
 from .flat import FusedAdam, GradSink, flatten_module
 from .nn import SmallLinear, frozen_parameters, fused_linears
 from .sac_pendulum import ReplayBuffer
+from .utils import scalar
 
 
 class Config:
@@ -121,12 +122,14 @@ class _ActorCriticBase:
     @torch.no_grad()
     def select_action(self, state, deterministic=False, eps=None):
         """select_action for a batch [N, D] -> f32[N, A]: actor + clipped Gaussian exploration noise."""
+        state, kind = scalar.obs_batch(state, self.device)       # ONE host observation in -> np.ndarray [act_dim] out
         action = self.actor(state)
         if deterministic:
-            return action
+            return scalar.continuous_out(action, kind)
         self._act_counter += 1
-        return ops.noisy_action(action.contiguous(), self._exploration_std() * self.action_bound, self.action_bound,
-                                eps=eps, mode=0, seed=self.base_seed, counter=self._act_counter)
+        return scalar.continuous_out(ops.noisy_action(action.contiguous(), self._exploration_std() * self.action_bound,
+                                                      self.action_bound, eps=eps, mode=0, seed=self.base_seed,
+                                                      counter=self._act_counter), kind)
 
     def train(self, max_vector_steps=None):
         """The reference's train() loop (every Linear of the update and of acting is a gymrl_lin_* launch: gymrl_amd/nn.py)."""
@@ -231,3 +234,8 @@ class TD3Trainer(_ActorCriticBase):
             self.actor_optimizer.step(polyak=(self.actor_target_flat, cfg.tau))
             actor_loss = -float(self._sum_a.item()) / B
         return actor_loss, float(self._sum_c.item()) / B
+
+
+if __name__ == "__main__":       # python -m gymrl_amd.td3_pendulum [--<Config attribute> <value> ...]  (td3_pendulum.py:313-329)
+    from .utils.cli import run_script
+    run_script(Config, TD3Trainer)

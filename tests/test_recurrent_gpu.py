@@ -8,7 +8,7 @@ from conftest import bounded, load_golden, rel_close
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
-TOL_PPO_LSTM_SD = 2e-4
+TOL_PPO_LSTM_SD = 1e-5      # the contract's bound; observed 1.5e-6 / 2.1e-7 (profiles/r04_trace_tolerances.json)
 
 
 @pytest.fixture(scope="module")
@@ -145,7 +145,7 @@ def test_ppo_lstm_train_trace_matches_reference():
             assert rel_close(s[k], g[f"r{r}_{k}"], 1e-5) <= 1e-5, (r, k)
         assert abs(s["next_value"] - float(g[f"r{r}_next_value"])) <= 1e-5 * max(1.0, abs(float(g[f"r{r}_next_value"])))
         assert np.array_equal(s["mask_counts"], g["mask_counts"][r]), (r, s["mask_counts"], g["mask_counts"][r])
-        assert rel_close(s["grad_norms"], g["grad_norms"][r], 1e-4) <= 1e-4, (r, s["grad_norms"], g["grad_norms"][r])
+        bounded(f"ppo_lstm_trace r{r} grad_norms", rel_close(s["grad_norms"], g["grad_norms"][r], 1e-4), 1e-4)
         assert abs(s["lr"] - float(g[f"r{r}_lr"])) <= 1e-12 and abs(s["ent_coef"] - float(g[f"r{r}_ent_coef"])) <= 1e-12
         assert s["step_count"] == int(g[f"r{r}_step_count"])
         assert np.array_equal(np.array(s["episode_rewards"]), g[f"r{r}_episode_rewards"]), r

@@ -9,26 +9,17 @@ from conftest import bounded, load_golden
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
-# ---- bounds of the multi-step traces that are looser than the contract's 1e-5, and why -------------------------------
-# Single ops and single update() calls are pinned at 1e-5 or tighter (bit-exact vs the oracle) elsewhere in this suite.
-# The traces below replay S CONSECUTIVE optimiser steps against weights that torch-CPU produced: its GEMMs sum each dot
-# product in another order than the MFMA kernels (documented K-order, include/gymrl.h), so a gradient element g differs by
-# about sqrt(K) * 2^-24 * sum|terms|.  Adam divides by sqrt(v): the parameter step is lr * m_hat / (sqrt(v_hat) + eps),
-# which has magnitude ~lr whatever |g| is, so a perturbation dg moves a parameter by ~lr * dg / |g| per step — the
-# RELATIVE error of that gradient element, which is ~1e-6 for a typical element and up to ~1e-2 for the few elements
-# whose terms cancel (|g| two to four orders below sum|terms|).  Differences then feed back through the next forward
-# (and, off-policy, through the bootstrap target), so the drift grows about linearly in S:
-#     |dp| <~ S * lr * rho,     rho = worst relative error of a gradient element (observed 1e-4 .. 1e-2).
-# The bounds are ~4x the drift observed on an MI355X (profiles/r04_trace_tolerances.json: observed value next to every
-# bound, written by conftest.bounded under GYMRL_TOL_LEDGER); the integer side of every trace (actions, dones, flags,
-# step counts, shuffles) is exact, and returns / advantages stay at 1e-5.
-TOL_PPO_METRICS = 2e-5      # S = 12 steps, lr 3e-4: S*lr = 3.6e-3; metrics are means over the minibatch of 1e-5-close terms
-TOL_PPO_SD = 5e-5           # S = 12, lr 3e-4  -> S*lr*rho = 3.6e-3 * 1.4e-2
-TOL_DQN_TRACE = 2e-4        # S = 163, lr 1e-3 -> S*lr = 0.163; rho ~ 1e-3 (grad clamp +-1 keeps |g| small near convergence)
-TOL_SAC_TRACE = 5e-4        # S = 3 x 72 (critic, actor, alpha), lr 3e-4; actions = tanh of the drifting actor's mean
-TOL_SAC_LOSS = 1e-3         # losses are differences of Q values of O(10): 1e-3 relative = the Q drift above
-TOL_RAINBOW_TRACE = 5e-4    # S = 100 noisy updates, lr 1e-3 -> S*lr = 0.1
-TOL_RAINBOW_LOSS = 1e-3     # IS-weighted TD^2 and the float64 tree's priorities |td|^0.6: d(p)/p = 0.6 * d(td)/td
+# ---- bounds of the multi-step traces ----------------------------------------------------------------------------------
+# Round 3 accepted 5e-5 .. 1e-3 here ("accumulated GEMM-order drift that nobody has bounded").  Round 4 measured it:
+# conftest.bounded() wrote every observed error of an MI355X run to profiles/r04_trace_tolerances.json — the largest is
+# 1.5e-6 (PPO-full's weights after 16 Adam steps), the DQN / SAC / Rainbow traces sit at 1e-7 .. 1e-6 after 100 - 216
+# sequential optimiser steps.  Why so small: the fixtures come from torch-CPU GEMMs whose dot products sum in another order
+# than the MFMA kernels' documented K-order, which perturbs a gradient element by ~sqrt(K) * 2^-24 relative; Adam turns a
+# relative gradient error rho into a parameter error of ~lr * rho per step, and the errors of S steps add at most linearly:
+#     |dp| <~ S * lr * rho = 216 * 3e-4 * 1e-6 ~ 1e-10 for typical elements, ~1e-6 for the few whose terms cancel.
+# So every trace bound is the contract's 1e-5 (floats to rtol 1e-5); integer fields are exact.
+TOL_TRACE = 1e-5
+TOL_PPO_METRICS = TOL_PPO_SD = TOL_DQN_TRACE = TOL_SAC_TRACE = TOL_SAC_LOSS = TOL_RAINBOW_TRACE = TOL_RAINBOW_LOSS = TOL_TRACE
 
 
 def _load(module, g, prefix):
@@ -75,8 +66,8 @@ def test_sac_update_matches_reference():
                             eps_next=torch.from_numpy(g["u_eps_next"]).to(dev),
                             eps_cur=torch.from_numpy(g["u_eps_cur"]).to(dev))
     ref = g["u_losses"]
-    assert abs(al - ref[0]) <= 2e-5 * max(1, abs(ref[0])) and abs(cl - ref[1]) <= 2e-5 * max(1, abs(ref[1]))
-    assert abs(aal - ref[2]) <= 2e-5 * max(1, abs(ref[2]))
+    for nm, got_, want_ in (("actor", al, ref[0]), ("critic", cl, ref[1]), ("alpha", aal, ref[2])):
+        bounded(f"sac_update {nm}_loss", abs(got_ - want_) / max(1, abs(want_)), 2e-5)
     assert abs(tr.log_alpha.item() - float(g["u_log_alpha1"])) <= 1e-9
     for name, net in (("actor", tr.actor), ("critic", tr.critic), ("critic_target", tr.critic_target)):
         assert _maxdiff(net, g, f"u1_{name}_") <= 5e-6, name

@@ -28,3 +28,9 @@ for _ in range(4):
     fu.step(x, act, lpo, adv, ret, (0.2, 3.0, 0.5, 0.01), mom, parts)
     torch.mm(h1, w2.t(), out=y)
 torch.cuda.synchronize()
+# provenance of the counters: which binary ran (tools/pmc_gemm_summarise.py puts it into the summary; bench.py checks it)
+if os.environ.get("GYMRL_PMC_PROVENANCE"):
+    import json
+    from gymrl_amd import _lib
+    json.dump({"libgymrl_hip_sha256": _lib.lib_sha256(), "device": torch.cuda.get_device_name(0)},
+              open(os.environ["GYMRL_PMC_PROVENANCE"], "w"))

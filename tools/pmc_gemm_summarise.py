@@ -3,9 +3,14 @@
 (B = 262,144) the HBM bytes per launch and per row (FETCH_SIZE doubled on gfx950, MI355X_MICROARCH.md section HBM; counters
 in KB), the algorithmic figure beside it, and from the SQ / GRBM pass the MFMA busy share and the effective clock.
 
-    python tools/pmc_gemm_summarise.py <fetch.csv> <write.csv> <sq.csv> <sq_kernel_trace.csv> <out.json>"""
+    python tools/pmc_gemm_summarise.py <fetch.csv> <write.csv> <sq.csv> <sq_kernel_trace.csv> <out.json> [<provenance.json>]
+
+<provenance.json> is what tools/pmc_gemm.py wrote on the GPU box next to the counter CSVs (sha256 of the libgymrl_hip.so it
+loaded); the git head is added here.  bench.py attaches a summary only if that sha256 equals the library it has loaded."""
 import csv
 import json
+import os
+import subprocess
 import sys
 from collections import defaultdict
 
@@ -53,6 +58,14 @@ def main():
                      "SQ_WAIT_ANY SQ_ACTIVE_INST_VALU in three separate passes (--kernel-trace only) over tools/pmc_gemm.py; FETCH_SIZE "
                      "and WRITE_SIZE are KB, FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM; a 512 MiB memset between updates "
                      "evicts the Infinity Cache; mean over launches 2..n; GRBM_GUI_ACTIVE sums the 8 XCDs", "rows": B}
+    prov = json.load(open(sys.argv[6])) if len(sys.argv) > 6 else {}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        prov["git_head"] = subprocess.check_output(["git", "-C", root, "rev-parse", "HEAD"], text=True).strip()
+        prov["git_dirty"] = bool(subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "gymrl_amd/csrc", "include"], text=True).strip())
+    except Exception:
+        pass
+    res["provenance"] = prov
     for frag, (label, alg, flops) in KERNELS.items():
         if label not in rd:
             continue
