@@ -51,6 +51,7 @@ SYMBOLS = [
     "gymrl_mhc_read_fwd", "gymrl_mhc_read_bwd", "gymrl_mhc_combine_bwd",
     "gymrl_mhc_gates_bwd_workspace_bytes", "gymrl_mhc_gates_bwd", "gymrl_rmsnorm_bwd_workspace_bytes", "gymrl_rmsnorm_bwd",
     "gymrl_mhc_policy_forward", "gymrl_mhc_sub_forward", "gymrl_rollout_lunar_mhc",
+    "gymrl_sac_update_workspace_bytes", "gymrl_sac_args_bytes", "gymrl_sac_act_step", "gymrl_sac_update",
 ]
 
 
@@ -129,6 +130,48 @@ class RolloutLunarArgs(C.Structure):
                 ("refill", C.c_int)]
 
 
+class SacActorParams(C.Structure):        # gymrl_sac_actor_params: fc1, fc2, mean, log_std
+    _fields_ = [("w", C.c_void_p * 4), ("b", C.c_void_p * 4)]
+
+
+class SacCriticParams(C.Structure):       # gymrl_sac_critic_params: fc1..fc6
+    _fields_ = [("w", C.c_void_p * 6), ("b", C.c_void_p * 6)]
+
+
+class SacActArgs(C.Structure):            # gymrl_sac_act_args (include/gymrl.h), field for field
+    _fields_ = [("N", C.c_int), ("D", C.c_int), ("A", C.c_int), ("H", C.c_int), ("env_kind", C.c_int),
+                ("env_state", C.c_void_p), ("env_seed", C.c_uint64), ("env_id0", C.c_int64),
+                ("obs", C.c_void_p), ("obs_out", C.c_void_p), ("eps", C.c_void_p),
+                ("noise_seed", C.c_uint64), ("noise_counter", C.c_uint64), ("noise_counter_dev", C.c_void_p),
+                ("bound", C.c_float), ("log_std_min", C.c_float), ("log_std_max", C.c_float),
+                ("actor", SacActorParams),
+                ("r_state", C.c_void_p), ("r_action", C.c_void_p), ("r_reward", C.c_void_p), ("r_next", C.c_void_p),
+                ("r_flag", C.c_void_p), ("cap", C.c_int64), ("cursor", C.c_int64), ("cursor_dev", C.c_void_p),
+                ("action_out", C.c_void_p), ("rew_out", C.c_void_p), ("done_out", C.c_void_p), ("ep_ret_out", C.c_void_p),
+                ("ep_stats", C.c_void_p)]
+
+
+class SacUpdateArgs(C.Structure):         # gymrl_sac_update_args (include/gymrl.h), field for field
+    _fields_ = [("B", C.c_int), ("D", C.c_int), ("A", C.c_int), ("H", C.c_int),
+                ("gamma", C.c_float), ("bound", C.c_float), ("log_std_min", C.c_float), ("log_std_max", C.c_float),
+                ("target_entropy", C.c_float), ("tau", C.c_double),
+                ("r_state", C.c_void_p), ("r_action", C.c_void_p), ("r_reward", C.c_void_p), ("r_next", C.c_void_p),
+                ("r_flag", C.c_void_p),
+                ("idx", C.c_void_p), ("idx_seed", C.c_uint64), ("idx_counter", C.c_uint64), ("idx_size", C.c_int64),
+                ("idx_dev", C.c_void_p),
+                ("eps_next", C.c_void_p), ("eps_cur", C.c_void_p),
+                ("noise_seed", C.c_uint64), ("noise_counter", C.c_uint64), ("noise_counter_dev", C.c_void_p),
+                ("actor", SacActorParams), ("critic", SacCriticParams), ("target", SacCriticParams),
+                ("actor_p", C.c_void_p), ("actor_m", C.c_void_p), ("actor_v", C.c_void_p),
+                ("critic_p", C.c_void_p), ("critic_m", C.c_void_p), ("critic_v", C.c_void_p),
+                ("adam_critic", C.c_float * 4), ("adam_actor", C.c_float * 4),
+                ("adam_critic_dev", C.c_void_p), ("adam_actor_dev", C.c_void_p),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps_adam", C.c_double),
+                ("log_alpha", C.c_void_p), ("alpha_m", C.c_void_p), ("alpha_v", C.c_void_p), ("lr_alpha", C.c_double),
+                ("alpha_bias", C.c_double * 2), ("alpha_bias_dev", C.c_void_p),
+                ("sums", C.c_void_p), ("alpha_loss", C.c_void_p), ("workspace", C.c_void_p)]
+
+
 class PPOFullCfg(C.Structure):
     _fields_ = [("clip_eps_min", C.c_float), ("clip_eps_max", C.c_float), ("dual_clip", C.c_float),
                 ("erc_beta_low", C.c_float), ("erc_beta_high", C.c_float), ("entropy_coef", C.c_float)]
@@ -159,6 +202,12 @@ def lib():
         L.gymrl_lin_workspace_bytes.restype = C.c_size_t
         L.gymrl_mhc_gates_bwd_workspace_bytes.restype = C.c_size_t
         L.gymrl_rmsnorm_bwd_workspace_bytes.restype = C.c_size_t
+        L.gymrl_sac_update_workspace_bytes.restype = C.c_size_t
+        L.gymrl_sac_args_bytes.restype = C.c_size_t
+        if L.gymrl_sac_args_bytes(0) != C.sizeof(SacActArgs) or L.gymrl_sac_args_bytes(1) != C.sizeof(SacUpdateArgs):
+            raise RuntimeError("gymrl_amd/_lib.py: SacActArgs / SacUpdateArgs do not mirror include/gymrl.h "
+                               f"({C.sizeof(SacActArgs)} / {C.sizeof(SacUpdateArgs)} bytes here, "
+                               f"{L.gymrl_sac_args_bytes(0)} / {L.gymrl_sac_args_bytes(1)} in the library)")
         for name in SYMBOLS:
             if name.endswith(("_bytes", "_floats")):
                 continue

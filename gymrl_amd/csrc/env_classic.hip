@@ -10,36 +10,14 @@
 //
 // One lane = one env; SoA state [field][N]; per-lane work is ~40 flop, so the
 // kernels are trivially HBM/launch bound (58 / 38 algorithmic bytes per env-step).
-#include "env_common.hpp"
+#include "env_classic_device.hpp"
 
 using namespace gymrl;
 
 namespace {
 
 // ------------------------------------------------------------- CartPole ----
-struct CartPoleState {
-  double *x, *xd, *th, *thd;
-  EpisodeFields ep;
-  __host__ __device__ CartPoleState(void* buf, int n) {
-    Carver c(buf, n);
-    x = c.take<double>(); xd = c.take<double>(); th = c.take<double>(); thd = c.take<double>();
-    ep.ep_ret = c.take<double>(); ep.ep_len = c.take<int32_t>(); ep.episode = c.take<uint32_t>();
-    bytes = c.off;
-  }
-  size_t bytes;
-};
-
-__device__ __forceinline__ void cartpole_draw(uint64_t seed, uint64_t env, uint32_t episode,
-                                              double (&s)[4]) {
-  // reset: U(-0.05, 0.05)^4 in float64 (gymnasium CartPoleEnv.reset)
-  const u32x4 a = philox4x32(seed, (uint32_t)env, (uint32_t)(env >> 32), episode, RNG_ENV_RESET | 0u);
-  const u32x4 b = philox4x32(seed, (uint32_t)env, (uint32_t)(env >> 32), episode, RNG_ENV_RESET | 1u);
-  s[0] = -0.05 + 0.1 * u01d(a.x, a.y);
-  s[1] = -0.05 + 0.1 * u01d(a.z, a.w);
-  s[2] = -0.05 + 0.1 * u01d(b.x, b.y);
-  s[3] = -0.05 + 0.1 * u01d(b.z, b.w);
-}
-
+// (state layout, reset draws and the per-env step: env_classic_device.hpp)
 __global__ __launch_bounds__(kEnvBlock) void cartpole_reset_kernel(void* buf, int n, uint64_t seed,
                                                                    int64_t env_id0,
                                                                    float* __restrict__ obs_out) {
@@ -62,74 +40,24 @@ __global__ __launch_bounds__(kEnvBlock) void cartpole_step_kernel(
   CartPoleState st(buf, n);
   const int i = blockIdx.x * kEnvBlock + threadIdx.x;
   const bool valid = i < n;
-  bool done = false;
-  double ret = 0.0; int len = 0;
+  ClassicStep<4> r;
+  r.done = false; r.ret = 0.0; r.len = 0;
   if (valid) {
-    double x = st.x[i], xd = st.xd[i], th = st.th[i], thd = st.thd[i];
-    const double force = action[i] == 1 ? 10.0 : -10.0;
-    double s, c;
-    det_sincos(th, &s, &c);                          // not ocml: reproducible on the host bit for bit
-    const double temp = (force + 0.05 * (thd * thd) * s) / 1.1;
-    const double thacc = (9.8 * s - c * temp) / (0.5 * (4.0 / 3.0 - 0.1 * (c * c) / 1.1));
-    const double xacc = temp - 0.05 * thacc * c / 1.1;
-    x = x + 0.02 * xd; xd = xd + 0.02 * xacc;
-    th = th + 0.02 * thd; thd = thd + 0.02 * thacc;
-    const double th_lim = 12.0 * 2.0 * 3.14159265358979323846 / 360.0;
-    const bool terminated = x < -2.4 || x > 2.4 || th < -th_lim || th > th_lim;
-    len = st.ep.ep_len[i] + 1;
-    const bool truncated = len >= 500;
-    done = terminated || truncated;
-    ret = st.ep.ep_ret[i] + 1.0;
-    rew_out[i] = 1.0f;
-    terminated_out[i] = terminated; truncated_out[i] = truncated;
-    if (done_out) done_out[i] = done;
-    const float4 o = make_float4((float)x, (float)xd, (float)th, (float)thd);
-    if (term_obs_out) reinterpret_cast<float4*>(term_obs_out)[i] = o;
-    if (done) {
-      if (ep_ret_out) ep_ret_out[i] = (float)ret;
-      if (ep_len_out) ep_len_out[i] = len;
-      const uint32_t e = st.ep.episode[i] + 1u;
-      double r[4];
-      cartpole_draw(seed, (uint64_t)(env_id0 + i), e, r);
-      st.x[i] = r[0]; st.xd[i] = r[1]; st.th[i] = r[2]; st.thd[i] = r[3];
-      st.ep.ep_ret[i] = 0.0; st.ep.ep_len[i] = 0; st.ep.episode[i] = e;
-      reinterpret_cast<float4*>(obs_out)[i] = make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
-    } else {
-      st.x[i] = x; st.xd[i] = xd; st.th[i] = th; st.thd[i] = thd;
-      st.ep.ep_ret[i] = ret; st.ep.ep_len[i] = len;
-      reinterpret_cast<float4*>(obs_out)[i] = o;
+    cartpole_step_one(st, i, seed, env_id0, action[i], r);
+    rew_out[i] = r.reward;
+    terminated_out[i] = r.terminated; truncated_out[i] = r.truncated;
+    if (done_out) done_out[i] = r.done;
+    if (term_obs_out) reinterpret_cast<float4*>(term_obs_out)[i] = make_float4(r.o_term[0], r.o_term[1], r.o_term[2], r.o_term[3]);
+    if (r.done) {
+      if (ep_ret_out) ep_ret_out[i] = (float)r.ret;
+      if (ep_len_out) ep_len_out[i] = r.len;
     }
+    reinterpret_cast<float4*>(obs_out)[i] = make_float4(r.o_next[0], r.o_next[1], r.o_next[2], r.o_next[3]);
   }
-  accumulate_ep_stats(ep_stats, done, ret, len);
+  accumulate_ep_stats(ep_stats, r.done, r.ret, r.len);
 }
 
 // ------------------------------------------------------------- Pendulum ----
-struct PendulumState {
-  double *th, *thd;
-  EpisodeFields ep;
-  size_t bytes;
-  __host__ __device__ PendulumState(void* buf, int n) {
-    Carver c(buf, n);
-    th = c.take<double>(); thd = c.take<double>();
-    ep.ep_ret = c.take<double>(); ep.ep_len = c.take<int32_t>(); ep.episode = c.take<uint32_t>();
-    bytes = c.off;
-  }
-};
-
-__device__ __forceinline__ void pendulum_draw(uint64_t seed, uint64_t env, uint32_t episode,
-                                              double& th, double& thd) {
-  const u32x4 a = philox4x32(seed, (uint32_t)env, (uint32_t)(env >> 32), episode, RNG_ENV_RESET | 0u);
-  const double pi = 3.14159265358979323846;
-  th = -pi + (2.0 * pi) * u01d(a.x, a.y);
-  thd = -1.0 + 2.0 * u01d(a.z, a.w);
-}
-
-__device__ __forceinline__ void pendulum_obs(double th, double thd, float (&o)[3]) {
-  double s, c;
-  det_sincos(th, &s, &c);
-  o[0] = (float)c; o[1] = (float)s; o[2] = (float)thd;
-}
-
 __global__ __launch_bounds__(kEnvBlock) void pendulum_reset_kernel(void* buf, int n, uint64_t seed,
                                                                    int64_t env_id0,
                                                                    float* __restrict__ obs_out) {
@@ -158,52 +86,24 @@ __global__ __launch_bounds__(kEnvBlock) void pendulum_step_kernel(
   PendulumState st(buf, n);
   const int i = blockIdx.x * kEnvBlock + threadIdx.x;
   const bool valid = i < n;
-  bool done = false;
-  double ret = 0.0; int len = 0;
-  float o_next[3] = {0.f, 0.f, 0.f}, o_term[3] = {0.f, 0.f, 0.f};
+  ClassicStep<3> r;
+  r.done = false; r.ret = 0.0; r.len = 0;
+  r.o_next[0] = r.o_next[1] = r.o_next[2] = 0.f; r.o_term[0] = r.o_term[1] = r.o_term[2] = 0.f;
   if (valid) {
-    const double pi = 3.14159265358979323846;
-    double th = st.th[i], thd = st.thd[i];
-    double u = (double)action[i];
-    u = u < -2.0 ? -2.0 : (u > 2.0 ? 2.0 : u);
-    // angle_normalize(x) = ((x + pi) mod 2pi) - pi with python's floor-mod
-    double a = th + pi;
-    a = a - floor(a / (2.0 * pi)) * (2.0 * pi);
-    const double an = a - pi;
-    const double cost = an * an + 0.1 * (thd * thd) + 0.001 * (u * u);
-    double sin_th, cos_th;
-    det_sincos(th, &sin_th, &cos_th);
-    double nthd = thd + (15.0 * sin_th + 3.0 * u) * 0.05;    // 3g/(2l) = 15, 3/(ml^2) = 3
-    nthd = nthd < -8.0 ? -8.0 : (nthd > 8.0 ? 8.0 : nthd);
-    const double nth = th + nthd * 0.05;
-    len = st.ep.ep_len[i] + 1;
-    const bool truncated = len >= 200;
-    done = truncated;
-    ret = st.ep.ep_ret[i] + (-cost);
-    rew_out[i] = (float)(-cost);
-    terminated_out[i] = 0; truncated_out[i] = truncated;
-    if (done_out) done_out[i] = done;
-    pendulum_obs(nth, nthd, o_term);
-    if (done) {
-      if (ep_ret_out) ep_ret_out[i] = (float)ret;
-      if (ep_len_out) ep_len_out[i] = len;
-      const uint32_t e = st.ep.episode[i] + 1u;
-      double rth, rthd;
-      pendulum_draw(seed, (uint64_t)(env_id0 + i), e, rth, rthd);
-      st.th[i] = rth; st.thd[i] = rthd;
-      st.ep.ep_ret[i] = 0.0; st.ep.ep_len[i] = 0; st.ep.episode[i] = e;
-      pendulum_obs(rth, rthd, o_next);
-    } else {
-      st.th[i] = nth; st.thd[i] = nthd;
-      st.ep.ep_ret[i] = ret; st.ep.ep_len[i] = len;
-      o_next[0] = o_term[0]; o_next[1] = o_term[1]; o_next[2] = o_term[2];
+    pendulum_step_one(st, i, seed, env_id0, action[i], r);
+    rew_out[i] = r.reward;
+    terminated_out[i] = 0; truncated_out[i] = r.truncated;
+    if (done_out) done_out[i] = r.done;
+    if (r.done) {
+      if (ep_ret_out) ep_ret_out[i] = (float)r.ret;
+      if (ep_len_out) ep_len_out[i] = r.len;
     }
   }
   const int nv = min(kEnvBlock, n - blockIdx.x * kEnvBlock);
   const size_t base = (size_t)blockIdx.x * kEnvBlock * 3;
-  store_obs_tile<3>(obs_out + base, o_next, tile, threadIdx.x, nv);
-  if (term_obs_out) store_obs_tile<3>(term_obs_out + base, o_term, tile, threadIdx.x, nv);
-  accumulate_ep_stats(ep_stats, done, ret, len);
+  store_obs_tile<3>(obs_out + base, r.o_next, tile, threadIdx.x, nv);
+  if (term_obs_out) store_obs_tile<3>(term_obs_out + base, r.o_term, tile, threadIdx.x, nv);
+  accumulate_ep_stats(ep_stats, r.done, r.ret, r.len);
 }
 
 // Episodes a trainer abandons at its own step cap (dqn_cartpole.py:178 `for step in range(cfg.max_steps)` below the

@@ -26,8 +26,7 @@
 //   lin_bwd_input:  the same with n in place of k
 //   lin_bwd_weight: for b0 = lo, lo + 16, ...: for e = 0..3: rows b = b0 + 4 e + q, q = 0..3; B > 512 rows are cut into
 //                   slices whose partial tiles are added in slice order by a second launch (fixed order, no atomics)
-#include "train_device.hpp"
-#include "../../include/gymrl.h"
+#include "lin_device.hpp"
 
 namespace {
 
@@ -37,24 +36,9 @@ constexpr int kItems = GYMRL_LIN_MAX_ITEMS;
 constexpr int kWavesPerBlock = 4;
 constexpr int kChunk = 8;       // reduction steps (of 16) whose loads are in flight together
 
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ float act_fwd(float z, int act, float lo, float hi) {
-  if (act == GYMRL_ACT_RELU) return fmaxf(z, 0.0f);
-  if (act == GYMRL_ACT_TANH) return train_tanhf(z);
-  if (act == GYMRL_ACT_CLAMP) return fminf(fmaxf(z, lo), hi);
-  if (act == GYMRL_ACT_SILU) return z / (1.0f + expf(-z));          // forward only (its derivative needs z, not y)
-  return z;
-}
-// d act / d z as a function of the saved OUTPUT y
-__device__ __forceinline__ float act_bwd(float y, int act, float lo, float hi) {
-  if (act == GYMRL_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
-  if (act == GYMRL_ACT_TANH) return 1.0f - y * y;
-  if (act == GYMRL_ACT_CLAMP) return (y > lo && y < hi) ? 1.0f : 0.0f;
-  return 1.0f;
-}
+using lin::mfma16;
+using lin::act_fwd;
+using lin::act_bwd;
 
 struct LinFwd {
   const float* X[kItems]; const float* X2[kItems]; const float* W[kItems]; const float* b[kItems]; float* Y[kItems];

@@ -1,0 +1,195 @@
+// lin_device.hpp — the 16 x 16 MFMA tile bodies of the off-policy networks' layers as device functions.
+//
+// lin.hip runs every Linear(+activation) of the DQN / Rainbow / SAC / TD3 / DDPG networks as one launch per layer and
+// direction: a wavefront owns a 16 x 16 output tile and walks the whole reduction with v_mfma_f32_16x16x4_f32.  At the
+// reference's batch sizes (128 / 256 rows) such a launch is ~1 us of work behind ~4-7 us of dispatch, first-load latency
+// and drain, and a SAC update is ~50 of them.  The fused step kernels (offpolicy_step.hip) keep a 16-row slab of the
+// batch in ONE workgroup's LDS through a whole chain of layers — rows never interact in a forward or input-gradient
+// pass — so a layer costs its tile's MFMA chain and a workgroup barrier instead of a launch.  The tile bodies below are
+// what both use: the SAME sequence of MFMAs on the SAME operands in the SAME order (documented in lin.hip's header), so
+// the fused path is bit-identical to the layer-by-layer path and every parity test of the latter pins the former.
+//
+//   tile_fwd        acc = X[16 x K] . W[n-tile]^T          X from LDS (row stride ldx, optional second block X2)
+//   tile_bwd_input  acc = dZ[16 x N] . W[:, k-tile]        dZ from LDS
+//   tile_bwd_weight acc = dZ[B x n-tile]^T . X[B x k-tile] dZ, X from global (the weight gradient reduces over the batch)
+//
+// Lane (r = lane & 15, q = lane >> 4) of the result holds acc[g] = out[row 4q + g][col r] of the tile (rows of the slab /
+// of the n-tile for tile_bwd_weight).
+#pragma once
+#include "train_device.hpp"
+#include "../../include/gymrl.h"
+
+namespace gymrl {
+namespace lin {
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float act_fwd(float z, int act, float lo, float hi) {
+  if (act == GYMRL_ACT_RELU) return fmaxf(z, 0.0f);
+  if (act == GYMRL_ACT_TANH) return train_tanhf(z);
+  if (act == GYMRL_ACT_CLAMP) return fminf(fmaxf(z, lo), hi);
+  if (act == GYMRL_ACT_SILU) return z / (1.0f + expf(-z));          // forward only (its derivative needs z, not y)
+  return z;
+}
+// d act / d z as a function of the saved OUTPUT y
+__device__ __forceinline__ float act_bwd(float y, int act, float lo, float hi) {
+  if (act == GYMRL_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
+  if (act == GYMRL_ACT_TANH) return 1.0f - y * y;
+  if (act == GYMRL_ACT_CLAMP) return (y > lo && y < hi) ? 1.0f : 0.0f;
+  return 1.0f;
+}
+
+constexpr int kSlab = 16;                 // rows of a slab = rows of an MFMA tile
+
+// Row stride (floats) of a [16][K] slab in LDS: K rounded up to a multiple of 4, plus 4 — 16-byte rows for the f32x4
+// reads, and the 16 rows of a quarter-wave land in 16 different 16-byte bank groups when K is a multiple of 64.
+__host__ __device__ __forceinline__ int slab_ld(int K) { return ((K + 3) & ~3) + 4; }
+
+// acc = X . W[nb .. nb + 15]^T for the slab X = [Xs | X2s] ([16][K1] and [16][K - K1] in LDS; K1 == K: one block).
+// The order of lin_fwd_kernel: k0 = 0, 16, ...; e = 0..3; the MFMA adds k = k0 + 4q + e over q.  Rows beyond the slab's
+// valid rows must hold zeros (the callers zero-fill), columns n >= N and k >= K contribute exact zeros.
+__device__ __forceinline__ f32x4 tile_fwd(const float* Xs, int ldx, const float* X2s, int ldx2, int K, int K1,
+                                          const float* __restrict__ W, int N, int nb, int lane) {
+  const int r = lane & 15, q = lane >> 4;
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  const int n = nb + r;
+  const bool n_ok = n < N;
+  const float* wrow = W + (size_t)(n_ok ? n : 0) * K;
+  const float* xrow = Xs + r * ldx;
+  if (K1 == K && (K & 3) == 0) {
+    for (int k0 = 0; k0 < K; k0 += 16) {
+      const int k = k0 + 4 * q;
+      const bool k_ok = k < K;
+      const int ks = k_ok ? k : 0;
+      const f32x4 xa = *reinterpret_cast<const f32x4*>(xrow + ks);
+      const f32x4 wb = *reinterpret_cast<const f32x4*>(wrow + ks);
+      const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+      const f32x4 x = k_ok ? xa : zero;
+      const f32x4 w = (n_ok && k_ok) ? wb : zero;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = mfma16(x[e], w[e], acc);
+    }
+  } else {
+    const float* x2row = X2s ? X2s + r * ldx2 : nullptr;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+      const int k = k0 + 4 * q;
+      float xa[4], wb[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kk = k + e;
+        float v = 0.0f;
+        if (kk < K) v = kk < K1 ? xrow[kk] : x2row[kk - K1];
+        xa[e] = v;
+        wb[e] = (n_ok && kk < K) ? W[(size_t)n * K + kk] : 0.0f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = mfma16(xa[e], wb[e], acc);
+    }
+  }
+  return acc;
+}
+
+// acc += dZ . W[:, kb .. kb + 15] for the slab dZ [16][N] in LDS (already multiplied by the activation's derivative).
+// The order of lin_bwd_input_kernel: n0 = 0, 16, ...; e = 0..3; the MFMA adds n = n0 + 4q + e over q.  Calling it again
+// with another layer's dZ / W continues the same accumulator (the summed gradient of an input two layers share).
+__device__ __forceinline__ f32x4 tile_bwd_input(f32x4 acc, const float* dZs, int ldz, int N, const float* __restrict__ W, int K,
+                                                int kb, int lane) {
+  const int r = lane & 15, q = lane >> 4;
+  const int kc = kb + r;
+  const bool k_ok = kc < K;
+  const int kcol = k_ok ? kc : 0;
+  const float* zrow = dZs + r * ldz;
+  if ((N & 3) == 0) {
+    for (int n0 = 0; n0 < N; n0 += 16) {
+      const int n = n0 + 4 * q;
+      const bool ok = n < N;
+      const int ns = ok ? n : 0;
+      const f32x4 za = *reinterpret_cast<const f32x4*>(zrow + ns);
+      const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+      const f32x4 dz = ok ? za : zero;
+      float wb[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wb[e] = W[(size_t)(ns + e) * K + kcol];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = mfma16(dz[e], k_ok ? wb[e] : 0.0f, acc);      // (as lin_bwd_input_kernel: the weight of a padded n is whatever row 0 holds, times an exact zero)
+    }
+  } else {
+    for (int n0 = 0; n0 < N; n0 += 16) {
+      const int n = n0 + 4 * q;
+      float dz[4], wb[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dz[e] = n + e < N ? zrow[n + e] : 0.0f;
+        wb[e] = (n + e < N && k_ok) ? W[(size_t)(n + e) * K + kc] : 0.0f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = mfma16(dz[e], wb[e], acc);
+    }
+  }
+  return acc;
+}
+
+// One 16 x 16 tile of dW = dZ^T X over rows [0, B) (dZ [B][ldz] column tile nt, X = [X | X2] column tile kb, all in global
+// memory), and the tile's share of the bias gradient: the order of lin_bwd_weight_kernel with one slice — rows
+// b = b0 + 4e + q, b0 = 0, 16, ...; e = 0..3; per-lane serial column sums folded (q0 + q1) + (q2 + q3).
+// acc[g] = dW[nt*16 + 4q + g][kb + r]; colsum (every lane of a column r) = db[nt*16 + r].
+constexpr int kWChunk = 8;      // 16-row steps whose loads are in flight together
+__device__ __forceinline__ f32x4 tile_bwd_weight(const float* __restrict__ dZ, int ldz, int N, int nt, const float* __restrict__ X,
+                                                 int ldx, const float* __restrict__ X2, int ldx2, int K, int K1, int kb, int B,
+                                                 int lane, float& colsum_out) {
+  const int r = lane & 15, q = lane >> 4;
+  const int n = nt * 16 + r;
+  const bool n_ok = n < N;
+  const int ns = n_ok ? n : 0;
+  const int kc = kb + r;
+  const bool k_ok = kc < K;
+  const int ks = k_ok ? kc : 0;
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  float colsum = 0.0f;
+  for (int bc0 = 0; bc0 < B; bc0 += 16 * kWChunk) {
+    float dy[kWChunk][4], xb[kWChunk][4];
+#pragma unroll
+    for (int c = 0; c < kWChunk; ++c) {
+      if (bc0 + 16 * c >= B) break;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int b = bc0 + 16 * c + 4 * e + q;
+        const size_t bs = (size_t)(b < B ? b : 0);
+        dy[c][e] = dZ[bs * ldz + ns];
+        xb[c][e] = ks < K1 ? X[bs * ldx + ks] : X2[bs * ldx2 + (ks - K1)];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kWChunk; ++c) {
+      if (bc0 + 16 * c >= B) break;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = n_ok && bc0 + 16 * c + 4 * e + q < B;
+        const float dz = ok ? dy[c][e] : 0.0f;
+        colsum += dz;
+        acc = mfma16(dz, k_ok ? xb[c][e] : 0.0f, acc);
+      }
+    }
+  }
+  colsum += __shfl_xor(colsum, 16, 64);
+  colsum += __shfl_xor(colsum, 32, 64);
+  colsum_out = colsum;
+  return acc;
+}
+
+// torch.optim.Adam's step on ONE element (optim.hip adam_one with grad_scale = scale = 1 and no clamp: the off-policy
+// optimisers that clip by norm keep their own launch).  step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t).
+struct AdamScalars { float step_size, bc2_sqrt, omb1, beta2, omb2, eps; };
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamScalars& a) {
+  float gg = g * 1.0f;
+  gg = gg * 1.0f;
+  m = m + (gg - m) * a.omb1;
+  v = v * a.beta2 + a.omb2 * gg * gg;
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  p = p - a.step_size * (m / denom);
+}
+
+}  // namespace lin
+}  // namespace gymrl

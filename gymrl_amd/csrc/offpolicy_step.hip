@@ -1,0 +1,626 @@
+// offpolicy_step.hip — a whole SAC vector step (sac_pendulum.py:269-310) in five launches.
+//
+// Round 3's step was ~60 launches of 4-14 us each (profiles/r03_sac_kernel_stats.csv: 0.325 ms per vector step, the acting
+// forward at 0.03 of the f32-MFMA peak): every Linear of a 128-row batch is ~1 us of MFMA work behind a dispatch, a first
+// load from L2 and a drain.  Nothing in a forward or input-gradient pass mixes batch rows, so here ONE workgroup of 16
+// waves carries a 16-row slab of the batch through a whole chain of layers — activations in LDS, weights read from L2
+// in nn.Linear's own layout, a workgroup barrier between layers — and only what reduces over the batch (weight
+// gradients, loss sums) sits behind a kernel boundary:
+//
+//   sac_act_kernel   N/16 workgroups: Actor forward, reparameterised draw, Pendulum step, replay row         (acting)
+//   sac_p1_kernel    B/16 workgroups: draw + gather, target chain, Q(s, a), loss gradient, critic dX chain    (rows)
+//   sac_dw_kernel    one wave per 16 x 16 weight tile: dW tile, Adam on it, soft target update; loss sums    (tiles)
+//   sac_p3_kernel    B/16 workgroups: actor forward + draw, Q(s, a) of the new critic, chain back to the actor (rows)
+//   sac_dw_kernel    actor tiles + Adam; loss sums; the float64 temperature step                               (tiles)
+//
+// Every tile is computed by the device functions of lin_device.hpp — the MFMA sequence of gymrl_lin_fwd / _bwd_input /
+// _bwd_weight — and every scalar expression is the one of the stand-alone kernels it replaces (offpolicy.hip sac_*,
+// optim.hip adam_one / soft update, replay.hip, env_classic_device.hpp), so parameters, Adam moments, target network,
+// temperature and replay ring after a step equal the layer-by-layer path's bit for bit (tests/test_fused_step_gpu.py).
+#include "env_classic_device.hpp"
+#include "lin_device.hpp"
+
+namespace {
+
+using namespace gymrl;
+using lin::act_bwd;
+using lin::act_fwd;
+
+constexpr int kWaves = 16, kThreads = 64 * kWaves;
+constexpr int kMaxD = 8, kMaxA = 4;
+constexpr float kLogSqrt2Pi = 0.91893853320467274178f;   // math.log(math.sqrt(2*math.pi))
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- hand-off between the row phases and the tile phases (caller-owned workspace) -------------------------------------
+struct SacWs {
+  float *s, *a;                       // [B][D], [B][A]: the gathered batch
+  float *H1[2], *Z1[2], *H2[2], *Z2[2], *dq[2];      // critic net i: activations and dL/dz per layer
+  float *aH1, *aZ1, *aH2, *aZ2, *dmean, *dls;        // actor
+  double* terms;                      // [B][3]: per-row critic term, actor term, temperature term
+  __host__ __device__ static size_t carve(SacWs* w, void* base, int B, int D, int A, int H) {
+    size_t off = 0;
+    auto take = [&](size_t n) { float* p = base ? reinterpret_cast<float*>(static_cast<char*>(base) + off) : nullptr; off += ((n * 4 + 255) & ~(size_t)255); return p; };
+    float* s = take((size_t)B * D); float* a = take((size_t)B * A);
+    float* h[16];
+    for (int i = 0; i < 12; ++i) h[i] = take((size_t)B * H);
+    float* dq0 = take(B); float* dq1 = take(B); float* dm = take((size_t)B * A); float* dl = take((size_t)B * A);
+    double* terms = reinterpret_cast<double*>(take((size_t)B * 6));
+    if (w) {
+      w->s = s; w->a = a;
+      w->H1[0] = h[0]; w->H1[1] = h[1]; w->Z1[0] = h[2]; w->Z1[1] = h[3]; w->H2[0] = h[4]; w->H2[1] = h[5]; w->Z2[0] = h[6]; w->Z2[1] = h[7];
+      w->aH1 = h[8]; w->aZ1 = h[9]; w->aH2 = h[10]; w->aZ2 = h[11];
+      w->dq[0] = dq0; w->dq[1] = dq1; w->dmean = dm; w->dls = dl; w->terms = terms;
+    }
+    return off;
+  }
+};
+
+// ---- a layer over the slab: all 16 waves, tile t -> wave t % 16 --------------------------------------------------------
+struct FwdItem { int X, X2, Ys; const float* W; const float* b; float* Yg; int act; };      // X, X2, Ys: LDS float offsets (X2 < 0: none)
+
+__device__ __forceinline__ void fwd_stage(float* lds, const FwdItem& i0, const FwdItem& i1, int ni, int ldx, int ldx2, int K, int K1,
+                                          int N, float lo, float hi, int ldy, int ldyg, int row0, int nrows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+  const int ntiles = (N + 15) >> 4;
+  for (int t = wave; t < ni * ntiles; t += kWaves) {
+    const bool second = t >= ntiles;
+    const int nb = (second ? t - ntiles : t) * 16;
+    const int X = second ? i1.X : i0.X, X2 = second ? i1.X2 : i0.X2, Ys = second ? i1.Ys : i0.Ys;
+    const float* W = second ? i1.W : i0.W;
+    const float* bias = second ? i1.b : i0.b;
+    float* Yg = second ? i1.Yg : i0.Yg;
+    const int act = second ? i1.act : i0.act;
+    const f32x4 acc = lin::tile_fwd(lds + X, ldx, X2 >= 0 ? lds + X2 : nullptr, ldx2, K, K1, W, N, nb, lane);
+    const int n = nb + r;
+    if (n < N) {
+      const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = 4 * q + g;
+        const float y = act_fwd(acc[g] + bv, act, lo, hi);
+        lds[Ys + row * ldy + n] = y;
+        if (Yg && row < nrows) Yg[(size_t)(row0 + row) * ldyg + n] = y;
+      }
+    }
+  }
+}
+
+// dX = sum over the items of dZ_i . W_i (sum != 0: ONE output, the items' reductions run on in order — the gradient of an
+// input two layers share) or one output per item; then dL/dz of the layer below = dX * act'(its saved output Hs).
+struct BwdItem { int dZ; const float* W; int Hs, Out; float* Outg; };     // dZ, Hs, Out: LDS offsets (Hs < 0: no activation below; Out < 0: none)
+
+__device__ __forceinline__ void bwd_stage(float* lds, const BwdItem& i0, const BwdItem& i1, int ni, bool sum, int ldz, int N, int K,
+                                          int act_below, int ldh, int ldo, int ldog, int row0, int nrows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+  const int ktiles = (K + 15) >> 4;
+  const int total = (sum ? 1 : ni) * ktiles;
+  for (int t = wave; t < total; t += kWaves) {
+    const bool second = t >= ktiles;
+    const int kb = (second ? t - ktiles : t) * 16;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (sum) {
+      acc = lin::tile_bwd_input(acc, lds + i0.dZ, ldz, N, i0.W, K, kb, lane);
+      if (ni > 1) acc = lin::tile_bwd_input(acc, lds + i1.dZ, ldz, N, i1.W, K, kb, lane);
+    } else {
+      acc = lin::tile_bwd_input(acc, lds + (second ? i1.dZ : i0.dZ), ldz, N, second ? i1.W : i0.W, K, kb, lane);
+    }
+    const int Hs = second ? i1.Hs : i0.Hs, Out = second ? i1.Out : i0.Out;
+    float* Outg = second ? i1.Outg : i0.Outg;
+    const int kc = kb + r;
+    if (kc < K) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = 4 * q + g;
+        float v = acc[g];
+        if (Hs >= 0) v = v * act_bwd(lds[Hs + row * ldh + kc], act_below, 0.0f, 0.0f);
+        if (Out >= 0) lds[Out + row * ldo + kc] = v;
+        if (Outg && row < nrows) Outg[(size_t)(row0 + row) * ldog + kc] = v;
+      }
+    }
+  }
+}
+
+// N(0,1) draw of the fused path when the caller passes no explicit draws: NoisyNet's Box-Muller on its own stream ids
+__device__ __forceinline__ float fused_normal(uint64_t seed, uint64_t counter, uint32_t stream, uint32_t i) {
+  return box_muller(seed, counter, stream, i);
+}
+
+// Actor.sample's tail for one row (offpolicy.hip sac_sample_fwd_kernel, the same expressions)
+__device__ __forceinline__ void sample_row(const float* mean, const float* log_std, const float* eps, int A, float bound, float* action,
+                                           float& logp) {
+  float lp = 0.0f;
+  for (int j = 0; j < A; ++j) {
+    const float mu = mean[j], std = det_expf(log_std[j]);
+    const float x = mu + std * eps[j];
+    const float t = det_tanhf(x);
+    action[j] = t * bound;
+    const float var = std * std, log_scale = det_logf(std);
+    float l = -((x - mu) * (x - mu)) / (2.0f * var) - log_scale - kLogSqrt2Pi;
+    l -= det_logf(bound * (1.0f - t * t) + 1e-6f);
+    lp += l;
+  }
+  logp = lp;
+}
+
+struct Lds {                          // float offsets of the small per-row slabs, then the [16][ld] activation slabs
+  int S, S2, A, A2, Mean, Ls, Eps, Q0, Q1, Dq0, Dq1, Misc, big;
+  __device__ Lds() {
+    int o = 0;
+    S = o; o += 16 * kMaxD; S2 = o; o += 16 * kMaxD; A = o; o += 16 * kMaxA; A2 = o; o += 16 * kMaxA;
+    Mean = o; o += 16 * kMaxA; Ls = o; o += 16 * kMaxA; Eps = o; o += 16 * kMaxA;
+    Q0 = o; o += 16 * 4; Q1 = o; o += 16 * 4; Dq0 = o; o += 16 * 4; Dq1 = o; o += 16 * 4; Misc = o; o += 16 * 4;
+    big = o;
+  }
+};
+constexpr int kSmallFloats = 16 * (2 * kMaxD + 5 * kMaxA + 5 * 4);
+
+// ======================================================================================================== P1 =====
+__global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update_args a, const SacWs ws) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const Lds L;
+  const int D = a.D, A = a.A, H = a.H, ld = lin::slab_ld(H);
+  const int X0 = L.big, X1 = X0 + 16 * ld, H1a = X1 + 16 * ld, H1b = H1a + 16 * ld, H2a = H1b + 16 * ld, H2b = H2a + 16 * ld;
+  const int row0 = blockIdx.x * 16, nrows = min(16, a.B - row0);
+  const int t = threadIdx.x;
+  // ---- 0: index draw + ring gather (one thread per row; rows beyond the batch are zero) ----
+  if (t < 16) {
+    const int b = row0 + t;
+    const bool ok = t < nrows;
+    int64_t row = 0;
+    if (ok) {
+      if (a.idx) row = a.idx[b];
+      else {
+        uint64_t counter = a.idx_counter; uint32_t size = (uint32_t)a.idx_size;
+        if (a.idx_dev) { const uint64_t* d = static_cast<const uint64_t*>(a.idx_dev); counter = d[0]; size = (uint32_t)(int64_t)d[1]; }
+        int bits = 2;
+        while (((int64_t)1 << bits) < (int64_t)size) ++bits;
+        row = keyed_permute((uint32_t)b, size, bits / 2, bits - bits / 2, a.idx_seed ^ 0x5265706C61794944ull, counter);
+      }
+    }
+    for (int k = 0; k < kMaxD; ++k) {
+      const float s = (ok && k < D) ? a.r_state[row * D + k] : 0.0f, s2 = (ok && k < D) ? a.r_next[row * D + k] : 0.0f;
+      lds[L.S + t * kMaxD + k] = s; lds[L.S2 + t * kMaxD + k] = s2;
+      if (ok && k < D) ws.s[(size_t)b * D + k] = s;
+    }
+    uint64_t ncounter = a.noise_counter_dev ? a.noise_counter_dev[0] : a.noise_counter;
+    for (int j = 0; j < kMaxA; ++j) {
+      const float av = (ok && j < A) ? __uint_as_float(a.r_action[row * A + j]) : 0.0f;
+      lds[L.A + t * kMaxA + j] = av;
+      if (ok && j < A) ws.a[(size_t)b * A + j] = av;
+      float e = 0.0f;
+      if (ok && j < A) e = a.eps_next ? a.eps_next[(size_t)b * A + j] : fused_normal(a.noise_seed, ncounter, 3u, (uint32_t)(b * A + j));
+      lds[L.Eps + t * kMaxA + j] = e;
+    }
+    lds[L.Misc + t * 4 + 0] = ok ? a.r_reward[row] : 0.0f;
+    lds[L.Misc + t * 4 + 1] = ok ? (float)a.r_flag[row] : 0.0f;          // dones become float32 (dqn_cartpole.py:155)
+  }
+  __syncthreads();
+  const FwdItem none{0, -1, 0, nullptr, nullptr, nullptr, GYMRL_ACT_NONE};
+  // ---- 1-4: a', logp' = Actor.sample(s') (:233-234) ----
+  fwd_stage(lds, FwdItem{L.S2, -1, X0, a.actor.w[0], a.actor.b[0], nullptr, GYMRL_ACT_RELU}, none, 1, kMaxD, 0, D, D, H, 0.f, 0.f, ld, 0, row0, nrows);
+  __syncthreads();
+  fwd_stage(lds, FwdItem{X0, -1, X1, a.actor.w[1], a.actor.b[1], nullptr, GYMRL_ACT_RELU}, none, 1, ld, 0, H, H, H, 0.f, 0.f, ld, 0, row0, nrows);
+  __syncthreads();
+  fwd_stage(lds, FwdItem{X1, -1, L.Mean, a.actor.w[2], a.actor.b[2], nullptr, GYMRL_ACT_NONE},
+            FwdItem{X1, -1, L.Ls, a.actor.w[3], a.actor.b[3], nullptr, GYMRL_ACT_CLAMP}, 2, ld, 0, H, H, A, a.log_std_min, a.log_std_max, kMaxA, 0, row0, nrows);
+  __syncthreads();
+  if (t < 16) {
+    float lp;
+    sample_row(lds + L.Mean + t * kMaxA, lds + L.Ls + t * kMaxA, lds + L.Eps + t * kMaxA, A, a.bound, lds + L.A2 + t * kMaxA, lp);
+    lds[L.Misc + t * 4 + 2] = lp;
+  }
+  __syncthreads();
+  // ---- 5-8: target Q(s', a') of both networks, y (:235-237) ----
+  fwd_stage(lds, FwdItem{L.S2, L.A2, H1a, a.target.w[0], a.target.b[0], nullptr, GYMRL_ACT_RELU},
+            FwdItem{L.S2, L.A2, H1b, a.target.w[3], a.target.b[3], nullptr, GYMRL_ACT_RELU}, 2, kMaxD, kMaxA, D + A, D, H, 0.f, 0.f, ld, 0, row0, nrows);
+  __syncthreads();
+  fwd_stage(lds, FwdItem{H1a, -1, H2a, a.target.w[1], a.target.b[1], nullptr, GYMRL_ACT_RELU},
+            FwdItem{H1b, -1, H2b, a.target.w[4], a.target.b[4], nullptr, GYMRL_ACT_RELU}, 2, ld, 0, H, H, H, 0.f, 0.f, ld, 0, row0, nrows);
+  __syncthreads();
+  fwd_stage(lds, FwdItem{H2a, -1, L.Q0, a.target.w[2], a.target.b[2], nullptr, GYMRL_ACT_NONE},
+            FwdItem{H2b, -1, L.Q1, a.target.w[5], a.target.b[5], nullptr, GYMRL_ACT_NONE}, 2, ld, 0, H, H, 1, 0.f, 0.f, 4, 0, row0, nrows);
+  __syncthreads();
+  if (t < 16) {                         // offpolicy.hip sac_target_kernel
+    const float alpha = (float)exp(a.log_alpha[0]);
+    const float tq = fminf(lds[L.Q0 + t * 4], lds[L.Q1 + t * 4]) - alpha * lds[L.Misc + t * 4 + 2];
+    lds[L.Misc + t * 4 + 3] = lds[L.Misc + t * 4 + 0] + a.gamma * (1.0f - lds[L.Misc + t * 4 + 1]) * tq;
+  }
+  __syncthreads();
+  // ---- 9-12: Q(s, a) of both networks, critic loss gradient (:239-241) ----
+  fwd_stage(lds, FwdItem{L.S, L.A, H1a, a.critic.w[0], a.critic.b[0], ws.H1[0], GYMRL_ACT_RELU},
+            FwdItem{L.S, L.A, H1b, a.critic.w[3], a.critic.b[3], ws.H1[1], GYMRL_ACT_RELU}, 2, kMaxD, kMaxA, D + A, D, H, 0.f, 0.f, ld, H, row0, nrows);
+  __syncthreads();
+  fwd_stage(lds, FwdItem{H1a, -1, H2a, a.critic.w[1], a.critic.b[1], ws.H2[0], GYMRL_ACT_RELU},
+            FwdItem{H1b, -1, H2b, a.critic.w[4], a.critic.b[4], ws.H2[1], GYMRL_ACT_RELU}, 2, ld, 0, H, H, H, 0.f, 0.f, ld, H, row0, nrows);
+  __syncthreads();
+  fwd_stage(lds, FwdItem{H2a, -1, L.Q0, a.critic.w[2], a.critic.b[2], nullptr, GYMRL_ACT_NONE},
+            FwdItem{H2b, -1, L.Q1, a.critic.w[5], a.critic.b[5], nullptr, GYMRL_ACT_NONE}, 2, ld, 0, H, H, 1, 0.f, 0.f, 4, 0, row0, nrows);
+  __syncthreads();
+  if (t < 16) {                         // offpolicy.hip sac_critic_kernel
+    const float invB = 1.0f / (float)a.B;
+    const float y = lds[L.Misc + t * 4 + 3];
+    const float e1 = lds[L.Q0 + t * 4] - y, e2 = lds[L.Q1 + t * 4] - y;
+    const float d1 = 2.0f * e1 * invB, d2 = 2.0f * e2 * invB;
+    for (int k = 0; k < 4; ++k) { lds[L.Dq0 + t * 4 + k] = k == 0 ? d1 : 0.0f; lds[L.Dq1 + t * 4 + k] = k == 0 ? d2 : 0.0f; }
+    if (t < nrows) {
+      ws.dq[0][row0 + t] = d1; ws.dq[1][row0 + t] = d2;
+      ws.terms[(size_t)(row0 + t) * 3 + 0] = (double)(e1 * e1) + (double)(e2 * e2);
+    }
+  }
+  __syncthreads();
+  // ---- 13-14: input-gradient chain of both Q networks (what q.backward() computes before the weight gradients) ----
+  bwd_stage(lds, BwdItem{L.Dq0, a.critic.w[2], H2a, X0, ws.Z2[0]}, BwdItem{L.Dq1, a.critic.w[5], H2b, X1, ws.Z2[1]}, 2, false, 4, 1, H,
+            GYMRL_ACT_RELU, ld, ld, H, row0, nrows);
+  __syncthreads();
+  bwd_stage(lds, BwdItem{X0, a.critic.w[1], H1a, -1, ws.Z1[0]}, BwdItem{X1, a.critic.w[4], H1b, -1, ws.Z1[1]}, 2, false, ld, H, H,
+            GYMRL_ACT_RELU, ld, ld, H, row0, nrows);
+}
+
+// ======================================================================================================== P3 =====
+__global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update_args a, const SacWs ws) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const Lds L;
+  const int D = a.D, A = a.A, H = a.H, ld = lin::slab_ld(H);
+  const int X0 = L.big, X1 = X0 + 16 * ld, H1a = X1 + 16 * ld, H1b = H1a + 16 * ld, H2a = H1b + 16 * ld, H2b = H2a + 16 * ld;
+  const int AH1 = H2b + 16 * ld, AH2 = AH1 + 16 * ld;
+  const int row0 = blockIdx.x * 16, nrows = min(16, a.B - row0);
+  const int t = threadIdx.x;
+  if (t < 16) {
+    const int b = row0 + t;
+    const bool ok = t < nrows;
+    for (int k = 0; k < kMaxD; ++k) lds[L.S + t * kMaxD + k] = (ok && k < D) ? ws.s[(size_t)b * D + k] : 0.0f;
+    uint64_t ncounter = a.noise_counter_dev ? a.noise_counter_dev[0] : a.noise_counter;
+    for (int j = 0; j < kMaxA; ++j) {
+      float e = 0.0f;
+      if (ok && j < A) e = a.eps_cur ? a.eps_cur[(size_t)b * A + j] : fused_normal(a.noise_seed, ncounter, 4u, (uint32_t)(b * A + j));
+      lds[L.Eps + t * kMaxA + j] = e;
+    }
+  }
+  __syncthreads();
+  const FwdItem none{0, -1, 0, nullptr, nullptr, nullptr, GYMRL_ACT_NONE};
+  // ---- a, logp = Actor.sample(s) (:248) ----
+  fwd_stage(lds, FwdItem{L.S, -1, AH1, a.actor.w[0], a.actor.b[0], ws.aH1, GYMRL_ACT_RELU}, none, 1, kMaxD, 0, D, D, H, 0.f, 0.f, ld, H, row0, nrows);
+  __syncthreads();
+  fwd_stage(lds, FwdItem{AH1, -1, AH2, a.actor.w[1], a.actor.b[1], ws.aH2, GYMRL_ACT_RELU}, none, 1, ld, 0, H, H, H, 0.f, 0.f, ld, H, row0, nrows);
+  __syncthreads();
+  fwd_stage(lds, FwdItem{AH2, -1, L.Mean, a.actor.w[2], a.actor.b[2], nullptr, GYMRL_ACT_NONE},
+            FwdItem{AH2, -1, L.Ls, a.actor.w[3], a.actor.b[3], nullptr, GYMRL_ACT_CLAMP}, 2, ld, 0, H, H, A, a.log_std_min, a.log_std_max, kMaxA, 0, row0, nrows);
+  __syncthreads();
+  if (t < 16) {
+    float lp;
+    sample_row(lds + L.Mean + t * kMaxA, lds + L.Ls + t * kMaxA, lds + L.Eps + t * kMaxA, A, a.bound, lds + L.A + t * kMaxA, lp);
+    lds[L.Misc + t * 4 + 2] = lp;
+  }
+  __syncthreads();
+  // ---- Q(s, a) of the critic P2 has just updated (:249-250) ----
+  fwd_stage(lds, FwdItem{L.S, L.A, H1a, a.critic.w[0], a.critic.b[0], nullptr, GYMRL_ACT_RELU},
+            FwdItem{L.S, L.A, H1b, a.critic.w[3], a.critic.b[3], nullptr, GYMRL_ACT_RELU}, 2, kMaxD, kMaxA, D + A, D, H, 0.f, 0.f, ld, 0, row0, nrows);
+  __syncthreads();
+  fwd_stage(lds, FwdItem{H1a, -1, H2a, a.critic.w[1], a.critic.b[1], nullptr, GYMRL_ACT_RELU},
+            FwdItem{H1b, -1, H2b, a.critic.w[4], a.critic.b[4], nullptr, GYMRL_ACT_RELU}, 2, ld, 0, H, H, H, 0.f, 0.f, ld, 0, row0, nrows);
+  __syncthreads();
+  fwd_stage(lds, FwdItem{H2a, -1, L.Q0, a.critic.w[2], a.critic.b[2], nullptr, GYMRL_ACT_NONE},
+            FwdItem{H2b, -1, L.Q1, a.critic.w[5], a.critic.b[5], nullptr, GYMRL_ACT_NONE}, 2, ld, 0, H, H, 1, 0.f, 0.f, 4, 0, row0, nrows);
+  __syncthreads();
+  float dlogp = 0.0f;
+  if (t < 16) {                         // offpolicy.hip sac_actor_kernel
+    const float invB = 1.0f / (float)a.B;
+    const float alpha = (float)exp(a.log_alpha[0]);
+    const float qa = lds[L.Q0 + t * 4], qc = lds[L.Q1 + t * 4], lp = lds[L.Misc + t * 4 + 2];
+    const float w1 = qa < qc ? 1.0f : (qa == qc ? 0.5f : 0.0f);          // torch.min tie rule
+    dlogp = alpha * invB;
+    const float d1 = -w1 * invB, d2 = -(1.0f - w1) * invB;
+    for (int k = 0; k < 4; ++k) { lds[L.Dq0 + t * 4 + k] = k == 0 ? d1 : 0.0f; lds[L.Dq1 + t * 4 + k] = k == 0 ? d2 : 0.0f; }
+    if (t < nrows) {
+      ws.terms[(size_t)(row0 + t) * 3 + 1] = (double)(alpha * lp - fminf(qa, qc));
+      ws.terms[(size_t)(row0 + t) * 3 + 2] = (double)(lp + a.target_entropy);
+    }
+  }
+  __syncthreads();
+  // ---- back through both Q networks to the action (their parameters are frozen here: no weight gradients) ----
+  bwd_stage(lds, BwdItem{L.Dq0, a.critic.w[2], H2a, X0, nullptr}, BwdItem{L.Dq1, a.critic.w[5], H2b, X1, nullptr}, 2, false, 4, 1, H,
+            GYMRL_ACT_RELU, ld, ld, 0, row0, nrows);
+  __syncthreads();
+  bwd_stage(lds, BwdItem{X0, a.critic.w[1], H1a, H2a, nullptr}, BwdItem{X1, a.critic.w[4], H1b, H2b, nullptr}, 2, false, ld, H, H,
+            GYMRL_ACT_RELU, ld, ld, 0, row0, nrows);
+  __syncthreads();
+  // d action = the action columns of (dZ1_Q1 . W1_Q1 + dZ1_Q2 . W1_Q2): ONE accumulator over both networks (the layers share their input)
+  {
+    const int lane = t & 63, wave = t >> 6, r = lane & 15, q = lane >> 4;
+    if (wave == 0) {
+      f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+      acc = lin::tile_bwd_input(acc, lds + H2a, ld, H, a.critic.w[0], D + A, 0, lane);
+      acc = lin::tile_bwd_input(acc, lds + H2b, ld, H, a.critic.w[3], D + A, 0, lane);
+      if (r >= D && r < D + A) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) lds[L.A2 + (4 * q + g) * kMaxA + (r - D)] = acc[g];
+      }
+    }
+  }
+  __syncthreads();
+  if (t < 16) {                         // offpolicy.hip sac_sample_bwd_kernel, then the heads' dL/dz (log_std through its clamp)
+    for (int j = 0; j < kMaxA; ++j) {
+      float dm = 0.0f, dl = 0.0f;
+      if (j < A) {
+        const float mu = lds[L.Mean + t * kMaxA + j], ls = lds[L.Ls + t * kMaxA + j], e = lds[L.Eps + t * kMaxA + j];
+        const float std = det_expf(ls);
+        const float x = mu + std * e;
+        const float th = det_tanhf(x);
+        const float omt = 1.0f - th * th;
+        const float ga = lds[L.A2 + t * kMaxA + j], gl = dlogp;
+        const float dx = ga * a.bound * omt + gl * (2.0f * th * a.bound * omt / (a.bound * omt + 1e-6f));
+        dm = dx;
+        dl = (dx * (std * e) - gl) * act_bwd(ls, GYMRL_ACT_CLAMP, a.log_std_min, a.log_std_max);
+        if (t < nrows) { ws.dmean[(size_t)(row0 + t) * A + j] = dm; ws.dls[(size_t)(row0 + t) * A + j] = dl; }
+      }
+      lds[L.Dq0 + t * 4 + j] = dm; lds[L.Dq1 + t * 4 + j] = dl;
+    }
+  }
+  __syncthreads();
+  // ---- back through the actor: heads (one summed input gradient), fc2 ----
+  bwd_stage(lds, BwdItem{L.Dq0, a.actor.w[2], AH2, X0, ws.aZ2}, BwdItem{L.Dq1, a.actor.w[3], AH2, X0, ws.aZ2}, 2, true, 4, A, H,
+            GYMRL_ACT_RELU, ld, ld, H, row0, nrows);
+  __syncthreads();
+  const BwdItem nob{0, nullptr, -1, -1, nullptr};
+  bwd_stage(lds, BwdItem{X0, a.actor.w[1], AH1, -1, ws.aZ1}, nob, 1, false, ld, H, H, GYMRL_ACT_RELU, ld, ld, H, row0, nrows);
+}
+
+// ================================================================================================= P2 / P4 =====
+struct DwSeg {
+  const float* dZ; const float* X; const float* X2;
+  float* W; float* b; float* Wt; float* bt;       // parameters and (critic) their target twins
+  int ldz, ldx, ldx2, N, K, K1, wave0;            // wave0: first global wave of this segment
+};
+struct DwArgs {
+  DwSeg seg[6];
+  int nseg, total_waves, B;
+  float* p; float* m; float* v;                   // flat parameter buffer and its Adam moments
+  float adam[4]; const float* adam_dev;
+  float omb1, beta2, omb2, eps;
+  float tau, omt;
+  // loss sums + temperature (the launch's last workgroup)
+  const double* terms; int term0, nterms; double* sums;
+  int alpha_step;
+  double* log_alpha; double* alpha_m; double* alpha_v; double lr_alpha, abeta1, abeta2, aeps; double alpha_bias[2];
+  const double* alpha_bias_dev; double* alpha_loss;
+};
+
+__global__ __launch_bounds__(256) void sac_dw_kernel(const DwArgs a) {
+  __shared__ double sm[3][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+  if (blockIdx.x == gridDim.x - 1) {
+    // ---- the loss sums in the stand-alone kernels' order (offpolicy.hip block_partials with one block: thread t owns row t) ----
+    double v[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < a.B; b += 256)
+      for (int k = 0; k < a.nterms; ++k) v[k] += a.terms[(size_t)b * 3 + a.term0 + k];
+    for (int k = 0; k < a.nterms; ++k) {
+      const double s = wave_sum(v[k]);
+      if (lane == 0) sm[k][wave] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < a.nterms) {
+      double s = 0.0;
+      for (int w = 0; w < 4; ++w) s += sm[threadIdx.x][w];
+      a.sums[a.term0 + threadIdx.x] = 0.0 + s;
+    }
+    if (!a.alpha_step) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {               // offpolicy.hip sac_alpha_step_kernel
+      double bc1 = a.alpha_bias[0], bc2_sqrt = sqrt(a.alpha_bias[1]);
+      if (a.alpha_bias_dev) { bc1 = a.alpha_bias_dev[0]; bc2_sqrt = sqrt(a.alpha_bias_dev[1]); }
+      double s2 = 0.0;
+      for (int w = 0; w < 4; ++w) s2 += sm[1][w];
+      const double mean_term = (0.0 + s2) / (double)a.B;
+      if (a.alpha_loss) a.alpha_loss[0] = -(a.log_alpha[0] * mean_term);
+      const double g = -mean_term;
+      a.alpha_m[0] = a.alpha_m[0] + (g - a.alpha_m[0]) * (1.0 - a.abeta1);
+      a.alpha_v[0] = a.alpha_v[0] * a.abeta2 + (1.0 - a.abeta2) * g * g;
+      const double denom = sqrt(a.alpha_v[0]) / bc2_sqrt + a.aeps;
+      a.log_alpha[0] = a.log_alpha[0] - (a.lr_alpha / bc1) * (a.alpha_m[0] / denom);
+    }
+    return;
+  }
+  const int gw = blockIdx.x * 4 + wave;
+  if (gw >= a.total_waves) return;
+  int si = 0;
+#pragma unroll
+  for (int k = 1; k < 6; ++k) if (k < a.nseg && gw >= a.seg[k].wave0) si = k;
+  const DwSeg& s = a.seg[si];
+  const int local = gw - s.wave0, ktiles = (s.K + 15) >> 4;
+  const int nt = local / ktiles, cg = local - nt * ktiles, kb = cg * 16;
+  float colsum;
+  const f32x4 acc = lin::tile_bwd_weight(s.dZ, s.ldz, s.N, nt, s.X, s.ldx, s.X2, s.ldx2, s.K, s.K1, kb, a.B, lane, colsum);
+  lin::AdamScalars ad;
+  ad.step_size = a.adam_dev ? a.adam_dev[0] : a.adam[0];
+  ad.bc2_sqrt = a.adam_dev ? a.adam_dev[2] : a.adam[2];
+  ad.omb1 = a.omb1; ad.beta2 = a.beta2; ad.omb2 = a.omb2; ad.eps = a.eps;
+  const int kc = kb + r;
+  if (kc < s.K) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int no = nt * 16 + 4 * q + g;
+      if (no >= s.N) continue;
+      const size_t o = (size_t)no * s.K + kc;
+      const size_t po = (size_t)(s.W - a.p) + o;
+      float P = s.W[o], M = a.m[po], V = a.v[po];
+      lin::adam_elem(P, acc[g], M, V, ad);
+      s.W[o] = P; a.m[po] = M; a.v[po] = V;
+      if (s.Wt) s.Wt[o] = a.tau * P + a.omt * s.Wt[o];
+    }
+  }
+  const int n = nt * 16 + r;
+  if (cg == 0 && q == 0 && n < s.N && s.b) {
+    const size_t po = (size_t)(s.b - a.p) + n;
+    float P = s.b[n], M = a.m[po], V = a.v[po];
+    lin::adam_elem(P, colsum, M, V, ad);
+    s.b[n] = P; a.m[po] = M; a.v[po] = V;
+    if (s.bt) s.bt[n] = a.tau * P + a.omt * s.bt[n];
+  }
+}
+
+// ==================================================================================================== acting =====
+__global__ __launch_bounds__(kThreads) void sac_act_kernel(const gymrl_sac_act_args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const Lds L;
+  const int D = a.D, A = a.A, H = a.H, ld = lin::slab_ld(H);
+  const int X0 = L.big, X1 = X0 + 16 * ld;
+  const int row0 = blockIdx.x * 16, nrows = min(16, a.N - row0);
+  const int t = threadIdx.x;
+  if (t < 16) {
+    const int i = row0 + t;
+    const bool ok = t < nrows;
+    for (int k = 0; k < kMaxD; ++k) lds[L.S + t * kMaxD + k] = (ok && k < D) ? a.obs[(size_t)i * D + k] : 0.0f;
+    const uint64_t ncounter = a.noise_counter_dev ? a.noise_counter_dev[0] : a.noise_counter;
+    for (int j = 0; j < kMaxA; ++j) {
+      float e = 0.0f;
+      if (ok && j < A) e = a.eps ? a.eps[(size_t)i * A + j] : fused_normal(a.noise_seed, ncounter, 2u, (uint32_t)(i * A + j));
+      lds[L.Eps + t * kMaxA + j] = e;
+    }
+  }
+  __syncthreads();
+  const FwdItem none{0, -1, 0, nullptr, nullptr, nullptr, GYMRL_ACT_NONE};
+  fwd_stage(lds, FwdItem{L.S, -1, X0, a.actor.w[0], a.actor.b[0], nullptr, GYMRL_ACT_RELU}, none, 1, kMaxD, 0, D, D, H, 0.f, 0.f, ld, 0, row0, nrows);
+  __syncthreads();
+  fwd_stage(lds, FwdItem{X0, -1, X1, a.actor.w[1], a.actor.b[1], nullptr, GYMRL_ACT_RELU}, none, 1, ld, 0, H, H, H, 0.f, 0.f, ld, 0, row0, nrows);
+  __syncthreads();
+  fwd_stage(lds, FwdItem{X1, -1, L.Mean, a.actor.w[2], a.actor.b[2], nullptr, GYMRL_ACT_NONE},
+            FwdItem{X1, -1, L.Ls, a.actor.w[3], a.actor.b[3], nullptr, GYMRL_ACT_CLAMP}, 2, ld, 0, H, H, A, a.log_std_min, a.log_std_max, kMaxA, 0, row0, nrows);
+  __syncthreads();
+  // one lane per env: draw, Pendulum step with auto-reset, replay row (the first wave: 16 lanes busy)
+  if (t < 64) {
+    const bool ok = t < nrows;
+    ClassicStep<3> r;
+    r.done = false; r.ret = 0.0; r.len = 0;
+    if (ok) {
+      const int i = row0 + t;
+      float act[kMaxA], lp;
+      sample_row(lds + L.Mean + t * kMaxA, lds + L.Ls + t * kMaxA, lds + L.Eps + t * kMaxA, A, a.bound, act, lp);
+      const PendulumState st(a.env_state, a.N);
+      pendulum_step_one(st, i, a.env_seed, a.env_id0, act[0], r);
+      const int64_t cursor = a.cursor_dev ? a.cursor_dev[0] : a.cursor;
+      const int64_t row = (cursor + i) % a.cap;
+      for (int k = 0; k < D; ++k) {
+        a.r_state[row * D + k] = lds[L.S + t * kMaxD + k];
+        a.r_next[row * D + k] = r.o_term[k];              // the TERMINAL observation is what the buffer keeps (:283)
+        a.obs_out[(size_t)i * D + k] = r.o_next[k];
+      }
+      for (int j = 0; j < A; ++j) {
+        a.r_action[row * A + j] = __float_as_uint(act[j]);
+        if (a.action_out) a.action_out[(size_t)i * A + j] = act[j];
+      }
+      a.r_reward[row] = r.reward;
+      a.r_flag[row] = r.done;                             // done = terminated or truncated
+      if (a.rew_out) a.rew_out[i] = r.reward;
+      if (a.done_out) a.done_out[i] = r.done;
+      if (r.done && a.ep_ret_out) a.ep_ret_out[i] = (float)r.ret;
+    }
+    accumulate_ep_stats(a.ep_stats, r.done && ok, r.ret, r.len);
+  }
+}
+
+inline bool sac_shape_ok(int B, int D, int A, int H) {
+  return B > 0 && B <= 256 && D > 0 && D <= kMaxD && A > 0 && A <= kMaxA && H >= 4 && H <= 256 && (H & 3) == 0;
+}
+inline size_t lds_bytes(int H, int slabs) { return sizeof(float) * (size_t)(kSmallFloats + slabs * 16 * lin::slab_ld(H)); }
+
+}  // namespace
+
+extern "C" {
+
+size_t gymrl_sac_update_workspace_bytes(int B, int D, int A, int H) {
+  if (B <= 0 || D <= 0 || A <= 0 || H <= 0) return 0;
+  return SacWs::carve(nullptr, nullptr, B, D, A, H) + 256;
+}
+
+size_t gymrl_sac_args_bytes(int which) { return which == 0 ? sizeof(gymrl_sac_act_args) : which == 1 ? sizeof(gymrl_sac_update_args) : 0; }
+
+int gymrl_sac_act_step(const gymrl_sac_act_args* args, void* stream_) {
+  if (!args) return -22;
+  const gymrl_sac_act_args& a = *args;
+  if (a.N <= 0 || !sac_shape_ok(1, a.D, a.A, a.H) || a.env_kind != GYMRL_ENV_PENDULUM || a.D != 3 || a.A != 1) return -22;
+  if (!a.env_state || !a.obs || !a.obs_out || !a.r_state || !a.r_action || !a.r_reward || !a.r_next || !a.r_flag || a.cap < a.N) return -22;
+  for (int k = 0; k < 4; ++k) if (!a.actor.w[k] || !a.actor.b[k]) return -22;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)sac_act_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(256, 2)) != hipSuccess)
+      return -1000 - (int)hipGetLastError();
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(sac_act_kernel, dim3((a.N + 15) / 16), dim3(kThreads), lds_bytes(a.H, 2), (hipStream_t)stream_, a);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream_) {
+  if (!args) return -22;
+  const gymrl_sac_update_args& a = *args;
+  if (!sac_shape_ok(a.B, a.D, a.A, a.H)) return -22;
+  if (!a.r_state || !a.r_action || !a.r_reward || !a.r_next || !a.r_flag || !a.workspace || !a.sums || !a.log_alpha || !a.alpha_m || !a.alpha_v ||
+      !a.actor_p || !a.actor_m || !a.actor_v || !a.critic_p || !a.critic_m || !a.critic_v || (!a.idx && a.idx_size < a.B))
+    return -22;
+  for (int k = 0; k < 4; ++k) if (!a.actor.w[k] || !a.actor.b[k]) return -22;
+  for (int k = 0; k < 6; ++k) if (!a.critic.w[k] || !a.critic.b[k] || !a.target.w[k] || !a.target.b[k]) return -22;
+  hipStream_t stream = (hipStream_t)stream_;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)sac_p1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(256, 6)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)sac_p3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(256, 8)) != hipSuccess)
+      return -1000 - (int)hipGetLastError();
+    attr_set = true;
+  }
+  SacWs ws;
+  void* base = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(a.workspace) + 255) & ~(uintptr_t)255);
+  SacWs::carve(&ws, base, a.B, a.D, a.A, a.H);
+  const int B = a.B, D = a.D, A = a.A, H = a.H, slabs = (B + 15) / 16;
+  auto tiles = [](int N, int K) { return ((N + 15) / 16) * ((K + 15) / 16); };
+
+  hipLaunchKernelGGL(sac_p1_kernel, dim3(slabs), dim3(kThreads), lds_bytes(H, 6), stream, a, ws);
+
+  DwArgs c{};
+  int w0 = 0, ns = 0;
+  auto seg = [&](DwArgs& d, const float* dZ, int ldz, int N, const float* X, int ldx, const float* X2, int ldx2, int K, int K1, float* W, float* b,
+                 float* Wt, float* bt) {
+    DwSeg& s = d.seg[ns++];
+    s.dZ = dZ; s.X = X; s.X2 = X2; s.W = W; s.b = b; s.Wt = Wt; s.bt = bt;
+    s.ldz = ldz; s.ldx = ldx; s.ldx2 = ldx2; s.N = N; s.K = K; s.K1 = K1; s.wave0 = w0;
+    w0 += tiles(N, K);
+  };
+  // critic: launch order of the layer-by-layer backward is irrelevant here (tiles are independent); fc1/fc4, fc2/fc5, fc3/fc6
+  for (int i = 0; i < 2; ++i) {
+    seg(c, ws.Z1[i], H, H, ws.s, D, ws.a, A, D + A, D, a.critic.w[3 * i], a.critic.b[3 * i], a.target.w[3 * i], a.target.b[3 * i]);
+    seg(c, ws.Z2[i], H, H, ws.H1[i], H, nullptr, 0, H, H, a.critic.w[3 * i + 1], a.critic.b[3 * i + 1], a.target.w[3 * i + 1], a.target.b[3 * i + 1]);
+    seg(c, ws.dq[i], 1, 1, ws.H2[i], H, nullptr, 0, H, H, a.critic.w[3 * i + 2], a.critic.b[3 * i + 2], a.target.w[3 * i + 2], a.target.b[3 * i + 2]);
+  }
+  c.nseg = ns; c.total_waves = w0; c.B = B;
+  c.p = a.critic_p; c.m = a.critic_m; c.v = a.critic_v;
+  for (int k = 0; k < 4; ++k) c.adam[k] = a.adam_critic[k];
+  c.adam_dev = a.adam_critic_dev;
+  c.omb1 = (float)(1.0 - a.beta1); c.beta2 = (float)a.beta2; c.omb2 = (float)(1.0 - a.beta2); c.eps = (float)a.eps_adam;
+  c.tau = (float)a.tau; c.omt = (float)(1.0 - a.tau);
+  c.terms = ws.terms; c.term0 = 0; c.nterms = 1; c.sums = a.sums; c.alpha_step = 0;
+  hipLaunchKernelGGL(sac_dw_kernel, dim3((w0 + 3) / 4 + 1), dim3(256), 0, stream, c);
+
+  hipLaunchKernelGGL(sac_p3_kernel, dim3(slabs), dim3(kThreads), lds_bytes(H, 8), stream, a, ws);
+
+  DwArgs p{};
+  w0 = 0; ns = 0;
+  seg(p, ws.aZ1, H, H, ws.s, D, nullptr, 0, D, D, a.actor.w[0], a.actor.b[0], nullptr, nullptr);
+  seg(p, ws.aZ2, H, H, ws.aH1, H, nullptr, 0, H, H, a.actor.w[1], a.actor.b[1], nullptr, nullptr);
+  seg(p, ws.dmean, A, A, ws.aH2, H, nullptr, 0, H, H, a.actor.w[2], a.actor.b[2], nullptr, nullptr);
+  seg(p, ws.dls, A, A, ws.aH2, H, nullptr, 0, H, H, a.actor.w[3], a.actor.b[3], nullptr, nullptr);
+  p.nseg = ns; p.total_waves = w0; p.B = B;
+  p.p = a.actor_p; p.m = a.actor_m; p.v = a.actor_v;
+  for (int k = 0; k < 4; ++k) p.adam[k] = a.adam_actor[k];
+  p.adam_dev = a.adam_actor_dev;
+  p.omb1 = c.omb1; p.beta2 = c.beta2; p.omb2 = c.omb2; p.eps = c.eps;
+  p.tau = 0.0f; p.omt = 0.0f;
+  p.terms = ws.terms; p.term0 = 1; p.nterms = 2; p.sums = a.sums; p.alpha_step = 1;
+  p.log_alpha = a.log_alpha; p.alpha_m = a.alpha_m; p.alpha_v = a.alpha_v; p.lr_alpha = a.lr_alpha;
+  p.abeta1 = 0.9; p.abeta2 = 0.999; p.aeps = 1e-8;
+  p.alpha_bias[0] = a.alpha_bias[0]; p.alpha_bias[1] = a.alpha_bias[1]; p.alpha_bias_dev = a.alpha_bias_dev; p.alpha_loss = a.alpha_loss;
+  hipLaunchKernelGGL(sac_dw_kernel, dim3((w0 + 3) / 4 + 1), dim3(256), 0, stream, p);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

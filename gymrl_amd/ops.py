@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from ._lib import (ACT_NONE, ACT_RELU, ACT_TANH, MLP_MAX_INPUT, MLP_MAX_STAGES, MLP_MAX_WIDTH, GaeOnline,
-                   MlpDesc, PPOCfg, PPOFullCfg, RolloutLunarArgs, check, lib)
+                   MlpDesc, PPOCfg, PPOFullCfg, RolloutLunarArgs, SacActArgs, SacUpdateArgs, check, lib)
 
 _vp = C.c_void_p
 
@@ -1214,3 +1214,93 @@ def mhc_gates_bwd(h, norm_w, w, alpha, pre, post, mix, stats, d_pre, d_post, d_m
                                     C.c_int(B), C.c_int(n), C.c_int(D), _ptr(d_h), _ptr(d_nw), _ptr(d_w), _ptr(d_alpha),
                                     _ptr(d_beta), _ptr(ws), _stream()), "gymrl_mhc_gates_bwd")
     return d_h, d_nw, d_w, d_alpha, d_beta
+
+
+# ------------------------------------------------- fused SAC vector step ---
+def _addr(t):
+    return None if t is None else _ptr(t).value
+
+
+def sac_fused_shape_ok(B, D, A, H):
+    """Shapes gymrl_sac_act_step / gymrl_sac_update take (include/gymrl.h): everything else runs layer by layer."""
+    return 0 < B <= 256 and 0 < D <= 8 and 0 < A <= 4 and 4 <= H <= 256 and H % 4 == 0
+
+
+def sac_update_workspace(B, D, A, H, device):
+    return torch.empty(int(lib().gymrl_sac_update_workspace_bytes(C.c_int(B), C.c_int(D), C.c_int(A), C.c_int(H))),
+                       dtype=torch.uint8, device=device)
+
+
+def _sac_actor_params(dst, actor):
+    for k, layer in enumerate((actor.fc1, actor.fc2, actor.mean, actor.log_std)):
+        dst.w[k], dst.b[k] = _addr(layer.weight), _addr(layer.bias)
+
+
+def _sac_critic_params(dst, critic):
+    for k, layer in enumerate((critic.fc1, critic.fc2, critic.fc3, critic.fc4, critic.fc5, critic.fc6)):
+        dst.w[k], dst.b[k] = _addr(layer.weight), _addr(layer.bias)
+
+
+def sac_act_args(env, actor, ring, cap, bound, log_std_min, log_std_max):
+    """A gymrl_sac_act_args with everything that does not change from step to step filled in (env, actor parameters —
+    views of a flat buffer the optimiser updates in place — and the replay ring)."""
+    a = SacActArgs()
+    a.N, a.D, a.A, a.H = env.n, env.obs_dim, env.act_dim, actor.fc1.weight.shape[0]
+    a.env_kind, a.env_state, a.env_seed, a.env_id0 = env.kind, _addr(env.state), env.seed, env.env_id0
+    a.bound, a.log_std_min, a.log_std_max = float(bound), float(log_std_min), float(log_std_max)
+    _sac_actor_params(a.actor, actor)
+    a.r_state, a.r_action, a.r_reward, a.r_next, a.r_flag = (_addr(t) for t in ring)
+    a.cap = cap
+    return a
+
+
+def sac_act_step(a, env, obs, obs_out, cursor=0, cursor_dev=None, eps=None, noise_seed=0, noise_counter=0, noise_counter_dev=None,
+                 action_out=None, rew_out=None, done_out=None, ep_ret_out=None, ep_stats=None):
+    """gymrl_sac_act_step: Actor forward on obs [N, D], reparameterised draw, env step with auto-reset, replay rows at
+    (cursor + env) % cap — ONE launch (sac_pendulum.py:278-283)."""
+    a.env_seed = env.seed                              # reset(seed=...) may have moved it
+    a.obs, a.obs_out, a.eps = _ptr(obs, torch.float32).value, _ptr(obs_out, torch.float32).value, _addr(eps)
+    a.noise_seed, a.noise_counter, a.noise_counter_dev = noise_seed, noise_counter, _addr(noise_counter_dev)
+    a.cursor, a.cursor_dev = cursor, _addr(cursor_dev)
+    a.action_out, a.rew_out, a.done_out, a.ep_ret_out, a.ep_stats = (_addr(t) for t in (action_out, rew_out, done_out, ep_ret_out, ep_stats))
+    check(lib().gymrl_sac_act_step(C.byref(a), _stream()), "gymrl_sac_act_step")
+
+
+def sac_update_args(B, D, A, actor, critic, target, actor_opt, critic_opt, ring, cfg_scalars, log_alpha, alpha_m, alpha_v, sums,
+                    alpha_loss, workspace):
+    """A gymrl_sac_update_args with the per-trainer constants filled in.  cfg_scalars = (gamma, tau, bound, log_std_min,
+    log_std_max, target_entropy, lr_alpha); actor_opt / critic_opt: FusedAdam over the modules' flat buffers."""
+    a = SacUpdateArgs()
+    a.B, a.D, a.A, a.H = B, D, A, actor.fc1.weight.shape[0]
+    gamma, tau, bound, lo, hi, tent, lr_alpha = cfg_scalars
+    a.gamma, a.tau, a.bound, a.log_std_min, a.log_std_max, a.target_entropy = float(gamma), float(tau), float(bound), float(lo), float(hi), float(tent)
+    a.r_state, a.r_action, a.r_reward, a.r_next, a.r_flag = (_addr(t) for t in ring)
+    _sac_actor_params(a.actor, actor)
+    _sac_critic_params(a.critic, critic)
+    _sac_critic_params(a.target, target)
+    a.actor_p, a.actor_m, a.actor_v = _addr(actor_opt.p), _addr(actor_opt.m), _addr(actor_opt.v)
+    a.critic_p, a.critic_m, a.critic_v = _addr(critic_opt.p), _addr(critic_opt.m), _addr(critic_opt.v)
+    g = critic_opt.param_groups[0]
+    a.beta1, a.beta2, a.eps_adam = g["betas"][0], g["betas"][1], g["eps"]
+    a.log_alpha, a.alpha_m, a.alpha_v, a.lr_alpha = _addr(log_alpha), _addr(alpha_m), _addr(alpha_v), float(lr_alpha)
+    a.sums, a.alpha_loss, a.workspace = _addr(sums), _addr(alpha_loss), _addr(workspace)
+    return a
+
+
+def sac_update(a, idx=None, idx_seed=0, idx_counter=0, idx_size=0, idx_dev=None, eps_next=None, eps_cur=None, noise_seed=0,
+               noise_counter=0, noise_counter_dev=None, adam_critic=None, adam_actor=None, adam_critic_dev=None, adam_actor_dev=None,
+               alpha_bias=(1.0, 1.0), alpha_bias_dev=None):
+    """gymrl_sac_update: SACTrainer.update() (sac_pendulum.py:213-267) as four launches.  adam_critic / adam_actor: the
+    16-byte blocks of adam_bias() (host) or device views of them; alpha_bias = (1 - 0.9^t, 1 - 0.999^t)."""
+    a.idx, a.idx_seed, a.idx_counter, a.idx_size, a.idx_dev = _addr(idx), idx_seed, idx_counter, idx_size, _addr(idx_dev)
+    a.eps_next, a.eps_cur = _addr(eps_next), _addr(eps_cur)
+    a.noise_seed, a.noise_counter, a.noise_counter_dev = noise_seed, noise_counter, _addr(noise_counter_dev)
+    for dst, blk in ((a.adam_critic, adam_critic), (a.adam_actor, adam_actor)):
+        if blk is not None:
+            vals = (C.c_float * 4).from_buffer_copy(blk)
+            for k in range(4):
+                dst[k] = vals[k]
+    a.adam_critic_dev, a.adam_actor_dev = _addr(adam_critic_dev), _addr(adam_actor_dev)
+    a.alpha_bias[0], a.alpha_bias[1], a.alpha_bias_dev = alpha_bias[0], alpha_bias[1], _addr(alpha_bias_dev)
+    check(lib().gymrl_sac_update(C.byref(a), _stream()), "gymrl_sac_update")
+

@@ -45,6 +45,9 @@ class Config:
         self.num_envs = 1
         self.updates_per_step = 1
         self.use_graphs = True             # replay the update as one captured hipGraph (train(); update() stays eager)
+        self.fused_step = True             # a vector step = 5 launches (csrc/offpolicy_step.hip: acting + env + append in one, the
+        #                                    update in four) instead of ~60; bit-identical to the layer-by-layer path, which remains
+        #                                    for shapes beyond the kernels' limits (hidden_dim > 256, batch > 256) and custom envs
         self.chunk_steps = 0               # 16: whole vector steps as one hipGraph per 16 (graphs.StepChunk).  Measured slower
         #                                    here (0.37 vs 0.29 ms per step at N = 4096, B = 128): SAC's step is GPU-bound, and
         #                                    the executor's cost per graph node grows with the graph (944 nodes per chunk)
@@ -166,6 +169,8 @@ class SACTrainer:
         self._parity_eps = None        # tests: iterator of f32[N, A] N(0,1) draws for select_action
         self._graph = None             # hipGraph of the update, captured on first use (update_async)
         self._parity_updates = None    # tests: iterator of (indices i32[B], eps_next [B, A], eps_cur [B, A]) for update()
+        self._fused = None             # (act args, update args, workspace) of the fused step, built on first use
+        self._act_noise = self._upd_noise = 0      # Philox counters of the fused step's own N(0,1) draws
 
     @property
     def alpha(self):
@@ -175,6 +180,54 @@ class SACTrainer:
         """:194-199 on the flat parameter buffers."""
         ops.soft_update(self.critic_target_flat if target_flat is None else target_flat,
                         self.critic_flat if source_flat is None else source_flat, self.cfg.tau)
+
+    # ------------------------------------------------------------ fused vector step (csrc/offpolicy_step.hip) --
+    def _fused_update_ok(self):
+        """update() as gymrl_sac_update: a matter of shapes only (any env, any source of transitions)."""
+        cfg, m = self.cfg, self.memory
+        return (bool(getattr(cfg, "fused_step", True))
+                and ops.sac_fused_shape_ok(cfg.batch_size, m.ring[0].shape[1], m.ring[1].shape[1], cfg.hidden_dim))
+
+    def _fused_ok(self):
+        """The whole vector step fused: the update AND acting + env step + replay row (gymrl_sac_act_step steps Pendulum itself)."""
+        cfg, env = self.cfg, self.env
+        return (self._fused_update_ok() and isinstance(env, VecEnv) and env.kind == ops.PENDULUM
+                and cfg.max_steps >= env.max_steps and self.memory.capacity >= env.n)
+
+    def _fused_args(self):
+        if self._fused is None or self._fused[3] is not self.env:
+            cfg, env, m = self.cfg, self.env, self.memory
+            D, A = m.ring[0].shape[1], m.ring[1].shape[1]
+            act = (ops.sac_act_args(env, self.actor, m.ring, m.capacity, self.action_bound, cfg.log_std_min, cfg.log_std_max)
+                   if isinstance(env, VecEnv) else None)
+            ws = ops.sac_update_workspace(cfg.batch_size, D, A, cfg.hidden_dim, self.device)
+            upd = ops.sac_update_args(cfg.batch_size, D, A, self.actor, self.critic, self.critic_target,
+                                      self.actor_optimizer, self.critic_optimizer, m.ring,
+                                      (cfg.gamma, cfg.tau, self.action_bound, cfg.log_std_min, cfg.log_std_max, self.target_entropy,
+                                       cfg.lr_alpha), self.log_alpha, self._alpha_m, self._alpha_v, self._sums, self._alpha_loss, ws)
+            self._fused = (act, upd, ws, env)
+        return self._fused
+
+    def _update_fused(self, indices=None, eps_next=None, eps_cur=None, dev=None):
+        """update() as gymrl_sac_update's four launches.  dev = (draw, adam_c, adam_a, alpha, noise) device records of a
+        StepChunk replay; None: this call's scalars travel as arguments and the host counters advance here."""
+        m = self.memory
+        upd = self._fused_args()[1]
+        if dev is not None:
+            ops.sac_update(upd, idx_seed=m.seed, idx_dev=dev[0], adam_critic_dev=dev[1], adam_actor_dev=dev[2], alpha_bias_dev=dev[3],
+                           noise_seed=self.base_seed, noise_counter_dev=dev[4], idx_size=m.capacity)
+            return
+        if indices is None:
+            counter, size = m.draws, m.size
+            m.draws += 1
+        else:
+            counter, size = 0, 0
+        self._alpha_steps += 1
+        self._upd_noise += 1
+        t = self._alpha_steps
+        ops.sac_update(upd, idx=indices, idx_seed=m.seed, idx_counter=counter, idx_size=size, eps_next=eps_next, eps_cur=eps_cur,
+                       noise_seed=self.base_seed, noise_counter=self._upd_noise, adam_critic=self.critic_optimizer.next_bias(),
+                       adam_actor=self.actor_optimizer.next_bias(), alpha_bias=(1.0 - 0.9 ** t, 1.0 - 0.999 ** t))
 
     @torch.no_grad()
     def select_action(self, state, deterministic=False, eps=None):
@@ -190,6 +243,10 @@ class SACTrainer:
             return 0.0, 0.0, 0.0
         if indices is None and self._parity_updates is not None:
             indices, eps_next, eps_cur = next(self._parity_updates)
+        if self._fused_update_ok() and (indices is None or indices.numel() == cfg.batch_size):
+            self._update_fused(indices, eps_next, eps_cur)
+            s = self._sums.tolist()
+            return s[1] / cfg.batch_size, s[0] / cfg.batch_size, float(self._alpha_loss.item())
         if indices is None:
             indices = self.memory.draw_indices(cfg.batch_size)
         B = self._update_body(indices, eps_next, eps_cur)
@@ -240,6 +297,8 @@ class SACTrainer:
         cfg, m = self.cfg, self.memory
         if len(m) < cfg.batch_size:
             return
+        if self._fused_update_ok():        # four launches: nothing left for a graph to save
+            return self._update_fused()
         if self._graph is None:
             from .graphs import GraphedStep, StepScalars
             sc = self._scalars = StepScalars(self.device)
@@ -267,6 +326,7 @@ class SACTrainer:
                                       "critic_optimizer": (self.critic, self.critic_optimizer)},
                                      log_alpha=self.log_alpha.detach().cpu(), alpha_m=self._alpha_m.cpu(),
                                      alpha_v=self._alpha_v.cpu(), alpha_steps=self._alpha_steps,
+                                     act_noise=self._act_noise, upd_noise=self._upd_noise,
                                      episode_rewards=list(self.episode_rewards), **extra)
 
     def load_checkpoint(self, path):
@@ -278,6 +338,7 @@ class SACTrainer:
         self._alpha_m.copy_(rest["alpha_m"].to(self.device))
         self._alpha_v.copy_(rest["alpha_v"].to(self.device))
         self._alpha_steps = int(rest["alpha_steps"])
+        self._act_noise, self._upd_noise = int(rest.get("act_noise", 0)), int(rest.get("upd_noise", 0))
         self.episode_rewards.clear()
         self.episode_rewards.extend(rest.get("episode_rewards", []))
         if "memory_state_dict" in rest:
@@ -301,9 +362,20 @@ class SACTrainer:
         lb["tracker"].k, lb["tracker"].episodes = 0, 0
         return lb
 
-    def _vector_step(self, lb, obs, nxt, ep_ret, done, cursor_dev=None):
+    def _vector_step(self, lb, obs, nxt, ep_ret, done, cursor_dev=None, noise_dev=None):
         """One vector step of :269-310 up to (not including) the update."""
         cfg, env = self.cfg, self.env
+        if self._fused_ok():               # forward + draw + env step + ring row: one launch
+            m = self.memory
+            eps = None if self._parity_eps is None else next(self._parity_eps)
+            if cursor_dev is None:
+                self._act_noise += 1
+            ops.sac_act_step(self._fused_args()[0], env, obs, nxt, cursor=m.cursor, cursor_dev=cursor_dev, eps=eps,
+                             noise_seed=self.base_seed, noise_counter=self._act_noise, noise_counter_dev=noise_dev,
+                             rew_out=lb["rew"], done_out=done, ep_ret_out=ep_ret, ep_stats=env.ep_stats)
+            if cursor_dev is None:
+                m.advance(env.n)
+            return
         action = self.select_action(obs, eps=None if self._parity_eps is None else next(self._parity_eps))
         env.step(action, nxt, lb["rew"], done_out=done, term_obs_out=lb["tobs"], ep_ret_out=ep_ret)
         if cursor_dev is None:
@@ -318,6 +390,11 @@ class SACTrainer:
         read from record j."""
         ch, tr = self._chunk, lb["tracker"]
         obs, nxt = (lb["obs"], lb["nxt"]) if j % 2 == 0 else (lb["nxt"], lb["obs"])
+        if self._fused_ok():
+            self._vector_step(lb, obs, nxt, tr.ret[j], tr.done[j], cursor_dev=ch.view(j, "push"), noise_dev=ch.view(j, "noise_a"))
+            self._update_fused(dev=(ch.view(j, "draw"), ch.view(j, "adam_c", torch.float32), ch.view(j, "adam_a", torch.float32),
+                                    ch.view(j, "alpha", torch.float64), ch.view(j, "noise_u")))
+            return
         self._vector_step(lb, obs, nxt, tr.ret[j], tr.done[j], cursor_dev=ch.view(j, "push"))
         self.memory.draw_indices(self.cfg.batch_size, out=self._g_idx, dev=ch.view(j, "draw"))
         self._update_body(self._g_idx, bias=(ch.view(j, "adam_c", torch.float32), ch.view(j, "adam_a", torch.float32),
@@ -335,6 +412,10 @@ class SACTrainer:
             ch.set_bytes(j, "adam_a", self.actor_optimizer.next_bias())
             self._alpha_steps += 1
             ch.set(j, "alpha", 1.0 - 0.9 ** self._alpha_steps, 1.0 - 0.999 ** self._alpha_steps)
+            self._act_noise += 1
+            self._upd_noise += 1
+            ch.set(j, "noise_a", self._act_noise)
+            ch.set(j, "noise_u", self._upd_noise)
         ch.flush()
 
     def _train(self, max_vector_steps=None):
@@ -347,7 +428,10 @@ class SACTrainer:
         env.reset(obs)
         step = 0
         graphed = bool(getattr(cfg, "use_graphs", True)) and self._parity_updates is None
-        chunked = graphed and N > 1 and cfg.updates_per_step == 1 and getattr(cfg, "chunk_steps", self.CHUNK) > 0 and self._parity_eps is None
+        # the fused step is 5 launches: 16 steps replay as ONE 80-node graph (the layer-by-layer step's 944-node chunk is slower
+        # than its eager loop, hence chunk_steps = 0 there)
+        want_chunk = getattr(cfg, "chunk_steps", self.CHUNK) > 0 or self._fused_ok()
+        chunked = graphed and N > 1 and cfg.updates_per_step == 1 and want_chunk and self._parity_eps is None
         limit = max_vector_steps or (cfg.max_episodes * cfg.max_steps // N + 1)
         while tracker.episodes < cfg.max_episodes and step < limit:
             if (chunked and tracker.k == 0 and limit - step >= self.CHUNK and obs is lb["obs"]
@@ -355,7 +439,8 @@ class SACTrainer:
                 if getattr(self, "_chunk", None) is None:
                     from .graphs import StepChunk
                     self._chunk = StepChunk(self.device, self.CHUNK, [("push", "q"), ("draw", "Qq"), ("adam_c", "4f"),
-                                                                      ("adam_a", "4f"), ("alpha", "2d")])
+                                                                      ("adam_a", "4f"), ("alpha", "2d"), ("noise_a", "Q"),
+                                                                      ("noise_u", "Q")])
                     if getattr(self, "_g_idx", None) is None:
                         self._g_idx = torch.empty(cfg.batch_size, dtype=torch.int32, device=self.device)
                 self._stage_chunk()

@@ -995,6 +995,71 @@ int gymrl_running_norm(const float* x, int N, int D, double* stats, int update, 
 int gymrl_reward_scaling(const float* r, const uint8_t* done, int N, double gamma, double* R,
                          double* stats, float* y_out, void* stream);
 
+/* ============================================ fused off-policy vector step ===== */
+/*
+ * One SAC vector step of sac_pendulum.py:269-310 as FIVE launches instead of ~60 (csrc/offpolicy_step.hip; round 3's step:
+ * 3 gymrl_lin_fwd + sample + env step + append + index draw + gather + ~45 layer / loss / optimiser launches of 4-14 us).
+ * A forward or input-gradient pass never mixes batch rows, so ONE workgroup carries a 16-row slab of the batch through a
+ * whole chain of layers in LDS (tile bodies of csrc/lin_device.hpp: the very MFMA sequence of gymrl_lin_*), and only the
+ * weight gradients, which reduce over the batch, need a kernel boundary:
+ *   gymrl_sac_act_step   acting (:278-283): Actor forward on the N observations, reparameterised draw, Pendulum step with
+ *                        auto-reset, replay row (obs, action, reward, TERMINAL next obs, done) at (cursor + env) % cap
+ *   gymrl_sac_update     update() (:213-267), four launches:
+ *     P1 rows   index draw (gymrl_uniform_indices' permutation) + ring gather; a', logp' = Actor.sample(s'); target
+ *               Q(s', a'); y; Q(s, a); critic loss gradient; input-gradient chain of both Q networks
+ *     P2 tiles  every critic weight / bias gradient tile (gymrl_lin_bwd_weight's order) + Adam on that tile + the soft target
+ *               update of the element just written (gymrl_adam_step's expressions); critic loss sum
+ *     P3 rows   a, logp = Actor.sample(s); Q(s, a) of the UPDATED critic; actor loss gradient; the chain back through both
+ *               Q networks to the action, through the sample, through the actor
+ *     P4 tiles  actor weight gradients + Adam; actor loss / temperature sums; the float64 temperature step
+ * Results are those of the layer-by-layer path bit for bit (same products, same orders; tests/test_fused_step_gpu.py), which
+ * tests/test_trainers_gpu.py pins against the reference.  Limits: H % 4 == 0, H <= 256, D <= 8, A <= 4, B <= 256
+ * (-22 otherwise: use the layer-by-layer path).  Pointers are device pointers; W = [out][in] row-major (nn.Linear).
+ */
+typedef struct { float* w[4]; float* b[4]; } gymrl_sac_actor_params;     /* fc1, fc2, mean, log_std (sac_pendulum.py:58-61) */
+typedef struct { float* w[6]; float* b[6]; } gymrl_sac_critic_params;    /* fc1..fc6: fc1-3 = Q1, fc4-6 = Q2 (:108-113) */
+typedef struct {
+  int N, D, A, H;                          /* envs, obs dim, action dim, hidden width */
+  int env_kind;                            /* GYMRL_ENV_PENDULUM */
+  void* env_state; uint64_t env_seed; int64_t env_id0;
+  const float* obs;                        /* f32[N, D] the observations to act on */
+  float* obs_out;                          /* f32[N, D] next observations (post-reset where an episode ended) */
+  const float* eps;                        /* f32[N, A] N(0,1) draws, or NULL: Philox (noise_seed, noise_counter, stream 2, env * A + j) */
+  uint64_t noise_seed, noise_counter; const uint64_t* noise_counter_dev;
+  float bound, log_std_min, log_std_max;
+  gymrl_sac_actor_params actor;
+  /* replay ring (gymrl_replay_append's layout); cursor_dev int64[1] or NULL */
+  float* r_state; uint32_t* r_action; float* r_reward; float* r_next; uint8_t* r_flag; int64_t cap, cursor;
+  const int64_t* cursor_dev;
+  /* per-step outputs of the episode bookkeeping (any may be NULL) */
+  float* action_out; float* rew_out; uint8_t* done_out; float* ep_ret_out; double* ep_stats;
+} gymrl_sac_act_args;
+typedef struct {
+  int B, D, A, H;
+  float gamma, bound, log_std_min, log_std_max, target_entropy;
+  double tau;                              /* soft target update rate (a python float: rounded like gymrl_adam_step does) */
+  const float* r_state; const uint32_t* r_action; const float* r_reward; const float* r_next; const uint8_t* r_flag;
+  const int32_t* idx;                      /* i32[B] explicit rows, or NULL: the keyed permutation of gymrl_uniform_indices */
+  uint64_t idx_seed, idx_counter; int64_t idx_size; const void* idx_dev;     /* idx_dev: {uint64 counter; int64 size} */
+  const float* eps_next; const float* eps_cur;     /* f32[B, A] each, or NULL: Philox streams 3 / 4 of (noise_seed, noise_counter) */
+  uint64_t noise_seed, noise_counter; const uint64_t* noise_counter_dev;
+  gymrl_sac_actor_params actor; gymrl_sac_critic_params critic, target;
+  /* flat parameter buffers and their Adam moments (same layout): m of a parameter p lives at critic_m + (p - critic_p) */
+  float* actor_p; float* actor_m; float* actor_v; float* critic_p; float* critic_m; float* critic_v;
+  float adam_critic[4], adam_actor[4];     /* gymrl_adam_bias' block {lr/(1-b1^t), 1/(1-b1^t), sqrt(1-b2^t), 0} */
+  const float* adam_critic_dev; const float* adam_actor_dev;      /* the same from device memory (hipGraph replay) or NULL */
+  double beta1, beta2, eps_adam;
+  double* log_alpha; double* alpha_m; double* alpha_v; double lr_alpha;
+  double alpha_bias[2]; const double* alpha_bias_dev;             /* {1 - 0.9^t, 1 - 0.999^t} (gymrl_sac_alpha_step) */
+  double* sums;                            /* f64[3] out: critic loss sum, actor loss sum, sum of (logp + target_entropy) */
+  double* alpha_loss;                      /* f64[1] out or NULL */
+  void* workspace;                         /* >= gymrl_sac_update_workspace_bytes(B, D, A, H) */
+} gymrl_sac_update_args;
+size_t gymrl_sac_update_workspace_bytes(int B, int D, int A, int H);
+size_t gymrl_sac_args_bytes(int which);      /* sizeof(gymrl_sac_act_args) (0) / sizeof(gymrl_sac_update_args) (1): a binding checks its mirror */
+int gymrl_sac_act_step(const gymrl_sac_act_args* args, void* stream);
+int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,86 @@
+"""The fused SAC vector step (csrc/offpolicy_step.hip: acting + env + replay row in one launch, update() in four) against the
+layer-by-layer path it replaces (gymrl_lin_* launches + the stand-alone loss / optimiser / replay / env kernels, which
+tests/test_trainers_gpu.py pins against the reference's own update() and train()): same noise, same index draws ->
+every parameter, Adam moment, the target network, the float64 temperature and the replay ring equal BIT FOR BIT."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _run(fused, steps, N, B, hidden, seed=5):
+    from gymrl_amd.sac_pendulum import Config, SACTrainer
+    cfg = Config()
+    cfg.num_envs, cfg.batch_size, cfg.hidden_dim, cfg.seed = N, B, hidden, seed
+    cfg.max_episodes, cfg.memory_capacity, cfg.use_graphs, cfg.fused_step = 10 ** 9, 4096, False, fused
+    tr = SACTrainer(cfg)
+    assert tr._fused_ok() == fused
+    g = torch.Generator(device="cuda").manual_seed(7)
+    A = tr.env.act_dim
+    tr._parity_eps = iter([torch.randn(N, A, generator=g, device="cuda") for _ in range(steps)])
+    # explicit N(0,1) draws for both samples of every update; indices None: each path draws its own (the eager path through
+    # gymrl_uniform_indices, the fused path inside P1) from the same (seed, counter, size)
+    tr._parity_updates = iter([(None, torch.randn(B, A, generator=g, device="cuda"), torch.randn(B, A, generator=g, device="cuda"))
+                               for _ in range(steps)])
+    tr.train(max_vector_steps=steps)
+    torch.cuda.synchronize()
+    return tr
+
+
+@pytest.mark.parametrize("N,B,hidden,steps", [(64, 128, 256, 40), (20, 24, 32, 30), (48, 256, 64, 24)])
+def test_sac_fused_step_equals_layer_by_layer(N, B, hidden, steps):
+    a, b = _run(False, steps, N, B, hidden), _run(True, steps, N, B, hidden)
+    assert a.critic_optimizer.step_count == b.critic_optimizer.step_count > 10
+    assert (a.memory.cursor, a.memory.size, a.memory.draws) == (b.memory.cursor, b.memory.size, b.memory.draws)
+    for x, y in zip(a.memory.ring, b.memory.ring):
+        assert torch.equal(x, y)                                    # acting: same actions, same physics, same rows
+    for name in ("actor_flat", "critic_flat", "critic_target_flat", "log_alpha", "_alpha_m", "_alpha_v"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    for opt in ("actor_optimizer", "critic_optimizer"):
+        assert torch.equal(getattr(a, opt).m, getattr(b, opt).m) and torch.equal(getattr(a, opt).v, getattr(b, opt).v), opt
+    assert torch.equal(a._sums[:3], b._sums[:3]) and torch.equal(a._alpha_loss, b._alpha_loss)
+    assert list(a.episode_rewards) == list(b.episode_rewards)
+
+
+def test_sac_fused_update_matches_reference_update():
+    """The reference's own SACTrainer.update() (tests/golden/sac.npz: one update from fixed weights, batch, N(0,1) draws)
+    reproduced by the FUSED update: losses, the float64 temperature, actor / critic / target parameters."""
+    from conftest import load_golden
+    from gymrl_amd.sac_pendulum import Config, SACTrainer
+    g = load_golden("sac")
+    cfg = Config()
+    cfg.hidden_dim, cfg.batch_size = 32, 24
+    cfg.gamma, cfg.tau = float(g["u_gamma"]), float(g["u_tau"])
+    tr = SACTrainer(cfg)
+    assert tr._fused_update_ok()
+    for name, net in (("actor", tr.actor), ("critic", tr.critic), ("critic_target", tr.critic_target)):
+        pre = f"u0_{name}_"
+        net.load_state_dict({k[len(pre):]: torch.from_numpy(np.array(g[k])) for k in g.files
+                             if k.startswith(pre) and not k[len(pre):].startswith("target_")})
+    dev = tr.device
+    tr.memory.push(torch.from_numpy(g["u_states"]).to(dev), torch.from_numpy(g["u_actions"]).to(dev),
+                   torch.from_numpy(g["u_rewards"]).to(dev), torch.from_numpy(g["u_next_states"]).to(dev),
+                   torch.from_numpy(g["u_dones"]).to(dev))
+    al, cl, aal = tr.update(indices=torch.from_numpy(g["u_order"]).to(dev), eps_next=torch.from_numpy(g["u_eps_next"]).to(dev),
+                            eps_cur=torch.from_numpy(g["u_eps_cur"]).to(dev))
+    ref = g["u_losses"]
+    for got, want in ((al, ref[0]), (cl, ref[1]), (aal, ref[2])):
+        assert abs(got - want) <= 2e-5 * max(1, abs(want))
+    assert abs(tr.log_alpha.item() - float(g["u_log_alpha1"])) <= 1e-9
+    for name, net in (("actor", tr.actor), ("critic", tr.critic), ("critic_target", tr.critic_target)):
+        err = max(float(np.max(np.abs(v.detach().cpu().numpy() - g[f"u1_{name}_" + k]))) for k, v in net.state_dict().items())
+        assert err <= 5e-6, (name, err)
+
+
+def test_sac_fused_step_is_five_launches():
+    """What the fusion is for: a vector step of the chunked graph is 5 kernel nodes (acting; rows; tiles; rows; tiles)."""
+    from gymrl_amd.sac_pendulum import Config, SACTrainer
+    cfg = Config()
+    cfg.num_envs, cfg.batch_size, cfg.seed, cfg.max_episodes, cfg.memory_capacity = 256, 128, 1, 10 ** 9, 1 << 14
+    tr = SACTrainer(cfg)
+    tr.train(max_vector_steps=64)
+    torch.cuda.synchronize()
+    assert tr._fused_ok() and tr._chunk is not None and tr._chunk.graph is not None
+    assert all(torch.isfinite(getattr(tr, n)).all() for n in ("actor_flat", "critic_flat", "log_alpha"))
+    assert tr.critic_optimizer.step_count >= 60

@@ -53,7 +53,7 @@ def test_rainbow_loop_written_against_the_reference():
     """rainbow_dqn_cartpole.py:363-405: select_action -> int, store_transition(host scalars incl. terminal), update() -> float."""
     from gymrl_amd.rainbow_dqn_cartpole import Config, RainbowDQNTrainer
     cfg = Config()
-    cfg.num_envs, cfg.hidden_dim, cfg.batch_size, cfg.memory_capacity, cfg.seed = 1, 32, 16, 256, 4
+    cfg.num_envs, cfg.hidden_dim, cfg.batch_size, cfg.memory_capacity, cfg.seed = 1, 32, 16, 4096, 4
     tr = RainbowDQNTrainer(cfg)
     env = tr.env.gym
     n_steps, losses = 0, []

@@ -55,6 +55,7 @@ def test_sac_update_matches_reference():
     cfg = Config()
     cfg.hidden_dim, cfg.batch_size = 32, 24
     cfg.gamma, cfg.tau = float(g["u_gamma"]), float(g["u_tau"])
+    cfg.fused_step = False            # the layer-by-layer update; the fused one takes the same fixture in tests/test_fused_step_gpu.py
     tr = SACTrainer(cfg)
     for name, net in (("actor", tr.actor), ("critic", tr.critic), ("critic_target", tr.critic_target)):
         _load(net, g, f"u0_{name}_")
