@@ -47,6 +47,12 @@ constexpr int kSlab = 16;                 // rows of a slab = rows of an MFMA ti
 // reads, and the 16 rows of a quarter-wave land in 16 different 16-byte bank groups when K is a multiple of 64.
 __host__ __device__ __forceinline__ int slab_ld(int K) { return ((K + 3) & ~3) + 4; }
 
+// The reduction of a slab tile is at most kMaxSteps 16-deep MFMA steps per pass (K <= 256: the fused kernels' limit; longer
+// reductions take further passes).  ALL of a pass's weight loads are issued before its first MFMA — a slab stage is one
+// L2 round trip plus the MFMA chain, not a round trip per step (the first version, with the loads inside the loop, ran a
+// 256 x 256 layer in ~6 us per stage; the MFMA chain is 0.85 us) — and the X operand comes from LDS step by step.
+constexpr int kMaxSteps = 16;
+
 // acc = X . W[nb .. nb + 15]^T for the slab X = [Xs | X2s] ([16][K1] and [16][K - K1] in LDS; K1 == K: one block).
 // The order of lin_fwd_kernel: k0 = 0, 16, ...; e = 0..3; the MFMA adds k = k0 + 4q + e over q.  Rows beyond the slab's
 // valid rows must hold zeros (the callers zero-fill), columns n >= N and k >= K contribute exact zeros.
@@ -58,18 +64,27 @@ __device__ __forceinline__ f32x4 tile_fwd(const float* Xs, int ldx, const float*
   const bool n_ok = n < N;
   const float* wrow = W + (size_t)(n_ok ? n : 0) * K;
   const float* xrow = Xs + r * ldx;
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
   if (K1 == K && (K & 3) == 0) {
-    for (int k0 = 0; k0 < K; k0 += 16) {
-      const int k = k0 + 4 * q;
-      const bool k_ok = k < K;
-      const int ks = k_ok ? k : 0;
-      const f32x4 xa = *reinterpret_cast<const f32x4*>(xrow + ks);
-      const f32x4 wb = *reinterpret_cast<const f32x4*>(wrow + ks);
-      const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-      const f32x4 x = k_ok ? xa : zero;
-      const f32x4 w = (n_ok && k_ok) ? wb : zero;
+    for (int kp = 0; kp < K; kp += 16 * kMaxSteps) {
+      f32x4 wb[kMaxSteps];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = mfma16(x[e], w[e], acc);
+      for (int c = 0; c < kMaxSteps; ++c) {
+        if (kp + 16 * c >= K) break;                          // (wave-uniform)
+        const int k = kp + 16 * c + 4 * q;
+        wb[c] = *reinterpret_cast<const f32x4*>(wrow + (k < K ? k : 0));
+      }
+#pragma unroll
+      for (int c = 0; c < kMaxSteps; ++c) {
+        if (kp + 16 * c >= K) break;
+        const int k = kp + 16 * c + 4 * q;
+        const bool k_ok = k < K;
+        const f32x4 xa = *reinterpret_cast<const f32x4*>(xrow + (k_ok ? k : 0));
+        const f32x4 x = k_ok ? xa : zero;
+        const f32x4 w = (n_ok && k_ok) ? wb[c] : zero;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma16(x[e], w[e], acc);
+      }
     }
   } else {
     const float* x2row = X2s ? X2s + r * ldx2 : nullptr;
@@ -101,19 +116,28 @@ __device__ __forceinline__ f32x4 tile_bwd_input(f32x4 acc, const float* dZs, int
   const bool k_ok = kc < K;
   const int kcol = k_ok ? kc : 0;
   const float* zrow = dZs + r * ldz;
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
   if ((N & 3) == 0) {
-    for (int n0 = 0; n0 < N; n0 += 16) {
-      const int n = n0 + 4 * q;
-      const bool ok = n < N;
-      const int ns = ok ? n : 0;
-      const f32x4 za = *reinterpret_cast<const f32x4*>(zrow + ns);
-      const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-      const f32x4 dz = ok ? za : zero;
-      float wb[4];
+    for (int np = 0; np < N; np += 16 * kMaxSteps) {
+      float wb[kMaxSteps][4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) wb[e] = W[(size_t)(ns + e) * K + kcol];
+      for (int c = 0; c < kMaxSteps; ++c) {
+        if (np + 16 * c >= N) break;                          // (wave-uniform)
+        const int n = np + 16 * c + 4 * q;
+        const int ns = n < N ? n : 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = mfma16(dz[e], k_ok ? wb[e] : 0.0f, acc);      // (as lin_bwd_input_kernel: the weight of a padded n is whatever row 0 holds, times an exact zero)
+        for (int e = 0; e < 4; ++e) wb[c][e] = W[(size_t)(ns + e) * K + kcol];
+      }
+#pragma unroll
+      for (int c = 0; c < kMaxSteps; ++c) {
+        if (np + 16 * c >= N) break;
+        const int n = np + 16 * c + 4 * q;
+        const bool ok = n < N;
+        const f32x4 za = *reinterpret_cast<const f32x4*>(zrow + (ok ? n : 0));
+        const f32x4 dz = ok ? za : zero;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma16(dz[e], k_ok ? wb[c][e] : 0.0f, acc);      // (as lin_bwd_input_kernel: the weight of a padded n is whatever row 0 holds, times an exact zero)
+      }
     }
   } else {
     for (int n0 = 0; n0 < N; n0 += 16) {

@@ -27,6 +27,14 @@ using lin::act_bwd;
 using lin::act_fwd;
 
 constexpr int kWaves = 16, kThreads = 64 * kWaves;
+
+// Probe build only (make prof): 100 MHz wall-clock stamps at the stage boundaries of workgroup 0 (tools/probe_sac_stages.py)
+#ifdef GYMRL_PROF_BUILD
+__device__ long long g_step_prof[3][32];
+#define STEP_MARK(k, i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_step_prof[k][i] = (long long)wall_clock64(); } while (0)
+#else
+#define STEP_MARK(k, i) do {} while (0)
+#endif
 constexpr int kMaxD = 8, kMaxA = 4;
 constexpr float kLogSqrt2Pi = 0.91893853320467274178f;   // math.log(math.sqrt(2*math.pi))
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -55,68 +63,82 @@ struct SacWs {
   }
 };
 
-// ---- a layer over the slab: all 16 waves, tile t -> wave t % 16 --------------------------------------------------------
-struct FwdItem { int X, X2, Ys; const float* W; const float* b; float* Yg; int act; };      // X, X2, Ys: LDS float offsets (X2 < 0: none)
+// ---- a stage = up to four independent layers over the slab; their tiles are dealt round-robin to the 16 waves -----------
+// (independent layers share a stage — Q(s, a)'s forward rides along with the target chain's — because a stage costs a
+// workgroup barrier and one L2 round trip for the weights whatever it computes)
+struct FwdItem {
+  int X, ldx, X2, ldx2, K, K1, N;          // input slab(s) in LDS (float offsets; X2 < 0: none), reduction, outputs
+  const float* W; const float* b;
+  int Ys, ldy; float* Yg; int ldyg;        // output slab in LDS, optional copy in global memory
+  int act; float lo, hi;
+};
+__device__ __forceinline__ FwdItem fwd_item(int X, int ldx, int X2, int ldx2, int K, int K1, int N, const float* W, const float* b, int Ys,
+                                            int ldy, float* Yg, int ldyg, int act, float lo = 0.0f, float hi = 0.0f) {
+  return FwdItem{X, ldx, X2, ldx2, K, K1, N, W, b, Ys, ldy, Yg, ldyg, act, lo, hi};
+}
 
-__device__ __forceinline__ void fwd_stage(float* lds, const FwdItem& i0, const FwdItem& i1, int ni, int ldx, int ldx2, int K, int K1,
-                                          int N, float lo, float hi, int ldy, int ldyg, int row0, int nrows) {
+template <int NI>
+__device__ __forceinline__ void fwd_stage(float* lds, const FwdItem (&it)[NI], int row0, int nrows) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
-  const int ntiles = (N + 15) >> 4;
-  for (int t = wave; t < ni * ntiles; t += kWaves) {
-    const bool second = t >= ntiles;
-    const int nb = (second ? t - ntiles : t) * 16;
-    const int X = second ? i1.X : i0.X, X2 = second ? i1.X2 : i0.X2, Ys = second ? i1.Ys : i0.Ys;
-    const float* W = second ? i1.W : i0.W;
-    const float* bias = second ? i1.b : i0.b;
-    float* Yg = second ? i1.Yg : i0.Yg;
-    const int act = second ? i1.act : i0.act;
-    const f32x4 acc = lin::tile_fwd(lds + X, ldx, X2 >= 0 ? lds + X2 : nullptr, ldx2, K, K1, W, N, nb, lane);
-    const int n = nb + r;
-    if (n < N) {
-      const float bv = bias ? bias[n] : 0.0f;
+  int g0 = 0;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int row = 4 * q + g;
-        const float y = act_fwd(acc[g] + bv, act, lo, hi);
-        lds[Ys + row * ldy + n] = y;
-        if (Yg && row < nrows) Yg[(size_t)(row0 + row) * ldyg + n] = y;
+  for (int i = 0; i < NI; ++i) {
+    const FwdItem& I = it[i];
+    const int ntiles = (I.N + 15) >> 4;
+    for (int t = (wave - g0) & (kWaves - 1); t < ntiles; t += kWaves) {
+      const int nb = t * 16;
+      const f32x4 acc = lin::tile_fwd(lds + I.X, I.ldx, I.X2 >= 0 ? lds + I.X2 : nullptr, I.ldx2, I.K, I.K1, I.W, I.N, nb, lane);
+      const int n = nb + r;
+      if (n < I.N) {
+        const float bv = I.b ? I.b[n] : 0.0f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 4 * q + g;
+          const float y = act_fwd(acc[g] + bv, I.act, I.lo, I.hi);
+          lds[I.Ys + row * I.ldy + n] = y;
+          if (I.Yg && row < nrows) I.Yg[(size_t)(row0 + row) * I.ldyg + n] = y;
+        }
       }
     }
+    g0 += ntiles;
   }
 }
 
-// dX = sum over the items of dZ_i . W_i (sum != 0: ONE output, the items' reductions run on in order — the gradient of an
-// input two layers share) or one output per item; then dL/dz of the layer below = dX * act'(its saved output Hs).
-struct BwdItem { int dZ; const float* W; int Hs, Out; float* Outg; };     // dZ, Hs, Out: LDS offsets (Hs < 0: no activation below; Out < 0: none)
+// dX = dZ . W (+ dZb . Wb: ONE accumulator running on over a second layer — the gradient of an input two layers share);
+// then dL/dz of the layer below = dX * act'(its saved output Hs).
+struct BwdItem {
+  int dZ, ldz, N; const float* W; int K;   // dZ slab in LDS, its width, the layer's weight [N][K]
+  int dZb; const float* Wb;                // optional second (dZ, W) pair of the same shape (dZb < 0: none)
+  int Hs, ldh, act_below;                  // saved output of the layer below in LDS (Hs < 0: no activation)
+  int Out, ldo; float* Outg; int ldog;     // dL/dz of the layer below: LDS slab (Out < 0: none) and / or global
+};
 
-__device__ __forceinline__ void bwd_stage(float* lds, const BwdItem& i0, const BwdItem& i1, int ni, bool sum, int ldz, int N, int K,
-                                          int act_below, int ldh, int ldo, int ldog, int row0, int nrows) {
+template <int NI>
+__device__ __forceinline__ void bwd_stage(float* lds, const BwdItem (&it)[NI], int row0, int nrows) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
-  const int ktiles = (K + 15) >> 4;
-  const int total = (sum ? 1 : ni) * ktiles;
-  for (int t = wave; t < total; t += kWaves) {
-    const bool second = t >= ktiles;
-    const int kb = (second ? t - ktiles : t) * 16;
-    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (sum) {
-      acc = lin::tile_bwd_input(acc, lds + i0.dZ, ldz, N, i0.W, K, kb, lane);
-      if (ni > 1) acc = lin::tile_bwd_input(acc, lds + i1.dZ, ldz, N, i1.W, K, kb, lane);
-    } else {
-      acc = lin::tile_bwd_input(acc, lds + (second ? i1.dZ : i0.dZ), ldz, N, second ? i1.W : i0.W, K, kb, lane);
-    }
-    const int Hs = second ? i1.Hs : i0.Hs, Out = second ? i1.Out : i0.Out;
-    float* Outg = second ? i1.Outg : i0.Outg;
-    const int kc = kb + r;
-    if (kc < K) {
+  int g0 = 0;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int row = 4 * q + g;
-        float v = acc[g];
-        if (Hs >= 0) v = v * act_bwd(lds[Hs + row * ldh + kc], act_below, 0.0f, 0.0f);
-        if (Out >= 0) lds[Out + row * ldo + kc] = v;
-        if (Outg && row < nrows) Outg[(size_t)(row0 + row) * ldog + kc] = v;
+  for (int i = 0; i < NI; ++i) {
+    const BwdItem& I = it[i];
+    const int ktiles = (I.K + 15) >> 4;
+    for (int t = (wave - g0) & (kWaves - 1); t < ktiles; t += kWaves) {
+      const int kb = t * 16;
+      f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+      acc = lin::tile_bwd_input(acc, lds + I.dZ, I.ldz, I.N, I.W, I.K, kb, lane);
+      if (I.dZb >= 0) acc = lin::tile_bwd_input(acc, lds + I.dZb, I.ldz, I.N, I.Wb, I.K, kb, lane);
+      const int kc = kb + r;
+      if (kc < I.K) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 4 * q + g;
+          float v = acc[g];
+          if (I.Hs >= 0) v = v * act_bwd(lds[I.Hs + row * I.ldh + kc], I.act_below, 0.0f, 0.0f);
+          if (I.Out >= 0) lds[I.Out + row * I.ldo + kc] = v;
+          if (I.Outg && row < nrows) I.Outg[(size_t)(row0 + row) * I.ldog + kc] = v;
+        }
       }
     }
+    g0 += ktiles;
   }
 }
 
@@ -143,16 +165,16 @@ __device__ __forceinline__ void sample_row(const float* mean, const float* log_s
 }
 
 struct Lds {                          // float offsets of the small per-row slabs, then the [16][ld] activation slabs
-  int S, S2, A, A2, Mean, Ls, Eps, Q0, Q1, Dq0, Dq1, Misc, big;
+  int S, S2, A, A2, Mean, Ls, Eps, Q0, Q1, Cq0, Cq1, Dq0, Dq1, Misc, big;
   __device__ Lds() {
     int o = 0;
     S = o; o += 16 * kMaxD; S2 = o; o += 16 * kMaxD; A = o; o += 16 * kMaxA; A2 = o; o += 16 * kMaxA;
     Mean = o; o += 16 * kMaxA; Ls = o; o += 16 * kMaxA; Eps = o; o += 16 * kMaxA;
-    Q0 = o; o += 16 * 4; Q1 = o; o += 16 * 4; Dq0 = o; o += 16 * 4; Dq1 = o; o += 16 * 4; Misc = o; o += 16 * 4;
+    Q0 = o; o += 16 * 4; Q1 = o; o += 16 * 4; Cq0 = o; o += 16 * 4; Cq1 = o; o += 16 * 4; Dq0 = o; o += 16 * 4; Dq1 = o; o += 16 * 4; Misc = o; o += 16 * 4;
     big = o;
   }
 };
-constexpr int kSmallFloats = 16 * (2 * kMaxD + 5 * kMaxA + 5 * 4);
+constexpr int kSmallFloats = 16 * (2 * kMaxD + 5 * kMaxA + 7 * 4);
 
 // ======================================================================================================== P1 =====
 __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update_args a, const SacWs ws) {
@@ -160,8 +182,10 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
   const Lds L;
   const int D = a.D, A = a.A, H = a.H, ld = lin::slab_ld(H);
   const int X0 = L.big, X1 = X0 + 16 * ld, H1a = X1 + 16 * ld, H1b = H1a + 16 * ld, H2a = H1b + 16 * ld, H2b = H2a + 16 * ld;
+  const int T2a = H2b + 16 * ld, T2b = T2a + 16 * ld;
   const int row0 = blockIdx.x * 16, nrows = min(16, a.B - row0);
   const int t = threadIdx.x;
+  STEP_MARK(0, 0);
   // ---- 0: index draw + ring gather (one thread per row; rows beyond the batch are zero) ----
   if (t < 16) {
     const int b = row0 + t;
@@ -195,51 +219,70 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
     lds[L.Misc + t * 4 + 1] = ok ? (float)a.r_flag[row] : 0.0f;          // dones become float32 (dqn_cartpole.py:155)
   }
   __syncthreads();
-  const FwdItem none{0, -1, 0, nullptr, nullptr, nullptr, GYMRL_ACT_NONE};
-  // ---- 1-4: a', logp' = Actor.sample(s') (:233-234) ----
-  fwd_stage(lds, FwdItem{L.S2, -1, X0, a.actor.w[0], a.actor.b[0], nullptr, GYMRL_ACT_RELU}, none, 1, kMaxD, 0, D, D, H, 0.f, 0.f, ld, 0, row0, nrows);
+  STEP_MARK(0, 1);
+  const int R = GYMRL_ACT_RELU, NA = GYMRL_ACT_NONE, kD = kMaxD, kA = kMaxA;
+  // ---- 1-3: the actor on s' (:233), and — independent of it — Q(s, a) of both networks (:239) in the same stages ----
+  {
+    const FwdItem st[3] = {fwd_item(L.S2, kD, -1, 0, D, D, H, a.actor.w[0], a.actor.b[0], X0, ld, nullptr, 0, R),
+                           fwd_item(L.S, kD, L.A, kA, D + A, D, H, a.critic.w[0], a.critic.b[0], H1a, ld, ws.H1[0], H, R),
+                           fwd_item(L.S, kD, L.A, kA, D + A, D, H, a.critic.w[3], a.critic.b[3], H1b, ld, ws.H1[1], H, R)};
+    fwd_stage<3>(lds, st, row0, nrows);
+  }
   __syncthreads();
-  fwd_stage(lds, FwdItem{X0, -1, X1, a.actor.w[1], a.actor.b[1], nullptr, GYMRL_ACT_RELU}, none, 1, ld, 0, H, H, H, 0.f, 0.f, ld, 0, row0, nrows);
+  STEP_MARK(0, 2);
+  {
+    const FwdItem st[3] = {fwd_item(X0, ld, -1, 0, H, H, H, a.actor.w[1], a.actor.b[1], X1, ld, nullptr, 0, R),
+                           fwd_item(H1a, ld, -1, 0, H, H, H, a.critic.w[1], a.critic.b[1], H2a, ld, ws.H2[0], H, R),
+                           fwd_item(H1b, ld, -1, 0, H, H, H, a.critic.w[4], a.critic.b[4], H2b, ld, ws.H2[1], H, R)};
+    fwd_stage<3>(lds, st, row0, nrows);
+  }
   __syncthreads();
-  fwd_stage(lds, FwdItem{X1, -1, L.Mean, a.actor.w[2], a.actor.b[2], nullptr, GYMRL_ACT_NONE},
-            FwdItem{X1, -1, L.Ls, a.actor.w[3], a.actor.b[3], nullptr, GYMRL_ACT_CLAMP}, 2, ld, 0, H, H, A, a.log_std_min, a.log_std_max, kMaxA, 0, row0, nrows);
+  STEP_MARK(0, 3);
+  {
+    const FwdItem st[4] = {fwd_item(X1, ld, -1, 0, H, H, A, a.actor.w[2], a.actor.b[2], L.Mean, kA, nullptr, 0, NA),
+                           fwd_item(X1, ld, -1, 0, H, H, A, a.actor.w[3], a.actor.b[3], L.Ls, kA, nullptr, 0, GYMRL_ACT_CLAMP, a.log_std_min, a.log_std_max),
+                           fwd_item(H2a, ld, -1, 0, H, H, 1, a.critic.w[2], a.critic.b[2], L.Cq0, 4, nullptr, 0, NA),
+                           fwd_item(H2b, ld, -1, 0, H, H, 1, a.critic.w[5], a.critic.b[5], L.Cq1, 4, nullptr, 0, NA)};
+    fwd_stage<4>(lds, st, row0, nrows);
+  }
   __syncthreads();
-  if (t < 16) {
+  STEP_MARK(0, 4);
+  if (t < 16) {                         // a', logp' (:234)
     float lp;
     sample_row(lds + L.Mean + t * kMaxA, lds + L.Ls + t * kMaxA, lds + L.Eps + t * kMaxA, A, a.bound, lds + L.A2 + t * kMaxA, lp);
     lds[L.Misc + t * 4 + 2] = lp;
   }
   __syncthreads();
-  // ---- 5-8: target Q(s', a') of both networks, y (:235-237) ----
-  fwd_stage(lds, FwdItem{L.S2, L.A2, H1a, a.target.w[0], a.target.b[0], nullptr, GYMRL_ACT_RELU},
-            FwdItem{L.S2, L.A2, H1b, a.target.w[3], a.target.b[3], nullptr, GYMRL_ACT_RELU}, 2, kMaxD, kMaxA, D + A, D, H, 0.f, 0.f, ld, 0, row0, nrows);
-  __syncthreads();
-  fwd_stage(lds, FwdItem{H1a, -1, H2a, a.target.w[1], a.target.b[1], nullptr, GYMRL_ACT_RELU},
-            FwdItem{H1b, -1, H2b, a.target.w[4], a.target.b[4], nullptr, GYMRL_ACT_RELU}, 2, ld, 0, H, H, H, 0.f, 0.f, ld, 0, row0, nrows);
-  __syncthreads();
-  fwd_stage(lds, FwdItem{H2a, -1, L.Q0, a.target.w[2], a.target.b[2], nullptr, GYMRL_ACT_NONE},
-            FwdItem{H2b, -1, L.Q1, a.target.w[5], a.target.b[5], nullptr, GYMRL_ACT_NONE}, 2, ld, 0, H, H, 1, 0.f, 0.f, 4, 0, row0, nrows);
-  __syncthreads();
-  if (t < 16) {                         // offpolicy.hip sac_target_kernel
-    const float alpha = (float)exp(a.log_alpha[0]);
-    const float tq = fminf(lds[L.Q0 + t * 4], lds[L.Q1 + t * 4]) - alpha * lds[L.Misc + t * 4 + 2];
-    lds[L.Misc + t * 4 + 3] = lds[L.Misc + t * 4 + 0] + a.gamma * (1.0f - lds[L.Misc + t * 4 + 1]) * tq;
+  STEP_MARK(0, 5);
+  // ---- 4-6: target Q(s', a') of both networks (:235-236) ----
+  {
+    const FwdItem st[2] = {fwd_item(L.S2, kD, L.A2, kA, D + A, D, H, a.target.w[0], a.target.b[0], X0, ld, nullptr, 0, R),
+                           fwd_item(L.S2, kD, L.A2, kA, D + A, D, H, a.target.w[3], a.target.b[3], X1, ld, nullptr, 0, R)};
+    fwd_stage<2>(lds, st, row0, nrows);
   }
   __syncthreads();
-  // ---- 9-12: Q(s, a) of both networks, critic loss gradient (:239-241) ----
-  fwd_stage(lds, FwdItem{L.S, L.A, H1a, a.critic.w[0], a.critic.b[0], ws.H1[0], GYMRL_ACT_RELU},
-            FwdItem{L.S, L.A, H1b, a.critic.w[3], a.critic.b[3], ws.H1[1], GYMRL_ACT_RELU}, 2, kMaxD, kMaxA, D + A, D, H, 0.f, 0.f, ld, H, row0, nrows);
+  STEP_MARK(0, 6);
+  {
+    const FwdItem st[2] = {fwd_item(X0, ld, -1, 0, H, H, H, a.target.w[1], a.target.b[1], T2a, ld, nullptr, 0, R),
+                           fwd_item(X1, ld, -1, 0, H, H, H, a.target.w[4], a.target.b[4], T2b, ld, nullptr, 0, R)};
+    fwd_stage<2>(lds, st, row0, nrows);
+  }
   __syncthreads();
-  fwd_stage(lds, FwdItem{H1a, -1, H2a, a.critic.w[1], a.critic.b[1], ws.H2[0], GYMRL_ACT_RELU},
-            FwdItem{H1b, -1, H2b, a.critic.w[4], a.critic.b[4], ws.H2[1], GYMRL_ACT_RELU}, 2, ld, 0, H, H, H, 0.f, 0.f, ld, H, row0, nrows);
+  STEP_MARK(0, 7);
+  {
+    const FwdItem st[2] = {fwd_item(T2a, ld, -1, 0, H, H, 1, a.target.w[2], a.target.b[2], L.Q0, 4, nullptr, 0, NA),
+                           fwd_item(T2b, ld, -1, 0, H, H, 1, a.target.w[5], a.target.b[5], L.Q1, 4, nullptr, 0, NA)};
+    fwd_stage<2>(lds, st, row0, nrows);
+  }
   __syncthreads();
-  fwd_stage(lds, FwdItem{H2a, -1, L.Q0, a.critic.w[2], a.critic.b[2], nullptr, GYMRL_ACT_NONE},
-            FwdItem{H2b, -1, L.Q1, a.critic.w[5], a.critic.b[5], nullptr, GYMRL_ACT_NONE}, 2, ld, 0, H, H, 1, 0.f, 0.f, 4, 0, row0, nrows);
-  __syncthreads();
-  if (t < 16) {                         // offpolicy.hip sac_critic_kernel
+  STEP_MARK(0, 8);
+  if (t < 16) {
+    // y (:237; offpolicy.hip sac_target_kernel), then the critic loss gradient (:240-241; sac_critic_kernel)
+    const float alpha = (float)exp(a.log_alpha[0]);
+    const float tq = fminf(lds[L.Q0 + t * 4], lds[L.Q1 + t * 4]) - alpha * lds[L.Misc + t * 4 + 2];
+    const float y = lds[L.Misc + t * 4 + 0] + a.gamma * (1.0f - lds[L.Misc + t * 4 + 1]) * tq;
     const float invB = 1.0f / (float)a.B;
-    const float y = lds[L.Misc + t * 4 + 3];
-    const float e1 = lds[L.Q0 + t * 4] - y, e2 = lds[L.Q1 + t * 4] - y;
+    const float e1 = lds[L.Cq0 + t * 4] - y, e2 = lds[L.Cq1 + t * 4] - y;
     const float d1 = 2.0f * e1 * invB, d2 = 2.0f * e2 * invB;
     for (int k = 0; k < 4; ++k) { lds[L.Dq0 + t * 4 + k] = k == 0 ? d1 : 0.0f; lds[L.Dq1 + t * 4 + k] = k == 0 ? d2 : 0.0f; }
     if (t < nrows) {
@@ -248,12 +291,21 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
     }
   }
   __syncthreads();
-  // ---- 13-14: input-gradient chain of both Q networks (what q.backward() computes before the weight gradients) ----
-  bwd_stage(lds, BwdItem{L.Dq0, a.critic.w[2], H2a, X0, ws.Z2[0]}, BwdItem{L.Dq1, a.critic.w[5], H2b, X1, ws.Z2[1]}, 2, false, 4, 1, H,
-            GYMRL_ACT_RELU, ld, ld, H, row0, nrows);
+  STEP_MARK(0, 9);
+  // ---- 7-8: input-gradient chain of both Q networks (what q.backward() computes before the weight gradients) ----
+  {
+    const BwdItem st[2] = {BwdItem{L.Dq0, 4, 1, a.critic.w[2], H, -1, nullptr, H2a, ld, R, X0, ld, ws.Z2[0], H},
+                           BwdItem{L.Dq1, 4, 1, a.critic.w[5], H, -1, nullptr, H2b, ld, R, X1, ld, ws.Z2[1], H}};
+    bwd_stage<2>(lds, st, row0, nrows);
+  }
   __syncthreads();
-  bwd_stage(lds, BwdItem{X0, a.critic.w[1], H1a, -1, ws.Z1[0]}, BwdItem{X1, a.critic.w[4], H1b, -1, ws.Z1[1]}, 2, false, ld, H, H,
-            GYMRL_ACT_RELU, ld, ld, H, row0, nrows);
+  STEP_MARK(0, 10);
+  {
+    const BwdItem st[2] = {BwdItem{X0, ld, H, a.critic.w[1], H, -1, nullptr, H1a, ld, R, -1, 0, ws.Z1[0], H},
+                           BwdItem{X1, ld, H, a.critic.w[4], H, -1, nullptr, H1b, ld, R, -1, 0, ws.Z1[1], H}};
+    bwd_stage<2>(lds, st, row0, nrows);
+  }
+  STEP_MARK(0, 11);
 }
 
 // ======================================================================================================== P3 =====
@@ -265,6 +317,7 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
   const int AH1 = H2b + 16 * ld, AH2 = AH1 + 16 * ld;
   const int row0 = blockIdx.x * 16, nrows = min(16, a.B - row0);
   const int t = threadIdx.x;
+  STEP_MARK(1, 0);
   if (t < 16) {
     const int b = row0 + t;
     const bool ok = t < nrows;
@@ -277,31 +330,57 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
     }
   }
   __syncthreads();
-  const FwdItem none{0, -1, 0, nullptr, nullptr, nullptr, GYMRL_ACT_NONE};
+  STEP_MARK(1, 1);
+  const int R = GYMRL_ACT_RELU, NA = GYMRL_ACT_NONE, kD = kMaxD, kA = kMaxA;
   // ---- a, logp = Actor.sample(s) (:248) ----
-  fwd_stage(lds, FwdItem{L.S, -1, AH1, a.actor.w[0], a.actor.b[0], ws.aH1, GYMRL_ACT_RELU}, none, 1, kMaxD, 0, D, D, H, 0.f, 0.f, ld, H, row0, nrows);
+  {
+    const FwdItem st[1] = {fwd_item(L.S, kD, -1, 0, D, D, H, a.actor.w[0], a.actor.b[0], AH1, ld, ws.aH1, H, R)};
+    fwd_stage<1>(lds, st, row0, nrows);
+  }
   __syncthreads();
-  fwd_stage(lds, FwdItem{AH1, -1, AH2, a.actor.w[1], a.actor.b[1], ws.aH2, GYMRL_ACT_RELU}, none, 1, ld, 0, H, H, H, 0.f, 0.f, ld, H, row0, nrows);
+  STEP_MARK(1, 2);
+  {
+    const FwdItem st[1] = {fwd_item(AH1, ld, -1, 0, H, H, H, a.actor.w[1], a.actor.b[1], AH2, ld, ws.aH2, H, R)};
+    fwd_stage<1>(lds, st, row0, nrows);
+  }
   __syncthreads();
-  fwd_stage(lds, FwdItem{AH2, -1, L.Mean, a.actor.w[2], a.actor.b[2], nullptr, GYMRL_ACT_NONE},
-            FwdItem{AH2, -1, L.Ls, a.actor.w[3], a.actor.b[3], nullptr, GYMRL_ACT_CLAMP}, 2, ld, 0, H, H, A, a.log_std_min, a.log_std_max, kMaxA, 0, row0, nrows);
+  STEP_MARK(1, 3);
+  {
+    const FwdItem st[2] = {fwd_item(AH2, ld, -1, 0, H, H, A, a.actor.w[2], a.actor.b[2], L.Mean, kA, nullptr, 0, NA),
+                           fwd_item(AH2, ld, -1, 0, H, H, A, a.actor.w[3], a.actor.b[3], L.Ls, kA, nullptr, 0, GYMRL_ACT_CLAMP, a.log_std_min, a.log_std_max)};
+    fwd_stage<2>(lds, st, row0, nrows);
+  }
   __syncthreads();
+  STEP_MARK(1, 4);
   if (t < 16) {
     float lp;
     sample_row(lds + L.Mean + t * kMaxA, lds + L.Ls + t * kMaxA, lds + L.Eps + t * kMaxA, A, a.bound, lds + L.A + t * kMaxA, lp);
     lds[L.Misc + t * 4 + 2] = lp;
   }
   __syncthreads();
+  STEP_MARK(1, 5);
   // ---- Q(s, a) of the critic P2 has just updated (:249-250) ----
-  fwd_stage(lds, FwdItem{L.S, L.A, H1a, a.critic.w[0], a.critic.b[0], nullptr, GYMRL_ACT_RELU},
-            FwdItem{L.S, L.A, H1b, a.critic.w[3], a.critic.b[3], nullptr, GYMRL_ACT_RELU}, 2, kMaxD, kMaxA, D + A, D, H, 0.f, 0.f, ld, 0, row0, nrows);
+  {
+    const FwdItem st[2] = {fwd_item(L.S, kD, L.A, kA, D + A, D, H, a.critic.w[0], a.critic.b[0], H1a, ld, nullptr, 0, R),
+                           fwd_item(L.S, kD, L.A, kA, D + A, D, H, a.critic.w[3], a.critic.b[3], H1b, ld, nullptr, 0, R)};
+    fwd_stage<2>(lds, st, row0, nrows);
+  }
   __syncthreads();
-  fwd_stage(lds, FwdItem{H1a, -1, H2a, a.critic.w[1], a.critic.b[1], nullptr, GYMRL_ACT_RELU},
-            FwdItem{H1b, -1, H2b, a.critic.w[4], a.critic.b[4], nullptr, GYMRL_ACT_RELU}, 2, ld, 0, H, H, H, 0.f, 0.f, ld, 0, row0, nrows);
+  STEP_MARK(1, 6);
+  {
+    const FwdItem st[2] = {fwd_item(H1a, ld, -1, 0, H, H, H, a.critic.w[1], a.critic.b[1], H2a, ld, nullptr, 0, R),
+                           fwd_item(H1b, ld, -1, 0, H, H, H, a.critic.w[4], a.critic.b[4], H2b, ld, nullptr, 0, R)};
+    fwd_stage<2>(lds, st, row0, nrows);
+  }
   __syncthreads();
-  fwd_stage(lds, FwdItem{H2a, -1, L.Q0, a.critic.w[2], a.critic.b[2], nullptr, GYMRL_ACT_NONE},
-            FwdItem{H2b, -1, L.Q1, a.critic.w[5], a.critic.b[5], nullptr, GYMRL_ACT_NONE}, 2, ld, 0, H, H, 1, 0.f, 0.f, 4, 0, row0, nrows);
+  STEP_MARK(1, 7);
+  {
+    const FwdItem st[2] = {fwd_item(H2a, ld, -1, 0, H, H, 1, a.critic.w[2], a.critic.b[2], L.Q0, 4, nullptr, 0, NA),
+                           fwd_item(H2b, ld, -1, 0, H, H, 1, a.critic.w[5], a.critic.b[5], L.Q1, 4, nullptr, 0, NA)};
+    fwd_stage<2>(lds, st, row0, nrows);
+  }
   __syncthreads();
+  STEP_MARK(1, 8);
   float dlogp = 0.0f;
   if (t < 16) {                         // offpolicy.hip sac_actor_kernel
     const float invB = 1.0f / (float)a.B;
@@ -317,13 +396,22 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
     }
   }
   __syncthreads();
+  STEP_MARK(1, 9);
   // ---- back through both Q networks to the action (their parameters are frozen here: no weight gradients) ----
-  bwd_stage(lds, BwdItem{L.Dq0, a.critic.w[2], H2a, X0, nullptr}, BwdItem{L.Dq1, a.critic.w[5], H2b, X1, nullptr}, 2, false, 4, 1, H,
-            GYMRL_ACT_RELU, ld, ld, 0, row0, nrows);
+  {
+    const BwdItem st[2] = {BwdItem{L.Dq0, 4, 1, a.critic.w[2], H, -1, nullptr, H2a, ld, R, X0, ld, nullptr, 0},
+                           BwdItem{L.Dq1, 4, 1, a.critic.w[5], H, -1, nullptr, H2b, ld, R, X1, ld, nullptr, 0}};
+    bwd_stage<2>(lds, st, row0, nrows);
+  }
   __syncthreads();
-  bwd_stage(lds, BwdItem{X0, a.critic.w[1], H1a, H2a, nullptr}, BwdItem{X1, a.critic.w[4], H1b, H2b, nullptr}, 2, false, ld, H, H,
-            GYMRL_ACT_RELU, ld, ld, 0, row0, nrows);
+  STEP_MARK(1, 10);
+  {
+    const BwdItem st[2] = {BwdItem{X0, ld, H, a.critic.w[1], H, -1, nullptr, H1a, ld, R, H2a, ld, nullptr, 0},
+                           BwdItem{X1, ld, H, a.critic.w[4], H, -1, nullptr, H1b, ld, R, H2b, ld, nullptr, 0}};
+    bwd_stage<2>(lds, st, row0, nrows);
+  }
   __syncthreads();
+  STEP_MARK(1, 11);
   // d action = the action columns of (dZ1_Q1 . W1_Q1 + dZ1_Q2 . W1_Q2): ONE accumulator over both networks (the layers share their input)
   {
     const int lane = t & 63, wave = t >> 6, r = lane & 15, q = lane >> 4;
@@ -338,6 +426,7 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
     }
   }
   __syncthreads();
+  STEP_MARK(1, 12);
   if (t < 16) {                         // offpolicy.hip sac_sample_bwd_kernel, then the heads' dL/dz (log_std through its clamp)
     for (int j = 0; j < kMaxA; ++j) {
       float dm = 0.0f, dl = 0.0f;
@@ -357,12 +446,19 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
     }
   }
   __syncthreads();
+  STEP_MARK(1, 13);
   // ---- back through the actor: heads (one summed input gradient), fc2 ----
-  bwd_stage(lds, BwdItem{L.Dq0, a.actor.w[2], AH2, X0, ws.aZ2}, BwdItem{L.Dq1, a.actor.w[3], AH2, X0, ws.aZ2}, 2, true, 4, A, H,
-            GYMRL_ACT_RELU, ld, ld, H, row0, nrows);
+  {
+    const BwdItem st[1] = {BwdItem{L.Dq0, 4, A, a.actor.w[2], H, L.Dq1, a.actor.w[3], AH2, ld, R, X0, ld, ws.aZ2, H}};
+    bwd_stage<1>(lds, st, row0, nrows);
+  }
   __syncthreads();
-  const BwdItem nob{0, nullptr, -1, -1, nullptr};
-  bwd_stage(lds, BwdItem{X0, a.actor.w[1], AH1, -1, ws.aZ1}, nob, 1, false, ld, H, H, GYMRL_ACT_RELU, ld, ld, H, row0, nrows);
+  STEP_MARK(1, 14);
+  {
+    const BwdItem st[1] = {BwdItem{X0, ld, H, a.actor.w[1], H, -1, nullptr, AH1, ld, R, -1, 0, ws.aZ1, H}};
+    bwd_stage<1>(lds, st, row0, nrows);
+  }
+  STEP_MARK(1, 15);
 }
 
 // ================================================================================================= P2 / P4 =====
@@ -466,6 +562,7 @@ __global__ __launch_bounds__(kThreads) void sac_act_kernel(const gymrl_sac_act_a
   const int X0 = L.big, X1 = X0 + 16 * ld;
   const int row0 = blockIdx.x * 16, nrows = min(16, a.N - row0);
   const int t = threadIdx.x;
+  STEP_MARK(2, 0);
   if (t < 16) {
     const int i = row0 + t;
     const bool ok = t < nrows;
@@ -478,14 +575,27 @@ __global__ __launch_bounds__(kThreads) void sac_act_kernel(const gymrl_sac_act_a
     }
   }
   __syncthreads();
-  const FwdItem none{0, -1, 0, nullptr, nullptr, nullptr, GYMRL_ACT_NONE};
-  fwd_stage(lds, FwdItem{L.S, -1, X0, a.actor.w[0], a.actor.b[0], nullptr, GYMRL_ACT_RELU}, none, 1, kMaxD, 0, D, D, H, 0.f, 0.f, ld, 0, row0, nrows);
+  STEP_MARK(2, 1);
+  const int R = GYMRL_ACT_RELU, kD = kMaxD, kA = kMaxA;
+  {
+    const FwdItem st[1] = {fwd_item(L.S, kD, -1, 0, D, D, H, a.actor.w[0], a.actor.b[0], X0, ld, nullptr, 0, R)};
+    fwd_stage<1>(lds, st, row0, nrows);
+  }
   __syncthreads();
-  fwd_stage(lds, FwdItem{X0, -1, X1, a.actor.w[1], a.actor.b[1], nullptr, GYMRL_ACT_RELU}, none, 1, ld, 0, H, H, H, 0.f, 0.f, ld, 0, row0, nrows);
+  STEP_MARK(2, 2);
+  {
+    const FwdItem st[1] = {fwd_item(X0, ld, -1, 0, H, H, H, a.actor.w[1], a.actor.b[1], X1, ld, nullptr, 0, R)};
+    fwd_stage<1>(lds, st, row0, nrows);
+  }
   __syncthreads();
-  fwd_stage(lds, FwdItem{X1, -1, L.Mean, a.actor.w[2], a.actor.b[2], nullptr, GYMRL_ACT_NONE},
-            FwdItem{X1, -1, L.Ls, a.actor.w[3], a.actor.b[3], nullptr, GYMRL_ACT_CLAMP}, 2, ld, 0, H, H, A, a.log_std_min, a.log_std_max, kMaxA, 0, row0, nrows);
+  STEP_MARK(2, 3);
+  {
+    const FwdItem st[2] = {fwd_item(X1, ld, -1, 0, H, H, A, a.actor.w[2], a.actor.b[2], L.Mean, kA, nullptr, 0, GYMRL_ACT_NONE),
+                           fwd_item(X1, ld, -1, 0, H, H, A, a.actor.w[3], a.actor.b[3], L.Ls, kA, nullptr, 0, GYMRL_ACT_CLAMP, a.log_std_min, a.log_std_max)};
+    fwd_stage<2>(lds, st, row0, nrows);
+  }
   __syncthreads();
+  STEP_MARK(2, 4);
   // one lane per env: draw, Pendulum step with auto-reset, replay row (the first wave: 16 lanes busy)
   if (t < 64) {
     const bool ok = t < nrows;
@@ -516,6 +626,7 @@ __global__ __launch_bounds__(kThreads) void sac_act_kernel(const gymrl_sac_act_a
     }
     accumulate_ep_stats(a.ep_stats, r.done && ok, r.ret, r.len);
   }
+  STEP_MARK(2, 5);
 }
 
 inline bool sac_shape_ok(int B, int D, int A, int H) {
@@ -531,6 +642,12 @@ size_t gymrl_sac_update_workspace_bytes(int B, int D, int A, int H) {
   if (B <= 0 || D <= 0 || A <= 0 || H <= 0) return 0;
   return SacWs::carve(nullptr, nullptr, B, D, A, H) + 256;
 }
+
+#ifdef GYMRL_PROF_BUILD
+int gymrl_step_prof_read(long long* out_host) {      // probe build only: [3][32] stamps of the last launches (workgroup 0)
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_step_prof), sizeof(long long) * 96) == hipSuccess ? 0 : -1;
+}
+#endif
 
 size_t gymrl_sac_args_bytes(int which) { return which == 0 ? sizeof(gymrl_sac_act_args) : which == 1 ? sizeof(gymrl_sac_update_args) : 0; }
 
@@ -563,7 +680,7 @@ int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)sac_p1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(256, 6)) != hipSuccess ||
+    if (hipFuncSetAttribute((const void*)sac_p1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(256, 8)) != hipSuccess ||
         hipFuncSetAttribute((const void*)sac_p3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(256, 8)) != hipSuccess)
       return -1000 - (int)hipGetLastError();
     attr_set = true;
@@ -574,7 +691,7 @@ int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream_) {
   const int B = a.B, D = a.D, A = a.A, H = a.H, slabs = (B + 15) / 16;
   auto tiles = [](int N, int K) { return ((N + 15) / 16) * ((K + 15) / 16); };
 
-  hipLaunchKernelGGL(sac_p1_kernel, dim3(slabs), dim3(kThreads), lds_bytes(H, 6), stream, a, ws);
+  hipLaunchKernelGGL(sac_p1_kernel, dim3(slabs), dim3(kThreads), lds_bytes(H, 8), stream, a, ws);
 
   DwArgs c{};
   int w0 = 0, ns = 0;

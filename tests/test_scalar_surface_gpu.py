@@ -123,7 +123,7 @@ def test_ppo_surface_at_one_env():
     assert np.allclose(ret - adv, tr.buffer.values[:, 0].cpu().numpy(), atol=1e-5)
     metrics = tr.update(next_value)
     assert set(metrics) == {"policy_loss", "value_loss", "entropy", "clip_frac", "approx_kl"}
-    assert all(type(v) is float and np.isfinite(v) for v in metrics.values())
+    assert all(isinstance(v, float) and np.isfinite(v) for v in metrics.values())      # np.mean's float64, as in the reference (:323-329)
     assert tr.step_count == 128 and isinstance(tr.episode_rewards, type(tr.episode_rewards)) and tr.episode_rewards.maxlen == 100
     # engine path unchanged: N > 1 keeps device tensors
     cfg2 = Config()
