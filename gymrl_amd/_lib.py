@@ -51,7 +51,7 @@ SYMBOLS = [
     "gymrl_mhc_read_fwd", "gymrl_mhc_read_bwd", "gymrl_mhc_combine_bwd",
     "gymrl_mhc_gates_bwd_workspace_bytes", "gymrl_mhc_gates_bwd", "gymrl_rmsnorm_bwd_workspace_bytes", "gymrl_rmsnorm_bwd",
     "gymrl_mhc_policy_forward", "gymrl_mhc_sub_forward", "gymrl_rollout_lunar_mhc",
-    "gymrl_sac_update_workspace_bytes", "gymrl_sac_args_bytes", "gymrl_sac_act_step", "gymrl_sac_update",
+    "gymrl_sac_update_workspace_bytes", "gymrl_sac_args_bytes", "gymrl_sac_act_step", "gymrl_sac_update", "gymrl_sac_pack_images",
 ]
 
 
@@ -148,7 +148,7 @@ class SacActArgs(C.Structure):            # gymrl_sac_act_args (include/gymrl.h)
                 ("r_state", C.c_void_p), ("r_action", C.c_void_p), ("r_reward", C.c_void_p), ("r_next", C.c_void_p),
                 ("r_flag", C.c_void_p), ("cap", C.c_int64), ("cursor", C.c_int64), ("cursor_dev", C.c_void_p),
                 ("action_out", C.c_void_p), ("rew_out", C.c_void_p), ("done_out", C.c_void_p), ("ep_ret_out", C.c_void_p),
-                ("ep_stats", C.c_void_p)]
+                ("ep_stats", C.c_void_p), ("images", C.c_void_p)]
 
 
 class SacUpdateArgs(C.Structure):         # gymrl_sac_update_args (include/gymrl.h), field for field
@@ -169,7 +169,7 @@ class SacUpdateArgs(C.Structure):         # gymrl_sac_update_args (include/gymrl
                 ("beta1", C.c_double), ("beta2", C.c_double), ("eps_adam", C.c_double),
                 ("log_alpha", C.c_void_p), ("alpha_m", C.c_void_p), ("alpha_v", C.c_void_p), ("lr_alpha", C.c_double),
                 ("alpha_bias", C.c_double * 2), ("alpha_bias_dev", C.c_void_p),
-                ("sums", C.c_void_p), ("alpha_loss", C.c_void_p), ("workspace", C.c_void_p)]
+                ("sums", C.c_void_p), ("alpha_loss", C.c_void_p), ("workspace", C.c_void_p), ("images", C.c_void_p)]
 
 
 class PPOFullCfg(C.Structure):

@@ -155,6 +155,69 @@ __device__ __forceinline__ f32x4 tile_bwd_input(f32x4 acc, const float* dZs, int
   return acc;
 }
 
+// ---- weight IMAGES for the square H x H layers (H % 16 == 0) ---------------------------------------------------------------
+// A slab kernel streams a layer's whole weight matrix through ONE compute unit, and from nn.Linear's row-major layout a
+// wave-wide 16-byte load touches sixteen 64-byte pieces of sixteen rows: 34 GB/s per CU, 8-9 us per 256 x 256 layer
+// (tools/probe_sac_stages.py).  An image stores, for every (output tile, reduction step), the MFMA B-operand exactly as the
+// 64 lanes hold it — one contiguous 1 KiB block per wave-wide load.  Two images per matrix: the forward operand
+// (lane (r, q) holds W[16t + r][16c + 4q .. + 3]) and the input-gradient operand (W[16c + 4q .. + 3][16t + r]).  The
+// weight-gradient kernel writes both next to the parameter it has just updated; gymrl_sac_pack_images rebuilds them after
+// anything else touched the parameters.  Same values in the same registers: the tiles stay bit-identical.
+__host__ __device__ __forceinline__ size_t img_fwd_index(int n, int k, int steps) {
+  return ((size_t)((n >> 4) * steps + (k >> 4)) * 64 + ((k & 15) >> 2) * 16 + (n & 15)) * 4 + (k & 3);
+}
+__host__ __device__ __forceinline__ size_t img_bwd_index(int n, int k, int steps) {
+  return ((size_t)((k >> 4) * steps + (n >> 4)) * 64 + ((n & 15) >> 2) * 16 + (k & 15)) * 4 + (n & 3);
+}
+
+// tile_fwd for K == N == 16 * steps from the forward image (K1 == K; same MFMA sequence as tile_fwd's vector branch)
+__device__ __forceinline__ f32x4 tile_fwd_img(const float* Xs, int ldx, int steps, const float* __restrict__ img, int tile, int lane) {
+  const int r = lane & 15, q = lane >> 4;
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  const f32x4* wp = reinterpret_cast<const f32x4*>(img) + (size_t)tile * steps * 64 + lane;
+  const float* xrow = Xs + r * ldx + 4 * q;
+  for (int cp = 0; cp < steps; cp += kMaxSteps) {
+    f32x4 wb[kMaxSteps];
+#pragma unroll
+    for (int c = 0; c < kMaxSteps; ++c) {
+      if (cp + c >= steps) break;                             // (wave-uniform)
+      wb[c] = wp[(size_t)(cp + c) * 64];
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxSteps; ++c) {
+      if (cp + c >= steps) break;
+      const f32x4 x = *reinterpret_cast<const f32x4*>(xrow + 16 * (cp + c));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = mfma16(x[e], wb[c][e], acc);
+    }
+  }
+  return acc;
+}
+
+// tile_bwd_input for K == N == 16 * steps from the input-gradient image
+__device__ __forceinline__ f32x4 tile_bwd_input_img(f32x4 acc, const float* dZs, int ldz, int steps, const float* __restrict__ img, int ktile,
+                                                    int lane) {
+  const int r = lane & 15, q = lane >> 4;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(img) + (size_t)ktile * steps * 64 + lane;
+  const float* zrow = dZs + r * ldz + 4 * q;
+  for (int cp = 0; cp < steps; cp += kMaxSteps) {
+    f32x4 wb[kMaxSteps];
+#pragma unroll
+    for (int c = 0; c < kMaxSteps; ++c) {
+      if (cp + c >= steps) break;
+      wb[c] = wp[(size_t)(cp + c) * 64];
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxSteps; ++c) {
+      if (cp + c >= steps) break;
+      const f32x4 dz = *reinterpret_cast<const f32x4*>(zrow + 16 * (cp + c));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = mfma16(dz[e], wb[c][e], acc);
+    }
+  }
+  return acc;
+}
+
 // One 16 x 16 tile of dW = dZ^T X over rows [0, B) (dZ [B][ldz] column tile nt, X = [X | X2] column tile kb, all in global
 // memory), and the tile's share of the bias gradient: the order of lin_bwd_weight_kernel with one slice — rows
 // b = b0 + 4e + q, b0 = 0, 16, ...; e = 0..3; per-lane serial column sums folded (q0 + q1) + (q2 + q3).

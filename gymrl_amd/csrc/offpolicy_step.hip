@@ -71,10 +71,11 @@ struct FwdItem {
   const float* W; const float* b;
   int Ys, ldy; float* Yg; int ldyg;        // output slab in LDS, optional copy in global memory
   int act; float lo, hi;
+  const float* Wimg;                       // forward image of W (square layers, lin_device.hpp) or nullptr: read W in place
 };
 __device__ __forceinline__ FwdItem fwd_item(int X, int ldx, int X2, int ldx2, int K, int K1, int N, const float* W, const float* b, int Ys,
-                                            int ldy, float* Yg, int ldyg, int act, float lo = 0.0f, float hi = 0.0f) {
-  return FwdItem{X, ldx, X2, ldx2, K, K1, N, W, b, Ys, ldy, Yg, ldyg, act, lo, hi};
+                                            int ldy, float* Yg, int ldyg, int act, float lo = 0.0f, float hi = 0.0f, const float* Wimg = nullptr) {
+  return FwdItem{X, ldx, X2, ldx2, K, K1, N, W, b, Ys, ldy, Yg, ldyg, act, lo, hi, Wimg};
 }
 
 template <int NI>
@@ -87,7 +88,8 @@ __device__ __forceinline__ void fwd_stage(float* lds, const FwdItem (&it)[NI], i
     const int ntiles = (I.N + 15) >> 4;
     for (int t = (wave - g0) & (kWaves - 1); t < ntiles; t += kWaves) {
       const int nb = t * 16;
-      const f32x4 acc = lin::tile_fwd(lds + I.X, I.ldx, I.X2 >= 0 ? lds + I.X2 : nullptr, I.ldx2, I.K, I.K1, I.W, I.N, nb, lane);
+      const f32x4 acc = I.Wimg ? lin::tile_fwd_img(lds + I.X, I.ldx, I.K >> 4, I.Wimg, t, lane)
+                               : lin::tile_fwd(lds + I.X, I.ldx, I.X2 >= 0 ? lds + I.X2 : nullptr, I.ldx2, I.K, I.K1, I.W, I.N, nb, lane);
       const int n = nb + r;
       if (n < I.N) {
         const float bv = I.b ? I.b[n] : 0.0f;
@@ -111,6 +113,7 @@ struct BwdItem {
   int dZb; const float* Wb;                // optional second (dZ, W) pair of the same shape (dZb < 0: none)
   int Hs, ldh, act_below;                  // saved output of the layer below in LDS (Hs < 0: no activation)
   int Out, ldo; float* Outg; int ldog;     // dL/dz of the layer below: LDS slab (Out < 0: none) and / or global
+  const float* Wimg;                       // input-gradient image of W (square layers) or nullptr
 };
 
 template <int NI>
@@ -124,7 +127,8 @@ __device__ __forceinline__ void bwd_stage(float* lds, const BwdItem (&it)[NI], i
     for (int t = (wave - g0) & (kWaves - 1); t < ktiles; t += kWaves) {
       const int kb = t * 16;
       f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-      acc = lin::tile_bwd_input(acc, lds + I.dZ, I.ldz, I.N, I.W, I.K, kb, lane);
+      if (I.Wimg) acc = lin::tile_bwd_input_img(acc, lds + I.dZ, I.ldz, I.N >> 4, I.Wimg, t, lane);
+      else acc = lin::tile_bwd_input(acc, lds + I.dZ, I.ldz, I.N, I.W, I.K, kb, lane);
       if (I.dZb >= 0) acc = lin::tile_bwd_input(acc, lds + I.dZb, I.ldz, I.N, I.Wb, I.K, kb, lane);
       const int kc = kb + r;
       if (kc < I.K) {
@@ -163,6 +167,17 @@ __device__ __forceinline__ void sample_row(const float* mean, const float* log_s
   }
   logp = lp;
 }
+
+// The eight weight images of gymrl_sac_update_args.images (f32[8][H*H]); all null when the caller passed none or H % 16 != 0
+struct Images {
+  const float *af, *c1f, *c2f, *t1f, *t2f, *ab, *c1b, *c2b;
+  __host__ __device__ Images(const float* base, int H) {
+    const bool on = base && (H & 15) == 0;
+    const size_t n = (size_t)H * H;
+    af = on ? base : nullptr; c1f = on ? base + n : nullptr; c2f = on ? base + 2 * n : nullptr; t1f = on ? base + 3 * n : nullptr;
+    t2f = on ? base + 4 * n : nullptr; ab = on ? base + 5 * n : nullptr; c1b = on ? base + 6 * n : nullptr; c2b = on ? base + 7 * n : nullptr;
+  }
+};
 
 struct Lds {                          // float offsets of the small per-row slabs, then the [16][ld] activation slabs
   int S, S2, A, A2, Mean, Ls, Eps, Q0, Q1, Cq0, Cq1, Dq0, Dq1, Misc, big;
@@ -221,6 +236,7 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
   __syncthreads();
   STEP_MARK(0, 1);
   const int R = GYMRL_ACT_RELU, NA = GYMRL_ACT_NONE, kD = kMaxD, kA = kMaxA;
+  const Images im(a.images, H);
   // ---- 1-3: the actor on s' (:233), and — independent of it — Q(s, a) of both networks (:239) in the same stages ----
   {
     const FwdItem st[3] = {fwd_item(L.S2, kD, -1, 0, D, D, H, a.actor.w[0], a.actor.b[0], X0, ld, nullptr, 0, R),
@@ -231,9 +247,9 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
   __syncthreads();
   STEP_MARK(0, 2);
   {
-    const FwdItem st[3] = {fwd_item(X0, ld, -1, 0, H, H, H, a.actor.w[1], a.actor.b[1], X1, ld, nullptr, 0, R),
-                           fwd_item(H1a, ld, -1, 0, H, H, H, a.critic.w[1], a.critic.b[1], H2a, ld, ws.H2[0], H, R),
-                           fwd_item(H1b, ld, -1, 0, H, H, H, a.critic.w[4], a.critic.b[4], H2b, ld, ws.H2[1], H, R)};
+    const FwdItem st[3] = {fwd_item(X0, ld, -1, 0, H, H, H, a.actor.w[1], a.actor.b[1], X1, ld, nullptr, 0, R, 0.0f, 0.0f, im.af),
+                           fwd_item(H1a, ld, -1, 0, H, H, H, a.critic.w[1], a.critic.b[1], H2a, ld, ws.H2[0], H, R, 0.0f, 0.0f, im.c1f),
+                           fwd_item(H1b, ld, -1, 0, H, H, H, a.critic.w[4], a.critic.b[4], H2b, ld, ws.H2[1], H, R, 0.0f, 0.0f, im.c2f)};
     fwd_stage<3>(lds, st, row0, nrows);
   }
   __syncthreads();
@@ -263,8 +279,8 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
   __syncthreads();
   STEP_MARK(0, 6);
   {
-    const FwdItem st[2] = {fwd_item(X0, ld, -1, 0, H, H, H, a.target.w[1], a.target.b[1], T2a, ld, nullptr, 0, R),
-                           fwd_item(X1, ld, -1, 0, H, H, H, a.target.w[4], a.target.b[4], T2b, ld, nullptr, 0, R)};
+    const FwdItem st[2] = {fwd_item(X0, ld, -1, 0, H, H, H, a.target.w[1], a.target.b[1], T2a, ld, nullptr, 0, R, 0.0f, 0.0f, im.t1f),
+                           fwd_item(X1, ld, -1, 0, H, H, H, a.target.w[4], a.target.b[4], T2b, ld, nullptr, 0, R, 0.0f, 0.0f, im.t2f)};
     fwd_stage<2>(lds, st, row0, nrows);
   }
   __syncthreads();
@@ -294,15 +310,15 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
   STEP_MARK(0, 9);
   // ---- 7-8: input-gradient chain of both Q networks (what q.backward() computes before the weight gradients) ----
   {
-    const BwdItem st[2] = {BwdItem{L.Dq0, 4, 1, a.critic.w[2], H, -1, nullptr, H2a, ld, R, X0, ld, ws.Z2[0], H},
-                           BwdItem{L.Dq1, 4, 1, a.critic.w[5], H, -1, nullptr, H2b, ld, R, X1, ld, ws.Z2[1], H}};
+    const BwdItem st[2] = {BwdItem{L.Dq0, 4, 1, a.critic.w[2], H, -1, nullptr, H2a, ld, R, X0, ld, ws.Z2[0], H, nullptr},
+                           BwdItem{L.Dq1, 4, 1, a.critic.w[5], H, -1, nullptr, H2b, ld, R, X1, ld, ws.Z2[1], H, nullptr}};
     bwd_stage<2>(lds, st, row0, nrows);
   }
   __syncthreads();
   STEP_MARK(0, 10);
   {
-    const BwdItem st[2] = {BwdItem{X0, ld, H, a.critic.w[1], H, -1, nullptr, H1a, ld, R, -1, 0, ws.Z1[0], H},
-                           BwdItem{X1, ld, H, a.critic.w[4], H, -1, nullptr, H1b, ld, R, -1, 0, ws.Z1[1], H}};
+    const BwdItem st[2] = {BwdItem{X0, ld, H, a.critic.w[1], H, -1, nullptr, H1a, ld, R, -1, 0, ws.Z1[0], H, im.c1b},
+                           BwdItem{X1, ld, H, a.critic.w[4], H, -1, nullptr, H1b, ld, R, -1, 0, ws.Z1[1], H, im.c2b}};
     bwd_stage<2>(lds, st, row0, nrows);
   }
   STEP_MARK(0, 11);
@@ -332,6 +348,7 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
   __syncthreads();
   STEP_MARK(1, 1);
   const int R = GYMRL_ACT_RELU, NA = GYMRL_ACT_NONE, kD = kMaxD, kA = kMaxA;
+  const Images im(a.images, H);
   // ---- a, logp = Actor.sample(s) (:248) ----
   {
     const FwdItem st[1] = {fwd_item(L.S, kD, -1, 0, D, D, H, a.actor.w[0], a.actor.b[0], AH1, ld, ws.aH1, H, R)};
@@ -340,7 +357,7 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
   __syncthreads();
   STEP_MARK(1, 2);
   {
-    const FwdItem st[1] = {fwd_item(AH1, ld, -1, 0, H, H, H, a.actor.w[1], a.actor.b[1], AH2, ld, ws.aH2, H, R)};
+    const FwdItem st[1] = {fwd_item(AH1, ld, -1, 0, H, H, H, a.actor.w[1], a.actor.b[1], AH2, ld, ws.aH2, H, R, 0.0f, 0.0f, im.af)};
     fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
@@ -368,8 +385,8 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
   __syncthreads();
   STEP_MARK(1, 6);
   {
-    const FwdItem st[2] = {fwd_item(H1a, ld, -1, 0, H, H, H, a.critic.w[1], a.critic.b[1], H2a, ld, nullptr, 0, R),
-                           fwd_item(H1b, ld, -1, 0, H, H, H, a.critic.w[4], a.critic.b[4], H2b, ld, nullptr, 0, R)};
+    const FwdItem st[2] = {fwd_item(H1a, ld, -1, 0, H, H, H, a.critic.w[1], a.critic.b[1], H2a, ld, nullptr, 0, R, 0.0f, 0.0f, im.c1f),
+                           fwd_item(H1b, ld, -1, 0, H, H, H, a.critic.w[4], a.critic.b[4], H2b, ld, nullptr, 0, R, 0.0f, 0.0f, im.c2f)};
     fwd_stage<2>(lds, st, row0, nrows);
   }
   __syncthreads();
@@ -399,15 +416,15 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
   STEP_MARK(1, 9);
   // ---- back through both Q networks to the action (their parameters are frozen here: no weight gradients) ----
   {
-    const BwdItem st[2] = {BwdItem{L.Dq0, 4, 1, a.critic.w[2], H, -1, nullptr, H2a, ld, R, X0, ld, nullptr, 0},
-                           BwdItem{L.Dq1, 4, 1, a.critic.w[5], H, -1, nullptr, H2b, ld, R, X1, ld, nullptr, 0}};
+    const BwdItem st[2] = {BwdItem{L.Dq0, 4, 1, a.critic.w[2], H, -1, nullptr, H2a, ld, R, X0, ld, nullptr, 0, nullptr},
+                           BwdItem{L.Dq1, 4, 1, a.critic.w[5], H, -1, nullptr, H2b, ld, R, X1, ld, nullptr, 0, nullptr}};
     bwd_stage<2>(lds, st, row0, nrows);
   }
   __syncthreads();
   STEP_MARK(1, 10);
   {
-    const BwdItem st[2] = {BwdItem{X0, ld, H, a.critic.w[1], H, -1, nullptr, H1a, ld, R, H2a, ld, nullptr, 0},
-                           BwdItem{X1, ld, H, a.critic.w[4], H, -1, nullptr, H1b, ld, R, H2b, ld, nullptr, 0}};
+    const BwdItem st[2] = {BwdItem{X0, ld, H, a.critic.w[1], H, -1, nullptr, H1a, ld, R, H2a, ld, nullptr, 0, im.c1b},
+                           BwdItem{X1, ld, H, a.critic.w[4], H, -1, nullptr, H1b, ld, R, H2b, ld, nullptr, 0, im.c2b}};
     bwd_stage<2>(lds, st, row0, nrows);
   }
   __syncthreads();
@@ -449,13 +466,13 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
   STEP_MARK(1, 13);
   // ---- back through the actor: heads (one summed input gradient), fc2 ----
   {
-    const BwdItem st[1] = {BwdItem{L.Dq0, 4, A, a.actor.w[2], H, L.Dq1, a.actor.w[3], AH2, ld, R, X0, ld, ws.aZ2, H}};
+    const BwdItem st[1] = {BwdItem{L.Dq0, 4, A, a.actor.w[2], H, L.Dq1, a.actor.w[3], AH2, ld, R, X0, ld, ws.aZ2, H, nullptr}};
     bwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
   STEP_MARK(1, 14);
   {
-    const BwdItem st[1] = {BwdItem{X0, ld, H, a.actor.w[1], H, -1, nullptr, AH1, ld, R, -1, 0, ws.aZ1, H}};
+    const BwdItem st[1] = {BwdItem{X0, ld, H, a.actor.w[1], H, -1, nullptr, AH1, ld, R, -1, 0, ws.aZ1, H, im.ab}};
     bwd_stage<1>(lds, st, row0, nrows);
   }
   STEP_MARK(1, 15);
@@ -465,6 +482,7 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
 struct DwSeg {
   const float* dZ; const float* X; const float* X2;
   float* W; float* b; float* Wt; float* bt;       // parameters and (critic) their target twins
+  float* img_f; float* img_b; float* img_tf;      // weight images to keep in step (square layers; nullptr: none)
   int ldz, ldx, ldx2, N, K, K1, wave0;            // wave0: first global wave of this segment
 };
 struct DwArgs {
@@ -541,7 +559,12 @@ __global__ __launch_bounds__(256) void sac_dw_kernel(const DwArgs a) {
       float P = s.W[o], M = a.m[po], V = a.v[po];
       lin::adam_elem(P, acc[g], M, V, ad);
       s.W[o] = P; a.m[po] = M; a.v[po] = V;
-      if (s.Wt) s.Wt[o] = a.tau * P + a.omt * s.Wt[o];
+      float T = 0.0f;
+      if (s.Wt) { T = a.tau * P + a.omt * s.Wt[o]; s.Wt[o] = T; }
+      const int steps = s.K >> 4;
+      if (s.img_f) s.img_f[lin::img_fwd_index(no, kc, steps)] = P;
+      if (s.img_b) s.img_b[lin::img_bwd_index(no, kc, steps)] = P;
+      if (s.img_tf) s.img_tf[lin::img_fwd_index(no, kc, steps)] = T;
     }
   }
   const int n = nt * 16 + r;
@@ -577,6 +600,7 @@ __global__ __launch_bounds__(kThreads) void sac_act_kernel(const gymrl_sac_act_a
   __syncthreads();
   STEP_MARK(2, 1);
   const int R = GYMRL_ACT_RELU, kD = kMaxD, kA = kMaxA;
+  const Images im(a.images, H);
   {
     const FwdItem st[1] = {fwd_item(L.S, kD, -1, 0, D, D, H, a.actor.w[0], a.actor.b[0], X0, ld, nullptr, 0, R)};
     fwd_stage<1>(lds, st, row0, nrows);
@@ -584,7 +608,7 @@ __global__ __launch_bounds__(kThreads) void sac_act_kernel(const gymrl_sac_act_a
   __syncthreads();
   STEP_MARK(2, 2);
   {
-    const FwdItem st[1] = {fwd_item(X0, ld, -1, 0, H, H, H, a.actor.w[1], a.actor.b[1], X1, ld, nullptr, 0, R)};
+    const FwdItem st[1] = {fwd_item(X0, ld, -1, 0, H, H, H, a.actor.w[1], a.actor.b[1], X1, ld, nullptr, 0, R, 0.0f, 0.0f, im.af)};
     fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
@@ -629,6 +653,19 @@ __global__ __launch_bounds__(kThreads) void sac_act_kernel(const gymrl_sac_act_a
   STEP_MARK(2, 5);
 }
 
+// All eight images from the parameters as they are (after load_state_dict / a checkpoint / a hard target copy)
+__global__ __launch_bounds__(256) void sac_pack_kernel(const gymrl_sac_update_args a) {
+  const int H = a.H, steps = H >> 4;
+  const size_t hh = (size_t)H * H;
+  const float* src[8] = {a.actor.w[1], a.critic.w[1], a.critic.w[4], a.target.w[1], a.target.w[4], a.actor.w[1], a.critic.w[1], a.critic.w[4]};
+  const int which = blockIdx.y;
+  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < hh; o += (size_t)gridDim.x * 256) {
+    const int n = (int)(o / H), k = (int)(o % H);
+    const float v = src[which][o];
+    a.images[which * hh + (which < 5 ? lin::img_fwd_index(n, k, steps) : lin::img_bwd_index(n, k, steps))] = v;
+  }
+}
+
 inline bool sac_shape_ok(int B, int D, int A, int H) {
   return B > 0 && B <= 256 && D > 0 && D <= kMaxD && A > 0 && A <= kMaxA && H >= 4 && H <= 256 && (H & 3) == 0;
 }
@@ -668,6 +705,16 @@ int gymrl_sac_act_step(const gymrl_sac_act_args* args, void* stream_) {
   return 0;
 }
 
+int gymrl_sac_pack_images(const gymrl_sac_update_args* args, void* stream_) {
+  if (!args) return -22;
+  const gymrl_sac_update_args& a = *args;
+  if (!a.images || a.H <= 0 || (a.H & 15) != 0 || a.H > 256) return -22;
+  if (!a.actor.w[1] || !a.critic.w[1] || !a.critic.w[4] || !a.target.w[1] || !a.target.w[4]) return -22;
+  hipLaunchKernelGGL(sac_pack_kernel, dim3((a.H * a.H + 255) / 256, 8), dim3(256), 0, (hipStream_t)stream_, a);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
 int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream_) {
   if (!args) return -22;
   const gymrl_sac_update_args& a = *args;
@@ -695,17 +742,22 @@ int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream_) {
 
   DwArgs c{};
   int w0 = 0, ns = 0;
+  const bool use_img = a.images && (a.H & 15) == 0;
+  const size_t hh = (size_t)a.H * a.H;
+  auto img = [&](int k) { return use_img ? a.images + k * hh : nullptr; };
   auto seg = [&](DwArgs& d, const float* dZ, int ldz, int N, const float* X, int ldx, const float* X2, int ldx2, int K, int K1, float* W, float* b,
-                 float* Wt, float* bt) {
+                 float* Wt, float* bt, float* img_f = nullptr, float* img_b = nullptr, float* img_tf = nullptr) {
     DwSeg& s = d.seg[ns++];
     s.dZ = dZ; s.X = X; s.X2 = X2; s.W = W; s.b = b; s.Wt = Wt; s.bt = bt;
+    s.img_f = img_f; s.img_b = img_b; s.img_tf = img_tf;
     s.ldz = ldz; s.ldx = ldx; s.ldx2 = ldx2; s.N = N; s.K = K; s.K1 = K1; s.wave0 = w0;
     w0 += tiles(N, K);
   };
   // critic: launch order of the layer-by-layer backward is irrelevant here (tiles are independent); fc1/fc4, fc2/fc5, fc3/fc6
   for (int i = 0; i < 2; ++i) {
     seg(c, ws.Z1[i], H, H, ws.s, D, ws.a, A, D + A, D, a.critic.w[3 * i], a.critic.b[3 * i], a.target.w[3 * i], a.target.b[3 * i]);
-    seg(c, ws.Z2[i], H, H, ws.H1[i], H, nullptr, 0, H, H, a.critic.w[3 * i + 1], a.critic.b[3 * i + 1], a.target.w[3 * i + 1], a.target.b[3 * i + 1]);
+    seg(c, ws.Z2[i], H, H, ws.H1[i], H, nullptr, 0, H, H, a.critic.w[3 * i + 1], a.critic.b[3 * i + 1], a.target.w[3 * i + 1], a.target.b[3 * i + 1],
+        img(1 + i), img(6 + i), img(3 + i));
     seg(c, ws.dq[i], 1, 1, ws.H2[i], H, nullptr, 0, H, H, a.critic.w[3 * i + 2], a.critic.b[3 * i + 2], a.target.w[3 * i + 2], a.target.b[3 * i + 2]);
   }
   c.nseg = ns; c.total_waves = w0; c.B = B;
@@ -722,7 +774,7 @@ int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream_) {
   DwArgs p{};
   w0 = 0; ns = 0;
   seg(p, ws.aZ1, H, H, ws.s, D, nullptr, 0, D, D, a.actor.w[0], a.actor.b[0], nullptr, nullptr);
-  seg(p, ws.aZ2, H, H, ws.aH1, H, nullptr, 0, H, H, a.actor.w[1], a.actor.b[1], nullptr, nullptr);
+  seg(p, ws.aZ2, H, H, ws.aH1, H, nullptr, 0, H, H, a.actor.w[1], a.actor.b[1], nullptr, nullptr, img(0), img(5), nullptr);
   seg(p, ws.dmean, A, A, ws.aH2, H, nullptr, 0, H, H, a.actor.w[2], a.actor.b[2], nullptr, nullptr);
   seg(p, ws.dls, A, A, ws.aH2, H, nullptr, 0, H, H, a.actor.w[3], a.actor.b[3], nullptr, nullptr);
   p.nseg = ns; p.total_waves = w0; p.B = B;

@@ -173,13 +173,42 @@ class EpisodeTracker:
         if self.k == self.K:
             self.flush(sink)
 
+    def drain_async(self):
+        """Enqueue the device -> pinned-host copy of the filled rows behind whatever produces them and return a token for
+        collect(); the rows may be overwritten by later steps at once (stream order).  No host sync, no device-side
+        compaction (the boolean-mask indexing this replaces was three launches and a sync per drain)."""
+        if not self.k:
+            return None
+        if getattr(self, "_pin", None) is None:
+            K, N = self.ret.shape
+            self._pin = [(torch.zeros(K, N, pin_memory=True), torch.zeros(K, N, dtype=torch.uint8, pin_memory=True),
+                          torch.zeros(K, N, dtype=torch.int32, pin_memory=True)) for _ in range(2)]
+            self._pp = 0
+        self._pp ^= 1
+        k, (pr, pd, pl) = self.k, self._pin[self._pp]
+        pr[:k].copy_(self.ret[:k], non_blocking=True)
+        pd[:k].copy_(self.done[:k], non_blocking=True)
+        if self._want_len:
+            pl[:k].copy_(self.len[:k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.k = 0
+        return (self._pp, k, ev)
+
+    def collect(self, token, sink):
+        """Wait for a drain_async() copy and append its finished episodes to `sink`, in time order (row-major: step, then env)."""
+        if token is None:
+            return
+        i, k, ev = token
+        ev.synchronize()
+        pr, pd, pl = self._pin[i]
+        mask = pd[:k].numpy().astype(bool)
+        fin = pr[:k].numpy()[mask].tolist()
+        for r in fin:
+            sink.append(r)
+        if self._want_len:
+            self.lengths.extend(pl[:k].numpy()[mask].tolist())
+        self.episodes += len(fin)
+
     def flush(self, sink):
-        if self.k:
-            mask = self.done[:self.k].bool()
-            fin = self.ret[:self.k][mask].tolist()
-            for r in fin:
-                sink.append(r)
-            if self._want_len:
-                self.lengths.extend(self.len[:self.k][mask].tolist())
-            self.episodes += len(fin)
-            self.k = 0
+        self.collect(self.drain_async(), sink)

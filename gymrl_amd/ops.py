@@ -1241,7 +1241,7 @@ def _sac_critic_params(dst, critic):
         dst.w[k], dst.b[k] = _addr(layer.weight), _addr(layer.bias)
 
 
-def sac_act_args(env, actor, ring, cap, bound, log_std_min, log_std_max):
+def sac_act_args(env, actor, ring, cap, bound, log_std_min, log_std_max, images=None):
     """A gymrl_sac_act_args with everything that does not change from step to step filled in (env, actor parameters —
     views of a flat buffer the optimiser updates in place — and the replay ring)."""
     a = SacActArgs()
@@ -1251,6 +1251,7 @@ def sac_act_args(env, actor, ring, cap, bound, log_std_min, log_std_max):
     _sac_actor_params(a.actor, actor)
     a.r_state, a.r_action, a.r_reward, a.r_next, a.r_flag = (_addr(t) for t in ring)
     a.cap = cap
+    a.images = _addr(images)
     return a
 
 
@@ -1266,8 +1267,18 @@ def sac_act_step(a, env, obs, obs_out, cursor=0, cursor_dev=None, eps=None, nois
     check(lib().gymrl_sac_act_step(C.byref(a), _stream()), "gymrl_sac_act_step")
 
 
+def sac_images(H, device):
+    """The eight weight images of the H x H layers (gymrl_sac_update_args.images), or None when H % 16 != 0."""
+    return torch.zeros(8 * H * H, device=device) if H % 16 == 0 else None
+
+
+def sac_pack_images(a):
+    """gymrl_sac_pack_images: rebuild every image from the parameters as they are now."""
+    check(lib().gymrl_sac_pack_images(C.byref(a), _stream()), "gymrl_sac_pack_images")
+
+
 def sac_update_args(B, D, A, actor, critic, target, actor_opt, critic_opt, ring, cfg_scalars, log_alpha, alpha_m, alpha_v, sums,
-                    alpha_loss, workspace):
+                    alpha_loss, workspace, images=None):
     """A gymrl_sac_update_args with the per-trainer constants filled in.  cfg_scalars = (gamma, tau, bound, log_std_min,
     log_std_max, target_entropy, lr_alpha); actor_opt / critic_opt: FusedAdam over the modules' flat buffers."""
     a = SacUpdateArgs()
@@ -1284,6 +1295,7 @@ def sac_update_args(B, D, A, actor, critic, target, actor_opt, critic_opt, ring,
     a.beta1, a.beta2, a.eps_adam = g["betas"][0], g["betas"][1], g["eps"]
     a.log_alpha, a.alpha_m, a.alpha_v, a.lr_alpha = _addr(log_alpha), _addr(alpha_m), _addr(alpha_v), float(lr_alpha)
     a.sums, a.alpha_loss, a.workspace = _addr(sums), _addr(alpha_loss), _addr(workspace)
+    a.images = _addr(images)
     return a
 
 

@@ -677,6 +677,7 @@ class RainbowDQNTrainer:
         obs, nxt, tracker = lb["obs"], lb["nxt"], lb["tracker"]
         env.reset(obs)
         step = 0
+        pending = None            # drain_async() token of the last chunk, collected one chunk later
         graphed = (bool(getattr(cfg, "use_graphs", True)) and self._parity_u is None
                    and self.policy_net.advantage.raw_noise is None)
         chunked = graphed and N > 1 and cfg.updates_per_step == 1 and getattr(cfg, "chunk_steps", self.CHUNK) > 0 and (self.memory.capacity & (self.memory.capacity - 1)) == 0 \
@@ -695,10 +696,16 @@ class RainbowDQNTrainer:
                 self._chunk.run(lambda j: self._chunk_body(lb, j), key=(id(env), env.state.data_ptr()))
                 step += self.CHUNK
                 tracker.k = self.CHUNK
-                tracker.flush(self.episode_rewards)
+                # the chunk's episode returns come back through a pinned buffer one chunk late: the host goes straight on
+                # to staging the next chunk while this one runs (a sync here left the GPU idle for the host work per chunk)
+                token = tracker.drain_async()
+                tracker.collect(pending, self.episode_rewards)
+                pending = token
                 if len(self.episode_rewards) >= 100 and np.mean(self.episode_rewards) >= 495.0:
                     break
                 continue
+            tracker.collect(pending, self.episode_rewards)
+            pending = None
             ep_ret, done = tracker.slot()
             self._vector_step(lb, obs, nxt, ep_ret, done)
             for _ in range(cfg.updates_per_step):
@@ -711,6 +718,7 @@ class RainbowDQNTrainer:
             tracker.advance(self.episode_rewards)
             if len(self.episode_rewards) >= 100 and np.mean(self.episode_rewards) >= 495.0:
                 break
+        tracker.collect(pending, self.episode_rewards)
         tracker.flush(self.episode_rewards)
         self.env.close()
 

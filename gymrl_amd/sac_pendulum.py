@@ -45,6 +45,7 @@ class Config:
         self.num_envs = 1
         self.updates_per_step = 1
         self.use_graphs = True             # replay the update as one captured hipGraph (train(); update() stays eager)
+        self.fused_images = True           # fused step: keep MFMA-operand images of the hidden x hidden weights (3x faster to stream)
         self.fused_step = True             # a vector step = 5 launches (csrc/offpolicy_step.hip: acting + env + append in one, the
         #                                    update in four) instead of ~60; bit-identical to the layer-by-layer path, which remains
         #                                    for shapes beyond the kernels' limits (hidden_dim > 256, batch > 256) and custom envs
@@ -169,7 +170,8 @@ class SACTrainer:
         self._parity_eps = None        # tests: iterator of f32[N, A] N(0,1) draws for select_action
         self._graph = None             # hipGraph of the update, captured on first use (update_async)
         self._parity_updates = None    # tests: iterator of (indices i32[B], eps_next [B, A], eps_cur [B, A]) for update()
-        self._fused = None             # (act args, update args, workspace) of the fused step, built on first use
+        self._fused = None             # (act args, update args, workspace, env, weight images) of the fused step, built on first use
+        self._img_versions = None      # versions of the flat buffers the weight images were last rebuilt from
         self._act_noise = self._upd_noise = 0      # Philox counters of the fused step's own N(0,1) draws
 
     @property
@@ -198,14 +200,24 @@ class SACTrainer:
         if self._fused is None or self._fused[3] is not self.env:
             cfg, env, m = self.cfg, self.env, self.memory
             D, A = m.ring[0].shape[1], m.ring[1].shape[1]
-            act = (ops.sac_act_args(env, self.actor, m.ring, m.capacity, self.action_bound, cfg.log_std_min, cfg.log_std_max)
+            img = ops.sac_images(cfg.hidden_dim, self.device) if getattr(cfg, "fused_images", True) else None
+            act = (ops.sac_act_args(env, self.actor, m.ring, m.capacity, self.action_bound, cfg.log_std_min, cfg.log_std_max, img)
                    if isinstance(env, VecEnv) else None)
             ws = ops.sac_update_workspace(cfg.batch_size, D, A, cfg.hidden_dim, self.device)
             upd = ops.sac_update_args(cfg.batch_size, D, A, self.actor, self.critic, self.critic_target,
                                       self.actor_optimizer, self.critic_optimizer, m.ring,
                                       (cfg.gamma, cfg.tau, self.action_bound, cfg.log_std_min, cfg.log_std_max, self.target_entropy,
-                                       cfg.lr_alpha), self.log_alpha, self._alpha_m, self._alpha_v, self._sums, self._alpha_loss, ws)
-            self._fused = (act, upd, ws, env)
+                                       cfg.lr_alpha), self.log_alpha, self._alpha_m, self._alpha_v, self._sums, self._alpha_loss, ws, img)
+            self._fused = (act, upd, ws, env, img)
+            self._img_versions = None
+        # the weight images follow the parameters as long as only the fused update writes them; anything that went through
+        # torch (load_state_dict, a checkpoint, a hard target copy: the flat buffers' version counters move) or through the
+        # layer-by-layer update (which resets _img_versions) makes them stale: rebuild (one launch)
+        if self._fused[4] is not None:
+            v = (self.actor_flat._version, self.critic_flat._version, self.critic_target_flat._version)
+            if v != self._img_versions:
+                ops.sac_pack_images(self._fused[1])
+                self._img_versions = v
         return self._fused
 
     def _update_fused(self, indices=None, eps_next=None, eps_cur=None, dev=None):
@@ -257,6 +269,7 @@ class SACTrainer:
         """Everything after the index draw.  bias = (critic f32[4], actor f32[4], alpha f64[2]) device views when
         the body runs inside / ahead of a hipGraph; None on the eager path."""
         cfg = self.cfg
+        self._img_versions = None             # this path writes the parameters without the fused step's weight images
         states, actions, rewards, next_states, dones = self.memory.gather(indices)
         B = states.shape[0]
         self._sums.zero_()
@@ -427,6 +440,7 @@ class SACTrainer:
         obs, nxt, tracker = lb["obs"], lb["nxt"], lb["tracker"]
         env.reset(obs)
         step = 0
+        pending = None            # drain_async() token of the last chunk, collected one chunk later
         graphed = bool(getattr(cfg, "use_graphs", True)) and self._parity_updates is None
         # the fused step is 5 launches: 16 steps replay as ONE 80-node graph (the layer-by-layer step's 944-node chunk is slower
         # than its eager loop, hence chunk_steps = 0 there)
@@ -443,12 +457,21 @@ class SACTrainer:
                                                                       ("noise_u", "Q")])
                     if getattr(self, "_g_idx", None) is None:
                         self._g_idx = torch.empty(cfg.batch_size, dtype=torch.int32, device=self.device)
+                if self._fused_update_ok():
+                    self._fused_args()         # weight images rebuilt (if stale) BEFORE the capture, not inside it
                 self._stage_chunk()
                 self._chunk.run(lambda j: self._chunk_body(lb, j), key=(id(env), env.state.data_ptr()))
                 step += self.CHUNK
                 tracker.k = self.CHUNK
-                tracker.flush(self.episode_rewards)
+                # the chunk's episode returns come back through a pinned buffer one chunk late: the host goes straight on
+                # to staging the next chunk while this one runs (a sync here left the GPU idle for the ~0.5 ms of host work
+                # per chunk: a quarter of a fused SAC step)
+                token = tracker.drain_async()
+                tracker.collect(pending, self.episode_rewards)
+                pending = token
                 continue
+            tracker.collect(pending, self.episode_rewards)
+            pending = None
             ep_ret, done = tracker.slot()
             self._vector_step(lb, obs, nxt, ep_ret, done)
             for _ in range(cfg.updates_per_step):
@@ -459,6 +482,7 @@ class SACTrainer:
             obs, nxt = nxt, obs
             step += 1
             tracker.advance(self.episode_rewards)
+        tracker.collect(pending, self.episode_rewards)
         tracker.flush(self.episode_rewards)
         self.env.close()
 

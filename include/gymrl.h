@@ -1033,6 +1033,7 @@ typedef struct {
   const int64_t* cursor_dev;
   /* per-step outputs of the episode bookkeeping (any may be NULL) */
   float* action_out; float* rew_out; uint8_t* done_out; float* ep_ret_out; double* ep_stats;
+  const float* images;                     /* gymrl_sac_update_args.images of the same trainer, or NULL (reads actor.fc2 in place) */
 } gymrl_sac_act_args;
 typedef struct {
   int B, D, A, H;
@@ -1054,8 +1055,15 @@ typedef struct {
   double* sums;                            /* f64[3] out: critic loss sum, actor loss sum, sum of (logp + target_entropy) */
   double* alpha_loss;                      /* f64[1] out or NULL */
   void* workspace;                         /* >= gymrl_sac_update_workspace_bytes(B, D, A, H) */
+  /* Weight images of the H x H layers (H % 16 == 0), f32[8][H*H], or NULL (every layer read in place).  The MFMA operands of
+   * actor.fc2, critic.fc2 / fc5, target.fc2 / fc5 (forward) and actor.fc2, critic.fc2 / fc5 (input gradient) as contiguous
+   * 1 KiB blocks per wave-wide load (csrc/lin_device.hpp): a slab kernel streams a whole weight matrix through one compute
+   * unit, 3x faster from the image.  gymrl_sac_update keeps the images equal to the parameters it updates;
+   * gymrl_sac_pack_images rebuilds them after anything else wrote the parameters (load_state_dict, a checkpoint, ...). */
+  float* images;
 } gymrl_sac_update_args;
 size_t gymrl_sac_update_workspace_bytes(int B, int D, int A, int H);
+int gymrl_sac_pack_images(const gymrl_sac_update_args* args, void* stream);
 size_t gymrl_sac_args_bytes(int which);      /* sizeof(gymrl_sac_act_args) (0) / sizeof(gymrl_sac_update_args) (1): a binding checks its mirror */
 int gymrl_sac_act_step(const gymrl_sac_act_args* args, void* stream);
 int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream);

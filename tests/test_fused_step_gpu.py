@@ -9,11 +9,11 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 
-def _run(fused, steps, N, B, hidden, seed=5):
+def _run(fused, steps, N, B, hidden, seed=5, images=True):
     from gymrl_amd.sac_pendulum import Config, SACTrainer
     cfg = Config()
     cfg.num_envs, cfg.batch_size, cfg.hidden_dim, cfg.seed = N, B, hidden, seed
-    cfg.max_episodes, cfg.memory_capacity, cfg.use_graphs, cfg.fused_step = 10 ** 9, 4096, False, fused
+    cfg.max_episodes, cfg.memory_capacity, cfg.use_graphs, cfg.fused_step, cfg.fused_images = 10 ** 9, 4096, False, fused, images
     tr = SACTrainer(cfg)
     assert tr._fused_ok() == fused
     g = torch.Generator(device="cuda").manual_seed(7)
@@ -41,6 +41,18 @@ def test_sac_fused_step_equals_layer_by_layer(N, B, hidden, steps):
         assert torch.equal(getattr(a, opt).m, getattr(b, opt).m) and torch.equal(getattr(a, opt).v, getattr(b, opt).v), opt
     assert torch.equal(a._sums[:3], b._sums[:3]) and torch.equal(a._alpha_loss, b._alpha_loss)
     assert list(a.episode_rewards) == list(b.episode_rewards)
+    if hidden % 16 == 0:
+        # the weight images (MFMA operands of the hidden x hidden layers, kept in step by the weight-gradient kernel) change
+        # where a value is read from, not the value: without them the same bits again
+        c = _run(True, steps, N, B, hidden, images=False)
+        assert b._fused[4] is not None and c._fused[4] is None
+        for name in ("actor_flat", "critic_flat", "critic_target_flat", "log_alpha"):
+            assert torch.equal(getattr(b, name), getattr(c, name)), name
+        # and they do hold the parameters: rebuilding them from scratch changes nothing
+        before = b._fused[4].clone()
+        from gymrl_amd import ops
+        ops.sac_pack_images(b._fused[1])
+        assert torch.equal(before, b._fused[4])
 
 
 def test_sac_fused_update_matches_reference_update():
