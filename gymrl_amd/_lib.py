@@ -52,6 +52,7 @@ SYMBOLS = [
     "gymrl_mhc_gates_bwd_workspace_bytes", "gymrl_mhc_gates_bwd", "gymrl_rmsnorm_bwd_workspace_bytes", "gymrl_rmsnorm_bwd",
     "gymrl_mhc_policy_forward", "gymrl_mhc_sub_forward", "gymrl_rollout_lunar_mhc",
     "gymrl_sac_update_workspace_bytes", "gymrl_sac_args_bytes", "gymrl_sac_act_step", "gymrl_sac_update", "gymrl_sac_pack_images",
+    "gymrl_rainbow_update_workspace_bytes", "gymrl_rainbow_args_bytes", "gymrl_rainbow_act_step", "gymrl_rainbow_update",
 ]
 
 
@@ -172,6 +173,32 @@ class SacUpdateArgs(C.Structure):         # gymrl_sac_update_args (include/gymrl
                 ("sums", C.c_void_p), ("alpha_loss", C.c_void_p), ("workspace", C.c_void_p), ("images", C.c_void_p)]
 
 
+class RainbowActArgs(C.Structure):        # gymrl_rainbow_act_args (include/gymrl.h), field for field
+    _fields_ = [("N", C.c_int), ("D", C.c_int), ("A", C.c_int), ("H", C.c_int), ("env_kind", C.c_int),
+                ("env_state", C.c_void_p), ("env_seed", C.c_uint64), ("env_id0", C.c_int64),
+                ("obs", C.c_void_p), ("obs_out", C.c_void_p),
+                ("fc1_w", C.c_void_p), ("fc1_b", C.c_void_p), ("fc2_w", C.c_void_p), ("fc2_b", C.c_void_p),
+                ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("max_episode_steps", C.c_int),
+                ("w_state", C.c_void_p), ("w_action", C.c_void_p), ("w_reward", C.c_void_p), ("w_next", C.c_void_p),
+                ("w_terminal", C.c_void_p), ("w_done", C.c_void_p),
+                ("n_steps", C.c_int), ("pushes", C.c_int64), ("gamma", C.c_double),
+                ("r_state", C.c_void_p), ("r_action", C.c_void_p), ("r_reward", C.c_void_p), ("r_next", C.c_void_p),
+                ("r_flag", C.c_void_p), ("cap", C.c_int64), ("cursor", C.c_int64), ("push_dev", C.c_void_p),
+                ("action_out", C.c_void_p), ("rew_out", C.c_void_p), ("done_out", C.c_void_p), ("ep_ret_out", C.c_void_p),
+                ("ep_stats", C.c_void_p)]
+
+
+class RainbowUpdateArgs(C.Structure):     # gymrl_rainbow_update_args (include/gymrl.h), field for field
+    _fields_ = [("B", C.c_int), ("D", C.c_int), ("A", C.c_int), ("H", C.c_int), ("gamma_n", C.c_float),
+                ("r_state", C.c_void_p), ("r_action", C.c_void_p), ("r_reward", C.c_void_p), ("r_next", C.c_void_p),
+                ("r_flag", C.c_void_p), ("idx", C.c_void_p), ("is_weight", C.c_void_p),
+                ("p_fc1_w", C.c_void_p), ("p_fc1_b", C.c_void_p), ("p_fc2_w", C.c_void_p), ("p_fc2_b", C.c_void_p),
+                ("t_fc1_w", C.c_void_p), ("t_fc1_b", C.c_void_p), ("t_fc2_w", C.c_void_p), ("t_fc2_b", C.c_void_p),
+                ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("td_out", C.c_void_p), ("loss_sum", C.c_void_p),
+                ("d_fc1_w", C.c_void_p), ("d_fc1_b", C.c_void_p), ("d_fc2_w", C.c_void_p), ("d_fc2_b", C.c_void_p),
+                ("d_head_w", C.c_void_p), ("d_head_b", C.c_void_p), ("workspace", C.c_void_p)]
+
+
 class PPOFullCfg(C.Structure):
     _fields_ = [("clip_eps_min", C.c_float), ("clip_eps_max", C.c_float), ("dual_clip", C.c_float),
                 ("erc_beta_low", C.c_float), ("erc_beta_high", C.c_float), ("entropy_coef", C.c_float)]
@@ -204,6 +231,12 @@ def lib():
         L.gymrl_rmsnorm_bwd_workspace_bytes.restype = C.c_size_t
         L.gymrl_sac_update_workspace_bytes.restype = C.c_size_t
         L.gymrl_sac_args_bytes.restype = C.c_size_t
+        L.gymrl_rainbow_update_workspace_bytes.restype = C.c_size_t
+        L.gymrl_rainbow_args_bytes.restype = C.c_size_t
+        if L.gymrl_rainbow_args_bytes(0) != C.sizeof(RainbowActArgs) or L.gymrl_rainbow_args_bytes(1) != C.sizeof(RainbowUpdateArgs):
+            raise RuntimeError("gymrl_amd/_lib.py: RainbowActArgs / RainbowUpdateArgs do not mirror include/gymrl.h "
+                               f"({C.sizeof(RainbowActArgs)} / {C.sizeof(RainbowUpdateArgs)} bytes here, "
+                               f"{L.gymrl_rainbow_args_bytes(0)} / {L.gymrl_rainbow_args_bytes(1)} in the library)")
         if L.gymrl_sac_args_bytes(0) != C.sizeof(SacActArgs) or L.gymrl_sac_args_bytes(1) != C.sizeof(SacUpdateArgs):
             raise RuntimeError("gymrl_amd/_lib.py: SacActArgs / SacUpdateArgs do not mirror include/gymrl.h "
                                f"({C.sizeof(SacActArgs)} / {C.sizeof(SacUpdateArgs)} bytes here, "

@@ -492,6 +492,7 @@ struct DwArgs {
   float adam[4]; const float* adam_dev;
   float omb1, beta2, omb2, eps;
   float tau, omt;
+  int store_grads;                                // != 0: seg.W / seg.b are gradient DESTINATIONS (overwritten), no optimiser step
   // loss sums + temperature (the launch's last workgroup)
   const double* terms; int term0, nterms; double* sums;
   int alpha_step;
@@ -549,6 +550,18 @@ __global__ __launch_bounds__(256) void sac_dw_kernel(const DwArgs a) {
   ad.bc2_sqrt = a.adam_dev ? a.adam_dev[2] : a.adam[2];
   ad.omb1 = a.omb1; ad.beta2 = a.beta2; ad.omb2 = a.omb2; ad.eps = a.eps;
   const int kc = kb + r;
+  if (a.store_grads) {                            // Rainbow: clip_grad_norm_ needs every gradient before Adam may run
+    if (kc < s.K) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int no = nt * 16 + 4 * q + g;
+        if (no < s.N) s.W[(size_t)no * s.K + kc] = acc[g];
+      }
+    }
+    const int nn = nt * 16 + r;
+    if (cg == 0 && q == 0 && nn < s.N && s.b) s.b[nn] = colsum;
+    return;
+  }
   if (kc < s.K) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -653,6 +666,219 @@ __global__ __launch_bounds__(kThreads) void sac_act_kernel(const gymrl_sac_act_a
   STEP_MARK(2, 5);
 }
 
+// ============================================================================================== Rainbow =====
+struct RbWs {
+  float *s, *h1, *h2, *dS, *dZ2, *dZ1;      // [B][D], [B][H], [B][H], [B][A+1], [B][H], [B][H]
+  double* terms;                             // [B][3] (column 0: w * td^2)
+  __host__ __device__ static size_t carve(RbWs* w, void* base, int B, int D, int A, int H) {
+    size_t off = 0;
+    auto take = [&](size_t n) { float* p = base ? reinterpret_cast<float*>(static_cast<char*>(base) + off) : nullptr; off += ((n * 4 + 255) & ~(size_t)255); return p; };
+    float* s_ = take((size_t)B * D); float* h1 = take((size_t)B * H); float* h2 = take((size_t)B * H); float* dS = take((size_t)B * (A + 1));
+    float* z2 = take((size_t)B * H); float* z1 = take((size_t)B * H);
+    double* terms = reinterpret_cast<double*>(take((size_t)B * 6));
+    if (w) { w->s = s_; w->h1 = h1; w->h2 = h2; w->dS = dS; w->dZ2 = z2; w->dZ1 = z1; w->terms = terms; }
+    return off;
+  }
+};
+
+// The dueling combination of one row (lin.hip lin_fwd_kernel's GYMRL_ACT_DUELING epilogue): z[0 .. A-1] = advantage stream,
+// z[A] = value stream -> q[k] = value + (z[k] - mean(advantage)); returns the greedy action (first index of the maximum).
+// The epilogue sums the advantages with a 16-lane butterfly over zero-padded lanes: ((z0 + z1) + (z2 + 0)) for A <= 3.
+__device__ __forceinline__ int dueling_row(const float* z, int A, float* q) {
+  const float z0 = z[0], z1 = A > 1 ? z[1] : 0.0f, z2 = A > 2 ? z[2] : 0.0f;
+  const float sum = (z0 + z1) + (z2 + 0.0f);
+  const float v = z[A];
+  int bi = 0;
+  float best = 0.0f;
+  for (int k = 0; k < A; ++k) {
+    const float qv = v + (z[k] - sum / (float)A);
+    q[k] = qv;
+    if (k == 0 || qv > best) { best = qv; bi = k; }
+  }
+  return bi;
+}
+
+constexpr int kRbMaxA = 3;
+
+__global__ __launch_bounds__(kThreads) void rainbow_rows_kernel(const gymrl_rainbow_update_args a, const RbWs ws) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const Lds L;
+  const int D = a.D, A = a.A, A1 = a.A + 1, H = a.H, ld = lin::slab_ld(H);
+  const int H1a = L.big, H1b = H1a + 16 * ld, H1c = H1b + 16 * ld, H2a = H1c + 16 * ld, H2b = H2a + 16 * ld, H2c = H2b + 16 * ld;
+  const int X0 = H2c + 16 * ld;
+  // head outputs of the three passes: [16][4] slabs in the small area (Q0, Q1, Cq0), dS in Dq0
+  const int Za = L.Q0, Zb = L.Q1, Zc = L.Cq0, DS = L.Dq0;
+  const int row0 = blockIdx.x * 16, nrows = min(16, a.B - row0);
+  const int t = threadIdx.x;
+  if (t < 16) {                         // gather (replay.hip replay_gather_kernel)
+    const int b = row0 + t;
+    const bool ok = t < nrows;
+    const int64_t row = ok ? a.idx[b] : 0;
+    for (int k = 0; k < kMaxD; ++k) {
+      const float sv = (ok && k < D) ? a.r_state[row * D + k] : 0.0f, s2 = (ok && k < D) ? a.r_next[row * D + k] : 0.0f;
+      lds[L.S + t * kMaxD + k] = sv; lds[L.S2 + t * kMaxD + k] = s2;
+      if (ok && k < D) ws.s[(size_t)b * D + k] = sv;
+    }
+    lds[L.Misc + t * 4 + 0] = ok ? a.r_reward[row] : 0.0f;
+    lds[L.Misc + t * 4 + 1] = ok ? (float)a.r_flag[row] : 0.0f;
+    lds[L.Misc + t * 4 + 2] = ok ? __int_as_float((int)a.r_action[row]) : 0.0f;
+    lds[L.Misc + t * 4 + 3] = (ok && a.is_weight) ? a.is_weight[b] : 1.0f;
+  }
+  __syncthreads();
+  const int R = GYMRL_ACT_RELU, NA = GYMRL_ACT_NONE, kD = kMaxD;
+  const size_t hw = (size_t)A1 * H;
+  // policy(s') [first draw] | target(s') [means] | policy(s) [second draw], the three passes sharing every stage (:320-334)
+  {
+    const FwdItem st[3] = {fwd_item(L.S2, kD, -1, 0, D, D, H, a.p_fc1_w, a.p_fc1_b, H1a, ld, nullptr, 0, R),
+                           fwd_item(L.S2, kD, -1, 0, D, D, H, a.t_fc1_w, a.t_fc1_b, H1b, ld, nullptr, 0, R),
+                           fwd_item(L.S, kD, -1, 0, D, D, H, a.p_fc1_w, a.p_fc1_b, H1c, ld, ws.h1, H, R)};
+    fwd_stage<3>(lds, st, row0, nrows);
+  }
+  __syncthreads();
+  {
+    const FwdItem st[3] = {fwd_item(H1a, ld, -1, 0, H, H, H, a.p_fc2_w, a.p_fc2_b, H2a, ld, nullptr, 0, R),
+                           fwd_item(H1b, ld, -1, 0, H, H, H, a.t_fc2_w, a.t_fc2_b, H2b, ld, nullptr, 0, R),
+                           fwd_item(H1c, ld, -1, 0, H, H, H, a.p_fc2_w, a.p_fc2_b, H2c, ld, ws.h2, H, R)};
+    fwd_stage<3>(lds, st, row0, nrows);
+  }
+  __syncthreads();
+  {
+    const FwdItem st[3] = {fwd_item(H2a, ld, -1, 0, H, H, A1, a.head_w, a.head_b, Za, 4, nullptr, 0, NA),
+                           fwd_item(H2b, ld, -1, 0, H, H, A1, a.head_w + hw, a.head_b + A1, Zb, 4, nullptr, 0, NA),
+                           fwd_item(H2c, ld, -1, 0, H, H, A1, a.head_w + 2 * hw, a.head_b + 2 * A1, Zc, 4, nullptr, 0, NA)};
+    fwd_stage<3>(lds, st, row0, nrows);
+  }
+  __syncthreads();
+  if (t < 16) {
+    // dueling heads, the double-DQN target and the IS-weighted loss gradient (offpolicy.hip dqn_td_kernel), dueling backward (lin.hip)
+    float q_no[kRbMaxA], q_nt[kRbMaxA], q[kRbMaxA];
+    const int astar = dueling_row(lds + Za + t * 4, A, q_no);
+    dueling_row(lds + Zb + t * 4, A, q_nt);
+    dueling_row(lds + Zc + t * 4, A, q);
+    const float invB = 1.0f / (float)a.B;
+    const float nq = q_nt[astar];
+    const float y = lds[L.Misc + t * 4 + 0] + a.gamma_n * nq * (1.0f - lds[L.Misc + t * 4 + 1]);
+    const int act = __float_as_int(lds[L.Misc + t * 4 + 2]);
+    const float td = q[act] - y;
+    const float wb = lds[L.Misc + t * 4 + 3];
+    float dq[kRbMaxA], sum = 0.0f;
+    for (int k = 0; k < A; ++k) { dq[k] = (k == act) ? (2.0f * td) * wb * invB : 0.0f; sum += dq[k]; }
+    const float m = sum / (float)A;
+    for (int k = 0; k < 4; ++k) {
+      const float v = k < A ? dq[k] - m : (k == A ? sum : 0.0f);
+      lds[DS + t * 4 + k] = v;
+      if (t < nrows && k < A1) ws.dS[(size_t)(row0 + t) * A1 + k] = v;
+    }
+    if (t < nrows) {
+      a.td_out[row0 + t] = td;
+      ws.terms[(size_t)(row0 + t) * 3 + 0] = (double)((td * td) * wb);
+    }
+  }
+  __syncthreads();
+  // loss.backward() of the third pass: head -> fc2 (the input gradients; the weight gradients are the tile launch's)
+  {
+    const BwdItem st[1] = {BwdItem{DS, 4, A1, a.head_w + 2 * hw, H, -1, nullptr, H2c, ld, R, X0, ld, ws.dZ2, H, nullptr}};
+    bwd_stage<1>(lds, st, row0, nrows);
+  }
+  __syncthreads();
+  {
+    const BwdItem st[1] = {BwdItem{X0, ld, H, a.p_fc2_w, H, -1, nullptr, H1c, ld, R, -1, 0, ws.dZ1, H, nullptr}};
+    bwd_stage<1>(lds, st, row0, nrows);
+  }
+}
+
+// Greedy acting on the noisy Q + CartPole + the n-step window: one lane per env after the network (16 per workgroup)
+__global__ __launch_bounds__(kThreads) void rainbow_act_kernel(const gymrl_rainbow_act_args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const Lds L;
+  const int D = a.D, A = a.A, A1 = a.A + 1, H = a.H, ld = lin::slab_ld(H);
+  const int X0 = L.big, X1 = X0 + 16 * ld;
+  const int row0 = blockIdx.x * 16, nrows = min(16, a.N - row0);
+  const int t = threadIdx.x;
+  if (t < 16) {
+    const int i = row0 + t;
+    for (int k = 0; k < kMaxD; ++k) lds[L.S + t * kMaxD + k] = (t < nrows && k < D) ? a.obs[(size_t)i * D + k] : 0.0f;
+  }
+  __syncthreads();
+  const int R = GYMRL_ACT_RELU, kD = kMaxD;
+  {
+    const FwdItem st[1] = {fwd_item(L.S, kD, -1, 0, D, D, H, a.fc1_w, a.fc1_b, X0, ld, nullptr, 0, R)};
+    fwd_stage<1>(lds, st, row0, nrows);
+  }
+  __syncthreads();
+  {
+    const FwdItem st[1] = {fwd_item(X0, ld, -1, 0, H, H, H, a.fc2_w, a.fc2_b, X1, ld, nullptr, 0, R)};
+    fwd_stage<1>(lds, st, row0, nrows);
+  }
+  __syncthreads();
+  {
+    const FwdItem st[1] = {fwd_item(X1, ld, -1, 0, H, H, A1, a.head_w, a.head_b, L.Q0, 4, nullptr, 0, GYMRL_ACT_NONE)};
+    fwd_stage<1>(lds, st, row0, nrows);
+  }
+  __syncthreads();
+  if (t < 64) {
+    const bool ok = t < nrows;
+    ClassicStep<4> r;
+    r.done = false; r.ret = 0.0; r.len = 0;
+    if (ok) {
+      const int e = row0 + t;
+      float q[kRbMaxA];
+      const int act = dueling_row(lds + L.Q0 + t * 4, A, q);
+      const CartPoleState st(a.env_state, a.N);
+      cartpole_step_one(st, e, a.env_seed, a.env_id0, act, r);
+      for (int k = 0; k < D; ++k) a.obs_out[(size_t)e * D + k] = r.o_next[k];
+      if (a.action_out) a.action_out[e] = act;
+      if (a.rew_out) a.rew_out[e] = r.reward;
+      if (a.done_out) a.done_out[e] = r.done;
+      if (r.done && a.ep_ret_out) a.ep_ret_out[e] = (float)r.ret;
+      // ---- replay.hip nstep_push_kernel for env e (deque.append :186-187, _get_n_step_transition :207-218) ----
+      const int N = a.N, n_steps = a.n_steps;
+      int64_t pushes = a.pushes, cursor = a.cursor;
+      if (a.push_dev) { pushes = a.push_dev[0]; cursor = a.push_dev[1]; }
+      const int slot = (int)(pushes % n_steps);
+      const bool emit = pushes + 1 >= n_steps;
+      const size_t so = (size_t)slot * N + e;
+      for (int k = 0; k < D; ++k) {
+        a.w_state[so * D + k] = lds[L.S + t * kMaxD + k];
+        a.w_next[so * D + k] = r.o_term[k];
+      }
+      a.w_action[so] = act; a.w_reward[so] = r.reward;
+      // :376 terminal = done and step != max_steps_per_episode - 1, by the step INDEX inside the episode
+      a.w_terminal[so] = (uint8_t)((r.done && r.len != a.max_episode_steps) ? 1 : 0);
+      a.w_done[so] = r.done;
+      if (emit) {
+        const int oldest = (slot + 1) % n_steps;
+        int src = slot;
+        double Rr = 0.0;
+        for (int i = n_steps - 1; i >= 0; --i) {
+          const int sidx = (oldest + i) % n_steps;
+          const size_t o = (size_t)sidx * N + e;
+          // this push's own slot is read back from what was just written (same lane, program order)
+          const bool dn = sidx == slot ? r.done : (a.w_done[o] != 0);
+          const float rw = sidx == slot ? r.reward : a.w_reward[o];
+          const double d = dn ? 1.0 : 0.0;
+          Rr = (double)rw + a.gamma * (1.0 - d) * Rr;
+          if (dn) src = sidx;
+        }
+        const int64_t row = (cursor + e) % a.cap;
+        const size_t oo = (size_t)oldest * N + e, ss = (size_t)src * N + e;
+        for (int k = 0; k < D; ++k) {
+          a.r_state[row * D + k] = oldest == slot ? lds[L.S + t * kMaxD + k] : a.w_state[oo * D + k];
+          a.r_next[row * D + k] = src == slot ? r.o_term[k] : a.w_next[ss * D + k];
+        }
+        a.r_action[row] = (uint32_t)(oldest == slot ? act : a.w_action[oo]);
+        a.r_reward[row] = (float)Rr;
+        a.r_flag[row] = src == slot ? (uint8_t)((r.done && r.len != a.max_episode_steps) ? 1 : 0) : a.w_terminal[ss];
+      }
+    }
+    accumulate_ep_stats(a.ep_stats, r.done && ok, r.ret, r.len);
+  }
+}
+
+inline bool rb_shape_ok(int B, int D, int A, int H) {
+  return B > 0 && B <= 256 && D > 0 && D <= kMaxD && A > 0 && A <= kRbMaxA && H >= 4 && H <= 256 && (H & 3) == 0;
+}
+
 // All eight images from the parameters as they are (after load_state_dict / a checkpoint / a hard target copy)
 __global__ __launch_bounds__(256) void sac_pack_kernel(const gymrl_sac_update_args a) {
   const int H = a.H, steps = H >> 4;
@@ -701,6 +927,70 @@ int gymrl_sac_act_step(const gymrl_sac_act_args* args, void* stream_) {
     attr_set = true;
   }
   hipLaunchKernelGGL(sac_act_kernel, dim3((a.N + 15) / 16), dim3(kThreads), lds_bytes(a.H, 2), (hipStream_t)stream_, a);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+size_t gymrl_rainbow_update_workspace_bytes(int B, int D, int A, int H) {
+  if (B <= 0 || D <= 0 || A <= 0 || H <= 0) return 0;
+  return RbWs::carve(nullptr, nullptr, B, D, A, H) + 256;
+}
+size_t gymrl_rainbow_args_bytes(int which) { return which == 0 ? sizeof(gymrl_rainbow_act_args) : which == 1 ? sizeof(gymrl_rainbow_update_args) : 0; }
+
+int gymrl_rainbow_act_step(const gymrl_rainbow_act_args* args, void* stream_) {
+  if (!args) return -22;
+  const gymrl_rainbow_act_args& a = *args;
+  if (a.N <= 0 || !rb_shape_ok(1, a.D, a.A, a.H) || a.env_kind != GYMRL_ENV_CARTPOLE || a.D != 4 || a.A != 2) return -22;
+  if (!a.env_state || !a.obs || !a.obs_out || !a.fc1_w || !a.fc1_b || !a.fc2_w || !a.fc2_b || !a.head_w || !a.head_b) return -22;
+  if (!a.w_state || !a.w_action || !a.w_reward || !a.w_next || !a.w_terminal || !a.w_done || a.n_steps <= 0 || a.pushes < 0 ||
+      !a.r_state || !a.r_action || !a.r_reward || !a.r_next || !a.r_flag || a.cap < a.N || a.cursor < 0)
+    return -22;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)rainbow_act_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(256, 2)) != hipSuccess)
+      return -1000 - (int)hipGetLastError();
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(rainbow_act_kernel, dim3((a.N + 15) / 16), dim3(kThreads), lds_bytes(a.H, 2), (hipStream_t)stream_, a);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_rainbow_update(const gymrl_rainbow_update_args* args, void* stream_) {
+  if (!args) return -22;
+  const gymrl_rainbow_update_args& a = *args;
+  if (!rb_shape_ok(a.B, a.D, a.A, a.H)) return -22;
+  if (!a.r_state || !a.r_action || !a.r_reward || !a.r_next || !a.r_flag || !a.idx || !a.p_fc1_w || !a.p_fc1_b || !a.p_fc2_w || !a.p_fc2_b ||
+      !a.t_fc1_w || !a.t_fc1_b || !a.t_fc2_w || !a.t_fc2_b || !a.head_w || !a.head_b || !a.td_out || !a.loss_sum || !a.d_fc1_w || !a.d_fc1_b ||
+      !a.d_fc2_w || !a.d_fc2_b || !a.d_head_w || !a.d_head_b || !a.workspace)
+    return -22;
+  hipStream_t stream = (hipStream_t)stream_;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)rainbow_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(256, 7)) != hipSuccess)
+      return -1000 - (int)hipGetLastError();
+    attr_set = true;
+  }
+  RbWs ws;
+  void* base = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(a.workspace) + 255) & ~(uintptr_t)255);
+  RbWs::carve(&ws, base, a.B, a.D, a.A, a.H);
+  const int B = a.B, D = a.D, A1 = a.A + 1, H = a.H;
+  hipLaunchKernelGGL(rainbow_rows_kernel, dim3((B + 15) / 16), dim3(kThreads), lds_bytes(H, 7), stream, a, ws);
+  DwArgs d{};
+  int w0 = 0, ns = 0;
+  auto seg = [&](const float* dZ, int ldz, int N, const float* X, int ldx, int K, float* gW, float* gb) {
+    DwSeg& s = d.seg[ns++];
+    s.dZ = dZ; s.X = X; s.X2 = nullptr; s.W = gW; s.b = gb; s.Wt = nullptr; s.bt = nullptr;
+    s.img_f = nullptr; s.img_b = nullptr; s.img_tf = nullptr;
+    s.ldz = ldz; s.ldx = ldx; s.ldx2 = 0; s.N = N; s.K = K; s.K1 = K; s.wave0 = w0;
+    w0 += ((N + 15) / 16) * ((K + 15) / 16);
+  };
+  seg(ws.dS, A1, A1, ws.h2, H, H, a.d_head_w, a.d_head_b);       // the stacked noisy heads (gymrl_noisy_split takes it from here)
+  seg(ws.dZ2, H, H, ws.h1, H, H, a.d_fc2_w, a.d_fc2_b);
+  seg(ws.dZ1, H, H, ws.s, D, D, a.d_fc1_w, a.d_fc1_b);
+  d.nseg = ns; d.total_waves = w0; d.B = B; d.store_grads = 1;
+  d.terms = ws.terms; d.term0 = 0; d.nterms = 1; d.sums = a.loss_sum; d.alpha_step = 0;
+  hipLaunchKernelGGL(sac_dw_kernel, dim3((w0 + 3) / 4 + 1), dim3(256), 0, stream, d);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

@@ -149,6 +149,89 @@ __global__ __launch_bounds__(1024) void per_ancestor_kernel(double* __restrict__
   }
 }
 
+// ---- explicit index batches of up to kSmallB elements (update_priorities at the reference's batch sizes) ------------------
+// The two kernels above resolve "who touched this leaf / node before me" with one thread per element walking the batch
+// (O(B) dependent LDS round trips each, 64-bit tree positions and a clz + shift per comparison): 27 + 44 us at B = 256
+// (profiles/r04_rainbow_kernel_stats_a.csv), a quarter of a Rainbow vector step.  Here the ids are 32-bit, computed ONCE per
+// element and level, four lanes share an element's search (each a quarter of the range, combined with two shuffles), and
+// only the ordered float64 sum of a node — the one thing the reference's order makes sequential — runs on one lane.
+// Same sums in the same order: the float64 tree stays bit-identical (tests/test_hip_parity_offpolicy.py::test_sumtree_*).
+constexpr int kSmallB = 512;
+
+__global__ __launch_bounds__(1024) void per_leaf_small_kernel(double* __restrict__ tree, int64_t cap, const int32_t* __restrict__ idx,
+                                                              int idx_is_tree, const double* __restrict__ prio,
+                                                              const double* __restrict__ ps_dev, double ps, int B,
+                                                              int64_t* __restrict__ leaf_out, double* __restrict__ change_out) {
+  __shared__ int32_t s_leaf[kSmallB];
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    const int32_t leaf = idx_is_tree ? idx[i] : idx[i] + (int32_t)(cap - 1);
+    s_leaf[i] = leaf;
+    leaf_out[i] = leaf;
+  }
+  __syncthreads();
+  // change_i = p_i - (value of the leaf just before element i is applied): the latest earlier element on the same leaf, else the tree
+  for (int w = threadIdx.x; w < 4 * B; w += blockDim.x) {
+    const int i = w >> 2, s = w & 3;
+    const int32_t leaf = s_leaf[i];
+    int found = -1;
+    for (int j = i - 1 - s; j >= 0; j -= 4)
+      if (s_leaf[j] == leaf) { found = j; break; }
+    found = max(found, __shfl_xor(found, 1, 64));
+    found = max(found, __shfl_xor(found, 2, 64));
+    if (s == 0) {
+      const double prev = found >= 0 ? prio_of(prio, ps_dev, ps, found) : tree[leaf];
+      change_out[i] = prio_of(prio, ps_dev, ps, i) - prev;
+    }
+  }
+  __syncthreads();
+  // last writer wins
+  for (int w = threadIdx.x; w < 4 * B; w += blockDim.x) {
+    const int i = w >> 2, s = w & 3;
+    const int32_t leaf = s_leaf[i];
+    int later = 0;
+    for (int j = i + 1 + s; j < B; j += 4)
+      if (s_leaf[j] == leaf) { later = 1; break; }
+    later |= __shfl_xor(later, 1, 64);
+    later |= __shfl_xor(later, 2, 64);
+    if (s == 0 && !later) tree[leaf] = prio_of(prio, ps_dev, ps, i);
+  }
+}
+
+// blockIdx.x = node depth d.  A node's additions happen in batch order (the reference's loop).
+__global__ __launch_bounds__(1024) void per_ancestor_small_kernel(double* __restrict__ tree, const int64_t* __restrict__ leaf_g,
+                                                                  const double* __restrict__ change_g, int B) {
+  __shared__ int32_t s_node[kSmallB];       // the element's ancestor at this depth, -1: none
+  __shared__ double s_change[kSmallB];
+  const int d = blockIdx.x;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    const int64_t lf = leaf_g[i];
+    const int L = depth_of(lf);
+    s_node[i] = L > d ? (int32_t)(((lf + 1) >> (L - d)) - 1) : -1;
+    s_change[i] = change_g[i];
+  }
+  __syncthreads();
+  for (int w = threadIdx.x; w < 4 * B; w += blockDim.x) {
+    const int i = w >> 2, s = w & 3;
+    const int32_t node = s_node[i];
+    int earlier = 0;                         // leader = the first batch element reaching this node
+    if (node >= 0)
+      for (int j = s; j < i; j += 4)
+        if (s_node[j] == node) { earlier = 1; break; }
+    earlier |= __shfl_xor(earlier, 1, 64);
+    earlier |= __shfl_xor(earlier, 2, 64);
+    if (s != 0 || node < 0 || earlier) continue;
+    double acc = tree[node];
+    for (int j0 = i; j0 < B; j0 += 8) {      // the node's additions in batch order, operands fetched eight at a time
+      int32_t v[8]; double c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const bool in = j0 + u < B; v[u] = in ? s_node[j0 + u] : -1; c[u] = in ? s_change[j0 + u] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (v[u] == node) acc += c[u];
+    }
+    tree[node] = acc;
+  }
+}
+
 // ---- the N-row vector store (idx == NULL): per_store_device.hpp ------------------------------------------------------
 // Launch 1: every row's leaf (no duplicates: B <= cap), change = p - old leaf, leaf := p.  Fully parallel.
 __global__ __launch_bounds__(kBlock) void per_store_leaf_kernel(double* __restrict__ tree, int64_t cap, int64_t idx_start,
@@ -461,6 +544,14 @@ int gymrl_per_update(double* tree, int64_t cap, const int32_t* idx, int64_t idx_
     if (depth > 0)
       hipLaunchKernelGGL(per_ancestor_sorted_kernel, dim3(depth), dim3(1024), (size_t)P * 16, stream, tree, ws.leaf,
                          ws.change, B, P);
+    GYMRL_CHECK_LAUNCH();
+    return 0;
+  }
+  if (B <= kSmallB && 2 * cap < (1ll << 31)) {                           // the reference's batch sizes: 32-bit ids, shared searches
+    hipLaunchKernelGGL(per_leaf_small_kernel, dim3(1), dim3(1024), 0, stream, tree, cap, idx, idx_is_tree, prio, prio_scalar_dev,
+                       prio_scalar, B, ws.leaf, ws.change);
+    if (depth > 0)
+      hipLaunchKernelGGL(per_ancestor_small_kernel, dim3(depth), dim3(1024), 0, stream, tree, ws.leaf, ws.change, B);
     GYMRL_CHECK_LAUNCH();
     return 0;
   }

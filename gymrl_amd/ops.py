@@ -10,7 +10,8 @@ import ctypes as C
 import torch
 
 from ._lib import (ACT_NONE, ACT_RELU, ACT_TANH, MLP_MAX_INPUT, MLP_MAX_STAGES, MLP_MAX_WIDTH, GaeOnline,
-                   MlpDesc, PPOCfg, PPOFullCfg, RolloutLunarArgs, SacActArgs, SacUpdateArgs, check, lib)
+                   MlpDesc, PPOCfg, PPOFullCfg, RainbowActArgs, RainbowUpdateArgs, RolloutLunarArgs, SacActArgs, SacUpdateArgs,
+                   check, lib)
 
 _vp = C.c_void_p
 
@@ -1315,4 +1316,62 @@ def sac_update(a, idx=None, idx_seed=0, idx_counter=0, idx_size=0, idx_dev=None,
     a.adam_critic_dev, a.adam_actor_dev = _addr(adam_critic_dev), _addr(adam_actor_dev)
     a.alpha_bias[0], a.alpha_bias[1], a.alpha_bias_dev = alpha_bias[0], alpha_bias[1], _addr(alpha_bias_dev)
     check(lib().gymrl_sac_update(C.byref(a), _stream()), "gymrl_sac_update")
+
+
+# --------------------------------------------- fused Rainbow vector step ---
+def rainbow_fused_shape_ok(B, D, A, H):
+    return 0 < B <= 256 and 0 < D <= 8 and 0 < A <= 3 and 4 <= H <= 256 and H % 4 == 0
+
+
+def rainbow_update_workspace(B, D, A, H, device):
+    return torch.empty(int(lib().gymrl_rainbow_update_workspace_bytes(C.c_int(B), C.c_int(D), C.c_int(A), C.c_int(H))),
+                       dtype=torch.uint8, device=device)
+
+
+def rainbow_act_args(env, net, win, ring, cap, n_steps, gamma, max_episode_steps):
+    """A gymrl_rainbow_act_args with the per-trainer constants filled in (net: DuelingNoisyNetwork — fc1 / fc2 are read in
+    place, the noisy heads arrive per step as gymrl_noisy_combine's stacked output)."""
+    a = RainbowActArgs()
+    a.N, a.D, a.A, a.H = env.n, env.obs_dim, env.act_dim, net.fc1.weight.shape[0]
+    a.env_kind, a.env_state, a.env_id0 = env.kind, _addr(env.state), env.env_id0
+    a.fc1_w, a.fc1_b, a.fc2_w, a.fc2_b = _addr(net.fc1.weight), _addr(net.fc1.bias), _addr(net.fc2.weight), _addr(net.fc2.bias)
+    a.max_episode_steps = int(max_episode_steps)
+    a.w_state, a.w_action, a.w_reward, a.w_next, a.w_terminal, a.w_done = (_addr(t) for t in win)
+    a.n_steps, a.gamma = int(n_steps), float(gamma)
+    a.r_state, a.r_action, a.r_reward, a.r_next, a.r_flag = (_addr(t) for t in ring)
+    a.cap = cap
+    return a
+
+
+def rainbow_act_step(a, env, obs, obs_out, head_w, head_b, pushes=0, cursor=0, push_dev=None, action_out=None, rew_out=None,
+                     done_out=None, ep_ret_out=None, ep_stats=None):
+    """gymrl_rainbow_act_step: greedy acting on the noisy Q + CartPole step + n-step push, one launch.  Returns what
+    gymrl_nstep_push returns: whether rows were emitted (by the HOST's push count)."""
+    a.env_seed = env.seed
+    a.obs, a.obs_out = _ptr(obs, torch.float32).value, _ptr(obs_out, torch.float32).value
+    a.head_w, a.head_b = _ptr(head_w, torch.float32).value, _ptr(head_b, torch.float32).value
+    a.pushes, a.cursor, a.push_dev = pushes, cursor, _addr(push_dev)
+    a.action_out, a.rew_out, a.done_out, a.ep_ret_out, a.ep_stats = (_addr(t) for t in (action_out, rew_out, done_out, ep_ret_out, ep_stats))
+    check(lib().gymrl_rainbow_act_step(C.byref(a), _stream()), "gymrl_rainbow_act_step")
+    return pushes + 1 >= a.n_steps
+
+
+def rainbow_update_args(B, D, A, policy, target, ring, gamma_n, loss_sum, d_head_w, d_head_b, workspace):
+    a = RainbowUpdateArgs()
+    a.B, a.D, a.A, a.H, a.gamma_n = B, D, A, policy.fc1.weight.shape[0], float(gamma_n)
+    a.r_state, a.r_action, a.r_reward, a.r_next, a.r_flag = (_addr(t) for t in ring)
+    a.p_fc1_w, a.p_fc1_b, a.p_fc2_w, a.p_fc2_b = (_addr(t) for t in (policy.fc1.weight, policy.fc1.bias, policy.fc2.weight, policy.fc2.bias))
+    a.t_fc1_w, a.t_fc1_b, a.t_fc2_w, a.t_fc2_b = (_addr(t) for t in (target.fc1.weight, target.fc1.bias, target.fc2.weight, target.fc2.bias))
+    a.d_fc1_w, a.d_fc1_b, a.d_fc2_w, a.d_fc2_b = (_addr(t) for t in (policy.fc1.weight.grad, policy.fc1.bias.grad, policy.fc2.weight.grad,
+                                                                     policy.fc2.bias.grad))
+    a.d_head_w, a.d_head_b, a.loss_sum, a.workspace = _addr(d_head_w), _addr(d_head_b), _addr(loss_sum), _addr(workspace)
+    return a
+
+
+def rainbow_update(a, idx, is_weight, head_w, head_b, td_out):
+    """gymrl_rainbow_update: gather + the three forwards + TD loss gradient + backward chain (rows), every weight gradient
+    (tiles) — two launches.  head_w [3 (A+1), H] / head_b [3 (A+1)]: gymrl_noisy_combine's stacked output."""
+    a.idx, a.is_weight = _ptr(idx, torch.int32).value, _addr(is_weight)
+    a.head_w, a.head_b, a.td_out = _ptr(head_w, torch.float32).value, _ptr(head_b, torch.float32).value, _ptr(td_out, torch.float32).value
+    check(lib().gymrl_rainbow_update(C.byref(a), _stream()), "gymrl_rainbow_update")
 

@@ -46,6 +46,9 @@ class Config:
         self.num_envs = 1
         self.updates_per_step = 1
         self.use_graphs = True             # replay the update as one captured hipGraph (train(); update() stays eager)
+        self.fused_step = True             # acting + env + n-step push in ONE launch, the update's ~20 Linear / loss launches in TWO
+        #                                    (csrc/offpolicy_step.hip; bit-identical to the layer-by-layer path, which remains for
+        #                                    other shapes and custom envs)
         self.chunk_steps = 16              # whole vector steps (acting, env, n-step store, sum tree, draw, update) as one
         #                                    hipGraph per 16 (graphs.StepChunk); 0: eager acting + a graph per update.  The
         #                                    eager launches of a step cost the host 0.46 ms at N = 8192 — more than the GPU needs
@@ -307,12 +310,7 @@ class PrioritizedNStepBuffer:
         if dev is not None:
             ops.nstep_push(self.win, self.n_steps, self.n_steps, self.gamma, state, action, reward, next_state,
                            terminal, done, self.ring, 0, dev=dev, ep_len=ep_len, max_episode_steps=max_len)
-            if self._tree_ahead is not None:
-                torch.cuda.current_stream().wait_stream(self._tree_ahead)
-                self._tree_ahead = None
-            else:
-                self._new_rows_priorities(dev[8:16])
-            return
+            return self.after_push(True, dev)
         if not (torch.is_tensor(reward) and reward.is_cuda):
             # host scalars / numpy rows — the reference's `store_transition(state, action, reward, next_state, terminal, done)` (:380)
             N, d_ = self.N, self.ring[0].device
@@ -322,6 +320,18 @@ class PrioritizedNStepBuffer:
             terminal, done = scalar.rows(terminal, N, torch.uint8, d_), scalar.rows(done, N, torch.uint8, d_)
         emitted = ops.nstep_push(self.win, self.n_steps, self.pushes, self.gamma, state, action, reward, next_state,
                                  terminal, done, self.ring, self.count)
+        self.after_push(emitted)
+
+    def after_push(self, emitted, dev=None):
+        """The sum-tree half of store_transition() once the n-step push (gymrl_nstep_push, or the fused acting launch)
+        is queued: the new rows' priorities — or the join with stage_tree()'s side stream — and the host cursors."""
+        if dev is not None:
+            if self._tree_ahead is not None:
+                torch.cuda.current_stream().wait_stream(self._tree_ahead)
+                self._tree_ahead = None
+            else:
+                self._new_rows_priorities(dev[8:16])
+            return
         self.pushes += 1
         if emitted:
             if self._tree_ahead is not None:
@@ -408,6 +418,34 @@ class RainbowDQNTrainer:
         self._parity_u = None          # tests: iterator of f64[B] PER uniforms for update()
         self._graph = None             # hipGraph of the update, captured on first use (update_async)
 
+    # ------------------------------------------------------------ fused vector step (csrc/offpolicy_step.hip) --
+    def _fused_update_ok(self):
+        cfg = self.cfg
+        return (bool(getattr(cfg, "fused_step", True)) and gnn.FUSED_LINEAR
+                and ops.rainbow_fused_shape_ok(cfg.batch_size, self.state_dim, self.action_dim, cfg.hidden_dim))
+
+    def _fused_act_ok(self):
+        env = self.env
+        return (self._fused_update_ok() and isinstance(env, VecEnv) and env.kind == ops.CARTPOLE and self.action_dim == 2
+                and self.memory.capacity >= env.n)
+
+    def _fused_state(self):
+        f = getattr(self, "_fused", None)
+        if f is None or f["env"] is not self.env:
+            cfg, m, p = self.cfg, self.memory, self.policy_net
+            A1, H, d = self.action_dim + 1, cfg.hidden_dim, self.device
+            f = self._fused = dict(env=self.env, dW=torch.empty(A1, H, device=d), db=torch.empty(A1, device=d),
+                                   ws=ops.rainbow_update_workspace(cfg.batch_size, self.state_dim, self.action_dim, H, d))
+            f["upd"] = ops.rainbow_update_args(cfg.batch_size, self.state_dim, self.action_dim, p, self.target_net, m.ring,
+                                               cfg.gamma ** cfg.n_steps, self._loss, f["dW"], f["db"], f["ws"])
+            f["act"] = (ops.rainbow_act_args(self.env, p, m.win, m.ring, m.capacity, m.n_steps, m.gamma, self.max_steps_per_episode)
+                        if isinstance(self.env, VecEnv) else None)
+        return f
+
+    @staticmethod
+    def _noisy_fields(m, **kw):
+        return dict(w_mu=m.weight_mu, w_sigma=m.weight_sigma, b_mu=m.bias_mu, b_sigma=m.bias_sigma, **kw)
+
     @torch.no_grad()
     def select_action(self, state, deterministic=False, count=True):
         """:293-309 for a batch [N, D]: greedy on the noisy Q (no epsilon).  count=False: the caller advances
@@ -440,6 +478,8 @@ class RainbowDQNTrainer:
         join=False (inside a StepChunk): the side stream keeps the sum tree — it goes straight on to the next vector
         step's new rows (stage_tree(chain=True)) and is joined when that step stores its transitions."""
         cfg = self.cfg
+        if self._fused_update_ok() and batch_index.numel() == cfg.batch_size:
+            return self._update_body_fused(batch_index, is_weight, bias, join)
         state, action, reward, next_state, terminal = ops.replay_gather(self.memory.ring, batch_index)
         fused = gnn.FUSED_LINEAR and self.policy_net.advantage.out_features + 1 <= 16
         if fused:
@@ -467,6 +507,55 @@ class RainbowDQNTrainer:
             self._sink.collect()
         self.optimizer.step(bias_dev=bias, polyak=(self.target_flat, cfg.tau))   # clip_grad_norm_(10) + Adam, then the soft
         #                                                                    target update :347-352 (parameters only) in the launch
+        with torch.cuda.stream(side):
+            side.wait_event(fork)
+            self.memory.update_priorities(batch_index, td)
+        if join:
+            main.wait_stream(side)
+        else:
+            self._tree_keep = (td, batch_index)       # read on the side stream: alive until the next join
+
+    @torch.no_grad()
+    def _noisy_heads3(self):
+        """The stacked effective head parameters of the update's three passes — policy on s' (first draw :320), target on s'
+        (means), policy on s (second draw :334) — built by ONE gymrl_noisy_combine launch, both draws made inside it in the
+        eager order.  -> (W [3 (A + 1), H], b [3 (A + 1)], the second draw's epsilons for the backward)."""
+        p, t = self.policy_net, self.target_net
+        first = []
+        for m in (p.advantage, p.value):
+            f = {k: v for k, v in m.noise_source()[0].items() if not k.endswith("_copy")}   # not needed after the launch
+            if f.get("w_eps") is m.weight_epsilon:        # parity mode: raw draws land in the module's buffers, which the
+                f["w_eps"], f["b_eps"] = f["w_eps"].clone(), f["b_eps"].clone()      # second draw below overwrites
+            first.append(self._noisy_fields(m, **f))
+        target = [self._noisy_fields(m, eval=True) for m in (t.advantage, t.value)]
+        second, eps = [], []
+        for m in (p.advantage, p.value):
+            f, saved = m.noise_source()
+            second.append(self._noisy_fields(m, **f))
+            eps += list(saved)
+        W, b = ops.noisy_combine(first + target + second, training=True)
+        return W, b, eps
+
+    @torch.no_grad()
+    def _update_body_fused(self, batch_index, is_weight, bias=None, join=True):
+        """_update_body with everything between the proportional draw and the optimiser step as gymrl_rainbow_update's two
+        launches (+ the two NoisyLinear launches that own the noise bookkeeping): same values, same destinations."""
+        cfg, p = self.cfg, self.policy_net
+        f = self._fused_state()
+        W, b, eps = self._noisy_heads3()
+        td = torch.empty(cfg.batch_size, device=self.device)
+        ops.rainbow_update(f["upd"], batch_index, is_weight, W, b, td)
+        main, side = torch.cuda.current_stream(), self._side if OVERLAP_TREE else torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(main)
+        layers = []
+        for i, m in enumerate((p.advantage, p.value)):
+            layers.append(dict(w_mu=m.weight_mu.grad, b_mu=m.bias_mu.grad, w_sigma=m.weight_sigma.grad,
+                               b_sigma=m.bias_sigma.grad, w_eps=eps[2 * i], b_eps=eps[2 * i + 1],
+                               dw_mu=m.weight_mu.grad, dw_sigma=m.weight_sigma.grad, db_mu=m.bias_mu.grad,
+                               db_sigma=m.bias_sigma.grad))
+        ops.noisy_split(layers, f["dW"], f["db"], training=True)
+        self.optimizer.step(bias_dev=bias, polyak=(self.target_flat, cfg.tau))
         with torch.cuda.stream(side):
             side.wait_event(fork)
             self.memory.update_priorities(batch_index, td)
@@ -619,6 +708,18 @@ class RainbowDQNTrainer:
         if rec is not None:
             for layer, c in ((self.policy_net.advantage, rec["noise"][0:8]), (self.policy_net.value, rec["noise"][8:16])):
                 layer.dev_counters = iter([c])
+        if self._fused_act_ok():
+            # greedy acting on the noisy Q (:371), env.step, `terminal` (:376) and the n-step push as ONE launch behind the
+            # launch that builds the heads' effective parameters (this forward's NoisyNet draw is made inside it)
+            p = self.policy_net
+            layers = [self._noisy_fields(mod, **mod.noise_source()[0]) for mod in (p.advantage, p.value)]
+            W, b = ops.noisy_combine(layers, training=True)
+            if rec is None:
+                self.total_steps += env.n                 # select_action's count (:301)
+            emitted = ops.rainbow_act_step(self._fused_state()["act"], env, obs, nxt, W, b, pushes=m.pushes, cursor=m.count,
+                                           push_dev=push, done_out=done, ep_ret_out=ep_ret, ep_stats=env.ep_stats)
+            m.after_push(emitted, push)
+            return
         action = self.select_action(obs) if rec is None else self.select_action(obs, count=False)
         env.step(action, nxt, lb["rew"], done_out=done, term_obs_out=lb["tobs"], ep_ret_out=ep_ret, ep_len_out=lb["ep_len"])
         # :376 terminal = done and step != max_steps_per_episode - 1: decided by the step INDEX inside the

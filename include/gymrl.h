@@ -1068,6 +1068,55 @@ size_t gymrl_sac_args_bytes(int which);      /* sizeof(gymrl_sac_act_args) (0) /
 int gymrl_sac_act_step(const gymrl_sac_act_args* args, void* stream);
 int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream);
 
+/*
+ * The same treatment for Rainbow's vector step (rainbow_dqn_cartpole.py:363-405; csrc/offpolicy_step.hip).  The NoisyLinear
+ * bookkeeping (which draw a forward uses, where its epsilons live) stays with gymrl_noisy_combine / gymrl_noisy_split, the sum
+ * tree with gymrl_per_*; the Linear / loss / env / n-step launches between them — ~20 of a step's ~45 — become three:
+ *   gymrl_rainbow_act_step     greedy acting on the noisy Q (:293-309, :371): fc1, fc2, the stacked noisy heads with the dueling
+ *                              combination, argmax (first maximum), CartPole step with auto-reset, `terminal = done and step !=
+ *                              max_steps - 1` (:376), the n-step window push and the emitted ring row (gymrl_nstep_push)
+ *   gymrl_rainbow_update       rows: ring gather at the sampled indices; policy(s') | target(s') | policy(s) through fc1, fc2 and
+ *                              their stacked heads (W_heads [3][A+1][H], b_heads [3][A+1] from gymrl_noisy_combine: first draw,
+ *                              target means, second draw); double-DQN target, IS-weighted TD loss gradient (gymrl_dqn_td_loss's
+ *                              expressions), dueling backward, input-gradient chain;  tiles: dW / db of the stacked head (for
+ *                              gymrl_noisy_split), fc2 and fc1 written where the caller says (the flat gradient buffer's views:
+ *                              clip_grad_norm_ needs every gradient before Adam), loss sum
+ * Bit-identical to the layer-by-layer path (same tile bodies, same scalar expressions).  Limits: H % 4 == 0, H <= 256, D <= 8,
+ * A <= 3, B <= 256; CartPole-v1 for the act step.
+ */
+typedef struct {
+  int N, D, A, H;
+  int env_kind;                              /* GYMRL_ENV_CARTPOLE */
+  void* env_state; uint64_t env_seed; int64_t env_id0;
+  const float* obs; float* obs_out;          /* f32[N, D] in / next observations out */
+  const float* fc1_w; const float* fc1_b; const float* fc2_w; const float* fc2_b;
+  const float* head_w; const float* head_b;  /* stacked effective head [A+1][H], [A+1] (advantage rows, then value) */
+  int max_episode_steps;
+  /* n-step windows + ring (gymrl_nstep_push's arguments) */
+  float* w_state; int32_t* w_action; float* w_reward; float* w_next; uint8_t* w_terminal; uint8_t* w_done;
+  int n_steps; int64_t pushes; double gamma;
+  float* r_state; uint32_t* r_action; float* r_reward; float* r_next; uint8_t* r_flag; int64_t cap, cursor;
+  const int64_t* push_dev;                   /* {pushes, cursor} from the device (hipGraph replay) or NULL */
+  int32_t* action_out; float* rew_out; uint8_t* done_out; float* ep_ret_out; double* ep_stats;   /* any may be NULL */
+} gymrl_rainbow_act_args;
+typedef struct {
+  int B, D, A, H;
+  float gamma_n;                             /* gamma ** n_steps */
+  const float* r_state; const uint32_t* r_action; const float* r_reward; const float* r_next; const uint8_t* r_flag;
+  const int32_t* idx; const float* is_weight;        /* i32[B] sampled rows, f32[B] importance weights (NULL: 1) */
+  const float* p_fc1_w; const float* p_fc1_b; const float* p_fc2_w; const float* p_fc2_b;    /* policy network */
+  const float* t_fc1_w; const float* t_fc1_b; const float* t_fc2_w; const float* t_fc2_b;    /* target network */
+  const float* head_w; const float* head_b;  /* [3][A+1][H], [3][A+1]: policy on s' (first draw), target on s', policy on s (second draw) */
+  float* td_out;                             /* f32[B] TD errors (update_priorities) */
+  double* loss_sum;                          /* f64[1] out: sum of w * td^2 */
+  float* d_fc1_w; float* d_fc1_b; float* d_fc2_w; float* d_fc2_b; float* d_head_w; float* d_head_b;   /* gradients (overwritten) */
+  void* workspace;                           /* >= gymrl_rainbow_update_workspace_bytes(B, D, A, H) */
+} gymrl_rainbow_update_args;
+size_t gymrl_rainbow_update_workspace_bytes(int B, int D, int A, int H);
+size_t gymrl_rainbow_args_bytes(int which);  /* sizeof(gymrl_rainbow_act_args) (0) / sizeof(gymrl_rainbow_update_args) (1) */
+int gymrl_rainbow_act_step(const gymrl_rainbow_act_args* args, void* stream);
+int gymrl_rainbow_update(const gymrl_rainbow_update_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

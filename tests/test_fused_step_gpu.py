@@ -96,3 +96,48 @@ def test_sac_fused_step_is_five_launches():
     assert tr._fused_ok() and tr._chunk is not None and tr._chunk.graph is not None
     assert all(torch.isfinite(getattr(tr, n)).all() for n in ("actor_flat", "critic_flat", "log_alpha"))
     assert tr.critic_optimizer.step_count >= 60
+
+
+def _run_rainbow(fused, steps, N, B, hidden, graphs=False, chunk=0):
+    from gymrl_amd import rainbow_dqn_cartpole as rb
+    rb.NoisyLinear._counter = 0
+    cfg = rb.Config()
+    cfg.num_envs, cfg.batch_size, cfg.hidden_dim, cfg.seed = N, B, hidden, 5
+    cfg.max_episodes, cfg.memory_capacity, cfg.use_graphs, cfg.chunk_steps, cfg.fused_step = 10 ** 9, 1 << 12, graphs, chunk, fused
+    torch.manual_seed(11)
+    tr = rb.RainbowDQNTrainer(cfg)
+    assert tr._fused_act_ok() == fused
+    tr.train(max_vector_steps=steps)
+    torch.cuda.synchronize()
+    return tr
+
+
+@pytest.mark.parametrize("N,B,hidden,steps", [(64, 256, 256, 70), (20, 24, 32, 40), (128, 128, 64, 50)])
+def test_rainbow_fused_step_equals_layer_by_layer(N, B, hidden, steps):
+    """Rainbow: acting + env + n-step push as one launch and the update's Linear / loss / backward launches as two, against
+    the layer-by-layer path (tests/test_trainers_gpu.py pins that one to the reference): networks, Adam moments, the float64
+    sum tree, the replay ring and the n-step windows bit for bit (the ring wraps: 4096 rows)."""
+    a, b = _run_rainbow(False, steps, N, B, hidden), _run_rainbow(True, steps, N, B, hidden)
+    assert a.optimizer.step_count == b.optimizer.step_count > 10
+    assert (a.total_steps, a.memory.count, a.memory.pushes, a.memory.draws) == (b.total_steps, b.memory.count, b.memory.pushes, b.memory.draws)
+    for x, y in zip(a.memory.ring + a.memory.win, b.memory.ring + b.memory.win):
+        assert torch.equal(x, y)
+    assert torch.equal(a.memory.sum_tree.tree, b.memory.sum_tree.tree)
+    assert torch.equal(a.flat_params, b.flat_params) and torch.equal(a.target_flat, b.target_flat)
+    assert torch.equal(a.optimizer.m, b.optimizer.m) and torch.equal(a.optimizer.v, b.optimizer.v)
+    assert torch.equal(a._loss, b._loss)
+    assert a.optimizer.param_groups[0]["lr"] == b.optimizer.param_groups[0]["lr"]
+    for name in ("advantage", "value"):
+        assert torch.equal(getattr(a.policy_net, name).weight_epsilon, getattr(b.policy_net, name).weight_epsilon)
+    assert list(a.episode_rewards) == list(b.episode_rewards)
+
+
+def test_rainbow_fused_chunked_equals_fused_eager():
+    a = _run_rainbow(True, 70, 64, 128, 256)
+    b = _run_rainbow(True, 70, 64, 128, 256, graphs=True, chunk=16)
+    assert b._chunk.graph is not None
+    assert torch.equal(a.flat_params, b.flat_params) and torch.equal(a.target_flat, b.target_flat)
+    assert torch.equal(a.memory.sum_tree.tree, b.memory.sum_tree.tree)
+    for x, y in zip(a.memory.ring, b.memory.ring):
+        assert torch.equal(x, y)
+    assert list(a.episode_rewards) == list(b.episode_rewards)
