@@ -196,7 +196,9 @@ class RainbowUpdateArgs(C.Structure):     # gymrl_rainbow_update_args (include/g
                 ("t_fc1_w", C.c_void_p), ("t_fc1_b", C.c_void_p), ("t_fc2_w", C.c_void_p), ("t_fc2_b", C.c_void_p),
                 ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("td_out", C.c_void_p), ("loss_sum", C.c_void_p),
                 ("d_fc1_w", C.c_void_p), ("d_fc1_b", C.c_void_p), ("d_fc2_w", C.c_void_p), ("d_fc2_b", C.c_void_p),
-                ("d_head_w", C.c_void_p), ("d_head_b", C.c_void_p), ("workspace", C.c_void_p)]
+                ("d_head_w", C.c_void_p), ("d_head_b", C.c_void_p), ("workspace", C.c_void_p),
+                ("split_heads", C.c_int), ("dw_mu", C.c_void_p * 2), ("dw_sigma", C.c_void_p * 2), ("db_mu", C.c_void_p * 2),
+                ("db_sigma", C.c_void_p * 2), ("w_eps", C.c_void_p * 2), ("b_eps", C.c_void_p * 2)]
 
 
 class PPOFullCfg(C.Structure):

@@ -493,6 +493,9 @@ struct DwArgs {
   float omb1, beta2, omb2, eps;
   float tau, omt;
   int store_grads;                                // != 0: seg.W / seg.b are gradient DESTINATIONS (overwritten), no optimiser step
+  // store_grads: segment 0 is Rainbow's stacked noisy head and its gradient is split here (lin.hip noisy_split_kernel)
+  int split_heads, split_A;
+  float* dw_mu[2]; float* dw_sigma[2]; float* db_mu[2]; float* db_sigma[2]; const float* w_eps[2]; const float* b_eps[2];
   // loss sums + temperature (the launch's last workgroup)
   const double* terms; int term0, nterms; double* sums;
   int alpha_step;
@@ -550,6 +553,27 @@ __global__ __launch_bounds__(256) void sac_dw_kernel(const DwArgs a) {
   ad.bc2_sqrt = a.adam_dev ? a.adam_dev[2] : a.adam[2];
   ad.omb1 = a.omb1; ad.beta2 = a.beta2; ad.omb2 = a.omb2; ad.eps = a.eps;
   const int kc = kb + r;
+  if (a.store_grads && a.split_heads && si == 0) {
+    // d mu = dW, d sigma = dW * eps, per NoisyLinear layer: rows 0 .. A-1 the advantage stream, row A the value stream
+    if (kc < s.K) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int no = nt * 16 + 4 * q + g;
+        if (no >= s.N) continue;
+        const int l = no < a.split_A ? 0 : 1, n = no - (l ? a.split_A : 0);
+        const size_t o = (size_t)n * s.K + kc;
+        a.dw_mu[l][o] = acc[g];
+        a.dw_sigma[l][o] = acc[g] * a.w_eps[l][o];
+      }
+    }
+    const int nn = nt * 16 + r;
+    if (cg == 0 && q == 0 && nn < s.N) {
+      const int l = nn < a.split_A ? 0 : 1, n = nn - (l ? a.split_A : 0);
+      a.db_mu[l][n] = colsum;
+      a.db_sigma[l][n] = colsum * a.b_eps[l][n];
+    }
+    return;
+  }
   if (a.store_grads) {                            // Rainbow: clip_grad_norm_ needs every gradient before Adam may run
     if (kc < s.K) {
 #pragma unroll
@@ -962,7 +986,7 @@ int gymrl_rainbow_update(const gymrl_rainbow_update_args* args, void* stream_) {
   if (!rb_shape_ok(a.B, a.D, a.A, a.H)) return -22;
   if (!a.r_state || !a.r_action || !a.r_reward || !a.r_next || !a.r_flag || !a.idx || !a.p_fc1_w || !a.p_fc1_b || !a.p_fc2_w || !a.p_fc2_b ||
       !a.t_fc1_w || !a.t_fc1_b || !a.t_fc2_w || !a.t_fc2_b || !a.head_w || !a.head_b || !a.td_out || !a.loss_sum || !a.d_fc1_w || !a.d_fc1_b ||
-      !a.d_fc2_w || !a.d_fc2_b || !a.d_head_w || !a.d_head_b || !a.workspace)
+      !a.d_fc2_w || !a.d_fc2_b || (!a.split_heads && (!a.d_head_w || !a.d_head_b)) || !a.workspace)
     return -22;
   hipStream_t stream = (hipStream_t)stream_;
   static bool attr_set = false;
@@ -989,6 +1013,12 @@ int gymrl_rainbow_update(const gymrl_rainbow_update_args* args, void* stream_) {
   seg(ws.dZ2, H, H, ws.h1, H, H, a.d_fc2_w, a.d_fc2_b);
   seg(ws.dZ1, H, H, ws.s, D, D, a.d_fc1_w, a.d_fc1_b);
   d.nseg = ns; d.total_waves = w0; d.B = B; d.store_grads = 1;
+  d.split_heads = a.split_heads ? 1 : 0; d.split_A = a.A;
+  for (int l = 0; l < 2; ++l) {
+    d.dw_mu[l] = a.dw_mu[l]; d.dw_sigma[l] = a.dw_sigma[l]; d.db_mu[l] = a.db_mu[l]; d.db_sigma[l] = a.db_sigma[l];
+    d.w_eps[l] = a.w_eps[l]; d.b_eps[l] = a.b_eps[l];
+    if (a.split_heads && (!a.dw_mu[l] || !a.dw_sigma[l] || !a.db_mu[l] || !a.db_sigma[l] || !a.w_eps[l] || !a.b_eps[l])) return -22;
+  }
   d.terms = ws.terms; d.term0 = 0; d.nterms = 1; d.sums = a.loss_sum; d.alpha_step = 0;
   hipLaunchKernelGGL(sac_dw_kernel, dim3((w0 + 3) / 4 + 1), dim3(256), 0, stream, d);
   GYMRL_CHECK_LAUNCH();

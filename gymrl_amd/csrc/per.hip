@@ -436,7 +436,7 @@ __global__ __launch_bounds__(kBlock) void per_sample_kernel(
     const double* __restrict__ tree, int64_t cap, const double* __restrict__ u, uint64_t seed,
     uint64_t counter, int B, int64_t size, double beta, int variant_b, int32_t* __restrict__ idx_out,
     double* __restrict__ prio_out, float* __restrict__ w32, double* __restrict__ w64,
-    double* __restrict__ blockmax, const PerSampleDev* __restrict__ dev) {
+    double* __restrict__ blockmax, const PerSampleDev* __restrict__ dev, int normalize_here) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const int64_t tcap = 2 * cap - 1;
   if (dev) { counter = dev->counter; size = dev->size; beta = dev->beta; }     // this replay's draw scalars
@@ -477,6 +477,13 @@ __global__ __launch_bounds__(kBlock) void per_sample_kernel(
     __syncthreads();
   }
   if (threadIdx.x == 0) blockmax[blockIdx.x] = sm[0];
+  if (normalize_here) {        // a single-block draw (B <= 256): per_normalize_kernel's division right here, one launch less
+    const double m = fmax(0.0, sm[0]);
+    if (i < B) {
+      if (variant_b) w32[i] = (float)(w64[i] / m);
+      else w32[i] = w32[i] / (float)m;
+    }
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void per_normalize_kernel(float* __restrict__ w32,
@@ -595,9 +602,10 @@ int gymrl_per_sample(const double* tree, int64_t cap, const double* u, uint64_t 
   double* w64 = ws.change;                 // reuse: f64[B]
   double* bmax = ws.partial;               // f64[nb]
   hipLaunchKernelGGL(per_sample_kernel, dim3(nb), dim3(kBlock), 0, stream, tree, cap, u, seed, counter, B,
-                     size, beta, variant_b, idx_out, prio_out, w_out, w64, bmax, static_cast<const PerSampleDev*>(dev));
-  hipLaunchKernelGGL(per_normalize_kernel, dim3(nb), dim3(kBlock), 0, stream, w_out, w64, B, bmax, nb,
-                     variant_b);
+                     size, beta, variant_b, idx_out, prio_out, w_out, w64, bmax, static_cast<const PerSampleDev*>(dev), nb == 1 ? 1 : 0);
+  if (nb > 1)
+    hipLaunchKernelGGL(per_normalize_kernel, dim3(nb), dim3(kBlock), 0, stream, w_out, w64, B, bmax, nb,
+                       variant_b);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

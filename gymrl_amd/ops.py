@@ -1368,10 +1368,17 @@ def rainbow_update_args(B, D, A, policy, target, ring, gamma_n, loss_sum, d_head
     return a
 
 
-def rainbow_update(a, idx, is_weight, head_w, head_b, td_out):
+def rainbow_update(a, idx, is_weight, head_w, head_b, td_out, split=None):
     """gymrl_rainbow_update: gather + the three forwards + TD loss gradient + backward chain (rows), every weight gradient
     (tiles) — two launches.  head_w [3 (A+1), H] / head_b [3 (A+1)]: gymrl_noisy_combine's stacked output."""
     a.idx, a.is_weight = _ptr(idx, torch.int32).value, _addr(is_weight)
     a.head_w, a.head_b, a.td_out = _ptr(head_w, torch.float32).value, _ptr(head_b, torch.float32).value, _ptr(td_out, torch.float32).value
+    # split: [(dw_mu, dw_sigma, db_mu, db_sigma, w_eps, b_eps)] of the advantage and the value layer -> gymrl_noisy_split's work
+    # happens in the weight-gradient launch (None: the stacked gradient goes to d_head_w / d_head_b)
+    a.split_heads = 0 if split is None else 1
+    if split is not None:
+        for l, (wm, wsg, bm, bsg, we, be) in enumerate(split):
+            a.dw_mu[l], a.dw_sigma[l], a.db_mu[l], a.db_sigma[l] = _addr(wm), _addr(wsg), _addr(bm), _addr(bsg)
+            a.w_eps[l], a.b_eps[l] = _addr(we), _addr(be)
     check(lib().gymrl_rainbow_update(C.byref(a), _stream()), "gymrl_rainbow_update")
 

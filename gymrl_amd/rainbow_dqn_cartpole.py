@@ -544,17 +544,13 @@ class RainbowDQNTrainer:
         f = self._fused_state()
         W, b, eps = self._noisy_heads3()
         td = torch.empty(cfg.batch_size, device=self.device)
-        ops.rainbow_update(f["upd"], batch_index, is_weight, W, b, td)
+        # the stacked head's gradient is split into d mu / d sigma of the two NoisyLinear layers by the weight-gradient launch
+        split = [(m.weight_mu.grad, m.weight_sigma.grad, m.bias_mu.grad, m.bias_sigma.grad, eps[2 * i], eps[2 * i + 1])
+                 for i, m in enumerate((p.advantage, p.value))]
+        ops.rainbow_update(f["upd"], batch_index, is_weight, W, b, td, split=split)
         main, side = torch.cuda.current_stream(), self._side if OVERLAP_TREE else torch.cuda.current_stream()
         fork = torch.cuda.Event()
         fork.record(main)
-        layers = []
-        for i, m in enumerate((p.advantage, p.value)):
-            layers.append(dict(w_mu=m.weight_mu.grad, b_mu=m.bias_mu.grad, w_sigma=m.weight_sigma.grad,
-                               b_sigma=m.bias_sigma.grad, w_eps=eps[2 * i], b_eps=eps[2 * i + 1],
-                               dw_mu=m.weight_mu.grad, dw_sigma=m.weight_sigma.grad, db_mu=m.bias_mu.grad,
-                               db_sigma=m.bias_sigma.grad))
-        ops.noisy_split(layers, f["dW"], f["db"], training=True)
         self.optimizer.step(bias_dev=bias, polyak=(self.target_flat, cfg.tau))
         with torch.cuda.stream(side):
             side.wait_event(fork)

@@ -1111,6 +1111,11 @@ typedef struct {
   double* loss_sum;                          /* f64[1] out: sum of w * td^2 */
   float* d_fc1_w; float* d_fc1_b; float* d_fc2_w; float* d_fc2_b; float* d_head_w; float* d_head_b;   /* gradients (overwritten) */
   void* workspace;                           /* >= gymrl_rainbow_update_workspace_bytes(B, D, A, H) */
+  /* gymrl_noisy_split inside the weight-gradient launch (split_heads != 0; d_head_w / d_head_b are then not written): the stacked
+   * head's gradient goes straight to the two NoisyLinear layers' parameters, [0] = advantage (rows 0 .. A-1), [1] = value (row A):
+   * d mu = dW, d sigma = dW * eps with the SECOND draw's epsilons (rainbow_dqn_cartpole.py:92-93 under autograd) */
+  int split_heads;
+  float* dw_mu[2]; float* dw_sigma[2]; float* db_mu[2]; float* db_sigma[2]; const float* w_eps[2]; const float* b_eps[2];
 } gymrl_rainbow_update_args;
 size_t gymrl_rainbow_update_workspace_bytes(int B, int D, int A, int H);
 size_t gymrl_rainbow_args_bytes(int which);  /* sizeof(gymrl_rainbow_act_args) (0) / sizeof(gymrl_rainbow_update_args) (1) */
