@@ -279,13 +279,28 @@ def main_offpolicy(a, rank, world, local_rank):
                 us=round(us, 2), indices_per_s=round(N / us * 1e6), bytes_per_index=16 * (depth - 1), GBps=round(store_bytes / us / 1e3, 3))
             roof = dict(bound="hbm", unit="GB/s", peak=HBM_PEAK / 1e9, achieved=round(store_bytes / us / 1e3, 3),
                         frac=round(store_bytes / us / 1e3 / (HBM_PEAK / 1e9), 6), traffic=None, launch_s=us * 1e-6,
-                        kernel="gymrl_per_update over the N new rows of a vector step (csrc/per.hip per_leaf + per_ancestor: the largest "
-                               "kernel group of a Rainbow step, 27 % of its kernel time): 320 algorithmic bytes per index (20 float64 "
-                               "read-modify-writes).  Bound by the REFERENCE'S ORDER, not by HBM: a node's additions are applied in batch "
-                               "order, so the root is one dependent chain of N float64 adds (DESIGN.md section 4); priced against HBM as the "
+                        kernel="gymrl_per_update over the N new rows of a vector step (csrc/per.hip per_store_leaf + per_store_ancestor): "
+                               "320 algorithmic bytes per index (20 float64 read-modify-writes).  Round 3 applied a node's additions in "
+                               "batch order (the root: one dependent chain of N float64 adds, 72-79 us); the reference stores ONE row per "
+                               "step, so the N-row store is now defined as one pairwise-summed addition per ancestor (DESIGN.md section 4, "
+                               "identical to the reference at N = 1).  Latency-bound scattered 8-byte accesses: priced against HBM as the "
                                "contract asks, and against this box's random-access rate below",
                         random_access_GBps_measured=round(ra_GBps, 1), random_accesses_per_s_measured=round(ra_per_s),
                         frac_of_random_access=round(store_bytes / us / 1e3 / ra_GBps, 5))
+            # the fused step's own launches (csrc/offpolicy_step.hip), event-timed at the run's sizes
+            if tr._fused_act_ok():
+                lb = tr._loop_buffers(N, 4)
+                trk = lb["tracker"]
+                us = _event_us(lambda: tr._vector_step(lb, lb["obs"], lb["nxt"], trk.ret[0], trk.done[0]), reps=20)
+                H = cfg.hidden_dim
+                fl = 2.0 * N * (4 * H + H * H + 3 * H)
+                pieces["acting step: noisy heads + fc1, fc2, dueling argmax + CartPole + n-step push (gymrl_noisy_combine + gymrl_rainbow_act_step) "
+                       "+ the new rows' sum-tree store on the side stream"] = dict(us=round(us, 2), TFLOPs=round(fl / us / 1e6, 2))
+                upd_us = _event_us(lambda: tr.update_async(), reps=30)
+                flu = 2.0 * B * (3 * (4 * H + H * H + 3 * H) + (3 * H + H * H) + (3 * H + H * H + 4 * H))
+                pieces[f"one update at batch {B} (proportional draw, three forwards, TD loss, backward, clip + Adam + Polyak, update_priorities)"] = dict(
+                    us=round(upd_us, 2), TFLOPs=round(flu / upd_us / 1e6, 3),
+                    note="gymrl_rainbow_update's row kernel carries 16 rows per workgroup: B / 16 = 16 of the 256 compute units do its MFMA work")
         else:
             from gymrl_amd import ops
             D, A = 3, 1
@@ -296,18 +311,32 @@ def main_offpolicy(a, rank, world, local_rank):
                 us = _event_us(lambda: ops.replay_gather(mem.ring, idx))
                 pieces[f"ring_gather B={nb}"] = dict(us=round(us, 2), rows_per_s=round(nb / us * 1e6), bytes_per_row=row_bytes,
                                                      GBps=round(row_bytes * nb / us / 1e3, 2), frac_hbm=round(row_bytes * nb / us / 1e3 / (HBM_PEAK / 1e9), 5))
-            obs = torch.randn(N, D, device=dev)
-            us = _event_us(lambda: tr.select_action(obs))
             H = cfg.hidden_dim
-            fl = 2.0 * N * (D * H + H * H + 2 * H * A)
-            pieces["acting forward (Actor: 3 Linear launches + the reparameterised sample)"] = dict(us=round(us, 2), TFLOPs=round(fl / us / 1e6, 2))
-            roof = dict(bound="mfma", unit="TFLOP/s", peak=MFMA_F32_PEAK / 1e12, achieved=round(fl / us / 1e6, 2),
-                        frac=round(fl / us / 1e6 / (MFMA_F32_PEAK / 1e12), 4), traffic=None, launch_s=us * 1e-6,
-                        kernel="the acting forward of one vector step (Actor.fc1, fc2, mean | log_std as gymrl_lin_fwd launches + "
-                               "gymrl_sac_sample_fwd; the 4096 x 256 x 256 layer is the largest kernel of a SAC step): launch- and "
-                               "latency-bound at this size, priced against the f32 MFMA peak as the only dense contraction of the step")
+            DA = D + A
+            # algorithmic f32 flops of one update (sac_pendulum.py:213-267): actor(s'), target Q x2, Q x2 forward + input gradients,
+            # actor(s), Q x2 forward + input gradients back to the action and through the actor, every weight gradient
+            actor_f, q_f = 2.0 * B * (D * H + H * H + 2 * H * A), 2.0 * B * (DA * H + H * H + H)
+            flu = (actor_f + 2 * q_f + 2 * q_f + 2 * 2.0 * B * (H + H * H) + 2 * q_f            # P1 + critic dW
+                   + actor_f + 2 * q_f + 2 * 2.0 * B * (H + H * H + DA * H) + 2.0 * B * (2 * A * H + H * H) + actor_f)   # P3 + actor dW
             upd_us = _event_us(lambda: tr.update_async() if getattr(cfg, "use_graphs", True) else tr.update(), reps=50)
-            pieces[f"one update at batch {B} (twin critics, actor, temperature, Adam x3 + Polyak; replayed as a hipGraph)"] = dict(us=round(upd_us, 2))
+            cus = (B + 15) // 16
+            roof = dict(bound="mfma", unit="TFLOP/s", peak=MFMA_F32_PEAK / 1e12, achieved=round(flu / upd_us / 1e6, 3),
+                        frac=round(flu / upd_us / 1e6 / (MFMA_F32_PEAK / 1e12), 5), traffic=None, launch_s=upd_us * 1e-6,
+                        flops_per_launch_group=flu, compute_units_carrying_rows=cus,
+                        frac_of_those_units=round(flu / upd_us / 1e6 / (MFMA_F32_PEAK / 1e12 * cus / 256.0), 4),
+                        kernel="gymrl_sac_update: the four launches of one update at batch 128 (csrc/offpolicy_step.hip: row-slab kernels P1 / P3, "
+                               "weight-gradient + Adam tile kernels P2 / P4).  A 16-row slab is ONE workgroup: B / 16 = 8 of the 256 compute units "
+                               "carry the MFMA work of the row kernels (a 16 x 256 x 256 layer is 3.9 us of f32 MFMA on one compute unit, "
+                               "5.9 us measured: tools/probe_sac_stages.py), so the figure is priced twice — against the chip's f32-MFMA peak "
+                               "as the contract asks (`frac`) and against the peak of the units that can work (`frac_of_those_units`)")
+            pieces[f"one update at batch {B} (twin critics, actor, temperature, Adam x3 + Polyak: gymrl_sac_update, 4 launches)"] = dict(us=round(upd_us, 2))
+            if tr._fused_ok():
+                lb = tr._loop_buffers(N, D)
+                trk = lb["tracker"]
+                us = _event_us(lambda: tr._vector_step(lb, lb["obs"], lb["nxt"], trk.ret[0], trk.done[0]), reps=20)
+                fl = 2.0 * N * (D * H + H * H + 2 * H * A)
+                pieces["acting step: Actor forward + reparameterised draw + Pendulum step + replay row (gymrl_sac_act_step, 1 launch)"] = dict(
+                    us=round(us, 2), TFLOPs=round(fl / us / 1e6, 2), frac_mfma=round(fl / us / 1e6 / (MFMA_F32_PEAK / 1e12), 4))
         vsteps = a.steps * VS
         out = {
             "metric": f"env-steps/sec at N envs/GPU ({'Rainbow DQN CartPole' if a.algo == 'rainbow' else 'SAC Pendulum'}), 1 update per vector step + %roofline",

@@ -106,6 +106,42 @@ __device__ __forceinline__ f32x4 tile_fwd(const float* Xs, int ldx, const float*
   return acc;
 }
 
+// tile_fwd's vector branch for TWO slabs that share the weight fragment (acting on more envs than the chip has compute units x 16:
+// one pass of 32-row workgroups instead of two of 16-row ones — the weights are streamed once and feed two MFMA chains).
+// K1 == K, K % 4 == 0.  Each slab's accumulator sees exactly tile_fwd's sequence.
+__device__ __forceinline__ void tile_fwd_x2(const float* Xs0, const float* Xs1, int ldx, int K, const float* __restrict__ W, int N, int nb,
+                                            int lane, f32x4& acc0, f32x4& acc1) {
+  const int r = lane & 15, q = lane >> 4;
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  acc0 = zero; acc1 = zero;
+  const int n = nb + r;
+  const bool n_ok = n < N;
+  const float* wrow = W + (size_t)(n_ok ? n : 0) * K;
+  const float* x0 = Xs0 + r * ldx;
+  const float* x1 = Xs1 + r * ldx;
+  for (int kp = 0; kp < K; kp += 16 * kMaxSteps) {
+    f32x4 wb[kMaxSteps];
+#pragma unroll
+    for (int c = 0; c < kMaxSteps; ++c) {
+      if (kp + 16 * c >= K) break;
+      const int k = kp + 16 * c + 4 * q;
+      wb[c] = *reinterpret_cast<const f32x4*>(wrow + (k < K ? k : 0));
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxSteps; ++c) {
+      if (kp + 16 * c >= K) break;
+      const int k = kp + 16 * c + 4 * q;
+      const bool k_ok = k < K;
+      const f32x4 xa = *reinterpret_cast<const f32x4*>(x0 + (k_ok ? k : 0));
+      const f32x4 xb = *reinterpret_cast<const f32x4*>(x1 + (k_ok ? k : 0));
+      const f32x4 a0 = k_ok ? xa : zero, a1 = k_ok ? xb : zero;
+      const f32x4 w = (n_ok && k_ok) ? wb[c] : zero;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc0 = mfma16(a0[e], w[e], acc0); acc1 = mfma16(a1[e], w[e], acc1); }
+    }
+  }
+}
+
 // acc += dZ . W[:, kb .. kb + 15] for the slab dZ [16][N] in LDS (already multiplied by the activation's derivative).
 // The order of lin_bwd_input_kernel: n0 = 0, 16, ...; e = 0..3; the MFMA adds n = n0 + 4q + e over q.  Calling it again
 // with another layer's dZ / W continues the same accumulator (the summed gradient of an input two layers share).

@@ -811,34 +811,47 @@ __global__ __launch_bounds__(kThreads) void rainbow_rows_kernel(const gymrl_rain
   }
 }
 
-// Greedy acting on the noisy Q + CartPole + the n-step window: one lane per env after the network (16 per workgroup)
+// Greedy acting on the noisy Q + CartPole + the n-step window: one lane per env after the network.  NS slabs of 16 envs per
+// workgroup: at N = 8192 the 16-row form is 512 workgroups = two rounds over the 256 compute units, each streaming every
+// weight again (45 us per launch); 32 rows per workgroup stream them once for two MFMA chains.
+template <int NS>
+__device__ __forceinline__ void act_layer(float* lds, int X, int ldx, int K, const float* W, const float* b, int N, int Ys, int ldy, int act) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+  const int ntiles = (N + 15) >> 4;
+  for (int t = wave; t < ntiles; t += kWaves) {
+    const int nb = t * 16;
+    f32x4 acc[2];
+    if (NS == 2) lin::tile_fwd_x2(lds + X, lds + X + 16 * ldx, ldx, K, W, N, nb, lane, acc[0], acc[1]);
+    else acc[0] = lin::tile_fwd(lds + X, ldx, nullptr, 0, K, K, W, N, nb, lane);
+    const int n = nb + r;
+    if (n < N) {
+      const float bv = b ? b[n] : 0.0f;
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) lds[Ys + (16 * sl + 4 * q + g) * ldy + n] = act_fwd(acc[sl][g] + bv, act, 0.0f, 0.0f);
+    }
+  }
+}
+
+template <int NS>
 __global__ __launch_bounds__(kThreads) void rainbow_act_kernel(const gymrl_rainbow_act_args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const Lds L;
+  constexpr int kRows = 16 * NS;
   const int D = a.D, A = a.A, A1 = a.A + 1, H = a.H, ld = lin::slab_ld(H);
-  const int X0 = L.big, X1 = X0 + 16 * ld;
-  const int row0 = blockIdx.x * 16, nrows = min(16, a.N - row0);
+  const int S = 0, Q = S + kRows * kMaxD, X0 = Q + kRows * 4, X1 = X0 + kRows * ld;
+  const int row0 = blockIdx.x * kRows, nrows = min(kRows, a.N - row0);
   const int t = threadIdx.x;
-  if (t < 16) {
+  if (t < kRows) {
     const int i = row0 + t;
-    for (int k = 0; k < kMaxD; ++k) lds[L.S + t * kMaxD + k] = (t < nrows && k < D) ? a.obs[(size_t)i * D + k] : 0.0f;
+    for (int k = 0; k < kMaxD; ++k) lds[S + t * kMaxD + k] = (t < nrows && k < D) ? a.obs[(size_t)i * D + k] : 0.0f;
   }
   __syncthreads();
-  const int R = GYMRL_ACT_RELU, kD = kMaxD;
-  {
-    const FwdItem st[1] = {fwd_item(L.S, kD, -1, 0, D, D, H, a.fc1_w, a.fc1_b, X0, ld, nullptr, 0, R)};
-    fwd_stage<1>(lds, st, row0, nrows);
-  }
+  act_layer<NS>(lds, S, kMaxD, D, a.fc1_w, a.fc1_b, H, X0, ld, GYMRL_ACT_RELU);
   __syncthreads();
-  {
-    const FwdItem st[1] = {fwd_item(X0, ld, -1, 0, H, H, H, a.fc2_w, a.fc2_b, X1, ld, nullptr, 0, R)};
-    fwd_stage<1>(lds, st, row0, nrows);
-  }
+  act_layer<NS>(lds, X0, ld, H, a.fc2_w, a.fc2_b, H, X1, ld, GYMRL_ACT_RELU);
   __syncthreads();
-  {
-    const FwdItem st[1] = {fwd_item(X1, ld, -1, 0, H, H, A1, a.head_w, a.head_b, L.Q0, 4, nullptr, 0, GYMRL_ACT_NONE)};
-    fwd_stage<1>(lds, st, row0, nrows);
-  }
+  act_layer<NS>(lds, X1, ld, H, a.head_w, a.head_b, A1, Q, 4, GYMRL_ACT_NONE);
   __syncthreads();
   if (t < 64) {
     const bool ok = t < nrows;
@@ -847,7 +860,7 @@ __global__ __launch_bounds__(kThreads) void rainbow_act_kernel(const gymrl_rainb
     if (ok) {
       const int e = row0 + t;
       float q[kRbMaxA];
-      const int act = dueling_row(lds + L.Q0 + t * 4, A, q);
+      const int act = dueling_row(lds + Q + t * 4, A, q);
       const CartPoleState st(a.env_state, a.N);
       cartpole_step_one(st, e, a.env_seed, a.env_id0, act, r);
       for (int k = 0; k < D; ++k) a.obs_out[(size_t)e * D + k] = r.o_next[k];
@@ -863,12 +876,13 @@ __global__ __launch_bounds__(kThreads) void rainbow_act_kernel(const gymrl_rainb
       const bool emit = pushes + 1 >= n_steps;
       const size_t so = (size_t)slot * N + e;
       for (int k = 0; k < D; ++k) {
-        a.w_state[so * D + k] = lds[L.S + t * kMaxD + k];
+        a.w_state[so * D + k] = lds[S + t * kMaxD + k];
         a.w_next[so * D + k] = r.o_term[k];
       }
       a.w_action[so] = act; a.w_reward[so] = r.reward;
       // :376 terminal = done and step != max_steps_per_episode - 1, by the step INDEX inside the episode
-      a.w_terminal[so] = (uint8_t)((r.done && r.len != a.max_episode_steps) ? 1 : 0);
+      const uint8_t term_now = (uint8_t)((r.done && r.len != a.max_episode_steps) ? 1 : 0);
+      a.w_terminal[so] = term_now;
       a.w_done[so] = r.done;
       if (emit) {
         const int oldest = (slot + 1) % n_steps;
@@ -877,7 +891,7 @@ __global__ __launch_bounds__(kThreads) void rainbow_act_kernel(const gymrl_rainb
         for (int i = n_steps - 1; i >= 0; --i) {
           const int sidx = (oldest + i) % n_steps;
           const size_t o = (size_t)sidx * N + e;
-          // this push's own slot is read back from what was just written (same lane, program order)
+          // this push's own slot comes from the registers that have just been stored (same lane)
           const bool dn = sidx == slot ? r.done : (a.w_done[o] != 0);
           const float rw = sidx == slot ? r.reward : a.w_reward[o];
           const double d = dn ? 1.0 : 0.0;
@@ -887,12 +901,12 @@ __global__ __launch_bounds__(kThreads) void rainbow_act_kernel(const gymrl_rainb
         const int64_t row = (cursor + e) % a.cap;
         const size_t oo = (size_t)oldest * N + e, ss = (size_t)src * N + e;
         for (int k = 0; k < D; ++k) {
-          a.r_state[row * D + k] = oldest == slot ? lds[L.S + t * kMaxD + k] : a.w_state[oo * D + k];
+          a.r_state[row * D + k] = oldest == slot ? lds[S + t * kMaxD + k] : a.w_state[oo * D + k];
           a.r_next[row * D + k] = src == slot ? r.o_term[k] : a.w_next[ss * D + k];
         }
         a.r_action[row] = (uint32_t)(oldest == slot ? act : a.w_action[oo]);
         a.r_reward[row] = (float)Rr;
-        a.r_flag[row] = src == slot ? (uint8_t)((r.done && r.len != a.max_episode_steps) ? 1 : 0) : a.w_terminal[ss];
+        a.r_flag[row] = src == slot ? term_now : a.w_terminal[ss];
       }
     }
     accumulate_ep_stats(a.ep_stats, r.done && ok, r.ret, r.len);
@@ -969,19 +983,25 @@ int gymrl_rainbow_act_step(const gymrl_rainbow_act_args* args, void* stream_) {
   if (!a.w_state || !a.w_action || !a.w_reward || !a.w_next || !a.w_terminal || !a.w_done || a.n_steps <= 0 || a.pushes < 0 ||
       !a.r_state || !a.r_action || !a.r_reward || !a.r_next || !a.r_flag || a.cap < a.N || a.cursor < 0)
     return -22;
+  auto act_lds = [](int H, int ns) { return sizeof(float) * (size_t)(16 * ns * (kMaxD + 4 + 2 * lin::slab_ld(H))); };
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)rainbow_act_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(256, 2)) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)rainbow_act_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)act_lds(256, 1)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)rainbow_act_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)act_lds(256, 2)) != hipSuccess)
       return -1000 - (int)hipGetLastError();
     attr_set = true;
   }
-  hipLaunchKernelGGL(rainbow_act_kernel, dim3((a.N + 15) / 16), dim3(kThreads), lds_bytes(a.H, 2), (hipStream_t)stream_, a);
+  // more envs than one round of 16-row workgroups over the 256 compute units: 32 rows per workgroup (weights streamed once)
+  if (a.N > 16 * 256 && (a.D & 3) == 0 && (a.H & 3) == 0)
+    hipLaunchKernelGGL(rainbow_act_kernel<2>, dim3((a.N + 31) / 32), dim3(kThreads), act_lds(a.H, 2), (hipStream_t)stream_, a);
+  else
+    hipLaunchKernelGGL(rainbow_act_kernel<1>, dim3((a.N + 15) / 16), dim3(kThreads), act_lds(a.H, 1), (hipStream_t)stream_, a);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
 
-int gymrl_rainbow_update(const gymrl_rainbow_update_args* args, void* stream_) {
-  if (!args) return -22;
+int gymrl_rainbow_update(const gymrl_rainbow_update_args* args, int phase, void* stream_) {
+  if (!args || phase < 0 || phase > 2) return -22;
   const gymrl_rainbow_update_args& a = *args;
   if (!rb_shape_ok(a.B, a.D, a.A, a.H)) return -22;
   if (!a.r_state || !a.r_action || !a.r_reward || !a.r_next || !a.r_flag || !a.idx || !a.p_fc1_w || !a.p_fc1_b || !a.p_fc2_w || !a.p_fc2_b ||
@@ -999,7 +1019,8 @@ int gymrl_rainbow_update(const gymrl_rainbow_update_args* args, void* stream_) {
   void* base = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(a.workspace) + 255) & ~(uintptr_t)255);
   RbWs::carve(&ws, base, a.B, a.D, a.A, a.H);
   const int B = a.B, D = a.D, A1 = a.A + 1, H = a.H;
-  hipLaunchKernelGGL(rainbow_rows_kernel, dim3((B + 15) / 16), dim3(kThreads), lds_bytes(H, 7), stream, a, ws);
+  if (phase != 2) hipLaunchKernelGGL(rainbow_rows_kernel, dim3((B + 15) / 16), dim3(kThreads), lds_bytes(H, 7), stream, a, ws);
+  if (phase == 1) { GYMRL_CHECK_LAUNCH(); return 0; }
   DwArgs d{};
   int w0 = 0, ns = 0;
   auto seg = [&](const float* dZ, int ldz, int N, const float* X, int ldx, int K, float* gW, float* gb) {

@@ -1368,7 +1368,7 @@ def rainbow_update_args(B, D, A, policy, target, ring, gamma_n, loss_sum, d_head
     return a
 
 
-def rainbow_update(a, idx, is_weight, head_w, head_b, td_out, split=None):
+def rainbow_update(a, idx, is_weight, head_w, head_b, td_out, split=None, phase=0):
     """gymrl_rainbow_update: gather + the three forwards + TD loss gradient + backward chain (rows), every weight gradient
     (tiles) — two launches.  head_w [3 (A+1), H] / head_b [3 (A+1)]: gymrl_noisy_combine's stacked output."""
     a.idx, a.is_weight = _ptr(idx, torch.int32).value, _addr(is_weight)
@@ -1380,5 +1380,5 @@ def rainbow_update(a, idx, is_weight, head_w, head_b, td_out, split=None):
         for l, (wm, wsg, bm, bsg, we, be) in enumerate(split):
             a.dw_mu[l], a.dw_sigma[l], a.db_mu[l], a.db_sigma[l] = _addr(wm), _addr(wsg), _addr(bm), _addr(bsg)
             a.w_eps[l], a.b_eps[l] = _addr(we), _addr(be)
-    check(lib().gymrl_rainbow_update(C.byref(a), _stream()), "gymrl_rainbow_update")
+    check(lib().gymrl_rainbow_update(C.byref(a), C.c_int(phase), _stream()), "gymrl_rainbow_update")
 

@@ -547,10 +547,13 @@ class RainbowDQNTrainer:
         # the stacked head's gradient is split into d mu / d sigma of the two NoisyLinear layers by the weight-gradient launch
         split = [(m.weight_mu.grad, m.weight_sigma.grad, m.bias_mu.grad, m.bias_sigma.grad, eps[2 * i], eps[2 * i + 1])
                  for i, m in enumerate((p.advantage, p.value))]
-        ops.rainbow_update(f["upd"], batch_index, is_weight, W, b, td, split=split)
+        ops.rainbow_update(f["upd"], batch_index, is_weight, W, b, td, split=split, phase=1)      # rows: td is complete
+        # :340 update_priorities needs only td: it forks off here, beside the weight gradients, the clip and Adam (the sum
+        # tree's chain — priorities, then the next step's new rows, then the draw — is the step's critical path)
         main, side = torch.cuda.current_stream(), self._side if OVERLAP_TREE else torch.cuda.current_stream()
         fork = torch.cuda.Event()
         fork.record(main)
+        ops.rainbow_update(f["upd"], batch_index, is_weight, W, b, td, split=split, phase=2)      # tiles
         self.optimizer.step(bias_dev=bias, polyak=(self.target_flat, cfg.tau))
         with torch.cuda.stream(side):
             side.wait_event(fork)

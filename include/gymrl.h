@@ -1120,7 +1120,7 @@ typedef struct {
 size_t gymrl_rainbow_update_workspace_bytes(int B, int D, int A, int H);
 size_t gymrl_rainbow_args_bytes(int which);  /* sizeof(gymrl_rainbow_act_args) (0) / sizeof(gymrl_rainbow_update_args) (1) */
 int gymrl_rainbow_act_step(const gymrl_rainbow_act_args* args, void* stream);
-int gymrl_rainbow_update(const gymrl_rainbow_update_args* args, void* stream);
+int gymrl_rainbow_update(const gymrl_rainbow_update_args* args, int phase, void* stream);   /* phase 0: both launches; 1: rows (td_out is complete after it: update_priorities may start); 2: tiles */
 
 #ifdef __cplusplus
 }

@@ -103,7 +103,7 @@ def _run_rainbow(fused, steps, N, B, hidden, graphs=False, chunk=0):
     rb.NoisyLinear._counter = 0
     cfg = rb.Config()
     cfg.num_envs, cfg.batch_size, cfg.hidden_dim, cfg.seed = N, B, hidden, 5
-    cfg.max_episodes, cfg.memory_capacity, cfg.use_graphs, cfg.chunk_steps, cfg.fused_step = 10 ** 9, 1 << 12, graphs, chunk, fused
+    cfg.max_episodes, cfg.memory_capacity, cfg.use_graphs, cfg.chunk_steps, cfg.fused_step = 10 ** 9, max(1 << 12, 2 * N), graphs, chunk, fused
     torch.manual_seed(11)
     tr = rb.RainbowDQNTrainer(cfg)
     assert tr._fused_act_ok() == fused
@@ -112,13 +112,13 @@ def _run_rainbow(fused, steps, N, B, hidden, graphs=False, chunk=0):
     return tr
 
 
-@pytest.mark.parametrize("N,B,hidden,steps", [(64, 256, 256, 70), (20, 24, 32, 40), (128, 128, 64, 50)])
+@pytest.mark.parametrize("N,B,hidden,steps", [(64, 256, 256, 70), (20, 24, 32, 40), (128, 128, 64, 50), (8192, 256, 256, 12), (4100, 64, 32, 9)])
 def test_rainbow_fused_step_equals_layer_by_layer(N, B, hidden, steps):
     """Rainbow: acting + env + n-step push as one launch and the update's Linear / loss / backward launches as two, against
     the layer-by-layer path (tests/test_trainers_gpu.py pins that one to the reference): networks, Adam moments, the float64
     sum tree, the replay ring and the n-step windows bit for bit (the ring wraps: 4096 rows)."""
     a, b = _run_rainbow(False, steps, N, B, hidden), _run_rainbow(True, steps, N, B, hidden)
-    assert a.optimizer.step_count == b.optimizer.step_count > 10
+    assert a.optimizer.step_count == b.optimizer.step_count > 4
     assert (a.total_steps, a.memory.count, a.memory.pushes, a.memory.draws) == (b.total_steps, b.memory.count, b.memory.pushes, b.memory.draws)
     for x, y in zip(a.memory.ring + a.memory.win, b.memory.ring + b.memory.win):
         assert torch.equal(x, y)

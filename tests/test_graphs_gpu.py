@@ -48,9 +48,14 @@ def test_store_scalars_and_device_bias_adam():
 
 
 def test_sac_graphed_update_equals_eager():
+    """The LAYER-BY-LAYER update as a per-update hipGraph (fused_step off: the fused step is 5 launches and replays whole
+    chunks of vector steps instead — tests/test_fused_step_gpu.py, tests/test_step_chunk_gpu.py)."""
     from gymrl_amd import sac_pendulum
-    eager = _run(sac_pendulum, "SACTrainer", False, 40)
-    graph = _run(sac_pendulum, "SACTrainer", True, 40)
+
+    def layerwise(cfg):
+        cfg.fused_step = False
+    eager = _run(sac_pendulum, "SACTrainer", False, 40, layerwise)
+    graph = _run(sac_pendulum, "SACTrainer", True, 40, layerwise)
     assert graph._graph is not None and graph._graph.graph is not None          # captured and replayed
     assert graph.critic_optimizer.step_count == eager.critic_optimizer.step_count > 30
     for name in ("actor_flat", "critic_flat", "critic_target_flat", "log_alpha", "_alpha_m", "_alpha_v"):
@@ -166,7 +171,7 @@ def test_baseline_config_sizes_graphed_equals_eager(algo):
         cls, n_envs = "SACTrainer", 4096
 
         def setup(cfg):
-            cfg.num_envs, cfg.memory_capacity = n_envs, 1 << 20
+            cfg.num_envs, cfg.memory_capacity, cfg.fused_step = n_envs, 1 << 20, False     # the layer-by-layer update's graph
     outs = []
     for graphs in (False, True):
         if algo == "rainbow":
