@@ -848,6 +848,21 @@ def rollout_lunar(env_state, n_envs, seed, env_id0, counter0, obs, act, logp, va
     check(lib().gymrl_rollout_lunar(C.byref(a), C.byref(policy_desc), _stream()), "gymrl_rollout_lunar")
 
 
+def rollout_cartpole(env_state, n_envs, seed, env_id0, counter0, obs, act, logp, val, rew, done, ep_ret, next_value, policy_desc,
+                     T, t0, nsteps, gamma, lam, noise_exp=None, gae_running=None, gae_workspace=None, ep_stats=None):
+    """gymrl_rollout_cartpole: the persistent rollout for PPO on CartPole-v1 (obs [T+1, N, 4], two actions)."""
+    a = RolloutLunarArgs()
+    a.env_state, a.n_envs, a.seed, a.env_id0, a.counter0 = _ptr(env_state).value, n_envs, seed, env_id0, counter0
+    a.obs, a.act, a.logp = _ptr(obs, torch.float32).value, _ptr(act, torch.int32).value, _ptr(logp, torch.float32).value
+    a.val, a.rew, a.done = _ptr(val, torch.float32).value, _ptr(rew, torch.float32).value, _ptr(done, torch.uint8).value
+    a.ep_ret, a.next_value = _ptr(ep_ret, torch.float32, True).value, _ptr(next_value, torch.float32).value
+    a.noise_exp = _ptr(noise_exp, torch.float32, True).value
+    a.gae_running, a.gae_workspace = _ptr(gae_running, torch.float64, True).value, _ptr(gae_workspace, None, True).value
+    a.gamma, a.lam, a.ep_stats = gamma, lam, _ptr(ep_stats, torch.float64, True).value
+    a.T, a.t0, a.nsteps = T, t0, nsteps
+    check(lib().gymrl_rollout_cartpole(C.byref(a), C.byref(policy_desc), _stream()), "gymrl_rollout_cartpole")
+
+
 def rollout_lunar_mhc(env_state, n_envs, seed, env_id0, counter0, obs, act, logp, val, rew, done, ep_ret, next_value, policy_desc,
                       T, t0, nsteps, gamma, lam, ent=None, lam2=0.0, noise_exp=None, gae_running=None, gae_running2=None,
                       gae_workspace=None, ep_stats=None, refill=True):

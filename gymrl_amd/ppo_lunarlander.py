@@ -370,10 +370,11 @@ class PPOTrainer:
         return self._next_value
 
     def _persistent_ok(self):
-        """gymrl_rollout_lunar covers: the built-in LunarLander env, a policy the one-launch forward supports."""
+        """gymrl_rollout_lunar / gymrl_rollout_cartpole cover: the built-in LunarLander and CartPole envs, a policy the
+        one-launch forward supports."""
         cfg, env = self.cfg, self.env
         return (cfg.persistent_rollout and cfg.fused_policy_forward and isinstance(env, VecEnv)
-                and env.kind == ops.LUNARLANDER and self.action_dim == 4 and bool(self.model._act_net()))
+                and (env.kind, self.action_dim) in ((ops.LUNARLANDER, 4), (ops.CARTPOLE, 2)) and bool(self.model._act_net()))
 
     def _collect_rollout_persistent(self, counter0, noise, fuse_gae):
         """:198-231 as ceil(T / rollout_chunk) launches: every workgroup runs its 16 envs through the whole chunk
@@ -388,11 +389,14 @@ class PPOTrainer:
             n = min(chunk, b.T - t0)
             if tm is not None:
                 tm.start("rollout_chunk")
-            ops.rollout_lunar(env.state, b.N, env.seed, env.env_id0, counter0, b.states, b.actions, b.log_probs, b.values,
-                              b.rewards, b.dones, b.ep_returns, self._next_value, desc, b.T, t0, n, cfg.gamma,
-                              cfg.gae_lambda, noise_exp=noise, gae_running=self._gae_running if fuse_gae else None,
-                              gae_workspace=self._gae_ws if fuse_gae else None, ep_stats=env.ep_stats,
-                              wg_ticks=self._wg_ticks, refill=getattr(cfg, "rollout_refill", True))
+            common = (env.state, b.N, env.seed, env.env_id0, counter0, b.states, b.actions, b.log_probs, b.values, b.rewards,
+                      b.dones, b.ep_returns, self._next_value, desc, b.T, t0, n, cfg.gamma, cfg.gae_lambda)
+            online = dict(noise_exp=noise, gae_running=self._gae_running if fuse_gae else None,
+                          gae_workspace=self._gae_ws if fuse_gae else None, ep_stats=env.ep_stats)
+            if env.kind == ops.CARTPOLE:
+                ops.rollout_cartpole(*common, **online)
+            else:
+                ops.rollout_lunar(*common, **online, wg_ticks=self._wg_ticks, refill=getattr(cfg, "rollout_refill", True))
             if tm is not None:
                 tm.stop("rollout_chunk", n * b.N)
         b.pos = b.T

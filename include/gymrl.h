@@ -464,6 +464,12 @@ typedef struct {
                                * function of (seed, env id, episode): the slab is bit-identical either way.             */
 } gymrl_rollout_lunar_args;
 int gymrl_rollout_lunar(const gymrl_rollout_lunar_args* args, const gymrl_mlp_desc* policy, void* stream);
+/* The same rollout for PPO on CartPole-v1 (PPOTrainer with env_name "CartPole-v1": the reference's collect_rollout is
+ * env-agnostic, ppo_lunarlander.py:198-231): obs f32[T+1][N][4], the policy's two dst == -1 stages are logits [2] then
+ * value [1], env_state is gymrl_env_state_bytes(GYMRL_ENV_CARTPOLE, n_envs); `ent`, `lam2`, `gae_running2`, `refill` and
+ * `wg_ticks` are ignored.  A step by step CartPole vector step is three launches at the launch floor; here a workgroup
+ * keeps its 16 envs for the whole chunk.  Bit-identical to gymrl_mlp_forward -> gymrl_categorical_sample -> gymrl_env_step. */
+int gymrl_rollout_cartpole(const gymrl_rollout_lunar_args* args, const gymrl_mlp_desc* policy, void* stream);
 /* The same persistent rollout for PPO-full (ppo_full_lunarlander.py collect_experience :440-505): the policy is the mHC network
  * (gymrl_mhc_policy, declared with gymrl_mhc_policy_forward below; obs_dim 8, n_act 4), `ent` receives the behaviour policy's
  * entropy, and with gae_running2 / lam2 both decoupled-lambda chunk maps are composed (the actor's with `lam`, then the critic's).

@@ -567,6 +567,39 @@ def test_persistent_rollout_bit_identical_to_stepwise(dev, N, T, chunk, hidden):
         assert torch.equal(adv_a, adv_b) and torch.equal(ret_a, ret_b) and torch.equal(a._moments, b._moments)
 
 
+@pytest.mark.parametrize("N,T,chunk,hidden", [(256, 160, 256, 64), (40, 140, 16, 64), (4096, 64, 0, 256), (48, 30, 1, 32)])
+def test_persistent_rollout_cartpole_bit_identical_to_stepwise(dev, N, T, chunk, hidden):
+    """gymrl_rollout_cartpole: PPOTrainer on CartPole-v1 with one launch per chunk writes the slab, bootstrap value, GAE
+    chunk maps, env state and episode statistics of the step-by-step sequence, bit for bit (ragged last workgroup at
+    N = 40, chunks that do not align with the GAE chunk, one-step launches, episode resets inside the rollout)."""
+    from gymrl_amd.ppo_lunarlander import Config, PPOTrainer
+
+    def make(persistent):
+        cfg = Config()
+        cfg.env_name = "CartPole-v1"
+        cfg.num_envs, cfg.update_freq, cfg.num_epochs, cfg.num_minibatches, cfg.seed = N, T, 1, 2, 11
+        cfg.hidden_dim, cfg.persistent_rollout, cfg.rollout_chunk = hidden, persistent, chunk
+        return PPOTrainer(cfg)
+    a, b = make(True), make(False)
+    assert a._persistent_ok() and not b._persistent_ok()
+    for rollout in range(2):
+        nva, nvb = a.collect_rollout(), b.collect_rollout()
+        assert torch.equal(nva, nvb)
+        ba, bb = a.buffer, b.buffer
+        for name in ("states", "actions", "log_probs", "values", "rewards", "dones"):
+            assert torch.equal(getattr(ba, name), getattr(bb, name)), (rollout, name)
+        d = ba.dones.bool()
+        assert int(d.sum()) > 0, "the rollout must contain episode resets"     # random play falls within ~20 steps
+        assert torch.equal(ba.ep_returns[d], bb.ep_returns[d])
+        assert torch.equal(a.env.state, b.env.state), rollout
+        assert torch.equal(a.env.ep_stats, b.env.ep_stats)
+        adv_a, ret_a = a.compute_gae()
+        adv_b, ret_b = b.compute_gae()
+        assert torch.equal(adv_a, adv_b) and torch.equal(ret_a, ret_b) and torch.equal(a._moments, b._moments)
+    a.update(a.collect_rollout()), b.update(b.collect_rollout())
+    assert torch.equal(a.flat_params, b.flat_params)
+
+
 def test_persistent_rollout_refill_wave_changes_nothing(dev):
     """The persistent kernel's wave 1 prepares every env's next episode while wave 0 steps (cfg.rollout_refill): a spare
     world is a pure function of (seed, env id, episode), so slab, env worlds and statistics equal the inline-reset run
