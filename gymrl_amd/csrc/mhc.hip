@@ -909,6 +909,379 @@ __global__ __launch_bounds__(64 * kSubWaves) void mhc_sub_fwd_kernel(const SubFw
   }
 }
 
+// ---- training pass: a whole sub-block BACKWARD in one launch (n = 2, D = 128) ---------------------------------------------
+// As four launches (combine_bwd, the Linear's input gradient, read_bwd, gates_bwd) the backward of one sub-block streams the
+// upstream gradient g and the branch stack h through HBM three times each and makes round trips of d_z, d_read, d_pre, d_post,
+// d_mix: 2.5 GB and 536 us per 262144-row micro-batch.  Here a wave carries a 16-row tile through all four (the forward
+// kernel's layout: lane (grp, sub) holds columns 64 q + 4 sub .. + 3 of rows 4 grp + it, so both branches of a column live
+// in one lane and a row's sums are four DPP adds):
+//   P1  d_z = SiLU'(z) sum_i post_i g_i -> the wave's LDS tile (+ HBM, for the Linear's weight gradient), and the row sums
+//       d_post_i = <g_i, SiLU(z)>, d_mix_ij = <g_i, h_j>;
+//   P2  d_read = d_z W on f32 MFMA (A from the tile, B from the transposed weight staged in LDS once per workgroup), back
+//       through the tile into the row view; d_pre_i = <d_read, h_i>;
+//   P3  the gates' backward for the row (one lane per row: sigmoid' / exp' from the saved outputs, the RMS statistic's path),
+//       broadcast to the row's lanes;
+//   P4  d_h = norm_w (dH w^T) + d|flat| flat / |flat| + pre_j d_read + sum_i mix_ij g_i, written once (optionally summed over
+//       the branches: the first sub-block's input is one row repeated), and the parameter sums: d norm_w per lane, d w as a
+//       [256 x rows] x [rows x 8] product on MFMA (A = norm_w * h from the registers, B = dH selected by lane), d alpha / d beta
+//       in the row lanes.  One partial vector per workgroup, added ascending by partial_reduce_kernel: no atomics.
+// g and h are read once (1 KB each per row), z once, d_z and d_h written once: 1.1 GB.  `g` / `h` may be broadcast over the
+// branches (branch stride 0): the last sub-block's upstream gradient is the final norm's d x for both branches.
+constexpr int kSubBwdWaves = 4;
+#ifdef GYMRL_PROF_BUILD
+// probe build only: shader-clock cycles per phase, summed over wave 0 of every workgroup (tools/micro_sub_bwd.py --phases)
+__device__ unsigned long long g_sub_bwd_prof[8];
+#define SUB_MARK(k) do { const long long now_ = (long long)__builtin_readcyclecounter(); prof_[k] += now_ - last_; last_ = now_; } while (0)
+#else
+#define SUB_MARK(k) do {} while (0)
+#endif
+constexpr size_t kSubBwdLdsBytes = sizeof(float) * ((size_t)128 * kSubPad + (size_t)kSubBwdWaves * 16 * kSubPad + 256);
+static_assert((size_t)kSubBwdWaves * kGatesLen <= (size_t)128 * kSubPad, "the partial sums reuse the weight's LDS");
+struct SubBwdArgs {
+  const float* g; const float* h; const float* z;
+  const float* pre; const float* post; const float* mix; const float* stats;
+  const float* norm_w; const float* gw; const float* alpha; const float* lw;
+  float* d_z; float* d_h; float* partial;
+  int B, g_rs, g_bs, h_rs, h_bs;                           // row / branch strides of g and h in floats
+};
+
+__device__ __forceinline__ float lane_bcast(int src_byte, float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(src_byte, __float_as_int(v)));
+}
+
+template <bool SUM_DH>
+__global__ __launch_bounds__(64 * kSubBwdWaves) void mhc_sub_bwd_kernel(const SubBwdArgs a) {
+  constexpr int D = 128, G = 8;
+  extern __shared__ float sub_lds[];
+  float* Wt = sub_lds;                                     // [128][kSubPad]   Wt[k][n] = W[n][k]
+  float* tiles = Wt + 128 * kSubPad;                       // [kSubBwdWaves][16][kSubPad]
+  float* nwl = tiles + kSubBwdWaves * 16 * kSubPad;        // [256]            the gates' RMS weight
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 128 * 32; i += 64 * kSubBwdWaves) {
+    const int n = i & 127, c = i >> 7;                     // lanes walk n: conflict-free LDS writes (the reads are 64 KB from L2, once)
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a.lw + (size_t)n * D + 4 * c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Wt[(4 * c + e) * kSubPad + n] = v[e];
+  }
+  for (int i = threadIdx.x; i < 256; i += 64 * kSubBwdWaves) nwl[i] = a.norm_w[i];
+  __syncthreads();
+  float* tb = tiles + (size_t)wave * 16 * kSubPad;
+  const int sub = lane & 15, grp = lane >> 4;
+  // the gates' read-out weight of this lane's 16 columns, for the whole launch, as the B operand of t2 = dH w^T (two k-steps
+  // of four gates: lane (grp, sub) holds w[column(q, e, sub)][4 s + grp])
+  float wB[4][4][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) wB[q][e][ks] = a.gw[(size_t)(64 * q + 4 * sub + e) * G + 4 * ks + grp];
+  }
+  const float al[3] = {a.alpha[0], a.alpha[1], a.alpha[2]};
+  const float inv_sqrt_nc = 1.0f / sqrtf(256.0f);
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 acc_w[4][4];                                       // [q][e]: d w[64 q + 4 (4 (lane >> 4) + g) + e][lane & 15]
+  float acc_nw[4][4], acc_al[3] = {0.0f, 0.0f, 0.0f}, acc_be[G];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc_w[q][e] = zero; acc_nw[q][e] = 0.0f; }
+#pragma unroll
+  for (int k = 0; k < G; ++k) acc_be[k] = 0.0f;
+  const int n_tiles = (a.B + 15) >> 4;
+#ifdef GYMRL_PROF_BUILD
+  long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = (long long)__builtin_readcyclecounter();
+#endif
+  // The tile loop is a software pipeline in the wave's own registers (one wave per SIMD: nobody else hides its latencies):
+  //   g, z and the row lanes' scalars of tile i + 1 are requested inside P4 of tile i, each half as soon as P4 has used
+  //   the registers it lands in; h of tile i is requested before the MFMA phase and first used after it (the d_mix sums
+  //   moved there from P1 for that).  Loads in flight: 24 KB under P4's second half, 16 KB under the 256 MFMAs.
+  const int tstride = gridDim.x * kSubBwdWaves;
+  f32x4 gv[4][4], zv[4][2];
+  f32x2 pre2, post2;
+  f32x4 mix4;
+  float st[G + 1];
+  // rows past the end read the last row instead and are switched off in P3 (their dH = 0: nothing of them reaches a sum or a store)
+  auto load_gz = [&](int t, int q2) {                      // columns 64 q2 .. 64 q2 + 63 of g (both branches) and z
+    if (t > n_tiles - 1) t = n_tiles - 1;
+    const int64_t nbase = (int64_t)t * 16;
+    const int nlast = (int)(a.B - 1 - nbase);
+    const float* gt = a.g + nbase * a.g_rs;                // (uniform: the tile's base; the lane's offsets are 32-bit)
+    const float* zt = a.z + nbase * D;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int lr = 4 * grp + it, rc = lr <= nlast ? lr : nlast;
+      const int off = 64 * q2 + 4 * sub;
+      gv[it][q2] = *reinterpret_cast<const f32x4*>(gt + (rc * a.g_rs + off));
+      gv[it][q2 + 2] = *reinterpret_cast<const f32x4*>(gt + (rc * a.g_rs + a.g_bs + off));
+      zv[it][q2] = *reinterpret_cast<const f32x4*>(zt + (rc * D + off));
+    }
+  };
+  auto load_scalars = [&](int t) {                         // lane 16 grp + it owns row 4 grp + it
+    if (t > n_tiles - 1) t = n_tiles - 1;
+    const int64_t nbase = (int64_t)t * 16;
+    const int nlast = (int)(a.B - 1 - nbase), own_l = 4 * grp + (sub & 3);
+    const int64_t own_c = nbase + (own_l <= nlast ? own_l : nlast);
+    pre2 = *reinterpret_cast<const f32x2*>(a.pre + own_c * 2);
+    post2 = *reinterpret_cast<const f32x2*>(a.post + own_c * 2);
+    mix4 = *reinterpret_cast<const f32x4*>(a.mix + own_c * 4);
+#pragma unroll
+    for (int k = 0; k <= G; ++k) st[k] = a.stats[own_c * (G + 1) + k];
+  };
+  const int tile0 = blockIdx.x * kSubBwdWaves + wave;
+  if (tile0 < n_tiles) { load_scalars(tile0); load_gz(tile0, 0); load_gz(tile0, 1); }
+  for (int tile = tile0; tile < n_tiles; tile += tstride) {
+    const int64_t base = (int64_t)tile * 16;
+    SUB_MARK(7);
+    const int last = (int)(a.B - 1 - base);                // >= 0: the tile's last valid local row (or beyond 15)
+    const bool own_in = 4 * grp + (sub & 3) <= last, own_ok = sub < 4 && own_in;
+    // ---- P1: d_z and d_post (what needs g and z only); columns 0..63 of every row first: their loads were requested first
+    float dsum[4][6];                                      // per row: d_post_0, d_post_1, d_mix_00, _01, _10, _11
+    {
+      float po[4][2], s0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int src = ((lane & 48) + it) << 2;
+        po[it][0] = lane_bcast(src, post2[0]); po[it][1] = lane_bcast(src, post2[1]);
+      }
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int lr = 4 * grp + it;
+          f32x4 dzv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float zt = zv[it][q2][e], sg = sigmoidf_(zt), o = zt * sg;
+            const float g0 = gv[it][q2][e], g1 = gv[it][q2 + 2][e];
+            dzv[e] = (po[it][0] * g0 + po[it][1] * g1) * (sg * (1.0f + zt * (1.0f - sg)));
+            s0[it] += g0 * o; s1[it] += g1 * o;
+          }
+          *reinterpret_cast<f32x4*>(&tb[lr * kSubPad + 64 * q2 + 4 * sub]) = dzv;
+          *reinterpret_cast<f32x4*>(a.d_z + (base + lr) * D + 64 * q2 + 4 * sub) = dzv;   // (the outputs are padded to whole tiles)
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) { dsum[it][0] = row16_sum(s0[it]); dsum[it][1] = row16_sum(s1[it]); }
+    }
+    SUB_MARK(1);                                           // P1, incl. the wait for g and z
+    // the branch stack: requested now, first used after the MFMA phase
+    f32x4 hv[4][4];
+    {
+      const float* ht = a.h + base * a.h_rs;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int lr = 4 * grp + it, rc = lr <= last ? lr : last;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          hv[it][q] = *reinterpret_cast<const f32x4*>(ht + (rc * a.h_rs + (q >> 1) * a.h_bs + 64 * (q & 1) + 4 * sub));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- P2: d_read = d_z W, all eight 16-column tiles (the forward's loop with the transposed weight)
+    f32x4 dr[4][2];
+    {
+      f32x4 acc[8], av[8], wv[2][8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) av[j] = *reinterpret_cast<const f32x4*>(&tb[sub * kSubPad + 16 * j + 4 * grp]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wv[0][j] = *reinterpret_cast<const f32x4*>(&Wt[sub * kSubPad + 4 * grp + 16 * j]);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        acc[t] = zero;
+        if (t < 7) {                                       // the next column tile's weights travel under this tile's 32 MFMAs
+#pragma unroll
+          for (int j = 0; j < 8; ++j) wv[(t + 1) & 1][j] = *reinterpret_cast<const f32x4*>(&Wt[(16 * (t + 1) + sub) * kSubPad + 4 * grp + 16 * j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][e], wv[t & 1][j][e], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                 // two column tiles' weight registers at a time, not all eight
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) tb[(4 * grp + gq) * kSubPad + 16 * t + sub] = acc[t][gq];
+    }
+    __builtin_amdgcn_wave_barrier();
+    SUB_MARK(2);                                           // P2: the MFMA phase and the tile's way back into LDS
+    // d_read back in the row view; the sums that need h: d_pre_i = <d_read, h_i>, d_mix_ij = <g_i, h_j>
+    float dpre[4][2];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      float s[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        dr[it][q2] = *reinterpret_cast<const f32x4*>(&tb[(4 * grp + it) * kSubPad + 64 * q2 + 4 * sub]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g0 = gv[it][q2][e], g1 = gv[it][q2 + 2][e], h0 = hv[it][q2][e], h1 = hv[it][q2 + 2][e];
+          s[0] += dr[it][q2][e] * h0; s[1] += dr[it][q2][e] * h1;
+          s[2] += g0 * h0; s[3] += g0 * h1; s[4] += g1 * h0; s[5] += g1 * h1;
+        }
+      }
+      dpre[it][0] = row16_sum(s[0]); dpre[it][1] = row16_sum(s[1]);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) dsum[it][2 + v] = row16_sum(s[2 + v]);
+    }
+    __builtin_amdgcn_wave_barrier();                       // the rows' scalars overwrite d_read in this wave's LDS tile
+    SUB_MARK(3);                                           // d_read back in the row view, the sums with h (incl. the wait for h)
+    // ---- P3: the row lane's gates backward (mhc_gates_bwd_kernel's phase A)
+    float dH[G], dn_over;
+    {
+      float up[G];                                         // d_pre 0 1, d_post 0 1, d_mix 00 01 10 11 of this lane's row
+#pragma unroll
+      for (int k = 0; k < G; ++k) up[k] = 0.0f;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const bool me = (sub & 3) == it;
+        up[0] = me ? dpre[it][0] : up[0]; up[1] = me ? dpre[it][1] : up[1];
+#pragma unroll
+        for (int v = 0; v < 6; ++v) up[2 + v] = me ? dsum[it][v] : up[2 + v];
+      }
+      const float norm = sqrtf(st[G]);
+      const float r = 1.0f / (norm * inv_sqrt_nc + 1e-6f);
+      float dz[G];
+      dz[0] = up[0] * pre2[0] * (1.0f - pre2[0]);
+      dz[1] = up[1] * pre2[1] * (1.0f - pre2[1]);
+      dz[2] = up[2] * post2[0] * (1.0f - 0.5f * post2[0]);
+      dz[3] = up[3] * post2[1] * (1.0f - 0.5f * post2[1]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dz[4 + k] = up[4 + k] * mix4[k];
+      if (!own_in) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) dz[k] = 0.0f;
+      }
+      float d_r = 0.0f;
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        const int gi = k < 2 ? 0 : (k < 4 ? 1 : 2);
+        dH[k] = dz[k] * r * al[gi];
+        d_r += dz[k] * st[k] * al[gi];
+        if (own_ok) { acc_al[gi] += dz[k] * r * st[k]; acc_be[k] += dz[k]; }
+      }
+      const float d_norm = d_r * (-r * r * inv_sqrt_nc);
+      dn_over = norm > 0.0f ? d_norm / norm : 0.0f;
+    }
+    SUB_MARK(4);                                           // P3
+    // the row lanes publish their row's sixteen scalars through the wave's LDS tile (free again: d_read is in registers)
+    if (sub < 4) {
+      float* rowp = &tb[(4 * grp + sub) * kSubPad];
+      *reinterpret_cast<f32x4*>(rowp) = f32x4{dH[0], dH[1], dH[2], dH[3]};
+      *reinterpret_cast<f32x4*>(rowp + 4) = f32x4{dH[4], dH[5], dH[6], dH[7]};
+      *reinterpret_cast<f32x4*>(rowp + 8) = f32x4{dn_over, pre2[0], pre2[1], 0.0f};
+      *reinterpret_cast<f32x4*>(rowp + 12) = mix4;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- P4: d_h and the column sums.  t2[row][column] = sum_k dH[row][k] w[column][k] is a [16 x 8] x [8 x 256] product:
+    // two MFMAs per 16 columns (A = dH[row = lane & 15][4 s + (lane >> 4)], B = the lane's weight registers); element `it` of
+    // the result is row 4 grp + it of this lane's column — the row view's own layout
+    const float aH0 = tb[sub * kSubPad + grp], aH1 = tb[sub * kSubPad + 4 + grp];
+    float sdn[4], sp[4][2], sm[4][4], bsel[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const float* rowp = &tb[(4 * grp + it) * kSubPad];
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(rowp + 8), c1 = *reinterpret_cast<const f32x4*>(rowp + 12);
+      sdn[it] = c0[0]; sp[it][0] = c0[1]; sp[it][1] = c0[2];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sm[it][k] = c1[k];
+      const float b = rowp[sub & 7];                       // the d w MFMA's B operand: dH[row][gate = lane & 15], 0 beyond the 8 gates
+      bsel[it] = sub < G ? b : 0.0f;
+    }
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2) {
+      f32x4 dx0[4];                                        // (sum_dh) branch 0's gradient of these columns
+#pragma unroll
+      for (int br = 0; br < 2; ++br) {
+        const int q = 2 * br + q2;
+        f32x4 dx[4];
+        const f32x4 nw = *reinterpret_cast<const f32x4*>(&nwl[64 * q + 4 * sub]);
+        f32x4 t2v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          t2v[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(aH0, wB[q][e][0], zero, 0, 0, 0);
+          t2v[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(aH1, wB[q][e][1], t2v[e], 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {                    // (four accumulators in turn: no MFMA waits for the one before it)
+            const float x = hv[it][q][e], t2 = t2v[e][it];
+            dx[it][e] = nw[e] * t2 + sdn[it] * x + sp[it][br] * dr[it][q2][e] +
+                        (sm[it][br] * gv[it][q2][e] + sm[it][2 + br] * gv[it][q2 + 2][e]);
+            acc_nw[q][e] += x * t2;
+            acc_w[q][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(nw[e] * x, bsel[it], acc_w[q][e], 0, 0, 0);
+          }
+          // rows past the end of the batch are written too: d_z and d_h are padded to whole 16-row tiles
+          float* dst = SUM_DH ? a.d_h + (base + 4 * grp + it) * D + 64 * q2 + 4 * sub
+                              : a.d_h + ((base + 4 * grp + it) * 2 + br) * D + 64 * q2 + 4 * sub;
+          if constexpr (!SUM_DH) *reinterpret_cast<f32x4*>(dst) = dx[it];
+          else if (br == 0) dx0[it] = dx[it];
+          else *reinterpret_cast<f32x4*>(dst) = dx0[it] + dx[it];   // d of a repeated row: the branches' gradients added
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);                   // (the loads below must not move up over the last use of their registers)
+      load_gz(tile + tstride, q2);                         // these columns of g and z are done: the next tile's are requested
+      if (q2 == 0) load_scalars(tile + tstride);           // (P1 starts with them: not at the very end)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    SUB_MARK(5);                                           // P4
+    __builtin_amdgcn_wave_barrier();                       // the next tile's d_z overwrites the rows' scalars
+    SUB_MARK(6);
+  }
+#ifdef GYMRL_PROF_BUILD
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_sub_bwd_prof[k], (unsigned long long)prof_[k]);
+#endif
+  // ---- the workgroup's partial: rows across the wave, then the four waves in a fixed order
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc_nw[q][e] += __shfl_xor(acc_nw[q][e], 16, 64);
+      acc_nw[q][e] += __shfl_xor(acc_nw[q][e], 32, 64);
+    }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int gi = 0; gi < 3; ++gi) acc_al[gi] += __shfl_xor(acc_al[gi], off, 64);
+#pragma unroll
+    for (int k = 0; k < G; ++k) acc_be[k] += __shfl_xor(acc_be[k], off, 64);
+  }
+  __syncthreads();                                         // every wave is done with the weight: its LDS holds the partials now
+  float* mine = sub_lds + (size_t)wave * kGatesLen;
+  if (grp == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mine[64 * q + 4 * sub + e] = acc_nw[q][e];
+  }
+  if (sub < G) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) mine[256 + (64 * q + 4 * (4 * grp + gq) + e) * G + sub] = acc_w[q][e][gq];
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int gi = 0; gi < 3; ++gi) mine[256 + 256 * G + gi] = acc_al[gi];
+#pragma unroll
+    for (int k = 0; k < G; ++k) mine[256 + 256 * G + 3 + k] = acc_be[k];
+  }
+  __syncthreads();
+  float* out = a.partial + (size_t)blockIdx.x * kGatesLen;
+  for (int i = threadIdx.x; i < kGatesLen; i += 64 * kSubBwdWaves) {
+    float sum = sub_lds[i];
+#pragma unroll
+    for (int w2 = 1; w2 < kSubBwdWaves; ++w2) sum += sub_lds[(size_t)w2 * kGatesLen + i];
+    out[i] = sum;
+  }
+}
+
 // ---- the whole rollout forward of PPO-full's network in ONE launch: mhc_policy_device.hpp's 16-row tile per workgroup --------
 __global__ __launch_bounds__(256) void mhc_policy_kernel(const PolicyArgs a, const float* __restrict__ obs, int B,
                                                          float* __restrict__ logits, float* __restrict__ value) {
@@ -1095,6 +1468,41 @@ int gymrl_mhc_sub_forward(const float* h, const float* norm_w, const float* w, c
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
+
+int gymrl_mhc_sub_backward(const float* g, int g_broadcast, const float* h, int h_broadcast, const float* z, const float* pre,
+                           const float* post, const float* mix, const float* stats, const float* norm_w, const float* w,
+                           const float* alpha, const float* lin_w, int B, int n, int D, float* d_z, float* d_h, int sum_branches,
+                           float* d_norm_w, float* d_w, float* d_alpha, float* d_beta, void* workspace, void* stream) {
+  if (!g || !h || !z || !pre || !post || !mix || !stats || !norm_w || !w || !alpha || !lin_w || !d_z || !d_h || !d_norm_w || !d_w ||
+      !d_alpha || !d_beta || !workspace || B < 1 || n != 2 || D != 128)
+    return -22;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)mhc_sub_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSubBwdLdsBytes) != hipSuccess ||
+        hipFuncSetAttribute((const void*)mhc_sub_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSubBwdLdsBytes) != hipSuccess)
+      return -1000 - (int)hipGetLastError();
+    attr = true;
+  }
+  int blocks = ((B + 15) / 16 + kSubBwdWaves - 1) / kSubBwdWaves;
+  if (blocks > 256) blocks = 256;                          // one workgroup per CU (110 KB of LDS), its waves walk the tiles
+  SubBwdArgs a{g, h, z, pre, post, mix, stats, norm_w, w, alpha, lin_w, d_z, d_h, static_cast<float*>(workspace), B,
+               g_broadcast ? D : 2 * D, g_broadcast ? 0 : D, h_broadcast ? D : 2 * D, h_broadcast ? 0 : D};
+  if (sum_branches) hipLaunchKernelGGL(mhc_sub_bwd_kernel<true>, dim3(blocks), dim3(64 * kSubBwdWaves), kSubBwdLdsBytes, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(mhc_sub_bwd_kernel<false>, dim3(blocks), dim3(64 * kSubBwdWaves), kSubBwdLdsBytes, (hipStream_t)stream, a);
+  ReduceArgs r{static_cast<const float*>(workspace), blocks, kGatesLen, 4,
+               {256, 256 + 256 * 8, 256 + 256 * 8 + 3, kGatesLen}, {256, 256 * 8, 0, 0}, {d_norm_w, d_w, d_alpha, d_beta}};
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((kGatesLen + 31) / 32, 1), dim3(256), 0, (hipStream_t)stream, r);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+#ifdef GYMRL_PROF_BUILD
+int gymrl_mhc_sub_bwd_prof_read(unsigned long long* out8, int reset) {   // probe build only (not in include/gymrl.h)
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_sub_bwd_prof), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sub_bwd_prof), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 
 int gymrl_mhc_policy_forward(const gymrl_mhc_policy* p, const float* obs, int B, float* logits_out, float* value_out, void* stream) {
   if (!obs || !logits_out || !value_out || B < 0) return -22;

@@ -1160,6 +1160,30 @@ def mhc_sub_forward(h, norm_w, w, alpha, beta, lin_w, lin_b, sk_it):
     return pre, post, mix, stats, read, z, h_out
 
 
+def mhc_sub_backward(g, h, z, pre, post, mix, stats, norm_w, w, alpha, lin_w, sum_branches=False):
+    """gymrl_mhc_sub_backward: one hyper-connection sub-block backward (n = 2, D = 128) in one launch ->
+    (d_z, d_h, d_norm_w, d_w, d_alpha, d_beta).  g / h may be [B, 128] (the same row for both branches); sum_branches: d_h
+    comes back [B, 128], the branches' gradients added."""
+    B, D = z.shape
+    dev = z.device
+    f = torch.float32
+    for t, nm in ((g, "g"), (h, "h")):
+        if t.shape not in ((B, 2, D), (B, D)) or not t.is_contiguous():
+            raise ValueError(f"{nm}: expected a contiguous [B, 2, D] or [B, D] tensor")
+    ws = _scratch("mhc_gates_bwd", (2, D), lib().gymrl_mhc_gates_bwd_workspace_bytes(C.c_int(2), C.c_int(D)), dev)
+    Bp = (B + 15) // 16 * 16                               # the kernel writes whole 16-row tiles
+    d_z = torch.empty(Bp, D, device=dev)[:B]
+    d_h = (torch.empty(Bp, D, device=dev) if sum_branches else torch.empty(Bp, 2, D, device=dev))[:B]
+    d_nw, d_w = torch.empty_like(norm_w), torch.empty_like(w)
+    d_alpha, d_beta = torch.empty(3, device=dev), torch.empty(w.shape[1], device=dev)
+    check(lib().gymrl_mhc_sub_backward(_ptr(g, f), C.c_int(g.dim() == 2), _ptr(h, f), C.c_int(h.dim() == 2), _ptr(z, f),
+                                       _ptr(pre, f), _ptr(post, f), _ptr(mix, f), _ptr(stats, f), _ptr(norm_w, f), _ptr(w, f),
+                                       _ptr(alpha, f), _ptr(lin_w, f), C.c_int(B), C.c_int(2), C.c_int(D), _ptr(d_z), _ptr(d_h),
+                                       C.c_int(bool(sum_branches)), _ptr(d_nw), _ptr(d_w), _ptr(d_alpha), _ptr(d_beta), _ptr(ws),
+                                       _stream()), "gymrl_mhc_sub_backward")
+    return d_z, d_h, d_nw, d_w, d_alpha, d_beta
+
+
 def mhc_policy(desc, obs, logits_out=None, value_out=None):
     """gymrl_mhc_policy_forward: PPO-full's whole rollout forward in one launch.  desc: a filled _lib.MhcPolicy (its pointers
     must stay alive: they are the modules' parameters); obs [B, obs_dim] -> (logits [B, n_act], value [B])."""

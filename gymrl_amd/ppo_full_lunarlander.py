@@ -72,6 +72,7 @@ FUSED_MIXING = True         # training pass: read / combine products as fused fo
 FUSED_INFERENCE = True      # rollout forward on the inference kernels (tools A/B; False: the torch modules)
 FUSED_POLICY = True         # rollout forward as ONE launch (gymrl_mhc_policy_forward) when the network has the default shape
 FUSED_SUB_FORWARD = True    # ... and its forward as ONE launch when D = 128 (False: gates + Linear + combine launches)
+FUSED_SUB_BACKWARD = True   # ... and its backward as ONE launch + the Linear's weight gradient (False: the five backward launches)
 FUSED_SUB = True            # training pass: a whole hyper-connection sub-block as one autograd node (3 launches forward, 7 backward)
 FUSED_NORM = True           # training pass: RMSNorm (+ the SiLU before it) as one launch each way
 
@@ -211,6 +212,16 @@ class _MhcSub(torch.autograd.Function):
     def backward(ctx, g):
         h, norm_w, w, alpha, pre, post, mix, stats, read, z, W = ctx.saved_tensors
         g = g.contiguous()
+        if FUSED_SUB_BACKWARD and h.shape[2] == 128:         # csrc/mhc.hip mhc_sub_bwd_kernel: g and h cross HBM once
+            d_z, d_h, d_nw, d_w, d_alpha, d_beta = ops.mhc_sub_backward(g, h, z, pre, post, mix, stats, norm_w, w, alpha, W)
+            slot = GradSink_direct(ctx.sinks[0], ctx.sinks[1], True)
+            if slot is not None:
+                ops.lin_bwd_weight(d_z, z, read, slot[0], slot[1], accumulate=slot[2])
+                d_W = d_b = None
+            else:
+                d_W, d_b = torch.empty_like(W), torch.empty(W.shape[0], dtype=W.dtype, device=W.device)
+                ops.lin_bwd_weight(d_z, z, read, d_W, d_b)
+            return d_h, d_nw, d_w, d_alpha, d_beta, d_W, d_b, None
         d_post, d_mix, d_z, _ = ops.mhc_combine_bwd(g, post, mix, z, h, act=ops.LIN_ACT["silu"], want_dh=False)
         if h.shape[0] >= _LIBRARY_ROWS and ops.linear_shape_ok(W.shape[1], W.shape[0]):
             d_read = ops.linear_bwd_input(d_z, W, None, torch.empty_like(read))      # csrc/gemm.hip, exact f32 MFMA

@@ -627,6 +627,20 @@ int gymrl_mhc_combine_bwd(const float* g, const float* post, const float* mix, c
 int gymrl_mhc_sub_forward(const float* h, const float* norm_w, const float* w, const float* alpha, const float* beta,
                           const float* lin_w, const float* lin_b, int B, int n, int D, int sk_it, float* pre_out, float* post_out,
                           float* mix_out, float* stats_out, float* read_out, float* z_out, float* h_out, void* stream);
+/* Training pass: the backward of the same sub-block in ONE launch (+ the fixed-order reduction of the parameter partials).
+ * Inputs: the upstream gradient g [B, 2, 128] (g_broadcast != 0: [B, 128], the same row for both branches — the final norm's
+ * d x), the saved h [B, 2, 128] (h_broadcast != 0: [B, 128], the repeated input of the first sub-block), z, pre, post, mix, stats.
+ * Outputs: d_z [B, 128] = dL/dz (what gymrl_lin_bwd_weight takes with `read` for the Linear's d W, d b), d_h [B, 2, 128] — the
+ * gates', the read's and the combine's paths into h added (sum_branches != 0: [B, 128], the two branches' gradients added:
+ * the gradient of a repeated row), d_norm_w [256], d_w [256, 8], d_alpha [3], d_beta [8].  d_z and d_h must have room for
+ * ceil(B / 16) * 16 rows: the kernel writes whole 16-row tiles (rows past B hold unspecified values).  workspace:
+ * gymrl_mhc_gates_bwd_workspace_bytes(2, 128).  The values of gymrl_mhc_combine_bwd + gymrl_linear_bwd_input +
+ * gymrl_mhc_read_bwd + gymrl_mhc_gates_bwd up to the order of the sums (float64 autograd at 3e-5: tests/test_mhc_fused_gpu.py);
+ * g and h cross HBM once instead of three times. */
+int gymrl_mhc_sub_backward(const float* g, int g_broadcast, const float* h, int h_broadcast, const float* z, const float* pre,
+                           const float* post, const float* mix, const float* stats, const float* norm_w, const float* w,
+                           const float* alpha, const float* lin_w, int B, int n, int D, float* d_z, float* d_h, int sum_branches,
+                           float* d_norm_w, float* d_w, float* d_alpha, float* d_beta, void* workspace, void* stream);
 /* The whole rollout forward of PPO-full's network (ActorCritic.forward :377-407 as called by get_action / get_value) in ONE
  * launch, for the reference's default shape: n = 2 branches of D = 128 (mhc_rate, mhc_dim), 256-wide heads
  * (MLP([128, 256, n_out]) :371-402), obs_dim <= 16, n_act <= 8, n_sub = 2 * mhc_layers <= 8 sub-blocks.  Rows are

@@ -131,13 +131,14 @@ def test_gates_backward_matches_autograd(dim, B):
 
 
 @pytest.mark.parametrize("one_launch", [True, False])
-@pytest.mark.parametrize("dim,B", [(128, 2500), (256, 300), (128, 1), (128, 16500)])   # >= 16384 rows: library GEMMs inside
+@pytest.mark.parametrize("dim,B", [(128, 2500), (256, 300), (128, 1), (128, 16500), (128, 17)])   # >= 16384 rows: library GEMMs inside
 def test_sub_block_node_matches_autograd(dim, B, one_launch, monkeypatch):
     """A whole MHCBlock (two sub-blocks, each ONE autograd node: _MhcSub) against the module's torch expression in float64:
     output, the gradient of h and of every parameter — incl. the read's and the combine's paths into h that
     gymrl_mhc_gates_bwd folds in, and the Linear's gradients written by the node itself."""
     import gymrl_amd.ppo_full_lunarlander as pf
     monkeypatch.setattr(pf, "FUSED_SUB_FORWARD", one_launch)    # gymrl_mhc_sub_forward (D = 128) / the three forward launches
+    monkeypatch.setattr(pf, "FUSED_SUB_BACKWARD", one_launch)   # gymrl_mhc_sub_backward (D = 128) / the five backward launches
     torch.manual_seed(dim + B)
     block = pf.MHCBlock(dim, 2, 10)
     with torch.no_grad():
@@ -255,3 +256,39 @@ def test_one_launch_sub_block_forward_matches_its_three_launches(B):
     z64 = read.double() @ W.double().t() + b.double()
     _close(z, z64, 2e-6)
     _close(h_out, ops.mhc_combine(post, mix, z, h, act=ops.LIN_ACT["silu"]).double(), 1e-6)
+
+
+@pytest.mark.parametrize("B,g_b,h_b,sum_b", [(1000, False, False, False), (1000, True, False, False), (1000, False, True, True),
+                                             (33, True, True, True), (40000, False, False, False)])
+def test_one_launch_sub_block_backward_matches_its_launches(B, g_b, h_b, sum_b):
+    """gymrl_mhc_sub_backward against the launches it replaces (combine_bwd, the Linear's input gradient, read_bwd, gates_bwd)
+    on the same saved tensors — with the upstream gradient / the branch stack broadcast over the branches and the branch-summed
+    d_h — at the sums' rounding (2e-5 of the largest value), and bit-identical on a second run (fixed-order sums)."""
+    from gymrl_amd import ops
+    torch.manual_seed(B)
+    dev = "cuda"
+    D, sk = 128, 10
+    h = torch.randn(B, D, device=dev).unsqueeze(1).repeat(1, 2, 1).contiguous() if h_b else torch.randn(B, 2, D, device=dev)
+    g = torch.randn(B, D, device=dev).unsqueeze(1).repeat(1, 2, 1).contiguous() if g_b else torch.randn(B, 2, D, device=dev)
+    norm_w = torch.empty(256, device=dev).uniform_(0.5, 1.5)
+    w = torch.randn(256, 8, device=dev) * 0.3
+    alpha, beta = torch.tensor([0.7, -0.4, 0.9], device=dev), torch.randn(8, device=dev) * 0.1
+    W, b = torch.randn(D, D, device=dev) / 11.0, torch.randn(D, device=dev) * 0.1
+    pre, post, mix, stats, read, z, _ = ops.mhc_sub_forward(h, norm_w, w, alpha, beta, W, b, sk)
+    # the launches
+    d_post, d_mix, d_z, _ = ops.mhc_combine_bwd(g, post, mix, z, h, act=ops.LIN_ACT["silu"], want_dh=False)
+    d_read, _ = ops.lin_bwd_input(d_z, z, W)
+    d_pre, _ = ops.mhc_read_bwd(d_read, pre, h, want_dh=False)
+    ref = (d_z,) + tuple(ops.mhc_gates_bwd(h, norm_w, w, alpha, pre, post, mix, stats, d_pre, d_post, d_mix, d_read=d_read, g_out=g))
+    if sum_b:
+        ref = (ref[0], ref[1].sum(1)) + ref[2:]
+    run = lambda: ops.mhc_sub_backward(g[:, 0].contiguous() if g_b else g, h[:, 0].contiguous() if h_b else h, z, pre, post, mix,  # noqa: E731
+                                       stats, norm_w, w, alpha, W, sum_branches=sum_b)
+    got = run()
+    for name, x, y in zip(("d_z", "d_h", "d_norm_w", "d_w", "d_alpha", "d_beta"), got, ref):
+        assert x.shape == y.shape, name
+        err = float((x.double() - y.double()).abs().max()) / max(1.0, float(y.abs().max()))
+        assert err < 2e-5, (name, err)
+    again = run()
+    for x, y in zip(got, again):
+        assert torch.equal(x, y)
