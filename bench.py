@@ -480,17 +480,17 @@ def main():
         gdist.shutdown()               # always release the other ranks, even if the report fails
 
 
-def _gates_bwd_launch(rows, D, sk_it, dev, reps=5):
-    """Average duration (HIP events on the launch stream) of gymrl_mhc_gates_bwd at `rows` rows of a 2 x D branch stack, and its
-    algorithmic bytes: h, g_out, d_h [rows, 2, D] + d_read [rows, D] + the row's saved sums and gates (9 + 8 + 8 floats)."""
+def _sub_bwd_launch(rows, D, sk_it, dev, reps=5):
+    """Average duration (HIP events on the launch stream) of gymrl_mhc_sub_backward at `rows` rows of a 2 x D branch stack, and
+    its algorithmic bytes per row: g, h, d_h [2, D] + z, d_z [D] + the row's saved gates and sums (2 + 2 + 4 + 9 floats)."""
     from gymrl_amd import ops
     n = 2
     h, g = torch.randn(rows, n, D, device=dev), torch.randn(rows, n, D, device=dev)
     nw, w = torch.rand(n * D, device=dev) + 0.5, torch.randn(n * D, 8, device=dev) * 0.3
     alpha, beta = torch.tensor([0.7, -0.4, 0.9], device=dev), torch.randn(8, device=dev) * 0.1
-    pre, post, mix, read, stats = ops.mhc_gates(h, nw, w, alpha, beta, sk_it, stats=True)
-    d_pre, d_post, d_mix = torch.randn_like(pre), torch.randn_like(post), torch.randn_like(mix)
-    run = lambda: ops.mhc_gates_bwd(h, nw, w, alpha, pre, post, mix, stats, d_pre, d_post, d_mix, d_read=read, g_out=g)  # noqa: E731
+    W, b = torch.randn(D, D, device=dev) / D ** 0.5, torch.zeros(D, device=dev)
+    pre, post, mix, stats, read, z, _ = ops.mhc_sub_forward(h, nw, w, alpha, beta, W, b, sk_it)
+    run = lambda: ops.mhc_sub_backward(g, h, z, pre, post, mix, stats, nw, w, alpha, W)  # noqa: E731
     run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -498,7 +498,7 @@ def _gates_bwd_launch(rows, D, sk_it, dev, reps=5):
         run()
     e1.record()
     torch.cuda.synchronize()
-    per_row = 4 * (3 * n * D + D + 25)
+    per_row = 4 * (3 * n * D + 2 * D + 17)
     return {"s": e0.elapsed_time(e1) * 1e-3 / reps, "rows": rows, "bytes_per_row": per_row, "bytes": per_row * rows}
 
 
@@ -563,7 +563,7 @@ def main_ppo_full(a, rank, world, local_rank):
         ph = [sum(e[i].elapsed_time(e[i + 1]) for e in ev_all) / a.steps for i in range(3)]
         gae_s = ph[1] * 1e-3
         mb = T * N // cfg.num_minibatches
-        gates = _gates_bwd_launch(min(cfg.micro_batch, mb), cfg.mhc_dim, cfg.mhc_sk_it, dev) if (cfg.mhc_rate == 2 and cfg.mhc_dim in (128, 256)) else None
+        gates = _sub_bwd_launch(min(cfg.micro_batch, mb), cfg.mhc_dim, cfg.mhc_sk_it, dev) if (cfg.mhc_rate == 2 and cfg.mhc_dim == 128) else None
         out = {
             "metric": "env-steps/sec at N envs/GPU (PPO-full LunarLander), 1/2/4/8 GPUs + %HBM roofline",
             "value": T * N * world * a.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps,
@@ -575,8 +575,9 @@ def main_ppo_full(a, rank, world, local_rank):
                        "optimizer_steps_per_iteration": cfg.num_epochs * cfg.num_minibatches,
                        "parallelism": f"dp{world} (env shards + flat-gradient all-reduce)" if world > 1 else "single GPU"},
             "roofline": ({"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK / 1e9,
-                          "kernel": "gymrl_mhc_gates_bwd with the read's and the combine's paths folded in (csrc/mhc.hip): the largest "
-                                    "kernel of the training pass, one launch per hyper-connection sub-block and micro-batch",
+                          "kernel": "gymrl_mhc_sub_backward (csrc/mhc.hip: combine, the Linear's input gradient on f32 MFMA, read and gates "
+                                    "backward of one hyper-connection sub-block in one launch): the largest kernel of the training "
+                                    "pass, four launches per micro-batch; bound by the CU's memory pipe and 352 f32 MFMAs per 16 rows",
                           "achieved": round(gates["bytes"] / gates["s"] / 1e9, 1), "frac": round(gates["bytes"] / gates["s"] / HBM_PEAK, 4),
                           "traffic": None, "launch_s": gates["s"], "rows": gates["rows"], "bytes_per_row": gates["bytes_per_row"],
                           "note": "event-timed after the timed region at the micro-batch size (cold inputs of that size: 0.9 GB)"}

@@ -649,7 +649,7 @@ __global__ __launch_bounds__(64 * kWaves) void rmsnorm_reg_kernel(const float* _
 // the wave visits, added across the workgroup's waves through LDS, one partial vector per workgroup for partial_reduce_kernel.
 template <int kNormQ>
 __global__ __launch_bounds__(64 * kWaves) void rmsnorm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
-                                                                 const float* __restrict__ w, int B, int D, float eps, int silu,
+                                                                 const float* __restrict__ w, int B, int D, int n_sum, float eps, int silu,
                                                                  float* __restrict__ d_x, float* __restrict__ partial) {
   __shared__ float red[kWaves][64 * kNormQ];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -666,7 +666,10 @@ __global__ __launch_bounds__(64 * kWaves) void rmsnorm_bwd_kernel(const float* _
 #pragma unroll
     for (int q = 0; q < kNormQ; ++q) {
       const int d = lane + 64 * q;
-      xv[q] = d < D ? x[row * D + d] : 0.0f;
+      float xs = 0.0f;                                     // x = the sum of the row's n_sum blocks (ascending, as the forward adds them)
+      if (d < D)
+        for (int i = 0; i < n_sum; ++i) xs += x[(row * n_sum + i) * D + d];
+      xv[q] = xs;
       gv[q] = d < D ? g[row * D + d] : 0.0f;
     }
 #pragma unroll
@@ -717,7 +720,7 @@ constexpr size_t kSubLdsBytes = sizeof(float) * ((size_t)128 * kSubPad + (size_t
 struct SubFwdArgs {
   const float* h; const float* norm_w; const float* gw; const float* alpha; const float* beta; const float* lw; const float* lb;
   float* pre; float* post; float* mix; float* stats; float* read; float* z; float* h_out;
-  int B, sk_it;
+  int B, sk_it, h_rs, h_bs;                                // row / branch stride of h in floats (branch stride 0: one row repeated)
 };
 
 __global__ __launch_bounds__(64 * kSubWaves) void mhc_sub_fwd_kernel(const SubFwdArgs a) {
@@ -750,9 +753,9 @@ __global__ __launch_bounds__(64 * kSubWaves) void mhc_sub_fwd_kernel(const SubFw
     for (int it = 0; it < 4; ++it) {
       int64_t row = (int64_t)tile * 16 + 4 * grp + it;
       if (row > a.B - 1) row = a.B - 1;
-      const float* hr = a.h + row * NC + 4 * sub;
+      const float* hr = a.h + row * a.h_rs + 4 * sub;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) dst[it][q] = *reinterpret_cast<const f32x4*>(hr + 64 * q);
+      for (int q = 0; q < 4; ++q) dst[it][q] = *reinterpret_cast<const f32x4*>(hr + (q >> 1) * a.h_bs + 64 * (q & 1));
     }
   };
   const int tile0 = blockIdx.x * kSubWaves + wave, tstride = gridDim.x * kSubWaves;
@@ -1432,23 +1435,32 @@ static int rmsnorm_bwd_blocks(int B) {
 
 size_t gymrl_rmsnorm_bwd_workspace_bytes(int D) { return sizeof(float) * 2048 * (size_t)(D < 1 ? 1 : D); }
 
+int gymrl_rmsnorm_sum_bwd(const float* g, const float* x, const float* w, int B, int D, int n_sum, float eps, int act, float* d_x,
+                          float* d_w, void* workspace, void* stream);
+
 int gymrl_rmsnorm_bwd(const float* g, const float* x, const float* w, int B, int D, float eps, int act, float* d_x, float* d_w,
                       void* workspace, void* stream) {
-  if (!g || !x || !w || !d_x || !d_w || !workspace || B < 1 || D < 1 || D > 512 || (act != GYMRL_ACT_NONE && act != GYMRL_ACT_SILU))
+  return gymrl_rmsnorm_sum_bwd(g, x, w, B, D, 1, eps, act, d_x, d_w, workspace, stream);
+}
+
+int gymrl_rmsnorm_sum_bwd(const float* g, const float* x, const float* w, int B, int D, int n_sum, float eps, int act, float* d_x,
+                          float* d_w, void* workspace, void* stream) {
+  if (!g || !x || !w || !d_x || !d_w || !workspace || B < 1 || D < 1 || D > 512 || n_sum < 1 ||
+      (act != GYMRL_ACT_NONE && act != GYMRL_ACT_SILU))
     return -22;
   const int blocks = rmsnorm_bwd_blocks(B), silu = act == GYMRL_ACT_SILU;
   float* part = static_cast<float*>(workspace);
   const dim3 grid(blocks), block(64 * kWaves);
-  if (D <= 128) hipLaunchKernelGGL(rmsnorm_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, g, x, w, B, D, eps, silu, d_x, part);
-  else if (D <= 256) hipLaunchKernelGGL(rmsnorm_bwd_kernel<4>, grid, block, 0, (hipStream_t)stream, g, x, w, B, D, eps, silu, d_x, part);
-  else hipLaunchKernelGGL(rmsnorm_bwd_kernel<8>, grid, block, 0, (hipStream_t)stream, g, x, w, B, D, eps, silu, d_x, part);
+  if (D <= 128) hipLaunchKernelGGL(rmsnorm_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, g, x, w, B, D, n_sum, eps, silu, d_x, part);
+  else if (D <= 256) hipLaunchKernelGGL(rmsnorm_bwd_kernel<4>, grid, block, 0, (hipStream_t)stream, g, x, w, B, D, n_sum, eps, silu, d_x, part);
+  else hipLaunchKernelGGL(rmsnorm_bwd_kernel<8>, grid, block, 0, (hipStream_t)stream, g, x, w, B, D, n_sum, eps, silu, d_x, part);
   ReduceArgs r{part, blocks, D, 1, {D, 0, 0, 0}, {0, 0, 0, 0}, {d_w, nullptr, nullptr, nullptr}};
   hipLaunchKernelGGL(partial_reduce_kernel, dim3((D + 31) / 32, 1), dim3(256), 0, (hipStream_t)stream, r);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
 
-int gymrl_mhc_sub_forward(const float* h, const float* norm_w, const float* w, const float* alpha, const float* beta,
+int gymrl_mhc_sub_forward(const float* h, int h_broadcast, const float* norm_w, const float* w, const float* alpha, const float* beta,
                           const float* lin_w, const float* lin_b, int B, int n, int D, int sk_it, float* pre_out, float* post_out,
                           float* mix_out, float* stats_out, float* read_out, float* z_out, float* h_out, void* stream) {
   if (!h || !norm_w || !w || !alpha || !beta || !lin_w || !lin_b || !pre_out || !post_out || !mix_out || !stats_out || !read_out ||
@@ -1461,7 +1473,8 @@ int gymrl_mhc_sub_forward(const float* h, const float* norm_w, const float* w, c
       return -1000 - (int)hipGetLastError();
     attr = true;
   }
-  SubFwdArgs a{h, norm_w, w, alpha, beta, lin_w, lin_b, pre_out, post_out, mix_out, stats_out, read_out, z_out, h_out, B, sk_it};
+  SubFwdArgs a{h, norm_w, w, alpha, beta, lin_w, lin_b, pre_out, post_out, mix_out, stats_out, read_out, z_out, h_out, B, sk_it,
+               h_broadcast ? D : 2 * D, h_broadcast ? 0 : D};
   int blocks = ((B + 15) / 16 + kSubWaves - 1) / kSubWaves;
   if (blocks > 256) blocks = 256;                          // one workgroup per CU (145 KB of LDS), its waves walk the tiles
   hipLaunchKernelGGL(mhc_sub_fwd_kernel, dim3(blocks), dim3(64 * kSubWaves), kSubLdsBytes, (hipStream_t)stream, a);

@@ -1135,26 +1135,28 @@ def _scratch(kind, shape_key, nbytes, dev):
     return ws
 
 
-def rmsnorm_bwd(g, x, w, eps, act=0):
-    """gymrl_rmsnorm_bwd: (dL/dx [B, D], dL/dw [D]) of y = rmsnorm(x, w, eps, act=act); D <= 512."""
-    B, D = x.shape
+def rmsnorm_bwd(g, x, w, eps, act=0, n_sum=1):
+    """gymrl_rmsnorm_bwd / gymrl_rmsnorm_sum_bwd: (dL/dx [B, D], dL/dw [D]) of y = rmsnorm(x, w, eps, act=act); D <= 512.
+    n_sum > 1: x is [B, n_sum, D] and the norm is of the blocks' sum — dL/dx [B, D] is every block's gradient."""
+    B, D = x.shape[0], w.numel()
     ws = _scratch("rmsnorm_bwd", D, lib().gymrl_rmsnorm_bwd_workspace_bytes(C.c_int(D)), x.device)
-    d_x, d_w = torch.empty_like(x), torch.empty_like(w)
-    check(lib().gymrl_rmsnorm_bwd(_ptr(g, torch.float32), _ptr(x, torch.float32), _ptr(w, torch.float32), C.c_int(B), C.c_int(D),
-                                  C.c_float(eps), C.c_int(act), _ptr(d_x), _ptr(d_w), _ptr(ws), _stream()), "gymrl_rmsnorm_bwd")
+    d_x, d_w = torch.empty(B, D, device=x.device), torch.empty_like(w)
+    check(lib().gymrl_rmsnorm_sum_bwd(_ptr(g, torch.float32), _ptr(x, torch.float32), _ptr(w, torch.float32), C.c_int(B), C.c_int(D),
+                                      C.c_int(n_sum), C.c_float(eps), C.c_int(act), _ptr(d_x), _ptr(d_w), _ptr(ws), _stream()),
+          "gymrl_rmsnorm_sum_bwd")
     return d_x, d_w
 
 
 def mhc_sub_forward(h, norm_w, w, alpha, beta, lin_w, lin_b, sk_it):
     """gymrl_mhc_sub_forward: one hyper-connection sub-block forward (n = 2, D = 128) in one launch ->
-    (pre, post, mix, stats, read, z, h_out)."""
-    B, n, D = h.shape
+    (pre, post, mix, stats, read, z, h_out).  h [B, 2, D], or [B, D]: the same row for both branches."""
+    B, n, D = (h.shape[0], 2, h.shape[1]) if h.dim() == 2 else h.shape
     dev = h.device
     pre, post, mix = torch.empty(B, n, device=dev), torch.empty(B, n, device=dev), torch.empty(B, n, n, device=dev)
     stats, read, z = torch.empty(B, n * n + 2 * n + 1, device=dev), torch.empty(B, D, device=dev), torch.empty(B, D, device=dev)
-    h_out = torch.empty_like(h)
+    h_out = torch.empty(B, n, D, device=dev)
     f = torch.float32
-    check(lib().gymrl_mhc_sub_forward(_ptr(h, f), _ptr(norm_w, f), _ptr(w, f), _ptr(alpha, f), _ptr(beta, f), _ptr(lin_w, f),
+    check(lib().gymrl_mhc_sub_forward(_ptr(h, f), C.c_int(h.dim() == 2), _ptr(norm_w, f), _ptr(w, f), _ptr(alpha, f), _ptr(beta, f), _ptr(lin_w, f),
                                       _ptr(lin_b, f), C.c_int(B), C.c_int(n), C.c_int(D), C.c_int(sk_it), _ptr(pre), _ptr(post),
                                       _ptr(mix), _ptr(stats), _ptr(read), _ptr(z), _ptr(h_out), _stream()), "gymrl_mhc_sub_forward")
     return pre, post, mix, stats, read, z, h_out

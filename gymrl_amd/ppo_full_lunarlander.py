@@ -116,6 +116,24 @@ class _RmsNorm(torch.autograd.Function):
         return d_x, d_w, None, None
 
 
+class _RmsNormSum(torch.autograd.Function):
+    """final_norm(h.sum(dim=1)) (:243) as one launch each way: the branch sum is taken on load, and the backward hands the branches
+    ONE [B, D] gradient as a stride-0 view — _MhcSub.backward reads it as such, nothing [B, n, D] is written or re-read."""
+
+    @staticmethod
+    def forward(ctx, h, w, eps):
+        h = h.contiguous()
+        ctx.save_for_backward(h, w)
+        ctx.eps = eps
+        return ops.rmsnorm(h, w, eps, n_sum=h.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        h, w = ctx.saved_tensors
+        d_x, d_w = ops.rmsnorm_bwd(g.contiguous(), h, w, ctx.eps, 0, n_sum=h.shape[1])
+        return d_x.unsqueeze(1).expand(-1, h.shape[1], -1), d_w, None
+
+
 class ManifoldHyperConnectionFuse(nn.Module):
     """One hyper-connection: per-sample gates (H_pre, H_post) and a doubly-stochastic branch
     mixing matrix H_res from an RMS-fused linear read-out of the branch stack (:106-194)."""
@@ -192,7 +210,10 @@ class _MhcSub(torch.autograd.Function):
     def forward(ctx, h, norm_w, w, alpha, beta, W, b, sk_it):
         h = h.contiguous()
         ctx.sinks = (getattr(W, "_gymrl_sink", None), getattr(b, "_gymrl_sink", None))
-        if FUSED_SUB_FORWARD and h.shape[2] == 128:          # gates + Linear + combine in one launch (csrc/mhc.hip mhc_sub_fwd_kernel)
+        ctx.repeated = h.dim() == 2                          # [B, D]: the input projection, the same row for both branches
+        if ctx.repeated and not (FUSED_SUB_FORWARD and FUSED_SUB_BACKWARD and h.shape[1] == 128):
+            raise ValueError("_MhcSub takes a [B, D] input only on the one-launch kernels (D = 128)")
+        if FUSED_SUB_FORWARD and h.shape[-1] == 128:         # gates + Linear + combine in one launch (csrc/mhc.hip mhc_sub_fwd_kernel)
             pre, post, mix, stats, read, z, h_out = ops.mhc_sub_forward(h, norm_w, w, alpha, beta, W, b, sk_it)
             ctx.save_for_backward(h, norm_w, w, alpha, pre, post, mix, stats, read, z, W)
             return h_out
@@ -211,9 +232,11 @@ class _MhcSub(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         h, norm_w, w, alpha, pre, post, mix, stats, read, z, W = ctx.saved_tensors
-        g = g.contiguous()
-        if FUSED_SUB_BACKWARD and h.shape[2] == 128:         # csrc/mhc.hip mhc_sub_bwd_kernel: g and h cross HBM once
-            d_z, d_h, d_nw, d_w, d_alpha, d_beta = ops.mhc_sub_backward(g, h, z, pre, post, mix, stats, norm_w, w, alpha, W)
+        if FUSED_SUB_BACKWARD and h.shape[-1] == 128:        # csrc/mhc.hip mhc_sub_bwd_kernel: g and h cross HBM once
+            # a stride-0 branch dimension is _RmsNormSum's gradient: one [B, D] row for both branches, read as such
+            g = g[:, 0].contiguous() if g.stride(1) == 0 else g.contiguous()
+            d_z, d_h, d_nw, d_w, d_alpha, d_beta = ops.mhc_sub_backward(g, h, z, pre, post, mix, stats, norm_w, w, alpha, W,
+                                                                        sum_branches=ctx.repeated)
             slot = GradSink_direct(ctx.sinks[0], ctx.sinks[1], True)
             if slot is not None:
                 ops.lin_bwd_weight(d_z, z, read, slot[0], slot[1], accumulate=slot[2])
@@ -222,6 +245,7 @@ class _MhcSub(torch.autograd.Function):
                 d_W, d_b = torch.empty_like(W), torch.empty(W.shape[0], dtype=W.dtype, device=W.device)
                 ops.lin_bwd_weight(d_z, z, read, d_W, d_b)
             return d_h, d_nw, d_w, d_alpha, d_beta, d_W, d_b, None
+        g = g.contiguous()
         d_post, d_mix, d_z, _ = ops.mhc_combine_bwd(g, post, mix, z, h, act=ops.LIN_ACT["silu"], want_dh=False)
         if h.shape[0] >= _LIBRARY_ROWS and ops.linear_shape_ok(W.shape[1], W.shape[0]):
             d_read = ops.linear_bwd_input(d_z, W, None, torch.empty_like(read))      # csrc/gemm.hip, exact f32 MFMA
@@ -283,6 +307,9 @@ class MHCBlock(nn.Module):
 
     @staticmethod
     def _sub(h, fuse, linear, act):
+        if h.dim() == 2 and not (FUSED_SUB and FUSED_GATES and FUSED_MIXING and FUSED_SUB_FORWARD and FUSED_SUB_BACKWARD
+                                 and h.shape[1] == 128 and fuse.n == 2):
+            h = h.unsqueeze(1).repeat(1, fuse.n, 1)          # (only the one-launch node takes the un-repeated input projection)
         if (FUSED_SUB and FUSED_GATES and FUSED_MIXING and h.is_cuda and h.dtype == torch.float32 and fuse.n == 2
                 and fuse.nc in (256, 512) and isinstance(act, nn.SiLU) and isinstance(linear, SmallLinear)
                 and linear.bias is not None and getattr(linear, "act", None) in (None, "none")):
@@ -320,9 +347,19 @@ class MHCBackbone(nn.Module):
         self.final_norm = RMSNorm(output_dim)
 
     def forward(self, x):
-        h = self.input_proj(x).unsqueeze(1).repeat(1, self.rate, 1)     # [B, n, D]
+        z0 = self.input_proj(x)
+        # training pass on the one-launch sub-block kernels: the first sub-block reads the projection as the repeated row it is
+        # and returns the branches' summed gradient, the final norm sums the branches on load and hands both ONE gradient row —
+        # the reference's repeat / sum (:239, :243) and their backward cost four [B, n, D] passes through torch (0.38 ms per
+        # 262144-row micro-batch, `profiles/r03_ppo_full_kernel_stats.csv`)
+        direct = (FUSED_SUB and FUSED_GATES and FUSED_MIXING and FUSED_SUB_FORWARD and FUSED_SUB_BACKWARD and FUSED_NORM
+                  and z0.is_cuda and z0.dtype == torch.float32 and self.rate == 2 and z0.shape[1] == 128 and z0.shape[0] > 0
+                  and len(self.layers) > 0)
+        h = z0 if direct else z0.unsqueeze(1).repeat(1, self.rate, 1)     # [B, n, D]
         for layer in self.layers:
             h = layer(h)
+        if direct:
+            return _RmsNormSum.apply(h, self.final_norm.weight, self.final_norm.eps)
         return self.final_norm(h.sum(dim=1))
 
 

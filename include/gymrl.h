@@ -590,6 +590,10 @@ int gymrl_rmsnorm(const float* x, const float* w, int B, int D, int n_sum, float
 size_t gymrl_rmsnorm_bwd_workspace_bytes(int D);
 int gymrl_rmsnorm_bwd(const float* g, const float* x, const float* w, int B, int D, float eps, int act, float* d_x, float* d_w,
                       void* workspace, void* stream);
+/* The same for the norm of a branch sum (final_norm(h.sum(dim=1)), MHCBackbone.forward :243): x [B, n_sum, D], d_x [B, D] is
+ * the gradient of EVERY block (the sum hands each the same one — the caller broadcasts it, nothing is materialised). */
+int gymrl_rmsnorm_sum_bwd(const float* g, const float* x, const float* w, int B, int D, int n_sum, float eps, int act, float* d_x,
+                          float* d_w, void* workspace, void* stream);
 /* The Sinkhorn-Knopp sweeps alone (:141-146; constants of the backward pass in the reference): A f32[B, n, n] > 0 ->
  * u [B, n], v [B, n] after sk_it sweeps u = 1/(A v + 1e-8), v = 1/(A^T u + 1e-8) from u = v = 1 — for gate shapes
  * gymrl_mhc_gates_bwd does not cover, whose other gate operations stay with autograd. */
@@ -622,9 +626,10 @@ int gymrl_mhc_combine_bwd(const float* g, const float* post, const float* mix, c
 /* Training pass: the forward of one hyper-connection sub-block (MHCBlock._sub :160-165 with the gates :125-147) in ONE launch for
  * n = 2 branches of D = 128: h [B, 2, 128] -> h_out = post (x) SiLU(z) + mix h with z = read lin_w^T + lin_b, read = sum_i pre_i h_i,
  * and everything the backward takes: pre_out [B, 2], post_out [B, 2], mix_out [B, 2, 2], stats_out [B, 9] (as gymrl_mhc_gates),
- * read_out [B, 128], z_out [B, 128].  The same values as gymrl_mhc_gates + gymrl_lin_fwd + gymrl_mhc_combine(GYMRL_ACT_SILU) up to
+ * read_out [B, 128], z_out [B, 128].  h_broadcast != 0: h is [B, 128], the same row for both branches (the first sub-block's
+ * input is the input projection repeated, MHCBackbone.forward :239: no [B, 2, 128] copy is made of it).  The same values as gymrl_mhc_gates + gymrl_lin_fwd + gymrl_mhc_combine(GYMRL_ACT_SILU) up to
  * the order of the Linear's sums; 16-row tiles per wave, the weights staged in LDS once per workgroup. */
-int gymrl_mhc_sub_forward(const float* h, const float* norm_w, const float* w, const float* alpha, const float* beta,
+int gymrl_mhc_sub_forward(const float* h, int h_broadcast, const float* norm_w, const float* w, const float* alpha, const float* beta,
                           const float* lin_w, const float* lin_b, int B, int n, int D, int sk_it, float* pre_out, float* post_out,
                           float* mix_out, float* stats_out, float* read_out, float* z_out, float* h_out, void* stream);
 /* Training pass: the backward of the same sub-block in ONE launch (+ the fixed-order reduction of the parameter partials).

@@ -292,3 +292,35 @@ def test_one_launch_sub_block_backward_matches_its_launches(B, g_b, h_b, sum_b):
     again = run()
     for x, y in zip(got, again):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("B,layers", [(3000, 2), (1, 1), (20000, 1)])
+def test_backbone_training_pass_matches_autograd(B, layers):
+    """MHCBackbone on the one-launch nodes — the first sub-block fed the un-repeated input projection (its backward returns the
+    branches' summed gradient), the final norm summing the branches on load and handing the last sub-block one gradient row
+    through a stride-0 view — against the module's torch expression in float64: output, d x, every parameter's gradient."""
+    import gymrl_amd.ppo_full_lunarlander as pf
+    torch.manual_seed(B + layers)
+    net = pf.MHCBackbone(8, 128, 2, layers, 10)
+    with torch.no_grad():
+        for blk in net.layers:
+            for m in (blk.mhc1, blk.mhc2):
+                m.w.normal_(0, 0.3)
+                m.alpha.copy_(torch.tensor([0.7, -0.4, 0.9]))
+                m.norm.weight.uniform_(0.5, 1.5)
+        net.final_norm.weight.uniform_(0.5, 1.5)
+    ref = pf.MHCBackbone(8, 128, 2, layers, 10).double()
+    ref.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    x, g = torch.randn(B, 8), torch.randn(B, 128)
+    x64 = x.double().requires_grad_(True)
+    y64 = ref(x64)
+    y64.backward(g.double())
+    net = net.cuda()
+    xd = x.cuda().requires_grad_(True)
+    y = net(xd)
+    assert type(y.grad_fn).__name__ == "_RmsNormSumBackward"
+    y.backward(g.cuda())
+    _close(y, y64.detach(), 1e-5)
+    _close(xd.grad, x64.grad, 3e-5)
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        _close(p.grad, q.grad, 3e-5)
