@@ -33,7 +33,7 @@ SYMBOLS = [
     "gymrl_pack_rollout", "gymrl_gather_minibatch", "gymrl_loss_blocks", "gymrl_reduce_rows",
     "gymrl_sqnorm", "gymrl_adam_step", "gymrl_adam_bias", "gymrl_store_scalars", "gymrl_soft_update",
     "gymrl_replay_append", "gymrl_replay_gather", "gymrl_uniform_indices", "gymrl_nstep_push",
-    "gymrl_per_workspace_bytes", "gymrl_per_update", "gymrl_per_max_leaf", "gymrl_per_priorities",
+    "gymrl_per_workspace_bytes", "gymrl_per_update", "gymrl_per_max_leaf", "gymrl_per_priorities", "gymrl_per_update_td",
     "gymrl_per_sample", "gymrl_noisy_noise", "gymrl_epsilon_greedy", "gymrl_dqn_td_loss",
     "gymrl_sac_sample_fwd", "gymrl_sac_sample_bwd", "gymrl_sac_target", "gymrl_sac_critic_loss",
     "gymrl_sac_actor_loss", "gymrl_sac_alpha_step", "gymrl_running_norm", "gymrl_reward_scaling",

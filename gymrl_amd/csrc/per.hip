@@ -158,15 +158,29 @@ __global__ __launch_bounds__(1024) void per_ancestor_kernel(double* __restrict__
 // Same sums in the same order: the float64 tree stays bit-identical (tests/test_hip_parity_offpolicy.py::test_sumtree_*).
 constexpr int kSmallB = 512;
 
+// |td| -> priority, update_priorities' transform (rainbow_dqn_cartpole.py:258-261): float32 arithmetic like the reference —
+// np.abs(f32) + python float and ** python float stay float32 under NumPy >= 2 —, x**a as exp(a log x) with the reproducible
+// f32 kernels
+__device__ __forceinline__ double td_priority(float td, double alpha, double eps, double clip) {
+  float e = fabsf(td) + (float)eps;
+  if (clip > 0.0 && e > (float)clip) e = (float)clip;
+  return (double)det_expf((float)alpha * det_logf(e));
+}
+
+struct TdPrio { const float* td; double alpha, eps, clip; };   // td != nullptr: the batch's priorities are td_priority(td[i])
+
 __global__ __launch_bounds__(1024) void per_leaf_small_kernel(double* __restrict__ tree, int64_t cap, const int32_t* __restrict__ idx,
                                                               int idx_is_tree, const double* __restrict__ prio,
                                                               const double* __restrict__ ps_dev, double ps, int B,
-                                                              int64_t* __restrict__ leaf_out, double* __restrict__ change_out) {
+                                                              int64_t* __restrict__ leaf_out, double* __restrict__ change_out,
+                                                              TdPrio tp) {
   __shared__ int32_t s_leaf[kSmallB];
+  __shared__ double s_prio[kSmallB];
   for (int i = threadIdx.x; i < B; i += blockDim.x) {
     const int32_t leaf = idx_is_tree ? idx[i] : idx[i] + (int32_t)(cap - 1);
     s_leaf[i] = leaf;
     leaf_out[i] = leaf;
+    s_prio[i] = tp.td ? td_priority(tp.td[i], tp.alpha, tp.eps, tp.clip) : prio_of(prio, ps_dev, ps, i);
   }
   __syncthreads();
   // change_i = p_i - (value of the leaf just before element i is applied): the latest earlier element on the same leaf, else the tree
@@ -179,8 +193,8 @@ __global__ __launch_bounds__(1024) void per_leaf_small_kernel(double* __restrict
     found = max(found, __shfl_xor(found, 1, 64));
     found = max(found, __shfl_xor(found, 2, 64));
     if (s == 0) {
-      const double prev = found >= 0 ? prio_of(prio, ps_dev, ps, found) : tree[leaf];
-      change_out[i] = prio_of(prio, ps_dev, ps, i) - prev;
+      const double prev = found >= 0 ? s_prio[found] : tree[leaf];
+      change_out[i] = s_prio[i] - prev;
     }
   }
   __syncthreads();
@@ -193,15 +207,52 @@ __global__ __launch_bounds__(1024) void per_leaf_small_kernel(double* __restrict
       if (s_leaf[j] == leaf) { later = 1; break; }
     later |= __shfl_xor(later, 1, 64);
     later |= __shfl_xor(later, 2, 64);
-    if (s == 0 && !later) tree[leaf] = prio_of(prio, ps_dev, ps, i);
+    if (s == 0 && !later) tree[leaf] = s_prio[i];
   }
+}
+
+// The maximum over the leaves beside the ancestors' sums: what the NEXT store_transition() gives its new rows (:186-189).
+// It needs the leaves only, which the launch before this one has written — so the scan rides in the ancestor launch as
+// extra workgroups (blockIdx.x >= depth) instead of two launches of its own behind it, and the last of them to finish
+// folds the partials (`ticket`: zero before the first use, left zero).  max is exact in any order.
+struct MaxLeaf { int64_t cap; double* partial; double* out; unsigned int* ticket; int nb; };
+
+__device__ __forceinline__ void max_leaf_block(const double* __restrict__ tree, const MaxLeaf& m, int b) {
+  __shared__ double sm[1024];
+  __shared__ unsigned int s_last;
+  double v = -1.0e308;
+  for (int64_t i = (int64_t)b * blockDim.x + threadIdx.x; i < m.cap; i += (int64_t)m.nb * blockDim.x) v = fmax(v, tree[m.cap - 1 + i]);
+  sm[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(m.partial + b, sm[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    s_last = atomicAdd(m.ticket, 1u) == (unsigned int)(m.nb - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  v = -1.0e308;
+  for (int i = threadIdx.x; i < m.nb; i += blockDim.x) v = fmax(v, __hip_atomic_load(m.partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  sm[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { m.out[0] = sm[0]; *m.ticket = 0u; }
 }
 
 // blockIdx.x = node depth d.  A node's additions happen in batch order (the reference's loop).
 __global__ __launch_bounds__(1024) void per_ancestor_small_kernel(double* __restrict__ tree, const int64_t* __restrict__ leaf_g,
-                                                                  const double* __restrict__ change_g, int B) {
+                                                                  const double* __restrict__ change_g, int B, int depth, MaxLeaf mx) {
   __shared__ int32_t s_node[kSmallB];       // the element's ancestor at this depth, -1: none
   __shared__ double s_change[kSmallB];
+  if ((int)blockIdx.x >= depth) { max_leaf_block(tree, mx, (int)blockIdx.x - depth); return; }
   const int d = blockIdx.x;
   for (int i = threadIdx.x; i < B; i += blockDim.x) {
     const int64_t lf = leaf_g[i];
@@ -423,11 +474,7 @@ __global__ __launch_bounds__(kBlock) void per_priorities_kernel(const float* __r
                                                                 double* __restrict__ out) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= B) return;
-  // float32 arithmetic like the reference: np.abs(f32) + python float and ** python float stay
-  // float32 under NumPy >= 2; x**a as exp(a*log x) with the reproducible f32 kernels
-  float e = fabsf(td[i]) + (float)eps;
-  if (clip > 0.0 && e > (float)clip) e = (float)clip;
-  out[i] = (double)det_expf((float)alpha * det_logf(e));
+  out[i] = td_priority(td[i], alpha, eps, clip);
 }
 
 struct PerSampleDev { uint64_t counter; int64_t size; double beta; };
@@ -556,9 +603,10 @@ int gymrl_per_update(double* tree, int64_t cap, const int32_t* idx, int64_t idx_
   }
   if (B <= kSmallB && 2 * cap < (1ll << 31)) {                           // the reference's batch sizes: 32-bit ids, shared searches
     hipLaunchKernelGGL(per_leaf_small_kernel, dim3(1), dim3(1024), 0, stream, tree, cap, idx, idx_is_tree, prio, prio_scalar_dev,
-                       prio_scalar, B, ws.leaf, ws.change);
+                       prio_scalar, B, ws.leaf, ws.change, TdPrio{nullptr, 0.0, 0.0, 0.0});
     if (depth > 0)
-      hipLaunchKernelGGL(per_ancestor_small_kernel, dim3(depth), dim3(1024), 0, stream, tree, ws.leaf, ws.change, B);
+      hipLaunchKernelGGL(per_ancestor_small_kernel, dim3(depth), dim3(1024), 0, stream, tree, ws.leaf, ws.change, B, depth,
+                         MaxLeaf{0, nullptr, nullptr, nullptr, 0});
     GYMRL_CHECK_LAUNCH();
     return 0;
   }
@@ -588,6 +636,25 @@ int gymrl_per_priorities(const float* td, int B, double alpha, double eps, doubl
   if (B == 0) return 0;
   hipLaunchKernelGGL(per_priorities_kernel, dim3(cdiv(B, kBlock)), dim3(kBlock), 0, (hipStream_t)stream_,
                      td, B, alpha, eps, clip, prio_out);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_per_update_td(double* tree, int64_t cap, const int32_t* idx, const float* td, int B, double alpha, double eps,
+                        double clip, double* max_out, unsigned int* ticket, void* workspace, void* stream_) {
+  if (!tree || !idx || !td || !workspace || cap <= 0 || B < 1 || B > kSmallB || 2 * cap >= (1ll << 31) || (max_out && !ticket))
+    return -22;
+  hipStream_t stream = (hipStream_t)stream_;
+  Ws ws(workspace, B);
+  int depth = 0;
+  { int64_t t = 2 * cap - 2; while (t > 0) { t = (t - 1) / 2; ++depth; } }
+  int nb = max_out ? cdiv(cap, (int64_t)1024 * 8) : 0;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(per_leaf_small_kernel, dim3(1), dim3(1024), 0, stream, tree, cap, idx, 0, nullptr, nullptr, 0.0, B,
+                     ws.leaf, ws.change, TdPrio{td, alpha, eps, clip});
+  if (depth + nb > 0)
+    hipLaunchKernelGGL(per_ancestor_small_kernel, dim3(depth + nb), dim3(1024), 0, stream, tree, ws.leaf, ws.change, B, depth,
+                       MaxLeaf{cap, ws.partial, max_out, ticket, nb});
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

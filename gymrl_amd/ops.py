@@ -459,6 +459,18 @@ def per_priorities(td, alpha, eps, clip=0.0, out=None):
     return out
 
 
+PER_TD_MAX_BATCH = 512
+
+
+def per_update_td(tree, cap, idx, td, alpha, eps, workspace, clip=0.0, max_out=None, ticket=None):
+    """gymrl_per_update_td: update_priorities of a sampled batch straight from the TD errors (B <= 512, cap < 2^30); with
+    max_out f64[1] + ticket i32[1] (zero) the maximum over the leaves after the update comes out of the same two launches."""
+    check(lib().gymrl_per_update_td(_ptr(tree, torch.float64), C.c_int64(cap), _ptr(idx, torch.int32), _ptr(td, torch.float32),
+                                    C.c_int(idx.numel()), C.c_double(alpha), C.c_double(eps), C.c_double(clip),
+                                    _ptr(max_out, torch.float64, True), _ptr(ticket, torch.int32, True), _ptr(workspace),
+                                    _stream()), "gymrl_per_update_td")
+
+
 def per_sample(tree, cap, B, size, beta, workspace, u=None, seed=0, counter=0, variant_b=False, out=None, dev=None):
     if out is None:
         idx = torch.empty(B, dtype=torch.int32, device=tree.device)

@@ -9,6 +9,7 @@ update, stratified sampling, priority_max), NoisyNet noise generation, the doubl
 loss forward/backward, clip-norm + Adam and the soft target update are HIP kernels behind
 the C-ABI; the four Linear layers run through PyTorch-ROCm autograd.
 """
+import os
 import copy
 import math
 from collections import deque
@@ -142,6 +143,7 @@ class NoisyLinear(nn.Module):
         return small_linear(x, weight, bias)
 
 
+FUSED_TREE_UPDATE = os.environ.get("GYMRL_FUSED_TREE_UPDATE", "1") != "0"  # update_priorities + the next store's priority_max in two launches (gymrl_per_update_td); False: five
 OVERLAP_TREE = True     # sum-tree updates on a side stream beside the forward / backward passes (tools/micro_offpolicy.py A/B)
 
 
@@ -236,16 +238,30 @@ class SumTree:
         self.tree = torch.zeros(self.tree_capacity, dtype=torch.float64, device=device)
         self._ws = ops.per_workspace(max(8192, capacity), device)
         self._max = torch.zeros(1, dtype=torch.float64, device=device)
+        self._ticket = torch.zeros(1, dtype=torch.int32, device=device)
+        self._max_fresh = False        # _max holds the maximum over the leaves as they are (update_td() just computed it)
 
     def update(self, data_index, priority):
         idx = torch.as_tensor([int(data_index)], dtype=torch.int32, device=self.tree.device)
         pr = torch.as_tensor([float(priority)], dtype=torch.float64, device=self.tree.device)
+        self._max_fresh = False
         ops.per_update(self.tree, self.capacity, 1, self._ws, idx=idx, prio=pr)
 
     def update_batch(self, idx, prio):
+        self._max_fresh = False
         ops.per_update(self.tree, self.capacity, idx.numel(), self._ws, idx=idx, prio=prio)
 
+    def update_td(self, idx, td, alpha, eps):
+        """update_priorities straight from the TD errors, the leaves' new maximum riding in the same two launches (the next
+        store needs it: priority_max then costs nothing).  False: the batch / capacity is outside that kernel's range."""
+        if idx.numel() > ops.PER_TD_MAX_BATCH or self.capacity >= 1 << 30:
+            return False
+        ops.per_update_td(self.tree, self.capacity, idx, td, alpha, eps, self._ws, max_out=self._max, ticket=self._ticket)
+        self._max_fresh = True
+        return True
+
     def update_range(self, start, n, priority=None, priority_dev=None, start_dev=None):
+        self._max_fresh = False
         ops.per_update(self.tree, self.capacity, n, self._ws, idx_start=start, prio_scalar=priority or 0.0,
                        prio_scalar_dev=priority_dev, idx_start_dev=start_dev)
 
@@ -255,6 +271,8 @@ class SumTree:
 
     @property
     def priority_max(self):
+        if self._max_fresh:            # (same stream order as the launches that wrote it)
+            return self._max
         return ops.per_max_leaf(self.tree, self.capacity, self._max, self._ws)
 
 
@@ -368,6 +386,9 @@ class PrioritizedNStepBuffer:
 
     def update_priorities(self, batch_index, td_errors):
         """:258-261: p = (|td| + 0.01)^alpha, applied in batch order."""
+        if FUSED_TREE_UPDATE and td_errors.dtype == torch.float32 and batch_index.dtype == torch.int32 \
+                and self.sum_tree.update_td(batch_index, td_errors, self.alpha, 0.01):
+            return
         pr = ops.per_priorities(td_errors, self.alpha, 0.01)
         self.sum_tree.update_batch(batch_index, pr)
 
@@ -384,6 +405,7 @@ class PrioritizedNStepBuffer:
         for dst, src in zip(self.ring + self.win, list(sd["ring"]) + list(sd["win"])):
             dst.copy_(src.to(dst.device))
         self.sum_tree.tree.copy_(sd["tree"].to(self.device))
+        self.sum_tree._max_fresh = False
         self.current_size, self.count, self.pushes = int(sd["current_size"]), int(sd["count"]), int(sd["pushes"])
         self.draws, self.beta = int(sd["draws"]), float(sd["beta"])
 

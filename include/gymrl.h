@@ -895,6 +895,13 @@ int gymrl_per_max_leaf(const double* tree, int64_t cap, double* out, void* works
                        void* stream);
 int gymrl_per_priorities(const float* td, int B, double alpha, double eps, double clip,
                          double* prio_out, void* stream);
+/* update_priorities of a sampled batch (rainbow_dqn_cartpole.py:258-261) in two launches: gymrl_per_priorities' transform of
+ * td inside gymrl_per_update's leaf pass (data indices idx i32[B], B <= 512, cap < 2^30), and — max_out != NULL — the maximum
+ * over the leaves AFTER the update (gymrl_per_max_leaf: what the next store gives its new rows) computed by extra workgroups
+ * of the ancestor launch; `ticket` u32[1] must be zero before the first call and is left zero.  The tree and max_out hold the
+ * bits of gymrl_per_priorities -> gymrl_per_update -> gymrl_per_max_leaf. */
+int gymrl_per_update_td(double* tree, int64_t cap, const int32_t* idx, const float* td, int B, double alpha, double eps,
+                        double clip, double* max_out, unsigned int* ticket, void* workspace, void* stream);
 int gymrl_per_sample(const double* tree, int64_t cap, const double* u, uint64_t seed,
                      uint64_t counter, int B, int64_t size, double beta, int variant_b,
                      int32_t* idx_out, double* prio_out, float* w_out, const void* dev, void* workspace,

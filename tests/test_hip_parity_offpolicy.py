@@ -432,3 +432,32 @@ def test_env_abandon_vs_oracle(dev, oracle, kind_name):
         assert np.all(ep_len[flag.astype(bool)] == cap)
         hits += int(flag.sum())
     assert hits > n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cap,B", [(1 << 20, 256), (5000, 512), (1, 1), (300, 37)])
+def test_per_update_td_equals_its_three_calls(dev, cap, B):
+    """gymrl_per_update_td (update_priorities from the TD errors + the next store's priority_max, two launches) leaves the
+    tree and the maximum with the bits of gymrl_per_priorities -> gymrl_per_update -> gymrl_per_max_leaf — duplicates in the
+    batch included — and its ticket back at zero."""
+    from gymrl_amd import ops
+    g = torch.Generator().manual_seed(cap + B)
+    tree_a = torch.zeros(2 * cap - 1, dtype=torch.float64, device=dev)
+    ws = ops.per_workspace(max(8192, cap), dev)
+    n0 = min(cap, 4096)
+    ops.per_update(tree_a, cap, n0, ws, idx_start=0, prio=torch.rand(n0, generator=g, dtype=torch.float64).to(dev) + 0.1)
+    tree_b = tree_a.clone()
+    mx_a, mx_b = torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)
+    ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+    for rep in range(3):
+        idx = torch.randint(0, min(cap, n0), (B,), generator=g).to(torch.int32).to(dev)
+        if B > 8:
+            idx[5] = idx[2]
+            idx[B - 1] = idx[2]
+        td = (torch.randn(B, generator=g) * 3.0).to(dev)
+        ops.per_update(tree_a, cap, B, ws, idx=idx, prio=ops.per_priorities(td, 0.6, 0.01))
+        ops.per_max_leaf(tree_a, cap, mx_a, ws)
+        ops.per_update_td(tree_b, cap, idx, td, 0.6, 0.01, ws, max_out=mx_b, ticket=ticket)
+        assert torch.equal(tree_a, tree_b), rep
+        assert torch.equal(mx_a, mx_b), rep
+        assert int(ticket.item()) == 0
