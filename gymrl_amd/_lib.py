@@ -49,7 +49,7 @@ SYMBOLS = [
     "gymrl_noisy_combine", "gymrl_noisy_split", "gymrl_dueling_bwd",
     "gymrl_mhc_gates", "gymrl_mhc_combine", "gymrl_rmsnorm", "gymrl_sinkhorn",
     "gymrl_mhc_read_fwd", "gymrl_mhc_read_bwd", "gymrl_mhc_combine_bwd",
-    "gymrl_mhc_gates_bwd_workspace_bytes", "gymrl_mhc_gates_bwd", "gymrl_rmsnorm_bwd_workspace_bytes", "gymrl_rmsnorm_bwd", "gymrl_rmsnorm_sum_bwd",
+    "gymrl_mhc_gates_bwd_workspace_bytes", "gymrl_mhc_gates_bwd", "gymrl_rmsnorm_bwd_workspace_bytes", "gymrl_rmsnorm_bwd", "gymrl_rmsnorm_sum_bwd", "gymrl_norm_proj_fwd", "gymrl_norm_proj_bwd_workspace_bytes", "gymrl_norm_proj_bwd",
     "gymrl_mhc_policy_forward", "gymrl_mhc_sub_forward", "gymrl_mhc_sub_backward", "gymrl_rollout_lunar_mhc",
     "gymrl_sac_update_workspace_bytes", "gymrl_sac_args_bytes", "gymrl_sac_act_step", "gymrl_sac_update", "gymrl_sac_pack_images",
     "gymrl_rainbow_update_workspace_bytes", "gymrl_rainbow_args_bytes", "gymrl_rainbow_act_step", "gymrl_rainbow_update",
@@ -231,6 +231,7 @@ def lib():
         L.gymrl_lin_workspace_bytes.restype = C.c_size_t
         L.gymrl_mhc_gates_bwd_workspace_bytes.restype = C.c_size_t
         L.gymrl_rmsnorm_bwd_workspace_bytes.restype = C.c_size_t
+        L.gymrl_norm_proj_bwd_workspace_bytes.restype = C.c_size_t
         L.gymrl_sac_update_workspace_bytes.restype = C.c_size_t
         L.gymrl_sac_args_bytes.restype = C.c_size_t
         L.gymrl_rainbow_update_workspace_bytes.restype = C.c_size_t

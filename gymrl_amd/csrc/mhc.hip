@@ -707,6 +707,136 @@ __global__ __launch_bounds__(64 * kWaves) void rmsnorm_bwd_kernel(const float* _
   }
 }
 
+// ---- training pass: a head's tail, SiLU -> RMSNorm -> Linear(D -> n_out <= 8), in one launch each way ---------------------
+// MLP([128, 256, n_out]) (:371-402) ends in y = RMSNorm(SiLU(x)), out = y W2^T + b2 with n_out = 4 (actor) or 1 (critic).  As the
+// norm's launches plus the layer kernels that is 1 KB of y per row written, read back twice (the projection, its weight
+// gradient) and a [B, D] gradient d y written and re-read: 2.2 KB per row of traffic that carries 16 bytes of information.
+// Here a wave walks rows with the row in registers (rmsnorm_reg_kernel's layout: lane l holds columns l + 64 q): forward =
+// one read of x, n_out + 1 wave sums; backward = x and the n_out output gradients in, d x out, y recomputed for d W2, and
+// the three parameter sums (d norm_w, d W2, d b2) per lane over the rows the wave visits, added across the workgroup through
+// LDS: one partial vector per workgroup for partial_reduce_kernel.
+template <int Q, int NO>
+__global__ __launch_bounds__(64 * kWaves) void norm_proj_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                   const float* __restrict__ W2, const float* __restrict__ b2, int B,
+                                                                   int D, int n_out, float eps, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  float wv[Q], W2r[NO][Q], b2r[NO];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int d = lane + 64 * q;
+    wv[q] = d < D ? w[d] : 0.0f;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) W2r[o][q] = (o < n_out && d < D) ? W2[(size_t)o * D + d] : 0.0f;
+  }
+#pragma unroll
+  for (int o = 0; o < NO; ++o) b2r[o] = (o < n_out && b2) ? b2[o] : 0.0f;
+  for (int64_t row = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6); row < B; row += (int64_t)gridDim.x * kWaves) {
+    float sq = 0.0f, dot[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) dot[o] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int d = lane + 64 * q;
+      const float sv = d < D ? silu_(x[row * D + d]) : 0.0f;
+      sq += sv * sv;
+      const float t = sv * wv[q];
+#pragma unroll
+      for (int o = 0; o < NO; ++o) dot[o] += t * W2r[o][q];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sq += __shfl_xor(sq, off, 64);
+#pragma unroll
+      for (int o = 0; o < NO; ++o) dot[o] += __shfl_xor(dot[o], off, 64);
+    }
+    const float r = rsqrtf(sq / (float)D + eps);
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+      if (lane == o && o < n_out) out[row * n_out + o] = r * dot[o] + b2r[o];
+  }
+}
+
+template <int Q, int NO>
+__global__ __launch_bounds__(64 * kWaves) void norm_proj_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ x,
+                                                                   const float* __restrict__ w, const float* __restrict__ W2, int B, int D,
+                                                                   int n_out, float eps, float* __restrict__ d_x, float* __restrict__ partial) {
+  extern __shared__ float np_red[];                        // [kWaves][len], len = D + n_out * (D + 1)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int len = D + n_out * (D + 1);
+  float wv[Q], W2r[NO][Q], acc_w[Q], acc_W2[NO][Q], acc_b[NO];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int d = lane + 64 * q;
+    wv[q] = d < D ? w[d] : 0.0f;
+    acc_w[q] = 0.0f;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) { W2r[o][q] = (o < n_out && d < D) ? W2[(size_t)o * D + d] : 0.0f; acc_W2[o][q] = 0.0f; }
+  }
+#pragma unroll
+  for (int o = 0; o < NO; ++o) acc_b[o] = 0.0f;
+  const float inv_d = 1.0f / (float)D;
+  for (int64_t row = (int64_t)blockIdx.x * kWaves + wave; row < B; row += (int64_t)gridDim.x * kWaves) {
+    float xv[Q], sv[Q], gv[Q], dlv[NO], sq = 0.0f, dot = 0.0f;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) dlv[o] = o < n_out ? dl[row * n_out + o] : 0.0f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int d = lane + 64 * q;
+      xv[q] = d < D ? x[row * D + d] : 0.0f;
+      sv[q] = silu_(xv[q]);
+      float g = 0.0f;
+#pragma unroll
+      for (int o = 0; o < NO; ++o) g += dlv[o] * W2r[o][q];
+      gv[q] = g;
+      sq += sv[q] * sv[q];
+      dot += wv[q] * g * sv[q];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sq += __shfl_xor(sq, off, 64);
+      dot += __shfl_xor(dot, off, 64);
+    }
+    const float r = rsqrtf(sq * inv_d + eps);
+    const float k3 = r * r * r * inv_d * dot;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int d = lane + 64 * q;
+      if (d < D) {
+        d_x[row * D + d] = (r * wv[q] * gv[q] - sv[q] * k3) * silu_grad_(xv[q]);
+        acc_w[q] += gv[q] * sv[q] * r;
+        const float y = sv[q] * r * wv[q];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) acc_W2[o][q] += dlv[o] * y;
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) acc_b[o] += dlv[o];
+  }
+  float* mine = np_red + (size_t)wave * len;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int d = lane + 64 * q;
+    if (d < D) {
+      mine[d] = acc_w[q];
+#pragma unroll
+      for (int o = 0; o < NO; ++o)
+        if (o < n_out) mine[D + o * D + d] = acc_W2[o][q];
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+      if (o < n_out) mine[D + n_out * D + o] = acc_b[o];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < len; i += 64 * kWaves) {
+    float sum = np_red[i];
+#pragma unroll
+    for (int w2 = 1; w2 < kWaves; ++w2) sum += np_red[(size_t)w2 * len + i];
+    partial[(size_t)blockIdx.x * len + i] = sum;
+  }
+}
+
 // ---- training pass: a whole sub-block forward in one launch (n = 2, D = 128) ----------------------------------------------
 // gates + Linear + combine of MHCBlock._sub as three launches move 1.34 GB per 262144-row micro-batch (h is read twice, the
 // branch sum and the Linear's output make a round trip each: 120 + 97 + 140 us).  Here a wave carries a 16-row tile through all
@@ -1456,6 +1586,51 @@ int gymrl_rmsnorm_sum_bwd(const float* g, const float* x, const float* w, int B,
   else hipLaunchKernelGGL(rmsnorm_bwd_kernel<8>, grid, block, 0, (hipStream_t)stream, g, x, w, B, D, n_sum, eps, silu, d_x, part);
   ReduceArgs r{part, blocks, D, 1, {D, 0, 0, 0}, {0, 0, 0, 0}, {d_w, nullptr, nullptr, nullptr}};
   hipLaunchKernelGGL(partial_reduce_kernel, dim3((D + 31) / 32, 1), dim3(256), 0, (hipStream_t)stream, r);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+#define NORM_PROJ_DISPATCH(KERNEL, ...)                                                                            \
+  do {                                                                                                             \
+    if (D <= 128) {                                                                                                \
+      if (n_out <= 1) hipLaunchKernelGGL((KERNEL<2, 1>), __VA_ARGS__);                                            \
+      else if (n_out <= 4) hipLaunchKernelGGL((KERNEL<2, 4>), __VA_ARGS__);                                       \
+      else hipLaunchKernelGGL((KERNEL<2, 8>), __VA_ARGS__);                                                        \
+    } else {                                                                                                       \
+      if (n_out <= 1) hipLaunchKernelGGL((KERNEL<4, 1>), __VA_ARGS__);                                            \
+      else if (n_out <= 4) hipLaunchKernelGGL((KERNEL<4, 4>), __VA_ARGS__);                                       \
+      else hipLaunchKernelGGL((KERNEL<4, 8>), __VA_ARGS__);                                                        \
+    }                                                                                                              \
+  } while (0)
+
+int gymrl_norm_proj_fwd(const float* x, const float* norm_w, const float* W2, const float* b2, int B, int D, int n_out, float eps,
+                        float* out, void* stream) {
+  if (!x || !norm_w || !W2 || !out || B < 0 || D < 1 || D > 256 || n_out < 1 || n_out > 8) return -22;
+  if (B == 0) return 0;
+  const dim3 block(64 * kWaves);
+  const unsigned want = (unsigned)((B + kWaves - 1) / kWaves);
+  const dim3 grid(want > 4096 ? 4096 : want);
+  NORM_PROJ_DISPATCH(norm_proj_fwd_kernel, grid, block, 0, (hipStream_t)stream, x, norm_w, W2, b2, B, D, n_out, eps, out);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+size_t gymrl_norm_proj_bwd_workspace_bytes(int D, int n_out) {
+  return sizeof(float) * 2048 * ((size_t)(D < 1 ? 1 : D) * (size_t)((n_out < 1 ? 1 : n_out) + 1) + (size_t)(n_out < 1 ? 1 : n_out));
+}
+
+int gymrl_norm_proj_bwd(const float* d_out, const float* x, const float* norm_w, const float* W2, int B, int D, int n_out, float eps,
+                        float* d_x, float* d_norm_w, float* d_W2, float* d_b2, void* workspace, void* stream) {
+  if (!d_out || !x || !norm_w || !W2 || !d_x || !d_norm_w || !d_W2 || !d_b2 || !workspace || B < 1 || D < 1 || D > 256 || n_out < 1 ||
+      n_out > 8)
+    return -22;
+  const int blocks = rmsnorm_bwd_blocks(B), len = D + n_out * (D + 1);
+  float* part = static_cast<float*>(workspace);
+  const dim3 grid(blocks), block(64 * kWaves);
+  const size_t lds = sizeof(float) * (size_t)kWaves * len;
+  NORM_PROJ_DISPATCH(norm_proj_bwd_kernel, grid, block, lds, (hipStream_t)stream, d_out, x, norm_w, W2, B, D, n_out, eps, d_x, part);
+  ReduceArgs r{part, blocks, len, 3, {D, D + n_out * D, len, 0}, {0, 0, 0, 0}, {d_norm_w, d_W2, d_b2, nullptr}};
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((len + 31) / 32, 1), dim3(256), 0, (hipStream_t)stream, r);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

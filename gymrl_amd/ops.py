@@ -1159,6 +1159,35 @@ def rmsnorm_bwd(g, x, w, eps, act=0, n_sum=1):
     return d_x, d_w
 
 
+def norm_proj_ok(D, n_out):
+    """Shapes gymrl_norm_proj_fwd / _bwd take."""
+    return 0 < D <= 256 and 0 < n_out <= 8
+
+
+def norm_proj_fwd(x, norm_w, eps, W2, b2):
+    """gymrl_norm_proj_fwd: RMSNorm(SiLU(x)) W2^T + b2 -> [B, n_out] in one launch."""
+    B, D = x.shape
+    out = torch.empty(B, W2.shape[0], device=x.device)
+    f = torch.float32
+    check(lib().gymrl_norm_proj_fwd(_ptr(x, f), _ptr(norm_w, f), _ptr(W2, f), _ptr(b2, f, True), C.c_int(B), C.c_int(D),
+                                    C.c_int(W2.shape[0]), C.c_float(eps), _ptr(out), _stream()), "gymrl_norm_proj_fwd")
+    return out
+
+
+def norm_proj_bwd(d_out, x, norm_w, eps, W2):
+    """gymrl_norm_proj_bwd -> (d_x, d_norm_w, d_W2, d_b2)."""
+    B, D = x.shape
+    n_out = W2.shape[0]
+    ws = _scratch("norm_proj_bwd", (D, n_out), lib().gymrl_norm_proj_bwd_workspace_bytes(C.c_int(D), C.c_int(n_out)), x.device)
+    d_x, d_nw, d_W2 = torch.empty_like(x), torch.empty_like(norm_w), torch.empty_like(W2)
+    d_b2 = torch.empty(n_out, device=x.device)
+    f = torch.float32
+    check(lib().gymrl_norm_proj_bwd(_ptr(d_out, f), _ptr(x, f), _ptr(norm_w, f), _ptr(W2, f), C.c_int(B), C.c_int(D), C.c_int(n_out),
+                                    C.c_float(eps), _ptr(d_x), _ptr(d_nw), _ptr(d_W2), _ptr(d_b2), _ptr(ws), _stream()),
+          "gymrl_norm_proj_bwd")
+    return d_x, d_nw, d_W2, d_b2
+
+
 def mhc_sub_forward(h, norm_w, w, alpha, beta, lin_w, lin_b, sk_it):
     """gymrl_mhc_sub_forward: one hyper-connection sub-block forward (n = 2, D = 128) in one launch ->
     (pre, post, mix, stats, read, z, h_out).  h [B, 2, D], or [B, D]: the same row for both branches."""

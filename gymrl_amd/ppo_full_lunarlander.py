@@ -72,6 +72,7 @@ FUSED_MIXING = True         # training pass: read / combine products as fused fo
 FUSED_INFERENCE = True      # rollout forward on the inference kernels (tools A/B; False: the torch modules)
 FUSED_POLICY = True         # rollout forward as ONE launch (gymrl_mhc_policy_forward) when the network has the default shape
 FUSED_SUB_FORWARD = True    # ... and its forward as ONE launch when D = 128 (False: gates + Linear + combine launches)
+FUSED_HEAD_TAIL = True      # training pass: a head's SiLU -> RMSNorm -> output Linear as one launch each way
 FUSED_SUB_BACKWARD = True   # ... and its backward as ONE launch + the Linear's weight gradient (False: the five backward launches)
 FUSED_SUB = True            # training pass: a whole hyper-connection sub-block as one autograd node (3 launches forward, 7 backward)
 FUSED_NORM = True           # training pass: RMSNorm (+ the SiLU before it) as one launch each way
@@ -132,6 +133,24 @@ class _RmsNormSum(torch.autograd.Function):
         h, w = ctx.saved_tensors
         d_x, d_w = ops.rmsnorm_bwd(g.contiguous(), h, w, ctx.eps, 0, n_sum=h.shape[1])
         return d_x.unsqueeze(1).expand(-1, h.shape[1], -1), d_w, None
+
+
+class _NormProj(torch.autograd.Function):
+    """A head's tail SiLU -> RMSNorm -> Linear(D -> n_out) (:371-402) as gymrl_norm_proj_fwd / _bwd: the normalised activations
+    and their gradient stay in registers (as three nodes they are 2.2 KB per row of HBM traffic for 16 bytes of output)."""
+
+    @staticmethod
+    def forward(ctx, x, norm_w, eps, W2, b2):
+        x = x.contiguous()
+        ctx.save_for_backward(x, norm_w, W2)
+        ctx.eps, ctx.has_bias = eps, b2 is not None
+        return ops.norm_proj_fwd(x, norm_w, eps, W2, b2)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, norm_w, W2 = ctx.saved_tensors
+        d_x, d_nw, d_W2, d_b2 = ops.norm_proj_bwd(g.contiguous(), x, norm_w, ctx.eps, W2)
+        return d_x, d_nw, None, d_W2, d_b2 if ctx.has_bias else None
 
 
 class ManifoldHyperConnectionFuse(nn.Module):
@@ -401,6 +420,12 @@ class MLP(nn.Module):
         mods = list(self.mlp)
         i = 0
         while i < len(mods):
+            if (FUSED_HEAD_TAIL and FUSED_NORM and i + 3 == len(mods) and isinstance(mods[i], nn.SiLU) and isinstance(mods[i + 1], RMSNorm)
+                    and isinstance(mods[i + 2], SmallLinear) and getattr(mods[i + 2], "act", None) in (None, "none")
+                    and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] > 0
+                    and ops.norm_proj_ok(x.shape[1], mods[i + 2].out_features)):
+                # SiLU -> RMSNorm -> the output Linear in one launch each way (csrc/mhc.hip norm_proj_*_kernel)
+                return _NormProj.apply(x, mods[i + 1].weight, mods[i + 1].eps, mods[i + 2].weight, mods[i + 2].bias)
             if i + 1 < len(mods) and isinstance(mods[i], nn.SiLU) and isinstance(mods[i + 1], RMSNorm):
                 x = mods[i + 1](x, silu=True)        # SiLU rides in the norm's launches on the GPU
                 i += 2

@@ -594,6 +594,15 @@ int gymrl_rmsnorm_bwd(const float* g, const float* x, const float* w, int B, int
  * the gradient of EVERY block (the sum hands each the same one — the caller broadcasts it, nothing is materialised). */
 int gymrl_rmsnorm_sum_bwd(const float* g, const float* x, const float* w, int B, int D, int n_sum, float eps, int act, float* d_x,
                           float* d_w, void* workspace, void* stream);
+/* A head's tail in one launch each way: out [B, n_out] = RMSNorm(SiLU(x)) W2^T + b2 for x [B, D], D <= 256, n_out <= 8
+ * (MLP([128, 256, n_out]) :371-402: the actor's and the critic's Linear -> SiLU -> RMSNorm -> Linear; b2 may be NULL), and its
+ * backward from d_out [B, n_out]: d_x [B, D], d_norm_w [D], d_W2 [n_out, D], d_b2 [n_out] (overwritten; per-workgroup partial
+ * sums in `workspace`, added in a fixed order).  The normalised activations and their gradient never touch HBM. */
+int gymrl_norm_proj_fwd(const float* x, const float* norm_w, const float* W2, const float* b2, int B, int D, int n_out, float eps,
+                        float* out, void* stream);
+size_t gymrl_norm_proj_bwd_workspace_bytes(int D, int n_out);
+int gymrl_norm_proj_bwd(const float* d_out, const float* x, const float* norm_w, const float* W2, int B, int D, int n_out, float eps,
+                        float* d_x, float* d_norm_w, float* d_W2, float* d_b2, void* workspace, void* stream);
 /* The Sinkhorn-Knopp sweeps alone (:141-146; constants of the backward pass in the reference): A f32[B, n, n] > 0 ->
  * u [B, n], v [B, n] after sk_it sweeps u = 1/(A v + 1e-8), v = 1/(A^T u + 1e-8) from u = v = 1 — for gate shapes
  * gymrl_mhc_gates_bwd does not cover, whose other gate operations stay with autograd. */

@@ -324,3 +324,44 @@ def test_backbone_training_pass_matches_autograd(B, layers):
     _close(xd.grad, x64.grad, 3e-5)
     for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         _close(p.grad, q.grad, 3e-5)
+
+
+@pytest.mark.parametrize("B,D,n_out,bias", [(3000, 256, 4, True), (1, 256, 1, True), (517, 128, 8, False), (40000, 256, 1, True),
+                                            (70, 96, 3, True)])
+def test_head_tail_node_matches_autograd(B, D, n_out, bias):
+    """SiLU -> RMSNorm -> Linear(D -> n_out) as one launch each way (_NormProj) against the modules in float64: output, d x,
+    and the gradients of the norm's weight, the projection and its bias; a second pass gives the same bits."""
+    import gymrl_amd.ppo_full_lunarlander as pf
+    from gymrl_amd.nn import SmallLinear
+    torch.manual_seed(B + D + n_out)
+    norm, lin = pf.RMSNorm(D), SmallLinear(D, n_out, bias=bias)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        lin.weight.normal_(0, 0.3)
+    x, g = torch.randn(B, D) * 2, torch.randn(B, n_out)
+    x64 = x.double().requires_grad_(True)
+    w64, W64 = norm.weight.detach().double().requires_grad_(True), lin.weight.detach().double().requires_grad_(True)
+    b64 = lin.bias.detach().double().requires_grad_(True) if bias else None
+    s = torch.nn.functional.silu(x64)
+    y64 = (s * torch.rsqrt(s.pow(2).mean(-1, keepdim=True) + norm.eps) * w64) @ W64.t()
+    if bias:
+        y64 = y64 + b64
+    y64.backward(g.double())
+    dev = "cuda"
+    xd = x.to(dev).requires_grad_(True)
+    nw, W = norm.weight.detach().to(dev).requires_grad_(True), lin.weight.detach().to(dev).requires_grad_(True)
+    b = lin.bias.detach().to(dev).requires_grad_(True) if bias else None
+    y = pf._NormProj.apply(xd, nw, norm.eps, W, b)
+    y.backward(g.to(dev))
+    _close(y, y64.detach(), 1e-5)
+    _close(xd.grad, x64.grad, 2e-5)
+    _close(nw.grad, w64.grad, 2e-5)
+    _close(W.grad, W64.grad, 2e-5)
+    if bias:
+        _close(b.grad, b64.grad, 2e-5)
+    first = [t.grad.clone() for t in (xd, nw, W)]
+    for t in (xd, nw, W):
+        t.grad = None
+    pf._NormProj.apply(xd, nw, norm.eps, W, b).backward(g.to(dev))
+    for a_, t in zip(first, (xd, nw, W)):
+        assert torch.equal(a_, t.grad)
