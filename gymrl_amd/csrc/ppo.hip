@@ -376,6 +376,17 @@ __global__ __launch_bounds__(kBlock) void gather_minibatch_kernel(
   }
 }
 
+// out[b, :] = src[idx[b], :] for rows of `quads` float4s (a minibatch of observations by index: states[mb_idx]); one lane
+// per float4, so a row is `quads` adjacent lanes' 16-byte loads
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float4* __restrict__ src, const int32_t* __restrict__ idx, int64_t n,
+                                                             int quads, float4* __restrict__ out) {
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n * quads; e += (int64_t)gridDim.x * kBlock) {
+    const int64_t b = e / quads;
+    const int q = (int)(e - b * quads);
+    out[e] = src[(int64_t)idx[b] * quads + q];
+  }
+}
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace
@@ -577,6 +588,18 @@ int gymrl_gather_minibatch(const float* packed, const int32_t* idx, int B, int o
   const int nb = cdiv(B, kBlock) < 4096 ? cdiv(B, kBlock) : 4096;
   hipLaunchKernelGGL(gather_minibatch_kernel, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream_, packed, idx,
                      B, obs_dim, obs_out, act_out, logp_out, adv_out, ret_out);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_gather_rows(const float* src, const int32_t* idx, int B, int row_floats, float* out, void* stream_) {
+  if (!src || !idx || !out || B < 0 || row_floats < 4 || row_floats % 4 || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(out)) & 15))
+    return -22;
+  if (B == 0) return 0;
+  const int quads = row_floats / 4;
+  const int64_t want = ((int64_t)B * quads + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(kBlock), 0, (hipStream_t)stream_,
+                     reinterpret_cast<const float4*>(src), idx, (int64_t)B, quads, reinterpret_cast<float4*>(out));
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

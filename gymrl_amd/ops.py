@@ -269,6 +269,15 @@ def pack_rollout(obs, act, logp, adv, ret, packed=None):
     return packed
 
 
+def gather_rows(src, idx, out=None):
+    """gymrl_gather_rows: src[idx] for a 2-D float32 `src` whose rows are a multiple of 16 bytes (idx int32)."""
+    B, D = idx.numel(), src.shape[1]
+    out = torch.empty(B, D, device=src.device) if out is None else out
+    check(lib().gymrl_gather_rows(_ptr(src, torch.float32), _ptr(idx, torch.int32), C.c_int(B), C.c_int(D), _ptr(out, torch.float32),
+                                  _stream()), "gymrl_gather_rows")
+    return out
+
+
 def gather_minibatch(packed, idx, obs_dim, out=None):
     """P7: rows idx[0..B) of the packed rollout -> contiguous (obs, act, logp_old, adv, ret)."""
     B, dev = idx.numel(), packed.device

@@ -742,7 +742,9 @@ class PPOTrainer:
         acc = n_micro > 1
 
         def fwd_bwd(idx, metrics_row):
-            logits, values = self.model(states.index_select(0, idx))
+            rows_in = (ops.gather_rows(states, idx) if states.shape[1] % 4 == 0 and idx.dtype == torch.int32 and states.is_contiguous()
+                       else states.index_select(0, idx))
+            logits, values = self.model(rows_in)
             values = values.view(-1)
             mul = None
             if cfg.clip_cov_ratio > 0:                                     # :594-616 (off by default)

@@ -316,6 +316,9 @@ int gymrl_pack_rollout(const float* obs, const int32_t* act, const float* logp,
 int gymrl_gather_minibatch(const float* packed, const int32_t* idx, int B, int obs_dim,
                            float* obs_out, int32_t* act_out, float* logp_out,
                            float* adv_out, float* ret_out, void* stream);
+/* out [B, row_floats] = src[idx[b], :] — a minibatch of rows by index (ppo_full_lunarlander.py:574 `states[mb_idx]`);
+ * row_floats a multiple of 4, src and out 16-byte aligned. */
+int gymrl_gather_rows(const float* src, const int32_t* idx, int B, int row_floats, float* out, void* stream);
 
 /* ------------------------------------------------------------ optimiser --- */
 /*
