@@ -125,7 +125,10 @@ struct SbArgs {
 // TRANS_W == false: W is [n][red] (nn.Linear weight, forward);  true: W is [red][n] (input gradient).
 // ABL (probe build only, tools/abl_gemm_sb.py; wrong results by design): 1 no MFMAs, 2 no split / LDS parking, 4 no activation
 // loads inside the loop, 8 no stores.
-template <int RED, int NT, bool TRANS_W, int EPI, int LDO, int ABL = 0>
+// PL (producer-side planes, round 4's bounded experiment): the activations arrive ALREADY split — three bf16 planes
+// [plane][M][RED] written by gymrl_split_planes (in a pipeline: by the producing layer's epilogue) — so a stage is six
+// 16-byte loads per lane that go to the LDS stage as they are: no split, no VALU between the MFMAs; 6 bytes per element in.
+template <int RED, int NT, bool TRANS_W, int EPI, int LDO, int ABL = 0, bool PL = false>
 __global__ __launch_bounds__(256) void gemm_sb_ws_kernel(SbArgs p) {
   constexpr int BN = 32 * NT, KG = RED / 8, KS = 32, NSTG = RED / KS, kWaves = 4, kThreads = 256, ROWS = 32;
   constexpr int XCH = 5;                                 // 16-byte chunks per staged row (4 used): 80-byte pitch
@@ -177,15 +180,44 @@ __global__ __launch_bounds__(256) void gemm_sb_ws_kernel(SbArgs p) {
   // every load has a full tile of matrix work (NSTG stages, ~3 us) to arrive — one stage ahead (0.35 us) exposed the whole
   // HBM latency on every stage (measured: 5 x the matrix time).
   int64_t bt = rg;
-  f32x4 ring[NSTG][4];
+  constexpr int NLD = PL ? 6 : 4;                        // 16-byte loads per lane and stage
+  f32x4 ring[NSTG][NLD];
   auto tile_rsrc = [&](int64_t bt_) {
     const int64_t task = bt_ * kWaves + wave;
     return rsrc_of(p.A + task * ROWS * RED, rows_of(task) * RED * 4u);
   };
-  {
+  // PL: plane pl of a row tile; lane (l >> 2, l & 3) loads row 16 hq + (l >> 2), reduction indices 8 (l & 3) .. + 7 of the stage
+  const uint16_t* planes = reinterpret_cast<const uint16_t*>(p.A);
+  auto plane_rsrc = [&](int64_t bt_, int pl) {
+    const int64_t task = bt_ * kWaves + wave;
+    return rsrc_of(planes + ((int64_t)pl * M + task * ROWS) * RED, rows_of(task) * RED * 2u);
+  };
+  const uint32_t poff = (uint32_t)((lane >> 2) * RED + 8 * (lane & 3)) * 2u;
+  auto fetch_pl = [&](int64_t bt_, int stg, f32x4 (&v)[NLD]) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const __amdgpu_buffer_rsrc_t r = plane_rsrc(bt_, pl);
+#pragma unroll
+      for (int hq = 0; hq < 2; ++hq) v[2 * pl + hq] = ld4(r, poff + (uint32_t)(hq * 16 * RED + stg * KS) * 2u);
+    }
+  };
+  auto park_pl = [&](int buf, const f32x4 (&v)[NLD]) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int hq = 0; hq < 2; ++hq)
+        myst[buf * XBUF + pl * ROWS * XCH + (16 * hq + (lane >> 2)) * XCH + (lane & 3)] = __builtin_bit_cast(u32x4, v[2 * pl + hq]);
+  };
+  if constexpr (PL) {
+#pragma unroll
+    for (int stg = 0; stg < NSTG; ++stg) fetch_pl(bt, stg, ring[stg]);
+  } else {
     const __amdgpu_buffer_rsrc_t first = tile_rsrc(bt);
 #pragma unroll
-    for (int stg = 0; stg < NSTG; ++stg) fetch(first, stg, ring[stg]);      // in flight under the weight fill
+    for (int stg = 0; stg < NSTG; ++stg) {
+      f32x4 (&dst)[4] = reinterpret_cast<f32x4 (&)[4]>(ring[stg]);
+      fetch(first, stg, dst);                             // in flight under the weight fill
+    }
   }
 
   // ---- weight slice -> three bf16 planes in LDS, once per workgroup
@@ -213,8 +245,14 @@ __global__ __launch_bounds__(256) void gemm_sb_ws_kernel(SbArgs p) {
 
   const uint32_t ooff = (uint32_t)(j * LDO + 4 * g) * 4u;               // lane (j, g): row j, columns 8 q + 4 g .. + 3 of a tile
   static_assert(NSTG % 2 == 0, "stage buffers alternate across tiles");
-  park(0, ring[0]);
-  fetch(tile_rsrc(bt + RG), 0, ring[0]);
+  if constexpr (PL) {
+    park_pl(0, ring[0]);
+    fetch_pl(bt + RG, 0, ring[0]);
+  } else {
+    f32x4 (&r0)[4] = reinterpret_cast<f32x4 (&)[4]>(ring[0]);
+    park(0, r0);
+    fetch(tile_rsrc(bt + RG), 0, r0);
+  }
   // operand registers of one 16-deep step: three planes of the activations and of NT weight tiles.  Two sets: the set of a
   // step is requested from LDS while the previous step's 6 NT MFMAs run (left to the compiler, every read sat next to its
   // first use behind an lgkmcnt(0): the LDS latency was exposed ~8 times per stage)
@@ -275,6 +313,15 @@ __global__ __launch_bounds__(256) void gemm_sb_ws_kernel(SbArgs p) {
         uint32_t ph[4], pm[4], pl[4];
         u32x4* const dstbuf = myst + (buf ^ 1) * XBUF;
         auto slice = [&](int c) {
+          if constexpr (PL) {                             // six pieces: the loaded chunk goes to the LDS stage as it is, its slot is refilled
+            if (c < 6) {
+              const int pl = c >> 1, hq = c & 1;
+              dstbuf[pl * ROWS * XCH + (16 * hq + (lane >> 2)) * XCH + (lane & 3)] = __builtin_bit_cast(u32x4, ring[ns][c]);
+              const int64_t nbt = ns ? bt + RG : bt + 2 * RG;
+              ring[ns][c] = ld4(plane_rsrc(nbt, pl), poff + (uint32_t)(hq * 16 * RED + ns * KS) * 2u);
+            }
+            return;
+          }
           const int q = c / 3, part = c % 3;
           if (part < 2) {
             if constexpr (!(ABL & 2)) {
@@ -337,6 +384,24 @@ __global__ __launch_bounds__(256) void gemm_sb_ws_kernel(SbArgs p) {
 #ifdef GYMRL_PROF_BUILD
 int g_sb_abl = 0;
 #endif
+// ---- the three bf16 planes of an f32 array (what a producing layer's epilogue would write): P[plane][n] -------------------
+__global__ __launch_bounds__(256) void split_planes_kernel(const f32x4* __restrict__ x, int64_t n4, u32x2* __restrict__ planes) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    u32x2 H, Mm, L;
+    split4(x[i], H, Mm, L);
+    planes[i] = H; planes[n4 + i] = Mm; planes[2 * n4 + i] = L;
+  }
+}
+
+template <int EPI, int LDO>
+void launch_sb_ws_planes(const SbArgs& a, hipStream_t s) {
+  const int64_t tasks = (a.M + 31) / 32, bts = (tasks + 3) / 4;
+  int64_t rg = kCUs / a.slices;
+  if (bts < rg) rg = bts;
+  if (rg < 1) rg = 1;
+  hipLaunchKernelGGL((gemm_sb_ws_kernel<256, 2, false, EPI, LDO, 0, true>), dim3((unsigned)(rg * a.slices)), dim3(256), 0, s, a);
+}
+
 template <int RED, int NT, bool TRANS_W, int EPI, int LDO>
 void launch_sb_ws(const SbArgs& a, hipStream_t s) {
   const int64_t tasks = (a.M + 31) / 32, bts = (tasks + 3) / 4;
@@ -384,6 +449,34 @@ int gymrl_linear_fwd_sb(const float* X, const float* W, const float* b, int64_t 
     if (act) launch_sb_ws<256, 2, false, EPI_TANH, 256>(a, s); else launch_sb_ws<256, 2, false, EPI_NONE, 256>(a, s);
   } else {
     if (act) launch_sb_ws<256, 2, false, EPI_TANH, 512>(a, s); else launch_sb_ws<256, 2, false, EPI_NONE, 512>(a, s);
+  }
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_split_planes(const float* X, int64_t n, void* planes, void* stream) {
+  if (!X || !planes || n < 0 || n % 4 || !al16(X) || !al16(planes)) return -22;
+  if (n == 0) return 0;
+  const int64_t n4 = n / 4, want = (n4 + 255) / 256;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const f32x4*>(X), n4, reinterpret_cast<u32x2*>(planes));
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_linear_fwd_sb_planes(const void* X_planes, const float* W, const float* b, int64_t B, int K, int N, int act, float* Y,
+                               void* stream) {
+  if (!X_planes || !W || !Y || B < 0 || K != 256 || (N != 256 && N != 512) || (act != 0 && act != 1) || !al16(X_planes) || !al16(W) ||
+      !al16(Y))
+    return -22;
+  if (B == 0) return 0;
+  SbArgs a{};
+  a.A = static_cast<const float*>(X_planes); a.M = B; a.W = W; a.ldw = K; a.out = Y; a.bias = b; a.slices = N / 64;
+  hipStream_t s = (hipStream_t)stream;
+  if (N == 256) {
+    if (act) launch_sb_ws_planes<EPI_TANH, 256>(a, s); else launch_sb_ws_planes<EPI_NONE, 256>(a, s);
+  } else {
+    if (act) launch_sb_ws_planes<EPI_TANH, 512>(a, s); else launch_sb_ws_planes<EPI_NONE, 512>(a, s);
   }
   GYMRL_CHECK_LAUNCH();
   return 0;

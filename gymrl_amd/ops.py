@@ -825,6 +825,22 @@ def linear_fwd_sb(x, W, b, out, act=True):
     return out
 
 
+def split_planes(x, out=None):
+    """gymrl_split_planes: the three bf16 planes [3, *x.shape] (as int16 storage) of a float32 tensor."""
+    out = torch.empty((3,) + tuple(x.shape), dtype=torch.int16, device=x.device) if out is None else out
+    check(lib().gymrl_split_planes(_ptr(x, torch.float32), C.c_int64(x.numel()), _ptr(out, torch.int16), _stream()), "gymrl_split_planes")
+    return out
+
+
+def linear_fwd_sb_planes(x_planes, W, b, out, act=True):
+    """gymrl_linear_fwd_sb_planes: linear_fwd_sb on activations already split into planes [3, B, 256]."""
+    _, B, K = x_planes.shape
+    check(lib().gymrl_linear_fwd_sb_planes(_ptr(x_planes, torch.int16), _ptr(W, torch.float32), _ptr(b, torch.float32, True),
+                                           C.c_int64(B), C.c_int(K), C.c_int(W.shape[0]), C.c_int(int(act)), _ptr(out, torch.float32),
+                                           _stream()), "gymrl_linear_fwd_sb_planes")
+    return out
+
+
 def linear_bwd_input_sb(dy, W, H, dx):
     """gymrl_linear_bwd_input_sb: linear_bwd_input's product on the bf16 matrix cores (opt-in)."""
     B, N = dy.shape

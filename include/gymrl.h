@@ -815,6 +815,13 @@ int gymrl_linear_bwd_weight_geometry(int64_t B, int N, int* slices, int64_t* row
  */
 int gymrl_linear_fwd_sb(const float* X, const float* W, const float* b, int64_t B, int K, int N, int act,
                         float* Y, void* stream);
+/* Round 4's bounded experiment on that mode: the activations split by their PRODUCER.  gymrl_split_planes writes the three bf16
+ * planes of an f32 array (P[plane][n], 6 bytes per element; in a pipeline the producing layer's epilogue would); the consumer
+ * gymrl_linear_fwd_sb_planes is gymrl_linear_fwd_sb reading them ([3][B][256] bf16) — MFMAs, LDS reads and loads only, the
+ * same products in the same order (bit-identical results).  Measured and not adopted: DESIGN.md section 4a. */
+int gymrl_split_planes(const float* X, int64_t n, void* planes, void* stream);
+int gymrl_linear_fwd_sb_planes(const void* X_planes, const float* W, const float* b, int64_t B, int K, int N, int act, float* Y,
+                               void* stream);
 int gymrl_linear_bwd_input_sb(const float* dY, const float* W, const float* H, int64_t B, int N, int K,
                               float* dX, void* stream);
 int gymrl_linear_bwd_weight(const float* dY, const float* X, int64_t B, int N, int K, float* dW,

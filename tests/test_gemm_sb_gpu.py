@@ -95,3 +95,24 @@ def test_split_is_exact_on_the_device(dev):
     eye = torch.eye(256, device=dev)
     y = ops.linear_fwd_sb(x, eye, None, torch.empty(B, 256, device=dev), act=False)
     assert torch.equal(y, x)
+
+
+@pytest.mark.parametrize("N,act", [(256, True), (512, False)])
+def test_split_bf16_forward_on_producer_planes_equals_consumer_split(dev, N, act):
+    """The producer-planes variant (gymrl_split_planes + gymrl_linear_fwd_sb_planes) runs the consumer-split kernel's products
+    in its order on the same bf16 pieces: bit-identical outputs, ragged last tile included, nothing written past it."""
+    from gymrl_amd import ops
+    gen = torch.Generator(device=dev).manual_seed(N + 1)
+    B, K = 8192 + 21, 256
+    W = torch.randn(N, K, device=dev, generator=gen) / 16
+    b = torch.randn(N, device=dev, generator=gen)
+    for name, x in _cases(B, K, dev, gen).items():
+        y_sb = ops.linear_fwd_sb(x, W, b, torch.empty(B, N, device=dev), act=act)
+        planes = ops.split_planes(x)
+        rebuilt = sum((planes[k].view(torch.bfloat16).float() for k in range(3)))
+        if name not in ("near_denormal",):                                 # (the third piece of a near-denormal may flush)
+            assert torch.equal(rebuilt, x), name                           # the three pieces ARE the float
+        y_pl = torch.full((B + 2, N), float("nan"), device=dev)
+        ops.linear_fwd_sb_planes(planes, W, b, y_pl[:B], act=act)
+        assert bool(torch.isnan(y_pl[B:]).all()), name
+        assert torch.equal(y_pl[:B], y_sb), name

@@ -45,6 +45,13 @@ def main():
         rows["exact"] = (timeit(lambda: ops.linear_fwd(x, W, b, y, act=False)), err(y, ref))
         rows["split_bf16"] = (timeit(lambda: ops.linear_fwd_sb(x, W, b, y2, act=False)), err(y2, ref))
         rows["library"] = (timeit(lambda: torch.addmm(b, x, W.t(), out=y)), err(y, ref))
+        # round 4: the activations split by their producer (three bf16 planes, 6 B per element in); the producer's share is
+        # what writing 1.5 x the bytes costs an HBM-bound layer kernel — measured here as the stand-alone split's time
+        planes = ops.split_planes(x)
+        y3 = torch.empty(B, N, device=dev)
+        rows["split_bf16_producer_planes"] = (timeit(lambda: ops.linear_fwd_sb_planes(planes, W, b, y3, act=False)), err(y3, ref))
+        rows["(stand-alone split of x into planes)"] = (timeit(lambda: ops.split_planes(x, planes)), 0.0)
+        del planes, y3
         del ref
         out[f"fwd 256->{N}"] = {k: dict(us=round(u, 1), TFLOPs=round(fl / u / 1e6, 1), err_vs_f64=float(f"{e:.3g}")) for k, (u, e) in rows.items()}
         dy = torch.randn(B, N, device=dev, generator=g)
