@@ -679,6 +679,21 @@ def report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev,
     for k in ("flops_per_launch_group", "bytes_per_launch_group", "share_of_step"):
         if k in head:
             roofline[k] = head[k]
+    if prof:
+        # the counters of the same binary's six GEMM launches: HBM bytes per launch group beside the algorithmic ones, and the
+        # clock the chip sustains under f32 MFMA (GRBM_GUI_ACTIVE / wall time; the 157.3 TFLOP/s peak assumes 2.4 GHz —
+        # MI355X_MICROARCH.md "DVFS give-back": a dense matrix body clocks to its power budget, not to the nameplate)
+        six = [prof[1][k] for k in ("gemm_fwd_256_tanh", "gemm_fwd_512", "gemm_dw_512", "gemm_dx_512_tanhbwd", "gemm_dw_256_db",
+                                    "gemm_dx_256_tanhbwd") if k in prof[1]]
+        if len(six) == 6:
+            roofline["traffic"] = float(sum(e["hbm_bytes_per_launch"] for e in six))
+            roofline["algorithmic_bytes_per_launch_group"] = float(sum(e["algorithmic_bytes_per_row"] for e in six) * prof[1]["rows"])
+            t_us = sum(e["duration_us_profiled"] for e in six)
+            clk = sum(e["effective_clock_GHz"] * e["duration_us_profiled"] for e in six) / t_us
+            roofline["clock"] = dict(effective_GHz_under_counters=round(clk, 3), nameplate_GHz=2.4,
+                                     peak_at_effective_clock=round(head["peak"] * clk / 2.4, 1),
+                                     frac_at_effective_clock=round(head["frac"] * 2.4 / clk, 4),
+                                     mfma_busy_share=round(sum(e["mfma_busy_share"] * e["duration_us_profiled"] for e in six) / t_us, 3))
 
     out = {
         "metric": "env-steps/sec at N envs/GPU (PPO LunarLander), 1/2/4/8 GPUs + %HBM roofline",

@@ -1,0 +1,40 @@
+#!/bin/bash
+# Runs on the GPU box (through tools/gpu.sh): the round-4 measurement set committed under profiles/.
+# usage: tools/profile_round4.sh <outdir under gpurun_out> [quick]
+set -u
+OUT=/root/repo/gpurun_out/$1
+mkdir -p "$OUT"
+cd /root/repo
+timeout 600 python bench.py > "$OUT/bench_final.json" 2> "$OUT/bench_final.err"
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_20steps.json" 2> /dev/null
+timeout 300 python bench.py --algo ppo_full --steps 3 --warmup 1 > "$OUT/bench_ppo_full.json" 2> /dev/null
+timeout 300 python bench.py --algo sac --steps 100 --warmup 20 > "$OUT/bench_sac.json" 2> /dev/null
+timeout 300 python bench.py --algo rainbow --steps 100 --warmup 20 > "$OUT/bench_rainbow.json" 2> /dev/null
+timeout 200 python tools/micro_per.py > "$OUT/micro_per.txt" 2> /dev/null
+timeout 200 python tools/micro_sub_bwd.py > "$OUT/micro_sub_bwd.txt" 2> /dev/null
+GYMRL_HIP_LIB=gymrl_amd/libgymrl_hip_prof.so timeout 200 python tools/micro_sub_bwd.py --phases >> "$OUT/micro_sub_bwd.txt" 2> /dev/null
+timeout 200 python tools/bench_cartpole_rollout.py "$OUT/cartpole_rollout.json" > /dev/null 2>&1
+timeout 200 python tools/probe_rollout_balance.py 2048 > "$OUT/rollout_balance.txt" 2> /dev/null
+cd /tmp && export TMPDIR=/tmp
+prof() {   # prof <name> <cmd...>: kernel stats CSV of a command
+  local name=$1; shift
+  rm -rf /tmp/p_$name
+  timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$name -- "$@" > "$OUT/${name}_under_rocprof.json" 2> /dev/null
+  cp "$(find /tmp/p_$name -name '*kernel_stats.csv' | head -1)" "$OUT/${name}_kernel_stats.csv"
+}
+prof bench python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline
+prof ppo_full python /root/repo/bench.py --algo ppo_full --rollout 256 --steps 1 --warmup 1
+prof rainbow python /root/repo/bench.py --algo rainbow --steps 10 --warmup 2
+prof sac python /root/repo/bench.py --algo sac --steps 10 --warmup 2
+export GYMRL_PMC_PROVENANCE="$OUT/pmc_provenance.json"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/p_$c
+  timeout -k 5 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/p_$c -- python /root/repo/tools/pmc_gemm.py > /dev/null 2>&1
+  cp "$(find /tmp/p_$c -name '*counter_collection.csv' | head -1)" "$OUT/pmc_${c}_counter_collection.csv"
+done
+rm -rf /tmp/p_sq
+timeout -k 5 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d /tmp/p_sq -- python /root/repo/tools/pmc_gemm.py > /dev/null 2>&1
+cp "$(find /tmp/p_sq -name '*counter_collection.csv' | head -1)" "$OUT/pmc_gemm_sq.csv"
+cp "$(find /tmp/p_sq -name '*kernel_trace.csv' | head -1)" "$OUT/pmc_gemm_sq_trace.csv"
+ls -la "$OUT"
+tail -c 300 "$OUT/bench_final.json"
