@@ -372,7 +372,8 @@ def main():
     ap.add_argument("--algo", choices=("ppo", "ppo_full", "rainbow", "sac"), default="ppo",
                     help="ppo = the headline benchmark (BASELINE configs[1]); ppo_full = configs[4]'s per-GPU workload; "
                          "rainbow / sac = configs[2] / configs[3] (a step = 16 vector steps with one update each)")
-    ap.add_argument("--micro-batch", type=int, default=262144, help="ppo_full: rows per forward/backward pass")
+    ap.add_argument("--micro-batch", type=int, default=524288,
+                    help="ppo_full: rows per forward/backward pass (524288: each launch's fixed cost — weight staging, partial sums — halves against 262144; larger is flat)")
     ap.add_argument("--timer-every", type=int, default=8,
                     help="ppo: HIP-event brackets around the launches of every K-th minibatch of the timed region (1: all; "
                          "the gather of the next minibatch is issued inside the previous one's bracket window either way)")
