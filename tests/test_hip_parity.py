@@ -650,3 +650,17 @@ def test_permutation_bit_exact_vs_oracle(dev, oracle):
     assert torch.equal(torch.sort(big.long()).values, torch.arange(1 << 23, device=dev))
     buf = torch.empty(1 << 23, dtype=torch.int32, device=dev)
     assert ops.permutation(3, (1 << 40) + 1, 1 << 23, dev, out=buf) is buf and not torch.equal(buf, big)
+
+
+@pytest.mark.parametrize("B,D", [(1, 8), (1000, 8), (70000, 4), (513, 12)])
+def test_gather_rows_is_index_select(dev, B, D):
+    """gymrl_gather_rows copies whole rows by index: bytes equal to torch's index_select (signed zeros, NaN payloads included)."""
+    from gymrl_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(B + D)
+    src = torch.randn(5000, D, generator=g)
+    src[3, 0], src[4, 1] = -0.0, float("nan")
+    idx = torch.randint(0, 5000, (B,), generator=g).to(torch.int32)
+    src_d, idx_d = src.to(dev), idx.to(dev)
+    out = ops.gather_rows(src_d, idx_d)
+    ref = src_d.index_select(0, idx_d.long())
+    assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
