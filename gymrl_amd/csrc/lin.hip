@@ -471,6 +471,115 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lin_bwd_weight_big_kernel
   }
 }
 
+// N and K multiples of 128: the four 64 x 64 blocks of a 128 x 128 block of dW are ONE workgroup's four waves and read the
+// same rows — as four independent streams (above) every operand row crosses the CU's memory pipe twice, 2 KB per row at
+// N = K = 128, and the pipe is the bound (122 us against 57 of f32 MFMA at 262144 rows).  Here the workgroup loads each
+// 16-row batch of dY and X ONCE, coalesced (a thread's four float4), into a double-buffered LDS stage and the waves read
+// their operands from there (rows padded to 132 floats: the four row groups of a wave's 16-byte reads start 16 bytes
+// apart); one barrier per batch, the next batch's global loads in flight under the current batch's 64 MFMAs per wave.
+// Every wave issues the MFMAs of the kernel above on the same values in the same order: the same bits.
+constexpr int kStagePitch = 132;
+__global__ __launch_bounds__(256) void lin_bwd_weight_big_lds_kernel(const LinBwdW a) {
+  __shared__ __attribute__((aligned(16))) float stage[2][2][16 * kStagePitch];   // [buffer][dY | X][16 rows][128 + pad]
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4, wave = tid >> 6;
+  const int item = blockIdx.y, slice = blockIdx.z;
+  const int kb128 = a.K >> 7;
+  const int nb = blockIdx.x / kb128, kb = blockIdx.x - nb * kb128;
+  const int ng = 2 * nb + (wave >> 1), kg = 2 * kb + (wave & 1);        // this wave's 64 x 64 block
+  const int n0 = ng * 64, k0 = kg * 64;
+  const int b_lo = slice * a.rows_per_slice;
+  const int b_hi = min(a.B, b_lo + a.rows_per_slice);
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[i][t] = zero;
+  f32x4 colsum = zero;
+  // the workgroup's loads of a batch: float4 number j * 256 + tid of the [16 rows][32 float4] tile of each matrix
+  const float* __restrict__ dYg = a.dY[item] + 128 * nb;
+  const float* __restrict__ Xg = a.X[item] + 128 * kb;
+  f32x4 ld[2][2];
+  auto fetch = [&](int bc0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int f4 = j * 256 + tid, row = f4 >> 5, c4 = f4 & 31;
+      const int bb = bc0 + row;
+      const size_t bs = (size_t)(bb < b_hi ? bb : b_lo);
+      ld[0][j] = *reinterpret_cast<const f32x4*>(dYg + bs * a.ldy + 4 * c4);
+      ld[1][j] = *reinterpret_cast<const f32x4*>(Xg + bs * a.ldx + 4 * c4);
+    }
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int f4 = j * 256 + tid, row = f4 >> 5, c4 = f4 & 31;
+      *reinterpret_cast<f32x4*>(&stage[buf][0][row * kStagePitch + 4 * c4]) = ld[0][j];
+      *reinterpret_cast<f32x4*>(&stage[buf][1][row * kStagePitch + 4 * c4]) = ld[1][j];
+    }
+  };
+  if (b_lo < b_hi) {
+    fetch(b_lo);
+    park(0);
+    __syncthreads();
+    int buf = 0;
+    for (int bc0 = b_lo; bc0 < b_hi; bc0 += 4 * kBigSteps, buf ^= 1) {
+      const bool more = bc0 + 4 * kBigSteps < b_hi;
+      if (more) fetch(bc0 + 4 * kBigSteps);
+      const float* sy = &stage[buf][0][64 * (wave >> 1) + 4 * r];
+      const float* sx = &stage[buf][1][64 * (wave & 1) + 4 * r];
+#pragma unroll
+      for (int s2 = 0; s2 < kBigSteps; ++s2) {
+        const int row = 4 * s2 + q;
+        const f32x4 dy = *reinterpret_cast<const f32x4*>(sy + row * kStagePitch);
+        const f32x4 x = *reinterpret_cast<const f32x4*>(sx + row * kStagePitch);
+        const f32x4 dz = bc0 + row < b_hi ? dy : zero;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          colsum[i] += dz[i];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(dz[i], x[t], acc[i][t]);
+        }
+      }
+      if (more) park(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  // bias gradient: the four row groups' serial sums, added pairwise (q0 + q1) + (q2 + q3)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    colsum[i] += __shfl_xor(colsum[i], 16, 64);
+    colsum[i] += __shfl_xor(colsum[i], 32, 64);
+  }
+  const size_t wk = (size_t)a.N * a.K;
+  float* __restrict__ dW = a.dW[item];
+  float* __restrict__ db = a.db[item];
+  float* part = a.slices > 1 ? a.partial + ((size_t)item * a.slices + slice) * (wk + a.N) : nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const size_t o = (size_t)(n0 + 4 * (4 * q + g) + i) * a.K + k0 + 4 * r;
+      f32x4 v = {acc[i][0][g], acc[i][1][g], acc[i][2][g], acc[i][3][g]};
+      if (part) *reinterpret_cast<f32x4*>(part + o) = v;
+      else {
+        if (a.accumulate) {
+          const f32x4 old = *reinterpret_cast<const f32x4*>(dW + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += old[e];
+        }
+        *reinterpret_cast<f32x4*>(dW + o) = v;
+      }
+    }
+  if (kg == 0 && q == 0) {
+    if (part) *reinterpret_cast<f32x4*>(part + wk + n0 + 4 * r) = colsum;
+    else if (db) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) db[n0 + 4 * r + e] = a.accumulate ? db[n0 + 4 * r + e] + colsum[e] : colsum[e];
+    }
+  }
+}
+
 // dW / db = the slices' partials added in a fixed order: eight groups of consecutive slices, each ascending, then the groups ascending
 __global__ __launch_bounds__(256) void lin_slice_reduce_kernel(const LinBwdW a) {
   __shared__ float grp[8][32];
@@ -750,7 +859,10 @@ int gymrl_lin_bwd_weight(const gymrl_lin_item* items, int n_items, int B, int N,
     big = big && items[i].act == GYMRL_ACT_NONE && aligned16(items[i].dy) && aligned16(items[i].x) && aligned16(items[i].dw);
   if (big) {
     const dim3 grid(cdiv((N / 64) * (K / 64), kWavesPerBlock), n_items, a.slices), block(64 * kWavesPerBlock);
-    hipLaunchKernelGGL(lin_bwd_weight_big_kernel, grid, block, 0, s, a);
+    if (N % 128 == 0 && K % 128 == 0)
+      hipLaunchKernelGGL(lin_bwd_weight_big_lds_kernel, dim3((N / 128) * (K / 128), n_items, a.slices), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL(lin_bwd_weight_big_kernel, grid, block, 0, s, a);
     if (a.slices > 1) {
       const size_t per = (size_t)N * K + N;
       hipLaunchKernelGGL(lin_slice_reduce_kernel, dim3((unsigned)((per + 31) / 32), n_items), dim3(256), 0, s, a);
