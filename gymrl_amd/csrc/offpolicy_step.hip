@@ -30,7 +30,7 @@ constexpr int kWaves = 16, kThreads = 64 * kWaves;
 
 // Probe build only (make prof): 100 MHz wall-clock stamps at the stage boundaries of workgroup 0 (tools/probe_sac_stages.py)
 #ifdef GYMRL_PROF_BUILD
-__device__ long long g_step_prof[3][32];
+__device__ long long g_step_prof[4][32];
 #define STEP_MARK(k, i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_step_prof[k][i] = (long long)wall_clock64(); } while (0)
 #else
 #define STEP_MARK(k, i) do {} while (0)
@@ -45,6 +45,8 @@ struct SacWs {
   float *H1[2], *Z1[2], *H2[2], *Z2[2], *dq[2];      // critic net i: activations and dL/dz per layer
   float *aH1, *aZ1, *aH2, *aZ2, *dmean, *dls;        // actor
   double* terms;                      // [B][3]: per-row critic term, actor term, temperature term
+  float* y;                           // [16 ceil(B / 16)]: the Bellman target, from P1's target-chain workgroup to its critic-chain workgroup
+  unsigned int* flag;                 // [ceil(B / 16)]: 1 while a slab's y waits to be consumed (zero before the first launch, left zero)
   __host__ __device__ static size_t carve(SacWs* w, void* base, int B, int D, int A, int H) {
     size_t off = 0;
     auto take = [&](size_t n) { float* p = base ? reinterpret_cast<float*>(static_cast<char*>(base) + off) : nullptr; off += ((n * 4 + 255) & ~(size_t)255); return p; };
@@ -53,7 +55,10 @@ struct SacWs {
     for (int i = 0; i < 12; ++i) h[i] = take((size_t)B * H);
     float* dq0 = take(B); float* dq1 = take(B); float* dm = take((size_t)B * A); float* dl = take((size_t)B * A);
     double* terms = reinterpret_cast<double*>(take((size_t)B * 6));
+    float* yv = take((size_t)(B + 15) / 16 * 16);
+    unsigned int* fl = reinterpret_cast<unsigned int*>(take((size_t)(B + 15) / 16));
     if (w) {
+      w->y = yv; w->flag = fl;
       w->s = s; w->a = a;
       w->H1[0] = h[0]; w->H1[1] = h[1]; w->Z1[0] = h[2]; w->Z1[1] = h[3]; w->H2[0] = h[4]; w->H2[1] = h[5]; w->Z2[0] = h[6]; w->Z2[1] = h[7];
       w->aH1 = h[8]; w->aZ1 = h[9]; w->aH2 = h[10]; w->aZ2 = h[11];
@@ -192,6 +197,12 @@ struct Lds {                          // float offsets of the small per-row slab
 constexpr int kSmallFloats = 16 * (2 * kMaxD + 5 * kMaxA + 7 * 4);
 
 // ======================================================================================================== P1 =====
+// Two workgroups per 16-row slab (blockIdx.y): the target chain — actor(s'), both target critics, y (:233-237) — and the
+// critic chain — Q(s, a) of both networks, the loss gradient, the input-gradient chain (:239-241) — are independent until y
+// meets the loss, and ONE compute unit's f32 MFMA rate is what a slab's stage costs (3 + 3 wide items on one CU: 30 us of
+// the kernel's 64).  The target workgroup publishes y with a release flag, the critic workgroup — which needs 22 us for its
+// forward anyway — spins on it with agent-scope loads, consumes y and clears the flag.  Both workgroups of every slab are
+// resident (2 * B / 16 <= 32 of 256 CUs), the producer waits for nobody: no deadlock.  Same layers, same order per element.
 __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update_args a, const SacWs ws) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const Lds L;
@@ -200,8 +211,11 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
   const int T2a = H2b + 16 * ld, T2b = T2a + 16 * ld;
   const int row0 = blockIdx.x * 16, nrows = min(16, a.B - row0);
   const int t = threadIdx.x;
-  STEP_MARK(0, 0);
-  // ---- 0: index draw + ring gather (one thread per row; rows beyond the batch are zero) ----
+  const bool target_chain = blockIdx.y == 0;
+  const int R = GYMRL_ACT_RELU, NA = GYMRL_ACT_NONE, kD = kMaxD, kA = kMaxA;
+  const Images im(a.images, H);
+  // ---- 0: index draw + ring gather (one thread per row; rows beyond the batch are zero); each workgroup takes what its chain reads ----
+  if (target_chain) STEP_MARK(3, 0); else STEP_MARK(0, 0);
   if (t < 16) {
     const int b = row0 + t;
     const bool ok = t < nrows;
@@ -216,87 +230,124 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
         row = keyed_permute((uint32_t)b, size, bits / 2, bits - bits / 2, a.idx_seed ^ 0x5265706C61794944ull, counter);
       }
     }
-    for (int k = 0; k < kMaxD; ++k) {
-      const float s = (ok && k < D) ? a.r_state[row * D + k] : 0.0f, s2 = (ok && k < D) ? a.r_next[row * D + k] : 0.0f;
-      lds[L.S + t * kMaxD + k] = s; lds[L.S2 + t * kMaxD + k] = s2;
-      if (ok && k < D) ws.s[(size_t)b * D + k] = s;
+    if (target_chain) {
+      for (int k = 0; k < kMaxD; ++k) lds[L.S2 + t * kMaxD + k] = (ok && k < D) ? a.r_next[row * D + k] : 0.0f;
+      const uint64_t ncounter = a.noise_counter_dev ? a.noise_counter_dev[0] : a.noise_counter;
+      for (int j = 0; j < kMaxA; ++j) {
+        float e = 0.0f;
+        if (ok && j < A) e = a.eps_next ? a.eps_next[(size_t)b * A + j] : fused_normal(a.noise_seed, ncounter, 3u, (uint32_t)(b * A + j));
+        lds[L.Eps + t * kMaxA + j] = e;
+      }
+      lds[L.Misc + t * 4 + 0] = ok ? a.r_reward[row] : 0.0f;
+      lds[L.Misc + t * 4 + 1] = ok ? (float)a.r_flag[row] : 0.0f;          // dones become float32 (dqn_cartpole.py:155)
+    } else {
+      for (int k = 0; k < kMaxD; ++k) {
+        const float sv = (ok && k < D) ? a.r_state[row * D + k] : 0.0f;
+        lds[L.S + t * kMaxD + k] = sv;
+        if (ok && k < D) ws.s[(size_t)b * D + k] = sv;
+      }
+      for (int j = 0; j < kMaxA; ++j) {
+        const float av = (ok && j < A) ? __uint_as_float(a.r_action[row * A + j]) : 0.0f;
+        lds[L.A + t * kMaxA + j] = av;
+        if (ok && j < A) ws.a[(size_t)b * A + j] = av;
+      }
     }
-    uint64_t ncounter = a.noise_counter_dev ? a.noise_counter_dev[0] : a.noise_counter;
-    for (int j = 0; j < kMaxA; ++j) {
-      const float av = (ok && j < A) ? __uint_as_float(a.r_action[row * A + j]) : 0.0f;
-      lds[L.A + t * kMaxA + j] = av;
-      if (ok && j < A) ws.a[(size_t)b * A + j] = av;
-      float e = 0.0f;
-      if (ok && j < A) e = a.eps_next ? a.eps_next[(size_t)b * A + j] : fused_normal(a.noise_seed, ncounter, 3u, (uint32_t)(b * A + j));
-      lds[L.Eps + t * kMaxA + j] = e;
-    }
-    lds[L.Misc + t * 4 + 0] = ok ? a.r_reward[row] : 0.0f;
-    lds[L.Misc + t * 4 + 1] = ok ? (float)a.r_flag[row] : 0.0f;          // dones become float32 (dqn_cartpole.py:155)
   }
   __syncthreads();
+  if (target_chain) {
+    STEP_MARK(3, 1);
+    // ---- the actor on s' (:233) ----
+    {
+      const FwdItem st[1] = {fwd_item(L.S2, kD, -1, 0, D, D, H, a.actor.w[0], a.actor.b[0], X0, ld, nullptr, 0, R)};
+      fwd_stage<1>(lds, st, row0, nrows);
+    }
+    __syncthreads();
+    STEP_MARK(3, 2);
+    {
+      const FwdItem st[1] = {fwd_item(X0, ld, -1, 0, H, H, H, a.actor.w[1], a.actor.b[1], X1, ld, nullptr, 0, R, 0.0f, 0.0f, im.af)};
+      fwd_stage<1>(lds, st, row0, nrows);
+    }
+    __syncthreads();
+    STEP_MARK(3, 3);
+    {
+      const FwdItem st[2] = {fwd_item(X1, ld, -1, 0, H, H, A, a.actor.w[2], a.actor.b[2], L.Mean, kA, nullptr, 0, NA),
+                             fwd_item(X1, ld, -1, 0, H, H, A, a.actor.w[3], a.actor.b[3], L.Ls, kA, nullptr, 0, GYMRL_ACT_CLAMP, a.log_std_min, a.log_std_max)};
+      fwd_stage<2>(lds, st, row0, nrows);
+    }
+    __syncthreads();
+    STEP_MARK(3, 4);
+    if (t < 16) {                         // a', logp' (:234)
+      float lp;
+      sample_row(lds + L.Mean + t * kMaxA, lds + L.Ls + t * kMaxA, lds + L.Eps + t * kMaxA, A, a.bound, lds + L.A2 + t * kMaxA, lp);
+      lds[L.Misc + t * 4 + 2] = lp;
+    }
+    __syncthreads();
+    STEP_MARK(3, 5);
+    // ---- target Q(s', a') of both networks (:235-236) ----
+    {
+      const FwdItem st[2] = {fwd_item(L.S2, kD, L.A2, kA, D + A, D, H, a.target.w[0], a.target.b[0], X0, ld, nullptr, 0, R),
+                             fwd_item(L.S2, kD, L.A2, kA, D + A, D, H, a.target.w[3], a.target.b[3], X1, ld, nullptr, 0, R)};
+      fwd_stage<2>(lds, st, row0, nrows);
+    }
+    __syncthreads();
+    STEP_MARK(3, 6);
+    {
+      const FwdItem st[2] = {fwd_item(X0, ld, -1, 0, H, H, H, a.target.w[1], a.target.b[1], T2a, ld, nullptr, 0, R, 0.0f, 0.0f, im.t1f),
+                             fwd_item(X1, ld, -1, 0, H, H, H, a.target.w[4], a.target.b[4], T2b, ld, nullptr, 0, R, 0.0f, 0.0f, im.t2f)};
+      fwd_stage<2>(lds, st, row0, nrows);
+    }
+    __syncthreads();
+    STEP_MARK(3, 7);
+    {
+      const FwdItem st[2] = {fwd_item(T2a, ld, -1, 0, H, H, 1, a.target.w[2], a.target.b[2], L.Q0, 4, nullptr, 0, NA),
+                             fwd_item(T2b, ld, -1, 0, H, H, 1, a.target.w[5], a.target.b[5], L.Q1, 4, nullptr, 0, NA)};
+      fwd_stage<2>(lds, st, row0, nrows);
+    }
+    __syncthreads();
+    STEP_MARK(3, 8);
+    if (t < 16) {                         // y (:237; offpolicy.hip sac_target_kernel)
+      const float alpha = (float)exp(a.log_alpha[0]);
+      const float tq = fminf(lds[L.Q0 + t * 4], lds[L.Q1 + t * 4]) - alpha * lds[L.Misc + t * 4 + 2];
+      const float y = lds[L.Misc + t * 4 + 0] + a.gamma * (1.0f - lds[L.Misc + t * 4 + 1]) * tq;
+      __hip_atomic_store(ws.y + row0 + t, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (16 slots per slab: y is padded to whole slabs)
+    }
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(ws.flag + blockIdx.x, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    STEP_MARK(3, 9);
+    return;
+  }
   STEP_MARK(0, 1);
-  const int R = GYMRL_ACT_RELU, NA = GYMRL_ACT_NONE, kD = kMaxD, kA = kMaxA;
-  const Images im(a.images, H);
-  // ---- 1-3: the actor on s' (:233), and — independent of it — Q(s, a) of both networks (:239) in the same stages ----
+  // ---- Q(s, a) of both networks (:239) ----
   {
-    const FwdItem st[3] = {fwd_item(L.S2, kD, -1, 0, D, D, H, a.actor.w[0], a.actor.b[0], X0, ld, nullptr, 0, R),
-                           fwd_item(L.S, kD, L.A, kA, D + A, D, H, a.critic.w[0], a.critic.b[0], H1a, ld, ws.H1[0], H, R),
+    const FwdItem st[2] = {fwd_item(L.S, kD, L.A, kA, D + A, D, H, a.critic.w[0], a.critic.b[0], H1a, ld, ws.H1[0], H, R),
                            fwd_item(L.S, kD, L.A, kA, D + A, D, H, a.critic.w[3], a.critic.b[3], H1b, ld, ws.H1[1], H, R)};
-    fwd_stage<3>(lds, st, row0, nrows);
+    fwd_stage<2>(lds, st, row0, nrows);
   }
   __syncthreads();
   STEP_MARK(0, 2);
   {
-    const FwdItem st[3] = {fwd_item(X0, ld, -1, 0, H, H, H, a.actor.w[1], a.actor.b[1], X1, ld, nullptr, 0, R, 0.0f, 0.0f, im.af),
-                           fwd_item(H1a, ld, -1, 0, H, H, H, a.critic.w[1], a.critic.b[1], H2a, ld, ws.H2[0], H, R, 0.0f, 0.0f, im.c1f),
+    const FwdItem st[2] = {fwd_item(H1a, ld, -1, 0, H, H, H, a.critic.w[1], a.critic.b[1], H2a, ld, ws.H2[0], H, R, 0.0f, 0.0f, im.c1f),
                            fwd_item(H1b, ld, -1, 0, H, H, H, a.critic.w[4], a.critic.b[4], H2b, ld, ws.H2[1], H, R, 0.0f, 0.0f, im.c2f)};
-    fwd_stage<3>(lds, st, row0, nrows);
+    fwd_stage<2>(lds, st, row0, nrows);
   }
   __syncthreads();
   STEP_MARK(0, 3);
   {
-    const FwdItem st[4] = {fwd_item(X1, ld, -1, 0, H, H, A, a.actor.w[2], a.actor.b[2], L.Mean, kA, nullptr, 0, NA),
-                           fwd_item(X1, ld, -1, 0, H, H, A, a.actor.w[3], a.actor.b[3], L.Ls, kA, nullptr, 0, GYMRL_ACT_CLAMP, a.log_std_min, a.log_std_max),
-                           fwd_item(H2a, ld, -1, 0, H, H, 1, a.critic.w[2], a.critic.b[2], L.Cq0, 4, nullptr, 0, NA),
+    const FwdItem st[2] = {fwd_item(H2a, ld, -1, 0, H, H, 1, a.critic.w[2], a.critic.b[2], L.Cq0, 4, nullptr, 0, NA),
                            fwd_item(H2b, ld, -1, 0, H, H, 1, a.critic.w[5], a.critic.b[5], L.Cq1, 4, nullptr, 0, NA)};
-    fwd_stage<4>(lds, st, row0, nrows);
+    fwd_stage<2>(lds, st, row0, nrows);
   }
   __syncthreads();
   STEP_MARK(0, 4);
-  if (t < 16) {                         // a', logp' (:234)
-    float lp;
-    sample_row(lds + L.Mean + t * kMaxA, lds + L.Ls + t * kMaxA, lds + L.Eps + t * kMaxA, A, a.bound, lds + L.A2 + t * kMaxA, lp);
-    lds[L.Misc + t * 4 + 2] = lp;
+  // ---- y from the slab's target-chain workgroup ----
+  if (t == 0) {
+    while (__hip_atomic_load(ws.flag + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1u) __builtin_amdgcn_s_sleep(2);
   }
   __syncthreads();
   STEP_MARK(0, 5);
-  // ---- 4-6: target Q(s', a') of both networks (:235-236) ----
-  {
-    const FwdItem st[2] = {fwd_item(L.S2, kD, L.A2, kA, D + A, D, H, a.target.w[0], a.target.b[0], X0, ld, nullptr, 0, R),
-                           fwd_item(L.S2, kD, L.A2, kA, D + A, D, H, a.target.w[3], a.target.b[3], X1, ld, nullptr, 0, R)};
-    fwd_stage<2>(lds, st, row0, nrows);
-  }
-  __syncthreads();
-  STEP_MARK(0, 6);
-  {
-    const FwdItem st[2] = {fwd_item(X0, ld, -1, 0, H, H, H, a.target.w[1], a.target.b[1], T2a, ld, nullptr, 0, R, 0.0f, 0.0f, im.t1f),
-                           fwd_item(X1, ld, -1, 0, H, H, H, a.target.w[4], a.target.b[4], T2b, ld, nullptr, 0, R, 0.0f, 0.0f, im.t2f)};
-    fwd_stage<2>(lds, st, row0, nrows);
-  }
-  __syncthreads();
-  STEP_MARK(0, 7);
-  {
-    const FwdItem st[2] = {fwd_item(T2a, ld, -1, 0, H, H, 1, a.target.w[2], a.target.b[2], L.Q0, 4, nullptr, 0, NA),
-                           fwd_item(T2b, ld, -1, 0, H, H, 1, a.target.w[5], a.target.b[5], L.Q1, 4, nullptr, 0, NA)};
-    fwd_stage<2>(lds, st, row0, nrows);
-  }
-  __syncthreads();
-  STEP_MARK(0, 8);
   if (t < 16) {
-    // y (:237; offpolicy.hip sac_target_kernel), then the critic loss gradient (:240-241; sac_critic_kernel)
-    const float alpha = (float)exp(a.log_alpha[0]);
-    const float tq = fminf(lds[L.Q0 + t * 4], lds[L.Q1 + t * 4]) - alpha * lds[L.Misc + t * 4 + 2];
-    const float y = lds[L.Misc + t * 4 + 0] + a.gamma * (1.0f - lds[L.Misc + t * 4 + 1]) * tq;
+    // the critic loss gradient (:240-241; sac_critic_kernel)
+    const float y = __hip_atomic_load(ws.y + row0 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float invB = 1.0f / (float)a.B;
     const float e1 = lds[L.Cq0 + t * 4] - y, e2 = lds[L.Cq1 + t * 4] - y;
     const float d1 = 2.0f * e1 * invB, d2 = 2.0f * e2 * invB;
@@ -307,21 +358,22 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
     }
   }
   __syncthreads();
-  STEP_MARK(0, 9);
-  // ---- 7-8: input-gradient chain of both Q networks (what q.backward() computes before the weight gradients) ----
+  if (t == 0) __hip_atomic_store(ws.flag + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: ready for the next launch
+  STEP_MARK(0, 6);
+  // ---- input-gradient chain of both Q networks (what q.backward() computes before the weight gradients) ----
   {
     const BwdItem st[2] = {BwdItem{L.Dq0, 4, 1, a.critic.w[2], H, -1, nullptr, H2a, ld, R, X0, ld, ws.Z2[0], H, nullptr},
                            BwdItem{L.Dq1, 4, 1, a.critic.w[5], H, -1, nullptr, H2b, ld, R, X1, ld, ws.Z2[1], H, nullptr}};
     bwd_stage<2>(lds, st, row0, nrows);
   }
   __syncthreads();
-  STEP_MARK(0, 10);
+  STEP_MARK(0, 7);
   {
     const BwdItem st[2] = {BwdItem{X0, ld, H, a.critic.w[1], H, -1, nullptr, H1a, ld, R, -1, 0, ws.Z1[0], H, im.c1b},
                            BwdItem{X1, ld, H, a.critic.w[4], H, -1, nullptr, H1b, ld, R, -1, 0, ws.Z1[1], H, im.c2b}};
     bwd_stage<2>(lds, st, row0, nrows);
   }
-  STEP_MARK(0, 11);
+  STEP_MARK(0, 8);
 }
 
 // ======================================================================================================== P3 =====
@@ -945,8 +997,8 @@ size_t gymrl_sac_update_workspace_bytes(int B, int D, int A, int H) {
 }
 
 #ifdef GYMRL_PROF_BUILD
-int gymrl_step_prof_read(long long* out_host) {      // probe build only: [3][32] stamps of the last launches (workgroup 0)
-  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_step_prof), sizeof(long long) * 96) == hipSuccess ? 0 : -1;
+int gymrl_step_prof_read(long long* out_host) {      // probe build only: [4][32] stamps of the last launches (workgroup 0)
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_step_prof), sizeof(long long) * 128) == hipSuccess ? 0 : -1;
 }
 #endif
 
@@ -1079,7 +1131,7 @@ int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream_) {
   const int B = a.B, D = a.D, A = a.A, H = a.H, slabs = (B + 15) / 16;
   auto tiles = [](int N, int K) { return ((N + 15) / 16) * ((K + 15) / 16); };
 
-  hipLaunchKernelGGL(sac_p1_kernel, dim3(slabs), dim3(kThreads), lds_bytes(H, 8), stream, a, ws);
+  hipLaunchKernelGGL(sac_p1_kernel, dim3(slabs, 2), dim3(kThreads), lds_bytes(H, 8), stream, a, ws);   // y: the target chain, then the critic chain
 
   DwArgs c{};
   int w0 = 0, ns = 0;

@@ -1105,7 +1105,8 @@ typedef struct {
   double alpha_bias[2]; const double* alpha_bias_dev;             /* {1 - 0.9^t, 1 - 0.999^t} (gymrl_sac_alpha_step) */
   double* sums;                            /* f64[3] out: critic loss sum, actor loss sum, sum of (logp + target_entropy) */
   double* alpha_loss;                      /* f64[1] out or NULL */
-  void* workspace;                         /* >= gymrl_sac_update_workspace_bytes(B, D, A, H) */
+  void* workspace;                         /* >= gymrl_sac_update_workspace_bytes(B, D, A, H); ZEROED once before the first call (the
+                                            * hand-off flags between the row phase's paired workgroups live in it and are left zero) */
   /* Weight images of the H x H layers (H % 16 == 0), f32[8][H*H], or NULL (every layer read in place).  The MFMA operands of
    * actor.fc2, critic.fc2 / fc5, target.fc2 / fc5 (forward) and actor.fc2, critic.fc2 / fc5 (input gradient) as contiguous
    * 1 KiB blocks per wave-wide load (csrc/lin_device.hpp): a slab kernel streams a whole weight matrix through one compute

@@ -17,12 +17,13 @@ tr = SACTrainer(cfg)
 tr.train(max_vector_steps=24)
 torch.cuda.synchronize()
 L = _lib.lib()
-out = (C.c_longlong * 96)()
+out = (C.c_longlong * 128)()
 assert L.gymrl_step_prof_read(out) == 0
-names = ("P1 rows (draw+gather | fc1 x3 | fc2 x3 | heads+q | sample | tgt fc1 | tgt fc2 | tgt fc3 | y+loss | bwd3 | bwd2)",
+names = ("P1 critic chain (draw+gather | fc1 x2 | fc2 x2 | q heads | wait for y | loss | bwd3 | bwd2)",
          "P3 rows (load | a.fc1 | a.fc2 | heads | sample | c.fc1 | c.fc2 | c.fc3 | loss | bwd3 | bwd2 | d action | sample bwd | heads bwd | fc2 bwd)",
-         "acting (load | fc1 | fc2 | heads | sample+env+row)")
-for k in range(3):
+         "acting (load | fc1 | fc2 | heads | sample+env+row)",
+         "P1 target chain (draw+gather | a.fc1 | a.fc2 | heads | sample | tgt fc1 x2 | tgt fc2 x2 | tgt fc3 x2 | y)")
+for k in range(4):
     st = [out[k * 32 + i] for i in range(32)]
     n = max(i for i, v in enumerate(st) if v) + 1
     d = [st[i + 1] - st[i] for i in range(n - 1)]
