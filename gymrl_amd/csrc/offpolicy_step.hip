@@ -46,7 +46,9 @@ struct SacWs {
   float *aH1, *aZ1, *aH2, *aZ2, *dmean, *dls;        // actor
   double* terms;                      // [B][3]: per-row critic term, actor term, temperature term
   float* y;                           // [16 ceil(B / 16)]: the Bellman target, from P1's target-chain workgroup to its critic-chain workgroup
-  unsigned int* flag;                 // [ceil(B / 16)]: 1 while a slab's y waits to be consumed (zero before the first launch, left zero)
+  unsigned int* flag;                 // [5][ceil(B / 16)]: hand-off flags (1 = waiting to be consumed; zero before the first launch, left zero):
+                                      //   0 P1's y;  P3: 1 the sampled action, 2 / 3 Q1 / Q2, 4 the second network's dZ1 slab
+  float *xa, *xq[2], *xz;             // P3's exchanges: action [16 S][kMaxA], the two Q columns [16 S], dZ1 of network 2 [16 S][H]
   __host__ __device__ static size_t carve(SacWs* w, void* base, int B, int D, int A, int H) {
     size_t off = 0;
     auto take = [&](size_t n) { float* p = base ? reinterpret_cast<float*>(static_cast<char*>(base) + off) : nullptr; off += ((n * 4 + 255) & ~(size_t)255); return p; };
@@ -55,10 +57,12 @@ struct SacWs {
     for (int i = 0; i < 12; ++i) h[i] = take((size_t)B * H);
     float* dq0 = take(B); float* dq1 = take(B); float* dm = take((size_t)B * A); float* dl = take((size_t)B * A);
     double* terms = reinterpret_cast<double*>(take((size_t)B * 6));
-    float* yv = take((size_t)(B + 15) / 16 * 16);
-    unsigned int* fl = reinterpret_cast<unsigned int*>(take((size_t)(B + 15) / 16));
+    const size_t S16 = (size_t)(B + 15) / 16 * 16;
+    float* yv = take(S16);
+    unsigned int* fl = reinterpret_cast<unsigned int*>(take(5 * S16 / 16));
+    float* xa = take(S16 * 4); float* xq0 = take(S16); float* xq1 = take(S16); float* xz = take(S16 * H);
     if (w) {
-      w->y = yv; w->flag = fl;
+      w->y = yv; w->flag = fl; w->xa = xa; w->xq[0] = xq0; w->xq[1] = xq1; w->xz = xz;
       w->s = s; w->a = a;
       w->H1[0] = h[0]; w->H1[1] = h[1]; w->Z1[0] = h[2]; w->Z1[1] = h[3]; w->H2[0] = h[4]; w->H2[1] = h[5]; w->Z2[0] = h[6]; w->Z2[1] = h[7];
       w->aH1 = h[8]; w->aZ1 = h[9]; w->aH2 = h[10]; w->aZ2 = h[11];
@@ -197,6 +201,17 @@ struct Lds {                          // float offsets of the small per-row slab
 constexpr int kSmallFloats = 16 * (2 * kMaxD + 5 * kMaxA + 7 * 4);
 
 // ======================================================================================================== P1 =====
+// hand-off between the paired workgroups of a slab: the producer's data stores, a workgroup barrier, then ONE release store of
+// the flag; the consumer's thread 0 spins on it (agent scope), a workgroup barrier, the data is read with agent-scope loads,
+// and the consumer — the flag's only reader — clears it for the next launch
+__device__ __forceinline__ void flag_post(unsigned int* f) { __hip_atomic_store(f, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void flag_wait(unsigned int* f) {
+  while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1u) __builtin_amdgcn_s_sleep(2);
+}
+__device__ __forceinline__ void flag_clear(unsigned int* f) { __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float xload(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xstore(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // Two workgroups per 16-row slab (blockIdx.y): the target chain — actor(s'), both target critics, y (:233-237) — and the
 // critic chain — Q(s, a) of both networks, the loss gradient, the input-gradient chain (:239-241) — are independent until y
 // meets the loss, and ONE compute unit's f32 MFMA rate is what a slab's stage costs (3 + 3 wide items on one CU: 30 us of
@@ -377,6 +392,10 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
 }
 
 // ======================================================================================================== P3 =====
+// Two workgroups per slab here as well (blockIdx.y): workgroup 0 runs the actor, Q1 and the way back through the actor,
+// workgroup 1 only Q2 — forward from the action workgroup 0 has sampled, backward to its first layer's dZ.  They exchange
+// the action (0 -> 1), the two Q columns (both ways: the min's tie rule needs both) and network 2's dZ1 slab (1 -> 0), because
+// d action is ONE accumulator chain over both networks in the per-layer path (Q1's terms, then Q2's): workgroup 0 runs it.
 __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update_args a, const SacWs ws) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const Lds L;
@@ -385,102 +404,138 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
   const int AH1 = H2b + 16 * ld, AH2 = AH1 + 16 * ld;
   const int row0 = blockIdx.x * 16, nrows = min(16, a.B - row0);
   const int t = threadIdx.x;
-  STEP_MARK(1, 0);
+  const bool second = blockIdx.y == 1;                   // the workgroup that carries Q2
+  const int S = gridDim.x;
+  unsigned int* f_act = ws.flag + 1 * S + blockIdx.x;
+  unsigned int* f_q[2] = {ws.flag + 2 * S + blockIdx.x, ws.flag + 3 * S + blockIdx.x};
+  unsigned int* f_dz = ws.flag + 4 * S + blockIdx.x;
+  const int R = GYMRL_ACT_RELU, NA = GYMRL_ACT_NONE, kD = kMaxD, kA = kMaxA;
+  const Images im(a.images, H);
+  if (!second) STEP_MARK(1, 0);
   if (t < 16) {
     const int b = row0 + t;
     const bool ok = t < nrows;
     for (int k = 0; k < kMaxD; ++k) lds[L.S + t * kMaxD + k] = (ok && k < D) ? ws.s[(size_t)b * D + k] : 0.0f;
-    uint64_t ncounter = a.noise_counter_dev ? a.noise_counter_dev[0] : a.noise_counter;
-    for (int j = 0; j < kMaxA; ++j) {
-      float e = 0.0f;
-      if (ok && j < A) e = a.eps_cur ? a.eps_cur[(size_t)b * A + j] : fused_normal(a.noise_seed, ncounter, 4u, (uint32_t)(b * A + j));
-      lds[L.Eps + t * kMaxA + j] = e;
+    if (!second) {
+      uint64_t ncounter = a.noise_counter_dev ? a.noise_counter_dev[0] : a.noise_counter;
+      for (int j = 0; j < kMaxA; ++j) {
+        float e = 0.0f;
+        if (ok && j < A) e = a.eps_cur ? a.eps_cur[(size_t)b * A + j] : fused_normal(a.noise_seed, ncounter, 4u, (uint32_t)(b * A + j));
+        lds[L.Eps + t * kMaxA + j] = e;
+      }
     }
   }
   __syncthreads();
-  STEP_MARK(1, 1);
-  const int R = GYMRL_ACT_RELU, NA = GYMRL_ACT_NONE, kD = kMaxD, kA = kMaxA;
-  const Images im(a.images, H);
-  // ---- a, logp = Actor.sample(s) (:248) ----
+  if (!second) {
+    STEP_MARK(1, 1);
+    // ---- a, logp = Actor.sample(s) (:248) ----
+    {
+      const FwdItem st[1] = {fwd_item(L.S, kD, -1, 0, D, D, H, a.actor.w[0], a.actor.b[0], AH1, ld, ws.aH1, H, R)};
+      fwd_stage<1>(lds, st, row0, nrows);
+    }
+    __syncthreads();
+    STEP_MARK(1, 2);
+    {
+      const FwdItem st[1] = {fwd_item(AH1, ld, -1, 0, H, H, H, a.actor.w[1], a.actor.b[1], AH2, ld, ws.aH2, H, R, 0.0f, 0.0f, im.af)};
+      fwd_stage<1>(lds, st, row0, nrows);
+    }
+    __syncthreads();
+    STEP_MARK(1, 3);
+    {
+      const FwdItem st[2] = {fwd_item(AH2, ld, -1, 0, H, H, A, a.actor.w[2], a.actor.b[2], L.Mean, kA, nullptr, 0, NA),
+                             fwd_item(AH2, ld, -1, 0, H, H, A, a.actor.w[3], a.actor.b[3], L.Ls, kA, nullptr, 0, GYMRL_ACT_CLAMP, a.log_std_min, a.log_std_max)};
+      fwd_stage<2>(lds, st, row0, nrows);
+    }
+    __syncthreads();
+    STEP_MARK(1, 4);
+    if (t < 16) {
+      float lp;
+      sample_row(lds + L.Mean + t * kMaxA, lds + L.Ls + t * kMaxA, lds + L.Eps + t * kMaxA, A, a.bound, lds + L.A + t * kMaxA, lp);
+      lds[L.Misc + t * 4 + 2] = lp;
+      for (int j = 0; j < kMaxA; ++j) xstore(ws.xa + (size_t)(row0 + t) * kMaxA + j, lds[L.A + t * kMaxA + j]);
+    }
+    __syncthreads();
+    if (t == 0) flag_post(f_act);
+    STEP_MARK(1, 5);
+  } else {
+    if (t == 0) flag_wait(f_act);
+    __syncthreads();
+    if (t < 16)
+      for (int j = 0; j < kMaxA; ++j) lds[L.A + t * kMaxA + j] = xload(ws.xa + (size_t)(row0 + t) * kMaxA + j);
+    __syncthreads();
+    if (t == 0) flag_clear(f_act);
+  }
+  // ---- Q(s, a) of the critic P2 has just updated (:249-250): this workgroup's network ----
+  const int n = second ? 1 : 0;
+  const int H1n = second ? H1b : H1a, H2n = second ? H2b : H2a, Xn = second ? X1 : X0, Qn = second ? L.Q1 : L.Q0, Dqn = second ? L.Dq1 : L.Dq0;
   {
-    const FwdItem st[1] = {fwd_item(L.S, kD, -1, 0, D, D, H, a.actor.w[0], a.actor.b[0], AH1, ld, ws.aH1, H, R)};
+    const FwdItem st[1] = {fwd_item(L.S, kD, L.A, kA, D + A, D, H, a.critic.w[3 * n], a.critic.b[3 * n], H1n, ld, nullptr, 0, R)};
     fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
-  STEP_MARK(1, 2);
+  if (!second) STEP_MARK(1, 6);
   {
-    const FwdItem st[1] = {fwd_item(AH1, ld, -1, 0, H, H, H, a.actor.w[1], a.actor.b[1], AH2, ld, ws.aH2, H, R, 0.0f, 0.0f, im.af)};
+    const FwdItem st[1] = {fwd_item(H1n, ld, -1, 0, H, H, H, a.critic.w[3 * n + 1], a.critic.b[3 * n + 1], H2n, ld, nullptr, 0, R, 0.0f, 0.0f, second ? im.c2f : im.c1f)};
     fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
-  STEP_MARK(1, 3);
+  if (!second) STEP_MARK(1, 7);
   {
-    const FwdItem st[2] = {fwd_item(AH2, ld, -1, 0, H, H, A, a.actor.w[2], a.actor.b[2], L.Mean, kA, nullptr, 0, NA),
-                           fwd_item(AH2, ld, -1, 0, H, H, A, a.actor.w[3], a.actor.b[3], L.Ls, kA, nullptr, 0, GYMRL_ACT_CLAMP, a.log_std_min, a.log_std_max)};
-    fwd_stage<2>(lds, st, row0, nrows);
+    const FwdItem st[1] = {fwd_item(H2n, ld, -1, 0, H, H, 1, a.critic.w[3 * n + 2], a.critic.b[3 * n + 2], Qn, 4, nullptr, 0, NA)};
+    fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
-  STEP_MARK(1, 4);
-  if (t < 16) {
-    float lp;
-    sample_row(lds + L.Mean + t * kMaxA, lds + L.Ls + t * kMaxA, lds + L.Eps + t * kMaxA, A, a.bound, lds + L.A + t * kMaxA, lp);
-    lds[L.Misc + t * 4 + 2] = lp;
-  }
+  if (!second) STEP_MARK(1, 8);
+  // the two Q columns meet: each workgroup posts its own, takes the other's
+  if (t < 16) xstore(ws.xq[n] + row0 + t, lds[Qn + t * 4]);
   __syncthreads();
-  STEP_MARK(1, 5);
-  // ---- Q(s, a) of the critic P2 has just updated (:249-250) ----
-  {
-    const FwdItem st[2] = {fwd_item(L.S, kD, L.A, kA, D + A, D, H, a.critic.w[0], a.critic.b[0], H1a, ld, nullptr, 0, R),
-                           fwd_item(L.S, kD, L.A, kA, D + A, D, H, a.critic.w[3], a.critic.b[3], H1b, ld, nullptr, 0, R)};
-    fwd_stage<2>(lds, st, row0, nrows);
-  }
+  if (t == 0) { flag_post(f_q[n]); flag_wait(f_q[1 - n]); }
   __syncthreads();
-  STEP_MARK(1, 6);
-  {
-    const FwdItem st[2] = {fwd_item(H1a, ld, -1, 0, H, H, H, a.critic.w[1], a.critic.b[1], H2a, ld, nullptr, 0, R, 0.0f, 0.0f, im.c1f),
-                           fwd_item(H1b, ld, -1, 0, H, H, H, a.critic.w[4], a.critic.b[4], H2b, ld, nullptr, 0, R, 0.0f, 0.0f, im.c2f)};
-    fwd_stage<2>(lds, st, row0, nrows);
-  }
-  __syncthreads();
-  STEP_MARK(1, 7);
-  {
-    const FwdItem st[2] = {fwd_item(H2a, ld, -1, 0, H, H, 1, a.critic.w[2], a.critic.b[2], L.Q0, 4, nullptr, 0, NA),
-                           fwd_item(H2b, ld, -1, 0, H, H, 1, a.critic.w[5], a.critic.b[5], L.Q1, 4, nullptr, 0, NA)};
-    fwd_stage<2>(lds, st, row0, nrows);
-  }
-  __syncthreads();
-  STEP_MARK(1, 8);
   float dlogp = 0.0f;
   if (t < 16) {                         // offpolicy.hip sac_actor_kernel
+    const float other = xload(ws.xq[1 - n] + row0 + t);
+    const float qa = second ? other : lds[L.Q0 + t * 4], qc = second ? lds[L.Q1 + t * 4] : other;
     const float invB = 1.0f / (float)a.B;
-    const float alpha = (float)exp(a.log_alpha[0]);
-    const float qa = lds[L.Q0 + t * 4], qc = lds[L.Q1 + t * 4], lp = lds[L.Misc + t * 4 + 2];
     const float w1 = qa < qc ? 1.0f : (qa == qc ? 0.5f : 0.0f);          // torch.min tie rule
-    dlogp = alpha * invB;
-    const float d1 = -w1 * invB, d2 = -(1.0f - w1) * invB;
-    for (int k = 0; k < 4; ++k) { lds[L.Dq0 + t * 4 + k] = k == 0 ? d1 : 0.0f; lds[L.Dq1 + t * 4 + k] = k == 0 ? d2 : 0.0f; }
-    if (t < nrows) {
-      ws.terms[(size_t)(row0 + t) * 3 + 1] = (double)(alpha * lp - fminf(qa, qc));
-      ws.terms[(size_t)(row0 + t) * 3 + 2] = (double)(lp + a.target_entropy);
+    const float dn = second ? -(1.0f - w1) * invB : -w1 * invB;
+    for (int k = 0; k < 4; ++k) lds[Dqn + t * 4 + k] = k == 0 ? dn : 0.0f;
+    if (!second) {
+      const float alpha = (float)exp(a.log_alpha[0]);
+      const float lp = lds[L.Misc + t * 4 + 2];
+      dlogp = alpha * invB;
+      if (t < nrows) {
+        ws.terms[(size_t)(row0 + t) * 3 + 1] = (double)(alpha * lp - fminf(qa, qc));
+        ws.terms[(size_t)(row0 + t) * 3 + 2] = (double)(lp + a.target_entropy);
+      }
     }
   }
   __syncthreads();
-  STEP_MARK(1, 9);
-  // ---- back through both Q networks to the action (their parameters are frozen here: no weight gradients) ----
+  if (t == 0) flag_clear(f_q[1 - n]);
+  if (!second) STEP_MARK(1, 9);
+  // ---- back through this workgroup's Q network to its first layer (the parameters are frozen here: no weight gradients) ----
   {
-    const BwdItem st[2] = {BwdItem{L.Dq0, 4, 1, a.critic.w[2], H, -1, nullptr, H2a, ld, R, X0, ld, nullptr, 0, nullptr},
-                           BwdItem{L.Dq1, 4, 1, a.critic.w[5], H, -1, nullptr, H2b, ld, R, X1, ld, nullptr, 0, nullptr}};
-    bwd_stage<2>(lds, st, row0, nrows);
+    const BwdItem st[1] = {BwdItem{Dqn, 4, 1, a.critic.w[3 * n + 2], H, -1, nullptr, H2n, ld, R, Xn, ld, nullptr, 0, nullptr}};
+    bwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
-  STEP_MARK(1, 10);
+  if (!second) STEP_MARK(1, 10);
   {
-    const BwdItem st[2] = {BwdItem{X0, ld, H, a.critic.w[1], H, -1, nullptr, H1a, ld, R, H2a, ld, nullptr, 0, im.c1b},
-                           BwdItem{X1, ld, H, a.critic.w[4], H, -1, nullptr, H1b, ld, R, H2b, ld, nullptr, 0, im.c2b}};
-    bwd_stage<2>(lds, st, row0, nrows);
+    const BwdItem st[1] = {BwdItem{Xn, ld, H, a.critic.w[3 * n + 1], H, -1, nullptr, H1n, ld, R, H2n, ld, nullptr, 0, second ? im.c2b : im.c1b}};
+    bwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
+  if (second) {                         // network 2's dZ1 slab goes to workgroup 0, which runs the one d action chain
+    for (int e = t; e < 16 * H; e += kThreads) xstore(ws.xz + (size_t)(row0 + e / H) * H + e % H, lds[H2b + (e / H) * ld + e % H]);
+    __syncthreads();
+    if (t == 0) flag_post(f_dz);
+    return;
+  }
   STEP_MARK(1, 11);
+  if (t == 0) flag_wait(f_dz);
+  __syncthreads();
+  for (int e = t; e < 16 * H; e += kThreads) lds[H2b + (e / H) * ld + e % H] = xload(ws.xz + (size_t)(row0 + e / H) * H + e % H);
+  __syncthreads();
+  if (t == 0) flag_clear(f_dz);
   // d action = the action columns of (dZ1_Q1 . W1_Q1 + dZ1_Q2 . W1_Q2): ONE accumulator over both networks (the layers share their input)
   {
     const int lane = t & 63, wave = t >> 6, r = lane & 15, q = lane >> 4;
@@ -1162,7 +1217,7 @@ int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream_) {
   c.terms = ws.terms; c.term0 = 0; c.nterms = 1; c.sums = a.sums; c.alpha_step = 0;
   hipLaunchKernelGGL(sac_dw_kernel, dim3((w0 + 3) / 4 + 1), dim3(256), 0, stream, c);
 
-  hipLaunchKernelGGL(sac_p3_kernel, dim3(slabs), dim3(kThreads), lds_bytes(H, 8), stream, a, ws);
+  hipLaunchKernelGGL(sac_p3_kernel, dim3(slabs, 2), dim3(kThreads), lds_bytes(H, 8), stream, a, ws);   // y: the actor + Q1, then Q2
 
   DwArgs p{};
   w0 = 0; ns = 0;
