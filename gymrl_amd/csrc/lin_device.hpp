@@ -142,6 +142,12 @@ __device__ __forceinline__ void tile_fwd_x2(const float* Xs0, const float* Xs1, 
   }
 }
 
+// tile_bwd_input(tile_bwd_input(acc, dZa, Wa), dZb, Wb) — the summed input gradient of an input two layers share, ONE
+// accumulator chain (layer a's terms, then layer b's) — with BOTH layers' weights requested before the first MFMA: as two
+// calls the second layer's 64 scalar loads wait behind the first layer's dependent chain.  N <= 16 * kMaxSteps, N % 4 == 0.
+__device__ __forceinline__ f32x4 tile_bwd_input_pair(f32x4 acc, const float* dZa, const float* dZb, int ldz, int N,
+                                                     const float* __restrict__ Wa, const float* __restrict__ Wb, int K, int kb, int lane);
+
 // acc += dZ . W[:, kb .. kb + 15] for the slab dZ [16][N] in LDS (already multiplied by the activation's derivative).
 // The order of lin_bwd_input_kernel: n0 = 0, 16, ...; e = 0..3; the MFMA adds n = n0 + 4q + e over q.  Calling it again
 // with another layer's dZ / W continues the same accumulator (the summed gradient of an input two layers share).
@@ -186,6 +192,40 @@ __device__ __forceinline__ f32x4 tile_bwd_input(f32x4 acc, const float* dZs, int
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc = mfma16(dz[e], wb[e], acc);
+    }
+  }
+  return acc;
+}
+
+__device__ __forceinline__ f32x4 tile_bwd_input_pair(f32x4 acc, const float* dZa, const float* dZb, int ldz, int N,
+                                                     const float* __restrict__ Wa, const float* __restrict__ Wb, int K, int kb, int lane) {
+  if ((N & 3) != 0 || N > 16 * kMaxSteps) return tile_bwd_input(tile_bwd_input(acc, dZa, ldz, N, Wa, K, kb, lane), dZb, ldz, N, Wb, K, kb, lane);
+  const int r = lane & 15, q = lane >> 4;
+  const int kc = kb + r;
+  const bool k_ok = kc < K;
+  const int kcol = k_ok ? kc : 0;
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  float wa[kMaxSteps][4], wb[kMaxSteps][4];
+#pragma unroll
+  for (int c = 0; c < kMaxSteps; ++c) {
+    if (16 * c >= N) break;                                   // (wave-uniform)
+    const int n = 16 * c + 4 * q;
+    const int ns = n < N ? n : 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { wa[c][e] = Wa[(size_t)(ns + e) * K + kcol]; wb[c][e] = Wb[(size_t)(ns + e) * K + kcol]; }
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const float* zrow = (half ? dZb : dZa) + r * ldz;
+#pragma unroll
+    for (int c = 0; c < kMaxSteps; ++c) {
+      if (16 * c >= N) break;
+      const int n = 16 * c + 4 * q;
+      const bool ok = n < N;
+      const f32x4 za = *reinterpret_cast<const f32x4*>(zrow + (ok ? n : 0));
+      const f32x4 dz = ok ? za : zero;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = mfma16(dz[e], k_ok ? (half ? wb[c][e] : wa[c][e]) : 0.0f, acc);
     }
   }
   return acc;

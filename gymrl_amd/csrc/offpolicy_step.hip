@@ -49,6 +49,8 @@ struct SacWs {
   unsigned int* flag;                 // [5][ceil(B / 16)]: hand-off flags (1 = waiting to be consumed; zero before the first launch, left zero):
                                       //   0 P1's y;  P3: 1 the sampled action, 2 / 3 Q1 / Q2, 4 the second network's dZ1 slab
   float *xa, *xq[2], *xz;             // P3's exchanges: action [16 S][kMaxA], the two Q columns [16 S], dZ1 of network 2 [16 S][H]
+  float *xmean, *xls, *xeps, *xlp;    // the actor step's sample (mean, log_std, eps [16 S][kMaxA], logp [16 S]): P1's critic-chain workgroup
+                                      // computes it while it waits for y, P3 starts from it
   __host__ __device__ static size_t carve(SacWs* w, void* base, int B, int D, int A, int H) {
     size_t off = 0;
     auto take = [&](size_t n) { float* p = base ? reinterpret_cast<float*>(static_cast<char*>(base) + off) : nullptr; off += ((n * 4 + 255) & ~(size_t)255); return p; };
@@ -61,8 +63,10 @@ struct SacWs {
     float* yv = take(S16);
     unsigned int* fl = reinterpret_cast<unsigned int*>(take(5 * S16 / 16));
     float* xa = take(S16 * 4); float* xq0 = take(S16); float* xq1 = take(S16); float* xz = take(S16 * H);
+    float* xm = take(S16 * 4); float* xl = take(S16 * 4); float* xe = take(S16 * 4); float* xp = take(S16);
     if (w) {
       w->y = yv; w->flag = fl; w->xa = xa; w->xq[0] = xq0; w->xq[1] = xq1; w->xz = xz;
+      w->xmean = xm; w->xls = xl; w->xeps = xe; w->xlp = xp;
       w->s = s; w->a = a;
       w->H1[0] = h[0]; w->H1[1] = h[1]; w->Z1[0] = h[2]; w->Z1[1] = h[3]; w->H2[0] = h[4]; w->H2[1] = h[5]; w->Z2[0] = h[6]; w->Z2[1] = h[7];
       w->aH1 = h[8]; w->aZ1 = h[9]; w->aH2 = h[10]; w->aZ2 = h[11];
@@ -354,6 +358,48 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
   }
   __syncthreads();
   STEP_MARK(0, 4);
+  // ---- while the target chain is still on its way (13 us): a, logp = Actor.sample(s) of the ACTOR step (:248).  It reads the
+  // actor's parameters only, which nothing touches before P4 — so it is the work of P3 that does not have to wait for the
+  // critic's update (P2), done here in this workgroup's idle time; P3 starts from what is saved. ----
+  {
+    const int AH1 = T2a, AH2 = T2b;                    // (P3's slab positions)
+    if (t < 16) {
+      const int b = row0 + t;
+      const bool ok = t < nrows;
+      const uint64_t ncounter = a.noise_counter_dev ? a.noise_counter_dev[0] : a.noise_counter;
+      for (int j = 0; j < kMaxA; ++j) {
+        float e = 0.0f;
+        if (ok && j < A) e = a.eps_cur ? a.eps_cur[(size_t)b * A + j] : fused_normal(a.noise_seed, ncounter, 4u, (uint32_t)(b * A + j));
+        lds[L.Eps + t * kMaxA + j] = e;
+      }
+    }
+    {
+      const FwdItem st[1] = {fwd_item(L.S, kD, -1, 0, D, D, H, a.actor.w[0], a.actor.b[0], AH1, ld, ws.aH1, H, R)};
+      fwd_stage<1>(lds, st, row0, nrows);
+    }
+    __syncthreads();
+    {
+      const FwdItem st[1] = {fwd_item(AH1, ld, -1, 0, H, H, H, a.actor.w[1], a.actor.b[1], AH2, ld, ws.aH2, H, R, 0.0f, 0.0f, im.af)};
+      fwd_stage<1>(lds, st, row0, nrows);
+    }
+    __syncthreads();
+    {
+      const FwdItem st[2] = {fwd_item(AH2, ld, -1, 0, H, H, A, a.actor.w[2], a.actor.b[2], L.Mean, kA, nullptr, 0, NA),
+                             fwd_item(AH2, ld, -1, 0, H, H, A, a.actor.w[3], a.actor.b[3], L.Ls, kA, nullptr, 0, GYMRL_ACT_CLAMP, a.log_std_min, a.log_std_max)};
+      fwd_stage<2>(lds, st, row0, nrows);
+    }
+    __syncthreads();
+    if (t < 16) {
+      float lp;
+      sample_row(lds + L.Mean + t * kMaxA, lds + L.Ls + t * kMaxA, lds + L.Eps + t * kMaxA, A, a.bound, lds + L.A2 + t * kMaxA, lp);
+      const size_t o = (size_t)(row0 + t) * kMaxA;
+      for (int j = 0; j < kMaxA; ++j) {
+        ws.xa[o + j] = lds[L.A2 + t * kMaxA + j]; ws.xmean[o + j] = lds[L.Mean + t * kMaxA + j];
+        ws.xls[o + j] = lds[L.Ls + t * kMaxA + j]; ws.xeps[o + j] = lds[L.Eps + t * kMaxA + j];
+      }
+      ws.xlp[row0 + t] = lp;
+    }
+  }
   // ---- y from the slab's target-chain workgroup ----
   if (t == 0) {
     while (__hip_atomic_load(ws.flag + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1u) __builtin_amdgcn_s_sleep(2);
@@ -406,65 +452,34 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
   const int t = threadIdx.x;
   const bool second = blockIdx.y == 1;                   // the workgroup that carries Q2
   const int S = gridDim.x;
-  unsigned int* f_act = ws.flag + 1 * S + blockIdx.x;
   unsigned int* f_q[2] = {ws.flag + 2 * S + blockIdx.x, ws.flag + 3 * S + blockIdx.x};
   unsigned int* f_dz = ws.flag + 4 * S + blockIdx.x;
   const int R = GYMRL_ACT_RELU, NA = GYMRL_ACT_NONE, kD = kMaxD, kA = kMaxA;
   const Images im(a.images, H);
   if (!second) STEP_MARK(1, 0);
+  // the batch's states and the actor step's sample (a, logp, mean, log_std, eps: P1 computed them); workgroup 0 also takes the
+  // actor's two activation slabs back for the way home
   if (t < 16) {
     const int b = row0 + t;
     const bool ok = t < nrows;
     for (int k = 0; k < kMaxD; ++k) lds[L.S + t * kMaxD + k] = (ok && k < D) ? ws.s[(size_t)b * D + k] : 0.0f;
-    if (!second) {
-      uint64_t ncounter = a.noise_counter_dev ? a.noise_counter_dev[0] : a.noise_counter;
-      for (int j = 0; j < kMaxA; ++j) {
-        float e = 0.0f;
-        if (ok && j < A) e = a.eps_cur ? a.eps_cur[(size_t)b * A + j] : fused_normal(a.noise_seed, ncounter, 4u, (uint32_t)(b * A + j));
-        lds[L.Eps + t * kMaxA + j] = e;
-      }
+    const size_t o = (size_t)(row0 + t) * kMaxA;
+    for (int j = 0; j < kMaxA; ++j) {
+      lds[L.A + t * kMaxA + j] = ws.xa[o + j];
+      if (!second) { lds[L.Mean + t * kMaxA + j] = ws.xmean[o + j]; lds[L.Ls + t * kMaxA + j] = ws.xls[o + j]; lds[L.Eps + t * kMaxA + j] = ws.xeps[o + j]; }
+    }
+    if (!second) lds[L.Misc + t * 4 + 2] = ws.xlp[row0 + t];
+  }
+  if (!second) {
+    for (int e = t; e < 16 * H; e += kThreads) {
+      const int rr = e / H, c = e % H;
+      const bool ok = rr < nrows;
+      lds[AH1 + rr * ld + c] = ok ? ws.aH1[(size_t)(row0 + rr) * H + c] : 0.0f;
+      lds[AH2 + rr * ld + c] = ok ? ws.aH2[(size_t)(row0 + rr) * H + c] : 0.0f;
     }
   }
   __syncthreads();
-  if (!second) {
-    STEP_MARK(1, 1);
-    // ---- a, logp = Actor.sample(s) (:248) ----
-    {
-      const FwdItem st[1] = {fwd_item(L.S, kD, -1, 0, D, D, H, a.actor.w[0], a.actor.b[0], AH1, ld, ws.aH1, H, R)};
-      fwd_stage<1>(lds, st, row0, nrows);
-    }
-    __syncthreads();
-    STEP_MARK(1, 2);
-    {
-      const FwdItem st[1] = {fwd_item(AH1, ld, -1, 0, H, H, H, a.actor.w[1], a.actor.b[1], AH2, ld, ws.aH2, H, R, 0.0f, 0.0f, im.af)};
-      fwd_stage<1>(lds, st, row0, nrows);
-    }
-    __syncthreads();
-    STEP_MARK(1, 3);
-    {
-      const FwdItem st[2] = {fwd_item(AH2, ld, -1, 0, H, H, A, a.actor.w[2], a.actor.b[2], L.Mean, kA, nullptr, 0, NA),
-                             fwd_item(AH2, ld, -1, 0, H, H, A, a.actor.w[3], a.actor.b[3], L.Ls, kA, nullptr, 0, GYMRL_ACT_CLAMP, a.log_std_min, a.log_std_max)};
-      fwd_stage<2>(lds, st, row0, nrows);
-    }
-    __syncthreads();
-    STEP_MARK(1, 4);
-    if (t < 16) {
-      float lp;
-      sample_row(lds + L.Mean + t * kMaxA, lds + L.Ls + t * kMaxA, lds + L.Eps + t * kMaxA, A, a.bound, lds + L.A + t * kMaxA, lp);
-      lds[L.Misc + t * 4 + 2] = lp;
-      for (int j = 0; j < kMaxA; ++j) xstore(ws.xa + (size_t)(row0 + t) * kMaxA + j, lds[L.A + t * kMaxA + j]);
-    }
-    __syncthreads();
-    if (t == 0) flag_post(f_act);
-    STEP_MARK(1, 5);
-  } else {
-    if (t == 0) flag_wait(f_act);
-    __syncthreads();
-    if (t < 16)
-      for (int j = 0; j < kMaxA; ++j) lds[L.A + t * kMaxA + j] = xload(ws.xa + (size_t)(row0 + t) * kMaxA + j);
-    __syncthreads();
-    if (t == 0) flag_clear(f_act);
-  }
+  if (!second) STEP_MARK(1, 1);
   // ---- Q(s, a) of the critic P2 has just updated (:249-250): this workgroup's network ----
   const int n = second ? 1 : 0;
   const int H1n = second ? H1b : H1a, H2n = second ? H2b : H2a, Xn = second ? X1 : X0, Qn = second ? L.Q1 : L.Q0, Dqn = second ? L.Dq1 : L.Dq0;
@@ -473,19 +488,19 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
     fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
-  if (!second) STEP_MARK(1, 6);
+  if (!second) STEP_MARK(1, 2);
   {
     const FwdItem st[1] = {fwd_item(H1n, ld, -1, 0, H, H, H, a.critic.w[3 * n + 1], a.critic.b[3 * n + 1], H2n, ld, nullptr, 0, R, 0.0f, 0.0f, second ? im.c2f : im.c1f)};
     fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
-  if (!second) STEP_MARK(1, 7);
+  if (!second) STEP_MARK(1, 3);
   {
     const FwdItem st[1] = {fwd_item(H2n, ld, -1, 0, H, H, 1, a.critic.w[3 * n + 2], a.critic.b[3 * n + 2], Qn, 4, nullptr, 0, NA)};
     fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
-  if (!second) STEP_MARK(1, 8);
+  if (!second) STEP_MARK(1, 4);
   // the two Q columns meet: each workgroup posts its own, takes the other's
   if (t < 16) xstore(ws.xq[n] + row0 + t, lds[Qn + t * 4]);
   __syncthreads();
@@ -511,14 +526,14 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
   }
   __syncthreads();
   if (t == 0) flag_clear(f_q[1 - n]);
-  if (!second) STEP_MARK(1, 9);
+  if (!second) STEP_MARK(1, 5);
   // ---- back through this workgroup's Q network to its first layer (the parameters are frozen here: no weight gradients) ----
   {
     const BwdItem st[1] = {BwdItem{Dqn, 4, 1, a.critic.w[3 * n + 2], H, -1, nullptr, H2n, ld, R, Xn, ld, nullptr, 0, nullptr}};
     bwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
-  if (!second) STEP_MARK(1, 10);
+  if (!second) STEP_MARK(1, 6);
   {
     const BwdItem st[1] = {BwdItem{Xn, ld, H, a.critic.w[3 * n + 1], H, -1, nullptr, H1n, ld, R, H2n, ld, nullptr, 0, second ? im.c2b : im.c1b}};
     bwd_stage<1>(lds, st, row0, nrows);
@@ -530,7 +545,7 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
     if (t == 0) flag_post(f_dz);
     return;
   }
-  STEP_MARK(1, 11);
+  STEP_MARK(1, 7);
   if (t == 0) flag_wait(f_dz);
   __syncthreads();
   for (int e = t; e < 16 * H; e += kThreads) lds[H2b + (e / H) * ld + e % H] = xload(ws.xz + (size_t)(row0 + e / H) * H + e % H);
@@ -541,8 +556,7 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
     const int lane = t & 63, wave = t >> 6, r = lane & 15, q = lane >> 4;
     if (wave == 0) {
       f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-      acc = lin::tile_bwd_input(acc, lds + H2a, ld, H, a.critic.w[0], D + A, 0, lane);
-      acc = lin::tile_bwd_input(acc, lds + H2b, ld, H, a.critic.w[3], D + A, 0, lane);
+      acc = lin::tile_bwd_input_pair(acc, lds + H2a, lds + H2b, ld, H, a.critic.w[0], a.critic.w[3], D + A, 0, lane);
       if (r >= D && r < D + A) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) lds[L.A2 + (4 * q + g) * kMaxA + (r - D)] = acc[g];
@@ -550,7 +564,7 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
     }
   }
   __syncthreads();
-  STEP_MARK(1, 12);
+  STEP_MARK(1, 8);
   if (t < 16) {                         // offpolicy.hip sac_sample_bwd_kernel, then the heads' dL/dz (log_std through its clamp)
     for (int j = 0; j < kMaxA; ++j) {
       float dm = 0.0f, dl = 0.0f;
@@ -570,19 +584,19 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
     }
   }
   __syncthreads();
-  STEP_MARK(1, 13);
+  STEP_MARK(1, 9);
   // ---- back through the actor: heads (one summed input gradient), fc2 ----
   {
     const BwdItem st[1] = {BwdItem{L.Dq0, 4, A, a.actor.w[2], H, L.Dq1, a.actor.w[3], AH2, ld, R, X0, ld, ws.aZ2, H, nullptr}};
     bwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
-  STEP_MARK(1, 14);
+  STEP_MARK(1, 10);
   {
     const BwdItem st[1] = {BwdItem{X0, ld, H, a.actor.w[1], H, -1, nullptr, AH1, ld, R, -1, 0, ws.aZ1, H, im.ab}};
     bwd_stage<1>(lds, st, row0, nrows);
   }
-  STEP_MARK(1, 15);
+  STEP_MARK(1, 11);
 }
 
 // ================================================================================================= P2 / P4 =====

@@ -20,7 +20,7 @@ L = _lib.lib()
 out = (C.c_longlong * 128)()
 assert L.gymrl_step_prof_read(out) == 0
 names = ("P1 critic chain (draw+gather | fc1 x2 | fc2 x2 | q heads | wait for y | loss | bwd3 | bwd2)",
-         "P3 rows (load | a.fc1 | a.fc2 | heads | sample | c.fc1 | c.fc2 | c.fc3 | loss | bwd3 | bwd2 | d action | sample bwd | heads bwd | fc2 bwd)",
+         "P3 workgroup 0 (load s, sample, actor slabs | Q1.fc1 | Q1.fc2 | Q1.fc3 | Q exchange + loss | bwd3 | bwd2 | wait for Q2's dZ1 + d action | sample bwd | heads bwd | fc2 bwd)",
          "acting (load | fc1 | fc2 | heads | sample+env+row)",
          "P1 target chain (draw+gather | a.fc1 | a.fc2 | heads | sample | tgt fc1 x2 | tgt fc2 x2 | tgt fc3 x2 | y)")
 for k in range(4):
