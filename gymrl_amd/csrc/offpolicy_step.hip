@@ -815,13 +815,18 @@ __global__ __launch_bounds__(kThreads) void sac_act_kernel(const gymrl_sac_act_a
 struct RbWs {
   float *s, *h1, *h2, *dS, *dZ2, *dZ1;      // [B][D], [B][H], [B][H], [B][A+1], [B][H], [B][H]
   double* terms;                             // [B][3] (column 0: w * td^2)
+  float* xz;                                 // [2][16 S][4]: head outputs of policy(s') and target(s') on their way to the policy(s) workgroup
+  unsigned int* flag;                        // [2][S]: their hand-off flags (zero before the first launch, left zero)
   __host__ __device__ static size_t carve(RbWs* w, void* base, int B, int D, int A, int H) {
     size_t off = 0;
     auto take = [&](size_t n) { float* p = base ? reinterpret_cast<float*>(static_cast<char*>(base) + off) : nullptr; off += ((n * 4 + 255) & ~(size_t)255); return p; };
     float* s_ = take((size_t)B * D); float* h1 = take((size_t)B * H); float* h2 = take((size_t)B * H); float* dS = take((size_t)B * (A + 1));
     float* z2 = take((size_t)B * H); float* z1 = take((size_t)B * H);
     double* terms = reinterpret_cast<double*>(take((size_t)B * 6));
-    if (w) { w->s = s_; w->h1 = h1; w->h2 = h2; w->dS = dS; w->dZ2 = z2; w->dZ1 = z1; w->terms = terms; }
+    const size_t S16 = (size_t)(B + 15) / 16 * 16;
+    float* xz = take(2 * S16 * 4);
+    unsigned int* fl = reinterpret_cast<unsigned int*>(take(2 * S16 / 16));
+    if (w) { w->s = s_; w->h1 = h1; w->h2 = h2; w->dS = dS; w->dZ2 = z2; w->dZ1 = z1; w->terms = terms; w->xz = xz; w->flag = fl; }
     return off;
   }
 };
@@ -845,55 +850,75 @@ __device__ __forceinline__ int dueling_row(const float* z, int A, float* q) {
 
 constexpr int kRbMaxA = 3;
 
+// Three workgroups per 16-row slab (blockIdx.y): policy(s) — the pass the gradient flows through —, policy(s') and target(s')
+// are independent chains until the double-DQN target meets the TD error (:320-334), and a slab's stage costs what ONE compute
+// unit's f32 MFMA rate makes of its items (three 256 x 256 layers per stage on one CU before).  Workgroups 1 and 2 publish
+// their head outputs ([16][4]) with release flags; workgroup 0, whose own forward takes as long, consumes them, clears the
+// flags and runs the loss and the way back.  All three are resident (3 * B / 16 <= 48 of 256 CUs), the producers wait for nobody.
 __global__ __launch_bounds__(kThreads) void rainbow_rows_kernel(const gymrl_rainbow_update_args a, const RbWs ws) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const Lds L;
   const int D = a.D, A = a.A, A1 = a.A + 1, H = a.H, ld = lin::slab_ld(H);
-  const int H1a = L.big, H1b = H1a + 16 * ld, H1c = H1b + 16 * ld, H2a = H1c + 16 * ld, H2b = H2a + 16 * ld, H2c = H2b + 16 * ld;
-  const int X0 = H2c + 16 * ld;
+  const int H1 = L.big, H2 = H1 + 16 * ld, X0 = H2 + 16 * ld;
   // head outputs of the three passes: [16][4] slabs in the small area (Q0, Q1, Cq0), dS in Dq0
   const int Za = L.Q0, Zb = L.Q1, Zc = L.Cq0, DS = L.Dq0;
   const int row0 = blockIdx.x * 16, nrows = min(16, a.B - row0);
   const int t = threadIdx.x;
-  if (t < 16) {                         // gather (replay.hip replay_gather_kernel)
+  const int pass = blockIdx.y;          // 0: policy(s) [second draw], 1: policy(s') [first draw], 2: target(s') [means]
+  const int S = gridDim.x;
+  if (t < 16) {                         // gather (replay.hip replay_gather_kernel): what this workgroup's pass reads
     const int b = row0 + t;
     const bool ok = t < nrows;
     const int64_t row = ok ? a.idx[b] : 0;
+    const float* src = pass == 0 ? a.r_state : a.r_next;
     for (int k = 0; k < kMaxD; ++k) {
-      const float sv = (ok && k < D) ? a.r_state[row * D + k] : 0.0f, s2 = (ok && k < D) ? a.r_next[row * D + k] : 0.0f;
-      lds[L.S + t * kMaxD + k] = sv; lds[L.S2 + t * kMaxD + k] = s2;
-      if (ok && k < D) ws.s[(size_t)b * D + k] = sv;
+      const float sv = (ok && k < D) ? src[row * D + k] : 0.0f;
+      lds[L.S + t * kMaxD + k] = sv;
+      if (pass == 0 && ok && k < D) ws.s[(size_t)b * D + k] = sv;
     }
-    lds[L.Misc + t * 4 + 0] = ok ? a.r_reward[row] : 0.0f;
-    lds[L.Misc + t * 4 + 1] = ok ? (float)a.r_flag[row] : 0.0f;
-    lds[L.Misc + t * 4 + 2] = ok ? __int_as_float((int)a.r_action[row]) : 0.0f;
-    lds[L.Misc + t * 4 + 3] = (ok && a.is_weight) ? a.is_weight[b] : 1.0f;
+    if (pass == 0) {
+      lds[L.Misc + t * 4 + 0] = ok ? a.r_reward[row] : 0.0f;
+      lds[L.Misc + t * 4 + 1] = ok ? (float)a.r_flag[row] : 0.0f;
+      lds[L.Misc + t * 4 + 2] = ok ? __int_as_float((int)a.r_action[row]) : 0.0f;
+      lds[L.Misc + t * 4 + 3] = (ok && a.is_weight) ? a.is_weight[b] : 1.0f;
+    }
   }
   __syncthreads();
   const int R = GYMRL_ACT_RELU, NA = GYMRL_ACT_NONE, kD = kMaxD;
   const size_t hw = (size_t)A1 * H;
-  // policy(s') [first draw] | target(s') [means] | policy(s) [second draw], the three passes sharing every stage (:320-334)
+  const bool tgt = pass == 2;
+  const int hslot = pass == 0 ? 2 : (pass == 1 ? 0 : 1);            // the stacked heads: first draw | target means | second draw
+  const int Zme = pass == 0 ? Zc : (pass == 1 ? Za : Zb);
   {
-    const FwdItem st[3] = {fwd_item(L.S2, kD, -1, 0, D, D, H, a.p_fc1_w, a.p_fc1_b, H1a, ld, nullptr, 0, R),
-                           fwd_item(L.S2, kD, -1, 0, D, D, H, a.t_fc1_w, a.t_fc1_b, H1b, ld, nullptr, 0, R),
-                           fwd_item(L.S, kD, -1, 0, D, D, H, a.p_fc1_w, a.p_fc1_b, H1c, ld, ws.h1, H, R)};
-    fwd_stage<3>(lds, st, row0, nrows);
+    const FwdItem st[1] = {fwd_item(L.S, kD, -1, 0, D, D, H, tgt ? a.t_fc1_w : a.p_fc1_w, tgt ? a.t_fc1_b : a.p_fc1_b, H1, ld, pass == 0 ? ws.h1 : nullptr, H, R)};
+    fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
   {
-    const FwdItem st[3] = {fwd_item(H1a, ld, -1, 0, H, H, H, a.p_fc2_w, a.p_fc2_b, H2a, ld, nullptr, 0, R),
-                           fwd_item(H1b, ld, -1, 0, H, H, H, a.t_fc2_w, a.t_fc2_b, H2b, ld, nullptr, 0, R),
-                           fwd_item(H1c, ld, -1, 0, H, H, H, a.p_fc2_w, a.p_fc2_b, H2c, ld, ws.h2, H, R)};
-    fwd_stage<3>(lds, st, row0, nrows);
+    const FwdItem st[1] = {fwd_item(H1, ld, -1, 0, H, H, H, tgt ? a.t_fc2_w : a.p_fc2_w, tgt ? a.t_fc2_b : a.p_fc2_b, H2, ld, pass == 0 ? ws.h2 : nullptr, H, R)};
+    fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
   {
-    const FwdItem st[3] = {fwd_item(H2a, ld, -1, 0, H, H, A1, a.head_w, a.head_b, Za, 4, nullptr, 0, NA),
-                           fwd_item(H2b, ld, -1, 0, H, H, A1, a.head_w + hw, a.head_b + A1, Zb, 4, nullptr, 0, NA),
-                           fwd_item(H2c, ld, -1, 0, H, H, A1, a.head_w + 2 * hw, a.head_b + 2 * A1, Zc, 4, nullptr, 0, NA)};
-    fwd_stage<3>(lds, st, row0, nrows);
+    const FwdItem st[1] = {fwd_item(H2, ld, -1, 0, H, H, A1, a.head_w + hslot * hw, a.head_b + hslot * A1, Zme, 4, nullptr, 0, NA)};
+    fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
+  if (pass != 0) {                      // the head outputs go to workgroup 0
+    float* xz = ws.xz + ((size_t)(pass - 1) * S * 16 + row0) * 4;
+    if (t < 64) xstore(xz + t, lds[Zme + t]);
+    __syncthreads();
+    if (t == 0) flag_post(ws.flag + (pass - 1) * S + blockIdx.x);
+    return;
+  }
+  if (t == 0) { flag_wait(ws.flag + blockIdx.x); flag_wait(ws.flag + S + blockIdx.x); }
+  __syncthreads();
+  if (t < 64) {
+    lds[Za + t] = xload(ws.xz + ((size_t)row0) * 4 + t);
+    lds[Zb + t] = xload(ws.xz + ((size_t)S * 16 + row0) * 4 + t);
+  }
+  __syncthreads();
+  if (t == 0) { flag_clear(ws.flag + blockIdx.x); flag_clear(ws.flag + S + blockIdx.x); }
   if (t < 16) {
     // dueling heads, the double-DQN target and the IS-weighted loss gradient (offpolicy.hip dqn_td_kernel), dueling backward (lin.hip)
     float q_no[kRbMaxA], q_nt[kRbMaxA], q[kRbMaxA];
@@ -920,14 +945,14 @@ __global__ __launch_bounds__(kThreads) void rainbow_rows_kernel(const gymrl_rain
     }
   }
   __syncthreads();
-  // loss.backward() of the third pass: head -> fc2 (the input gradients; the weight gradients are the tile launch's)
+  // loss.backward() of this pass: head -> fc2 (the input gradients; the weight gradients are the tile launch's)
   {
-    const BwdItem st[1] = {BwdItem{DS, 4, A1, a.head_w + 2 * hw, H, -1, nullptr, H2c, ld, R, X0, ld, ws.dZ2, H, nullptr}};
+    const BwdItem st[1] = {BwdItem{DS, 4, A1, a.head_w + 2 * hw, H, -1, nullptr, H2, ld, R, X0, ld, ws.dZ2, H, nullptr}};
     bwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
   {
-    const BwdItem st[1] = {BwdItem{X0, ld, H, a.p_fc2_w, H, -1, nullptr, H1c, ld, R, -1, 0, ws.dZ1, H, nullptr}};
+    const BwdItem st[1] = {BwdItem{X0, ld, H, a.p_fc2_w, H, -1, nullptr, H1, ld, R, -1, 0, ws.dZ1, H, nullptr}};
     bwd_stage<1>(lds, st, row0, nrows);
   }
 }
@@ -1140,7 +1165,7 @@ int gymrl_rainbow_update(const gymrl_rainbow_update_args* args, int phase, void*
   void* base = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(a.workspace) + 255) & ~(uintptr_t)255);
   RbWs::carve(&ws, base, a.B, a.D, a.A, a.H);
   const int B = a.B, D = a.D, A1 = a.A + 1, H = a.H;
-  if (phase != 2) hipLaunchKernelGGL(rainbow_rows_kernel, dim3((B + 15) / 16), dim3(kThreads), lds_bytes(H, 7), stream, a, ws);
+  if (phase != 2) hipLaunchKernelGGL(rainbow_rows_kernel, dim3((B + 15) / 16, 3), dim3(kThreads), lds_bytes(H, 7), stream, a, ws);
   if (phase == 1) { GYMRL_CHECK_LAUNCH(); return 0; }
   DwArgs d{};
   int w0 = 0, ns = 0;

@@ -1432,7 +1432,8 @@ def rainbow_fused_shape_ok(B, D, A, H):
 
 
 def rainbow_update_workspace(B, D, A, H, device):
-    return torch.empty(int(lib().gymrl_rainbow_update_workspace_bytes(C.c_int(B), C.c_int(D), C.c_int(A), C.c_int(H))),
+    # zeroed: the hand-off flags between gymrl_rainbow_update's three workgroups per slab live in it (zero before the first launch, left zero)
+    return torch.zeros(int(lib().gymrl_rainbow_update_workspace_bytes(C.c_int(B), C.c_int(D), C.c_int(A), C.c_int(H))),
                        dtype=torch.uint8, device=device)
 
 

@@ -1162,7 +1162,8 @@ typedef struct {
   float* td_out;                             /* f32[B] TD errors (update_priorities) */
   double* loss_sum;                          /* f64[1] out: sum of w * td^2 */
   float* d_fc1_w; float* d_fc1_b; float* d_fc2_w; float* d_fc2_b; float* d_head_w; float* d_head_b;   /* gradients (overwritten) */
-  void* workspace;                           /* >= gymrl_rainbow_update_workspace_bytes(B, D, A, H) */
+  void* workspace;                           /* >= gymrl_rainbow_update_workspace_bytes(B, D, A, H); ZEROED once before the first call
+                                              * (the hand-off flags between the row phase's three workgroups per slab live in it) */
   /* gymrl_noisy_split inside the weight-gradient launch (split_heads != 0; d_head_w / d_head_b are then not written): the stacked
    * head's gradient goes straight to the two NoisyLinear layers' parameters, [0] = advantage (rows 0 .. A-1), [1] = value (row A):
    * d mu = dW, d sigma = dW * eps with the SECOND draw's epsilons (rainbow_dqn_cartpole.py:92-93 under autograd) */
