@@ -362,8 +362,10 @@ def main_offpolicy(a, rank, world, local_rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default 3; 100 for --algo sac / rainbow, whose step — 16 vector steps, ~2.3 ms — is short "
+                         "enough for the host's first chunks to move the figure by 15 %% below ~50)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 1; 20 for --algo sac / rainbow)")
     ap.add_argument("--envs", type=int, default=None,
                     help="env instances per GPU (default: the BASELINE config's — 4096 for ppo / ppo_full / sac, 8192 for rainbow)")
     ap.add_argument("--rollout", type=int, default=2048, help="T: vector steps per rollout (reference update_freq)")
@@ -387,6 +389,11 @@ def main():
         ap.error("--gpus must be >= 1")
     if a.envs is None:
         a.envs = 8192 if a.algo == "rainbow" else 4096
+    short = a.algo in ("sac", "rainbow")
+    if a.steps is None:
+        a.steps = 100 if short else 3
+    if a.warmup is None:
+        a.warmup = 20 if short else 1
     if a.envs < 1:
         ap.error("--envs must be >= 1")
     if a.backend == "gloo" and not a.spawn_selftest:

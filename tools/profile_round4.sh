@@ -8,8 +8,8 @@ cd /root/repo
 timeout 600 python bench.py > "$OUT/bench_final.json" 2> "$OUT/bench_final.err"
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_20steps.json" 2> /dev/null
 timeout 300 python bench.py --algo ppo_full --steps 3 --warmup 1 > "$OUT/bench_ppo_full.json" 2> /dev/null
-timeout 300 python bench.py --algo sac --steps 100 --warmup 20 > "$OUT/bench_sac.json" 2> /dev/null
-timeout 300 python bench.py --algo rainbow --steps 100 --warmup 20 > "$OUT/bench_rainbow.json" 2> /dev/null
+timeout 300 python bench.py --algo sac > "$OUT/bench_sac.json" 2> /dev/null
+timeout 300 python bench.py --algo rainbow > "$OUT/bench_rainbow.json" 2> /dev/null
 timeout 200 python tools/micro_per.py > "$OUT/micro_per.txt" 2> /dev/null
 timeout 200 python tools/micro_sub_bwd.py > "$OUT/micro_sub_bwd.txt" 2> /dev/null
 GYMRL_HIP_LIB=gymrl_amd/libgymrl_hip_prof.so timeout 200 python tools/micro_sub_bwd.py --phases >> "$OUT/micro_sub_bwd.txt" 2> /dev/null
