@@ -45,9 +45,12 @@ struct SacWs {
   float *H1[2], *Z1[2], *H2[2], *Z2[2], *dq[2];      // critic net i: activations and dL/dz per layer
   float *aH1, *aZ1, *aH2, *aZ2, *dmean, *dls;        // actor
   double* terms;                      // [B][3]: per-row critic term, actor term, temperature term
-  float* y;                           // [16 ceil(B / 16)]: the Bellman target, from P1's target-chain workgroup to its critic-chain workgroup
-  unsigned int* flag;                 // [5][ceil(B / 16)]: hand-off flags (1 = waiting to be consumed; zero before the first launch, left zero):
-                                      //   0 P1's y;  P3: 1 the sampled action, 2 / 3 Q1 / Q2, 4 the second network's dZ1 slab
+  double* terms2;                     // [B]: the second Q network's critic term (its workgroup's share of terms[.][0])
+  float *xtq[2], *xmisc;              // P1: the two target networks' Q(s', a') columns [16 S] and {reward, done, logp'} [16 S][4], from the
+                                      // target-chain workgroups to the critic-chain workgroups (each forms y itself)
+  unsigned int* flag;                 // [8][ceil(B / 16)]: hand-off flags (1 = waiting to be consumed; zero before the first launch, left zero):
+                                      //   P1: 0 / 1 target network 1 -> critic workgroup 1 / 2, 5 / 6 target network 2 -> critic workgroup 1 / 2;
+                                      //   P3: 2 / 3 Q1 / Q2, 4 the second network's dZ1 slab
   float *xa, *xq[2], *xz;             // P3's exchanges: action [16 S][kMaxA], the two Q columns [16 S], dZ1 of network 2 [16 S][H]
   float *xmean, *xls, *xeps, *xlp;    // the actor step's sample (mean, log_std, eps [16 S][kMaxA], logp [16 S]): P1's critic-chain workgroup
                                       // computes it while it waits for y, P3 starts from it
@@ -60,12 +63,13 @@ struct SacWs {
     float* dq0 = take(B); float* dq1 = take(B); float* dm = take((size_t)B * A); float* dl = take((size_t)B * A);
     double* terms = reinterpret_cast<double*>(take((size_t)B * 6));
     const size_t S16 = (size_t)(B + 15) / 16 * 16;
-    float* yv = take(S16);
-    unsigned int* fl = reinterpret_cast<unsigned int*>(take(5 * S16 / 16));
+    double* terms2 = reinterpret_cast<double*>(take((size_t)B * 2));
+    float* tq0 = take(S16); float* tq1 = take(S16); float* xmi = take(S16 * 4);
+    unsigned int* fl = reinterpret_cast<unsigned int*>(take(8 * S16 / 16));
     float* xa = take(S16 * 4); float* xq0 = take(S16); float* xq1 = take(S16); float* xz = take(S16 * H);
     float* xm = take(S16 * 4); float* xl = take(S16 * 4); float* xe = take(S16 * 4); float* xp = take(S16);
     if (w) {
-      w->y = yv; w->flag = fl; w->xa = xa; w->xq[0] = xq0; w->xq[1] = xq1; w->xz = xz;
+      w->terms2 = terms2; w->xtq[0] = tq0; w->xtq[1] = tq1; w->xmisc = xmi; w->flag = fl; w->xa = xa; w->xq[0] = xq0; w->xq[1] = xq1; w->xz = xz;
       w->xmean = xm; w->xls = xl; w->xeps = xe; w->xlp = xp;
       w->s = s; w->a = a;
       w->H1[0] = h[0]; w->H1[1] = h[1]; w->Z1[0] = h[2]; w->Z1[1] = h[3]; w->H2[0] = h[4]; w->H2[1] = h[5]; w->Z2[0] = h[6]; w->Z2[1] = h[7];
@@ -216,12 +220,15 @@ __device__ __forceinline__ void flag_clear(unsigned int* f) { __hip_atomic_store
 __device__ __forceinline__ float xload(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void xstore(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Two workgroups per 16-row slab (blockIdx.y): the target chain — actor(s'), both target critics, y (:233-237) — and the
-// critic chain — Q(s, a) of both networks, the loss gradient, the input-gradient chain (:239-241) — are independent until y
-// meets the loss, and ONE compute unit's f32 MFMA rate is what a slab's stage costs (3 + 3 wide items on one CU: 30 us of
-// the kernel's 64).  The target workgroup publishes y with a release flag, the critic workgroup — which needs 22 us for its
-// forward anyway — spins on it with agent-scope loads, consumes y and clears the flag.  Both workgroups of every slab are
-// resident (2 * B / 16 <= 32 of 256 CUs), the producer waits for nobody: no deadlock.  Same layers, same order per element.
+// Four workgroups per 16-row slab (blockIdx.y): ONE compute unit's f32 MFMA rate is what a slab's stage costs, so every
+// chain that does not depend on another runs on a compute unit of its own —
+//   0 / 1  the target chain of target network 1 / 2: actor(s'), a' and logp' (both compute them: nothing is waited for), then
+//          THEIR network's Q(s', a') (:233-236), posted with a release flag per consumer;
+//   2 / 3  the critic chain of Q network 1 / 2: Q(s, a) (:239), then — both target columns taken — y (:237), the loss gradient
+//          and the input-gradient chain of its network (:240-241).  Workgroup 2 also runs the ACTOR step's forward (:248) in
+//          the time it would otherwise wait.
+// All workgroups of every slab are resident (4 * B / 16 <= 64 of 256 CUs) and the producers wait for nobody: no deadlock.
+// Every flag has one writer and one reader, who clears it.  Same layers, same order per element as the per-layer path.
 __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update_args a, const SacWs ws) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const Lds L;
@@ -230,11 +237,16 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
   const int T2a = H2b + 16 * ld, T2b = T2a + 16 * ld;
   const int row0 = blockIdx.x * 16, nrows = min(16, a.B - row0);
   const int t = threadIdx.x;
-  const bool target_chain = blockIdx.y == 0;
+  const int role = blockIdx.y, S = gridDim.x;
+  const bool target_chain = role < 2;
+  const int n = role & 1;                                // which of the twin networks this workgroup carries
   const int R = GYMRL_ACT_RELU, NA = GYMRL_ACT_NONE, kD = kMaxD, kA = kMaxA;
   const Images im(a.images, H);
+  unsigned int* const f_t[2] = {ws.flag + (size_t)n * S + blockIdx.x, ws.flag + (size_t)(5 + n) * S + blockIdx.x};   // target net 1 / 2 -> critic workgroup n
+#define P1_MARK_T(i) do { if (role == 0) STEP_MARK(3, i); } while (0)
+#define P1_MARK_C(i) do { if (role == 2) STEP_MARK(0, i); } while (0)
   // ---- 0: index draw + ring gather (one thread per row; rows beyond the batch are zero); each workgroup takes what its chain reads ----
-  if (target_chain) STEP_MARK(3, 0); else STEP_MARK(0, 0);
+  P1_MARK_T(0); P1_MARK_C(0);
   if (t < 16) {
     const int b = row0 + t;
     const bool ok = t < nrows;
@@ -263,105 +275,99 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
       for (int k = 0; k < kMaxD; ++k) {
         const float sv = (ok && k < D) ? a.r_state[row * D + k] : 0.0f;
         lds[L.S + t * kMaxD + k] = sv;
-        if (ok && k < D) ws.s[(size_t)b * D + k] = sv;
+        if (n == 0 && ok && k < D) ws.s[(size_t)b * D + k] = sv;
       }
       for (int j = 0; j < kMaxA; ++j) {
         const float av = (ok && j < A) ? __uint_as_float(a.r_action[row * A + j]) : 0.0f;
         lds[L.A + t * kMaxA + j] = av;
-        if (ok && j < A) ws.a[(size_t)b * A + j] = av;
+        if (n == 0 && ok && j < A) ws.a[(size_t)b * A + j] = av;
       }
     }
   }
   __syncthreads();
   if (target_chain) {
-    STEP_MARK(3, 1);
+    P1_MARK_T(1);
     // ---- the actor on s' (:233) ----
     {
       const FwdItem st[1] = {fwd_item(L.S2, kD, -1, 0, D, D, H, a.actor.w[0], a.actor.b[0], X0, ld, nullptr, 0, R)};
       fwd_stage<1>(lds, st, row0, nrows);
     }
     __syncthreads();
-    STEP_MARK(3, 2);
+    P1_MARK_T(2);
     {
       const FwdItem st[1] = {fwd_item(X0, ld, -1, 0, H, H, H, a.actor.w[1], a.actor.b[1], X1, ld, nullptr, 0, R, 0.0f, 0.0f, im.af)};
       fwd_stage<1>(lds, st, row0, nrows);
     }
     __syncthreads();
-    STEP_MARK(3, 3);
+    P1_MARK_T(3);
     {
       const FwdItem st[2] = {fwd_item(X1, ld, -1, 0, H, H, A, a.actor.w[2], a.actor.b[2], L.Mean, kA, nullptr, 0, NA),
                              fwd_item(X1, ld, -1, 0, H, H, A, a.actor.w[3], a.actor.b[3], L.Ls, kA, nullptr, 0, GYMRL_ACT_CLAMP, a.log_std_min, a.log_std_max)};
       fwd_stage<2>(lds, st, row0, nrows);
     }
     __syncthreads();
-    STEP_MARK(3, 4);
+    P1_MARK_T(4);
     if (t < 16) {                         // a', logp' (:234)
       float lp;
       sample_row(lds + L.Mean + t * kMaxA, lds + L.Ls + t * kMaxA, lds + L.Eps + t * kMaxA, A, a.bound, lds + L.A2 + t * kMaxA, lp);
       lds[L.Misc + t * 4 + 2] = lp;
     }
     __syncthreads();
-    STEP_MARK(3, 5);
-    // ---- target Q(s', a') of both networks (:235-236) ----
+    P1_MARK_T(5);
+    // ---- target Q(s', a') of this workgroup's network (:235-236) ----
     {
-      const FwdItem st[2] = {fwd_item(L.S2, kD, L.A2, kA, D + A, D, H, a.target.w[0], a.target.b[0], X0, ld, nullptr, 0, R),
-                             fwd_item(L.S2, kD, L.A2, kA, D + A, D, H, a.target.w[3], a.target.b[3], X1, ld, nullptr, 0, R)};
-      fwd_stage<2>(lds, st, row0, nrows);
+      const FwdItem st[1] = {fwd_item(L.S2, kD, L.A2, kA, D + A, D, H, a.target.w[3 * n], a.target.b[3 * n], X0, ld, nullptr, 0, R)};
+      fwd_stage<1>(lds, st, row0, nrows);
     }
     __syncthreads();
-    STEP_MARK(3, 6);
+    P1_MARK_T(6);
     {
-      const FwdItem st[2] = {fwd_item(X0, ld, -1, 0, H, H, H, a.target.w[1], a.target.b[1], T2a, ld, nullptr, 0, R, 0.0f, 0.0f, im.t1f),
-                             fwd_item(X1, ld, -1, 0, H, H, H, a.target.w[4], a.target.b[4], T2b, ld, nullptr, 0, R, 0.0f, 0.0f, im.t2f)};
-      fwd_stage<2>(lds, st, row0, nrows);
+      const FwdItem st[1] = {fwd_item(X0, ld, -1, 0, H, H, H, a.target.w[3 * n + 1], a.target.b[3 * n + 1], T2a, ld, nullptr, 0, R, 0.0f, 0.0f, n ? im.t2f : im.t1f)};
+      fwd_stage<1>(lds, st, row0, nrows);
     }
     __syncthreads();
-    STEP_MARK(3, 7);
+    P1_MARK_T(7);
     {
-      const FwdItem st[2] = {fwd_item(T2a, ld, -1, 0, H, H, 1, a.target.w[2], a.target.b[2], L.Q0, 4, nullptr, 0, NA),
-                             fwd_item(T2b, ld, -1, 0, H, H, 1, a.target.w[5], a.target.b[5], L.Q1, 4, nullptr, 0, NA)};
-      fwd_stage<2>(lds, st, row0, nrows);
+      const FwdItem st[1] = {fwd_item(T2a, ld, -1, 0, H, H, 1, a.target.w[3 * n + 2], a.target.b[3 * n + 2], L.Q0, 4, nullptr, 0, NA)};
+      fwd_stage<1>(lds, st, row0, nrows);
     }
     __syncthreads();
-    STEP_MARK(3, 8);
-    if (t < 16) {                         // y (:237; offpolicy.hip sac_target_kernel)
-      const float alpha = (float)exp(a.log_alpha[0]);
-      const float tq = fminf(lds[L.Q0 + t * 4], lds[L.Q1 + t * 4]) - alpha * lds[L.Misc + t * 4 + 2];
-      const float y = lds[L.Misc + t * 4 + 0] + a.gamma * (1.0f - lds[L.Misc + t * 4 + 1]) * tq;
-      __hip_atomic_store(ws.y + row0 + t, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (16 slots per slab: y is padded to whole slabs)
+    P1_MARK_T(8);
+    if (t < 16) {                         // (16 slots per slab: the columns are padded to whole slabs)
+      xstore(ws.xtq[n] + row0 + t, lds[L.Q0 + t * 4]);
+      if (n == 0) {
+        for (int k = 0; k < 3; ++k) xstore(ws.xmisc + (size_t)(row0 + t) * 4 + k, lds[L.Misc + t * 4 + k]);
+      }
     }
     __syncthreads();
-    if (t == 0) __hip_atomic_store(ws.flag + blockIdx.x, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    STEP_MARK(3, 9);
+    if (t == 0) { flag_post(ws.flag + (size_t)(n ? 5 : 0) * S + blockIdx.x); flag_post(ws.flag + (size_t)(n ? 6 : 1) * S + blockIdx.x); }
+    P1_MARK_T(9);
     return;
   }
-  STEP_MARK(0, 1);
-  // ---- Q(s, a) of both networks (:239) ----
+  P1_MARK_C(1);
+  // ---- Q(s, a) of this workgroup's network (:239) ----
   {
-    const FwdItem st[2] = {fwd_item(L.S, kD, L.A, kA, D + A, D, H, a.critic.w[0], a.critic.b[0], H1a, ld, ws.H1[0], H, R),
-                           fwd_item(L.S, kD, L.A, kA, D + A, D, H, a.critic.w[3], a.critic.b[3], H1b, ld, ws.H1[1], H, R)};
-    fwd_stage<2>(lds, st, row0, nrows);
+    const FwdItem st[1] = {fwd_item(L.S, kD, L.A, kA, D + A, D, H, a.critic.w[3 * n], a.critic.b[3 * n], H1a, ld, ws.H1[n], H, R)};
+    fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
-  STEP_MARK(0, 2);
+  P1_MARK_C(2);
   {
-    const FwdItem st[2] = {fwd_item(H1a, ld, -1, 0, H, H, H, a.critic.w[1], a.critic.b[1], H2a, ld, ws.H2[0], H, R, 0.0f, 0.0f, im.c1f),
-                           fwd_item(H1b, ld, -1, 0, H, H, H, a.critic.w[4], a.critic.b[4], H2b, ld, ws.H2[1], H, R, 0.0f, 0.0f, im.c2f)};
-    fwd_stage<2>(lds, st, row0, nrows);
+    const FwdItem st[1] = {fwd_item(H1a, ld, -1, 0, H, H, H, a.critic.w[3 * n + 1], a.critic.b[3 * n + 1], H2a, ld, ws.H2[n], H, R, 0.0f, 0.0f, n ? im.c2f : im.c1f)};
+    fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
-  STEP_MARK(0, 3);
+  P1_MARK_C(3);
   {
-    const FwdItem st[2] = {fwd_item(H2a, ld, -1, 0, H, H, 1, a.critic.w[2], a.critic.b[2], L.Cq0, 4, nullptr, 0, NA),
-                           fwd_item(H2b, ld, -1, 0, H, H, 1, a.critic.w[5], a.critic.b[5], L.Cq1, 4, nullptr, 0, NA)};
-    fwd_stage<2>(lds, st, row0, nrows);
+    const FwdItem st[1] = {fwd_item(H2a, ld, -1, 0, H, H, 1, a.critic.w[3 * n + 2], a.critic.b[3 * n + 2], L.Cq0, 4, nullptr, 0, NA)};
+    fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
-  STEP_MARK(0, 4);
-  // ---- while the target chain is still on its way (13 us): a, logp = Actor.sample(s) of the ACTOR step (:248).  It reads the
+  P1_MARK_C(4);
+  // ---- while the target chains are still on their way: a, logp = Actor.sample(s) of the ACTOR step (:248).  It reads the
   // actor's parameters only, which nothing touches before P4 — so it is the work of P3 that does not have to wait for the
-  // critic's update (P2), done here in this workgroup's idle time; P3 starts from what is saved. ----
-  {
+  // critic's update (P2), done here in the first critic workgroup's idle time; P3 starts from what is saved. ----
+  if (n == 0) {
     const int AH1 = T2a, AH2 = T2b;                    // (P3's slab positions)
     if (t < 16) {
       const int b = row0 + t;
@@ -400,41 +406,43 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
       ws.xlp[row0 + t] = lp;
     }
   }
-  // ---- y from the slab's target-chain workgroup ----
-  if (t == 0) {
-    while (__hip_atomic_load(ws.flag + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1u) __builtin_amdgcn_s_sleep(2);
-  }
+  // ---- both target columns ----
+  if (t == 0) { flag_wait(f_t[0]); flag_wait(f_t[1]); }
   __syncthreads();
-  STEP_MARK(0, 5);
+  P1_MARK_C(5);
   if (t < 16) {
-    // the critic loss gradient (:240-241; sac_critic_kernel)
-    const float y = __hip_atomic_load(ws.y + row0 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // y (:237; offpolicy.hip sac_target_kernel), then the critic loss gradient (:240-241; sac_critic_kernel)
+    const float alpha = (float)exp(a.log_alpha[0]);
+    const float* mi = ws.xmisc + (size_t)(row0 + t) * 4;
+    const float tq = fminf(xload(ws.xtq[0] + row0 + t), xload(ws.xtq[1] + row0 + t)) - alpha * xload(mi + 2);
+    const float y = xload(mi + 0) + a.gamma * (1.0f - xload(mi + 1)) * tq;
     const float invB = 1.0f / (float)a.B;
-    const float e1 = lds[L.Cq0 + t * 4] - y, e2 = lds[L.Cq1 + t * 4] - y;
-    const float d1 = 2.0f * e1 * invB, d2 = 2.0f * e2 * invB;
-    for (int k = 0; k < 4; ++k) { lds[L.Dq0 + t * 4 + k] = k == 0 ? d1 : 0.0f; lds[L.Dq1 + t * 4 + k] = k == 0 ? d2 : 0.0f; }
+    const float e = lds[L.Cq0 + t * 4] - y;
+    const float d = 2.0f * e * invB;
+    for (int k = 0; k < 4; ++k) lds[L.Dq0 + t * 4 + k] = k == 0 ? d : 0.0f;
     if (t < nrows) {
-      ws.dq[0][row0 + t] = d1; ws.dq[1][row0 + t] = d2;
-      ws.terms[(size_t)(row0 + t) * 3 + 0] = (double)(e1 * e1) + (double)(e2 * e2);
+      ws.dq[n][row0 + t] = d;
+      if (n == 0) ws.terms[(size_t)(row0 + t) * 3 + 0] = (double)(e * e);       // the row's critic term = this + terms2 (P2 adds them)
+      else ws.terms2[row0 + t] = (double)(e * e);
     }
   }
   __syncthreads();
-  if (t == 0) __hip_atomic_store(ws.flag + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: ready for the next launch
-  STEP_MARK(0, 6);
-  // ---- input-gradient chain of both Q networks (what q.backward() computes before the weight gradients) ----
+  if (t == 0) { flag_clear(f_t[0]); flag_clear(f_t[1]); }                        // consumed: ready for the next launch
+  P1_MARK_C(6);
+  // ---- input-gradient chain of this Q network (what q.backward() computes before the weight gradients) ----
   {
-    const BwdItem st[2] = {BwdItem{L.Dq0, 4, 1, a.critic.w[2], H, -1, nullptr, H2a, ld, R, X0, ld, ws.Z2[0], H, nullptr},
-                           BwdItem{L.Dq1, 4, 1, a.critic.w[5], H, -1, nullptr, H2b, ld, R, X1, ld, ws.Z2[1], H, nullptr}};
-    bwd_stage<2>(lds, st, row0, nrows);
+    const BwdItem st[1] = {BwdItem{L.Dq0, 4, 1, a.critic.w[3 * n + 2], H, -1, nullptr, H2a, ld, R, X0, ld, ws.Z2[n], H, nullptr}};
+    bwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
-  STEP_MARK(0, 7);
+  P1_MARK_C(7);
   {
-    const BwdItem st[2] = {BwdItem{X0, ld, H, a.critic.w[1], H, -1, nullptr, H1a, ld, R, -1, 0, ws.Z1[0], H, im.c1b},
-                           BwdItem{X1, ld, H, a.critic.w[4], H, -1, nullptr, H1b, ld, R, -1, 0, ws.Z1[1], H, im.c2b}};
-    bwd_stage<2>(lds, st, row0, nrows);
+    const BwdItem st[1] = {BwdItem{X0, ld, H, a.critic.w[3 * n + 1], H, -1, nullptr, H1a, ld, R, -1, 0, ws.Z1[n], H, n ? im.c2b : im.c1b}};
+    bwd_stage<1>(lds, st, row0, nrows);
   }
-  STEP_MARK(0, 8);
+  P1_MARK_C(8);
+#undef P1_MARK_T
+#undef P1_MARK_C
 }
 
 // ======================================================================================================== P3 =====
@@ -619,6 +627,7 @@ struct DwArgs {
   float* dw_mu[2]; float* dw_sigma[2]; float* db_mu[2]; float* db_sigma[2]; const float* w_eps[2]; const float* b_eps[2];
   // loss sums + temperature (the launch's last workgroup)
   const double* terms; int term0, nterms; double* sums;
+  const double* terms_b;                          // SAC's critic term is the sum of its two workgroups' shares (nullptr: terms alone)
   int alpha_step;
   double* log_alpha; double* alpha_m; double* alpha_v; double lr_alpha, abeta1, abeta2, aeps; double alpha_bias[2];
   const double* alpha_bias_dev; double* alpha_loss;
@@ -631,7 +640,8 @@ __global__ __launch_bounds__(256) void sac_dw_kernel(const DwArgs a) {
     // ---- the loss sums in the stand-alone kernels' order (offpolicy.hip block_partials with one block: thread t owns row t) ----
     double v[3] = {0.0, 0.0, 0.0};
     for (int b = threadIdx.x; b < a.B; b += 256)
-      for (int k = 0; k < a.nterms; ++k) v[k] += a.terms[(size_t)b * 3 + a.term0 + k];
+      for (int k = 0; k < a.nterms; ++k)
+        v[k] += (a.terms_b && a.term0 + k == 0) ? a.terms[(size_t)b * 3] + a.terms_b[b] : a.terms[(size_t)b * 3 + a.term0 + k];
     for (int k = 0; k < a.nterms; ++k) {
       const double s = wave_sum(v[k]);
       if (lane == 0) sm[k][wave] = s;
@@ -1225,7 +1235,7 @@ int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream_) {
   const int B = a.B, D = a.D, A = a.A, H = a.H, slabs = (B + 15) / 16;
   auto tiles = [](int N, int K) { return ((N + 15) / 16) * ((K + 15) / 16); };
 
-  hipLaunchKernelGGL(sac_p1_kernel, dim3(slabs, 2), dim3(kThreads), lds_bytes(H, 8), stream, a, ws);   // y: the target chain, then the critic chain
+  hipLaunchKernelGGL(sac_p1_kernel, dim3(slabs, 4), dim3(kThreads), lds_bytes(H, 8), stream, a, ws);   // y: the two target chains, the two critic chains
 
   DwArgs c{};
   int w0 = 0, ns = 0;
@@ -1253,7 +1263,7 @@ int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream_) {
   c.adam_dev = a.adam_critic_dev;
   c.omb1 = (float)(1.0 - a.beta1); c.beta2 = (float)a.beta2; c.omb2 = (float)(1.0 - a.beta2); c.eps = (float)a.eps_adam;
   c.tau = (float)a.tau; c.omt = (float)(1.0 - a.tau);
-  c.terms = ws.terms; c.term0 = 0; c.nterms = 1; c.sums = a.sums; c.alpha_step = 0;
+  c.terms = ws.terms; c.terms_b = ws.terms2; c.term0 = 0; c.nterms = 1; c.sums = a.sums; c.alpha_step = 0;
   hipLaunchKernelGGL(sac_dw_kernel, dim3((w0 + 3) / 4 + 1), dim3(256), 0, stream, c);
 
   hipLaunchKernelGGL(sac_p3_kernel, dim3(slabs, 2), dim3(kThreads), lds_bytes(H, 8), stream, a, ws);   // y: the actor + Q1, then Q2
