@@ -51,7 +51,7 @@ SYMBOLS = [
     "gymrl_mhc_read_fwd", "gymrl_mhc_read_bwd", "gymrl_mhc_combine_bwd",
     "gymrl_mhc_gates_bwd_workspace_bytes", "gymrl_mhc_gates_bwd", "gymrl_rmsnorm_bwd_workspace_bytes", "gymrl_rmsnorm_bwd", "gymrl_rmsnorm_sum_bwd", "gymrl_norm_proj_fwd", "gymrl_norm_proj_bwd_workspace_bytes", "gymrl_norm_proj_bwd",
     "gymrl_mhc_policy_forward", "gymrl_mhc_sub_forward", "gymrl_mhc_sub_backward", "gymrl_rollout_lunar_mhc",
-    "gymrl_sac_update_workspace_bytes", "gymrl_sac_args_bytes", "gymrl_sac_act_step", "gymrl_sac_update", "gymrl_sac_pack_images",
+    "gymrl_sac_update_workspace_bytes", "gymrl_sac_args_bytes", "gymrl_sac_act_step", "gymrl_sac_update", "gymrl_sac_step", "gymrl_sac_pack_images",
     "gymrl_rainbow_update_workspace_bytes", "gymrl_rainbow_args_bytes", "gymrl_rainbow_act_step", "gymrl_rainbow_update",
 ]
 

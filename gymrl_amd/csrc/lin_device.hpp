@@ -53,6 +53,48 @@ __host__ __device__ __forceinline__ int slab_ld(int K) { return ((K + 3) & ~3) +
 // 256 x 256 layer in ~6 us per stage; the MFMA chain is 0.85 us) — and the X operand comes from LDS step by step.
 constexpr int kMaxSteps = 16;
 
+// tile_fwd's vector branch (K1 == K, K % 4 == 0).  KC: the reduction length as a compile-time constant (0: take Kr — itself a
+// constant after inlining in the kernels built for one hidden width): with K = 256 known, the sixteen "beyond K?" tests, their
+// selects and the loop's exits fold away, which in a narrow layer's lone chain of 64 MFMAs was most of the instructions between them.
+template <int KC>
+__device__ __forceinline__ f32x4 tile_fwd_vec(const float* xrow, const float* wrow, int Kr, bool n_ok, int q) {
+  const int K = KC ? KC : Kr;
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  {
+    for (int kp = 0; kp < K; kp += 16 * kMaxSteps) {
+      f32x4 wb[kMaxSteps];
+#pragma unroll
+      for (int c = 0; c < kMaxSteps; ++c) {
+        if (kp + 16 * c >= K) break;                          // (wave-uniform)
+        const int k = kp + 16 * c + 4 * q;
+        wb[c] = *reinterpret_cast<const f32x4*>(wrow + (k < K ? k : 0));
+      }
+      // the X operand of step c + 2 is requested before step c's four MFMAs (a lone chain — a narrow layer is ONE tile on one
+      // wave — otherwise waits out an LDS round trip per step: 16 x ~120 clocks on top of the chain's 64 x 32)
+      auto xread = [&](int c) {
+        const int k = kp + 16 * c + 4 * q;
+        const bool k_ok = k < K;
+        const f32x4 xa = *reinterpret_cast<const f32x4*>(xrow + (k_ok ? k : 0));
+        return k_ok ? xa : zero;
+      };
+      f32x4 xq[2] = {xread(0), kp + 16 < K ? xread(1) : zero};
+#pragma unroll
+      for (int c = 0; c < kMaxSteps; ++c) {
+        if (kp + 16 * c >= K) break;
+        const bool k_ok = kp + 16 * c + 4 * q < K;
+        const f32x4 x = xq[c & 1];
+        if (c + 2 < kMaxSteps && kp + 16 * (c + 2) < K) xq[c & 1] = xread(c + 2);
+        const f32x4 w = (n_ok && k_ok) ? wb[c] : zero;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma16(x[e], w[e], acc);
+        __builtin_amdgcn_sched_barrier(0);                    // (the reads stay two steps ahead: hoisted to the top they spill)
+      }
+    }
+  }
+  return acc;
+}
+
 // acc = X . W[nb .. nb + 15]^T for the slab X = [Xs | X2s] ([16][K1] and [16][K - K1] in LDS; K1 == K: one block).
 // The order of lin_fwd_kernel: k0 = 0, 16, ...; e = 0..3; the MFMA adds k = k0 + 4q + e over q.  Rows beyond the slab's
 // valid rows must hold zeros (the callers zero-fill), columns n >= N and k >= K contribute exact zeros.
@@ -64,28 +106,8 @@ __device__ __forceinline__ f32x4 tile_fwd(const float* Xs, int ldx, const float*
   const bool n_ok = n < N;
   const float* wrow = W + (size_t)(n_ok ? n : 0) * K;
   const float* xrow = Xs + r * ldx;
-  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
   if (K1 == K && (K & 3) == 0) {
-    for (int kp = 0; kp < K; kp += 16 * kMaxSteps) {
-      f32x4 wb[kMaxSteps];
-#pragma unroll
-      for (int c = 0; c < kMaxSteps; ++c) {
-        if (kp + 16 * c >= K) break;                          // (wave-uniform)
-        const int k = kp + 16 * c + 4 * q;
-        wb[c] = *reinterpret_cast<const f32x4*>(wrow + (k < K ? k : 0));
-      }
-#pragma unroll
-      for (int c = 0; c < kMaxSteps; ++c) {
-        if (kp + 16 * c >= K) break;
-        const int k = kp + 16 * c + 4 * q;
-        const bool k_ok = k < K;
-        const f32x4 xa = *reinterpret_cast<const f32x4*>(xrow + (k_ok ? k : 0));
-        const f32x4 x = k_ok ? xa : zero;
-        const f32x4 w = (n_ok && k_ok) ? wb[c] : zero;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = mfma16(x[e], w[e], acc);
-      }
-    }
+    acc = tile_fwd_vec<0>(xrow, wrow, K, n_ok, q);           // (K is a constant after inlining where the kernel is built for one H)
   } else {
     const float* x2row = X2s ? X2s + r * ldx2 : nullptr;
     for (int k0 = 0; k0 < K; k0 += 16) {
@@ -148,18 +170,12 @@ __device__ __forceinline__ void tile_fwd_x2(const float* Xs0, const float* Xs1, 
 __device__ __forceinline__ f32x4 tile_bwd_input_pair(f32x4 acc, const float* dZa, const float* dZb, int ldz, int N,
                                                      const float* __restrict__ Wa, const float* __restrict__ Wb, int K, int kb, int lane);
 
-// acc += dZ . W[:, kb .. kb + 15] for the slab dZ [16][N] in LDS (already multiplied by the activation's derivative).
-// The order of lin_bwd_input_kernel: n0 = 0, 16, ...; e = 0..3; the MFMA adds n = n0 + 4q + e over q.  Calling it again
-// with another layer's dZ / W continues the same accumulator (the summed gradient of an input two layers share).
-__device__ __forceinline__ f32x4 tile_bwd_input(f32x4 acc, const float* dZs, int ldz, int N, const float* __restrict__ W, int K,
-                                                int kb, int lane) {
-  const int r = lane & 15, q = lane >> 4;
-  const int kc = kb + r;
-  const bool k_ok = kc < K;
-  const int kcol = k_ok ? kc : 0;
-  const float* zrow = dZs + r * ldz;
+// tile_bwd_input's vector branch (N % 4 == 0); NC: N as a compile-time constant (0: take Nr), as tile_fwd_vec's KC
+template <int NC>
+__device__ __forceinline__ f32x4 tile_bwd_input_vec(f32x4 acc, const float* zrow, int Nr, const float* __restrict__ W, int K, int kcol, bool k_ok, int q) {
+  const int N = NC ? NC : Nr;
   const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-  if ((N & 3) == 0) {
+  {
     for (int np = 0; np < N; np += 16 * kMaxSteps) {
       float wb[kMaxSteps][4];
 #pragma unroll
@@ -170,17 +186,39 @@ __device__ __forceinline__ f32x4 tile_bwd_input(f32x4 acc, const float* dZs, int
 #pragma unroll
         for (int e = 0; e < 4; ++e) wb[c][e] = W[(size_t)(ns + e) * K + kcol];
       }
-#pragma unroll
-      for (int c = 0; c < kMaxSteps; ++c) {
-        if (np + 16 * c >= N) break;
+      auto zread = [&](int c) {                               // (two steps ahead, as tile_fwd's X operand)
         const int n = np + 16 * c + 4 * q;
         const bool ok = n < N;
         const f32x4 za = *reinterpret_cast<const f32x4*>(zrow + (ok ? n : 0));
-        const f32x4 dz = ok ? za : zero;
+        return ok ? za : zero;
+      };
+      f32x4 zq[2] = {zread(0), np + 16 < N ? zread(1) : zero};
+#pragma unroll
+      for (int c = 0; c < kMaxSteps; ++c) {
+        if (np + 16 * c >= N) break;
+        const f32x4 dz = zq[c & 1];
+        if (c + 2 < kMaxSteps && np + 16 * (c + 2) < N) zq[c & 1] = zread(c + 2);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = mfma16(dz[e], k_ok ? wb[c][e] : 0.0f, acc);      // (as lin_bwd_input_kernel: the weight of a padded n is whatever row 0 holds, times an exact zero)
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+  }
+  return acc;
+}
+
+// acc += dZ . W[:, kb .. kb + 15] for the slab dZ [16][N] in LDS (already multiplied by the activation's derivative).
+// The order of lin_bwd_input_kernel: n0 = 0, 16, ...; e = 0..3; the MFMA adds n = n0 + 4q + e over q.  Calling it again
+// with another layer's dZ / W continues the same accumulator (the summed gradient of an input two layers share).
+__device__ __forceinline__ f32x4 tile_bwd_input(f32x4 acc, const float* dZs, int ldz, int N, const float* __restrict__ W, int K,
+                                                int kb, int lane) {
+  const int r = lane & 15, q = lane >> 4;
+  const int kc = kb + r;
+  const bool k_ok = kc < K;
+  const int kcol = k_ok ? kc : 0;
+  const float* zrow = dZs + r * ldz;
+  if ((N & 3) == 0) {
+    acc = tile_bwd_input_vec<0>(acc, zrow, N, W, K, kcol, k_ok, q);
   } else {
     for (int n0 = 0; n0 < N; n0 += 16) {
       const int n = n0 + 4 * q;
@@ -217,13 +255,18 @@ __device__ __forceinline__ f32x4 tile_bwd_input_pair(f32x4 acc, const float* dZa
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     const float* zrow = (half ? dZb : dZa) + r * ldz;
-#pragma unroll
-    for (int c = 0; c < kMaxSteps; ++c) {
-      if (16 * c >= N) break;
+    auto zread = [&](int c) {
       const int n = 16 * c + 4 * q;
       const bool ok = n < N;
       const f32x4 za = *reinterpret_cast<const f32x4*>(zrow + (ok ? n : 0));
-      const f32x4 dz = ok ? za : zero;
+      return ok ? za : zero;
+    };
+    f32x4 zq[2] = {zread(0), 16 < N ? zread(1) : zero};
+#pragma unroll
+    for (int c = 0; c < kMaxSteps; ++c) {
+      if (16 * c >= N) break;
+      const f32x4 dz = zq[c & 1];
+      if (c + 2 < kMaxSteps && 16 * (c + 2) < N) zq[c & 1] = zread(c + 2);
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc = mfma16(dz[e], k_ok ? (half ? wb[c][e] : wa[c][e]) : 0.0f, acc);
     }
@@ -247,7 +290,9 @@ __host__ __device__ __forceinline__ size_t img_bwd_index(int n, int k, int steps
 }
 
 // tile_fwd for K == N == 16 * steps from the forward image (K1 == K; same MFMA sequence as tile_fwd's vector branch)
-__device__ __forceinline__ f32x4 tile_fwd_img(const float* Xs, int ldx, int steps, const float* __restrict__ img, int tile, int lane) {
+template <int SC>
+__device__ __forceinline__ f32x4 tile_fwd_img_t(const float* Xs, int ldx, int steps_r, const float* __restrict__ img, int tile, int lane) {
+  const int steps = SC ? SC : steps_r;                       // (SC: the step count as a compile-time constant, as tile_fwd_vec's KC)
   const int r = lane & 15, q = lane >> 4;
   f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
   const f32x4* wp = reinterpret_cast<const f32x4*>(img) + (size_t)tile * steps * 64 + lane;
@@ -259,20 +304,29 @@ __device__ __forceinline__ f32x4 tile_fwd_img(const float* Xs, int ldx, int step
       if (cp + c >= steps) break;                             // (wave-uniform)
       wb[c] = wp[(size_t)(cp + c) * 64];
     }
+    f32x4 xq[2] = {*reinterpret_cast<const f32x4*>(xrow + 16 * cp), *reinterpret_cast<const f32x4*>(xrow + 16 * (cp + 1 < steps ? cp + 1 : cp))};
 #pragma unroll
     for (int c = 0; c < kMaxSteps; ++c) {
       if (cp + c >= steps) break;
-      const f32x4 x = *reinterpret_cast<const f32x4*>(xrow + 16 * (cp + c));
+      const f32x4 x = xq[c & 1];
+      if (c + 2 < kMaxSteps && cp + c + 2 < steps) xq[c & 1] = *reinterpret_cast<const f32x4*>(xrow + 16 * (cp + c + 2));
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc = mfma16(x[e], wb[c][e], acc);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   return acc;
 }
 
+__device__ __forceinline__ f32x4 tile_fwd_img(const float* Xs, int ldx, int steps, const float* __restrict__ img, int tile, int lane) {
+  return tile_fwd_img_t<0>(Xs, ldx, steps, img, tile, lane);
+}
+
 // tile_bwd_input for K == N == 16 * steps from the input-gradient image
-__device__ __forceinline__ f32x4 tile_bwd_input_img(f32x4 acc, const float* dZs, int ldz, int steps, const float* __restrict__ img, int ktile,
-                                                    int lane) {
+template <int SC>
+__device__ __forceinline__ f32x4 tile_bwd_input_img_t(f32x4 acc, const float* dZs, int ldz, int steps_r, const float* __restrict__ img, int ktile,
+                                                      int lane) {
+  const int steps = SC ? SC : steps_r;
   const int r = lane & 15, q = lane >> 4;
   const f32x4* wp = reinterpret_cast<const f32x4*>(img) + (size_t)ktile * steps * 64 + lane;
   const float* zrow = dZs + r * ldz + 4 * q;
@@ -283,15 +337,23 @@ __device__ __forceinline__ f32x4 tile_bwd_input_img(f32x4 acc, const float* dZs,
       if (cp + c >= steps) break;
       wb[c] = wp[(size_t)(cp + c) * 64];
     }
+    f32x4 zq[2] = {*reinterpret_cast<const f32x4*>(zrow + 16 * cp), *reinterpret_cast<const f32x4*>(zrow + 16 * (cp + 1 < steps ? cp + 1 : cp))};
 #pragma unroll
     for (int c = 0; c < kMaxSteps; ++c) {
       if (cp + c >= steps) break;
-      const f32x4 dz = *reinterpret_cast<const f32x4*>(zrow + 16 * (cp + c));
+      const f32x4 dz = zq[c & 1];
+      if (c + 2 < kMaxSteps && cp + c + 2 < steps) zq[c & 1] = *reinterpret_cast<const f32x4*>(zrow + 16 * (cp + c + 2));
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc = mfma16(dz[e], wb[c][e], acc);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   return acc;
+}
+
+__device__ __forceinline__ f32x4 tile_bwd_input_img(f32x4 acc, const float* dZs, int ldz, int steps, const float* __restrict__ img, int ktile,
+                                                    int lane) {
+  return tile_bwd_input_img_t<0>(acc, dZs, ldz, steps, img, ktile, lane);
 }
 
 // One 16 x 16 tile of dW = dZ^T X over rows [0, B) (dZ [B][ldz] column tile nt, X = [X | X2] column tile kb, all in global

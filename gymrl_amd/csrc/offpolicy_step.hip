@@ -31,7 +31,7 @@ constexpr int kWaves = 16, kThreads = 64 * kWaves;
 // Probe build only (make prof): 100 MHz wall-clock stamps at the stage boundaries of workgroup 0 (tools/probe_sac_stages.py)
 #ifdef GYMRL_PROF_BUILD
 __device__ long long g_step_prof[4][32];
-#define STEP_MARK(k, i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_step_prof[k][i] = (long long)wall_clock64(); } while (0)
+#define STEP_MARK(k, i) do { if (threadIdx.x == 0 && bx == 0) g_step_prof[k][i] = (long long)wall_clock64(); } while (0)
 #else
 #define STEP_MARK(k, i) do {} while (0)
 #endif
@@ -48,10 +48,11 @@ struct SacWs {
   double* terms2;                     // [B]: the second Q network's critic term (its workgroup's share of terms[.][0])
   float *xtq[2], *xmisc;              // P1: the two target networks' Q(s', a') columns [16 S] and {reward, done, logp'} [16 S][4], from the
                                       // target-chain workgroups to the critic-chain workgroups (each forms y itself)
+  unsigned int* sync;                 // [16]: gymrl_sac_step's phase counters (0 acting, 1 P1, 2 P2, 3 P3 done; 7 finished workgroups) — zero between launches
   unsigned int* flag;                 // [8][ceil(B / 16)]: hand-off flags (1 = waiting to be consumed; zero before the first launch, left zero):
                                       //   P1: 0 / 1 target network 1 -> critic workgroup 1 / 2, 5 / 6 target network 2 -> critic workgroup 1 / 2;
                                       //   P3: 2 / 3 Q1 / Q2, 4 the second network's dZ1 slab
-  float *xa, *xq[2], *xz;             // P3's exchanges: action [16 S][kMaxA], the two Q columns [16 S], dZ1 of network 2 [16 S][H]
+  float *xa, *xq[2], *xpart;          // P3's exchanges: action [16 S][kMaxA], the two Q columns [16 S], network 1's half of the d action chain [16 S][kMaxA]
   float *xmean, *xls, *xeps, *xlp;    // the actor step's sample (mean, log_std, eps [16 S][kMaxA], logp [16 S]): P1's critic-chain workgroup
                                       // computes it while it waits for y, P3 starts from it
   __host__ __device__ static size_t carve(SacWs* w, void* base, int B, int D, int A, int H) {
@@ -66,10 +67,11 @@ struct SacWs {
     double* terms2 = reinterpret_cast<double*>(take((size_t)B * 2));
     float* tq0 = take(S16); float* tq1 = take(S16); float* xmi = take(S16 * 4);
     unsigned int* fl = reinterpret_cast<unsigned int*>(take(8 * S16 / 16));
-    float* xa = take(S16 * 4); float* xq0 = take(S16); float* xq1 = take(S16); float* xz = take(S16 * H);
+    unsigned int* sy = reinterpret_cast<unsigned int*>(take(16));
+    float* xa = take(S16 * 4); float* xq0 = take(S16); float* xq1 = take(S16); float* xpart = take(S16 * 4);
     float* xm = take(S16 * 4); float* xl = take(S16 * 4); float* xe = take(S16 * 4); float* xp = take(S16);
     if (w) {
-      w->terms2 = terms2; w->xtq[0] = tq0; w->xtq[1] = tq1; w->xmisc = xmi; w->flag = fl; w->xa = xa; w->xq[0] = xq0; w->xq[1] = xq1; w->xz = xz;
+      w->terms2 = terms2; w->xtq[0] = tq0; w->xtq[1] = tq1; w->xmisc = xmi; w->flag = fl; w->sync = sy; w->xa = xa; w->xq[0] = xq0; w->xq[1] = xq1; w->xpart = xpart;
       w->xmean = xm; w->xls = xl; w->xeps = xe; w->xlp = xp;
       w->s = s; w->a = a;
       w->H1[0] = h[0]; w->H1[1] = h[1]; w->Z1[0] = h[2]; w->Z1[1] = h[3]; w->H2[0] = h[4]; w->H2[1] = h[5]; w->Z2[0] = h[6]; w->Z2[1] = h[7];
@@ -208,17 +210,80 @@ struct Lds {                          // float offsets of the small per-row slab
 };
 constexpr int kSmallFloats = 16 * (2 * kMaxD + 5 * kMaxA + 7 * 4);
 
+// The NARROW layers' parameters (fc1: [H][D (+ A)], the heads [A][H], fc3 [1][H], their biases) are copied into LDS slabs the
+// role does not use, at the start of the kernel and under the gather's own memory round trips: a narrow stage is one dependent
+// chain of <= 64 MFMAs (1 us) behind an L2 — right after a launch, HBM — round trip for its weights (1.5-2 us), and a step has a
+// dozen of them on its critical path.  Same values, same order: only where the operand is read from changes.
+struct Stager {
+  float* lds; int at;
+  int n = 0, total = 0;
+  static constexpr int kMaxSeg = 12;
+  const float* src[kMaxSeg]; int dst[kMaxSeg], cnt[kMaxSeg];
+  __device__ __forceinline__ const float* put(const float* s, int count) {      // reserve; run() copies
+    src[n] = s; dst[n] = at; cnt[n] = count; ++n;
+    total += count;
+    at += (count + 3) & ~3;                              // 16-byte rows for the f32x4 operand reads
+    return lds + dst[n - 1];
+  }
+  // every segment in ONE pass over the concatenation, four elements per thread in flight (as separate loops the segments'
+  // round trips followed one another: +2 us in front of the gather)
+  __device__ __forceinline__ void run() const {
+    for (int e0 = threadIdx.x; e0 < total; e0 += 4 * kThreads) {
+      float v[4]; int d[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int off = e0 + j * kThreads;
+        const bool live = off < total;
+        const float* p = src[0]; int base = dst[0]; bool found = false;
+#pragma unroll
+        for (int i = 0; i < kMaxSeg; ++i) {
+          if (i < n && !found) {
+            if (off < cnt[i]) { p = src[i] + off; base = dst[i] + off; found = true; }
+            else off -= cnt[i];
+          }
+        }
+        v[j] = live ? *p : 0.0f;
+        d[j] = live ? base : -1;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (d[j] >= 0) lds[d[j]] = v[j];
+    }
+  }
+};
+
 // ======================================================================================================== P1 =====
 // hand-off between the paired workgroups of a slab: the producer's data stores, a workgroup barrier, then ONE release store of
 // the flag; the consumer's thread 0 spins on it (agent scope), a workgroup barrier, the data is read with agent-scope loads,
 // and the consumer — the flag's only reader — clears it for the next launch
 __device__ __forceinline__ void flag_post(unsigned int* f) { __hip_atomic_store(f, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+// (polling with relaxed loads and ONE acquire fence at the end: an acquire per poll invalidates the compute unit's L1 and the
+// XCD's L2 lines each time round, under the workgroups that are streaming weights through them)
 __device__ __forceinline__ void flag_wait(unsigned int* f) {
-  while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1u) __builtin_amdgcn_s_sleep(2);
+  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) __builtin_amdgcn_s_sleep(2);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 __device__ __forceinline__ void flag_clear(unsigned int* f) { __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float xload(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void xstore(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// phase counters of the one-launch step (gymrl_sac_step): a workgroup that has finished a phase adds one with a release, after
+// every wave has waited for its own global stores and a workgroup barrier; a workgroup of a later phase spins until the
+// count is complete (acquire: what it then reads with plain loads is what the producers wrote), thread 0 for everybody
+__device__ __forceinline__ void phase_done(unsigned int* c) {
+  // __syncthreads() alone waits for LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): every wave first waits until its OWN
+  // global stores have reached the L2 (vmcnt(0)), then the barrier, then thread 0's release writes the L2 back and publishes
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void phase_wait(const unsigned int* c, unsigned int n) {
+  if (c) {
+    if (threadIdx.x == 0) {
+      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+  }
+}
 
 // Four workgroups per 16-row slab (blockIdx.y): ONE compute unit's f32 MFMA rate is what a slab's stage costs, so every
 // chain that does not depend on another runs on a compute unit of its own —
@@ -229,38 +294,60 @@ __device__ __forceinline__ void xstore(float* p, float v) { __hip_atomic_store(p
 //          the time it would otherwise wait.
 // All workgroups of every slab are resident (4 * B / 16 <= 64 of 256 CUs) and the producers wait for nobody: no deadlock.
 // Every flag has one writer and one reader, who clears it.  Same layers, same order per element as the per-layer path.
-__global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update_args a, const SacWs ws) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+// ring_ready / ring_n (the one-launch step): the acting workgroups of the same launch that must have written their replay rows
+// before this workgroup gathers (its index draw does not wait for them)
+template <int HC>
+__device__ __forceinline__ void sac_p1_body(const gymrl_sac_update_args& a, const SacWs& ws, float* lds, const int bx, const int role, const int S,
+                                            const unsigned int* ring_ready, unsigned int ring_n) {
   const Lds L;
-  const int D = a.D, A = a.A, H = a.H, ld = lin::slab_ld(H);
+  const int D = a.D, A = a.A, H = HC ? HC : a.H, ld = lin::slab_ld(H);      // HC: the hidden width this instance is built for (0: any)
   const int X0 = L.big, X1 = X0 + 16 * ld, H1a = X1 + 16 * ld, H1b = H1a + 16 * ld, H2a = H1b + 16 * ld, H2b = H2a + 16 * ld;
   const int T2a = H2b + 16 * ld, T2b = T2a + 16 * ld;
-  const int row0 = blockIdx.x * 16, nrows = min(16, a.B - row0);
+  const int row0 = bx * 16, nrows = min(16, a.B - row0);
   const int t = threadIdx.x;
-  const int role = blockIdx.y, S = gridDim.x;
   const bool target_chain = role < 2;
   const int n = role & 1;                                // which of the twin networks this workgroup carries
   const int R = GYMRL_ACT_RELU, NA = GYMRL_ACT_NONE, kD = kMaxD, kA = kMaxA;
   const Images im(a.images, H);
-  unsigned int* const f_t[2] = {ws.flag + (size_t)n * S + blockIdx.x, ws.flag + (size_t)(5 + n) * S + blockIdx.x};   // target net 1 / 2 -> critic workgroup n
+  unsigned int* const f_t[2] = {ws.flag + (size_t)n * S + bx, ws.flag + (size_t)(5 + n) * S + bx};   // target net 1 / 2 -> critic workgroup n
 #define P1_MARK_T(i) do { if (role == 0) STEP_MARK(3, i); } while (0)
 #define P1_MARK_C(i) do { if (role == 2) STEP_MARK(0, i); } while (0)
   // ---- 0: index draw + ring gather (one thread per row; rows beyond the batch are zero); each workgroup takes what its chain reads ----
   P1_MARK_T(0); P1_MARK_C(0);
+  // the narrow layers' parameters into slabs this role leaves free (Stager): target chain X0 / X1 / T2a busy, critic chain
+  // H1a / H2a / X0 (+ T2a / T2b in the workgroup that also runs the actor step's forward)
+  const float *aw0 = nullptr, *ab0 = nullptr, *aw2 = nullptr, *aw3 = nullptr, *ab2 = nullptr, *ab3 = nullptr;   // actor fc1, heads
+  const float *qw0, *qb0, *qw2, *qb2;                                                                            // this role's Q network: fc1, fc3
+  {
+    const gymrl_sac_critic_params& net = target_chain ? a.target : a.critic;
+    Stager sg{lds, target_chain ? H1a : X1};
+    qw0 = sg.put(net.w[3 * n], H * (D + A)); qb0 = sg.put(net.b[3 * n], H);
+    qw2 = sg.put(net.w[3 * n + 2], H); qb2 = sg.put(net.b[3 * n + 2], 1);
+    if (target_chain || n == 0) {
+      sg.at = H1b;
+      aw0 = sg.put(a.actor.w[0], H * D); ab0 = sg.put(a.actor.b[0], H);
+      sg.at = H2b;
+      aw2 = sg.put(a.actor.w[2], A * H); aw3 = sg.put(a.actor.w[3], A * H);
+      ab2 = sg.put(a.actor.b[2], A); ab3 = sg.put(a.actor.b[3], A);
+    }
+    sg.run();
+  }
+  int64_t row = 0;
+  if (t < nrows) {
+    const int b = row0 + t;
+    if (a.idx) row = a.idx[b];
+    else {
+      uint64_t counter = a.idx_counter; uint32_t size = (uint32_t)a.idx_size;
+      if (a.idx_dev) { const uint64_t* d = static_cast<const uint64_t*>(a.idx_dev); counter = d[0]; size = (uint32_t)(int64_t)d[1]; }
+      int bits = 2;
+      while (((int64_t)1 << bits) < (int64_t)size) ++bits;
+      row = keyed_permute((uint32_t)b, size, bits / 2, bits - bits / 2, a.idx_seed ^ 0x5265706C61794944ull, counter);
+    }
+  }
+  phase_wait(ring_ready, ring_n);
   if (t < 16) {
     const int b = row0 + t;
     const bool ok = t < nrows;
-    int64_t row = 0;
-    if (ok) {
-      if (a.idx) row = a.idx[b];
-      else {
-        uint64_t counter = a.idx_counter; uint32_t size = (uint32_t)a.idx_size;
-        if (a.idx_dev) { const uint64_t* d = static_cast<const uint64_t*>(a.idx_dev); counter = d[0]; size = (uint32_t)(int64_t)d[1]; }
-        int bits = 2;
-        while (((int64_t)1 << bits) < (int64_t)size) ++bits;
-        row = keyed_permute((uint32_t)b, size, bits / 2, bits - bits / 2, a.idx_seed ^ 0x5265706C61794944ull, counter);
-      }
-    }
     if (target_chain) {
       for (int k = 0; k < kMaxD; ++k) lds[L.S2 + t * kMaxD + k] = (ok && k < D) ? a.r_next[row * D + k] : 0.0f;
       const uint64_t ncounter = a.noise_counter_dev ? a.noise_counter_dev[0] : a.noise_counter;
@@ -289,7 +376,7 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
     P1_MARK_T(1);
     // ---- the actor on s' (:233) ----
     {
-      const FwdItem st[1] = {fwd_item(L.S2, kD, -1, 0, D, D, H, a.actor.w[0], a.actor.b[0], X0, ld, nullptr, 0, R)};
+      const FwdItem st[1] = {fwd_item(L.S2, kD, -1, 0, D, D, H, aw0, ab0, X0, ld, nullptr, 0, R)};
       fwd_stage<1>(lds, st, row0, nrows);
     }
     __syncthreads();
@@ -301,8 +388,8 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
     __syncthreads();
     P1_MARK_T(3);
     {
-      const FwdItem st[2] = {fwd_item(X1, ld, -1, 0, H, H, A, a.actor.w[2], a.actor.b[2], L.Mean, kA, nullptr, 0, NA),
-                             fwd_item(X1, ld, -1, 0, H, H, A, a.actor.w[3], a.actor.b[3], L.Ls, kA, nullptr, 0, GYMRL_ACT_CLAMP, a.log_std_min, a.log_std_max)};
+      const FwdItem st[2] = {fwd_item(X1, ld, -1, 0, H, H, A, aw2, ab2, L.Mean, kA, nullptr, 0, NA),
+                             fwd_item(X1, ld, -1, 0, H, H, A, aw3, ab3, L.Ls, kA, nullptr, 0, GYMRL_ACT_CLAMP, a.log_std_min, a.log_std_max)};
       fwd_stage<2>(lds, st, row0, nrows);
     }
     __syncthreads();
@@ -316,7 +403,7 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
     P1_MARK_T(5);
     // ---- target Q(s', a') of this workgroup's network (:235-236) ----
     {
-      const FwdItem st[1] = {fwd_item(L.S2, kD, L.A2, kA, D + A, D, H, a.target.w[3 * n], a.target.b[3 * n], X0, ld, nullptr, 0, R)};
+      const FwdItem st[1] = {fwd_item(L.S2, kD, L.A2, kA, D + A, D, H, qw0, qb0, X0, ld, nullptr, 0, R)};
       fwd_stage<1>(lds, st, row0, nrows);
     }
     __syncthreads();
@@ -328,7 +415,7 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
     __syncthreads();
     P1_MARK_T(7);
     {
-      const FwdItem st[1] = {fwd_item(T2a, ld, -1, 0, H, H, 1, a.target.w[3 * n + 2], a.target.b[3 * n + 2], L.Q0, 4, nullptr, 0, NA)};
+      const FwdItem st[1] = {fwd_item(T2a, ld, -1, 0, H, H, 1, qw2, qb2, L.Q0, 4, nullptr, 0, NA)};
       fwd_stage<1>(lds, st, row0, nrows);
     }
     __syncthreads();
@@ -340,14 +427,14 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
       }
     }
     __syncthreads();
-    if (t == 0) { flag_post(ws.flag + (size_t)(n ? 5 : 0) * S + blockIdx.x); flag_post(ws.flag + (size_t)(n ? 6 : 1) * S + blockIdx.x); }
+    if (t == 0) { flag_post(ws.flag + (size_t)(n ? 5 : 0) * S + bx); flag_post(ws.flag + (size_t)(n ? 6 : 1) * S + bx); }
     P1_MARK_T(9);
     return;
   }
   P1_MARK_C(1);
   // ---- Q(s, a) of this workgroup's network (:239) ----
   {
-    const FwdItem st[1] = {fwd_item(L.S, kD, L.A, kA, D + A, D, H, a.critic.w[3 * n], a.critic.b[3 * n], H1a, ld, ws.H1[n], H, R)};
+    const FwdItem st[1] = {fwd_item(L.S, kD, L.A, kA, D + A, D, H, qw0, qb0, H1a, ld, ws.H1[n], H, R)};
     fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
@@ -359,7 +446,7 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
   __syncthreads();
   P1_MARK_C(3);
   {
-    const FwdItem st[1] = {fwd_item(H2a, ld, -1, 0, H, H, 1, a.critic.w[3 * n + 2], a.critic.b[3 * n + 2], L.Cq0, 4, nullptr, 0, NA)};
+    const FwdItem st[1] = {fwd_item(H2a, ld, -1, 0, H, H, 1, qw2, qb2, L.Cq0, 4, nullptr, 0, NA)};
     fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
@@ -380,7 +467,7 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
       }
     }
     {
-      const FwdItem st[1] = {fwd_item(L.S, kD, -1, 0, D, D, H, a.actor.w[0], a.actor.b[0], AH1, ld, ws.aH1, H, R)};
+      const FwdItem st[1] = {fwd_item(L.S, kD, -1, 0, D, D, H, aw0, ab0, AH1, ld, ws.aH1, H, R)};
       fwd_stage<1>(lds, st, row0, nrows);
     }
     __syncthreads();
@@ -390,8 +477,8 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
     }
     __syncthreads();
     {
-      const FwdItem st[2] = {fwd_item(AH2, ld, -1, 0, H, H, A, a.actor.w[2], a.actor.b[2], L.Mean, kA, nullptr, 0, NA),
-                             fwd_item(AH2, ld, -1, 0, H, H, A, a.actor.w[3], a.actor.b[3], L.Ls, kA, nullptr, 0, GYMRL_ACT_CLAMP, a.log_std_min, a.log_std_max)};
+      const FwdItem st[2] = {fwd_item(AH2, ld, -1, 0, H, H, A, aw2, ab2, L.Mean, kA, nullptr, 0, NA),
+                             fwd_item(AH2, ld, -1, 0, H, H, A, aw3, ab3, L.Ls, kA, nullptr, 0, GYMRL_ACT_CLAMP, a.log_std_min, a.log_std_max)};
       fwd_stage<2>(lds, st, row0, nrows);
     }
     __syncthreads();
@@ -431,7 +518,7 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
   P1_MARK_C(6);
   // ---- input-gradient chain of this Q network (what q.backward() computes before the weight gradients) ----
   {
-    const BwdItem st[1] = {BwdItem{L.Dq0, 4, 1, a.critic.w[3 * n + 2], H, -1, nullptr, H2a, ld, R, X0, ld, ws.Z2[n], H, nullptr}};
+    const BwdItem st[1] = {BwdItem{L.Dq0, 4, 1, qw2, H, -1, nullptr, H2a, ld, R, X0, ld, ws.Z2[n], H, nullptr}};
     bwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
@@ -445,26 +532,36 @@ __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update
 #undef P1_MARK_C
 }
 
-// ======================================================================================================== P3 =====
-// Two workgroups per slab here as well (blockIdx.y): workgroup 0 runs the actor, Q1 and the way back through the actor,
-// workgroup 1 only Q2 — forward from the action workgroup 0 has sampled, backward to its first layer's dZ.  They exchange
-// the action (0 -> 1), the two Q columns (both ways: the min's tie rule needs both) and network 2's dZ1 slab (1 -> 0), because
-// d action is ONE accumulator chain over both networks in the per-layer path (Q1's terms, then Q2's): workgroup 0 runs it.
-__global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update_args a, const SacWs ws) {
+template <int HC>
+__global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update_args a, const SacWs ws) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  sac_p1_body<HC>(a, ws, lds, blockIdx.x, blockIdx.y, gridDim.x, nullptr, 0u);
+}
+
+// ======================================================================================================== P3 =====
+// Two workgroups per slab here as well (blockIdx.y), both starting from the sample P1 saved: workgroup 0 carries Q2 and the
+// way back through the actor, workgroup 1 (the helper) only Q1 — forward, backward to its first layer's dZ.  They exchange
+// the two Q columns (both ways: the min's tie rule needs both) and the helper's half of d action (1 -> 0): d action is ONE
+// accumulator chain over both networks in the per-layer path (Q1's terms, then Q2's), so the helper runs Q1's half and
+// workgroup 0 goes on from its 16 x A partial sums.
+// rows_ready / critic_ready (the one-launch step): P1's and P2's phase counters — the saved sample and slabs are P1's, the
+// critic's parameters P2's; what does not need the updated critic is loaded before the second wait
+template <int HC>
+__device__ __forceinline__ void sac_p3_body(const gymrl_sac_update_args& a, const SacWs& ws, float* lds, const int bx, const int by, const int S,
+                                            const unsigned int* rows_ready, unsigned int rows_n, const unsigned int* critic_ready, unsigned int critic_n) {
   const Lds L;
-  const int D = a.D, A = a.A, H = a.H, ld = lin::slab_ld(H);
+  const int D = a.D, A = a.A, H = HC ? HC : a.H, ld = lin::slab_ld(H);      // HC: the hidden width this instance is built for (0: any)
   const int X0 = L.big, X1 = X0 + 16 * ld, H1a = X1 + 16 * ld, H1b = H1a + 16 * ld, H2a = H1b + 16 * ld, H2b = H2a + 16 * ld;
   const int AH1 = H2b + 16 * ld, AH2 = AH1 + 16 * ld;
-  const int row0 = blockIdx.x * 16, nrows = min(16, a.B - row0);
+  const int row0 = bx * 16, nrows = min(16, a.B - row0);
   const int t = threadIdx.x;
-  const bool second = blockIdx.y == 1;                   // the workgroup that carries Q2
-  const int S = gridDim.x;
-  unsigned int* f_q[2] = {ws.flag + 2 * S + blockIdx.x, ws.flag + 3 * S + blockIdx.x};
-  unsigned int* f_dz = ws.flag + 4 * S + blockIdx.x;
+  const bool helper = by == 1;                           // the workgroup that carries Q1 only; workgroup 0: the actor and Q2
+  unsigned int* f_q[2] = {ws.flag + 2 * S + bx, ws.flag + 3 * S + bx};
+  unsigned int* f_dz = ws.flag + 4 * S + bx;
   const int R = GYMRL_ACT_RELU, NA = GYMRL_ACT_NONE, kD = kMaxD, kA = kMaxA;
   const Images im(a.images, H);
-  if (!second) STEP_MARK(1, 0);
+  if (!helper) STEP_MARK(1, 0);
+  phase_wait(rows_ready, rows_n);
   // the batch's states and the actor step's sample (a, logp, mean, log_std, eps: P1 computed them); workgroup 0 also takes the
   // actor's two activation slabs back for the way home
   if (t < 16) {
@@ -474,11 +571,11 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
     const size_t o = (size_t)(row0 + t) * kMaxA;
     for (int j = 0; j < kMaxA; ++j) {
       lds[L.A + t * kMaxA + j] = ws.xa[o + j];
-      if (!second) { lds[L.Mean + t * kMaxA + j] = ws.xmean[o + j]; lds[L.Ls + t * kMaxA + j] = ws.xls[o + j]; lds[L.Eps + t * kMaxA + j] = ws.xeps[o + j]; }
+      if (!helper) { lds[L.Mean + t * kMaxA + j] = ws.xmean[o + j]; lds[L.Ls + t * kMaxA + j] = ws.xls[o + j]; lds[L.Eps + t * kMaxA + j] = ws.xeps[o + j]; }
     }
-    if (!second) lds[L.Misc + t * 4 + 2] = ws.xlp[row0 + t];
+    if (!helper) lds[L.Misc + t * 4 + 2] = ws.xlp[row0 + t];
   }
-  if (!second) {
+  if (!helper) {
     for (int e = t; e < 16 * H; e += kThreads) {
       const int rr = e / H, c = e % H;
       const bool ok = rr < nrows;
@@ -486,29 +583,38 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
       lds[AH2 + rr * ld + c] = ok ? ws.aH2[(size_t)(row0 + rr) * H + c] : 0.0f;
     }
   }
+  phase_wait(critic_ready, critic_n);
+  // the narrow layers' parameters into a slab this workgroup leaves free (Stager): its Q network's fc1 and fc3 — forward, and
+  // fc1 again as the d action chain's operand — and, for the way home, the actor's heads
+  const int n = helper ? 0 : 1;
+  const int H1n = n ? H1b : H1a, H2n = n ? H2b : H2a, Xn = n ? X1 : X0, Qn = n ? L.Q1 : L.Q0, Dqn = n ? L.Dq1 : L.Dq0;
+  Stager sg{lds, n ? H1a : H1b};
+  const float* qw0 = sg.put(a.critic.w[3 * n], H * (D + A)); const float* qb0 = sg.put(a.critic.b[3 * n], H);
+  const float* qw2 = sg.put(a.critic.w[3 * n + 2], H); const float* qb2 = sg.put(a.critic.b[3 * n + 2], 1);
+  const float *aw2 = nullptr, *aw3 = nullptr;
+  if (!helper) { sg.at = H2a; aw2 = sg.put(a.actor.w[2], A * H); aw3 = sg.put(a.actor.w[3], A * H); }
+  sg.run();
   __syncthreads();
-  if (!second) STEP_MARK(1, 1);
+  if (!helper) STEP_MARK(1, 1);
   // ---- Q(s, a) of the critic P2 has just updated (:249-250): this workgroup's network ----
-  const int n = second ? 1 : 0;
-  const int H1n = second ? H1b : H1a, H2n = second ? H2b : H2a, Xn = second ? X1 : X0, Qn = second ? L.Q1 : L.Q0, Dqn = second ? L.Dq1 : L.Dq0;
   {
-    const FwdItem st[1] = {fwd_item(L.S, kD, L.A, kA, D + A, D, H, a.critic.w[3 * n], a.critic.b[3 * n], H1n, ld, nullptr, 0, R)};
+    const FwdItem st[1] = {fwd_item(L.S, kD, L.A, kA, D + A, D, H, qw0, qb0, H1n, ld, nullptr, 0, R)};
     fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
-  if (!second) STEP_MARK(1, 2);
+  if (!helper) STEP_MARK(1, 2);
   {
-    const FwdItem st[1] = {fwd_item(H1n, ld, -1, 0, H, H, H, a.critic.w[3 * n + 1], a.critic.b[3 * n + 1], H2n, ld, nullptr, 0, R, 0.0f, 0.0f, second ? im.c2f : im.c1f)};
+    const FwdItem st[1] = {fwd_item(H1n, ld, -1, 0, H, H, H, a.critic.w[3 * n + 1], a.critic.b[3 * n + 1], H2n, ld, nullptr, 0, R, 0.0f, 0.0f, n ? im.c2f : im.c1f)};
     fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
-  if (!second) STEP_MARK(1, 3);
+  if (!helper) STEP_MARK(1, 3);
   {
-    const FwdItem st[1] = {fwd_item(H2n, ld, -1, 0, H, H, 1, a.critic.w[3 * n + 2], a.critic.b[3 * n + 2], Qn, 4, nullptr, 0, NA)};
+    const FwdItem st[1] = {fwd_item(H2n, ld, -1, 0, H, H, 1, qw2, qb2, Qn, 4, nullptr, 0, NA)};
     fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
-  if (!second) STEP_MARK(1, 4);
+  if (!helper) STEP_MARK(1, 4);
   // the two Q columns meet: each workgroup posts its own, takes the other's
   if (t < 16) xstore(ws.xq[n] + row0 + t, lds[Qn + t * 4]);
   __syncthreads();
@@ -517,12 +623,13 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
   float dlogp = 0.0f;
   if (t < 16) {                         // offpolicy.hip sac_actor_kernel
     const float other = xload(ws.xq[1 - n] + row0 + t);
-    const float qa = second ? other : lds[L.Q0 + t * 4], qc = second ? lds[L.Q1 + t * 4] : other;
+    const float own = lds[Qn + t * 4];
+    const float qa = n ? other : own, qc = n ? own : other;            // Q1, Q2
     const float invB = 1.0f / (float)a.B;
     const float w1 = qa < qc ? 1.0f : (qa == qc ? 0.5f : 0.0f);          // torch.min tie rule
-    const float dn = second ? -(1.0f - w1) * invB : -w1 * invB;
+    const float dn = n ? -(1.0f - w1) * invB : -w1 * invB;
     for (int k = 0; k < 4; ++k) lds[Dqn + t * 4 + k] = k == 0 ? dn : 0.0f;
-    if (!second) {
+    if (!helper) {
       const float alpha = (float)exp(a.log_alpha[0]);
       const float lp = lds[L.Misc + t * 4 + 2];
       dlogp = alpha * invB;
@@ -534,41 +641,52 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
   }
   __syncthreads();
   if (t == 0) flag_clear(f_q[1 - n]);
-  if (!second) STEP_MARK(1, 5);
+  if (!helper) STEP_MARK(1, 5);
   // ---- back through this workgroup's Q network to its first layer (the parameters are frozen here: no weight gradients) ----
   {
-    const BwdItem st[1] = {BwdItem{Dqn, 4, 1, a.critic.w[3 * n + 2], H, -1, nullptr, H2n, ld, R, Xn, ld, nullptr, 0, nullptr}};
+    const BwdItem st[1] = {BwdItem{Dqn, 4, 1, qw2, H, -1, nullptr, H2n, ld, R, Xn, ld, nullptr, 0, nullptr}};
     bwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
-  if (!second) STEP_MARK(1, 6);
+  if (!helper) STEP_MARK(1, 6);
   {
-    const BwdItem st[1] = {BwdItem{Xn, ld, H, a.critic.w[3 * n + 1], H, -1, nullptr, H1n, ld, R, H2n, ld, nullptr, 0, second ? im.c2b : im.c1b}};
+    const BwdItem st[1] = {BwdItem{Xn, ld, H, a.critic.w[3 * n + 1], H, -1, nullptr, H1n, ld, R, H2n, ld, nullptr, 0, n ? im.c2b : im.c1b}};
     bwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
-  if (second) {                         // network 2's dZ1 slab goes to workgroup 0, which runs the one d action chain
-    for (int e = t; e < 16 * H; e += kThreads) xstore(ws.xz + (size_t)(row0 + e / H) * H + e % H, lds[H2b + (e / H) * ld + e % H]);
-    __syncthreads();
-    if (t == 0) flag_post(f_dz);
-    return;
-  }
-  STEP_MARK(1, 7);
-  if (t == 0) flag_wait(f_dz);
-  __syncthreads();
-  for (int e = t; e < 16 * H; e += kThreads) lds[H2b + (e / H) * ld + e % H] = xload(ws.xz + (size_t)(row0 + e / H) * H + e % H);
-  __syncthreads();
-  if (t == 0) flag_clear(f_dz);
-  // d action = the action columns of (dZ1_Q1 . W1_Q1 + dZ1_Q2 . W1_Q2): ONE accumulator over both networks (the layers share their input)
+  // d action = the action columns of (dZ1_Q1 . W1_Q1 + dZ1_Q2 . W1_Q2): ONE accumulator over both networks (the layers share their
+  // input), network 1's terms first.  The helper runs its half of the chain and hands the 16 x A partial sums over (wave 0's own
+  // stores, published by its lane 0's release); workgroup 0 goes on from them with network 2's terms — the same MFMA sequence
+  // per element as the one-workgroup chain, and 16 x A floats cross instead of a 16 x H slab.
   {
     const int lane = t & 63, wave = t >> 6, r = lane & 15, q = lane >> 4;
+    const bool mine = r >= D && r < D + A;
+    if (helper) {
+      if (wave == 0) {
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        acc = lin::tile_bwd_input(acc, lds + H2n, ld, H, qw0, D + A, 0, lane);
+        if (mine) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) xstore(ws.xpart + (size_t)(row0 + 4 * q + g) * kMaxA + (r - D), acc[g]);
+        }
+        if (lane == 0) flag_post(f_dz);
+      }
+      return;
+    }
+    STEP_MARK(1, 7);
     if (wave == 0) {
+      if (lane == 0) flag_wait(f_dz);
       f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-      acc = lin::tile_bwd_input_pair(acc, lds + H2a, lds + H2b, ld, H, a.critic.w[0], a.critic.w[3], D + A, 0, lane);
-      if (r >= D && r < D + A) {
+      if (mine) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = xload(ws.xpart + (size_t)(row0 + 4 * q + g) * kMaxA + (r - D));
+      }
+      acc = lin::tile_bwd_input(acc, lds + H2n, ld, H, qw0, D + A, 0, lane);
+      if (mine) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) lds[L.A2 + (4 * q + g) * kMaxA + (r - D)] = acc[g];
       }
+      if (lane == 0) flag_clear(f_dz);
     }
   }
   __syncthreads();
@@ -595,7 +713,7 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
   STEP_MARK(1, 9);
   // ---- back through the actor: heads (one summed input gradient), fc2 ----
   {
-    const BwdItem st[1] = {BwdItem{L.Dq0, 4, A, a.actor.w[2], H, L.Dq1, a.actor.w[3], AH2, ld, R, X0, ld, ws.aZ2, H, nullptr}};
+    const BwdItem st[1] = {BwdItem{L.Dq0, 4, A, aw2, H, L.Dq1, aw3, AH2, ld, R, X0, ld, ws.aZ2, H, nullptr}};
     bwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
@@ -605,6 +723,12 @@ __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update
     bwd_stage<1>(lds, st, row0, nrows);
   }
   STEP_MARK(1, 11);
+}
+
+template <int HC>
+__global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update_args a, const SacWs ws) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  sac_p3_body<HC>(a, ws, lds, blockIdx.x, blockIdx.y, gridDim.x, nullptr, 0u, nullptr, 0u);
 }
 
 // ================================================================================================= P2 / P4 =====
@@ -633,18 +757,21 @@ struct DwArgs {
   const double* alpha_bias_dev; double* alpha_loss;
 };
 
-__global__ __launch_bounds__(256) void sac_dw_kernel(const DwArgs a) {
-  __shared__ double sm[3][4];
+// One wave per 16 x 16 tile of a weight gradient + its Adam step; the last block of the group sums the loss terms (its first
+// 256 threads: the stand-alone kernels' order) and steps the temperature.  block / nblocks: this block's place in the group.
+__device__ __forceinline__ void sac_dw_body(const DwArgs& a, const int block, const int nblocks, double (*sm)[4]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
-  if (blockIdx.x == gridDim.x - 1) {
+  if (block == nblocks - 1) {
     // ---- the loss sums in the stand-alone kernels' order (offpolicy.hip block_partials with one block: thread t owns row t) ----
     double v[3] = {0.0, 0.0, 0.0};
-    for (int b = threadIdx.x; b < a.B; b += 256)
-      for (int k = 0; k < a.nterms; ++k)
-        v[k] += (a.terms_b && a.term0 + k == 0) ? a.terms[(size_t)b * 3] + a.terms_b[b] : a.terms[(size_t)b * 3 + a.term0 + k];
-    for (int k = 0; k < a.nterms; ++k) {
-      const double s = wave_sum(v[k]);
-      if (lane == 0) sm[k][wave] = s;
+    if (threadIdx.x < 256) {
+      for (int b = threadIdx.x; b < a.B; b += 256)
+        for (int k = 0; k < a.nterms; ++k)
+          v[k] += (a.terms_b && a.term0 + k == 0) ? a.terms[(size_t)b * 3] + a.terms_b[b] : a.terms[(size_t)b * 3 + a.term0 + k];
+      for (int k = 0; k < a.nterms; ++k) {
+        const double s = wave_sum(v[k]);
+        if (lane == 0) sm[k][wave] = s;
+      }
     }
     __syncthreads();
     if ((int)threadIdx.x < a.nterms) {
@@ -669,7 +796,7 @@ __global__ __launch_bounds__(256) void sac_dw_kernel(const DwArgs a) {
     }
     return;
   }
-  const int gw = blockIdx.x * 4 + wave;
+  const int gw = block * (int)(blockDim.x >> 6) + wave;
   if (gw >= a.total_waves) return;
   int si = 0;
 #pragma unroll
@@ -745,15 +872,25 @@ __global__ __launch_bounds__(256) void sac_dw_kernel(const DwArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void sac_dw_kernel(const DwArgs a) {
+  __shared__ double sm[3][4];
+  sac_dw_body(a, blockIdx.x, gridDim.x, sm);
+}
+
 // ==================================================================================================== acting =====
-__global__ __launch_bounds__(kThreads) void sac_act_kernel(const gymrl_sac_act_args a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+template <int HC>
+__device__ __forceinline__ void sac_act_body(const gymrl_sac_act_args& a, float* lds, const int bx) {
   const Lds L;
-  const int D = a.D, A = a.A, H = a.H, ld = lin::slab_ld(H);
+  const int D = a.D, A = a.A, H = HC ? HC : a.H, ld = lin::slab_ld(H);      // HC: the hidden width this instance is built for (0: any)
   const int X0 = L.big, X1 = X0 + 16 * ld;
-  const int row0 = blockIdx.x * 16, nrows = min(16, a.N - row0);
+  const int row0 = bx * 16, nrows = min(16, a.N - row0);
   const int t = threadIdx.x;
   STEP_MARK(2, 0);
+  Stager sg{lds, X1 + 16 * ld};                          // (slabs 2, 3)
+  const float* w0 = sg.put(a.actor.w[0], H * D); const float* b0 = sg.put(a.actor.b[0], H);
+  const float* w2 = sg.put(a.actor.w[2], A * H); const float* w3 = sg.put(a.actor.w[3], A * H);
+  const float* b2 = sg.put(a.actor.b[2], A); const float* b3 = sg.put(a.actor.b[3], A);
+  sg.run();
   if (t < 16) {
     const int i = row0 + t;
     const bool ok = t < nrows;
@@ -770,7 +907,7 @@ __global__ __launch_bounds__(kThreads) void sac_act_kernel(const gymrl_sac_act_a
   const int R = GYMRL_ACT_RELU, kD = kMaxD, kA = kMaxA;
   const Images im(a.images, H);
   {
-    const FwdItem st[1] = {fwd_item(L.S, kD, -1, 0, D, D, H, a.actor.w[0], a.actor.b[0], X0, ld, nullptr, 0, R)};
+    const FwdItem st[1] = {fwd_item(L.S, kD, -1, 0, D, D, H, w0, b0, X0, ld, nullptr, 0, R)};
     fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
@@ -782,8 +919,8 @@ __global__ __launch_bounds__(kThreads) void sac_act_kernel(const gymrl_sac_act_a
   __syncthreads();
   STEP_MARK(2, 3);
   {
-    const FwdItem st[2] = {fwd_item(X1, ld, -1, 0, H, H, A, a.actor.w[2], a.actor.b[2], L.Mean, kA, nullptr, 0, GYMRL_ACT_NONE),
-                           fwd_item(X1, ld, -1, 0, H, H, A, a.actor.w[3], a.actor.b[3], L.Ls, kA, nullptr, 0, GYMRL_ACT_CLAMP, a.log_std_min, a.log_std_max)};
+    const FwdItem st[2] = {fwd_item(X1, ld, -1, 0, H, H, A, w2, b2, L.Mean, kA, nullptr, 0, GYMRL_ACT_NONE),
+                           fwd_item(X1, ld, -1, 0, H, H, A, w3, b3, L.Ls, kA, nullptr, 0, GYMRL_ACT_CLAMP, a.log_std_min, a.log_std_max)};
     fwd_stage<2>(lds, st, row0, nrows);
   }
   __syncthreads();
@@ -819,6 +956,74 @@ __global__ __launch_bounds__(kThreads) void sac_act_kernel(const gymrl_sac_act_a
     accumulate_ep_stats(a.ep_stats, r.done && ok, r.ret, r.len);
   }
   STEP_MARK(2, 5);
+}
+
+template <int HC>
+__global__ __launch_bounds__(kThreads) void sac_act_kernel(const gymrl_sac_act_args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  sac_act_body<HC>(a, lds, blockIdx.x);
+}
+
+// ======================================================================================== the step as ONE launch =====
+// gymrl_sac_step: acting + env step + replay rows, then the whole update, in one grid.  Block ranges are the five phases in
+// order (acting | P1: 4 per slab | P2: critic tiles | P3: 2 per slab | P4: actor tiles); a phase that needs an earlier one
+// complete spins on that phase's counter (phase_wait) — a launch boundary's 3-4 us become ~1 us, and what a phase can do
+// before it needs its predecessor (P1's index draw: 6 Philox-keyed Feistel rounds; P3's loads of the saved sample and the
+// actor's slabs) is hidden behind it.  No deadlock: the acting blocks wait for nobody, every wait is on an earlier range, and
+// the blocks that can wait (at most 4 + 2 per slab + the tile blocks: < 150 at B = 256) are fewer than the 256 compute units,
+// so whatever order the dispatcher takes, the blocks a waiter needs get a unit.  The last block to finish (a ticket) clears
+// the counters: the workspace is as zero after the launch as before it.
+struct SacStepArgs {
+  gymrl_sac_act_args act; gymrl_sac_update_args upd; SacWs ws; DwArgs c, p;
+  int n_act, slabs, c_blocks, p_blocks;
+};
+static_assert(sizeof(SacStepArgs) <= 4096, "kernel arguments");
+
+template <int HC>
+__global__ __launch_bounds__(kThreads) void sac_step_kernel(const SacStepArgs by_value) {
+  // read in place from the kernel-argument segment (the struct is the first argument): as a by-value object the dynamic
+  // indices into its pointer tables made hipcc copy all of it into every lane's scratch (3.5 KB per lane)
+  const SacStepArgs& s = *(const SacStepArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ double sm[3][4];
+  unsigned int* const sync = s.ws.sync;
+  const int S = s.slabs;
+  int b = blockIdx.x;
+  if (b < s.n_act) {
+    sac_act_body<HC>(s.act, lds, b);
+    phase_done(sync + 0);
+  } else if ((b -= s.n_act) < 4 * S) {
+    const int role = b / S;
+    sac_p1_body<HC>(s.upd, s.ws, lds, b - role * S, role, S, sync + 0, (unsigned)s.n_act);
+    if (role >= 2) phase_done(sync + 1);
+  } else if ((b -= 4 * S) < s.c_blocks) {
+    [[maybe_unused]] const int bx = b;                 // (probe build: stamps of the group's first block)
+    STEP_MARK(2, 16);
+    phase_wait(sync + 1, 2u * S);
+    STEP_MARK(2, 17);
+    sac_dw_body(s.c, b, s.c_blocks, sm);
+    phase_done(sync + 2);
+    STEP_MARK(2, 18);
+  } else if ((b -= s.c_blocks) < 2 * S) {
+    const int by = b / S;
+    sac_p3_body<HC>(s.upd, s.ws, lds, b - by * S, by, S, sync + 1, 2u * S, sync + 2, (unsigned)s.c_blocks);
+    if (by == 0) phase_done(sync + 3);
+  } else {
+    b -= 2 * S;
+    [[maybe_unused]] const int bx = b;
+    STEP_MARK(2, 19);
+    phase_wait(sync + 3, (unsigned)S);
+    STEP_MARK(2, 20);
+    sac_dw_body(s.p, b, s.p_blocks, sm);
+    STEP_MARK(2, 21);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (__hip_atomic_fetch_add(sync + 7, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+      for (int k = 0; k < 4; ++k) __hip_atomic_store(sync + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sync + 7, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // ============================================================================================== Rainbow =====
@@ -1108,19 +1313,25 @@ int gymrl_step_prof_read(long long* out_host) {      // probe build only: [4][32
 
 size_t gymrl_sac_args_bytes(int which) { return which == 0 ? sizeof(gymrl_sac_act_args) : which == 1 ? sizeof(gymrl_sac_update_args) : 0; }
 
+static bool sac_act_args_ok(const gymrl_sac_act_args& a) {
+  if (a.N <= 0 || !sac_shape_ok(1, a.D, a.A, a.H) || a.env_kind != GYMRL_ENV_PENDULUM || a.D != 3 || a.A != 1) return false;
+  if (!a.env_state || !a.obs || !a.obs_out || !a.r_state || !a.r_action || !a.r_reward || !a.r_next || !a.r_flag || a.cap < a.N) return false;
+  for (int k = 0; k < 4; ++k) if (!a.actor.w[k] || !a.actor.b[k]) return false;
+  return true;
+}
+
 int gymrl_sac_act_step(const gymrl_sac_act_args* args, void* stream_) {
   if (!args) return -22;
   const gymrl_sac_act_args& a = *args;
-  if (a.N <= 0 || !sac_shape_ok(1, a.D, a.A, a.H) || a.env_kind != GYMRL_ENV_PENDULUM || a.D != 3 || a.A != 1) return -22;
-  if (!a.env_state || !a.obs || !a.obs_out || !a.r_state || !a.r_action || !a.r_reward || !a.r_next || !a.r_flag || a.cap < a.N) return -22;
-  for (int k = 0; k < 4; ++k) if (!a.actor.w[k] || !a.actor.b[k]) return -22;
+  if (!sac_act_args_ok(a)) return -22;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)sac_act_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(256, 2)) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)sac_act_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(256, 4)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)sac_act_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(256, 4)) != hipSuccess)
       return -1000 - (int)hipGetLastError();
     attr_set = true;
   }
-  hipLaunchKernelGGL(sac_act_kernel, dim3((a.N + 15) / 16), dim3(kThreads), lds_bytes(a.H, 2), (hipStream_t)stream_, a);
+  hipLaunchKernelGGL(a.H == 256 ? sac_act_kernel<256> : sac_act_kernel<0>, dim3((a.N + 15) / 16), dim3(kThreads), lds_bytes(a.H, 4), (hipStream_t)stream_, a);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
@@ -1212,32 +1423,32 @@ int gymrl_sac_pack_images(const gymrl_sac_update_args* args, void* stream_) {
   return 0;
 }
 
-int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream_) {
-  if (!args) return -22;
-  const gymrl_sac_update_args& a = *args;
-  if (!sac_shape_ok(a.B, a.D, a.A, a.H)) return -22;
+static bool sac_update_args_ok(const gymrl_sac_update_args& a) {
+  if (!sac_shape_ok(a.B, a.D, a.A, a.H)) return false;
   if (!a.r_state || !a.r_action || !a.r_reward || !a.r_next || !a.r_flag || !a.workspace || !a.sums || !a.log_alpha || !a.alpha_m || !a.alpha_v ||
       !a.actor_p || !a.actor_m || !a.actor_v || !a.critic_p || !a.critic_m || !a.critic_v || (!a.idx && a.idx_size < a.B))
-    return -22;
-  for (int k = 0; k < 4; ++k) if (!a.actor.w[k] || !a.actor.b[k]) return -22;
-  for (int k = 0; k < 6; ++k) if (!a.critic.w[k] || !a.critic.b[k] || !a.target.w[k] || !a.target.b[k]) return -22;
-  hipStream_t stream = (hipStream_t)stream_;
+    return false;
+  for (int k = 0; k < 4; ++k) if (!a.actor.w[k] || !a.actor.b[k]) return false;
+  for (int k = 0; k < 6; ++k) if (!a.critic.w[k] || !a.critic.b[k] || !a.target.w[k] || !a.target.b[k]) return false;
+  return true;
+}
+
+static int sac_set_lds_attr() {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)sac_p1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(256, 8)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)sac_p3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(256, 8)) != hipSuccess)
-      return -1000 - (int)hipGetLastError();
+    const void* fns[6] = {(const void*)sac_p1_kernel<0>, (const void*)sac_p1_kernel<256>, (const void*)sac_p3_kernel<0>, (const void*)sac_p3_kernel<256>,
+                          (const void*)sac_step_kernel<0>, (const void*)sac_step_kernel<256>};
+    for (const void* f : fns)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(256, 8)) != hipSuccess) return -1000 - (int)hipGetLastError();
     attr_set = true;
   }
-  SacWs ws;
-  void* base = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(a.workspace) + 255) & ~(uintptr_t)255);
-  SacWs::carve(&ws, base, a.B, a.D, a.A, a.H);
-  const int B = a.B, D = a.D, A = a.A, H = a.H, slabs = (B + 15) / 16;
+  return 0;
+}
+
+// The tile lists of P2 (critic: c) and P4 (actor + temperature: p)
+static void sac_build_dw(const gymrl_sac_update_args& a, const SacWs& ws, DwArgs& c, DwArgs& p) {
+  const int B = a.B, D = a.D, A = a.A, H = a.H;
   auto tiles = [](int N, int K) { return ((N + 15) / 16) * ((K + 15) / 16); };
-
-  hipLaunchKernelGGL(sac_p1_kernel, dim3(slabs, 4), dim3(kThreads), lds_bytes(H, 8), stream, a, ws);   // y: the two target chains, the two critic chains
-
-  DwArgs c{};
   int w0 = 0, ns = 0;
   const bool use_img = a.images && (a.H & 15) == 0;
   const size_t hh = (size_t)a.H * a.H;
@@ -1251,6 +1462,7 @@ int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream_) {
     w0 += tiles(N, K);
   };
   // critic: launch order of the layer-by-layer backward is irrelevant here (tiles are independent); fc1/fc4, fc2/fc5, fc3/fc6
+  c = DwArgs{};
   for (int i = 0; i < 2; ++i) {
     seg(c, ws.Z1[i], H, H, ws.s, D, ws.a, A, D + A, D, a.critic.w[3 * i], a.critic.b[3 * i], a.target.w[3 * i], a.target.b[3 * i]);
     seg(c, ws.Z2[i], H, H, ws.H1[i], H, nullptr, 0, H, H, a.critic.w[3 * i + 1], a.critic.b[3 * i + 1], a.target.w[3 * i + 1], a.target.b[3 * i + 1],
@@ -1264,11 +1476,8 @@ int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream_) {
   c.omb1 = (float)(1.0 - a.beta1); c.beta2 = (float)a.beta2; c.omb2 = (float)(1.0 - a.beta2); c.eps = (float)a.eps_adam;
   c.tau = (float)a.tau; c.omt = (float)(1.0 - a.tau);
   c.terms = ws.terms; c.terms_b = ws.terms2; c.term0 = 0; c.nterms = 1; c.sums = a.sums; c.alpha_step = 0;
-  hipLaunchKernelGGL(sac_dw_kernel, dim3((w0 + 3) / 4 + 1), dim3(256), 0, stream, c);
 
-  hipLaunchKernelGGL(sac_p3_kernel, dim3(slabs, 2), dim3(kThreads), lds_bytes(H, 8), stream, a, ws);   // y: the actor + Q1, then Q2
-
-  DwArgs p{};
+  p = DwArgs{};
   w0 = 0; ns = 0;
   seg(p, ws.aZ1, H, H, ws.s, D, nullptr, 0, D, D, a.actor.w[0], a.actor.b[0], nullptr, nullptr);
   seg(p, ws.aZ2, H, H, ws.aH1, H, nullptr, 0, H, H, a.actor.w[1], a.actor.b[1], nullptr, nullptr, img(0), img(5), nullptr);
@@ -1284,7 +1493,44 @@ int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream_) {
   p.log_alpha = a.log_alpha; p.alpha_m = a.alpha_m; p.alpha_v = a.alpha_v; p.lr_alpha = a.lr_alpha;
   p.abeta1 = 0.9; p.abeta2 = 0.999; p.aeps = 1e-8;
   p.alpha_bias[0] = a.alpha_bias[0]; p.alpha_bias[1] = a.alpha_bias[1]; p.alpha_bias_dev = a.alpha_bias_dev; p.alpha_loss = a.alpha_loss;
-  hipLaunchKernelGGL(sac_dw_kernel, dim3((w0 + 3) / 4 + 1), dim3(256), 0, stream, p);
+}
+
+int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream_) {
+  if (!args) return -22;
+  const gymrl_sac_update_args& a = *args;
+  if (!sac_update_args_ok(a)) return -22;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (const int rc = sac_set_lds_attr()) return rc;
+  SacWs ws;
+  void* base = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(a.workspace) + 255) & ~(uintptr_t)255);
+  SacWs::carve(&ws, base, a.B, a.D, a.A, a.H);
+  const int H = a.H, slabs = (a.B + 15) / 16;
+  DwArgs c, p;
+  sac_build_dw(a, ws, c, p);
+  // (the instances built for the reference's hidden width 256 know every reduction length at compile time)
+  hipLaunchKernelGGL(H == 256 ? sac_p1_kernel<256> : sac_p1_kernel<0>, dim3(slabs, 4), dim3(kThreads), lds_bytes(H, 8), stream, a, ws);   // y: the two target chains, the two critic chains
+  hipLaunchKernelGGL(sac_dw_kernel, dim3((c.total_waves + 3) / 4 + 1), dim3(256), 0, stream, c);
+  hipLaunchKernelGGL(H == 256 ? sac_p3_kernel<256> : sac_p3_kernel<0>, dim3(slabs, 2), dim3(kThreads), lds_bytes(H, 8), stream, a, ws);   // y: the actor + Q2, then Q1
+  hipLaunchKernelGGL(sac_dw_kernel, dim3((p.total_waves + 3) / 4 + 1), dim3(256), 0, stream, p);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_sac_step(const gymrl_sac_act_args* act_args, const gymrl_sac_update_args* upd_args, void* stream_) {
+  if (!act_args || !upd_args) return -22;
+  const gymrl_sac_act_args& a = *act_args;
+  const gymrl_sac_update_args& u = *upd_args;
+  if (!sac_act_args_ok(a) || !sac_update_args_ok(u) || a.H != u.H) return -22;
+  if (const int rc = sac_set_lds_attr()) return rc;
+  SacStepArgs s;
+  s.act = a; s.upd = u;
+  void* base = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(u.workspace) + 255) & ~(uintptr_t)255);
+  SacWs::carve(&s.ws, base, u.B, u.D, u.A, u.H);
+  sac_build_dw(u, s.ws, s.c, s.p);
+  s.n_act = (a.N + 15) / 16; s.slabs = (u.B + 15) / 16;
+  s.c_blocks = (s.c.total_waves + kWaves - 1) / kWaves + 1; s.p_blocks = (s.p.total_waves + kWaves - 1) / kWaves + 1;
+  const int blocks = s.n_act + 6 * s.slabs + s.c_blocks + s.p_blocks;
+  hipLaunchKernelGGL(u.H == 256 ? sac_step_kernel<256> : sac_step_kernel<0>, dim3(blocks), dim3(kThreads), lds_bytes(u.H, 8), (hipStream_t)stream_, s);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

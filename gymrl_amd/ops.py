@@ -1335,7 +1335,8 @@ def sac_fused_shape_ok(B, D, A, H):
 
 
 def sac_update_workspace(B, D, A, H, device):
-    # zeroed: the hand-off flags between gymrl_sac_update's paired workgroups live in it (zero before the first launch, left zero)
+    # zeroed: the hand-off flags between the row phases' workgroups and gymrl_sac_step's phase counters live in it (zero before
+    # the first launch, left zero)
     return torch.zeros(int(lib().gymrl_sac_update_workspace_bytes(C.c_int(B), C.c_int(D), C.c_int(A), C.c_int(H))),
                        dtype=torch.uint8, device=device)
 
@@ -1365,15 +1366,17 @@ def sac_act_args(env, actor, ring, cap, bound, log_std_min, log_std_max, images=
 
 
 def sac_act_step(a, env, obs, obs_out, cursor=0, cursor_dev=None, eps=None, noise_seed=0, noise_counter=0, noise_counter_dev=None,
-                 action_out=None, rew_out=None, done_out=None, ep_ret_out=None, ep_stats=None):
+                 action_out=None, rew_out=None, done_out=None, ep_ret_out=None, ep_stats=None, launch=True):
     """gymrl_sac_act_step: Actor forward on obs [N, D], reparameterised draw, env step with auto-reset, replay rows at
-    (cursor + env) % cap — ONE launch (sac_pendulum.py:278-283)."""
+    (cursor + env) % cap — ONE launch (sac_pendulum.py:278-283).  launch=False: the arguments are filled in only (sac_step
+    launches them together with the update's)."""
     a.env_seed = env.seed                              # reset(seed=...) may have moved it
     a.obs, a.obs_out, a.eps = _ptr(obs, torch.float32).value, _ptr(obs_out, torch.float32).value, _addr(eps)
     a.noise_seed, a.noise_counter, a.noise_counter_dev = noise_seed, noise_counter, _addr(noise_counter_dev)
     a.cursor, a.cursor_dev = cursor, _addr(cursor_dev)
     a.action_out, a.rew_out, a.done_out, a.ep_ret_out, a.ep_stats = (_addr(t) for t in (action_out, rew_out, done_out, ep_ret_out, ep_stats))
-    check(lib().gymrl_sac_act_step(C.byref(a), _stream()), "gymrl_sac_act_step")
+    if launch:
+        check(lib().gymrl_sac_act_step(C.byref(a), _stream()), "gymrl_sac_act_step")
 
 
 def sac_images(H, device):
@@ -1410,9 +1413,10 @@ def sac_update_args(B, D, A, actor, critic, target, actor_opt, critic_opt, ring,
 
 def sac_update(a, idx=None, idx_seed=0, idx_counter=0, idx_size=0, idx_dev=None, eps_next=None, eps_cur=None, noise_seed=0,
                noise_counter=0, noise_counter_dev=None, adam_critic=None, adam_actor=None, adam_critic_dev=None, adam_actor_dev=None,
-               alpha_bias=(1.0, 1.0), alpha_bias_dev=None):
+               alpha_bias=(1.0, 1.0), alpha_bias_dev=None, launch=True):
     """gymrl_sac_update: SACTrainer.update() (sac_pendulum.py:213-267) as four launches.  adam_critic / adam_actor: the
-    16-byte blocks of adam_bias() (host) or device views of them; alpha_bias = (1 - 0.9^t, 1 - 0.999^t)."""
+    16-byte blocks of adam_bias() (host) or device views of them; alpha_bias = (1 - 0.9^t, 1 - 0.999^t).  launch=False: the
+    arguments are filled in only (sac_step)."""
     a.idx, a.idx_seed, a.idx_counter, a.idx_size, a.idx_dev = _addr(idx), idx_seed, idx_counter, idx_size, _addr(idx_dev)
     a.eps_next, a.eps_cur = _addr(eps_next), _addr(eps_cur)
     a.noise_seed, a.noise_counter, a.noise_counter_dev = noise_seed, noise_counter, _addr(noise_counter_dev)
@@ -1423,7 +1427,14 @@ def sac_update(a, idx=None, idx_seed=0, idx_counter=0, idx_size=0, idx_dev=None,
                 dst[k] = vals[k]
     a.adam_critic_dev, a.adam_actor_dev = _addr(adam_critic_dev), _addr(adam_actor_dev)
     a.alpha_bias[0], a.alpha_bias[1], a.alpha_bias_dev = alpha_bias[0], alpha_bias[1], _addr(alpha_bias_dev)
-    check(lib().gymrl_sac_update(C.byref(a), _stream()), "gymrl_sac_update")
+    if launch:
+        check(lib().gymrl_sac_update(C.byref(a), _stream()), "gymrl_sac_update")
+
+
+def sac_step(act, upd):
+    """gymrl_sac_step: the acting step and the update whose arguments sac_act_step(..., launch=False) and
+    sac_update(..., launch=False) have filled in, as ONE launch."""
+    check(lib().gymrl_sac_step(C.byref(act), C.byref(upd), _stream()), "gymrl_sac_step")
 
 
 # --------------------------------------------- fused Rainbow vector step ---

@@ -9,6 +9,7 @@ forward+backward, the float64 log_alpha Adam step, the three fused Adam steps an
 Polyak update are HIP kernels behind the C-ABI; Linear layers run through PyTorch-ROCm.
 """
 import copy
+import os
 from collections import deque
 
 import numpy as np
@@ -49,6 +50,8 @@ class Config:
         self.fused_step = True             # a vector step = 5 launches (csrc/offpolicy_step.hip: acting + env + append in one, the
         #                                    update in four) instead of ~60; bit-identical to the layer-by-layer path, which remains
         #                                    for shapes beyond the kernels' limits (hidden_dim > 256, batch > 256) and custom envs
+        self.one_launch_step = os.environ.get("GYMRL_SAC_ONE_LAUNCH", "1") != "0"   # ... and inside a replayed chunk ONE launch: gymrl_sac_step, the five phases as block ranges
+        #                                    of one grid that hand over through counters in the workspace (bit-identical)
         self.chunk_steps = 0               # 16: whole vector steps as one hipGraph per 16 (graphs.StepChunk).  Measured slower
         #                                    here (0.37 vs 0.29 ms per step at N = 4096, B = 128): SAC's step is GPU-bound, and
         #                                    the executor's cost per graph node grows with the graph (944 nodes per chunk)
@@ -220,14 +223,15 @@ class SACTrainer:
                 self._img_versions = v
         return self._fused
 
-    def _update_fused(self, indices=None, eps_next=None, eps_cur=None, dev=None):
+    def _update_fused(self, indices=None, eps_next=None, eps_cur=None, dev=None, launch=True):
         """update() as gymrl_sac_update's four launches.  dev = (draw, adam_c, adam_a, alpha, noise) device records of a
-        StepChunk replay; None: this call's scalars travel as arguments and the host counters advance here."""
+        StepChunk replay; None: this call's scalars travel as arguments and the host counters advance here.  launch=False: the
+        arguments are prepared only (ops.sac_step issues them with the acting step's)."""
         m = self.memory
         upd = self._fused_args()[1]
         if dev is not None:
             ops.sac_update(upd, idx_seed=m.seed, idx_dev=dev[0], adam_critic_dev=dev[1], adam_actor_dev=dev[2], alpha_bias_dev=dev[3],
-                           noise_seed=self.base_seed, noise_counter_dev=dev[4], idx_size=m.capacity)
+                           noise_seed=self.base_seed, noise_counter_dev=dev[4], idx_size=m.capacity, launch=launch)
             return
         if indices is None:
             counter, size = m.draws, m.size
@@ -239,7 +243,7 @@ class SACTrainer:
         t = self._alpha_steps
         ops.sac_update(upd, idx=indices, idx_seed=m.seed, idx_counter=counter, idx_size=size, eps_next=eps_next, eps_cur=eps_cur,
                        noise_seed=self.base_seed, noise_counter=self._upd_noise, adam_critic=self.critic_optimizer.next_bias(),
-                       adam_actor=self.actor_optimizer.next_bias(), alpha_bias=(1.0 - 0.9 ** t, 1.0 - 0.999 ** t))
+                       adam_actor=self.actor_optimizer.next_bias(), alpha_bias=(1.0 - 0.9 ** t, 1.0 - 0.999 ** t), launch=launch)
 
     @torch.no_grad()
     def select_action(self, state, deterministic=False, eps=None):
@@ -375,8 +379,9 @@ class SACTrainer:
         lb["tracker"].k, lb["tracker"].episodes = 0, 0
         return lb
 
-    def _vector_step(self, lb, obs, nxt, ep_ret, done, cursor_dev=None, noise_dev=None):
-        """One vector step of :269-310 up to (not including) the update."""
+    def _vector_step(self, lb, obs, nxt, ep_ret, done, cursor_dev=None, noise_dev=None, launch=True):
+        """One vector step of :269-310 up to (not including) the update.  launch=False (fused path only): the acting launch's
+        arguments are prepared and the caller issues them together with the update's (ops.sac_step)."""
         cfg, env = self.cfg, self.env
         if self._fused_ok():               # forward + draw + env step + ring row: one launch
             m = self.memory
@@ -385,7 +390,7 @@ class SACTrainer:
                 self._act_noise += 1
             ops.sac_act_step(self._fused_args()[0], env, obs, nxt, cursor=m.cursor, cursor_dev=cursor_dev, eps=eps,
                              noise_seed=self.base_seed, noise_counter=self._act_noise, noise_counter_dev=noise_dev,
-                             rew_out=lb["rew"], done_out=done, ep_ret_out=ep_ret, ep_stats=env.ep_stats)
+                             rew_out=lb["rew"], done_out=done, ep_ret_out=ep_ret, ep_stats=env.ep_stats, launch=launch)
             if cursor_dev is None:
                 m.advance(env.n)
             return
@@ -404,9 +409,13 @@ class SACTrainer:
         ch, tr = self._chunk, lb["tracker"]
         obs, nxt = (lb["obs"], lb["nxt"]) if j % 2 == 0 else (lb["nxt"], lb["obs"])
         if self._fused_ok():
-            self._vector_step(lb, obs, nxt, tr.ret[j], tr.done[j], cursor_dev=ch.view(j, "push"), noise_dev=ch.view(j, "noise_a"))
+            one = bool(getattr(self.cfg, "one_launch_step", True))       # acting + update as ONE launch (gymrl_sac_step)
+            self._vector_step(lb, obs, nxt, tr.ret[j], tr.done[j], cursor_dev=ch.view(j, "push"), noise_dev=ch.view(j, "noise_a"),
+                              launch=not one)
             self._update_fused(dev=(ch.view(j, "draw"), ch.view(j, "adam_c", torch.float32), ch.view(j, "adam_a", torch.float32),
-                                    ch.view(j, "alpha", torch.float64), ch.view(j, "noise_u")))
+                                    ch.view(j, "alpha", torch.float64), ch.view(j, "noise_u")), launch=not one)
+            if one:
+                ops.sac_step(*self._fused_args()[:2])
             return
         self._vector_step(lb, obs, nxt, tr.ret[j], tr.done[j], cursor_dev=ch.view(j, "push"))
         self.memory.draw_indices(self.cfg.batch_size, out=self._g_idx, dev=ch.view(j, "draw"))

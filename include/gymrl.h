@@ -1048,7 +1048,8 @@ int gymrl_reward_scaling(const float* r, const uint8_t* done, int N, double gamm
 
 /* ============================================ fused off-policy vector step ===== */
 /*
- * One SAC vector step of sac_pendulum.py:269-310 as FIVE launches instead of ~60 (csrc/offpolicy_step.hip; round 3's step:
+ * One SAC vector step of sac_pendulum.py:269-310 as ONE launch (gymrl_sac_step) or five (gymrl_sac_act_step + gymrl_sac_update's
+ * four) instead of ~60 (csrc/offpolicy_step.hip; round 3's step:
  * 3 gymrl_lin_fwd + sample + env step + append + index draw + gather + ~45 layer / loss / optimiser launches of 4-14 us).
  * A forward or input-gradient pass never mixes batch rows, so ONE workgroup carries a 16-row slab of the batch through a
  * whole chain of layers in LDS (tile bodies of csrc/lin_device.hpp: the very MFMA sequence of gymrl_lin_*), and only the
@@ -1063,6 +1064,11 @@ int gymrl_reward_scaling(const float* r, const uint8_t* done, int N, double gamm
  *     P3 rows   a, logp = Actor.sample(s); Q(s, a) of the UPDATED critic; actor loss gradient; the chain back through both
  *               Q networks to the action, through the sample, through the actor
  *     P4 tiles  actor weight gradients + Adam; actor loss / temperature sums; the float64 temperature step
+ *   gymrl_sac_step       gymrl_sac_act_step followed by gymrl_sac_update in ONE grid: the five phases are block ranges, a phase
+ *                        that needs an earlier one complete waits on that phase's counter in the workspace (release / acquire at
+ *                        device scope) instead of a launch boundary, and does before the wait what does not depend on it (P1's index
+ *                        draw, P3's loads).  The blocks that can wait are fewer than the compute units, so the blocks they wait
+ *                        for always get one; the last block to finish zeroes the counters.  Same arguments, same results.
  * Results are those of the layer-by-layer path bit for bit (same products, same orders; tests/test_fused_step_gpu.py), which
  * tests/test_trainers_gpu.py pins against the reference.  Limits: H % 4 == 0, H <= 256, D <= 8, A <= 4, B <= 256
  * (-22 otherwise: use the layer-by-layer path).  Pointers are device pointers; W = [out][in] row-major (nn.Linear).
@@ -1106,7 +1112,8 @@ typedef struct {
   double* sums;                            /* f64[3] out: critic loss sum, actor loss sum, sum of (logp + target_entropy) */
   double* alpha_loss;                      /* f64[1] out or NULL */
   void* workspace;                         /* >= gymrl_sac_update_workspace_bytes(B, D, A, H); ZEROED once before the first call (the
-                                            * hand-off flags between the row phase's paired workgroups live in it and are left zero) */
+                                            * hand-off flags between the row phases' workgroups and gymrl_sac_step's phase counters
+                                            * live in it and are left zero) */
   /* Weight images of the H x H layers (H % 16 == 0), f32[8][H*H], or NULL (every layer read in place).  The MFMA operands of
    * actor.fc2, critic.fc2 / fc5, target.fc2 / fc5 (forward) and actor.fc2, critic.fc2 / fc5 (input gradient) as contiguous
    * 1 KiB blocks per wave-wide load (csrc/lin_device.hpp): a slab kernel streams a whole weight matrix through one compute
@@ -1119,6 +1126,7 @@ int gymrl_sac_pack_images(const gymrl_sac_update_args* args, void* stream);
 size_t gymrl_sac_args_bytes(int which);      /* sizeof(gymrl_sac_act_args) (0) / sizeof(gymrl_sac_update_args) (1): a binding checks its mirror */
 int gymrl_sac_act_step(const gymrl_sac_act_args* args, void* stream);
 int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream);
+int gymrl_sac_step(const gymrl_sac_act_args* act, const gymrl_sac_update_args* update, void* stream);   /* both, one launch */
 
 /*
  * The same treatment for Rainbow's vector step (rainbow_dqn_cartpole.py:363-405; csrc/offpolicy_step.hip).  The NoisyLinear

@@ -85,17 +85,31 @@ def test_sac_fused_update_matches_reference_update():
         assert err <= 5e-6, (name, err)
 
 
-def test_sac_fused_step_is_five_launches():
-    """What the fusion is for: a vector step of the chunked graph is 5 kernel nodes (acting; rows; tiles; rows; tiles)."""
+def test_sac_fused_step_is_one_launch_and_equals_its_five():
+    """What the fusion is for: a vector step of the chunked graph is ONE kernel node (gymrl_sac_step: acting | rows | tiles |
+    rows | tiles as block ranges of one grid, handing over through counters in the workspace) — and what it computes is what
+    the five launches it replaces compute, bit for bit (48 launches in a row: the counters come back to zero each time)."""
     from gymrl_amd.sac_pendulum import Config, SACTrainer
-    cfg = Config()
-    cfg.num_envs, cfg.batch_size, cfg.seed, cfg.max_episodes, cfg.memory_capacity = 256, 128, 1, 10 ** 9, 1 << 14
-    tr = SACTrainer(cfg)
-    tr.train(max_vector_steps=64)
-    torch.cuda.synchronize()
-    assert tr._fused_ok() and tr._chunk is not None and tr._chunk.graph is not None
-    assert all(torch.isfinite(getattr(tr, n)).all() for n in ("actor_flat", "critic_flat", "log_alpha"))
-    assert tr.critic_optimizer.step_count >= 60
+    outs = []
+    for one, (N, B, hidden) in [(o, shp) for shp in ((256, 128, 256), (4100, 256, 256), (40, 24, 32)) for o in (True, False)]:
+        cfg = Config()
+        cfg.num_envs, cfg.batch_size, cfg.hidden_dim, cfg.seed, cfg.max_episodes = N, B, hidden, 1, 10 ** 9
+        cfg.memory_capacity, cfg.one_launch_step = max(1 << 14, 2 * N), one
+        torch.manual_seed(3)
+        tr = SACTrainer(cfg)
+        tr.train(max_vector_steps=64)
+        torch.cuda.synchronize()
+        assert tr._fused_ok() and tr._chunk is not None and tr._chunk.graph is not None
+        assert all(torch.isfinite(getattr(tr, n)).all() for n in ("actor_flat", "critic_flat", "log_alpha"))
+        assert tr.critic_optimizer.step_count >= 48
+        outs.append(tr)
+        if not one:
+            a, b = outs[-2], outs[-1]
+            for name in ("actor_flat", "critic_flat", "critic_target_flat", "log_alpha", "_alpha_m", "_alpha_v", "_sums"):
+                assert torch.equal(getattr(a, name), getattr(b, name)), (N, B, hidden, name)
+            for x, y in zip(a.memory.ring, b.memory.ring):
+                assert torch.equal(x, y)
+            assert list(a.episode_rewards) == list(b.episode_rewards)
 
 
 def _run_rainbow(fused, steps, N, B, hidden, graphs=False, chunk=0):
