@@ -1070,10 +1070,11 @@ constexpr int kRbMaxA = 3;
 // unit's f32 MFMA rate makes of its items (three 256 x 256 layers per stage on one CU before).  Workgroups 1 and 2 publish
 // their head outputs ([16][4]) with release flags; workgroup 0, whose own forward takes as long, consumes them, clears the
 // flags and runs the loss and the way back.  All three are resident (3 * B / 16 <= 48 of 256 CUs), the producers wait for nobody.
+template <int HC>                       // HC: the hidden width this instance is built for (0: any), as the SAC kernels'
 __global__ __launch_bounds__(kThreads) void rainbow_rows_kernel(const gymrl_rainbow_update_args a, const RbWs ws) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const Lds L;
-  const int D = a.D, A = a.A, A1 = a.A + 1, H = a.H, ld = lin::slab_ld(H);
+  const int D = a.D, A = a.A, A1 = a.A + 1, H = HC ? HC : a.H, ld = lin::slab_ld(H);
   const int H1 = L.big, H2 = H1 + 16 * ld, X0 = H2 + 16 * ld;
   // head outputs of the three passes: [16][4] slabs in the small area (Q0, Q1, Cq0), dS in Dq0
   const int Za = L.Q0, Zb = L.Q1, Zc = L.Cq0, DS = L.Dq0;
@@ -1195,11 +1196,11 @@ __device__ __forceinline__ void act_layer(float* lds, int X, int ldx, int K, con
   }
 }
 
-template <int NS>
+template <int NS, int HC>
 __global__ __launch_bounds__(kThreads) void rainbow_act_kernel(const gymrl_rainbow_act_args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int kRows = 16 * NS;
-  const int D = a.D, A = a.A, A1 = a.A + 1, H = a.H, ld = lin::slab_ld(H);
+  const int D = a.D, A = a.A, A1 = a.A + 1, H = HC ? HC : a.H, ld = lin::slab_ld(H);
   const int S = 0, Q = S + kRows * kMaxD, X0 = Q + kRows * 4, X1 = X0 + kRows * ld;
   const int row0 = blockIdx.x * kRows, nrows = min(kRows, a.N - row0);
   const int t = threadIdx.x;
@@ -1353,16 +1354,21 @@ int gymrl_rainbow_act_step(const gymrl_rainbow_act_args* args, void* stream_) {
   auto act_lds = [](int H, int ns) { return sizeof(float) * (size_t)(16 * ns * (kMaxD + 4 + 2 * lin::slab_ld(H))); };
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)rainbow_act_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)act_lds(256, 1)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)rainbow_act_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)act_lds(256, 2)) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)rainbow_act_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)act_lds(256, 1)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)rainbow_act_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)act_lds(256, 2)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)rainbow_act_kernel<1, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)act_lds(256, 1)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)rainbow_act_kernel<2, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)act_lds(256, 2)) != hipSuccess)
       return -1000 - (int)hipGetLastError();
     attr_set = true;
   }
+  using ActK = void (*)(const gymrl_rainbow_act_args);
+  const ActK k1 = rainbow_act_kernel<1, 0>, k2 = rainbow_act_kernel<2, 0>, k1w = rainbow_act_kernel<1, 256>, k2w = rainbow_act_kernel<2, 256>;
+  const bool wide = a.H == 256;      // the instances built for the reference's hidden width
   // more envs than one round of 16-row workgroups over the 256 compute units: 32 rows per workgroup (weights streamed once)
   if (a.N > 16 * 256 && (a.D & 3) == 0 && (a.H & 3) == 0)
-    hipLaunchKernelGGL(rainbow_act_kernel<2>, dim3((a.N + 31) / 32), dim3(kThreads), act_lds(a.H, 2), (hipStream_t)stream_, a);
+    hipLaunchKernelGGL(wide ? k2w : k2, dim3((a.N + 31) / 32), dim3(kThreads), act_lds(a.H, 2), (hipStream_t)stream_, a);
   else
-    hipLaunchKernelGGL(rainbow_act_kernel<1>, dim3((a.N + 15) / 16), dim3(kThreads), act_lds(a.H, 1), (hipStream_t)stream_, a);
+    hipLaunchKernelGGL(wide ? k1w : k1, dim3((a.N + 15) / 16), dim3(kThreads), act_lds(a.H, 1), (hipStream_t)stream_, a);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
@@ -1378,7 +1384,8 @@ int gymrl_rainbow_update(const gymrl_rainbow_update_args* args, int phase, void*
   hipStream_t stream = (hipStream_t)stream_;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)rainbow_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(256, 7)) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)rainbow_rows_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(256, 7)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)rainbow_rows_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(256, 7)) != hipSuccess)
       return -1000 - (int)hipGetLastError();
     attr_set = true;
   }
@@ -1386,7 +1393,7 @@ int gymrl_rainbow_update(const gymrl_rainbow_update_args* args, int phase, void*
   void* base = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(a.workspace) + 255) & ~(uintptr_t)255);
   RbWs::carve(&ws, base, a.B, a.D, a.A, a.H);
   const int B = a.B, D = a.D, A1 = a.A + 1, H = a.H;
-  if (phase != 2) hipLaunchKernelGGL(rainbow_rows_kernel, dim3((B + 15) / 16, 3), dim3(kThreads), lds_bytes(H, 7), stream, a, ws);
+  if (phase != 2) hipLaunchKernelGGL(H == 256 ? rainbow_rows_kernel<256> : rainbow_rows_kernel<0>, dim3((B + 15) / 16, 3), dim3(kThreads), lds_bytes(H, 7), stream, a, ws);
   if (phase == 1) { GYMRL_CHECK_LAUNCH(); return 0; }
   DwArgs d{};
   int w0 = 0, ns = 0;

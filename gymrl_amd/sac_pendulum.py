@@ -50,8 +50,9 @@ class Config:
         self.fused_step = True             # a vector step = 5 launches (csrc/offpolicy_step.hip: acting + env + append in one, the
         #                                    update in four) instead of ~60; bit-identical to the layer-by-layer path, which remains
         #                                    for shapes beyond the kernels' limits (hidden_dim > 256, batch > 256) and custom envs
-        self.one_launch_step = os.environ.get("GYMRL_SAC_ONE_LAUNCH", "1") != "0"   # ... and inside a replayed chunk ONE launch: gymrl_sac_step, the five phases as block ranges
-        #                                    of one grid that hand over through counters in the workspace (bit-identical)
+        self.one_launch_step = os.environ.get("GYMRL_SAC_ONE_LAUNCH", "0") != "0"   # the vector step as ONE launch (gymrl_sac_step: the five
+        #                                    phases as block ranges of one grid, handing over through counters in the workspace;
+        #                                    bit-identical).  Measured slower than the five launches (0.123 vs 0.100 ms): off
         self.chunk_steps = 0               # 16: whole vector steps as one hipGraph per 16 (graphs.StepChunk).  Measured slower
         #                                    here (0.37 vs 0.29 ms per step at N = 4096, B = 128): SAC's step is GPU-bound, and
         #                                    the executor's cost per graph node grows with the graph (944 nodes per chunk)
@@ -409,7 +410,7 @@ class SACTrainer:
         ch, tr = self._chunk, lb["tracker"]
         obs, nxt = (lb["obs"], lb["nxt"]) if j % 2 == 0 else (lb["nxt"], lb["obs"])
         if self._fused_ok():
-            one = bool(getattr(self.cfg, "one_launch_step", True))       # acting + update as ONE launch (gymrl_sac_step)
+            one = bool(getattr(self.cfg, "one_launch_step", False))      # acting + update as ONE launch (gymrl_sac_step)
             self._vector_step(lb, obs, nxt, tr.ret[j], tr.done[j], cursor_dev=ch.view(j, "push"), noise_dev=ch.view(j, "noise_a"),
                               launch=not one)
             self._update_fused(dev=(ch.view(j, "draw"), ch.view(j, "adam_c", torch.float32), ch.view(j, "adam_a", torch.float32),
