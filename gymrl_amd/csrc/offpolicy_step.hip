@@ -226,29 +226,36 @@ struct Stager {
     return lds + dst[n - 1];
   }
   // every segment in ONE pass over the concatenation, four elements per thread in flight (as separate loops the segments'
-  // round trips followed one another: +2 us in front of the gather)
-  __device__ __forceinline__ void run() const {
-    for (int e0 = threadIdx.x; e0 < total; e0 += 4 * kThreads) {
-      float v[4]; int d[4];
+  // round trips followed one another: +2 us in front of the gather).  issue() requests the first pass's elements, commit()
+  // writes them to LDS (and runs any further pass): what lies between the two — P1's index draw — overlaps the round trip.
+  float v[4]; int d[4];
+  __device__ __forceinline__ void fetch(int e0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int off = e0 + j * kThreads;
-        const bool live = off < total;
-        const float* p = src[0]; int base = dst[0]; bool found = false;
+    for (int j = 0; j < 4; ++j) {
+      int off = e0 + j * kThreads;
+      const bool live = off < total;
+      const float* p = src[0]; int base = dst[0]; bool found = false;
 #pragma unroll
-        for (int i = 0; i < kMaxSeg; ++i) {
-          if (i < n && !found) {
-            if (off < cnt[i]) { p = src[i] + off; base = dst[i] + off; found = true; }
-            else off -= cnt[i];
-          }
+      for (int i = 0; i < kMaxSeg; ++i) {
+        if (i < n && !found) {
+          if (off < cnt[i]) { p = src[i] + off; base = dst[i] + off; found = true; }
+          else off -= cnt[i];
         }
-        v[j] = live ? *p : 0.0f;
-        d[j] = live ? base : -1;
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) if (d[j] >= 0) lds[d[j]] = v[j];
+      v[j] = live ? *p : 0.0f;
+      d[j] = live ? base : -1;
     }
   }
+  __device__ __forceinline__ void store() const {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (d[j] >= 0) lds[d[j]] = v[j];
+  }
+  __device__ __forceinline__ void issue() { fetch(threadIdx.x); }
+  __device__ __forceinline__ void commit() {
+    store();
+    for (int e0 = threadIdx.x + 4 * kThreads; e0 < total; e0 += 4 * kThreads) { fetch(e0); store(); }
+  }
+  __device__ __forceinline__ void run() { issue(); commit(); }
 };
 
 // ======================================================================================================== P1 =====
@@ -318,9 +325,9 @@ __device__ __forceinline__ void sac_p1_body(const gymrl_sac_update_args& a, cons
   // H1a / H2a / X0 (+ T2a / T2b in the workgroup that also runs the actor step's forward)
   const float *aw0 = nullptr, *ab0 = nullptr, *aw2 = nullptr, *aw3 = nullptr, *ab2 = nullptr, *ab3 = nullptr;   // actor fc1, heads
   const float *qw0, *qb0, *qw2, *qb2;                                                                            // this role's Q network: fc1, fc3
+  Stager sg{lds, target_chain ? H1a : X1};
   {
     const gymrl_sac_critic_params& net = target_chain ? a.target : a.critic;
-    Stager sg{lds, target_chain ? H1a : X1};
     qw0 = sg.put(net.w[3 * n], H * (D + A)); qb0 = sg.put(net.b[3 * n], H);
     qw2 = sg.put(net.w[3 * n + 2], H); qb2 = sg.put(net.b[3 * n + 2], 1);
     if (target_chain || n == 0) {
@@ -330,7 +337,7 @@ __device__ __forceinline__ void sac_p1_body(const gymrl_sac_update_args& a, cons
       aw2 = sg.put(a.actor.w[2], A * H); aw3 = sg.put(a.actor.w[3], A * H);
       ab2 = sg.put(a.actor.b[2], A); ab3 = sg.put(a.actor.b[3], A);
     }
-    sg.run();
+    sg.issue();
   }
   int64_t row = 0;
   if (t < nrows) {
@@ -344,6 +351,7 @@ __device__ __forceinline__ void sac_p1_body(const gymrl_sac_update_args& a, cons
       row = keyed_permute((uint32_t)b, size, bits / 2, bits - bits / 2, a.idx_seed ^ 0x5265706C61794944ull, counter);
     }
   }
+  sg.commit();
   phase_wait(ring_ready, ring_n);
   if (t < 16) {
     const int b = row0 + t;
@@ -804,13 +812,27 @@ __device__ __forceinline__ void sac_dw_body(const DwArgs& a, const int block, co
   const DwSeg& s = a.seg[si];
   const int local = gw - s.wave0, ktiles = (s.K + 15) >> 4;
   const int nt = local / ktiles, cg = local - nt * ktiles, kb = cg * 16;
-  float colsum;
-  const f32x4 acc = lin::tile_bwd_weight(s.dZ, s.ldz, s.N, nt, s.X, s.ldx, s.X2, s.ldx2, s.K, s.K1, kb, a.B, lane, colsum);
+  const int kc = kb + r;
+  // the optimiser's state of this tile (parameter, both moments, the target twin) is requested BEFORE the gradient's own
+  // loads and MFMA chain: behind them it was a second memory round trip per tile
   lin::AdamScalars ad;
   ad.step_size = a.adam_dev ? a.adam_dev[0] : a.adam[0];
   ad.bc2_sqrt = a.adam_dev ? a.adam_dev[2] : a.adam[2];
   ad.omb1 = a.omb1; ad.beta2 = a.beta2; ad.omb2 = a.omb2; ad.eps = a.eps;
-  const int kc = kb + r;
+  float Pv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, Mv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, Vv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, Tv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (!a.store_grads && kc < s.K) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int no = nt * 16 + 4 * q + g;
+      if (no >= s.N) continue;
+      const size_t o = (size_t)no * s.K + kc;
+      const size_t po = (size_t)(s.W - a.p) + o;
+      Pv[g] = s.W[o]; Mv[g] = a.m[po]; Vv[g] = a.v[po];
+      if (s.Wt) Tv[g] = s.Wt[o];
+    }
+  }
+  float colsum;
+  const f32x4 acc = lin::tile_bwd_weight(s.dZ, s.ldz, s.N, nt, s.X, s.ldx, s.X2, s.ldx2, s.K, s.K1, kb, a.B, lane, colsum);
   if (a.store_grads && a.split_heads && si == 0) {
     // d mu = dW, d sigma = dW * eps, per NoisyLinear layer: rows 0 .. A-1 the advantage stream, row A the value stream
     if (kc < s.K) {
@@ -851,11 +873,11 @@ __device__ __forceinline__ void sac_dw_body(const DwArgs& a, const int block, co
       if (no >= s.N) continue;
       const size_t o = (size_t)no * s.K + kc;
       const size_t po = (size_t)(s.W - a.p) + o;
-      float P = s.W[o], M = a.m[po], V = a.v[po];
+      float P = Pv[g], M = Mv[g], V = Vv[g];
       lin::adam_elem(P, acc[g], M, V, ad);
       s.W[o] = P; a.m[po] = M; a.v[po] = V;
       float T = 0.0f;
-      if (s.Wt) { T = a.tau * P + a.omt * s.Wt[o]; s.Wt[o] = T; }
+      if (s.Wt) { T = a.tau * P + a.omt * Tv[g]; s.Wt[o] = T; }
       const int steps = s.K >> 4;
       if (s.img_f) s.img_f[lin::img_fwd_index(no, kc, steps)] = P;
       if (s.img_b) s.img_b[lin::img_bwd_index(no, kc, steps)] = P;
