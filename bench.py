@@ -319,16 +319,17 @@ def main_offpolicy(a, rank, world, local_rank):
             flu = (actor_f + 2 * q_f + 2 * q_f + 2 * 2.0 * B * (H + H * H) + 2 * q_f            # P1 + critic dW
                    + actor_f + 2 * q_f + 2 * 2.0 * B * (H + H * H + DA * H) + 2.0 * B * (2 * A * H + H * H) + actor_f)   # P3 + actor dW
             upd_us = _event_us(lambda: tr.update_async() if getattr(cfg, "use_graphs", True) else tr.update(), reps=50)
-            cus = (B + 15) // 16
+            cus = 4 * ((B + 15) // 16)      # P1: four workgroups per 16-row slab (P3: two)
             roof = dict(bound="mfma", unit="TFLOP/s", peak=MFMA_F32_PEAK / 1e12, achieved=round(flu / upd_us / 1e6, 3),
                         frac=round(flu / upd_us / 1e6 / (MFMA_F32_PEAK / 1e12), 5), traffic=None, launch_s=upd_us * 1e-6,
                         flops_per_launch_group=flu, compute_units_carrying_rows=cus,
                         frac_of_those_units=round(flu / upd_us / 1e6 / (MFMA_F32_PEAK / 1e12 * cus / 256.0), 4),
                         kernel="gymrl_sac_update: the four launches of one update at batch 128 (csrc/offpolicy_step.hip: row-slab kernels P1 / P3, "
-                               "weight-gradient + Adam tile kernels P2 / P4).  A 16-row slab is ONE workgroup: B / 16 = 8 of the 256 compute units "
-                               "carry the MFMA work of the row kernels (a 16 x 256 x 256 layer is 3.9 us of f32 MFMA on one compute unit, "
-                               "5.9 us measured: tools/probe_sac_stages.py), so the figure is priced twice — against the chip's f32-MFMA peak "
-                               "as the contract asks (`frac`) and against the peak of the units that can work (`frac_of_those_units`)")
+                               "weight-gradient + Adam tile kernels P2 / P4).  A 16-row slab's chain of layers runs on ONE compute unit, its independent "
+                               "chains on units of their own: 4 B / 16 = 32 (P1) and 2 B / 16 = 16 (P3) of the 256 compute units carry the MFMA "
+                               "work of the row kernels (a 16 x 256 x 256 layer is 3.9 us of f32 MFMA on one compute unit, 4.6-4.9 us measured: "
+                               "tools/probe_sac_stages.py), so the figure is priced twice — against the chip's f32-MFMA peak as the contract asks "
+                               "(`frac`) and against the peak of the units that can work (`frac_of_those_units`, P1's 32)")
             pieces[f"one update at batch {B} (twin critics, actor, temperature, Adam x3 + Polyak: gymrl_sac_update, 4 launches)"] = dict(us=round(upd_us, 2))
             if tr._fused_ok():
                 lb = tr._loop_buffers(N, D)
