@@ -88,6 +88,11 @@ def test_new_entry_points_validate_arguments_without_gpu():
     assert L.gymrl_heads_fwd_tanh(null, i64(8), 64, 4, null, fake, null, fake, null, fake, fake, 1, null) == -22
     args = _lib.RolloutLunarArgs()
     assert L.gymrl_rollout_lunar(ctypes.byref(args), ctypes.byref(desc), null) == -22          # NULL slabs
+    # the fused off-policy steps: NULL / empty argument blocks are refused before any launch
+    act, upd = _lib.SacActArgs(), _lib.SacUpdateArgs()
+    assert L.gymrl_sac_act_step(ctypes.byref(act), null) == -22 and L.gymrl_sac_update(ctypes.byref(upd), null) == -22
+    assert L.gymrl_sac_step(ctypes.byref(act), ctypes.byref(upd), null) == -22
+    assert L.gymrl_sac_step(null, ctypes.byref(upd), null) == -22 and L.gymrl_sac_step(ctypes.byref(act), null, null) == -22
     # empty work is a no-op that returns 0 without launching anything
     assert L.gymrl_tanh_inplace(fake, i64(0), null, 0, null) == 0
     assert L.gymrl_linear_tanh_smallk(fake, fake, null, i64(0), 8, 64, fake, null) == 0

@@ -28,7 +28,8 @@ def _run(fused, steps, N, B, hidden, seed=5, images=True):
     return tr
 
 
-@pytest.mark.parametrize("N,B,hidden,steps", [(64, 128, 256, 40), (20, 24, 32, 30), (48, 256, 64, 24)])
+# (hidden 256: the instances built for that width; 36: no weight images, no 16-column alignment; B = 100: a partial last slab)
+@pytest.mark.parametrize("N,B,hidden,steps", [(64, 128, 256, 40), (20, 24, 32, 30), (48, 256, 64, 24), (33, 100, 36, 20), (17, 250, 256, 30)])
 def test_sac_fused_step_equals_layer_by_layer(N, B, hidden, steps):
     a, b = _run(False, steps, N, B, hidden), _run(True, steps, N, B, hidden)
     assert a.critic_optimizer.step_count == b.critic_optimizer.step_count > 10
