@@ -20,7 +20,19 @@ constexpr int kTPW    = 4;                  // 16-column tiles a wave accumulate
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Probe build (make prof): 100 MHz ticks workgroup 0's first lane spends in every stage interval of forward_tile, summed over
+// the calls ([15] counts them); read back by the translation unit that wants them (rollout_lunar.hip: gymrl_mlp_fwd_prof_read).
+#ifdef GYMRL_LUNAR_PROF
+static __device__ unsigned long long g_fwd_prof[16];
+#define MLP_FWD_MARK(i) do { if (blockIdx.x == 0 && tid == 0) { const unsigned long long now_ = wall_clock64(); g_fwd_prof[i] += now_ - fwd_t_; fwd_t_ = now_; } } while (0)
+#else
+#define MLP_FWD_MARK(i) do {} while (0)
+#endif
+
 __device__ __forceinline__ float activate(float x, int act) {
+#ifdef GYMRL_ABL_NOTANH               // (timing ablation of the probe tools: wrong values)
+  if (act == GYMRL_ACT_TANH) return x * 0.5f;
+#endif
   if (act == GYMRL_ACT_TANH) return det_tanhf_sel(x);
   if (act == GYMRL_ACT_RELU) return fmaxf(x, 0.0f);
   return x;
@@ -59,7 +71,11 @@ __device__ __forceinline__ void mfma_batch(f32x4 (&acc)[NT], const Batch<NT, UK>
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
       for (int i = 0; i < NT; ++i)
+#ifdef GYMRL_ABL_NOMFMA               // (timing ablation: the operands stay live, the matrix pipe idle)
+        acc[i][j] += a[j] * b.w[u][i][j];
+#else
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b.w[u][i][j], acc[i], 0, 0, 0);
+#endif
     }
   }
 }
@@ -153,6 +169,10 @@ __device__ __forceinline__ void forward_tile(const gymrl_mlp_desc& d, float (*ld
   const int lane = tid & 63, wave = tid >> 6;
   int head_col = 0;
   bool paired = false;                  // this stage runs in the previous stage's barrier interval
+#ifdef GYMRL_LUNAR_PROF
+  unsigned long long fwd_t_ = wall_clock64();
+  if (blockIdx.x == 0 && tid == 0) g_fwd_prof[15] += 1;
+#endif
   for (int s = 0; s < d.n_stages; ++s) {
     const gymrl_mlp_stage st = d.stage[s];
     if ((skip >> s) & 1u) { if (st.dst < 0) head_col += st.out_dim; continue; }
@@ -176,6 +196,7 @@ __device__ __forceinline__ void forward_tile(const gymrl_mlp_desc& d, float (*ld
     const bool pair_next = !paired && nx < d.n_stages && stages_independent(st, d.stage[nx]);
     if (!pair_next) __syncthreads();
     paired = pair_next;
+    MLP_FWD_MARK(s);
   }
 }
 
