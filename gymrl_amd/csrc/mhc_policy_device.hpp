@@ -43,6 +43,14 @@ __device__ __forceinline__ float row16_sum(float v) {
 // (v_mfma_f32_16x16x4_f32, weights from L2).  As 19 launches the forward is 177 us per 4096-row vector step (each launch
 // 6-14 us of latency: 256 waves on 1024 SIMDs); the per-row work is ~30 us.
 constexpr int kPolMaxSub = 8, kPolMaxOut = 8, kPolPad = 132;
+// Probe build (make prof): 100 MHz ticks workgroup 0's first lane spends in the phases of policy_tile, summed over the calls
+// ([15] counts them): 0 input projection, 1 gates + read (all sub-blocks), 2 Linear + SiLU, 3 combine, 4 final norm, 5 heads, 6 tail
+#ifdef GYMRL_LUNAR_PROF
+static __device__ unsigned long long g_pol_prof[16];
+#define POL_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); g_pol_prof[i] += now_ - pol_t_; pol_t_ = now_; } } while (0)
+#else
+#define POL_MARK(i) do {} while (0)
+#endif
 struct PolicyArgs {
   const float* in_w; const float* in_b;
   const float* norm_w[kPolMaxSub]; const float* gw[kPolMaxSub]; const float* alpha[kPolMaxSub]; const float* beta[kPolMaxSub];
@@ -75,10 +83,41 @@ __device__ __forceinline__ void policy_tile(const PolicyArgs& a, PolicyLds& L, c
   const int r = sub, qq = grp;                             // MFMA view: lane = (row / column r, k-quarter qq)
   const int lrow = 4 * wave + grp;
   const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#ifdef GYMRL_LUNAR_PROF
+  unsigned long long pol_t_ = wall_clock64();
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_pol_prof[15] += 1;
+#endif
 
   // input projection (:178-181): z = obs W^T + b, both branches start as z
   f32x4 x[4];
-  {
+  if (a.obs_dim == 8 && ((reinterpret_cast<uintptr_t>(a.in_w) | reinterpret_cast<uintptr_t>(a.in_b) | reinterpret_cast<uintptr_t>(obs_row)) & 15) == 0) {
+    // LunarLander's width: the lane's eight weight rows as sixteen 16-byte loads and its two bias quads, all requested before the
+    // first product (the general form below issues one dword load per product behind a test of obs_dim: 8.5 us of a 58 us
+    // forward, tools/probe_mhc_policy.py; 2.6 us this way).  Same products, same order: z = b, then + ob[k] w[k] for k = 0 .. 7.
+    const f32x4 o0 = *reinterpret_cast<const f32x4*>(obs_row), o1 = *reinterpret_cast<const f32x4*>(obs_row + 4);
+    f32x4 w[2][4][2], bq[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      bq[q] = *reinterpret_cast<const f32x4*>(a.in_b + 64 * q + 4 * sub);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* wr = a.in_w + (size_t)(64 * q + 4 * sub + e) * 8;
+        w[q][e][0] = *reinterpret_cast<const f32x4*>(wr); w[q][e][1] = *reinterpret_cast<const f32x4*>(wr + 4);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float z = bq[q][e];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) z += o0[k] * w[q][e][0][k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) z += o1[k] * w[q][e][1][k];
+        x[q][e] = z;
+      }
+    x[2] = x[0]; x[3] = x[1];
+  } else {
     float ob[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) ob[k] = k < a.obs_dim ? obs_row[k] : 0.0f;
@@ -95,6 +134,7 @@ __device__ __forceinline__ void policy_tile(const PolicyArgs& a, PolicyLds& L, c
       }
     x[2] = x[0]; x[3] = x[1];
   }
+  POL_MARK(0);
 
   for (int s = 0; s < a.n_sub; ++s) {
     // this wave's two weight tiles of the sub-block's Linear: requested now, needed after the gates (their L2 latency hides there)
@@ -158,6 +198,7 @@ __device__ __forceinline__ void policy_tile(const PolicyArgs& a, PolicyLds& L, c
       *reinterpret_cast<f32x4*>(&rbuf[lrow][64 * q + 4 * sub]) = rd;
     }
     __syncthreads();
+    POL_MARK(1);
     // out = SiLU(read W^T + b): this wave's two 16-column tiles
     {
       f32x4 av[8], acc[2] = {zero, zero};
@@ -178,6 +219,7 @@ __device__ __forceinline__ void policy_tile(const PolicyArgs& a, PolicyLds& L, c
       }
     }
     __syncthreads();
+    POL_MARK(2);
     // h'_i = post_i out + mix_i0 h_0 + mix_i1 h_1 (:165), back in the row view
     {
       f32x4 o[2], nx[4];
@@ -192,6 +234,7 @@ __device__ __forceinline__ void policy_tile(const PolicyArgs& a, PolicyLds& L, c
 #pragma unroll
       for (int q = 0; q < 4; ++q) x[q] = nx[q];
     }
+    POL_MARK(3);
   }
 
   // the heads' first weight tile is requested before the final norm (wave = (head wave / 2, column half wave % 2))
@@ -219,6 +262,7 @@ __device__ __forceinline__ void policy_tile(const PolicyArgs& a, PolicyLds& L, c
     }
   }
   __syncthreads();
+  POL_MARK(4);
   // heads (:371-402): wave = (head wave / 2, column half wave % 2) of Linear(128, 256) -> SiLU; the RMSNorm's scale is a per-row
   // factor of the last Linear, so each wave hands over its half's sum of squares and norm-weighted dot products
   {
@@ -278,6 +322,7 @@ __device__ __forceinline__ void policy_tile(const PolicyArgs& a, PolicyLds& L, c
     }
   }
   __syncthreads();
+  POL_MARK(5);
   if (threadIdx.x < 32) {                                  // thread = (head, row)
     const int hd = threadIdx.x >> 4, lr = threadIdx.x & 15;
     if (lr < n_valid) {
@@ -290,6 +335,7 @@ __device__ __forceinline__ void policy_tile(const PolicyArgs& a, PolicyLds& L, c
       }
     }
   }
+  POL_MARK(6);
 }
 
 // host side: gymrl_mhc_policy (include/gymrl.h) -> PolicyArgs; -22 when a pointer is missing or the shape is not the kernel's

@@ -288,6 +288,14 @@ int gymrl_mlp_fwd_prof_read(unsigned long long* out16, int reset) {      // prob
 }
 #endif
 
+#ifdef GYMRL_LUNAR_PROF
+int gymrl_mhc_policy_prof_read(unsigned long long* out16, int reset) {   // probe build only (not in include/gymrl.h)
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(mhc::g_pol_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(mhc::g_pol_prof), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
+
 int gymrl_rollout_lunar_mhc(const gymrl_rollout_lunar_args* a, const gymrl_mhc_policy* policy, void* stream) {
   if (!a || !policy || !a->env_state || !a->obs || !a->act || !a->logp || !a->val || !a->rew || !a->done ||
       !a->next_value || a->n_envs <= 0 || a->T <= 0 || a->t0 < 0 || a->nsteps < 0 || a->t0 + a->nsteps > a->T)
