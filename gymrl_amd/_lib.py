@@ -50,7 +50,7 @@ SYMBOLS = [
     "gymrl_mhc_gates", "gymrl_mhc_combine", "gymrl_rmsnorm", "gymrl_sinkhorn",
     "gymrl_mhc_read_fwd", "gymrl_mhc_read_bwd", "gymrl_mhc_combine_bwd",
     "gymrl_mhc_gates_bwd_workspace_bytes", "gymrl_mhc_gates_bwd", "gymrl_rmsnorm_bwd_workspace_bytes", "gymrl_rmsnorm_bwd", "gymrl_rmsnorm_sum_bwd", "gymrl_norm_proj_fwd", "gymrl_norm_proj_bwd_workspace_bytes", "gymrl_norm_proj_bwd",
-    "gymrl_mhc_policy_forward", "gymrl_mhc_sub_forward", "gymrl_mhc_sub_backward", "gymrl_rollout_lunar_mhc",
+    "gymrl_mhc_policy_forward", "gymrl_mhc_policy_image_floats", "gymrl_mhc_policy_pack", "gymrl_mhc_sub_forward", "gymrl_mhc_sub_backward", "gymrl_rollout_lunar_mhc",
     "gymrl_sac_update_workspace_bytes", "gymrl_sac_args_bytes", "gymrl_sac_act_step", "gymrl_sac_update", "gymrl_sac_step", "gymrl_sac_pack_images",
     "gymrl_rainbow_update_workspace_bytes", "gymrl_rainbow_args_bytes", "gymrl_rainbow_act_step", "gymrl_rainbow_update",
 ]
@@ -93,7 +93,7 @@ class MhcPolicy(C.Structure):
     """gymrl_mhc_policy (include/gymrl.h)."""
     _fields_ = [("obs_dim", C.c_int), ("n_sub", C.c_int), ("n_act", C.c_int), ("sk_it", C.c_int), ("in_w", C.c_void_p),
                 ("in_b", C.c_void_p), ("sub", MhcSub * 8), ("final_norm_w", C.c_void_p), ("final_norm_eps", C.c_float),
-                ("head", MhcHead * 2)]
+                ("head", MhcHead * 2), ("image", C.c_void_p)]
 
 
 class PPOCfg(C.Structure):
@@ -226,6 +226,7 @@ def lib():
         L.gymrl_reduce_workspace_bytes.restype = C.c_size_t
         L.gymrl_per_workspace_bytes.restype = C.c_size_t
         L.gymrl_mlp_packed_floats.restype = C.c_size_t
+        L.gymrl_mhc_policy_image_floats.restype = C.c_size_t
         L.gymrl_mlp_train_workspace_bytes.restype = C.c_size_t
         L.gymrl_gemm_workspace_bytes.restype = C.c_size_t
         L.gymrl_lin_workspace_bytes.restype = C.c_size_t

@@ -1416,6 +1416,31 @@ __global__ __launch_bounds__(64 * kSubBwdWaves) void mhc_sub_bwd_kernel(const Su
 }
 
 // ---- the whole rollout forward of PPO-full's network in ONE launch: mhc_policy_device.hpp's 16-row tile per workgroup --------
+// gymrl_mhc_policy_pack: one thread per float of the image (mhc_policy_device.hpp: layout next to PolicyArgs)
+__global__ __launch_bounds__(256) void mhc_policy_pack_kernel(const PolicyArgs a, float* __restrict__ img) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t subs = (size_t)a.n_sub * kPolSubFloats;
+  if (idx >= subs + 2 * (size_t)kPolHeadFloats) return;
+  if (idx < subs) {
+    const int s = (int)(idx / kPolSubFloats);
+    int o = (int)(idx - (size_t)s * kPolSubFloats);
+    if (o < kPolLwFloats) {                                  // ((T * 8 + j) * 64 + lane) * 4 + c
+      const int c = o & 3, lane = (o >> 2) & 63, j = (o >> 8) & 7, T = o >> 11;
+      img[idx] = a.lw[s][(size_t)(16 * T + (lane & 15)) * 128 + 16 * j + 4 * (lane >> 4) + c];
+    } else {                                                 // (((q * 4 + e) * 2 + half) * 16 + sub) * 4 + k
+      o -= kPolLwFloats;
+      const int k = o & 3, sub = (o >> 2) & 15, half = (o >> 6) & 1, e = (o >> 7) & 3, q = o >> 9;
+      img[idx] = a.gw[s][(size_t)(64 * q + 4 * sub + e) * 8 + 4 * half + k];
+    }
+    return;
+  }
+  int o = (int)(idx - subs);
+  const int hd = o / kPolHeadFloats;
+  o -= hd * kPolHeadFloats;
+  const int c = o & 3, lane = (o >> 2) & 63, j = (o >> 8) & 7, T = o >> 11;
+  img[idx] = a.h1_w[hd][(size_t)(16 * T + (lane & 15)) * 128 + 16 * j + 4 * (lane >> 4) + c];
+}
+
 __global__ __launch_bounds__(256) void mhc_policy_kernel(const PolicyArgs a, const float* __restrict__ obs, int B,
                                                          float* __restrict__ logits, float* __restrict__ value) {
   __shared__ PolicyLds L;
@@ -1691,6 +1716,21 @@ int gymrl_mhc_sub_bwd_prof_read(unsigned long long* out8, int reset) {   // prob
   return 0;
 }
 #endif
+
+size_t gymrl_mhc_policy_image_floats(int n_sub) { return n_sub < 0 || n_sub > kPolMaxSub ? 0 : policy_image_floats(n_sub); }
+
+int gymrl_mhc_policy_pack(const gymrl_mhc_policy* p, float* image, void* stream) {
+  if (!image || (reinterpret_cast<uintptr_t>(image) & 15)) return -22;
+  PolicyArgs a{};
+  gymrl_mhc_policy q;
+  if (!p) return -22;
+  q = *p; q.image = nullptr;
+  if (const int rc = policy_fill(a, &q)) return rc;
+  const size_t total = policy_image_floats(a.n_sub);
+  hipLaunchKernelGGL(mhc_policy_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, image);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
 
 int gymrl_mhc_policy_forward(const gymrl_mhc_policy* p, const float* obs, int B, float* logits_out, float* value_out, void* stream) {
   if (!obs || !logits_out || !value_out || B < 0) return -22;

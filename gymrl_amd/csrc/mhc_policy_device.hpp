@@ -59,7 +59,16 @@ struct PolicyArgs {
   const float* h1_w[2]; const float* h1_b[2]; const float* hn_w[2]; const float* h2_w[2]; const float* h2_b[2];
   float fn_eps, hn_eps[2];
   int obs_dim, n_sub, n_act, sk_it;
+  const float* img;                                        // gymrl_mhc_policy_pack's image of the wide operands, or nullptr: read in place
 };
+
+// The image: per sub-block its Linear [128 x 128] as MFMA B-operand tiles — (tile T, k-step j, lane) -> W[16 T + lane % 16][16 j + 4 (lane / 16) .. + 3],
+// one contiguous KiB per wave-wide load — then its gate weights in the order the row view reads them ((q, e, half, sub) ->
+// w[64 q + 4 sub + e][4 half .. + 3]); after the sub-blocks the two heads' first Linears [256 x 128] as 16 tiles each.  Read from
+// nn.Linear's rows a wave-wide 16-byte load touches sixteen cache lines (a 64-byte piece of sixteen rows) and the compute unit's
+// memory pipe moves the 0.5 MB a step needs at 21 GB/s; from the image at 50+ (tools/probe_mhc_policy.py).  Same values.
+constexpr int kPolLwFloats = 128 * 128, kPolGwFloats = 256 * 8, kPolSubFloats = kPolLwFloats + kPolGwFloats, kPolHeadFloats = 256 * 128;
+__host__ __device__ inline size_t policy_image_floats(int n_sub) { return (size_t)n_sub * kPolSubFloats + 2 * (size_t)kPolHeadFloats; }
 
 struct PolicyLds {
   float rbuf[16][kPolPad];                                 // a Linear's input rows (the MFMA A operand)
@@ -137,36 +146,69 @@ __device__ __forceinline__ void policy_tile(const PolicyArgs& a, PolicyLds& L, c
   POL_MARK(0);
 
   for (int s = 0; s < a.n_sub; ++s) {
-    // this wave's two weight tiles of the sub-block's Linear: requested now, needed after the gates (their L2 latency hides there)
-    f32x4 wv[2][8];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const float* wrow = a.lw[s] + (size_t)(16 * (2 * wave + t) + r) * D + 4 * qq;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) wv[t][j] = *reinterpret_cast<const f32x4*>(wrow + 16 * j);
-    }
     // gates (:125-147): every lane of a row's 16 ends with the row's nine sums and evaluates the gates itself
     float Hs[G + 1];
 #pragma unroll
     for (int k = 0; k <= G; ++k) Hs[k] = 0.0f;
     const float* __restrict__ nwp = a.norm_w[s];
     const float* __restrict__ gwp = a.gw[s];
+    // The lane's gate weights in two rounds of 18 sixteen-byte loads, each round requested before its first product: with the
+    // loads inside the (q, e) loop every one of the 16 iterations waited out its own L2 round trip — 6 of the sub-block's 7 us
+    // (tools/probe_mhc_policy.py).  Same products in the same order.
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = 64 * q + 4 * sub;
-      const f32x4 nw = *reinterpret_cast<const f32x4*>(nwp + c);
+    for (int hq = 0; hq < 2; ++hq) {
+      f32x4 nw[2], lo[2][4], hi[2][4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(gwp + (size_t)(c + e) * G);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(gwp + (size_t)(c + e) * G + 4);
-        const float xv = x[q][e], t = nw[e] * xv;
-        Hs[G] += xv * xv;
+      for (int u = 0; u < 2; ++u) {
+        const int c = 64 * (2 * hq + u) + 4 * sub;
+        nw[u] = *reinterpret_cast<const f32x4*>(nwp + c);
+        if (a.img) {
+          const f32x4* gi = reinterpret_cast<const f32x4*>(a.img + (size_t)s * kPolSubFloats + kPolLwFloats) + (size_t)(2 * hq + u) * 128 + sub;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { Hs[k] += t * lo[k]; Hs[4 + k] += t * hi[k]; }
+          for (int e = 0; e < 4; ++e) { lo[u][e] = gi[e * 32]; hi[u][e] = gi[e * 32 + 16]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            lo[u][e] = *reinterpret_cast<const f32x4*>(gwp + (size_t)(c + e) * G);
+            hi[u][e] = *reinterpret_cast<const f32x4*>(gwp + (size_t)(c + e) * G + 4);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = 2 * hq + u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xv = x[q][e], t = nw[u][e] * xv;
+          Hs[G] += xv * xv;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { Hs[k] += t * lo[u][e][k]; Hs[4 + k] += t * hi[u][e][k]; }
+        }
+      }
+    }
+    // this wave's two weight tiles of the sub-block's Linear: requested behind the gates' operands and ahead of the reductions,
+    // transcendentals and Sinkhorn sweeps whose latency hides their arrival
+    POL_MARK(7);
+    f32x4 wv[2][8];
+    if (a.img) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f32x4* wi = reinterpret_cast<const f32x4*>(a.img + (size_t)s * kPolSubFloats) + (size_t)(2 * wave + t) * 512 + lane;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[t][j] = wi[64 * j];
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float* wrow = a.lw[s] + (size_t)(16 * (2 * wave + t) + r) * D + 4 * qq;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[t][j] = *reinterpret_cast<const f32x4*>(wrow + 16 * j);
       }
     }
 #pragma unroll
     for (int k = 0; k <= G; ++k) Hs[k] = row16_sum(Hs[k]);
+    POL_MARK(8);
     const float r_inv = 1.0f / (sqrtf(Hs[G]) / sqrtf((float)NC) + 1e-6f);
     const float a0 = a.alpha[s][0], a1 = a.alpha[s][1], a2 = a.alpha[s][2];
     const float* __restrict__ be = a.beta[s];
@@ -189,6 +231,7 @@ __device__ __forceinline__ void policy_tile(const PolicyArgs& a, PolicyLds& L, c
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) mix[i][j] = u[i] * A[i][j] * v[j];
+    POL_MARK(9);
     // read = pre_0 h_0 + pre_1 h_1 -> the Linear's input rows
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -197,6 +240,7 @@ __device__ __forceinline__ void policy_tile(const PolicyArgs& a, PolicyLds& L, c
       for (int e = 0; e < 4; ++e) rd[e] = pre[0] * x[q][e] + pre[1] * x[q + 2][e];
       *reinterpret_cast<f32x4*>(&rbuf[lrow][64 * q + 4 * sub]) = rd;
     }
+    POL_MARK(10);
     __syncthreads();
     POL_MARK(1);
     // out = SiLU(read W^T + b): this wave's two 16-column tiles
@@ -239,9 +283,21 @@ __device__ __forceinline__ void policy_tile(const PolicyArgs& a, PolicyLds& L, c
 
   // the heads' first weight tile is requested before the final norm (wave = (head wave / 2, column half wave % 2))
   const float* __restrict__ W1 = a.h1_w[wave >> 1] + (size_t)(128 * (wave & 1) + r) * D + 4 * qq;
-  f32x4 wA[8], wB[8];
+  // (image: this wave's eight tiles of its head, tile t at + 512 t)
+  const f32x4* __restrict__ W1i = a.img ? reinterpret_cast<const f32x4*>(a.img + (size_t)a.n_sub * kPolSubFloats + (size_t)(wave >> 1) * kPolHeadFloats) +
+                                              (size_t)(8 * (wave & 1)) * 512 + lane
+                                        : nullptr;
+  auto head_tile_load = [&](f32x4 (&w)[8], int t) {
+    if (W1i) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) wA[j] = *reinterpret_cast<const f32x4*>(W1 + 16 * j);
+      for (int j = 0; j < 8; ++j) w[j] = W1i[(size_t)t * 512 + 64 * j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const f32x4*>(W1 + (size_t)(16 * t) * D + 16 * j);
+    }
+  };
+  f32x4 wA[8], wB[8];
+  head_tile_load(wA, 0);
   // final_norm(h.sum(1)) (:182-183) -> the heads' input rows
   {
     f32x4 sv[2];
@@ -297,13 +353,9 @@ __device__ __forceinline__ void policy_tile(const PolicyArgs& a, PolicyLds& L, c
       }
     };
     for (int t = 0; t < 8; t += 2) {                       // the next tile's weights are in flight while this one multiplies
-#pragma unroll
-      for (int j = 0; j < 8; ++j) wB[j] = *reinterpret_cast<const f32x4*>(W1 + (size_t)(16 * (t + 1)) * D + 16 * j);
+      head_tile_load(wB, t + 1);
       tile(wA, t);
-      if (t + 2 < 8) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) wA[j] = *reinterpret_cast<const f32x4*>(W1 + (size_t)(16 * (t + 2)) * D + 16 * j);
-      }
+      if (t + 2 < 8) head_tile_load(wA, t + 2);
       tile(wB, t + 1);
     }
 #pragma unroll
@@ -355,6 +407,8 @@ inline int policy_fill(PolicyArgs& a, const gymrl_mhc_policy* p) {
   }
   a.in_w = p->in_w; a.in_b = p->in_b; a.fn_w = p->final_norm_w; a.fn_eps = p->final_norm_eps;
   a.obs_dim = p->obs_dim; a.n_sub = p->n_sub; a.n_act = p->n_act; a.sk_it = p->sk_it;
+  if (reinterpret_cast<uintptr_t>(p->image) & 15) return -22;
+  a.img = p->image;
   return 0;
 }
 

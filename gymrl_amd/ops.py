@@ -1263,6 +1263,17 @@ def mhc_policy(desc, obs, logits_out=None, value_out=None):
     return logits, value
 
 
+def mhc_policy_pack(desc, image=None):
+    """gymrl_mhc_policy_pack: the image of desc's wide operands (the sub-blocks' Linears and gate weights, the heads' first
+    Linears) in the order the one-launch forward's lanes read them; returns the buffer (desc.image is the caller's to set —
+    and to refresh: the image does not follow the parameters)."""
+    n = int(lib().gymrl_mhc_policy_image_floats(C.c_int(desc.n_sub)))
+    if image is None or image.numel() != n:
+        image = torch.empty(n, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+    check(lib().gymrl_mhc_policy_pack(C.byref(desc), _ptr(image, torch.float32), _stream()), "gymrl_mhc_policy_pack")
+    return image
+
+
 def sinkhorn(A, sk_it):
     """gymrl_sinkhorn: A [B, n, n] -> (u [B, n], v [B, n])."""
     B, n, _ = A.shape

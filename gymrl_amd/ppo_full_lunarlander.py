@@ -71,6 +71,7 @@ FUSED_GATES = True          # training pass: the gates as one forward + one back
 FUSED_MIXING = True         # training pass: read / combine products as fused forward + backward launches (False: broadcast multiplies)
 FUSED_INFERENCE = True      # rollout forward on the inference kernels (tools A/B; False: the torch modules)
 FUSED_POLICY = True         # rollout forward as ONE launch (gymrl_mhc_policy_forward) when the network has the default shape
+POLICY_IMAGE = True         # ... the persistent rollout reading its wide weights from a packed image (gymrl_mhc_policy_pack, once per rollout)
 FUSED_SUB_FORWARD = True    # ... and its forward as ONE launch when D = 128 (False: gates + Linear + combine launches)
 FUSED_HEAD_TAIL = True      # training pass: a head's SiLU -> RMSNorm -> output Linear as one launch each way
 FUSED_SUB_BACKWARD = True   # ... and its backward as ONE launch + the Linear's weight gradient (False: the five backward launches)
@@ -554,6 +555,7 @@ class ActorCritic(nn.Module):
         d = self._policy_desc()
         if d is None:
             return None
+        d.image = None                       # (an image is only as fresh as its last pack: this call reads the parameters in place)
         logits, value = ops.mhc_policy(d, x, logits_out, value_out)
         return logits, value.view(-1, 1)
 
@@ -659,7 +661,13 @@ class PPOTrainer:
                 and env.kind == ops.LUNARLANDER and desc.obs_dim == 8 and desc.n_act == 4):
             # the whole rollout as ONE launch: a workgroup owns 16 envs for all T steps (policy tile, draw, both GAE chunk maps,
             # Box2D step, slab writes) and never waits for another one — a step costs the mean wave's solver time, not the
-            # slowest wave's of 256 (csrc/rollout_lunar.hip; bit-identical to the loop below)
+            # slowest wave's of 256 (csrc/rollout_lunar.hip; bit-identical to the loop below).  Its T forwards read the wide
+            # weights from an image packed here, once per rollout (gymrl_mhc_policy_pack: the parameters do not move before the update)
+            if POLICY_IMAGE:
+                self._pol_image = ops.mhc_policy_pack(desc, getattr(self, "_pol_image", None))
+                desc.image = self._pol_image.data_ptr()
+            else:
+                desc.image = None
             ops.rollout_lunar_mhc(env.state, b.N, env.seed, env.env_id0, c0, b.states, b.actions, b.log_probs, b.values, b.rewards,
                                   b.dones, b.ep_returns, b.next_value, desc, b.T, 0, b.T, cfg.gamma, cfg.lam_actor,
                                   ent=b.old_entropies, lam2=cfg.lam_critic, noise_exp=noise,

@@ -688,7 +688,13 @@ typedef struct gymrl_mhc_policy_s {
   const float* final_norm_w;   /* [128] */
   float final_norm_eps;
   gymrl_mhc_head head[2];      /* 0 = actor, 1 = critic */
+  const float* image;          /* NULL: every weight is read in place.  Else gymrl_mhc_policy_pack's output (16-byte aligned,
+                                * gymrl_mhc_policy_image_floats(n_sub) floats): the sub-blocks' Linears and gate weights and the heads'
+                                * first Linears in the order the kernel's lanes read them — one contiguous KiB per wave-wide load
+                                * instead of a 64-byte piece of sixteen rows; repack after the parameters change.  Same values. */
 } gymrl_mhc_policy;
+size_t gymrl_mhc_policy_image_floats(int n_sub);
+int gymrl_mhc_policy_pack(const gymrl_mhc_policy* p, float* image, void* stream);      /* p->image is ignored */
 int gymrl_mhc_policy_forward(const gymrl_mhc_policy* p, const float* obs, int B, float* logits_out, float* value_out, void* stream);
 
 /* ===================================================== MLP update path ===== */

@@ -236,6 +236,17 @@ def test_one_launch_policy_forward_matches_actor_critic(B, layers, obs):
     _close(out[0], fused[0].double(), 2e-5)
     _close(out[1], fused[1].double(), 2e-5)
     assert net.forward_inference(x.cuda())[0].shape == (B, 4)
+    # the packed image of the wide operands (gymrl_mhc_policy_pack) changes where a weight is read from, not its value
+    from gymrl_amd import ops
+    d = net._policy_desc()
+    d.image = None
+    plain = ops.mhc_policy(d, x.cuda())
+    img = ops.mhc_policy_pack(d)
+    assert img.numel() == 2 * layers * (128 * 128 + 256 * 8) + 2 * 256 * 128
+    d.image = img.data_ptr()
+    packed = ops.mhc_policy(d, x.cuda())
+    d.image = None
+    assert torch.equal(plain[0], packed[0]) and torch.equal(plain[1], packed[1])
 
 
 @pytest.mark.parametrize("B", [1, 16, 100, 5000, 40000])

@@ -15,6 +15,8 @@ from gymrl_amd.ppo_full_lunarlander import Config, PPOTrainer  # noqa: E402
 
 cfg = Config()
 cfg.num_envs, cfg.update_freq, cfg.seed = 4096, 256, 0
+if len(sys.argv) > 1:
+    cfg.mhc_sk_it = int(sys.argv[1])          # (how much of the gates is the Sinkhorn loop: run with 0)
 sys.stdout = open(os.devnull, "w")
 tr = PPOTrainer(cfg)
 sys.stdout = sys.__stdout__
@@ -34,4 +36,5 @@ names = ("input projection", "gates + read (x n_sub)", "Linear + SiLU (x n_sub)"
 print(f"calls {n}; rollout {t0.elapsed_time(t1) * 1000 / cfg.update_freq:.1f} us per vector step")
 for i, nm in enumerate(names):
     print(f"  {nm:28s} {out[i] / 100.0 / n:6.2f} us per call")
-print(f"  total {sum(out[:7]) / 100.0 / n:.2f} us")
+print(f"  total {sum(out[:7]) / 100.0 / n + sum(out[7:11]) / 100.0 / n:.2f} us")
+print("  inside gates + read: accumulate, reductions, transcendentals + Sinkhorn, read + LDS store, (barrier = the first line):", [round(out[i] / 100.0 / n, 2) for i in range(7, 11)])
