@@ -126,6 +126,11 @@ def test_mhc_entry_points_validate_arguments_without_gpu():
     assert L.gymrl_rmsnorm_bwd_workspace_bytes(256) >= 2048 * 256 * 4
     pol = _lib.MhcPolicy()
     assert L.gymrl_mhc_policy_forward(null, fake, 8, fake, fake, null) == -22
+    # the packed operand image: its size is a function of the sub-block count; pack refuses NULL / misaligned / incomplete inputs
+    assert L.gymrl_mhc_policy_image_floats(4) == 4 * (128 * 128 + 256 * 8) + 2 * 256 * 128 and L.gymrl_mhc_policy_image_floats(9) == 0
+    assert L.gymrl_mhc_policy_pack(null, fake, null) == -22 and L.gymrl_mhc_policy_pack(ctypes.byref(pol), null, null) == -22
+    assert L.gymrl_mhc_policy_pack(ctypes.byref(pol), ctypes.c_void_p(260), null) == -22        # image not 16-byte aligned
+    assert L.gymrl_mhc_policy_pack(ctypes.byref(pol), fake, null) == -22                        # NULL parameters
     pol.obs_dim, pol.n_sub, pol.n_act, pol.sk_it = 8, 2, 4, 10
     assert L.gymrl_mhc_policy_forward(ctypes.byref(pol), fake, 8, fake, fake, null) == -22       # NULL parameters
     pol.in_w = pol.in_b = pol.final_norm_w = 256
