@@ -655,6 +655,8 @@ class PPOTrainer:
         # the whole forward as one launch when the network has the kernel's shape (the parameters do not move during a rollout:
         # one descriptor, fixed output buffers — nothing for a graph to save)
         desc = self.model._policy_desc() if (FUSED_INFERENCE and FUSED_POLICY and b.states.is_cuda) else None
+        if desc is not None:
+            desc.image = None                # (only the persistent launch below packs one, for its own T steps)
         if desc is not None and self._pol_out is None:
             self._pol_out = (torch.empty(b.N, desc.n_act, device=b.states.device), torch.empty(b.N, device=b.states.device))
         if (desc is not None and getattr(cfg, "persistent_rollout", True) and isinstance(env, VecEnv)
