@@ -112,6 +112,10 @@ struct Lds {
   unsigned long long* prof;
 #endif
   uint32_t* park = nullptr;   // persistent kernels: this lane's column of the parking area ([kParkWords][64 lanes]), see world_park
+#ifdef GYMRL_LUNAR_PROF
+  unsigned long long* envp = nullptr;   // probe build: this lane's env's counters, [3][envn]: steps with a contact of its own, its own
+  int envn = 0;                         // position iterations, steps on which the WAVE ran the contact sweeps
+#endif
   __device__ __forceinline__ float& mf(int s, int f) const { return reinterpret_cast<float*>(w)[(s * kMfWords + f) * kEnvBlock]; }
   __device__ __forceinline__ uint32_t& mu(int s, int f) const { return w[(s * kMfWords + f) * kEnvBlock]; }
   __device__ __forceinline__ float& vc(int s, int f) const { return reinterpret_cast<float*>(w)[(2 * kMfWords + s * kVcWords + f) * kEnvBlock]; }
@@ -884,7 +888,10 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
   }
   LUNAR_PROF_MARK(pt3);
   LUNAR_PROF_ADD(lds, 2, pt2, pt3);          // 180 velocity sweeps
-  LUNAR_PROF_ADD(lds, any_contact ? 6 : 7, pt2, pt3);
+#ifdef GYMRL_LUNAR_PROF
+  const bool wave_contact = __builtin_amdgcn_ballot_w64(any_contact) != 0ull;   // the path the wave took (not lane 0's own env)
+  LUNAR_PROF_ADD(lds, wave_contact ? 6 : 7, pt2, pt3);
+#endif
   // b2ContactSolver::StoreImpulses
   if (my_contact) {
 #pragma unroll
@@ -1064,6 +1071,11 @@ __device__ __forceinline__ void world_step(World& W, const Lds& lds, int role, i
     int wmax = prof_pos_iters + (position_solved ? 1 : 0), mine = wmax;
     for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
     if (lds.prof && (threadIdx.x & 63) == 0) { lds.prof[11] += (unsigned long long)wmax; lds.prof[12] += (unsigned long long)mine; }
+    if (lds.envp && role == 0) {
+      lds.envp[0] += any_contact ? 1ull : 0ull;
+      lds.envp[lds.envn] += (unsigned long long)mine;
+      lds.envp[2 * (size_t)lds.envn] += wave_contact ? 1ull : 0ull;
+    }
   }
 #endif
 

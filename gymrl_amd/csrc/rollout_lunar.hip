@@ -57,7 +57,16 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_kernel(gymrl_rollout_l
   const bool valid = i < N;
   const LunarState st(a.env_state, N);
 #ifdef GYMRL_LUNAR_PROF
-  const Lds slds{lds_words + lane, a.wg_ticks ? reinterpret_cast<unsigned long long*>(a.wg_ticks) + 2 * gridDim.x + 16 * blockIdx.x : nullptr, lds_park + lane};
+  // probe layout of wg_ticks (u64): [2][G] start / end | [G][kProfSlots] per-workgroup sections | [3][N] per-env counters
+  constexpr int kProfSlots = 24;
+  unsigned long long* const wprof = a.wg_ticks ? reinterpret_cast<unsigned long long*>(a.wg_ticks) + 2 * gridDim.x + kProfSlots * blockIdx.x : nullptr;
+  Lds slds_{lds_words + lane, wprof, lds_park + lane};
+  if (a.wg_ticks && valid) { slds_.envp = reinterpret_cast<unsigned long long*>(a.wg_ticks) + (2 + kProfSlots) * gridDim.x + i; slds_.envn = N; }
+  const Lds slds = slds_;
+  if (wprof && lane == 0) {                       // where the hardware put this wave: HW_ID (wave / SIMD / pipe / CU / SH / SE) and XCC_ID
+    wprof[20 + wave] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) |
+                       ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
+  }
 #else
   const Lds slds{lds_words + lane, lds_park + lane};
 #endif
@@ -80,8 +89,10 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_kernel(gymrl_rollout_l
   for (int t = a.t0; t <= t_end; ++t) {
     const bool tail = t == t_end;                   // only the bootstrap value of the finished rollout is left
     if (tail && t_end != T) break;
+    LUNAR_PROF_MARK(rtb);
     __syncthreads();                                // xin of step t is complete
     LUNAR_PROF_MARK(rt0);
+    if (wave == 0) LUNAR_PROF_ADD(slds, 16, rtb, rt0);  // wave 0 waiting for the refill / critic waves at the step's barrier
     // logits -> head[row][0..3] by all four waves; the critic's layers and the value head (-> head[row][4]) are not on the
     // way to the action: wave 2 runs them while wave 0 steps the envs (`vdefer` = their stage bits, 0 if the network has
     // no such split) and does what the value is needed for — val[t], the GAE delta of step t-1, the bootstrap value
@@ -105,6 +116,9 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_kernel(gymrl_rollout_l
     if (wave == 2 && vdefer) {
       M::forward_deferred(d, lds, head, m0, N, lane, vdefer);
       value_part();
+#ifdef GYMRL_LUNAR_PROF
+      if (wprof && lane == 0) wprof[17] += wall_clock64() - rt1;     // the critic wave's busy time
+#endif
     }
     // wave 0 steps the envs; wave 1 (idle otherwise) keeps their next episodes prepared — ONE call site of the solver
     const bool refill_wave = wave == 1;
@@ -134,6 +148,9 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_kernel(gymrl_rollout_l
         lunar_step_quad(st, refill_wave ? rlds : slds, N, i, role, valid, act, a.seed, a.env_id0, out, o_next, refill_wave, io_mode);
         LUNAR_PROF_MARK(rt3);
         if (!refill_wave) LUNAR_PROF_ADD(slds, 10, rt2, rt3);         // whole env step (state load, world_step, reward, reset, store)
+#ifdef GYMRL_LUNAR_PROF
+        if (refill_wave && wprof && lane == 0) { wprof[18] += rt3 - rt2; wprof[19] += (rt3 - rt2) > 1000ull ? 1ull : 0ull; }   // the refill wave's busy time, steps on which it built a world (> 10 us)
+#endif
         if (!refill_wave && valid && role < 2) {      // next policy input: straight into the forward's LDS tile
 #pragma unroll
           for (int k = 0; k < 4; ++k) xin[row * M::kInStride + 4 * role + k] = o_next[4 * role + k];

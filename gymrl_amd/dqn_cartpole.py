@@ -89,8 +89,12 @@ class ReplayBuffer:
             action = scalar.rows(action, n, self.action_dtype, self.device, AW)
             reward, done = scalar.rows(reward, n, torch.float32, self.device), scalar.rows(done, n, torch.uint8, self.device)
         n = reward.numel()
-        if action.dtype != torch.int32:                       # float32 action words (SAC / TD3 / DDPG rings)
-            action = action.contiguous().view(torch.int32)
+        if action.dtype == torch.float32 and self.action_dtype == torch.float32:
+            action = action.contiguous().view(torch.int32)    # float32 action words (SAC / TD3 / DDPG rings), reinterpreted
+        elif action.dtype != torch.int32:
+            if self.action_dtype == torch.float32 or action.is_floating_point():
+                raise TypeError(f"replay ring of {self.action_dtype} actions got a {action.dtype} action tensor")
+            action = action.to(torch.int32)                   # discrete ring: an int64 tensor (the reference's dtype) is converted
         ops.replay_append(self.ring, self.cursor, state, action.view(n, -1), reward, next_state, done, cursor_dev=cursor_dev)
         if cursor_dev is None:
             self.advance(n)

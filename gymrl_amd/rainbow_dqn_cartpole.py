@@ -760,6 +760,11 @@ class RainbowDQNTrainer:
         ch, tr = self._chunk, lb["tracker"]
         rec = {"noise": ch.view(j, "noise"), "push": ch.view(j, "push")}
         obs, nxt = (lb["obs"], lb["nxt"]) if j % 2 == 0 else (lb["nxt"], lb["obs"])
+        if j == 0:
+            # `_max_fresh` is a HOST flag read while capturing: whatever ran between two replays (an eager update_batch, a
+            # load_checkpoint) may have changed the leaves without this graph knowing — its first store always recomputes
+            # priority_max (one per_max_leaf launch per 16 vector steps); steps 1.. follow the chunk's own update_td
+            self.memory.sum_tree._max_fresh = False
         self._vector_step(lb, obs, nxt, tr.ret[j], tr.done[j], rec, chain=j > 0 and OVERLAP_TREE)
         self.memory.draw(0, 1, out=self._g_draw, dev=ch.view(j, "sample"))
         noise = ch.view(j, "noise")
@@ -823,6 +828,12 @@ class RainbowDQNTrainer:
                 token = tracker.drain_async()
                 tracker.collect(pending, self.episode_rewards)
                 pending = token
+                # ... except where the lag could change WHEN training stops (:398-401's `mean(last 100) >= 495`, the episode
+                # budget): within reach of either rule this chunk's returns are collected at once, as the eager loop does
+                if (cfg.max_episodes - tracker.episodes <= N * self.CHUNK
+                        or (len(self.episode_rewards) >= 100 and np.mean(self.episode_rewards) >= 0.9 * 495.0)):
+                    tracker.collect(pending, self.episode_rewards)
+                    pending = None
                 if len(self.episode_rewards) >= 100 and np.mean(self.episode_rewards) >= 495.0:
                     break
                 continue

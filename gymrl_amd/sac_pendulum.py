@@ -186,6 +186,7 @@ class SACTrainer:
         """:194-199 on the flat parameter buffers."""
         ops.soft_update(self.critic_target_flat if target_flat is None else target_flat,
                         self.critic_flat if source_flat is None else source_flat, self.cfg.tau)
+        self._img_versions = None             # a raw-pointer write: the fused step's weight images of the target are stale
 
     # ------------------------------------------------------------ fused vector step (csrc/offpolicy_step.hip) --
     def _fused_update_ok(self):
@@ -218,7 +219,12 @@ class SACTrainer:
         # torch (load_state_dict, a checkpoint, a hard target copy: the flat buffers' version counters move) or through the
         # layer-by-layer update (which resets _img_versions) makes them stale: rebuild (one launch)
         if self._fused[4] is not None:
-            v = (self.actor_flat._version, self.critic_flat._version, self.critic_target_flat._version)
+            # (flatten_module binds every parameter as a VIEW tensor of its own: load_state_dict / a checkpoint bump the
+            # parameters' version counters, not the flat buffers' — so both are summed; writers that go around torch
+            # altogether, soft_update() and load_checkpoint(), reset _img_versions themselves)
+            v = tuple(f._version + sum(p._version for p in net.parameters())
+                      for f, net in ((self.actor_flat, self.actor), (self.critic_flat, self.critic),
+                                     (self.critic_target_flat, self.critic_target)))
             if v != self._img_versions:
                 ops.sac_pack_images(self._fused[1])
                 self._img_versions = v
@@ -352,6 +358,7 @@ class SACTrainer:
         rest = checkpoint.load_agent(path, {"actor": self.actor, "critic": self.critic, "critic_target": self.critic_target},
                                      {"actor_optimizer": (self.actor, self.actor_optimizer),
                                       "critic_optimizer": (self.critic, self.critic_optimizer)})
+        self._img_versions = None             # the fused step's weight images are rebuilt from the loaded parameters
         self.log_alpha.copy_(rest["log_alpha"].to(self.device))
         self._alpha_m.copy_(rest["alpha_m"].to(self.device))
         self._alpha_v.copy_(rest["alpha_v"].to(self.device))
@@ -479,6 +486,9 @@ class SACTrainer:
                 token = tracker.drain_async()
                 tracker.collect(pending, self.episode_rewards)
                 pending = token
+                if cfg.max_episodes - tracker.episodes <= N * self.CHUNK:      # within reach of the episode budget (:269): no lag,
+                    tracker.collect(pending, self.episode_rewards)             # the loop stops where the eager loop would
+                    pending = None
                 continue
             tracker.collect(pending, self.episode_rewards)
             pending = None

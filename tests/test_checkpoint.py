@@ -123,3 +123,39 @@ def test_off_policy_trainers_resume_bit_exactly(tmp_path, algo):
         assert torch.equal(a.memory.sum_tree.tree, b.memory.sum_tree.tree)
     if algo == "sac":
         assert torch.equal(a.log_alpha, b.log_alpha)
+
+
+@pytest.mark.gpu
+def test_sac_weight_images_follow_load_checkpoint_and_soft_update(tmp_path):
+    """The fused SAC step streams the hidden x hidden layers from MFMA-operand IMAGES of the weights, kept in step by its own
+    weight-gradient kernel.  Writers that go around it — load_checkpoint() / load_state_dict() (they bump the version counters
+    of the parameter views, not of the flat buffers) and the public soft_update() (a raw-pointer kernel) — must make the next
+    fused launch rebuild them: a trainer whose images hold LATER weights loads a checkpoint and then takes exactly the
+    updates of a trainer that keeps no images at all."""
+    from gymrl_amd import sac_pendulum
+
+    def make(images):
+        cfg = sac_pendulum.Config()
+        cfg.num_envs, cfg.max_episodes, cfg.batch_size, cfg.seed, cfg.memory_capacity, cfg.fused_images = 32, 10**9, 64, 4, 4096, images
+        return sac_pendulum.SACTrainer(cfg)
+    torch.manual_seed(3)
+    a = make(True)
+    a.train(max_vector_steps=30)
+    path = str(tmp_path / "sac.pth")
+    a.save_checkpoint(path)
+    a.train(max_vector_steps=20)                          # the images now hold weights 20 updates past the checkpoint
+    assert a._fused[4] is not None and a._img_versions is not None
+    b = make(False)
+    outs = []
+    for tr in (a, b):
+        tr.load_checkpoint(path)
+        losses = [tr.update() for _ in range(3)]
+        tr.soft_update()                                   # the public Polyak step between updates (sac_pendulum.py:194-199)
+        tr.actor.load_state_dict({k: v.clone() for k, v in tr.actor.state_dict().items()})   # a torch-side write of the same values
+        losses += [tr.update() for _ in range(3)]
+        outs.append(losses)
+    assert b._fused[4] is None
+    assert outs[0] == outs[1]
+    for name in ("actor_flat", "critic_flat", "critic_target_flat", "log_alpha"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert torch.equal(a.critic_optimizer.m, b.critic_optimizer.m) and torch.equal(a.actor_optimizer.v, b.actor_optimizer.v)

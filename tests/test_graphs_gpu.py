@@ -155,11 +155,14 @@ def test_ddpg_dsac_graphed_update_equals_eager(algo):
     assert getattr(eager, opt).step_count == getattr(graph, opt).step_count > 30
 
 
-@pytest.mark.parametrize("algo", ["rainbow", "sac"])
+@pytest.mark.parametrize("algo", ["rainbow", "sac", "sac_fused"])
 def test_baseline_config_sizes_graphed_equals_eager(algo):
     """BASELINE configs 3 and 4 at their own sizes — Rainbow DQN CartPole-v1 with 8192 envs (2^20-leaf PER tree, n-step
     windows, NoisyNet) and SAC Pendulum-v1 with 4096 envs — for 12 vector steps: the hipGraph-replayed update equals the
-    eager one bit for bit and every network / the float64 sum tree is finite."""
+    eager one bit for bit and every network / the float64 sum tree is finite.  "sac_fused" is the DEFAULT SAC path (what
+    bench.py --algo sac times): the five-launch fused step, eager against its 16-step StepChunk graph, 36 vector steps; the
+    fused step against the layer-by-layer path at this size is tests/test_fused_step_gpu.py's (4096, 128, 256) case and its
+    acting launch against the oracle test_sac_act_step_vs_oracle's."""
     if algo == "rainbow":
         from gymrl_amd import rainbow_dqn_cartpole as mod
         cls, n_envs = "RainbowDQNTrainer", 8192
@@ -171,14 +174,20 @@ def test_baseline_config_sizes_graphed_equals_eager(algo):
         cls, n_envs = "SACTrainer", 4096
 
         def setup(cfg):
-            cfg.num_envs, cfg.memory_capacity, cfg.fused_step = n_envs, 1 << 20, False     # the layer-by-layer update's graph
+            cfg.num_envs, cfg.memory_capacity, cfg.fused_step = n_envs, 1 << 20, algo == "sac_fused"   # "sac": the layer-by-layer update's graph
     outs = []
     for graphs in (False, True):
         if algo == "rainbow":
             mod.NoisyLinear._counter = 0
-        outs.append(_run(mod, cls, graphs, 12, setup))
+        outs.append(_run(mod, cls, graphs, 36 if algo == "sac_fused" else 12, setup))
     eager, graph = outs
-    assert graph._graph is not None and graph._graph.graph is not None
+    if algo == "sac_fused":
+        assert graph._fused_ok() and graph._chunk is not None and graph._chunk.graph is not None and getattr(eager, "_chunk", None) is None
+        for x, y in zip(eager.memory.ring, graph.memory.ring):
+            assert torch.equal(x, y)
+        assert torch.equal(eager._alpha_m, graph._alpha_m) and torch.equal(eager.actor_optimizer.v, graph.actor_optimizer.v)
+    else:
+        assert graph._graph is not None and graph._graph.graph is not None
     if algo == "rainbow":
         assert eager.optimizer.step_count == graph.optimizer.step_count >= 4
         assert torch.equal(eager.flat_params, graph.flat_params) and torch.equal(eager.target_flat, graph.target_flat)

@@ -22,19 +22,19 @@ sys.stdout = sys.__stdout__
 tr.collect_rollout()
 tr.rollout_count = 0                                   # profile the same rollout whatever ran before
 G = N // 16
-tr._wg_ticks = torch.zeros(2 * G + 16 * G, dtype=torch.int64, device=tr.device)
+tr._wg_ticks = torch.zeros(2 * G + 24 * G + 3 * N, dtype=torch.int64, device=tr.device)
 tr.collect_rollout()
 torch.cuda.synchronize()
 tk = tr._wg_ticks.cpu().numpy()
 busy = (tk[1:2 * G:2] - tk[0:2 * G:2]) / 100.0 / T
-sec = tk[2 * G:].reshape(G, 16) / 100.0 / T
+sec = tk[2 * G:26 * G].reshape(G, 24) / 100.0 / T
 slow = int(np.argmax(busy))
 names = {0: "engines+collide", 1: "constraint init", 2: "velocity sweeps (180)", 3: "store+integrate", 4: "position iterations",
          6: "  velocity sweeps, steps with a contact in the wave", 7: "  velocity sweeps, steps without", 8: "policy forward",
          9: "GAE compose + draw", 10: "env step total (load, world_step, reward, reset, store)"}
-print(f"position iterations per step: wave max {tk[2 * G:].reshape(G, 16)[:, 11].mean() / T:.2f} (slowest wg {tk[2 * G:].reshape(G, 16)[slow, 11] / T:.2f}), "
-      f"lane 0's own env {tk[2 * G:].reshape(G, 16)[:, 12].mean() / T:.2f}")
-raw = tk[2 * G:].reshape(G, 16)
+print(f"position iterations per step: wave max {tk[2 * G:26 * G].reshape(G, 24)[:, 11].mean() / T:.2f} (slowest wg {tk[2 * G:26 * G].reshape(G, 24)[slow, 11] / T:.2f}), "
+      f"lane 0's own env {tk[2 * G:26 * G].reshape(G, 24)[:, 12].mean() / T:.2f}")
+raw = tk[2 * G:26 * G].reshape(G, 24)
 print(f"env-steps still iterating at position iteration 10: {raw[:, 5].sum() / (N * T) * 100:.2f} % of env-steps; causes (may overlap): "
       f"contact separation {raw[:, 13].sum()}, joint position error {raw[:, 14].sum()}, joint angle error {raw[:, 15].sum()} of {raw[:, 5].sum()}")
 print(f"T={T}: per-WG busy us/step mean {busy.mean():.1f} max {busy.max():.1f} (wg {slow})")

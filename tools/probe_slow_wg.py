@@ -22,13 +22,13 @@ sys.stdout = sys.__stdout__
 tr.collect_rollout()
 tr.rollout_count = 0
 G = N // 16
-tr._wg_ticks = torch.zeros(2 * G + 16 * G, dtype=torch.int64, device=tr.device)
+tr._wg_ticks = torch.zeros(2 * G + 24 * G + 3 * N, dtype=torch.int64, device=tr.device)
 tr.collect_rollout()
 torch.cuda.synchronize()
 tk = tr._wg_ticks.cpu().numpy()
 busy = (tk[1:2 * G:2] - tk[0:2 * G:2]) / 100.0 / T
-sec = tk[2 * G:].reshape(G, 16) / 100.0 / T
-raw = tk[2 * G:].reshape(G, 16)
+sec = tk[2 * G:26 * G].reshape(G, 24) / 100.0 / T
+raw = tk[2 * G:26 * G].reshape(G, 24)
 order = np.argsort(-busy)
 print("wg   busy  engines  init  sweeps  (contact / none)  positions  pos-iters/step  forward")
 for g in list(order[:8]) + list(order[G // 2:G // 2 + 3]):
