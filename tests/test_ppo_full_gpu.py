@@ -125,6 +125,10 @@ def test_persistent_rollout_is_bit_identical_to_the_step_loop(N, T, variant):
         assert torch.equal(getattr(ba, k), getattr(bb, k)), k
     done = ba.dones.bool()
     assert torch.equal(ba.ep_returns[done], bb.ep_returns[done])
-    assert torch.equal(a.env.ep_stats, b.env.ep_stats)
+    # ep_stats = (episodes, sum of returns, sum of lengths) accumulated with float64 atomics, one per wave and step: counts and
+    # lengths are integers (exact in any order); the sum of ~10^5 float64 returns depends on the order the waves arrive in
+    sa, sb = a.env.ep_stats.cpu(), b.env.ep_stats.cpu()
+    assert sa[0] == sb[0] and sa[2] == sb[2] and abs(float(sa[1] - sb[1])) <= 1e-12 * max(1.0, abs(float(sa[1])))
+    assert T >= 1000 or torch.equal(sa, sb)
     assert torch.equal(adv_a, adv_b) and torch.equal(ret_a, ret_b)
     assert a.step_count == b.step_count and a.rollout_count == b.rollout_count
