@@ -43,7 +43,7 @@ SYMBOLS = [
     "gymrl_mlp_train_workspace_bytes", "gymrl_linear_tanh_smallk", "gymrl_tanh_inplace", "gymrl_tanh_bwd_colsum",
     "gymrl_linear_smallk_bwd", "gymrl_heads_fwd_tanh", "gymrl_heads_bwd", "gymrl_rollout_lunar", "gymrl_rollout_cartpole",
     "gymrl_gemm_workspace_bytes", "gymrl_linear_fwd", "gymrl_linear_bwd_input",
-    "gymrl_linear_bwd_weight_geometry", "gymrl_linear_bwd_weight", "gymrl_linear_fwd_sb", "gymrl_split_planes", "gymrl_linear_fwd_sb_planes", "gymrl_linear_bwd_input_sb",
+    "gymrl_linear_bwd_weight_geometry", "gymrl_linear_bwd_weight",
     "gymrl_heads_loss_blocks", "gymrl_heads_loss_fwd_bwd",
     "gymrl_lin_workspace_bytes", "gymrl_lin_fwd", "gymrl_lin_bwd_input", "gymrl_lin_bwd_weight",
     "gymrl_noisy_combine", "gymrl_noisy_split", "gymrl_dueling_bwd",

@@ -782,8 +782,8 @@ int gymrl_heads_loss_fwd_bwd(float* Zac, int64_t B, int C, int A, const float* b
  *                      (b NULL: no bias).  Linear + Tanh of shared.2 (N = 256) and of actor.0 | critic.0
  *                      as one N = 512 layer over their adjacent weights.
  *   linear_bwd_input   dX [B, K] = (dY [B, N] W[N, K]) * (1 - H^2), H [B, K] = the tanh output of the layer
- *                      BELOW (H NULL: no factor); colsum_out [K] = sum_rows dX (that layer's bias
- *                      gradient; NULL: skipped).  N in {256, 512}.
+ *                      BELOW (H NULL: no factor).  N in {256, 512}.  (The bias gradient of the layer below —
+ *                      the column sums of dX — comes out of that layer's linear_bwd_weight as `db`.)
  *   linear_bwd_weight  dW [N, K] = dY [B, N]^T X [B, K];  N in {256, 512}.
  *
  * Accumulation order (part of the contract — oracle/gymrl_oracle.c restates it and tests compare bit for
@@ -792,8 +792,7 @@ int gymrl_heads_loss_fwd_bwd(float* Zac, int64_t B, int C, int A, const float* b
  * f32 ((acc + b), acc * (1 - h*h)).  bwd_weight: the rows are cut into `slices` slices of
  * `rows_per_slice` rows (gymrl_linear_bwd_weight_geometry); inside a slice one fmaf chain from +0 over
  * the rows ascending; dW = ((g0 + g1) + g2) + g3 in f64, g_j = the f64 sum of the slice results s = j
- * (mod 4) ascending, rounded once to f32.  colsum_out is a fixed-order sum (device-deterministic,
- * compared at 1e-5).  act = tanh uses the same hardware-exp2 form as the passes above.  bwd_weight's db [N]
+ * (mod 4) ascending, rounded once to f32.  act = tanh uses the same hardware-exp2 form as the passes above.  bwd_weight's db [N]
  * (NULL: skipped) = column sums of dY — the bias gradient of the same layer: per slice the even- and the odd-offset
  * rows are summed sequentially in f32 and added, slices combine like the weight tiles (bit for bit in the oracle).
  * gymrl_gemm_config(key, value) exists ONLY in the probe build (make -C gymrl_amd/csrc prof -> libgymrl_hip_prof.so,
@@ -809,27 +808,6 @@ int gymrl_linear_fwd(const float* X, const float* W, const float* b, int64_t B, 
 int gymrl_linear_bwd_input(const float* dY, const float* W, const float* H, int64_t B, int N, int K,
                            float* dX, void* stream);
 int gymrl_linear_bwd_weight_geometry(int64_t B, int N, int* slices, int64_t* rows_per_slice);
-/*
- * OPT-IN split-bf16 variants of the forward and the input gradient above for the 256-wide layers (K = 256, N in {256, 512}): csrc/gemm_sb.hip.
- * Every f32 operand is split exactly into three bf16 pieces (hi / mid / lo by truncation) and six bf16 MFMAs per 16-deep step
- * (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; f32 accumulation) reproduce the f32 products to ~1.2e-7 relative at 6/16 of
- * the exact f32-MFMA time.  f32-ACCURATE, not bit-exact: results are compared with float64 (error not above the exact
- * kernels' on benign and adversarial inputs, tests/test_gemm_sb_gpu.py), never with the oracle's fmaf chain.  TWO entry points,
- * no weight-gradient variant; no trainer selects them (there is no Config switch and no bench.py line): they are reached only
- * from tests/test_gemm_sb_gpu.py and tools/{micro,abl,pmc}_gemm_sb.py — built and measured, not enabled.
- * Same argument meaning as the exact entry points.
- */
-int gymrl_linear_fwd_sb(const float* X, const float* W, const float* b, int64_t B, int K, int N, int act,
-                        float* Y, void* stream);
-/* Round 4's bounded experiment on that mode: the activations split by their PRODUCER.  gymrl_split_planes writes the three bf16
- * planes of an f32 array (P[plane][n], 6 bytes per element; in a pipeline the producing layer's epilogue would); the consumer
- * gymrl_linear_fwd_sb_planes is gymrl_linear_fwd_sb reading them ([3][B][256] bf16) — MFMAs, LDS reads and loads only, the
- * same products in the same order (bit-identical results).  Measured and not adopted: DESIGN.md section 4a. */
-int gymrl_split_planes(const float* X, int64_t n, void* planes, void* stream);
-int gymrl_linear_fwd_sb_planes(const void* X_planes, const float* W, const float* b, int64_t B, int K, int N, int act, float* Y,
-                               void* stream);
-int gymrl_linear_bwd_input_sb(const float* dY, const float* W, const float* H, int64_t B, int N, int K,
-                              float* dX, void* stream);
 int gymrl_linear_bwd_weight(const float* dY, const float* X, int64_t B, int N, int K, float* dW,
                             float* db, void* workspace, void* stream);
 

@@ -13,6 +13,8 @@ import ctypes as C  # noqa: E402
 import torch  # noqa: E402
 
 from gymrl_amd import ops  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tools", "probes"))
+import sb  # noqa: E402
 
 dev = torch.device("cuda:0")
 B = 262144
@@ -36,6 +38,6 @@ def timeit(fn, reps=20):
 names = {0: "product kernel", 1: "no MFMAs", 2: "no split / parking", 3: "no MFMAs, no split", 4: "no loads in the loop",
          6: "no split, no loads", 8: "no stores", 12: "no loads, no stores", 14: "MFMAs + LDS operand reads only"}
 for abl, name in names.items():
-    ops.lib().gymrl_gemm_sb_config(C.c_int(abl))
-    print(f"{name:36s} {timeit(lambda: ops.linear_fwd_sb(x, W, b, y, act=False)):8.1f} us", flush=True)
-ops.lib().gymrl_gemm_sb_config(C.c_int(0))
+    sb.lib().gymrl_gemm_sb_config(C.c_int(abl))
+    print(f"{name:36s} {timeit(lambda: sb.linear_fwd_sb(x, W, b, y, act=False)):8.1f} us", flush=True)
+sb.lib().gymrl_gemm_sb_config(C.c_int(0))

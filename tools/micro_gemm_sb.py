@@ -9,6 +9,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gymrl_amd import ops  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes"))
+import sb  # noqa: E402  (tools/probes/sb.py: the probe library's wrappers)
 
 
 def timeit(fn, reps=20):
@@ -43,14 +45,14 @@ def main():
         fl = 2.0 * B * 256 * N
         rows = {}
         rows["exact"] = (timeit(lambda: ops.linear_fwd(x, W, b, y, act=False)), err(y, ref))
-        rows["split_bf16"] = (timeit(lambda: ops.linear_fwd_sb(x, W, b, y2, act=False)), err(y2, ref))
+        rows["split_bf16"] = (timeit(lambda: sb.linear_fwd_sb(x, W, b, y2, act=False)), err(y2, ref))
         rows["library"] = (timeit(lambda: torch.addmm(b, x, W.t(), out=y)), err(y, ref))
         # round 4: the activations split by their producer (three bf16 planes, 6 B per element in); the producer's share is
         # what writing 1.5 x the bytes costs an HBM-bound layer kernel — measured here as the stand-alone split's time
-        planes = ops.split_planes(x)
+        planes = sb.split_planes(x)
         y3 = torch.empty(B, N, device=dev)
-        rows["split_bf16_producer_planes"] = (timeit(lambda: ops.linear_fwd_sb_planes(planes, W, b, y3, act=False)), err(y3, ref))
-        rows["(stand-alone split of x into planes)"] = (timeit(lambda: ops.split_planes(x, planes)), 0.0)
+        rows["split_bf16_producer_planes"] = (timeit(lambda: sb.linear_fwd_sb_planes(planes, W, b, y3, act=False)), err(y3, ref))
+        rows["(stand-alone split of x into planes)"] = (timeit(lambda: sb.split_planes(x, planes)), 0.0)
         del planes, y3
         del ref
         out[f"fwd 256->{N}"] = {k: dict(us=round(u, 1), TFLOPs=round(fl / u / 1e6, 1), err_vs_f64=float(f"{e:.3g}")) for k, (u, e) in rows.items()}
@@ -59,7 +61,7 @@ def main():
         ref = (dy.double() @ W.double()) * (1 - h.double() ** 2)
         rows = {}
         rows["exact"] = (timeit(lambda: ops.linear_bwd_input(dy, W, h, dx)), err(dx, ref))
-        rows["split_bf16"] = (timeit(lambda: ops.linear_bwd_input_sb(dy, W, h, dx2)), err(dx2, ref))
+        rows["split_bf16"] = (timeit(lambda: sb.linear_bwd_input_sb(dy, W, h, dx2)), err(dx2, ref))
         del ref
         out[f"dX {N}->256 tanh'"] = {k: dict(us=round(u, 1), TFLOPs=round(fl / u / 1e6, 1), err_vs_f64=float(f"{e:.3g}")) for k, (u, e) in rows.items()}
         if hasattr(ops, "linear_bwd_weight_sb") and hasattr(ops.lib(), "gymrl_linear_bwd_weight_sb"):

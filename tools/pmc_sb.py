@@ -3,6 +3,8 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gymrl_amd import ops
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes"))
+import sb
 dev = torch.device("cuda:0")
 B = 262144
 g = torch.Generator(device=dev).manual_seed(0)
@@ -11,6 +13,6 @@ W = torch.randn(256, 256, device=dev, generator=g) / 16
 b = torch.randn(256, device=dev, generator=g)
 y = torch.empty(B, 256, device=dev)
 for _ in range(3):
-    ops.linear_fwd_sb(x, W, b, y, act=False)
+    sb.linear_fwd_sb(x, W, b, y, act=False)
     ops.linear_fwd(x, W, b, y, act=False)
 torch.cuda.synchronize()

@@ -1,4 +1,4 @@
-"""The opt-in split-bf16 GEMMs (csrc/gemm_sb.hip: every f32 operand as three bf16 pieces, six bf16 MFMAs per step, f32
+"""The opt-in split-bf16 GEMMs (tools/probes/gemm_sb.hip — a PROBE library since round 5, run with `python -m pytest tools/probes -m gpu`: every f32 operand as three bf16 pieces, six bf16 MFMAs per step, f32
 accumulation) against float64 — beside the exact f32-MFMA kernels on the SAME inputs: the mode's error against float64 must
 not exceed the exact kernel's class of error (a small multiple, never an order of magnitude), on benign inputs and on
 adversarial ones: heavy cancellation, 2^+-60 dynamic range inside one reduction, denormal-adjacent magnitudes, exact
@@ -6,8 +6,14 @@ powers of two, signed zeros.  Never compared with the oracle's fmaf chain: this 
 import numpy as np
 import pytest
 
+import os
+import sys
+
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.dirname(os.path.abspath(__file__))]
+import sb  # noqa: E402  (this directory: the probe library's wrappers)
 
 
 @pytest.fixture(scope="module")
@@ -54,14 +60,14 @@ def test_split_bf16_forward_is_f32_accurate(dev, N):
         ref = x.double() @ W.double().t() + b.double()
         y_ex = ops.linear_fwd(x, W, b, torch.empty(B, N, device=dev), act=False)
         y_sb = torch.full((B + 2, N), float("nan"), device=dev)
-        ops.linear_fwd_sb(x, W, b, y_sb[:B], act=False)
+        sb.linear_fwd_sb(x, W, b, y_sb[:B], act=False)
         assert bool(torch.isnan(y_sb[B:]).all()), name                 # nothing written past the last row
         e_ex, e_sb = _rel(y_ex, ref), _rel(y_sb[:B], ref)
         assert e_sb <= max(2.0 * e_ex, 3e-7), (name, e_sb, e_ex)
     # tanh epilogue = the exact kernel's (hardware exp2 / rcp on a sum that differs by f32 round-off)
     x = torch.randn(B, K, device=dev, generator=gen)
     h_ex = ops.linear_fwd(x, W, b, torch.empty(B, N, device=dev), act=True)
-    h_sb = ops.linear_fwd_sb(x, W, b, torch.empty(B, N, device=dev), act=True)
+    h_sb = sb.linear_fwd_sb(x, W, b, torch.empty(B, N, device=dev), act=True)
     assert float((h_ex - h_sb).abs().max()) <= 1e-5
 
 
@@ -79,7 +85,7 @@ def test_split_bf16_input_gradient_is_f32_accurate(dev, N, with_h):
             ref = ref * (1 - H.double() ** 2)
         dx_ex = ops.linear_bwd_input(dy, W, H, torch.empty(B, K, device=dev))
         dx_sb = torch.full((B + 3, K), float("nan"), device=dev)
-        ops.linear_bwd_input_sb(dy, W, H, dx_sb[:B])
+        sb.linear_bwd_input_sb(dy, W, H, dx_sb[:B])
         assert bool(torch.isnan(dx_sb[B:]).all()), name
         e_ex, e_sb = _rel(dx_ex, ref), _rel(dx_sb[:B], ref)
         assert e_sb <= max(2.0 * e_ex, 3e-7), (name, e_sb, e_ex)
@@ -93,7 +99,7 @@ def test_split_is_exact_on_the_device(dev):
     B = 2048
     x = torch.randn(B, 256, device=dev, generator=gen) * torch.exp2(torch.randint(-40, 41, (B, 256), device=dev, generator=gen).float())
     eye = torch.eye(256, device=dev)
-    y = ops.linear_fwd_sb(x, eye, None, torch.empty(B, 256, device=dev), act=False)
+    y = sb.linear_fwd_sb(x, eye, None, torch.empty(B, 256, device=dev), act=False)
     assert torch.equal(y, x)
 
 
@@ -107,12 +113,12 @@ def test_split_bf16_forward_on_producer_planes_equals_consumer_split(dev, N, act
     W = torch.randn(N, K, device=dev, generator=gen) / 16
     b = torch.randn(N, device=dev, generator=gen)
     for name, x in _cases(B, K, dev, gen).items():
-        y_sb = ops.linear_fwd_sb(x, W, b, torch.empty(B, N, device=dev), act=act)
-        planes = ops.split_planes(x)
+        y_sb = sb.linear_fwd_sb(x, W, b, torch.empty(B, N, device=dev), act=act)
+        planes = sb.split_planes(x)
         rebuilt = sum((planes[k].view(torch.bfloat16).float() for k in range(3)))
         if name not in ("near_denormal",):                                 # (the third piece of a near-denormal may flush)
             assert torch.equal(rebuilt, x), name                           # the three pieces ARE the float
         y_pl = torch.full((B + 2, N), float("nan"), device=dev)
-        ops.linear_fwd_sb_planes(planes, W, b, y_pl[:B], act=act)
+        sb.linear_fwd_sb_planes(planes, W, b, y_pl[:B], act=act)
         assert bool(torch.isnan(y_pl[B:]).all()), name
         assert torch.equal(y_pl[:B], y_sb), name
