@@ -150,13 +150,25 @@ __global__ __launch_bounds__(1024) void per_ancestor_kernel(double* __restrict__
 }
 
 // ---- explicit index batches of up to kSmallB elements (update_priorities at the reference's batch sizes) ------------------
-// The two kernels above resolve "who touched this leaf / node before me" with one thread per element walking the batch
-// (O(B) dependent LDS round trips each, 64-bit tree positions and a clz + shift per comparison): 27 + 44 us at B = 256
-// (profiles/r04_rainbow_kernel_stats_a.csv), a quarter of a Rainbow vector step.  Here the ids are 32-bit, computed ONCE per
-// element and level, four lanes share an element's search (each a quarter of the range, combined with two shuffles), and
-// only the ordered float64 sum of a node — the one thing the reference's order makes sequential — runs on one lane.
-// Same sums in the same order: the float64 tree stays bit-identical (tests/test_hip_parity_offpolicy.py::test_sumtree_*).
+// Rounds 2-4 resolved "who touched this leaf / node before me" with per-element SEARCHES through LDS (dependent ~100-clock
+// round trips, O(B) each: 15 + 28 us for 256 priorities in two launches, a quarter of a Rainbow vector step).  Here a wave
+// keeps the whole batch's ids in registers — lane l holds elements l, l + 64, ... — and asks the question for one element at
+// a time with a wave-wide compare: the answer is a B-bit ballot mask in scalar registers, "the latest earlier element on
+// the same leaf" / "is there a later one" / "am I the first to reach this node" are bit scans of it, and a node's elements
+// are compacted (popcount below the lane = position in batch order) into a staging row from which ONE lane adds them in
+// order — the one thing the reference's loop (:258-261 -> :122-128) makes sequential.  Same float64 sums in the same
+// order: the tree stays bit-identical (tests/test_hip_parity_offpolicy.py::test_sumtree_*).
+//
+// ONE launch (gymrl_per_update_td with a ticket): blocks 0 .. depth-1 take one tree depth each — every one of them derives
+// leaves, priorities and the per-element change itself from (idx, td, the OLD leaf values), nothing is handed over —, blocks
+// depth .. depth+nb-1 scan the leaves for the new maximum (the batch's leaves masked out by a bitmap and replaced by their
+// final values), and the LAST block to finish (a ticket) writes the leaves and folds the maxima: every reader of an old
+// leaf value has then passed the ticket.  Without a ticket (gymrl_per_update) the same code runs as two launches: a leaf
+// block that also publishes the changes, then the depth blocks.
 constexpr int kSmallB = 512;
+constexpr int kSmallK = kSmallB / 64;          // register slots per lane: elements lane + 64 k
+constexpr int kSmallWaves = 16;                // 1024 threads
+constexpr int kMaxChunk = 8192;                // leaves per maximum block (8 per thread)
 
 // |td| -> priority, update_priorities' transform (rainbow_dqn_cartpole.py:258-261): float32 arithmetic like the reference —
 // np.abs(f32) + python float and ** python float stay float32 under NumPy >= 2 —, x**a as exp(a log x) with the reproducible
@@ -168,118 +180,238 @@ __device__ __forceinline__ double td_priority(float td, double alpha, double eps
 }
 
 struct TdPrio { const float* td; double alpha, eps, clip; };   // td != nullptr: the batch's priorities are td_priority(td[i])
-
-__global__ __launch_bounds__(1024) void per_leaf_small_kernel(double* __restrict__ tree, int64_t cap, const int32_t* __restrict__ idx,
-                                                              int idx_is_tree, const double* __restrict__ prio,
-                                                              const double* __restrict__ ps_dev, double ps, int B,
-                                                              int64_t* __restrict__ leaf_out, double* __restrict__ change_out,
-                                                              TdPrio tp) {
-  __shared__ int32_t s_leaf[kSmallB];
-  __shared__ double s_prio[kSmallB];
-  for (int i = threadIdx.x; i < B; i += blockDim.x) {
-    const int32_t leaf = idx_is_tree ? idx[i] : idx[i] + (int32_t)(cap - 1);
-    s_leaf[i] = leaf;
-    leaf_out[i] = leaf;
-    s_prio[i] = tp.td ? td_priority(tp.td[i], tp.alpha, tp.eps, tp.clip) : prio_of(prio, ps_dev, ps, i);
-  }
-  __syncthreads();
-  // change_i = p_i - (value of the leaf just before element i is applied): the latest earlier element on the same leaf, else the tree
-  for (int w = threadIdx.x; w < 4 * B; w += blockDim.x) {
-    const int i = w >> 2, s = w & 3;
-    const int32_t leaf = s_leaf[i];
-    int found = -1;
-    for (int j = i - 1 - s; j >= 0; j -= 4)
-      if (s_leaf[j] == leaf) { found = j; break; }
-    found = max(found, __shfl_xor(found, 1, 64));
-    found = max(found, __shfl_xor(found, 2, 64));
-    if (s == 0) {
-      const double prev = found >= 0 ? s_prio[found] : tree[leaf];
-      change_out[i] = s_prio[i] - prev;
-    }
-  }
-  __syncthreads();
-  // last writer wins
-  for (int w = threadIdx.x; w < 4 * B; w += blockDim.x) {
-    const int i = w >> 2, s = w & 3;
-    const int32_t leaf = s_leaf[i];
-    int later = 0;
-    for (int j = i + 1 + s; j < B; j += 4)
-      if (s_leaf[j] == leaf) { later = 1; break; }
-    later |= __shfl_xor(later, 1, 64);
-    later |= __shfl_xor(later, 2, 64);
-    if (s == 0 && !later) tree[leaf] = s_prio[i];
-  }
-}
-
-// The maximum over the leaves beside the ancestors' sums: what the NEXT store_transition() gives its new rows (:186-189).
-// It needs the leaves only, which the launch before this one has written — so the scan rides in the ancestor launch as
-// extra workgroups (blockIdx.x >= depth) instead of two launches of its own behind it, and the last of them to finish
-// folds the partials (`ticket`: zero before the first use, left zero).  max is exact in any order.
 struct MaxLeaf { int64_t cap; double* partial; double* out; unsigned int* ticket; int nb; };
+enum { SMALL_FUSED = 0, SMALL_LEAF = 1, SMALL_ANC = 2 };
+struct SmallArgs {
+  double* tree; int64_t cap; const int32_t* idx; int idx_is_tree; const double* prio; const double* ps_dev; double ps; int B;
+  TdPrio tp; int depth; MaxLeaf mx; double* change_ws; int mode;
+};
+struct SmallLds {
+  int32_t leaf[kSmallB];
+  double p[kSmallB], old[kSmallB], change[kSmallB];
+  uint8_t last[kSmallB];
+};
 
-__device__ __forceinline__ void max_leaf_block(const double* __restrict__ tree, const MaxLeaf& m, int b) {
-  __shared__ double sm[1024];
-  __shared__ unsigned int s_last;
-  double v = -1.0e308;
-  for (int64_t i = (int64_t)b * blockDim.x + threadIdx.x; i < m.cap; i += (int64_t)m.nb * blockDim.x) v = fmax(v, tree[m.cap - 1 + i]);
-  sm[threadIdx.x] = v;
-  __syncthreads();
-  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
-    __syncthreads();
+// bit scans of a B-bit mask held as kSmallK 64-bit words (all operands wave-uniform: scalar code)
+__device__ __forceinline__ int highest_below(const uint64_t (&m)[kSmallK], int KB, int i) {
+  int r = -1;
+#pragma unroll
+  for (int k = 0; k < kSmallK; ++k) {
+    if (k >= KB) break;
+    const uint64_t mm = k < (i >> 6) ? m[k] : (k == (i >> 6) ? m[k] & ((1ull << (i & 63)) - 1ull) : 0ull);
+    if (mm) r = 64 * k + 63 - __clzll((unsigned long long)mm);
   }
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(m.partial + b, sm[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
-    s_last = atomicAdd(m.ticket, 1u) == (unsigned int)(m.nb - 1);
+  return r;
+}
+__device__ __forceinline__ bool any_above(const uint64_t (&m)[kSmallK], int KB, int i) {
+  uint64_t acc = 0ull;
+#pragma unroll
+  for (int k = 0; k < kSmallK; ++k) {
+    if (k >= KB) break;
+    acc |= k > (i >> 6) ? m[k] : (k == (i >> 6) ? m[k] & ~((2ull << (i & 63)) - 1ull) : 0ull);
   }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  v = -1.0e308;
-  for (int i = threadIdx.x; i < m.nb; i += blockDim.x) v = fmax(v, __hip_atomic_load(m.partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  sm[threadIdx.x] = v;
-  __syncthreads();
-  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) { m.out[0] = sm[0]; *m.ticket = 0u; }
+  return acc != 0ull;
 }
 
-// blockIdx.x = node depth d.  A node's additions happen in batch order (the reference's loop).
-__global__ __launch_bounds__(1024) void per_ancestor_small_kernel(double* __restrict__ tree, const int64_t* __restrict__ leaf_g,
-                                                                  const double* __restrict__ change_g, int B, int depth, MaxLeaf mx) {
-  __shared__ int32_t s_node[kSmallB];       // the element's ancestor at this depth, -1: none
-  __shared__ double s_change[kSmallB];
-  if ((int)blockIdx.x >= depth) { max_leaf_block(tree, mx, (int)blockIdx.x - depth); return; }
-  const int d = blockIdx.x;
-  for (int i = threadIdx.x; i < B; i += blockDim.x) {
-    const int64_t lf = leaf_g[i];
-    const int L = depth_of(lf);
-    s_node[i] = L > d ? (int32_t)(((lf + 1) >> (L - d)) - 1) : -1;
-    s_change[i] = change_g[i];
+__device__ __forceinline__ int small_node(int32_t leaf, int d) {          // the leaf's ancestor at depth d, -1: none
+  if (leaf < 0) return -1;
+  const int L = 31 - __clz(leaf + 1);
+  return L > d ? ((leaf + 1) >> (L - d)) - 1 : -1;
+}
+
+// batch -> LDS: leaves, new priorities and (want_old) the leaves' current values
+__device__ __forceinline__ void small_load(const SmallArgs& a, SmallLds& s, bool want_old) {
+  for (int i = threadIdx.x; i < a.B; i += blockDim.x) {
+    const int32_t leaf = a.idx_is_tree ? a.idx[i] : a.idx[i] + (int32_t)(a.cap - 1);
+    s.leaf[i] = leaf;
+    if (want_old) s.old[i] = a.tree[leaf];
+    s.p[i] = a.tp.td ? td_priority(a.tp.td[i], a.tp.alpha, a.tp.eps, a.tp.clip) : prio_of(a.prio, a.ps_dev, a.ps, i);
+  }
+}
+
+// change_i = p_i - (value of the leaf just before element i is applied: the latest earlier element on the same leaf, else the
+// tree); last_i = no later element writes the same leaf.  Wave w takes the elements w, w + 16, ...
+__device__ __forceinline__ void small_dups(const SmallArgs& a, SmallLds& s, const int32_t (&my_leaf)[kSmallK], int KB, int wave, int lane) {
+  const int cand = wave + kSmallWaves * lane;                       // lane c finishes candidate c of this wave
+  const int32_t cl = (lane < kSmallB / kSmallWaves && cand < a.B) ? s.leaf[cand] : -2;
+  int prevL = -1;
+  bool laterL = false;
+  for (int c = 0; wave + kSmallWaves * c < a.B; ++c) {
+    const int i = wave + kSmallWaves * c;
+    const int32_t li = __builtin_amdgcn_readlane(cl, c);
+    uint64_t m[kSmallK];
+#pragma unroll
+    for (int k = 0; k < kSmallK; ++k) m[k] = k < KB ? __builtin_amdgcn_ballot_w64(my_leaf[k] == li) : 0ull;
+    const int prev = highest_below(m, KB, i);
+    const bool later = any_above(m, KB, i);
+    if (lane == c) { prevL = prev; laterL = later; }
+  }
+  if (cl >= 0) {
+    s.change[cand] = s.p[cand] - (prevL >= 0 ? s.p[prevL] : s.old[cand]);
+    s.last[cand] = laterL ? 0 : 1;
+  }
+}
+
+// The additions of depth d's nodes, each node's in batch order.  stage: this wave's row of B doubles.
+__device__ __forceinline__ void small_ancestors(const SmallArgs& a, SmallLds& s, const int32_t (&my_leaf)[kSmallK], int KB, int d,
+                                                int wave, int lane, double* stage) {
+  int32_t my_node[kSmallK];
+  double my_change[kSmallK];
+#pragma unroll
+  for (int k = 0; k < kSmallK; ++k) {
+    my_node[k] = k < KB ? small_node(my_leaf[k], d) : -1;
+    my_change[k] = (k < KB && lane + 64 * k < a.B) ? s.change[lane + 64 * k] : 0.0;
+  }
+  const int cand = wave + kSmallWaves * lane;
+  const int32_t cn = (lane < kSmallB / kSmallWaves && cand < a.B) ? small_node(s.leaf[cand], d) : -1;
+  const double treeval = cn >= 0 ? a.tree[cn] : 0.0;               // requested now, needed after the loop
+  int startL = 0, lenL = 0, base = 0;
+  for (int c = 0; wave + kSmallWaves * c < a.B; ++c) {
+    const int i = wave + kSmallWaves * c;
+    const int32_t ni = __builtin_amdgcn_readlane(cn, c);
+    if (ni < 0) continue;
+    uint64_t m[kSmallK];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kSmallK; ++k) {
+      m[k] = k < KB ? __builtin_amdgcn_ballot_w64(my_node[k] == ni) : 0ull;
+      cnt += __popcll((unsigned long long)m[k]);
+    }
+    if (highest_below(m, KB, i) >= 0) continue;                    // an earlier element reaches this node first: its run
+    if (cnt == 1) {                                                // a run of one (nearly every node of the deep levels)
+      if (lane == c) { startL = -1; lenL = 1; }
+      continue;
+    }
+    int at = base;
+#pragma unroll
+    for (int k = 0; k < kSmallK; ++k) {
+      if (k >= KB || m[k] == 0ull) continue;
+      const uint32_t lo = (uint32_t)m[k], hi = (uint32_t)(m[k] >> 32);
+      const int below = (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+      if ((m[k] >> lane) & 1ull) stage[at + below] = my_change[k];
+      at += __popcll((unsigned long long)m[k]);
+    }
+    if (lane == c) { startL = base; lenL = cnt; }
+    base = at;
+  }
+  __syncthreads();                                                 // (uniform: every wave's loop is wave-uniform) staged runs are visible
+  if (lenL > 0) {
+    double acc = treeval;
+    if (startL < 0) acc += s.change[cand];
+    else {
+      const double* run = stage + startL;
+      int t = 0;
+      for (; t + 8 <= lenL; t += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = run[t + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+      }
+      for (; t < lenL; ++t) acc += run[t];
+    }
+    a.tree[cn] = acc;
+  }
+}
+
+__device__ __forceinline__ double block_max(double v, double* sm16) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm16[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = sm16[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = fmax(r, sm16[w]);
+  return r;
+}
+
+// The maximum over the leaves AS THEY WILL BE after this update: what the NEXT store_transition() gives its new rows
+// (:186-189).  Block b scans leaves [b * kMaxChunk, ...): the batch's leaves are skipped (bitmap) and enter with their final
+// values (the last element on each leaf), so the scan needs no leaf that this launch writes.  max is exact in any order.
+__device__ __forceinline__ void small_max_block(const SmallArgs& a, SmallLds& s, int b, double* sm16) {
+  __shared__ uint32_t bm[kMaxChunk / 32];
+  const int64_t lo = (int64_t)b * kMaxChunk;
+  for (int t = threadIdx.x; t < kMaxChunk / 32; t += blockDim.x) bm[t] = 0u;
+  __syncthreads();
+  const int i = threadIdx.x;
+  int64_t off = -1;
+  if (i < a.B) {
+    off = (int64_t)s.leaf[i] - (a.cap - 1) - lo;
+    if (off >= 0 && off < kMaxChunk) atomicOr(&bm[off >> 5], 1u << (off & 31));
   }
   __syncthreads();
-  for (int w = threadIdx.x; w < 4 * B; w += blockDim.x) {
-    const int i = w >> 2, s = w & 3;
-    const int32_t node = s_node[i];
-    int earlier = 0;                         // leader = the first batch element reaching this node
-    if (node >= 0)
-      for (int j = s; j < i; j += 4)
-        if (s_node[j] == node) { earlier = 1; break; }
-    earlier |= __shfl_xor(earlier, 1, 64);
-    earlier |= __shfl_xor(earlier, 2, 64);
-    if (s != 0 || node < 0 || earlier) continue;
-    double acc = tree[node];
-    for (int j0 = i; j0 < B; j0 += 8) {      // the node's additions in batch order, operands fetched eight at a time
-      int32_t v[8]; double c[8];
+  double v = -1.0e308;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const bool in = j0 + u < B; v[u] = in ? s_node[j0 + u] : -1; c[u] = in ? s_change[j0 + u] : 0.0; }
+  for (int u = 0; u < kMaxChunk / 1024; ++u) {
+    const int o = threadIdx.x + 1024 * u;
+    if (lo + o < a.cap && !((bm[o >> 5] >> (o & 31)) & 1u)) v = fmax(v, a.tree[a.cap - 1 + lo + o]);
+  }
+  if (off >= 0 && off < kMaxChunk) {                               // (about two elements per block at B = 256, cap = 2^20)
+    bool later = false;
+    for (int j = i + 1; j < a.B; ++j) later = later || s.leaf[j] == s.leaf[i];
+    if (!later) v = fmax(v, s.p[i]);
+  }
+  v = block_max(v, sm16);
+  if (threadIdx.x == 0) __hip_atomic_store(a.mx.partial + b, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(1024) void per_small_kernel(SmallArgs a) {
+  __shared__ SmallLds s;
+  __shared__ double sm16[kSmallWaves];
+  __shared__ unsigned int s_is_last;
+  extern __shared__ __attribute__((aligned(16))) double s_stage[];   // [16 waves][B]
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int KB = (a.B + 63) >> 6;
+  const bool depth_block = a.mode == SMALL_ANC || (a.mode == SMALL_FUSED && (int)blockIdx.x < a.depth);
+  const bool need_change = a.mode != SMALL_ANC && (a.mode == SMALL_LEAF || depth_block);
+  small_load(a, s, need_change);
+  if (a.mode == SMALL_ANC)
+    for (int i = threadIdx.x; i < a.B; i += blockDim.x) s.change[i] = a.change_ws[i];
+  __syncthreads();
+  int32_t my_leaf[kSmallK];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) if (v[u] == node) acc += c[u];
+  for (int k = 0; k < kSmallK; ++k) my_leaf[k] = (k < KB && lane + 64 * k < a.B) ? s.leaf[lane + 64 * k] : -1;
+  bool have_last = false;
+  if (need_change) {
+    small_dups(a, s, my_leaf, KB, wave, lane);
+    have_last = true;
+    __syncthreads();
+  }
+  if (depth_block) small_ancestors(a, s, my_leaf, KB, (int)blockIdx.x, wave, lane, s_stage + (size_t)wave * a.B);
+  else if (a.mode == SMALL_FUSED) small_max_block(a, s, (int)blockIdx.x - a.depth, sm16);
+  if (a.mode == SMALL_ANC) return;
+  bool write_leaves = a.mode == SMALL_LEAF;
+  if (a.mode == SMALL_LEAF)
+    for (int i = threadIdx.x; i < a.B; i += blockDim.x) a.change_ws[i] = s.change[i];
+  if (a.mode == SMALL_FUSED) {                                     // the last block to get here: every old leaf value has been read
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      s_is_last = atomicAdd(a.mx.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
     }
-    tree[node] = acc;
+    __syncthreads();
+    write_leaves = s_is_last != 0u;
+    if (write_leaves) __threadfence();
+  }
+  if (!write_leaves) return;
+  if (!have_last) {                                                // (a maximum block came last)
+    for (int i = threadIdx.x; i < a.B; i += blockDim.x) {
+      bool later = false;
+      for (int j = i + 1; j < a.B; ++j) later = later || s.leaf[j] == s.leaf[i];
+      s.last[i] = later ? 0 : 1;
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < a.B; i += blockDim.x)
+    if (s.last[i]) a.tree[s.leaf[i]] = s.p[i];                     // last writer wins
+  if (a.mode == SMALL_FUSED) {
+    if (a.mx.nb > 0) {
+      double v = -1.0e308;
+      for (int t = threadIdx.x; t < a.mx.nb; t += blockDim.x) v = fmax(v, __hip_atomic_load(a.mx.partial + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      v = block_max(v, sm16);
+      if (threadIdx.x == 0) a.mx.out[0] = v;
+    }
+    if (threadIdx.x == 0) *a.mx.ticket = 0u;
   }
 }
 
@@ -545,6 +677,17 @@ __global__ __launch_bounds__(kBlock) void per_normalize_kernel(float* __restrict
   else w32[i] = w32[i] / (float)m;                        // is_weight /= is_weight.max() in float32 (:241)
 }
 
+inline size_t small_stage_bytes(int B) { return sizeof(double) * (size_t)kSmallWaves * (size_t)B; }
+inline bool small_attr() {
+  static bool set = false;
+  if (!set) {
+    if (hipFuncSetAttribute((const void*)per_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_stage_bytes(kSmallB)) != hipSuccess)
+      return false;
+    set = true;
+  }
+  return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -601,12 +744,13 @@ int gymrl_per_update(double* tree, int64_t cap, const int32_t* idx, int64_t idx_
     GYMRL_CHECK_LAUNCH();
     return 0;
   }
-  if (B <= kSmallB && 2 * cap < (1ll << 31)) {                           // the reference's batch sizes: 32-bit ids, shared searches
-    hipLaunchKernelGGL(per_leaf_small_kernel, dim3(1), dim3(1024), 0, stream, tree, cap, idx, idx_is_tree, prio, prio_scalar_dev,
-                       prio_scalar, B, ws.leaf, ws.change, TdPrio{nullptr, 0.0, 0.0, 0.0});
-    if (depth > 0)
-      hipLaunchKernelGGL(per_ancestor_small_kernel, dim3(depth), dim3(1024), 0, stream, tree, ws.leaf, ws.change, B, depth,
-                         MaxLeaf{0, nullptr, nullptr, nullptr, 0});
+  if (B <= kSmallB && 2 * cap < (1ll << 31)) {                           // the reference's batch sizes: ballots, no searches (two launches: no ticket here)
+    if (!small_attr()) return -1000 - (int)hipGetLastError();
+    SmallArgs a{tree, cap, idx, idx_is_tree, prio, prio_scalar_dev, prio_scalar, B, TdPrio{nullptr, 0.0, 0.0, 0.0}, depth,
+                MaxLeaf{0, nullptr, nullptr, nullptr, 0}, ws.change, SMALL_LEAF};
+    hipLaunchKernelGGL(per_small_kernel, dim3(1), dim3(1024), 0, stream, a);
+    a.mode = SMALL_ANC;
+    if (depth > 0) hipLaunchKernelGGL(per_small_kernel, dim3(depth), dim3(1024), small_stage_bytes(B), stream, a);
     GYMRL_CHECK_LAUNCH();
     return 0;
   }
@@ -648,14 +792,21 @@ int gymrl_per_update_td(double* tree, int64_t cap, const int32_t* idx, const flo
   Ws ws(workspace, B);
   int depth = 0;
   { int64_t t = 2 * cap - 2; while (t > 0) { t = (t - 1) / 2; ++depth; } }
-  int nb = max_out ? cdiv(cap, (int64_t)1024 * 8) : 0;
-  if (nb > 1024) nb = 1024;
-  hipLaunchKernelGGL(per_leaf_small_kernel, dim3(1), dim3(1024), 0, stream, tree, cap, idx, 0, nullptr, nullptr, 0.0, B,
-                     ws.leaf, ws.change, TdPrio{td, alpha, eps, clip});
-  if (depth + nb > 0)
-    hipLaunchKernelGGL(per_ancestor_small_kernel, dim3(depth + nb), dim3(1024), 0, stream, tree, ws.leaf, ws.change, B, depth,
-                       MaxLeaf{cap, ws.partial, max_out, ticket, nb});
+  if (!small_attr()) return -1000 - (int)hipGetLastError();
+  SmallArgs a{tree, cap, idx, 0, nullptr, nullptr, 0.0, B, TdPrio{td, alpha, eps, clip}, depth,
+              MaxLeaf{cap, ws.partial, max_out, ticket, 0}, ws.change, SMALL_FUSED};
+  const bool fused_max = max_out && cap <= (int64_t)kMaxChunk * 1024;
+  if (ticket && depth > 0) {                             // ONE launch: depth blocks | maximum blocks, the last one writes the leaves
+    a.mx.nb = fused_max ? cdiv(cap, kMaxChunk) : 0;
+    hipLaunchKernelGGL(per_small_kernel, dim3(depth + a.mx.nb), dim3(1024), small_stage_bytes(B), stream, a);
+  } else {
+    a.mode = SMALL_LEAF;
+    hipLaunchKernelGGL(per_small_kernel, dim3(1), dim3(1024), 0, stream, a);
+    a.mode = SMALL_ANC;
+    if (depth > 0) hipLaunchKernelGGL(per_small_kernel, dim3(depth), dim3(1024), small_stage_bytes(B), stream, a);
+  }
   GYMRL_CHECK_LAUNCH();
+  if (max_out && !(ticket && depth > 0 && fused_max)) return gymrl_per_max_leaf(tree, cap, max_out, ws.partial, stream_);
   return 0;
 }
 

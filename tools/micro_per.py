@@ -39,3 +39,18 @@ for B, kind in ((8192, "rows"), (256, "idx"), (256, "idx_dup"), (512, "idx"), (1
             idx[::3] = idx[0]
         fn = lambda: ops.per_update(tree, cap, B, ws, idx=idx, prio=prio)
     print(f"B = {B:5d} {kind:8s}: {timeit(fn):7.1f} us per update (back-to-back launches)")
+
+# update_priorities as the Rainbow trainer issues it: straight from the TD errors, the next store's priority_max in the same
+# ONE launch (gymrl_per_update_td with a ticket: depth blocks | maximum blocks, the last block writes the leaves)
+ws = ops.per_workspace(8192, dev)
+mx = torch.zeros(1, dtype=torch.float64, device=dev)
+ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+for B in (128, 256, 512):
+    idx = torch.randint(0, cap, (B,), device=dev, generator=g, dtype=torch.int32)
+    td = torch.randn(B, device=dev, generator=g)
+    fn = lambda: ops.per_update_td(tree, cap, idx, td, 0.6, 0.01, ws, max_out=mx, ticket=ticket)
+    print(f"B = {B:5d} td+max  : {timeit(fn):7.1f} us per update_td (one launch, leaves' maximum included)")
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record(); fn(); e.record(); torch.cuda.synchronize()
+    print(f"          single launch, idle queue: {s.elapsed_time(e) * 1e3:7.1f} us")
