@@ -206,10 +206,10 @@ def main_offpolicy(a, rank, world, local_rank):
     VS = 16
     if a.algo == "rainbow":
         from gymrl_amd.rainbow_dqn_cartpole import Config, RainbowDQNTrainer as Trainer
-        N, B, env_name = a.envs, 256, "CartPole-v1"
+        N, B, env_name = a.envs, a.batch or 256, "CartPole-v1"
     else:
         from gymrl_amd.sac_pendulum import Config, SACTrainer as Trainer
-        N, B, env_name = a.envs, 128, "Pendulum-v1"
+        N, B, env_name = a.envs, a.batch or 128, "Pendulum-v1"
     cfg = Config()
     cfg.num_envs, cfg.memory_capacity, cfg.max_episodes, cfg.batch_size, cfg.seed = N, 1 << 20, 10 ** 9, B, 0
     cfg.device = str(dev)
@@ -247,7 +247,7 @@ def main_offpolicy(a, rank, world, local_rank):
             from gymrl_amd import ops
             D = 4
             row_bytes = 4 * (2 * D + 2) + 1 + 4                     # state, next_state, action, reward, flag + the index
-            for nb in (B, 65536):
+            for nb in sorted({B, 8192, 65536}):
                 idx = torch.empty(nb, dtype=torch.int32, device=dev)
                 pr, w = torch.empty(nb, dtype=torch.float64, device=dev), torch.empty(nb, device=dev)
                 ws = ops.per_workspace(max(8192, cap, nb), dev)
@@ -298,9 +298,18 @@ def main_offpolicy(a, rank, world, local_rank):
                        "+ the new rows' sum-tree store on the side stream"] = dict(us=round(us, 2), TFLOPs=round(fl / us / 1e6, 2))
                 upd_us = _event_us(lambda: tr.update_async(), reps=30)
                 flu = 2.0 * B * (3 * (4 * H + H * H + 3 * H) + (3 * H + H * H) + (3 * H + H * H + 4 * H))
+                cus = min(256, 3 * ((B + 15) // 16))
                 pieces[f"one update at batch {B} (proportional draw, three forwards, TD loss, backward, clip + Adam + Polyak, update_priorities)"] = dict(
-                    us=round(upd_us, 2), TFLOPs=round(flu / upd_us / 1e6, 3),
-                    note="gymrl_rainbow_update's row kernel carries 16 rows per workgroup: B / 16 = 16 of the 256 compute units do its MFMA work")
+                    us=round(upd_us, 2), TFLOPs=round(flu / upd_us / 1e6, 3), frac_mfma=round(flu / upd_us / 1e6 / (MFMA_F32_PEAK / 1e12), 5),
+                    note=f"gymrl_rainbow_update's row kernel carries 16 rows per workgroup, three workgroups per slab: {cus} of the 256 compute units do its MFMA work")
+                if B > 256:      # SURVEY 8(d)'s throughput-sized line: the update is the dominant launch group, priced against the f32-MFMA peak
+                    pieces[f"per_update N={N} (the new rows of one vector step): the small-batch line's roofline"] = roof
+                    roof = dict(bound="mfma", unit="TFLOP/s", peak=MFMA_F32_PEAK / 1e12, achieved=round(flu / upd_us / 1e6, 3),
+                                frac=round(flu / upd_us / 1e6 / (MFMA_F32_PEAK / 1e12), 5), traffic=None, launch_s=upd_us * 1e-6,
+                                flops_per_launch_group=flu, compute_units_carrying_rows=cus,
+                                kernel=f"one Rainbow update at batch {B}: gymrl_rainbow_update's row-slab kernel ({3 * ((B + 15) // 16)} workgroups of 16 rows on slab-adjacent "
+                                       "1-D grids) + the weight-gradient tiles in lin.hip's 256-row slices + clip / Adam / Polyak + update_priorities "
+                                       "(sort-based passes above 512 indices)")
         else:
             from gymrl_amd import ops
             D, A = 3, 1
@@ -319,17 +328,17 @@ def main_offpolicy(a, rank, world, local_rank):
             flu = (actor_f + 2 * q_f + 2 * q_f + 2 * 2.0 * B * (H + H * H) + 2 * q_f            # P1 + critic dW
                    + actor_f + 2 * q_f + 2 * 2.0 * B * (H + H * H + DA * H) + 2.0 * B * (2 * A * H + H * H) + actor_f)   # P3 + actor dW
             upd_us = _event_us(lambda: tr.update_async() if getattr(cfg, "use_graphs", True) else tr.update(), reps=50)
-            cus = 4 * ((B + 15) // 16)      # P1: four workgroups per 16-row slab (P3: two)
+            cus = min(256, 4 * ((B + 15) // 16))      # P1: four workgroups per 16-row slab (P3: two)
             roof = dict(bound="mfma", unit="TFLOP/s", peak=MFMA_F32_PEAK / 1e12, achieved=round(flu / upd_us / 1e6, 3),
                         frac=round(flu / upd_us / 1e6 / (MFMA_F32_PEAK / 1e12), 5), traffic=None, launch_s=upd_us * 1e-6,
                         flops_per_launch_group=flu, compute_units_carrying_rows=cus,
                         frac_of_those_units=round(flu / upd_us / 1e6 / (MFMA_F32_PEAK / 1e12 * cus / 256.0), 4),
-                        kernel="gymrl_sac_update: the four launches of one update at batch 128 (csrc/offpolicy_step.hip: row-slab kernels P1 / P3, "
+                        kernel=f"gymrl_sac_update: the four launches of one update at batch {B} (csrc/offpolicy_step.hip: row-slab kernels P1 / P3, "
                                "weight-gradient + Adam tile kernels P2 / P4).  A 16-row slab's chain of layers runs on ONE compute unit, its independent "
-                               "chains on units of their own: 4 B / 16 = 32 (P1) and 2 B / 16 = 16 (P3) of the 256 compute units carry the MFMA "
+                               "chains on units of their own: 4 B / 16 (P1: 32 at batch 128) and 2 B / 16 (P3) workgroups carry the MFMA "
                                "work of the row kernels (a 16 x 256 x 256 layer is 3.9 us of f32 MFMA on one compute unit, 4.6-4.9 us measured: "
                                "tools/probe_sac_stages.py), so the figure is priced twice — against the chip's f32-MFMA peak as the contract asks "
-                               "(`frac`) and against the peak of the units that can work (`frac_of_those_units`, P1's 32)")
+                               "(`frac`) and against the peak of the units that can work (`frac_of_those_units`: P1's workgroups, at most 256)")
             pieces[f"one update at batch {B} (twin critics, actor, temperature, Adam x3 + Polyak: gymrl_sac_update, 4 launches)"] = dict(us=round(upd_us, 2))
             if tr._fused_ok():
                 lb = tr._loop_buffers(N, D)
@@ -345,9 +354,9 @@ def main_offpolicy(a, rank, world, local_rank):
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (sum tree f64)" if a.algo == "rainbow" else "f32 (temperature f64)", "data": "synthetic",
             "config": {"workload": (f"Rainbow DQN CartPole-v1, {N} envs, PER sum tree (2^20 leaves) + 5-step returns + NoisyNet, batch {B} "
-                                    "(BASELINE.json configs[2])" if a.algo == "rainbow" else
+                                    + ("(BASELINE.json configs[2])" if not a.batch else "(configs[2] at SURVEY 8(d)'s throughput-sized batch)") if a.algo == "rainbow" else
                                     f"SAC Pendulum-v1, {N} envs, twin Q + reparameterised sample + automatic temperature, ring 2^20, batch {B} "
-                                    "(BASELINE.json configs[3])"),
+                                    + ("(BASELINE.json configs[3])" if not a.batch else "(configs[3] at SURVEY 8(d)'s throughput-sized batch)")),
                        "envs_per_gpu": N, "vector_steps_per_step": VS, "updates_per_vector_step": 1, "batch": B, "replay_rows": cap,
                        "ms_per_vector_step": round(dt / vsteps * 1e3, 4), "updates_per_s": round(vsteps * world / dt, 1),
                        "parallelism": f"{world} independent replicas (no exchange step on this path)" if world > 1 else "single GPU"},
@@ -369,6 +378,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 1; 20 for --algo sac / rainbow)")
     ap.add_argument("--envs", type=int, default=None,
                     help="env instances per GPU (default: the BASELINE config's — 4096 for ppo / ppo_full / sac, 8192 for rainbow)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="sac / rainbow: rows per update (default: the reference's 128 / 256; SURVEY 8(d)'s throughput-sized lines: 4096 / 8192)")
     ap.add_argument("--rollout", type=int, default=2048, help="T: vector steps per rollout (reference update_freq)")
     ap.add_argument("--epochs", type=int, default=10)
     ap.add_argument("--minibatches", type=int, default=32)

@@ -735,22 +735,8 @@ inline int pick_nt(int row_tiles, int cols) { return (cols > 16 && (int64_t)row_
 // row slices of the weight gradient: enough (tile, slice) waves to fill the chip — a skinny layer has few output tiles, so
 // at 262144 rows its reduction is cut 128 ways (16 slices left 256 waves walking 16384 rows each: 440 us) — and never
 // fewer than 256 rows per slice
-inline bool big_shape(int B, int N, int K) { return B >= 16384 && N % 64 == 0 && K % 64 == 0; }
-inline int slices_for(int B, int N, int K) {
-  if (B <= 512) return 1;
-  if (big_shape(B, N, K)) {      // 64 x 64 blocks: ~2048 waves, never fewer than 256 rows per slice
-    int s = cdiv(2048, (N / 64) * (K / 64));
-    if (s > 512) s = 512;
-    const int by_rows = cdiv(B, 256);
-    return s < by_rows ? s : by_rows;
-  }
-  const int tiles = cdiv(N, 16) * cdiv(K, 16);
-  int s = cdiv(2048, tiles);
-  if (s < 16) s = 16;
-  if (s > 256) s = 256;
-  const int by_rows = cdiv(B, 256);
-  return s < by_rows ? s : by_rows;
-}
+inline bool big_shape(int B, int N, int K) { return lin::bwd_weight_big_shape(B, N, K); }     // (lin_device.hpp: shared with the
+inline int slices_for(int B, int N, int K) { return lin::bwd_weight_slices(B, N, K); }           //  fused step's weight-gradient tiles)
 
 }  // namespace
 
@@ -850,7 +836,7 @@ int gymrl_lin_bwd_weight(const gymrl_lin_item* items, int n_items, int B, int N,
   a.B = B; a.N = N; a.K = K; a.K1 = K1; a.ldy = ldy; a.ldx = ldx; a.ldx2 = ldx2;
   a.accumulate = accumulate;
   a.slices = slices_for(B, N, K);
-  a.rows_per_slice = cdiv(cdiv(B, a.slices), 32) * 32;
+  a.rows_per_slice = lin::bwd_weight_rows_per_slice(B, a.slices);
   if (a.slices > 1 && !workspace) return -22;
   a.partial = static_cast<float*>(workspace);
   hipStream_t s = static_cast<hipStream_t>(stream_);

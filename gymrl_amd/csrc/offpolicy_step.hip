@@ -27,6 +27,7 @@ using lin::act_bwd;
 using lin::act_fwd;
 
 constexpr int kWaves = 16, kThreads = 64 * kWaves;
+constexpr int kMaxBatch = 8192;      // (ops.FUSED_MAX_BATCH) rows of an update: 512 slabs
 
 // Probe build only (make prof): 100 MHz wall-clock stamps at the stage boundaries of workgroup 0 (tools/probe_sac_stages.py)
 #ifdef GYMRL_PROF_BUILD
@@ -540,10 +541,23 @@ __device__ __forceinline__ void sac_p1_body(const gymrl_sac_update_args& a, cons
 #undef P1_MARK_C
 }
 
+// Grid shapes of the row kernels.  B <= 256 (the reference's batch sizes): dim3(slabs, R) — every workgroup of every slab is
+// resident at once.  Larger batches (SURVEY 8(d)'s B = 4096 / 8192 lines: up to 4 x 512 workgroups on 256 compute units):
+// a 1-D grid of slabs * R blocks with the R workgroups of a slab ADJACENT in dispatch order — a workgroup that waits for a
+// flag waits for one of its own slab, which is dispatched right beside it (blocks are handed to compute units in ascending
+// order), so the waiters can never hold every compute unit.
+struct SlabGrid { int slab, role, slabs; };
+__device__ __forceinline__ SlabGrid slab_grid(int R) {
+  if (gridDim.y > 1) return SlabGrid{(int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x};
+  return SlabGrid{(int)blockIdx.x / R, (int)blockIdx.x % R, (int)gridDim.x / R};
+}
+__host__ inline dim3 slab_launch_grid(int slabs, int R) { return slabs * 16 <= 256 ? dim3(slabs, R) : dim3(slabs * R); }
+
 template <int HC>
 __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update_args a, const SacWs ws) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  sac_p1_body<HC>(a, ws, lds, blockIdx.x, blockIdx.y, gridDim.x, nullptr, 0u);
+  const SlabGrid g = slab_grid(4);
+  sac_p1_body<HC>(a, ws, lds, g.slab, g.role, g.slabs, nullptr, 0u);
 }
 
 // ======================================================================================================== P3 =====
@@ -736,7 +750,8 @@ __device__ __forceinline__ void sac_p3_body(const gymrl_sac_update_args& a, cons
 template <int HC>
 __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update_args a, const SacWs ws) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  sac_p3_body<HC>(a, ws, lds, blockIdx.x, blockIdx.y, gridDim.x, nullptr, 0u, nullptr, 0u);
+  const SlabGrid g = slab_grid(2);
+  sac_p3_body<HC>(a, ws, lds, g.slab, g.role, g.slabs, nullptr, 0u, nullptr, 0u);
 }
 
 // ================================================================================================= P2 / P4 =====
@@ -770,21 +785,48 @@ struct DwArgs {
 __device__ __forceinline__ void sac_dw_body(const DwArgs& a, const int block, const int nblocks, double (*sm)[4]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
   if (block == nblocks - 1) {
-    // ---- the loss sums in the stand-alone kernels' order (offpolicy.hip block_partials with one block: thread t owns row t) ----
-    double v[3] = {0.0, 0.0, 0.0};
-    if (threadIdx.x < 256) {
-      for (int b = threadIdx.x; b < a.B; b += 256)
-        for (int k = 0; k < a.nterms; ++k)
-          v[k] += (a.terms_b && a.term0 + k == 0) ? a.terms[(size_t)b * 3] + a.terms_b[b] : a.terms[(size_t)b * 3 + a.term0 + k];
-      for (int k = 0; k < a.nterms; ++k) {
-        const double s = wave_sum(v[k]);
-        if (lane == 0) sm[k][wave] = s;
+    // ---- the loss sums in the stand-alone kernels' order (offpolicy.hip: one row per thread, block_partials per 256 rows — a
+    // single block adds its partial to the zeroed destination itself, more blocks go through finalize_kernel's second level) ----
+    __shared__ double part[3][kMaxBatch / 256];
+    __shared__ double fin[3];
+    const int nb = (a.B + 255) / 256;
+    for (int j = 0; j < nb; ++j) {
+      double v[3] = {0.0, 0.0, 0.0};
+      if (threadIdx.x < 256) {
+        const int b = 256 * j + (int)threadIdx.x;
+        if (b < a.B)
+          for (int k = 0; k < a.nterms; ++k)
+            v[k] += (a.terms_b && a.term0 + k == 0) ? a.terms[(size_t)b * 3] + a.terms_b[b] : a.terms[(size_t)b * 3 + a.term0 + k];
+        for (int k = 0; k < a.nterms; ++k) {
+          const double s = wave_sum(v[k]);
+          if (lane == 0) sm[k][wave] = s;
+        }
       }
+      __syncthreads();
+      if ((int)threadIdx.x < a.nterms) {
+        double s = 0.0;
+        for (int w = 0; w < 4; ++w) s += sm[threadIdx.x][w];
+        part[threadIdx.x][j] = s;
+      }
+      __syncthreads();
     }
-    __syncthreads();
+    if (nb > 1) {                           // finalize_kernel: thread i takes partial i (nb <= 256), the same two-level sum again
+      double v[3] = {0.0, 0.0, 0.0};
+      if (threadIdx.x < 256) {
+        if ((int)threadIdx.x < nb)
+          for (int k = 0; k < a.nterms; ++k) v[k] += part[k][threadIdx.x];
+        for (int k = 0; k < a.nterms; ++k) {
+          const double s = wave_sum(v[k]);
+          if (lane == 0) sm[k][wave] = s;
+        }
+      }
+      __syncthreads();
+    }
     if ((int)threadIdx.x < a.nterms) {
-      double s = 0.0;
-      for (int w = 0; w < 4; ++w) s += sm[threadIdx.x][w];
+      double s;
+      if (nb > 1) { s = 0.0; for (int w = 0; w < 4; ++w) s += sm[threadIdx.x][w]; }
+      else s = part[threadIdx.x][0];
+      fin[threadIdx.x] = s;
       a.sums[a.term0 + threadIdx.x] = 0.0 + s;
     }
     if (!a.alpha_step) return;
@@ -792,9 +834,7 @@ __device__ __forceinline__ void sac_dw_body(const DwArgs& a, const int block, co
     if (threadIdx.x == 0) {               // offpolicy.hip sac_alpha_step_kernel
       double bc1 = a.alpha_bias[0], bc2_sqrt = sqrt(a.alpha_bias[1]);
       if (a.alpha_bias_dev) { bc1 = a.alpha_bias_dev[0]; bc2_sqrt = sqrt(a.alpha_bias_dev[1]); }
-      double s2 = 0.0;
-      for (int w = 0; w < 4; ++w) s2 += sm[1][w];
-      const double mean_term = (0.0 + s2) / (double)a.B;
+      const double mean_term = (0.0 + fin[1]) / (double)a.B;
       if (a.alpha_loss) a.alpha_loss[0] = -(a.log_alpha[0] * mean_term);
       const double g = -mean_term;
       a.alpha_m[0] = a.alpha_m[0] + (g - a.alpha_m[0]) * (1.0 - a.abeta1);
@@ -832,7 +872,7 @@ __device__ __forceinline__ void sac_dw_body(const DwArgs& a, const int block, co
     }
   }
   float colsum;
-  const f32x4 acc = lin::tile_bwd_weight(s.dZ, s.ldz, s.N, nt, s.X, s.ldx, s.X2, s.ldx2, s.K, s.K1, kb, a.B, lane, colsum);
+  const f32x4 acc = lin::tile_bwd_weight_sliced(s.dZ, s.ldz, s.N, nt, s.X, s.ldx, s.X2, s.ldx2, s.K, s.K1, kb, a.B, lane, colsum);
   if (a.store_grads && a.split_heads && si == 0) {
     // d mu = dW, d sigma = dW * eps, per NoisyLinear layer: rows 0 .. A-1 the advantage stream, row A the value stream
     if (kc < s.K) {
@@ -1100,10 +1140,12 @@ __global__ __launch_bounds__(kThreads) void rainbow_rows_kernel(const gymrl_rain
   const int H1 = L.big, H2 = H1 + 16 * ld, X0 = H2 + 16 * ld;
   // head outputs of the three passes: [16][4] slabs in the small area (Q0, Q1, Cq0), dS in Dq0
   const int Za = L.Q0, Zb = L.Q1, Zc = L.Cq0, DS = L.Dq0;
-  const int row0 = blockIdx.x * 16, nrows = min(16, a.B - row0);
+  const SlabGrid sg_ = slab_grid(3);
+  const int bx = sg_.slab;
+  const int row0 = bx * 16, nrows = min(16, a.B - row0);
   const int t = threadIdx.x;
-  const int pass = blockIdx.y;          // 0: policy(s) [second draw], 1: policy(s') [first draw], 2: target(s') [means]
-  const int S = gridDim.x;
+  const int pass = sg_.role;            // 0: policy(s) [second draw], 1: policy(s') [first draw], 2: target(s') [means]
+  const int S = sg_.slabs;
   if (t < 16) {                         // gather (replay.hip replay_gather_kernel): what this workgroup's pass reads
     const int b = row0 + t;
     const bool ok = t < nrows;
@@ -1146,17 +1188,17 @@ __global__ __launch_bounds__(kThreads) void rainbow_rows_kernel(const gymrl_rain
     float* xz = ws.xz + ((size_t)(pass - 1) * S * 16 + row0) * 4;
     if (t < 64) xstore(xz + t, lds[Zme + t]);
     __syncthreads();
-    if (t == 0) flag_post(ws.flag + (pass - 1) * S + blockIdx.x);
+    if (t == 0) flag_post(ws.flag + (pass - 1) * S + bx);
     return;
   }
-  if (t == 0) { flag_wait(ws.flag + blockIdx.x); flag_wait(ws.flag + S + blockIdx.x); }
+  if (t == 0) { flag_wait(ws.flag + bx); flag_wait(ws.flag + S + bx); }
   __syncthreads();
   if (t < 64) {
     lds[Za + t] = xload(ws.xz + ((size_t)row0) * 4 + t);
     lds[Zb + t] = xload(ws.xz + ((size_t)S * 16 + row0) * 4 + t);
   }
   __syncthreads();
-  if (t == 0) { flag_clear(ws.flag + blockIdx.x); flag_clear(ws.flag + S + blockIdx.x); }
+  if (t == 0) { flag_clear(ws.flag + bx); flag_clear(ws.flag + S + bx); }
   if (t < 16) {
     // dueling heads, the double-DQN target and the IS-weighted loss gradient (offpolicy.hip dqn_td_kernel), dueling backward (lin.hip)
     float q_no[kRbMaxA], q_nt[kRbMaxA], q[kRbMaxA];
@@ -1298,7 +1340,7 @@ __global__ __launch_bounds__(kThreads) void rainbow_act_kernel(const gymrl_rainb
 }
 
 inline bool rb_shape_ok(int B, int D, int A, int H) {
-  return B > 0 && B <= 256 && D > 0 && D <= kMaxD && A > 0 && A <= kRbMaxA && H >= 4 && H <= 256 && (H & 3) == 0;
+  return B > 0 && B <= kMaxBatch && D > 0 && D <= kMaxD && A > 0 && A <= kRbMaxA && H >= 4 && H <= 256 && (H & 3) == 0;
 }
 
 // All eight images from the parameters as they are (after load_state_dict / a checkpoint / a hard target copy)
@@ -1315,7 +1357,7 @@ __global__ __launch_bounds__(256) void sac_pack_kernel(const gymrl_sac_update_ar
 }
 
 inline bool sac_shape_ok(int B, int D, int A, int H) {
-  return B > 0 && B <= 256 && D > 0 && D <= kMaxD && A > 0 && A <= kMaxA && H >= 4 && H <= 256 && (H & 3) == 0;
+  return B > 0 && B <= kMaxBatch && D > 0 && D <= kMaxD && A > 0 && A <= kMaxA && H >= 4 && H <= 256 && (H & 3) == 0;
 }
 inline size_t lds_bytes(int H, int slabs) { return sizeof(float) * (size_t)(kSmallFloats + slabs * 16 * lin::slab_ld(H)); }
 
@@ -1415,7 +1457,7 @@ int gymrl_rainbow_update(const gymrl_rainbow_update_args* args, int phase, void*
   void* base = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(a.workspace) + 255) & ~(uintptr_t)255);
   RbWs::carve(&ws, base, a.B, a.D, a.A, a.H);
   const int B = a.B, D = a.D, A1 = a.A + 1, H = a.H;
-  if (phase != 2) hipLaunchKernelGGL(H == 256 ? rainbow_rows_kernel<256> : rainbow_rows_kernel<0>, dim3((B + 15) / 16, 3), dim3(kThreads), lds_bytes(H, 7), stream, a, ws);
+  if (phase != 2) hipLaunchKernelGGL(H == 256 ? rainbow_rows_kernel<256> : rainbow_rows_kernel<0>, slab_launch_grid((B + 15) / 16, 3), dim3(kThreads), lds_bytes(H, 7), stream, a, ws);
   if (phase == 1) { GYMRL_CHECK_LAUNCH(); return 0; }
   DwArgs d{};
   int w0 = 0, ns = 0;
@@ -1537,9 +1579,9 @@ int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream_) {
   DwArgs c, p;
   sac_build_dw(a, ws, c, p);
   // (the instances built for the reference's hidden width 256 know every reduction length at compile time)
-  hipLaunchKernelGGL(H == 256 ? sac_p1_kernel<256> : sac_p1_kernel<0>, dim3(slabs, 4), dim3(kThreads), lds_bytes(H, 8), stream, a, ws);   // y: the two target chains, the two critic chains
+  hipLaunchKernelGGL(H == 256 ? sac_p1_kernel<256> : sac_p1_kernel<0>, slab_launch_grid(slabs, 4), dim3(kThreads), lds_bytes(H, 8), stream, a, ws);   // y / role: the two target chains, the two critic chains
   hipLaunchKernelGGL(sac_dw_kernel, dim3((c.total_waves + 3) / 4 + 1), dim3(256), 0, stream, c);
-  hipLaunchKernelGGL(H == 256 ? sac_p3_kernel<256> : sac_p3_kernel<0>, dim3(slabs, 2), dim3(kThreads), lds_bytes(H, 8), stream, a, ws);   // y: the actor + Q2, then Q1
+  hipLaunchKernelGGL(H == 256 ? sac_p3_kernel<256> : sac_p3_kernel<0>, slab_launch_grid(slabs, 2), dim3(kThreads), lds_bytes(H, 8), stream, a, ws);   // y / role: the actor + Q2, then Q1
   hipLaunchKernelGGL(sac_dw_kernel, dim3((p.total_waves + 3) / 4 + 1), dim3(256), 0, stream, p);
   GYMRL_CHECK_LAUNCH();
   return 0;
@@ -1549,7 +1591,7 @@ int gymrl_sac_step(const gymrl_sac_act_args* act_args, const gymrl_sac_update_ar
   if (!act_args || !upd_args) return -22;
   const gymrl_sac_act_args& a = *act_args;
   const gymrl_sac_update_args& u = *upd_args;
-  if (!sac_act_args_ok(a) || !sac_update_args_ok(u) || a.H != u.H) return -22;
+  if (!sac_act_args_ok(a) || !sac_update_args_ok(u) || a.H != u.H || u.B > 256) return -22;   // one grid: every waiting block must be resident
   if (const int rc = sac_set_lds_attr()) return rc;
   SacStepArgs s;
   s.act = a; s.upd = u;

@@ -1306,9 +1306,12 @@ def _addr(t):
     return None if t is None else _ptr(t).value
 
 
+FUSED_MAX_BATCH = 8192     # row-slab kernels: B <= 256 as resident 2-D grids, above that slab-adjacent 1-D grids (offpolicy_step.hip slab_grid)
+
+
 def sac_fused_shape_ok(B, D, A, H):
     """Shapes gymrl_sac_act_step / gymrl_sac_update take (include/gymrl.h): everything else runs layer by layer."""
-    return 0 < B <= 256 and 0 < D <= 8 and 0 < A <= 4 and 4 <= H <= 256 and H % 4 == 0
+    return 0 < B <= FUSED_MAX_BATCH and 0 < D <= 8 and 0 < A <= 4 and 4 <= H <= 256 and H % 4 == 0
 
 
 def sac_update_workspace(B, D, A, H, device):
@@ -1416,7 +1419,7 @@ def sac_step(act, upd):
 
 # --------------------------------------------- fused Rainbow vector step ---
 def rainbow_fused_shape_ok(B, D, A, H):
-    return 0 < B <= 256 and 0 < D <= 8 and 0 < A <= 3 and 4 <= H <= 256 and H % 4 == 0
+    return 0 < B <= FUSED_MAX_BATCH and 0 < D <= 8 and 0 < A <= 3 and 4 <= H <= 256 and H % 4 == 0
 
 
 def rainbow_update_workspace(B, D, A, H, device):

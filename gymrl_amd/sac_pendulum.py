@@ -417,7 +417,7 @@ class SACTrainer:
         ch, tr = self._chunk, lb["tracker"]
         obs, nxt = (lb["obs"], lb["nxt"]) if j % 2 == 0 else (lb["nxt"], lb["obs"])
         if self._fused_ok():
-            one = bool(getattr(self.cfg, "one_launch_step", False))      # acting + update as ONE launch (gymrl_sac_step)
+            one = bool(getattr(self.cfg, "one_launch_step", False)) and self.cfg.batch_size <= 256   # acting + update as ONE launch (gymrl_sac_step: every waiting block resident)
             self._vector_step(lb, obs, nxt, tr.ret[j], tr.done[j], cursor_dev=ch.view(j, "push"), noise_dev=ch.view(j, "noise_a"),
                               launch=not one)
             self._update_fused(dev=(ch.view(j, "draw"), ch.view(j, "adam_c", torch.float32), ch.view(j, "adam_a", torch.float32),

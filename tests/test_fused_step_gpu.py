@@ -13,7 +13,7 @@ def _run(fused, steps, N, B, hidden, seed=5, images=True):
     from gymrl_amd.sac_pendulum import Config, SACTrainer
     cfg = Config()
     cfg.num_envs, cfg.batch_size, cfg.hidden_dim, cfg.seed = N, B, hidden, seed
-    cfg.max_episodes, cfg.memory_capacity, cfg.use_graphs, cfg.fused_step, cfg.fused_images = 10 ** 9, (1 << 20 if N >= 4096 else 4096), False, fused, images
+    cfg.max_episodes, cfg.memory_capacity, cfg.use_graphs, cfg.fused_step, cfg.fused_images = 10 ** 9, (1 << 20 if N >= 4096 else max(4096, 4 * B)), False, fused, images
     tr = SACTrainer(cfg)
     assert tr._fused_ok() == fused
     g = torch.Generator(device="cuda").manual_seed(7)
@@ -29,12 +29,14 @@ def _run(fused, steps, N, B, hidden, seed=5, images=True):
 
 
 # (hidden 256: the instances built for that width; 36: no weight images, no 16-column alignment; B = 100: a partial last slab;
+#  B = 1024 / 2100: the large-batch form — slab-adjacent 1-D grids, the weight gradients' 256-row slices and the two-level loss
+#  sums of the layer-by-layer kernels beyond 512 / 256 rows (SURVEY 8(d)'s B = 4096 line runs this code);
 #  4096 / 128 / 256 is BASELINE config 4 itself: sac_act_kernel<256> on 256 workgroups, ring of 2^20 rows)
 @pytest.mark.parametrize("N,B,hidden,steps", [(64, 128, 256, 40), (20, 24, 32, 30), (48, 256, 64, 24), (33, 100, 36, 20), (17, 250, 256, 30),
-                                              (4096, 128, 256, 12)])
+                                              (4096, 128, 256, 12), (512, 1024, 256, 7), (1100, 2100, 64, 5)])
 def test_sac_fused_step_equals_layer_by_layer(N, B, hidden, steps):
     a, b = _run(False, steps, N, B, hidden), _run(True, steps, N, B, hidden)
-    assert a.critic_optimizer.step_count == b.critic_optimizer.step_count > 10
+    assert a.critic_optimizer.step_count == b.critic_optimizer.step_count > (10 if B <= 256 else 2)
     assert (a.memory.cursor, a.memory.size, a.memory.draws) == (b.memory.cursor, b.memory.size, b.memory.draws)
     for x, y in zip(a.memory.ring, b.memory.ring):
         assert torch.equal(x, y)                                    # acting: same actions, same physics, same rows
@@ -120,7 +122,7 @@ def _run_rainbow(fused, steps, N, B, hidden, graphs=False, chunk=0):
     rb.NoisyLinear._counter = 0
     cfg = rb.Config()
     cfg.num_envs, cfg.batch_size, cfg.hidden_dim, cfg.seed = N, B, hidden, 5
-    cfg.max_episodes, cfg.memory_capacity, cfg.use_graphs, cfg.chunk_steps, cfg.fused_step = 10 ** 9, max(1 << 12, 2 * N), graphs, chunk, fused
+    cfg.max_episodes, cfg.memory_capacity, cfg.use_graphs, cfg.chunk_steps, cfg.fused_step = 10 ** 9, max(1 << 12, 2 * N, 2 * B), graphs, chunk, fused
     torch.manual_seed(11)
     tr = rb.RainbowDQNTrainer(cfg)
     assert tr._fused_act_ok() == fused
@@ -129,7 +131,8 @@ def _run_rainbow(fused, steps, N, B, hidden, graphs=False, chunk=0):
     return tr
 
 
-@pytest.mark.parametrize("N,B,hidden,steps", [(64, 256, 256, 70), (20, 24, 32, 40), (128, 128, 64, 50), (8192, 256, 256, 12), (4100, 64, 32, 9)])
+@pytest.mark.parametrize("N,B,hidden,steps", [(64, 256, 256, 70), (20, 24, 32, 40), (128, 128, 64, 50), (8192, 256, 256, 12), (4100, 64, 32, 9),
+                                              (1024, 2048, 256, 10), (8192, 8192, 256, 8)])
 def test_rainbow_fused_step_equals_layer_by_layer(N, B, hidden, steps):
     """Rainbow: acting + env + n-step push as one launch and the update's Linear / loss / backward launches as two, against
     the layer-by-layer path (tests/test_trainers_gpu.py pins that one to the reference): networks, Adam moments, the float64
