@@ -151,13 +151,16 @@ __global__ __launch_bounds__(1024) void per_ancestor_kernel(double* __restrict__
 
 // ---- explicit index batches of up to kSmallB elements (update_priorities at the reference's batch sizes) ------------------
 // Rounds 2-4 resolved "who touched this leaf / node before me" with per-element SEARCHES through LDS (dependent ~100-clock
-// round trips, O(B) each: 15 + 28 us for 256 priorities in two launches, a quarter of a Rainbow vector step).  Here a wave
-// keeps the whole batch's ids in registers — lane l holds elements l, l + 64, ... — and asks the question for one element at
-// a time with a wave-wide compare: the answer is a B-bit ballot mask in scalar registers, "the latest earlier element on
-// the same leaf" / "is there a later one" / "am I the first to reach this node" are bit scans of it, and a node's elements
-// are compacted (popcount below the lane = position in batch order) into a staging row from which ONE lane adds them in
-// order — the one thing the reference's loop (:258-261 -> :122-128) makes sequential.  Same float64 sums in the same
-// order: the tree stays bit-identical (tests/test_hip_parity_offpolicy.py::test_sumtree_*).
+// round trips, O(B) each: 15 + 28 us for 256 priorities in two launches, a quarter of a Rainbow vector step).  Here every
+// element is a LANE and the batch walks past it: a wave holds 64 candidates, reads the ids of the others one at a time as a
+// scalar (v_readlane of a register that holds 64 of them) and counts with vector compares — matches before me (my place in
+// my node's run), matches in all (the run's length), the first match (the run's leader).  ~5 vector instructions per pair
+// of 64 candidates, four SIMDs per compute unit, the batch's range split over the waves and combined with LDS atomics (integer:
+// order-free).  A node's elements are then staged contiguously, in batch order, and its leader adds them one after another —
+// the one thing the reference's loop (:258-261 -> :122-128) makes sequential.  Same float64 sums in the same order: the tree
+// stays bit-identical (tests/test_hip_parity_offpolicy.py::test_sumtree_*).  (A first version of this round asked the same
+// questions with wave-wide ballots and bit scans of the masks in SCALAR registers: 150 scalar instructions per element and ONE
+// scalar unit per compute unit for its 16 waves — 28 us; this form: tools/micro_per.py.)
 //
 // ONE launch (gymrl_per_update_td with a ticket): blocks 0 .. depth-1 take one tree depth each — every one of them derives
 // leaves, priorities and the per-element change itself from (idx, td, the OLD leaf values), nothing is handed over —, blocks
@@ -166,9 +169,9 @@ __global__ __launch_bounds__(1024) void per_ancestor_kernel(double* __restrict__
 // leaf value has then passed the ticket.  Without a ticket (gymrl_per_update) the same code runs as two launches: a leaf
 // block that also publishes the changes, then the depth blocks.
 constexpr int kSmallB = 512;
-constexpr int kSmallK = kSmallB / 64;          // register slots per lane: elements lane + 64 k
 constexpr int kSmallWaves = 16;                // 1024 threads
 constexpr int kMaxChunk = 8192;                // leaves per maximum block (8 per thread)
+constexpr int32_t kNoFirst = 0x7fffffff;
 
 // |td| -> priority, update_priorities' transform (rainbow_dqn_cartpole.py:258-261): float32 arithmetic like the reference —
 // np.abs(f32) + python float and ** python float stay float32 under NumPy >= 2 —, x**a as exp(a log x) with the reproducible
@@ -188,33 +191,26 @@ struct SmallArgs {
 };
 struct SmallLds {
   int32_t leaf[kSmallB];
-  double p[kSmallB], old[kSmallB], change[kSmallB];
+  double p[kSmallB], old[kSmallB], change[kSmallB], stage[kSmallB];
   uint8_t last[kSmallB];
+  int32_t prev[kSmallB], lastm[kSmallB];                       // duplicates: the latest earlier / the latest element on my leaf
+  int32_t node[kSmallB], rank[kSmallB], cnt[kSmallB], first[kSmallB], slot[kSmallB];
 };
 
-// bit scans of a B-bit mask held as kSmallK 64-bit words (all operands wave-uniform: scalar code)
-__device__ __forceinline__ int highest_below(const uint64_t (&m)[kSmallK], int KB, int i) {
-  int r = -1;
-#pragma unroll
-  for (int k = 0; k < kSmallK; ++k) {
-    if (k >= KB) break;
-    const uint64_t mm = k < (i >> 6) ? m[k] : (k == (i >> 6) ? m[k] & ((1ull << (i & 63)) - 1ull) : 0ull);
-    if (mm) r = 64 * k + 63 - __clzll((unsigned long long)mm);
-  }
+// Wave roles: candidate group g (elements 64 g + lane) x part q of the batch's range.
+struct Roles { int g, q, j0, j1, i; bool valid; };
+__device__ __forceinline__ Roles roles(int B, int wave, int lane) {
+  int groups = 1;
+  while (groups * 64 < B) groups <<= 1;                            // 1, 2, 4, 8
+  const int parts = kSmallWaves / groups, per = (B + parts - 1) / parts;
+  Roles r;
+  r.g = wave & (groups - 1); r.q = wave / groups;
+  r.j0 = r.q * per; r.j1 = r.j0 + per < B ? r.j0 + per : B;
+  r.i = 64 * r.g + lane; r.valid = r.i < B;
   return r;
-}
-__device__ __forceinline__ bool any_above(const uint64_t (&m)[kSmallK], int KB, int i) {
-  uint64_t acc = 0ull;
-#pragma unroll
-  for (int k = 0; k < kSmallK; ++k) {
-    if (k >= KB) break;
-    acc |= k > (i >> 6) ? m[k] : (k == (i >> 6) ? m[k] & ~((2ull << (i & 63)) - 1ull) : 0ull);
-  }
-  return acc != 0ull;
 }
 
 __device__ __forceinline__ int small_node(int32_t leaf, int d) {          // the leaf's ancestor at depth d, -1: none
-  if (leaf < 0) return -1;
   const int L = 31 - __clz(leaf + 1);
   return L > d ? ((leaf + 1) >> (L - d)) - 1 : -1;
 }
@@ -226,91 +222,105 @@ __device__ __forceinline__ void small_load(const SmallArgs& a, SmallLds& s, bool
     s.leaf[i] = leaf;
     if (want_old) s.old[i] = a.tree[leaf];
     s.p[i] = a.tp.td ? td_priority(a.tp.td[i], a.tp.alpha, a.tp.eps, a.tp.clip) : prio_of(a.prio, a.ps_dev, a.ps, i);
+    s.prev[i] = -1; s.lastm[i] = -1;
   }
 }
 
 // change_i = p_i - (value of the leaf just before element i is applied: the latest earlier element on the same leaf, else the
-// tree); last_i = no later element writes the same leaf.  Wave w takes the elements w, w + 16, ...
-__device__ __forceinline__ void small_dups(const SmallArgs& a, SmallLds& s, const int32_t (&my_leaf)[kSmallK], int KB, int wave, int lane) {
-  const int cand = wave + kSmallWaves * lane;                       // lane c finishes candidate c of this wave
-  const int32_t cl = (lane < kSmallB / kSmallWaves && cand < a.B) ? s.leaf[cand] : -2;
-  int prevL = -1;
-  bool laterL = false;
-  for (int c = 0; wave + kSmallWaves * c < a.B; ++c) {
-    const int i = wave + kSmallWaves * c;
-    const int32_t li = __builtin_amdgcn_readlane(cl, c);
-    uint64_t m[kSmallK];
-#pragma unroll
-    for (int k = 0; k < kSmallK; ++k) m[k] = k < KB ? __builtin_amdgcn_ballot_w64(my_leaf[k] == li) : 0ull;
-    const int prev = highest_below(m, KB, i);
-    const bool later = any_above(m, KB, i);
-    if (lane == c) { prevL = prev; laterL = later; }
+// tree); last_i = no later element writes the same leaf (want_change false: last_i alone — the maximum blocks, which never
+// read an old leaf value).  Ends with the results visible to the block.
+__device__ __forceinline__ void small_dups(const SmallArgs& a, SmallLds& s, int wave, int lane, bool want_change) {
+  const Roles r = roles(a.B, wave, lane);
+  const int32_t mine = r.valid ? s.leaf[r.i] : -2;
+  int prev = -1, lastm = -1;
+  for (int jb = r.j0; jb < r.j1; jb += 64) {
+    const int32_t vj = jb + lane < r.j1 ? s.leaf[jb + lane] : -1;
+    const int n = r.j1 - jb < 64 ? r.j1 - jb : 64;
+#pragma unroll 8
+    for (int u = 0; u < n; ++u) {
+      const int32_t L = __builtin_amdgcn_readlane(vj, u);
+      const int j = jb + u;
+      const bool eq = L == mine;
+      lastm = eq ? j : lastm;                                      // (ascending: ends as the latest)
+      prev = (eq && j < r.i) ? j : prev;
+    }
   }
-  if (cl >= 0) {
-    s.change[cand] = s.p[cand] - (prevL >= 0 ? s.p[prevL] : s.old[cand]);
-    s.last[cand] = laterL ? 0 : 1;
+  if (r.valid) {
+    if (prev >= 0) atomicMax(&s.prev[r.i], prev);
+    if (lastm >= 0) atomicMax(&s.lastm[r.i], lastm);
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.B; i += blockDim.x) {
+    if (want_change) s.change[i] = s.p[i] - (s.prev[i] >= 0 ? s.p[s.prev[i]] : s.old[i]);
+    s.last[i] = s.lastm[i] == i ? 1 : 0;                           // (i matches itself: lastm >= i)
+  }
+  __syncthreads();
 }
 
-// The additions of depth d's nodes, each node's in batch order.  stage: this wave's row of B doubles.
-__device__ __forceinline__ void small_ancestors(const SmallArgs& a, SmallLds& s, const int32_t (&my_leaf)[kSmallK], int KB, int d,
-                                                int wave, int lane, double* stage) {
-  int32_t my_node[kSmallK];
-  double my_change[kSmallK];
-#pragma unroll
-  for (int k = 0; k < kSmallK; ++k) {
-    my_node[k] = k < KB ? small_node(my_leaf[k], d) : -1;
-    my_change[k] = (k < KB && lane + 64 * k < a.B) ? s.change[lane + 64 * k] : 0.0;
+// The additions of depth d's nodes, each node's in batch order.
+__device__ __forceinline__ void small_ancestors(const SmallArgs& a, SmallLds& s, int d, int wave, int lane) {
+  const Roles r = roles(a.B, wave, lane);
+  double treeval = 0.0;
+  for (int i = threadIdx.x; i < a.B; i += blockDim.x) {           // (B <= 512 < 1024 threads: one element per thread, i == r.i of part 0)
+    const int32_t n = small_node(s.leaf[i], d);
+    s.node[i] = n; s.rank[i] = 0; s.cnt[i] = 0; s.first[i] = kNoFirst; s.slot[i] = 0;
+    if (n >= 0) treeval = a.tree[n];                               // requested now, needed by the node's leader at the end
   }
-  const int cand = wave + kSmallWaves * lane;
-  const int32_t cn = (lane < kSmallB / kSmallWaves && cand < a.B) ? small_node(s.leaf[cand], d) : -1;
-  const double treeval = cn >= 0 ? a.tree[cn] : 0.0;               // requested now, needed after the loop
-  int startL = 0, lenL = 0, base = 0;
-  for (int c = 0; wave + kSmallWaves * c < a.B; ++c) {
-    const int i = wave + kSmallWaves * c;
-    const int32_t ni = __builtin_amdgcn_readlane(cn, c);
-    if (ni < 0) continue;
-    uint64_t m[kSmallK];
-    int cnt = 0;
-#pragma unroll
-    for (int k = 0; k < kSmallK; ++k) {
-      m[k] = k < KB ? __builtin_amdgcn_ballot_w64(my_node[k] == ni) : 0ull;
-      cnt += __popcll((unsigned long long)m[k]);
-    }
-    if (highest_below(m, KB, i) >= 0) continue;                    // an earlier element reaches this node first: its run
-    if (cnt == 1) {                                                // a run of one (nearly every node of the deep levels)
-      if (lane == c) { startL = -1; lenL = 1; }
-      continue;
-    }
-    int at = base;
-#pragma unroll
-    for (int k = 0; k < kSmallK; ++k) {
-      if (k >= KB || m[k] == 0ull) continue;
-      const uint32_t lo = (uint32_t)m[k], hi = (uint32_t)(m[k] >> 32);
-      const int below = (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-      if ((m[k] >> lane) & 1ull) stage[at + below] = my_change[k];
-      at += __popcll((unsigned long long)m[k]);
-    }
-    if (lane == c) { startL = base; lenL = cnt; }
-    base = at;
-  }
-  __syncthreads();                                                 // (uniform: every wave's loop is wave-uniform) staged runs are visible
-  if (lenL > 0) {
-    double acc = treeval;
-    if (startL < 0) acc += s.change[cand];
-    else {
-      const double* run = stage + startL;
-      int t = 0;
-      for (; t + 8 <= lenL; t += 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = run[t + u];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];
+  __syncthreads();
+  const int32_t mine = r.valid ? s.node[r.i] : -1;
+  const int32_t key = mine >= 0 ? mine : -3;                       // (no ancestor at this depth: matches nothing)
+  {
+    int rank = 0, cnt = 0, first = kNoFirst;
+    for (int jb = r.j0; jb < r.j1; jb += 64) {
+      const int32_t vj = jb + lane < r.j1 ? s.node[jb + lane] : -1;
+      const int n = r.j1 - jb < 64 ? r.j1 - jb : 64;
+  #pragma unroll 8
+    for (int u = 0; u < n; ++u) {
+        const int32_t L = __builtin_amdgcn_readlane(vj, u);
+        const int j = jb + u;
+        const bool eq = L == key;
+        cnt += eq ? 1 : 0;
+        rank += (eq && j < r.i) ? 1 : 0;
+        first = min(first, eq ? j : kNoFirst);
       }
-      for (; t < lenL; ++t) acc += run[t];
     }
-    a.tree[cn] = acc;
+    if (mine >= 0 && cnt > 0) {
+      atomicAdd(&s.cnt[r.i], cnt);
+      if (rank) atomicAdd(&s.rank[r.i], rank);
+      atomicMin(&s.first[r.i], first);
+    }
+  }
+  __syncthreads();
+  {                                                                // where my node's run starts: the elements of the nodes that began earlier
+    const int32_t myfirst = r.valid ? s.first[r.i] : 0;
+    int slot = 0;
+    for (int jb = r.j0; jb < r.j1; jb += 64) {
+      const int32_t vj = jb + lane < r.j1 ? s.first[jb + lane] : kNoFirst;
+      const int n = r.j1 - jb < 64 ? r.j1 - jb : 64;
+#pragma unroll 8
+      for (int u = 0; u < n; ++u) slot += __builtin_amdgcn_readlane(vj, u) < myfirst ? 1 : 0;
+    }
+    if (mine >= 0 && slot) atomicAdd(&s.slot[r.i], slot);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.B; i += blockDim.x)
+    if (s.node[i] >= 0) s.stage[s.slot[i] + s.rank[i]] = s.change[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.B; i += blockDim.x) {
+    if (s.node[i] < 0 || s.rank[i] != 0) continue;                 // the run's first element adds it up
+    const double* run = s.stage + s.slot[i];
+    const int len = s.cnt[i];
+    double acc = treeval;
+    int t = 0;
+    for (; t + 8 <= len; t += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = run[t + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; t < len; ++t) acc += run[t];
+    a.tree[s.node[i]] = acc;
   }
 }
 
@@ -346,11 +356,7 @@ __device__ __forceinline__ void small_max_block(const SmallArgs& a, SmallLds& s,
     const int o = threadIdx.x + 1024 * u;
     if (lo + o < a.cap && !((bm[o >> 5] >> (o & 31)) & 1u)) v = fmax(v, a.tree[a.cap - 1 + lo + o]);
   }
-  if (off >= 0 && off < kMaxChunk) {                               // (about two elements per block at B = 256, cap = 2^20)
-    bool later = false;
-    for (int j = i + 1; j < a.B; ++j) later = later || s.leaf[j] == s.leaf[i];
-    if (!later) v = fmax(v, s.p[i]);
-  }
+  if (off >= 0 && off < kMaxChunk && s.last[i]) v = fmax(v, s.p[i]);   // (about two elements per block at B = 256, cap = 2^20)
   v = block_max(v, sm16);
   if (threadIdx.x == 0) __hip_atomic_store(a.mx.partial + b, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -359,25 +365,15 @@ __global__ __launch_bounds__(1024) void per_small_kernel(SmallArgs a) {
   __shared__ SmallLds s;
   __shared__ double sm16[kSmallWaves];
   __shared__ unsigned int s_is_last;
-  extern __shared__ __attribute__((aligned(16))) double s_stage[];   // [16 waves][B]
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  const int KB = (a.B + 63) >> 6;
   const bool depth_block = a.mode == SMALL_ANC || (a.mode == SMALL_FUSED && (int)blockIdx.x < a.depth);
   const bool need_change = a.mode != SMALL_ANC && (a.mode == SMALL_LEAF || depth_block);
   small_load(a, s, need_change);
   if (a.mode == SMALL_ANC)
     for (int i = threadIdx.x; i < a.B; i += blockDim.x) s.change[i] = a.change_ws[i];
   __syncthreads();
-  int32_t my_leaf[kSmallK];
-#pragma unroll
-  for (int k = 0; k < kSmallK; ++k) my_leaf[k] = (k < KB && lane + 64 * k < a.B) ? s.leaf[lane + 64 * k] : -1;
-  bool have_last = false;
-  if (need_change) {
-    small_dups(a, s, my_leaf, KB, wave, lane);
-    have_last = true;
-    __syncthreads();
-  }
-  if (depth_block) small_ancestors(a, s, my_leaf, KB, (int)blockIdx.x, wave, lane, s_stage + (size_t)wave * a.B);
+  if (a.mode != SMALL_ANC) small_dups(a, s, wave, lane, need_change);   // (a maximum block: the last-writer flags alone)
+  if (depth_block) small_ancestors(a, s, (int)blockIdx.x, wave, lane);
   else if (a.mode == SMALL_FUSED) small_max_block(a, s, (int)blockIdx.x - a.depth, sm16);
   if (a.mode == SMALL_ANC) return;
   bool write_leaves = a.mode == SMALL_LEAF;
@@ -394,14 +390,6 @@ __global__ __launch_bounds__(1024) void per_small_kernel(SmallArgs a) {
     if (write_leaves) __threadfence();
   }
   if (!write_leaves) return;
-  if (!have_last) {                                                // (a maximum block came last)
-    for (int i = threadIdx.x; i < a.B; i += blockDim.x) {
-      bool later = false;
-      for (int j = i + 1; j < a.B; ++j) later = later || s.leaf[j] == s.leaf[i];
-      s.last[i] = later ? 0 : 1;
-    }
-    __syncthreads();
-  }
   for (int i = threadIdx.x; i < a.B; i += blockDim.x)
     if (s.last[i]) a.tree[s.leaf[i]] = s.p[i];                     // last writer wins
   if (a.mode == SMALL_FUSED) {
@@ -677,17 +665,6 @@ __global__ __launch_bounds__(kBlock) void per_normalize_kernel(float* __restrict
   else w32[i] = w32[i] / (float)m;                        // is_weight /= is_weight.max() in float32 (:241)
 }
 
-inline size_t small_stage_bytes(int B) { return sizeof(double) * (size_t)kSmallWaves * (size_t)B; }
-inline bool small_attr() {
-  static bool set = false;
-  if (!set) {
-    if (hipFuncSetAttribute((const void*)per_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_stage_bytes(kSmallB)) != hipSuccess)
-      return false;
-    set = true;
-  }
-  return true;
-}
-
 }  // namespace
 
 extern "C" {
@@ -745,12 +722,11 @@ int gymrl_per_update(double* tree, int64_t cap, const int32_t* idx, int64_t idx_
     return 0;
   }
   if (B <= kSmallB && 2 * cap < (1ll << 31)) {                           // the reference's batch sizes: ballots, no searches (two launches: no ticket here)
-    if (!small_attr()) return -1000 - (int)hipGetLastError();
     SmallArgs a{tree, cap, idx, idx_is_tree, prio, prio_scalar_dev, prio_scalar, B, TdPrio{nullptr, 0.0, 0.0, 0.0}, depth,
                 MaxLeaf{0, nullptr, nullptr, nullptr, 0}, ws.change, SMALL_LEAF};
     hipLaunchKernelGGL(per_small_kernel, dim3(1), dim3(1024), 0, stream, a);
     a.mode = SMALL_ANC;
-    if (depth > 0) hipLaunchKernelGGL(per_small_kernel, dim3(depth), dim3(1024), small_stage_bytes(B), stream, a);
+    if (depth > 0) hipLaunchKernelGGL(per_small_kernel, dim3(depth), dim3(1024), 0, stream, a);
     GYMRL_CHECK_LAUNCH();
     return 0;
   }
@@ -792,18 +768,17 @@ int gymrl_per_update_td(double* tree, int64_t cap, const int32_t* idx, const flo
   Ws ws(workspace, B);
   int depth = 0;
   { int64_t t = 2 * cap - 2; while (t > 0) { t = (t - 1) / 2; ++depth; } }
-  if (!small_attr()) return -1000 - (int)hipGetLastError();
   SmallArgs a{tree, cap, idx, 0, nullptr, nullptr, 0.0, B, TdPrio{td, alpha, eps, clip}, depth,
               MaxLeaf{cap, ws.partial, max_out, ticket, 0}, ws.change, SMALL_FUSED};
   const bool fused_max = max_out && cap <= (int64_t)kMaxChunk * 1024;
   if (ticket && depth > 0) {                             // ONE launch: depth blocks | maximum blocks, the last one writes the leaves
     a.mx.nb = fused_max ? cdiv(cap, kMaxChunk) : 0;
-    hipLaunchKernelGGL(per_small_kernel, dim3(depth + a.mx.nb), dim3(1024), small_stage_bytes(B), stream, a);
+    hipLaunchKernelGGL(per_small_kernel, dim3(depth + a.mx.nb), dim3(1024), 0, stream, a);
   } else {
     a.mode = SMALL_LEAF;
     hipLaunchKernelGGL(per_small_kernel, dim3(1), dim3(1024), 0, stream, a);
     a.mode = SMALL_ANC;
-    if (depth > 0) hipLaunchKernelGGL(per_small_kernel, dim3(depth), dim3(1024), small_stage_bytes(B), stream, a);
+    if (depth > 0) hipLaunchKernelGGL(per_small_kernel, dim3(depth), dim3(1024), 0, stream, a);
   }
   GYMRL_CHECK_LAUNCH();
   if (max_out && !(ticket && depth > 0 && fused_max)) return gymrl_per_max_leaf(tree, cap, max_out, ws.partial, stream_);

@@ -222,9 +222,11 @@ class SACTrainer:
             # (flatten_module binds every parameter as a VIEW tensor of its own: load_state_dict / a checkpoint bump the
             # parameters' version counters, not the flat buffers' — so both are summed; writers that go around torch
             # altogether, soft_update() and load_checkpoint(), reset _img_versions themselves)
-            v = tuple(f._version + sum(p._version for p in net.parameters())
-                      for f, net in ((self.actor_flat, self.actor), (self.critic_flat, self.critic),
-                                     (self.critic_target_flat, self.critic_target)))
+            ps = getattr(self, "_img_params", None)
+            if ps is None:
+                ps = self._img_params = tuple([f] + list(net.parameters()) for f, net in (
+                    (self.actor_flat, self.actor), (self.critic_flat, self.critic), (self.critic_target_flat, self.critic_target)))
+            v = tuple(sum([t._version for t in group]) for group in ps)
             if v != self._img_versions:
                 ops.sac_pack_images(self._fused[1])
                 self._img_versions = v
