@@ -44,7 +44,7 @@ SYMBOLS = [
     "gymrl_linear_smallk_bwd", "gymrl_heads_fwd_tanh", "gymrl_heads_bwd", "gymrl_rollout_lunar", "gymrl_rollout_cartpole",
     "gymrl_gemm_workspace_bytes", "gymrl_linear_fwd", "gymrl_linear_bwd_input",
     "gymrl_linear_bwd_weight_geometry", "gymrl_linear_bwd_weight",
-    "gymrl_heads_loss_blocks", "gymrl_heads_loss_fwd_bwd",
+    "gymrl_heads_loss_blocks", "gymrl_heads_loss_fwd_bwd", "gymrl_update_finalize",
     "gymrl_lin_workspace_bytes", "gymrl_lin_fwd", "gymrl_lin_bwd_input", "gymrl_lin_bwd_weight",
     "gymrl_noisy_combine", "gymrl_noisy_split", "gymrl_dueling_bwd",
     "gymrl_mhc_gates", "gymrl_mhc_combine", "gymrl_rmsnorm", "gymrl_sinkhorn",

@@ -36,6 +36,7 @@
 // once to f32.
 #include <type_traits>
 #include "train_device.hpp"
+#include "finalize_device.hpp"
 #include "../../include/gymrl.h"
 
 namespace {
@@ -43,7 +44,7 @@ namespace {
 using namespace gymrl;
 
 
-constexpr int kCUs = 256;
+using fin::kCUs;
 // Column slices of the N = 256 weight-stationary kernels.  2: a [256 x 128] slice per workgroup (128 KiB of LDS, 8 row tiles
 // per wave at 262,144 rows); 4: [256 x 64] slices (64 KiB, 16 row tiles per wave, 64 x 64 wave tiles) — the fixed cost of a
 // launch (weight fill, first loads, the last tile's exposed epilogue) is halved and spread over twice the tiles, at the
@@ -574,61 +575,15 @@ __global__ __launch_bounds__(kTnThreads) void gemm_tn_kernel(TnArgs p) {
   }
 }
 
-// db[ntile*256 + n] from the per-slice column sums, same slice grouping as the weight tiles: thread (n, j) adds the
-// slices s = j (mod 4) ascending (independent loads, 8 in flight), the four group sums combine as ((g0 + g1) + g2) + g3
+// The slice partials' second halves: finalize_device.hpp (shared with gymrl_update_finalize's one launch)
 __global__ __launch_bounds__(256) void tn_colsum_kernel(const float* __restrict__ parts, int slices, float* __restrict__ db) {
   __shared__ double sm[4][64];
-  const int n = blockIdx.x * 64 + (threadIdx.x & 63), j = threadIdx.x >> 6;     // n: column over all tiles
-  const int ntile = n >> 8, nl = n & 255;
-  const float* src = parts + (size_t)ntile * slices * 256 + nl;
-  double g = 0.0;
-  int s = j;
-  for (; s + 28 < slices; s += 32) {
-    float v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(s + 4 * k) * 256];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) g += (double)v[k];
-  }
-  for (; s < slices; s += 4) g += (double)src[(size_t)s * 256];
-  sm[j][threadIdx.x & 63] = g;
-  __syncthreads();
-  if (j == 0) {
-    const int l = threadIdx.x;
-    db[n] = (float)(((sm[0][l] + sm[1][l]) + sm[2][l]) + sm[3][l]);
-  }
+  fin::tn_colsum_body(parts, slices, db, blockIdx.x, sm);
 }
-
-// dW[ntile*256 + n][k] = ((g0 + g1) + g2) + g3, g_j = sum over slices s = j (mod 4) ascending (f64)
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ parts, int slices, int ldw,
                                                         float* __restrict__ dW) {
   __shared__ double sm[3][64][4];
-  const int g = threadIdx.x >> 6, e = blockIdx.x * 64 + (threadIdx.x & 63);    // e: float4 index inside all tiles
-  const int ntile = e >> 14, e4 = e & 16383;
-  const f32x4* src = reinterpret_cast<const f32x4*>(parts) + (size_t)ntile * slices * 16384 + e4;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int s = g;
-  for (; s + 12 < slices; s += 16) {
-    const f32x4 v0 = src[(size_t)s * 16384], v1 = src[(size_t)(s + 4) * 16384];
-    const f32x4 v2 = src[(size_t)(s + 8) * 16384], v3 = src[(size_t)(s + 12) * 16384];
-    s0 += (double)v0[0]; s1 += (double)v0[1]; s2 += (double)v0[2]; s3 += (double)v0[3];
-    s0 += (double)v1[0]; s1 += (double)v1[1]; s2 += (double)v1[2]; s3 += (double)v1[3];
-    s0 += (double)v2[0]; s1 += (double)v2[1]; s2 += (double)v2[2]; s3 += (double)v2[3];
-    s0 += (double)v3[0]; s1 += (double)v3[1]; s2 += (double)v3[2]; s3 += (double)v3[3];
-  }
-  for (; s < slices; s += 4) {
-    const f32x4 v = src[(size_t)s * 16384];
-    s0 += (double)v[0]; s1 += (double)v[1]; s2 += (double)v[2]; s3 += (double)v[3];
-  }
-  const int le = threadIdx.x & 63;
-  if (g > 0) { sm[g - 1][le][0] = s0; sm[g - 1][le][1] = s1; sm[g - 1][le][2] = s2; sm[g - 1][le][3] = s3; }
-  __syncthreads();
-  if (g == 0) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { s0 += sm[j][le][0]; s1 += sm[j][le][1]; s2 += sm[j][le][2]; s3 += sm[j][le][3]; }
-    const int n = e4 >> 6, k4 = e4 & 63;
-    *reinterpret_cast<f32x4*>(dW + (size_t)(ntile * 256 + n) * ldw + 4 * k4) = f32x4{(float)s0, (float)s1, (float)s2, (float)s3};
-  }
+  fin::tn_reduce_body(parts, slices, ldw, dW, blockIdx.x, sm);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -685,19 +640,8 @@ void launch_ns(const WsArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((gemm_ns_kernel<RED, NT, TRANS_W, EPI, LDO>), dim3((unsigned)(rg * a.slices)), dim3(256), 0, s, a);
 }
 
-inline void tn_geometry(int64_t B, int N, int* slices, int64_t* rps) {
-  const int ntiles = N / 256;
-  int s = kCUs / ntiles;
-  int64_t r = (B + s - 1) / s;
-  r += r & 1;                                     // row pairs are the MFMA's K = 2
-  if (r < 64) r = 64;                             // tiny minibatches: fewer, non-trivial slices
-  s = (int)((B + r - 1) / r);
-  if (s < 1) s = 1;
-  *slices = s;
-  *rps = r;
-}
-
-constexpr size_t kColsumBytes = (size_t)kCUs * 512 * sizeof(float);
+using fin::tn_geometry;
+using fin::kColsumBytes;
 
 }  // namespace
 
@@ -799,8 +743,10 @@ int gymrl_linear_bwd_input(const float* dY, const float* W, const float* H, int6
 
 int gymrl_linear_bwd_weight(const float* dY, const float* X, int64_t B, int N, int K, float* dW, float* db,
                             void* workspace, void* stream) {
-  if (!dY || !X || !dW || !workspace || B <= 0 || K != 256 || N < 256 || N % 256 || N > 512 || !al16(dY) || !al16(X) ||
-      !al16(dW) || !al16(workspace))
+  // dW == NULL: the slice partials only (they stay in `workspace`; db != NULL still asks for the column-sum partials) —
+  // gymrl_update_finalize reduces them together with the minibatch's other reductions
+  if (!dY || !X || !workspace || B <= 0 || K != 256 || N < 256 || N % 256 || N > 512 || !al16(dY) || !al16(X) ||
+      (dW && !al16(dW)) || !al16(workspace))
     return -22;
   TnArgs a{};
   a.dY = dY; a.ldy = N; a.X = X; a.ldx = K; a.M = B; a.ntiles = N / 256;
@@ -819,8 +765,10 @@ int gymrl_linear_bwd_weight(const float* dY, const float* X, int64_t B, int N, i
 #endif
   if (N == 256) hipLaunchKernelGGL((gemm_tn_kernel<8, 256>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((gemm_tn_kernel<8, 512>), grid, block, 0, s, a);
-  hipLaunchKernelGGL(tn_reduce_kernel, dim3(a.ntiles * 256), dim3(256), 0, s, a.parts, a.slices, K, dW);
-  if (db) hipLaunchKernelGGL(tn_colsum_kernel, dim3(a.ntiles * 4), dim3(256), 0, s, a.cs_parts, a.slices, db);
+  if (dW) {
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(a.ntiles * 256), dim3(256), 0, s, a.parts, a.slices, K, dW);
+    if (db) hipLaunchKernelGGL(tn_colsum_kernel, dim3(a.ntiles * 4), dim3(256), 0, s, a.cs_parts, a.slices, db);
+  }
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

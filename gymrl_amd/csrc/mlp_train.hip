@@ -23,6 +23,7 @@
 // per-lane serial f32 sums over the rows a lane visits, LDS tree inside the workgroup, one f32
 // partial row per workgroup, fixed-order f64 finalize.
 #include "train_device.hpp"
+#include "finalize_device.hpp"
 #include "policy_device.hpp"
 #include "../../include/gymrl.h"
 
@@ -306,15 +307,19 @@ __global__ __launch_bounds__(kTB) void linear_smallk_bwd_kernel(const float* __r
 }
 
 // dW[col][d] = sum over blocks of partials[b][(d+1)*C + col]; db[col] = ... [col]
-__global__ __launch_bounds__(kTB) void smallk_finalize_kernel(const float* __restrict__ partials, int nblocks, int C, int D,
-                                                              float* __restrict__ dW, float* __restrict__ db) {
-  const int e = blockIdx.x * kFinE + threadIdx.x % kFinE;
+__device__ __forceinline__ void smallk_finalize_body(const float* __restrict__ partials, int nblocks, int C, int D,
+                                                     float* __restrict__ dW, float* __restrict__ db, int block) {
+  const int e = block * kFinE + threadIdx.x % kFinE;
   const int width = (D + 1) * C;
   const double s = reduce_partials(partials, nblocks, width, e, e < width);
   if (e >= width || threadIdx.x >= kFinE) return;
   const int v = e / C, col = e - v * C;
   if (v == 0) db[col] = (float)s;
   else dW[(size_t)col * D + (v - 1)] = (float)s;
+}
+__global__ __launch_bounds__(kTB) void smallk_finalize_kernel(const float* __restrict__ partials, int nblocks, int C, int D,
+                                                              float* __restrict__ dW, float* __restrict__ db) {
+  smallk_finalize_body(partials, nblocks, C, D, dW, db, blockIdx.x);
 }
 
 // ------------------------------------------------------------------ B4 -------
@@ -403,13 +408,13 @@ __global__ __launch_bounds__(kTB) void heads_bwd_kernel(const float* Hac, const 
 
 // partial row (vectors of C): v0 dba, v1 dbc, v2..v(1+A) dWa2[a], v(2+A) dWc2, v(3+A).. dlogit sums at col 0..3
 template <int A>
-__global__ __launch_bounds__(kTB) void heads_finalize_kernel(const float* __restrict__ partials, int nblocks, int C,
-                                                             float* __restrict__ dbac, float* __restrict__ dWa2,
-                                                             float* __restrict__ dWc2, float* __restrict__ dba2,
-                                                             float* __restrict__ dbc2) {
+__device__ __forceinline__ void heads_finalize_body(const float* __restrict__ partials, int nblocks, int C,
+                                                    float* __restrict__ dbac, float* __restrict__ dWa2,
+                                                    float* __restrict__ dWc2, float* __restrict__ dba2,
+                                                    float* __restrict__ dbc2, int block) {
   constexpr int NV = (8 + 4 * A + 4 + 4 * ((A + 1 + 3) / 4)) / 4;
   const int width = NV * C;
-  const int e = blockIdx.x * kFinE + threadIdx.x % kFinE;
+  const int e = block * kFinE + threadIdx.x % kFinE;
   const int v = e / C, col = e - v * C;
   const bool want = e < width && !(v >= 3 + A && col >= 4);
   const double s = reduce_partials(partials, nblocks, width, e, want);
@@ -424,6 +429,13 @@ __global__ __launch_bounds__(kTB) void heads_finalize_kernel(const float* __rest
     if (k < A) dba2[k] = f;
     else if (k == A) dbc2[0] = f;
   }
+}
+template <int A>
+__global__ __launch_bounds__(kTB) void heads_finalize_kernel(const float* __restrict__ partials, int nblocks, int C,
+                                                             float* __restrict__ dbac, float* __restrict__ dWa2,
+                                                             float* __restrict__ dWc2, float* __restrict__ dba2,
+                                                             float* __restrict__ dbc2) {
+  heads_finalize_body<A>(partials, nblocks, C, dbac, dWa2, dWc2, dba2, dbc2, blockIdx.x);
 }
 
 // ------------------------------------------------------------------ F3+L1+B4 -
@@ -599,6 +611,31 @@ inline bool pow2_cols(int C) { return C >= 16 && C <= 256 && (C & (C - 1)) == 0;
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline size_t sm_bytes(int C, int nv4) { return sizeof(float) * (size_t)(kTB / 64) * (64 / (C / 4)) * nv4 * C; }
 
+
+// ------------------------------------------------------------------ the minibatch's reductions, one launch ---
+// A minibatch's backward leaves five batch reductions half done — the slice partials of the two 256-deep weight gradients
+// (gemm.hip), the block partials of the heads' and of the first layer's gradients (above) — and their second halves were
+// five launches of 5-17 us behind one another (3 % of the update).  They do not depend on each other: here they are block
+// ranges of ONE grid, each block running the body its own kernel runs (finalize_device.hpp, *_finalize_body): same loads,
+// same float64 sums in the same order, bit-identical outputs.
+struct UpdFinArgs {
+  const float* parts_ac; int slices_ac; float* dWac;                    // [2C x C] from 2C/256 tiles x slices_ac partials
+  const float* parts_2; const float* cs_2; int slices_2; float* dW2; float* db2;
+  const float* parts_h; int nb_h; float* dbac; float* dWa2; float* dWc2; float* dba2; float* dbc2;
+  const float* parts_1; int nb_1; int D; float* dW1; float* db1;
+  int C, b_ac, b_2, b_cs, b_h;                                           // first block of each job after the first
+};
+template <int A>
+__global__ __launch_bounds__(kTB) void update_finalize_kernel(const UpdFinArgs a) {
+  __shared__ double sm[3][64][4];
+  const int b = blockIdx.x;
+  if (b < a.b_ac) fin::tn_reduce_body(a.parts_ac, a.slices_ac, a.C, a.dWac, b, sm);
+  else if (b < a.b_2) fin::tn_reduce_body(a.parts_2, a.slices_2, a.C, a.dW2, b - a.b_ac, sm);
+  else if (b < a.b_cs) fin::tn_colsum_body(a.cs_2, a.slices_2, a.db2, b - a.b_2, reinterpret_cast<double (*)[64]>(sm));
+  else if (b < a.b_h) heads_finalize_body<A>(a.parts_h, a.nb_h, a.C, a.dbac, a.dWa2, a.dWc2, a.dba2, a.dbc2, b - a.b_cs);
+  else smallk_finalize_body(a.parts_1, a.nb_1, a.C, a.D, a.dW1, a.db1, b - a.b_h);
+}
+
 }  // namespace
 
 extern "C" {
@@ -653,7 +690,8 @@ int gymrl_tanh_bwd_colsum(float* dH, const float* H, int64_t B, int C, float* co
 
 int gymrl_linear_smallk_bwd(const float* dH, const float* H, const float* x, int64_t B, int D, int C, float* dW,
                             float* db, const float* W, const float* b, void* workspace, void* stream) {
-  if (!dH || !x || !dW || !db || !workspace || B < 0 || !pow2_cols(C) || !al16(dH) || (H && !al16(H)) ||
+  // dW == NULL && db == NULL: the block partials only (they stay in `workspace` for gymrl_update_finalize)
+  if (!dH || !x || (!dW != !db) || !workspace || B < 0 || !pow2_cols(C) || !al16(dH) || (H && !al16(H)) ||
       !al16(x))
     return -22;
   hipStream_t s = (hipStream_t)stream;
@@ -667,7 +705,7 @@ int gymrl_linear_smallk_bwd(const float* dH, const float* H, const float* x, int
     case 8: hipLaunchKernelGGL(linear_smallk_bwd_kernel<8>, grid, block, sm_bytes(C, 9), s, dH, H, x, B, C, parts, W, b); break;
     default: return -22;
   }
-  hipLaunchKernelGGL(smallk_finalize_kernel, dim3(((D + 1) * C + kFinE - 1) / kFinE), dim3(kTB), 0, s, parts, nb, C, D, dW, db);
+  if (dW) hipLaunchKernelGGL(smallk_finalize_kernel, dim3(((D + 1) * C + kFinE - 1) / kFinE), dim3(kTB), 0, s, parts, nb, C, D, dW, db);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
@@ -731,7 +769,10 @@ int gymrl_heads_loss_fwd_bwd(float* Zac, int64_t B, int C, int A, const float* b
                              const float* adv, const float* ret, const double* adv_moments, const gymrl_ppo_cfg* cfg,
                              float* dbac, float* dWa2, float* dba2, float* dWc2, float* dbc2, double* metric_parts,
                              void* workspace, void* stream) {
-  if (!Zac || !Wa2 || !Wc2 || !act || !logp_old || !adv || !ret || !cfg || !dbac || !dWa2 || !dba2 || !dWc2 || !dbc2 ||
+  // all five gradient outputs NULL: the block partials only (they stay in `workspace` for gymrl_update_finalize)
+  const bool parts_only = !dbac && !dWa2 && !dba2 && !dWc2 && !dbc2;
+  if (!Zac || !Wa2 || !Wc2 || !act || !logp_old || !adv || !ret || !cfg ||
+      (!parts_only && (!dbac || !dWa2 || !dba2 || !dWc2 || !dbc2)) ||
       !metric_parts || !workspace || B <= 0 || C != 256 || !al16(Zac) || (bac && !al16(bac)))
     return -22;
   hipStream_t s = (hipStream_t)stream;
@@ -742,17 +783,48 @@ int gymrl_heads_loss_fwd_bwd(float* Zac, int64_t B, int C, int A, const float* b
     constexpr int NV = (8 + 16 + 4 + 8) / 4;
     hipLaunchKernelGGL(heads_loss_kernel<4>, grid, block, sm_bytes(C, NV), s, Zac, B, bac, Wa2, ba2, Wc2, bc2, act,
                        logp_old, adv, ret, adv_moments, *cfg, parts, metric_parts);
-    hipLaunchKernelGGL(heads_finalize_kernel<4>, dim3((NV * C + kFinE - 1) / kFinE), block, 0, s, parts, nb, C, dbac, dWa2,
-                       dWc2, dba2, dbc2);
+    if (!parts_only)
+      hipLaunchKernelGGL(heads_finalize_kernel<4>, dim3((NV * C + kFinE - 1) / kFinE), block, 0, s, parts, nb, C, dbac, dWa2,
+                         dWc2, dba2, dbc2);
   } else if (A == 2) {
     constexpr int NV = (8 + 8 + 4 + 4) / 4;
     hipLaunchKernelGGL(heads_loss_kernel<2>, grid, block, sm_bytes(C, NV), s, Zac, B, bac, Wa2, ba2, Wc2, bc2, act,
                        logp_old, adv, ret, adv_moments, *cfg, parts, metric_parts);
-    hipLaunchKernelGGL(heads_finalize_kernel<2>, dim3((NV * C + kFinE - 1) / kFinE), block, 0, s, parts, nb, C, dbac, dWa2,
-                       dWc2, dba2, dbc2);
+    if (!parts_only)
+      hipLaunchKernelGGL(heads_finalize_kernel<2>, dim3((NV * C + kFinE - 1) / kFinE), block, 0, s, parts, nb, C, dbac, dWa2,
+                         dWc2, dba2, dbc2);
   } else {
     return -22;
   }
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_update_finalize(int64_t B, int C, int A, int D, const void* ws_dw_ac, float* dWac, const void* ws_dw_2, float* dW2,
+                          float* db2, const void* ws_heads, float* dbac, float* dWa2, float* dba2, float* dWc2, float* dbc2,
+                          const void* ws_smallk, float* dW1, float* db1, void* stream) {
+  if (B <= 0 || C != 256 || (A != 2 && A != 4) || (D != 2 && D != 3 && D != 4 && D != 8) || !ws_dw_ac || !dWac || !ws_dw_2 ||
+      !dW2 || !db2 || !ws_heads || !dbac || !dWa2 || !dba2 || !dWc2 || !dbc2 || !ws_smallk || !dW1 || !db1 || !al16(dWac) ||
+      !al16(dW2) || !al16(ws_dw_ac) || !al16(ws_dw_2))
+    return -22;
+  UpdFinArgs a{};
+  int64_t rps;
+  fin::tn_geometry(B, 2 * C, &a.slices_ac, &rps);
+  fin::tn_geometry(B, C, &a.slices_2, &rps);
+  a.parts_ac = (const float*)((const char*)ws_dw_ac + fin::kColsumBytes); a.dWac = dWac;
+  a.cs_2 = (const float*)ws_dw_2; a.parts_2 = (const float*)((const char*)ws_dw_2 + fin::kColsumBytes); a.dW2 = dW2; a.db2 = db2;
+  a.parts_h = (const float*)ws_heads; a.nb_h = heads_loss_grid(B);
+  a.dbac = dbac; a.dWa2 = dWa2; a.dWc2 = dWc2; a.dba2 = dba2; a.dbc2 = dbc2;
+  a.parts_1 = (const float*)ws_smallk; a.nb_1 = grid_for(B, C); a.D = D; a.dW1 = dW1; a.db1 = db1;
+  a.C = C;
+  const int NV = (8 + 4 * A + 4 + 4 * ((A + 1 + 3) / 4)) / 4;
+  a.b_ac = (2 * C / 256) * 256;
+  a.b_2 = a.b_ac + (C / 256) * 256;
+  a.b_cs = a.b_2 + (C / 256) * 4;
+  a.b_h = a.b_cs + (NV * C + kFinE - 1) / kFinE;
+  const int total = a.b_h + ((D + 1) * C + kFinE - 1) / kFinE;
+  if (A == 4) hipLaunchKernelGGL(update_finalize_kernel<4>, dim3(total), dim3(kTB), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(update_finalize_kernel<2>, dim3(total), dim3(kTB), 0, (hipStream_t)stream, a);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

@@ -235,9 +235,8 @@ __device__ __forceinline__ void small_dups(const SmallArgs& a, SmallLds& s, int 
   int prev = -1, lastm = -1;
   for (int jb = r.j0; jb < r.j1; jb += 64) {
     const int32_t vj = jb + lane < r.j1 ? s.leaf[jb + lane] : -1;
-    const int n = r.j1 - jb < 64 ? r.j1 - jb : 64;
-#pragma unroll 8
-    for (int u = 0; u < n; ++u) {
+#pragma unroll
+    for (int u = 0; u < 64; ++u) {                                 // (entries beyond the range hold a value that matches nothing)
       const int32_t L = __builtin_amdgcn_readlane(vj, u);
       const int j = jb + u;
       const bool eq = L == mine;
@@ -273,9 +272,8 @@ __device__ __forceinline__ void small_ancestors(const SmallArgs& a, SmallLds& s,
     int rank = 0, cnt = 0, first = kNoFirst;
     for (int jb = r.j0; jb < r.j1; jb += 64) {
       const int32_t vj = jb + lane < r.j1 ? s.node[jb + lane] : -1;
-      const int n = r.j1 - jb < 64 ? r.j1 - jb : 64;
-  #pragma unroll 8
-    for (int u = 0; u < n; ++u) {
+    #pragma unroll
+    for (int u = 0; u < 64; ++u) {                                 // (entries beyond the range hold a value that matches nothing)
         const int32_t L = __builtin_amdgcn_readlane(vj, u);
         const int j = jb + u;
         const bool eq = L == key;
@@ -296,9 +294,8 @@ __device__ __forceinline__ void small_ancestors(const SmallArgs& a, SmallLds& s,
     int slot = 0;
     for (int jb = r.j0; jb < r.j1; jb += 64) {
       const int32_t vj = jb + lane < r.j1 ? s.first[jb + lane] : kNoFirst;
-      const int n = r.j1 - jb < 64 ? r.j1 - jb : 64;
-#pragma unroll 8
-      for (int u = 0; u < n; ++u) slot += __builtin_amdgcn_readlane(vj, u) < myfirst ? 1 : 0;
+  #pragma unroll
+      for (int u = 0; u < 64; ++u) slot += __builtin_amdgcn_readlane(vj, u) < myfirst ? 1 : 0;
     }
     if (mine >= 0 && slot) atomicAdd(&s.slot[r.i], slot);
   }

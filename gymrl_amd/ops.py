@@ -732,11 +732,12 @@ def tanh_bwd_colsum(dH, H, colsum_out, workspace):
 
 def linear_smallk_bwd(dH, H, x, dW, db, workspace, W=None, b=None):
     """First layer backward without materialising dZ: dW = (dH (1 - H^2))^T x, db = colsum.  With the layer's own
-    (W, b) the kernel recomputes H = tanh(x W^T + b) instead of reading it (H may then be None)."""
+    (W, b) the kernel recomputes H = tanh(x W^T + b) instead of reading it (H may then be None).  dW = db = None: the
+    block partials only (they stay in `workspace` for update_finalize)."""
     B, Cc = dH.shape
     check(lib().gymrl_linear_smallk_bwd(_ptr(dH, torch.float32), _ptr(H, torch.float32, True), _ptr(x, torch.float32),
-                                        C.c_int64(B), C.c_int(x.shape[1]), C.c_int(Cc), _ptr(dW, torch.float32),
-                                        _ptr(db, torch.float32), _ptr(W, torch.float32, True), _ptr(b, torch.float32, True),
+                                        C.c_int64(B), C.c_int(x.shape[1]), C.c_int(Cc), _ptr(dW, torch.float32, True),
+                                        _ptr(db, torch.float32, True), _ptr(W, torch.float32, True), _ptr(b, torch.float32, True),
                                         _ptr(workspace), _stream()), "gymrl_linear_smallk_bwd")
 
 
@@ -766,15 +767,16 @@ def heads_loss_blocks(B, C_=256):
 
 def heads_loss_fwd_bwd(Zac, bac, Wa2, ba2, Wc2, bc2, act, logp_old, adv, ret, cfg, adv_moments, dbac, dWa2, dba2, dWc2,
                        dbc2, metric_parts, workspace):
-    """Heads forward + PPO loss + heads backward in one pass; dZac overwrites Zac (include/gymrl.h)."""
+    """Heads forward + PPO loss + heads backward in one pass; dZac overwrites Zac (include/gymrl.h).  All five gradient
+    outputs None: the block partials only (they stay in `workspace` for update_finalize)."""
     B, C2 = Zac.shape
     c = PPOCfg(*[float(v) for v in cfg])
     check(lib().gymrl_heads_loss_fwd_bwd(
         _ptr(Zac, torch.float32), C.c_int64(B), C.c_int(C2 // 2), C.c_int(Wa2.shape[0]), _ptr(bac, torch.float32, True),
         _ptr(Wa2, torch.float32), _ptr(ba2, torch.float32, True), _ptr(Wc2, torch.float32), _ptr(bc2, torch.float32, True),
         _ptr(act, torch.int32), _ptr(logp_old, torch.float32), _ptr(adv, torch.float32), _ptr(ret, torch.float32),
-        _ptr(adv_moments, torch.float64, True), C.byref(c), _ptr(dbac, torch.float32), _ptr(dWa2, torch.float32),
-        _ptr(dba2, torch.float32), _ptr(dWc2, torch.float32), _ptr(dbc2, torch.float32), _ptr(metric_parts, torch.float64),
+        _ptr(adv_moments, torch.float64, True), C.byref(c), _ptr(dbac, torch.float32, True), _ptr(dWa2, torch.float32, True),
+        _ptr(dba2, torch.float32, True), _ptr(dWc2, torch.float32, True), _ptr(dbc2, torch.float32, True), _ptr(metric_parts, torch.float64),
         _ptr(workspace), _stream()), "gymrl_heads_loss_fwd_bwd")
 
 
@@ -823,13 +825,27 @@ def linear_bwd_weight_geometry(B, N):
     return s.value, r.value
 
 
-def linear_bwd_weight(dy, x, dW, workspace, db=None):
-    """dW [N, 256] = dy [B, N]^T x [B, 256]; db [N] = column sums of dy (None: skipped).  Overwrites."""
+def linear_bwd_weight(dy, x, dW, workspace, db=None, partials_db=False):
+    """dW [N, 256] = dy [B, N]^T x [B, 256]; db [N] = column sums of dy (None: skipped).  Overwrites.  dW = None: the slice
+    partials only (they stay in `workspace` for update_finalize; partials_db: with the column-sum partials)."""
     B, N = dy.shape
+    if dW is None and partials_db:
+        db_arg = _ptr(workspace)                       # a non-NULL flag: nothing is written through it in this mode
+    else:
+        db_arg = _ptr(db, torch.float32, True)
     check(lib().gymrl_linear_bwd_weight(_ptr(dy, torch.float32), _ptr(x, torch.float32), C.c_int64(B), C.c_int(N),
-                                        C.c_int(x.shape[1]), _ptr(dW, torch.float32), _ptr(db, torch.float32, True),
+                                        C.c_int(x.shape[1]), _ptr(dW, torch.float32, True), db_arg,
                                         _ptr(workspace), _stream()), "gymrl_linear_bwd_weight")
     return dW
+
+
+def update_finalize(B, C_, A, D, ws_dw_ac, dWac, ws_dw_2, dW2, db2, ws_heads, dbac, dWa2, dba2, dWc2, dbc2, ws_smallk, dW1, db1):
+    """gymrl_update_finalize: the second halves of a minibatch's five batch reductions (both 256-deep weight gradients, the
+    heads' and the first layer's gradients) as ONE launch, from the partials their producers left in their workspaces."""
+    f = lambda t: _ptr(t, torch.float32)        # noqa: E731
+    check(lib().gymrl_update_finalize(C.c_int64(B), C.c_int(C_), C.c_int(A), C.c_int(D), _ptr(ws_dw_ac), f(dWac), _ptr(ws_dw_2),
+                                      f(dW2), f(db2), _ptr(ws_heads), f(dbac), f(dWa2), f(dba2), f(dWc2), f(dbc2), _ptr(ws_smallk),
+                                      f(dW1), f(db1), _stream()), "gymrl_update_finalize")
 
 
 # ------------------------------------------------------ persistent rollout ---

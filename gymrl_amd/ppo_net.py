@@ -80,6 +80,11 @@ class FusedActorCriticUpdate:
         self.timers = None      # bench.py: KernelTimers bracketing every launch
         self.one_pass_heads = H == 256           # gymrl_heads_loss_fwd_bwd (a row = one 64-lane load of 4 columns per lane)
         self.gemm_ws = ops.gemm_workspace(dev) if H == 256 else None
+        # the five batch reductions' second halves as ONE launch at the end of step() (gymrl_update_finalize) instead of five
+        # behind their producers: every producer then keeps its partials in a workspace of its own until that launch
+        self.defer_finalize = H == 256
+        self.gemm_ws2 = ops.gemm_workspace(dev) if H == 256 else None
+        self.ws2 = ops.mlp_train_workspace(H, self.D, self.A, dev) if H == 256 else None
         if not self.one_pass_heads:
             self.logits = torch.empty(R, self.A, device=dev)
             self.value = torch.empty(R, 1, device=dev)
@@ -118,7 +123,13 @@ class FusedActorCriticUpdate:
         t(f"gemm_fwd_{2 * H}", B, ops.linear_fwd, H2, self.Wac, self.bac, Zac, False)
         heads = (m.actor[2].weight, m.actor[2].bias, m.critic[2].weight, m.critic[2].bias)
         hgrads = (m.actor[2].weight.grad, m.actor[2].bias.grad, m.critic[2].weight.grad, m.critic[2].bias.grad)
-        if self.one_pass_heads:
+        # (multi-rank: bucket 1 of the gradient all-reduce leaves in the middle of step(): its gradients are finalized at once)
+        defer = self.defer_finalize and self.one_pass_heads and reducer is None
+        if self.one_pass_heads and defer:
+            t("heads_loss_fwd_bwd", B, ops.heads_loss_fwd_bwd, Zac, None, *heads, act, logp_old, adv, ret, loss_cfg, adv_moments,
+              None, None, None, None, None, metric_parts, self.ws)
+            t("gemm_dw_512", B, ops.linear_bwd_weight, Zac, H2, None, ws)
+        elif self.one_pass_heads:
             t("heads_loss_fwd_bwd", B, ops.heads_loss_fwd_bwd, Zac, None, *heads, act, logp_old, adv, ret, loss_cfg, adv_moments,
               self.dbac, *hgrads, metric_parts, self.ws)
             t("gemm_dw_512", B, ops.linear_bwd_weight, Zac, H2, self.dWac, ws)
@@ -134,12 +145,20 @@ class FusedActorCriticUpdate:
         if reducer is not None:
             reducer.launch(1)
         t(f"gemm_dx_{2 * H}_tanhbwd", B, ops.linear_bwd_input, Zac, self.Wac, H2, dZ2)
-        if self.one_pass_heads:
+        if defer:
+            t("gemm_dw_256_db", B, ops.linear_bwd_weight, dZ2, H1, None, self.gemm_ws2, None, True)
+        elif self.one_pass_heads:
             t("gemm_dw_256_db", B, ops.linear_bwd_weight, dZ2, H1, W2.grad, ws, m.shared[2].bias.grad)
         else:
             t(f"lin_dw_{H}_db", B, ops.lin_bwd_weight, dZ2, None, H1, W2.grad, m.shared[2].bias.grad, workspace=self.lin_ws)
         t(f"gemm_dx_{H}_tanhbwd", B, ops.linear_bwd_input, dZ2, W2, H1, dZ1)
-        t("linear_smallk_bwd", B, ops.linear_smallk_bwd, dZ1, None, x, m.shared[0].weight.grad, m.shared[0].bias.grad,
-          self.ws)
+        if defer:
+            t("linear_smallk_bwd", B, ops.linear_smallk_bwd, dZ1, None, x, None, None, self.ws2)
+            t("update_finalize", B, ops.update_finalize, B, H, self.A, self.D, ws, self.dWac, self.gemm_ws2, W2.grad,
+              m.shared[2].bias.grad, self.ws, self.dbac, hgrads[0], hgrads[1], hgrads[2], hgrads[3], self.ws2,
+              m.shared[0].weight.grad, m.shared[0].bias.grad)
+        else:
+            t("linear_smallk_bwd", B, ops.linear_smallk_bwd, dZ1, None, x, m.shared[0].weight.grad, m.shared[0].bias.grad,
+              self.ws)
         if reducer is not None:
             reducer.launch(0)

@@ -368,6 +368,7 @@ int gymrl_adam_step(float* p, float* g, float* m, float* v, int64_t n,
                     double eps, int64_t step, const float* bias_dev, float grad_scale,
                     float max_grad_norm, const double* sqnorm, float clamp_abs, int zero_grad,
                     float* polyak_target, double tau, void* stream);
+
 int gymrl_adam_bias(double lr, double beta1, double beta2, int64_t step, float* out_host4);
 int gymrl_store_scalars(void* dst_dev, const void* src_host, int nbytes, void* stream);
 
@@ -761,6 +762,8 @@ int gymrl_heads_bwd(const float* Hac, const float* dlogits, const float* dv, int
  *   clip fraction, approx KL) sums — reduce with gymrl_reduce_rows.  Same arithmetic per row as the three
  *   separate passes (one shared device function each), so gradients and metrics are bit-identical to them.
  */
+/* (gradient outputs: all five non-NULL, or all five NULL = "block partials only": they stay in `workspace` for
+ *  gymrl_update_finalize below; gymrl_linear_smallk_bwd takes dW = db = NULL and gymrl_linear_bwd_weight dW = NULL the same way) */
 int gymrl_heads_loss_blocks(int64_t B, int C);
 int gymrl_heads_loss_fwd_bwd(float* Zac, int64_t B, int C, int A, const float* bac, const float* Wa2,
                              const float* ba2, const float* Wc2, const float* bc2, const int32_t* act,
@@ -810,6 +813,18 @@ int gymrl_linear_bwd_input(const float* dY, const float* W, const float* H, int6
 int gymrl_linear_bwd_weight_geometry(int64_t B, int N, int* slices, int64_t* rows_per_slice);
 int gymrl_linear_bwd_weight(const float* dY, const float* X, int64_t B, int N, int K, float* dW,
                             float* db, void* workspace, void* stream);
+/*
+ * The second halves of the five batch reductions that close one ActorCritic minibatch backward (ppo_lunarlander.py:303) as ONE
+ * launch: the slice partials of dWac = d[actor.0 | critic.0].weight (gymrl_linear_bwd_weight, N = 2C, called with dW = NULL)
+ * and of dW2 / db2 = d shared.2 (N = C, dW = NULL, db != NULL), the block partials of the heads' gradients
+ * (gymrl_heads_loss_fwd_bwd with its five outputs NULL) and of the first layer's (gymrl_linear_smallk_bwd, dW = db = NULL) —
+ * each left in the workspace handed to that call (FOUR DIFFERENT workspaces: a deferred reduction's partials must survive
+ * until this launch).  Every block runs the body of the kernel it replaces: same loads, same float64 sums in the same order,
+ * outputs bit-identical to the five separate launches (tests/test_update_path_gpu.py).  C = 256, A in {2, 4}, D in {2, 3, 4, 8}.
+ */
+int gymrl_update_finalize(int64_t B, int C, int A, int D, const void* ws_dw_ac, float* dWac, const void* ws_dw_2, float* dW2,
+                          float* db2, const void* ws_heads, float* dbac, float* dWa2, float* dba2, float* dWc2, float* dbc2,
+                          const void* ws_smallk, float* dW1, float* db1, void* stream);
 
 /* ========================================================= off-policy ===== */
 /*

@@ -97,6 +97,27 @@ def test_step_matches_autograd_f32_and_f64(dev, B, hidden, D, A):
     print(f"B={B} hidden={hidden}: worst relative gradient error vs f64 = {worst:.2e}")
 
 
+@pytest.mark.parametrize("B,D,A", [(1, 8, 4), (300, 8, 4), (16385, 4, 2), (262144, 8, 4)])
+def test_one_finalize_launch_equals_five(dev, B, D, A):
+    """step() with the five batch reductions' second halves as ONE launch (gymrl_update_finalize: the default) against the
+    five launches behind their producers — every gradient of the flat buffer and the metric partials bit for bit."""
+    from gymrl_amd import ppo_net
+    outs = []
+    for defer in (False, True):
+        net = _net(dev, 3, 256, D, A)
+        x, act, lpo, adv, ret = _minibatch(B, dev, B + 5, D, A)
+        fu = ppo_net.FusedActorCriticUpdate(net, B)
+        assert fu.defer_finalize
+        fu.defer_finalize = defer
+        net._flat_grads.fill_(float("nan"))           # every element is written
+        parts = torch.zeros(fu.metric_blocks(B), 5, dtype=torch.float64, device=dev)
+        for _ in range(2):                            # the second pass finds the workspaces dirty
+            fu.step(x, act, lpo, adv, ret, LOSS_CFG, None, parts)
+        assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+        outs.append((torch.cat([p.grad.reshape(-1) for p in net.parameters()]), parts.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("B", [1, 7, 8, 1000, 40000])
 def test_heads_loss_one_pass_equals_three_passes(dev, B):
     """gymrl_heads_loss_fwd_bwd vs gymrl_heads_fwd_tanh -> gymrl_ppo_loss_fwd_bwd -> gymrl_heads_bwd on the same
