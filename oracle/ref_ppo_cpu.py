@@ -103,15 +103,20 @@ class PPOTrainerCPU:
         self.episode_rewards = deque(maxlen=100)
 
     def compute_gae(self, next_value):
-        rewards = np.array(self.buf["rewards"])
-        dones = np.array(self.buf["dones"], dtype=np.float32)
-        values = np.array(self.buf["values"] + [next_value])
-        advantages = np.zeros_like(rewards)
-        last_gae = 0.0
-        for t in reversed(range(len(rewards))):
-            delta = rewards[t] + self.cfg.gamma * values[t + 1] * (1 - dones[t]) - values[t]
-            advantages[t] = last_gae = delta + self.cfg.gamma * self.cfg.gae_lambda * (1 - dones[t]) * last_gae
-        return advantages, advantages + values[:-1]
+        """GAE(gamma, lambda) backwards over the one env's rollout, in the precision the reference computes it in: rewards and
+        values collected as python floats (float64 arrays), the episode-end mask float32 (ppo_lunarlander.py:179-196)."""
+        g, lam = self.cfg.gamma, self.cfg.gae_lambda
+        r = np.asarray(self.buf["rewards"])
+        v = np.asarray(self.buf["values"] + [next_value])
+        alive = 1 - np.asarray(self.buf["dones"], dtype=np.float32)       # 0 where the episode ended at step t
+        adv = np.zeros_like(r)
+        carry, t = 0.0, len(r)
+        while t > 0:
+            t -= 1
+            td = r[t] + g * v[t + 1] * alive[t] - v[t]                  # one-step TD error
+            carry = td + g * lam * alive[t] * carry
+            adv[t] = carry
+        return adv, adv + v[:-1]
 
     def collect_rollout(self):
         for v in self.buf.values():
