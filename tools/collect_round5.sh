@@ -1,0 +1,21 @@
+#!/bin/bash
+# Copies one tools/profile_round5.sh output directory (under gpurun_out/) into profiles/ under the r05_ names and
+# rebuilds the PMC summary with its provenance stamp.  usage: tools/collect_round5.sh <dir under gpurun_out>
+set -eu
+cd "$(dirname "$0")/.."
+R=gpurun_out/$1
+for f in bench_final.json bench_20steps.json bench_ppo_full.json bench_sac.json bench_rainbow.json bench_sac_bigbatch.json \
+         bench_rainbow_bigbatch.json bench_kernel_stats.csv bench_under_rocprof.json ppo_full_kernel_stats.csv sac_kernel_stats.csv \
+         rainbow_kernel_stats.csv sac_bigbatch_kernel_stats.csv rainbow_bigbatch_kernel_stats.csv micro_per.txt rollout_balance.txt \
+         pmc_FETCH_SIZE_counter_collection.csv pmc_WRITE_SIZE_counter_collection.csv; do
+  cp "$R/$f" "profiles/r05_$f"
+done
+cp "$R/pmc_gemm_sq.csv" profiles/r05_pmc_gemm.csv
+python tools/pmc_gemm_summarise.py "$R/pmc_FETCH_SIZE_counter_collection.csv" "$R/pmc_WRITE_SIZE_counter_collection.csv" \
+  "$R/pmc_gemm_sq.csv" "$R/pmc_gemm_sq_trace.csv" profiles/r05_pmc_summary.json "$R/pmc_provenance.json" > /dev/null
+python - <<'PY'
+import json, hashlib
+s = json.load(open("profiles/r05_pmc_summary.json"))["provenance"]
+h = hashlib.sha256(open("gymrl_amd/libgymrl_hip.so", "rb").read()).hexdigest()
+print("summary stamped with", s["libgymrl_hip_sha256"][:16], "| library in tree", h[:16], "|", "MATCH" if s["libgymrl_hip_sha256"] == h else "MISMATCH")
+PY

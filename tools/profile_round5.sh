@@ -1,0 +1,46 @@
+#!/bin/bash
+# Runs on the GPU box (through tools/gpu.sh): the round-5 measurement set committed under profiles/.
+# usage: tools/profile_round5.sh <outdir under gpurun_out>
+set -u
+OUT=/root/repo/gpurun_out/$1
+mkdir -p "$OUT"
+cd /root/repo
+timeout 600 python bench.py > "$OUT/bench_final.json" 2> "$OUT/bench_final.err"
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_20steps.json" 2> /dev/null
+timeout 300 python bench.py --algo ppo_full --steps 3 --warmup 1 > "$OUT/bench_ppo_full.json" 2> /dev/null
+timeout 300 python bench.py --algo sac > "$OUT/bench_sac.json" 2> /dev/null
+timeout 300 python bench.py --algo rainbow > "$OUT/bench_rainbow.json" 2> /dev/null
+timeout 300 python bench.py --algo sac --batch 4096 --steps 30 --warmup 5 > "$OUT/bench_sac_bigbatch.json" 2> /dev/null
+timeout 300 python bench.py --algo rainbow --batch 8192 --steps 30 --warmup 5 > "$OUT/bench_rainbow_bigbatch.json" 2> /dev/null
+timeout 200 python tools/micro_per.py > "$OUT/micro_per.txt" 2> /dev/null
+timeout 200 python tools/probe_rollout_balance.py 2048 > "$OUT/rollout_balance.txt" 2> /dev/null
+cd /tmp && export TMPDIR=/tmp
+prof() {   # prof <name> <cmd...>: kernel stats CSV of a command
+  local name=$1; shift
+  rm -rf /tmp/p_$name
+  timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$name -- "$@" > "$OUT/${name}_under_rocprof.json" 2> /dev/null
+  cp "$(find /tmp/p_$name -name '*kernel_stats.csv' | head -1)" "$OUT/${name}_kernel_stats.csv"
+}
+prof bench python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline
+prof ppo_full python /root/repo/bench.py --algo ppo_full --rollout 256 --steps 1 --warmup 1
+prof rainbow python /root/repo/bench.py --algo rainbow --steps 10 --warmup 2
+prof sac python /root/repo/bench.py --algo sac --steps 10 --warmup 2
+prof sac_bigbatch python /root/repo/bench.py --algo sac --batch 4096 --steps 4 --warmup 1
+prof rainbow_bigbatch python /root/repo/bench.py --algo rainbow --batch 8192 --steps 4 --warmup 1
+export GYMRL_PMC_PROVENANCE="$OUT/pmc_provenance.json"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/p_$c
+  timeout -k 5 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/p_$c -- python /root/repo/tools/pmc_gemm.py > /dev/null 2>&1
+  cp "$(find /tmp/p_$c -name '*counter_collection.csv' | head -1)" "$OUT/pmc_${c}_counter_collection.csv"
+done
+rm -rf /tmp/p_sq
+timeout -k 5 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d /tmp/p_sq -- python /root/repo/tools/pmc_gemm.py > /dev/null 2>&1
+cp "$(find /tmp/p_sq -name '*counter_collection.csv' | head -1)" "$OUT/pmc_gemm_sq.csv"
+cp "$(find /tmp/p_sq -name '*kernel_trace.csv' | head -1)" "$OUT/pmc_gemm_sq_trace.csv"
+ls -la "$OUT"
+for f in final 20steps ppo_full sac rainbow sac_bigbatch rainbow_bigbatch; do python -c "
+import json
+try:
+    d=json.load(open('$OUT/bench_$f.json')); print('$f', round(d['value']/1e6,3), 'M', round(d['ms_per_step'],3), 'ms', d['roofline']['frac'])
+except Exception as e: print('$f FAILED', e)
+"; done
