@@ -407,7 +407,8 @@ __device__ __forceinline__ f32x4 tile_bwd_weight(const float* __restrict__ dZ, i
 // gymrl_lin_bwd_weight's cut of the batch reduction (lin.hip): one chain up to 512 rows; above that `slices` slices of
 // rows_per_slice rows (a multiple of 32) whose partial tiles lin_slice_reduce_kernel adds in eight groups — group g the slices
 // g * each .. (g + 1) * each - 1 one after another from +0, then the groups in turn.  B >= 16384 on 64-aligned shapes takes the
-// 64 x 64-block kernels (another order: not restated here, the fused step stops at 8192 rows).
+// 64 x 64-block kernels (another order: not restated here, the fused step stops at 8192 rows).  The fused step's weight-gradient
+// tiles (offpolicy_step.hip sac_dw_body) follow the same cut: one wave per slice, the last one to arrive adds them in this order.
 __host__ __device__ __forceinline__ bool bwd_weight_big_shape(int B, int N, int K) { return B >= 16384 && N % 64 == 0 && K % 64 == 0; }
 __host__ __device__ __forceinline__ int bwd_weight_slices(int B, int N, int K) {
   if (B <= 512) return 1;
@@ -424,34 +425,6 @@ __host__ __device__ __forceinline__ int bwd_weight_slices(int B, int N, int K) {
   return s < by_rows ? s : by_rows;
 }
 __host__ __device__ __forceinline__ int bwd_weight_rows_per_slice(int B, int slices) { return (((B + slices - 1) / slices) + 31) / 32 * 32; }
-
-// tile_bwd_weight over a batch of any size in THAT order: what the weight-gradient tiles of the fused step kernels compute, so
-// that they stay bit-identical to the layer-by-layer path beyond 512 rows.
-__device__ __forceinline__ f32x4 tile_bwd_weight_sliced(const float* __restrict__ dZ, int ldz, int N, int nt, const float* __restrict__ X,
-                                                        int ldx, const float* __restrict__ X2, int ldx2, int K, int K1, int kb, int B,
-                                                        int lane, float& colsum_out) {
-  const int slices = bwd_weight_slices(B, N, K);
-  if (slices == 1) return tile_bwd_weight(dZ, ldz, N, nt, X, ldx, X2, ldx2, K, K1, kb, B, lane, colsum_out);
-  const int rps = bwd_weight_rows_per_slice(B, slices), each = (slices + 7) / 8;
-  f32x4 total = {0.0f, 0.0f, 0.0f, 0.0f};
-  float ctotal = 0.0f;
-  for (int g = 0; g < 8; ++g) {
-    f32x4 gs = {0.0f, 0.0f, 0.0f, 0.0f};
-    float gc = 0.0f;
-    for (int k = g * each; k < (g + 1) * each && k < slices; ++k) {
-      const int b0 = k * rps, rows = (B - b0 < rps) ? B - b0 : rps;
-      if (rows <= 0) continue;                       // (an empty slice's partial is +0)
-      float c;
-      const f32x4 part = tile_bwd_weight(dZ + (size_t)b0 * ldz, ldz, N, nt, X + (size_t)b0 * ldx, ldx,
-                                         X2 ? X2 + (size_t)b0 * ldx2 : nullptr, ldx2, K, K1, kb, rows, lane, c);
-      gs += part; gc += c;
-    }
-    if (g == 0) { total = gs; ctotal = gc; }
-    else { total += gs; ctotal += gc; }
-  }
-  colsum_out = ctotal;
-  return total;
-}
 
 // torch.optim.Adam's step on ONE element (optim.hip adam_one with grad_scale = scale = 1 and no clamp: the off-policy
 // optimisers that clip by norm keep their own launch).  step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t).

@@ -28,6 +28,7 @@ using lin::act_fwd;
 
 constexpr int kWaves = 16, kThreads = 64 * kWaves;
 constexpr int kMaxBatch = 8192;      // (ops.FUSED_MAX_BATCH) rows of an update: 512 slabs
+constexpr int kDwMaxSlices = 32;     // lin_device.hpp bwd_weight_slices(B <= 8192, ...) <= cdiv(B, 256)
 
 // Probe build only (make prof): 100 MHz wall-clock stamps at the stage boundaries of workgroup 0 (tools/probe_sac_stages.py)
 #ifdef GYMRL_PROF_BUILD
@@ -54,6 +55,7 @@ struct SacWs {
                                       //   P1: 0 / 1 target network 1 -> critic workgroup 1 / 2, 5 / 6 target network 2 -> critic workgroup 1 / 2;
                                       //   P3: 2 / 3 Q1 / Q2, 4 the second network's dZ1 slab
   float *xa, *xq[2], *xpart;          // P3's exchanges: action [16 S][kMaxA], the two Q columns [16 S], network 1's half of the d action chain [16 S][kMaxA]
+  float* dw_parts;                    // B > 512: the weight-gradient tiles' slice partials (DwArgs)
   float *xmean, *xls, *xeps, *xlp;    // the actor step's sample (mean, log_std, eps [16 S][kMaxA], logp [16 S]): P1's critic-chain workgroup
                                       // computes it while it waits for y, P3 starts from it
   __host__ __device__ static size_t carve(SacWs* w, void* base, int B, int D, int A, int H) {
@@ -71,7 +73,11 @@ struct SacWs {
     unsigned int* sy = reinterpret_cast<unsigned int*>(take(16));
     float* xa = take(S16 * 4); float* xq0 = take(S16); float* xq1 = take(S16); float* xpart = take(S16 * 4);
     float* xm = take(S16 * 4); float* xl = take(S16 * 4); float* xe = take(S16 * 4); float* xp = take(S16);
+    // weight-gradient tiles beyond 512 rows: at most 16 slices of 320 floats per tile, tiles of the larger (critic) group
+    const size_t dw_tiles = B > 512 ? 2 * ((size_t)((H + 15) / 16) * ((D + A + 15) / 16) + (size_t)((H + 15) / 16) * ((H + 15) / 16) + (size_t)((H + 15) / 16)) : 0;
+    float* dwp = take(dw_tiles * kDwMaxSlices * 320);
     if (w) {
+      w->dw_parts = dwp;
       w->terms2 = terms2; w->xtq[0] = tq0; w->xtq[1] = tq1; w->xmisc = xmi; w->flag = fl; w->sync = sy; w->xa = xa; w->xq[0] = xq0; w->xq[1] = xq1; w->xpart = xpart;
       w->xmean = xm; w->xls = xl; w->xeps = xe; w->xlp = xp;
       w->s = s; w->a = a;
@@ -760,10 +766,13 @@ struct DwSeg {
   float* W; float* b; float* Wt; float* bt;       // parameters and (critic) their target twins
   float* img_f; float* img_b; float* img_tf;      // weight images to keep in step (square layers; nullptr: none)
   int ldz, ldx, ldx2, N, K, K1, wave0;            // wave0: first global wave of this segment
+  int slices, tile0;                              // waves per tile (lin_device.hpp bwd_weight_slices: 1 up to 512 rows) and the segment's first tile
 };
 struct DwArgs {
   DwSeg seg[6];
   int nseg, total_waves, B;
+  float* parts; int phase, total_tiles;           // B > 512: [tile][slice][64 lanes][5] slice partials; phase 1 = this launch writes them (one wave per
+                                                  // tile and slice), phase 2 = it adds them and takes the tiles' optimiser steps (one wave per tile); 0: up to 512 rows, one launch
   float* p; float* m; float* v;                   // flat parameter buffer and its Adam moments
   float adam[4]; const float* adam_dev;
   float omb1, beta2, omb2, eps;
@@ -785,6 +794,7 @@ struct DwArgs {
 __device__ __forceinline__ void sac_dw_body(const DwArgs& a, const int block, const int nblocks, double (*sm)[4]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
   if (block == nblocks - 1) {
+    if (a.phase == 1) return;
     // ---- the loss sums in the stand-alone kernels' order (offpolicy.hip: one row per thread, block_partials per 256 rows — a
     // single block adds its partial to the zeroed destination itself, more blocks go through finalize_kernel's second level) ----
     __shared__ double part[3][kMaxBatch / 256];
@@ -845,14 +855,49 @@ __device__ __forceinline__ void sac_dw_body(const DwArgs& a, const int block, co
     return;
   }
   const int gw = block * (int)(blockDim.x >> 6) + wave;
-  if (gw >= a.total_waves) return;
+  if (gw >= (a.phase == 2 ? a.total_tiles : a.total_waves)) return;
   int si = 0;
 #pragma unroll
-  for (int k = 1; k < 6; ++k) if (k < a.nseg && gw >= a.seg[k].wave0) si = k;
+  for (int k = 1; k < 6; ++k) if (k < a.nseg && gw >= (a.phase == 2 ? a.seg[k].tile0 : a.seg[k].wave0)) si = k;
   const DwSeg& s = a.seg[si];
-  const int local = gw - s.wave0, ktiles = (s.K + 15) >> 4;
+  const int S = a.phase == 0 ? 1 : s.slices;
+  const int rel = gw - (a.phase == 2 ? s.tile0 : s.wave0);
+  const int local = a.phase == 1 ? rel / S : rel, slice = a.phase == 1 ? rel - local * S : 0, ktiles = (s.K + 15) >> 4;
   const int nt = local / ktiles, cg = local - nt * ktiles, kb = cg * 16;
   const int kc = kb + r;
+  // More than 512 rows: the tile's reduction is cut into lin.hip's slices (bwd_weight_slices).  Phase 1: ONE WAVE PER SLICE
+  // leaves its partial in the workspace (a lone wave walking 4096 rows was 118 us per launch); phase 2, the next launch: one
+  // wave per tile adds them in lin_slice_reduce_kernel's order and goes on with the tile's optimiser step.  (A single launch
+  // with a counter per tile — the last wave to arrive reduces — was built first and measured 2.4 x SLOWER: every agent-scope
+  // release / acquire writes back and invalidates an XCD's L2, and 13 000 waves did one each.)
+  f32x4 sl_acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  float sl_col = 0.0f;
+  if (a.phase == 1) {
+    const int rps = lin::bwd_weight_rows_per_slice(a.B, S), b0 = slice * rps, rows = a.B - b0 < rps ? a.B - b0 : rps;
+    f32x4 part = {0.0f, 0.0f, 0.0f, 0.0f};
+    float pc = 0.0f;
+    if (rows > 0)
+      part = lin::tile_bwd_weight(s.dZ + (size_t)b0 * s.ldz, s.ldz, s.N, nt, s.X + (size_t)b0 * s.ldx, s.ldx,
+                                  s.X2 ? s.X2 + (size_t)b0 * s.ldx2 : nullptr, s.ldx2, s.K, s.K1, kb, rows, lane, pc);
+    float* mine = a.parts + ((size_t)(s.tile0 + local) * kDwMaxSlices + slice) * 320;   // (segments differ in S: a fixed pitch per tile)
+    *reinterpret_cast<f32x4*>(mine + 4 * lane) = part;
+    mine[256 + lane] = pc;
+    return;
+  }
+  if (a.phase == 2) {
+    const int each = (S + 7) / 8;
+    for (int g = 0; g < 8; ++g) {
+      f32x4 gs = {0.0f, 0.0f, 0.0f, 0.0f};
+      float gc = 0.0f;
+      for (int k = g * each; k < (g + 1) * each && k < S; ++k) {
+        const float* src = a.parts + ((size_t)(s.tile0 + local) * kDwMaxSlices + k) * 320;
+        gs += *reinterpret_cast<const f32x4*>(src + 4 * lane);
+        gc += src[256 + lane];
+      }
+      if (g == 0) { sl_acc = gs; sl_col = gc; }
+      else { sl_acc += gs; sl_col += gc; }
+    }
+  }
   // the optimiser's state of this tile (parameter, both moments, the target twin) is requested BEFORE the gradient's own
   // loads and MFMA chain: behind them it was a second memory round trip per tile
   lin::AdamScalars ad;
@@ -871,8 +916,8 @@ __device__ __forceinline__ void sac_dw_body(const DwArgs& a, const int block, co
       if (s.Wt) Tv[g] = s.Wt[o];
     }
   }
-  float colsum;
-  const f32x4 acc = lin::tile_bwd_weight_sliced(s.dZ, s.ldz, s.N, nt, s.X, s.ldx, s.X2, s.ldx2, s.K, s.K1, kb, a.B, lane, colsum);
+  float colsum = sl_col;
+  const f32x4 acc = a.phase == 2 ? sl_acc : lin::tile_bwd_weight(s.dZ, s.ldz, s.N, nt, s.X, s.ldx, s.X2, s.ldx2, s.K, s.K1, kb, a.B, lane, colsum);
   if (a.store_grads && a.split_heads && si == 0) {
     // d mu = dW, d sigma = dW * eps, per NoisyLinear layer: rows 0 .. A-1 the advantage stream, row A the value stream
     if (kc < s.K) {
@@ -937,6 +982,14 @@ __device__ __forceinline__ void sac_dw_body(const DwArgs& a, const int block, co
 __global__ __launch_bounds__(256) void sac_dw_kernel(const DwArgs a) {
   __shared__ double sm[3][4];
   sac_dw_body(a, blockIdx.x, gridDim.x, sm);
+}
+// one launch up to 512 rows; beyond: the slice partials, then their ordered sums + the tiles' epilogues + the loss sums
+static void launch_dw(DwArgs d, hipStream_t stream) {
+  hipLaunchKernelGGL(sac_dw_kernel, dim3((d.total_waves + 3) / 4 + 1), dim3(256), 0, stream, d);
+  if (d.phase == 1) {
+    d.phase = 2;
+    hipLaunchKernelGGL(sac_dw_kernel, dim3((d.total_tiles + 3) / 4 + 1), dim3(256), 0, stream, d);
+  }
 }
 
 // ==================================================================================================== acting =====
@@ -1094,6 +1147,7 @@ struct RbWs {
   double* terms;                             // [B][3] (column 0: w * td^2)
   float* xz;                                 // [2][16 S][4]: head outputs of policy(s') and target(s') on their way to the policy(s) workgroup
   unsigned int* flag;                        // [2][S]: their hand-off flags (zero before the first launch, left zero)
+  float* dw_parts;                           // B > 512: the weight-gradient tiles' slice partials (DwArgs)
   __host__ __device__ static size_t carve(RbWs* w, void* base, int B, int D, int A, int H) {
     size_t off = 0;
     auto take = [&](size_t n) { float* p = base ? reinterpret_cast<float*>(static_cast<char*>(base) + off) : nullptr; off += ((n * 4 + 255) & ~(size_t)255); return p; };
@@ -1103,7 +1157,10 @@ struct RbWs {
     const size_t S16 = (size_t)(B + 15) / 16 * 16;
     float* xz = take(2 * S16 * 4);
     unsigned int* fl = reinterpret_cast<unsigned int*>(take(2 * S16 / 16));
-    if (w) { w->s = s_; w->h1 = h1; w->h2 = h2; w->dS = dS; w->dZ2 = z2; w->dZ1 = z1; w->terms = terms; w->xz = xz; w->flag = fl; }
+    const size_t dw_tiles = B > 512 ? (size_t)((A + 1 + 15) / 16) * ((H + 15) / 16) + (size_t)((H + 15) / 16) * ((H + 15) / 16) + (size_t)((H + 15) / 16) * ((D + 15) / 16) : 0;
+    float* dwp = take(dw_tiles * kDwMaxSlices * 320);
+    if (w) { w->s = s_; w->h1 = h1; w->h2 = h2; w->dS = dS; w->dZ2 = z2; w->dZ1 = z1; w->terms = terms; w->xz = xz; w->flag = fl;
+             w->dw_parts = dwp; }
     return off;
   }
 };
@@ -1460,18 +1517,20 @@ int gymrl_rainbow_update(const gymrl_rainbow_update_args* args, int phase, void*
   if (phase != 2) hipLaunchKernelGGL(H == 256 ? rainbow_rows_kernel<256> : rainbow_rows_kernel<0>, slab_launch_grid((B + 15) / 16, 3), dim3(kThreads), lds_bytes(H, 7), stream, a, ws);
   if (phase == 1) { GYMRL_CHECK_LAUNCH(); return 0; }
   DwArgs d{};
-  int w0 = 0, ns = 0;
+  int w0 = 0, ns = 0, t0 = 0;
   auto seg = [&](const float* dZ, int ldz, int N, const float* X, int ldx, int K, float* gW, float* gb) {
     DwSeg& s = d.seg[ns++];
     s.dZ = dZ; s.X = X; s.X2 = nullptr; s.W = gW; s.b = gb; s.Wt = nullptr; s.bt = nullptr;
     s.img_f = nullptr; s.img_b = nullptr; s.img_tf = nullptr;
     s.ldz = ldz; s.ldx = ldx; s.ldx2 = 0; s.N = N; s.K = K; s.K1 = K; s.wave0 = w0;
-    w0 += ((N + 15) / 16) * ((K + 15) / 16);
+    const int tl = ((N + 15) / 16) * ((K + 15) / 16);
+    s.slices = lin::bwd_weight_slices(B, N, K); s.tile0 = t0;
+    w0 += tl * s.slices; t0 += tl;
   };
   seg(ws.dS, A1, A1, ws.h2, H, H, a.d_head_w, a.d_head_b);       // the stacked noisy heads (gymrl_noisy_split takes it from here)
   seg(ws.dZ2, H, H, ws.h1, H, H, a.d_fc2_w, a.d_fc2_b);
   seg(ws.dZ1, H, H, ws.s, D, D, a.d_fc1_w, a.d_fc1_b);
-  d.nseg = ns; d.total_waves = w0; d.B = B; d.store_grads = 1;
+  d.nseg = ns; d.total_waves = w0; d.total_tiles = t0; d.B = B; d.store_grads = 1; d.parts = ws.dw_parts; d.phase = B > 512 ? 1 : 0;
   d.split_heads = a.split_heads ? 1 : 0; d.split_A = a.A;
   for (int l = 0; l < 2; ++l) {
     d.dw_mu[l] = a.dw_mu[l]; d.dw_sigma[l] = a.dw_sigma[l]; d.db_mu[l] = a.db_mu[l]; d.db_sigma[l] = a.db_sigma[l];
@@ -1479,7 +1538,7 @@ int gymrl_rainbow_update(const gymrl_rainbow_update_args* args, int phase, void*
     if (a.split_heads && (!a.dw_mu[l] || !a.dw_sigma[l] || !a.db_mu[l] || !a.db_sigma[l] || !a.w_eps[l] || !a.b_eps[l])) return -22;
   }
   d.terms = ws.terms; d.term0 = 0; d.nterms = 1; d.sums = a.loss_sum; d.alpha_step = 0;
-  hipLaunchKernelGGL(sac_dw_kernel, dim3((w0 + 3) / 4 + 1), dim3(256), 0, stream, d);
+  launch_dw(d, stream);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
@@ -1520,7 +1579,7 @@ static int sac_set_lds_attr() {
 static void sac_build_dw(const gymrl_sac_update_args& a, const SacWs& ws, DwArgs& c, DwArgs& p) {
   const int B = a.B, D = a.D, A = a.A, H = a.H;
   auto tiles = [](int N, int K) { return ((N + 15) / 16) * ((K + 15) / 16); };
-  int w0 = 0, ns = 0;
+  int w0 = 0, ns = 0, t0 = 0;
   const bool use_img = a.images && (a.H & 15) == 0;
   const size_t hh = (size_t)a.H * a.H;
   auto img = [&](int k) { return use_img ? a.images + k * hh : nullptr; };
@@ -1530,7 +1589,8 @@ static void sac_build_dw(const gymrl_sac_update_args& a, const SacWs& ws, DwArgs
     s.dZ = dZ; s.X = X; s.X2 = X2; s.W = W; s.b = b; s.Wt = Wt; s.bt = bt;
     s.img_f = img_f; s.img_b = img_b; s.img_tf = img_tf;
     s.ldz = ldz; s.ldx = ldx; s.ldx2 = ldx2; s.N = N; s.K = K; s.K1 = K1; s.wave0 = w0;
-    w0 += tiles(N, K);
+    s.slices = lin::bwd_weight_slices(B, N, K); s.tile0 = t0;
+    w0 += tiles(N, K) * s.slices; t0 += tiles(N, K);
   };
   // critic: launch order of the layer-by-layer backward is irrelevant here (tiles are independent); fc1/fc4, fc2/fc5, fc3/fc6
   c = DwArgs{};
@@ -1540,7 +1600,7 @@ static void sac_build_dw(const gymrl_sac_update_args& a, const SacWs& ws, DwArgs
         img(1 + i), img(6 + i), img(3 + i));
     seg(c, ws.dq[i], 1, 1, ws.H2[i], H, nullptr, 0, H, H, a.critic.w[3 * i + 2], a.critic.b[3 * i + 2], a.target.w[3 * i + 2], a.target.b[3 * i + 2]);
   }
-  c.nseg = ns; c.total_waves = w0; c.B = B;
+  c.nseg = ns; c.total_waves = w0; c.total_tiles = t0; c.B = B; c.parts = ws.dw_parts; c.phase = B > 512 ? 1 : 0;
   c.p = a.critic_p; c.m = a.critic_m; c.v = a.critic_v;
   for (int k = 0; k < 4; ++k) c.adam[k] = a.adam_critic[k];
   c.adam_dev = a.adam_critic_dev;
@@ -1549,12 +1609,12 @@ static void sac_build_dw(const gymrl_sac_update_args& a, const SacWs& ws, DwArgs
   c.terms = ws.terms; c.terms_b = ws.terms2; c.term0 = 0; c.nterms = 1; c.sums = a.sums; c.alpha_step = 0;
 
   p = DwArgs{};
-  w0 = 0; ns = 0;
+  w0 = 0; ns = 0; t0 = 0;
   seg(p, ws.aZ1, H, H, ws.s, D, nullptr, 0, D, D, a.actor.w[0], a.actor.b[0], nullptr, nullptr);
   seg(p, ws.aZ2, H, H, ws.aH1, H, nullptr, 0, H, H, a.actor.w[1], a.actor.b[1], nullptr, nullptr, img(0), img(5), nullptr);
   seg(p, ws.dmean, A, A, ws.aH2, H, nullptr, 0, H, H, a.actor.w[2], a.actor.b[2], nullptr, nullptr);
   seg(p, ws.dls, A, A, ws.aH2, H, nullptr, 0, H, H, a.actor.w[3], a.actor.b[3], nullptr, nullptr);
-  p.nseg = ns; p.total_waves = w0; p.B = B;
+  p.nseg = ns; p.total_waves = w0; p.total_tiles = t0; p.B = B; p.parts = ws.dw_parts; p.phase = B > 512 ? 1 : 0;
   p.p = a.actor_p; p.m = a.actor_m; p.v = a.actor_v;
   for (int k = 0; k < 4; ++k) p.adam[k] = a.adam_actor[k];
   p.adam_dev = a.adam_actor_dev;
@@ -1580,9 +1640,9 @@ int gymrl_sac_update(const gymrl_sac_update_args* args, void* stream_) {
   sac_build_dw(a, ws, c, p);
   // (the instances built for the reference's hidden width 256 know every reduction length at compile time)
   hipLaunchKernelGGL(H == 256 ? sac_p1_kernel<256> : sac_p1_kernel<0>, slab_launch_grid(slabs, 4), dim3(kThreads), lds_bytes(H, 8), stream, a, ws);   // y / role: the two target chains, the two critic chains
-  hipLaunchKernelGGL(sac_dw_kernel, dim3((c.total_waves + 3) / 4 + 1), dim3(256), 0, stream, c);
+  launch_dw(c, stream);
   hipLaunchKernelGGL(H == 256 ? sac_p3_kernel<256> : sac_p3_kernel<0>, slab_launch_grid(slabs, 2), dim3(kThreads), lds_bytes(H, 8), stream, a, ws);   // y / role: the actor + Q2, then Q1
-  hipLaunchKernelGGL(sac_dw_kernel, dim3((p.total_waves + 3) / 4 + 1), dim3(256), 0, stream, p);
+  launch_dw(p, stream);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }
