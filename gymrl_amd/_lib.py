@@ -31,7 +31,7 @@ SYMBOLS = [
     "gymrl_ppo_loss_fwd_bwd", "gymrl_ppo_full_loss_fwd_bwd", "gymrl_ppo_rnn_loss_fwd_bwd",
     "gymrl_gru_cell_fwd", "gymrl_gru_cell_bwd", "gymrl_rnd_reward", "gymrl_permutation",
     "gymrl_pack_rollout", "gymrl_gather_minibatch", "gymrl_gather_rows", "gymrl_loss_blocks", "gymrl_reduce_rows",
-    "gymrl_sqnorm", "gymrl_adam_step", "gymrl_adam_bias", "gymrl_store_scalars", "gymrl_soft_update",
+    "gymrl_sqnorm", "gymrl_adam_step", "gymrl_clip_adam_step", "gymrl_adam_bias", "gymrl_store_scalars", "gymrl_soft_update",
     "gymrl_replay_append", "gymrl_replay_gather", "gymrl_uniform_indices", "gymrl_nstep_push",
     "gymrl_per_workspace_bytes", "gymrl_per_update", "gymrl_per_max_leaf", "gymrl_per_priorities", "gymrl_per_update_td",
     "gymrl_per_sample", "gymrl_noisy_noise", "gymrl_epsilon_greedy", "gymrl_dqn_td_loss",

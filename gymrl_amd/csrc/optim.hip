@@ -103,9 +103,28 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ p, flo
                                                       const float* __restrict__ lr_dev,
                                                       const float* __restrict__ bias_dev,
                                                       const double* __restrict__ sqnorm,
-                                                      float* __restrict__ polyak, float tau, float omt) {
+                                                      float* __restrict__ polyak, float tau, float omt,
+                                                      const double* __restrict__ partials, int nparts,
+                                                      double* __restrict__ sqnorm_out) {
   if (bias_dev) {          // graph replay: the step-dependent scalars live in device memory
     a.step_size_host = bias_dev[0]; a.inv_bc1 = bias_dev[1]; a.bc2_sqrt = bias_dev[2];
+  }
+  // gymrl_clip_adam_step: the squared norm's second level here instead of in a launch of its own — every workgroup folds
+  // sqnorm_partial_kernel's block partials exactly as sqnorm_final_kernel does (the same bits in every workgroup)
+  __shared__ double fold[kBlock];
+  double folded = 0.0;
+  if (partials) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += kBlock) acc += partials[i];
+    fold[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) fold[threadIdx.x] += fold[threadIdx.x + s];
+      __syncthreads();
+    }
+    folded = fold[0];
+    if (sqnorm_out && blockIdx.x == 0 && threadIdx.x == 0) sqnorm_out[0] = folded;
+    sqnorm = &folded;
   }
   float scale = 1.0f;
   if (a.max_grad_norm > 0.0f && sqnorm) {
@@ -242,7 +261,38 @@ int gymrl_adam_step(float* p, float* g, float* m, float* v, int64_t n, double lr
   a.grad_scale = grad_scale; a.max_grad_norm = max_grad_norm; a.clamp_abs = clamp_abs;
   a.zero_grad = zero_grad;
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4)), dim3(kBlock), 0, (hipStream_t)stream_, p, g,
-                     m, v, n, a, lr_dev, bias_dev, sqnorm, polyak_target, (float)tau, (float)(1.0 - tau));
+                     m, v, n, a, lr_dev, bias_dev, sqnorm, polyak_target, (float)tau, (float)(1.0 - tau),
+                     (const double*)nullptr, 0, (double*)nullptr);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// clip_grad_norm_ + Adam as TWO launches instead of three: gymrl_sqnorm's first level, then gymrl_adam_step's kernel with the
+// norm's second level folded in (above).  Same sums in the same order: the same bits.
+int gymrl_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, double lr_host, const float* lr_dev, double beta1,
+                         double beta2, double eps, int64_t step, const float* bias_dev, float grad_scale, float max_grad_norm,
+                         double* sqnorm_out, float clamp_abs, int zero_grad, float* polyak_target, double tau, void* workspace,
+                         void* stream_) {
+  if (!p || !g || !m || !v || !workspace || n < 0 || (step < 1 && !bias_dev) || (polyak_target && !aligned16(polyak_target)) ||
+      !aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v) || !(max_grad_norm > 0.0f))
+    return -22;
+  if (bias_dev) step = 1;
+  if (n == 0) return 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  AdamArgs a;
+  const double bc1 = 1.0 - __builtin_pow(beta1, (double)step);
+  const double bc2 = 1.0 - __builtin_pow(beta2, (double)step);
+  a.step_size_host = (float)(lr_host / bc1);
+  a.inv_bc1 = (float)(1.0 / bc1);
+  a.bc2_sqrt = (float)__builtin_sqrt(bc2);
+  a.omb1 = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.omb2 = (float)(1.0 - beta2);
+  a.eps = (float)eps;
+  a.grad_scale = grad_scale; a.max_grad_norm = max_grad_norm; a.clamp_abs = clamp_abs;
+  a.zero_grad = zero_grad;
+  const int nb = grid_for(n, 16);
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nb), dim3(kBlock), 0, stream, g, n, grad_scale, (double*)workspace);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4)), dim3(kBlock), 0, stream, p, g, m, v, n, a, lr_dev, bias_dev,
+                     (const double*)nullptr, polyak_target, (float)tau, (float)(1.0 - tau), (const double*)workspace, nb, sqnorm_out);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

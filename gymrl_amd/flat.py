@@ -124,8 +124,12 @@ class FusedAdam:
         g = self.param_groups[0]
         if bias_dev is None:
             self.step_count += 1
-        if self.max_grad_norm > 0:
-            ops.sqnorm(self.g, self._sq, self._ws, grad_scale)
+        if self.max_grad_norm > 0:      # the norm's second level inside the Adam launch: two launches, not three
+            ops.clip_adam_step(self.p, self.g, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                               max(self.step_count, 1), self.max_grad_norm, self._ws, grad_scale=grad_scale, sqnorm_out=self._sq,
+                               clamp_abs=self.clamp_abs, zero_grad=True, bias_dev=bias_dev,
+                               polyak_target=None if polyak is None else polyak[0], tau=0.0 if polyak is None else polyak[1])
+            return
         ops.adam_step(self.p, self.g, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                       max(self.step_count, 1), grad_scale=grad_scale, max_grad_norm=self.max_grad_norm,
                       sqnorm_buf=self._sq, clamp_abs=self.clamp_abs, zero_grad=True, bias_dev=bias_dev,

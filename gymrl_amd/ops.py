@@ -312,6 +312,17 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, max_grad_
                                 C.c_double(tau), _stream()), "gymrl_adam_step")
 
 
+def clip_adam_step(p, g, m, v, lr, beta1, beta2, eps, step, max_grad_norm, workspace, grad_scale=1.0, sqnorm_out=None,
+                   clamp_abs=0.0, zero_grad=True, lr_dev=None, bias_dev=None, polyak_target=None, tau=0.0):
+    """gymrl_clip_adam_step: sqnorm() + adam_step() as two launches instead of three (same bits)."""
+    check(lib().gymrl_clip_adam_step(_ptr(p, torch.float32), _ptr(g, torch.float32), _ptr(m, torch.float32), _ptr(v, torch.float32),
+                                     C.c_int64(p.numel()), C.c_double(lr), _ptr(lr_dev, torch.float32, True), C.c_double(beta1),
+                                     C.c_double(beta2), C.c_double(eps), C.c_int64(step), _ptr(bias_dev, torch.float32, True),
+                                     C.c_float(grad_scale), C.c_float(max_grad_norm), _ptr(sqnorm_out, torch.float64, True),
+                                     C.c_float(clamp_abs), C.c_int(int(zero_grad)), _ptr(polyak_target, torch.float32, True),
+                                     C.c_double(tau), _ptr(workspace), _stream()), "gymrl_clip_adam_step")
+
+
 def adam_bias(lr, beta1, beta2, step):
     """Host arithmetic of Adam's step-dependent scalars -> 4 float32 (gymrl_adam_bias)."""
     out = (C.c_float * 4)()

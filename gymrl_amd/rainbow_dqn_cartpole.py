@@ -538,11 +538,16 @@ class RainbowDQNTrainer:
             self._tree_keep = (td, batch_index)       # read on the side stream: alive until the next join
 
     @torch.no_grad()
-    def _noisy_heads3(self):
+    def _noisy_heads3(self, with_acting=False):
         """The stacked effective head parameters of the update's three passes — policy on s' (first draw :320), target on s'
         (means), policy on s (second draw :334) — built by ONE gymrl_noisy_combine launch, both draws made inside it in the
-        eager order.  -> (W [3 (A + 1), H], b [3 (A + 1)], the second draw's epsilons for the backward)."""
+        eager order.  -> (W [3 (A + 1), H], b [3 (A + 1)], the second draw's epsilons for the backward).  with_acting: the
+        vector step's acting forward (its own draw, made FIRST: the eager order) rides in the same launch, its rows in front."""
         p, t = self.policy_net, self.target_net
+        acting = []
+        if with_acting:       # (no *_copy: the module's epsilon buffers end the step holding the second draw, as in the eager order)
+            acting = [self._noisy_fields(m, **{k: v for k, v in m.noise_source()[0].items() if not k.endswith("_copy")})
+                      for m in (p.advantage, p.value)]
         first = []
         for m in (p.advantage, p.value):
             f = {k: v for k, v in m.noise_source()[0].items() if not k.endswith("_copy")}   # not needed after the launch
@@ -555,16 +560,16 @@ class RainbowDQNTrainer:
             f, saved = m.noise_source()
             second.append(self._noisy_fields(m, **f))
             eps += list(saved)
-        W, b = ops.noisy_combine(first + target + second, training=True)
+        W, b = ops.noisy_combine(acting + first + target + second, training=True)
         return W, b, eps
 
     @torch.no_grad()
-    def _update_body_fused(self, batch_index, is_weight, bias=None, join=True):
+    def _update_body_fused(self, batch_index, is_weight, bias=None, join=True, heads=None):
         """_update_body with everything between the proportional draw and the optimiser step as gymrl_rainbow_update's two
         launches (+ the two NoisyLinear launches that own the noise bookkeeping): same values, same destinations."""
         cfg, p = self.cfg, self.policy_net
         f = self._fused_state()
-        W, b, eps = self._noisy_heads3()
+        W, b, eps = self._noisy_heads3() if heads is None else heads
         td = torch.empty(cfg.batch_size, device=self.device)
         # the stacked head's gradient is split into d mu / d sigma of the two NoisyLinear layers by the weight-gradient launch
         split = [(m.weight_mu.grad, m.weight_sigma.grad, m.bias_mu.grad, m.bias_sigma.grad, eps[2 * i], eps[2 * i + 1])
@@ -720,21 +725,24 @@ class RainbowDQNTrainer:
         lb["tracker"].k, lb["tracker"].episodes = 0, 0
         return lb
 
-    def _vector_step(self, lb, obs, nxt, ep_ret, done, rec=None, chain=False):
+    def _vector_step(self, lb, obs, nxt, ep_ret, done, rec=None, chain=False, act_heads=None):
         """One vector step of :363-405 up to (not including) the update.  rec: this step's StepChunk record views
         when the step is being captured (every per-step scalar then comes from the device)."""
         env, m = self.env, self.memory
         push = None if rec is None else rec["push"]
         m.stage_tree(self._side, dev=push, chain=chain)   # this step's new priorities, beside the acting forward + env step
-        if rec is not None:
+        if rec is not None and act_heads is None:
             for layer, c in ((self.policy_net.advantage, rec["noise"][0:8]), (self.policy_net.value, rec["noise"][8:16])):
                 layer.dev_counters = iter([c])
         if self._fused_act_ok():
             # greedy acting on the noisy Q (:371), env.step, `terminal` (:376) and the n-step push as ONE launch behind the
             # launch that builds the heads' effective parameters (this forward's NoisyNet draw is made inside it)
             p = self.policy_net
-            layers = [self._noisy_fields(mod, **mod.noise_source()[0]) for mod in (p.advantage, p.value)]
-            W, b = ops.noisy_combine(layers, training=True)
+            if act_heads is None:
+                layers = [self._noisy_fields(mod, **mod.noise_source()[0]) for mod in (p.advantage, p.value)]
+                W, b = ops.noisy_combine(layers, training=True)
+            else:
+                W, b = act_heads
             if rec is None:
                 self.total_steps += env.n                 # select_action's count (:301)
             emitted = ops.rainbow_act_step(self._fused_state()["act"], env, obs, nxt, W, b, pushes=m.pushes, cursor=m.count,
@@ -765,14 +773,27 @@ class RainbowDQNTrainer:
             # load_checkpoint) may have changed the leaves without this graph knowing — its first store always recomputes
             # priority_max (one per_max_leaf launch per 16 vector steps); steps 1.. follow the chunk's own update_td
             self.memory.sum_tree._max_fresh = False
-        self._vector_step(lb, obs, nxt, tr.ret[j], tr.done[j], rec, chain=j > 0 and OVERLAP_TREE)
-        self.memory.draw(0, 1, out=self._g_draw, dev=ch.view(j, "sample"))
         noise = ch.view(j, "noise")
         layers = (self.policy_net.advantage, self.policy_net.value)
-        for i, layer in enumerate(layers):             # the eager order: (advantage, value) per training-mode forward
-            layer.dev_counters = iter([noise[16 + 8 * i:24 + 8 * i], noise[32 + 8 * i:40 + 8 * i]])
-        self._update_body(self._g_draw[0], self._g_draw[2], bias=ch.view(j, "adam", torch.float32),
-                          join=j == ch.K - 1 or not OVERLAP_TREE)
+        if self._fused_act_ok() and self._fused_update_ok():
+            # ONE NoisyLinear launch per vector step: the parameters do not change between the acting forward and the update's
+            # three passes, so the acting heads (draw 1) and the update's (draws 2 and 3, the target's means) are built together —
+            # eight layer entries, the draws in the eager order — and a launch leaves the chain adam -> heads -> acting
+            for i, layer in enumerate(layers):
+                layer.dev_counters = iter([noise[8 * i:8 + 8 * i], noise[16 + 8 * i:24 + 8 * i], noise[32 + 8 * i:40 + 8 * i]])
+            W, b, eps = self._noisy_heads3(with_acting=True)
+            A1 = self.policy_net.advantage.out_features + 1
+            self._vector_step(lb, obs, nxt, tr.ret[j], tr.done[j], rec, chain=j > 0 and OVERLAP_TREE, act_heads=(W[:A1], b[:A1]))
+            self.memory.draw(0, 1, out=self._g_draw, dev=ch.view(j, "sample"))
+            self._update_body_fused(self._g_draw[0], self._g_draw[2], bias=ch.view(j, "adam", torch.float32),
+                                    join=j == ch.K - 1 or not OVERLAP_TREE, heads=(W[A1:], b[A1:], eps))
+        else:
+            self._vector_step(lb, obs, nxt, tr.ret[j], tr.done[j], rec, chain=j > 0 and OVERLAP_TREE)
+            self.memory.draw(0, 1, out=self._g_draw, dev=ch.view(j, "sample"))
+            for i, layer in enumerate(layers):             # the eager order: (advantage, value) per training-mode forward
+                layer.dev_counters = iter([noise[16 + 8 * i:24 + 8 * i], noise[32 + 8 * i:40 + 8 * i]])
+            self._update_body(self._g_draw[0], self._g_draw[2], bias=ch.view(j, "adam", torch.float32),
+                              join=j == ch.K - 1 or not OVERLAP_TREE)
         for layer in layers:
             layer.dev_counters = None
 

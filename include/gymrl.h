@@ -368,6 +368,16 @@ int gymrl_adam_step(float* p, float* g, float* m, float* v, int64_t n,
                     double eps, int64_t step, const float* bias_dev, float grad_scale,
                     float max_grad_norm, const double* sqnorm, float clamp_abs, int zero_grad,
                     float* polyak_target, double tau, void* stream);
+/*
+ * clip_grad_norm_ + Adam as TWO launches instead of gymrl_sqnorm's two + gymrl_adam_step's one: the squared norm's first level,
+ * then the Adam kernel, every workgroup of which folds the block partials itself exactly as gymrl_sqnorm's second launch does.
+ * Same sums in the same order, same bits (tests/test_hip_parity.py).  max_grad_norm > 0; sqnorm_out f64[1] or NULL (the squared
+ * norm, for logging); workspace: gymrl_reduce_workspace_bytes().  Other arguments as gymrl_adam_step.
+ */
+int gymrl_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, double lr_host, const float* lr_dev, double beta1,
+                         double beta2, double eps, int64_t step, const float* bias_dev, float grad_scale, float max_grad_norm,
+                         double* sqnorm_out, float clamp_abs, int zero_grad, float* polyak_target, double tau, void* workspace,
+                         void* stream);
 
 int gymrl_adam_bias(double lr, double beta1, double beta2, int64_t step, float* out_host4);
 int gymrl_store_scalars(void* dst_dev, const void* src_host, int nbytes, void* stream);

@@ -664,3 +664,36 @@ def test_gather_rows_is_index_select(dev, B, D):
     out = ops.gather_rows(src_d, idx_d)
     ref = src_d.index_select(0, idx_d.long())
     assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,norm", [(200965, 0.5), (68103, 10.0), (5, 0.5), (1 << 21, 1e9)])
+def test_clip_adam_two_launches_equal_three(dev, n, norm):
+    """gymrl_clip_adam_step (the squared norm's first level, then Adam with the second level folded into every workgroup:
+    FusedAdam's default) against gymrl_sqnorm's two launches + gymrl_adam_step: parameters, both moments, the zeroed gradient,
+    the Polyak target and the norm itself bit for bit over five steps; PPO's and Rainbow's parameter counts, a buffer shorter
+    than a float4, more first-level blocks than one fold round, a norm that never clips."""
+    from gymrl_amd import ops
+    outs = []
+    for one in (False, True):
+        g = torch.Generator(device=dev).manual_seed(n)
+        pad = (n + 63) // 64 * 64
+        p, m, v, tgt = (torch.randn(pad, device=dev, generator=g)[:n] for _ in range(4))
+        m.mul_(0.01); v.abs_().mul_(0.01)
+        ws, sq = ops.reduce_workspace(dev), torch.zeros(1, dtype=torch.float64, device=dev)
+        norms = []
+        for step in range(1, 6):
+            grad = torch.randn(pad, device=dev, generator=g)[:n] * (3.0 if step % 2 else 0.01)
+            if one:
+                ops.clip_adam_step(p, grad, m, v, 3e-4, 0.9, 0.999, 1e-8, step, norm, ws, grad_scale=0.5, sqnorm_out=sq,
+                                   polyak_target=tgt, tau=0.005)
+            else:
+                ops.sqnorm(grad, sq, ws, 0.5)
+                ops.adam_step(p, grad, m, v, 3e-4, 0.9, 0.999, 1e-8, step, grad_scale=0.5, max_grad_norm=norm, sqnorm_buf=sq,
+                              polyak_target=tgt, tau=0.005)
+            norms.append(float(sq.item()))
+            assert float(grad.abs().max()) == 0.0          # zero_grad
+        outs.append((p.clone(), m.clone(), v.clone(), tgt.clone(), norms))
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(a, b)
+    assert outs[0][4] == outs[1][4]
