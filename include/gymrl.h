@@ -1079,8 +1079,10 @@ int gymrl_reward_scaling(const float* r, const uint8_t* done, int N, double gamm
  *                        draw, P3's loads).  The blocks that can wait are fewer than the compute units, so the blocks they wait
  *                        for always get one; the last block to finish zeroes the counters.  Same arguments, same results.
  * Results are those of the layer-by-layer path bit for bit (same products, same orders; tests/test_fused_step_gpu.py), which
- * tests/test_trainers_gpu.py pins against the reference.  Limits: H % 4 == 0, H <= 256, D <= 8, A <= 4, B <= 256
- * (-22 otherwise: use the layer-by-layer path).  Pointers are device pointers; W = [out][in] row-major (nn.Linear).
+ * tests/test_trainers_gpu.py pins against the reference.  Limits: H % 4 == 0, H <= 256, D <= 8, A <= 4, B <= 8192
+ * (gymrl_sac_step: B <= 256; -22 otherwise: use the layer-by-layer path).  Above 256 rows the row kernels run on 1-D grids with a
+ * slab's workgroups adjacent in dispatch order, above 512 the weight gradients are two launches (slice partials in
+ * gymrl_lin_bwd_weight's cut, then their ordered sums + the optimiser step): still the layer path's bits.  Pointers are device pointers; W = [out][in] row-major (nn.Linear).
  */
 typedef struct { float* w[4]; float* b[4]; } gymrl_sac_actor_params;     /* fc1, fc2, mean, log_std (sac_pendulum.py:58-61) */
 typedef struct { float* w[6]; float* b[6]; } gymrl_sac_critic_params;    /* fc1..fc6: fc1-3 = Q1, fc4-6 = Q2 (:108-113) */
@@ -1151,7 +1153,7 @@ int gymrl_sac_step(const gymrl_sac_act_args* act, const gymrl_sac_update_args* u
  *                              gymrl_noisy_split), fc2 and fc1 written where the caller says (the flat gradient buffer's views:
  *                              clip_grad_norm_ needs every gradient before Adam), loss sum
  * Bit-identical to the layer-by-layer path (same tile bodies, same scalar expressions).  Limits: H % 4 == 0, H <= 256, D <= 8,
- * A <= 3, B <= 256; CartPole-v1 for the act step.
+ * A <= 3, B <= 8192 (above 256 / 512 rows: as gymrl_sac_update); CartPole-v1 for the act step.
  */
 typedef struct {
   int N, D, A, H;
