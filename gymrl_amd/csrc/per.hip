@@ -17,6 +17,7 @@
 // addition per ancestor (per_store_device.hpp; identical to the reference at N = 1): per_store_* below.
 // Sampling is a pointer chase (ceil(log2 cap)+1 dependent f64 loads per draw):
 // latency-bound, one lane per draw, upper tree levels stay L2-resident.
+#include <rocprim/block/block_radix_sort.hpp>
 #include "gymrl_device.hpp"
 #include "per_store_device.hpp"
 #include "../../include/gymrl.h"
@@ -451,46 +452,51 @@ __global__ __launch_bounds__(1024) void per_store_ancestor_kernel(double* __rest
 }
 
 // ---- large unordered batches (512 < B <= kLdsB with explicit indices) -------------------------------
-// The searches above are O(B^2 / threads): 6.7 ms per call at B = 8192.  Sorting the batch by
-// (leaf or ancestor id, batch index) makes every node's elements one contiguous run that is already in
-// batch order, so "latest earlier element on the same leaf", "last writer" and the ordered per-node sums
-// become neighbour tests and run walks.  Bitonic sort of 64-bit keys (id << 13 | index) in LDS.
+// The searches above are O(B^2 / threads): 6.7 ms per call at B = 8192.  Ordering the batch by (leaf or ancestor id, batch
+// index) makes every node's elements one contiguous run that is already in batch order, so "latest earlier element on the
+// same leaf", "last writer" and the ordered per-node sums become neighbour tests and run walks.  The order comes from a
+// STABLE block radix sort by the id alone (rocPRIM's block_radix_sort: the batch index is the value, the elements enter in
+// index order, so equal ids keep it), over exactly the id's bits — 1 pass for the root's block, 5 for the deepest level of a
+// 2^20-leaf tree; rounds 3-4 bitonic-sorted 64-bit (id, index) keys, 91 compare-exchange stages per depth: 593 us per update
+// of 8192 indices, 77 % of a Rainbow vector step at that batch.  Keys are rebuilt as id << 13 | index afterwards.
 constexpr int kIdxBits = 13;                       // kLdsB = 2^13
 constexpr uint64_t kPadKey = ~0ull;
+constexpr int kSortItems = kLdsB / 1024;
+using BlockSort = rocprim::block_radix_sort<uint32_t, 1024, kSortItems, uint32_t>;
 
-__device__ __forceinline__ void bitonic_sort_lds(uint64_t* keys, int P) {
-  for (int k = 2; k <= P; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = threadIdx.x; t < P / 2; t += blockDim.x) {
-        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));      // index with bit j clear
-        const int hi = lo | j;
-        const uint64_t a = keys[lo], b = keys[hi];
-        const bool up = (lo & k) == 0;
-        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
-      }
-      __syncthreads();
-    }
+// s_keys[0 .. kLdsB) <- the batch ordered by (id, index); id_of(i) for i < B, pad (= all ones in `bits` bits: above every valid
+// id) for "no id"; the pads end up behind the valid elements as kPadKey.  1024 threads; `st` may alias memory the caller uses later.
+template <class F>
+__device__ __forceinline__ void sort_by_id(uint64_t* s_keys, BlockSort::storage_type& st, int B, unsigned bits, F id_of) {
+  const uint32_t pad = bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u;
+  uint32_t k[kSortItems], v[kSortItems];
+#pragma unroll
+  for (int u = 0; u < kSortItems; ++u) {
+    const int i = threadIdx.x * kSortItems + u;
+    v[u] = (uint32_t)i;
+    k[u] = i < B ? id_of(i, pad) : pad;
   }
+  BlockSort().sort(k, v, st, 0, bits);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kSortItems; ++u)
+    s_keys[threadIdx.x * kSortItems + u] = k[u] == pad ? kPadKey : (((uint64_t)k[u] << kIdxBits) | (uint64_t)v[u]);
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(1024) void per_leaf_sorted_kernel(double* __restrict__ tree, int64_t cap,
                                                                const int32_t* __restrict__ idx, int idx_is_tree,
                                                                const double* __restrict__ prio,
-                                                               const double* __restrict__ ps_dev, double ps, int B, int P,
+                                                               const double* __restrict__ ps_dev, double ps, int B, int bits,
                                                                int64_t* __restrict__ leaf_out,
                                                                double* __restrict__ change_out) {
-  extern __shared__ uint64_t s_keys[];
-  for (int i = threadIdx.x; i < P; i += blockDim.x) {
-    uint64_t key = kPadKey;
-    if (i < B) {
-      const int64_t leaf = idx_is_tree ? (int64_t)idx[i] : (int64_t)idx[i] + cap - 1;
-      leaf_out[i] = leaf;
-      key = ((uint64_t)leaf << kIdxBits) | (uint64_t)i;
-    }
-    s_keys[i] = key;
-  }
-  __syncthreads();
-  bitonic_sort_lds(s_keys, P);
+  extern __shared__ uint64_t s_keys[];               // [kLdsB]
+  __shared__ BlockSort::storage_type st;
+  sort_by_id(s_keys, st, B, (unsigned)bits, [&](int i, uint32_t) {
+    const int64_t leaf = idx_is_tree ? (int64_t)idx[i] : (int64_t)idx[i] + cap - 1;
+    leaf_out[i] = leaf;
+    return (uint32_t)leaf;
+  });
   for (int sidx = threadIdx.x; sidx < B; sidx += blockDim.x) {
     const uint64_t key = s_keys[sidx];
     const int64_t leaf = (int64_t)(key >> kIdxBits);
@@ -513,46 +519,43 @@ __global__ __launch_bounds__(1024) void per_leaf_sorted_kernel(double* __restric
 
 __global__ __launch_bounds__(1024) void per_ancestor_sorted_kernel(double* __restrict__ tree,
                                                                    const int64_t* __restrict__ leaf_g,
-                                                                   const double* __restrict__ change_g, int B, int P) {
-  extern __shared__ uint64_t s_keys[];
-  double* s_change = reinterpret_cast<double*>(s_keys + P);
+                                                                   const double* __restrict__ change_g, int B) {
+  extern __shared__ uint64_t s_keys[];               // [kLdsB] keys, then [kLdsB] doubles: the changes IN SORTED ORDER (the sort's scratch first)
+  double* s_sorted = reinterpret_cast<double*>(s_keys + kLdsB);
   const int d = blockIdx.x;
-  for (int i = threadIdx.x; i < P; i += blockDim.x) {
-    uint64_t key = kPadKey;
-    if (i < B) {
-      const int64_t lf = leaf_g[i];
-      const int L = depth_of(lf);
-      s_change[i] = change_g[i];
-      if (L > d) key = ((uint64_t)(((lf + 1) >> (L - d)) - 1) << kIdxBits) | (uint64_t)i;
-    }
-    s_keys[i] = key;
+  sort_by_id(s_keys, *reinterpret_cast<BlockSort::storage_type*>(s_sorted), B, (unsigned)(d + 1), [&](int i, uint32_t pad) {
+    const int64_t lf = leaf_g[i];
+    const int L = depth_of(lf);
+    return L > d ? (uint32_t)(((lf + 1) >> (L - d)) - 1) : pad;       // (a depth-d node index is < 2^(d+1) - 1 = pad)
+  });
+  const uint64_t imask = (1u << kIdxBits) - 1;
+  // a run's changes side by side, in batch order: its leader then adds contiguous doubles (the root's run is the whole batch —
+  // 8192 dependent adds; with a key read, a mask and an indexed read per element that chain was 0.5 ms)
+  for (int sidx = threadIdx.x; sidx < B; sidx += blockDim.x) {
+    const uint64_t key = s_keys[sidx];
+    s_sorted[sidx] = key == kPadKey ? 0.0 : change_g[key & imask];
   }
   __syncthreads();
-  bitonic_sort_lds(s_keys, P);
-  const uint64_t imask = (1u << kIdxBits) - 1;
   for (int sidx = threadIdx.x; sidx < B; sidx += blockDim.x) {
     const uint64_t key = s_keys[sidx];
     if (key == kPadKey) continue;
     const uint64_t node = key >> kIdxBits;
     if (sidx > 0 && (s_keys[sidx - 1] >> kIdxBits) == node) continue;      // not the run's first element
+    int lo = sidx, hi = B;                             // the run's end: the first position whose node differs (binary search)
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((s_keys[mid] >> kIdxBits) == node) lo = mid; else hi = mid;
+    }
     double acc = tree[node];
     int j = sidx;
-    for (;;) {                                         // the run, in batch order: one ordered chain of adds
-      uint64_t k8[8];
-      int n = 0;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        k8[u] = (j + u < B) ? s_keys[j + u] : kPadKey;
-        if (n == u && k8[u] != kPadKey && (k8[u] >> kIdxBits) == node) n = u + 1;
-      }
+    for (; j + 8 <= hi; j += 8) {                      // one ordered chain of adds
       double c8[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) c8[u] = u < n ? s_change[k8[u] & imask] : 0.0;
+      for (int u = 0; u < 8; ++u) c8[u] = s_sorted[j + u];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) if (u < n) acc += c8[u];
-      j += n;
-      if (n < 8) break;
+      for (int u = 0; u < 8; ++u) acc += c8[u];
     }
+    for (; j < hi; ++j) acc += s_sorted[j];
     tree[node] = acc;
   }
 }
@@ -707,14 +710,14 @@ int gymrl_per_update(double* tree, int64_t cap, const int32_t* idx, int64_t idx_
     GYMRL_CHECK_LAUNCH();
     return 0;
   }
-  if (B > 512 && B <= kLdsB && 2 * cap < (1ll << (63 - kIdxBits))) {     // large unordered batch: sort-based passes
-    int P = 1;
-    while (P < B) P <<= 1;
-    hipLaunchKernelGGL(per_leaf_sorted_kernel, dim3(1), dim3(1024), (size_t)P * 8, stream, tree, cap, idx, idx_is_tree,
-                       prio, prio_scalar_dev, prio_scalar, B, P, ws.leaf, ws.change);
+  if (B > 512 && B <= kLdsB && 2 * cap < (1ll << 32)) {     // large unordered batch: radix-ordered passes (32-bit ids)
+    int bits = 1;
+    while ((1ll << bits) - 1 <= 2 * cap - 2) ++bits;        // the largest leaf index 2 cap - 2 stays below the pad (all ones)
+    hipLaunchKernelGGL(per_leaf_sorted_kernel, dim3(1), dim3(1024), (size_t)kLdsB * 8, stream, tree, cap, idx, idx_is_tree,
+                       prio, prio_scalar_dev, prio_scalar, B, bits, ws.leaf, ws.change);
     if (depth > 0)
-      hipLaunchKernelGGL(per_ancestor_sorted_kernel, dim3(depth), dim3(1024), (size_t)P * 16, stream, tree, ws.leaf,
-                         ws.change, B, P);
+      hipLaunchKernelGGL(per_ancestor_sorted_kernel, dim3(depth), dim3(1024), (size_t)kLdsB * 16, stream, tree, ws.leaf,
+                         ws.change, B);
     GYMRL_CHECK_LAUNCH();
     return 0;
   }
