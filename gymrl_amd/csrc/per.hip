@@ -402,42 +402,88 @@ __global__ __launch_bounds__(1024) void per_small_kernel(SmallArgs a) {
 }
 
 // ---- the N-row vector store (idx == NULL): per_store_device.hpp ------------------------------------------------------
-// Launch 1: every row's leaf (no duplicates: B <= cap), change = p - old leaf, leaf := p.  Fully parallel.
+// The batch tree (pairwise sums over the batch index, P = the next power of two >= B leaves) is built ONCE, by the launch
+// that writes the leaves, into the workspace; the ancestor launch is then ~B small independent node updates.  Rounds 3-5 had
+// every depth's workgroup rebuild the whole tree in 64-131 KB of LDS: 13 us alone, but 25-30 us in a Rainbow vector step,
+// where it runs on the tree's stream beside the acting launch (whose 256 x 16 waves hold every compute unit) and was the end
+// of the step's critical chain (profiles/r05_rainbow_timeline.txt).
+constexpr int kSegChunk = 512;                           // batch leaves per workgroup of launch 1
+constexpr int kSegTop = per::kStoreChunk / kSegChunk;    // <= 16 chunk roots: the levels above them are rebuilt where needed
+
+// Launch 1: every row's leaf (no duplicates: B <= cap), change = p - old leaf, leaf := p; the chunk's sub-tree of the batch
+// tree -> seg_g (node k of the P-leaf tree at seg_g[k], chunk c's root at P / W + c; the leaves stay in change_out).
 __global__ __launch_bounds__(kBlock) void per_store_leaf_kernel(double* __restrict__ tree, int64_t cap, int64_t idx_start,
                                                                 const int64_t* __restrict__ idx_start_dev, int64_t offset,
                                                                 const double* __restrict__ prio,
-                                                                const double* __restrict__ ps_dev, double ps, int B,
-                                                                double* __restrict__ change_out) {
+                                                                const double* __restrict__ ps_dev, double ps, int B, int P,
+                                                                double* __restrict__ change_out, double* __restrict__ seg_g) {
+  __shared__ double s[2 * kSegChunk];
   if (idx_start_dev) idx_start = idx_start_dev[0];       // recorded into a hipGraph: this replay's ring cursor
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= B) return;
-  const int64_t leaf = (idx_start + offset + i) % cap + cap - 1;
-  const double p = prio_of(prio, ps_dev, ps, i);
-  change_out[i] = p - tree[leaf];
-  tree[leaf] = p;
-}
-
-// Launch 2: blockIdx.x = node depth d.  Every workgroup builds the batch tree in LDS (2P doubles: 13 levels at 8192
-// rows), then its threads take the depth's nodes: <= 4 runs per node in closed form, <= 2 log2(P) LDS reads per run,
-// ONE addition into the node.  No chain is longer than log2(P) + 4 float64 adds.
-__global__ __launch_bounds__(1024) void per_store_ancestor_kernel(double* __restrict__ tree, int64_t cap, int64_t idx_start,
-                                                                  const int64_t* __restrict__ idx_start_dev, int64_t offset,
-                                                                  const double* __restrict__ change, int B, int P) {
-  extern __shared__ __attribute__((aligned(16))) double s_seg[];
-  if (idx_start_dev) idx_start = idx_start_dev[0];
-  const int d = blockIdx.x;
-  for (int i = threadIdx.x; i < P; i += blockDim.x) s_seg[P + i] = i < B ? change[i] : 0.0;
+  const int W = P < kSegChunk ? P : kSegChunk, c = blockIdx.x;
+  for (int i = threadIdx.x; i < W; i += kBlock) {
+    const int b = c * W + i;
+    double ch = 0.0;                                     // batch positions B .. P - 1 are zeros
+    if (b < B) {
+      const int64_t leaf = (idx_start + offset + b) % cap + cap - 1;
+      const double p = prio_of(prio, ps_dev, ps, b);
+      ch = p - tree[leaf];
+      tree[leaf] = p;
+      change_out[b] = ch;
+    }
+    s[W + i] = ch;
+  }
   __syncthreads();
-  for (int w = P >> 1; w >= 1; w >>= 1) {
-    for (int k = w + threadIdx.x; k < 2 * w; k += blockDim.x) s_seg[k] = s_seg[2 * k] + s_seg[2 * k + 1];
+  for (int w = W >> 1; w >= 1; w >>= 1) {
+    for (int k = w + threadIdx.x; k < 2 * w; k += kBlock) s[k] = s[2 * k] + s[2 * k + 1];
     __syncthreads();
   }
+  const size_t root = (size_t)(P / W + c);
+  for (int k = 1 + threadIdx.x; k < W; k += kBlock) {
+    const int w = 1 << (31 - __clz(k));                  // k = w + j: level of width w below the chunk's root
+    seg_g[root * w + (k - w)] = s[k];
+  }
+}
+
+// The batch tree as launch 2 reads it: the levels above the chunk roots from LDS, the rest from seg_g, the leaves in place.
+struct StoreSeg {
+  const double* top;      // nodes 1 .. C - 1 (C = chunk roots)
+  const double* seg;      // nodes C .. P - 1
+  const double* leaf;     // change[0 .. B)
+  int C, P, B;
+  __device__ __forceinline__ double operator[](int k) const {
+    return k < C ? top[k] : (k < P ? seg[k] : (k - P < B ? leaf[k - P] : 0.0));
+  }
+};
+
+// Launch 2: blockIdx.y = node depth d, the depth's nodes over blockIdx.x: <= 4 runs per node in closed form, <= 2 log2(P)
+// reads per run, ONE addition into the node.  No chain is longer than log2(P) + 4 float64 adds.
+__global__ __launch_bounds__(kBlock) void per_store_ancestor_kernel(double* __restrict__ tree, int64_t cap, int64_t idx_start,
+                                                                    const int64_t* __restrict__ idx_start_dev, int64_t offset,
+                                                                    const double* __restrict__ change,
+                                                                    const double* __restrict__ seg_g, int B, int P) {
+  __shared__ double s_top[2 * kSegTop];
+  if (idx_start_dev) idx_start = idx_start_dev[0];
+  const int d = blockIdx.y;
   const per::StoreGeom g = per::store_geom(cap, idx_start + offset, B);
   int64_t n0[4], n1[4];
   const int nr = per::store_node_ranges(g, d, n0, n1);
+  const int64_t first = (int64_t)blockIdx.x * kBlock;
+  bool any = false;
+  for (int r = 0; r < nr; ++r) any = any || first <= n1[r] - n0[r];
+  if (!any) return;                                       // (uniform: before the barrier)
+  const int C = P > kSegChunk ? P / kSegChunk : 1;
+  if (C > 1) {
+    if (threadIdx.x < C) s_top[C + threadIdx.x] = seg_g[C + threadIdx.x];
+    __syncthreads();
+    for (int w = C >> 1; w >= 1; w >>= 1) {
+      if (threadIdx.x < w) s_top[w + threadIdx.x] = s_top[2 * (w + threadIdx.x)] + s_top[2 * (w + threadIdx.x) + 1];
+      __syncthreads();
+    }
+  }
+  const StoreSeg seg{s_top, seg_g, change, C, P, B};
   for (int r = 0; r < nr; ++r) {
     const int64_t cnt = n1[r] - n0[r] + 1;
-    for (int64_t t = threadIdx.x; t < cnt; t += blockDim.x) {
+    for (int64_t t = first + threadIdx.x; t < cnt; t += (int64_t)gridDim.x * kBlock) {
       const int64_t node = n0[r] + t;
       bool seen = false;                                   // a node two ranges share belongs to the first
       for (int q = 0; q < r; ++q) seen = seen || (node >= n0[q] && node <= n1[q]);
@@ -445,7 +491,7 @@ __global__ __launch_bounds__(1024) void per_store_ancestor_kernel(double* __rest
       int a[4], e[4];
       const int m = per::store_node_runs(g, d, node, a, e);
       double S = 0.0;
-      for (int q = 0; q < m; ++q) S += per::store_run_sum(s_seg, P, a[q], e[q]);
+      for (int q = 0; q < m; ++q) S += per::store_run_sum(seg, P, a[q], e[q]);
       tree[node] = tree[node] + S;
     }
   }
@@ -687,7 +733,6 @@ int gymrl_per_update(double* tree, int64_t cap, const int32_t* idx, int64_t idx_
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)per_leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsB * 8) != hipSuccess ||
         hipFuncSetAttribute((const void*)per_ancestor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsB * 16) != hipSuccess ||
-        hipFuncSetAttribute((const void*)per_store_ancestor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, per::kStoreChunk * 16) != hipSuccess ||
         hipFuncSetAttribute((const void*)per_leaf_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsB * 8) != hipSuccess ||
         hipFuncSetAttribute((const void*)per_ancestor_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsB * 16) != hipSuccess)
       return -1000 - (int)hipGetLastError();
@@ -701,11 +746,13 @@ int gymrl_per_update(double* tree, int64_t cap, const int32_t* idx, int64_t idx_
       const int n = B - o < per::kStoreChunk ? B - o : per::kStoreChunk;
       int P = 1;
       while (P < n) P <<= 1;
-      hipLaunchKernelGGL(per_store_leaf_kernel, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, stream, tree, cap, idx_start,
-                         idx_start_dev, (int64_t)o, prio ? prio + o : nullptr, prio_scalar_dev, prio_scalar, n, ws.change);
+      // seg_g: P doubles of the scratch area (P <= n + 4096 for every n <= kStoreChunk: gymrl_per_workspace_bytes)
+      hipLaunchKernelGGL(per_store_leaf_kernel, dim3(P > kSegChunk ? P / kSegChunk : 1), dim3(kBlock), 0, stream, tree, cap,
+                         idx_start, idx_start_dev, (int64_t)o, prio ? prio + o : nullptr, prio_scalar_dev, prio_scalar, n, P,
+                         ws.change, ws.partial);
       if (depth > 0)
-        hipLaunchKernelGGL(per_store_ancestor_kernel, dim3(depth), dim3(1024), (size_t)P * 16, stream, tree, cap, idx_start,
-                           idx_start_dev, (int64_t)o, ws.change, n, P);
+        hipLaunchKernelGGL(per_store_ancestor_kernel, dim3(cdiv(n / 2 + 2, kBlock), depth), dim3(kBlock), 0, stream, tree, cap,
+                           idx_start, idx_start_dev, (int64_t)o, ws.change, ws.partial, n, P);
     }
     GYMRL_CHECK_LAUNCH();
     return 0;
