@@ -46,7 +46,7 @@ SYMBOLS = [
     "gymrl_linear_bwd_weight_geometry", "gymrl_linear_bwd_weight",
     "gymrl_heads_loss_blocks", "gymrl_heads_loss_fwd_bwd", "gymrl_update_finalize",
     "gymrl_lin_workspace_bytes", "gymrl_lin_fwd", "gymrl_lin_bwd_input", "gymrl_lin_bwd_weight",
-    "gymrl_noisy_combine", "gymrl_noisy_split", "gymrl_dueling_bwd",
+    "gymrl_noisy_combine", "gymrl_noisy_combine_images", "gymrl_noisy_split", "gymrl_dueling_bwd",
     "gymrl_mhc_gates", "gymrl_mhc_combine", "gymrl_rmsnorm", "gymrl_sinkhorn",
     "gymrl_mhc_read_fwd", "gymrl_mhc_read_bwd", "gymrl_mhc_combine_bwd",
     "gymrl_mhc_gates_bwd_workspace_bytes", "gymrl_mhc_gates_bwd", "gymrl_rmsnorm_bwd_workspace_bytes", "gymrl_rmsnorm_bwd", "gymrl_rmsnorm_sum_bwd", "gymrl_norm_proj_fwd", "gymrl_norm_proj_bwd_workspace_bytes", "gymrl_norm_proj_bwd",
@@ -185,7 +185,7 @@ class RainbowActArgs(C.Structure):        # gymrl_rainbow_act_args (include/gymr
                 ("r_state", C.c_void_p), ("r_action", C.c_void_p), ("r_reward", C.c_void_p), ("r_next", C.c_void_p),
                 ("r_flag", C.c_void_p), ("cap", C.c_int64), ("cursor", C.c_int64), ("push_dev", C.c_void_p),
                 ("action_out", C.c_void_p), ("rew_out", C.c_void_p), ("done_out", C.c_void_p), ("ep_ret_out", C.c_void_p),
-                ("ep_stats", C.c_void_p)]
+                ("ep_stats", C.c_void_p), ("fc2_img", C.c_void_p)]
 
 
 class RainbowUpdateArgs(C.Structure):     # gymrl_rainbow_update_args (include/gymrl.h), field for field
@@ -198,7 +198,12 @@ class RainbowUpdateArgs(C.Structure):     # gymrl_rainbow_update_args (include/g
                 ("d_fc1_w", C.c_void_p), ("d_fc1_b", C.c_void_p), ("d_fc2_w", C.c_void_p), ("d_fc2_b", C.c_void_p),
                 ("d_head_w", C.c_void_p), ("d_head_b", C.c_void_p), ("workspace", C.c_void_p),
                 ("split_heads", C.c_int), ("dw_mu", C.c_void_p * 2), ("dw_sigma", C.c_void_p * 2), ("db_mu", C.c_void_p * 2),
-                ("db_sigma", C.c_void_p * 2), ("w_eps", C.c_void_p * 2), ("b_eps", C.c_void_p * 2)]
+                ("db_sigma", C.c_void_p * 2), ("w_eps", C.c_void_p * 2), ("b_eps", C.c_void_p * 2),
+                ("p_fc2_img_f", C.c_void_p), ("p_fc2_img_b", C.c_void_p), ("t_fc2_img_f", C.c_void_p)]
+
+
+class WeightImage(C.Structure):           # gymrl_weight_image
+    _fields_ = [("W", C.c_void_p), ("H", C.c_int), ("img_fwd", C.c_void_p), ("img_bwd", C.c_void_p)]
 
 
 class PPOFullCfg(C.Structure):

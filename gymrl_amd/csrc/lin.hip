@@ -617,13 +617,38 @@ struct NoisyArgs {
   int n_layers, K, training, accumulate;
   float* W; float* b;               // stacked [rows, K], [rows]
   const float* dW; const float* db;
+  // gymrl_noisy_combine_images: workgroups combine_blocks .. gridDim.x - 1 rebuild weight images instead
+  int combine_blocks, n_img;
+  const float* img_W[GYMRL_NOISY_MAX_IMAGES]; float* img_f[GYMRL_NOISY_MAX_IMAGES]; float* img_b[GYMRL_NOISY_MAX_IMAGES];
+  int img_H[GYMRL_NOISY_MAX_IMAGES];
 };
+
+// lin_device.hpp's img_fwd_index / img_bwd_index by DESTINATION float4 j = (tile * steps + c) * 64 + 16 q + r: coalesced stores
+__device__ __forceinline__ void pack_images(const NoisyArgs& a, int pb, int npb) {
+  for (int i = 0; i < a.n_img; ++i) {
+    const int H = a.img_H[i], steps = H >> 4;
+    const float* __restrict__ W = a.img_W[i];
+    const int64_t nv = (int64_t)H * H / 4;
+    for (int64_t j = (int64_t)pb * 256 + threadIdx.x; j < nv; j += (int64_t)npb * 256) {
+      const int lane = (int)(j & 63), c = (int)((j >> 6) % steps), tile = (int)((j >> 6) / steps), r = lane & 15, q = lane >> 4;
+      if (a.img_f[i])
+        reinterpret_cast<f32x4*>(a.img_f[i])[j] = *reinterpret_cast<const f32x4*>(W + (size_t)(16 * tile + r) * H + 16 * c + 4 * q);
+      if (a.img_b[i]) {
+        const float* w = W + (size_t)(16 * c + 4 * q) * H + 16 * tile + r;
+        const f32x4 v = {w[0], w[H], w[2 * (size_t)H], w[3 * (size_t)H]};
+        reinterpret_cast<f32x4*>(a.img_b[i])[j] = v;
+      }
+    }
+  }
+}
 
 // W[row0 + n] = mu + sigma * eps (training) | mu (eval); the noise is also copied through to the module's buffers
 __global__ __launch_bounds__(256) void noisy_combine_kernel(const NoisyArgs a) {
   const int rows = a.row0[a.n_layers];
   const int64_t total = (int64_t)rows * (a.K + 1);
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+  const int cb = a.n_img > 0 ? a.combine_blocks : (int)gridDim.x;
+  if ((int)blockIdx.x >= cb) { pack_images(a, (int)blockIdx.x - cb, (int)gridDim.x - cb); return; }
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)cb * 256) {
     const int row = (int)(t / (a.K + 1)), k = (int)(t % (a.K + 1));
     int l = 0;
     while (l + 1 < a.n_layers && row >= a.row0[l + 1]) ++l;
@@ -900,6 +925,28 @@ int gymrl_noisy_combine(const gymrl_noisy_layer* layers, int n_layers, int K, in
   a.W = W_out; a.b = b_out;
   const int64_t total = (int64_t)rows * (K + 1);
   hipLaunchKernelGGL(noisy_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), a);
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_noisy_combine_images(const gymrl_noisy_layer* layers, int n_layers, int K, int training, float* W_out, float* b_out,
+                               const gymrl_weight_image* images, int n_images, void* stream_) {
+  NoisyArgs a{};
+  const int rows = noisy_fill(a, layers, n_layers, K, training);
+  if (rows < 0 || !W_out || !b_out || n_images < 0 || n_images > GYMRL_NOISY_MAX_IMAGES || (n_images > 0 && !images)) return -22;
+  a.W = W_out; a.b = b_out;
+  int pack_blocks = 0;
+  for (int i = 0; i < n_images; ++i) {
+    const gymrl_weight_image& im = images[i];
+    if (!im.W || im.H < 16 || (im.H & 15) != 0 || (!im.img_fwd && !im.img_bwd)) return -22;
+    a.img_W[i] = im.W; a.img_H[i] = im.H; a.img_f[i] = im.img_fwd; a.img_b[i] = im.img_bwd;
+    pack_blocks += (im.H * im.H / 4 + 255) / 256;
+  }
+  const int64_t total = (int64_t)rows * (K + 1);
+  a.combine_blocks = (int)((total + 255) / 256);
+  a.n_img = n_images;
+  hipLaunchKernelGGL(noisy_combine_kernel, dim3((unsigned)(a.combine_blocks + pack_blocks)), dim3(256), 0,
                      static_cast<hipStream_t>(stream_), a);
   GYMRL_CHECK_LAUNCH();
   return 0;

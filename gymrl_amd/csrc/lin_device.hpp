@@ -322,6 +322,36 @@ __device__ __forceinline__ f32x4 tile_fwd_img(const float* Xs, int ldx, int step
   return tile_fwd_img_t<0>(Xs, ldx, steps, img, tile, lane);
 }
 
+// tile_fwd_x2 from the forward image: two slabs share every weight fragment (the 32-row acting workgroups); each accumulator
+// sees exactly tile_fwd_img's sequence.
+template <int SC>
+__device__ __forceinline__ void tile_fwd_img_x2_t(const float* Xs0, const float* Xs1, int ldx, int steps_r, const float* __restrict__ img,
+                                                  int tile, int lane, f32x4& acc0, f32x4& acc1) {
+  const int steps = SC ? SC : steps_r;
+  const int r = lane & 15, q = lane >> 4;
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  acc0 = zero; acc1 = zero;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(img) + (size_t)tile * steps * 64 + lane;
+  const float* x0 = Xs0 + r * ldx + 4 * q;
+  const float* x1 = Xs1 + r * ldx + 4 * q;
+  for (int cp = 0; cp < steps; cp += kMaxSteps) {
+    f32x4 wb[kMaxSteps];
+#pragma unroll
+    for (int c = 0; c < kMaxSteps; ++c) {
+      if (cp + c >= steps) break;                             // (wave-uniform)
+      wb[c] = wp[(size_t)(cp + c) * 64];
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxSteps; ++c) {
+      if (cp + c >= steps) break;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(x0 + 16 * (cp + c));
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(x1 + 16 * (cp + c));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc0 = mfma16(a0[e], wb[c][e], acc0); acc1 = mfma16(a1[e], wb[c][e], acc1); }
+    }
+  }
+}
+
 // tile_bwd_input for K == N == 16 * steps from the input-gradient image
 template <int SC>
 __device__ __forceinline__ f32x4 tile_bwd_input_img_t(f32x4 acc, const float* dZs, int ldz, int steps_r, const float* __restrict__ img, int ktile,

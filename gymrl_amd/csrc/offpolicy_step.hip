@@ -1232,7 +1232,8 @@ __global__ __launch_bounds__(kThreads) void rainbow_rows_kernel(const gymrl_rain
   }
   __syncthreads();
   {
-    const FwdItem st[1] = {fwd_item(H1, ld, -1, 0, H, H, H, tgt ? a.t_fc2_w : a.p_fc2_w, tgt ? a.t_fc2_b : a.p_fc2_b, H2, ld, pass == 0 ? ws.h2 : nullptr, H, R)};
+    const FwdItem st[1] = {fwd_item(H1, ld, -1, 0, H, H, H, tgt ? a.t_fc2_w : a.p_fc2_w, tgt ? a.t_fc2_b : a.p_fc2_b, H2, ld, pass == 0 ? ws.h2 : nullptr, H, R,
+                                    0.0f, 0.0f, tgt ? a.t_fc2_img_f : a.p_fc2_img_f)};
     fwd_stage<1>(lds, st, row0, nrows);
   }
   __syncthreads();
@@ -1289,7 +1290,7 @@ __global__ __launch_bounds__(kThreads) void rainbow_rows_kernel(const gymrl_rain
   }
   __syncthreads();
   {
-    const BwdItem st[1] = {BwdItem{X0, ld, H, a.p_fc2_w, H, -1, nullptr, H1, ld, R, -1, 0, ws.dZ1, H, nullptr}};
+    const BwdItem st[1] = {BwdItem{X0, ld, H, a.p_fc2_w, H, -1, nullptr, H1, ld, R, -1, 0, ws.dZ1, H, a.p_fc2_img_b}};
     bwd_stage<1>(lds, st, row0, nrows);
   }
 }
@@ -1298,13 +1299,17 @@ __global__ __launch_bounds__(kThreads) void rainbow_rows_kernel(const gymrl_rain
 // workgroup: at N = 8192 the 16-row form is 512 workgroups = two rounds over the 256 compute units, each streaming every
 // weight again (45 us per launch); 32 rows per workgroup stream them once for two MFMA chains.
 template <int NS>
-__device__ __forceinline__ void act_layer(float* lds, int X, int ldx, int K, const float* W, const float* b, int N, int Ys, int ldy, int act) {
+__device__ __forceinline__ void act_layer(float* lds, int X, int ldx, int K, const float* W, const float* b, int N, int Ys, int ldy, int act,
+                                          const float* Wimg = nullptr) {       // Wimg: forward image of a square W (K == N, % 16)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
   const int ntiles = (N + 15) >> 4;
   for (int t = wave; t < ntiles; t += kWaves) {
     const int nb = t * 16;
     f32x4 acc[2];
-    if (NS == 2) lin::tile_fwd_x2(lds + X, lds + X + 16 * ldx, ldx, K, W, N, nb, lane, acc[0], acc[1]);
+    if (Wimg) {
+      if (NS == 2) lin::tile_fwd_img_x2_t<0>(lds + X, lds + X + 16 * ldx, ldx, K >> 4, Wimg, t, lane, acc[0], acc[1]);
+      else acc[0] = lin::tile_fwd_img(lds + X, ldx, K >> 4, Wimg, t, lane);
+    } else if (NS == 2) lin::tile_fwd_x2(lds + X, lds + X + 16 * ldx, ldx, K, W, N, nb, lane, acc[0], acc[1]);
     else acc[0] = lin::tile_fwd(lds + X, ldx, nullptr, 0, K, K, W, N, nb, lane);
     const int n = nb + r;
     if (n < N) {
@@ -1332,7 +1337,7 @@ __global__ __launch_bounds__(kThreads) void rainbow_act_kernel(const gymrl_rainb
   __syncthreads();
   act_layer<NS>(lds, S, kMaxD, D, a.fc1_w, a.fc1_b, H, X0, ld, GYMRL_ACT_RELU);
   __syncthreads();
-  act_layer<NS>(lds, X0, ld, H, a.fc2_w, a.fc2_b, H, X1, ld, GYMRL_ACT_RELU);
+  act_layer<NS>(lds, X0, ld, H, a.fc2_w, a.fc2_b, H, X1, ld, GYMRL_ACT_RELU, a.fc2_img);
   __syncthreads();
   act_layer<NS>(lds, X1, ld, H, a.head_w, a.head_b, A1, Q, 4, GYMRL_ACT_NONE);
   __syncthreads();
@@ -1472,6 +1477,7 @@ int gymrl_rainbow_act_step(const gymrl_rainbow_act_args* args, void* stream_) {
   if (!a.w_state || !a.w_action || !a.w_reward || !a.w_next || !a.w_terminal || !a.w_done || a.n_steps <= 0 || a.pushes < 0 ||
       !a.r_state || !a.r_action || !a.r_reward || !a.r_next || !a.r_flag || a.cap < a.N || a.cursor < 0)
     return -22;
+  if (a.fc2_img && (a.H & 15) != 0) return -22;
   auto act_lds = [](int H, int ns) { return sizeof(float) * (size_t)(16 * ns * (kMaxD + 4 + 2 * lin::slab_ld(H))); };
   static bool attr_set = false;
   if (!attr_set) {
@@ -1502,6 +1508,7 @@ int gymrl_rainbow_update(const gymrl_rainbow_update_args* args, int phase, void*
       !a.t_fc1_w || !a.t_fc1_b || !a.t_fc2_w || !a.t_fc2_b || !a.head_w || !a.head_b || !a.td_out || !a.loss_sum || !a.d_fc1_w || !a.d_fc1_b ||
       !a.d_fc2_w || !a.d_fc2_b || (!a.split_heads && (!a.d_head_w || !a.d_head_b)) || !a.workspace)
     return -22;
+  if ((a.p_fc2_img_f || a.p_fc2_img_b || a.t_fc2_img_f) && (a.H & 15) != 0) return -22;
   hipStream_t stream = (hipStream_t)stream_;
   static bool attr_set = false;
   if (!attr_set) {

@@ -1076,11 +1076,25 @@ def _noisy_layers(layers):
     return arr, K, rows
 
 
-def noisy_combine(layers, training=True):
-    """gymrl_noisy_combine: stacked effective parameters (W [rows, K], b [rows]) of NoisyLinear layers in one launch."""
+def noisy_combine(layers, training=True, images=None):
+    """gymrl_noisy_combine: stacked effective parameters (W [rows, K], b [rows]) of NoisyLinear layers in one launch.
+    images: [(W [H, H], img_fwd or None, img_bwd or None)] — gymrl_noisy_combine_images: the MFMA-operand images of square
+    weights rebuilt on extra workgroups of the same launch (flat f32[H * H] outputs)."""
     arr, K, rows = _noisy_layers(layers)
     dev = layers[0]["w_mu"].device
     W, b = torch.empty(rows, K, dtype=torch.float32, device=dev), torch.empty(rows, dtype=torch.float32, device=dev)
+    if images:
+        from ._lib import WeightImage
+        ims = (WeightImage * len(images))()
+        for i, (w, f, bw) in enumerate(images):
+            H = w.shape[0]
+            if w.shape != (H, H) or not w.is_contiguous() or any(t is not None and t.numel() != H * H for t in (f, bw)):
+                raise ValueError("noisy_combine: an image needs a contiguous square weight and H * H floats per image")
+            ims[i].W, ims[i].H = _ptr(w, torch.float32).value, H
+            ims[i].img_fwd, ims[i].img_bwd = (None if t is None else _ptr(t, torch.float32).value for t in (f, bw))
+        check(lib().gymrl_noisy_combine_images(arr, C.c_int(len(layers)), C.c_int(K), C.c_int(int(training)), _ptr(W), _ptr(b),
+                                               ims, C.c_int(len(images)), _stream()), "gymrl_noisy_combine_images")
+        return W, b
     check(lib().gymrl_noisy_combine(arr, C.c_int(len(layers)), C.c_int(K), C.c_int(int(training)), _ptr(W), _ptr(b), _stream()),
           "gymrl_noisy_combine")
     return W, b
@@ -1471,10 +1485,12 @@ def rainbow_act_args(env, net, win, ring, cap, n_steps, gamma, max_episode_steps
 
 
 def rainbow_act_step(a, env, obs, obs_out, head_w, head_b, pushes=0, cursor=0, push_dev=None, action_out=None, rew_out=None,
-                     done_out=None, ep_ret_out=None, ep_stats=None):
+                     done_out=None, ep_ret_out=None, ep_stats=None, fc2_img=None):
     """gymrl_rainbow_act_step: greedy acting on the noisy Q + CartPole step + n-step push, one launch.  Returns what
-    gymrl_nstep_push returns: whether rows were emitted (by the HOST's push count)."""
+    gymrl_nstep_push returns: whether rows were emitted (by the HOST's push count).  fc2_img: the forward weight image of fc2
+    (noisy_combine(images=...)) — the caller vouches that it equals fc2.weight; None: read in place."""
     a.env_seed = env.seed
+    a.fc2_img = _addr(fc2_img)
     a.obs, a.obs_out = _ptr(obs, torch.float32).value, _ptr(obs_out, torch.float32).value
     a.head_w, a.head_b = _ptr(head_w, torch.float32).value, _ptr(head_b, torch.float32).value
     a.pushes, a.cursor, a.push_dev = pushes, cursor, _addr(push_dev)
@@ -1495,10 +1511,12 @@ def rainbow_update_args(B, D, A, policy, target, ring, gamma_n, loss_sum, d_head
     return a
 
 
-def rainbow_update(a, idx, is_weight, head_w, head_b, td_out, split=None, phase=0):
+def rainbow_update(a, idx, is_weight, head_w, head_b, td_out, split=None, phase=0, images=None):
     """gymrl_rainbow_update: gather + the three forwards + TD loss gradient + backward chain (rows), every weight gradient
-    (tiles) — two launches.  head_w [3 (A+1), H] / head_b [3 (A+1)]: gymrl_noisy_combine's stacked output."""
+    (tiles) — two launches.  head_w [3 (A+1), H] / head_b [3 (A+1)]: gymrl_noisy_combine's stacked output.
+    images: (policy fc2 forward, policy fc2 input-gradient, target fc2 forward) weight images the caller vouches for, or None."""
     a.idx, a.is_weight = _ptr(idx, torch.int32).value, _addr(is_weight)
+    a.p_fc2_img_f, a.p_fc2_img_b, a.t_fc2_img_f = (None, None, None) if images is None else (_addr(t) for t in images)
     a.head_w, a.head_b, a.td_out = _ptr(head_w, torch.float32).value, _ptr(head_b, torch.float32).value, _ptr(td_out, torch.float32).value
     # split: [(dw_mu, dw_sigma, db_mu, db_sigma, w_eps, b_eps)] of the advantage and the value layer -> gymrl_noisy_split's work
     # happens in the weight-gradient launch (None: the stacked gradient goes to d_head_w / d_head_b)

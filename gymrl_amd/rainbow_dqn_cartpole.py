@@ -50,6 +50,9 @@ class Config:
         self.fused_step = True             # acting + env + n-step push in ONE launch, the update's ~20 Linear / loss launches in TWO
         #                                    (csrc/offpolicy_step.hip; bit-identical to the layer-by-layer path, which remains for
         #                                    other shapes and custom envs)
+        self.fused_images = True           # fused step: fc2 (hidden x hidden, hidden % 16 == 0) is streamed from MFMA-operand images
+        #                                    that the step's NoisyLinear launch rebuilds from the parameters (same values, same
+        #                                    registers: bit-identical; False: nn.Linear's rows are read in place)
         self.chunk_steps = 16              # whole vector steps (acting, env, n-step store, sum tree, draw, update) as one
         #                                    hipGraph per 16 (graphs.StepChunk); 0: eager acting + a graph per update.  The
         #                                    eager launches of a step cost the host 0.46 ms at N = 8192 — more than the GPU needs
@@ -462,7 +465,19 @@ class RainbowDQNTrainer:
                                                cfg.gamma ** cfg.n_steps, self._loss, f["dW"], f["db"], f["ws"])
             f["act"] = (ops.rainbow_act_args(self.env, p, m.win, m.ring, m.capacity, m.n_steps, m.gamma, self.max_steps_per_episode)
                         if isinstance(self.env, VecEnv) else None)
+            # MFMA-operand images of fc2 (policy forward / input-gradient, target forward; csrc/lin_device.hpp): never kept
+            # across parameter writes — every consumer's own gymrl_noisy_combine launch rebuilds the ones it reads
+            f["img"] = (torch.empty(3, H * H, device=d) if H % 16 == 0 and getattr(cfg, "fused_images", True) else None)
         return f
+
+    def _fc2_images(self, update=True):
+        """noisy_combine(images=...) entries: policy fc2 forward (+ input-gradient and the target's forward for the update)."""
+        img = self._fused_state()["img"]
+        if img is None:
+            return None
+        if not update:
+            return [(self.policy_net.fc2.weight, img[0], None)]
+        return [(self.policy_net.fc2.weight, img[0], img[1]), (self.target_net.fc2.weight, img[2], None)]
 
     @staticmethod
     def _noisy_fields(m, **kw):
@@ -538,11 +553,13 @@ class RainbowDQNTrainer:
             self._tree_keep = (td, batch_index)       # read on the side stream: alive until the next join
 
     @torch.no_grad()
-    def _noisy_heads3(self, with_acting=False):
+    def _noisy_heads3(self, with_acting=False, images=False):
         """The stacked effective head parameters of the update's three passes — policy on s' (first draw :320), target on s'
         (means), policy on s (second draw :334) — built by ONE gymrl_noisy_combine launch, both draws made inside it in the
         eager order.  -> (W [3 (A + 1), H], b [3 (A + 1)], the second draw's epsilons for the backward).  with_acting: the
-        vector step's acting forward (its own draw, made FIRST: the eager order) rides in the same launch, its rows in front."""
+        vector step's acting forward (its own draw, made FIRST: the eager order) rides in the same launch, its rows in front.
+        images: fc2's weight images are rebuilt on extra workgroups of the launch (the caller consumes them before the next
+        parameter write)."""
         p, t = self.policy_net, self.target_net
         acting = []
         if with_acting:       # (no *_copy: the module's epsilon buffers end the step holding the second draw, as in the eager order)
@@ -560,27 +577,31 @@ class RainbowDQNTrainer:
             f, saved = m.noise_source()
             second.append(self._noisy_fields(m, **f))
             eps += list(saved)
-        W, b = ops.noisy_combine(acting + first + target + second, training=True)
+        W, b = ops.noisy_combine(acting + first + target + second, training=True, images=self._fc2_images() if images else None)
         return W, b, eps
 
     @torch.no_grad()
-    def _update_body_fused(self, batch_index, is_weight, bias=None, join=True, heads=None):
+    def _update_body_fused(self, batch_index, is_weight, bias=None, join=True, heads=None, images=None):
         """_update_body with everything between the proportional draw and the optimiser step as gymrl_rainbow_update's two
         launches (+ the two NoisyLinear launches that own the noise bookkeeping): same values, same destinations."""
         cfg, p = self.cfg, self.policy_net
         f = self._fused_state()
-        W, b, eps = self._noisy_heads3() if heads is None else heads
+        if heads is None:            # the launch that builds the heads also rebuilds fc2's weight images for the row launch
+            W, b, eps = self._noisy_heads3(images=True)
+            images = f["img"]
+        else:                        # the caller's launch did (images) or did not (None: fc2 is read in place)
+            W, b, eps = heads
         td = torch.empty(cfg.batch_size, device=self.device)
         # the stacked head's gradient is split into d mu / d sigma of the two NoisyLinear layers by the weight-gradient launch
         split = [(m.weight_mu.grad, m.weight_sigma.grad, m.bias_mu.grad, m.bias_sigma.grad, eps[2 * i], eps[2 * i + 1])
                  for i, m in enumerate((p.advantage, p.value))]
-        ops.rainbow_update(f["upd"], batch_index, is_weight, W, b, td, split=split, phase=1)      # rows: td is complete
+        ops.rainbow_update(f["upd"], batch_index, is_weight, W, b, td, split=split, phase=1, images=images)   # rows: td is complete
         # :340 update_priorities needs only td: it forks off here, beside the weight gradients, the clip and Adam (the sum
         # tree's chain — priorities, then the next step's new rows, then the draw — is the step's critical path)
         main, side = torch.cuda.current_stream(), self._side if OVERLAP_TREE else torch.cuda.current_stream()
         fork = torch.cuda.Event()
         fork.record(main)
-        ops.rainbow_update(f["upd"], batch_index, is_weight, W, b, td, split=split, phase=2)      # tiles
+        ops.rainbow_update(f["upd"], batch_index, is_weight, W, b, td, split=split, phase=2, images=images)   # tiles
         self.optimizer.step(bias_dev=bias, polyak=(self.target_flat, cfg.tau))
         with torch.cuda.stream(side):
             side.wait_event(fork)
@@ -725,12 +746,19 @@ class RainbowDQNTrainer:
         lb["tracker"].k, lb["tracker"].episodes = 0, 0
         return lb
 
-    def _vector_step(self, lb, obs, nxt, ep_ret, done, rec=None, chain=False, act_heads=None):
+    def _vector_step(self, lb, obs, nxt, ep_ret, done, rec=None, chain=False, act_heads=None, draw_dev=None, fc2_img=None):
         """One vector step of :363-405 up to (not including) the update.  rec: this step's StepChunk record views
-        when the step is being captured (every per-step scalar then comes from the device)."""
+        when the step is being captured (every per-step scalar then comes from the device).  draw_dev: the step's
+        `sample` record — the proportional draw (:220-243) reads the tree and the record, not the transitions, so it
+        follows the new priorities on the tree's stream, beside the acting launch; returns whether it was issued."""
         env, m = self.env, self.memory
         push = None if rec is None else rec["push"]
         m.stage_tree(self._side, dev=push, chain=chain)   # this step's new priorities, beside the acting forward + env step
+        drawn = False
+        if draw_dev is not None and m._tree_ahead is not None:
+            with torch.cuda.stream(m._tree_ahead):
+                m.draw(0, 1, out=self._g_draw, dev=draw_dev)
+            drawn = True
         if rec is not None and act_heads is None:
             for layer, c in ((self.policy_net.advantage, rec["noise"][0:8]), (self.policy_net.value, rec["noise"][8:16])):
                 layer.dev_counters = iter([c])
@@ -740,15 +768,17 @@ class RainbowDQNTrainer:
             p = self.policy_net
             if act_heads is None:
                 layers = [self._noisy_fields(mod, **mod.noise_source()[0]) for mod in (p.advantage, p.value)]
-                W, b = ops.noisy_combine(layers, training=True)
-            else:
+                ims = self._fc2_images(update=False)
+                W, b = ops.noisy_combine(layers, training=True, images=ims)
+                fc2_img = None if ims is None else ims[0][1]
+            else:                     # fc2_img: rebuilt by the caller's launch, or None
                 W, b = act_heads
             if rec is None:
                 self.total_steps += env.n                 # select_action's count (:301)
             emitted = ops.rainbow_act_step(self._fused_state()["act"], env, obs, nxt, W, b, pushes=m.pushes, cursor=m.count,
-                                           push_dev=push, done_out=done, ep_ret_out=ep_ret, ep_stats=env.ep_stats)
+                                           push_dev=push, done_out=done, ep_ret_out=ep_ret, ep_stats=env.ep_stats, fc2_img=fc2_img)
             m.after_push(emitted, push)
-            return
+            return drawn
         action = self.select_action(obs) if rec is None else self.select_action(obs, count=False)
         env.step(action, nxt, lb["rew"], done_out=done, term_obs_out=lb["tobs"], ep_ret_out=ep_ret, ep_len_out=lb["ep_len"])
         # :376 terminal = done and step != max_steps_per_episode - 1: decided by the step INDEX inside the
@@ -761,6 +791,7 @@ class RainbowDQNTrainer:
         else:                                                        # the same flag, formed inside the n-step push
             m.store_transition(obs, action, lb["rew"], lb["tobs"], None, done, dev=push, ep_len=lb["ep_len"],
                                max_len=self.max_steps_per_episode)
+        return drawn
 
     def _chunk_body(self, lb, j):
         """Vector step j of a StepChunk capture: acting + env + store + proportional draw + update, every per-step
@@ -781,12 +812,16 @@ class RainbowDQNTrainer:
             # eight layer entries, the draws in the eager order — and a launch leaves the chain adam -> heads -> acting
             for i, layer in enumerate(layers):
                 layer.dev_counters = iter([noise[8 * i:8 + 8 * i], noise[16 + 8 * i:24 + 8 * i], noise[32 + 8 * i:40 + 8 * i]])
-            W, b, eps = self._noisy_heads3(with_acting=True)
+            W, b, eps = self._noisy_heads3(with_acting=True, images=True)
+            img = self._fused_state()["img"]
             A1 = self.policy_net.advantage.out_features + 1
-            self._vector_step(lb, obs, nxt, tr.ret[j], tr.done[j], rec, chain=j > 0 and OVERLAP_TREE, act_heads=(W[:A1], b[:A1]))
-            self.memory.draw(0, 1, out=self._g_draw, dev=ch.view(j, "sample"))
+            drawn = self._vector_step(lb, obs, nxt, tr.ret[j], tr.done[j], rec, chain=j > 0 and OVERLAP_TREE,
+                                      act_heads=(W[:A1], b[:A1]), draw_dev=ch.view(j, "sample"),
+                                      fc2_img=None if img is None else img[0])
+            if not drawn:
+                self.memory.draw(0, 1, out=self._g_draw, dev=ch.view(j, "sample"))
             self._update_body_fused(self._g_draw[0], self._g_draw[2], bias=ch.view(j, "adam", torch.float32),
-                                    join=j == ch.K - 1 or not OVERLAP_TREE, heads=(W[A1:], b[A1:], eps))
+                                    join=j == ch.K - 1 or not OVERLAP_TREE, heads=(W[A1:], b[A1:], eps), images=img)
         else:
             self._vector_step(lb, obs, nxt, tr.ret[j], tr.done[j], rec, chain=j > 0 and OVERLAP_TREE)
             self.memory.draw(0, 1, out=self._g_draw, dev=ch.view(j, "sample"))

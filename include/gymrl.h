@@ -572,6 +572,15 @@ int gymrl_noisy_combine(const gymrl_noisy_layer* layers, int n_layers, int K, in
                         void* stream);
 int gymrl_noisy_split(const gymrl_noisy_layer* layers, int n_layers, int K, int training, const float* dW, const float* db,
                       int accumulate, void* stream);
+/* MFMA-operand images of a square Linear weight W [H][H] (H % 16 == 0), csrc/lin_device.hpp: the forward operand (lane (r, q) of
+ * (tile t, step c) holds W[16t + r][16c + 4q .. + 3]) and the input-gradient operand (W[16c + 4q .. + 3][16t + r]), one contiguous
+ * 1 KiB block per wave-wide load — what a slab kernel streams 2-3x faster than nn.Linear's rows.  Either output may be NULL. */
+typedef struct { const float* W; int H; float* img_fwd; float* img_bwd; } gymrl_weight_image;
+#define GYMRL_NOISY_MAX_IMAGES 4
+/* gymrl_noisy_combine and, on extra workgroups of the SAME launch, n_images (<= GYMRL_NOISY_MAX_IMAGES) weight images rebuilt from
+ * the parameters as they are: Rainbow's vector step has this launch between the optimiser step and the acting forward anyway. */
+int gymrl_noisy_combine_images(const gymrl_noisy_layer* layers, int n_layers, int K, int training, float* W_out, float* b_out,
+                               const gymrl_weight_image* images, int n_images, void* stream);
 int gymrl_dueling_bwd(const float* dq, int B, int A, float* dS_out, void* stream);
 
 /* ================================================ mHC backbone ============== */
@@ -1169,6 +1178,7 @@ typedef struct {
   float* r_state; uint32_t* r_action; float* r_reward; float* r_next; uint8_t* r_flag; int64_t cap, cursor;
   const int64_t* push_dev;                   /* {pushes, cursor} from the device (hipGraph replay) or NULL */
   int32_t* action_out; float* rew_out; uint8_t* done_out; float* ep_ret_out; double* ep_stats;   /* any may be NULL */
+  const float* fc2_img;                      /* forward weight image of fc2_w (gymrl_weight_image; H % 16 == 0) or NULL: read in place */
 } gymrl_rainbow_act_args;
 typedef struct {
   int B, D, A, H;
@@ -1188,6 +1198,10 @@ typedef struct {
    * d mu = dW, d sigma = dW * eps with the SECOND draw's epsilons (rainbow_dqn_cartpole.py:92-93 under autograd) */
   int split_heads;
   float* dw_mu[2]; float* dw_sigma[2]; float* db_mu[2]; float* db_sigma[2]; const float* w_eps[2]; const float* b_eps[2];
+  /* Weight images of the H x H layer (H % 16 == 0; gymrl_weight_image) or NULL (read in place): p_fc2_w forward and
+   * input-gradient, t_fc2_w forward.  The CALLER keeps them equal to the parameters: the Rainbow trainer rebuilds all three in
+   * the step's gymrl_noisy_combine_images launch, between the optimiser step and the next acting forward. */
+  const float* p_fc2_img_f; const float* p_fc2_img_b; const float* t_fc2_img_f;
 } gymrl_rainbow_update_args;
 size_t gymrl_rainbow_update_workspace_bytes(int B, int D, int A, int H);
 size_t gymrl_rainbow_args_bytes(int which);  /* sizeof(gymrl_rainbow_act_args) (0) / sizeof(gymrl_rainbow_update_args) (1) */
