@@ -408,9 +408,12 @@ def main():
         a.envs = 8192 if a.algo == "rainbow" else 4096
     short = a.algo in ("sac", "rainbow")
     if a.steps is None:
-        a.steps = 100 if short else 3
+        a.steps = 200 if short else 3
     if a.warmup is None:
-        a.warmup = 20 if short else 1
+        # sac / rainbow: a step is 16 vector steps = ~1.5 ms of a FEW compute units' work, and the shader clock climbs from its
+        # idle level over the first ~0.2 s of such a load (measured: 20 warm-up steps = 30 ms gave 33-34 M env-steps/s for SAC in
+        # every process but a box's first, 41.7 M there and 39 M over 400 timed steps) — the default warm-up covers the ramp
+        a.warmup = 300 if short else 1
     if a.envs < 1:
         ap.error("--envs must be >= 1")
     if a.backend == "gloo" and not a.spawn_selftest:

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(1024) void per_small_kernel(SmallArgs a) {
 // that writes the leaves, into the workspace; the ancestor launch is then ~B small independent node updates.  Rounds 3-5 had
 // every depth's workgroup rebuild the whole tree in 64-131 KB of LDS: 13 us alone, but 25-30 us in a Rainbow vector step,
 // where it runs on the tree's stream beside the acting launch (whose 256 x 16 waves hold every compute unit) and was the end
-// of the step's critical chain (profiles/r05_rainbow_timeline.txt).
+// of the step's critical chain (profiles/r05_rainbow_timeline_before.txt; after: r05_rainbow_timeline.txt).
 constexpr int kSegChunk = 512;                           // batch leaves per workgroup of launch 1
 constexpr int kSegTop = per::kStoreChunk / kSegChunk;    // <= 16 chunk roots: the levels above them are rebuilt where needed
 

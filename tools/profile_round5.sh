@@ -25,6 +25,12 @@ prof bench python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline
 prof ppo_full python /root/repo/bench.py --algo ppo_full --rollout 256 --steps 1 --warmup 1
 prof rainbow python /root/repo/bench.py --algo rainbow --steps 10 --warmup 2
 prof sac python /root/repo/bench.py --algo sac --steps 10 --warmup 2
+# two vector steps of each off-policy chunk on the queue timeline (tools/trace_steps.py)
+for a in rainbow:rainbow_act_kernel sac:sac_act_kernel; do
+  rm -rf /tmp/t_${a%%:*}
+  timeout -k 5 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/t_${a%%:*} -- python /root/repo/bench.py --algo ${a%%:*} --steps 64 --warmup 32 > /dev/null 2>&1
+  python /root/repo/tools/trace_steps.py "$(find /tmp/t_${a%%:*} -name '*kernel_trace.csv' | head -1)" ${a##*:} 2 > "$OUT/${a%%:*}_timeline.txt"
+done
 prof sac_bigbatch python /root/repo/bench.py --algo sac --batch 4096 --steps 4 --warmup 1
 prof rainbow_bigbatch python /root/repo/bench.py --algo rainbow --batch 8192 --steps 4 --warmup 1
 export GYMRL_PMC_PROVENANCE="$OUT/pmc_provenance.json"
