@@ -42,7 +42,7 @@ SYMBOLS = [
     "gymrl_mlp_packed_floats", "gymrl_mlp_pack", "gymrl_mlp_forward",
     "gymrl_mlp_train_workspace_bytes", "gymrl_linear_tanh_smallk", "gymrl_tanh_inplace", "gymrl_tanh_bwd_colsum",
     "gymrl_linear_smallk_bwd", "gymrl_heads_fwd_tanh", "gymrl_heads_bwd", "gymrl_rollout_lunar", "gymrl_rollout_cartpole",
-    "gymrl_gemm_workspace_bytes", "gymrl_linear_fwd", "gymrl_linear_bwd_input",
+    "gymrl_gemm_workspace_bytes", "gymrl_linear_fwd", "gymrl_linear_bwd_input", "gymrl_linear_bwd_input_add",
     "gymrl_linear_bwd_weight_geometry", "gymrl_linear_bwd_weight",
     "gymrl_heads_loss_blocks", "gymrl_heads_loss_fwd_bwd", "gymrl_update_finalize",
     "gymrl_lin_workspace_bytes", "gymrl_lin_fwd", "gymrl_lin_bwd_input", "gymrl_lin_bwd_weight",

@@ -51,7 +51,8 @@ using fin::kCUs;
 // price of reading every activation row from L2 four times instead of twice.
 constexpr int kSlices256 = 2;
 
-enum { EPI_NONE = 0, EPI_TANH = 1, EPI_TANHBWD = 2 };
+enum { EPI_NONE = 0, EPI_TANH = 1, EPI_TANHBWD = 2, EPI_ADD = 3 };     // EPI_ADD: out = acc + H (H: a tensor of the output's shape)
+constexpr bool epi_reads_h(int epi) { return epi == EPI_TANHBWD || epi == EPI_ADD; }
 
 struct WsArgs {
   const float* A; int64_t M; int lda;
@@ -107,7 +108,7 @@ template <int RED, int NT, int RT, bool TRANS_W, int EPI, int LDO, int ABL = 0>
 __global__ __launch_bounds__(256) void gemm_ws_kernel(WsArgs p) {
   constexpr int BN = 32 * NT, NCH = RED / 8, PF = 4, NGR = RT * NT * 4, CPG = NCH / NGR, REG = 4 * RT * NT, SPAN = REG * CPG;
   constexpr int kWaves = 4, kThreads = 256, ROWS = 32 * RT;
-  constexpr int NST = EPI == EPI_TANH ? 6 : (EPI == EPI_TANHBWD ? 3 : 1);    // VALU stages per output element
+  constexpr int NST = EPI == EPI_TANH ? 6 : (EPI == EPI_TANHBWD ? 3 : 1);    // VALU stages per output element (EPI_ADD: 1)
   static_assert(NCH % PF == 0 && NCH % NGR == 0 && CPG >= 1 && 4 * NST <= SPAN - 1, "epilogue groups per chunk");
   static_assert(RED * BN * 4 <= 128 * 1024, "weight slice must fit LDS");
   __shared__ float lds[RED * BN + BN];                 // [q = 2c + h][n][4]: value W(red = 4q + e, n); then bias[BN]
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(WsArgs p) {
       }
     }
   }
-  if (tid < BN) lds[RED * BN + tid] = (EPI != EPI_TANHBWD && p.bias) ? p.bias[n0 + tid] : 0.0f;
+  if (tid < BN) lds[RED * BN + tid] = (!epi_reads_h(EPI) && p.bias) ? p.bias[n0 + tid] : 0.0f;
   __syncthreads();
 
   const int64_t M = p.M;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(WsArgs p) {
     return make_rsrc(p.out + task * ROWS * LDO + n0, r * LDO * 4u - (r ? n0 * 4u : 0u));
   };
   auto h_rsrc = [&](int64_t task) {
-    const uint32_t r = (EPI == EPI_TANHBWD && p.H) ? rows_of(task) : 0u;
+    const uint32_t r = (epi_reads_h(EPI) && p.H) ? rows_of(task) : 0u;
     return make_rsrc(p.H + task * ROWS * LDO + n0, r * LDO * 4u - (r ? n0 * 4u : 0u));
   };
   // group G = (rt, nt, g): 4 adjacent outputs of one row
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(WsArgs p) {
       if (k == 1) x = 1.0f - x;
       if (k == 2) x = p.H ? v * x : v;
     }
+    if constexpr (EPI == EPI_ADD) x = v + hval;
     return x;
   };
 
@@ -244,8 +246,8 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(WsArgs p) {
 #pragma unroll
           for (int n2 = 0; n2 < NT; ++n2) bn[n2] = (ABL & 2) ? bc[n2] : bl[(size_t)((c + 1) % NCH) * 2 * BN + 32 * n2];
         }
-        if (R == 0 && EPI != EPI_TANHBWD) bv = bias4[(32 * ((G / 4) % NT) + 8 * (G % 4)) / 4];
-        if (EPI == EPI_TANHBWD && R == 8)           // H of group G + HD - 1 (past the tile's last group: this tile's own)
+        if (R == 0 && !epi_reads_h(EPI)) bv = bias4[(32 * ((G / 4) % NT) + 8 * (G % 4)) / 4];
+        if (epi_reads_h(EPI) && R == 8)             // H of group G + HD - 1 (past the tile's last group: this tile's own)
           hring[(G + HD - 1) % HD] = (G + HD - 1 < NGR) ? bload4(ph, group_off(G + HD - 1)) : bload4(chh, group_off(G + HD - 1 - NGR));
         if (c == 0 && e == 0) {
           f32x16 z;
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(WsArgs p) {
 #pragma unroll
   for (int G = 0; G < NGR; ++G) {
     f32x4 hq = hring[G % HD], x4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (EPI == EPI_TANHBWD && G >= HD - 1) hq = bload4(ph, group_off(G));
+    if (epi_reads_h(EPI) && G >= HD - 1) hq = bload4(ph, group_off(G));
     const f32x4 b4 = bias4[(32 * ((G / 4) % NT) + 8 * (G % 4)) / 4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -737,6 +739,17 @@ int gymrl_linear_bwd_input(const float* dY, const float* W, const float* H, int6
     if (N == 64) launch_ns<64, 2, true, EPI_TANHBWD, 64>(a, s);
     else launch_ns<128, 2, true, EPI_TANHBWD, 64>(a, s);
   }
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_linear_bwd_input_add(const float* dY, const float* W, const float* G, int64_t B, int N, int K, float* dX, void* stream) {
+  if (!dY || !W || !G || !dX || B < 0 || N != 256 || K != 128 || !al16(dY) || !al16(W) || !al16(dX) || !al16(G)) return -22;
+  if (B == 0) return 0;
+  WsArgs a{};
+  a.A = dY; a.M = B; a.lda = N; a.W = W; a.ldw = K; a.out = dX; a.ldo = K; a.H = G; a.ldh = K;
+  a.slices = 1;
+  launch_ws<256, 4, 2, true, EPI_ADD, 128>(a, ws_row_groups(B, 64, 1), (hipStream_t)stream);
   GYMRL_CHECK_LAUNCH();
   return 0;
 }

@@ -208,6 +208,56 @@ class _WideLinear(torch.autograd.Function):
         return dx, dw, db
 
 
+class _WideLinearPair(torch.autograd.Function):
+    """Two `_WideLinear` layers of the (256, 128) shape on ONE input (PPO-full's actor.mlp.0 and critic.mlp.0 on the backbone's
+    output): the same forward launches, and the backward adds the second layer's input gradient to the first one's inside its
+    GEMM's epilogue (gymrl_linear_bwd_input_add) — as two autograd nodes the sum was a torch add over [B, 128] per micro-batch,
+    16 ms of config 5's update.  a + b either way: the same bits."""
+
+    @staticmethod
+    def forward(ctx, x, wa, ba, wc, bc):
+        from . import ops
+        x = x.contiguous()
+        ctx.save_for_backward(x, wa, wc)
+        ctx.sinks = [(getattr(w, "_gymrl_sink", None), getattr(b, "_gymrl_sink", None)) for w, b in ((wa, ba), (wc, bc))]
+        B = x.shape[0]
+        ya = ops.linear_fwd(x, wa, ba, torch.empty(B, wa.shape[0], device=x.device), act=False)
+        yc = ops.linear_fwd(x, wc, bc, torch.empty(B, wc.shape[0], device=x.device), act=False)
+        return ya, yc
+
+    @staticmethod
+    def backward(ctx, dya, dyc):
+        from . import ops
+        x, wa, wc = ctx.saved_tensors
+        dya, dyc = dya.contiguous(), dyc.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            ga = ops.linear_bwd_input(dya, wa, None, torch.empty_like(x))
+            dx = ops.linear_bwd_input_add(dyc, wc, ga, torch.empty_like(x))
+        grads = []
+        for k, (dy, w) in enumerate(((dya, wa), (dyc, wc))):
+            dw = db = None
+            if ctx.needs_input_grad[1 + 2 * k]:
+                slot = GradSink_direct(ctx.sinks[k][0], ctx.sinks[k][1], True)
+                if slot is not None:
+                    ops.lin_bwd_weight(dy, None, x, slot[0], slot[1], accumulate=slot[2])
+                else:
+                    dw, db = torch.empty_like(w), torch.empty(w.shape[0], dtype=w.dtype, device=w.device)
+                    ops.lin_bwd_weight(dy, None, x, dw, db)
+            grads += [dw, db]
+        return (dx, *grads)
+
+
+def wide_linear_pair(x, la, lc):
+    """(la(x), lc(x)) for two bias-carrying (256, 128) `SmallLinear` layers without activation at >= 16384 rows, or None when
+    the pair is not that shape (the caller then runs the layers one by one)."""
+    from . import ops
+    ok = (all(isinstance(l, SmallLinear) and l.act in (None, "none") and l.bias is not None and tuple(l.weight.shape) == (256, 128)
+              and l.weight.is_contiguous() and _wide(x, l.weight) and not _fusable(x, l.weight) for l in (la, lc))
+          and x.is_contiguous() and x.data_ptr() % 16 == 0 and ops.linear_shape_ok(128, 256))
+    return _WideLinearPair.apply(x, la.weight, la.bias, lc.weight, lc.bias) if ok else None
+
+
 def _act_torch(z, act, clamp):
     if act == "relu":
         return F.relu(z)

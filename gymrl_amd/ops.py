@@ -829,6 +829,17 @@ def linear_bwd_input(dy, W, H, dx):
     return dx
 
 
+def linear_bwd_input_add(dy, W, g, dx):
+    """dx [B, 128] = g + dy [B, 256] W[256, 128]: a second Linear's input gradient added to the first one's in the epilogue."""
+    B, N = dy.shape
+    if g.shape != dx.shape or g.data_ptr() == dx.data_ptr():
+        raise ValueError("linear_bwd_input_add: g and dx are two tensors of one shape")
+    check(lib().gymrl_linear_bwd_input_add(_ptr(dy, torch.float32), _ptr(W, torch.float32), _ptr(g, torch.float32),
+                                           C.c_int64(B), C.c_int(N), C.c_int(W.shape[1]), _ptr(dx, torch.float32), _stream()),
+          "gymrl_linear_bwd_input_add")
+    return dx
+
+
 def linear_bwd_weight_geometry(B, N):
     s, r = C.c_int(0), C.c_int64(0)
     check(lib().gymrl_linear_bwd_weight_geometry(C.c_int64(B), C.c_int(N), C.byref(s), C.byref(r)),

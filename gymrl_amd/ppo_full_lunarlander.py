@@ -24,7 +24,7 @@ from . import ops
 from .graphs import capture as gcapture
 from .envs import VecEnv
 from .flat import FusedAdam, GradSink, flatten_module
-from .nn import GradSink_direct, SmallLinear, skinny_matmul
+from .nn import GradSink_direct, SmallLinear, skinny_matmul, wide_linear_pair
 
 
 class Config:
@@ -74,6 +74,7 @@ FUSED_POLICY = True         # rollout forward as ONE launch (gymrl_mhc_policy_fo
 POLICY_IMAGE = True         # ... the persistent rollout reading its wide weights from a packed image (gymrl_mhc_policy_pack, once per rollout)
 FUSED_SUB_FORWARD = True    # ... and its forward as ONE launch when D = 128 (False: gates + Linear + combine launches)
 FUSED_HEAD_TAIL = True      # training pass: a head's SiLU -> RMSNorm -> output Linear as one launch each way
+FUSED_HEAD_PAIR = True      # training pass: actor.mlp.0 and critic.mlp.0 as one autograd node (their input gradients added in the GEMM)
 FUSED_SUB_BACKWARD = True   # ... and its backward as ONE launch + the Linear's weight gradient (False: the five backward launches)
 FUSED_SUB = True            # training pass: a whole hyper-connection sub-block as one autograd node (3 launches forward, 7 backward)
 FUSED_NORM = True           # training pass: RMSNorm (+ the SiLU before it) as one launch each way
@@ -417,9 +418,12 @@ class MLP(nn.Module):
                 layers += [nn.SiLU(), RMSNorm(dims[i + 1])]
         self.mlp = nn.Sequential(*layers)
 
-    def forward(self, x):
+    def forward(self, x, first=None):
+        """first: the output of mlp.0 computed by the caller (ActorCritic: both heads' first layers as one autograd node)."""
         mods = list(self.mlp)
         i = 0
+        if first is not None:
+            x, i = first, 1
         while i < len(mods):
             if (FUSED_HEAD_TAIL and FUSED_NORM and i + 3 == len(mods) and isinstance(mods[i], nn.SiLU) and isinstance(mods[i + 1], RMSNorm)
                     and isinstance(mods[i + 2], SmallLinear) and getattr(mods[i + 2], "act", None) in (None, "none")
@@ -481,6 +485,9 @@ class ActorCritic(nn.Module):
 
     def forward(self, x):
         x = self.shared(x)
+        pair = wide_linear_pair(x, self.actor.mlp[0], self.critic.mlp[0]) if FUSED_HEAD_PAIR and x.is_cuda and x.dim() == 2 else None
+        if pair is not None:        # the two heads' first layers share their input: ONE autograd node, no gradient add pass
+            return self.actor(x, first=pair[0]), self.critic(x, first=pair[1])
         return self.actor(x), self.critic(x)
 
     @torch.no_grad()

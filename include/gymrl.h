@@ -829,6 +829,10 @@ int gymrl_linear_fwd(const float* X, const float* W, const float* b, int64_t B, 
                      float* Y, void* stream);
 int gymrl_linear_bwd_input(const float* dY, const float* W, const float* H, int64_t B, int N, int K,
                            float* dX, void* stream);
+/* dX [B, K] = G + dY W for the (N, K) = (256, 128) layer: the input gradient of a SECOND Linear on the same input added to the
+ * first one's in the GEMM's epilogue (PPO-full's actor and critic heads both read the backbone's output: the separate add was a
+ * 0.8 GB pass per 524 288-row micro-batch).  Same sums as gymrl_linear_bwd_input followed by G + . ; G may not alias dX. */
+int gymrl_linear_bwd_input_add(const float* dY, const float* W, const float* G, int64_t B, int N, int K, float* dX, void* stream);
 int gymrl_linear_bwd_weight_geometry(int64_t B, int N, int* slices, int64_t* rows_per_slice);
 int gymrl_linear_bwd_weight(const float* dY, const float* X, int64_t B, int N, int K, float* dW,
                             float* db, void* workspace, void* stream);

@@ -132,3 +132,36 @@ def test_persistent_rollout_is_bit_identical_to_the_step_loop(N, T, variant):
     assert T >= 1000 or torch.equal(sa, sb)
     assert torch.equal(adv_a, adv_b) and torch.equal(ret_a, ret_b)
     assert a.step_count == b.step_count and a.rollout_count == b.rollout_count
+
+
+def test_head_pair_node_equals_two_linear_nodes():
+    """ActorCritic.forward with actor.mlp.0 and critic.mlp.0 as ONE autograd node (nn._WideLinearPair: the critic layer's input
+    gradient added to the actor layer's inside gymrl_linear_bwd_input_add's epilogue) against the two `_WideLinear` nodes whose
+    input gradients autograd adds with a torch kernel: outputs and every parameter gradient bit for bit (a + b either way), at a
+    row count the wide kernels take, with a ragged last row tile."""
+    from gymrl_amd import ops
+    from gymrl_amd import ppo_full_lunarlander as pf
+    torch.manual_seed(5)
+    net = pf.ActorCritic(8, 4).cuda()
+    x = torch.randn(16384 + 40, 8, device="cuda")
+    runs = []
+    try:
+        for flag in (False, True):
+            pf.FUSED_HEAD_PAIR = flag
+            net.zero_grad(set_to_none=True)
+            logits, value = net(x)
+            (logits.square().sum() + 0.5 * value.square().sum() + (logits[:, 0] * value[:, 0]).sum()).backward()
+            runs.append((logits.detach().clone(), value.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters()}))
+    finally:
+        pf.FUSED_HEAD_PAIR = True
+    (la, va, ga), (lb, vb, gb) = runs
+    assert torch.equal(la, lb) and torch.equal(va, vb)
+    for n in ga:
+        assert torch.isfinite(gb[n]).all() and torch.equal(ga[n], gb[n]), n
+    # the entry itself: dx = g + dy W against the two-step form
+    g = torch.Generator(device="cuda").manual_seed(1)
+    dy, W = torch.randn(16384 + 40, 256, device="cuda", generator=g), torch.randn(256, 128, device="cuda", generator=g)
+    G = torch.randn(16384 + 40, 128, device="cuda", generator=g)
+    two = G + ops.linear_bwd_input(dy, W, None, torch.empty_like(G))
+    one = ops.linear_bwd_input_add(dy, W, G, torch.empty_like(G))
+    assert torch.equal(one, two)
