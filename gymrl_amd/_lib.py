@@ -208,7 +208,8 @@ class WeightImage(C.Structure):           # gymrl_weight_image
 
 class PPOFullCfg(C.Structure):
     _fields_ = [("clip_eps_min", C.c_float), ("clip_eps_max", C.c_float), ("dual_clip", C.c_float),
-                ("erc_beta_low", C.c_float), ("erc_beta_high", C.c_float), ("entropy_coef", C.c_float)]
+                ("erc_beta_low", C.c_float), ("erc_beta_high", C.c_float), ("entropy_coef", C.c_float),
+                ("entropy_coef_dev", C.c_void_p)]
 
 
 def lib():

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void ppo_full_loss_kernel(
     const float ms = fminf(s1, s2);
     const float dms_dr = w1 * ad * in1 + (1.0f - w1) * ad * in2;
     const float g_lp = -invB * corr * dms_dr * ratio;
-    const float g_H = -cfg.entropy_coef * invB * corr;
+    const float g_H = -(cfg.entropy_coef_dev ? cfg.entropy_coef_dev[0] : cfg.entropy_coef) * invB * corr;
     float dz[A];
 #pragma unroll
     for (int k = 0; k < A; ++k) {
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void ppo_rnn_loss_kernel(
     const float dms_dr = w1 * ad * in1 + (1.0f - w1) * ad * in2;
     const float scale = corr * inv;
     const float g_lp = -scale * dms_dr * ratio;
-    const float g_H = -cfg.entropy_coef * scale;
+    const float g_H = -(cfg.entropy_coef_dev ? cfg.entropy_coef_dev[0] : cfg.entropy_coef) * scale;
     float dz[A];
 #pragma unroll
     for (int k = 0; k < A; ++k) {

@@ -179,12 +179,14 @@ def ppo_loss_fwd_bwd(logits, value, act, logp_old, adv, ret, cfg, idx=None, adv_
 
 
 def ppo_full_loss_fwd_bwd(logits, value, act, logp_old, ent_old, adv, ret, cfg, idx=None, dlogits_out=None,
-                          dvalue_out=None, metrics_sum=None, workspace=None, corr_mul=None):
-    """L3 (ppo_full_lunarlander.py:575-652)."""
+                          dvalue_out=None, metrics_sum=None, workspace=None, corr_mul=None, entropy_coef_dev=None):
+    """L3 (ppo_full_lunarlander.py:575-652).  entropy_coef_dev: f32[1] on the device that overrides cfg's entropy coefficient
+    (a captured graph replayed across updates)."""
     B, A = logits.shape
     dlogits_out = torch.empty_like(logits) if dlogits_out is None else dlogits_out
     dvalue_out = torch.empty(B, dtype=torch.float32, device=logits.device) if dvalue_out is None else dvalue_out
     c = PPOFullCfg(*cfg)
+    c.entropy_coef_dev = None if entropy_coef_dev is None else _ptr(entropy_coef_dev, torch.float32).value
     if metrics_sum is not None and workspace is None:
         workspace = _reduce_ws(logits.device)
     check(lib().gymrl_ppo_full_loss_fwd_bwd(_ptr(logits, torch.float32), _ptr(value, torch.float32),

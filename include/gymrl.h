@@ -247,6 +247,8 @@ typedef struct {
   float erc_beta_low;  /* :39 (0.06)                        */
   float erc_beta_high; /* :40 (0.06)                        */
   float entropy_coef;  /* current (annealed) value, :662-666 */
+  const float* entropy_coef_dev;   /* the same from device memory (a hipGraph replayed across updates: the coefficient is
+                                    * annealed after every update) or NULL */
 } gymrl_ppo_full_cfg;
 
 /* L3: ppo_full update_model minibatch loss — ppo_full_lunarlander.py:575-652.
