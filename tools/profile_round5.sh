@@ -5,6 +5,23 @@ set -u
 OUT=/root/repo/gpurun_out/$1
 mkdir -p "$OUT"
 cd /root/repo
+# PMC passes first: the summary they produce is stamped with this library's sha256, and bench.py attaches `traffic` / `clock`
+# to the lines below only from a summary whose stamp matches the library it loads
+pushd /tmp > /dev/null && export TMPDIR=/tmp
+export GYMRL_PMC_PROVENANCE="$OUT/pmc_provenance.json"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/p_$c
+  timeout -k 5 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/p_$c -- python /root/repo/tools/pmc_gemm.py > /dev/null 2>&1
+  cp "$(find /tmp/p_$c -name '*counter_collection.csv' | head -1)" "$OUT/pmc_${c}_counter_collection.csv"
+done
+rm -rf /tmp/p_sq
+timeout -k 5 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d /tmp/p_sq -- python /root/repo/tools/pmc_gemm.py > /dev/null 2>&1
+cp "$(find /tmp/p_sq -name '*counter_collection.csv' | head -1)" "$OUT/pmc_gemm_sq.csv"
+cp "$(find /tmp/p_sq -name '*kernel_trace.csv' | head -1)" "$OUT/pmc_gemm_sq_trace.csv"
+python /root/repo/tools/pmc_gemm_summarise.py "$OUT/pmc_FETCH_SIZE_counter_collection.csv" "$OUT/pmc_WRITE_SIZE_counter_collection.csv" \
+  "$OUT/pmc_gemm_sq.csv" "$OUT/pmc_gemm_sq_trace.csv" /root/repo/profiles/r05_pmc_summary.json "$OUT/pmc_provenance.json" > /dev/null
+cp /root/repo/profiles/r05_pmc_summary.json "$OUT/pmc_summary.json"
+popd > /dev/null
 timeout 600 python bench.py > "$OUT/bench_final.json" 2> "$OUT/bench_final.err"
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_20steps.json" 2> /dev/null
 timeout 300 python bench.py --algo ppo_full --steps 3 --warmup 1 > "$OUT/bench_ppo_full.json" 2> /dev/null
@@ -33,16 +50,6 @@ for a in rainbow:rainbow_act_kernel sac:sac_act_kernel; do
 done
 prof sac_bigbatch python /root/repo/bench.py --algo sac --batch 4096 --steps 4 --warmup 1
 prof rainbow_bigbatch python /root/repo/bench.py --algo rainbow --batch 8192 --steps 4 --warmup 1
-export GYMRL_PMC_PROVENANCE="$OUT/pmc_provenance.json"
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/p_$c
-  timeout -k 5 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/p_$c -- python /root/repo/tools/pmc_gemm.py > /dev/null 2>&1
-  cp "$(find /tmp/p_$c -name '*counter_collection.csv' | head -1)" "$OUT/pmc_${c}_counter_collection.csv"
-done
-rm -rf /tmp/p_sq
-timeout -k 5 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d /tmp/p_sq -- python /root/repo/tools/pmc_gemm.py > /dev/null 2>&1
-cp "$(find /tmp/p_sq -name '*counter_collection.csv' | head -1)" "$OUT/pmc_gemm_sq.csv"
-cp "$(find /tmp/p_sq -name '*kernel_trace.csv' | head -1)" "$OUT/pmc_gemm_sq_trace.csv"
 ls -la "$OUT"
 for f in final 20steps ppo_full sac rainbow sac_bigbatch rainbow_bigbatch; do python -c "
 import json
