@@ -40,7 +40,7 @@ SYMBOLS = [
     "gymrl_noisy_action", "gymrl_mse_loss", "gymrl_neg_mean_loss",
     "gymrl_dsac_target", "gymrl_dsac_critic_loss", "gymrl_dsac_actor_loss", "gymrl_dsac_alpha_step",
     "gymrl_mlp_packed_floats", "gymrl_mlp_pack", "gymrl_mlp_forward",
-    "gymrl_mlp_train_workspace_bytes", "gymrl_linear_tanh_smallk", "gymrl_tanh_inplace", "gymrl_tanh_bwd_colsum",
+    "gymrl_mlp_train_workspace_bytes", "gymrl_linear_tanh_smallk", "gymrl_linear_smallk", "gymrl_tanh_inplace", "gymrl_tanh_bwd_colsum",
     "gymrl_linear_smallk_bwd", "gymrl_heads_fwd_tanh", "gymrl_heads_bwd", "gymrl_rollout_lunar", "gymrl_rollout_cartpole",
     "gymrl_gemm_workspace_bytes", "gymrl_linear_fwd", "gymrl_linear_bwd_input", "gymrl_linear_bwd_input_add",
     "gymrl_linear_bwd_weight_geometry", "gymrl_linear_bwd_weight",

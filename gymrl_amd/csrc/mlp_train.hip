@@ -114,7 +114,7 @@ __device__ __forceinline__ void load_row(float (&xv)[D], const float* __restrict
 }
 
 // ------------------------------------------------------------------ F1 -------
-template <int D>
+template <int D, bool TANH = true>
 __global__ __launch_bounds__(kTB) void linear_tanh_smallk_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                                  const float* __restrict__ b, int64_t B, int C,
                                                                  float* __restrict__ out) {
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kTB) void linear_tanh_smallk_kernel(const float* __
       float acc = 0.0f;
 #pragma unroll
       for (int d = 0; d < D; ++d) acc = fmaf(xv[d], w[j][d], acc);
-      o[j] = train_tanhf(acc + bias[j]);
+      o[j] = TANH ? train_tanhf(acc + bias[j]) : acc + bias[j];
     }
     __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(out + r * C + 4 * m.c4));
   }
@@ -657,6 +657,22 @@ int gymrl_linear_tanh_smallk(const float* x, const float* W, const float* b, int
     case 3: hipLaunchKernelGGL(linear_tanh_smallk_kernel<3>, grid, block, 0, s, x, W, b, B, C, out); break;
     case 4: hipLaunchKernelGGL(linear_tanh_smallk_kernel<4>, grid, block, 0, s, x, W, b, B, C, out); break;
     case 8: hipLaunchKernelGGL(linear_tanh_smallk_kernel<8>, grid, block, 0, s, x, W, b, B, C, out); break;
+    default: return -22;
+  }
+  GYMRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int gymrl_linear_smallk(const float* x, const float* W, const float* b, int64_t B, int D, int C, float* out, void* stream) {
+  if (!x || !W || !out || B < 0 || !pow2_cols(C) || !al16(out) || !al16(x)) return -22;
+  if (B == 0) return 0;
+  const dim3 grid(grid_for(B, C) * 1), block(kTB);
+  hipStream_t s = (hipStream_t)stream;
+  switch (D) {
+    case 2: hipLaunchKernelGGL((linear_tanh_smallk_kernel<2, false>), grid, block, 0, s, x, W, b, B, C, out); break;
+    case 3: hipLaunchKernelGGL((linear_tanh_smallk_kernel<3, false>), grid, block, 0, s, x, W, b, B, C, out); break;
+    case 4: hipLaunchKernelGGL((linear_tanh_smallk_kernel<4, false>), grid, block, 0, s, x, W, b, B, C, out); break;
+    case 8: hipLaunchKernelGGL((linear_tanh_smallk_kernel<8, false>), grid, block, 0, s, x, W, b, B, C, out); break;
     default: return -22;
   }
   GYMRL_CHECK_LAUNCH();

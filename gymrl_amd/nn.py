@@ -248,6 +248,49 @@ class _WideLinearPair(torch.autograd.Function):
         return (dx, *grads)
 
 
+class _SmallKLinear(torch.autograd.Function):
+    """A Linear layer on 2 / 3 / 4 / 8 inputs at a large batch (PPO-full's input projection at 524 288-row micro-batches): the
+    forward is gymrl_linear_smallk (one fmaf chain per output, 16-byte stores: HBM-bound), the weight + bias gradient the layer
+    kernels' (gymrl_lin_bwd_weight, into an armed GradSink's buffer).  No input gradient: the input is the observation."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        from . import ops
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.sinks = (getattr(w, "_gymrl_sink", None), getattr(b, "_gymrl_sink", None))
+        return ops.linear_smallk(x, w, b, torch.empty(x.shape[0], w.shape[0], device=x.device))
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.mm(dy, w) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            slot = GradSink_direct(ctx.sinks[0], ctx.sinks[1], True)
+            if slot is not None:
+                ops.lin_bwd_weight(dy, None, x, slot[0], slot[1], accumulate=slot[2])
+            else:
+                dw, db = torch.empty_like(w), torch.empty(w.shape[0], dtype=w.dtype, device=w.device)
+                ops.lin_bwd_weight(dy, None, x, dw, db)
+        return dx, dw, db
+
+
+def smallk_linear(x, layer):
+    """layer(x) through `_SmallKLinear` where it applies (>= 16384 rows, 2 / 3 / 4 / 8 inputs, a power-of-two width, bias, no
+    activation), else None."""
+    w = layer.weight
+    ok = (FUSED_LINEAR and isinstance(layer, SmallLinear) and layer.act in (None, "none") and layer.bias is not None
+          and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= 16384 and w.shape[1] in (2, 3, 4, 8)
+          and w.shape[0] >= 4 and (w.shape[0] & (w.shape[0] - 1)) == 0 and w.is_contiguous() and x.is_contiguous()
+          and x.data_ptr() % 16 == 0)
+    if not ok:
+        return None
+    return _SmallKLinear.apply(x, w, layer.bias)
+
+
 def wide_linear_pair(x, la, lc):
     """(la(x), lc(x)) for two bias-carrying (256, 128) `SmallLinear` layers without activation at >= 16384 rows, or None when
     the pair is not that shape (the caller then runs the layers one by one)."""

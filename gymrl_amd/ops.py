@@ -727,6 +727,15 @@ def linear_tanh_smallk(x, W, b, out):
     return out
 
 
+def linear_smallk(x, W, b, out):
+    """out = x W^T + b for a first layer with in_features in {2,3,4,8} and a power-of-two width (no activation)."""
+    B, D = x.shape
+    check(lib().gymrl_linear_smallk(_ptr(x, torch.float32), _ptr(W, torch.float32), _ptr(b, torch.float32, True),
+                                    C.c_int64(B), C.c_int(D), C.c_int(W.shape[0]), _ptr(out, torch.float32), _stream()),
+          "gymrl_linear_smallk")
+    return out
+
+
 def tanh_inplace(z, bias=None):
     """z <- tanh(z + bias) in place; bias [C] broadcasts over the rows of z [..., C]."""
     check(lib().gymrl_tanh_inplace(_ptr(z, torch.float32), C.c_int64(z.numel()), _ptr(bias, torch.float32, True),

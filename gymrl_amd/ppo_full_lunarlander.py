@@ -26,7 +26,7 @@ from . import ops
 from .graphs import capture as gcapture
 from .envs import VecEnv
 from .flat import FusedAdam, GradSink, flatten_module
-from .nn import GradSink_direct, SmallLinear, skinny_matmul, wide_linear_pair
+from .nn import GradSink_direct, SmallLinear, skinny_matmul, smallk_linear, wide_linear_pair
 
 
 class Config:
@@ -371,7 +371,9 @@ class MHCBackbone(nn.Module):
         self.final_norm = RMSNorm(output_dim)
 
     def forward(self, x):
-        z0 = self.input_proj(x)
+        z0 = smallk_linear(x, self.input_proj) if FUSED_SUB and x.is_cuda and x.dim() == 2 else None
+        if z0 is None:
+            z0 = self.input_proj(x)
         # training pass on the one-launch sub-block kernels: the first sub-block reads the projection as the repeated row it is
         # and returns the branches' summed gradient, the final norm sums the branches on load and hands both ONE gradient row —
         # the reference's repeat / sum (:239, :243) and their backward cost four [B, n, D] passes through torch (0.38 ms per

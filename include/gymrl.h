@@ -759,6 +759,10 @@ int gymrl_mhc_policy_forward(const gymrl_mhc_policy* p, const float* obs, int B,
 size_t gymrl_mlp_train_workspace_bytes(int C, int D, int A);
 int gymrl_linear_tanh_smallk(const float* x, const float* W, const float* b, int64_t B, int D, int C,
                              float* out, void* stream);
+/* The same launch without the tanh: out [B, C] = x [B, D] W[C, D]^T + b (D in {2, 3, 4, 8}, C a power of two >= 4), one fmaf chain
+ * per output in ascending d — PPO-full's input projection (ppo_full_lunarlander.py:236: Linear(obs, 128)) at 524 288-row
+ * micro-batches, where the 16 x 16-tile layer kernel writes its 268 MB in 64-byte pieces (152 us; this one: 16-byte stores). */
+int gymrl_linear_smallk(const float* x, const float* W, const float* b, int64_t B, int D, int C, float* out, void* stream);
 int gymrl_tanh_inplace(float* z, int64_t n, const float* bias, int C, void* stream);
 int gymrl_tanh_bwd_colsum(float* dH, const float* H, int64_t B, int C, float* colsum_out,
                           void* workspace, void* stream);
