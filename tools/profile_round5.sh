@@ -27,8 +27,8 @@ timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/benc
 timeout 300 python bench.py --algo ppo_full --steps 3 --warmup 1 > "$OUT/bench_ppo_full.json" 2> /dev/null
 timeout 300 python bench.py --algo sac > "$OUT/bench_sac.json" 2> /dev/null
 timeout 300 python bench.py --algo rainbow > "$OUT/bench_rainbow.json" 2> /dev/null
-timeout 300 python bench.py --algo sac --batch 4096 --steps 30 --warmup 5 > "$OUT/bench_sac_bigbatch.json" 2> /dev/null
-timeout 300 python bench.py --algo rainbow --batch 8192 --steps 30 --warmup 5 > "$OUT/bench_rainbow_bigbatch.json" 2> /dev/null
+timeout 300 python bench.py --algo sac --batch 4096 --steps 30 --warmup 30 > "$OUT/bench_sac_bigbatch.json" 2> /dev/null
+timeout 300 python bench.py --algo rainbow --batch 8192 --steps 30 --warmup 30 > "$OUT/bench_rainbow_bigbatch.json" 2> /dev/null
 timeout 200 python tools/micro_per.py > "$OUT/micro_per.txt" 2> /dev/null
 timeout 200 python tools/probe_rollout_balance.py 2048 > "$OUT/rollout_balance.txt" 2> /dev/null
 cd /tmp && export TMPDIR=/tmp
