@@ -23,7 +23,11 @@ import os
 import sys
 import time
 
-import torch
+# dmabuf IPC only on this driver: RCCL's P2P set-up between the ranks of a node fails with `hipIpcGetMemHandle: invalid argument`
+# under the legacy mode.  Set before the HIP runtime initialises, also when torchrun (not spawn_ranks below) started this process.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
