@@ -899,6 +899,123 @@ __global__ __launch_bounds__(64 * kWaves) void norm_proj_bwd_kernel(const float*
   }
 }
 
+// The backward at D = 256 with four rows per wave (norm_proj_fwd4_kernel's layout): x in 16-byte loads, d x in 16-byte stores, a
+// row's two sums four DPP adds; the per-lane parameter sums (d norm_w, d W2, d b2 over the rows the lane sees) are folded across the
+// four row groups by two butterflies per accumulator at the END, then across the workgroup's waves through LDS as before.
+template <int NO>
+__global__ __launch_bounds__(64 * kWaves) void norm_proj_bwd4_kernel(const float* __restrict__ dl, const float* __restrict__ x,
+                                                                    const float* __restrict__ w, const float* __restrict__ W2, int B,
+                                                                    int n_out, float eps, float* __restrict__ d_x, float* __restrict__ partial) {
+  constexpr int D = 256;
+  extern __shared__ float np_red[];                        // [kWaves][len], len = D + n_out * (D + 1)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 15, grp = lane >> 4;
+  const int len = D + n_out * (D + 1);
+  f32x4 wv[4], W2r[NO][4], acc_w[4], acc_W2[NO][4];
+  float acc_b[NO];
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    wv[q] = *reinterpret_cast<const f32x4*>(w + 64 * q + 4 * sub);
+    acc_w[q] = zero;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      W2r[o][q] = o < n_out ? *reinterpret_cast<const f32x4*>(W2 + (size_t)o * D + 64 * q + 4 * sub) : zero;
+      acc_W2[o][q] = zero;
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < NO; ++o) acc_b[o] = 0.0f;
+  const float inv_d = 1.0f / (float)D;
+  const int64_t quads = ((int64_t)B + 3) >> 2;
+  const int64_t q0 = (int64_t)blockIdx.x * kWaves + wave, qs = (int64_t)gridDim.x * kWaves;
+  auto load = [&](f32x4 (&v)[4], float (&dv)[NO], int64_t quad) {
+    int64_t row = 4 * quad + grp;
+    if (row > B - 1) row = B - 1;
+    const float* xr = x + row * D + 4 * sub;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(xr + 64 * q);
+#pragma unroll
+    for (int o = 0; o < NO; ++o) dv[o] = o < n_out ? dl[row * n_out + o] : 0.0f;
+  };
+  f32x4 cur[4], nxt[4];
+  float dcur[NO], dnxt[NO];
+  if (q0 < quads) load(cur, dcur, q0);
+  for (int64_t quad = q0; quad < quads; quad += qs) {
+    if (quad + qs < quads) load(nxt, dnxt, quad + qs);
+    const int64_t row = 4 * quad + grp;
+    const bool ok = row < B;                               // (rows past the batch: loaded as a copy of the last row, no contribution)
+    f32x4 sv[4], gv[4];
+    float sq = 0.0f, dot = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s1 = silu_(cur[q][e]);
+        float g = 0.0f;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) g += dcur[o] * W2r[o][q][e];
+        sv[q][e] = s1; gv[q][e] = g;
+        sq += s1 * s1;
+        dot += wv[q][e] * g * s1;
+      }
+    sq = row16_sum(sq);
+    dot = row16_sum(dot);
+    const float r = rsqrtf(sq * inv_d + eps);
+    const float k3 = r * r * r * inv_d * dot;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 dx;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dx[e] = (r * wv[q][e] * gv[q][e] - sv[q][e] * k3) * silu_grad_(cur[q][e]);
+        if (ok) {
+          acc_w[q][e] += gv[q][e] * sv[q][e] * r;
+          const float y = sv[q][e] * r * wv[q][e];
+#pragma unroll
+          for (int o = 0; o < NO; ++o) acc_W2[o][q][e] += dcur[o] * y;
+        }
+      }
+      if (ok) *reinterpret_cast<f32x4*>(d_x + row * D + 64 * q + 4 * sub) = dx;
+    }
+    if (ok) {
+#pragma unroll
+      for (int o = 0; o < NO; ++o) acc_b[o] += dcur[o];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) dcur[o] = dnxt[o];
+  }
+  // the four row groups hold the same columns: (g0 + g1) + (g2 + g3)
+  auto fold = [](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
+  float* mine = np_red + (size_t)wave * len;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int d = 64 * q + 4 * sub + e;
+      const float sw = fold(acc_w[q][e]);
+      if (grp == 0) mine[d] = sw;
+#pragma unroll
+      for (int o = 0; o < NO; ++o) {
+        const float s2 = fold(acc_W2[o][q][e]);
+        if (grp == 0 && o < n_out) mine[D + o * D + d] = s2;
+      }
+    }
+#pragma unroll
+  for (int o = 0; o < NO; ++o) {
+    const float sb = fold(acc_b[o]);                       // (every lane of a row group counted its row once: lane 0's view)
+    if (lane == 0 && o < n_out) mine[D + n_out * D + o] = sb;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < len; i += 64 * kWaves) {
+    float sum = np_red[i];
+#pragma unroll
+    for (int w2 = 1; w2 < kWaves; ++w2) sum += np_red[(size_t)w2 * len + i];
+    partial[(size_t)blockIdx.x * len + i] = sum;
+  }
+}
+
 // ---- training pass: a whole sub-block forward in one launch (n = 2, D = 128) ----------------------------------------------
 // gates + Linear + combine of MHCBlock._sub as three launches move 1.34 GB per 262144-row micro-batch (h is read twice, the
 // branch sum and the Linear's output make a round trip each: 120 + 97 + 140 us).  Here a wave carries a 16-row tile through all
@@ -1725,6 +1842,12 @@ int gymrl_norm_proj_bwd(const float* d_out, const float* x, const float* norm_w,
   float* part = static_cast<float*>(workspace);
   const dim3 grid(blocks), block(64 * kWaves);
   const size_t lds = sizeof(float) * (size_t)kWaves * len;
+  const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  // four rows per wave for ONE output (the critic's head: 244 -> 189 us at 524 288 rows).  With four outputs the per-lane weight and
+  // accumulator vectors take 292 registers — one wave per SIMD: 410 us against the one-row kernel's 268 — so n_out > 1 stays there
+  if (D == 256 && n_out == 1 && al16(x) && al16(norm_w) && al16(W2) && al16(d_x))
+    hipLaunchKernelGGL(norm_proj_bwd4_kernel<1>, grid, block, lds, (hipStream_t)stream, d_out, x, norm_w, W2, B, n_out, eps, d_x, part);
+  else
   NORM_PROJ_DISPATCH(norm_proj_bwd_kernel, grid, block, lds, (hipStream_t)stream, d_out, x, norm_w, W2, B, D, n_out, eps, d_x, part);
   ReduceArgs r{part, blocks, len, 3, {D, D + n_out * D, len, 0}, {0, 0, 0, 0}, {d_norm_w, d_W2, d_b2, nullptr}};
   hipLaunchKernelGGL(partial_reduce_kernel, dim3((len + 31) / 32, 1), dim3(256), 0, (hipStream_t)stream, r);
