@@ -149,12 +149,23 @@ def spawn_selftest(a, rank, world):
     gdist.shutdown()
 
 
+def _backend_name():
+    from gymrl_amd import dist as gdist
+    b = gdist.backend() if gdist.collectives_active() else None
+    return "nccl (RCCL)" if b == "nccl" else b
+
+
 def comm_summary(world, reducer, ks, step_s, steps):
     """All-reduce figures of the timed region (SURVEY.md 8(d) "Grad all-reduce" row): the collectives' own durations on the
     communication stream, and how long the compute stream actually stalled on them."""
-    if world <= 1:
+    from gymrl_amd import dist as gdist
+    if not gdist.collectives_active():
         return {"rccl_world_size": 1, "grad_allreduce": None, "moments_allreduce": None}
     out = {"rccl_world_size": world}
+    if world == 1:
+        out["forced"] = ("GYMRL_FORCE_COLLECTIVES=1: ONE rank runs every collective of the multi-GPU path through RCCL (sums over "
+                         "one rank: the result's bits are those of a run without a process group); the figures are the path's "
+                         "fixed cost per collective on this box, not an xGMI measurement")
     st = reducer.stats() if reducer is not None else None
     if st:
         n = max(st["collectives"], 1)
@@ -370,7 +381,7 @@ def main_offpolicy(a, rank, world, local_rank):
                        "ms_per_vector_step": round(dt / vsteps * 1e3, 4), "updates_per_s": round(vsteps * world / dt, 1),
                        "parallelism": f"{world} independent replicas (no exchange step on this path)" if world > 1 else "single GPU"},
             "roofline": roof, "pieces": pieces,
-            "comm": dict(rccl_world_size=world, grad_allreduce=None, backend="nccl (RCCL)" if world > 1 else None, rank_devices=devices),
+            "comm": dict(rccl_world_size=world, grad_allreduce=None, backend=_backend_name(), rank_devices=devices),
         }
         print(json.dumps(out))
         sys.stdout.flush()
@@ -618,7 +629,7 @@ def main_ppo_full(a, rank, world, local_rank):
                          "GBps": round(17.0 * T * N / gae_s / 1e9, 1), "frac": round(17.0 * T * N / gae_s / HBM_PEAK, 4), "launch_s": gae_s},
             "phases": {"rollout_ms": round(ph[0], 1), "gae_ms": round(ph[1], 3), "update_ms": round(ph[2], 1)},
             "train_metrics": {k: float(v) for k, v in (m or {}).items()},
-            "comm": dict(comm_summary(world, tr._reducer, None, dt / a.steps, a.steps), backend="nccl (RCCL)" if world > 1 else None,
+            "comm": dict(comm_summary(world, tr._reducer, None, dt / a.steps, a.steps), backend=_backend_name(),
                          rank_devices=devices),
         }
         print(json.dumps(out))
@@ -748,7 +759,7 @@ def report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev,
                    "rollout_frozen_policy_ms": frozen_ms},
         "train_metrics": {k: float(v) for k, v in (metrics or {}).items()},
         "avg_episode_return": (sum(trainer.episode_rewards) / len(trainer.episode_rewards)) if trainer.episode_rewards else None,
-        "comm": dict(comm_summary(world, trainer._reducer, ks, dt / a.steps, a.steps), backend="nccl (RCCL)" if world > 1 else None,
+        "comm": dict(comm_summary(world, trainer._reducer, ks, dt / a.steps, a.steps), backend=_backend_name(),
                      rank_devices=devices),
     }
     if world == 1 and not a.no_cpu_baseline:

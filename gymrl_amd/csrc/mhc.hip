@@ -1815,7 +1815,11 @@ int gymrl_norm_proj_fwd(const float* x, const float* norm_w, const float* W2, co
   const unsigned want = (unsigned)((B + kWaves - 1) / kWaves);
   const dim3 grid(want > 4096 ? 4096 : want);
   const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  if (D == 256 && al16(x) && al16(norm_w) && al16(W2)) {            // four rows per wave (16-byte loads, 16-lane sums)
+  // The kernel — and with it the summation order, i.e. the result's last bits — is chosen by SHAPE alone: D = 256 takes the
+  // four-row kernel and therefore REQUIRES 16-byte aligned operands (-22 otherwise: the caller copies to an aligned buffer);
+  // a choice by pointer alignment would make the bits depend on where an allocation or a view happens to start.
+  if (D == 256 && !(al16(x) && al16(norm_w) && al16(W2))) return -22;
+  if (D == 256) {                                                   // four rows per wave (16-byte loads, 16-lane sums)
     const unsigned wq = (unsigned)(((B + 3) / 4 + kWaves - 1) / kWaves);
     const dim3 g4(wq > 2048 ? 2048 : wq);
     if (n_out <= 1) hipLaunchKernelGGL(norm_proj_fwd4_kernel<1>, g4, block, 0, (hipStream_t)stream, x, norm_w, W2, b2, B, n_out, eps, out);
@@ -1844,8 +1848,12 @@ int gymrl_norm_proj_bwd(const float* d_out, const float* x, const float* norm_w,
   const size_t lds = sizeof(float) * (size_t)kWaves * len;
   const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   // four rows per wave for ONE output (the critic's head: 244 -> 189 us at 524 288 rows).  With four outputs the per-lane weight and
-  // accumulator vectors take 292 registers — one wave per SIMD: 410 us against the one-row kernel's 268 — so n_out > 1 stays there
-  if (D == 256 && n_out == 1 && al16(x) && al16(norm_w) && al16(W2) && al16(d_x))
+  // accumulator vectors take 292 registers — one wave per SIMD: 410 us against the one-row kernel's 268 — so n_out > 1 stays there.
+  // Chosen by shape alone (gymrl_norm_proj_fwd's rule): D = 256 with one output requires aligned operands.  The backward
+  // recomputes the row's 1 / rms in ITS kernel's summation order — for n_out > 1 at D = 256 not the forward's (four-row) order:
+  // the two values of r can differ in the last bit, a relative 1e-7 on the gradient, the same for every run.
+  if (D == 256 && n_out == 1 && !(al16(x) && al16(norm_w) && al16(W2) && al16(d_x))) return -22;
+  if (D == 256 && n_out == 1)
     hipLaunchKernelGGL(norm_proj_bwd4_kernel<1>, grid, block, lds, (hipStream_t)stream, d_out, x, norm_w, W2, B, n_out, eps, d_x, part);
   else
   NORM_PROJ_DISPATCH(norm_proj_bwd_kernel, grid, block, lds, (hipStream_t)stream, d_out, x, norm_w, W2, B, D, n_out, eps, d_x, part);

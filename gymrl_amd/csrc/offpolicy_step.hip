@@ -50,7 +50,8 @@ struct SacWs {
   double* terms2;                     // [B]: the second Q network's critic term (its workgroup's share of terms[.][0])
   float *xtq[2], *xmisc;              // P1: the two target networks' Q(s', a') columns [16 S] and {reward, done, logp'} [16 S][4], from the
                                       // target-chain workgroups to the critic-chain workgroups (each forms y itself)
-  unsigned int* sync;                 // [16]: gymrl_sac_step's phase counters (0 acting, 1 P1, 2 P2, 3 P3 done; 7 finished workgroups) — zero between launches
+  unsigned int* sync;                 // [16]: gymrl_sac_step's phase counters (0 acting, 1 P1, 2 P2, 3 P3 done; 6 next ticket, 7 finished workgroups);
+                                      // the large-batch row kernels' tickets (slab_grid: 8 / 9 P1's, 10 / 11 P3's) — all zero between launches
   unsigned int* flag;                 // [8][ceil(B / 16)]: hand-off flags (1 = waiting to be consumed; zero before the first launch, left zero):
                                       //   P1: 0 / 1 target network 1 -> critic workgroup 1 / 2, 5 / 6 target network 2 -> critic workgroup 1 / 2;
                                       //   P3: 2 / 3 Q1 / Q2, 4 the second network's dZ1 slab
@@ -272,8 +273,17 @@ struct Stager {
 __device__ __forceinline__ void flag_post(unsigned int* f) { __hip_atomic_store(f, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 // (polling with relaxed loads and ONE acquire fence at the end: an acquire per poll invalidates the compute unit's L1 and the
 // XCD's L2 lines each time round, under the workgroups that are streaming weights through them)
+// Every spin in this file is BOUNDED: kSpinLimit polls (each a sleep + an L2 round trip, ~0.3-1 us: seconds in all, against
+// hand-offs that take microseconds) and then a trap — the launch fails with a hardware exception and every later HIP call
+// reports it, instead of a training run that hangs silently if a producer should ever not be running (see slab_grid below for
+// why it always is).
+constexpr unsigned int kSpinLimit = 1u << 23;
 __device__ __forceinline__ void flag_wait(unsigned int* f) {
-  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) __builtin_amdgcn_s_sleep(2);
+  unsigned int polls = 0;
+  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
+    __builtin_amdgcn_s_sleep(2);
+    if (++polls > kSpinLimit) __builtin_trap();
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 __device__ __forceinline__ void flag_clear(unsigned int* f) { __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -292,7 +302,11 @@ __device__ __forceinline__ void phase_done(unsigned int* c) {
 __device__ __forceinline__ void phase_wait(const unsigned int* c, unsigned int n) {
   if (c) {
     if (threadIdx.x == 0) {
-      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) __builtin_amdgcn_s_sleep(8);
+      unsigned int polls = 0;
+      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++polls > kSpinLimit) __builtin_trap();
+      }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -547,23 +561,60 @@ __device__ __forceinline__ void sac_p1_body(const gymrl_sac_update_args& a, cons
 #undef P1_MARK_C
 }
 
-// Grid shapes of the row kernels.  B <= 256 (the reference's batch sizes): dim3(slabs, R) — every workgroup of every slab is
-// resident at once.  Larger batches (SURVEY 8(d)'s B = 4096 / 8192 lines: up to 4 x 512 workgroups on 256 compute units):
-// a 1-D grid of slabs * R blocks with the R workgroups of a slab ADJACENT in dispatch order — a workgroup that waits for a
-// flag waits for one of its own slab, which is dispatched right beside it (blocks are handed to compute units in ascending
-// order), so the waiters can never hold every compute unit.
-struct SlabGrid { int slab, role, slabs; };
-__device__ __forceinline__ SlabGrid slab_grid(int R) {
-  if (gridDim.y > 1) return SlabGrid{(int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x};
-  return SlabGrid{(int)blockIdx.x / R, (int)blockIdx.x % R, (int)gridDim.x / R};
+// Grid shapes of the row kernels, and why a waiting workgroup's producer is always running.
+//   B <= 256 (the reference's batch sizes): dim3(slabs, R), y = role — at most 64 workgroups of one per compute unit, every one
+//   of them resident at once on the chip's 256 compute units whatever the dispatch order (the launch refuses a device with
+//   fewer compute units than workgroups — slab_launch_grid takes the ticketed form there), so nobody can wait for a workgroup that is not running.
+//   Larger batches (SURVEY 8(d)'s B = 4096 / 8192 lines: up to 4 x 512 workgroups on 256 compute units): a 1-D grid of
+//   slabs * R blocks whose place in the launch is NOT blockIdx (HIP promises no dispatch order, and consecutive blocks go
+//   round-robin to the eight XCDs) but a TICKET taken at entry (one relaxed fetch-add per workgroup): logical place v = the
+//   v-th workgroup to START.  The started workgroups are therefore always the logical prefix [0, k), whatever the dispatcher
+//   did.  Place v is slab v / R, slot v % R, and `order` maps slots to roles producers-first, so (a) a one-way waiter
+//   (P1's critic chains, Rainbow's policy(s) pass) has a higher ticket than its producers — they started before it and wait
+//   for nobody —, and (b) of two workgroups that exchange both ways (P3) only the LAST started one, place k - 1, can ever
+//   wait for a partner that has not started: every other started workgroup has its whole slab running, finishes, and frees a
+//   compute unit for place k.  No assumption about residency or dispatch order is left.  The last workgroup to finish zeroes
+//   the two counters for the next launch (tk[0] next ticket, tk[1] finished).
+struct SlabGrid { int slab, role, slabs; unsigned int* tk; };
+template <int R>
+__device__ __forceinline__ SlabGrid slab_grid(unsigned int* tk, const int (&order)[R]) {
+  if (gridDim.y > 1) return SlabGrid{(int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, nullptr};   // all resident: y IS the role (the longest chain first)
+#ifdef GYMRL_PROBE_NO_TICKETS          // A/B probe only (tools/probes): the place is blockIdx, as before round 6
+  const int v0 = (int)blockIdx.x;
+  return SlabGrid{v0 / R, order[v0 % R], (int)gridDim.x / R, nullptr};
+#endif
+  __shared__ unsigned int place;
+  if (threadIdx.x == 0) place = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int v = (int)__builtin_amdgcn_readfirstlane(place);
+  return SlabGrid{v / R, order[v % R], (int)gridDim.x / R, tk};
 }
-__host__ inline dim3 slab_launch_grid(int slabs, int R) { return slabs * 16 <= 256 ? dim3(slabs, R) : dim3(slabs * R); }
+__device__ __forceinline__ void slab_grid_done(const SlabGrid& g) {
+  if (g.tk && threadIdx.x == 0 &&
+      __hip_atomic_fetch_add(g.tk + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+    // everybody has started (they all finished): nobody takes a ticket any more; the kernel boundary publishes the stores
+    __hip_atomic_store(g.tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g.tk + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+inline int device_cus() {                      // compute units of the current device (asked once per device)
+  static int cus[64];
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (!cus[dev] && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus[dev] = v;
+  return cus[dev];
+}
+// the y = role form only while every workgroup has a compute unit of its own (B <= 256 on this chip: at
+// most 64 of 256; a partitioned or masked device with fewer compute units takes the ticketed form instead)
+__host__ inline dim3 slab_launch_grid(int slabs, int R) { return (slabs * 16 <= 256 && slabs * R <= device_cus()) ? dim3(slabs, R) : dim3(slabs * R); }
 
 template <int HC>
 __global__ __launch_bounds__(kThreads) void sac_p1_kernel(const gymrl_sac_update_args a, const SacWs ws) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const SlabGrid g = slab_grid(4);
+  constexpr int order[4] = {0, 1, 2, 3};                 // the two target chains wait for nobody; the critic chains wait for them
+  const SlabGrid g = slab_grid<4>(ws.sync + 8, order);
   sac_p1_body<HC>(a, ws, lds, g.slab, g.role, g.slabs, nullptr, 0u);
+  slab_grid_done(g);
 }
 
 // ======================================================================================================== P3 =====
@@ -756,8 +807,10 @@ __device__ __forceinline__ void sac_p3_body(const gymrl_sac_update_args& a, cons
 template <int HC>
 __global__ __launch_bounds__(kThreads) void sac_p3_kernel(const gymrl_sac_update_args a, const SacWs ws) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const SlabGrid g = slab_grid(2);
+  constexpr int order[2] = {0, 1};                       // they exchange both ways: case (b) of slab_grid's comment
+  const SlabGrid g = slab_grid<2>(ws.sync + 10, order);
   sac_p3_body<HC>(a, ws, lds, g.slab, g.role, g.slabs, nullptr, 0u, nullptr, 0u);
+  slab_grid_done(g);
 }
 
 // ================================================================================================= P2 / P4 =====
@@ -1103,7 +1156,13 @@ __global__ __launch_bounds__(kThreads) void sac_step_kernel(const SacStepArgs by
   __shared__ double sm[3][4];
   unsigned int* const sync = s.ws.sync;
   const int S = s.slabs;
-  int b = blockIdx.x;
+  // the block's place in the launch is the order in which it STARTED (a ticket), not blockIdx: every phase_wait / flag_wait
+  // below waits for places lower than its own or — P1's / P3's pairs — for a place at most 3 S (48) higher, whose
+  // workgroups start as the earlier ones finish (slab_grid's argument: the started places are always a prefix)
+  __shared__ unsigned int place;
+  if (threadIdx.x == 0) place = __hip_atomic_fetch_add(sync + 6, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  int b = (int)__builtin_amdgcn_readfirstlane(place);
   if (b < s.n_act) {
     sac_act_body<HC>(s.act, lds, b);
     phase_done(sync + 0);
@@ -1136,6 +1195,7 @@ __global__ __launch_bounds__(kThreads) void sac_step_kernel(const SacStepArgs by
   if (threadIdx.x == 0) {
     if (__hip_atomic_fetch_add(sync + 7, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
       for (int k = 0; k < 4; ++k) __hip_atomic_store(sync + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sync + 6, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(sync + 7, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -1147,6 +1207,7 @@ struct RbWs {
   double* terms;                             // [B][3] (column 0: w * td^2)
   float* xz;                                 // [2][16 S][4]: head outputs of policy(s') and target(s') on their way to the policy(s) workgroup
   unsigned int* flag;                        // [2][S]: their hand-off flags (zero before the first launch, left zero)
+  unsigned int* tk;                          // [2]: slab_grid's next ticket / finished count of the large-batch row kernel (zero between launches)
   float* dw_parts;                           // B > 512: the weight-gradient tiles' slice partials (DwArgs)
   __host__ __device__ static size_t carve(RbWs* w, void* base, int B, int D, int A, int H) {
     size_t off = 0;
@@ -1157,10 +1218,11 @@ struct RbWs {
     const size_t S16 = (size_t)(B + 15) / 16 * 16;
     float* xz = take(2 * S16 * 4);
     unsigned int* fl = reinterpret_cast<unsigned int*>(take(2 * S16 / 16));
+    unsigned int* tk = reinterpret_cast<unsigned int*>(take(2));
     const size_t dw_tiles = B > 512 ? (size_t)((A + 1 + 15) / 16) * ((H + 15) / 16) + (size_t)((H + 15) / 16) * ((H + 15) / 16) + (size_t)((H + 15) / 16) * ((D + 15) / 16) : 0;
     float* dwp = take(dw_tiles * kDwMaxSlices * 320);
     if (w) { w->s = s_; w->h1 = h1; w->h2 = h2; w->dS = dS; w->dZ2 = z2; w->dZ1 = z1; w->terms = terms; w->xz = xz; w->flag = fl;
-             w->dw_parts = dwp; }
+             w->tk = tk; w->dw_parts = dwp; }
     return off;
   }
 };
@@ -1188,16 +1250,15 @@ constexpr int kRbMaxA = 3;
 // are independent chains until the double-DQN target meets the TD error (:320-334), and a slab's stage costs what ONE compute
 // unit's f32 MFMA rate makes of its items (three 256 x 256 layers per stage on one CU before).  Workgroups 1 and 2 publish
 // their head outputs ([16][4]) with release flags; workgroup 0, whose own forward takes as long, consumes them, clears the
-// flags and runs the loss and the way back.  All three are resident (3 * B / 16 <= 48 of 256 CUs), the producers wait for nobody.
+// flags and runs the loss and the way back.  The producers wait for nobody and come first in the launch (slab_grid: y / slot
+// 0, 1 -> passes 1, 2; the waiting pass 0 last), so the pass that waits always finds its producers started.
 template <int HC>                       // HC: the hidden width this instance is built for (0: any), as the SAC kernels'
-__global__ __launch_bounds__(kThreads) void rainbow_rows_kernel(const gymrl_rainbow_update_args a, const RbWs ws) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void rainbow_rows_body(const gymrl_rainbow_update_args& a, const RbWs& ws, float* lds, const SlabGrid& sg_) {
   const Lds L;
   const int D = a.D, A = a.A, A1 = a.A + 1, H = HC ? HC : a.H, ld = lin::slab_ld(H);
   const int H1 = L.big, H2 = H1 + 16 * ld, X0 = H2 + 16 * ld;
   // head outputs of the three passes: [16][4] slabs in the small area (Q0, Q1, Cq0), dS in Dq0
   const int Za = L.Q0, Zb = L.Q1, Zc = L.Cq0, DS = L.Dq0;
-  const SlabGrid sg_ = slab_grid(3);
   const int bx = sg_.slab;
   const int row0 = bx * 16, nrows = min(16, a.B - row0);
   const int t = threadIdx.x;
@@ -1293,6 +1354,15 @@ __global__ __launch_bounds__(kThreads) void rainbow_rows_kernel(const gymrl_rain
     const BwdItem st[1] = {BwdItem{X0, ld, H, a.p_fc2_w, H, -1, nullptr, H1, ld, R, -1, 0, ws.dZ1, H, a.p_fc2_img_b}};
     bwd_stage<1>(lds, st, row0, nrows);
   }
+}
+
+template <int HC>
+__global__ __launch_bounds__(kThreads) void rainbow_rows_kernel(const gymrl_rainbow_update_args a, const RbWs ws) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int order[3] = {1, 2, 0};                    // policy(s') and target(s') first: pass 0 waits for them
+  const SlabGrid g = slab_grid<3>(ws.tk, order);
+  rainbow_rows_body<HC>(a, ws, lds, g);
+  slab_grid_done(g);
 }
 
 // Greedy acting on the noisy Q + CartPole + the n-step window: one lane per env after the network.  NS slabs of 16 envs per

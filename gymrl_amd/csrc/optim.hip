@@ -97,6 +97,7 @@ __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v,
   if (a.zero_grad) g = 0.0f;
 }
 
+template <bool FOLD>      // FOLD: gymrl_clip_adam_step's form (the plain step carries neither the shared array nor the fold)
 __global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                       float* __restrict__ m, float* __restrict__ v,
                                                       int64_t n, AdamArgs a,
@@ -111,9 +112,9 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ p, flo
   }
   // gymrl_clip_adam_step: the squared norm's second level here instead of in a launch of its own — every workgroup folds
   // sqnorm_partial_kernel's block partials exactly as sqnorm_final_kernel does (the same bits in every workgroup)
-  __shared__ double fold[kBlock];
   double folded = 0.0;
-  if (partials) {
+  if constexpr (FOLD) {
+    __shared__ double fold[kBlock];
     double acc = 0.0;
     for (int i = threadIdx.x; i < nparts; i += kBlock) acc += partials[i];
     fold[threadIdx.x] = acc;
@@ -260,7 +261,7 @@ int gymrl_adam_step(float* p, float* g, float* m, float* v, int64_t n, double lr
   a.eps = (float)eps;
   a.grad_scale = grad_scale; a.max_grad_norm = max_grad_norm; a.clamp_abs = clamp_abs;
   a.zero_grad = zero_grad;
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4)), dim3(kBlock), 0, (hipStream_t)stream_, p, g,
+  hipLaunchKernelGGL(adam_kernel<false>, dim3(grid_for(n, 4)), dim3(kBlock), 0, (hipStream_t)stream_, p, g,
                      m, v, n, a, lr_dev, bias_dev, sqnorm, polyak_target, (float)tau, (float)(1.0 - tau),
                      (const double*)nullptr, 0, (double*)nullptr);
   GYMRL_CHECK_LAUNCH();
@@ -277,8 +278,11 @@ int gymrl_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, doub
       !aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v) || !(max_grad_norm > 0.0f))
     return -22;
   if (bias_dev) step = 1;
-  if (n == 0) return 0;
   hipStream_t stream = (hipStream_t)stream_;
+  if (n == 0) {                 // no parameters: the norm gymrl_sqnorm would have written is 0 (a reader of sqnorm_out never sees a stale one)
+    if (sqnorm_out && hipMemsetAsync(sqnorm_out, 0, sizeof(double), stream) != hipSuccess) return -5;
+    return 0;
+  }
   AdamArgs a;
   const double bc1 = 1.0 - __builtin_pow(beta1, (double)step);
   const double bc2 = 1.0 - __builtin_pow(beta2, (double)step);
@@ -291,7 +295,7 @@ int gymrl_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, doub
   a.zero_grad = zero_grad;
   const int nb = grid_for(n, 16);
   hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nb), dim3(kBlock), 0, stream, g, n, grad_scale, (double*)workspace);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4)), dim3(kBlock), 0, stream, p, g, m, v, n, a, lr_dev, bias_dev,
+  hipLaunchKernelGGL(adam_kernel<true>, dim3(grid_for(n, 4)), dim3(kBlock), 0, stream, p, g, m, v, n, a, lr_dev, bias_dev,
                      (const double*)nullptr, polyak_target, (float)tau, (float)(1.0 - tau), (const double*)workspace, nb, sqnorm_out);
   GYMRL_CHECK_LAUNCH();
   return 0;

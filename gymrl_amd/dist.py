@@ -26,13 +26,30 @@ def world_size():
     return td.get_world_size() if is_dist() else 1
 
 
+def force_collectives():
+    """GYMRL_FORCE_COLLECTIVES=1: run every collective branch with ONE rank as well.  A sum over one rank is the identity,
+    so a forced single-rank run must end with the bits of a run without a process group — which is how a 1-GPU box
+    executes the whole RCCL path (communicator, the reducer's communication stream, its buckets and events, the moments'
+    all-reduce, the parameter broadcast): tests/test_multirank_gpu.py, `bench.py --gpus 1` under that variable."""
+    return os.environ.get("GYMRL_FORCE_COLLECTIVES", "0") not in ("", "0")
+
+
+def collectives_active():
+    """True where the trainers issue collectives: more than one rank, or one rank under force_collectives()."""
+    return is_dist() and (world_size() > 1 or force_collectives())
+
+
+def backend():
+    return td.get_backend() if is_dist() else None
+
+
 def init_from_env(backend=None):
     """Initialise from torchrun-style env vars (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).
-    Returns (rank, world_size, local_rank).  No-op for WORLD_SIZE <= 1."""
+    Returns (rank, world_size, local_rank).  No-op for WORLD_SIZE <= 1 (unless force_collectives())."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rk = int(os.environ.get("RANK", "0"))
     lrk = int(os.environ.get("LOCAL_RANK", "0"))
-    if ws > 1 and not is_dist():
+    if (ws > 1 or force_collectives()) and not is_dist():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -46,25 +63,25 @@ def init_from_env(backend=None):
 
 
 def all_reduce_sum(t):
-    if is_dist() and world_size() > 1:
+    if collectives_active():
         td.all_reduce(t, op=td.ReduceOp.SUM)
     return t
 
 
 def all_reduce_max(t):
-    if is_dist() and world_size() > 1:
+    if collectives_active():
         td.all_reduce(t, op=td.ReduceOp.MAX)
     return t
 
 
 def broadcast(t, src=0):
-    if is_dist() and world_size() > 1:
+    if collectives_active():
         td.broadcast(t, src=src)
     return t
 
 
 def barrier():
-    if is_dist() and world_size() > 1:
+    if collectives_active():
         td.barrier()
 
 
@@ -72,7 +89,7 @@ def shutdown():
     """Collective teardown: every rank waits for the slowest one, then the process group is destroyed
     (ranks that simply exit while another still runs local work make RCCL's watchdog noisy)."""
     if is_dist():
-        if world_size() > 1:
+        if collectives_active():
             td.barrier()
         td.destroy_process_group()
 
@@ -113,7 +130,7 @@ class GradReducer:
 
     def launch(self, k):
         """Reduce bucket k; everything queued on the current stream so far is ordered before it."""
-        if world_size() <= 1:
+        if not collectives_active():
             return
         buf = self.buckets[k]
         if not self.cuda:
@@ -179,7 +196,7 @@ def rank_devices():
         mine = {"rank": rank(), "device": i, "name": pr.name, "pci_bus_id": getattr(pr, "pci_bus_id", None)}
     else:
         mine = {"rank": rank(), "device": None, "name": "cpu", "pci_bus_id": None}
-    if not is_dist() or world_size() <= 1:
+    if not collectives_active():
         return [mine]
     out = [None] * world_size()
     td.all_gather_object(out, mine)

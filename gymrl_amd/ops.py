@@ -1218,9 +1218,17 @@ def norm_proj_ok(D, n_out):
     return 0 < D <= 256 and 0 < n_out <= 8
 
 
+def _al16(t):
+    """A tensor whose storage starts on a 16-byte boundary (a copy if the view does not): the D = 256 head-tail kernels are
+    chosen by shape alone and require it (-22 otherwise), so that a result's bits never depend on where a view starts."""
+    return t if t.data_ptr() % 16 == 0 else t.clone(memory_format=torch.contiguous_format)
+
+
 def norm_proj_fwd(x, norm_w, eps, W2, b2):
     """gymrl_norm_proj_fwd: RMSNorm(SiLU(x)) W2^T + b2 -> [B, n_out] in one launch."""
     B, D = x.shape
+    if D == 256:
+        x, norm_w, W2 = _al16(x), _al16(norm_w), _al16(W2)
     out = torch.empty(B, W2.shape[0], device=x.device)
     f = torch.float32
     check(lib().gymrl_norm_proj_fwd(_ptr(x, f), _ptr(norm_w, f), _ptr(W2, f), _ptr(b2, f, True), C.c_int(B), C.c_int(D),
@@ -1232,6 +1240,8 @@ def norm_proj_bwd(d_out, x, norm_w, eps, W2):
     """gymrl_norm_proj_bwd -> (d_x, d_norm_w, d_W2, d_b2)."""
     B, D = x.shape
     n_out = W2.shape[0]
+    if D == 256:
+        x, norm_w, W2 = _al16(x), _al16(norm_w), _al16(W2)
     ws = _scratch("norm_proj_bwd", (D, n_out), lib().gymrl_norm_proj_bwd_workspace_bytes(C.c_int(D), C.c_int(n_out)), x.device)
     d_x, d_nw, d_W2 = torch.empty_like(x), torch.empty_like(norm_w), torch.empty_like(W2)
     d_b2 = torch.empty(n_out, device=x.device)

@@ -77,6 +77,8 @@ POLICY_IMAGE = True         # ... the persistent rollout reading its wide weight
 FUSED_SUB_FORWARD = True    # ... and its forward as ONE launch when D = 128 (False: gates + Linear + combine launches)
 FUSED_HEAD_TAIL = True      # training pass: a head's SiLU -> RMSNorm -> output Linear as one launch each way
 KEEP_UPDATE_GRAPHS = os.environ.get("GYMRL_KEEP_UPDATE_GRAPHS", "1") != "0"   # update_model(): captured graphs outlive the call
+                            # (and with them their private memory pool — the activations of one micro-batch, several GB at 524 288
+                            # rows — stays allocated through the rollout phase; "0" re-captures per call and frees it: +19 ms per update)
 FUSED_HEAD_PAIR = True      # training pass: actor.mlp.0 and critic.mlp.0 as one autograd node (their input gradients added in the GEMM)
 FUSED_SUB_BACKWARD = True   # ... and its backward as ONE launch + the Linear's weight gradient (False: the five backward launches)
 FUSED_SUB = True            # training pass: a whole hyper-connection sub-block as one autograd node (3 launches forward, 7 backward)
@@ -614,6 +616,7 @@ class PPOTrainer:
         if not torch.cuda.is_available() or not ops.device_ok():
             raise RuntimeError("gymrl_amd PPO-full needs an MI355X and libgymrl_hip.so; no CPU fallback")
         self.rank, self.world_size = gdist.rank(), gdist.world_size()
+        self.collective = gdist.collectives_active()          # world_size > 1 (or one rank under GYMRL_FORCE_COLLECTIVES)
         self.device = torch.device(config.device if ":" in str(config.device) else f"cuda:{torch.cuda.current_device()}")
         self.base_seed = 0 if config.seed is None else int(config.seed)
         N = int(config.num_envs)
@@ -786,7 +789,7 @@ class PPOTrainer:
         def reduce_grads():
             # one collective over the flat gradient per optimiser step (after the last micro-batch's backward), on the
             # reducer's communication stream so that bench.py can time it apart from the compute stream's kernels
-            if self.world_size > 1:
+            if self.collective:
                 if self._reducer is None:
                     self._reducer = gdist.GradReducer(self.flat_grads)
                 self._reducer.timed = self._time_collectives
@@ -821,8 +824,16 @@ class PPOTrainer:
             self._g_graphs = None
         if graphed:
             ent_dev[0] = self._g_ent
+            # every HOST constant the captured launches bake in belongs to the key next to the addresses: Adam's betas / eps
+            # (load_state_dict() may change them), the clip settings, the gradient scale's inputs, and the module-level
+            # FUSED_* switches that choose which kernels a capture records (lr, the bias corrections and the entropy
+            # coefficient are read from device memory and may change freely)
+            og = self.optimizer.param_groups[0]
             key = (rows, n_micro, self.world_size, lcfg[:5], tuple(t.data_ptr() for t in (states, act, lp, ent_old, adv, ret)),
-                   tuple(p.data_ptr() for p in self.model.parameters()), self.flat_grads.data_ptr(), self.optimizer.m.data_ptr())
+                   tuple(p.data_ptr() for p in self.model.parameters()), self.flat_grads.data_ptr(), self.optimizer.m.data_ptr(),
+                   self.optimizer.v.data_ptr(), tuple(float(b) for b in og["betas"]), float(og["eps"]),
+                   self.optimizer.max_grad_norm, self.optimizer.clamp_abs,
+                   tuple(sorted((k, bool(v)) for k, v in globals().items() if k.startswith("FUSED_"))))
             kept = getattr(self, "_g_graphs", None)
             if KEEP_UPDATE_GRAPHS and kept is not None and kept[0] == key:
                 graph, graph2 = kept[1], kept[2]

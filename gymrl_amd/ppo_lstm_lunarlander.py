@@ -196,6 +196,7 @@ class PPOTrainer:
         self.num_sequences = T // L * N
         assert self.num_sequences % int(config.batch_size) == 0             # :546
         self.rank, self.world_size = gdist.rank(), gdist.world_size()
+        self.collective = gdist.collectives_active()          # world_size > 1 (or one rank under GYMRL_FORCE_COLLECTIVES)
         self.device = torch.device(config.device if ":" in str(config.device) else f"cuda:{torch.cuda.current_device()}")
         self.base_seed = 0 if config.seed is None else int(config.seed)
         self.env = VecEnv(config.env_name, N, device=self.device, seed=self.base_seed, env_id0=self.rank * N)
@@ -303,13 +304,13 @@ class PPOTrainer:
             self._sink.arm()
             torch.autograd.backward([logits_flat, values_flat, rnd_loss], [dlogits, dvalues, None])
             self._sink.collect()
-            if self.world_size > 1:
+            if self.collective:
                 gdist.all_reduce_sum(self.flat_grads)
             self.optimizer.step(grad_scale=1.0 / self.world_size, bias_dev=bias)
             rnd_out.copy_(rnd_loss.detach())
 
         # Same scheme as PPO-full: the minibatch body is captured once per update_model() call and replayed.
-        graphed = (bool(getattr(cfg, "use_graphs", True)) and self.world_size == 1 and self.grad_norms is None
+        graphed = (bool(getattr(cfg, "use_graphs", True)) and not self.collective and self.grad_norms is None
                    and cfg.num_epochs * n_mb > 2 and cfg.clip_cov_ratio <= 0)
         graph = None
         if graphed and self._g_seq is None:

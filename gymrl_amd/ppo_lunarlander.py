@@ -226,6 +226,7 @@ class PPOTrainer:
         if not torch.cuda.is_available() or not ops.device_ok():
             raise RuntimeError("gymrl_amd.PPOTrainer needs an MI355X (gfx950) and libgymrl_hip.so; no CPU fallback")
         self.rank, self.world_size = gdist.rank(), gdist.world_size()
+        self.collective = gdist.collectives_active()          # world_size > 1 (or one rank under GYMRL_FORCE_COLLECTIVES)
         self.device = torch.device(config.device if ":" in str(config.device) else f"cuda:{torch.cuda.current_device()}")
         self.base_seed = 0 if config.seed is None else int(config.seed)
         N = int(config.num_envs)
@@ -269,7 +270,7 @@ class PPOTrainer:
         self._stage = (torch.empty(mb, state_dim, device=self.device), torch.empty(mb, dtype=torch.int32, device=self.device),
                        torch.empty(mb, device=self.device), torch.empty(mb, device=self.device),
                        torch.empty(mb, device=self.device))
-        self._stage2 = tuple(torch.empty_like(t) for t in self._stage) if self.world_size > 1 else None
+        self._stage2 = tuple(torch.empty_like(t) for t in self._stage) if self.collective else None
         self._reducer = None     # gdist.GradReducer over the flat gradient (world_size > 1; built on the first update)
         self._graph = None       # captured minibatch body (one rank; update())
         self._timers = None      # set to a KernelTimers() to time kernels with HIP events (bench.py)
@@ -435,7 +436,7 @@ class PPOTrainer:
             next_value = (None if float(next_value) == getattr(self, "_nv_float", None)
                           else torch.full((b.N,), float(next_value), device=self.device))
         self._compute_gae(None if next_value is self._next_value else next_value)
-        if self.world_size > 1:
+        if self.collective:
             if self._timers is not None:
                 self._timers.start("moments_allreduce")
             gdist.all_reduce_sum(self._moments)          # :236 mean/std over the WHOLE rollout (all ranks)
@@ -464,7 +465,7 @@ class PPOTrainer:
         else:
             self._metric_parts.zero_()
         red = None
-        if self.world_size > 1:
+        if self.collective:
             # the flat gradient is all-reduced in two buckets on a communication stream.  The
             # tail of the flat buffer (actor.0 | critic.0 and the heads: 2/3 of the bytes) is complete once the N = 512
             # weight gradient is queued and is reduced under the trunk's three GEMMs; the head follows the last backward
@@ -638,7 +639,7 @@ class PPOTrainer:
             # the stop decision is collective: every rank sees different episodes, and a rank that left alone would
             # strand the others in the next all-reduce
             solved = len(self.episode_rewards) >= 100 and np.mean(self.episode_rewards) >= self.cfg.solved_reward
-            if self.world_size > 1:
+            if self.collective:
                 flag = torch.tensor([1.0 if solved else 0.0], device=self.device)
                 gdist.all_reduce_max(flag)
                 solved = bool(flag.item() > 0)

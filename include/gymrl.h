@@ -622,7 +622,9 @@ int gymrl_rmsnorm_sum_bwd(const float* g, const float* x, const float* w, int B,
 /* A head's tail in one launch each way: out [B, n_out] = RMSNorm(SiLU(x)) W2^T + b2 for x [B, D], D <= 256, n_out <= 8
  * (MLP([128, 256, n_out]) :371-402: the actor's and the critic's Linear -> SiLU -> RMSNorm -> Linear; b2 may be NULL), and its
  * backward from d_out [B, n_out]: d_x [B, D], d_norm_w [D], d_W2 [n_out, D], d_b2 [n_out] (overwritten; per-workgroup partial
- * sums in `workspace`, added in a fixed order).  The normalised activations and their gradient never touch HBM. */
+ * sums in `workspace`, added in a fixed order).  The normalised activations and their gradient never touch HBM.
+ * The kernel (one row or four rows per wave, i.e. the summation order) is chosen by (D, n_out) ALONE: at D = 256 x, norm_w, W2
+ * (and d_x, n_out = 1) must be 16-byte aligned — -22 otherwise; a result's bits never depend on where a buffer starts. */
 int gymrl_norm_proj_fwd(const float* x, const float* norm_w, const float* W2, const float* b2, int B, int D, int n_out, float eps,
                         float* out, void* stream);
 size_t gymrl_norm_proj_bwd_workspace_bytes(int D, int n_out);

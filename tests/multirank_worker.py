@@ -1,6 +1,7 @@
 """Worker of tests/test_multirank_gpu.py: one of `world` gloo ranks sharing cuda:0 (the 1-GPU lease has no second
-device; RCCL needs one device per rank, gloo does not).  Runs one iteration of a trainer with world_size > 1 and
-leaves what the parent checks in `outdir`."""
+device; RCCL needs one device per rank, gloo does not) — or ONE "nccl" (= RCCL) rank under GYMRL_FORCE_COLLECTIVES=1, or no
+process group at all ("none": the run the forced one must equal bit for bit).  Runs one iteration of a trainer through
+its collective branches and leaves what the parent checks in `outdir`."""
 import os
 import sys
 
@@ -26,15 +27,18 @@ def ppo_full_cfg(n_envs):
     return cfg
 
 
-def run(rank, world, port, outdir, n_envs):
+def run(rank, world, port, outdir, n_envs, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0")
     torch.cuda.set_device(0)
-    td.init_process_group("gloo", rank=rank, world_size=world)
+    if backend != "none":
+        td.init_process_group(backend, rank=rank, world_size=world)
     try:
+        from gymrl_amd import dist as gdist
         from gymrl_amd.ppo_lunarlander import PPOTrainer
         tr = PPOTrainer(ppo_cfg(n_envs))
         assert tr.world_size == world and tr.env.env_id0 == rank * n_envs
+        assert tr.collective == (backend != "none") and gdist.backend() == (None if backend == "none" else backend)
         p0 = tr.flat_params.clone()
         nv = tr.collect_rollout()
         from gymrl_amd.ppo_lunarlander import KernelTimers
@@ -42,8 +46,9 @@ def run(rank, world, port, outdir, n_envs):
         m = tr.update(nv)
         tr._timers = None
         b = tr.buffer
-        rs = tr._reducer.stats()
-        out = dict(p0=p0.cpu(), params=tr.flat_params.cpu(), moments=tr._moments.cpu(), adv=b.advantages.cpu(),
+        rs = tr._reducer.stats() if tr._reducer is not None else None
+        out = dict(backend=gdist.backend(),
+                   p0=p0.cpu(), params=tr.flat_params.cpu(), moments=tr._moments.cpu(), adv=b.advantages.cpu(),
                    metrics={k: float(v) for k, v in m.items()}, reducer=rs,
                    **{k: getattr(b, k).cpu() for k in ("states", "actions", "log_probs", "values", "rewards", "dones")})
         # PPO-full: two iterations (the second replays the two hipGraphs around the eager all-reduce)
@@ -59,9 +64,10 @@ def run(rank, world, port, outdir, n_envs):
                    full_actions=ft.buffer.actions.cpu(), full_steps=ft.optimizer.step_count)
         torch.save(out, os.path.join(outdir, f"rank{rank}.pt"))
     finally:
-        td.barrier()
-        td.destroy_process_group()
+        if backend != "none":
+            td.barrier()
+            td.destroy_process_group()
 
 
 if __name__ == "__main__":
-    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]))
+    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), *(sys.argv[6:7]))

@@ -107,3 +107,40 @@ def test_grad_reducer_rejects_bounds_outside_the_buffer():
     assert [b.numel() for b in r.buckets] == [40, 60]
     r.launch(0)                                      # world_size 1: no-ops
     r.wait()
+
+
+def _forced_worker(port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from gymrl_amd import dist as gdist
+    os.environ["GYMRL_FORCE_COLLECTIVES"] = "0"
+    assert gdist.init_from_env(backend="gloo") == (0, 1, 0) and not gdist.is_dist() and not gdist.collectives_active()
+    os.environ["GYMRL_FORCE_COLLECTIVES"] = "1"
+    assert gdist.init_from_env(backend="gloo") == (0, 1, 0) and gdist.is_dist() and gdist.collectives_active()
+    assert gdist.backend() == "gloo" and gdist.world_size() == 1
+    g = torch.arange(10, dtype=torch.float32)
+    red = gdist.GradReducer(g, [4])
+    red.launch(1)
+    red.launch(0)
+    red.wait()
+    t = torch.tensor([3.0], dtype=torch.float64)
+    gdist.all_reduce_sum(t)
+    gdist.all_reduce_max(t)
+    gdist.broadcast(t)
+    gdist.barrier()
+    ret["ok"] = bool(torch.equal(g, torch.arange(10, dtype=torch.float32)) and t.item() == 3.0
+                     and len(gdist.rank_devices()) == 1)
+    gdist.shutdown()
+    ret["down"] = not gdist.is_dist()
+
+
+def test_forced_collectives_with_one_rank_are_the_identity():
+    """GYMRL_FORCE_COLLECTIVES=1 (dist.force_collectives): ONE rank builds a process group and every helper issues its
+    collective — the switch tests/test_multirank_gpu.py uses to take the trainers through RCCL on a 1-GPU box."""
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        ret = m.dict()
+        p = ctx.Process(target=_forced_worker, args=(_free_port(), ret))
+        p.start()
+        p.join(120)
+        assert p.exitcode == 0 and ret.get("ok") and ret.get("down")

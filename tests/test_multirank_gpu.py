@@ -64,3 +64,34 @@ def test_two_ranks_ppo_and_ppo_full(tmp_path):
     assert torch.equal(r[0]["full_params"], r[1]["full_params"]) and r[0]["full_steps"] == r[1]["full_steps"] == 2 * 2 * 8
     assert not torch.equal(r[0]["full_actions"], r[1]["full_actions"])
     assert all(np.isfinite(v) for m in r[0]["full_metrics"] for v in m.values())
+
+
+def test_one_rccl_rank_runs_every_collective_and_changes_no_bit(tmp_path):
+    """The multi-GPU path ON RCCL, as far as a 1-GPU box can take it: ONE "nccl" rank with GYMRL_FORCE_COLLECTIVES=1 goes
+    through every collective branch of PPO and PPO-full — communicator, parameter broadcast, the reducer's communication
+    stream with its two buckets and events, the float64 moments' all-reduce, PPO-full's eager all-reduce between its two
+    hipGraphs — and, a sum over one rank being the identity, must end with exactly the bits of a run without any process
+    group (worker "none")."""
+    N = 64
+    outs, res = {}, {}
+    for mode in ("nccl", "none"):
+        d = tmp_path / mode
+        d.mkdir()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("GYMRL_FORCE_COLLECTIVES", None)
+        if mode == "nccl":
+            env["GYMRL_FORCE_COLLECTIVES"] = "1"
+        p = subprocess.run([sys.executable, os.path.join(HERE, "multirank_worker.py"), "0", "1", str(_free_port()), str(d), str(N), mode],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        outs[mode] = p.stdout.decode()
+        assert p.returncode == 0, outs[mode]
+        res[mode] = torch.load(os.path.join(d, "rank0.pt"), weights_only=False)
+    a, b = res["nccl"], res["none"]
+    assert a["backend"] == "nccl" and b["backend"] is None
+    rs = a["reducer"]                   # 2 epochs x 4 minibatches: two buckets per optimiser step on the communication stream
+    assert rs["collectives"] == 2 * 8 and rs["stalls"] == 8 and rs["collective_s"] > 0 and b["reducer"] is None
+    for k in ("p0", "params", "moments", "adv", "states", "actions", "log_probs", "values", "rewards", "dones", "full_params",
+              "full_actions"):
+        assert torch.equal(a[k], b[k]), k
+    assert a["metrics"] == b["metrics"] and a["full_metrics"] == b["full_metrics"]
+    assert a["full_steps"] == b["full_steps"] == 2 * 2 * 8 and a["full_graphed"] and b["full_graphed"]
