@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 R=gpurun_out/$1
 for f in bench_final.json bench_20steps.json bench_ppo_full.json bench_sac.json bench_rainbow.json bench_sac_bigbatch.json \
          bench_rainbow_bigbatch.json bench_ppo_forced_rccl.json bench_ppo_full_forced_rccl.json bench_kernel_stats.csv bench_under_rocprof.json ppo_full_kernel_stats.csv sac_kernel_stats.csv \
-         rainbow_kernel_stats.csv sac_bigbatch_kernel_stats.csv rainbow_bigbatch_kernel_stats.csv micro_per.txt rollout_balance.txt rainbow_timeline.txt sac_timeline.txt \
+         rainbow_kernel_stats.csv sac_bigbatch_kernel_stats.csv rainbow_bigbatch_kernel_stats.csv micro_per.txt micro_kernels.json rollout_balance.txt rainbow_timeline.txt sac_timeline.txt \
          pmc_FETCH_SIZE_counter_collection.csv pmc_WRITE_SIZE_counter_collection.csv; do
   cp "$R/$f" "profiles/r06_$f"
 done

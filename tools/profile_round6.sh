@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (through tools/gpu.sh): the round-6 measurement set committed under profiles/.
-# usage: tools/profile_round5.sh <outdir under gpurun_out>
+# usage: tools/profile_round6.sh <outdir under gpurun_out>
 set -u
 OUT=/root/repo/gpurun_out/$1
 mkdir -p "$OUT"
@@ -34,6 +34,7 @@ GYMRL_FORCE_COLLECTIVES=1 timeout 600 python -m torch.distributed.run --nnodes=1
   bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_ppo_forced_rccl.json" 2> /dev/null
 GYMRL_FORCE_COLLECTIVES=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29562 \
   bench.py --algo ppo_full --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_ppo_full_forced_rccl.json" 2> /dev/null
+timeout 200 python tools/micro_kernels.py > "$OUT/micro_kernels.json" 2> /dev/null
 timeout 200 python tools/micro_per.py > "$OUT/micro_per.txt" 2> /dev/null
 timeout 200 python tools/probe_rollout_balance.py 2048 > "$OUT/rollout_balance.txt" 2> /dev/null
 cd /tmp && export TMPDIR=/tmp
