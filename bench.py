@@ -60,7 +60,7 @@ def full_pass(trainer, T, N, dev, iters=5):
     flush = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
     src = torch.empty(1 << 29, dtype=torch.uint8, device=dev)
     dst = torch.empty_like(src)
-    variant = trainer._last_gae_variant      # 2: the chunk maps of the last rollout are still in the workspace
+    variant = trainer._last_gae_variant      # 2 / 3: the chunk maps (and carries) of the last rollout are still in the workspace
 
     def timed(fn):
         tot = 0.0
@@ -710,7 +710,7 @@ def report(a, cfg, trainer, timers, phase_events, metrics, dt, world, T, N, dev,
         loss_s = ks["ppo_loss_fwd_bwd"]["total_s"] / ks["ppo_loss_fwd_bwd"]["launches"] * cfg.num_minibatches
         in_run["ppo_loss_fwd_bwd"] = dict(launch_s=loss_s, achieved=round(56.0 * transitions / loss_s / 1e9, 1),
                                           frac=round(56.0 * transitions / loss_s / HBM_PEAK, 4), note="32 minibatch launches per pass")
-    gae_loss = dict(kernel="gae(G1: chunk maps fused in the rollout + carry + apply + moments) + ppo_loss_fwd_bwd",
+    gae_loss = dict(kernel="gae(G1: chunk maps and — variant 3 — the carry pass composed inside the rollout launch; apply + moments launches) + ppo_loss_fwd_bwd",
                     in_run=in_run, at_rollout_size=full_pass(trainer, T, N, dev), bytes_per_pass=73.0 * transitions)
     roofline = dict(bound=head["bound"], achieved=head["achieved"], peak=head["peak"], unit=head["unit"], frac=head["frac"],
                     traffic=None, kernel=head["kernel"], launch_s=head["launch_s"],

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GYMRL_HIP_LIB") or os.path.join(_HERE, "libgymrl_hip.so")   # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 2      # == GYMRL_ABI_VERSION of the include/gymrl.h this front-end was written against
+ABI_VERSION = 3      # == GYMRL_ABI_VERSION of the include/gymrl.h this front-end was written against
 
 _lib = None
 
@@ -128,7 +128,7 @@ class RolloutLunarArgs(C.Structure):
                 ("gae_workspace", C.c_void_p), ("gamma", C.c_double), ("lam", C.c_double), ("ep_stats", C.c_void_p),
                 ("wg_ticks", C.c_void_p), ("T", C.c_int), ("t0", C.c_int), ("nsteps", C.c_int),
                 ("ent", C.c_void_p), ("lam2", C.c_double), ("gae_running2", C.c_void_p),   # gymrl_rollout_lunar_mhc only
-                ("refill", C.c_int)]
+                ("refill", C.c_int), ("gae_carry", C.c_int)]
 
 
 class SacActorParams(C.Structure):        # gymrl_sac_actor_params: fc1, fc2, mean, log_std

@@ -165,8 +165,8 @@ __global__ __launch_bounds__(kBlkBlock) void gae_blk_aggregate_kernel(
 // takes 64 envs (lanes) x kCarrySeg chunk-segments (waves): every thread loads its
 // segment's <= kCarryL aggregates at once, composes them, the segment maps are
 // exchanged through LDS, and each thread replays its own segment from its carry-in.
-constexpr int kCarrySeg = 16;
-constexpr int kCarryL   = 8;    // chunks per segment per round (registers: 8 double2)
+constexpr int kCarrySeg = kGaeCarrySeg;   // 16 (gymrl_device.hpp: gae_carry_scan restates this kernel per lane)
+constexpr int kCarryL   = kGaeCarryL;    // chunks per segment per round (registers: 8 double2)
 
 __global__ __launch_bounds__(kSeqBlock * kCarrySeg) void gae_blk_carry_kernel(
     const double2* __restrict__ agg, int C, int N, double* __restrict__ carry) {
@@ -533,7 +533,8 @@ int gymrl_gae(const float* rew, const float* val, const uint8_t* done, const flo
   const bool vec_ok = (N % 4 == 0) && aligned16(rew) && aligned16(val) && aligned16(adv_out) &&
                       aligned16(ret_out) && aligned16(next_val) &&
                       ((reinterpret_cast<uintptr_t>(done) & 3) == 0);
-  if ((variant == 1 || variant == 2) && vec_ok && workspace) {
+  if (variant == 3 && !(vec_ok && workspace)) return -22;   // the rollout only composes maps / carries under the same layout rules
+  if ((variant == 1 || variant == 2 || variant == 3) && vec_ok && workspace) {
     const int C = cdiv(T, kBlkTC);
     char* ws = (char*)workspace;
     double2* agg = (double2*)ws;
@@ -543,8 +544,9 @@ int gymrl_gae(const float* rew, const float* val, const uint8_t* done, const flo
     if (variant == 1)   // variant 2: the chunk maps were composed online during the rollout
       hipLaunchKernelGGL((gae_blk_aggregate_kernel<kBlkTC, kBlkV>), grid, dim3(kBlkBlock), 0, stream, rew, val, done,
                          next_val, T, N, gamma, gl, agg);
-    hipLaunchKernelGGL(gae_blk_carry_kernel, dim3(cdiv(N, kSeqBlock)), dim3(kSeqBlock * kCarrySeg), 0,
-                       stream, agg, C, N, carry);
+    if (variant != 3)   // variant 3: the persistent rollout ran this pass for its own envs at its tail (gymrl_device.hpp gae_carry_scan)
+      hipLaunchKernelGGL(gae_blk_carry_kernel, dim3(cdiv(N, kSeqBlock)), dim3(kSeqBlock * kCarrySeg), 0,
+                         stream, agg, C, N, carry);
     hipLaunchKernelGGL((gae_blk_apply_kernel<kBlkTC, kBlkV>), grid, dim3(kBlkBlock), 0, stream, rew, val, done,
                        next_val, T, N, gamma, gl, carry, adv_out, ret_out,
                        moments_out ? parts : nullptr);
@@ -618,7 +620,8 @@ int gymrl_gae_decoupled(const float* rew, const float* val, const uint8_t* done,
   const bool vec_ok = (N % 4 == 0) && aligned16(rew) && aligned16(val) && aligned16(adv_actor_out) &&
                       aligned16(ret_out) && aligned16(next_val) &&
                       ((reinterpret_cast<uintptr_t>(done) & 3) == 0);
-  if ((variant == 1 || variant == 2) && vec_ok && workspace) {
+  if (variant == 3 && !(vec_ok && workspace)) return -22;   // the rollout only composes maps / carries under the same layout rules
+  if ((variant == 1 || variant == 2 || variant == 3) && vec_ok && workspace) {
     const int C = cdiv(T, kBlkTC);
     const size_t CN = (size_t)C * N;
     double2* agg_a = (double2*)workspace;

@@ -246,6 +246,57 @@ __device__ __forceinline__ void gae_online_compose(float r, uint8_t d, float v_p
   else { running[i] = A; running[(size_t)N + i] = b; }
 }
 
+// The blocked scan's second pass for ONE env, by one lane: carry[c][n] = the advantage entering chunk c from the future.  It
+// restates gae.hip's gae_blk_carry_kernel operation for operation — rounds of 16 segments x 8 chunks walked from the last
+// chunk down, a segment's maps composed top-down into one (A, b), the value entering a segment folded through the HIGHER
+// segments' composed maps, the chunks inside a segment replayed one by one — so the carries (and with them every advantage)
+// carry the same bits whether that kernel computes them or the persistent rollout does at its tail (gymrl_gae variant 3).
+constexpr int kGaeCarrySeg = 16, kGaeCarryL = 8;     // == gae.hip kCarrySeg / kCarryL
+// m: kGaeCarrySeg double2 of scratch for this lane (element s at m[s * m_stride]; LDS in the rollout kernels — as a private
+// array it went to the stack of a kernel whose register budget the solver owns).  The segment loops are NOT unrolled for the
+// same reason: eight maps in flight per segment are all the memory parallelism a lane needs at a kernel's tail.
+__device__ __forceinline__ void gae_carry_scan(const double2* __restrict__ agg, int C, int N, int n, double* __restrict__ carry,
+                                               double2* m, int m_stride) {
+  double top = 0.0;
+  for (int c_hi = C; c_hi > 0; c_hi -= kGaeCarrySeg * kGaeCarryL) {
+#pragma unroll 1
+    for (int seg = 0; seg < kGaeCarrySeg; ++seg) {
+      const int c_top = c_hi - 1 - (kGaeCarrySeg - 1 - seg) * kGaeCarryL;
+      double2 ab[kGaeCarryL];
+#pragma unroll
+      for (int j = 0; j < kGaeCarryL; ++j) {
+        const int c = c_top - j;
+        ab[j] = c >= 0 ? agg[(size_t)c * N + n] : make_double2(1.0, 0.0);
+      }
+      double A = 1.0, b = 0.0;
+#pragma unroll
+      for (int j = 0; j < kGaeCarryL; ++j) { b = ab[j].y + ab[j].x * b; A = ab[j].x * A; }
+      m[seg * m_stride] = make_double2(A, b);
+    }
+    double x_in = top;                                // the value entering segment 15, then 14, ...
+#pragma unroll 1
+    for (int seg = kGaeCarrySeg - 1; seg >= 0; --seg) {
+      const int c_top = c_hi - 1 - (kGaeCarrySeg - 1 - seg) * kGaeCarryL;
+      double2 ab[kGaeCarryL];
+#pragma unroll
+      for (int j = 0; j < kGaeCarryL; ++j) {
+        const int c = c_top - j;
+        ab[j] = c >= 0 ? agg[(size_t)c * N + n] : make_double2(1.0, 0.0);
+      }
+      double x = x_in;
+#pragma unroll
+      for (int j = 0; j < kGaeCarryL; ++j) {
+        const int c = c_top - j;
+        if (c >= 0) carry[(size_t)c * N + n] = x;
+        x = ab[j].y + ab[j].x * x;
+      }
+      const double2 ms = m[seg * m_stride];
+      x_in = ms.y + ms.x * x_in;
+    }
+    top = x_in;
+  }
+}
+
 // ------------------------------------------------------------ reductions ---
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -109,8 +109,20 @@ __global__ __launch_bounds__(kThreads) void rollout_lunar_kernel(gymrl_rollout_l
           gae_online_compose(a.rew[o], a.done[o], a.val[o], v, a.gamma, gl, (tp % kGaeChunk) == 0,
                              (tp % kGaeChunk) == kGaeChunk - 1 || tp == T - 1, a.gae_running, agg, N, i);
         }
-        if (tail) a.next_value[i] = v;
-        else a.val[(size_t)t * N + i] = v;
+        if (tail) {
+          a.next_value[i] = v;
+          // the rollout is complete and this lane has just closed its env's last chunk map: the blocked scan's carry pass for
+          // this env here (128 maps this lane wrote itself), so that gymrl_gae (variant 3) is its apply launch alone
+          if (a.gae_carry && a.gae_running) {
+            const int C = (T + kGaeChunk - 1) / kGaeChunk;
+            const double2* agg0 = reinterpret_cast<const double2*>(a.gae_workspace);
+            // (scratch: the refill wave's solver columns — wave 1 does nothing at the tail, and the barrier at the top of this
+            // iteration is behind its last use of them; element s of env `row` at [s][row])
+            static_assert(sizeof(lds_words_refill) >= sizeof(double2) * kGaeCarrySeg * kEnvBlock / 4, "carry scratch");
+            gae_carry_scan(agg0, C, N, i, reinterpret_cast<double*>(const_cast<double2*>(agg0) + (size_t)C * N),
+                           reinterpret_cast<double2*>(lds_words_refill) + row, kEnvBlock / 4);
+          }
+        } else a.val[(size_t)t * N + i] = v;
       }
     };
     if (wave == 2 && vdefer) {

@@ -884,9 +884,10 @@ def update_finalize(B, C_, A, D, ws_dw_ac, dWac, ws_dw_2, dW2, db2, ws_heads, db
 # ------------------------------------------------------ persistent rollout ---
 def rollout_lunar(env_state, n_envs, seed, env_id0, counter0, obs, act, logp, val, rew, done, ep_ret, next_value, policy_desc,
                   T, t0, nsteps, gamma, lam, noise_exp=None, gae_running=None, gae_workspace=None, ep_stats=None, wg_ticks=None,
-                  refill=True):
+                  refill=True, gae_carry=False):
     """gymrl_rollout_lunar: `nsteps` vector steps of collect_rollout (policy forward, draw, env step, slab writes,
-    online GAE) in one launch; see include/gymrl.h for the slab layout."""
+    online GAE) in one launch; see include/gymrl.h for the slab layout.  gae_carry: the launch that reaches T also runs the
+    blocked scan's carry pass for its envs (then gae(..., variant=3) is the apply launch alone)."""
     a = RolloutLunarArgs()
     a.env_state, a.n_envs, a.seed, a.env_id0, a.counter0 = _ptr(env_state).value, n_envs, seed, env_id0, counter0
     a.obs, a.act, a.logp = _ptr(obs, torch.float32).value, _ptr(act, torch.int32).value, _ptr(logp, torch.float32).value
@@ -897,6 +898,7 @@ def rollout_lunar(env_state, n_envs, seed, env_id0, counter0, obs, act, logp, va
     a.gamma, a.lam, a.ep_stats = gamma, lam, _ptr(ep_stats, torch.float64, True).value
     a.wg_ticks = _ptr(wg_ticks, torch.int64, True).value
     a.T, a.t0, a.nsteps, a.refill = T, t0, nsteps, int(bool(refill))
+    a.gae_carry = int(bool(gae_carry) and gae_running is not None)
     check(lib().gymrl_rollout_lunar(C.byref(a), C.byref(policy_desc), _stream()), "gymrl_rollout_lunar")
 
 

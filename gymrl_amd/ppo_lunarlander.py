@@ -58,6 +58,7 @@ class Config:
         self.scalar_surface = True       # num_envs == 1: collect_rollout() returns the python float of :231 (False: f32[1] on the device)
         self.reset_each_rollout = True   # ppo_lunarlander.py:200 resets the env at every rollout start
         self.gae_variant = 1             # 1 = time-blocked scan, 0 = sequential reference order
+        self.gae_carry_in_rollout = True  # LunarLander's persistent rollout also runs the scan's carry pass at its tail (same bits; one launch fewer)
         self.fused_policy_forward = True  # rollout forward = one gymrl_mlp_forward launch (False: per-layer torch)
         self.fused_update = True          # update = ppo_net.FusedActorCriticUpdate.step(): hand-written f32-MFMA GEMMs + fused
                                           # HBM passes, hidden_dim 64 / 128 / 256 (False or another shape: torch autograd)
@@ -259,7 +260,7 @@ class PPOTrainer:
         self._loss_cfg = (config.clip_eps, config.dual_clip, config.value_coef, config.entropy_coef)
         self._finished = None
         self._metric_parts = None
-        self._agg_ready = False
+        self._agg_ready = self._carry_ready = False
         self._parity_noise = None      # tests: f32[rollouts, T, N, A] Exp(1) draws (ops.categorical_sample noise_exp)
         self._parity_indices = []      # tests: per-update [num_epochs, T*N] shuffle orders consumed by update()
         self._wg_ticks = None          # profiling: i64[2 * ceil(N/16)] start/end ticks of the last persistent launch
@@ -297,7 +298,9 @@ class PPOTrainer:
         nv = self._next_value if next_value is None else next_value
         # variant 2 = the blocked scan minus its first pass: the rollout composed the chunk maps
         variant = 2 if (self.cfg.gae_variant == 1 and self._agg_ready and next_value is None) else self.cfg.gae_variant
-        self._agg_ready = False
+        if variant == 2 and getattr(self, "_carry_ready", False):
+            variant = 3                  # ... and its second: the persistent rollout left the carries in the workspace too
+        self._agg_ready = self._carry_ready = False
         self._last_gae_variant = variant
         if self._timers is not None:
             self._timers.start("gae")
@@ -386,6 +389,7 @@ class PPOTrainer:
         desc = net.descriptor(b.N, self.device)
         tm = self._timers
         chunk = int(cfg.rollout_chunk) if int(cfg.rollout_chunk) > 0 else b.T
+        carry = bool(fuse_gae and getattr(cfg, "gae_carry_in_rollout", True) and env.kind == ops.LUNARLANDER)
         for t0 in range(0, b.T, chunk):
             n = min(chunk, b.T - t0)
             if tm is not None:
@@ -397,13 +401,15 @@ class PPOTrainer:
             if env.kind == ops.CARTPOLE:
                 ops.rollout_cartpole(*common, **online)
             else:
-                ops.rollout_lunar(*common, **online, wg_ticks=self._wg_ticks, refill=getattr(cfg, "rollout_refill", True))
+                ops.rollout_lunar(*common, **online, wg_ticks=self._wg_ticks, refill=getattr(cfg, "rollout_refill", True),
+                                  gae_carry=carry)
             if tm is not None:
                 tm.stop("rollout_chunk", n * b.N)
         b.pos = b.T
         self.step_count += b.T * b.N
         self.rollout_count += 1
         self._agg_ready = bool(fuse_gae)
+        self._carry_ready = carry
         self._finished = True
         return self._next_value
 

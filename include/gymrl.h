@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define GYMRL_ABI_VERSION 2   /* 2: round-2 signature changes (adam_step, per_*, replay_append, nstep_push, gae_decoupled, rollout descriptors); gymrl_gemm_config left the product library */
+#define GYMRL_ABI_VERSION 3   /* 2: round-2 signature changes (adam_step, per_*, replay_append, nstep_push, gae_decoupled, rollout descriptors); gymrl_gemm_config left the product library
+                               * 3: gymrl_rollout_lunar_args grew `gae_carry` (round 6), gymrl_gae variant 3 */
 
 /* ---------------------------------------------------------------- misc --- */
 int gymrl_abi_version(void);
@@ -157,6 +158,9 @@ int gymrl_gae_chunk(void);   /* time-chunk length of the blocked GAE (16) */
  * variant 2 = variant 1 without its first pass: the per-chunk maps were composed during
  *             the rollout (gymrl_gae_online in gymrl_categorical_sample + _flush), so the
  *             launch reads r, v, d once (17 -> ~19 HBM bytes per transition instead of 29).
+ * variant 3 = variant 2 without its carry launch: the persistent rollout ran the carry pass for its own envs
+ *             at its tail (gymrl_rollout_lunar_args.gae_carry) — the apply launch (+ the moments' fold) alone;
+ *             the carries, and so every advantage, have variant 2's bits.
  * workspace: gymrl_gae_workspace_bytes(T, N) bytes, 256-B aligned; required for
  * variant 1 or when moments_out != NULL.
  */
@@ -478,6 +482,10 @@ typedef struct {
                                * prepared in the state buffer's spare world (reset() ends with a full physics step; built inline
                                * it stalls the 15 other envs of the wave on every step an episode ends).  A spare is a pure
                                * function of (seed, env id, episode): the slab is bit-identical either way.             */
+  /* gymrl_rollout_lunar only (ABI 3): */
+  int gae_carry;              /* != 0 (with gae_running): the launch that reaches T also runs the blocked scan's carry pass for its
+                               * own envs into the workspace (gymrl_gae_blk_carry's arithmetic, operation for operation), so
+                               * gymrl_gae may be called with variant 3 — the apply launch alone; the same bits as variant 2 */
 } gymrl_rollout_lunar_args;
 int gymrl_rollout_lunar(const gymrl_rollout_lunar_args* args, const gymrl_mlp_desc* policy, void* stream);
 /* The same rollout for PPO on CartPole-v1 (PPOTrainer with env_name "CartPole-v1": the reference's collect_rollout is

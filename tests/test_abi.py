@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/gymrl.h but not exported"
     assert sorted(_lib.SYMBOLS) == declared, "gymrl_amd/_lib.py SYMBOLS out of sync with include/gymrl.h"
-    assert L.gymrl_abi_version() == 2 == _lib.ABI_VERSION
+    assert L.gymrl_abi_version() == 3 == _lib.ABI_VERSION
     # the product library carries no diagnostic switches (timing-only kernel variants live in the probe build)
     assert not hasattr(L, "gymrl_gemm_config")
 
@@ -35,8 +35,8 @@ def test_stale_library_is_refused(tmp_path, monkeypatch):
     monkeypatch.setattr(_lib, "ABI_VERSION", 999)
     with pytest.raises(RuntimeError, match="ABI version"):
         _lib.lib()
-    monkeypatch.setattr(_lib, "ABI_VERSION", 2)
-    assert _lib.lib().gymrl_abi_version() == 2
+    monkeypatch.setattr(_lib, "ABI_VERSION", 3)
+    assert _lib.lib().gymrl_abi_version() == 3
 
 
 def test_size_queries_need_no_gpu():
