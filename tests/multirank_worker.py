@@ -28,9 +28,11 @@ def ppo_full_cfg(n_envs):
 
 
 def run(rank, world, port, outdir, n_envs, backend="gloo"):
+    # "nccl" with more than one rank needs a device per rank (the day a lease has two: rank r on cuda:r); everything else shares cuda:0
+    local = rank if (backend == "nccl" and world > 1) else 0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0")
-    torch.cuda.set_device(0)
+                      LOCAL_RANK=str(local))
+    torch.cuda.set_device(local)
     if backend != "none":
         td.init_process_group(backend, rank=rank, world_size=world)
     try:

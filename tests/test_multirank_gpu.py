@@ -25,12 +25,16 @@ def test_two_ranks_ppo_and_ppo_full(tmp_path):
     N, world = 64, 2
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("GYMRL_FORCE_COLLECTIVES", None)
+    # two RCCL ranks on two devices where a lease has them; the 1-GPU boxes of this pool run the same ranks over gloo on cuda:0
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "multirank_worker.py"), str(r), str(world), str(port),
-                               str(tmp_path), str(N)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                               str(tmp_path), str(N), backend], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(world)]
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     r = [torch.load(os.path.join(tmp_path, f"rank{k}.pt"), weights_only=False) for k in range(world)]
+    assert all(x["backend"] == backend for x in r)
     # identical initial parameters (broadcast) and bit-identical parameters after 8 all-reduced optimiser steps
     assert torch.equal(r[0]["p0"], r[1]["p0"]) and torch.equal(r[0]["params"], r[1]["params"])
     assert not torch.equal(r[0]["params"], r[0]["p0"])
