@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/<ledger>.jsonl (written by tests/conftest.py::bounded under GYMRL_TOL_LEDGER) -> profiles/r04_trace_tolerances.json:
+"""gpurun_out/<ledger>.jsonl (written by tests/conftest.py::bounded under GYMRL_TOL_LEDGER) -> profiles/rNN_trace_tolerances.json:
 the observed drift of every multi-step trace bound of an MI355X run next to the bound the test enforces.
 usage: python tools/ledger_to_profile.py <ledger.jsonl> <out.json>"""
 import json
