@@ -368,6 +368,7 @@ class PPOTrainer:
                                                 self._gae_running, self._gae_ws, b.T - 1, b.T, cfg.gamma,
                                                 cfg.gae_lambda), self._next_value)
             self._agg_ready = True
+        self._carry_ready = False        # (the step-by-step path composes the maps only: gymrl_gae variant 2 runs the carry pass)
         # :220-221 episode_rewards.append on done: compacted on the device here, read back by
         # _drain_episode_returns() once the update's kernels are queued (no sync in the rollout)
         self._finished = True
